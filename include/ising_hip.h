@@ -1,0 +1,141 @@
+/*
+ * ising_hip.h -- C-ABI of libising_hip.so: the MI355X (gfx950) checkerboard-Metropolis engine.
+ *
+ * The reference (NVIDIA/ising-gpu, optimized/main.cu) has no library or FFI surface: its boundary is the
+ * process (argv in, transcript out) and, inside main(), the kernel-launch sites.  This header is the drop-in
+ * boundary for those launch sites: every entry point names the reference code it replaces (file:line are
+ * relative to /root/reference).  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * Conventions
+ *   - All functions return 0 on success and a non-zero ISING_E_* code on failure; ising_last_error() gives a
+ *     human-readable message for the calling thread's last failure.  (The reference prints and calls
+ *     exit(EXIT_FAILURE), optimized/cudamacro.h:25-39; the CLI front does that with these codes.)
+ *   - A context owns one *slab*: rows [slab*Y, (slab+1)*Y) of both colour arrays of a lattice that is
+ *     nslabs*Y rows by X columns (optimized/main.cu:1627-1628).  nslabs == 1 is the single-GPU case.
+ *   - Packed layout is the reference's: per colour, row-major [Y][X/32] 64-bit words, 16 spins per word,
+ *     4 bits per spin, bit 0 of each nibble = spin (1 = up) (optimized/main.cu:40, :1243, :1539).
+ *   - All device work is enqueued on the context's stream (default: the legacy default stream, 0) and is
+ *     asynchronous unless stated; the context is not re-entrant (one host thread per context, as the
+ *     reference drives all devices from one thread, optimized/main.cu:1764-1805).
+ */
+#ifndef ISING_HIP_H
+#define ISING_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISING_BLACK 0  /* enum {C_BLACK, C_WHITE}, optimized/main.cu:80 */
+#define ISING_WHITE 1
+
+#define ISING_CRIT_TEMP 2.26918531421f /* CRIT_TEMP, optimized/main.cu:42 */
+#define ISING_SEED_DEF 463463564571ull /* SEED_DEF, optimized/main.cu:63 */
+
+enum {
+	ISING_OK = 0,
+	ISING_E_ARG = 1,      /* bad argument (sizes not multiples of 2048 / 16, null pointer, ...) */
+	ISING_E_HIP = 2,      /* a HIP runtime call failed */
+	ISING_E_STATE = 3,    /* call sequence error (e.g. sweep with nslabs > 1) */
+	ISING_E_NOGPU = 4     /* no usable gfx950 device / kernel image */
+};
+
+/* kernel selection for ising_update_color / ising_sweep (A/B and fallback) */
+enum {
+	ISING_KERNEL_AUTO = 0,    /* fast integer-threshold kernel when the temperature admits it, else generic */
+	ISING_KERNEL_GENERIC = 1, /* per-site FP32 compare against the exp table, exactly as the reference writes it */
+	ISING_KERNEL_FAST = 2     /* force the integer-threshold kernel (error if thresholds do not fit) */
+};
+
+typedef struct ising_ctx ising_ctx;
+
+typedef struct ising_config {
+	int32_t X;        /* lattice columns (black+white spins); multiple of 2048 (optimized/main.cu:1314, :1412-1416) */
+	int32_t Y;        /* rows of THIS slab; multiple of 16 (optimized/main.cu:1317, :1417-1421) */
+	int32_t nslabs;   /* slabs in the periodic ring = the reference's ndev (-d, optimized/main.cu:1335) */
+	int32_t slab;     /* index of this slab = the reference's devid kernel argument */
+	uint64_t seed;    /* -s (optimized/main.cu:1329) */
+	float temp;       /* absolute temperature, float as in the reference (optimized/main.cu:1342, :1465-1471) */
+	int32_t device;   /* HIP device ordinal that holds this slab */
+	int32_t strip_rows; /* rows each thread marches per launch; 0 = choose automatically */
+	int32_t kernel;   /* ISING_KERNEL_* */
+} ising_config;
+
+const char *ising_last_error(void);
+
+/* Number of visible HIP devices (cudaGetDeviceCount at optimized/main.cu:1481-1491). */
+int ising_device_count(int *count);
+/* Device description for the "Using GPUs" block (optimized/main.cu:1482-1490). */
+int ising_device_info(int device, char *name, size_t name_len, int *cus, int *max_threads_per_cu, int *major, int *minor);
+
+/* Allocates the slab (both colours, zeroed), halo-receive rows and the threshold/exp tables.
+ * Replaces the cudaMalloc/cudaMallocManaged + memset + exp_d upload of optimized/main.cu:1599-1703. */
+int ising_create(const ising_config *cfg, ising_ctx **out);
+/* Frees everything the context owns (optimized/main.cu:1900-1924). */
+int ising_destroy(ising_ctx *ctx);
+
+/* Use an externally created hipStream_t (e.g. torch's current stream) for all subsequent work. */
+int ising_set_stream(ising_ctx *ctx, void *hip_stream);
+/* Blocks until all work enqueued by this context has finished (cudaDeviceSynchronize, optimized/main.cu:1751-1754). */
+int ising_synchronize(ising_ctx *ctx);
+
+/* latticeInit_k<BLACK> + latticeInit_k<WHITE> for this slab (optimized/main.cu:92-151, launches :1708-1726). */
+int ising_init_lattice(ising_ctx *ctx);
+
+/* Recomputes the exp table / integer thresholds (optimized/main.cu:1684-1703, temperature ramp :1848-1859). */
+int ising_set_temperature(ising_ctx *ctx, float temp);
+/* The ten FP32 table entries exp_h[2][5] in use (optimized/main.cu:1681-1697) and the derived integer
+ * thresholds: thr[a] = number of 32-bit draws x with curand_uniform(x) <= table value for `a` aligned
+ * neighbours (0..4); 2^32 means "always flips". */
+int ising_get_tables(ising_ctx *ctx, float exp_table[10], uint64_t thr[5]);
+
+/* One colour half-sweep, spinUpdateV_2D_k<COLOR> (optimized/main.cu:463-670; launches :1766-1777, :1787-1798)
+ * restricted to row strips [strip_lo, strip_hi) of this slab (strip = cfg.strip_rows rows; see
+ * ising_strip_info).  `it` is the reference's 1-based iteration argument (j+1).  Rows 0 and Y-1 read the
+ * halo rows of the opposite colour: for nslabs == 1 these alias the slab itself (periodic wrap), otherwise
+ * they must have been delivered into the buffers returned by ising_halo_ptrs before the launch runs. */
+int ising_update_color(ising_ctx *ctx, int it, int color, int strip_lo, int strip_hi);
+int ising_strip_info(ising_ctx *ctx, int *strip_rows, int *nstrips);
+
+/* nslabs == 1 only: `nsweeps` full sweeps, black then white, iterations first_it .. first_it+nsweeps-1
+ * (the hot loop, optimized/main.cu:1763-1805). */
+int ising_sweep(ising_ctx *ctx, int first_it, int nsweeps);
+/* Same, bracketed by HIP events on the context's stream; returns elapsed milliseconds (blocking). */
+int ising_sweep_timed(ising_ctx *ctx, int first_it, int nsweeps, float *elapsed_ms);
+
+/* Halo exchange surface for nslabs > 1 (replaces the managed-memory remote loads of
+ * optimized/main.cu:1637-1642 / loadTile :413-428).  For colour `color`:
+ *   send_top / send_bot : device pointers to this slab's first / last row (row_bytes each), to be sent to the
+ *                         previous / next slab in the ring;
+ *   recv_top / recv_bot : device buffers that must receive the previous slab's last row / the next slab's
+ *                         first row before a half-sweep of the OTHER colour touches strips 0 / nstrips-1. */
+int ising_halo_ptrs(ising_ctx *ctx, int color, void **send_top, void **send_bot, void **recv_top, void **recv_bot,
+                    size_t *row_bytes);
+
+/* countSpins / getMagn_k for this slab (optimized/main.cu:701-734, :831-868): number of up and down spins.
+ * Blocking (copies two 64-bit counters back, as :860-866 does). */
+int ising_count(ising_ctx *ctx, uint64_t *up, uint64_t *down);
+
+/* Build-side observable (the reference never computes energy): A = sum over this slab's black sites of the
+ * number of white neighbours equal to the site.  Over all slabs, sum_<ij> s_i s_j = 2A - 2N.  Reads the white
+ * halo rows like ising_update_color(BLACK).  Blocking. */
+int ising_bond_equal(ising_ctx *ctx, int64_t *A);
+
+/* Copies rows [row0,row0+nrows) of one colour to / from host memory in the packed layout
+ * (the D2H copy of dumpLattice, optimized/main.cu:1150-1152).  Blocking. */
+int ising_read_packed(ising_ctx *ctx, int color, int64_t row0, int64_t nrows, uint64_t *dst_host);
+int ising_write_packed(ising_ctx *ctx, int color, int64_t row0, int64_t nrows, const uint64_t *src_host);
+
+/* Device pointer to a colour array of this slab ([Y][X/32] words) for zero-copy consumers. */
+int ising_device_ptr(ising_ctx *ctx, int color, void **ptr, size_t *bytes);
+
+/* dumpLattice (optimized/main.cu:1140-1209): writes "<prefix><slab>.txt", one text row per lattice row, one
+ * hex digit per spin, colours interleaved by row parity. */
+int ising_dump_text(ising_ctx *ctx, const char *prefix);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISING_HIP_H */

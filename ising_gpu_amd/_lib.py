@@ -1,0 +1,79 @@
+"""ctypes binding of libising_hip.so (the C-ABI declared in include/ising_hip.h).
+
+The shared library is the product; this module only declares prototypes.  There is NO CPU fallback: if the
+library is missing or cannot be loaded the import of any compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libising_hip.so")
+
+BLACK, WHITE = 0, 1
+CRIT_TEMP_F32 = 2.2691853046417236  # float32(2.26918531421f), CRIT_TEMP optimized/main.cu:42
+SEED_DEF = 463463564571  # optimized/main.cu:63
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST = 0, 1, 2
+
+
+class IsingConfig(C.Structure):
+    _fields_ = [
+        ("X", C.c_int32), ("Y", C.c_int32), ("nslabs", C.c_int32), ("slab", C.c_int32),
+        ("seed", C.c_uint64), ("temp", C.c_float), ("device", C.c_int32),
+        ("strip_rows", C.c_int32), ("kernel", C.c_int32),
+    ]
+
+
+class IsingError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/ising_hip.h declares
+PROTOTYPES = {
+    "ising_last_error": (C.c_char_p, []),
+    "ising_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "ising_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                    C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ising_create": (C.c_int, [C.POINTER(IsingConfig), C.POINTER(C.c_void_p)]),
+    "ising_destroy": (C.c_int, [C.c_void_p]),
+    "ising_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ising_synchronize": (C.c_int, [C.c_void_p]),
+    "ising_init_lattice": (C.c_int, [C.c_void_p]),
+    "ising_set_temperature": (C.c_int, [C.c_void_p, C.c_float]),
+    "ising_get_tables": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
+    "ising_update_color": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ising_strip_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ising_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "ising_sweep_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "ising_halo_ptrs": (C.c_int, [C.c_void_p, C.c_int] + [C.POINTER(C.c_void_p)] * 4 + [C.POINTER(C.c_size_t)]),
+    "ising_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "ising_bond_equal": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "ising_read_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
+    "ising_write_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
+    "ising_device_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "ising_dump_text": (C.c_int, [C.c_void_p, C.c_char_p]),
+}
+
+
+def load() -> C.CDLL:
+    """Load libising_hip.so; raises IsingError (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IsingError(f"{LIB_PATH} is missing: build it with `make -C ising_gpu_amd/csrc` "
+                             "(or __graft_entry__.build()); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load().ising_last_error()
+        raise IsingError(f"libising_hip error {rc}: {msg.decode() if msg else '?'}")

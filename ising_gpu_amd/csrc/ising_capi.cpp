@@ -1,0 +1,424 @@
+// ising_capi.cpp -- the C-ABI of libising_hip.so (see include/ising_hip.h for the reference file:line each
+// entry point replaces).  Host side only: owns device memory, tables and launch order; all arithmetic on the
+// lattice happens in ising_kernels.hip.
+#include "../../include/ising_hip.h"
+#include "ising_kernels.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof(buf), fmt, ap);
+	va_end(ap);
+	g_err = buf;
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                                       \
+	do {                                                                                                    \
+		hipError_t e_ = (expr);                                                                             \
+		if (e_ != hipSuccess) return fail(ISING_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+	} while (0)
+
+// cuRAND's curand_uniform on the host: x*2^-32 + 2^-33 in FP32 (product exact, one rounding).
+inline float u01(uint32_t x) { return (float)x * 0x1p-32f + 0x1p-33f; }
+
+// Number of 32-bit draws x for which curand_uniform(x) <= p (le) or < p (!le).  curand_uniform is monotone
+// non-decreasing in x, so the accepted draws form a prefix [0, N) and N is found by bisection over the exact
+// FP32 formula.  NaN p accepts nothing, exactly like the FP32 comparison it replaces.
+uint64_t draw_prefix(float p, bool le) {
+	auto ok = [&](uint32_t x) { const float u = u01(x); return le ? (u <= p) : (u < p); };
+	if (!ok(0u)) return 0;
+	if (ok(0xFFFFFFFFu)) return 1ull << 32;
+	uint32_t lo = 0u, hi = 0xFFFFFFFFu; // ok(lo), !ok(hi)
+	while (hi - lo > 1u) {
+		const uint32_t mid = lo + (hi - lo) / 2u;
+		if (ok(mid)) lo = mid; else hi = mid;
+	}
+	return hi;
+}
+
+} // namespace
+
+struct ising_ctx {
+	ising_config cfg{};
+	int lld = 0;      // 64-bit words per colour row
+	int gx = 0;       // X/2048
+	int H = 0;        // rows per strip
+	int nstrips = 0;
+	size_t color_words = 0;
+	uint64_t *d_lat = nullptr;          // [2][Y][lld]
+	uint64_t *d_halo = nullptr;         // [2 colours][2 (top,bot)][lld], nslabs > 1 only
+	unsigned long long *d_acc = nullptr; // 2 counters
+	float tab[10]{};
+	uint64_t thr[5]{};
+	bool fast_ok = false;
+	hipStream_t stream = nullptr;
+
+	uint64_t *lat(int color) const { return d_lat + (size_t)color * color_words; }
+	uint64_t *halo(int color, int which) const { return d_halo + ((size_t)color * 2 + which) * lld; }
+};
+
+namespace {
+
+int bind(const ising_ctx *c) {
+	HIP_TRY(hipSetDevice(c->cfg.device));
+	return ISING_OK;
+}
+
+// exp table exactly as optimized/main.cu:1684-1697 evaluates it (FP32, left to right), then the integer
+// thresholds per number of aligned neighbours.
+void compute_tables(ising_ctx *c, float temp) {
+	for (int i = 0; i < 2; i++) {
+		for (int j = 0; j < 5; j++) {
+			if (temp > 0) {
+				c->tab[i * 5 + j] = expf((i ? -2.0f : 2.0f) * static_cast<float>(j * 2 - 4) * (1.0f / temp));
+			} else {
+				c->tab[i * 5 + j] = (j == 2) ? 0.5f : (i ? -2.0f : 2.0f) * static_cast<float>(j * 2 - 4);
+			}
+		}
+	}
+	bool symmetric = true;
+	for (int a = 0; a < 5; a++) {
+		const uint64_t up = draw_prefix(c->tab[5 + a], true);       // spin up, n = a neighbours up
+		const uint64_t dn = draw_prefix(c->tab[0 + (4 - a)], true); // spin down, 4-a neighbours up
+		c->thr[a] = up;
+		if (up != dn) symmetric = false;
+	}
+	const uint64_t always = 1ull << 32;
+	c->fast_ok = symmetric && c->thr[0] == always && c->thr[1] == always && c->thr[2] == always &&
+	             c->thr[3] < always && c->thr[4] <= c->thr[3];
+	c->cfg.temp = temp;
+}
+
+int choose_strip_rows(int gx, int Y) {
+	// Enough (column-group x strip) units to give every SIMD several waves, while keeping strips tall so the two
+	// halo rows per strip stay a small fraction of the source traffic.
+	const long long want_units = 4LL * 8192; // 4 units per wave, ~8 waves on each of 1024 SIMDs
+	int H = 32;
+	while (H > 1 && ((Y % H) != 0 || (long long)gx * (Y / H) < want_units)) H >>= 1;
+	return H;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *ising_last_error(void) { return g_err.c_str(); }
+
+int ising_device_count(int *count) {
+	if (!count) return fail(ISING_E_ARG, "count is null");
+	hipError_t e = hipGetDeviceCount(count);
+	if (e != hipSuccess) { *count = 0; return fail(ISING_E_NOGPU, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+	return ISING_OK;
+}
+
+int ising_device_info(int device, char *name, size_t name_len, int *cus, int *max_threads_per_cu, int *major, int *minor) {
+	hipDeviceProp_t p;
+	HIP_TRY(hipGetDeviceProperties(&p, device));
+	if (name && name_len) {
+		const char *n = p.name[0] ? p.name : p.gcnArchName;
+		snprintf(name, name_len, "%s", n);
+	}
+	if (cus) *cus = p.multiProcessorCount;
+	if (max_threads_per_cu) *max_threads_per_cu = p.maxThreadsPerMultiProcessor;
+	if (major) *major = p.major;
+	if (minor) *minor = p.minor;
+	return ISING_OK;
+}
+
+int ising_create(const ising_config *cfg, ising_ctx **out) {
+	if (!cfg || !out) return fail(ISING_E_ARG, "null argument");
+	*out = nullptr;
+	// optimized/main.cu:1412-1421
+	if (cfg->X <= 0 || (cfg->X % 2048)) return fail(ISING_E_ARG, "Please specify an X dim multiple of 2048 (got %d)", cfg->X);
+	if (cfg->Y <= 0 || (cfg->Y % 16)) return fail(ISING_E_ARG, "Please specify a Y dim multiple of 16 (got %d)", cfg->Y);
+	if (cfg->nslabs < 1 || cfg->slab < 0 || cfg->slab >= cfg->nslabs) return fail(ISING_E_ARG, "bad slab %d of %d", cfg->slab, cfg->nslabs);
+	if ((long long)cfg->Y * cfg->nslabs >= (1LL << 31)) return fail(ISING_E_ARG, "total rows must be < 2^31");
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(ISING_E_NOGPU, "no HIP device visible");
+	if (cfg->device < 0 || cfg->device >= ndev) return fail(ISING_E_ARG, "device %d out of range (%d visible)", cfg->device, ndev);
+
+	ising_ctx *c = new ising_ctx();
+	c->cfg = *cfg;
+	c->lld = cfg->X / 32;
+	c->gx = cfg->X / 2048;
+	c->H = cfg->strip_rows > 0 ? cfg->strip_rows : choose_strip_rows(c->gx, cfg->Y);
+	if (cfg->Y % c->H) { const int h = c->H; delete c; return fail(ISING_E_ARG, "strip_rows %d does not divide Y %d", h, cfg->Y); }
+	c->nstrips = cfg->Y / c->H;
+	c->color_words = (size_t)cfg->Y * c->lld;
+	compute_tables(c, cfg->temp);
+
+	hipError_t e = hipSetDevice(cfg->device);
+	if (e == hipSuccess) e = hipMalloc((void **)&c->d_lat, 2 * c->color_words * sizeof(uint64_t));
+	if (e == hipSuccess) e = hipMemset(c->d_lat, 0, 2 * c->color_words * sizeof(uint64_t)); // optimized/main.cu:1603
+	if (e == hipSuccess) e = hipMalloc((void **)&c->d_acc, 2 * sizeof(unsigned long long));
+	if (e == hipSuccess && cfg->nslabs > 1) {
+		e = hipMalloc((void **)&c->d_halo, 4 * (size_t)c->lld * sizeof(uint64_t));
+		if (e == hipSuccess) e = hipMemset(c->d_halo, 0, 4 * (size_t)c->lld * sizeof(uint64_t));
+	}
+	if (e != hipSuccess) {
+		const int rc = fail(ISING_E_HIP, "device allocation failed: %s", hipGetErrorString(e));
+		ising_destroy(c);
+		return rc;
+	}
+	*out = c;
+	return ISING_OK;
+}
+
+int ising_destroy(ising_ctx *c) {
+	if (!c) return ISING_OK;
+	(void)hipSetDevice(c->cfg.device);
+	if (c->d_lat) (void)hipFree(c->d_lat);
+	if (c->d_halo) (void)hipFree(c->d_halo);
+	if (c->d_acc) (void)hipFree(c->d_acc);
+	delete c;
+	return ISING_OK;
+}
+
+int ising_set_stream(ising_ctx *c, void *hip_stream) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	c->stream = static_cast<hipStream_t>(hip_stream);
+	return ISING_OK;
+}
+
+int ising_synchronize(ising_ctx *c) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (int rc = bind(c)) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return ISING_OK;
+}
+
+int ising_init_lattice(ising_ctx *c) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (int rc = bind(c)) return rc;
+	const uint64_t half = draw_prefix(0.5f, false); // curand_uniform(x) < 0.5f, optimized/main.cu:133
+	for (int color = 0; color < 2; color++) {
+		ising::InitParams p{};
+		p.dst = c->lat(color);
+		p.seed_lo = (uint32_t)c->cfg.seed;
+		p.seed_hi = (uint32_t)(c->cfg.seed >> 32);
+		p.color = (uint32_t)color;
+		p.gx = c->gx;
+		p.Y = c->cfg.Y;
+		p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
+		p.thr_half = (uint32_t)half;
+		HIP_TRY(ising::launch_init(p, c->stream));
+	}
+	return ISING_OK;
+}
+
+int ising_set_temperature(ising_ctx *c, float temp) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	compute_tables(c, temp);
+	return ISING_OK;
+}
+
+int ising_get_tables(ising_ctx *c, float exp_table[10], uint64_t thr[5]) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (exp_table) memcpy(exp_table, c->tab, sizeof(c->tab));
+	if (thr) memcpy(thr, c->thr, sizeof(c->thr));
+	return ISING_OK;
+}
+
+int ising_strip_info(ising_ctx *c, int *strip_rows, int *nstrips) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (strip_rows) *strip_rows = c->H;
+	if (nstrips) *nstrips = c->nstrips;
+	return ISING_OK;
+}
+
+int ising_update_color(ising_ctx *c, int it, int color, int strip_lo, int strip_hi) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
+	if (it < 0 || it >= (1 << 26)) return fail(ISING_E_ARG, "iteration %d outside [0, 2^26)", it); // counter word 0 must not carry
+	if (strip_lo < 0 || strip_hi > c->nstrips || strip_lo > strip_hi) return fail(ISING_E_ARG, "bad strip range [%d,%d) of %d", strip_lo, strip_hi, c->nstrips);
+	int mode = c->cfg.kernel == ISING_KERNEL_GENERIC ? 1 : 0;
+	if (mode == 0 && !c->fast_ok) {
+		if (c->cfg.kernel == ISING_KERNEL_FAST) return fail(ISING_E_STATE, "temperature %g does not admit the integer-threshold kernel", (double)c->cfg.temp);
+		mode = 1;
+	}
+	if (int rc = bind(c)) return rc;
+	const int other = 1 - color;
+	ising::UpdateParams p{};
+	p.dst = c->lat(color);
+	p.src = c->lat(other);
+	if (c->cfg.nslabs == 1) {
+		p.halo_top = p.src + (size_t)(c->cfg.Y - 1) * c->lld; // periodic wrap, loadTile optimized/main.cu:414,:422
+		p.halo_bot = p.src;
+	} else {
+		p.halo_top = c->halo(other, 0);
+		p.halo_bot = c->halo(other, 1);
+	}
+	p.seed_lo = (uint32_t)c->cfg.seed;
+	p.seed_hi = (uint32_t)(c->cfg.seed >> 32);
+	p.it = (uint32_t)it;
+	p.color = (uint32_t)color;
+	p.gx = c->gx;
+	p.Y = c->cfg.Y;
+	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
+	p.H = c->H;
+	p.strip_lo = strip_lo;
+	p.nunits = c->gx * (strip_hi - strip_lo);
+	p.n3 = (uint32_t)c->thr[3];
+	p.n4 = (uint32_t)c->thr[4];
+	memcpy(p.tab, c->tab, sizeof(p.tab));
+	HIP_TRY(ising::launch_update(p, mode, c->stream));
+	return ISING_OK;
+}
+
+int ising_sweep(ising_ctx *c, int first_it, int nsweeps) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (c->cfg.nslabs != 1) return fail(ISING_E_STATE, "ising_sweep needs nslabs == 1; drive slabs with ising_update_color + halo exchange");
+	for (int it = first_it; it < first_it + nsweeps; it++) {
+		if (int rc = ising_update_color(c, it, ISING_BLACK, 0, c->nstrips)) return rc;
+		if (int rc = ising_update_color(c, it, ISING_WHITE, 0, c->nstrips)) return rc;
+	}
+	return ISING_OK;
+}
+
+int ising_sweep_timed(ising_ctx *c, int first_it, int nsweeps, float *elapsed_ms) {
+	if (!c || !elapsed_ms) return fail(ISING_E_ARG, "null argument");
+	if (int rc = bind(c)) return rc;
+	hipEvent_t e0, e1;
+	HIP_TRY(hipEventCreate(&e0));
+	HIP_TRY(hipEventCreate(&e1));
+	HIP_TRY(hipEventRecord(e0, c->stream));
+	int rc = ising_sweep(c, first_it, nsweeps);
+	if (rc == ISING_OK) {
+		hipError_t e = hipEventRecord(e1, c->stream);
+		if (e == hipSuccess) e = hipEventSynchronize(e1);
+		if (e == hipSuccess) e = hipEventElapsedTime(elapsed_ms, e0, e1);
+		if (e != hipSuccess) rc = fail(ISING_E_HIP, "event timing failed: %s", hipGetErrorString(e));
+	}
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	return rc;
+}
+
+int ising_halo_ptrs(ising_ctx *c, int color, void **send_top, void **send_bot, void **recv_top, void **recv_bot, size_t *row_bytes) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
+	if (c->cfg.nslabs == 1) return fail(ISING_E_STATE, "no halo buffers with nslabs == 1 (rows wrap inside the slab)");
+	if (send_top) *send_top = c->lat(color);
+	if (send_bot) *send_bot = c->lat(color) + (size_t)(c->cfg.Y - 1) * c->lld;
+	if (recv_top) *recv_top = c->halo(color, 0);
+	if (recv_bot) *recv_bot = c->halo(color, 1);
+	if (row_bytes) *row_bytes = (size_t)c->lld * sizeof(uint64_t);
+	return ISING_OK;
+}
+
+int ising_count(ising_ctx *c, uint64_t *up, uint64_t *down) {
+	if (!c || !up || !down) return fail(ISING_E_ARG, "null argument");
+	if (int rc = bind(c)) return rc;
+	HIP_TRY(hipMemsetAsync(c->d_acc, 0, 2 * sizeof(unsigned long long), c->stream));
+	HIP_TRY(ising::launch_popcount(c->d_lat, 2 * c->color_words, c->d_acc, c->stream));
+	unsigned long long h = 0;
+	HIP_TRY(hipMemcpyAsync(&h, c->d_acc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	*up = h;
+	*down = 2ull * c->color_words * 16ull - h; // SPIN_X_WORD - popc per word, optimized/main.cu:722-723
+	return ISING_OK;
+}
+
+int ising_bond_equal(ising_ctx *c, int64_t *A) {
+	if (!c || !A) return fail(ISING_E_ARG, "null argument");
+	if (int rc = bind(c)) return rc;
+	ising::BondParams p{};
+	p.black = c->lat(ISING_BLACK);
+	p.white = c->lat(ISING_WHITE);
+	if (c->cfg.nslabs == 1) {
+		p.halo_top = p.white + (size_t)(c->cfg.Y - 1) * c->lld;
+		p.halo_bot = p.white;
+	} else {
+		p.halo_top = c->halo(ISING_WHITE, 0);
+		p.halo_bot = c->halo(ISING_WHITE, 1);
+	}
+	p.gx = c->gx;
+	p.Y = c->cfg.Y;
+	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
+	p.acc = c->d_acc + 1;
+	HIP_TRY(hipMemsetAsync(c->d_acc + 1, 0, sizeof(unsigned long long), c->stream));
+	HIP_TRY(ising::launch_bond_equal(p, c->stream));
+	unsigned long long h = 0;
+	HIP_TRY(hipMemcpyAsync(&h, c->d_acc + 1, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	*A = (int64_t)h;
+	return ISING_OK;
+}
+
+static int check_rows(ising_ctx *c, int color, int64_t row0, int64_t nrows, const void *host) {
+	if (!c || !host) return fail(ISING_E_ARG, "null argument");
+	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
+	if (row0 < 0 || nrows < 0 || row0 + nrows > c->cfg.Y) return fail(ISING_E_ARG, "rows [%lld,%lld) outside slab of %d rows", (long long)row0, (long long)(row0 + nrows), c->cfg.Y);
+	return ISING_OK;
+}
+
+int ising_read_packed(ising_ctx *c, int color, int64_t row0, int64_t nrows, uint64_t *dst_host) {
+	if (int rc = check_rows(c, color, row0, nrows, dst_host)) return rc;
+	if (int rc = bind(c)) return rc;
+	HIP_TRY(hipMemcpyAsync(dst_host, c->lat(color) + (size_t)row0 * c->lld, (size_t)nrows * c->lld * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return ISING_OK;
+}
+
+int ising_write_packed(ising_ctx *c, int color, int64_t row0, int64_t nrows, const uint64_t *src_host) {
+	if (int rc = check_rows(c, color, row0, nrows, src_host)) return rc;
+	if (int rc = bind(c)) return rc;
+	HIP_TRY(hipMemcpyAsync(c->lat(color) + (size_t)row0 * c->lld, src_host, (size_t)nrows * c->lld * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return ISING_OK;
+}
+
+int ising_device_ptr(ising_ctx *c, int color, void **ptr, size_t *bytes) {
+	if (!c || !ptr) return fail(ISING_E_ARG, "null argument");
+	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
+	*ptr = c->lat(color);
+	if (bytes) *bytes = c->color_words * sizeof(uint64_t);
+	return ISING_OK;
+}
+
+int ising_dump_text(ising_ctx *c, const char *prefix) {
+	if (!c || !prefix) return fail(ISING_E_ARG, "null argument");
+	if (int rc = bind(c)) return rc;
+	std::vector<uint64_t> h(2 * c->color_words);
+	HIP_TRY(hipMemcpyAsync(h.data(), c->d_lat, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	char fname[512];
+	snprintf(fname, sizeof(fname), "%s%d.txt", prefix, c->cfg.slab); // optimized/main.cu:1157,:1185
+	FILE *fp = fopen(fname, "w");
+	if (!fp) return fail(ISING_E_ARG, "cannot open %s for writing", fname);
+	static const char hex[] = "0123456789ABCDEF";
+	std::string line((size_t)c->cfg.X + 1, '\n');
+	const uint64_t *b = h.data(), *w = h.data() + c->color_words;
+	for (int i = 0; i < c->cfg.Y; i++) {
+		char *q = &line[0];
+		// local row parity decides the interleave, as in the reference's per-device loop (optimized/main.cu:1188-1201)
+		for (int j = 0; j < c->lld; j++) {
+			const uint64_t vb = b[(size_t)i * c->lld + j], vw = w[(size_t)i * c->lld + j];
+			for (int k = 0; k < 64; k += 4) {
+				const char cb = hex[(vb >> k) & 0xF], cw = hex[(vw >> k) & 0xF];
+				if (i & 1) { *q++ = cw; *q++ = cb; } else { *q++ = cb; *q++ = cw; }
+			}
+		}
+		fwrite(line.data(), 1, line.size(), fp);
+	}
+	fclose(fp);
+	return ISING_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,56 @@
+// ising_kernels.h -- launch wrappers of the gfx950 kernels (internal to libising_hip.so).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace ising {
+
+// Philox4x32-10 constants (Salmon et al. SC'11 / Random123; cuRAND's curandStatePhilox4_32_10_t uses the same).
+constexpr uint32_t PHILOX_M0 = 0xD2511F53u;
+constexpr uint32_t PHILOX_M1 = 0xCD9E8D57u;
+constexpr uint32_t PHILOX_W0 = 0x9E3779B9u;
+constexpr uint32_t PHILOX_W1 = 0xBB67AE85u;
+
+struct UpdateParams {
+	uint64_t *dst;            // colour being updated, [Y][lld] words
+	const uint64_t *src;      // opposite colour, [Y][lld] words
+	const uint64_t *halo_top; // opposite colour, global row (slab*Y - 1) mod Ytot, lld words
+	const uint64_t *halo_bot; // opposite colour, global row ((slab+1)*Y) mod Ytot, lld words
+	uint32_t seed_lo, seed_hi;
+	uint32_t it;              // reference's 1-based iteration index (0 for init)
+	uint32_t color;           // 0 black, 1 white
+	int32_t gx;               // X/2048: 32-vector column groups per row (= reference gridDim.x)
+	int32_t Y;                // rows in this slab
+	uint32_t row_base;        // global row of slab row 0 (slab*Y)
+	int32_t H;                // rows per strip
+	int32_t strip_lo;         // first strip of this launch
+	int32_t nunits;           // gx * (number of strips in this launch)
+	uint32_t n3, n4;          // integer accept thresholds for 3 / 4 aligned neighbours (fast kernel)
+	float tab[10];            // exp table exp_h[2][5] (generic kernel)
+};
+
+// mode: 0 = fast integer-threshold kernel, 1 = generic FP32-table kernel
+hipError_t launch_update(const UpdateParams &p, int mode, hipStream_t stream);
+
+struct InitParams {
+	uint64_t *dst;
+	uint32_t seed_lo, seed_hi;
+	uint32_t color;
+	int32_t gx, Y;
+	uint32_t row_base;
+	uint32_t thr_half; // number of draws x with curand_uniform(x) < 0.5f
+};
+hipError_t launch_init(const InitParams &p, hipStream_t stream);
+
+// up-spin count of `nwords` packed words, accumulated into *acc (one 64-bit atomic per block)
+hipError_t launch_popcount(const uint64_t *v, size_t nwords, unsigned long long *acc, hipStream_t stream);
+
+struct BondParams {
+	const uint64_t *black, *white, *halo_top, *halo_bot; // halos of the WHITE colour
+	int32_t gx, Y;
+	uint32_t row_base;
+	unsigned long long *acc;
+};
+hipError_t launch_bond_equal(const BondParams &p, hipStream_t stream);
+
+} // namespace ising

@@ -1,0 +1,406 @@
+// ising_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the checkerboard-Metropolis hot path.
+//
+// What each kernel replaces in the reference (file:line relative to /root/reference):
+//   update_k      <- spinUpdateV_2D_k + loadTile ......... optimized/main.cu:463-670, :380-461
+//   init_k        <- latticeInit_k ........................ optimized/main.cu:92-151
+//   popcount_k    <- getMagn_k + __block_sum .............. optimized/main.cu:701-734, :672-699
+//   bond_equal_k  <- (none: the reference has no energy observable)
+//
+// Design (see DESIGN.md for the measurements behind it):
+//   * Thread geometry.  A lane owns what a reference thread owns: the two 128-bit vectors (2 x 32 spins) at
+//     vector columns c and c+16 of one row, so the Philox subsequence id ("tid") and the 64-draw order are the
+//     reference's.  Sixteen lanes = one reference block-row (256 B contiguous per vector
+//     load); a wave64 holds four such groups on consecutive 32-vector column groups, so its two loads cover
+//     2 KiB of contiguous HBM per row.
+//   * Row marching instead of an LDS tile.  Each lane walks H consecutive rows with the (up, centre, down)
+//     source rows in registers, so the opposite-colour array is streamed from HBM once per half-sweep plus
+//     2/H halo rows; the 4-bit side-neighbour carry comes from one extra dword load that hits the line the
+//     neighbouring lane just fetched.  (The reference stages an 18x34 tile in shared memory; on CDNA4 that
+//     would spend LDS bandwidth and a barrier per tile for data the register window already holds.)
+//   * Philox4x32-10 with the first two rounds hoisted.  The counter of draw block b of thread t is
+//     (16(2it+c)+b, 0, tid, 0): the low word is wave-uniform (scalar ALU), the third is constant over the 16
+//     blocks of a row, so rounds 1-2 cost no vector multiplies per block (16 v_mad_u64_u32 instead of 20).
+//   * Integer accept test.  curand_uniform(x) <= exp_table[s][n] is monotone in the raw draw x, so it is
+//     replaced by x < N(a) with a = number of aligned neighbours; a <= 2 always flips (table >= 1), a = 3 and
+//     a = 4 use the host-computed N3 > N4.  Each site adds r = [x<N3] + [x<N4] into a nibble of a per-dword
+//     accumulator; flips for 8 sites are then resolved with a handful of nibble-parallel word operations:
+//     spin up   (a = n):   flip <=> n - r <= 2;   spin down (a = 4-n): flip <=> n + r >= 2.
+//     Bit-exactness of this rewrite against the FP32 form is what tests/test_gpu_parity.py establishes.
+#include <hip/hip_runtime.h>
+#include "ising_kernels.h"
+
+namespace ising {
+namespace {
+
+constexpr int GROUP = 16;                 // lanes per reference block-row (BLOCK_X, optimized/main.cu:55)
+constexpr int THREADS = 256;
+constexpr int GROUPS_PER_BLOCK = THREADS / GROUP;
+
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+	return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+
+__device__ __forceinline__ void mul_hilo(uint32_t a, uint32_t b, uint32_t &hi, uint32_t &lo) {
+	const unsigned long long p = (unsigned long long)a * b; // v_mad_u64_u32 / s_mul_hi_u32+s_mul_i32
+	hi = (uint32_t)(p >> 32);
+	lo = (uint32_t)p;
+}
+
+// Per-row Philox state shared by the 16 draw blocks of one lane-row.
+struct PhiloxRow {
+	uint32_t t_lo1;  // lo(M1*tid)                      -> c1.y
+	uint32_t t_hi0;  // hi(M0*c1.x)
+	uint32_t t_lo0;  // lo(M0*c1.x)                     -> c2.w
+	uint32_t t_e;    // t_lo0 ^ key2.y
+};
+
+__device__ __forceinline__ PhiloxRow philox_row_setup(uint32_t tid, uint32_t k0x, uint32_t k2y) {
+	PhiloxRow r;
+	uint32_t hi1;
+	mul_hilo(PHILOX_M1, tid, hi1, r.t_lo1);
+	const uint32_t c1x = hi1 ^ k0x;
+	mul_hilo(PHILOX_M0, c1x, r.t_hi0, r.t_lo0);
+	r.t_e = r.t_lo0 ^ k2y;
+	return r;
+}
+
+// One Philox4x32-10 block for counter (cx, 0, tid, 0): cx is wave-uniform, everything derived from it alone is
+// computed on the scalar unit by the compiler.
+__device__ __forceinline__ void philox_block(const PhiloxRow &pr, uint32_t cx, uint32_t seed_lo, uint32_t seed_hi,
+                                             uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
+	// round 1 (key 0), scalar half
+	uint32_t s_hi0, s_lo0;
+	mul_hilo(PHILOX_M0, cx, s_hi0, s_lo0);
+	const uint32_t c1z = s_hi0 ^ seed_hi;
+	// round 2 (key 1)
+	const uint32_t k1x = seed_lo + PHILOX_W0, k1y = seed_hi + PHILOX_W1;
+	uint32_t s_hi1, s_lo1;
+	mul_hilo(PHILOX_M1, c1z, s_hi1, s_lo1);
+	uint32_t c0 = (s_hi1 ^ k1x) ^ pr.t_lo1;
+	uint32_t c1 = s_lo1;
+	uint32_t c2 = pr.t_hi0 ^ (s_lo0 ^ k1y);
+	uint32_t c3 = pr.t_lo0;
+	// round 3 (key 2)
+	uint32_t kx = seed_lo + 2u * PHILOX_W0, ky = seed_hi + 2u * PHILOX_W1;
+	{
+		uint32_t hi0, lo0, hi1, lo1;
+		mul_hilo(PHILOX_M0, c0, hi0, lo0);
+		mul_hilo(PHILOX_M1, c2, hi1, lo1);
+		c0 = hi1 ^ (c1 ^ kx);
+		c1 = lo1;
+		c2 = hi0 ^ pr.t_e; // c3 ^ ky == t_lo0 ^ key2.y
+		c3 = lo0;
+	}
+	// rounds 4..10 (keys 3..9)
+#pragma unroll
+	for (int r = 3; r < 10; ++r) {
+		kx += PHILOX_W0;
+		ky += PHILOX_W1;
+		uint32_t hi0, lo0, hi1, lo1;
+		mul_hilo(PHILOX_M0, c0, hi0, lo0);
+		mul_hilo(PHILOX_M1, c2, hi1, lo1);
+		c0 = xor3(hi1, c1, kx);
+		c1 = lo1;
+		c2 = xor3(hi0, c3, ky);
+		c3 = lo0;
+	}
+	o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+
+// cuRAND's curand_uniform: x*2^-32 + 2^-33 in FP32, one rounding (the product is exact).
+__device__ __forceinline__ float u01(uint32_t x) {
+	return __fmaf_rn(__uint2float_rn(x), 0x1p-32f, 0x1p-33f);
+}
+
+__device__ __forceinline__ uint32_t dword(const uint4 &v, int k) {
+	return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
+}
+
+// Nibble-wise number of up neighbours for the four dwords of one vector.
+// ct/up/dw: centre/up/down source vectors; side: the neighbouring vector's dword that supplies the carry nibble
+// (dword 3 of the left vector when back, dword 0 of the right vector otherwise); optimized/main.cu:546-573,:623-635.
+__device__ __forceinline__ void neighbour_sums(const uint4 &up, const uint4 &ct, const uint4 &dw, uint32_t side, bool back,
+                                               uint32_t S[4]) {
+	uint32_t sd[4];
+	if (back) {
+		sd[0] = __builtin_amdgcn_alignbit(ct.x, side, 28);
+		sd[1] = __builtin_amdgcn_alignbit(ct.y, ct.x, 28);
+		sd[2] = __builtin_amdgcn_alignbit(ct.z, ct.y, 28);
+		sd[3] = __builtin_amdgcn_alignbit(ct.w, ct.z, 28);
+	} else {
+		sd[0] = __builtin_amdgcn_alignbit(ct.y, ct.x, 4);
+		sd[1] = __builtin_amdgcn_alignbit(ct.z, ct.y, 4);
+		sd[2] = __builtin_amdgcn_alignbit(ct.w, ct.z, 4);
+		sd[3] = __builtin_amdgcn_alignbit(side, ct.w, 4);
+	}
+	S[0] = up.x + ct.x + dw.x + sd[0];
+	S[1] = up.y + ct.y + dw.y + sd[1];
+	S[2] = up.z + ct.z + dw.z + sd[2];
+	S[3] = up.w + ct.w + dw.w + sd[3];
+}
+
+struct RowPtrs {
+	const uint4 *src;
+	const uint4 *halo_top, *halo_bot;
+	int Y, vecs;
+	__device__ __forceinline__ const uint4 *row(int r) const {
+		return r < 0 ? halo_top : (r >= Y ? halo_bot : src + (size_t)r * vecs);
+	}
+};
+
+// ---------------------------------------------------------------------------------------------- update
+template <int MODE>
+__global__ void __launch_bounds__(THREADS) update_k(const UpdateParams p) {
+	__shared__ float sh_tab[10];
+	if (MODE == 1) {
+		if (threadIdx.x < 10) sh_tab[threadIdx.x] = p.tab[threadIdx.x];
+		__syncthreads();
+	}
+	const int tx = threadIdx.x & (GROUP - 1);
+	const int unit = blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x >> 4);
+	if (unit >= p.nunits) return;
+	const int sidx = unit / p.gx;
+	const int bx = unit - sidx * p.gx;
+	const int r0 = (p.strip_lo + sidx) * p.H;
+	const int vecs = p.gx * 32;
+	const int col0 = bx * 32 + tx, col1 = col0 + GROUP;
+	// side-neighbour vector columns with the periodic wrap of loadTile (optimized/main.cu:433,:441)
+	const int colL0 = col0 == 0 ? vecs - 1 : col0 - 1, colL1 = col1 - 1;
+	const int colR0 = col0 + 1, colR1 = (col1 + 1 == vecs) ? 0 : col1 + 1;
+
+	RowPtrs rp{reinterpret_cast<const uint4 *>(p.src), reinterpret_cast<const uint4 *>(p.halo_top),
+	           reinterpret_cast<const uint4 *>(p.halo_bot), p.Y, vecs};
+	uint4 *dst = reinterpret_cast<uint4 *>(p.dst);
+
+	const uint32_t k2y = p.seed_hi + 2u * PHILOX_W1;
+	const uint32_t cx_base = 16u * (2u * p.it + p.color);
+
+	const uint4 *pu = rp.row(r0 - 1);
+	const uint4 *pc = rp.row(r0);
+	uint4 up0 = pu[col0], up1 = pu[col1];
+	uint4 ct0 = pc[col0], ct1 = pc[col1];
+
+	for (int r = 0; r < p.H; ++r) {
+		const int lr = r0 + r;
+		const uint32_t grow = p.row_base + (uint32_t)lr;
+		const bool back = (p.color == 0) ? !(grow & 1u) : (grow & 1u); // readBack, optimized/main.cu:542
+		// issue this row's loads; they are consumed only after the 16 Philox blocks below
+		const uint4 *pd = rp.row(lr + 1);
+		const uint4 dw0 = pd[col0], dw1 = pd[col1];
+		const uint32_t *pcw = reinterpret_cast<const uint32_t *>(pc);
+		const uint32_t side0 = back ? pcw[4 * colL0 + 3] : pcw[4 * colR0];
+		const uint32_t side1 = back ? pcw[4 * colL1 + 3] : pcw[4 * colR1];
+		uint4 *pm = dst + (size_t)lr * vecs;
+		uint4 me0 = pm[col0], me1 = pm[col1];
+
+		// stream id of the reference thread that owns these two vectors (optimized/main.cu:514-515)
+		const uint32_t tid = ((grow >> 4) * (uint32_t)p.gx + (uint32_t)bx) * 256u + (grow & 15u) * 16u + (uint32_t)tx;
+		const PhiloxRow pr = philox_row_setup(tid, p.seed_lo, k2y);
+
+		if (MODE == 0) {
+			uint32_t R[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+			for (int j = 0; j < 2; ++j) {
+#pragma unroll
+				for (int m = 0; m < 8; ++m) {
+					uint32_t o[4];
+					philox_block(pr, cx_base + 8u * j + m, p.seed_lo, p.seed_hi, o[0], o[1], o[2], o[3]);
+					// outputs: (nibble 2m, word x), (2m, y), (2m+1, x), (2m+1, y)   
+#pragma unroll
+					for (int q = 0; q < 4; ++q) {
+						const int z = 2 * m + (q >> 1), w = q & 1;
+						const uint32_t K = 1u << (4 * (z & 7));
+						const uint32_t add = (o[q] < p.n3 ? K : 0u) + (o[q] < p.n4 ? K : 0u);
+						R[j][2 * w + (z >> 3)] += add;
+					}
+				}
+			}
+			uint32_t S[4];
+			neighbour_sums(up0, ct0, dw0, side0, back, S);
+			uint32_t mv[4] = {me0.x, me0.y, me0.z, me0.w};
+#pragma unroll
+			for (int d = 0; d < 4; ++d) {
+				const uint32_t t0 = S[d] + R[0][d] + 0x66666666u; // bit3 of nibble <=> n + r >= 2
+				const uint32_t t1 = S[d] + 0x55555555u - R[0][d]; // bit3 of nibble <=> n - r >= 3
+				const uint32_t m8 = mv[d] << 3;
+				const uint32_t f = (t0 & ~m8) | (~t1 & m8);
+				mv[d] ^= (f >> 3) & 0x11111111u;
+			}
+			me0 = make_uint4(mv[0], mv[1], mv[2], mv[3]);
+			neighbour_sums(up1, ct1, dw1, side1, back, S);
+			uint32_t nv[4] = {me1.x, me1.y, me1.z, me1.w};
+#pragma unroll
+			for (int d = 0; d < 4; ++d) {
+				const uint32_t t0 = S[d] + R[1][d] + 0x66666666u;
+				const uint32_t t1 = S[d] + 0x55555555u - R[1][d];
+				const uint32_t m8 = nv[d] << 3;
+				const uint32_t f = (t0 & ~m8) | (~t1 & m8);
+				nv[d] ^= (f >> 3) & 0x11111111u;
+			}
+			me1 = make_uint4(nv[0], nv[1], nv[2], nv[3]);
+		} else {
+			// generic: the reference's own per-site FP32 test, optimized/main.cu:637-660
+			uint32_t S[2][4];
+			neighbour_sums(up0, ct0, dw0, side0, back, S[0]);
+			neighbour_sums(up1, ct1, dw1, side1, back, S[1]);
+			uint32_t mv[2][4] = {{me0.x, me0.y, me0.z, me0.w}, {me1.x, me1.y, me1.z, me1.w}};
+#pragma unroll
+			for (int j = 0; j < 2; ++j) {
+#pragma unroll
+				for (int m = 0; m < 8; ++m) {
+					uint32_t o[4];
+					philox_block(pr, cx_base + 8u * j + m, p.seed_lo, p.seed_hi, o[0], o[1], o[2], o[3]);
+#pragma unroll
+					for (int q = 0; q < 4; ++q) {
+						const int z = 2 * m + (q >> 1), w = q & 1;
+						const int d = 2 * w + (z >> 3), sh = 4 * (z & 7);
+						const uint32_t s = (mv[j][d] >> sh) & 0xFu;
+						const uint32_t n = (S[j][d] >> sh) & 0xFu;
+						if (u01(o[q]) <= sh_tab[s * 5 + n]) mv[j][d] ^= 1u << sh;
+					}
+				}
+			}
+			me0 = make_uint4(mv[0][0], mv[0][1], mv[0][2], mv[0][3]);
+			me1 = make_uint4(mv[1][0], mv[1][1], mv[1][2], mv[1][3]);
+		}
+		pm[col0] = me0;
+		pm[col1] = me1;
+		up0 = ct0; up1 = ct1;
+		ct0 = dw0; ct1 = dw1;
+		pc = pd;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------- init
+__global__ void __launch_bounds__(THREADS) init_k(const InitParams p) {
+	const int tx = threadIdx.x & (GROUP - 1);
+	const int unit = blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x >> 4); // (row, bx)
+	if (unit >= p.gx * p.Y) return;
+	const int lr = unit / p.gx;
+	const int bx = unit - lr * p.gx;
+	const int vecs = p.gx * 32;
+	const uint32_t grow = p.row_base + (uint32_t)lr;
+	const uint32_t tid = ((grow >> 4) * (uint32_t)p.gx + (uint32_t)bx) * 256u + (grow & 15u) * 16u + (uint32_t)tx;
+	const PhiloxRow pr = philox_row_setup(tid, p.seed_lo, p.seed_hi + 2u * PHILOX_W1);
+	const uint32_t cx_base = 16u * p.color; // it = 0, optimized/main.cu:116
+	uint4 *row = reinterpret_cast<uint4 *>(p.dst) + (size_t)lr * vecs;
+#pragma unroll
+	for (int j = 0; j < 2; ++j) {
+		uint32_t v[4] = {0, 0, 0, 0};
+#pragma unroll
+		for (int m = 0; m < 8; ++m) {
+			uint32_t o[4];
+			philox_block(pr, cx_base + 8u * j + m, p.seed_lo, p.seed_hi, o[0], o[1], o[2], o[3]);
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const int z = 2 * m + (q >> 1), w = q & 1;
+				// curand_uniform(x) < 0.5f  <=>  x < thr_half   (optimized/main.cu:133,:136)
+				if (o[q] < p.thr_half) v[2 * w + (z >> 3)] |= 1u << (4 * (z & 7));
+			}
+		}
+		row[bx * 32 + tx + j * GROUP] = make_uint4(v[0], v[1], v[2], v[3]);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------- popcount
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+	for (int off = 32; off; off >>= 1) v += __shfl_down(v, off, 64);
+	return v;
+}
+
+__global__ void __launch_bounds__(THREADS) popcount_k(const uint4 *__restrict__ v, size_t nvec, unsigned long long *acc) {
+	__shared__ unsigned long long part[THREADS / 64];
+	unsigned long long c = 0;
+	for (size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x; i < nvec; i += (size_t)gridDim.x * THREADS) {
+		const uint4 w = v[i];
+		c += __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
+	}
+	c = wave_sum(c);
+	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned long long t = 0;
+#pragma unroll
+		for (int i = 0; i < THREADS / 64; ++i) t += part[i];
+		atomicAdd(acc, t);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------- bond sum
+__global__ void __launch_bounds__(THREADS) bond_equal_k(const BondParams p) {
+	__shared__ unsigned long long part[THREADS / 64];
+	const int vecs = p.gx * 32;
+	const size_t total = (size_t)vecs * p.Y;
+	RowPtrs rp{reinterpret_cast<const uint4 *>(p.white), reinterpret_cast<const uint4 *>(p.halo_top),
+	           reinterpret_cast<const uint4 *>(p.halo_bot), p.Y, vecs};
+	const uint4 *black = reinterpret_cast<const uint4 *>(p.black);
+	unsigned long long acc = 0;
+	for (size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * THREADS) {
+		const int lr = (int)(i / vecs);
+		const int col = (int)(i - (size_t)lr * vecs);
+		const uint32_t grow = p.row_base + (uint32_t)lr;
+		const bool back = !(grow & 1u); // black sites
+		const uint4 *pu = rp.row(lr - 1), *pc = rp.row(lr), *pd = rp.row(lr + 1);
+		const int colL = col == 0 ? vecs - 1 : col - 1, colR = (col + 1 == vecs) ? 0 : col + 1;
+		const uint32_t *pcw = reinterpret_cast<const uint32_t *>(pc);
+		const uint32_t side = back ? pcw[4 * colL + 3] : pcw[4 * colR];
+		uint32_t S[4];
+		neighbour_sums(pu[col], pc[col], pd[col], side, back, S);
+		const uint4 me = black[i];
+		const uint32_t mv[4] = {me.x, me.y, me.z, me.w};
+#pragma unroll
+		for (int d = 0; d < 4; ++d) {
+			const uint32_t mask = mv[d] * 15u;                               // 0xF where spin up
+			const uint32_t a = (S[d] & mask) | ((0x44444444u - S[d]) & ~mask); // aligned neighbours per nibble
+			const uint32_t b = (a & 0x0F0F0F0Fu) + ((a >> 4) & 0x0F0F0F0Fu);
+			acc += (b * 0x01010101u) >> 24;
+		}
+	}
+	acc = wave_sum(acc);
+	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned long long t = 0;
+#pragma unroll
+		for (int i = 0; i < THREADS / 64; ++i) t += part[i];
+		atomicAdd(p.acc, t);
+	}
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------- launchers
+hipError_t launch_update(const UpdateParams &p, int mode, hipStream_t stream) {
+	if (p.nunits <= 0) return hipSuccess;
+	const dim3 grid((p.nunits + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), block(THREADS);
+	if (mode == 0) hipLaunchKernelGGL(update_k<0>, grid, block, 0, stream, p);
+	else           hipLaunchKernelGGL(update_k<1>, grid, block, 0, stream, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_init(const InitParams &p, hipStream_t stream) {
+	const long long units = (long long)p.gx * p.Y;
+	const dim3 grid((unsigned)((units + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)), block(THREADS);
+	hipLaunchKernelGGL(init_k, grid, block, 0, stream, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_popcount(const uint64_t *v, size_t nwords, unsigned long long *acc, hipStream_t stream) {
+	const size_t nvec = nwords / 2;
+	size_t blocks = (nvec + THREADS - 1) / THREADS;
+	if (blocks > 2048) blocks = 2048;
+	if (blocks == 0) return hipSuccess;
+	hipLaunchKernelGGL(popcount_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, reinterpret_cast<const uint4 *>(v), nvec, acc);
+	return hipGetLastError();
+}
+
+hipError_t launch_bond_equal(const BondParams &p, hipStream_t stream) {
+	const size_t total = (size_t)p.gx * 32 * p.Y;
+	size_t blocks = (total + THREADS - 1) / THREADS;
+	if (blocks > 4096) blocks = 4096;
+	hipLaunchKernelGGL(bond_equal_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, p);
+	return hipGetLastError();
+}
+
+} // namespace ising

@@ -1,0 +1,136 @@
+"""Host-side mirror of the reference's driver operations for one slab (optimized/main.cu main(), :1230-1926).
+
+`IsingSlab` wraps one `ising_ctx` of libising_hip.so.  Method names follow the reference's steps: init
+(latticeInit_k launches :1708-1726), update_color / sweep (spinUpdateV_2D_k launches :1763-1805), count
+(countSpins :831-868), set_temperature (:1848-1859), dump (dumpLattice :1140-1209).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BLACK, WHITE, IsingConfig, IsingError, check
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    lib = _lib.load()
+    rc = lib.ising_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class IsingSlab:
+    """One slab (rows [slab*Y, (slab+1)*Y) of an (nslabs*Y) x X periodic lattice) resident on one GPU."""
+
+    def __init__(self, X: int, Y: int, seed: int = _lib.SEED_DEF, temp: float = 0.1 * _lib.CRIT_TEMP_F32,
+                 nslabs: int = 1, slab: int = 0, device: int = 0, strip_rows: int = 0, kernel: int = _lib.KERNEL_AUTO):
+        self._lib = _lib.load()
+        self.cfg = IsingConfig(X=X, Y=Y, nslabs=nslabs, slab=slab, seed=seed, temp=float(np.float32(temp)),
+                               device=device, strip_rows=strip_rows, kernel=kernel)
+        self._h = C.c_void_p()
+        check(self._lib.ising_create(C.byref(self.cfg), C.byref(self._h)))
+        self.X, self.Y, self.nslabs, self.slab = X, Y, nslabs, slab
+        self.lld = X // 32
+        self.it = 0  # completed sweeps (the next sweep uses the reference's it = self.it + 1)
+        sr, ns = C.c_int(), C.c_int()
+        check(self._lib.ising_strip_info(self._h, C.byref(sr), C.byref(ns)))
+        self.strip_rows, self.nstrips = sr.value, ns.value
+
+    # -- lifetime ----------------------------------------------------------------------------------------
+    def close(self):
+        if self._h:
+            self._lib.ising_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- driver steps ------------------------------------------------------------------------------------
+    def set_stream(self, hip_stream: int):
+        check(self._lib.ising_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def synchronize(self):
+        check(self._lib.ising_synchronize(self._h))
+
+    def init(self):
+        check(self._lib.ising_init_lattice(self._h))
+        self.it = 0
+        return self
+
+    def set_temperature(self, temp: float):
+        check(self._lib.ising_set_temperature(self._h, C.c_float(float(np.float32(temp)))))
+
+    def tables(self):
+        tab = (C.c_float * 10)()
+        thr = (C.c_uint64 * 5)()
+        check(self._lib.ising_get_tables(self._h, tab, thr))
+        return np.array(list(tab), dtype=np.float32).reshape(2, 5), [int(v) for v in thr]
+
+    def update_color(self, it: int, color: int, strip_lo: int = 0, strip_hi: int | None = None):
+        check(self._lib.ising_update_color(self._h, it, color, strip_lo, self.nstrips if strip_hi is None else strip_hi))
+
+    def sweep(self, n: int = 1):
+        check(self._lib.ising_sweep(self._h, self.it + 1, n))
+        self.it += n
+        return self
+
+    def sweep_timed(self, n: int) -> float:
+        ms = C.c_float()
+        check(self._lib.ising_sweep_timed(self._h, self.it + 1, n, C.byref(ms)))
+        self.it += n
+        return ms.value
+
+    def count(self):
+        up, dw = C.c_uint64(), C.c_uint64()
+        check(self._lib.ising_count(self._h, C.byref(up), C.byref(dw)))
+        return int(up.value), int(dw.value)
+
+    def bond_equal(self) -> int:
+        a = C.c_int64()
+        check(self._lib.ising_bond_equal(self._h, C.byref(a)))
+        return int(a.value)
+
+    def halo_ptrs(self, color: int):
+        p = [C.c_void_p() for _ in range(4)]
+        nb = C.c_size_t()
+        check(self._lib.ising_halo_ptrs(self._h, color, *[C.byref(x) for x in p], C.byref(nb)))
+        return [x.value for x in p], nb.value
+
+    def device_ptr(self, color: int):
+        p, nb = C.c_void_p(), C.c_size_t()
+        check(self._lib.ising_device_ptr(self._h, color, C.byref(p), C.byref(nb)))
+        return p.value, nb.value
+
+    def read(self, color: int, row0: int = 0, nrows: int | None = None) -> np.ndarray:
+        nrows = self.Y - row0 if nrows is None else nrows
+        out = np.empty((nrows, self.lld), dtype=np.uint64)
+        check(self._lib.ising_read_packed(self._h, color, row0, nrows, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def write(self, color: int, rows: np.ndarray, row0: int = 0):
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        check(self._lib.ising_write_packed(self._h, color, row0, rows.shape[0], rows.ctypes.data_as(C.c_void_p)))
+
+    def dump(self, prefix: str):
+        check(self._lib.ising_dump_text(self._h, prefix.encode()))
+
+
+def magnetization(up: int, down: int) -> float:
+    """|up - down| / N as the reference prints it (optimized/main.cu:1748)."""
+    return abs(float(up) - float(down)) / float(up + down)
+
+
+def energy_per_spin(bond_equal_total: int, nspins: int) -> float:
+    """E/N = -(2A - 2N)/N with A the black-site aligned-neighbour count over the whole lattice."""
+    return -(2 * bond_equal_total - 2 * nspins) / nspins

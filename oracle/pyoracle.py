@@ -1,0 +1,168 @@
+"""ctypes front for libising_oracle.so (TEST INFRASTRUCTURE ONLY, see package docstring)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libising_oracle.so")
+
+BLACK, WHITE = 0, 1
+CRIT_TEMP = float(np.float32(2.26918531421))  # optimized/main.cu:42
+SEED_DEF = 463463564571  # optimized/main.cu:63
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with the committed Makefile (gcc, no reference sources involved)."""
+    srcs = [os.path.join(_HERE, f) for f in ("ising_oracle.c", "basic_cpu.c", "Makefile")]
+    stale = not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+    return _SO
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        u64p = C.POINTER(C.c_uint64)
+        L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
+        L.orc_uniform.argtypes = [C.c_uint32]
+        L.orc_uniform.restype = C.c_float
+        L.orc_exp_table.argtypes = [C.c_float, C.POINTER(C.c_float)]
+        L.orc_init.argtypes = [u64p, u64p, C.c_int64, C.c_int64, C.c_uint64]
+        L.orc_init.restype = C.c_int
+        L.orc_update_color.argtypes = [u64p, u64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_uint64,
+                                       C.c_int, C.c_int, C.POINTER(C.c_float)]
+        L.orc_update_color.restype = C.c_int
+        L.orc_sweep.argtypes = [u64p, u64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_uint64,
+                                C.c_int, C.c_int, C.c_float]
+        L.orc_sweep.restype = C.c_int
+        L.orc_count.argtypes = [u64p, u64p, C.c_int64, C.c_int64, u64p, u64p]
+        L.orc_bond_equal.argtypes = [u64p, u64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64]
+        L.orc_bond_equal.restype = C.c_int64
+        L.orc_dump_rows.argtypes = [u64p, u64p, C.c_int64, C.c_int64, C.c_int64, C.c_char_p]
+        L.orc_dump_rows.restype = C.c_int64
+        L.orc_site_draw.argtypes = [C.c_int64, C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int]
+        L.orc_site_draw.restype = C.c_uint32
+        i8p = C.POINTER(C.c_int8)
+        f32p = C.POINTER(C.c_float)
+        L.basic_init.argtypes = [i8p, i8p, C.c_int64, C.c_int64, C.c_uint64, f32p]
+        L.basic_sweeps.argtypes = [i8p, i8p, C.c_int64, C.c_int64, C.c_float, C.c_uint64, C.c_int64, C.c_int64, f32p]
+        L.basic_observables.argtypes = [i8p, i8p, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        _lib = L
+    return _lib
+
+
+def _u64(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def philox4x32_10(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return tuple(int(v) for v in o)
+
+
+def uniform(x: int) -> float:
+    return float(lib().orc_uniform(C.c_uint32(x)))
+
+
+def exp_table(temp: float) -> np.ndarray:
+    t = (C.c_float * 10)()
+    lib().orc_exp_table(C.c_float(temp), t)
+    return np.array(list(t), dtype=np.float32).reshape(2, 5)
+
+
+def site_draw(X, seed, it, color, row, word, nib) -> int:
+    return int(lib().orc_site_draw(X, C.c_uint64(seed), it, color, row, word, nib))
+
+
+class OracleLattice:
+    """Whole (all-slab) lattice on the host in the reference's packed layout: black[Ytot][X/32], white[...]."""
+
+    def __init__(self, X: int, Ytot: int, seed: int = SEED_DEF, temp: float = 0.1 * CRIT_TEMP,
+                 XSL: int = 0, YSL: int = 0):
+        if X % 2048 or Ytot % 16:
+            raise ValueError("X must be a multiple of 2048 and Y of 16 (optimized/main.cu:1412-1421)")
+        self.X, self.Y, self.seed, self.temp = X, Ytot, seed, float(np.float32(temp))
+        self.XSL, self.YSL = XSL, YSL
+        self.lld = X // 32
+        self.black = np.zeros((Ytot, self.lld), dtype=np.uint64)
+        self.white = np.zeros((Ytot, self.lld), dtype=np.uint64)
+        self.it = 0  # completed sweeps
+
+    def init(self):
+        rc = lib().orc_init(_u64(self.black), _u64(self.white), self.X, self.Y, C.c_uint64(self.seed))
+        assert rc == 0
+        self.it = 0
+        return self
+
+    def update_color(self, it: int, color: int):
+        tab = (C.c_float * 10)()
+        lib().orc_exp_table(C.c_float(self.temp), tab)
+        rc = lib().orc_update_color(_u64(self.black), _u64(self.white), self.X, self.Y, self.XSL, self.YSL,
+                                    C.c_uint64(self.seed), it, color, tab)
+        assert rc == 0, rc
+
+    def sweep(self, n: int = 1):
+        rc = lib().orc_sweep(_u64(self.black), _u64(self.white), self.X, self.Y, self.XSL, self.YSL,
+                             C.c_uint64(self.seed), self.it + 1, n, C.c_float(self.temp))
+        assert rc == 0, rc
+        self.it += n
+        return self
+
+    def count(self):
+        up, dw = C.c_uint64(), C.c_uint64()
+        lib().orc_count(_u64(self.black), _u64(self.white), self.X, self.Y, C.byref(up), C.byref(dw))
+        return int(up.value), int(dw.value)
+
+    def bond_equal(self) -> int:
+        return int(lib().orc_bond_equal(_u64(self.black), _u64(self.white), self.X, self.Y, self.XSL, self.YSL))
+
+    def energy_per_spin(self) -> float:
+        n = self.X * self.Y
+        return -(2 * self.bond_equal() - 2 * n) / n
+
+    def dump_rows(self, row0: int, nrows: int) -> bytes:
+        buf = C.create_string_buffer(nrows * (self.X + 1))
+        n = lib().orc_dump_rows(_u64(self.black), _u64(self.white), self.X, row0, nrows, buf)
+        return buf.raw[:n]
+
+
+class BasicCpuIsing:
+    """Byte-per-spin baseline (basic_python/ising_basic.py algorithm) on host cores."""
+
+    def __init__(self, n: int, m: int, alpha: float = 1.0, seed: int = 1234):
+        self.n, self.m, self.alpha, self.seed = n, m, alpha, seed
+        self.black = np.empty((n, m // 2), dtype=np.int8)
+        self.white = np.empty((n, m // 2), dtype=np.int8)
+        self._scratch = np.empty(n * (m // 2), dtype=np.float32)
+        self.it = 0
+        p8 = C.POINTER(C.c_int8)
+        lib().basic_init(self.black.ctypes.data_as(p8), self.white.ctypes.data_as(p8), n, m, C.c_uint64(seed),
+                         self._scratch.ctypes.data_as(C.POINTER(C.c_float)))
+
+    def sweeps(self, k: int):
+        p8 = C.POINTER(C.c_int8)
+        lib().basic_sweeps(self.black.ctypes.data_as(p8), self.white.ctypes.data_as(p8), self.n, self.m,
+                           C.c_float(self.alpha), C.c_uint64(self.seed), self.it, k,
+                           self._scratch.ctypes.data_as(C.POINTER(C.c_float)))
+        self.it += k
+
+    def observables(self):
+        p8 = C.POINTER(C.c_int8)
+        ms, b = C.c_int64(), C.c_int64()
+        lib().basic_observables(self.black.ctypes.data_as(p8), self.white.ctypes.data_as(p8), self.n, self.m,
+                                C.byref(ms), C.byref(b))
+        nm = self.n * self.m
+        return ms.value / nm, -b.value / nm  # magnetisation per spin, energy per spin

@@ -1,0 +1,92 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle, bit for bit, on the same seeded inputs.
+
+Integer state => the bar is bit-exact: every packed word of both colours, the up/down counts and the bond sum.
+"""
+import numpy as np
+import pytest
+
+import ising_gpu_amd as ig
+
+pytestmark = pytest.mark.gpu
+
+TC = ig.CRIT_TEMP_F32
+
+
+def _compare(slab, orc, what):
+    for color, ref in ((ig.BLACK, orc.black), (ig.WHITE, orc.white)):
+        got = slab.read(color)
+        if not np.array_equal(got, ref):
+            bad = np.argwhere(got != ref)
+            r, q = bad[0]
+            raise AssertionError(f"{what}: colour {color} differs in {len(bad)} words; first at row {r} word {q}: "
+                                 f"hip {int(got[r, q]):016x} oracle {int(ref[r, q]):016x}")
+
+
+@pytest.mark.parametrize("kernel", [ig.KERNEL_FAST, ig.KERNEL_GENERIC])
+@pytest.mark.parametrize("X,Y,strip", [(2048, 16, 0), (2048, 64, 4), (4096, 256, 16), (8192, 128, 0), (6144, 48, 1)])
+@pytest.mark.parametrize("temp,seed", [(1.5, ig.SEED_DEF), (TC, 1234)])
+def test_state_bit_exact(gpu, oracle_mod, kernel, X, Y, strip, temp, seed):
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=temp).init()
+    with ig.IsingSlab(X, Y, seed=seed, temp=temp, strip_rows=strip, kernel=kernel) as s:
+        s.init()
+        _compare(s, orc, "init")
+        assert s.count() == orc.count()
+        done = 0
+        for upto in (1, 2, 17):
+            s.sweep(upto - done)
+            orc.sweep(upto - done)
+            done = upto
+            _compare(s, orc, f"after {upto} sweeps (kernel {kernel}, strip {s.strip_rows})")
+            assert s.count() == orc.count()
+            assert s.bond_equal() == orc.bond_equal()
+
+
+def test_tables_match_oracle(gpu, oracle_mod):
+    for temp in (1.5, 2.0, 2.26918, TC, 3.0, 10.0, 0.05 * TC):
+        with ig.IsingSlab(2048, 16, temp=temp) as s:
+            tab, thr = s.tables()
+            assert np.array_equal(tab.view(np.uint32), oracle_mod.exp_table(temp).view(np.uint32)), temp
+            # thresholds are prefixes of the draw range accepted by the FP32 test
+            for a in (3, 4):
+                n = thr[a]
+                if 0 < n < 2**32:
+                    assert oracle_mod.uniform(n - 1) <= tab[1, a] < oracle_mod.uniform(n)
+
+
+@pytest.mark.parametrize("temp", [0.0, -1.0, 1e9, 1e-30])
+def test_degenerate_temperatures_fall_back_to_generic(gpu, oracle_mod, temp):
+    """temp <= 0 uses the reference's special table (optimized/main.cu:1689-1693); huge temp saturates the table at 1."""
+    orc = oracle_mod.OracleLattice(2048, 32, seed=7, temp=temp).init().sweep(3)
+    with ig.IsingSlab(2048, 32, seed=7, temp=temp) as s:
+        s.init().sweep(3)
+        _compare(s, orc, f"temp {temp}")
+
+
+def test_8192_square_config5_prefix(gpu, oracle_mod):
+    """BASELINE config 5 geometry (8192^2, seed 1234), first sweeps at two temperatures: full state + series."""
+    for temp in (1.5, 3.0):
+        orc = oracle_mod.OracleLattice(8192, 8192, seed=1234, temp=temp).init()
+        with ig.IsingSlab(8192, 8192, seed=1234, temp=temp) as s:
+            s.init()
+            assert s.count() == orc.count()
+            for _ in range(2):
+                s.sweep(2)
+                orc.sweep(2)
+                assert s.count() == orc.count()
+                assert s.bond_equal() == orc.bond_equal()
+            _compare(s, orc, f"8192^2 T={temp} after 4 sweeps")
+
+
+def test_temperature_ramp(gpu, oracle_mod):
+    """-u step,freq: the table is recomputed between sweeps (optimized/main.cu:1848-1859)."""
+    orc = oracle_mod.OracleLattice(2048, 64, seed=99, temp=1.0).init()
+    with ig.IsingSlab(2048, 64, seed=99, temp=1.0) as s:
+        s.init()
+        t = np.float32(1.0)
+        for _ in range(6):
+            s.sweep(2)
+            orc.sweep(2)
+            t = np.float32(max(np.float32(0.05) * np.float32(TC), t + np.float32(0.25)))
+            s.set_temperature(float(t))
+            orc.temp = float(t)
+        _compare(s, orc, "ramp")
