@@ -5,3 +5,4 @@ package is the thin host-side mirror of the reference driver (optimized/main.cu)
 """
 from ._lib import BLACK, WHITE, CRIT_TEMP_F32, SEED_DEF, KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST, IsingError, LIB_PATH  # noqa: F401
 from .lattice import IsingSlab, device_count, magnetization, energy_per_spin  # noqa: F401
+from .ring import SlabRing, LocalRing, HipSlabBackend  # noqa: F401

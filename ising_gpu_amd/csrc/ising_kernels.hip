@@ -28,6 +28,7 @@
 //     Bit-exactness of this rewrite against the FP32 form is what tests/test_gpu_parity.py establishes.
 #include <hip/hip_runtime.h>
 #include "ising_kernels.h"
+#include <utility>
 
 namespace ising {
 namespace {
@@ -35,6 +36,16 @@ namespace {
 constexpr int GROUP = 16;                 // lanes per reference block-row (BLOCK_X, optimized/main.cu:55)
 constexpr int THREADS = 256;
 constexpr int GROUPS_PER_BLOCK = THREADS / GROUP;
+
+template <int... Is, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
+	(f(std::integral_constant<int, Is>{}), ...);
+}
+// compile-time unrolled loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+	static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
 
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
 	return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
@@ -107,13 +118,55 @@ __device__ __forceinline__ void philox_block(const PhiloxRow &pr, uint32_t cx, u
 	o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
 
+// Accept-rank accumulation for the four draws of one Philox block.  For each draw x the nibble of its site gets
+// r = [x < n3] + [x < n4] added (n4 <= n3).  Draws 0/2 belong to nibbles NIB, NIB+1 of the dword rx (word x of the
+// vector), draws 1/3 to the same nibbles of ry (word y).
+//
+// gfx950 costs (measured, profiles/ubench_r01.txt): a VOPC compare is a 4-cycle issue, v_cndmask another 4 plus
+// a 2-state VCC hazard, while a plain VOP2 add is 2 cycles.  So the lane predicate is written straight into EXEC
+// (v_cmpx) and the add runs under it: 12 cycles per site instead of ~20 for compare+select+add.  The second
+// compare runs under the first one's EXEC, which is correct because x < n4 implies x < n3.
+template <int NIB>
+__device__ __forceinline__ void accept_rank(uint32_t &rx, uint32_t &ry, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3,
+                                            uint32_t n3, uint32_t n4) {
+#if defined(ISING_ACCEPT_PLAIN)
+	constexpr uint32_t K0 = 1u << (4 * NIB), K1 = 1u << (4 * NIB + 4);
+	rx += (o0 < n3 ? K0 : 0u) + (o0 < n4 ? K0 : 0u) + (o2 < n3 ? K1 : 0u) + (o2 < n4 ? K1 : 0u);
+	ry += (o1 < n3 ? K0 : 0u) + (o1 < n4 ? K0 : 0u) + (o3 < n3 ? K1 : 0u) + (o3 < n4 ? K1 : 0u);
+#else
+	constexpr uint32_t K0 = 1u << (4 * NIB), K1 = 1u << (4 * NIB + 4);
+	unsigned long long saved;
+	asm volatile(
+	    "s_mov_b64 %[sv], exec\n\t"
+	    "v_cmpx_gt_u32_e32 vcc, %[n3], %[o0]\n\t"
+	    "v_add_u32_e32 %[rx], %[k0], %[rx]\n\t"
+	    "v_cmpx_gt_u32_e32 vcc, %[n4], %[o0]\n\t"
+	    "v_add_u32_e32 %[rx], %[k0], %[rx]\n\t"
+	    "s_mov_b64 exec, %[sv]\n\t"
+	    "v_cmpx_gt_u32_e32 vcc, %[n3], %[o1]\n\t"
+	    "v_add_u32_e32 %[ry], %[k0], %[ry]\n\t"
+	    "v_cmpx_gt_u32_e32 vcc, %[n4], %[o1]\n\t"
+	    "v_add_u32_e32 %[ry], %[k0], %[ry]\n\t"
+	    "s_mov_b64 exec, %[sv]\n\t"
+	    "v_cmpx_gt_u32_e32 vcc, %[n3], %[o2]\n\t"
+	    "v_add_u32_e32 %[rx], %[k1], %[rx]\n\t"
+	    "v_cmpx_gt_u32_e32 vcc, %[n4], %[o2]\n\t"
+	    "v_add_u32_e32 %[rx], %[k1], %[rx]\n\t"
+	    "s_mov_b64 exec, %[sv]\n\t"
+	    "v_cmpx_gt_u32_e32 vcc, %[n3], %[o3]\n\t"
+	    "v_add_u32_e32 %[ry], %[k1], %[ry]\n\t"
+	    "v_cmpx_gt_u32_e32 vcc, %[n4], %[o3]\n\t"
+	    "v_add_u32_e32 %[ry], %[k1], %[ry]\n\t"
+	    "s_mov_b64 exec, %[sv]"
+	    : [rx] "+v"(rx), [ry] "+v"(ry), [sv] "=&s"(saved)
+	    : [o0] "v"(o0), [o1] "v"(o1), [o2] "v"(o2), [o3] "v"(o3), [n3] "s"(n3), [n4] "s"(n4), [k0] "n"(K0), [k1] "n"(K1)
+	    : "vcc");
+#endif
+}
+
 // cuRAND's curand_uniform: x*2^-32 + 2^-33 in FP32, one rounding (the product is exact).
 __device__ __forceinline__ float u01(uint32_t x) {
 	return __fmaf_rn(__uint2float_rn(x), 0x1p-32f, 0x1p-33f);
-}
-
-__device__ __forceinline__ uint32_t dword(const uint4 &v, int k) {
-	return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
 }
 
 // Nibble-wise number of up neighbours for the four dwords of one vector.
@@ -199,22 +252,13 @@ __global__ void __launch_bounds__(THREADS) update_k(const UpdateParams p) {
 
 		if (MODE == 0) {
 			uint32_t R[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll
-			for (int j = 0; j < 2; ++j) {
-#pragma unroll
-				for (int m = 0; m < 8; ++m) {
-					uint32_t o[4];
-					philox_block(pr, cx_base + 8u * j + m, p.seed_lo, p.seed_hi, o[0], o[1], o[2], o[3]);
-					// outputs: (nibble 2m, word x), (2m, y), (2m+1, x), (2m+1, y)   
-#pragma unroll
-					for (int q = 0; q < 4; ++q) {
-						const int z = 2 * m + (q >> 1), w = q & 1;
-						const uint32_t K = 1u << (4 * (z & 7));
-						const uint32_t add = (o[q] < p.n3 ? K : 0u) + (o[q] < p.n4 ? K : 0u);
-						R[j][2 * w + (z >> 3)] += add;
-					}
-				}
-			}
+			static_for<16>([&](auto B) {
+				constexpr int j = B.value >> 3, m = B.value & 7;
+				uint32_t o[4];
+				philox_block(pr, cx_base + (uint32_t)B.value, p.seed_lo, p.seed_hi, o[0], o[1], o[2], o[3]);
+				// outputs: (nibble 2m, word x), (2m, y), (2m+1, x), (2m+1, y)   
+				accept_rank<(2 * m) & 7>(R[j][m >> 2], R[j][2 + (m >> 2)], o[0], o[1], o[2], o[3], p.n3, p.n4);
+			});
 			uint32_t S[4];
 			neighbour_sums(up0, ct0, dw0, side0, back, S);
 			uint32_t mv[4] = {me0.x, me0.y, me0.z, me0.w};

@@ -1,0 +1,225 @@
+"""Slab ring: one slab per rank, periodic 1-row halo exchange per colour half-sweep, overlapped with the
+interior update.
+
+This replaces the reference's multi-GPU mechanism (one managed allocation, peer loads of the two rows outside
+each slab and a cudaDeviceSynchronize on every device after each colour -- optimized/main.cu:1599-1658,
+loadTile :413-428, barriers :1779-1784/:1800-1805) with the MI355X-native form: one process per GPU, explicit
+RCCL send/recv of one colour row (X/4 bytes) to each ring neighbour over xGMI, issued right after the two
+boundary strips of a colour are updated and hidden behind the interior strips' kernel:
+
+    for colour in (black, white):                      # it = sweep index + 1, as the reference
+        wait for the halo rows of the OTHER colour      (posted one half-sweep ago)
+        update boundary strips 0 and n-1 of `colour`    (they read the other colour's halo rows)
+        post send/recv of `colour` rows 0 and Y-1       (torch.distributed P2P = RCCL; runs on its own stream)
+        update interior strips 1..n-2 of `colour`       (overlaps with the exchange)
+
+Results do not depend on the decomposition: the Philox stream id uses the global row (optimized/main.cu:514).
+
+The orchestration only needs a *slab backend* with the small interface below, so the same code runs on GPUs
+(IsingSlab + NCCL) and, in tests, on CPU tensors with gloo.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Protocol
+
+import torch
+import torch.distributed as dist
+
+from ._lib import BLACK, WHITE
+
+
+class SlabBackend(Protocol):
+    nstrips: int
+
+    def init(self) -> None: ...
+    def update_strips(self, it: int, color: int, strip_lo: int, strip_hi: int) -> None: ...
+    def halo_tensors(self, color: int):
+        """-> (send_top, send_bot, recv_top, recv_bot): 1-D uint8 tensors of one colour row each."""
+    def count_up_down(self): ...
+    def bond_equal(self) -> int: ...
+
+
+class _DevMem:
+    """Zero-copy view of device memory owned by libising_hip.so as a torch tensor (__cuda_array_interface__)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+class HipSlabBackend:
+    """IsingSlab (libising_hip.so) as a ring backend; kernels run on torch's current stream."""
+
+    def __init__(self, slab):
+        self.slab = slab
+        self.nstrips = slab.nstrips
+        self.device = torch.device("cuda", slab.cfg.device)
+        slab.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self._halo = {}
+        if slab.nslabs > 1:
+            for color in (BLACK, WHITE):
+                ptrs, nb = slab.halo_ptrs(color)
+                self._halo[color] = tuple(torch.as_tensor(_DevMem(p, nb), device=self.device) for p in ptrs)
+
+    def init(self):
+        self.slab.init()
+
+    def update_strips(self, it, color, strip_lo, strip_hi):
+        self.slab.update_color(it, color, strip_lo, strip_hi)
+
+    def halo_tensors(self, color):
+        return self._halo[color]
+
+    def count_up_down(self):
+        return self.slab.count()
+
+    def bond_equal(self):
+        return self.slab.bond_equal()
+
+
+class SlabRing:
+    """Drives one slab of a ring of `world` slabs (world = torch.distributed world size)."""
+
+    def __init__(self, backend: SlabBackend, group: Optional[dist.ProcessGroup] = None):
+        self.b = backend
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.prev = (self.rank - 1) % self.world
+        self.next = (self.rank + 1) % self.world
+        self.it = 0
+        self._pending: List[Optional[list]] = [None, None]  # per colour: outstanding P2P works
+
+    # -- halo exchange -----------------------------------------------------------------------------------
+    def _post(self, color: int):
+        send_top, send_bot, recv_top, recv_bot = self.b.halo_tensors(color)
+        # Order matters when prev == next (world == 2): the peer's first receive (its recv_top, "from prev")
+        # must match our LAST row, so the bottom row is sent first.
+        ops = [
+            dist.P2POp(dist.isend, send_bot, self.next, self.group),
+            dist.P2POp(dist.isend, send_top, self.prev, self.group),
+            dist.P2POp(dist.irecv, recv_top, self.prev, self.group),
+            dist.P2POp(dist.irecv, recv_bot, self.next, self.group),
+        ]
+        self._pending[color] = dist.batch_isend_irecv(ops)
+
+    def _wait(self, color: int):
+        works = self._pending[color]
+        if works:
+            for w in works:
+                w.wait()  # NCCL: the current stream waits; gloo: host blocks
+        self._pending[color] = None
+
+    # -- driver steps ------------------------------------------------------------------------------------
+    def init(self):
+        self.b.init()
+        self.it = 0
+        if self.world > 1:
+            self._post(BLACK)
+            self._post(WHITE)
+        return self
+
+    def _half_sweep(self, it: int, color: int):
+        n = self.b.nstrips
+        if self.world == 1:
+            self.b.update_strips(it, color, 0, n)
+            return
+        self._wait(1 - color)
+        if n >= 3:
+            self.b.update_strips(it, color, 0, 1)
+            self.b.update_strips(it, color, n - 1, n)
+            self._post(color)
+            self.b.update_strips(it, color, 1, n - 1)
+        else:
+            self.b.update_strips(it, color, 0, n)
+            self._post(color)
+
+    def sweep(self, nsweeps: int = 1):
+        for _ in range(nsweeps):
+            self.it += 1
+            self._half_sweep(self.it, BLACK)
+            self._half_sweep(self.it, WHITE)
+        return self
+
+    def quiesce(self):
+        """Make sure every posted exchange has been consumed by the current stream / host."""
+        self._wait(BLACK)
+        self._wait(WHITE)
+
+    def count(self):
+        """Global (up, down) over all slabs (the host-side sum of countSpins, optimized/main.cu:860-866)."""
+        up, down = self.b.count_up_down()
+        if self.world > 1:
+            t = torch.tensor([up, down], dtype=torch.int64)
+            if dist.get_backend(self.group) == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t, group=self.group)
+            up, down = int(t[0]), int(t[1])
+        return up, down
+
+    def bond_equal(self) -> int:
+        if self.world > 1:
+            self._wait(WHITE)  # black sites read the white halo rows
+            self._pending[WHITE] = None
+        a = self.b.bond_equal()
+        if self.world > 1:
+            t = torch.tensor([a], dtype=torch.int64)
+            if dist.get_backend(self.group) == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t, group=self.group)
+            a = int(t[0])
+        return a
+
+
+class LocalRing:
+    """All slabs of a ring in ONE process (slabs may share a device): halo rows move by device-to-device
+    copies instead of RCCL.  Same boundary/interior launch order as SlabRing; used by the CLI-style
+    single-process driver and by the single-GPU tests of the nslabs > 1 kernel path."""
+
+    def __init__(self, backends):
+        self.b = list(backends)
+        self.n = len(self.b)
+        self.it = 0
+
+    def _exchange(self, color: int):
+        h = [b.halo_tensors(color) for b in self.b]
+        for k in range(self.n):
+            send_top, send_bot, _, _ = h[k]
+            h[(k + 1) % self.n][2].copy_(send_bot, non_blocking=True)  # next slab's recv_top <- my last row
+            h[(k - 1) % self.n][3].copy_(send_top, non_blocking=True)  # prev slab's recv_bot <- my first row
+
+    def init(self):
+        for b in self.b:
+            b.init()
+        self.it = 0
+        if self.n > 1:
+            self._exchange(BLACK)
+            self._exchange(WHITE)
+        return self
+
+    def sweep(self, nsweeps: int = 1):
+        for _ in range(nsweeps):
+            self.it += 1
+            for color in (BLACK, WHITE):
+                if self.n == 1:
+                    self.b[0].update_strips(self.it, color, 0, self.b[0].nstrips)
+                    continue
+                for b in self.b:
+                    n = b.nstrips
+                    if n >= 3:
+                        b.update_strips(self.it, color, 0, 1)
+                        b.update_strips(self.it, color, n - 1, n)
+                    else:
+                        b.update_strips(self.it, color, 0, n)
+                self._exchange(color)
+                for b in self.b:
+                    n = b.nstrips
+                    if n >= 3:
+                        b.update_strips(self.it, color, 1, n - 1)
+        return self
+
+    def count(self):
+        ups, downs = zip(*(b.count_up_down() for b in self.b))
+        return sum(ups), sum(downs)
+
+    def bond_equal(self) -> int:
+        return sum(b.bond_equal() for b in self.b)

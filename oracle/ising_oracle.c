@@ -34,6 +34,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <omp.h>
 
 #define BLK_X 16   /* optimized/main.cu:55 */
 #define BLK_Y 16   /* optimized/main.cu:56 */
@@ -122,53 +123,75 @@ static int geom(int64_t X, int64_t Ytot, orc_geom *g) {
 }
 
 /* ------------------------------------------------------------------ latticeInit_k, optimized/main.cu:92-151 */
-static void init_color(uint64_t *dst, const orc_geom *g, uint64_t seed, int color) {
-	#pragma omp parallel for collapse(2) schedule(static)
-	for (int64_t by = 0; by < g->gy; by++) {
-		for (int ty = 0; ty < BLK_Y; ty++) {
-			const int64_t i = by*BLK_Y + ty;
-			for (int64_t bx = 0; bx < g->gx; bx++) {
-				for (int tx = 0; tx < BLK_X; tx++) {
-					const uint32_t tid = (uint32_t)((by*g->gx + bx)*BLK_X*BLK_Y + ty*BLK_X + tx);
-					orc_gen st;
-					gen_init(&st, seed, tid, (uint64_t)(2*NIB)*VEC_PER_THREAD*(2*0 + color));
-					for (int j = 0; j < VEC_PER_THREAD; j++) {
-						uint64_t x = 0, y = 0;
-						for (int k = 0; k < 64; k += 4) {
-							if (u01(gen_next(&st)) < 0.5f) x |= 1ull << k;
-							if (u01(gen_next(&st)) < 0.5f) y |= 1ull << k;
-						}
-						const int64_t col = bx*BLK_X*VEC_PER_THREAD + tx + j*BLK_X;
-						dst[i*g->lld + 2*col]     = x;
-						dst[i*g->lld + 2*col + 1] = y;
+static void init_color(uint64_t *dst, const orc_geom *g, int64_t Y, int64_t row_base, uint64_t seed, int color) {
+	#pragma omp parallel for schedule(static)
+	for (int64_t i = 0; i < Y; i++) {
+		const int64_t gi = row_base + i;
+		const int64_t by = gi / BLK_Y; const int ty = (int)(gi % BLK_Y);
+		for (int64_t bx = 0; bx < g->gx; bx++) {
+			for (int tx = 0; tx < BLK_X; tx++) {
+				const uint32_t tid = (uint32_t)((by*g->gx + bx)*BLK_X*BLK_Y + ty*BLK_X + tx); /* :112-113 */
+				orc_gen st;
+				gen_init(&st, seed, tid, (uint64_t)(2*NIB)*VEC_PER_THREAD*(2*0 + color)); /* :116, it = 0 */
+				for (int j = 0; j < VEC_PER_THREAD; j++) {
+					uint64_t x = 0, y = 0;
+					for (int k = 0; k < 64; k += 4) {               /* :131-139 */
+						if (u01(gen_next(&st)) < 0.5f) x |= 1ull << k;
+						if (u01(gen_next(&st)) < 0.5f) y |= 1ull << k;
 					}
+					const int64_t col = bx*BLK_X*VEC_PER_THREAD + tx + j*BLK_X;
+					dst[i*g->lld + 2*col]     = x;
+					dst[i*g->lld + 2*col + 1] = y;
 				}
 			}
 		}
 	}
 }
 
-int orc_init(uint64_t *black, uint64_t *white, int64_t X, int64_t Ytot, uint64_t seed) {
+int orc_init_slab(uint64_t *black, uint64_t *white, int64_t X, int64_t Y, int64_t row_base, uint64_t seed) {
 	orc_geom g;
-	if (geom(X, Ytot, &g)) return -1;
-	init_color(black, &g, seed, ORC_BLACK);
-	init_color(white, &g, seed, ORC_WHITE);
+	if (geom(X, Y, &g)) return -1;
+	init_color(black, &g, Y, row_base, seed, ORC_BLACK);
+	init_color(white, &g, Y, row_base, seed, ORC_WHITE);
 	return 0;
 }
 
+int orc_init(uint64_t *black, uint64_t *white, int64_t X, int64_t Ytot, uint64_t seed) {
+	return orc_init_slab(black, white, X, Ytot, 0, seed);
+}
+
 /* ------------------------------------------------------------------ neighbour words
- * For destination colour `color`, row i, vector `col`: fills the nibble-wise neighbour-up counts of the two
- * words (x,y) of that vector.  slV / slY are the periodic sub-lattice extents (vectors per row, rows);
- * without sub-lattices slV = vecs and slY = Ytot (optimized/main.cu:1459-1462).
+ * A "view" is what one device sees: Y rows of the source colour starting at global row row_base, plus the two
+ * rows just outside it (the reference reads them from the neighbouring GPU through managed memory,
+ * optimized/main.cu:413-428, :1637-1642).  For the whole lattice the halo rows alias the array itself
+ * (periodic wrap).  With sub-lattices (slY < total rows) the wrap happens inside the view instead.
  */
-static inline void neighbour_sums(const uint64_t *src, const orc_geom *g, int64_t slV, int64_t slY,
-                                  int color, int64_t i, int64_t col, uint64_t sum[2]) {
-	const int64_t iu = (i % slY) == 0 ? i + slY - 1 : i - 1;          /* :414 */
-	const int64_t id = ((i + 1) % slY) == 0 ? i + 1 - slY : i + 1;    /* :422 */
-	const uint64_t *ru = src + iu*g->lld, *rc = src + i*g->lld, *rd = src + id*g->lld;
+typedef struct {
+	const uint64_t *src, *halo_top, *halo_bot;
+	int64_t Y;        /* rows in the view */
+	int64_t row_base; /* global row of view row 0 */
+	int64_t slV, slY; /* periodic extents: vectors per row, rows; slY <= 0 means "use the halo rows" */
+} orc_view;
+
+static inline const uint64_t *view_row(const orc_view *v, const orc_geom *g, int64_t r) {
+	if (r < 0) return v->halo_top;
+	if (r >= v->Y) return v->halo_bot;
+	return v->src + r*g->lld;
+}
+
+/* For destination colour `color`, view row i, vector `col`: nibble-wise neighbour-up counts of words (x,y). */
+static inline void neighbour_sums(const orc_view *v, const orc_geom *g, int color, int64_t i, int64_t col, uint64_t sum[2]) {
+	int64_t iu = i - 1, id = i + 1;
+	if (v->slY > 0) {
+		iu = (i % v->slY) == 0 ? i + v->slY - 1 : i - 1;          /* :414 */
+		id = ((i + 1) % v->slY) == 0 ? i + 1 - v->slY : i + 1;    /* :422 */
+	}
+	const uint64_t *ru = view_row(v, g, iu), *rc = view_row(v, g, i), *rd = view_row(v, g, id);
 	const uint64_t ctx = rc[2*col], cty = rc[2*col + 1];
 	uint64_t sdx, sdy;
-	const int readBack = (color == ORC_BLACK) ? !(i & 1) : (int)(i & 1); /* :542 */
+	const int64_t gi = v->row_base + i;
+	const int readBack = (color == ORC_BLACK) ? !(gi & 1) : (int)(gi & 1); /* :542 */
+	const int64_t slV = v->slV;
 	if (readBack) {
 		const int64_t cl = (col % slV) == 0 ? col + slV - 1 : col - 1; /* :433 */
 		const uint64_t ly = rc[2*cl + 1];
@@ -184,7 +207,42 @@ static inline void neighbour_sums(const uint64_t *src, const orc_geom *g, int64_
 	sum[1] = cty + ru[2*col + 1] + rd[2*col + 1] + sdy;
 }
 
-/* ------------------------------------------------------------------ spinUpdateV_2D_k, optimized/main.cu:463-670 */
+/* ------------------------------------------------------------------ spinUpdateV_2D_k, optimized/main.cu:463-670
+ * Updates view rows [r_lo, r_hi) (multiples of 16 are NOT required here: the reference launches whole 16-row
+ * blocks, but every thread is independent, so any row range gives the same result for those rows).
+ */
+static void update_rows(uint64_t *dst, const orc_view *v, const orc_geom *g, uint64_t seed, int it, int color,
+                        const float tab[10], int64_t r_lo, int64_t r_hi) {
+	#pragma omp parallel for schedule(static)
+	for (int64_t i = r_lo; i < r_hi; i++) {
+		const int64_t gi = v->row_base + i;
+		const int64_t by = gi / BLK_Y; const int ty = (int)(gi % BLK_Y);
+		for (int64_t bx = 0; bx < g->gx; bx++) {
+			for (int tx = 0; tx < BLK_X; tx++) {
+				const uint32_t tid = (uint32_t)((by*g->gx + bx)*BLK_X*BLK_Y + ty*BLK_X + tx); /* :514 */
+				orc_gen st;
+				gen_init(&st, seed, tid, (uint64_t)(2*NIB)*VEC_PER_THREAD*(2*(uint64_t)it + color)); /* :621 */
+				for (int j = 0; j < VEC_PER_THREAD; j++) {
+					const int64_t col = bx*BLK_X*VEC_PER_THREAD + tx + j*BLK_X;
+					uint64_t sum[2];
+					neighbour_sums(v, g, color, i, col, sum);
+					uint64_t me[2] = { dst[i*g->lld + 2*col], dst[i*g->lld + 2*col + 1] };
+					for (int z = 0; z < 64; z += 4) {   /* :637-660: x word first, then y word */
+						for (int w = 0; w < 2; w++) {
+							const int s = (int)((me[w] >> z) & 0xF);
+							const int n = (int)((sum[w] >> z) & 0xF);
+							if (u01(gen_next(&st)) <= tab[s*5 + n]) me[w] ^= 1ull << z;
+						}
+					}
+					dst[i*g->lld + 2*col]     = me[0];
+					dst[i*g->lld + 2*col + 1] = me[1];
+				}
+			}
+		}
+	}
+}
+
+/* whole lattice (all devices' rows in one array), optional sub-lattices */
 int orc_update_color(uint64_t *black, uint64_t *white, int64_t X, int64_t Ytot, int64_t XSL, int64_t YSL,
                      uint64_t seed, int it, int color, const float tab[10]) {
 	orc_geom g;
@@ -192,39 +250,22 @@ int orc_update_color(uint64_t *black, uint64_t *white, int64_t X, int64_t Ytot, 
 	if (XSL <= 0) XSL = X;
 	if (YSL <= 0) YSL = Ytot;
 	const int64_t slV = (XSL/2)/NIB/2;  /* (XSL/2)/SPIN_X_WORD/2, :1771 */
-	const int64_t slY = YSL;
-	if (slV <= 0 || g.vecs % slV || Ytot % slY) return -2;
+	if (slV <= 0 || g.vecs % slV || Ytot % YSL) return -2;
 	const uint64_t *src = (color == ORC_BLACK) ? white : black;
 	uint64_t *dst = (color == ORC_BLACK) ? black : white;
+	const orc_view v = { src, src + (Ytot - 1)*g.lld, src, Ytot, 0, slV, YSL };
+	update_rows(dst, &v, &g, seed, it, color, tab, 0, Ytot);
+	return 0;
+}
 
-	#pragma omp parallel for collapse(2) schedule(static)
-	for (int64_t by = 0; by < g.gy; by++) {
-		for (int ty = 0; ty < BLK_Y; ty++) {
-			const int64_t i = by*BLK_Y + ty;
-			for (int64_t bx = 0; bx < g.gx; bx++) {
-				for (int tx = 0; tx < BLK_X; tx++) {
-					const uint32_t tid = (uint32_t)((by*g.gx + bx)*BLK_X*BLK_Y + ty*BLK_X + tx); /* :514 */
-					orc_gen st;
-					gen_init(&st, seed, tid, (uint64_t)(2*NIB)*VEC_PER_THREAD*(2*(uint64_t)it + color)); /* :621 */
-					for (int j = 0; j < VEC_PER_THREAD; j++) {
-						const int64_t col = bx*BLK_X*VEC_PER_THREAD + tx + j*BLK_X;
-						uint64_t sum[2];
-						neighbour_sums(src, &g, slV, slY, color, i, col, sum);
-						uint64_t me[2] = { dst[i*g.lld + 2*col], dst[i*g.lld + 2*col + 1] };
-						for (int z = 0; z < 64; z += 4) {   /* :637-660: x word first, then y word */
-							for (int w = 0; w < 2; w++) {
-								const int s = (int)((me[w] >> z) & 0xF);
-								const int n = (int)((sum[w] >> z) & 0xF);
-								if (u01(gen_next(&st)) <= tab[s*5 + n]) me[w] ^= 1ull << z;
-							}
-						}
-						dst[i*g.lld + 2*col]     = me[0];
-						dst[i*g.lld + 2*col + 1] = me[1];
-					}
-				}
-			}
-		}
-	}
+/* one device's slab: Y rows starting at global row row_base, halo rows supplied by the caller */
+int orc_update_color_slab(uint64_t *dst, const uint64_t *src, const uint64_t *halo_top, const uint64_t *halo_bot,
+                          int64_t X, int64_t Y, int64_t row_base, uint64_t seed, int it, int color,
+                          const float tab[10], int64_t r_lo, int64_t r_hi) {
+	orc_geom g;
+	if (geom(X, Y, &g) || r_lo < 0 || r_hi > Y || r_lo > r_hi) return -1;
+	const orc_view v = { src, halo_top, halo_bot, Y, row_base, g.vecs, 0 };
+	update_rows(dst, &v, &g, seed, it, color, tab, r_lo, r_hi);
 	return 0;
 }
 
@@ -257,21 +298,15 @@ void orc_count(const uint64_t *black, const uint64_t *white, int64_t X, int64_t 
  * A = sum over black sites of the number of (white) neighbours equal to the site.  Every bond of the torus
  * has exactly one black end, so  sum_<ij> s_i s_j = 2A - 2N  and  E/N = -(2A - 2N)/N.
  */
-int64_t orc_bond_equal(const uint64_t *black, const uint64_t *white, int64_t X, int64_t Ytot,
-                       int64_t XSL, int64_t YSL) {
-	orc_geom g;
-	if (geom(X, Ytot, &g)) return -1;
-	if (XSL <= 0) XSL = X;
-	if (YSL <= 0) YSL = Ytot;
-	const int64_t slV = (XSL/2)/NIB/2, slY = YSL;
+static int64_t bond_rows(const uint64_t *black, const orc_view *v, const orc_geom *g) {
 	int64_t A = 0;
 	#pragma omp parallel for reduction(+:A) schedule(static)
-	for (int64_t i = 0; i < Ytot; i++) {
-		for (int64_t col = 0; col < g.vecs; col++) {
+	for (int64_t i = 0; i < v->Y; i++) {
+		for (int64_t col = 0; col < g->vecs; col++) {
 			uint64_t sum[2];
-			neighbour_sums(white, &g, slV, slY, ORC_BLACK, i, col, sum);
+			neighbour_sums(v, g, ORC_BLACK, i, col, sum);
 			for (int w = 0; w < 2; w++) {
-				const uint64_t me = black[i*g.lld + 2*col + w];
+				const uint64_t me = black[i*g->lld + 2*col + w];
 				for (int z = 0; z < 64; z += 4) {
 					const int s = (int)((me >> z) & 1), n = (int)((sum[w] >> z) & 0xF);
 					A += s ? n : 4 - n;
@@ -280,6 +315,24 @@ int64_t orc_bond_equal(const uint64_t *black, const uint64_t *white, int64_t X, 
 		}
 	}
 	return A;
+}
+
+int64_t orc_bond_equal(const uint64_t *black, const uint64_t *white, int64_t X, int64_t Ytot,
+                       int64_t XSL, int64_t YSL) {
+	orc_geom g;
+	if (geom(X, Ytot, &g)) return -1;
+	if (XSL <= 0) XSL = X;
+	if (YSL <= 0) YSL = Ytot;
+	const orc_view v = { white, white + (Ytot - 1)*g.lld, white, Ytot, 0, (XSL/2)/NIB/2, YSL };
+	return bond_rows(black, &v, &g);
+}
+
+int64_t orc_bond_equal_slab(const uint64_t *black, const uint64_t *white, const uint64_t *halo_top,
+                            const uint64_t *halo_bot, int64_t X, int64_t Y, int64_t row_base) {
+	orc_geom g;
+	if (geom(X, Y, &g)) return -1;
+	const orc_view v = { white, halo_top, halo_bot, Y, row_base, g.vecs, 0 };
+	return bond_rows(black, &v, &g);
 }
 
 /* ------------------------------------------------------------------ dumpLattice text, optimized/main.cu:1140-1209
@@ -320,3 +373,7 @@ uint32_t orc_site_draw(int64_t X, uint64_t seed, int it, int color, int64_t i, i
 	philox_block(ctr, key, out);
 	return out[2*(z & 1) + w];
 }
+
+/* thread control for the timed CPU baseline */
+void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int orc_max_threads(void) { return omp_get_max_threads(); }

@@ -52,6 +52,15 @@ def lib() -> C.CDLL:
         L.orc_dump_rows.restype = C.c_int64
         L.orc_site_draw.argtypes = [C.c_int64, C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int]
         L.orc_site_draw.restype = C.c_uint32
+        L.orc_init_slab.argtypes = [u64p, u64p, C.c_int64, C.c_int64, C.c_int64, C.c_uint64]
+        L.orc_init_slab.restype = C.c_int
+        L.orc_update_color_slab.argtypes = [u64p, u64p, u64p, u64p, C.c_int64, C.c_int64, C.c_int64, C.c_uint64,
+                                            C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int64, C.c_int64]
+        L.orc_update_color_slab.restype = C.c_int
+        L.orc_bond_equal_slab.argtypes = [u64p, u64p, u64p, u64p, C.c_int64, C.c_int64, C.c_int64]
+        L.orc_bond_equal_slab.restype = C.c_int64
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_max_threads.restype = C.c_int
         i8p = C.POINTER(C.c_int8)
         f32p = C.POINTER(C.c_float)
         L.basic_init.argtypes = [i8p, i8p, C.c_int64, C.c_int64, C.c_uint64, f32p]
@@ -166,3 +175,47 @@ class BasicCpuIsing:
                                 C.byref(ms), C.byref(b))
         nm = self.n * self.m
         return ms.value / nm, -b.value / nm  # magnetisation per spin, energy per spin
+
+
+def set_threads(n: int):
+    lib().orc_set_threads(int(n))
+
+
+def max_threads() -> int:
+    return int(lib().orc_max_threads())
+
+
+class OracleSlab:
+    """One slab of a ring on the host (the CPU counterpart of one device in optimized/main.cu's -d N runs).
+
+    Holds Y rows of both colours starting at global row slab*Y plus one received halo row above and below per
+    colour.  update_color() restricted to a row range restates a partial launch of spinUpdateV_2D_k.
+    """
+
+    def __init__(self, X: int, Y: int, seed: int, temp: float, nslabs: int, slab: int):
+        self.X, self.Y, self.seed, self.temp = X, Y, seed, float(np.float32(temp))
+        self.nslabs, self.slab = nslabs, slab
+        self.lld = X // 32
+        self.lat = np.zeros((2, Y, self.lld), dtype=np.uint64)
+        self.halo = np.zeros((2, 2, self.lld), dtype=np.uint64)  # [colour][top,bot]
+
+    def init(self):
+        rc = lib().orc_init_slab(_u64(self.lat[0]), _u64(self.lat[1]), self.X, self.Y, self.slab * self.Y,
+                                 C.c_uint64(self.seed))
+        assert rc == 0
+
+    def update_rows(self, it: int, color: int, r_lo: int, r_hi: int):
+        tab = (C.c_float * 10)()
+        lib().orc_exp_table(C.c_float(self.temp), tab)
+        other = 1 - color
+        rc = lib().orc_update_color_slab(_u64(self.lat[color]), _u64(self.lat[other]), _u64(self.halo[other, 0]),
+                                         _u64(self.halo[other, 1]), self.X, self.Y, self.slab * self.Y,
+                                         C.c_uint64(self.seed), it, color, tab, r_lo, r_hi)
+        assert rc == 0, rc
+
+    def count_up(self) -> int:
+        return int(sum(int(np.unpackbits(self.lat[c].view(np.uint8)).sum(dtype=np.int64)) for c in (0, 1)))
+
+    def bond_equal(self) -> int:
+        return int(lib().orc_bond_equal_slab(_u64(self.lat[0]), _u64(self.lat[1]), _u64(self.halo[1, 0]),
+                                             _u64(self.halo[1, 1]), self.X, self.Y, self.slab * self.Y))

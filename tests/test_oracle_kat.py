@@ -1,0 +1,142 @@
+"""CPU tests of the oracle against the reference's own golden vectors (the README transcripts) and against
+published Philox4x32-10 known answers.  The oracle is test infrastructure; these tests are what lets the GPU
+parity tests trust it."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors: philox4x32 10 rounds
+    assert oracle.philox4x32_10((0, 0, 0, 0), (0, 0)) == (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)
+    assert oracle.philox4x32_10((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2) == (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)
+    assert oracle.philox4x32_10((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0)) == \
+        (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)
+
+
+def test_philox_matches_rocrand_header_constants():
+    """The ROCm image ships the same generator (rocrand_philox4x32_10.h); its constants must be the ones we use."""
+    hdr = "/opt/rocm/include/rocrand/rocrand_philox4x32_10.h"
+    if not os.path.exists(hdr):
+        pytest.skip("rocrand header not present")
+    txt = open(hdr).read().upper()
+    for c in ("0XD2511F53", "0XCD9E8D57", "0X9E3779B9", "0XBB67AE85"):
+        assert c in txt
+
+
+def test_uniform_is_curand_formula():
+    # curand_uniform(x) = x*2^-32 + 2^-33 in FP32: (0,1], monotone
+    assert oracle.uniform(0) == float(np.float32(2.0 ** -33))
+    assert oracle.uniform(0xFFFFFFFF) == 1.0
+    xs = np.random.default_rng(0).integers(0, 2 ** 32, size=2000, dtype=np.uint64)
+    xs.sort()
+    us = [oracle.uniform(int(x)) for x in xs]
+    assert all(a <= b for a, b in zip(us, us[1:]))
+    # init rule u < 0.5f  <=>  x <= 0x7FFFFFBF
+    assert oracle.uniform(0x7FFFFFBF) < 0.5 <= oracle.uniform(0x7FFFFFC0)
+
+
+def test_readme_initial_counts_65536():
+    """optimized/README.md:128 -- 65536 x 65536, default seed: 'up_s: 2147484090, dw_s: 2147483206'."""
+    L = oracle.OracleLattice(65536, 65536, seed=oracle.SEED_DEF, temp=1.5).init()
+    assert L.count() == (2147484090, 2147483206)
+
+
+def test_full_readme_pin_file_all_matched():
+    """oracle/pin_readme_kats.py replays every README transcript (iterations 16..128, sub-lattices, 2- and 8-GPU
+    lattices); the committed result must say every check matched."""
+    pin = json.load(open(os.path.join(GOLD, "readme_kat_pin.json")))
+    assert pin["all_matched"] is True
+    checks = [c for case in pin["cases"] for c in case["checks"]]
+    assert len(checks) >= 22
+    assert all(c["match"] and c["readme"] == c["oracle"] for c in checks)
+
+
+@pytest.mark.slow
+def test_readme_trajectory_live():
+    if os.environ.get("ISING_SLOW") != "1":
+        pytest.skip("set ISING_SLOW=1 (takes minutes)")
+    L = oracle.OracleLattice(65536, 65536, seed=oracle.SEED_DEF, temp=1.5).init().sweep(16)
+    assert L.count() == (2147575418, 2147391878)  # optimized/README.md:129
+
+
+def test_closed_form_draw_mapping_reproduces_init():
+    """SURVEY 8a-R2 closed form (used by the HIP kernels) against the sequential generators of the oracle."""
+    X, Y, seed = 4096, 32, 424242
+    L = oracle.OracleLattice(X, Y, seed=seed).init()
+    rng = np.random.default_rng(1)
+    for _ in range(400):
+        color = int(rng.integers(0, 2)); i = int(rng.integers(0, Y)); q = int(rng.integers(0, X // 32)); z = int(rng.integers(0, 16))
+        x = oracle.site_draw(X, seed, 0, color, i, q, z)
+        bit = int(((L.black if color == 0 else L.white)[i, q] >> np.uint64(4 * z)) & np.uint64(1))
+        assert bit == (1 if oracle.uniform(x) < 0.5 else 0)
+
+
+def test_exp_table_fixture_bits():
+    fx = json.load(open(os.path.join(GOLD, "exp_tables.json")))
+    for rec in fx:
+        t = float(np.uint32(rec["temp_bits"]).view(np.float32))
+        got = [int(v) for v in oracle.exp_table(t).reshape(-1).view(np.uint32)]
+        assert got == rec["table_bits"], (t, got)
+
+
+def test_small_state_goldens_reproduce():
+    import hashlib
+    fx = json.load(open(os.path.join(GOLD, "small_states.json")))
+    for rec in fx:
+        L = oracle.OracleLattice(rec["X"], rec["Y"], seed=rec["seed"], temp=float(np.uint32(rec["temp_bits"]).view(np.float32))).init()
+        for st in rec["states"]:
+            L.sweep(st["sweeps"] - L.it)
+            h = hashlib.sha256(); h.update(L.black.tobytes()); h.update(L.white.tobytes())
+            assert h.hexdigest() == st["sha256"]
+            assert L.count() == (st["up"], st["down"])
+            assert L.bond_equal() == st["bond_equal"]
+
+
+def test_slab_decomposition_invariance_oracle():
+    """Results are independent of the number of slabs: 1 lattice == 4 slabs with halo rows."""
+    X, Y, n = 2048, 64, 4
+    L = oracle.OracleLattice(X, Y, seed=5, temp=2.0).init().sweep(3)
+    S = [oracle.OracleSlab(X, Y // n, 5, 2.0, n, k) for k in range(n)]
+    for s in S:
+        s.init()
+
+    def exch(c):
+        for k in range(n):
+            S[k].halo[c, 0] = S[(k - 1) % n].lat[c, -1]
+            S[k].halo[c, 1] = S[(k + 1) % n].lat[c, 0]
+    exch(0); exch(1)
+    for it in range(1, 4):
+        for c in (0, 1):
+            for s in S:
+                s.update_rows(it, c, 0, Y // n)
+            exch(c)
+    full = np.concatenate([s.lat for s in S], axis=1)
+    assert np.array_equal(full[0], L.black) and np.array_equal(full[1], L.white)
+    assert sum(s.bond_equal() for s in S) == L.bond_equal()
+
+
+def test_physics_sanity_high_temperature():
+    """Not parity: at T >> Tc the magnetisation stays ~0 and the energy is small in magnitude."""
+    L = oracle.OracleLattice(2048, 512, seed=3, temp=20.0).init().sweep(10)
+    up, dw = L.count()
+    assert abs(up - dw) / (up + dw) < 0.01
+    assert -0.2 < L.energy_per_spin() < 0.0
+
+
+def test_basic_cpu_baseline_statistics():
+    """basic (byte-per-spin) algorithm: parity is unpinned, so only statistics: T=0.5Tc orders, energy -> ~-2."""
+    b = oracle.BasicCpuIsing(256, 256, alpha=0.5, seed=1234)
+    b.sweeps(300)
+    m, e = b.observables()
+    assert e < -1.7
+    b2 = oracle.BasicCpuIsing(256, 256, alpha=4.0, seed=1234)
+    b2.sweeps(50)
+    m2, e2 = b2.observables()
+    assert abs(m2) < 0.05 and e2 > -0.6
