@@ -1,0 +1,85 @@
+"""Summarise rocprofv3 rocpd databases (tools/profile.sh output) into a small text + JSON report.
+
+Usage: python tools/summarize_prof.py gpurun_out/prof_<tag> profiles/<name>   (writes <name>.txt and traffic.json)
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are in KiB and are
+collected in separate passes; on gfx950 FETCH_SIZE tallies 128-B requests of wide coalesced streams as 64 B, so
+the read side is doubled ("corrected") -- both raw and corrected figures are reported.
+"""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+
+def q(db, sql):
+    con = sqlite3.connect(db)
+    try:
+        return con.execute(sql).fetchall()
+    finally:
+        con.close()
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    lines = []
+    out = {}
+    tr = glob.glob(os.path.join(src, "trace", "*.db"))
+    if tr:
+        lines.append("== kernel-trace --stats (bench.py --steps 32 --warmup 4), per kernel ==")
+        lines.append(f"{'kernel':28s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
+        rows = q(tr[0], "select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc")
+        tot = sum(r[2] for r in rows)
+        for n, c, s, a, mn, mx in rows:
+            lines.append(f"{n[:28]:28s} {c:6d} {s/1e6:10.3f} {a/1e3:10.2f} {mn/1e3:10.2f} {mx/1e3:10.2f} {100*s/tot:6.2f}")
+            if n.startswith("update_k"):
+                out["update_k_avg_us"] = a / 1e3
+                out["update_k_calls"] = c
+        vg = q(tr[0], "select distinct name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x from kernels where name like 'update_k%'")
+        for r in vg:
+            lines.append(f"   {r[0]}: vgpr {r[1]} agpr {r[2]} sgpr {r[3]} lds {r[4]} scratch {r[5]} grid {r[6]} wg {r[7]}")
+    lines.append("")
+    lines.append("== PMC passes (bench.py --steps 4 --warmup 1), averages over update_k dispatches ==")
+    pm = {}
+    for db in sorted(glob.glob(os.path.join(src, "pmc_*", "*.db"))):
+        try:
+            rows = q(db, "select counter_name, avg(counter_value), count(*), avg(duration) from pmc_events where name like 'update_k%' group by counter_name")
+        except Exception as e:
+            lines.append(f"{db}: {e}")
+            continue
+        for name, avg, cnt, dur in rows:
+            pm[name] = avg
+            lines.append(f"{name:24s} avg {avg:18.1f} over {cnt} dispatches (avg duration {dur/1e3:.1f} us under the profiler)")
+    if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+        rd, wr = pm["FETCH_SIZE"] * 1024.0, pm["WRITE_SIZE"] * 1024.0
+        out.update(fetch_bytes_raw=rd, fetch_bytes_corrected=2 * rd, write_bytes=wr,
+                   hbm_bytes_per_launch=2 * rd + wr, hbm_bytes_per_launch_uncorrected=rd + wr)
+        lines.append("")
+        lines.append(f"HBM per update_k launch: FETCH_SIZE {rd/1e9:.3f} GB raw (x2 gfx950 correction = {2*rd/1e9:.3f} GB), "
+                     f"WRITE_SIZE {wr/1e9:.3f} GB -> {(2*rd+wr)/1e9:.3f} GB corrected ({(rd+wr)/1e9:.3f} GB uncorrected)")
+    if "SQ_WAVE_CYCLES" in pm and "SQ_BUSY_CYCLES" in pm:
+        lines.append(f"VALU instructions per wave: {pm.get('SQ_INSTS_VALU', 0)/max(pm.get('SQ_WAVES', 1), 1):.1f}; "
+                     f"SALU per wave: {pm.get('SQ_INSTS_SALU', 0)/max(pm.get('SQ_WAVES', 1), 1):.1f}")
+        wc = pm["SQ_WAVE_CYCLES"]
+        for k in ("SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"):
+            if k in pm:
+                lines.append(f"{k}/SQ_WAVE_CYCLES = {pm[k]/wc:.3f}")
+    if "TCC_HIT_sum" in pm:
+        lines.append(f"L2 hit rate: {pm['TCC_HIT_sum']/(pm['TCC_HIT_sum']+pm['TCC_MISS_sum']):.3f}")
+    out["pmc"] = pm
+    bj = os.path.join(src, "bench_under_rocprof.json")
+    if os.path.exists(bj):
+        for ln in open(bj):
+            if ln.startswith("{"):
+                b = json.loads(ln)
+                out["x"], out["y"] = b["config"]["x"], b["config"]["y_per_gpu"]
+                lines.append("")
+                lines.append("bench.py line under the profiler: " + ln.strip())
+    os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+    open(dst + ".txt", "w").write("\n".join(lines) + "\n")
+    json.dump(out, open(dst + ".json", "w"), indent=1)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()

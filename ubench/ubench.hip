@@ -41,6 +41,38 @@ KERNEL32(k_lshlor,  "v_lshl_or_b32 %0, %0, 1, %1")
 KERNEL32(k_fma,     "v_fma_f32 %0, %0, %1, %0")
 KERNEL32(k_cmp_s,   "v_cmp_lt_u32 s[20:21], %0, %2")
 KERNEL32(k_dpp,     "v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf")
+KERNEL32(k_add_lit,  "v_add_u32 %0, 0x10000000, %0")
+KERNEL32(k_add_sgpr, "v_add_u32 %0, %2, %0")
+KERNEL32(k_add_inl,  "v_add_u32 %0, 16, %0")
+KERNEL32(k_and,      "v_and_b32 %0, %0, %1")
+KERNEL32(k_or,       "v_or_b32 %0, %0, %1")
+KERNEL32(k_sub,      "v_sub_u32 %0, %0, %1")
+KERNEL32(k_lshl,     "v_lshlrev_b32 %0, 3, %0")
+KERNEL32(k_lshr,     "v_lshrrev_b32 %0, 3, %0")
+KERNEL32(k_min,      "v_min_u32 %0, %0, %1")
+KERNEL32(k_mov,      "v_mov_b32 %0, %1")
+KERNEL32(k_alignbit, "v_alignbit_b32 %0, %0, %1, 28")
+KERNEL32(k_add3,     "v_add3_u32 %0, %0, %1, %2")
+KERNEL32(k_bfe,      "v_bfe_u32 %0, %0, 4, 4")
+KERNEL32(k_perm,     "v_perm_b32 %0, %0, %1, %2")
+KERNEL32(k_xor_sg,   "v_xor_b32 %0, %2, %0")
+KERNEL32(k_cmpx,     "v_cmpx_gt_u32 vcc, %2, %0\n\ts_mov_b64 exec, -1")
+// the accept pattern: cmpx, add, cmpx, add, restore exec  (counts as 1 "op" = one site)
+KERNEL32(k_accept,   "v_cmpx_gt_u32 vcc, %2, %1\n\tv_add_u32 %0, 16, %0\n\tv_cmpx_gt_u32 vcc, %2, %1\n\tv_add_u32 %0, 16, %0\n\ts_mov_b64 exec, -1")
+KERNEL32(k_accept_lit, "v_cmpx_gt_u32 vcc, %2, %1\n\tv_add_u32 %0, 0x10000000, %0\n\tv_cmpx_gt_u32 vcc, %2, %1\n\tv_add_u32 %0, 0x10000000, %0\n\ts_mov_b64 exec, -1")
+// compare+select+add as the compiler writes it
+KERNEL32(k_cmpsel,   "v_cmp_gt_u32 vcc, %2, %1\n\ts_nop 1\n\tv_cndmask_b32 %1, 0, %1, vcc\n\tv_add_u32 %0, %1, %0")
+
+// shader clock vs 100 MHz real-time counter under a VALU-heavy load
+__global__ void __launch_bounds__(256) k_clock(unsigned long long* out, unsigned s) {
+  unsigned a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  unsigned b = blockIdx.x * 2654435761u + 12345u;
+  unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+  for (int i = 0; i < ITERS * 4; ++i) { OP8("v_mul_hi_u32 %0, %0, %1") }
+  unsigned long long c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+  if (threadIdx.x == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = r1 - r0; }
+  if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) == 0x12345) out[0] = 0;
+}
 
 // v_mad_u64_u32: 64-bit destination -> use 64-bit lane values
 #define OP8W(INS) \
@@ -151,6 +183,17 @@ int main() {
     double ops = (double)blocks * 256 * ITERS * 16; \
     printf("%-12s %8.3f ms  %9.1f Glane-ops/s  %6.2f lanes/clk/CU @%.2fGHz\n", #NAME, ms, ops / ms * 1e-6, ops / (ms * 1e-3) / (ncu * ghz * 1e9), ghz); }
   RUN(k_xor) RUN(k_bitop3) RUN(k_add) RUN(k_fma) RUN(k_lshlor) RUN(k_cndmask) RUN(k_addc) RUN(k_cmp) RUN(k_cmp_s) RUN(k_dpp)
+  RUN(k_add_lit) RUN(k_add_sgpr) RUN(k_add_inl) RUN(k_and) RUN(k_or) RUN(k_sub) RUN(k_lshl) RUN(k_lshr) RUN(k_min) RUN(k_mov) RUN(k_xor_sg)
+  RUN(k_alignbit) RUN(k_add3) RUN(k_bfe) RUN(k_perm) RUN(k_cmpx) RUN(k_accept) RUN(k_accept_lit) RUN(k_cmpsel)
+  {
+    unsigned long long* d; CK(hipMalloc(&d, blocks * 16));
+    hipLaunchKernelGGL(k_clock, dim3(blocks), dim3(256), 0, 0, d, 12345u); CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(blocks * 2); CK(hipMemcpy(h.data(), d, blocks * 16, hipMemcpyDeviceToHost));
+    double sc = 0, sr = 0; for (int i = 0; i < blocks; ++i) { sc += h[2 * i]; sr += h[2 * i + 1]; }
+    int wc = 0; CK(hipDeviceGetAttribute(&wc, hipDeviceAttributeWallClockRate, 0));
+    printf("clock under v_mul_hi_u32 load: shader cycles / wall ticks = %.3f ; wall clock rate %d kHz -> %.3f GHz; cycles per wave-instr = %.2f\n",
+           sc / sr, wc, sc / sr * wc * 1e-6, sc / blocks / (ITERS * 4.0 * 8) / 1.0);
+  }
   RUN(k_mul24) RUN(k_mad24) RUN(k_mullo) RUN(k_mulhi) RUN(k_mad64) RUN(k_mad64z) RUN(k_lshladd64)
   {
     int nblk = 2048;
