@@ -135,6 +135,19 @@ int ising_device_ptr(ising_ctx *ctx, int color, void **ptr, size_t *bytes);
  * hex digit per spin, colours interleaved by row parity. */
 int ising_dump_text(ising_ctx *ctx, const char *prefix);
 
+/* ---- single-process multi-device ring (the reference's own process model: one host thread drives ndev GPUs,
+ * optimized/main.cu:1763-1805).  ctxs[k] must be slab k of nslabs == n contexts (any device placement).
+ * Halo rows move by peer-to-peer device copies ordered with HIP events instead of the reference's managed-memory
+ * remote loads + cudaDeviceSynchronize on every device (:1779-1784, :1800-1805). */
+
+/* Delivers colour `color`'s first/last rows of every slab into the neighbours' halo buffers (asynchronous). */
+int ising_ring_exchange(ising_ctx **ctxs, int n, int color);
+/* `nsweeps` full sweeps over all slabs, iterations first_it .. first_it+nsweeps-1: per colour, boundary strips first,
+ * then the halo copies, then the interior strips (which overlap with the copies).  Asynchronous. */
+int ising_ring_sweep(ising_ctx **ctxs, int n, int first_it, int nsweeps);
+/* Blocks until every slab's stream is idle. */
+int ising_ring_synchronize(ising_ctx **ctxs, int n);
+
 #ifdef __cplusplus
 }
 #endif

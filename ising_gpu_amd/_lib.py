@@ -55,6 +55,9 @@ PROTOTYPES = {
     "ising_write_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
     "ising_device_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "ising_dump_text": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "ising_ring_exchange": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "ising_ring_sweep": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
+    "ising_ring_synchronize": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
 }
 
 

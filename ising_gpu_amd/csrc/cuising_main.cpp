@@ -1,0 +1,316 @@
+// cuising_main.cpp -- command-line front with the reference's surface (optimized/main.cu main(), :1230-1926):
+// same flags, same defaults and the same transcript lines, over the C-ABI of libising_hip.so.  No HIP calls here.
+//
+// Supported: -x -y -n/--nit -s/--seed -d/--devs -a/--alpha -t/--temp -p/--print -e/--exppr -m/--magn -u/--update
+//            -o/--out -h, plus --energy (build-side addition: prints the energy per spin next to each
+//            magnetisation line) and --devmap a,b,.. (place slab k on device devmap[k]; lets a 1-GPU box run -d N).
+// Not yet supported (exit with a message): -c/--corr, -J, --xsl/--ysl  (SURVEY 8f rows 3-4).
+#include "../../include/ising_hip.h"
+
+#include <getopt.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr int SPIN_X_WORD = 16;        // optimized/main.cu:1243
+constexpr int X_MULT = 2048;           // 2*SPIN_X_WORD*2*BLOCK_X*BMULT_X, optimized/main.cu:1412
+constexpr int Y_MULT = 16;             // BLOCK_Y*BMULT_Y, optimized/main.cu:1417
+constexpr float ALPHA_DEF = 0.1f;      // optimized/main.cu:43
+constexpr float MIN_TEMP = 0.05f * ISING_CRIT_TEMP; // optimized/main.cu:44
+constexpr double TGT_MAGN_MAX_DIFF = 1.0E-3;         // optimized/main.cu:65
+constexpr int MAX_EXP_TIME = 200, MIN_EXP_TIME = 152; // optimized/main.cu:67-68
+constexpr int NUMIT_DEF = 1;
+
+[[noreturn]] void die(const char *what) {
+	fprintf(stderr, "%s: %s\n", what, ising_last_error());
+	exit(EXIT_FAILURE);
+}
+#define CHECK(call) do { if ((call) != ISING_OK) die(#call); } while (0)
+
+void usage(const char *pname) {
+	const char *bname = strrchr(pname, '/');
+	bname = bname ? bname + 1 : pname;
+	fprintf(stdout,
+	        "Usage: %s [options]\n"
+	        "options:\n"
+	        "\t-x|--x <HORIZ_DIM>     horizontal lattice dimension per GPU, multiple of %d\n"
+	        "\t-y|--y <VERT_DIM>      vertical lattice dimension per GPU, multiple of %d\n"
+	        "\t-n|--nit <NSTEPS>      number of iterations (default %d)\n"
+	        "\t-d|--devs <NUM_DEVICES> number of GPUs, devices [0, NUM_DEVS-1] (default 1)\n"
+	        "\t-s|--seed <SEED>       random seed (default %llu; 0 = random)\n"
+	        "\t-a|--alpha <ALPHA>     temperature in T_CRIT units (default %f)\n"
+	        "\t-t|--temp <TEMP>       absolute temperature; wins over -a (default %f)\n"
+	        "\t-p|--print <STAT_FREQ> print magnetization every STAT_FREQ iterations\n"
+	        "\t-e|--exppr             print magnetization at time steps 2^(x/4)\n"
+	        "\t-m|--magn <TGT_MAGN>   stop when the magnetization reaches TGT_MAGN (needs -p or -e)\n"
+	        "\t-u|--update <STEP,FREQ> add STEP to the temperature every FREQ iterations\n"
+	        "\t-o|--out               dump the lattice whenever the magnetization is printed\n"
+	        "\t   --energy            also print the energy per spin (not in the reference)\n"
+	        "\t   --devmap <a,b,...>  device ordinal of each slab (default 0..NUM_DEVS-1)\n"
+	        "\t-c|--corr, -J, --xsl, --ysl: not supported by this build\n\n",
+	        bname, X_MULT, Y_MULT, NUMIT_DEF, (unsigned long long)ISING_SEED_DEF, ALPHA_DEF, ALPHA_DEF * ISING_CRIT_TEMP);
+	exit(EXIT_SUCCESS);
+}
+
+// optimized/main.cu:1211-1228
+void generate_times(unsigned long long nsteps, unsigned long long *list_times) {
+	int nt = 0;
+	list_times[0] = MIN_EXP_TIME;
+	unsigned long long t = 0;
+	for (unsigned long long j = 0; j < nsteps && t < nsteps; j++) {
+		t = (unsigned long long)rint(pow(2.0, j / 4.0));
+		if (t >= 2 * list_times[nt] && nt < MAX_EXP_TIME - 1) {
+			nt++;
+			list_times[nt] = t;
+		}
+	}
+}
+
+struct Ring {
+	std::vector<ising_ctx *> ctx;
+	int n() const { return (int)ctx.size(); }
+
+	void count(unsigned long long *up, unsigned long long *dw) {
+		*up = *dw = 0;
+		for (ising_ctx *c : ctx) {
+			uint64_t u = 0, d = 0;
+			CHECK(ising_count(c, &u, &d));
+			*up += u; *dw += d;
+		}
+	}
+	double energy(size_t nspins) {
+		long long A = 0;
+		for (ising_ctx *c : ctx) {
+			int64_t a = 0;
+			CHECK(ising_bond_equal(c, &a));
+			A += a;
+		}
+		return -(2.0 * (double)A - 2.0 * (double)nspins) / (double)nspins;
+	}
+	void dump(const char *prefix) {
+		for (ising_ctx *c : ctx) CHECK(ising_dump_text(c, prefix));
+	}
+};
+
+} // namespace
+
+int main(int argc, char **argv) {
+	int X = 0, Y = 0, dumpOut = 0, nsteps = NUMIT_DEF, ndev = 1;
+	unsigned long long seed = ISING_SEED_DEF;
+	float alpha = -1.0f, temp = -1.0f, tempUpdStep = 0;
+	int tempUpdFreq = 0, printFreq = 0, printExp = 0, printExpCur = 0, printEnergy = 0;
+	unsigned long long printExpSteps[MAX_EXP_TIME];
+	double tgtMagn = -1.0;
+	std::vector<int> devmap;
+
+	static struct option long_options[] = {
+	    {"x", required_argument, 0, 'x'},      {"y", required_argument, 0, 'y'},     {"nit", required_argument, 0, 'n'},
+	    {"seed", required_argument, 0, 's'},   {"out", no_argument, 0, 'o'},         {"devs", required_argument, 0, 'd'},
+	    {"alpha", required_argument, 0, 'a'},  {"temp", required_argument, 0, 't'},  {"print", required_argument, 0, 'p'},
+	    {"update", required_argument, 0, 'u'}, {"magn", required_argument, 0, 'm'},  {"exppr", no_argument, 0, 'e'},
+	    {"corr", no_argument, 0, 'c'},         {"J", required_argument, 0, 'J'},     {"xsl", required_argument, 0, 1},
+	    {"ysl", required_argument, 0, 2},      {"help", required_argument, 0, 'h'},  {"energy", no_argument, 0, 3},
+	    {"devmap", required_argument, 0, 4},   {0, 0, 0, 0}};
+	while (1) {
+		int option_index = 0;
+		const int och = getopt_long(argc, argv, "x:y:n:ohs:d:a:t:p:u:m:ecJ:r:", long_options, &option_index);
+		if (och == -1) break;
+		switch (och) {
+		case 0: break;
+		case 'x': X = atoi(optarg); break;
+		case 'y': Y = atoi(optarg); break;
+		case 'n': nsteps = atoi(optarg); break;
+		case 'o': dumpOut = 1; break;
+		case 'h': usage(argv[0]); break;
+		case 's':
+			seed = atoll(optarg);
+			if (seed == 0) seed = ((getpid() * rand()) & 0x7FFFFFFFF); // optimized/main.cu:1331-1333
+			break;
+		case 'd': ndev = atoi(optarg); break;
+		case 'a': alpha = atof(optarg); break;
+		case 't': temp = atof(optarg); break;
+		case 'p': printFreq = atoi(optarg); break;
+		case 'e': printExp = 1; break;
+		case 'u': {
+			char *t0 = strtok(optarg, ",");
+			if (!t0) { fprintf(stderr, "cannot find temperature step in parameter...\n"); exit(EXIT_FAILURE); }
+			char *t1 = strtok(NULL, ",");
+			if (!t1) { fprintf(stderr, "cannot find iteration count in parameter...\n"); exit(EXIT_FAILURE); }
+			tempUpdStep = atof(t0);
+			tempUpdFreq = atoi(t1);
+			printf("tempUpdStep: %f, tempUpdFreq: %d\n", tempUpdStep, tempUpdFreq);
+		} break;
+		case 'm': tgtMagn = atof(optarg); break;
+		case 'c': fprintf(stderr, "-c/--corr (2-point correlations) is not supported by this build\n"); exit(EXIT_FAILURE);
+		case 'J': fprintf(stderr, "-J (random +-J couplings) is not supported by this build\n"); exit(EXIT_FAILURE);
+		case 1:
+		case 2: fprintf(stderr, "--xsl/--ysl (independent sub-lattices) are not supported by this build\n"); exit(EXIT_FAILURE);
+		case 3: printEnergy = 1; break;
+		case 4:
+			for (char *tok = strtok(optarg, ","); tok; tok = strtok(NULL, ",")) devmap.push_back(atoi(tok));
+			break;
+		case '?': exit(EXIT_FAILURE);
+		default: fprintf(stderr, "unknown option: %c\n", och); exit(EXIT_FAILURE);
+		}
+	}
+
+	// defaults and divisibility rules, optimized/main.cu:1395-1421
+	if (!X || !Y) {
+		if (!X) X = (Y && !(Y % X_MULT)) ? Y : X_MULT;
+		if (!Y) Y = !(X % Y_MULT) ? X : Y_MULT;
+	}
+	if (!X || (X % 2) || ((X / 2) % (SPIN_X_WORD * 2 * 16 * 2))) {
+		fprintf(stderr, "\nPlease specify an X dim multiple of %d\n\n", X_MULT);
+		usage(argv[0]);
+	}
+	if (!Y || (Y % Y_MULT)) {
+		fprintf(stderr, "\nPlease specify a Y dim multiple of %d\n\n", Y_MULT);
+		usage(argv[0]);
+	}
+	if (temp == -1.0f) temp = (alpha == -1.0f) ? ALPHA_DEF * ISING_CRIT_TEMP : alpha * ISING_CRIT_TEMP; // :1465-1471
+	if (printExp && printFreq) printFreq = 0;
+	if (printExp) generate_times(nsteps, printExpSteps);
+	if (ndev < 1) { fprintf(stderr, "error: need at least one device\n"); exit(EXIT_FAILURE); }
+
+	int visible = 0;
+	CHECK(ising_device_count(&visible));
+	if (devmap.empty()) for (int i = 0; i < ndev; i++) devmap.push_back(i);
+	if ((int)devmap.size() != ndev) { fprintf(stderr, "error: --devmap needs %d entries\n", ndev); exit(EXIT_FAILURE); }
+	for (int d : devmap) if (d < 0 || d >= visible) { fprintf(stderr, "error: device %d not available (%d visible)\n", d, visible); exit(EXIT_FAILURE); }
+
+	printf("\nUsing GPUs:\n");
+	for (int i = 0; i < ndev; i++) {
+		char name[256];
+		int cus = 0, thr = 0, major = 0, minor = 0;
+		CHECK(ising_device_info(devmap[i], name, sizeof(name), &cus, &thr, &major, &minor));
+		printf("\t%2d (%s, %d SMs, %d th/SM max, CC %d.%d, ECC %s)\n", i, name, cus, thr, major, minor, "on");
+	}
+	printf("\n");
+
+	const size_t lld = (X / 2) / SPIN_X_WORD;
+	const size_t llenLoc = (size_t)Y * lld;
+	const size_t llen = 2ull * ndev * llenLoc;
+	const int gridX = (int)((lld / 2 + 31) / 32), gridY = (Y + 15) / 16; // the reference's launch grid = RNG stream geometry
+
+	printf("Run configuration:\n");
+	printf("\tspin/word: %d\n", SPIN_X_WORD);
+	printf("\tspins: %zu\n", llen * SPIN_X_WORD);
+	printf("\tseed: %llu\n", seed);
+	printf("\titerations: %d\n", nsteps);
+	printf("\tblock (X, Y): %d, %d\n", 16, 16);
+	printf("\ttile  (X, Y): %d, %d\n", 32, 16);
+	printf("\tgrid  (X, Y): %d, %d\n", gridX, gridY);
+	if (printFreq) printf("\tprint magn. every %d steps\n", printFreq);
+	else if (printExp) printf("\tprint magn. following exponential series\n");
+	else printf("\tprint magn. at 1st and last step\n");
+	if ((printFreq || printExp) && tgtMagn != -1.0) printf("\tearly exit if magn. == %lf+-%lf\n", tgtMagn, TGT_MAGN_MAX_DIFF);
+	printf("\ttemp: %f (%f*T_crit)\n", temp, temp / ISING_CRIT_TEMP);
+	if (!tempUpdFreq) printf("\ttemp update not set\n");
+	else printf("\ttemp update: %f / %d iterations\n", tempUpdStep, tempUpdFreq);
+	printf("\tnot using Hamiltonian buffer\n");
+	printf("\n");
+	printf("\tlocal lattice size:      %8d x %8d\n", Y, X);
+	printf("\ttotal lattice size:      %8d x %8d\n", ndev * Y, X);
+	printf("\tlocal lattice shape: 2 x %8d x %8zu (%12zu %s)\n", Y, lld, llenLoc * 2, "ulls");
+	printf("\ttotal lattice shape: 2 x %8d x %8zu (%12zu %s)\n", ndev * Y, lld, llen, "ulls");
+	printf("\tmemory: %.2lf MB (%.2lf MB per GPU)\n", (llen * 8) / (1024.0 * 1024.0), llenLoc * 2 * 8 / (1024.0 * 1024.0));
+
+	Ring ring;
+	if (ndev > 1) { printf("\nSetting up multi-gpu configuration:\n"); fflush(stdout); }
+	for (int i = 0; i < ndev; i++) {
+		ising_config cfg;
+		memset(&cfg, 0, sizeof(cfg));
+		cfg.X = X; cfg.Y = Y; cfg.nslabs = ndev; cfg.slab = i; cfg.seed = seed; cfg.temp = temp; cfg.device = devmap[i];
+		cfg.strip_rows = 0; cfg.kernel = ISING_KERNEL_AUTO;
+		ising_ctx *c = nullptr;
+		CHECK(ising_create(&cfg, &c));
+		ring.ctx.push_back(c);
+		if (ndev > 1) { printf("\tGPU %2d done\n", i); fflush(stdout); }
+	}
+
+	for (ising_ctx *c : ring.ctx) CHECK(ising_init_lattice(c));
+	if (ndev > 1) {
+		CHECK(ising_ring_exchange(ring.ctx.data(), ndev, ISING_BLACK));
+		CHECK(ising_ring_exchange(ring.ctx.data(), ndev, ISING_WHITE));
+	}
+
+	const size_t nspins = llen * SPIN_X_WORD;
+	unsigned long long cntPos = 0, cntNeg = 0;
+	ring.count(&cntPos, &cntNeg);
+	printf("\nInitial magnetization: %9.6lf, up_s: %12llu, dw_s: %12llu\n",
+	       fabs((double)cntPos - (double)cntNeg) / (double)nspins, cntPos, cntNeg);
+	if (printEnergy) printf("Initial energy/spin:   %9.6lf\n", ring.energy(nspins));
+	CHECK(ising_ring_synchronize(ring.ctx.data(), ndev));
+
+	auto report = [&](int iter, bool exp_style) -> bool {
+		ring.count(&cntPos, &cntNeg);
+		const double magn = fabs((double)cntPos - (double)cntNeg) / (double)nspins;
+		if (exp_style) printf("        magnetization: %9.6lf (^2: %9.6lf), up_s: %12llu, dw_s: %12llu (iter: %8d)\n", magn, magn * magn, cntPos, cntNeg, iter);
+		else printf("        magnetization: %9.6lf, up_s: %12llu, dw_s: %12llu (iter: %8d)\n", magn, cntPos, cntNeg, iter);
+		if (printEnergy) printf("        energy/spin:   %9.6lf (iter: %8d)\n", ring.energy(nspins), iter);
+		if (dumpOut) {
+			char fname[256];
+			snprintf(fname, sizeof(fname), "lattice_%dx%d_T_%f_IT_%08d_", Y, X, temp, iter);
+			ring.dump(fname);
+		}
+		return tgtMagn != -1.0 && fabs(magn - tgtMagn) < TGT_MAGN_MAX_DIFF;
+	};
+
+	// hot loop, optimized/main.cu:1756-1871.  Sweeps between two host-side events (print, ramp) are enqueued as
+	// one batch; the launches are asynchronous, so the GPU never waits for the host.
+	const auto t0 = std::chrono::steady_clock::now();
+	int j = 0;
+	while (j < nsteps) {
+		int next = nsteps; // first iteration index (1-based count) at which the host must look at the lattice
+		if (printFreq) next = std::min(next, (j / printFreq + 1) * printFreq);
+		if (printExp) next = std::min<long long>(next, (long long)printExpSteps[printExpCur] + 1 > j ? (long long)printExpSteps[printExpCur] + 1 : nsteps);
+		if (tempUpdFreq) next = std::min(next, (j / tempUpdFreq + 1) * tempUpdFreq);
+		if (next <= j) next = j + 1;
+		CHECK(ising_ring_sweep(ring.ctx.data(), ndev, j + 1, next - j));
+		j = next;
+		bool stop = false;
+		if (printFreq && (j % printFreq) == 0) stop = report(j, false);
+		if (!stop && printExp && printExpSteps[printExpCur] == (unsigned long long)(j - 1)) {
+			printExpCur++;
+			stop = report(j, true);
+		}
+		if (stop) break;
+		if (tempUpdFreq && (j % tempUpdFreq) == 0) { // optimized/main.cu:1848-1860
+			temp = std::max(MIN_TEMP, temp + tempUpdStep);
+			printf("Changing temperature to %f\n", temp);
+			for (ising_ctx *c : ring.ctx) CHECK(ising_set_temperature(c, temp));
+			float tab[10];
+			CHECK(ising_get_tables(ring.ctx[0], tab, nullptr));
+			for (int i = 0; i < 2; i++)
+				for (int k = 0; k < 5; k++) printf("exp[%2d][%d]: %E\n", i ? 1 : -1, k, tab[i * 5 + k]);
+		}
+	}
+	CHECK(ising_ring_synchronize(ring.ctx.data(), ndev));
+	const double et = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+
+	ring.count(&cntPos, &cntNeg);
+	printf("Final   magnetization: %9.6lf, up_s: %12llu, dw_s: %12llu (iter: %8d)\n\n",
+	       fabs((double)cntPos - (double)cntNeg) / (double)nspins, cntPos, cntNeg, j);
+	if (printEnergy) printf("Final   energy/spin:   %9.6lf\n\n", ring.energy(nspins));
+
+	// optimized/main.cu:1884-1890 (1.5 bytes per flip + the 20-byte table per reference block)
+	printf("Kernel execution time for %d update steps: %E ms, %.2lf flips/ns (BW: %.2lf GB/s)\n", j, et,
+	       (double)nspins * j / (et * 1.0E+6),
+	       (2ull * j * (8.0 * ((llen / 2) + (llen / 2) + (llen / 2)) + 4.0 * 5 * gridX * gridY) / 1.0E+9) / (et / 1.0E+3));
+
+	if (dumpOut) {
+		char fname[256];
+		snprintf(fname, sizeof(fname), "lattice_%dx%d_T_%f_IT_%08d_", Y, X, temp, j);
+		ring.dump(fname);
+	}
+	for (ising_ctx *c : ring.ctx) ising_destroy(c);
+	return 0;
+}

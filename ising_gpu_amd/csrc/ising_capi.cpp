@@ -68,6 +68,8 @@ struct ising_ctx {
 	uint64_t thr[5]{};
 	bool fast_ok = false;
 	hipStream_t stream = nullptr;
+	hipEvent_t ev_sent[2] = {nullptr, nullptr}; // ring mode: "my boundary rows of colour c have been copied out"
+	bool peers_enabled = false;                  // ring mode: direct xGMI copies to the neighbours' devices
 
 	uint64_t *lat(int color) const { return d_lat + (size_t)color * color_words; }
 	uint64_t *halo(int color, int which) const { return d_halo + ((size_t)color * 2 + which) * lld; }
@@ -186,6 +188,7 @@ int ising_destroy(ising_ctx *c) {
 	if (c->d_lat) (void)hipFree(c->d_lat);
 	if (c->d_halo) (void)hipFree(c->d_halo);
 	if (c->d_acc) (void)hipFree(c->d_acc);
+	for (int k = 0; k < 2; k++) if (c->ev_sent[k]) (void)hipEventDestroy(c->ev_sent[k]);
 	delete c;
 	return ISING_OK;
 }
@@ -418,6 +421,104 @@ int ising_dump_text(ising_ctx *c, const char *prefix) {
 		fwrite(line.data(), 1, line.size(), fp);
 	}
 	fclose(fp);
+	return ISING_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ ring mode
+static int ring_check(ising_ctx **ctxs, int n) {
+	if (!ctxs || n < 1) return fail(ISING_E_ARG, "bad ring");
+	for (int k = 0; k < n; k++) {
+		if (!ctxs[k]) return fail(ISING_E_ARG, "ring slot %d is null", k);
+		if (ctxs[k]->cfg.nslabs != n || ctxs[k]->cfg.slab != k) return fail(ISING_E_ARG, "ring slot %d holds slab %d of %d", k, ctxs[k]->cfg.slab, ctxs[k]->cfg.nslabs);
+		if (ctxs[k]->lld != ctxs[0]->lld || ctxs[k]->cfg.Y != ctxs[0]->cfg.Y) return fail(ISING_E_ARG, "ring slabs differ in shape");
+	}
+	return ISING_OK;
+}
+
+// The reference requires and enables all-to-all peer access (optimized/main.cu:1507-1537); a ring only needs the two
+// neighbours.  Failure to enable is not fatal: hipMemcpyPeerAsync then stages through the host.
+static void ring_enable_peers(ising_ctx *c, const ising_ctx *prev, const ising_ctx *next) {
+	if (c->peers_enabled) return;
+	c->peers_enabled = true;
+	if (hipSetDevice(c->cfg.device) != hipSuccess) return;
+	const int peers[2] = {prev->cfg.device, next->cfg.device};
+	for (int k = 0; k < 2; k++) {
+		if (peers[k] == c->cfg.device || (k == 1 && peers[1] == peers[0])) continue;
+		int can = 0;
+		if (hipDeviceCanAccessPeer(&can, c->cfg.device, peers[k]) == hipSuccess && can) {
+			const hipError_t e = hipDeviceEnablePeerAccess(peers[k], 0);
+			if (e != hipSuccess) (void)hipGetLastError(); // already enabled or unsupported: fall back silently
+		}
+	}
+}
+
+static int ring_events(ising_ctx *c) {
+	for (int k = 0; k < 2; k++) {
+		if (!c->ev_sent[k]) {
+			if (int rc = bind(c)) return rc;
+			HIP_TRY(hipEventCreateWithFlags(&c->ev_sent[k], hipEventDisableTiming));
+		}
+	}
+	return ISING_OK;
+}
+
+// copies out slab k's first/last row of `color` and records ev_sent[color] on its stream
+static int ring_send(ising_ctx **ctxs, int n, int k, int color) {
+	ising_ctx *c = ctxs[k], *prev = ctxs[(k + n - 1) % n], *next = ctxs[(k + 1) % n];
+	const size_t nb = (size_t)c->lld * sizeof(uint64_t);
+	if (int rc = ring_events(c)) return rc;
+	ring_enable_peers(c, prev, next);
+	if (int rc = bind(c)) return rc;
+	// next slab's top halo <- my last row ; previous slab's bottom halo <- my first row
+	HIP_TRY(hipMemcpyPeerAsync(next->halo(color, 0), next->cfg.device, c->lat(color) + (size_t)(c->cfg.Y - 1) * c->lld, c->cfg.device, nb, c->stream));
+	HIP_TRY(hipMemcpyPeerAsync(prev->halo(color, 1), prev->cfg.device, c->lat(color), c->cfg.device, nb, c->stream));
+	HIP_TRY(hipEventRecord(c->ev_sent[color], c->stream));
+	return ISING_OK;
+}
+
+// slab k's stream waits until both neighbours have delivered their rows of `color`
+static int ring_wait(ising_ctx **ctxs, int n, int k, int color) {
+	ising_ctx *c = ctxs[k], *prev = ctxs[(k + n - 1) % n], *next = ctxs[(k + 1) % n];
+	if (int rc = bind(c)) return rc;
+	if (prev->ev_sent[color]) HIP_TRY(hipStreamWaitEvent(c->stream, prev->ev_sent[color], 0));
+	if (next != prev && next->ev_sent[color]) HIP_TRY(hipStreamWaitEvent(c->stream, next->ev_sent[color], 0));
+	return ISING_OK;
+}
+
+int ising_ring_exchange(ising_ctx **ctxs, int n, int color) {
+	if (int rc = ring_check(ctxs, n)) return rc;
+	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
+	if (n == 1) return ISING_OK;
+	for (int k = 0; k < n; k++) if (int rc = ring_send(ctxs, n, k, color)) return rc;
+	return ISING_OK;
+}
+
+int ising_ring_sweep(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
+	if (int rc = ring_check(ctxs, n)) return rc;
+	if (n == 1) return ising_sweep(ctxs[0], first_it, nsweeps);
+	for (int it = first_it; it < first_it + nsweeps; it++) {
+		for (int color = 0; color < 2; color++) {
+			for (int k = 0; k < n; k++) {
+				ising_ctx *c = ctxs[k];
+				const int ns = c->nstrips;
+				if (int rc = ring_wait(ctxs, n, k, 1 - color)) return rc; // halo rows of the source colour
+				if (ns >= 3) {
+					if (int rc = ising_update_color(c, it, color, 0, 1)) return rc;
+					if (int rc = ising_update_color(c, it, color, ns - 1, ns)) return rc;
+				} else {
+					if (int rc = ising_update_color(c, it, color, 0, ns)) return rc;
+				}
+				if (int rc = ring_send(ctxs, n, k, color)) return rc;
+				if (ns >= 3) if (int rc = ising_update_color(c, it, color, 1, ns - 1)) return rc;
+			}
+		}
+	}
+	return ISING_OK;
+}
+
+int ising_ring_synchronize(ising_ctx **ctxs, int n) {
+	if (int rc = ring_check(ctxs, n)) return rc;
+	for (int k = 0; k < n; k++) if (int rc = ising_synchronize(ctxs[k])) return rc;
 	return ISING_OK;
 }
 
