@@ -42,11 +42,12 @@ enum {
 	ISING_E_NOGPU = 4     /* no usable gfx950 device / kernel image */
 };
 
-/* kernel selection for ising_update_color / ising_sweep (A/B and fallback) */
+/* kernel selection for ising_update_color / ising_sweep (A/B and fallback); all variants give identical results */
 enum {
-	ISING_KERNEL_AUTO = 0,    /* fast integer-threshold kernel when the temperature admits it, else generic */
+	ISING_KERNEL_AUTO = 0,    /* LDS rank-table kernel when the temperature admits integer thresholds, else generic */
 	ISING_KERNEL_GENERIC = 1, /* per-site FP32 compare against the exp table, exactly as the reference writes it */
-	ISING_KERNEL_FAST = 2     /* force the integer-threshold kernel (error if thresholds do not fit) */
+	ISING_KERNEL_FAST = 2,    /* integer thresholds compared per site (v_cmpx); error if thresholds do not fit */
+	ISING_KERNEL_LUT = 3      /* integer thresholds through the 64 KiB LDS rank table; error if thresholds do not fit */
 };
 
 typedef struct ising_ctx ising_ctx;

@@ -9,12 +9,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libising_hip.so")
+LIB_PATH = os.environ.get("ISING_LIB", os.path.join(_HERE, "libising_hip.so"))  # ISING_LIB: perf-investigation builds only
 
 BLACK, WHITE = 0, 1
 CRIT_TEMP_F32 = 2.2691853046417236  # float32(2.26918531421f), CRIT_TEMP optimized/main.cu:42
 SEED_DEF = 463463564571  # optimized/main.cu:63
-KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST = 0, 1, 2
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST, KERNEL_LUT = 0, 1, 2, 3
 
 
 class IsingConfig(C.Structure):

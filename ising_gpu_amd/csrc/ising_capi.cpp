@@ -61,9 +61,10 @@ struct ising_ctx {
 	int H = 0;        // rows per strip
 	int nstrips = 0;
 	size_t color_words = 0;
-	uint64_t *d_lat = nullptr;          // [2][Y][lld]
-	uint64_t *d_halo = nullptr;         // [2 colours][2 (top,bot)][lld], nslabs > 1 only
+	uint64_t *d_lat = nullptr;          // [2 colours][Y + 2 rows][lld]: row -1 and row Y of each colour are halo rows
 	unsigned long long *d_acc = nullptr; // 2 counters
+	uint8_t *d_lut = nullptr;            // 64 KiB accept-rank table (see build_rank_table)
+	bool lut_dirty = true;
 	float tab[10]{};
 	uint64_t thr[5]{};
 	bool fast_ok = false;
@@ -71,8 +72,13 @@ struct ising_ctx {
 	hipEvent_t ev_sent[2] = {nullptr, nullptr}; // ring mode: "my boundary rows of colour c have been copied out"
 	bool peers_enabled = false;                  // ring mode: direct xGMI copies to the neighbours' devices
 
-	uint64_t *lat(int color) const { return d_lat + (size_t)color * color_words; }
-	uint64_t *halo(int color, int which) const { return d_halo + ((size_t)color * 2 + which) * lld; }
+	// Row 0 of a colour.  The halo rows sit directly above (row -1: global row slab*Y-1) and below (row Y) so the
+	// kernels address rows -1..Y uniformly.  With one slab they mirror the slab's own last / first row (periodic
+	// wrap, maintained by the kernels that write edge rows); with several slabs the neighbours' rows are delivered
+	// into them (ising_halo_ptrs / ising_ring_exchange).
+	uint64_t *lat(int color) const { return d_lat + (size_t)color * (color_words + 2 * (size_t)lld) + lld; }
+	uint64_t *halo(int color, int which) const { return which == 0 ? lat(color) - lld : lat(color) + color_words; }
+	size_t alloc_words() const { return 2 * (color_words + 2 * (size_t)lld); }
 };
 
 namespace {
@@ -105,6 +111,25 @@ void compute_tables(ising_ctx *c, float temp) {
 	c->fast_ok = symmetric && c->thr[0] == always && c->thr[1] == always && c->thr[2] == always &&
 	             c->thr[3] < always && c->thr[4] <= c->thr[3];
 	c->cfg.temp = temp;
+	c->lut_dirty = true;
+}
+
+// Accept-rank table for the LDS kernel: entry h (= top 16 bits of a draw x) holds [x < n3] + [x < n4] when h alone
+// decides both compares, and 4 ("undecidable": the kernel redoes those draws with exact compares) otherwise.
+void build_rank_table(const ising_ctx *c, uint8_t *tab) {
+	const uint32_t n3 = (uint32_t)c->thr[3], n4 = (uint32_t)c->thr[4];
+	auto decided = [](uint32_t h, uint32_t n, int *val) { // x in [h<<16, (h<<16)+0xFFFF] against threshold n
+		const uint32_t lo = h << 16, hi = lo | 0xFFFFu;
+		if (hi < n) { *val = 1; return true; }
+		if (lo >= n) { *val = 0; return true; }
+		return false;
+	};
+	for (uint32_t h = 0; h < 65536; h++) {
+		int a = 0, b = 0;
+		const bool ok3 = decided(h, n3, &a), ok4 = decided(h, n4, &b);
+		const bool ok = ok3 && ok4;
+		tab[h] = ok ? (uint8_t)(a + b) : (uint8_t)4;
+	}
 }
 
 int choose_strip_rows(int gx, int Y) {
@@ -166,13 +191,10 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	compute_tables(c, cfg->temp);
 
 	hipError_t e = hipSetDevice(cfg->device);
-	if (e == hipSuccess) e = hipMalloc((void **)&c->d_lat, 2 * c->color_words * sizeof(uint64_t));
-	if (e == hipSuccess) e = hipMemset(c->d_lat, 0, 2 * c->color_words * sizeof(uint64_t)); // optimized/main.cu:1603
+	if (e == hipSuccess) e = hipMalloc((void **)&c->d_lat, c->alloc_words() * sizeof(uint64_t));
+	if (e == hipSuccess) e = hipMemset(c->d_lat, 0, c->alloc_words() * sizeof(uint64_t)); // optimized/main.cu:1603
 	if (e == hipSuccess) e = hipMalloc((void **)&c->d_acc, 2 * sizeof(unsigned long long));
-	if (e == hipSuccess && cfg->nslabs > 1) {
-		e = hipMalloc((void **)&c->d_halo, 4 * (size_t)c->lld * sizeof(uint64_t));
-		if (e == hipSuccess) e = hipMemset(c->d_halo, 0, 4 * (size_t)c->lld * sizeof(uint64_t));
-	}
+	if (e == hipSuccess) e = hipMalloc((void **)&c->d_lut, 65536);
 	if (e != hipSuccess) {
 		const int rc = fail(ISING_E_HIP, "device allocation failed: %s", hipGetErrorString(e));
 		ising_destroy(c);
@@ -186,8 +208,8 @@ int ising_destroy(ising_ctx *c) {
 	if (!c) return ISING_OK;
 	(void)hipSetDevice(c->cfg.device);
 	if (c->d_lat) (void)hipFree(c->d_lat);
-	if (c->d_halo) (void)hipFree(c->d_halo);
 	if (c->d_acc) (void)hipFree(c->d_acc);
+	if (c->d_lut) (void)hipFree(c->d_lut);
 	for (int k = 0; k < 2; k++) if (c->ev_sent[k]) (void)hipEventDestroy(c->ev_sent[k]);
 	delete c;
 	return ISING_OK;
@@ -219,6 +241,7 @@ int ising_init_lattice(ising_ctx *c) {
 		p.gx = c->gx;
 		p.Y = c->cfg.Y;
 		p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
+		p.wrap = c->cfg.nslabs == 1;
 		p.thr_half = (uint32_t)half;
 		HIP_TRY(ising::launch_init(p, c->stream));
 	}
@@ -250,23 +273,25 @@ int ising_update_color(ising_ctx *c, int it, int color, int strip_lo, int strip_
 	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
 	if (it < 0 || it >= (1 << 26)) return fail(ISING_E_ARG, "iteration %d outside [0, 2^26)", it); // counter word 0 must not carry
 	if (strip_lo < 0 || strip_hi > c->nstrips || strip_lo > strip_hi) return fail(ISING_E_ARG, "bad strip range [%d,%d) of %d", strip_lo, strip_hi, c->nstrips);
-	int mode = c->cfg.kernel == ISING_KERNEL_GENERIC ? 1 : 0;
-	if (mode == 0 && !c->fast_ok) {
-		if (c->cfg.kernel == ISING_KERNEL_FAST) return fail(ISING_E_STATE, "temperature %g does not admit the integer-threshold kernel", (double)c->cfg.temp);
+	int mode = c->cfg.kernel == ISING_KERNEL_GENERIC ? 1 : (c->cfg.kernel == ISING_KERNEL_FAST ? 0 : 2); // AUTO, LUT -> 2
+	if (mode != 1 && !c->fast_ok) {
+		if (c->cfg.kernel != ISING_KERNEL_AUTO) return fail(ISING_E_STATE, "temperature %g does not admit the integer-threshold kernels", (double)c->cfg.temp);
 		mode = 1;
 	}
 	if (int rc = bind(c)) return rc;
+	if (mode == 2 && c->lut_dirty) {
+		std::vector<uint8_t> tab(65536);
+		build_rank_table(c, tab.data());
+		// pageable-host copy: the runtime stages it, so `tab` may go out of scope; ordered on the launch stream
+		HIP_TRY(hipMemcpyAsync(c->d_lut, tab.data(), tab.size(), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		c->lut_dirty = false;
+	}
 	const int other = 1 - color;
 	ising::UpdateParams p{};
 	p.dst = c->lat(color);
 	p.src = c->lat(other);
-	if (c->cfg.nslabs == 1) {
-		p.halo_top = p.src + (size_t)(c->cfg.Y - 1) * c->lld; // periodic wrap, loadTile optimized/main.cu:414,:422
-		p.halo_bot = p.src;
-	} else {
-		p.halo_top = c->halo(other, 0);
-		p.halo_bot = c->halo(other, 1);
-	}
+	p.wrap = c->cfg.nslabs == 1; // periodic wrap of loadTile (optimized/main.cu:414,:422) through mirrored halo rows
 	p.seed_lo = (uint32_t)c->cfg.seed;
 	p.seed_hi = (uint32_t)(c->cfg.seed >> 32);
 	p.it = (uint32_t)it;
@@ -280,6 +305,7 @@ int ising_update_color(ising_ctx *c, int it, int color, int strip_lo, int strip_
 	p.n3 = (uint32_t)c->thr[3];
 	p.n4 = (uint32_t)c->thr[4];
 	memcpy(p.tab, c->tab, sizeof(p.tab));
+	p.lut = c->d_lut;
 	HIP_TRY(ising::launch_update(p, mode, c->stream));
 	return ISING_OK;
 }
@@ -329,7 +355,8 @@ int ising_count(ising_ctx *c, uint64_t *up, uint64_t *down) {
 	if (!c || !up || !down) return fail(ISING_E_ARG, "null argument");
 	if (int rc = bind(c)) return rc;
 	HIP_TRY(hipMemsetAsync(c->d_acc, 0, 2 * sizeof(unsigned long long), c->stream));
-	HIP_TRY(ising::launch_popcount(c->d_lat, 2 * c->color_words, c->d_acc, c->stream));
+	HIP_TRY(ising::launch_popcount(c->lat(ISING_BLACK), c->color_words, c->d_acc, c->stream));
+	HIP_TRY(ising::launch_popcount(c->lat(ISING_WHITE), c->color_words, c->d_acc, c->stream));
 	unsigned long long h = 0;
 	HIP_TRY(hipMemcpyAsync(&h, c->d_acc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
@@ -344,13 +371,6 @@ int ising_bond_equal(ising_ctx *c, int64_t *A) {
 	ising::BondParams p{};
 	p.black = c->lat(ISING_BLACK);
 	p.white = c->lat(ISING_WHITE);
-	if (c->cfg.nslabs == 1) {
-		p.halo_top = p.white + (size_t)(c->cfg.Y - 1) * c->lld;
-		p.halo_bot = p.white;
-	} else {
-		p.halo_top = c->halo(ISING_WHITE, 0);
-		p.halo_bot = c->halo(ISING_WHITE, 1);
-	}
 	p.gx = c->gx;
 	p.Y = c->cfg.Y;
 	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
@@ -399,7 +419,8 @@ int ising_dump_text(ising_ctx *c, const char *prefix) {
 	if (!c || !prefix) return fail(ISING_E_ARG, "null argument");
 	if (int rc = bind(c)) return rc;
 	std::vector<uint64_t> h(2 * c->color_words);
-	HIP_TRY(hipMemcpyAsync(h.data(), c->d_lat, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+	for (int color = 0; color < 2; color++)
+		HIP_TRY(hipMemcpyAsync(h.data() + color * c->color_words, c->lat(color), c->color_words * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	char fname[512];
 	snprintf(fname, sizeof(fname), "%s%d.txt", prefix, c->cfg.slab); // optimized/main.cu:1157,:1185

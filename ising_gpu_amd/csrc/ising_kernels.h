@@ -12,10 +12,9 @@ constexpr uint32_t PHILOX_W0 = 0x9E3779B9u;
 constexpr uint32_t PHILOX_W1 = 0xBB67AE85u;
 
 struct UpdateParams {
-	uint64_t *dst;            // colour being updated, [Y][lld] words
-	const uint64_t *src;      // opposite colour, [Y][lld] words
-	const uint64_t *halo_top; // opposite colour, global row (slab*Y - 1) mod Ytot, lld words
-	const uint64_t *halo_bot; // opposite colour, global row ((slab+1)*Y) mod Ytot, lld words
+	uint64_t *dst;            // colour being updated: pointer to row 0 of [-1..Y][lld] words (rows -1, Y = halo rows)
+	const uint64_t *src;      // opposite colour, same shape; its rows -1 and Y must be current
+	int32_t wrap;             // single slab: mirror updated edge rows into dst's own halo rows (periodic wrap)
 	uint32_t seed_lo, seed_hi;
 	uint32_t it;              // reference's 1-based iteration index (0 for init)
 	uint32_t color;           // 0 black, 1 white
@@ -27,9 +26,10 @@ struct UpdateParams {
 	int32_t nunits;           // gx * (number of strips in this launch)
 	uint32_t n3, n4;          // integer accept thresholds for 3 / 4 aligned neighbours (fast kernel)
 	float tab[10];            // exp table exp_h[2][5] (generic kernel)
+	const uint8_t *lut;       // 64 KiB rank table indexed by the top 16 bits of a draw (mode 2)
 };
 
-// mode: 0 = fast integer-threshold kernel, 1 = generic FP32-table kernel
+// mode: 0 = integer thresholds via v_cmpx, 1 = generic FP32-table kernel, 2 = integer thresholds via the LDS rank table
 hipError_t launch_update(const UpdateParams &p, int mode, hipStream_t stream);
 
 struct InitParams {
@@ -38,6 +38,7 @@ struct InitParams {
 	uint32_t color;
 	int32_t gx, Y;
 	uint32_t row_base;
+	int32_t wrap;
 	uint32_t thr_half; // number of draws x with curand_uniform(x) < 0.5f
 };
 hipError_t launch_init(const InitParams &p, hipStream_t stream);
@@ -46,7 +47,7 @@ hipError_t launch_init(const InitParams &p, hipStream_t stream);
 hipError_t launch_popcount(const uint64_t *v, size_t nwords, unsigned long long *acc, hipStream_t stream);
 
 struct BondParams {
-	const uint64_t *black, *white, *halo_top, *halo_bot; // halos of the WHITE colour
+	const uint64_t *black, *white; // row-0 pointers; white's rows -1 and Y (halo rows) must be current
 	int32_t gx, Y;
 	uint32_t row_base;
 	unsigned long long *acc;

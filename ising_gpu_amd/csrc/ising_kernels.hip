@@ -12,6 +12,10 @@
 //     reference's.  Sixteen lanes = one reference block-row (256 B contiguous per vector
 //     load); a wave64 holds four such groups on consecutive 32-vector column groups, so its two loads cover
 //     2 KiB of contiguous HBM per row.
+//   * Accept ranks through a 64 KiB LDS table (default fast path, MODE 2): the top 16 bits of a draw index a byte that
+//     holds [x<N3]+[x<N4]; the two table rows that straddle a threshold hold 4 and send that dword pair (3 % of
+//     wave-pairs) through exact compares.  One v_lshrrev + ds_read_u8 + v_lshl_or per site instead of two VOPC
+//     compares and two masked adds; MODE 0 keeps the v_cmpx form as the cross-check.
 //   * Row marching instead of an LDS tile.  Each lane walks H consecutive rows with the (up, centre, down)
 //     source rows in registers, so the opposite-colour array is streamed from HBM once per half-sweep plus
 //     2/H halo rows; the 4-bit side-neighbour carry comes from one extra dword load that hits the line the
@@ -79,6 +83,10 @@ __device__ __forceinline__ PhiloxRow philox_row_setup(uint32_t tid, uint32_t k0x
 // computed on the scalar unit by the compiler.
 __device__ __forceinline__ void philox_block(const PhiloxRow &pr, uint32_t cx, uint32_t seed_lo, uint32_t seed_hi,
                                              uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
+#if defined(ISING_DBG_NORNG) // perf investigation only: not Philox, results are wrong by design
+	o0 = pr.t_lo1 + cx; o1 = pr.t_hi0 ^ cx; o2 = pr.t_lo0 + seed_lo; o3 = pr.t_e ^ seed_hi;
+	return;
+#endif
 	// round 1 (key 0), scalar half
 	uint32_t s_hi0, s_lo0;
 	mul_hilo(PHILOX_M0, cx, s_hi0, s_lo0);
@@ -192,66 +200,133 @@ __device__ __forceinline__ void neighbour_sums(const uint4 &up, const uint4 &ct,
 	S[3] = up.w + ct.w + dw.w + sd[3];
 }
 
-struct RowPtrs {
-	const uint4 *src;
-	const uint4 *halo_top, *halo_bot;
-	int Y, vecs;
-	__device__ __forceinline__ const uint4 *row(int r) const {
-		return r < 0 ? halo_top : (r >= Y ? halo_bot : src + (size_t)r * vecs);
+// Resolve the flips of 8 sites (one dword): S = neighbour-up counts, R6 = accept ranks + 6 per nibble.
+//   spin down: flip <=> n + r >= 2  <=> bit 3 of (n + r + 6);   spin up: flip <=> n - r <= 2 <=> !bit 3 of (n + 5 - r)
+__device__ __forceinline__ uint32_t apply_flips(uint32_t me, uint32_t S, uint32_t R6) {
+	const uint32_t t0 = S + R6;
+	const uint32_t t1 = (S + 0xBBBBBBBBu) - R6;               // == S + 0x55555555 - R as whole-word arithmetic
+	const uint32_t m8 = me << 3;
+	const uint32_t f = __builtin_amdgcn_bitop3_b32(t0, t1, m8, 0x72);  // m8 ? ~t1 : t0   (bit 3 of each nibble)
+	return __builtin_amdgcn_bitop3_b32(me, f >> 3, 0x11111111u, 0x78); // me ^ ((f >> 3) & 0x1111...)
+}
+
+// Exact accept ranks for the dword pair (rx, ry) fed by draw blocks cx0..cx0+3 of one vector: plain compares, runtime
+// nibble positions, rolled loop (small code).  Only runs when the rank table reports an undecidable entry
+// (about 3 % of wave-pairs).
+__device__ __forceinline__ void exact_rank_pair(const PhiloxRow &pr, uint32_t cx0, uint32_t seed_lo, uint32_t seed_hi,
+                                                uint32_t n3, uint32_t n4, uint32_t &rx, uint32_t &ry) {
+	uint32_t ax = 0, ay = 0;
+#pragma unroll 1
+	for (int mm = 0; mm < 4; ++mm) {
+		uint32_t o0, o1, o2, o3;
+		philox_block(pr, cx0 + (uint32_t)mm, seed_lo, seed_hi, o0, o1, o2, o3);
+		const int sh = 8 * mm;
+		ax += ((uint32_t)(o0 < n3) + (uint32_t)(o0 < n4)) << sh;
+		ay += ((uint32_t)(o1 < n3) + (uint32_t)(o1 < n4)) << sh;
+		ax += ((uint32_t)(o2 < n3) + (uint32_t)(o2 < n4)) << (sh + 4);
+		ay += ((uint32_t)(o3 < n3) + (uint32_t)(o3 < n4)) << (sh + 4);
 	}
-};
+	rx = ax;
+	ry = ay;
+}
+
+constexpr int LUT_BYTES = 65536;
+constexpr int threads_of(int mode) { return mode == 2 ? 1024 : THREADS; }
 
 // ---------------------------------------------------------------------------------------------- update
+// MODE 0: integer thresholds, v_cmpx accept.  MODE 1: generic FP32 table.  MODE 2: integer thresholds through the
+// 64 KiB LDS rank table (default fast path).
 template <int MODE>
-__global__ void __launch_bounds__(THREADS) update_k(const UpdateParams p) {
+__global__ void __launch_bounds__(threads_of(MODE)) update_k(const UpdateParams p) {
 	__shared__ float sh_tab[10];
+	__shared__ __attribute__((aligned(16))) uint8_t lut[MODE == 2 ? LUT_BYTES : 16];
 	if (MODE == 1) {
 		if (threadIdx.x < 10) sh_tab[threadIdx.x] = p.tab[threadIdx.x];
 		__syncthreads();
 	}
+	if (MODE == 2) {
+		// rank table: lut[x >> 16] = [x < n3] + [x < n4] where the top 16 bits decide, 4 where they do not
+		const uint4 *g = reinterpret_cast<const uint4 *>(p.lut);
+		uint4 *l = reinterpret_cast<uint4 *>(lut);
+		for (int i = threadIdx.x; i < LUT_BYTES / 16; i += threads_of(MODE)) l[i] = g[i];
+		__syncthreads();
+	}
 	const int tx = threadIdx.x & (GROUP - 1);
-	const int unit = blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x >> 4);
+	const int unit = blockIdx.x * (threads_of(MODE) / GROUP) + (threadIdx.x >> 4);
 	if (unit >= p.nunits) return;
 	const int sidx = unit / p.gx;
 	const int bx = unit - sidx * p.gx;
 	const int r0 = (p.strip_lo + sidx) * p.H;
 	const int vecs = p.gx * 32;
-	const int col0 = bx * 32 + tx, col1 = col0 + GROUP;
-	// side-neighbour vector columns with the periodic wrap of loadTile (optimized/main.cu:433,:441)
-	const int colL0 = col0 == 0 ? vecs - 1 : col0 - 1, colL1 = col1 - 1;
-	const int colR0 = col0 + 1, colR1 = (col1 + 1 == vecs) ? 0 : col1 + 1;
+	const int col0 = bx * 32 + tx;
+	// Side-neighbour carry dwords, as dword offsets from this lane's own vector in the same row, with the periodic
+	// wrap of loadTile (optimized/main.cu:433,:441): dword 3 of the vector to the left / dword 0 of the one to the right.
+	const int offL0 = (col0 == 0 ? vecs - 1 : -1) * 4 + 3, offL1 = 15 * 4 + 3;
+	const int offR0 = 4, offR1 = (col0 + GROUP + 1 == vecs ? 1 - vecs + GROUP : GROUP + 1) * 4;
 
-	RowPtrs rp{reinterpret_cast<const uint4 *>(p.src), reinterpret_cast<const uint4 *>(p.halo_top),
-	           reinterpret_cast<const uint4 *>(p.halo_bot), p.Y, vecs};
-	uint4 *dst = reinterpret_cast<uint4 *>(p.dst);
+	// Rows -1 and Y of every colour array are physically present (halo rows), so row r lives at src + r*vecs.
+	const uint4 *pc = reinterpret_cast<const uint4 *>(p.src) + ((ptrdiff_t)r0 * vecs + col0); // centre row, own vector
+	uint4 *pm = reinterpret_cast<uint4 *>(p.dst) + ((ptrdiff_t)r0 * vecs + col0);
+	const ptrdiff_t wrap_bot = (ptrdiff_t)p.Y * vecs; // row 0 mirrors to row Y, row Y-1 to row -1 (single slab)
 
 	const uint32_t k2y = p.seed_hi + 2u * PHILOX_W1;
 	const uint32_t cx_base = 16u * (2u * p.it + p.color);
 
-	const uint4 *pu = rp.row(r0 - 1);
-	const uint4 *pc = rp.row(r0);
-	uint4 up0 = pu[col0], up1 = pu[col1];
-	uint4 ct0 = pc[col0], ct1 = pc[col1];
+#if defined(ISING_DBG_NOMEM) // perf investigation only: no global traffic, results are wrong by design
+#define DBG_LD(expr) make_uint4(threadIdx.x, blockIdx.x, p.it, 0x01010101u)
+#define DBG_LDW(expr) (threadIdx.x * 0x10101u)
+#else
+#define DBG_LD(expr) (expr)
+#define DBG_LDW(expr) (expr)
+#endif
+	uint4 up0 = DBG_LD(pc[-vecs]), up1 = DBG_LD(pc[GROUP - vecs]);
+	uint4 ct0 = DBG_LD(pc[0]), ct1 = DBG_LD(pc[GROUP]);
 
 	for (int r = 0; r < p.H; ++r) {
 		const int lr = r0 + r;
 		const uint32_t grow = p.row_base + (uint32_t)lr;
 		const bool back = (p.color == 0) ? !(grow & 1u) : (grow & 1u); // readBack, optimized/main.cu:542
 		// issue this row's loads; they are consumed only after the 16 Philox blocks below
-		const uint4 *pd = rp.row(lr + 1);
-		const uint4 dw0 = pd[col0], dw1 = pd[col1];
+		const uint4 dw0 = DBG_LD(pc[vecs]), dw1 = DBG_LD(pc[vecs + GROUP]);
 		const uint32_t *pcw = reinterpret_cast<const uint32_t *>(pc);
-		const uint32_t side0 = back ? pcw[4 * colL0 + 3] : pcw[4 * colR0];
-		const uint32_t side1 = back ? pcw[4 * colL1 + 3] : pcw[4 * colR1];
-		uint4 *pm = dst + (size_t)lr * vecs;
-		uint4 me0 = pm[col0], me1 = pm[col1];
+		const uint32_t side0 = DBG_LDW(pcw[back ? offL0 : offR0]);
+		const uint32_t side1 = DBG_LDW(pcw[back ? offL1 : offR1]);
+		uint4 me0 = DBG_LD(pm[0]), me1 = DBG_LD(pm[GROUP]);
 
 		// stream id of the reference thread that owns these two vectors (optimized/main.cu:514-515)
 		const uint32_t tid = ((grow >> 4) * (uint32_t)p.gx + (uint32_t)bx) * 256u + (grow & 15u) * 16u + (uint32_t)tx;
 		const PhiloxRow pr = philox_row_setup(tid, p.seed_lo, k2y);
 
-		if (MODE == 0) {
+		if (MODE == 2) {
 			uint32_t R[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+			static_for<16>([&](auto B) {
+				// pairs of accumulators (word x, word y) are filled high nibble first so each new rank is OR-ed into
+				// nibble 0 after a shift: draw blocks 4k+3, 4k+2, 4k+1, 4k of vector j
+				constexpr int j = B.value >> 3, k = (B.value >> 2) & 1, m = 4 * k + 3 - (B.value & 3);
+				uint32_t o[4];
+				philox_block(pr, cx_base + (uint32_t)(8 * j + m), p.seed_lo, p.seed_hi, o[0], o[1], o[2], o[3]);
+				uint32_t &rx = R[j][k], &ry = R[j][2 + k];
+				const uint32_t a0 = lut[o[0] >> 16], a1 = lut[o[1] >> 16], a2 = lut[o[2] >> 16], a3 = lut[o[3] >> 16];
+				rx = (rx << 4) | a2; // nibble 2m+1
+				ry = (ry << 4) | a3;
+				rx = (rx << 4) | a0; // nibble 2m
+				ry = (ry << 4) | a1;
+				if ((B.value & 3) == 3) {
+					// table entries whose top 16 bits do not decide the compare carry bit 2: redo the pair exactly
+					if (__any(((rx | ry) & 0x44444444u) != 0u))
+						exact_rank_pair(pr, cx_base + (uint32_t)(8 * j + 4 * k), p.seed_lo, p.seed_hi, p.n3, p.n4, rx, ry);
+				}
+			});
+			uint32_t S[4];
+			neighbour_sums(up0, ct0, dw0, side0, back, S);
+			me0 = make_uint4(apply_flips(me0.x, S[0], R[0][0] + 0x66666666u), apply_flips(me0.y, S[1], R[0][1] + 0x66666666u),
+			                 apply_flips(me0.z, S[2], R[0][2] + 0x66666666u), apply_flips(me0.w, S[3], R[0][3] + 0x66666666u));
+			neighbour_sums(up1, ct1, dw1, side1, back, S);
+			me1 = make_uint4(apply_flips(me1.x, S[0], R[1][0] + 0x66666666u), apply_flips(me1.y, S[1], R[1][1] + 0x66666666u),
+			                 apply_flips(me1.z, S[2], R[1][2] + 0x66666666u), apply_flips(me1.w, S[3], R[1][3] + 0x66666666u));
+		} else if (MODE == 0) {
+			// accept ranks, pre-biased by 6 per nibble (see apply_flips)
+			uint32_t R[2][4] = {{0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u}, {0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u}};
 			static_for<16>([&](auto B) {
 				constexpr int j = B.value >> 3, m = B.value & 7;
 				uint32_t o[4];
@@ -261,27 +336,11 @@ __global__ void __launch_bounds__(THREADS) update_k(const UpdateParams p) {
 			});
 			uint32_t S[4];
 			neighbour_sums(up0, ct0, dw0, side0, back, S);
-			uint32_t mv[4] = {me0.x, me0.y, me0.z, me0.w};
-#pragma unroll
-			for (int d = 0; d < 4; ++d) {
-				const uint32_t t0 = S[d] + R[0][d] + 0x66666666u; // bit3 of nibble <=> n + r >= 2
-				const uint32_t t1 = S[d] + 0x55555555u - R[0][d]; // bit3 of nibble <=> n - r >= 3
-				const uint32_t m8 = mv[d] << 3;
-				const uint32_t f = (t0 & ~m8) | (~t1 & m8);
-				mv[d] ^= (f >> 3) & 0x11111111u;
-			}
-			me0 = make_uint4(mv[0], mv[1], mv[2], mv[3]);
+			me0 = make_uint4(apply_flips(me0.x, S[0], R[0][0]), apply_flips(me0.y, S[1], R[0][1]),
+			                 apply_flips(me0.z, S[2], R[0][2]), apply_flips(me0.w, S[3], R[0][3]));
 			neighbour_sums(up1, ct1, dw1, side1, back, S);
-			uint32_t nv[4] = {me1.x, me1.y, me1.z, me1.w};
-#pragma unroll
-			for (int d = 0; d < 4; ++d) {
-				const uint32_t t0 = S[d] + R[1][d] + 0x66666666u;
-				const uint32_t t1 = S[d] + 0x55555555u - R[1][d];
-				const uint32_t m8 = nv[d] << 3;
-				const uint32_t f = (t0 & ~m8) | (~t1 & m8);
-				nv[d] ^= (f >> 3) & 0x11111111u;
-			}
-			me1 = make_uint4(nv[0], nv[1], nv[2], nv[3]);
+			me1 = make_uint4(apply_flips(me1.x, S[0], R[1][0]), apply_flips(me1.y, S[1], R[1][1]),
+			                 apply_flips(me1.z, S[2], R[1][2]), apply_flips(me1.w, S[3], R[1][3]));
 		} else {
 			// generic: the reference's own per-site FP32 test, optimized/main.cu:637-660
 			uint32_t S[2][4];
@@ -298,20 +357,30 @@ __global__ void __launch_bounds__(THREADS) update_k(const UpdateParams p) {
 					for (int q = 0; q < 4; ++q) {
 						const int z = 2 * m + (q >> 1), w = q & 1;
 						const int d = 2 * w + (z >> 3), sh = 4 * (z & 7);
-						const uint32_t s = (mv[j][d] >> sh) & 0xFu;
+						const uint32_t sp = (mv[j][d] >> sh) & 0xFu;
 						const uint32_t n = (S[j][d] >> sh) & 0xFu;
-						if (u01(o[q]) <= sh_tab[s * 5 + n]) mv[j][d] ^= 1u << sh;
+						if (u01(o[q]) <= sh_tab[sp * 5 + n]) mv[j][d] ^= 1u << sh;
 					}
 				}
 			}
 			me0 = make_uint4(mv[0][0], mv[0][1], mv[0][2], mv[0][3]);
 			me1 = make_uint4(mv[1][0], mv[1][1], mv[1][2], mv[1][3]);
 		}
-		pm[col0] = me0;
-		pm[col1] = me1;
+#if defined(ISING_DBG_NOMEM)
+		if ((me0.x ^ me1.y) == 0x12345678u && me0.z == 0x9abcdef0u) // practically never: keeps the arithmetic alive
+#endif
+		{
+			pm[0] = me0;
+			pm[GROUP] = me1;
+		}
+		if (p.wrap) { // single slab: keep this colour's own halo rows equal to the opposite edge rows
+			if (lr == 0) { pm[wrap_bot] = me0; pm[wrap_bot + GROUP] = me1; }
+			if (lr == p.Y - 1) { pm[-wrap_bot] = me0; pm[-wrap_bot + GROUP] = me1; }
+		}
 		up0 = ct0; up1 = ct1;
 		ct0 = dw0; ct1 = dw1;
-		pc = pd;
+		pc += vecs;
+		pm += vecs;
 	}
 }
 
@@ -342,7 +411,12 @@ __global__ void __launch_bounds__(THREADS) init_k(const InitParams p) {
 				if (o[q] < p.thr_half) v[2 * w + (z >> 3)] |= 1u << (4 * (z & 7));
 			}
 		}
-		row[bx * 32 + tx + j * GROUP] = make_uint4(v[0], v[1], v[2], v[3]);
+		const uint4 val = make_uint4(v[0], v[1], v[2], v[3]);
+		row[bx * 32 + tx + j * GROUP] = val;
+		if (p.wrap) { // single slab: the halo rows mirror the opposite edge rows
+			if (lr == 0) row[(ptrdiff_t)p.Y * vecs + bx * 32 + tx + j * GROUP] = val;
+			if (lr == p.Y - 1) row[-(ptrdiff_t)p.Y * vecs + bx * 32 + tx + j * GROUP] = val;
+		}
 	}
 }
 
@@ -376,8 +450,7 @@ __global__ void __launch_bounds__(THREADS) bond_equal_k(const BondParams p) {
 	__shared__ unsigned long long part[THREADS / 64];
 	const int vecs = p.gx * 32;
 	const size_t total = (size_t)vecs * p.Y;
-	RowPtrs rp{reinterpret_cast<const uint4 *>(p.white), reinterpret_cast<const uint4 *>(p.halo_top),
-	           reinterpret_cast<const uint4 *>(p.halo_bot), p.Y, vecs};
+	const uint4 *white = reinterpret_cast<const uint4 *>(p.white);
 	const uint4 *black = reinterpret_cast<const uint4 *>(p.black);
 	unsigned long long acc = 0;
 	for (size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * THREADS) {
@@ -385,12 +458,12 @@ __global__ void __launch_bounds__(THREADS) bond_equal_k(const BondParams p) {
 		const int col = (int)(i - (size_t)lr * vecs);
 		const uint32_t grow = p.row_base + (uint32_t)lr;
 		const bool back = !(grow & 1u); // black sites
-		const uint4 *pu = rp.row(lr - 1), *pc = rp.row(lr), *pd = rp.row(lr + 1);
+		const uint4 *pc = white + (ptrdiff_t)lr * vecs; // rows -1 and Y are the halo rows
 		const int colL = col == 0 ? vecs - 1 : col - 1, colR = (col + 1 == vecs) ? 0 : col + 1;
 		const uint32_t *pcw = reinterpret_cast<const uint32_t *>(pc);
 		const uint32_t side = back ? pcw[4 * colL + 3] : pcw[4 * colR];
 		uint32_t S[4];
-		neighbour_sums(pu[col], pc[col], pd[col], side, back, S);
+		neighbour_sums(pc[col - vecs], pc[col], pc[col + vecs], side, back, S);
 		const uint4 me = black[i];
 		const uint32_t mv[4] = {me.x, me.y, me.z, me.w};
 #pragma unroll
@@ -417,9 +490,11 @@ __global__ void __launch_bounds__(THREADS) bond_equal_k(const BondParams p) {
 // ---------------------------------------------------------------------------------------------- launchers
 hipError_t launch_update(const UpdateParams &p, int mode, hipStream_t stream) {
 	if (p.nunits <= 0) return hipSuccess;
-	const dim3 grid((p.nunits + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), block(THREADS);
-	if (mode == 0) hipLaunchKernelGGL(update_k<0>, grid, block, 0, stream, p);
-	else           hipLaunchKernelGGL(update_k<1>, grid, block, 0, stream, p);
+	const int per_block = threads_of(mode) / GROUP;
+	const dim3 grid((p.nunits + per_block - 1) / per_block), block(threads_of(mode));
+	if (mode == 0)      hipLaunchKernelGGL(update_k<0>, grid, block, 0, stream, p);
+	else if (mode == 1) hipLaunchKernelGGL(update_k<1>, grid, block, 0, stream, p);
+	else                hipLaunchKernelGGL(update_k<2>, grid, block, 0, stream, p);
 	return hipGetLastError();
 }
 

@@ -22,7 +22,7 @@ def _compare(slab, orc, what):
                                  f"hip {int(got[r, q]):016x} oracle {int(ref[r, q]):016x}")
 
 
-@pytest.mark.parametrize("kernel", [ig.KERNEL_FAST, ig.KERNEL_GENERIC])
+@pytest.mark.parametrize("kernel", [ig.KERNEL_LUT, ig.KERNEL_FAST, ig.KERNEL_GENERIC])
 @pytest.mark.parametrize("X,Y,strip", [(2048, 16, 0), (2048, 64, 4), (4096, 256, 16), (8192, 128, 0), (6144, 48, 1)])
 @pytest.mark.parametrize("temp,seed", [(1.5, ig.SEED_DEF), (TC, 1234)])
 def test_state_bit_exact(gpu, oracle_mod, kernel, X, Y, strip, temp, seed):

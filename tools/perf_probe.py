@@ -35,5 +35,7 @@ if __name__ == "__main__":
         run(65536, 65536, 4, 16, ig.KERNEL_GENERIC)
     else:
         X, Y, sweeps = int(args[0]), int(args[1]), int(args[2])
-        for strip in [int(v) for v in args[3].split(",")]:
-            run(X, Y, sweeps, strip)
+        kernels = [int(v) for v in args[4].split(",")] if len(args) > 4 else [ig.KERNEL_AUTO]
+        for kernel in kernels:
+            for strip in [int(v) for v in args[3].split(",")]:
+                run(X, Y, sweeps, strip, kernel)
