@@ -44,10 +44,11 @@ enum {
 
 /* kernel selection for ising_update_color / ising_sweep (A/B and fallback); all variants give identical results */
 enum {
-	ISING_KERNEL_AUTO = 0,    /* LDS rank-table kernel when the temperature admits integer thresholds, else generic */
+	ISING_KERNEL_AUTO = 0,    /* integer-threshold kernel (v_cmpx form) when the temperature admits it, else generic */
 	ISING_KERNEL_GENERIC = 1, /* per-site FP32 compare against the exp table, exactly as the reference writes it */
 	ISING_KERNEL_FAST = 2,    /* integer thresholds compared per site (v_cmpx); error if thresholds do not fit */
-	ISING_KERNEL_LUT = 3      /* integer thresholds through the 64 KiB LDS rank table; error if thresholds do not fit */
+	ISING_KERNEL_LUT = 3      /* integer thresholds through a 64 KiB LDS rank table (A/B variant: fewer VALU cycles, same
+	                             speed in the power-limited regime); error if thresholds do not fit */
 };
 
 typedef struct ising_ctx ising_ctx;

@@ -273,7 +273,7 @@ int ising_update_color(ising_ctx *c, int it, int color, int strip_lo, int strip_
 	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
 	if (it < 0 || it >= (1 << 26)) return fail(ISING_E_ARG, "iteration %d outside [0, 2^26)", it); // counter word 0 must not carry
 	if (strip_lo < 0 || strip_hi > c->nstrips || strip_lo > strip_hi) return fail(ISING_E_ARG, "bad strip range [%d,%d) of %d", strip_lo, strip_hi, c->nstrips);
-	int mode = c->cfg.kernel == ISING_KERNEL_GENERIC ? 1 : (c->cfg.kernel == ISING_KERNEL_FAST ? 0 : 2); // AUTO, LUT -> 2
+	int mode = c->cfg.kernel == ISING_KERNEL_GENERIC ? 1 : (c->cfg.kernel == ISING_KERNEL_LUT ? 2 : 0); // AUTO, FAST -> 0
 	if (mode != 1 && !c->fast_ok) {
 		if (c->cfg.kernel != ISING_KERNEL_AUTO) return fail(ISING_E_STATE, "temperature %g does not admit the integer-threshold kernels", (double)c->cfg.temp);
 		mode = 1;

@@ -12,10 +12,11 @@
 //     reference's.  Sixteen lanes = one reference block-row (256 B contiguous per vector
 //     load); a wave64 holds four such groups on consecutive 32-vector column groups, so its two loads cover
 //     2 KiB of contiguous HBM per row.
-//   * Accept ranks through a 64 KiB LDS table (default fast path, MODE 2): the top 16 bits of a draw index a byte that
-//     holds [x<N3]+[x<N4]; the two table rows that straddle a threshold hold 4 and send that dword pair (3 % of
+//   * A/B variant MODE 2: accept ranks through a 64 KiB LDS table: the top 16 bits of a draw index a byte that holds
+//     [x<N3]+[x<N4]; the two table rows that straddle a threshold hold 4 and send that dword pair (3 % of
 //     wave-pairs) through exact compares.  One v_lshrrev + ds_read_u8 + v_lshl_or per site instead of two VOPC
-//     compares and two masked adds; MODE 0 keeps the v_cmpx form as the cross-check.
+//     compares and two masked adds: +8 % in an ALU-only build, but equal in the real kernel, which runs against the
+//     board power limit; MODE 0 (v_cmpx) is the default.
 //   * Row marching instead of an LDS tile.  Each lane walks H consecutive rows with the (up, centre, down)
 //     source rows in registers, so the opposite-colour array is streamed from HBM once per half-sweep plus
 //     2/H halo rows; the 4-bit side-neighbour carry comes from one extra dword load that hits the line the
@@ -234,10 +235,13 @@ constexpr int LUT_BYTES = 65536;
 constexpr int threads_of(int mode) { return mode == 2 ? 1024 : THREADS; }
 
 // ---------------------------------------------------------------------------------------------- update
-// MODE 0: integer thresholds, v_cmpx accept.  MODE 1: generic FP32 table.  MODE 2: integer thresholds through the
-// 64 KiB LDS rank table (default fast path).
+// MODE 0: integer thresholds, v_cmpx accept (default).  MODE 1: generic FP32 table.  MODE 2: integer thresholds
+// through the 64 KiB LDS rank table.
+#ifndef ISING_LUT_WAVES_PER_SIMD
+#define ISING_LUT_WAVES_PER_SIMD 4
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(threads_of(MODE)) update_k(const UpdateParams p) {
+__global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_PER_SIMD : 1) update_k(const UpdateParams p) {
 	__shared__ float sh_tab[10];
 	__shared__ __attribute__((aligned(16))) uint8_t lut[MODE == 2 ? LUT_BYTES : 16];
 	if (MODE == 1) {
@@ -252,7 +256,13 @@ __global__ void __launch_bounds__(threads_of(MODE)) update_k(const UpdateParams 
 		__syncthreads();
 	}
 	const int tx = threadIdx.x & (GROUP - 1);
-	const int unit = blockIdx.x * (threads_of(MODE) / GROUP) + (threadIdx.x >> 4);
+	// XCD-aware block order: hardware block b runs on XCD b % 8 (observed, used for speed only), so give each XCD a
+	// contiguous range of logical blocks; vertically adjacent strips then share halo rows through one L2.
+	int lb = blockIdx.x;
+#if defined(ISING_XCD_REMAP) // A/B tested at 65536^2: no measurable effect (within +-1 % noise), so off by default
+	if ((gridDim.x & 7) == 0) lb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+#endif
+	const int unit = lb * (threads_of(MODE) / GROUP) + (threadIdx.x >> 4);
 	if (unit >= p.nunits) return;
 	const int sidx = unit / p.gx;
 	const int bx = unit - sidx * p.gx;
