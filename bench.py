@@ -123,7 +123,7 @@ def main():
     value = total_flips / (dt * 1e9)
 
     if rank == 0:
-        # dominant kernel: update_k; 2 launches per step (3 per colour with N>1: two boundary strips + interior)
+        # dominant kernel: update_k; 2 full-slab launches per step (with N>1 each colour adds one tiny edge-row launch)
         launches = 2 * args.steps
         avg_launch_ms = ev_ms / launches
         alg_bytes_per_launch = BYTES_PER_FLIP * spins_per_gpu / 2.0  # src read + dst read + dst write of one colour

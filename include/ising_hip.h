@@ -94,11 +94,15 @@ int ising_set_temperature(ising_ctx *ctx, float temp);
 int ising_get_tables(ising_ctx *ctx, float exp_table[10], uint64_t thr[5]);
 
 /* One colour half-sweep, spinUpdateV_2D_k<COLOR> (optimized/main.cu:463-670; launches :1766-1777, :1787-1798)
- * restricted to row strips [strip_lo, strip_hi) of this slab (strip = cfg.strip_rows rows; see
- * ising_strip_info).  `it` is the reference's 1-based iteration argument (j+1).  Rows 0 and Y-1 read the
- * halo rows of the opposite colour: for nslabs == 1 these alias the slab itself (periodic wrap), otherwise
- * they must have been delivered into the buffers returned by ising_halo_ptrs before the launch runs. */
-int ising_update_color(ising_ctx *ctx, int it, int color, int strip_lo, int strip_hi);
+ * restricted to rows [row_lo, row_hi) of this slab.  `it` is the reference's 1-based iteration argument (j+1).
+ * Rows 0 and Y-1 read the halo rows of the opposite colour: for nslabs == 1 these mirror the slab itself (periodic
+ * wrap), otherwise they must have been delivered into the buffers returned by ising_halo_ptrs before the launch
+ * runs.  Every row is independent of the others within a colour, so any partition gives the same result. */
+int ising_update_color(ising_ctx *ctx, int it, int color, int row_lo, int row_hi);
+/* The same for just the two edge rows 0 and Y-1 in one launch: what the neighbours need first, so that the halo
+ * exchange can overlap with ising_update_color(ctx, it, color, 1, Y-1). */
+int ising_update_edges(ising_ctx *ctx, int it, int color);
+/* Rows each lane marches per launch (cfg.strip_rows or the automatic choice) and the resulting strip count. */
 int ising_strip_info(ising_ctx *ctx, int *strip_rows, int *nstrips);
 
 /* nslabs == 1 only: `nsweeps` full sweeps, black then white, iterations first_it .. first_it+nsweeps-1
@@ -112,7 +116,7 @@ int ising_sweep_timed(ising_ctx *ctx, int first_it, int nsweeps, float *elapsed_
  *   send_top / send_bot : device pointers to this slab's first / last row (row_bytes each), to be sent to the
  *                         previous / next slab in the ring;
  *   recv_top / recv_bot : device buffers that must receive the previous slab's last row / the next slab's
- *                         first row before a half-sweep of the OTHER colour touches strips 0 / nstrips-1. */
+ *                         first row before a half-sweep of the OTHER colour touches rows 0 / Y-1. */
 int ising_halo_ptrs(ising_ctx *ctx, int color, void **send_top, void **send_bot, void **recv_top, void **recv_bot,
                     size_t *row_bytes);
 
@@ -144,8 +148,8 @@ int ising_dump_text(ising_ctx *ctx, const char *prefix);
 
 /* Delivers colour `color`'s first/last rows of every slab into the neighbours' halo buffers (asynchronous). */
 int ising_ring_exchange(ising_ctx **ctxs, int n, int color);
-/* `nsweeps` full sweeps over all slabs, iterations first_it .. first_it+nsweeps-1: per colour, boundary strips first,
- * then the halo copies, then the interior strips (which overlap with the copies).  Asynchronous. */
+/* `nsweeps` full sweeps over all slabs, iterations first_it .. first_it+nsweeps-1: per colour, the two edge rows
+ * first, then the halo copies, then the interior rows (which overlap with the copies).  Asynchronous. */
 int ising_ring_sweep(ising_ctx **ctxs, int n, int first_it, int nsweeps);
 /* Blocks until every slab's stream is idle. */
 int ising_ring_synchronize(ising_ctx **ctxs, int n);

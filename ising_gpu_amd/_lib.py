@@ -45,6 +45,7 @@ PROTOTYPES = {
     "ising_set_temperature": (C.c_int, [C.c_void_p, C.c_float]),
     "ising_get_tables": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
     "ising_update_color": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ising_update_edges": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ising_strip_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ising_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ising_sweep_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),

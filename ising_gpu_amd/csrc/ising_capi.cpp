@@ -268,11 +268,10 @@ int ising_strip_info(ising_ctx *c, int *strip_rows, int *nstrips) {
 	return ISING_OK;
 }
 
-int ising_update_color(ising_ctx *c, int it, int color, int strip_lo, int strip_hi) {
-	if (!c) return fail(ISING_E_ARG, "null context");
+// launches update_k over up to two row ranges
+static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int lo1, int hi1) {
 	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
 	if (it < 0 || it >= (1 << 26)) return fail(ISING_E_ARG, "iteration %d outside [0, 2^26)", it); // counter word 0 must not carry
-	if (strip_lo < 0 || strip_hi > c->nstrips || strip_lo > strip_hi) return fail(ISING_E_ARG, "bad strip range [%d,%d) of %d", strip_lo, strip_hi, c->nstrips);
 	int mode = c->cfg.kernel == ISING_KERNEL_GENERIC ? 1 : (c->cfg.kernel == ISING_KERNEL_LUT ? 2 : 0); // AUTO, FAST -> 0
 	if (mode != 1 && !c->fast_ok) {
 		if (c->cfg.kernel != ISING_KERNEL_AUTO) return fail(ISING_E_STATE, "temperature %g does not admit the integer-threshold kernels", (double)c->cfg.temp);
@@ -282,9 +281,8 @@ int ising_update_color(ising_ctx *c, int it, int color, int strip_lo, int strip_
 	if (mode == 2 && c->lut_dirty) {
 		std::vector<uint8_t> tab(65536);
 		build_rank_table(c, tab.data());
-		// pageable-host copy: the runtime stages it, so `tab` may go out of scope; ordered on the launch stream
 		HIP_TRY(hipMemcpyAsync(c->d_lut, tab.data(), tab.size(), hipMemcpyHostToDevice, c->stream));
-		HIP_TRY(hipStreamSynchronize(c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream)); // `tab` is pageable host memory about to go out of scope
 		c->lut_dirty = false;
 	}
 	const int other = 1 - color;
@@ -300,8 +298,10 @@ int ising_update_color(ising_ctx *c, int it, int color, int strip_lo, int strip_
 	p.Y = c->cfg.Y;
 	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
 	p.H = c->H;
-	p.strip_lo = strip_lo;
-	p.nunits = c->gx * (strip_hi - strip_lo);
+	p.row_lo[0] = lo0; p.row_hi[0] = hi0;
+	p.row_lo[1] = lo1; p.row_hi[1] = hi1;
+	p.nunits0 = c->gx * ((hi0 - lo0 + c->H - 1) / c->H);
+	p.nunits = p.nunits0 + c->gx * ((hi1 - lo1 + c->H - 1) / c->H);
 	p.n3 = (uint32_t)c->thr[3];
 	p.n4 = (uint32_t)c->thr[4];
 	memcpy(p.tab, c->tab, sizeof(p.tab));
@@ -310,12 +310,23 @@ int ising_update_color(ising_ctx *c, int it, int color, int strip_lo, int strip_
 	return ISING_OK;
 }
 
+int ising_update_color(ising_ctx *c, int it, int color, int row_lo, int row_hi) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (row_lo < 0 || row_hi > c->cfg.Y || row_lo > row_hi) return fail(ISING_E_ARG, "bad row range [%d,%d) of %d", row_lo, row_hi, c->cfg.Y);
+	return launch_ranges(c, it, color, row_lo, row_hi, 0, 0);
+}
+
+int ising_update_edges(ising_ctx *c, int it, int color) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	return launch_ranges(c, it, color, 0, 1, c->cfg.Y - 1, c->cfg.Y);
+}
+
 int ising_sweep(ising_ctx *c, int first_it, int nsweeps) {
 	if (!c) return fail(ISING_E_ARG, "null context");
 	if (c->cfg.nslabs != 1) return fail(ISING_E_STATE, "ising_sweep needs nslabs == 1; drive slabs with ising_update_color + halo exchange");
 	for (int it = first_it; it < first_it + nsweeps; it++) {
-		if (int rc = ising_update_color(c, it, ISING_BLACK, 0, c->nstrips)) return rc;
-		if (int rc = ising_update_color(c, it, ISING_WHITE, 0, c->nstrips)) return rc;
+		if (int rc = ising_update_color(c, it, ISING_BLACK, 0, c->cfg.Y)) return rc;
+		if (int rc = ising_update_color(c, it, ISING_WHITE, 0, c->cfg.Y)) return rc;
 	}
 	return ISING_OK;
 }
@@ -521,16 +532,10 @@ int ising_ring_sweep(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 		for (int color = 0; color < 2; color++) {
 			for (int k = 0; k < n; k++) {
 				ising_ctx *c = ctxs[k];
-				const int ns = c->nstrips;
 				if (int rc = ring_wait(ctxs, n, k, 1 - color)) return rc; // halo rows of the source colour
-				if (ns >= 3) {
-					if (int rc = ising_update_color(c, it, color, 0, 1)) return rc;
-					if (int rc = ising_update_color(c, it, color, ns - 1, ns)) return rc;
-				} else {
-					if (int rc = ising_update_color(c, it, color, 0, ns)) return rc;
-				}
+				if (int rc = ising_update_edges(c, it, color)) return rc;
 				if (int rc = ring_send(ctxs, n, k, color)) return rc;
-				if (ns >= 3) if (int rc = ising_update_color(c, it, color, 1, ns - 1)) return rc;
+				if (int rc = ising_update_color(c, it, color, 1, c->cfg.Y - 1)) return rc;
 			}
 		}
 	}

@@ -21,9 +21,10 @@ struct UpdateParams {
 	int32_t gx;               // X/2048: 32-vector column groups per row (= reference gridDim.x)
 	int32_t Y;                // rows in this slab
 	uint32_t row_base;        // global row of slab row 0 (slab*Y)
-	int32_t H;                // rows per strip
-	int32_t strip_lo;         // first strip of this launch
-	int32_t nunits;           // gx * (number of strips in this launch)
+	int32_t H;                // rows each lane marches (a "strip"; the last strip of a range may be shorter)
+	int32_t row_lo[2], row_hi[2]; // up to two row ranges per launch (the two edge rows of a slab go in one launch)
+	int32_t nunits0;          // units (column group x strip) of range 0
+	int32_t nunits;           // units of both ranges
 	uint32_t n3, n4;          // integer accept thresholds for 3 / 4 aligned neighbours (fast kernel)
 	float tab[10];            // exp table exp_h[2][5] (generic kernel)
 	const uint8_t *lut;       // 64 KiB rank table indexed by the top 16 bits of a draw (mode 2)

@@ -264,9 +264,12 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 #endif
 	const int unit = lb * (threads_of(MODE) / GROUP) + (threadIdx.x >> 4);
 	if (unit >= p.nunits) return;
-	const int sidx = unit / p.gx;
-	const int bx = unit - sidx * p.gx;
-	const int r0 = (p.strip_lo + sidx) * p.H;
+	const int rng = unit >= p.nunits0;
+	const int u = unit - (rng ? p.nunits0 : 0);
+	const int sidx = u / p.gx;
+	const int bx = u - sidx * p.gx;
+	const int r0 = p.row_lo[rng] + sidx * p.H;
+	const int nrows = min(p.H, p.row_hi[rng] - r0);
 	const int vecs = p.gx * 32;
 	const int col0 = bx * 32 + tx;
 	// Side-neighbour carry dwords, as dword offsets from this lane's own vector in the same row, with the periodic
@@ -292,7 +295,7 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 	uint4 up0 = DBG_LD(pc[-vecs]), up1 = DBG_LD(pc[GROUP - vecs]);
 	uint4 ct0 = DBG_LD(pc[0]), ct1 = DBG_LD(pc[GROUP]);
 
-	for (int r = 0; r < p.H; ++r) {
+	for (int r = 0; r < nrows; ++r) {
 		const int lr = r0 + r;
 		const uint32_t grow = p.row_base + (uint32_t)lr;
 		const bool back = (p.color == 0) ? !(grow & 1u) : (grow & 1u); // readBack, optimized/main.cu:542

@@ -77,8 +77,11 @@ class IsingSlab:
         check(self._lib.ising_get_tables(self._h, tab, thr))
         return np.array(list(tab), dtype=np.float32).reshape(2, 5), [int(v) for v in thr]
 
-    def update_color(self, it: int, color: int, strip_lo: int = 0, strip_hi: int | None = None):
-        check(self._lib.ising_update_color(self._h, it, color, strip_lo, self.nstrips if strip_hi is None else strip_hi))
+    def update_color(self, it: int, color: int, row_lo: int = 0, row_hi: int | None = None):
+        check(self._lib.ising_update_color(self._h, it, color, row_lo, self.Y if row_hi is None else row_hi))
+
+    def update_edges(self, it: int, color: int):
+        check(self._lib.ising_update_edges(self._h, it, color))
 
     def sweep(self, n: int = 1):
         check(self._lib.ising_sweep(self._h, self.it + 1, n))

@@ -5,13 +5,13 @@ This replaces the reference's multi-GPU mechanism (one managed allocation, peer 
 each slab and a cudaDeviceSynchronize on every device after each colour -- optimized/main.cu:1599-1658,
 loadTile :413-428, barriers :1779-1784/:1800-1805) with the MI355X-native form: one process per GPU, explicit
 RCCL send/recv of one colour row (X/4 bytes) to each ring neighbour over xGMI, issued right after the two
-boundary strips of a colour are updated and hidden behind the interior strips' kernel:
+edge rows of a colour are updated and hidden behind the interior rows' kernel:
 
     for colour in (black, white):                      # it = sweep index + 1, as the reference
         wait for the halo rows of the OTHER colour      (posted one half-sweep ago)
-        update boundary strips 0 and n-1 of `colour`    (they read the other colour's halo rows)
+        update edge rows 0 and Y-1 of `colour`          (one tiny launch; they read the other colour's halo rows)
         post send/recv of `colour` rows 0 and Y-1       (torch.distributed P2P = RCCL; runs on its own stream)
-        update interior strips 1..n-2 of `colour`       (overlaps with the exchange)
+        update interior rows 1..Y-2 of `colour`         (overlaps with the exchange)
 
 Results do not depend on the decomposition: the Philox stream id uses the global row (optimized/main.cu:514).
 
@@ -29,10 +29,10 @@ from ._lib import BLACK, WHITE
 
 
 class SlabBackend(Protocol):
-    nstrips: int
-
     def init(self) -> None: ...
-    def update_strips(self, it: int, color: int, strip_lo: int, strip_hi: int) -> None: ...
+    def update_all(self, it: int, color: int) -> None: ...
+    def update_edges(self, it: int, color: int) -> None: ...      # rows 0 and Y-1
+    def update_interior(self, it: int, color: int) -> None: ...   # rows 1 .. Y-2
     def halo_tensors(self, color: int):
         """-> (send_top, send_bot, recv_top, recv_bot): 1-D uint8 tensors of one colour row each."""
     def count_up_down(self): ...
@@ -51,7 +51,6 @@ class HipSlabBackend:
 
     def __init__(self, slab):
         self.slab = slab
-        self.nstrips = slab.nstrips
         self.device = torch.device("cuda", slab.cfg.device)
         slab.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self._halo = {}
@@ -63,8 +62,14 @@ class HipSlabBackend:
     def init(self):
         self.slab.init()
 
-    def update_strips(self, it, color, strip_lo, strip_hi):
-        self.slab.update_color(it, color, strip_lo, strip_hi)
+    def update_all(self, it, color):
+        self.slab.update_color(it, color)
+
+    def update_edges(self, it, color):
+        self.slab.update_edges(it, color)
+
+    def update_interior(self, it, color):
+        self.slab.update_color(it, color, 1, self.slab.Y - 1)
 
     def halo_tensors(self, color):
         return self._halo[color]
@@ -119,19 +124,13 @@ class SlabRing:
         return self
 
     def _half_sweep(self, it: int, color: int):
-        n = self.b.nstrips
         if self.world == 1:
-            self.b.update_strips(it, color, 0, n)
+            self.b.update_all(it, color)
             return
         self._wait(1 - color)
-        if n >= 3:
-            self.b.update_strips(it, color, 0, 1)
-            self.b.update_strips(it, color, n - 1, n)
-            self._post(color)
-            self.b.update_strips(it, color, 1, n - 1)
-        else:
-            self.b.update_strips(it, color, 0, n)
-            self._post(color)
+        self.b.update_edges(it, color)
+        self._post(color)
+        self.b.update_interior(it, color)
 
     def sweep(self, nsweeps: int = 1):
         for _ in range(nsweeps):
@@ -201,20 +200,13 @@ class LocalRing:
             self.it += 1
             for color in (BLACK, WHITE):
                 if self.n == 1:
-                    self.b[0].update_strips(self.it, color, 0, self.b[0].nstrips)
+                    self.b[0].update_all(self.it, color)
                     continue
                 for b in self.b:
-                    n = b.nstrips
-                    if n >= 3:
-                        b.update_strips(self.it, color, 0, 1)
-                        b.update_strips(self.it, color, n - 1, n)
-                    else:
-                        b.update_strips(self.it, color, 0, n)
+                    b.update_edges(self.it, color)
                 self._exchange(color)
                 for b in self.b:
-                    n = b.nstrips
-                    if n >= 3:
-                        b.update_strips(self.it, color, 1, n - 1)
+                    b.update_interior(self.it, color)
         return self
 
     def count(self):

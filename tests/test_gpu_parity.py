@@ -90,3 +90,19 @@ def test_temperature_ramp(gpu, oracle_mod):
             s.set_temperature(float(t))
             orc.temp = float(t)
         _compare(s, orc, "ramp")
+
+
+def test_row_range_partition_is_invariant(gpu, oracle_mod):
+    """ising_update_color over arbitrary row ranges (not multiples of the strip height) + ising_update_edges must
+    equal one full launch: rows of one colour are independent (each launch only reads the other colour)."""
+    X, Y, seed, temp = 4096, 80, 31337, 2.1
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=temp).init().sweep(3)
+    with ig.IsingSlab(X, Y, seed=seed, temp=temp, strip_rows=16) as s:
+        s.init()
+        for it in (1, 2, 3):
+            for color in (ig.BLACK, ig.WHITE):
+                s.update_edges(it, color)
+                for lo, hi in ((1, 7), (7, 8), (8, 45), (45, 79)):
+                    s.update_color(it, color, lo, hi)
+        s.it = 3
+        _compare(s, orc, "row-range partition")

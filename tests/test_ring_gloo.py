@@ -12,16 +12,14 @@ import torch.multiprocessing as mp
 import oracle
 from ising_gpu_amd.ring import SlabRing
 
-X, YTOT, SEED, TEMP, SWEEPS, STRIP = 2048, 96, 77, 2.1, 3, 8
+X, YTOT, SEED, TEMP, SWEEPS = 2048, 96, 77, 2.1, 3
 
 
 class OracleBackend:
     """Adapts oracle.OracleSlab (test infrastructure) to the SlabBackend protocol of the product's ring."""
 
-    def __init__(self, slab, strip_rows):
+    def __init__(self, slab):
         self.s = slab
-        self.strip = strip_rows
-        self.nstrips = slab.Y // strip_rows
         self._t = {}
         for c in (0, 1):
             self._t[c] = (torch.from_numpy(slab.lat[c, 0].view(np.uint8)), torch.from_numpy(slab.lat[c, -1].view(np.uint8)),
@@ -30,8 +28,15 @@ class OracleBackend:
     def init(self):
         self.s.init()
 
-    def update_strips(self, it, color, lo, hi):
-        self.s.update_rows(it, color, lo * self.strip, hi * self.strip)
+    def update_all(self, it, color):
+        self.s.update_rows(it, color, 0, self.s.Y)
+
+    def update_edges(self, it, color):
+        self.s.update_rows(it, color, 0, 1)
+        self.s.update_rows(it, color, self.s.Y - 1, self.s.Y)
+
+    def update_interior(self, it, color):
+        self.s.update_rows(it, color, 1, self.s.Y - 1)
 
     def halo_tensors(self, color):
         return self._t[color]
@@ -50,7 +55,7 @@ def _worker(rank, world, port, q):
     oracle.set_threads(1)
     try:
         slab = oracle.OracleSlab(X, YTOT // world, SEED, TEMP, world, rank)
-        ring = SlabRing(OracleBackend(slab, STRIP)).init()
+        ring = SlabRing(OracleBackend(slab)).init()
         ring.sweep(SWEEPS)
         up, down = ring.count()
         bond = ring.bond_equal()
