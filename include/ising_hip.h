@@ -63,6 +63,10 @@ typedef struct ising_config {
 	int32_t device;   /* HIP device ordinal that holds this slab */
 	int32_t strip_rows; /* rows each thread marches per launch; 0 = choose automatically */
 	int32_t kernel;   /* ISING_KERNEL_* */
+	int32_t XSL;      /* --xsl: sub-lattice columns (multiple of 2048 dividing X); 0 = no sub-lattices */
+	int32_t YSL;      /* --ysl: sub-lattice rows (multiple of 16 dividing Y).  With sub-lattices every XSL x YSL block of
+	                     the slab is an independent periodic system (optimized/main.cu:1423-1462; loadTile wrap arguments
+	                     slX, slY :413-459), so no halo exchange is needed. */
 } ising_config;
 
 const char *ising_last_error(void);

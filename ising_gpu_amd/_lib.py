@@ -21,7 +21,7 @@ class IsingConfig(C.Structure):
     _fields_ = [
         ("X", C.c_int32), ("Y", C.c_int32), ("nslabs", C.c_int32), ("slab", C.c_int32),
         ("seed", C.c_uint64), ("temp", C.c_float), ("device", C.c_int32),
-        ("strip_rows", C.c_int32), ("kernel", C.c_int32),
+        ("strip_rows", C.c_int32), ("kernel", C.c_int32), ("XSL", C.c_int32), ("YSL", C.c_int32),
     ]
 
 

@@ -4,7 +4,8 @@
 // Supported: -x -y -n/--nit -s/--seed -d/--devs -a/--alpha -t/--temp -p/--print -e/--exppr -m/--magn -u/--update
 //            -o/--out -h, plus --energy (build-side addition: prints the energy per spin next to each
 //            magnetisation line) and --devmap a,b,.. (place slab k on device devmap[k]; lets a 1-GPU box run -d N).
-// Not yet supported (exit with a message): -c/--corr, -J, --xsl/--ysl  (SURVEY 8f rows 3-4).
+//            --xsl/--ysl (independent periodic sub-lattices, optimized/main.cu:1423-1462).
+// Not yet supported (exit with a message): -c/--corr, -J  (SURVEY 8f rows 3-4).
 #include "../../include/ising_hip.h"
 
 #include <getopt.h>
@@ -55,8 +56,10 @@ void usage(const char *pname) {
 	        "\t-o|--out               dump the lattice whenever the magnetization is printed\n"
 	        "\t   --energy            also print the energy per spin (not in the reference)\n"
 	        "\t   --devmap <a,b,...>  device ordinal of each slab (default 0..NUM_DEVS-1)\n"
-	        "\t-c|--corr, -J, --xsl, --ysl: not supported by this build\n\n",
-	        bname, X_MULT, Y_MULT, NUMIT_DEF, (unsigned long long)ISING_SEED_DEF, ALPHA_DEF, ALPHA_DEF * ISING_CRIT_TEMP);
+	        "\t   --xsl <HORIZ_SUB_DIM> horizontal sub-lattice dimension (divisor of -x, multiple of %d)\n"
+	        "\t   --ysl <VERT_SUB_DIM>  vertical sub-lattice dimension (divisor of -y, multiple of %d)\n"
+	        "\t-c|--corr, -J: not supported by this build\n\n",
+	        bname, X_MULT, Y_MULT, NUMIT_DEF, (unsigned long long)ISING_SEED_DEF, ALPHA_DEF, ALPHA_DEF * ISING_CRIT_TEMP, X_MULT, Y_MULT);
 	exit(EXIT_SUCCESS);
 }
 
@@ -109,6 +112,7 @@ int main(int argc, char **argv) {
 	int tempUpdFreq = 0, printFreq = 0, printExp = 0, printExpCur = 0, printEnergy = 0;
 	unsigned long long printExpSteps[MAX_EXP_TIME];
 	double tgtMagn = -1.0;
+	int useSubLatt = 0, XSL = 0, YSL = 0, NSLX = 1, NSLY = 1;
 	std::vector<int> devmap;
 
 	static struct option long_options[] = {
@@ -151,8 +155,8 @@ int main(int argc, char **argv) {
 		case 'm': tgtMagn = atof(optarg); break;
 		case 'c': fprintf(stderr, "-c/--corr (2-point correlations) is not supported by this build\n"); exit(EXIT_FAILURE);
 		case 'J': fprintf(stderr, "-J (random +-J couplings) is not supported by this build\n"); exit(EXIT_FAILURE);
-		case 1:
-		case 2: fprintf(stderr, "--xsl/--ysl (independent sub-lattices) are not supported by this build\n"); exit(EXIT_FAILURE);
+		case 1: useSubLatt = 1; XSL = atoi(optarg); break;
+		case 2: useSubLatt = 1; YSL = atoi(optarg); break;
 		case 3: printEnergy = 1; break;
 		case 4:
 			for (char *tok = strtok(optarg, ","); tok; tok = strtok(NULL, ",")) devmap.push_back(atoi(tok));
@@ -174,6 +178,22 @@ int main(int argc, char **argv) {
 	if (!Y || (Y % Y_MULT)) {
 		fprintf(stderr, "\nPlease specify a Y dim multiple of %d\n\n", Y_MULT);
 		usage(argv[0]);
+	}
+	if (useSubLatt) { // optimized/main.cu:1423-1457
+		if (!XSL || !YSL) {
+			if (!XSL) XSL = (YSL && !(YSL % X_MULT)) ? YSL : X_MULT;
+			if (!YSL) YSL = !(XSL % Y_MULT) ? XSL : Y_MULT;
+		}
+		if ((X % XSL) || !XSL || (XSL % 2) || ((XSL / 2) % (SPIN_X_WORD * 2 * 16 * 2))) {
+			fprintf(stderr, "\nPlease specify an X sub-lattice dim multiple of %d and divisor of %d\n\n", X_MULT, X);
+			usage(argv[0]);
+		}
+		if ((Y % YSL) || !YSL || (YSL % Y_MULT)) {
+			fprintf(stderr, "\nPlease specify a Y sub-lattice dim multiple of %d divisor of %d\n\n", Y_MULT, Y);
+			usage(argv[0]);
+		}
+		NSLX = X / XSL;
+		NSLY = Y / YSL;
 	}
 	if (temp == -1.0f) temp = (alpha == -1.0f) ? ALPHA_DEF * ISING_CRIT_TEMP : alpha * ISING_CRIT_TEMP; // :1465-1471
 	if (printExp && printFreq) printFreq = 0;
@@ -217,6 +237,12 @@ int main(int argc, char **argv) {
 	else printf("\ttemp update: %f / %d iterations\n", tempUpdStep, tempUpdFreq);
 	printf("\tnot using Hamiltonian buffer\n");
 	printf("\n");
+	if (useSubLatt) { // optimized/main.cu:1583-1588
+		printf("\tusing sub-lattices:\n");
+		printf("\t\tno. of sub-lattices per GPU: %8d\n", NSLX * NSLY);
+		printf("\t\tno. of sub-lattices (total): %8d\n", ndev * NSLX * NSLY);
+		printf("\t\tsub-lattices size:           %7d x %7d\n\n", XSL, YSL);
+	}
 	printf("\tlocal lattice size:      %8d x %8d\n", Y, X);
 	printf("\ttotal lattice size:      %8d x %8d\n", ndev * Y, X);
 	printf("\tlocal lattice shape: 2 x %8d x %8zu (%12zu %s)\n", Y, lld, llenLoc * 2, "ulls");
@@ -230,6 +256,7 @@ int main(int argc, char **argv) {
 		memset(&cfg, 0, sizeof(cfg));
 		cfg.X = X; cfg.Y = Y; cfg.nslabs = ndev; cfg.slab = i; cfg.seed = seed; cfg.temp = temp; cfg.device = devmap[i];
 		cfg.strip_rows = 0; cfg.kernel = ISING_KERNEL_AUTO;
+		cfg.XSL = useSubLatt ? XSL : 0; cfg.YSL = useSubLatt ? YSL : 0;
 		ising_ctx *c = nullptr;
 		CHECK(ising_create(&cfg, &c));
 		ring.ctx.push_back(c);

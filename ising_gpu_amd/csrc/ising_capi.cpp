@@ -176,6 +176,13 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (cfg->Y <= 0 || (cfg->Y % 16)) return fail(ISING_E_ARG, "Please specify a Y dim multiple of 16 (got %d)", cfg->Y);
 	if (cfg->nslabs < 1 || cfg->slab < 0 || cfg->slab >= cfg->nslabs) return fail(ISING_E_ARG, "bad slab %d of %d", cfg->slab, cfg->nslabs);
 	if ((long long)cfg->Y * cfg->nslabs >= (1LL << 31)) return fail(ISING_E_ARG, "total rows must be < 2^31");
+	if ((cfg->XSL != 0) != (cfg->YSL != 0)) return fail(ISING_E_ARG, "XSL and YSL must be given together");
+	if (cfg->XSL) { // optimized/main.cu:1440-1453
+		if (cfg->XSL < 0 || (cfg->X % cfg->XSL) || (cfg->XSL % 2048))
+			return fail(ISING_E_ARG, "Please specify an X sub-lattice dim multiple of 2048 and divisor of %d", cfg->X);
+		if (cfg->YSL < 0 || (cfg->Y % cfg->YSL) || (cfg->YSL % 16))
+			return fail(ISING_E_ARG, "Please specify a Y sub-lattice dim multiple of 16 divisor of %d", cfg->Y);
+	}
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(ISING_E_NOGPU, "no HIP device visible");
 	if (cfg->device < 0 || cfg->device >= ndev) return fail(ISING_E_ARG, "device %d out of range (%d visible)", cfg->device, ndev);
@@ -297,6 +304,8 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	p.gx = c->gx;
 	p.Y = c->cfg.Y;
 	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
+	p.slV = c->cfg.XSL ? c->cfg.XSL / 64 : c->gx * 32; // (XSL/2)/SPIN_X_WORD/2, optimized/main.cu:1771
+	p.slY = c->cfg.XSL ? c->cfg.YSL : 0;
 	p.H = c->H;
 	p.row_lo[0] = lo0; p.row_hi[0] = hi0;
 	p.row_lo[1] = lo1; p.row_hi[1] = hi1;
@@ -385,6 +394,8 @@ int ising_bond_equal(ising_ctx *c, int64_t *A) {
 	p.gx = c->gx;
 	p.Y = c->cfg.Y;
 	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
+	p.slV = c->cfg.XSL ? c->cfg.XSL / 64 : c->gx * 32;
+	p.slY = c->cfg.XSL ? c->cfg.YSL : 0;
 	p.acc = c->d_acc + 1;
 	HIP_TRY(hipMemsetAsync(c->d_acc + 1, 0, sizeof(unsigned long long), c->stream));
 	HIP_TRY(ising::launch_bond_equal(p, c->stream));
@@ -497,6 +508,7 @@ static int ring_events(ising_ctx *c) {
 // copies out slab k's first/last row of `color` and records ev_sent[color] on its stream
 static int ring_send(ising_ctx **ctxs, int n, int k, int color) {
 	ising_ctx *c = ctxs[k], *prev = ctxs[(k + n - 1) % n], *next = ctxs[(k + 1) % n];
+	if (c->cfg.XSL) return ISING_OK; // sub-lattices never reach across slabs
 	const size_t nb = (size_t)c->lld * sizeof(uint64_t);
 	if (int rc = ring_events(c)) return rc;
 	ring_enable_peers(c, prev, next);

@@ -21,6 +21,8 @@ struct UpdateParams {
 	int32_t gx;               // X/2048: 32-vector column groups per row (= reference gridDim.x)
 	int32_t Y;                // rows in this slab
 	uint32_t row_base;        // global row of slab row 0 (slab*Y)
+	int32_t slV;              // periodic extent in X in 128-bit vectors (= gx*32 without sub-lattices)
+	int32_t slY;              // periodic extent in Y in rows; 0 = no sub-lattices (rows -1 / Y are the halo rows)
 	int32_t H;                // rows each lane marches (a "strip"; the last strip of a range may be shorter)
 	int32_t row_lo[2], row_hi[2]; // up to two row ranges per launch (the two edge rows of a slab go in one launch)
 	int32_t nunits0;          // units (column group x strip) of range 0
@@ -51,6 +53,7 @@ struct BondParams {
 	const uint64_t *black, *white; // row-0 pointers; white's rows -1 and Y (halo rows) must be current
 	int32_t gx, Y;
 	uint32_t row_base;
+	int32_t slV, slY; // as in UpdateParams
 	unsigned long long *acc;
 };
 hipError_t launch_bond_equal(const BondParams &p, hipStream_t stream);

@@ -274,8 +274,15 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 	const int col0 = bx * 32 + tx;
 	// Side-neighbour carry dwords, as dword offsets from this lane's own vector in the same row, with the periodic
 	// wrap of loadTile (optimized/main.cu:433,:441): dword 3 of the vector to the left / dword 0 of the one to the right.
-	const int offL0 = (col0 == 0 ? vecs - 1 : -1) * 4 + 3, offL1 = 15 * 4 + 3;
-	const int offR0 = 4, offR1 = (col0 + GROUP + 1 == vecs ? 1 - vecs + GROUP : GROUP + 1) * 4;
+	// With sub-lattices (--xsl) the wrap happens every slV vectors instead of once per row.
+	const int slV = p.slV;
+	const int offL0 = ((col0 % slV) == 0 ? slV - 1 : -1) * 4 + 3, offL1 = 15 * 4 + 3;
+	const int offR0 = 4, offR1 = (((col0 + GROUP + 1) % slV) == 0 ? 1 - slV + GROUP : GROUP + 1) * 4;
+	// Row wrap: without sub-lattices rows -1 and Y are the physical halo rows; with them (--ysl) the row above the
+	// first row of a sub-lattice is its last row and vice versa (loadTile, optimized/main.cu:414,:422).
+	const int slY = p.slY;
+	auto up_off = [&](int row) -> ptrdiff_t { return (slY && (row % slY) == 0) ? (ptrdiff_t)(slY - 1) * vecs : -(ptrdiff_t)vecs; };
+	auto dw_off = [&](int row) -> ptrdiff_t { return (slY && ((row + 1) % slY) == 0) ? (ptrdiff_t)(1 - slY) * vecs : (ptrdiff_t)vecs; };
 
 	// Rows -1 and Y of every colour array are physically present (halo rows), so row r lives at src + r*vecs.
 	const uint4 *pc = reinterpret_cast<const uint4 *>(p.src) + ((ptrdiff_t)r0 * vecs + col0); // centre row, own vector
@@ -292,7 +299,8 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 #define DBG_LD(expr) (expr)
 #define DBG_LDW(expr) (expr)
 #endif
-	uint4 up0 = DBG_LD(pc[-vecs]), up1 = DBG_LD(pc[GROUP - vecs]);
+	const ptrdiff_t uo = up_off(r0);
+	uint4 up0 = DBG_LD(pc[uo]), up1 = DBG_LD(pc[uo + GROUP]);
 	uint4 ct0 = DBG_LD(pc[0]), ct1 = DBG_LD(pc[GROUP]);
 
 	for (int r = 0; r < nrows; ++r) {
@@ -300,7 +308,8 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 		const uint32_t grow = p.row_base + (uint32_t)lr;
 		const bool back = (p.color == 0) ? !(grow & 1u) : (grow & 1u); // readBack, optimized/main.cu:542
 		// issue this row's loads; they are consumed only after the 16 Philox blocks below
-		const uint4 dw0 = DBG_LD(pc[vecs]), dw1 = DBG_LD(pc[vecs + GROUP]);
+		const ptrdiff_t dwo = dw_off(lr);
+		const uint4 dw0 = DBG_LD(pc[dwo]), dw1 = DBG_LD(pc[dwo + GROUP]);
 		const uint32_t *pcw = reinterpret_cast<const uint32_t *>(pc);
 		const uint32_t side0 = DBG_LDW(pcw[back ? offL0 : offR0]);
 		const uint32_t side1 = DBG_LDW(pcw[back ? offL1 : offR1]);
@@ -390,10 +399,19 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 			if (lr == 0) { pm[wrap_bot] = me0; pm[wrap_bot + GROUP] = me1; }
 			if (lr == p.Y - 1) { pm[-wrap_bot] = me0; pm[-wrap_bot + GROUP] = me1; }
 		}
-		up0 = ct0; up1 = ct1;
-		ct0 = dw0; ct1 = dw1;
 		pc += vecs;
 		pm += vecs;
+		if (slY && ((lr + 1) % slY) == 0) {
+			// the next row opens a new sub-lattice: the register window does not slide across the seam
+			if (r + 1 < nrows) {
+				const ptrdiff_t uo2 = (ptrdiff_t)(slY - 1) * vecs;
+				up0 = pc[uo2]; up1 = pc[uo2 + GROUP];
+				ct0 = pc[0]; ct1 = pc[GROUP];
+			}
+		} else {
+			up0 = ct0; up1 = ct1;
+			ct0 = dw0; ct1 = dw1;
+		}
 	}
 }
 
@@ -472,11 +490,14 @@ __global__ void __launch_bounds__(THREADS) bond_equal_k(const BondParams p) {
 		const uint32_t grow = p.row_base + (uint32_t)lr;
 		const bool back = !(grow & 1u); // black sites
 		const uint4 *pc = white + (ptrdiff_t)lr * vecs; // rows -1 and Y are the halo rows
-		const int colL = col == 0 ? vecs - 1 : col - 1, colR = (col + 1 == vecs) ? 0 : col + 1;
+		const int slV = p.slV, slY = p.slY;
+		const int colL = (col % slV) == 0 ? col + slV - 1 : col - 1, colR = ((col + 1) % slV) == 0 ? col + 1 - slV : col + 1;
+		const ptrdiff_t uo = (slY && (lr % slY) == 0) ? (ptrdiff_t)(slY - 1) * vecs : -(ptrdiff_t)vecs;
+		const ptrdiff_t dwo = (slY && ((lr + 1) % slY) == 0) ? (ptrdiff_t)(1 - slY) * vecs : (ptrdiff_t)vecs;
 		const uint32_t *pcw = reinterpret_cast<const uint32_t *>(pc);
 		const uint32_t side = back ? pcw[4 * colL + 3] : pcw[4 * colR];
 		uint32_t S[4];
-		neighbour_sums(pc[col - vecs], pc[col], pc[col + vecs], side, back, S);
+		neighbour_sums(pc[col + uo], pc[col], pc[col + dwo], side, back, S);
 		const uint4 me = black[i];
 		const uint32_t mv[4] = {me.x, me.y, me.z, me.w};
 #pragma unroll

@@ -25,10 +25,11 @@ class IsingSlab:
     """One slab (rows [slab*Y, (slab+1)*Y) of an (nslabs*Y) x X periodic lattice) resident on one GPU."""
 
     def __init__(self, X: int, Y: int, seed: int = _lib.SEED_DEF, temp: float = 0.1 * _lib.CRIT_TEMP_F32,
-                 nslabs: int = 1, slab: int = 0, device: int = 0, strip_rows: int = 0, kernel: int = _lib.KERNEL_AUTO):
+                 nslabs: int = 1, slab: int = 0, device: int = 0, strip_rows: int = 0, kernel: int = _lib.KERNEL_AUTO,
+                 XSL: int = 0, YSL: int = 0):
         self._lib = _lib.load()
         self.cfg = IsingConfig(X=X, Y=Y, nslabs=nslabs, slab=slab, seed=seed, temp=float(np.float32(temp)),
-                               device=device, strip_rows=strip_rows, kernel=kernel)
+                               device=device, strip_rows=strip_rows, kernel=kernel, XSL=XSL, YSL=YSL)
         self._h = C.c_void_p()
         check(self._lib.ising_create(C.byref(self.cfg), C.byref(self._h)))
         self.X, self.Y, self.nslabs, self.slab = X, Y, nslabs, slab

@@ -83,3 +83,12 @@ def test_cli_ramp_and_exppr(gpu, oracle_mod):
 def test_cli_rejects_bad_sizes_like_the_reference(gpu):
     r = subprocess.run([CLI, "-x", "1024", "-y", "1024"], capture_output=True, text=True)
     assert "Please specify an X dim multiple of 2048" in r.stderr
+
+
+def test_cli_sublattices_transcript(gpu):
+    out = run(["-y", "32768", "-x", "65536", "-n", "16", "-p", "16", "-d", "2", "-t", "1.5", "--xsl", "2048", "--ysl", "2048", "--devmap", "0,0"])
+    assert "\tusing sub-lattices:\n" in out
+    assert "\t\tno. of sub-lattices per GPU:      512\n" in out
+    assert "\t\tno. of sub-lattices (total):     1024\n" in out
+    assert "\t\tsub-lattices size:              2048 x    2048\n" in out
+    assert "        magnetization:  0.000052, up_s:   2147594634, dw_s:   2147372662 (iter:       16)\n" in out  # README.md:188

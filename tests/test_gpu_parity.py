@@ -106,3 +106,31 @@ def test_row_range_partition_is_invariant(gpu, oracle_mod):
                     s.update_color(it, color, lo, hi)
         s.it = 3
         _compare(s, orc, "row-range partition")
+
+
+@pytest.mark.parametrize("X,Y,XSL,YSL,strip", [(4096, 64, 2048, 16, 0), (4096, 96, 2048, 32, 16), (6144, 48, 2048, 48, 0), (4096, 64, 4096, 16, 8)])
+def test_sublattices_bit_exact(gpu, oracle_mod, X, Y, XSL, YSL, strip):
+    """--xsl/--ysl: every XSL x YSL block is an independent torus (loadTile wrap arguments, optimized/main.cu:413-459)."""
+    orc = oracle_mod.OracleLattice(X, Y, seed=8, temp=2.0, XSL=XSL, YSL=YSL).init()
+    with ig.IsingSlab(X, Y, seed=8, temp=2.0, XSL=XSL, YSL=YSL, strip_rows=strip) as s:
+        s.init()
+        for n in (1, 4):
+            s.sweep(n)
+            orc.sweep(n)
+            _compare(s, orc, f"sub-lattices {XSL}x{YSL} after {s.it}")
+            assert s.count() == orc.count()
+            assert s.bond_equal() == orc.bond_equal()
+
+
+def test_readme_sublattice_transcript_65536(gpu):
+    """optimized/README.md:148-196: '-y 32768 -x 65536 -d 2 -t 1.5 --xsl 2048 --ysl 2048' (1024 replicas); counts are
+    decomposition independent, so one 65536-row slab must print the same numbers."""
+    with ig.IsingSlab(65536, 65536, seed=ig.SEED_DEF, temp=1.5, XSL=2048, YSL=2048) as s:
+        s.init()
+        assert s.count() == (2147484090, 2147483206)
+        s.sweep(16)
+        assert s.count() == (2147594634, 2147372662)   # README.md:188
+        s.sweep(16)
+        assert s.count() == (2147631783, 2147335513)   # README.md:189
+        s.sweep(96)
+        assert s.count() == (2147461873, 2147505423)   # README.md:195-196 (iter 128)
