@@ -158,6 +158,14 @@ int ising_ring_sweep(ising_ctx **ctxs, int n, int first_it, int nsweeps);
 /* Blocks until every slab's stream is idle. */
 int ising_ring_synchronize(ising_ctx **ctxs, int n);
 
+/* Two-point correlations, getCorr2D_k + computeCorr (optimized/main.cu:870-965, :1072-1138): for j = 1..ncorr
+ * (ncorr <= 128 = MAX_CORR_LEN, :70)  sums[j-1] = sum over all sites of [s(r,c)==s(r,c+j) ? +1 : -1] +
+ * [s(r,c)==s(r+j,c) ? +1 : -1], columns periodic in X, rows periodic in the whole lattice.  These are the exact
+ * integers the reference accumulates in doubles; it then prints sums[j-1] / (2*X*Y*ndev) (:1131).  Each slab needs
+ * at least ncorr rows.  Not available with sub-lattices (the reference uses a different kernel there).  Blocking. */
+int ising_correlations(ising_ctx *ctx, int ncorr, int64_t *sums);            /* nslabs == 1 */
+int ising_ring_correlations(ising_ctx **ctxs, int n, int ncorr, int64_t *sums); /* totals over all slabs of a ring */
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,8 @@ PROTOTYPES = {
     "ising_ring_exchange": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "ising_ring_sweep": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
     "ising_ring_synchronize": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "ising_correlations": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
+    "ising_ring_correlations": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_int64)]),
 }
 
 

@@ -4,8 +4,9 @@
 // Supported: -x -y -n/--nit -s/--seed -d/--devs -a/--alpha -t/--temp -p/--print -e/--exppr -m/--magn -u/--update
 //            -o/--out -h, plus --energy (build-side addition: prints the energy per spin next to each
 //            magnetisation line) and --devmap a,b,.. (place slab k on device devmap[k]; lets a 1-GPU box run -d N).
-//            --xsl/--ysl (independent periodic sub-lattices, optimized/main.cu:1423-1462).
-// Not yet supported (exit with a message): -c/--corr, -J  (SURVEY 8f rows 3-4).
+//            --xsl/--ysl (independent periodic sub-lattices, optimized/main.cu:1423-1462),
+//            -c/--corr (two-point correlations file, optimized/main.cu:1072-1138; not together with sub-lattices).
+// Not yet supported (exit with a message): -J  (SURVEY 8f row 4).
 #include "../../include/ising_hip.h"
 
 #include <getopt.h>
@@ -29,6 +30,7 @@ constexpr float MIN_TEMP = 0.05f * ISING_CRIT_TEMP; // optimized/main.cu:44
 constexpr double TGT_MAGN_MAX_DIFF = 1.0E-3;         // optimized/main.cu:65
 constexpr int MAX_EXP_TIME = 200, MIN_EXP_TIME = 152; // optimized/main.cu:67-68
 constexpr int NUMIT_DEF = 1;
+constexpr int MAX_CORR_LEN = 128;                     // optimized/main.cu:70
 
 [[noreturn]] void die(const char *what) {
 	fprintf(stderr, "%s: %s\n", what, ising_last_error());
@@ -58,7 +60,8 @@ void usage(const char *pname) {
 	        "\t   --devmap <a,b,...>  device ordinal of each slab (default 0..NUM_DEVS-1)\n"
 	        "\t   --xsl <HORIZ_SUB_DIM> horizontal sub-lattice dimension (divisor of -x, multiple of %d)\n"
 	        "\t   --ysl <VERT_SUB_DIM>  vertical sub-lattice dimension (divisor of -y, multiple of %d)\n"
-	        "\t-c|--corr, -J: not supported by this build\n\n",
+	        "\t-c|--corr              append the 128 two-point correlations to corr_{Y}x{X}_T_{TEMP}_{SEED} at every print\n"
+	        "\t-J: not supported by this build\n\n",
 	        bname, X_MULT, Y_MULT, NUMIT_DEF, (unsigned long long)ISING_SEED_DEF, ALPHA_DEF, ALPHA_DEF * ISING_CRIT_TEMP, X_MULT, Y_MULT);
 	exit(EXIT_SUCCESS);
 }
@@ -113,6 +116,8 @@ int main(int argc, char **argv) {
 	unsigned long long printExpSteps[MAX_EXP_TIME];
 	double tgtMagn = -1.0;
 	int useSubLatt = 0, XSL = 0, YSL = 0, NSLX = 1, NSLY = 1;
+	int corrOut = 0;
+	char cname[256];
 	std::vector<int> devmap;
 
 	static struct option long_options[] = {
@@ -153,7 +158,7 @@ int main(int argc, char **argv) {
 			printf("tempUpdStep: %f, tempUpdFreq: %d\n", tempUpdStep, tempUpdFreq);
 		} break;
 		case 'm': tgtMagn = atof(optarg); break;
-		case 'c': fprintf(stderr, "-c/--corr (2-point correlations) is not supported by this build\n"); exit(EXIT_FAILURE);
+		case 'c': corrOut = 1; break;
 		case 'J': fprintf(stderr, "-J (random +-J couplings) is not supported by this build\n"); exit(EXIT_FAILURE);
 		case 1: useSubLatt = 1; XSL = atoi(optarg); break;
 		case 2: useSubLatt = 1; YSL = atoi(optarg); break;
@@ -263,6 +268,11 @@ int main(int argc, char **argv) {
 		if (ndev > 1) { printf("\tGPU %2d done\n", i); fflush(stdout); }
 	}
 
+	if (corrOut) { // optimized/main.cu:1660-1663
+		if (useSubLatt) { fprintf(stderr, "-c together with --xsl/--ysl is not supported by this build\n"); exit(EXIT_FAILURE); }
+		snprintf(cname, sizeof(cname), "corr_%dx%d_T_%f_%llu", Y, X, temp, seed);
+		remove(cname);
+	}
 	for (ising_ctx *c : ring.ctx) CHECK(ising_init_lattice(c));
 	if (ndev > 1) {
 		CHECK(ising_ring_exchange(ring.ctx.data(), ndev, ISING_BLACK));
@@ -283,6 +293,16 @@ int main(int argc, char **argv) {
 		if (exp_style) printf("        magnetization: %9.6lf (^2: %9.6lf), up_s: %12llu, dw_s: %12llu (iter: %8d)\n", magn, magn * magn, cntPos, cntNeg, iter);
 		else printf("        magnetization: %9.6lf, up_s: %12llu, dw_s: %12llu (iter: %8d)\n", magn, cntPos, cntNeg, iter);
 		if (printEnergy) printf("        energy/spin:   %9.6lf (iter: %8d)\n", ring.energy(nspins), iter);
+		if (corrOut) { // computeCorr, optimized/main.cu:1072-1138
+			int64_t sums[MAX_CORR_LEN];
+			CHECK(ising_ring_correlations(ring.ctx.data(), ndev, MAX_CORR_LEN, sums));
+			FILE *fp = fopen(cname, "a");
+			if (!fp) { fprintf(stderr, "cannot open %s\n", cname); exit(EXIT_FAILURE); }
+			fprintf(fp, "%10d", iter);
+			for (int i = 0; i < MAX_CORR_LEN; i++) fprintf(fp, " % -12G", (double)sums[i] / (2.0 * X * Y * ndev));
+			fprintf(fp, "\n");
+			fclose(fp);
+		}
 		if (dumpOut) {
 			char fname[256];
 			snprintf(fname, sizeof(fname), "lattice_%dx%d_T_%f_IT_%08d_", Y, X, temp, iter);

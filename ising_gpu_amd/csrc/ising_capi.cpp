@@ -63,6 +63,9 @@ struct ising_ctx {
 	size_t color_words = 0;
 	uint64_t *d_lat = nullptr;          // [2 colours][Y + 2 rows][lld]: row -1 and row Y of each colour are halo rows
 	unsigned long long *d_acc = nullptr; // 2 counters
+	uint32_t *d_bits = nullptr;          // correlations: (Y + d_bits_extra) x lld words, one bit per spin
+	int d_bits_extra = 0;
+	long long *d_corr = nullptr;         // correlations: 128 sums
 	uint8_t *d_lut = nullptr;            // 64 KiB accept-rank table (see build_rank_table)
 	bool lut_dirty = true;
 	float tab[10]{};
@@ -217,6 +220,8 @@ int ising_destroy(ising_ctx *c) {
 	if (c->d_lat) (void)hipFree(c->d_lat);
 	if (c->d_acc) (void)hipFree(c->d_acc);
 	if (c->d_lut) (void)hipFree(c->d_lut);
+	if (c->d_bits) (void)hipFree(c->d_bits);
+	if (c->d_corr) (void)hipFree(c->d_corr);
 	for (int k = 0; k < 2; k++) if (c->ev_sent[k]) (void)hipEventDestroy(c->ev_sent[k]);
 	delete c;
 	return ISING_OK;
@@ -558,6 +563,53 @@ int ising_ring_synchronize(ising_ctx **ctxs, int n) {
 	if (int rc = ring_check(ctxs, n)) return rc;
 	for (int k = 0; k < n; k++) if (int rc = ising_synchronize(ctxs[k])) return rc;
 	return ISING_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ correlations
+int ising_ring_correlations(ising_ctx **ctxs, int n, int ncorr, int64_t *sums) {
+	if (int rc = ring_check(ctxs, n)) return rc;
+	if (!sums || ncorr < 1 || ncorr > 128) return fail(ISING_E_ARG, "ncorr must be in [1,128]");
+	for (int k = 0; k < n; k++) {
+		ising_ctx *c = ctxs[k];
+		if (c->cfg.XSL) return fail(ISING_E_STATE, "correlations with sub-lattices are not supported");
+		if (c->cfg.Y < ncorr) return fail(ISING_E_ARG, "each slab needs at least %d rows for %d correlation distances", ncorr, ncorr);
+		if (int rc = bind(c)) return rc;
+		if (!c->d_bits || c->d_bits_extra < ncorr) {
+			if (c->d_bits) HIP_TRY(hipFree(c->d_bits));
+			c->d_bits = nullptr;
+			HIP_TRY(hipMalloc((void **)&c->d_bits, (size_t)(c->cfg.Y + 128) * c->lld * sizeof(uint32_t)));
+			c->d_bits_extra = 128;
+		}
+		if (!c->d_corr) HIP_TRY(hipMalloc((void **)&c->d_corr, 128 * sizeof(long long)));
+		HIP_TRY(ising::launch_pack_bits(c->lat(ISING_BLACK), c->lat(ISING_WHITE), c->lld, c->cfg.Y,
+		                                (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y, c->d_bits, c->stream));
+		HIP_TRY(hipMemsetAsync(c->d_corr, 0, 128 * sizeof(long long), c->stream));
+	}
+	for (int k = 0; k < n; k++) if (int rc = ising_synchronize(ctxs[k])) return rc;
+	// rows that follow slab k (vertical partners of its last ncorr rows): the first ncorr bit-rows of slab k+1
+	for (int k = 0; k < n; k++) {
+		ising_ctx *c = ctxs[k], *next = ctxs[(k + 1) % n];
+		if (int rc = bind(c)) return rc;
+		HIP_TRY(hipMemcpyPeerAsync(c->d_bits + (size_t)c->cfg.Y * c->lld, c->cfg.device, next->d_bits, next->cfg.device,
+		                           (size_t)ncorr * c->lld * sizeof(uint32_t), c->stream));
+		HIP_TRY(ising::launch_corr(c->d_bits, c->lld, c->cfg.Y, ncorr, c->d_corr, c->stream));
+	}
+	std::vector<long long> h(ncorr);
+	for (int j = 0; j < ncorr; j++) sums[j] = 0;
+	for (int k = 0; k < n; k++) {
+		ising_ctx *c = ctxs[k];
+		if (int rc = bind(c)) return rc;
+		HIP_TRY(hipMemcpyAsync(h.data(), c->d_corr, (size_t)ncorr * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		for (int j = 0; j < ncorr; j++) sums[j] += h[j];
+	}
+	return ISING_OK;
+}
+
+int ising_correlations(ising_ctx *c, int ncorr, int64_t *sums) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (c->cfg.nslabs != 1) return fail(ISING_E_STATE, "ising_correlations needs nslabs == 1; use ising_ring_correlations");
+	return ising_ring_correlations(&c, 1, ncorr, sums);
 }
 
 } // extern "C"

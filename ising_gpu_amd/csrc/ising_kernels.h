@@ -58,4 +58,10 @@ struct BondParams {
 };
 hipError_t launch_bond_equal(const BondParams &p, hipStream_t stream);
 
+// one-bit-per-spin image of a slab in lattice-column order: bits[Y][lld] 32-bit words
+hipError_t launch_pack_bits(const uint64_t *black, const uint64_t *white, int lld, int Y, uint32_t row_base, uint32_t *bits,
+                            hipStream_t stream);
+// two-point sums for distances 1..ncorr over slab rows 0..Y-1; `bits` must hold Y + ncorr rows
+hipError_t launch_corr(const uint32_t *bits, int lld, int Y, int ncorr, long long *sums, hipStream_t stream);
+
 } // namespace ising

@@ -519,9 +519,92 @@ __global__ void __launch_bounds__(THREADS) bond_equal_k(const BondParams p) {
 	}
 }
 
+// ---------------------------------------------------------------------------------------------- correlations
+// Replaces getCorr2D_k (optimized/main.cu:870-965).  The reference extracts two nibbles per (site, distance); here the
+// lattice is first compressed to one bit per spin in lattice-column order (X bits per row), after which one
+// 32-site comparison is an XOR + popcount: #equal - #unequal = 32 - 2*popc(a ^ b).
+
+// 16 nibble-spins of one packed 64-bit word -> 16 bits (bit k = spin of nibble k)
+__device__ __forceinline__ uint32_t nibbles_to_bits(uint64_t w) {
+	uint64_t x = w & 0x1111111111111111ull;
+	x = (x | (x >> 3)) & 0x0303030303030303ull;
+	x = (x | (x >> 6)) & 0x000F000F000F000Full;
+	x = (x | (x >> 12)) & 0x000000FF000000FFull;
+	x = (x | (x >> 24)) & 0xFFFFull;
+	return (uint32_t)x;
+}
+// 16 bits -> the even bit positions of a 32-bit word
+__device__ __forceinline__ uint32_t spread16(uint32_t x) {
+	x = (x | (x << 8)) & 0x00FF00FFu;
+	x = (x | (x << 4)) & 0x0F0F0F0Fu;
+	x = (x | (x << 2)) & 0x33333333u;
+	x = (x | (x << 1)) & 0x55555555u;
+	return x;
+}
+
+// bits[r][q] (q = 0..lld-1) holds lattice columns 32q..32q+31 of slab row r: column c is colour-site c/2 of the white
+// array when (global row ^ c) is odd, of the black array otherwise (optimized/main.cu:928-929, dumpLattice :1165-1172).
+__global__ void __launch_bounds__(THREADS) pack_bits_k(const uint64_t *__restrict__ black, const uint64_t *__restrict__ white,
+                                                       int lld, int Y, uint32_t row_base, uint32_t *__restrict__ bits) {
+	const size_t total = (size_t)lld * Y;
+	for (size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * THREADS) {
+		const uint32_t r = (uint32_t)(i / lld);
+		const uint32_t b = nibbles_to_bits(black[i]), w = nibbles_to_bits(white[i]);
+		const bool odd = (row_base + r) & 1u;
+		// even row: columns 2k -> black k, 2k+1 -> white k; odd row: the other way round
+		bits[i] = odd ? (spread16(w) | (spread16(b) << 1)) : (spread16(b) | (spread16(w) << 1));
+	}
+}
+
+// grid (row chunks, ncorr): block (y = j-1) accumulates over its rows
+//   sum_c [s(r,c) == s(r,c+j)] - [!=]  +  [s(r,c) == s(r+j,c)] - [!=]      (c periodic in X; rows r+j come from `bits`
+// rows up to Y+ncorr-1, which the host fills with the rows that follow this slab).
+__global__ void __launch_bounds__(THREADS) corr_k(const uint32_t *__restrict__ bits, int lld, int Y, int rows_per_block,
+                                                  long long *__restrict__ sums) {
+	__shared__ long long part[THREADS / 64];
+	const int j = blockIdx.y + 1;
+	const int wsh = j >> 5, bsh = j & 31;
+	const int r_lo = blockIdx.x * rows_per_block, r_hi = min(Y, r_lo + rows_per_block);
+	long long acc = 0;
+	for (int r = r_lo; r < r_hi; ++r) {
+		const uint32_t *row = bits + (size_t)r * lld, *rowv = bits + (size_t)(r + j) * lld;
+		for (int q = threadIdx.x; q < lld; q += THREADS) {
+			const uint32_t a = row[q];
+			int q0 = q + wsh; if (q0 >= lld) q0 -= lld;
+			int q1 = q0 + 1;  if (q1 >= lld) q1 -= lld;
+			const uint32_t h = bsh ? __builtin_amdgcn_alignbit(row[q1], row[q0], bsh) : row[q0]; // columns 32q+j .. 32q+j+31
+			acc += 64 - 2 * (int)(__popc(a ^ h) + __popc(a ^ rowv[q]));
+		}
+	}
+	acc = (long long)wave_sum((unsigned long long)acc);
+	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		long long t = 0;
+#pragma unroll
+		for (int i = 0; i < THREADS / 64; ++i) t += part[i];
+		atomicAdd(reinterpret_cast<unsigned long long *>(sums + (j - 1)), (unsigned long long)t);
+	}
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------------------------- launchers
+hipError_t launch_pack_bits(const uint64_t *black, const uint64_t *white, int lld, int Y, uint32_t row_base, uint32_t *bits,
+                            hipStream_t stream) {
+	size_t blocks = ((size_t)lld * Y + THREADS - 1) / THREADS;
+	if (blocks > 8192) blocks = 8192;
+	hipLaunchKernelGGL(pack_bits_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, black, white, lld, Y, row_base, bits);
+	return hipGetLastError();
+}
+
+hipError_t launch_corr(const uint32_t *bits, int lld, int Y, int ncorr, long long *sums, hipStream_t stream) {
+	const int rows_per_block = 16;
+	const dim3 grid((Y + rows_per_block - 1) / rows_per_block, ncorr);
+	hipLaunchKernelGGL(corr_k, grid, dim3(THREADS), 0, stream, bits, lld, Y, rows_per_block, sums);
+	return hipGetLastError();
+}
+
 hipError_t launch_update(const UpdateParams &p, int mode, hipStream_t stream) {
 	if (p.nunits <= 0) return hipSuccess;
 	const int per_block = threads_of(mode) / GROUP;

@@ -105,6 +105,12 @@ class IsingSlab:
         check(self._lib.ising_bond_equal(self._h, C.byref(a)))
         return int(a.value)
 
+    def correlations(self, ncorr: int = 128):
+        """Exact two-point sums for distances 1..ncorr (getCorr2D_k); divide by 2*X*Y for the reference's output."""
+        out = (C.c_int64 * ncorr)()
+        check(self._lib.ising_correlations(self._h, ncorr, out))
+        return [int(v) for v in out]
+
     def halo_ptrs(self, color: int):
         p = [C.c_void_p() for _ in range(4)]
         nb = C.c_size_t()
@@ -138,3 +144,12 @@ def magnetization(up: int, down: int) -> float:
 def energy_per_spin(bond_equal_total: int, nspins: int) -> float:
     """E/N = -(2A - 2N)/N with A the black-site aligned-neighbour count over the whole lattice."""
     return -(2 * bond_equal_total - 2 * nspins) / nspins
+
+
+def ring_correlations(slabs, ncorr: int = 128):
+    """Totals over all slabs of a single-process ring (ising_ring_correlations)."""
+    lib = _lib.load()
+    arr = (C.c_void_p * len(slabs))(*[s._h for s in slabs])
+    out = (C.c_int64 * ncorr)()
+    check(lib.ising_ring_correlations(arr, len(slabs), ncorr, out))
+    return [int(v) for v in out]

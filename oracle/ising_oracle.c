@@ -335,6 +335,35 @@ int64_t orc_bond_equal_slab(const uint64_t *black, const uint64_t *white, const 
 	return bond_rows(black, &v, &g);
 }
 
+/* ------------------------------------------------------------------ getCorr2D_k + computeCorr, optimized/main.cu:870-965, :1072-1138
+ * sums[j-1] = sum over all sites (row r, lattice column c) of  [s(r,c) == s(r,c+j) ? +1 : -1]  (columns periodic in X)
+ *                                                           + [s(r,c) == s(r+j,c) ? +1 : -1]  (rows periodic in Ytot)
+ * for j = 1..ncorr.  Lattice column c of row r is colour-site c/2 of the white array when (r ^ c) is odd, of the black
+ * array otherwise (:928-929).  The reference accumulates these +-1 in doubles (exact) and prints sums/(2*X*Y*ndev).
+ */
+static inline int spin_at(const uint64_t *black, const uint64_t *white, int64_t lld, int64_t r, int64_t c) {
+	const uint64_t *a = ((r ^ c) & 1) ? white : black;
+	const int64_t k = c >> 1;
+	return (int)((a[r*lld + k/NIB] >> (4*(k % NIB))) & 0xF);
+}
+
+void orc_corr(const uint64_t *black, const uint64_t *white, int64_t X, int64_t Ytot, int ncorr, int64_t *sums) {
+	const int64_t lld = X/32;
+	for (int j = 1; j <= ncorr; j++) {
+		int64_t acc = 0;
+		#pragma omp parallel for reduction(+:acc) schedule(static)
+		for (int64_t r = 0; r < Ytot; r++) {
+			const int64_t rv = (r + j) % Ytot;
+			for (int64_t c = 0; c < X; c++) {
+				const int me = spin_at(black, white, lld, r, c);
+				acc += (me == spin_at(black, white, lld, r, (c + j) % X)) ? 1 : -1;
+				acc += (me == spin_at(black, white, lld, rv, c)) ? 1 : -1;
+			}
+		}
+		sums[j - 1] = acc;
+	}
+}
+
 /* ------------------------------------------------------------------ dumpLattice text, optimized/main.cu:1140-1209
  * One text row per lattice row, one hex digit per spin, colours interleaved by row parity.
  * Writes rows [row0,row0+nrows) into buf (X chars + '\n' per row); returns bytes written.

@@ -50,6 +50,7 @@ def lib() -> C.CDLL:
         L.orc_bond_equal.restype = C.c_int64
         L.orc_dump_rows.argtypes = [u64p, u64p, C.c_int64, C.c_int64, C.c_int64, C.c_char_p]
         L.orc_dump_rows.restype = C.c_int64
+        L.orc_corr.argtypes = [u64p, u64p, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64)]
         L.orc_site_draw.argtypes = [C.c_int64, C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int]
         L.orc_site_draw.restype = C.c_uint32
         L.orc_init_slab.argtypes = [u64p, u64p, C.c_int64, C.c_int64, C.c_int64, C.c_uint64]
@@ -141,6 +142,11 @@ class OracleLattice:
     def energy_per_spin(self) -> float:
         n = self.X * self.Y
         return -(2 * self.bond_equal() - 2 * n) / n
+
+    def corr(self, ncorr: int = 128):
+        out = (C.c_int64 * ncorr)()
+        lib().orc_corr(_u64(self.black), _u64(self.white), self.X, self.Y, ncorr, out)
+        return [int(v) for v in out]
 
     def dump_rows(self, row0: int, nrows: int) -> bytes:
         buf = C.create_string_buffer(nrows * (self.X + 1))
