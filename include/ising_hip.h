@@ -30,6 +30,7 @@ extern "C" {
 
 #define ISING_BLACK 0  /* enum {C_BLACK, C_WHITE}, optimized/main.cu:80 */
 #define ISING_WHITE 1
+#define ISING_HAM_BLACK 2 /* the black coupling array (-J), as a third "colour" for ising_halo_ptrs / ising_ring_exchange */
 
 #define ISING_CRIT_TEMP 2.26918531421f /* CRIT_TEMP, optimized/main.cu:42 */
 #define ISING_SEED_DEF 463463564571ull /* SEED_DEF, optimized/main.cu:63 */
@@ -67,6 +68,8 @@ typedef struct ising_config {
 	int32_t YSL;      /* --ysl: sub-lattice rows (multiple of 16 dividing Y).  With sub-lattices every XSL x YSL block of
 	                     the slab is an independent periodic system (optimized/main.cu:1423-1462; loadTile wrap arguments
 	                     slX, slY :413-459), so no halo exchange is needed. */
+	int32_t use_J;    /* -J given: allocate coupling arrays and apply them in every update (useGenHamilt, :1368-1372) */
+	float J_prob;     /* -J <PROB>: probability that a bond is anti-ferromagnetic, clamped to [0,1] (:1370) */
 } ising_config;
 
 const char *ising_last_error(void);
@@ -89,6 +92,16 @@ int ising_synchronize(ising_ctx *ctx);
 
 /* latticeInit_k<BLACK> + latticeInit_k<WHITE> for this slab (optimized/main.cu:92-151, launches :1708-1726). */
 int ising_init_lattice(ising_ctx *ctx);
+
+/* -J: hamiltInitB_k (seed+1) for this slab, then hamiltInitW_k (optimized/main.cu:153-331, launches :1729-1742).
+ * ising_init_couplings does both and needs nslabs == 1.  With several slabs the white array needs the neighbours'
+ * black edge rows: call ..._black on every slab, deliver the ISING_HAM_BLACK halo rows (ising_halo_ptrs /
+ * ising_ring_exchange), then ..._white.  ising_ring_init_couplings does all of that for a single-process ring. */
+int ising_init_couplings(ising_ctx *ctx);
+int ising_init_couplings_black(ising_ctx *ctx);
+int ising_init_couplings_white(ising_ctx *ctx);
+/* Copies rows of a coupling array (which = ISING_BLACK / ISING_WHITE for hamB / hamW) to host memory. Blocking. */
+int ising_read_couplings(ising_ctx *ctx, int which, int64_t row0, int64_t nrows, uint64_t *dst_host);
 
 /* Recomputes the exp table / integer thresholds (optimized/main.cu:1684-1703, temperature ramp :1848-1859). */
 int ising_set_temperature(ising_ctx *ctx, float temp);
@@ -152,6 +165,8 @@ int ising_dump_text(ising_ctx *ctx, const char *prefix);
 
 /* Delivers colour `color`'s first/last rows of every slab into the neighbours' halo buffers (asynchronous). */
 int ising_ring_exchange(ising_ctx **ctxs, int n, int color);
+/* -J for a whole ring: black couplings on every slab, their edge rows to the neighbours, then the white couplings. */
+int ising_ring_init_couplings(ising_ctx **ctxs, int n);
 /* `nsweeps` full sweeps over all slabs, iterations first_it .. first_it+nsweeps-1: per colour, the two edge rows
  * first, then the halo copies, then the interior rows (which overlap with the copies).  Asynchronous. */
 int ising_ring_sweep(ising_ctx **ctxs, int n, int first_it, int nsweeps);

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ISING_LIB", os.path.join(_HERE, "libising_hip.so"))  # ISING_LIB: perf-investigation builds only
 
 BLACK, WHITE = 0, 1
+HAM_BLACK = 2  # the black coupling array as a third plane for halo exchange
 CRIT_TEMP_F32 = 2.2691853046417236  # float32(2.26918531421f), CRIT_TEMP optimized/main.cu:42
 SEED_DEF = 463463564571  # optimized/main.cu:63
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST, KERNEL_LUT = 0, 1, 2, 3
@@ -22,6 +23,7 @@ class IsingConfig(C.Structure):
         ("X", C.c_int32), ("Y", C.c_int32), ("nslabs", C.c_int32), ("slab", C.c_int32),
         ("seed", C.c_uint64), ("temp", C.c_float), ("device", C.c_int32),
         ("strip_rows", C.c_int32), ("kernel", C.c_int32), ("XSL", C.c_int32), ("YSL", C.c_int32),
+        ("use_J", C.c_int32), ("J_prob", C.c_float),
     ]
 
 
@@ -42,6 +44,11 @@ PROTOTYPES = {
     "ising_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ising_synchronize": (C.c_int, [C.c_void_p]),
     "ising_init_lattice": (C.c_int, [C.c_void_p]),
+    "ising_init_couplings": (C.c_int, [C.c_void_p]),
+    "ising_init_couplings_black": (C.c_int, [C.c_void_p]),
+    "ising_init_couplings_white": (C.c_int, [C.c_void_p]),
+    "ising_read_couplings": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
+    "ising_ring_init_couplings": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "ising_set_temperature": (C.c_int, [C.c_void_p, C.c_float]),
     "ising_get_tables": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
     "ising_update_color": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -6,7 +6,7 @@
 //            magnetisation line) and --devmap a,b,.. (place slab k on device devmap[k]; lets a 1-GPU box run -d N).
 //            --xsl/--ysl (independent periodic sub-lattices, optimized/main.cu:1423-1462),
 //            -c/--corr (two-point correlations file, optimized/main.cu:1072-1138; not together with sub-lattices).
-// Not yet supported (exit with a message): -J  (SURVEY 8f row 4).
+//            -J <PROB> (random anti-ferromagnetic bonds, optimized/main.cu:153-331, :575-618).
 #include "../../include/ising_hip.h"
 
 #include <getopt.h>
@@ -61,7 +61,7 @@ void usage(const char *pname) {
 	        "\t   --xsl <HORIZ_SUB_DIM> horizontal sub-lattice dimension (divisor of -x, multiple of %d)\n"
 	        "\t   --ysl <VERT_SUB_DIM>  vertical sub-lattice dimension (divisor of -y, multiple of %d)\n"
 	        "\t-c|--corr              append the 128 two-point correlations to corr_{Y}x{X}_T_{TEMP}_{SEED} at every print\n"
-	        "\t-J: not supported by this build\n\n",
+	        "\t-J|--J <PROB>          probability [0.0-1.0] that a bond is anti-ferromagnetic (default 0.0)\n\n",
 	        bname, X_MULT, Y_MULT, NUMIT_DEF, (unsigned long long)ISING_SEED_DEF, ALPHA_DEF, ALPHA_DEF * ISING_CRIT_TEMP, X_MULT, Y_MULT);
 	exit(EXIT_SUCCESS);
 }
@@ -118,6 +118,8 @@ int main(int argc, char **argv) {
 	int useSubLatt = 0, XSL = 0, YSL = 0, NSLX = 1, NSLY = 1;
 	int corrOut = 0;
 	char cname[256];
+	int useGenHamilt = 0;
+	float hamiltPerc1 = 0.0f;
 	std::vector<int> devmap;
 
 	static struct option long_options[] = {
@@ -159,7 +161,11 @@ int main(int argc, char **argv) {
 		} break;
 		case 'm': tgtMagn = atof(optarg); break;
 		case 'c': corrOut = 1; break;
-		case 'J': fprintf(stderr, "-J (random +-J couplings) is not supported by this build\n"); exit(EXIT_FAILURE);
+		case 'J':
+			useGenHamilt = 1;
+			hamiltPerc1 = atof(optarg);
+			hamiltPerc1 = std::min(std::max(0.0f, hamiltPerc1), 1.0f); // optimized/main.cu:1370
+			break;
 		case 1: useSubLatt = 1; XSL = atoi(optarg); break;
 		case 2: useSubLatt = 1; YSL = atoi(optarg); break;
 		case 3: printEnergy = 1; break;
@@ -240,7 +246,8 @@ int main(int argc, char **argv) {
 	printf("\ttemp: %f (%f*T_crit)\n", temp, temp / ISING_CRIT_TEMP);
 	if (!tempUpdFreq) printf("\ttemp update not set\n");
 	else printf("\ttemp update: %f / %d iterations\n", tempUpdStep, tempUpdFreq);
-	printf("\tnot using Hamiltonian buffer\n");
+	if (useGenHamilt) printf("\tusing Hamiltonian buffer, setting links to -1 with prob %G\n", hamiltPerc1);
+	else printf("\tnot using Hamiltonian buffer\n");
 	printf("\n");
 	if (useSubLatt) { // optimized/main.cu:1583-1588
 		printf("\tusing sub-lattices:\n");
@@ -262,6 +269,7 @@ int main(int argc, char **argv) {
 		cfg.X = X; cfg.Y = Y; cfg.nslabs = ndev; cfg.slab = i; cfg.seed = seed; cfg.temp = temp; cfg.device = devmap[i];
 		cfg.strip_rows = 0; cfg.kernel = ISING_KERNEL_AUTO;
 		cfg.XSL = useSubLatt ? XSL : 0; cfg.YSL = useSubLatt ? YSL : 0;
+		cfg.use_J = useGenHamilt; cfg.J_prob = hamiltPerc1;
 		ising_ctx *c = nullptr;
 		CHECK(ising_create(&cfg, &c));
 		ring.ctx.push_back(c);
@@ -278,6 +286,7 @@ int main(int argc, char **argv) {
 		CHECK(ising_ring_exchange(ring.ctx.data(), ndev, ISING_BLACK));
 		CHECK(ising_ring_exchange(ring.ctx.data(), ndev, ISING_WHITE));
 	}
+	if (useGenHamilt) CHECK(ising_ring_init_couplings(ring.ctx.data(), ndev)); // optimized/main.cu:1729-1742
 
 	const size_t nspins = llen * SPIN_X_WORD;
 	unsigned long long cntPos = 0, cntNeg = 0;

@@ -62,6 +62,7 @@ struct ising_ctx {
 	int nstrips = 0;
 	size_t color_words = 0;
 	uint64_t *d_lat = nullptr;          // [2 colours][Y + 2 rows][lld]: row -1 and row Y of each colour are halo rows
+	uint64_t *d_ham = nullptr;          // -J: [hamB, hamW] in the same shape
 	unsigned long long *d_acc = nullptr; // 2 counters
 	uint32_t *d_bits = nullptr;          // correlations: (Y + d_bits_extra) x lld words, one bit per spin
 	int d_bits_extra = 0;
@@ -82,6 +83,9 @@ struct ising_ctx {
 	uint64_t *lat(int color) const { return d_lat + (size_t)color * (color_words + 2 * (size_t)lld) + lld; }
 	uint64_t *halo(int color, int which) const { return which == 0 ? lat(color) - lld : lat(color) + color_words; }
 	size_t alloc_words() const { return 2 * (color_words + 2 * (size_t)lld); }
+	uint64_t *ham(int which) const { return d_ham + (size_t)which * (color_words + 2 * (size_t)lld) + lld; }
+	// "colour" 0/1 = spin arrays, 2 = black couplings
+	uint64_t *plane(int kind) const { return kind == ISING_HAM_BLACK ? ham(0) : lat(kind); }
 };
 
 namespace {
@@ -205,6 +209,10 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (e == hipSuccess) e = hipMemset(c->d_lat, 0, c->alloc_words() * sizeof(uint64_t)); // optimized/main.cu:1603
 	if (e == hipSuccess) e = hipMalloc((void **)&c->d_acc, 2 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMalloc((void **)&c->d_lut, 65536);
+	if (e == hipSuccess && cfg->use_J) {
+		e = hipMalloc((void **)&c->d_ham, c->alloc_words() * sizeof(uint64_t));
+		if (e == hipSuccess) e = hipMemset(c->d_ham, 0, c->alloc_words() * sizeof(uint64_t)); // optimized/main.cu:1609
+	}
 	if (e != hipSuccess) {
 		const int rc = fail(ISING_E_HIP, "device allocation failed: %s", hipGetErrorString(e));
 		ising_destroy(c);
@@ -220,6 +228,7 @@ int ising_destroy(ising_ctx *c) {
 	if (c->d_lat) (void)hipFree(c->d_lat);
 	if (c->d_acc) (void)hipFree(c->d_acc);
 	if (c->d_lut) (void)hipFree(c->d_lut);
+	if (c->d_ham) (void)hipFree(c->d_ham);
 	if (c->d_bits) (void)hipFree(c->d_bits);
 	if (c->d_corr) (void)hipFree(c->d_corr);
 	for (int k = 0; k < 2; k++) if (c->ev_sent[k]) (void)hipEventDestroy(c->ev_sent[k]);
@@ -320,6 +329,8 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	p.n4 = (uint32_t)c->thr[4];
 	memcpy(p.tab, c->tab, sizeof(p.tab));
 	p.lut = c->d_lut;
+	// the reference hands hamW to the BLACK update and hamB to the WHITE one (optimized/main.cu:1774, :1795)
+	p.jdst = c->cfg.use_J ? c->ham(other) : nullptr;
 	HIP_TRY(ising::launch_update(p, mode, c->stream));
 	return ISING_OK;
 }
@@ -366,12 +377,14 @@ int ising_sweep_timed(ising_ctx *c, int first_it, int nsweeps, float *elapsed_ms
 
 int ising_halo_ptrs(ising_ctx *c, int color, void **send_top, void **send_bot, void **recv_top, void **recv_bot, size_t *row_bytes) {
 	if (!c) return fail(ISING_E_ARG, "null context");
-	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
+	if (color != ISING_BLACK && color != ISING_WHITE && color != ISING_HAM_BLACK) return fail(ISING_E_ARG, "bad colour %d", color);
+	if (color == ISING_HAM_BLACK && !c->cfg.use_J) return fail(ISING_E_STATE, "couplings are not enabled (use_J)");
 	if (c->cfg.nslabs == 1) return fail(ISING_E_STATE, "no halo buffers with nslabs == 1 (rows wrap inside the slab)");
-	if (send_top) *send_top = c->lat(color);
-	if (send_bot) *send_bot = c->lat(color) + (size_t)(c->cfg.Y - 1) * c->lld;
-	if (recv_top) *recv_top = c->halo(color, 0);
-	if (recv_bot) *recv_bot = c->halo(color, 1);
+	uint64_t *base = c->plane(color);
+	if (send_top) *send_top = base;
+	if (send_bot) *send_bot = base + (size_t)(c->cfg.Y - 1) * c->lld;
+	if (recv_top) *recv_top = base - c->lld;
+	if (recv_bot) *recv_bot = base + c->color_words;
 	if (row_bytes) *row_bytes = (size_t)c->lld * sizeof(uint64_t);
 	return ISING_OK;
 }
@@ -472,6 +485,61 @@ int ising_dump_text(ising_ctx *c, const char *prefix) {
 	return ISING_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ couplings (-J)
+int ising_init_couplings_black(ising_ctx *c) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (!c->cfg.use_J) return fail(ISING_E_STATE, "couplings are not enabled (use_J)");
+	if (int rc = bind(c)) return rc;
+	const float prob = fminf(fmaxf(0.0f, c->cfg.J_prob), 1.0f);  // optimized/main.cu:1370
+	const uint64_t seed = c->cfg.seed + 1;                        // "just use a different seed", :1734
+	ising::HamInitParams p{};
+	p.hamB = c->ham(0);
+	p.seed_lo = (uint32_t)seed;
+	p.seed_hi = (uint32_t)(seed >> 32);
+	p.gx = c->gx;
+	p.Y = c->cfg.Y;
+	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
+	p.wrap = c->cfg.nslabs == 1;
+	const uint64_t thr = draw_prefix(prob, false); // curand_uniform(x) < tgtProb, :193
+	if (thr >= (1ull << 32)) return fail(ISING_E_ARG, "J probability %g sets every bit", (double)prob); // unreachable: u <= 1 and prob <= 1 gives at most 2^32 - 1... see below
+	p.thr = (uint32_t)thr;
+	HIP_TRY(ising::launch_ham_init_black(p, c->stream));
+	return ISING_OK;
+}
+
+int ising_init_couplings_white(ising_ctx *c) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (!c->cfg.use_J) return fail(ISING_E_STATE, "couplings are not enabled (use_J)");
+	if (int rc = bind(c)) return rc;
+	ising::HamWhiteParams p{};
+	p.hamB = c->ham(0);
+	p.hamW = c->ham(1);
+	p.lld = c->lld;
+	p.Y = c->cfg.Y;
+	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
+	p.slW = c->cfg.XSL ? c->cfg.XSL / 32 : c->lld;
+	p.slY = c->cfg.XSL ? c->cfg.YSL : 0;
+	p.wrap = c->cfg.nslabs == 1;
+	HIP_TRY(ising::launch_ham_init_white(p, c->stream));
+	return ISING_OK;
+}
+
+int ising_init_couplings(ising_ctx *c) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (c->cfg.nslabs != 1 && !c->cfg.XSL) return fail(ISING_E_STATE, "ising_init_couplings needs nslabs == 1; use the _black/_white pair around a halo exchange");
+	if (int rc = ising_init_couplings_black(c)) return rc;
+	return ising_init_couplings_white(c);
+}
+
+int ising_read_couplings(ising_ctx *c, int which, int64_t row0, int64_t nrows, uint64_t *dst_host) {
+	if (int rc = check_rows(c, which, row0, nrows, dst_host)) return rc;
+	if (!c->cfg.use_J) return fail(ISING_E_STATE, "couplings are not enabled (use_J)");
+	if (int rc = bind(c)) return rc;
+	HIP_TRY(hipMemcpyAsync(dst_host, c->ham(which) + (size_t)row0 * c->lld, (size_t)nrows * c->lld * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return ISING_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ ring mode
 static int ring_check(ising_ctx **ctxs, int n) {
 	if (!ctxs || n < 1) return fail(ISING_E_ARG, "bad ring");
@@ -519,9 +587,9 @@ static int ring_send(ising_ctx **ctxs, int n, int k, int color) {
 	ring_enable_peers(c, prev, next);
 	if (int rc = bind(c)) return rc;
 	// next slab's top halo <- my last row ; previous slab's bottom halo <- my first row
-	HIP_TRY(hipMemcpyPeerAsync(next->halo(color, 0), next->cfg.device, c->lat(color) + (size_t)(c->cfg.Y - 1) * c->lld, c->cfg.device, nb, c->stream));
-	HIP_TRY(hipMemcpyPeerAsync(prev->halo(color, 1), prev->cfg.device, c->lat(color), c->cfg.device, nb, c->stream));
-	HIP_TRY(hipEventRecord(c->ev_sent[color], c->stream));
+	HIP_TRY(hipMemcpyPeerAsync(next->plane(color) - next->lld, next->cfg.device, c->plane(color) + (size_t)(c->cfg.Y - 1) * c->lld, c->cfg.device, nb, c->stream));
+	HIP_TRY(hipMemcpyPeerAsync(prev->plane(color) + prev->color_words, prev->cfg.device, c->plane(color), c->cfg.device, nb, c->stream));
+	if (color != ISING_HAM_BLACK) HIP_TRY(hipEventRecord(c->ev_sent[color], c->stream));
 	return ISING_OK;
 }
 
@@ -536,7 +604,7 @@ static int ring_wait(ising_ctx **ctxs, int n, int k, int color) {
 
 int ising_ring_exchange(ising_ctx **ctxs, int n, int color) {
 	if (int rc = ring_check(ctxs, n)) return rc;
-	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
+	if (color != ISING_BLACK && color != ISING_WHITE && color != ISING_HAM_BLACK) return fail(ISING_E_ARG, "bad colour %d", color);
 	if (n == 1) return ISING_OK;
 	for (int k = 0; k < n; k++) if (int rc = ring_send(ctxs, n, k, color)) return rc;
 	return ISING_OK;
@@ -556,6 +624,18 @@ int ising_ring_sweep(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 			}
 		}
 	}
+	return ISING_OK;
+}
+
+int ising_ring_init_couplings(ising_ctx **ctxs, int n) {
+	if (int rc = ring_check(ctxs, n)) return rc;
+	for (int k = 0; k < n; k++) if (int rc = ising_init_couplings_black(ctxs[k])) return rc;
+	if (n > 1 && !ctxs[0]->cfg.XSL) {
+		for (int k = 0; k < n; k++) if (int rc = ring_send(ctxs, n, k, ISING_HAM_BLACK)) return rc;
+		// the copies run on the senders' streams: make every slab's stream wait for both of its neighbours
+		for (int k = 0; k < n; k++) if (int rc = ising_synchronize(ctxs[k])) return rc;
+	}
+	for (int k = 0; k < n; k++) if (int rc = ising_init_couplings_white(ctxs[k])) return rc;
 	return ISING_OK;
 }
 

@@ -30,6 +30,7 @@ struct UpdateParams {
 	uint32_t n3, n4;          // integer accept thresholds for 3 / 4 aligned neighbours (fast kernel)
 	float tab[10];            // exp table exp_h[2][5] (generic kernel)
 	const uint8_t *lut;       // 64 KiB rank table indexed by the top 16 bits of a draw (mode 2)
+	const uint64_t *jdst;     // coupling words read for the rows being updated (NULL without -J); same shape as dst
 };
 
 // mode: 0 = integer thresholds via v_cmpx, 1 = generic FP32-table kernel, 2 = integer thresholds via the LDS rank table
@@ -57,6 +58,27 @@ struct BondParams {
 	unsigned long long *acc;
 };
 hipError_t launch_bond_equal(const BondParams &p, hipStream_t stream);
+
+// -J couplings.  hamiltInitB_k: random bits for the black coupling array (4 per site), generator seed, offset 0.
+struct HamInitParams {
+	uint64_t *hamB;        // row 0 of [-1..Y][lld]
+	uint32_t seed_lo, seed_hi;
+	int32_t gx, Y;
+	uint32_t row_base;
+	int32_t wrap;
+	uint32_t thr;          // number of draws x with curand_uniform(x) < prob
+};
+hipError_t launch_ham_init_black(const HamInitParams &p, hipStream_t stream);
+// hamiltInitW_k as a gather: every white coupling word is assembled from the black words at the other ends of its bonds
+struct HamWhiteParams {
+	const uint64_t *hamB;  // rows -1 and Y must be current
+	uint64_t *hamW;
+	int32_t lld, Y;
+	uint32_t row_base;
+	int32_t slW, slY;      // periodic extents: words per row (= lld without sub-lattices), rows (0 = use halo rows)
+	int32_t wrap;
+};
+hipError_t launch_ham_init_white(const HamWhiteParams &p, hipStream_t stream);
 
 // one-bit-per-spin image of a slab in lattice-column order: bits[Y][lld] 32-bit words
 hipError_t launch_pack_bits(const uint64_t *black, const uint64_t *white, int lld, int Y, uint32_t row_base, uint32_t *bits,

@@ -181,8 +181,9 @@ __device__ __forceinline__ float u01(uint32_t x) {
 // Nibble-wise number of up neighbours for the four dwords of one vector.
 // ct/up/dw: centre/up/down source vectors; side: the neighbouring vector's dword that supplies the carry nibble
 // (dword 3 of the left vector when back, dword 0 of the right vector otherwise); optimized/main.cu:546-573,:623-635.
+template <bool USEJ = false>
 __device__ __forceinline__ void neighbour_sums(const uint4 &up, const uint4 &ct, const uint4 &dw, uint32_t side, bool back,
-                                               uint32_t S[4]) {
+                                               uint32_t S[4], const uint4 &J = uint4()) {
 	uint32_t sd[4];
 	if (back) {
 		sd[0] = __builtin_amdgcn_alignbit(ct.x, side, 28);
@@ -195,10 +196,20 @@ __device__ __forceinline__ void neighbour_sums(const uint4 &up, const uint4 &ct,
 		sd[2] = __builtin_amdgcn_alignbit(ct.w, ct.z, 4);
 		sd[3] = __builtin_amdgcn_alignbit(side, ct.w, 4);
 	}
-	S[0] = up.x + ct.x + dw.x + sd[0];
-	S[1] = up.y + ct.y + dw.y + sd[1];
-	S[2] = up.z + ct.z + dw.z + sd[2];
-	S[3] = up.w + ct.w + dw.w + sd[3];
+	const uint32_t u[4] = {up.x, up.y, up.z, up.w}, c[4] = {ct.x, ct.y, ct.z, ct.w}, d[4] = {dw.x, dw.y, dw.z, dw.w};
+	const uint32_t j[4] = {J.x, J.y, J.z, J.w};
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		if (USEJ) {
+			// coupling bits <up, down, left, right> = 0x8, 0x4, 0x2, 0x1 flip the neighbour's contribution
+			// (optimized/main.cu:575-618); the side word holds the left neighbours when `back`, else the right ones
+			const uint32_t ju = (j[k] & 0x88888888u) >> 3, jd = (j[k] & 0x44444444u) >> 2;
+			const uint32_t jl = (j[k] & 0x22222222u) >> 1, jr = j[k] & 0x11111111u;
+			S[k] = (u[k] ^ ju) + (d[k] ^ jd) + (c[k] ^ (back ? jr : jl)) + (sd[k] ^ (back ? jl : jr));
+		} else {
+			S[k] = u[k] + c[k] + d[k] + sd[k];
+		}
+	}
 }
 
 // Resolve the flips of 8 sites (one dword): S = neighbour-up counts, R6 = accept ranks + 6 per nibble.
@@ -240,7 +251,7 @@ constexpr int threads_of(int mode) { return mode == 2 ? 1024 : THREADS; }
 #ifndef ISING_LUT_WAVES_PER_SIMD
 #define ISING_LUT_WAVES_PER_SIMD 4
 #endif
-template <int MODE>
+template <int MODE, bool USEJ = false>
 __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_PER_SIMD : 1) update_k(const UpdateParams p) {
 	__shared__ float sh_tab[10];
 	__shared__ __attribute__((aligned(16))) uint8_t lut[MODE == 2 ? LUT_BYTES : 16];
@@ -287,6 +298,7 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 	// Rows -1 and Y of every colour array are physically present (halo rows), so row r lives at src + r*vecs.
 	const uint4 *pc = reinterpret_cast<const uint4 *>(p.src) + ((ptrdiff_t)r0 * vecs + col0); // centre row, own vector
 	uint4 *pm = reinterpret_cast<uint4 *>(p.dst) + ((ptrdiff_t)r0 * vecs + col0);
+	const uint4 *pj = USEJ ? reinterpret_cast<const uint4 *>(p.jdst) + ((ptrdiff_t)r0 * vecs + col0) : nullptr;
 	const ptrdiff_t wrap_bot = (ptrdiff_t)p.Y * vecs; // row 0 mirrors to row Y, row Y-1 to row -1 (single slab)
 
 	const uint32_t k2y = p.seed_hi + 2u * PHILOX_W1;
@@ -314,6 +326,8 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 		const uint32_t side0 = DBG_LDW(pcw[back ? offL0 : offR0]);
 		const uint32_t side1 = DBG_LDW(pcw[back ? offL1 : offR1]);
 		uint4 me0 = DBG_LD(pm[0]), me1 = DBG_LD(pm[GROUP]);
+		uint4 j0 = uint4(), j1 = uint4();
+		if (USEJ) { j0 = pj[0]; j1 = pj[GROUP]; pj += vecs; }
 
 		// stream id of the reference thread that owns these two vectors (optimized/main.cu:514-515)
 		const uint32_t tid = ((grow >> 4) * (uint32_t)p.gx + (uint32_t)bx) * 256u + (grow & 15u) * 16u + (uint32_t)tx;
@@ -340,10 +354,10 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 				}
 			});
 			uint32_t S[4];
-			neighbour_sums(up0, ct0, dw0, side0, back, S);
+			neighbour_sums<USEJ>(up0, ct0, dw0, side0, back, S, j0);
 			me0 = make_uint4(apply_flips(me0.x, S[0], R[0][0] + 0x66666666u), apply_flips(me0.y, S[1], R[0][1] + 0x66666666u),
 			                 apply_flips(me0.z, S[2], R[0][2] + 0x66666666u), apply_flips(me0.w, S[3], R[0][3] + 0x66666666u));
-			neighbour_sums(up1, ct1, dw1, side1, back, S);
+			neighbour_sums<USEJ>(up1, ct1, dw1, side1, back, S, j1);
 			me1 = make_uint4(apply_flips(me1.x, S[0], R[1][0] + 0x66666666u), apply_flips(me1.y, S[1], R[1][1] + 0x66666666u),
 			                 apply_flips(me1.z, S[2], R[1][2] + 0x66666666u), apply_flips(me1.w, S[3], R[1][3] + 0x66666666u));
 		} else if (MODE == 0) {
@@ -357,17 +371,17 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 				accept_rank<(2 * m) & 7>(R[j][m >> 2], R[j][2 + (m >> 2)], o[0], o[1], o[2], o[3], p.n3, p.n4);
 			});
 			uint32_t S[4];
-			neighbour_sums(up0, ct0, dw0, side0, back, S);
+			neighbour_sums<USEJ>(up0, ct0, dw0, side0, back, S, j0);
 			me0 = make_uint4(apply_flips(me0.x, S[0], R[0][0]), apply_flips(me0.y, S[1], R[0][1]),
 			                 apply_flips(me0.z, S[2], R[0][2]), apply_flips(me0.w, S[3], R[0][3]));
-			neighbour_sums(up1, ct1, dw1, side1, back, S);
+			neighbour_sums<USEJ>(up1, ct1, dw1, side1, back, S, j1);
 			me1 = make_uint4(apply_flips(me1.x, S[0], R[1][0]), apply_flips(me1.y, S[1], R[1][1]),
 			                 apply_flips(me1.z, S[2], R[1][2]), apply_flips(me1.w, S[3], R[1][3]));
 		} else {
 			// generic: the reference's own per-site FP32 test, optimized/main.cu:637-660
 			uint32_t S[2][4];
-			neighbour_sums(up0, ct0, dw0, side0, back, S[0]);
-			neighbour_sums(up1, ct1, dw1, side1, back, S[1]);
+			neighbour_sums<USEJ>(up0, ct0, dw0, side0, back, S[0], j0);
+			neighbour_sums<USEJ>(up1, ct1, dw1, side1, back, S[1], j1);
 			uint32_t mv[2][4] = {{me0.x, me0.y, me0.z, me0.w}, {me1.x, me1.y, me1.z, me1.w}};
 #pragma unroll
 			for (int j = 0; j < 2; ++j) {
@@ -447,6 +461,72 @@ __global__ void __launch_bounds__(THREADS) init_k(const InitParams p) {
 		if (p.wrap) { // single slab: the halo rows mirror the opposite edge rows
 			if (lr == 0) row[(ptrdiff_t)p.Y * vecs + bx * 32 + tx + j * GROUP] = val;
 			if (lr == p.Y - 1) row[-(ptrdiff_t)p.Y * vecs + bx * 32 + tx + j * GROUP] = val;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------- couplings (-J)
+// hamiltInitB_k (optimized/main.cu:153-212): 256 draws per reference thread, generator offset 0: draw block
+// b = 32 j + 2 z + h of vector j feeds bits 4z+2h and 4z+2h+1 of word x (outputs 0, 2) and word y (outputs 1, 3).
+__global__ void __launch_bounds__(THREADS) ham_init_black_k(const HamInitParams p) {
+	const int tx = threadIdx.x & (GROUP - 1);
+	const int unit = blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x >> 4); // (row, bx)
+	if (unit >= p.gx * p.Y) return;
+	const int lr = unit / p.gx;
+	const int bx = unit - lr * p.gx;
+	const int vecs = p.gx * 32;
+	const uint32_t grow = p.row_base + (uint32_t)lr;
+	const uint32_t tid = ((grow >> 4) * (uint32_t)p.gx + (uint32_t)bx) * 256u + (grow & 15u) * 16u + (uint32_t)tx;
+	const PhiloxRow pr = philox_row_setup(tid, p.seed_lo, p.seed_hi + 2u * PHILOX_W1);
+	uint4 *row = reinterpret_cast<uint4 *>(p.hamB) + (size_t)lr * vecs;
+	for (int j = 0; j < 2; ++j) {
+		uint32_t v[4] = {0, 0, 0, 0};
+#pragma unroll 4
+		for (int b = 0; b < 32; ++b) {
+			uint32_t o[4];
+			philox_block(pr, (uint32_t)(32 * j + b), p.seed_lo, p.seed_hi, o[0], o[1], o[2], o[3]);
+			const int z = b >> 1, bit = 4 * (z & 7) + 2 * (b & 1), d = z >> 3;
+			if (o[0] < p.thr) v[d] |= 1u << bit;
+			if (o[1] < p.thr) v[2 + d] |= 1u << bit;
+			if (o[2] < p.thr) v[d] |= 2u << bit;
+			if (o[3] < p.thr) v[2 + d] |= 2u << bit;
+		}
+		const uint4 val = make_uint4(v[0], v[1], v[2], v[3]);
+		const int col = bx * 32 + tx + j * GROUP;
+		row[col] = val;
+		if (p.wrap) {
+			if (lr == 0) row[(ptrdiff_t)p.Y * vecs + col] = val;
+			if (lr == p.Y - 1) row[-(ptrdiff_t)p.Y * vecs + col] = val;
+		}
+	}
+}
+
+// hamiltInitW_k (optimized/main.cu:214-331) turned from a scatter with atomicOr into a gather: white word (i, q)
+// collects, from the black words at the other ends of its bonds, the bit that describes the same bond:
+//   down (0x4) <- up (0x8) of the black word below;  up (0x8) <- down (0x4) of the black word above;
+//   even rows: left (0x2) <- right (0x1) of the same black nibble, right (0x1) <- left (0x2) of the next black nibble;
+//   odd rows:  right (0x1) <- left (0x2) of the same black nibble, left (0x2) <- right (0x1) of the previous nibble.
+__global__ void __launch_bounds__(THREADS) ham_init_white_k(const HamWhiteParams p) {
+	const size_t total = (size_t)p.lld * p.Y;
+	const unsigned long long M8 = 0x8888888888888888ull, M4 = 0x4444444444444444ull, M2 = 0x2222222222222222ull, M1 = 0x1111111111111111ull;
+	for (size_t idx = blockIdx.x * (size_t)THREADS + threadIdx.x; idx < total; idx += (size_t)gridDim.x * THREADS) {
+		const int i = (int)(idx / p.lld), q = (int)(idx - (size_t)i * p.lld);
+		const ptrdiff_t uo = (p.slY && (i % p.slY) == 0) ? (ptrdiff_t)(p.slY - 1) * p.lld : -(ptrdiff_t)p.lld;
+		const ptrdiff_t dwo = (p.slY && ((i + 1) % p.slY) == 0) ? (ptrdiff_t)(1 - p.slY) * p.lld : (ptrdiff_t)p.lld;
+		const uint64_t *b = p.hamB + (ptrdiff_t)i * p.lld;
+		const unsigned long long me = b[q];
+		unsigned long long w = ((b[q + dwo] & M8) >> 1) | ((b[q + uo] & M4) << 1);
+		if ((p.row_base + (uint32_t)i) & 1u) {
+			const int qp = (q % p.slW) == 0 ? q + p.slW - 1 : q - 1;
+			w |= ((me & M2) >> 1) | ((me & M1) << 5) | ((b[qp] & M1) >> 59);
+		} else {
+			const int qn = ((q + 1) % p.slW) == 0 ? q + 1 - p.slW : q + 1;
+			w |= ((me & M1) << 1) | ((me & M2) >> 5) | ((b[qn] & M2) << 59);
+		}
+		p.hamW[idx] = w;
+		if (p.wrap) {
+			if (i == 0) p.hamW[idx + (size_t)p.Y * p.lld] = w;
+			if (i == p.Y - 1) p.hamW[(ptrdiff_t)idx - (ptrdiff_t)p.Y * p.lld] = w;
 		}
 	}
 }
@@ -609,9 +689,25 @@ hipError_t launch_update(const UpdateParams &p, int mode, hipStream_t stream) {
 	if (p.nunits <= 0) return hipSuccess;
 	const int per_block = threads_of(mode) / GROUP;
 	const dim3 grid((p.nunits + per_block - 1) / per_block), block(threads_of(mode));
-	if (mode == 0)      hipLaunchKernelGGL(update_k<0>, grid, block, 0, stream, p);
-	else if (mode == 1) hipLaunchKernelGGL(update_k<1>, grid, block, 0, stream, p);
-	else                hipLaunchKernelGGL(update_k<2>, grid, block, 0, stream, p);
+	if (p.jdst) { // -J: only the v_cmpx and generic kernels carry the coupling path
+		if (mode == 1) hipLaunchKernelGGL((update_k<1, true>), grid, block, 0, stream, p);
+		else           hipLaunchKernelGGL((update_k<0, true>), dim3((p.nunits + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(THREADS), 0, stream, p);
+	} else if (mode == 0) hipLaunchKernelGGL((update_k<0, false>), grid, block, 0, stream, p);
+	else if (mode == 1)   hipLaunchKernelGGL((update_k<1, false>), grid, block, 0, stream, p);
+	else                  hipLaunchKernelGGL((update_k<2, false>), grid, block, 0, stream, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_ham_init_black(const HamInitParams &p, hipStream_t stream) {
+	const long long units = (long long)p.gx * p.Y;
+	hipLaunchKernelGGL(ham_init_black_k, dim3((unsigned)((units + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)), dim3(THREADS), 0, stream, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_ham_init_white(const HamWhiteParams &p, hipStream_t stream) {
+	size_t blocks = ((size_t)p.lld * p.Y + THREADS - 1) / THREADS;
+	if (blocks > 8192) blocks = 8192;
+	hipLaunchKernelGGL(ham_init_white_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, p);
 	return hipGetLastError();
 }
 

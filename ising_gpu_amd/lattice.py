@@ -26,10 +26,12 @@ class IsingSlab:
 
     def __init__(self, X: int, Y: int, seed: int = _lib.SEED_DEF, temp: float = 0.1 * _lib.CRIT_TEMP_F32,
                  nslabs: int = 1, slab: int = 0, device: int = 0, strip_rows: int = 0, kernel: int = _lib.KERNEL_AUTO,
-                 XSL: int = 0, YSL: int = 0):
+                 XSL: int = 0, YSL: int = 0, J_prob: float | None = None):
         self._lib = _lib.load()
         self.cfg = IsingConfig(X=X, Y=Y, nslabs=nslabs, slab=slab, seed=seed, temp=float(np.float32(temp)),
-                               device=device, strip_rows=strip_rows, kernel=kernel, XSL=XSL, YSL=YSL)
+                               device=device, strip_rows=strip_rows, kernel=kernel, XSL=XSL, YSL=YSL,
+                               use_J=0 if J_prob is None else 1, J_prob=0.0 if J_prob is None else float(J_prob))
+        self.use_J = J_prob is not None
         self._h = C.c_void_p()
         check(self._lib.ising_create(C.byref(self.cfg), C.byref(self._h)))
         self.X, self.Y, self.nslabs, self.slab = X, Y, nslabs, slab
@@ -68,6 +70,22 @@ class IsingSlab:
         check(self._lib.ising_init_lattice(self._h))
         self.it = 0
         return self
+
+    def init_couplings(self):
+        """-J: hamiltInitB_k (seed+1) + hamiltInitW_k (single slab, or sub-lattices)."""
+        check(self._lib.ising_init_couplings(self._h))
+        return self
+
+    def init_couplings_black(self):
+        check(self._lib.ising_init_couplings_black(self._h))
+
+    def init_couplings_white(self):
+        check(self._lib.ising_init_couplings_white(self._h))
+
+    def read_couplings(self, which: int) -> np.ndarray:
+        out = np.empty((self.Y, self.lld), dtype=np.uint64)
+        check(self._lib.ising_read_couplings(self._h, which, 0, self.Y, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def set_temperature(self, temp: float):
         check(self._lib.ising_set_temperature(self._h, C.c_float(float(np.float32(temp)))))

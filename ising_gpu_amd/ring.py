@@ -25,7 +25,7 @@ from typing import List, Optional, Protocol
 import torch
 import torch.distributed as dist
 
-from ._lib import BLACK, WHITE
+from ._lib import BLACK, WHITE, HAM_BLACK
 
 
 class SlabBackend(Protocol):
@@ -54,13 +54,20 @@ class HipSlabBackend:
         self.device = torch.device("cuda", slab.cfg.device)
         slab.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self._halo = {}
+        self.use_J = bool(getattr(slab, "use_J", False))
         if slab.nslabs > 1:
-            for color in (BLACK, WHITE):
+            for color in (BLACK, WHITE) + ((HAM_BLACK,) if self.use_J else ()):
                 ptrs, nb = slab.halo_ptrs(color)
                 self._halo[color] = tuple(torch.as_tensor(_DevMem(p, nb), device=self.device) for p in ptrs)
 
     def init(self):
         self.slab.init()
+
+    def init_couplings_black(self):
+        self.slab.init_couplings_black()
+
+    def init_couplings_white(self):
+        self.slab.init_couplings_white()
 
     def update_all(self, it, color):
         self.slab.update_color(it, color)
@@ -92,7 +99,7 @@ class SlabRing:
         self.prev = (self.rank - 1) % self.world
         self.next = (self.rank + 1) % self.world
         self.it = 0
-        self._pending: List[Optional[list]] = [None, None]  # per colour: outstanding P2P works
+        self._pending: List[Optional[list]] = [None, None, None]  # per plane (black, white, black couplings)
 
     # -- halo exchange -----------------------------------------------------------------------------------
     def _post(self, color: int):
@@ -121,6 +128,13 @@ class SlabRing:
         if self.world > 1:
             self._post(BLACK)
             self._post(WHITE)
+        if getattr(self.b, "use_J", False):
+            # -J: the white couplings are assembled from the black ones, including the neighbours' edge rows
+            self.b.init_couplings_black()
+            if self.world > 1:
+                self._post(HAM_BLACK)
+                self._wait(HAM_BLACK)
+            self.b.init_couplings_white()
         return self
 
     def _half_sweep(self, it: int, color: int):
@@ -193,6 +207,13 @@ class LocalRing:
         if self.n > 1:
             self._exchange(BLACK)
             self._exchange(WHITE)
+        if getattr(self.b[0], "use_J", False):
+            for b in self.b:
+                b.init_couplings_black()
+            if self.n > 1:
+                self._exchange(HAM_BLACK)
+            for b in self.b:
+                b.init_couplings_white()
         return self
 
     def sweep(self, nsweeps: int = 1):

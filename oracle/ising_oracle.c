@@ -179,15 +179,19 @@ static inline const uint64_t *view_row(const orc_view *v, const orc_geom *g, int
 	return v->src + r*g->lld;
 }
 
-/* For destination colour `color`, view row i, vector `col`: nibble-wise neighbour-up counts of words (x,y). */
-static inline void neighbour_sums(const orc_view *v, const orc_geom *g, int color, int64_t i, int64_t col, uint64_t sum[2]) {
+/* For destination colour `color`, view row i, vector `col`: nibble-wise neighbour-up counts of words (x,y).
+ * jrow (may be NULL): the coupling words the reference passes as jDst for this row (:575-618): a set bit flips the
+ * neighbour's contribution.  Bits per nibble: 0x8 up, 0x4 down, 0x2 left, 0x1 right (:588).
+ */
+static inline void neighbour_sums(const orc_view *v, const orc_geom *g, int color, int64_t i, int64_t col, const uint64_t *jrow, uint64_t sum[2]) {
 	int64_t iu = i - 1, id = i + 1;
 	if (v->slY > 0) {
 		iu = (i % v->slY) == 0 ? i + v->slY - 1 : i - 1;          /* :414 */
 		id = ((i + 1) % v->slY) == 0 ? i + 1 - v->slY : i + 1;    /* :422 */
 	}
 	const uint64_t *ru = view_row(v, g, iu), *rc = view_row(v, g, i), *rd = view_row(v, g, id);
-	const uint64_t ctx = rc[2*col], cty = rc[2*col + 1];
+	uint64_t ctx = rc[2*col], cty = rc[2*col + 1];
+	uint64_t upx = ru[2*col], upy = ru[2*col + 1], dwx = rd[2*col], dwy = rd[2*col + 1];
 	uint64_t sdx, sdy;
 	const int64_t gi = v->row_base + i;
 	const int readBack = (color == ORC_BLACK) ? !(gi & 1) : (int)(gi & 1); /* :542 */
@@ -203,15 +207,109 @@ static inline void neighbour_sums(const orc_view *v, const orc_geom *g, int colo
 		sdy = (cty >> 4) | (rx << 60);   /* :569 */
 		sdx = (ctx >> 4) | (cty << 60);  /* :570 */
 	}
-	sum[0] = ctx + ru[2*col]     + rd[2*col]     + sdx;  /* :623-635, nibble sums never carry (max 4) */
-	sum[1] = cty + ru[2*col + 1] + rd[2*col + 1] + sdy;
+	if (jrow) {                          /* :575-618 */
+		const uint64_t jx = jrow[2*col], jy = jrow[2*col + 1];
+		upx ^= (jx & 0x8888888888888888ull) >> 3; upy ^= (jy & 0x8888888888888888ull) >> 3;
+		dwx ^= (jx & 0x4444444444444444ull) >> 2; dwy ^= (jy & 0x4444444444444444ull) >> 2;
+		if (readBack) {
+			sdx ^= (jx & 0x2222222222222222ull) >> 1; sdy ^= (jy & 0x2222222222222222ull) >> 1;
+			ctx ^= (jx & 0x1111111111111111ull);      cty ^= (jy & 0x1111111111111111ull);
+		} else {
+			ctx ^= (jx & 0x2222222222222222ull) >> 1; cty ^= (jy & 0x2222222222222222ull) >> 1;
+			sdx ^= (jx & 0x1111111111111111ull);      sdy ^= (jy & 0x1111111111111111ull);
+		}
+	}
+	sum[0] = ctx + upx + dwx + sdx;  /* :623-635, nibble sums never carry (max 4) */
+	sum[1] = cty + upy + dwy + sdy;
+}
+
+/* ------------------------------------------------------------------ hamiltInitB_k, optimized/main.cu:153-212
+ * Random coupling bits for the black array: for every nibble, bits l = 0..3 (<right, left, down, up> = 0x1,0x2,0x4,0x8,
+ * :588) are set with probability prob; draws in the order k (nibble), l (bit), word x then word y (:189-200);
+ * generator curand_init(seed, tid, 0) with the caller passing seed+1 (:1734).
+ */
+void orc_ham_init_black(uint64_t *hamB, int64_t X, int64_t Y, int64_t row_base, uint64_t seed, float prob) {
+	orc_geom g;
+	if (geom(X, Y, &g)) return;
+	#pragma omp parallel for schedule(static)
+	for (int64_t i = 0; i < Y; i++) {
+		const int64_t gi = row_base + i;
+		const int64_t by = gi / BLK_Y; const int ty = (int)(gi % BLK_Y);
+		for (int64_t bx = 0; bx < g.gx; bx++) {
+			for (int tx = 0; tx < BLK_X; tx++) {
+				const uint32_t tid = (uint32_t)((by*g.gx + bx)*BLK_X*BLK_Y + ty*BLK_X + tx);
+				orc_gen st;
+				gen_init(&st, seed, tid, 0);
+				for (int j = 0; j < VEC_PER_THREAD; j++) {
+					uint64_t x = 0, y = 0;
+					for (int k = 0; k < 64; k += 4) {
+						for (int l = 0; l < 4; l++) {
+							if (u01(gen_next(&st)) < prob) x |= 1ull << (k + l);
+							if (u01(gen_next(&st)) < prob) y |= 1ull << (k + l);
+						}
+					}
+					const int64_t col = bx*BLK_X*VEC_PER_THREAD + tx + j*BLK_X;
+					hamB[i*g.lld + 2*col]     = x;
+					hamB[i*g.lld + 2*col + 1] = y;
+				}
+			}
+		}
+	}
+}
+
+/* hamiltInitW_k, optimized/main.cu:214-331: every black vector scatters its four coupling bits to the white sites at
+ * the other end of the bonds (atomicOr there; plain |= in this sequential restatement).  Whole lattice (all rows in
+ * one array); xsl in 128-bit vectors, ysl in rows.  hamW must be zero on entry.
+ */
+void orc_ham_init_white(const uint64_t *hamB, uint64_t *hamW, int64_t X, int64_t Ytot, int64_t XSL, int64_t YSL) {
+	orc_geom g;
+	if (geom(X, Ytot, &g)) return;
+	if (XSL <= 0) XSL = X;
+	if (YSL <= 0) YSL = Ytot;
+	const int64_t xsl = (XSL/2)/NIB/2, ysl = YSL;
+	const uint64_t M8 = 0x8888888888888888ull, M4 = 0x4444444444444444ull, M2 = 0x2222222222222222ull, M1 = 0x1111111111111111ull;
+	for (int64_t yoff = 0; yoff < Ytot; yoff++) {
+		const int64_t upOff = (yoff % ysl) == 0 ? yoff + ysl - 1 : yoff - 1;       /* :306 */
+		const int64_t dwOff = ((yoff + 1) % ysl) == 0 ? yoff - ysl + 1 : yoff + 1; /* :307 */
+		const int readBack = !(yoff % 2);                                          /* :256 */
+		for (int64_t xoff = 0; xoff < g.vecs; xoff++) {
+			const uint64_t mx = hamB[yoff*g.lld + 2*xoff], my = hamB[yoff*g.lld + 2*xoff + 1];
+			const uint64_t upx = (mx & M8) >> 1, upy = (my & M8) >> 1;   /* :245-246 */
+			const uint64_t dwx = (mx & M4) << 1, dwy = (my & M4) << 1;   /* :248-249 */
+			uint64_t ctx, cty, sdx, sdy;
+			if (!readBack) {                                             /* :260-276 */
+				ctx = (mx & M2) >> 1;
+				cty = (my & M2) >> 1;
+				ctx |= (mx & M1) << 5;
+				cty |= (mx & M1) >> 59;
+				cty |= (my & M1) << 5;
+				sdx = (my & M1) >> 59;
+				sdy = 0;
+			} else {                                                     /* :278-294 */
+				ctx = (mx & M1) << 1;
+				cty = (my & M1) << 1;
+				cty |= (my & M2) >> 5;
+				ctx |= (my & M2) << 59;
+				ctx |= (mx & M2) >> 5;
+				sdy = (mx & M2) << 59;
+				sdx = 0;
+			}
+			hamW[yoff*g.lld + 2*xoff]      |= ctx;  hamW[yoff*g.lld + 2*xoff + 1]  |= cty;
+			hamW[upOff*g.lld + 2*xoff]     |= upx;  hamW[upOff*g.lld + 2*xoff + 1] |= upy;
+			hamW[dwOff*g.lld + 2*xoff]     |= dwx;  hamW[dwOff*g.lld + 2*xoff + 1] |= dwy;
+			const int64_t sideOff = readBack ? ((xoff % xsl) == 0 ? xoff + xsl - 1 : xoff - 1)
+			                                 : (((xoff + 1) % xsl) == 0 ? xoff - xsl + 1 : xoff + 1); /* :322-323 */
+			hamW[yoff*g.lld + 2*sideOff]     |= sdx;
+			hamW[yoff*g.lld + 2*sideOff + 1] |= sdy;
+		}
+	}
 }
 
 /* ------------------------------------------------------------------ spinUpdateV_2D_k, optimized/main.cu:463-670
  * Updates view rows [r_lo, r_hi) (multiples of 16 are NOT required here: the reference launches whole 16-row
  * blocks, but every thread is independent, so any row range gives the same result for those rows).
  */
-static void update_rows(uint64_t *dst, const orc_view *v, const orc_geom *g, uint64_t seed, int it, int color,
+static void update_rows(uint64_t *dst, const orc_view *v, const orc_geom *g, const uint64_t *jdst, uint64_t seed, int it, int color,
                         const float tab[10], int64_t r_lo, int64_t r_hi) {
 	#pragma omp parallel for schedule(static)
 	for (int64_t i = r_lo; i < r_hi; i++) {
@@ -225,7 +323,7 @@ static void update_rows(uint64_t *dst, const orc_view *v, const orc_geom *g, uin
 				for (int j = 0; j < VEC_PER_THREAD; j++) {
 					const int64_t col = bx*BLK_X*VEC_PER_THREAD + tx + j*BLK_X;
 					uint64_t sum[2];
-					neighbour_sums(v, g, color, i, col, sum);
+					neighbour_sums(v, g, color, i, col, jdst ? jdst + i*g->lld : NULL, sum);
 					uint64_t me[2] = { dst[i*g->lld + 2*col], dst[i*g->lld + 2*col + 1] };
 					for (int z = 0; z < 64; z += 4) {   /* :637-660: x word first, then y word */
 						for (int w = 0; w < 2; w++) {
@@ -254,7 +352,25 @@ int orc_update_color(uint64_t *black, uint64_t *white, int64_t X, int64_t Ytot, 
 	const uint64_t *src = (color == ORC_BLACK) ? white : black;
 	uint64_t *dst = (color == ORC_BLACK) ? black : white;
 	const orc_view v = { src, src + (Ytot - 1)*g.lld, src, Ytot, 0, slV, YSL };
-	update_rows(dst, &v, &g, seed, it, color, tab, 0, Ytot);
+	update_rows(dst, &v, &g, NULL, seed, it, color, tab, 0, Ytot);
+	return 0;
+}
+
+/* same with coupling arrays: the reference passes hamW as jDst when it updates BLACK and hamB when it updates WHITE
+ * (optimized/main.cu:1774, :1795) -- restated as written. */
+int orc_update_color_J(uint64_t *black, uint64_t *white, const uint64_t *hamB, const uint64_t *hamW, int64_t X, int64_t Ytot,
+                       int64_t XSL, int64_t YSL, uint64_t seed, int it, int color, const float tab[10]) {
+	orc_geom g;
+	if (geom(X, Ytot, &g)) return -1;
+	if (XSL <= 0) XSL = X;
+	if (YSL <= 0) YSL = Ytot;
+	const int64_t slV = (XSL/2)/NIB/2;
+	if (slV <= 0 || g.vecs % slV || Ytot % YSL) return -2;
+	const uint64_t *src = (color == ORC_BLACK) ? white : black;
+	uint64_t *dst = (color == ORC_BLACK) ? black : white;
+	const uint64_t *jdst = (color == ORC_BLACK) ? hamW : hamB;
+	const orc_view v = { src, src + (Ytot - 1)*g.lld, src, Ytot, 0, slV, YSL };
+	update_rows(dst, &v, &g, jdst, seed, it, color, tab, 0, Ytot);
 	return 0;
 }
 
@@ -265,7 +381,7 @@ int orc_update_color_slab(uint64_t *dst, const uint64_t *src, const uint64_t *ha
 	orc_geom g;
 	if (geom(X, Y, &g) || r_lo < 0 || r_hi > Y || r_lo > r_hi) return -1;
 	const orc_view v = { src, halo_top, halo_bot, Y, row_base, g.vecs, 0 };
-	update_rows(dst, &v, &g, seed, it, color, tab, r_lo, r_hi);
+	update_rows(dst, &v, &g, NULL, seed, it, color, tab, r_lo, r_hi);
 	return 0;
 }
 
@@ -304,7 +420,7 @@ static int64_t bond_rows(const uint64_t *black, const orc_view *v, const orc_geo
 	for (int64_t i = 0; i < v->Y; i++) {
 		for (int64_t col = 0; col < g->vecs; col++) {
 			uint64_t sum[2];
-			neighbour_sums(v, g, ORC_BLACK, i, col, sum);
+			neighbour_sums(v, g, ORC_BLACK, i, col, NULL, sum);
 			for (int w = 0; w < 2; w++) {
 				const uint64_t me = black[i*g->lld + 2*col + w];
 				for (int z = 0; z < 64; z += 4) {

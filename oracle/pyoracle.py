@@ -51,6 +51,11 @@ def lib() -> C.CDLL:
         L.orc_dump_rows.argtypes = [u64p, u64p, C.c_int64, C.c_int64, C.c_int64, C.c_char_p]
         L.orc_dump_rows.restype = C.c_int64
         L.orc_corr.argtypes = [u64p, u64p, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64)]
+        L.orc_ham_init_black.argtypes = [u64p, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_float]
+        L.orc_ham_init_white.argtypes = [u64p, u64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64]
+        L.orc_update_color_J.argtypes = [u64p, u64p, u64p, u64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_uint64,
+                                         C.c_int, C.c_int, C.POINTER(C.c_float)]
+        L.orc_update_color_J.restype = C.c_int
         L.orc_site_draw.argtypes = [C.c_int64, C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int]
         L.orc_site_draw.restype = C.c_uint32
         L.orc_init_slab.argtypes = [u64p, u64p, C.c_int64, C.c_int64, C.c_int64, C.c_uint64]
@@ -117,6 +122,15 @@ class OracleLattice:
         self.it = 0
         return self
 
+    def init_couplings(self, prob: float):
+        """-J prob: hamiltInitB_k with seed+1, then hamiltInitW_k (optimized/main.cu:1729-1742)."""
+        p = float(np.float32(min(max(0.0, prob), 1.0)))
+        self.hamB = np.zeros_like(self.black)
+        self.hamW = np.zeros_like(self.white)
+        lib().orc_ham_init_black(_u64(self.hamB), self.X, self.Y, 0, C.c_uint64(self.seed + 1), C.c_float(p))
+        lib().orc_ham_init_white(_u64(self.hamB), _u64(self.hamW), self.X, self.Y, self.XSL, self.YSL)
+        return self
+
     def update_color(self, it: int, color: int):
         tab = (C.c_float * 10)()
         lib().orc_exp_table(C.c_float(self.temp), tab)
@@ -125,6 +139,16 @@ class OracleLattice:
         assert rc == 0, rc
 
     def sweep(self, n: int = 1):
+        if getattr(self, "hamB", None) is not None:
+            tab = (C.c_float * 10)()
+            lib().orc_exp_table(C.c_float(self.temp), tab)
+            for it in range(self.it + 1, self.it + 1 + n):
+                for color in (BLACK, WHITE):
+                    rc = lib().orc_update_color_J(_u64(self.black), _u64(self.white), _u64(self.hamB), _u64(self.hamW),
+                                                  self.X, self.Y, self.XSL, self.YSL, C.c_uint64(self.seed), it, color, tab)
+                    assert rc == 0, rc
+            self.it += n
+            return self
         rc = lib().orc_sweep(_u64(self.black), _u64(self.white), self.X, self.Y, self.XSL, self.YSL,
                              C.c_uint64(self.seed), self.it + 1, n, C.c_float(self.temp))
         assert rc == 0, rc

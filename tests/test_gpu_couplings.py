@@ -1,0 +1,70 @@
+"""-J (random anti-ferromagnetic bonds): coupling arrays and the coupled update against the oracle's literal
+restatement of hamiltInitB_k / hamiltInitW_k / the jDst branch of spinUpdateV_2D_k (optimized/main.cu:153-331, :575-618).
+The reference has no transcript for -J, so these vectors come from the oracle only."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import ising_gpu_amd as ig
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(os.path.dirname(ig.LIB_PATH), "cuIsing")
+
+
+@pytest.mark.parametrize("X,Y,prob,kernel", [(2048, 32, 0.3, ig.KERNEL_AUTO), (4096, 64, 0.5, ig.KERNEL_GENERIC), (6144, 48, 1.0, ig.KERNEL_AUTO),
+                                             (2048, 16, 0.0, ig.KERNEL_AUTO)])
+def test_couplings_and_update_bit_exact(gpu, oracle_mod, X, Y, prob, kernel):
+    orc = oracle_mod.OracleLattice(X, Y, seed=1234, temp=1.8).init().init_couplings(prob)
+    with ig.IsingSlab(X, Y, seed=1234, temp=1.8, J_prob=prob, kernel=kernel) as s:
+        s.init().init_couplings()
+        assert np.array_equal(s.read_couplings(ig.BLACK), orc.hamB)
+        assert np.array_equal(s.read_couplings(ig.WHITE), orc.hamW)
+        for n in (1, 5):
+            s.sweep(n)
+            orc.sweep(n)
+            assert np.array_equal(s.read(ig.BLACK), orc.black) and np.array_equal(s.read(ig.WHITE), orc.white), (prob, s.it)
+
+
+def test_couplings_with_sublattices(gpu, oracle_mod):
+    X, Y = 4096, 64
+    orc = oracle_mod.OracleLattice(X, Y, seed=9, temp=1.2, XSL=2048, YSL=32).init().init_couplings(0.4)
+    with ig.IsingSlab(X, Y, seed=9, temp=1.2, XSL=2048, YSL=32, J_prob=0.4) as s:
+        s.init().init_couplings()
+        assert np.array_equal(s.read_couplings(ig.WHITE), orc.hamW)
+        s.sweep(3)
+        orc.sweep(3)
+        assert np.array_equal(s.read(ig.BLACK), orc.black) and np.array_equal(s.read(ig.WHITE), orc.white)
+
+
+def test_couplings_ring_matches_single_slab(gpu):
+    X, Y, n = 4096, 192, 3
+    with ig.IsingSlab(X, Y, seed=4, temp=1.5, J_prob=0.35) as one:
+        one.init().init_couplings().sweep(4)
+        ref = (one.read(ig.BLACK), one.read(ig.WHITE), one.read_couplings(ig.WHITE))
+    slabs = [ig.IsingSlab(X, Y // n, seed=4, temp=1.5, nslabs=n, slab=k, J_prob=0.35) for k in range(n)]
+    try:
+        ring = ig.LocalRing([ig.HipSlabBackend(s) for s in slabs]).init()
+        ring.sweep(4)
+        assert np.array_equal(np.concatenate([s.read_couplings(ig.WHITE) for s in slabs]), ref[2])
+        assert np.array_equal(np.concatenate([s.read(ig.BLACK) for s in slabs]), ref[0])
+        assert np.array_equal(np.concatenate([s.read(ig.WHITE) for s in slabs]), ref[1])
+    finally:
+        for s in slabs:
+            s.close()
+
+
+def test_cli_J_transcript(gpu, oracle_mod):
+    X, Y, seed = 2048, 64, 606
+    for ndev, ylocal, extra in ((1, Y, []), (2, Y // 2, ["--devmap", "0,0"])):
+        r = subprocess.run([CLI, "-x", str(X), "-y", str(ylocal), "-d", str(ndev), "-n", "6", "-p", "3", "-t", "1.0", "-s", str(seed), "-J", "0.25"] + extra,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert "\tusing Hamiltonian buffer, setting links to -1 with prob 0.25\n" in r.stdout
+        orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=1.0).init().init_couplings(0.25)
+        for it in (3, 6):
+            orc.sweep(it - orc.it)
+            up, dw = orc.count()
+            assert f"up_s: {up:12d}, dw_s: {dw:12d} (iter: {it:8d})" in r.stdout, (ndev, it)
