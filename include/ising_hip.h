@@ -177,7 +177,8 @@ int ising_ring_synchronize(ising_ctx **ctxs, int n);
  * (ncorr <= 128 = MAX_CORR_LEN, :70)  sums[j-1] = sum over all sites of [s(r,c)==s(r,c+j) ? +1 : -1] +
  * [s(r,c)==s(r+j,c) ? +1 : -1], columns periodic in X, rows periodic in the whole lattice.  These are the exact
  * integers the reference accumulates in doubles; it then prints sums[j-1] / (2*X*Y*ndev) (:1131).  Each slab needs
- * at least ncorr rows.  Not available with sub-lattices (the reference uses a different kernel there).  Blocking. */
+ * at least ncorr rows.  With sub-lattices both wraps stay inside the site's own sub-lattice (getCorr2DRepl_k, :967-1070)
+ * and YSL must be >= ncorr.  Blocking. */
 int ising_correlations(ising_ctx *ctx, int ncorr, int64_t *sums);            /* nslabs == 1 */
 int ising_ring_correlations(ising_ctx **ctxs, int n, int ncorr, int64_t *sums); /* totals over all slabs of a ring */
 

@@ -5,7 +5,7 @@
 //            -o/--out -h, plus --energy (build-side addition: prints the energy per spin next to each
 //            magnetisation line) and --devmap a,b,.. (place slab k on device devmap[k]; lets a 1-GPU box run -d N).
 //            --xsl/--ysl (independent periodic sub-lattices, optimized/main.cu:1423-1462),
-//            -c/--corr (two-point correlations file, optimized/main.cu:1072-1138; not together with sub-lattices).
+//            -c/--corr (two-point correlations file, optimized/main.cu:1072-1138).
 //            -J <PROB> (random anti-ferromagnetic bonds, optimized/main.cu:153-331, :575-618).
 #include "../../include/ising_hip.h"
 
@@ -277,7 +277,7 @@ int main(int argc, char **argv) {
 	}
 
 	if (corrOut) { // optimized/main.cu:1660-1663
-		if (useSubLatt) { fprintf(stderr, "-c together with --xsl/--ysl is not supported by this build\n"); exit(EXIT_FAILURE); }
+		if (useSubLatt && YSL < MAX_CORR_LEN) { fprintf(stderr, "-c needs sub-lattices of at least %d rows\n", MAX_CORR_LEN); exit(EXIT_FAILURE); }
 		snprintf(cname, sizeof(cname), "corr_%dx%d_T_%f_%llu", Y, X, temp, seed);
 		remove(cname);
 	}

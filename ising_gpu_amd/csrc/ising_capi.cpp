@@ -651,7 +651,7 @@ int ising_ring_correlations(ising_ctx **ctxs, int n, int ncorr, int64_t *sums) {
 	if (!sums || ncorr < 1 || ncorr > 128) return fail(ISING_E_ARG, "ncorr must be in [1,128]");
 	for (int k = 0; k < n; k++) {
 		ising_ctx *c = ctxs[k];
-		if (c->cfg.XSL) return fail(ISING_E_STATE, "correlations with sub-lattices are not supported");
+		if (c->cfg.XSL && c->cfg.YSL < ncorr) return fail(ISING_E_ARG, "sub-lattices need at least %d rows for %d correlation distances", ncorr, ncorr);
 		if (c->cfg.Y < ncorr) return fail(ISING_E_ARG, "each slab needs at least %d rows for %d correlation distances", ncorr, ncorr);
 		if (int rc = bind(c)) return rc;
 		if (!c->d_bits || c->d_bits_extra < ncorr) {
@@ -670,9 +670,11 @@ int ising_ring_correlations(ising_ctx **ctxs, int n, int ncorr, int64_t *sums) {
 	for (int k = 0; k < n; k++) {
 		ising_ctx *c = ctxs[k], *next = ctxs[(k + 1) % n];
 		if (int rc = bind(c)) return rc;
-		HIP_TRY(hipMemcpyPeerAsync(c->d_bits + (size_t)c->cfg.Y * c->lld, c->cfg.device, next->d_bits, next->cfg.device,
-		                           (size_t)ncorr * c->lld * sizeof(uint32_t), c->stream));
-		HIP_TRY(ising::launch_corr(c->d_bits, c->lld, c->cfg.Y, ncorr, c->d_corr, c->stream));
+		if (!c->cfg.XSL) // sub-lattices never look past their own rows
+			HIP_TRY(hipMemcpyPeerAsync(c->d_bits + (size_t)c->cfg.Y * c->lld, c->cfg.device, next->d_bits, next->cfg.device,
+			                           (size_t)ncorr * c->lld * sizeof(uint32_t), c->stream));
+		HIP_TRY(ising::launch_corr(c->d_bits, c->lld, c->cfg.Y, ncorr, c->cfg.XSL ? c->cfg.XSL / 32 : c->lld,
+		                           c->cfg.XSL ? c->cfg.YSL : 0, c->d_corr, c->stream));
 	}
 	std::vector<long long> h(ncorr);
 	for (int j = 0; j < ncorr; j++) sums[j] = 0;

@@ -84,6 +84,6 @@ hipError_t launch_ham_init_white(const HamWhiteParams &p, hipStream_t stream);
 hipError_t launch_pack_bits(const uint64_t *black, const uint64_t *white, int lld, int Y, uint32_t row_base, uint32_t *bits,
                             hipStream_t stream);
 // two-point sums for distances 1..ncorr over slab rows 0..Y-1; `bits` must hold Y + ncorr rows
-hipError_t launch_corr(const uint32_t *bits, int lld, int Y, int ncorr, long long *sums, hipStream_t stream);
+hipError_t launch_corr(const uint32_t *bits, int lld, int Y, int ncorr, int slW, int slY, long long *sums, hipStream_t stream);
 
 } // namespace ising

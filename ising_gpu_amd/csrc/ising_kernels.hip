@@ -640,19 +640,24 @@ __global__ void __launch_bounds__(THREADS) pack_bits_k(const uint64_t *__restric
 //   sum_c [s(r,c) == s(r,c+j)] - [!=]  +  [s(r,c) == s(r+j,c)] - [!=]      (c periodic in X; rows r+j come from `bits`
 // rows up to Y+ncorr-1, which the host fills with the rows that follow this slab).
 __global__ void __launch_bounds__(THREADS) corr_k(const uint32_t *__restrict__ bits, int lld, int Y, int rows_per_block,
-                                                  long long *__restrict__ sums) {
+                                                  int slW, int slY, long long *__restrict__ sums) {
+	// slW: words per periodic segment of a row (= lld without sub-lattices); slY: rows per sub-lattice, 0 = none (then the
+	// vertical partner of row r is row r+j of `bits`, which holds ncorr extra rows).  getCorr2DRepl_k :967-1070.
 	__shared__ long long part[THREADS / 64];
 	const int j = blockIdx.y + 1;
 	const int wsh = j >> 5, bsh = j & 31;
 	const int r_lo = blockIdx.x * rows_per_block, r_hi = min(Y, r_lo + rows_per_block);
 	long long acc = 0;
 	for (int r = r_lo; r < r_hi; ++r) {
-		const uint32_t *row = bits + (size_t)r * lld, *rowv = bits + (size_t)(r + j) * lld;
+		int rv = r + j;
+		if (slY && rv >= (r / slY + 1) * slY) rv -= slY;
+		const uint32_t *row = bits + (size_t)r * lld, *rowv = bits + (size_t)rv * lld;
 		for (int q = threadIdx.x; q < lld; q += THREADS) {
 			const uint32_t a = row[q];
-			int q0 = q + wsh; if (q0 >= lld) q0 -= lld;
-			int q1 = q0 + 1;  if (q1 >= lld) q1 -= lld;
-			const uint32_t h = bsh ? __builtin_amdgcn_alignbit(row[q1], row[q0], bsh) : row[q0]; // columns 32q+j .. 32q+j+31
+			const int seg = (q / slW) * slW;
+			int q0 = q - seg + wsh; if (q0 >= slW) q0 -= slW;
+			int q1 = q0 + 1;        if (q1 >= slW) q1 -= slW;
+			const uint32_t h = bsh ? __builtin_amdgcn_alignbit(row[seg + q1], row[seg + q0], bsh) : row[seg + q0]; // columns +j
 			acc += 64 - 2 * (int)(__popc(a ^ h) + __popc(a ^ rowv[q]));
 		}
 	}
@@ -678,10 +683,10 @@ hipError_t launch_pack_bits(const uint64_t *black, const uint64_t *white, int ll
 	return hipGetLastError();
 }
 
-hipError_t launch_corr(const uint32_t *bits, int lld, int Y, int ncorr, long long *sums, hipStream_t stream) {
+hipError_t launch_corr(const uint32_t *bits, int lld, int Y, int ncorr, int slW, int slY, long long *sums, hipStream_t stream) {
 	const int rows_per_block = 16;
 	const dim3 grid((Y + rows_per_block - 1) / rows_per_block, ncorr);
-	hipLaunchKernelGGL(corr_k, grid, dim3(THREADS), 0, stream, bits, lld, Y, rows_per_block, sums);
+	hipLaunchKernelGGL(corr_k, grid, dim3(THREADS), 0, stream, bits, lld, Y, rows_per_block, slW, slY, sums);
 	return hipGetLastError();
 }
 

@@ -463,16 +463,20 @@ static inline int spin_at(const uint64_t *black, const uint64_t *white, int64_t 
 	return (int)((a[r*lld + k/NIB] >> (4*(k % NIB))) & 0xF);
 }
 
-void orc_corr(const uint64_t *black, const uint64_t *white, int64_t X, int64_t Ytot, int ncorr, int64_t *sums) {
+void orc_corr(const uint64_t *black, const uint64_t *white, int64_t X, int64_t Ytot, int64_t XSL, int64_t YSL, int ncorr, int64_t *sums) {
+	/* XSL/YSL > 0: getCorr2DRepl_k (optimized/main.cu:967-1070), both wraps stay inside the site's own sub-lattice */
 	const int64_t lld = X/32;
+	if (XSL <= 0) XSL = X;
+	if (YSL <= 0) YSL = Ytot;
 	for (int j = 1; j <= ncorr; j++) {
 		int64_t acc = 0;
 		#pragma omp parallel for reduction(+:acc) schedule(static)
 		for (int64_t r = 0; r < Ytot; r++) {
-			const int64_t rv = (r + j) % Ytot;
+			const int64_t rv = (r + j >= (r/YSL + 1)*YSL) ? r + j - YSL : r + j;   /* :1038, :934 */
 			for (int64_t c = 0; c < X; c++) {
+				const int64_t c0 = (c/XSL)*XSL;
 				const int me = spin_at(black, white, lld, r, c);
-				acc += (me == spin_at(black, white, lld, r, (c + j) % X)) ? 1 : -1;
+				acc += (me == spin_at(black, white, lld, r, c0 + (c - c0 + j) % XSL)) ? 1 : -1;
 				acc += (me == spin_at(black, white, lld, rv, c)) ? 1 : -1;
 			}
 		}

@@ -50,7 +50,7 @@ def lib() -> C.CDLL:
         L.orc_bond_equal.restype = C.c_int64
         L.orc_dump_rows.argtypes = [u64p, u64p, C.c_int64, C.c_int64, C.c_int64, C.c_char_p]
         L.orc_dump_rows.restype = C.c_int64
-        L.orc_corr.argtypes = [u64p, u64p, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64)]
+        L.orc_corr.argtypes = [u64p, u64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64)]
         L.orc_ham_init_black.argtypes = [u64p, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_float]
         L.orc_ham_init_white.argtypes = [u64p, u64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64]
         L.orc_update_color_J.argtypes = [u64p, u64p, u64p, u64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_uint64,
@@ -169,7 +169,7 @@ class OracleLattice:
 
     def corr(self, ncorr: int = 128):
         out = (C.c_int64 * ncorr)()
-        lib().orc_corr(_u64(self.black), _u64(self.white), self.X, self.Y, ncorr, out)
+        lib().orc_corr(_u64(self.black), _u64(self.white), self.X, self.Y, self.XSL, self.YSL, ncorr, out)
         return [int(v) for v in out]
 
     def dump_rows(self, row0: int, nrows: int) -> bytes:

@@ -48,3 +48,12 @@ def test_cli_corr_file_format(gpu, oracle_mod, tmp_path):
         orc.sweep(it - orc.it)
         want = "%10d" % it + "".join(" % -12G" % (v / (2.0 * X * Y)) for v in orc.corr(128))
         assert line == want
+
+
+def test_correlations_with_sublattices(gpu, oracle_mod):
+    """getCorr2DRepl_k (optimized/main.cu:967-1070): wraps stay inside each XSL x YSL replica."""
+    X, Y, XSL, YSL = 4096, 256, 2048, 128
+    orc = oracle_mod.OracleLattice(X, Y, seed=13, temp=1.9, XSL=XSL, YSL=YSL).init().sweep(6)
+    with ig.IsingSlab(X, Y, seed=13, temp=1.9, XSL=XSL, YSL=YSL) as s:
+        s.init().sweep(6)
+        assert s.correlations(128) == orc.corr(128)
