@@ -92,9 +92,11 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    slab = ig.IsingSlab(args.x, args.y, seed=args.seed, temp=ig.CRIT_TEMP_F32, nslabs=world, slab=rank,
-                        device=local_rank, strip_rows=args.strip_rows)
-    ring = ig.SlabRing(ig.HipSlabBackend(slab))
+    # torch owns the slab's device buffer, so the rows RCCL sends/receives are slices of an ordinary torch tensor
+    backend = ig.HipSlabBackend.create(args.x, args.y, device=local_rank, seed=args.seed, temp=ig.CRIT_TEMP_F32,
+                                       nslabs=world, slab=rank, strip_rows=args.strip_rows)
+    slab = backend.slab
+    ring = ig.SlabRing(backend)
     ring.init()
 
     def barrier():

@@ -68,6 +68,10 @@ typedef struct ising_config {
 	int32_t YSL;      /* --ysl: sub-lattice rows (multiple of 16 dividing Y).  With sub-lattices every XSL x YSL block of
 	                     the slab is an independent periodic system (optimized/main.cu:1423-1462; loadTile wrap arguments
 	                     slX, slY :413-459), so no halo exchange is needed. */
+	void *lattice_mem;   /* optional caller-owned device buffer of ising_required_bytes() bytes for the spin arrays (e.g. a
+	                        torch tensor, so that its edge/halo rows can be handed to RCCL as ordinary tensors); NULL = the
+	                        library allocates */
+	void *coupling_mem;  /* the same for the -J coupling arrays */
 	int32_t use_J;    /* -J given: allocate coupling arrays and apply them in every update (useGenHamilt, :1368-1372) */
 	float J_prob;     /* -J <PROB>: probability that a bond is anti-ferromagnetic, clamped to [0,1] (:1370) */
 } ising_config;
@@ -78,6 +82,9 @@ const char *ising_last_error(void);
 int ising_device_count(int *count);
 /* Device description for the "Using GPUs" block (optimized/main.cu:1482-1490). */
 int ising_device_info(int device, char *name, size_t name_len, int *cus, int *max_threads_per_cu, int *major, int *minor);
+
+/* Bytes of one device buffer (spins; the coupling buffer has the same size): 2 colours x (Y + 2) rows x X/4 bytes. */
+size_t ising_required_bytes(int32_t X, int32_t Y);
 
 /* Allocates the slab (both colours, zeroed), halo-receive rows and the threshold/exp tables.
  * Replaces the cudaMalloc/cudaMallocManaged + memset + exp_d upload of optimized/main.cu:1599-1703. */

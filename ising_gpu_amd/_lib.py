@@ -23,6 +23,7 @@ class IsingConfig(C.Structure):
         ("X", C.c_int32), ("Y", C.c_int32), ("nslabs", C.c_int32), ("slab", C.c_int32),
         ("seed", C.c_uint64), ("temp", C.c_float), ("device", C.c_int32),
         ("strip_rows", C.c_int32), ("kernel", C.c_int32), ("XSL", C.c_int32), ("YSL", C.c_int32),
+        ("lattice_mem", C.c_void_p), ("coupling_mem", C.c_void_p),
         ("use_J", C.c_int32), ("J_prob", C.c_float),
     ]
 
@@ -39,6 +40,7 @@ PROTOTYPES = {
     "ising_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "ising_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ising_required_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "ising_create": (C.c_int, [C.POINTER(IsingConfig), C.POINTER(C.c_void_p)]),
     "ising_destroy": (C.c_int, [C.c_void_p]),
     "ising_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

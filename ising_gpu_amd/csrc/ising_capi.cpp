@@ -175,6 +175,11 @@ int ising_device_info(int device, char *name, size_t name_len, int *cus, int *ma
 	return ISING_OK;
 }
 
+size_t ising_required_bytes(int32_t X, int32_t Y) {
+	if (X <= 0 || Y <= 0) return 0;
+	return 2 * ((size_t)Y + 2) * (size_t)(X / 32) * sizeof(uint64_t);
+}
+
 int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (!cfg || !out) return fail(ISING_E_ARG, "null argument");
 	*out = nullptr;
@@ -205,12 +210,16 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	compute_tables(c, cfg->temp);
 
 	hipError_t e = hipSetDevice(cfg->device);
-	if (e == hipSuccess) e = hipMalloc((void **)&c->d_lat, c->alloc_words() * sizeof(uint64_t));
+	if (e == hipSuccess) {
+		if (cfg->lattice_mem) c->d_lat = static_cast<uint64_t *>(cfg->lattice_mem);
+		else e = hipMalloc((void **)&c->d_lat, c->alloc_words() * sizeof(uint64_t));
+	}
 	if (e == hipSuccess) e = hipMemset(c->d_lat, 0, c->alloc_words() * sizeof(uint64_t)); // optimized/main.cu:1603
 	if (e == hipSuccess) e = hipMalloc((void **)&c->d_acc, 2 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMalloc((void **)&c->d_lut, 65536);
 	if (e == hipSuccess && cfg->use_J) {
-		e = hipMalloc((void **)&c->d_ham, c->alloc_words() * sizeof(uint64_t));
+		if (cfg->coupling_mem) c->d_ham = static_cast<uint64_t *>(cfg->coupling_mem);
+		else e = hipMalloc((void **)&c->d_ham, c->alloc_words() * sizeof(uint64_t));
 		if (e == hipSuccess) e = hipMemset(c->d_ham, 0, c->alloc_words() * sizeof(uint64_t)); // optimized/main.cu:1609
 	}
 	if (e != hipSuccess) {
@@ -225,10 +234,10 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 int ising_destroy(ising_ctx *c) {
 	if (!c) return ISING_OK;
 	(void)hipSetDevice(c->cfg.device);
-	if (c->d_lat) (void)hipFree(c->d_lat);
+	if (c->d_lat && !c->cfg.lattice_mem) (void)hipFree(c->d_lat);
 	if (c->d_acc) (void)hipFree(c->d_acc);
 	if (c->d_lut) (void)hipFree(c->d_lut);
-	if (c->d_ham) (void)hipFree(c->d_ham);
+	if (c->d_ham && !c->cfg.coupling_mem) (void)hipFree(c->d_ham);
 	if (c->d_bits) (void)hipFree(c->d_bits);
 	if (c->d_corr) (void)hipFree(c->d_corr);
 	for (int k = 0; k < 2; k++) if (c->ev_sent[k]) (void)hipEventDestroy(c->ev_sent[k]);

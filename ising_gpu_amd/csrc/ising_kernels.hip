@@ -291,9 +291,10 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 	const int offR0 = 4, offR1 = (((col0 + GROUP + 1) % slV) == 0 ? 1 - slV + GROUP : GROUP + 1) * 4;
 	// Row wrap: without sub-lattices rows -1 and Y are the physical halo rows; with them (--ysl) the row above the
 	// first row of a sub-lattice is its last row and vice versa (loadTile, optimized/main.cu:414,:422).
+	// `seam` counts the rows left in the current sub-lattice (one integer division per strip, none per row).
 	const int slY = p.slY;
-	auto up_off = [&](int row) -> ptrdiff_t { return (slY && (row % slY) == 0) ? (ptrdiff_t)(slY - 1) * vecs : -(ptrdiff_t)vecs; };
-	auto dw_off = [&](int row) -> ptrdiff_t { return (slY && ((row + 1) % slY) == 0) ? (ptrdiff_t)(1 - slY) * vecs : (ptrdiff_t)vecs; };
+	const int r0_in_sl = slY ? r0 % slY : 1;
+	int seam = slY ? slY - r0_in_sl : 0x7fffffff;
 
 	// Rows -1 and Y of every colour array are physically present (halo rows), so row r lives at src + r*vecs.
 	const uint4 *pc = reinterpret_cast<const uint4 *>(p.src) + ((ptrdiff_t)r0 * vecs + col0); // centre row, own vector
@@ -311,7 +312,7 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 #define DBG_LD(expr) (expr)
 #define DBG_LDW(expr) (expr)
 #endif
-	const ptrdiff_t uo = up_off(r0);
+	const ptrdiff_t uo = (slY && r0_in_sl == 0) ? (ptrdiff_t)(slY - 1) * vecs : -(ptrdiff_t)vecs;
 	uint4 up0 = DBG_LD(pc[uo]), up1 = DBG_LD(pc[uo + GROUP]);
 	uint4 ct0 = DBG_LD(pc[0]), ct1 = DBG_LD(pc[GROUP]);
 
@@ -320,7 +321,8 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 		const uint32_t grow = p.row_base + (uint32_t)lr;
 		const bool back = (p.color == 0) ? !(grow & 1u) : (grow & 1u); // readBack, optimized/main.cu:542
 		// issue this row's loads; they are consumed only after the 16 Philox blocks below
-		const ptrdiff_t dwo = dw_off(lr);
+		const bool sl_last = seam == 1; // last row of its sub-lattice: the row below is the sub-lattice's first row
+		const ptrdiff_t dwo = sl_last ? (ptrdiff_t)(1 - slY) * vecs : (ptrdiff_t)vecs;
 		const uint4 dw0 = DBG_LD(pc[dwo]), dw1 = DBG_LD(pc[dwo + GROUP]);
 		const uint32_t *pcw = reinterpret_cast<const uint32_t *>(pc);
 		const uint32_t side0 = DBG_LDW(pcw[back ? offL0 : offR0]);
@@ -415,14 +417,16 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 		}
 		pc += vecs;
 		pm += vecs;
-		if (slY && ((lr + 1) % slY) == 0) {
+		if (sl_last) {
 			// the next row opens a new sub-lattice: the register window does not slide across the seam
+			seam = slY;
 			if (r + 1 < nrows) {
 				const ptrdiff_t uo2 = (ptrdiff_t)(slY - 1) * vecs;
 				up0 = pc[uo2]; up1 = pc[uo2 + GROUP];
 				ct0 = pc[0]; ct1 = pc[GROUP];
 			}
 		} else {
+			--seam;
 			up0 = ct0; up1 = ct1;
 			ct0 = dw0; ct1 = dw1;
 		}

@@ -26,10 +26,11 @@ class IsingSlab:
 
     def __init__(self, X: int, Y: int, seed: int = _lib.SEED_DEF, temp: float = 0.1 * _lib.CRIT_TEMP_F32,
                  nslabs: int = 1, slab: int = 0, device: int = 0, strip_rows: int = 0, kernel: int = _lib.KERNEL_AUTO,
-                 XSL: int = 0, YSL: int = 0, J_prob: float | None = None):
+                 XSL: int = 0, YSL: int = 0, J_prob: float | None = None, lattice_mem: int = 0, coupling_mem: int = 0):
         self._lib = _lib.load()
         self.cfg = IsingConfig(X=X, Y=Y, nslabs=nslabs, slab=slab, seed=seed, temp=float(np.float32(temp)),
                                device=device, strip_rows=strip_rows, kernel=kernel, XSL=XSL, YSL=YSL,
+                               lattice_mem=lattice_mem or None, coupling_mem=coupling_mem or None,
                                use_J=0 if J_prob is None else 1, J_prob=0.0 if J_prob is None else float(J_prob))
         self.use_J = J_prob is not None
         self._h = C.c_void_p()
@@ -152,6 +153,11 @@ class IsingSlab:
 
     def dump(self, prefix: str):
         check(self._lib.ising_dump_text(self._h, prefix.encode()))
+
+
+def required_bytes(X: int, Y: int) -> int:
+    """Size of the device buffer a slab needs for its spin arrays (and, again, for its coupling arrays)."""
+    return int(_lib.load().ising_required_bytes(X, Y))
 
 
 def magnetization(up: int, down: int) -> float:

@@ -47,18 +47,40 @@ class _DevMem:
 
 
 class HipSlabBackend:
-    """IsingSlab (libising_hip.so) as a ring backend; kernels run on torch's current stream."""
+    """IsingSlab (libising_hip.so) as a ring backend; kernels run on torch's current stream.
 
-    def __init__(self, slab):
+    `HipSlabBackend.create(...)` lets torch own the slab's device buffers (the C-ABI takes them as plain pointers),
+    so the edge and halo rows RCCL touches are slices of ordinary torch tensors.  Wrapping an existing IsingSlab
+    instead exposes the library-owned rows zero-copy through __cuda_array_interface__."""
+
+    def __init__(self, slab, buffers=None):
         self.slab = slab
         self.device = torch.device("cuda", slab.cfg.device)
         slab.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self._buffers = buffers or {}
         self._halo = {}
         self.use_J = bool(getattr(slab, "use_J", False))
         if slab.nslabs > 1:
             for color in (BLACK, WHITE) + ((HAM_BLACK,) if self.use_J else ()):
                 ptrs, nb = slab.halo_ptrs(color)
-                self._halo[color] = tuple(torch.as_tensor(_DevMem(p, nb), device=self.device) for p in ptrs)
+                buf = self._buffers.get("coupling" if color == HAM_BLACK else "lattice")
+                if buf is not None:
+                    base = buf.data_ptr()
+                    self._halo[color] = tuple(buf[p - base:p - base + nb] for p in ptrs)
+                else:
+                    self._halo[color] = tuple(torch.as_tensor(_DevMem(p, nb), device=self.device) for p in ptrs)
+
+    @classmethod
+    def create(cls, X, Y, device=0, J_prob=None, **kw):
+        from .lattice import IsingSlab, required_bytes
+        dev = torch.device("cuda", device)
+        nbytes = required_bytes(X, Y)
+        bufs = {"lattice": torch.empty(nbytes, dtype=torch.uint8, device=dev)}
+        if J_prob is not None:
+            bufs["coupling"] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        slab = IsingSlab(X, Y, device=device, J_prob=J_prob, lattice_mem=bufs["lattice"].data_ptr(),
+                         coupling_mem=bufs["coupling"].data_ptr() if "coupling" in bufs else 0, **kw)
+        return cls(slab, bufs)
 
     def init(self):
         self.slab.init()

@@ -36,3 +36,24 @@ def test_single_rank_slabring_is_plain_sweep(gpu, oracle_mod):
         orc = oracle_mod.OracleLattice(2048, 64, seed=11, temp=2.0).init().sweep(4)
         assert np.array_equal(s.read(ig.BLACK), orc.black) and np.array_equal(s.read(ig.WHITE), orc.white)
         assert ring.count() == orc.count()
+
+
+def test_local_ring_on_torch_owned_buffers(gpu):
+    """HipSlabBackend.create: torch allocates the slab buffers (the C-ABI sees plain pointers); halo tensors are
+    slices of those tensors -- the form the RCCL path sends and receives."""
+    X, Y, n, seed, temp, sweeps = 4096, 144, 3, 77, 2.0, 4
+    with ig.IsingSlab(X, Y, seed=seed, temp=temp) as one:
+        one.init().sweep(sweeps)
+        ref_b, ref_w = one.read(ig.BLACK), one.read(ig.WHITE)
+    backs = [ig.HipSlabBackend.create(X, Y // n, seed=seed, temp=temp, nslabs=n, slab=k) for k in range(n)]
+    try:
+        ring = ig.LocalRing(backs).init()
+        ring.sweep(sweeps)
+        assert np.array_equal(np.concatenate([b.slab.read(ig.BLACK) for b in backs]), ref_b)
+        assert np.array_equal(np.concatenate([b.slab.read(ig.WHITE) for b in backs]), ref_w)
+        for b in backs:
+            for t in b.halo_tensors(ig.BLACK):
+                assert t.untyped_storage().data_ptr() == b._buffers["lattice"].untyped_storage().data_ptr()
+    finally:
+        for b in backs:
+            b.slab.close()
