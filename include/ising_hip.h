@@ -52,6 +52,13 @@ enum {
 	                             speed in the power-limited regime); error if thresholds do not fit */
 };
 
+/* device layout of the spin arrays.  The C-ABI always speaks the reference's packed layout (read/write/dump convert). */
+enum {
+	ISING_LAYOUT_AUTO = 0,   /* dense unless a feature needs the nibble layout (-J couplings, sub-lattices) */
+	ISING_LAYOUT_NIBBLE = 1, /* the reference's: 4 bits per spin, 16 spins per 64-bit word (optimized/main.cu:40, :1243) */
+	ISING_LAYOUT_DENSE = 2   /* 1 bit per spin, 32 spins per 32-bit word = one reference 128-bit vector per word */
+};
+
 typedef struct ising_ctx ising_ctx;
 
 typedef struct ising_config {
@@ -72,6 +79,7 @@ typedef struct ising_config {
 	                        torch tensor, so that its edge/halo rows can be handed to RCCL as ordinary tensors); NULL = the
 	                        library allocates */
 	void *coupling_mem;  /* the same for the -J coupling arrays */
+	int32_t layout;   /* ISING_LAYOUT_* */
 	int32_t use_J;    /* -J given: allocate coupling arrays and apply them in every update (useGenHamilt, :1368-1372) */
 	float J_prob;     /* -J <PROB>: probability that a bond is anti-ferromagnetic, clamped to [0,1] (:1370) */
 } ising_config;
@@ -158,8 +166,11 @@ int ising_bond_equal(ising_ctx *ctx, int64_t *A);
 int ising_read_packed(ising_ctx *ctx, int color, int64_t row0, int64_t nrows, uint64_t *dst_host);
 int ising_write_packed(ising_ctx *ctx, int color, int64_t row0, int64_t nrows, const uint64_t *src_host);
 
-/* Device pointer to a colour array of this slab ([Y][X/32] words) for zero-copy consumers. */
+/* Device pointer to row 0 of a colour array of this slab in its DEVICE layout (see ising_layout) for zero-copy
+ * consumers: nibble layout = [Y][X/32] 64-bit words exactly as the reference's buffers; dense = [Y][X/64] 32-bit words. */
 int ising_device_ptr(ising_ctx *ctx, int color, void **ptr, size_t *bytes);
+/* The layout in use (ISING_LAYOUT_NIBBLE or ISING_LAYOUT_DENSE). */
+int ising_layout(ising_ctx *ctx, int *layout);
 
 /* dumpLattice (optimized/main.cu:1140-1209): writes "<prefix><slab>.txt", one text row per lattice row, one
  * hex digit per spin, colours interleaved by row parity. */

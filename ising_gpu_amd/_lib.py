@@ -16,6 +16,7 @@ HAM_BLACK = 2  # the black coupling array as a third plane for halo exchange
 CRIT_TEMP_F32 = 2.2691853046417236  # float32(2.26918531421f), CRIT_TEMP optimized/main.cu:42
 SEED_DEF = 463463564571  # optimized/main.cu:63
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST, KERNEL_LUT = 0, 1, 2, 3
+LAYOUT_AUTO, LAYOUT_NIBBLE, LAYOUT_DENSE = 0, 1, 2
 
 
 class IsingConfig(C.Structure):
@@ -24,7 +25,7 @@ class IsingConfig(C.Structure):
         ("seed", C.c_uint64), ("temp", C.c_float), ("device", C.c_int32),
         ("strip_rows", C.c_int32), ("kernel", C.c_int32), ("XSL", C.c_int32), ("YSL", C.c_int32),
         ("lattice_mem", C.c_void_p), ("coupling_mem", C.c_void_p),
-        ("use_J", C.c_int32), ("J_prob", C.c_float),
+        ("layout", C.c_int32), ("use_J", C.c_int32), ("J_prob", C.c_float),
     ]
 
 
@@ -64,6 +65,7 @@ PROTOTYPES = {
     "ising_read_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
     "ising_write_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
     "ising_device_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "ising_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "ising_dump_text": (C.c_int, [C.c_void_p, C.c_char_p]),
     "ising_ring_exchange": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "ising_ring_sweep": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),

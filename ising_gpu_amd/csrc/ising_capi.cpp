@@ -56,7 +56,9 @@ uint64_t draw_prefix(float p, bool le) {
 
 struct ising_ctx {
 	ising_config cfg{};
-	int lld = 0;      // 64-bit words per colour row
+	bool dense = false; // 1 bit per spin on the device (ising_dense.hip); false = the reference's nibble layout
+	int lld_packed = 0; // 64-bit words per colour row in the reference's packed layout (X/32)
+	int lld = 0;      // 64-bit words per colour row in the DEVICE layout (X/32 nibble, X/128 dense)
 	int gx = 0;       // X/2048
 	int H = 0;        // rows per strip
 	int nstrips = 0;
@@ -139,6 +141,33 @@ void build_rank_table(const ising_ctx *c, uint8_t *tab) {
 	}
 }
 
+// Dense device rows <-> the reference's packed rows, on the host (the C-ABI boundary always speaks the packed layout).
+// One dense 32-bit word = one reference 128-bit vector: bit k -> nibble k of word x (k < 16) / nibble k-16 of word y.
+void dense_to_packed(const uint32_t *dense, uint64_t *packed, size_t nvec) {
+	for (size_t v = 0; v < nvec; v++) {
+		const uint32_t d = dense[v];
+		uint64_t x = 0, y = 0;
+		for (int k = 0; k < 16; k++) {
+			x |= (uint64_t)((d >> k) & 1u) << (4 * k);
+			y |= (uint64_t)((d >> (16 + k)) & 1u) << (4 * k);
+		}
+		packed[2 * v] = x;
+		packed[2 * v + 1] = y;
+	}
+}
+
+void packed_to_dense(const uint64_t *packed, uint32_t *dense, size_t nvec) {
+	for (size_t v = 0; v < nvec; v++) {
+		const uint64_t x = packed[2 * v], y = packed[2 * v + 1];
+		uint32_t d = 0;
+		for (int k = 0; k < 16; k++) {
+			d |= (uint32_t)((x >> (4 * k)) & 1u) << k;
+			d |= (uint32_t)((y >> (4 * k)) & 1u) << (16 + k);
+		}
+		dense[v] = d;
+	}
+}
+
 int choose_strip_rows(int gx, int Y) {
 	// Enough (column-group x strip) units to give every SIMD several waves, while keeping strips tall so the two
 	// halo rows per strip stay a small fraction of the source traffic.
@@ -201,7 +230,18 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 
 	ising_ctx *c = new ising_ctx();
 	c->cfg = *cfg;
-	c->lld = cfg->X / 32;
+	if (cfg->layout != ISING_LAYOUT_AUTO && cfg->layout != ISING_LAYOUT_NIBBLE && cfg->layout != ISING_LAYOUT_DENSE) {
+		delete c;
+		return fail(ISING_E_ARG, "bad layout %d", cfg->layout);
+	}
+	const bool needs_nibble = cfg->use_J || cfg->XSL;
+	if (cfg->layout == ISING_LAYOUT_DENSE && needs_nibble) {
+		delete c;
+		return fail(ISING_E_ARG, "-J couplings and sub-lattices need the nibble layout");
+	}
+	c->dense = cfg->layout == ISING_LAYOUT_DENSE || (cfg->layout == ISING_LAYOUT_AUTO && !needs_nibble);
+	c->lld_packed = cfg->X / 32;
+	c->lld = c->dense ? cfg->X / 128 : cfg->X / 32;
 	c->gx = cfg->X / 2048;
 	c->H = cfg->strip_rows > 0 ? cfg->strip_rows : choose_strip_rows(c->gx, cfg->Y);
 	if (cfg->Y % c->H) { const int h = c->H; delete c; return fail(ISING_E_ARG, "strip_rows %d does not divide Y %d", h, cfg->Y); }
@@ -273,7 +313,7 @@ int ising_init_lattice(ising_ctx *c) {
 		p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
 		p.wrap = c->cfg.nslabs == 1;
 		p.thr_half = (uint32_t)half;
-		HIP_TRY(ising::launch_init(p, c->stream));
+		HIP_TRY(c->dense ? ising::launch_dense_init(p, c->stream) : ising::launch_init(p, c->stream));
 	}
 	return ISING_OK;
 }
@@ -340,6 +380,10 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	p.lut = c->d_lut;
 	// the reference hands hamW to the BLACK update and hamB to the WHITE one (optimized/main.cu:1774, :1795)
 	p.jdst = c->cfg.use_J ? c->ham(other) : nullptr;
+	if (c->dense) {
+		HIP_TRY(ising::launch_dense_update(p, mode == 1, c->stream));
+		return ISING_OK;
+	}
 	HIP_TRY(ising::launch_update(p, mode, c->stream));
 	return ISING_OK;
 }
@@ -408,7 +452,7 @@ int ising_count(ising_ctx *c, uint64_t *up, uint64_t *down) {
 	HIP_TRY(hipMemcpyAsync(&h, c->d_acc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	*up = h;
-	*down = 2ull * c->color_words * 16ull - h; // SPIN_X_WORD - popc per word, optimized/main.cu:722-723
+	*down = (uint64_t)c->cfg.X * (uint64_t)c->cfg.Y - h; // SPIN_X_WORD - popc per word, optimized/main.cu:722-723
 	return ISING_OK;
 }
 
@@ -425,7 +469,7 @@ int ising_bond_equal(ising_ctx *c, int64_t *A) {
 	p.slY = c->cfg.XSL ? c->cfg.YSL : 0;
 	p.acc = c->d_acc + 1;
 	HIP_TRY(hipMemsetAsync(c->d_acc + 1, 0, sizeof(unsigned long long), c->stream));
-	HIP_TRY(ising::launch_bond_equal(p, c->stream));
+	HIP_TRY(c->dense ? ising::launch_dense_bond_equal(p, c->stream) : ising::launch_bond_equal(p, c->stream));
 	unsigned long long h = 0;
 	HIP_TRY(hipMemcpyAsync(&h, c->d_acc + 1, sizeof(h), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
@@ -443,6 +487,14 @@ static int check_rows(ising_ctx *c, int color, int64_t row0, int64_t nrows, cons
 int ising_read_packed(ising_ctx *c, int color, int64_t row0, int64_t nrows, uint64_t *dst_host) {
 	if (int rc = check_rows(c, color, row0, nrows, dst_host)) return rc;
 	if (int rc = bind(c)) return rc;
+	if (c->dense) {
+		const size_t nvec = (size_t)nrows * c->lld * 2; // 32-bit words = reference vectors
+		std::vector<uint32_t> tmp(nvec);
+		HIP_TRY(hipMemcpyAsync(tmp.data(), c->lat(color) + (size_t)row0 * c->lld, nvec * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		dense_to_packed(tmp.data(), dst_host, nvec);
+		return ISING_OK;
+	}
 	HIP_TRY(hipMemcpyAsync(dst_host, c->lat(color) + (size_t)row0 * c->lld, (size_t)nrows * c->lld * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	return ISING_OK;
@@ -451,8 +503,28 @@ int ising_read_packed(ising_ctx *c, int color, int64_t row0, int64_t nrows, uint
 int ising_write_packed(ising_ctx *c, int color, int64_t row0, int64_t nrows, const uint64_t *src_host) {
 	if (int rc = check_rows(c, color, row0, nrows, src_host)) return rc;
 	if (int rc = bind(c)) return rc;
-	HIP_TRY(hipMemcpyAsync(c->lat(color) + (size_t)row0 * c->lld, src_host, (size_t)nrows * c->lld * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+	std::vector<uint32_t> tmp;
+	const void *src = src_host;
+	size_t row_bytes = (size_t)c->lld * sizeof(uint64_t);
+	if (c->dense) {
+		tmp.resize((size_t)nrows * c->lld * 2);
+		packed_to_dense(src_host, tmp.data(), tmp.size());
+		src = tmp.data();
+	}
+	HIP_TRY(hipMemcpyAsync(c->lat(color) + (size_t)row0 * c->lld, src, (size_t)nrows * row_bytes, hipMemcpyHostToDevice, c->stream));
+	// single slab: the halo rows mirror the opposite edge rows
+	if (c->cfg.nslabs == 1 && nrows > 0) {
+		const char *b = static_cast<const char *>(src);
+		if (row0 == 0) HIP_TRY(hipMemcpyAsync(c->lat(color) + c->color_words, b, row_bytes, hipMemcpyHostToDevice, c->stream));
+		if (row0 + nrows == c->cfg.Y) HIP_TRY(hipMemcpyAsync(c->lat(color) - c->lld, b + (size_t)(nrows - 1) * row_bytes, row_bytes, hipMemcpyHostToDevice, c->stream));
+	}
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	return ISING_OK;
+}
+
+int ising_layout(ising_ctx *c, int *layout) {
+	if (!c || !layout) return fail(ISING_E_ARG, "null argument");
+	*layout = c->dense ? ISING_LAYOUT_DENSE : ISING_LAYOUT_NIBBLE;
 	return ISING_OK;
 }
 
@@ -467,22 +539,23 @@ int ising_device_ptr(ising_ctx *c, int color, void **ptr, size_t *bytes) {
 int ising_dump_text(ising_ctx *c, const char *prefix) {
 	if (!c || !prefix) return fail(ISING_E_ARG, "null argument");
 	if (int rc = bind(c)) return rc;
-	std::vector<uint64_t> h(2 * c->color_words);
+	const size_t pw = (size_t)c->cfg.Y * c->lld_packed; // packed words per colour
+	std::vector<uint64_t> h(2 * pw);
 	for (int color = 0; color < 2; color++)
-		HIP_TRY(hipMemcpyAsync(h.data() + color * c->color_words, c->lat(color), c->color_words * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));
+		if (int rc = ising_read_packed(c, color, 0, c->cfg.Y, h.data() + color * pw)) return rc;
 	char fname[512];
 	snprintf(fname, sizeof(fname), "%s%d.txt", prefix, c->cfg.slab); // optimized/main.cu:1157,:1185
 	FILE *fp = fopen(fname, "w");
 	if (!fp) return fail(ISING_E_ARG, "cannot open %s for writing", fname);
 	static const char hex[] = "0123456789ABCDEF";
 	std::string line((size_t)c->cfg.X + 1, '\n');
-	const uint64_t *b = h.data(), *w = h.data() + c->color_words;
+	const uint64_t *b = h.data(), *w = h.data() + pw;
+	const int lp = c->lld_packed;
 	for (int i = 0; i < c->cfg.Y; i++) {
 		char *q = &line[0];
 		// local row parity decides the interleave, as in the reference's per-device loop (optimized/main.cu:1188-1201)
-		for (int j = 0; j < c->lld; j++) {
-			const uint64_t vb = b[(size_t)i * c->lld + j], vw = w[(size_t)i * c->lld + j];
+		for (int j = 0; j < lp; j++) {
+			const uint64_t vb = b[(size_t)i * lp + j], vw = w[(size_t)i * lp + j];
 			for (int k = 0; k < 64; k += 4) {
 				const char cb = hex[(vb >> k) & 0xF], cw = hex[(vw >> k) & 0xF];
 				if (i & 1) { *q++ = cw; *q++ = cb; } else { *q++ = cb; *q++ = cw; }
@@ -666,12 +739,15 @@ int ising_ring_correlations(ising_ctx **ctxs, int n, int ncorr, int64_t *sums) {
 		if (!c->d_bits || c->d_bits_extra < ncorr) {
 			if (c->d_bits) HIP_TRY(hipFree(c->d_bits));
 			c->d_bits = nullptr;
-			HIP_TRY(hipMalloc((void **)&c->d_bits, (size_t)(c->cfg.Y + 128) * c->lld * sizeof(uint32_t)));
+			HIP_TRY(hipMalloc((void **)&c->d_bits, (size_t)(c->cfg.Y + 128) * c->lld_packed * sizeof(uint32_t)));
 			c->d_bits_extra = 128;
 		}
 		if (!c->d_corr) HIP_TRY(hipMalloc((void **)&c->d_corr, 128 * sizeof(long long)));
-		HIP_TRY(ising::launch_pack_bits(c->lat(ISING_BLACK), c->lat(ISING_WHITE), c->lld, c->cfg.Y,
-		                                (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y, c->d_bits, c->stream));
+		// bit matrix: X bits = lld_packed 32-bit words per row
+		if (c->dense) HIP_TRY(ising::launch_dense_pack_bits(c->lat(ISING_BLACK), c->lat(ISING_WHITE), c->gx * 32, c->cfg.Y,
+		                                                    (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y, c->d_bits, c->stream));
+		else HIP_TRY(ising::launch_pack_bits(c->lat(ISING_BLACK), c->lat(ISING_WHITE), c->lld_packed, c->cfg.Y,
+		                                     (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y, c->d_bits, c->stream));
 		HIP_TRY(hipMemsetAsync(c->d_corr, 0, 128 * sizeof(long long), c->stream));
 	}
 	for (int k = 0; k < n; k++) if (int rc = ising_synchronize(ctxs[k])) return rc;
@@ -680,9 +756,9 @@ int ising_ring_correlations(ising_ctx **ctxs, int n, int ncorr, int64_t *sums) {
 		ising_ctx *c = ctxs[k], *next = ctxs[(k + 1) % n];
 		if (int rc = bind(c)) return rc;
 		if (!c->cfg.XSL) // sub-lattices never look past their own rows
-			HIP_TRY(hipMemcpyPeerAsync(c->d_bits + (size_t)c->cfg.Y * c->lld, c->cfg.device, next->d_bits, next->cfg.device,
-			                           (size_t)ncorr * c->lld * sizeof(uint32_t), c->stream));
-		HIP_TRY(ising::launch_corr(c->d_bits, c->lld, c->cfg.Y, ncorr, c->cfg.XSL ? c->cfg.XSL / 32 : c->lld,
+			HIP_TRY(hipMemcpyPeerAsync(c->d_bits + (size_t)c->cfg.Y * c->lld_packed, c->cfg.device, next->d_bits, next->cfg.device,
+			                           (size_t)ncorr * c->lld_packed * sizeof(uint32_t), c->stream));
+		HIP_TRY(ising::launch_corr(c->d_bits, c->lld_packed, c->cfg.Y, ncorr, c->cfg.XSL ? c->cfg.XSL / 32 : c->lld_packed,
 		                           c->cfg.XSL ? c->cfg.YSL : 0, c->d_corr, c->stream));
 	}
 	std::vector<long long> h(ncorr);

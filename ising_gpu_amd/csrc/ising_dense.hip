@@ -1,0 +1,303 @@
+// ising_dense.hip -- the same hot path on a dense device layout: 1 bit per spin instead of the reference's 4.
+//
+// Why a second layout.  The packed-nibble kernel (ising_kernels.hip) is VALU-bound AND runs against the board power
+// limit: with 4.2 TB/s of HBM traffic next to a saturated vector ALU the package sits at its cap and DVFS drops the
+// shader clock from 2.40 to 2.21 GHz.  The reference needs 4 bits per spin only so that four
+// neighbour words can be added nibble-wise; on a bit-sliced adder (a handful of 3-input bit operations per 32 sites)
+// the sum costs no more, and the lattice shrinks 4x: 0.375 instead of 1.5 bytes of HBM traffic per flip.  What comes
+// out is identical: the C-ABI converts to the reference's packed layout at its boundary (read/write/dump), and the
+// Philox stream mapping is untouched because one reference 128-bit vector (32 spins) is exactly one 32-bit word here:
+//   bit k of word c  <->  nibble k of word x (k < 16) / nibble k-16 of word y (k >= 16) of reference vector c.
+// Throughput is still reported against the reference's 1.5 B/flip accounting.
+//
+// Not in this layout (the nibble layout is selected automatically): -J couplings, sub-lattices.
+#include "ising_device.hpp"
+
+namespace ising {
+namespace {
+
+// The four draws of Philox block m of a vector belong to spins 2m, 16+2m, 2m+1, 17+2m.  Each draw sets
+// its spin's bit in c3 / c4 when it is below the threshold for 3 / 4 aligned neighbours.  v_cmpx writes the lane
+// predicate into EXEC and a 2-cycle VOP2 OR with a literal runs under it (see accept_rank in ising_kernels.hip).
+template <int M>
+__device__ __forceinline__ void accept_bits(uint32_t &c3, uint32_t &c4, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3,
+                                            uint32_t n3, uint32_t n4) {
+	constexpr uint32_t K0 = 1u << (2 * M), K1 = 1u << (16 + 2 * M), K2 = 1u << (2 * M + 1), K3 = 1u << (17 + 2 * M);
+	unsigned long long saved;
+	asm volatile(
+	    "s_mov_b64 %[sv], exec\n\t"
+	    "v_cmpx_gt_u32_e32 vcc, %[n3], %[o0]\n\t"
+	    "v_or_b32_e32 %[c3], %[k0], %[c3]\n\t"
+	    "v_cmpx_gt_u32_e32 vcc, %[n4], %[o0]\n\t"
+	    "v_or_b32_e32 %[c4], %[k0], %[c4]\n\t"
+	    "s_mov_b64 exec, %[sv]\n\t"
+	    "v_cmpx_gt_u32_e32 vcc, %[n3], %[o1]\n\t"
+	    "v_or_b32_e32 %[c3], %[k1], %[c3]\n\t"
+	    "v_cmpx_gt_u32_e32 vcc, %[n4], %[o1]\n\t"
+	    "v_or_b32_e32 %[c4], %[k1], %[c4]\n\t"
+	    "s_mov_b64 exec, %[sv]\n\t"
+	    "v_cmpx_gt_u32_e32 vcc, %[n3], %[o2]\n\t"
+	    "v_or_b32_e32 %[c3], %[k2], %[c3]\n\t"
+	    "v_cmpx_gt_u32_e32 vcc, %[n4], %[o2]\n\t"
+	    "v_or_b32_e32 %[c4], %[k2], %[c4]\n\t"
+	    "s_mov_b64 exec, %[sv]\n\t"
+	    "v_cmpx_gt_u32_e32 vcc, %[n3], %[o3]\n\t"
+	    "v_or_b32_e32 %[c3], %[k3], %[c3]\n\t"
+	    "v_cmpx_gt_u32_e32 vcc, %[n4], %[o3]\n\t"
+	    "v_or_b32_e32 %[c4], %[k3], %[c4]\n\t"
+	    "s_mov_b64 exec, %[sv]"
+	    : [c3] "+v"(c3), [c4] "+v"(c4), [sv] "=&s"(saved)
+	    : [o0] "v"(o0), [o1] "v"(o1), [o2] "v"(o2), [o3] "v"(o3), [n3] "s"(n3), [n4] "s"(n4), [k0] "n"(K0), [k1] "n"(K1),
+	      [k2] "n"(K2), [k3] "n"(K3)
+	    : "vcc");
+}
+
+// Bit-sliced count of up neighbours of 32 spins: (n2 n1 n0) = up + down + centre + side, each a 0/1 plane.
+__device__ __forceinline__ void neighbour_planes(uint32_t up, uint32_t ct, uint32_t dw, uint32_t side_word, bool back,
+                                                 uint32_t &n0, uint32_t &n1, uint32_t &n2) {
+	// the side neighbour of spin k is spin k-1 (back) or k+1 of the same row; the bit that falls off the word comes from
+	// the adjacent word (optimized/main.cu:546-573 does the same with nibbles)
+	const uint32_t sd = back ? __builtin_amdgcn_alignbit(ct, side_word, 31) : __builtin_amdgcn_alignbit(side_word, ct, 1);
+	const uint32_t x = up ^ dw, y = up & dw, z = ct ^ sd, w = ct & sd;
+	const uint32_t c1 = x & z;
+	n0 = x ^ z;
+	n1 = y ^ w ^ c1;
+	n2 = (y & w) | (c1 & (y ^ w));
+}
+
+// Metropolis decision for 32 spins at once.  a = aligned neighbours = n for an up spin, 4 - n for a down spin;
+// a <= 2 always flips, a = 3 / 4 flips where the draw was below n3 / n4 (planes c3 / c4).
+__device__ __forceinline__ uint32_t flip_mask(uint32_t me, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t c3, uint32_t c4) {
+	const uint32_t is3 = (me & n1 & n0) | (~me & n0 & ~n1 & ~n2);
+	const uint32_t is4 = (me & n2) | (~me & ~(n0 | n1 | n2));
+	return ~(is3 | is4) | (is3 & c3) | (is4 & c4);
+}
+
+// cuRAND's curand_uniform: x*2^-32 + 2^-33 in FP32, one rounding (the product is exact).
+__device__ __forceinline__ float u01(uint32_t x) {
+	return __fmaf_rn(__uint2float_rn(x), 0x1p-32f, 0x1p-33f);
+}
+
+// ---------------------------------------------------------------------------------------------- update
+// GENERIC = false: integer thresholds (needs table >= 1 for <= 2 aligned neighbours).  GENERIC = true: the reference's
+// literal per-site FP32 compare against exp_h[spin][n] (optimized/main.cu:637-660) for temperatures that do not admit
+// the integer form (T <= 0, saturated tables).
+template <bool GENERIC>
+__global__ void __launch_bounds__(THREADS) dense_update_k(const UpdateParams p) {
+	__shared__ float sh_tab[10];
+	if (GENERIC) {
+		if (threadIdx.x < 10) sh_tab[threadIdx.x] = p.tab[threadIdx.x];
+		__syncthreads();
+	}
+	const int tx = threadIdx.x & (GROUP - 1);
+	const int unit = blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x >> 4);
+	if (unit >= p.nunits) return;
+	const int rng = unit >= p.nunits0;
+	const int u = unit - (rng ? p.nunits0 : 0);
+	const int sidx = u / p.gx;
+	const int bx = u - sidx * p.gx;
+	const int r0 = p.row_lo[rng] + sidx * p.H;
+	const int nrows = min(p.H, p.row_hi[rng] - r0);
+	const int wpr = p.gx * 32; // 32-bit words per colour row; word index == reference vector index
+	const int col0 = bx * 32 + tx;
+	// adjacent words that supply the side carry bit, as word offsets from this lane's own word (periodic in the row)
+	const int offL0 = col0 == 0 ? wpr - 1 : -1, offL1 = GROUP - 1;
+	const int offR0 = 1, offR1 = (col0 + GROUP + 1 == wpr) ? GROUP + 1 - wpr : GROUP + 1;
+
+	const uint32_t *pc = reinterpret_cast<const uint32_t *>(p.src) + ((ptrdiff_t)r0 * wpr + col0);
+	uint32_t *pm = reinterpret_cast<uint32_t *>(p.dst) + ((ptrdiff_t)r0 * wpr + col0);
+	const ptrdiff_t wrap_bot = (ptrdiff_t)p.Y * wpr;
+
+	const uint32_t k2y = p.seed_hi + 2u * PHILOX_W1;
+	const uint32_t cx_base = 16u * (2u * p.it + p.color);
+
+	uint32_t up0 = pc[-wpr], up1 = pc[GROUP - wpr];
+	uint32_t ct0 = pc[0], ct1 = pc[GROUP];
+
+	for (int r = 0; r < nrows; ++r) {
+		const int lr = r0 + r;
+		const uint32_t grow = p.row_base + (uint32_t)lr;
+		const bool back = (p.color == 0) ? !(grow & 1u) : (grow & 1u); // readBack, optimized/main.cu:542
+		const uint32_t dw0 = pc[wpr], dw1 = pc[wpr + GROUP];
+		const uint32_t side0 = pc[back ? offL0 : offR0];
+		const uint32_t side1 = pc[back ? offL1 : offR1];
+		uint32_t me0 = pm[0], me1 = pm[GROUP];
+
+		const uint32_t tid = ((grow >> 4) * (uint32_t)p.gx + (uint32_t)bx) * 256u + (grow & 15u) * 16u + (uint32_t)tx;
+		const PhiloxRow pr = philox_row_setup(tid, p.seed_lo, k2y);
+
+		if (!GENERIC) {
+			uint32_t c3[2] = {0u, 0u}, c4[2] = {0u, 0u};
+			static_for<16>([&](auto B) {
+				constexpr int j = B.value >> 3, m = B.value & 7;
+				uint32_t o[4];
+				philox_block(pr, cx_base + (uint32_t)B.value, p.seed_lo, p.seed_hi, o[0], o[1], o[2], o[3]);
+				accept_bits<m>(c3[j], c4[j], o[0], o[1], o[2], o[3], p.n3, p.n4);
+			});
+			uint32_t n0, n1, n2;
+			neighbour_planes(up0, ct0, dw0, side0, back, n0, n1, n2);
+			me0 ^= flip_mask(me0, n0, n1, n2, c3[0], c4[0]);
+			neighbour_planes(up1, ct1, dw1, side1, back, n0, n1, n2);
+			me1 ^= flip_mask(me1, n0, n1, n2, c3[1], c4[1]);
+		} else {
+			uint32_t me[2] = {me0, me1}, n0[2], n1[2], n2[2], flip[2] = {0u, 0u};
+			neighbour_planes(up0, ct0, dw0, side0, back, n0[0], n1[0], n2[0]);
+			neighbour_planes(up1, ct1, dw1, side1, back, n0[1], n1[1], n2[1]);
+#pragma unroll
+			for (int j = 0; j < 2; ++j) {
+#pragma unroll
+				for (int m = 0; m < 8; ++m) {
+					uint32_t o[4];
+					philox_block(pr, cx_base + 8u * j + m, p.seed_lo, p.seed_hi, o[0], o[1], o[2], o[3]);
+					const int bit[4] = {2 * m, 16 + 2 * m, 2 * m + 1, 17 + 2 * m};
+#pragma unroll
+					for (int q = 0; q < 4; ++q) {
+						const uint32_t sp = (me[j] >> bit[q]) & 1u;
+						const uint32_t n = ((n0[j] >> bit[q]) & 1u) | (((n1[j] >> bit[q]) & 1u) << 1) | (((n2[j] >> bit[q]) & 1u) << 2);
+						if (u01(o[q]) <= sh_tab[sp * 5 + n]) flip[j] |= 1u << bit[q];
+					}
+				}
+			}
+			me0 ^= flip[0];
+			me1 ^= flip[1];
+		}
+
+		pm[0] = me0;
+		pm[GROUP] = me1;
+		if (p.wrap) { // single slab: keep this colour's own halo rows equal to the opposite edge rows
+			if (lr == 0) { pm[wrap_bot] = me0; pm[wrap_bot + GROUP] = me1; }
+			if (lr == p.Y - 1) { pm[-wrap_bot] = me0; pm[-wrap_bot + GROUP] = me1; }
+		}
+		up0 = ct0; up1 = ct1;
+		ct0 = dw0; ct1 = dw1;
+		pc += wpr;
+		pm += wpr;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------- init
+__global__ void __launch_bounds__(THREADS) dense_init_k(const InitParams p) {
+	const int tx = threadIdx.x & (GROUP - 1);
+	const int unit = blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x >> 4); // (row, bx)
+	if (unit >= p.gx * p.Y) return;
+	const int lr = unit / p.gx;
+	const int bx = unit - lr * p.gx;
+	const int wpr = p.gx * 32;
+	const uint32_t grow = p.row_base + (uint32_t)lr;
+	const uint32_t tid = ((grow >> 4) * (uint32_t)p.gx + (uint32_t)bx) * 256u + (grow & 15u) * 16u + (uint32_t)tx;
+	const PhiloxRow pr = philox_row_setup(tid, p.seed_lo, p.seed_hi + 2u * PHILOX_W1);
+	const uint32_t cx_base = 16u * p.color; // it = 0, optimized/main.cu:116
+	uint32_t *row = reinterpret_cast<uint32_t *>(p.dst) + (size_t)lr * wpr;
+#pragma unroll
+	for (int j = 0; j < 2; ++j) {
+		uint32_t v = 0;
+#pragma unroll
+		for (int m = 0; m < 8; ++m) {
+			uint32_t o[4];
+			philox_block(pr, cx_base + 8u * j + m, p.seed_lo, p.seed_hi, o[0], o[1], o[2], o[3]);
+			// curand_uniform(x) < 0.5f  <=>  x < thr_half   (optimized/main.cu:133,:136)
+			if (o[0] < p.thr_half) v |= 1u << (2 * m);
+			if (o[1] < p.thr_half) v |= 1u << (16 + 2 * m);
+			if (o[2] < p.thr_half) v |= 1u << (2 * m + 1);
+			if (o[3] < p.thr_half) v |= 1u << (17 + 2 * m);
+		}
+		const int col = bx * 32 + tx + j * GROUP;
+		row[col] = v;
+		if (p.wrap) {
+			if (lr == 0) row[(ptrdiff_t)p.Y * wpr + col] = v;
+			if (lr == p.Y - 1) row[-(ptrdiff_t)p.Y * wpr + col] = v;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------- bond sum
+__global__ void __launch_bounds__(THREADS) dense_bond_equal_k(const BondParams p) {
+	__shared__ unsigned long long part[THREADS / 64];
+	const int wpr = p.gx * 32;
+	const size_t total = (size_t)wpr * p.Y;
+	const uint32_t *white = reinterpret_cast<const uint32_t *>(p.white);
+	const uint32_t *black = reinterpret_cast<const uint32_t *>(p.black);
+	unsigned long long acc = 0;
+	for (size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * THREADS) {
+		const int lr = (int)(i / wpr);
+		const int col = (int)(i - (size_t)lr * wpr);
+		const bool back = !((p.row_base + (uint32_t)lr) & 1u); // black sites
+		const uint32_t *pc = white + (ptrdiff_t)lr * wpr;
+		const int colS = back ? (col == 0 ? wpr - 1 : col - 1) : (col + 1 == wpr ? 0 : col + 1);
+		uint32_t n0, n1, n2;
+		neighbour_planes(pc[col - wpr], pc[col], pc[col + wpr], pc[colS], back, n0, n1, n2);
+		const uint32_t me = black[i];
+		// aligned neighbours a = n (up spin) or 4 - n (down spin), as planes a2 a1 a0
+		const uint32_t a0 = n0;
+		const uint32_t a1 = (me & n1) | (~me & (n0 ^ n1) & ~n2);
+		const uint32_t a2 = (me & n2) | (~me & ~(n0 | n1 | n2));
+		acc += (unsigned)__popc(a0) + 2u * (unsigned)__popc(a1) + 4u * (unsigned)__popc(a2);
+	}
+	acc = wave_sum(acc);
+	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned long long t = 0;
+#pragma unroll
+		for (int i = 0; i < THREADS / 64; ++i) t += part[i];
+		atomicAdd(p.acc, t);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------- correlations input
+// 32 spins -> the even bit positions of a 64-bit word
+__device__ __forceinline__ unsigned long long spread32(unsigned long long x) {
+	x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+	x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+	x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+	x = (x | (x << 2)) & 0x3333333333333333ull;
+	x = (x | (x << 1)) & 0x5555555555555555ull;
+	return x;
+}
+
+// bits64[r][c] holds lattice columns 64c..64c+63 of slab row r (see pack_bits_k in ising_kernels.hip)
+__global__ void __launch_bounds__(THREADS) dense_pack_bits_k(const uint32_t *__restrict__ black, const uint32_t *__restrict__ white,
+                                                             int wpr, int Y, uint32_t row_base, unsigned long long *__restrict__ bits64) {
+	const size_t total = (size_t)wpr * Y;
+	for (size_t i = blockIdx.x * (size_t)THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * THREADS) {
+		const uint32_t r = (uint32_t)(i / wpr);
+		const unsigned long long b = spread32(black[i]), w = spread32(white[i]);
+		bits64[i] = ((row_base + r) & 1u) ? (w | (b << 1)) : (b | (w << 1));
+	}
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------- launchers
+hipError_t launch_dense_update(const UpdateParams &p, bool generic, hipStream_t stream) {
+	if (p.nunits <= 0) return hipSuccess;
+	const dim3 grid((p.nunits + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), block(THREADS);
+	if (generic) hipLaunchKernelGGL(dense_update_k<true>, grid, block, 0, stream, p);
+	else         hipLaunchKernelGGL(dense_update_k<false>, grid, block, 0, stream, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_dense_init(const InitParams &p, hipStream_t stream) {
+	const long long units = (long long)p.gx * p.Y;
+	hipLaunchKernelGGL(dense_init_k, dim3((unsigned)((units + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)), dim3(THREADS), 0, stream, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_dense_bond_equal(const BondParams &p, hipStream_t stream) {
+	const size_t total = (size_t)p.gx * 32 * p.Y;
+	size_t blocks = (total + THREADS - 1) / THREADS;
+	if (blocks > 4096) blocks = 4096;
+	hipLaunchKernelGGL(dense_bond_equal_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_dense_pack_bits(const uint64_t *black, const uint64_t *white, int wpr, int Y, uint32_t row_base, uint32_t *bits,
+                                  hipStream_t stream) {
+	size_t blocks = ((size_t)wpr * Y + THREADS - 1) / THREADS;
+	if (blocks > 8192) blocks = 8192;
+	hipLaunchKernelGGL(dense_pack_bits_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, reinterpret_cast<const uint32_t *>(black),
+	                   reinterpret_cast<const uint32_t *>(white), wpr, Y, row_base, reinterpret_cast<unsigned long long *>(bits));
+	return hipGetLastError();
+}
+
+} // namespace ising

@@ -1,0 +1,107 @@
+// ising_device.hpp -- device-side helpers shared by the kernel translation units: launch geometry constants, the
+// compile-time loop, Philox4x32-10 with the hoisted first two rounds (see ising_kernels.hip header comment), wave sum.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ising_kernels.h"
+#include <utility>
+
+namespace ising {
+namespace {
+
+constexpr int GROUP = 16;                 // lanes per reference block-row (BLOCK_X, optimized/main.cu:55)
+constexpr int THREADS = 256;
+constexpr int GROUPS_PER_BLOCK = THREADS / GROUP;
+
+template <int... Is, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
+	(f(std::integral_constant<int, Is>{}), ...);
+}
+// compile-time unrolled loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+	static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+	return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+
+__device__ __forceinline__ void mul_hilo(uint32_t a, uint32_t b, uint32_t &hi, uint32_t &lo) {
+	const unsigned long long p = (unsigned long long)a * b; // v_mad_u64_u32 / s_mul_hi_u32+s_mul_i32
+	hi = (uint32_t)(p >> 32);
+	lo = (uint32_t)p;
+}
+
+// Per-row Philox state shared by the 16 draw blocks of one lane-row.
+struct PhiloxRow {
+	uint32_t t_lo1;  // lo(M1*tid)                      -> c1.y
+	uint32_t t_hi0;  // hi(M0*c1.x)
+	uint32_t t_lo0;  // lo(M0*c1.x)                     -> c2.w
+	uint32_t t_e;    // t_lo0 ^ key2.y
+};
+
+__device__ __forceinline__ PhiloxRow philox_row_setup(uint32_t tid, uint32_t k0x, uint32_t k2y) {
+	PhiloxRow r;
+	uint32_t hi1;
+	mul_hilo(PHILOX_M1, tid, hi1, r.t_lo1);
+	const uint32_t c1x = hi1 ^ k0x;
+	mul_hilo(PHILOX_M0, c1x, r.t_hi0, r.t_lo0);
+	r.t_e = r.t_lo0 ^ k2y;
+	return r;
+}
+
+// One Philox4x32-10 block for counter (cx, 0, tid, 0): cx is wave-uniform, everything derived from it alone is
+// computed on the scalar unit by the compiler.
+__device__ __forceinline__ void philox_block(const PhiloxRow &pr, uint32_t cx, uint32_t seed_lo, uint32_t seed_hi,
+                                             uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
+#if defined(ISING_DBG_NORNG) // perf investigation only: not Philox, results are wrong by design
+	o0 = pr.t_lo1 + cx; o1 = pr.t_hi0 ^ cx; o2 = pr.t_lo0 + seed_lo; o3 = pr.t_e ^ seed_hi;
+	return;
+#endif
+	// round 1 (key 0), scalar half
+	uint32_t s_hi0, s_lo0;
+	mul_hilo(PHILOX_M0, cx, s_hi0, s_lo0);
+	const uint32_t c1z = s_hi0 ^ seed_hi;
+	// round 2 (key 1)
+	const uint32_t k1x = seed_lo + PHILOX_W0, k1y = seed_hi + PHILOX_W1;
+	uint32_t s_hi1, s_lo1;
+	mul_hilo(PHILOX_M1, c1z, s_hi1, s_lo1);
+	uint32_t c0 = (s_hi1 ^ k1x) ^ pr.t_lo1;
+	uint32_t c1 = s_lo1;
+	uint32_t c2 = pr.t_hi0 ^ (s_lo0 ^ k1y);
+	uint32_t c3 = pr.t_lo0;
+	// round 3 (key 2)
+	uint32_t kx = seed_lo + 2u * PHILOX_W0, ky = seed_hi + 2u * PHILOX_W1;
+	{
+		uint32_t hi0, lo0, hi1, lo1;
+		mul_hilo(PHILOX_M0, c0, hi0, lo0);
+		mul_hilo(PHILOX_M1, c2, hi1, lo1);
+		c0 = hi1 ^ (c1 ^ kx);
+		c1 = lo1;
+		c2 = hi0 ^ pr.t_e; // c3 ^ ky == t_lo0 ^ key2.y
+		c3 = lo0;
+	}
+	// rounds 4..10 (keys 3..9)
+#pragma unroll
+	for (int r = 3; r < 10; ++r) {
+		kx += PHILOX_W0;
+		ky += PHILOX_W1;
+		uint32_t hi0, lo0, hi1, lo1;
+		mul_hilo(PHILOX_M0, c0, hi0, lo0);
+		mul_hilo(PHILOX_M1, c2, hi1, lo1);
+		c0 = xor3(hi1, c1, kx);
+		c1 = lo1;
+		c2 = xor3(hi0, c3, ky);
+		c3 = lo0;
+	}
+	o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+	for (int off = 32; off; off >>= 1) v += __shfl_down(v, off, 64);
+	return v;
+}
+
+} // namespace
+} // namespace ising

@@ -26,11 +26,12 @@ class IsingSlab:
 
     def __init__(self, X: int, Y: int, seed: int = _lib.SEED_DEF, temp: float = 0.1 * _lib.CRIT_TEMP_F32,
                  nslabs: int = 1, slab: int = 0, device: int = 0, strip_rows: int = 0, kernel: int = _lib.KERNEL_AUTO,
-                 XSL: int = 0, YSL: int = 0, J_prob: float | None = None, lattice_mem: int = 0, coupling_mem: int = 0):
+                 XSL: int = 0, YSL: int = 0, J_prob: float | None = None, lattice_mem: int = 0, coupling_mem: int = 0,
+                 layout: int = _lib.LAYOUT_AUTO):
         self._lib = _lib.load()
         self.cfg = IsingConfig(X=X, Y=Y, nslabs=nslabs, slab=slab, seed=seed, temp=float(np.float32(temp)),
                                device=device, strip_rows=strip_rows, kernel=kernel, XSL=XSL, YSL=YSL,
-                               lattice_mem=lattice_mem or None, coupling_mem=coupling_mem or None,
+                               lattice_mem=lattice_mem or None, coupling_mem=coupling_mem or None, layout=layout,
                                use_J=0 if J_prob is None else 1, J_prob=0.0 if J_prob is None else float(J_prob))
         self.use_J = J_prob is not None
         self._h = C.c_void_p()
@@ -41,6 +42,9 @@ class IsingSlab:
         sr, ns = C.c_int(), C.c_int()
         check(self._lib.ising_strip_info(self._h, C.byref(sr), C.byref(ns)))
         self.strip_rows, self.nstrips = sr.value, ns.value
+        lay = C.c_int()
+        check(self._lib.ising_layout(self._h, C.byref(lay)))
+        self.layout = lay.value
 
     # -- lifetime ----------------------------------------------------------------------------------------
     def close(self):

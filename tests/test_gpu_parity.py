@@ -22,12 +22,17 @@ def _compare(slab, orc, what):
                                  f"hip {int(got[r, q]):016x} oracle {int(ref[r, q]):016x}")
 
 
-@pytest.mark.parametrize("kernel", [ig.KERNEL_LUT, ig.KERNEL_FAST, ig.KERNEL_GENERIC])
+VARIANTS = [(ig.LAYOUT_DENSE, ig.KERNEL_AUTO), (ig.LAYOUT_DENSE, ig.KERNEL_GENERIC), (ig.LAYOUT_NIBBLE, ig.KERNEL_FAST),
+            (ig.LAYOUT_NIBBLE, ig.KERNEL_LUT), (ig.LAYOUT_NIBBLE, ig.KERNEL_GENERIC)]
+
+
+@pytest.mark.parametrize("layout,kernel", VARIANTS)
 @pytest.mark.parametrize("X,Y,strip", [(2048, 16, 0), (2048, 64, 4), (4096, 256, 16), (8192, 128, 0), (6144, 48, 1)])
 @pytest.mark.parametrize("temp,seed", [(1.5, ig.SEED_DEF), (TC, 1234)])
-def test_state_bit_exact(gpu, oracle_mod, kernel, X, Y, strip, temp, seed):
+def test_state_bit_exact(gpu, oracle_mod, layout, kernel, X, Y, strip, temp, seed):
     orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=temp).init()
-    with ig.IsingSlab(X, Y, seed=seed, temp=temp, strip_rows=strip, kernel=kernel) as s:
+    with ig.IsingSlab(X, Y, seed=seed, temp=temp, strip_rows=strip, kernel=kernel, layout=layout) as s:
+        assert s.layout == layout
         s.init()
         _compare(s, orc, "init")
         assert s.count() == orc.count()
@@ -53,11 +58,12 @@ def test_tables_match_oracle(gpu, oracle_mod):
                     assert oracle_mod.uniform(n - 1) <= tab[1, a] < oracle_mod.uniform(n)
 
 
+@pytest.mark.parametrize("layout", [ig.LAYOUT_DENSE, ig.LAYOUT_NIBBLE])
 @pytest.mark.parametrize("temp", [0.0, -1.0, 1e9, 1e-30])
-def test_degenerate_temperatures_fall_back_to_generic(gpu, oracle_mod, temp):
+def test_degenerate_temperatures_fall_back_to_generic(gpu, oracle_mod, temp, layout):
     """temp <= 0 uses the reference's special table (optimized/main.cu:1689-1693); huge temp saturates the table at 1."""
     orc = oracle_mod.OracleLattice(2048, 32, seed=7, temp=temp).init().sweep(3)
-    with ig.IsingSlab(2048, 32, seed=7, temp=temp) as s:
+    with ig.IsingSlab(2048, 32, seed=7, temp=temp, layout=layout) as s:
         s.init().sweep(3)
         _compare(s, orc, f"temp {temp}")
 
@@ -134,3 +140,19 @@ def test_readme_sublattice_transcript_65536(gpu):
         assert s.count() == (2147631783, 2147335513)   # README.md:189
         s.sweep(96)
         assert s.count() == (2147461873, 2147505423)   # README.md:195-196 (iter 128)
+
+
+def test_write_packed_roundtrip_and_resume(gpu, oracle_mod):
+    """ising_write_packed / ising_read_packed are the binary checkpoint: a state written into a fresh context (either
+    device layout) continues exactly like the original run."""
+    X, Y, seed, temp = 4096, 64, 99, 2.0
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=temp).init().sweep(3)
+    for layout in (ig.LAYOUT_DENSE, ig.LAYOUT_NIBBLE):
+        with ig.IsingSlab(X, Y, seed=seed, temp=temp, layout=layout) as s:
+            s.write(ig.BLACK, orc.black)
+            s.write(ig.WHITE, orc.white)
+            assert np.array_equal(s.read(ig.BLACK), orc.black) and np.array_equal(s.read(ig.WHITE), orc.white)
+            s.it = 3
+            s.sweep(4)
+            ref = oracle_mod.OracleLattice(X, Y, seed=seed, temp=temp).init().sweep(7)
+            _compare(s, ref, f"resume layout {layout}")

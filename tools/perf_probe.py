@@ -9,8 +9,8 @@ sys.path.insert(0, ".")
 import ising_gpu_amd as ig
 
 
-def run(X, Y, sweeps, strip, kernel=ig.KERNEL_AUTO):
-    with ig.IsingSlab(X, Y, seed=1234, temp=ig.CRIT_TEMP_F32, strip_rows=strip, kernel=kernel) as s:
+def run(X, Y, sweeps, strip, kernel=ig.KERNEL_AUTO, layout=0):
+    with ig.IsingSlab(X, Y, seed=1234, temp=ig.CRIT_TEMP_F32, strip_rows=strip, kernel=kernel, layout=layout) as s:
         s.init()
         s.sweep(2)
         s.synchronize()
@@ -19,7 +19,7 @@ def run(X, Y, sweeps, strip, kernel=ig.KERNEL_AUTO):
             ms = s.sweep_timed(sweeps)
             best = min(best, ms)
         flips = X * Y * sweeps / (best * 1e6)
-        print(f"X={X} Y={Y} strip={s.strip_rows:3d} kernel={kernel} sweeps={sweeps}: {best/sweeps:8.3f} ms/sweep "
+        print(f"X={X} Y={Y} strip={s.strip_rows:3d} kernel={kernel} layout={s.layout} sweeps={sweeps}: {best/sweeps:8.3f} ms/sweep "
               f"{flips:8.1f} flips/ns  ({1.5*flips:7.1f} GB/s algorithmic)", flush=True)
 
 
@@ -36,6 +36,8 @@ if __name__ == "__main__":
     else:
         X, Y, sweeps = int(args[0]), int(args[1]), int(args[2])
         kernels = [int(v) for v in args[4].split(",")] if len(args) > 4 else [ig.KERNEL_AUTO]
-        for kernel in kernels:
-            for strip in [int(v) for v in args[3].split(",")]:
-                run(X, Y, sweeps, strip, kernel)
+        layouts = [int(v) for v in args[5].split(",")] if len(args) > 5 else [0]
+        for layout in layouts:
+            for kernel in kernels:
+                for strip in [int(v) for v in args[3].split(",")]:
+                    run(X, Y, sweeps, strip, kernel, layout)
