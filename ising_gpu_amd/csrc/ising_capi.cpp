@@ -137,7 +137,8 @@ void build_rank_table(const ising_ctx *c, uint8_t *tab) {
 		int a = 0, b = 0;
 		const bool ok3 = decided(h, n3, &a), ok4 = decided(h, n4, &b);
 		const bool ok = ok3 && ok4;
-		tab[h] = ok ? (uint8_t)(a + b) : (uint8_t)4;
+		if (c->dense) tab[h] = ok ? (uint8_t)(a | (b << 1)) : (uint8_t)2; // fields (c3, c4); "c4 without c3" marks undecided
+		else tab[h] = ok ? (uint8_t)(a + b) : (uint8_t)4;
 	}
 }
 
@@ -168,11 +169,12 @@ void packed_to_dense(const uint64_t *packed, uint32_t *dense, size_t nvec) {
 	}
 }
 
-int choose_strip_rows(int gx, int Y) {
+int choose_strip_rows(int gx, int Y, bool dense) {
 	// Enough (column-group x strip) units to give every SIMD several waves, while keeping strips tall so the two
-	// halo rows per strip stay a small fraction of the source traffic.
+	// halo rows per strip stay a small fraction of the source traffic (measured optimum: 32 rows for the nibble
+	// layout, 8-16 for the dense one, whose traffic is 4x smaller).
 	const long long want_units = 4LL * 8192; // 4 units per wave, ~8 waves on each of 1024 SIMDs
-	int H = 32;
+	int H = dense ? 16 : 32;
 	while (H > 1 && ((Y % H) != 0 || (long long)gx * (Y / H) < want_units)) H >>= 1;
 	return H;
 }
@@ -243,7 +245,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	c->lld_packed = cfg->X / 32;
 	c->lld = c->dense ? cfg->X / 128 : cfg->X / 32;
 	c->gx = cfg->X / 2048;
-	c->H = cfg->strip_rows > 0 ? cfg->strip_rows : choose_strip_rows(c->gx, cfg->Y);
+	c->H = cfg->strip_rows > 0 ? cfg->strip_rows : choose_strip_rows(c->gx, cfg->Y, c->dense);
 	if (cfg->Y % c->H) { const int h = c->H; delete c; return fail(ISING_E_ARG, "strip_rows %d does not divide Y %d", h, cfg->Y); }
 	c->nstrips = cfg->Y / c->H;
 	c->color_words = (size_t)cfg->Y * c->lld;
@@ -381,7 +383,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	// the reference hands hamW to the BLACK update and hamB to the WHITE one (optimized/main.cu:1774, :1795)
 	p.jdst = c->cfg.use_J ? c->ham(other) : nullptr;
 	if (c->dense) {
-		HIP_TRY(ising::launch_dense_update(p, mode == 1, c->stream));
+		HIP_TRY(ising::launch_dense_update(p, mode, c->stream));
 		return ISING_OK;
 	}
 	HIP_TRY(ising::launch_update(p, mode, c->stream));

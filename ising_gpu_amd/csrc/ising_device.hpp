@@ -52,6 +52,8 @@ __device__ __forceinline__ PhiloxRow philox_row_setup(uint32_t tid, uint32_t k0x
 
 // One Philox4x32-10 block for counter (cx, 0, tid, 0): cx is wave-uniform, everything derived from it alone is
 // computed on the scalar unit by the compiler.
+// (A/B, rejected: forcing the block-constant round-1/2 values into VGPRs -- so that their XORs are 2-cycle VGPR-VGPR
+// ops instead of 4-cycle SGPR-operand ops -- costs 48 VGPRs and ran 3.5 % slower.)
 __device__ __forceinline__ void philox_block(const PhiloxRow &pr, uint32_t cx, uint32_t seed_lo, uint32_t seed_hi,
                                              uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
 #if defined(ISING_DBG_NORNG) // perf investigation only: not Philox, results are wrong by design
