@@ -343,7 +343,7 @@ int ising_strip_info(ising_ctx *c, int *strip_rows, int *nstrips) {
 // launches update_k over up to two row ranges
 static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int lo1, int hi1) {
 	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
-	if (it < 0 || it >= (1 << 26)) return fail(ISING_E_ARG, "iteration %d outside [0, 2^26)", it); // counter word 0 must not carry
+	if (it < 0) return fail(ISING_E_ARG, "negative iteration %d", it);
 	int mode = c->cfg.kernel == ISING_KERNEL_GENERIC ? 1 : (c->cfg.kernel == ISING_KERNEL_LUT ? 2 : 0); // AUTO, FAST -> 0
 	if (mode != 1 && !c->fast_ok) {
 		if (c->cfg.kernel != ISING_KERNEL_AUTO) return fail(ISING_E_STATE, "temperature %g does not admit the integer-threshold kernels", (double)c->cfg.temp);

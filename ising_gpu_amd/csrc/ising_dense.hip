@@ -135,6 +135,9 @@ __global__ void __launch_bounds__(dense_threads(MODE)) dense_update_k(const Upda
 
 	const uint32_t k2y = p.seed_hi + 2u * PHILOX_W1;
 	const uint32_t cx_base = 16u * (2u * p.it + p.color);
+	// The draw-block counter 16(2 it + colour) + b is 64 bits wide in cuRAND; its high word (non-zero from iteration
+	// 2^27 on) enters round 1 next to key word 0, so it folds into the seed operand of the per-row setup.
+	const uint32_t seed_lo_cy = p.seed_lo ^ (uint32_t)((2ull * p.it + p.color) >> 28);
 
 	uint32_t up0 = pc[-wpr], up1 = pc[GROUP - wpr];
 	uint32_t ct0 = pc[0], ct1 = pc[GROUP];
@@ -149,7 +152,7 @@ __global__ void __launch_bounds__(dense_threads(MODE)) dense_update_k(const Upda
 		uint32_t me0 = pm[0], me1 = pm[GROUP];
 
 		const uint32_t tid = ((grow >> 4) * (uint32_t)p.gx + (uint32_t)bx) * 256u + (grow & 15u) * 16u + (uint32_t)tx;
-		const PhiloxRow pr = philox_row_setup(tid, p.seed_lo, k2y);
+		const PhiloxRow pr = philox_row_setup(tid, seed_lo_cy, k2y);
 
 		if (MODE == 2) {
 			uint32_t A[2][2] = {{0u, 0u}, {0u, 0u}}; // [vector][half]: sixteen 2-bit fields (c3, c4), site 0 in the low bits

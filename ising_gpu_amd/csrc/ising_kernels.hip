@@ -213,6 +213,9 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 
 	const uint32_t k2y = p.seed_hi + 2u * PHILOX_W1;
 	const uint32_t cx_base = 16u * (2u * p.it + p.color);
+	// The draw-block counter 16(2 it + colour) + b is 64 bits wide in cuRAND; its high word (non-zero from iteration
+	// 2^27 on) enters round 1 next to key word 0, so it folds into the seed operand of the per-row setup.
+	const uint32_t seed_lo_cy = p.seed_lo ^ (uint32_t)((2ull * p.it + p.color) >> 28);
 
 #if defined(ISING_DBG_NOMEM) // perf investigation only: no global traffic, results are wrong by design
 #define DBG_LD(expr) make_uint4(threadIdx.x, blockIdx.x, p.it, 0x01010101u)
@@ -242,7 +245,7 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 
 		// stream id of the reference thread that owns these two vectors (optimized/main.cu:514-515)
 		const uint32_t tid = ((grow >> 4) * (uint32_t)p.gx + (uint32_t)bx) * 256u + (grow & 15u) * 16u + (uint32_t)tx;
-		const PhiloxRow pr = philox_row_setup(tid, p.seed_lo, k2y);
+		const PhiloxRow pr = philox_row_setup(tid, seed_lo_cy, k2y);
 
 		if (MODE == 2) {
 			uint32_t R[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};

@@ -156,3 +156,34 @@ def test_write_packed_roundtrip_and_resume(gpu, oracle_mod):
             s.sweep(4)
             ref = oracle_mod.OracleLattice(X, Y, seed=seed, temp=temp).init().sweep(7)
             _compare(s, ref, f"resume layout {layout}")
+
+
+@pytest.mark.parametrize("layout", [ig.LAYOUT_DENSE, ig.LAYOUT_NIBBLE])
+def test_large_iteration_index_counter_carry(gpu, oracle_mod, layout):
+    """From iteration 2^27 on the 64-bit Philox block counter 16(2 it + colour) carries into its second word
+    (curand_init offset arithmetic, optimized/main.cu:621); the kernels fold that word into round 1."""
+    X, Y, seed, temp = 2048, 32, 55, 2.0
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=temp).init()
+    with ig.IsingSlab(X, Y, seed=seed, temp=temp, layout=layout) as s:
+        s.init()
+        for it in (2**26 - 1, 2**27 - 1, 2**27, 2**27 + 3, 2**30 + 12345, 2**31 - 1):
+            for color in (ig.BLACK, ig.WHITE):
+                s.update_color(it, color)
+                orc.update_color(it, color)
+            _compare(s, orc, f"it={it}")
+
+
+def test_wide_lattice_and_empty_ranges(gpu, oracle_mod):
+    """Widest row tested (X = 262144: 128 column groups) on the minimum height, plus empty row ranges (no-ops)."""
+    X, Y = 262144, 16
+    orc = oracle_mod.OracleLattice(X, Y, seed=3, temp=TC).init()
+    with ig.IsingSlab(X, Y, seed=3, temp=TC) as s:
+        s.init()
+        assert s.count() == orc.count()
+        s.update_color(1, ig.BLACK, 5, 5)   # empty range
+        s.update_color(1, ig.BLACK, 0, 0)
+        _compare(s, orc, "after empty launches")
+        s.sweep(2)
+        orc.sweep(2)
+        _compare(s, orc, "wide lattice")
+        assert s.bond_equal() == orc.bond_equal()

@@ -20,7 +20,8 @@ __device__ __forceinline__ void block(const Row& pr, uint32_t cx, uint32_t sl, u
 }
 template <int MODE>
 __global__ void __launch_bounds__(1024) k(uint32_t* out, uint32_t sl, uint32_t sh, uint32_t n3, uint32_t n4, int rows) {
-  __shared__ uint8_t lut[65536];
+  __shared__ uint8_t lut[MODE == 1 ? 65536 : 16];
+  __shared__ uint32_t accw[MODE == 2 ? 8 * 1024 : 1];
   if (MODE == 1) {
     const uint32_t h3 = n3 >> 16, h4 = n4 >> 16;
     for (int i = threadIdx.x; i < 16384; i += blockDim.x) {
@@ -39,7 +40,17 @@ __global__ void __launch_bounds__(1024) k(uint32_t* out, uint32_t sl, uint32_t s
     for (int b = 0; b < 16; ++b) {
       uint32_t o0, o1, o2, o3; block(pr, 16u * r + b, sl, sh, o0, o1, o2, o3);
       uint32_t& rx = R[(b >> 2) * 2], & ry = R[(b >> 2) * 2 + 1];
-      if (MODE == 1) {
+      if (MODE == 2) {
+        // accumulators live in LDS: word index (d*1024 + tid) -> conflict-free per instruction
+        const unsigned ax = (unsigned)(((b >> 2) * 2) * 1024 + threadIdx.x) * 4u, ay = ax + 4096u;
+        unsigned long long sv;
+        unsigned k16 = 16u, k1 = 1u;
+        asm volatile("s_mov_b64 %[sv], exec\n\tv_cmpx_gt_u32_e32 vcc, %[n3], %[o0]\n\tds_add_u32 %[ax], %[k16]\n\tv_cmpx_gt_u32_e32 vcc, %[n4], %[o0]\n\tds_add_u32 %[ax], %[k16]\n\ts_mov_b64 exec, %[sv]\n\t"
+                     "v_cmpx_gt_u32_e32 vcc, %[n3], %[o1]\n\tds_add_u32 %[ay], %[k16]\n\tv_cmpx_gt_u32_e32 vcc, %[n4], %[o1]\n\tds_add_u32 %[ay], %[k16]\n\ts_mov_b64 exec, %[sv]\n\t"
+                     "v_cmpx_gt_u32_e32 vcc, %[n3], %[o2]\n\tds_add_u32 %[ax], %[k1]\n\tv_cmpx_gt_u32_e32 vcc, %[n4], %[o2]\n\tds_add_u32 %[ax], %[k1]\n\ts_mov_b64 exec, %[sv]\n\t"
+                     "v_cmpx_gt_u32_e32 vcc, %[n3], %[o3]\n\tds_add_u32 %[ay], %[k1]\n\tv_cmpx_gt_u32_e32 vcc, %[n4], %[o3]\n\tds_add_u32 %[ay], %[k1]\n\ts_mov_b64 exec, %[sv]"
+                     : [sv] "=&s"(sv) : [ax] "v"(ax), [ay] "v"(ay), [k16] "v"(k16), [k1] "v"(k1), [o0] "v"(o0), [o1] "v"(o1), [o2] "v"(o2), [o3] "v"(o3), [n3] "s"(n3), [n4] "s"(n4) : "vcc", "memory");
+      } else if (MODE == 1) {
         uint32_t a0 = lut[o0 >> 16], a1 = lut[o1 >> 16], a2 = lut[o2 >> 16], a3 = lut[o3 >> 16];
         rx = (rx << 4) | a2; rx = (rx << 4) | a0; ry = (ry << 4) | a3; ry = (ry << 4) | a1;
       } else {
@@ -53,6 +64,11 @@ __global__ void __launch_bounds__(1024) k(uint32_t* out, uint32_t sl, uint32_t s
     }
 #pragma unroll
     for (int d = 0; d < 8; ++d) acc += R[d];
+    if (MODE == 2) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int d = 0; d < 8; ++d) { acc += accw[d * 1024 + threadIdx.x]; accw[d * 1024 + threadIdx.x] = 0; }
+    }
   }
   out[tid] = acc;
 }
@@ -61,16 +77,17 @@ int main() {
   const uint32_t n3 = 736899936u, n4 = 126432037u; const int rows = 32;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int blocks : {256, 512, 1024, 2048}) {
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode < 3; ++mode) {
       float best = 1e30f;
       for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(e0));
         if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(1024), 0, 0, out, 0x1234567u, 0x89abcdu, n3, n4, rows);
-        else hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(1024), 0, 0, out, 0x1234567u, 0x89abcdu, n3, n4, rows);
+        else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(1024), 0, 0, out, 0x1234567u, 0x89abcdu, n3, n4, rows);
+        else hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(1024), 0, 0, out, 0x1234567u, 0x89abcdu, n3, n4, rows);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
       }
       double sites = (double)blocks * 1024 * rows * 64;
-      printf("blocks %5d mode %s: %8.3f ms  %8.1f sites/ns\n", blocks, mode ? "LUT " : "CMPX", best, sites / best * 1e-6);
+      printf("blocks %5d mode %s: %8.3f ms  %8.1f sites/ns\n", blocks, mode == 0 ? "CMPX" : mode == 1 ? "LUT " : "DSOR", best, sites / best * 1e-6);
     }
   }
   return 0;
