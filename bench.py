@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
+    # must be in the environment before the HIP/HSA runtime initialises (RCCL P2P needs dmabuf IPC on this host driver)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     import ising_gpu_amd as ig
@@ -90,7 +92,6 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # torch owns the slab's device buffer, so the rows RCCL sends/receives are slices of an ordinary torch tensor
