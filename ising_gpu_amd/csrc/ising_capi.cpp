@@ -236,10 +236,10 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		delete c;
 		return fail(ISING_E_ARG, "bad layout %d", cfg->layout);
 	}
-	const bool needs_nibble = cfg->use_J || cfg->XSL;
+	const bool needs_nibble = cfg->use_J != 0;
 	if (cfg->layout == ISING_LAYOUT_DENSE && needs_nibble) {
 		delete c;
-		return fail(ISING_E_ARG, "-J couplings and sub-lattices need the nibble layout");
+		return fail(ISING_E_ARG, "-J couplings need the nibble layout");
 	}
 	c->dense = cfg->layout == ISING_LAYOUT_DENSE || (cfg->layout == ISING_LAYOUT_AUTO && !needs_nibble);
 	c->lld_packed = cfg->X / 32;

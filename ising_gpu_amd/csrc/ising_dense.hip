@@ -10,7 +10,7 @@
 //   bit k of word c  <->  nibble k of word x (k < 16) / nibble k-16 of word y (k >= 16) of reference vector c.
 // Throughput is still reported against the reference's 1.5 B/flip accounting.
 //
-// Not in this layout (the nibble layout is selected automatically): -J couplings, sub-lattices.
+// Not in this layout (the nibble layout is selected automatically): -J couplings.
 #include "ising_device.hpp"
 
 namespace ising {
@@ -126,8 +126,13 @@ __global__ void __launch_bounds__(dense_threads(MODE)) dense_update_k(const Upda
 	const int wpr = p.gx * 32; // 32-bit words per colour row; word index == reference vector index
 	const int col0 = bx * 32 + tx;
 	// adjacent words that supply the side carry bit, as word offsets from this lane's own word (periodic in the row)
-	const int offL0 = col0 == 0 ? wpr - 1 : -1, offL1 = GROUP - 1;
-	const int offR0 = 1, offR1 = (col0 + GROUP + 1 == wpr) ? GROUP + 1 - wpr : GROUP + 1;
+	// (with sub-lattices, --xsl, the row is periodic every slV words instead; rows every slY, see `seam` below)
+	const int slV = p.slV;
+	const int offL0 = (col0 % slV) == 0 ? slV - 1 : -1, offL1 = GROUP - 1;
+	const int offR0 = 1, offR1 = ((col0 + GROUP + 1) % slV) == 0 ? GROUP + 1 - slV : GROUP + 1;
+	const int slY = p.slY;
+	const int r0_in_sl = slY ? r0 % slY : 1;
+	int seam = slY ? slY - r0_in_sl : 0x7fffffff; // rows left in the current sub-lattice
 
 	const uint32_t *pc = reinterpret_cast<const uint32_t *>(p.src) + ((ptrdiff_t)r0 * wpr + col0);
 	uint32_t *pm = reinterpret_cast<uint32_t *>(p.dst) + ((ptrdiff_t)r0 * wpr + col0);
@@ -139,14 +144,17 @@ __global__ void __launch_bounds__(dense_threads(MODE)) dense_update_k(const Upda
 	// 2^27 on) enters round 1 next to key word 0, so it folds into the seed operand of the per-row setup.
 	const uint32_t seed_lo_cy = p.seed_lo ^ (uint32_t)((2ull * p.it + p.color) >> 28);
 
-	uint32_t up0 = pc[-wpr], up1 = pc[GROUP - wpr];
+	const ptrdiff_t uo = (slY && r0_in_sl == 0) ? (ptrdiff_t)(slY - 1) * wpr : -(ptrdiff_t)wpr; // loadTile wrap, :414
+	uint32_t up0 = pc[uo], up1 = pc[uo + GROUP];
 	uint32_t ct0 = pc[0], ct1 = pc[GROUP];
 
 	for (int r = 0; r < nrows; ++r) {
 		const int lr = r0 + r;
 		const uint32_t grow = p.row_base + (uint32_t)lr;
 		const bool back = (p.color == 0) ? !(grow & 1u) : (grow & 1u); // readBack, optimized/main.cu:542
-		const uint32_t dw0 = pc[wpr], dw1 = pc[wpr + GROUP];
+		const bool sl_last = seam == 1; // last row of its sub-lattice: the row below is the sub-lattice's first row (:422)
+		const ptrdiff_t dwo = sl_last ? (ptrdiff_t)(1 - slY) * wpr : (ptrdiff_t)wpr;
+		const uint32_t dw0 = pc[dwo], dw1 = pc[dwo + GROUP];
 		const uint32_t side0 = pc[back ? offL0 : offR0];
 		const uint32_t side1 = pc[back ? offL1 : offR1];
 		uint32_t me0 = pm[0], me1 = pm[GROUP];
@@ -234,10 +242,21 @@ __global__ void __launch_bounds__(dense_threads(MODE)) dense_update_k(const Upda
 			if (lr == 0) { pm[wrap_bot] = me0; pm[wrap_bot + GROUP] = me1; }
 			if (lr == p.Y - 1) { pm[-wrap_bot] = me0; pm[-wrap_bot + GROUP] = me1; }
 		}
-		up0 = ct0; up1 = ct1;
-		ct0 = dw0; ct1 = dw1;
 		pc += wpr;
 		pm += wpr;
+		if (sl_last) {
+			// the next row opens a new sub-lattice: the register window does not slide across the seam
+			seam = slY;
+			if (r + 1 < nrows) {
+				const ptrdiff_t uo2 = (ptrdiff_t)(slY - 1) * wpr;
+				up0 = pc[uo2]; up1 = pc[uo2 + GROUP];
+				ct0 = pc[0]; ct1 = pc[GROUP];
+			}
+		} else {
+			--seam;
+			up0 = ct0; up1 = ct1;
+			ct0 = dw0; ct1 = dw1;
+		}
 	}
 }
 
@@ -289,9 +308,12 @@ __global__ void __launch_bounds__(THREADS) dense_bond_equal_k(const BondParams p
 		const int col = (int)(i - (size_t)lr * wpr);
 		const bool back = !((p.row_base + (uint32_t)lr) & 1u); // black sites
 		const uint32_t *pc = white + (ptrdiff_t)lr * wpr;
-		const int colS = back ? (col == 0 ? wpr - 1 : col - 1) : (col + 1 == wpr ? 0 : col + 1);
+		const int slV = p.slV, slY = p.slY;
+		const int colS = back ? ((col % slV) == 0 ? col + slV - 1 : col - 1) : (((col + 1) % slV) == 0 ? col + 1 - slV : col + 1);
+		const ptrdiff_t uo = (slY && (lr % slY) == 0) ? (ptrdiff_t)(slY - 1) * wpr : -(ptrdiff_t)wpr;
+		const ptrdiff_t dwo = (slY && ((lr + 1) % slY) == 0) ? (ptrdiff_t)(1 - slY) * wpr : (ptrdiff_t)wpr;
 		uint32_t n0, n1, n2;
-		neighbour_planes(pc[col - wpr], pc[col], pc[col + wpr], pc[colS], back, n0, n1, n2);
+		neighbour_planes(pc[col + uo], pc[col], pc[col + dwo], pc[colS], back, n0, n1, n2);
 		const uint32_t me = black[i];
 		// aligned neighbours a = n (up spin) or 4 - n (down spin), as planes a2 a1 a0
 		const uint32_t a0 = n0;

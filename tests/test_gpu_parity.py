@@ -114,11 +114,12 @@ def test_row_range_partition_is_invariant(gpu, oracle_mod):
         _compare(s, orc, "row-range partition")
 
 
+@pytest.mark.parametrize("layout", [ig.LAYOUT_DENSE, ig.LAYOUT_NIBBLE])
 @pytest.mark.parametrize("X,Y,XSL,YSL,strip", [(4096, 64, 2048, 16, 0), (4096, 96, 2048, 32, 16), (6144, 48, 2048, 48, 0), (4096, 64, 4096, 16, 8)])
-def test_sublattices_bit_exact(gpu, oracle_mod, X, Y, XSL, YSL, strip):
+def test_sublattices_bit_exact(gpu, oracle_mod, X, Y, XSL, YSL, strip, layout):
     """--xsl/--ysl: every XSL x YSL block is an independent torus (loadTile wrap arguments, optimized/main.cu:413-459)."""
     orc = oracle_mod.OracleLattice(X, Y, seed=8, temp=2.0, XSL=XSL, YSL=YSL).init()
-    with ig.IsingSlab(X, Y, seed=8, temp=2.0, XSL=XSL, YSL=YSL, strip_rows=strip) as s:
+    with ig.IsingSlab(X, Y, seed=8, temp=2.0, XSL=XSL, YSL=YSL, strip_rows=strip, layout=layout) as s:
         s.init()
         for n in (1, 4):
             s.sweep(n)
