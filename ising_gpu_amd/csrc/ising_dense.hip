@@ -99,7 +99,7 @@ constexpr int dense_threads(int mode) { return mode == 2 ? DENSE_LUT_THREADS : T
 // 64 KiB LDS table indexed by the top 16 bits of a draw: entry = [x<n3] | [x<n4]<<1 (0, 1 or 3), or 2 where the top
 // half does not decide; sixteen sites accumulate as 2-bit fields with one v_lshl_or each, undecided sites are redone
 // with exact compares.
-template <int MODE>
+template <int MODE, bool SUBL = false>
 __global__ void __launch_bounds__(dense_threads(MODE)) dense_update_k(const UpdateParams p) {
 	constexpr bool GENERIC = MODE == 1;
 	__shared__ float sh_tab[10];
@@ -127,10 +127,10 @@ __global__ void __launch_bounds__(dense_threads(MODE)) dense_update_k(const Upda
 	const int col0 = bx * 32 + tx;
 	// adjacent words that supply the side carry bit, as word offsets from this lane's own word (periodic in the row)
 	// (with sub-lattices, --xsl, the row is periodic every slV words instead; rows every slY, see `seam` below)
-	const int slV = p.slV;
+	const int slV = SUBL ? p.slV : wpr;
 	const int offL0 = (col0 % slV) == 0 ? slV - 1 : -1, offL1 = GROUP - 1;
 	const int offR0 = 1, offR1 = ((col0 + GROUP + 1) % slV) == 0 ? GROUP + 1 - slV : GROUP + 1;
-	const int slY = p.slY;
+	const int slY = SUBL ? p.slY : 0; // SUBL is a template switch so the common case carries none of the seam logic
 	const int r0_in_sl = slY ? r0 % slY : 1;
 	int seam = slY ? slY - r0_in_sl : 0x7fffffff; // rows left in the current sub-lattice
 
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(dense_threads(MODE)) dense_update_k(const Upda
 		const int lr = r0 + r;
 		const uint32_t grow = p.row_base + (uint32_t)lr;
 		const bool back = (p.color == 0) ? !(grow & 1u) : (grow & 1u); // readBack, optimized/main.cu:542
-		const bool sl_last = seam == 1; // last row of its sub-lattice: the row below is the sub-lattice's first row (:422)
+		const bool sl_last = SUBL && seam == 1; // last row of its sub-lattice: the row below is the sub-lattice's first row (:422)
 		const ptrdiff_t dwo = sl_last ? (ptrdiff_t)(1 - slY) * wpr : (ptrdiff_t)wpr;
 		const uint32_t dw0 = pc[dwo], dw1 = pc[dwo + GROUP];
 		const uint32_t side0 = pc[back ? offL0 : offR0];
@@ -361,9 +361,13 @@ hipError_t launch_dense_update(const UpdateParams &p, int mode, hipStream_t stre
 	if (p.nunits <= 0) return hipSuccess;
 	const int per_block = dense_threads(mode) / GROUP;
 	const dim3 grid((p.nunits + per_block - 1) / per_block), block(dense_threads(mode));
-	if (mode == 1)      hipLaunchKernelGGL(dense_update_k<1>, grid, block, 0, stream, p);
-	else if (mode == 2) hipLaunchKernelGGL(dense_update_k<2>, grid, block, 0, stream, p);
-	else                hipLaunchKernelGGL(dense_update_k<0>, grid, block, 0, stream, p);
+	if (p.slY) { // sub-lattices: the v_cmpx and generic forms carry the seam logic
+		const dim3 g0((p.nunits + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), b0(THREADS);
+		if (mode == 1) hipLaunchKernelGGL((dense_update_k<1, true>), g0, b0, 0, stream, p);
+		else           hipLaunchKernelGGL((dense_update_k<0, true>), g0, b0, 0, stream, p);
+	} else if (mode == 1) hipLaunchKernelGGL((dense_update_k<1, false>), grid, block, 0, stream, p);
+	else if (mode == 2)   hipLaunchKernelGGL((dense_update_k<2, false>), grid, block, 0, stream, p);
+	else                  hipLaunchKernelGGL((dense_update_k<0, false>), grid, block, 0, stream, p);
 	return hipGetLastError();
 }
 

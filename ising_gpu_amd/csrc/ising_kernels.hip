@@ -160,7 +160,8 @@ constexpr int threads_of(int mode) { return mode == 2 ? 1024 : THREADS; }
 #ifndef ISING_LUT_WAVES_PER_SIMD
 #define ISING_LUT_WAVES_PER_SIMD 4
 #endif
-template <int MODE, bool USEJ = false>
+// USEJ (-J couplings) and SUBL (sub-lattices) are template switches so the common case carries none of their code.
+template <int MODE, bool USEJ = false, bool SUBL = false>
 __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_PER_SIMD : 1) update_k(const UpdateParams p) {
 	__shared__ float sh_tab[10];
 	__shared__ __attribute__((aligned(16))) uint8_t lut[MODE == 2 ? LUT_BYTES : 16];
@@ -195,13 +196,13 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 	// Side-neighbour carry dwords, as dword offsets from this lane's own vector in the same row, with the periodic
 	// wrap of loadTile (optimized/main.cu:433,:441): dword 3 of the vector to the left / dword 0 of the one to the right.
 	// With sub-lattices (--xsl) the wrap happens every slV vectors instead of once per row.
-	const int slV = p.slV;
+	const int slV = SUBL ? p.slV : vecs;
 	const int offL0 = ((col0 % slV) == 0 ? slV - 1 : -1) * 4 + 3, offL1 = 15 * 4 + 3;
 	const int offR0 = 4, offR1 = (((col0 + GROUP + 1) % slV) == 0 ? 1 - slV + GROUP : GROUP + 1) * 4;
 	// Row wrap: without sub-lattices rows -1 and Y are the physical halo rows; with them (--ysl) the row above the
 	// first row of a sub-lattice is its last row and vice versa (loadTile, optimized/main.cu:414,:422).
 	// `seam` counts the rows left in the current sub-lattice (one integer division per strip, none per row).
-	const int slY = p.slY;
+	const int slY = SUBL ? p.slY : 0;
 	const int r0_in_sl = slY ? r0 % slY : 1;
 	int seam = slY ? slY - r0_in_sl : 0x7fffffff;
 
@@ -233,7 +234,7 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 		const uint32_t grow = p.row_base + (uint32_t)lr;
 		const bool back = (p.color == 0) ? !(grow & 1u) : (grow & 1u); // readBack, optimized/main.cu:542
 		// issue this row's loads; they are consumed only after the 16 Philox blocks below
-		const bool sl_last = seam == 1; // last row of its sub-lattice: the row below is the sub-lattice's first row
+		const bool sl_last = SUBL && seam == 1; // last row of its sub-lattice: the row below is the sub-lattice's first row
 		const ptrdiff_t dwo = sl_last ? (ptrdiff_t)(1 - slY) * vecs : (ptrdiff_t)vecs;
 		const uint4 dw0 = DBG_LD(pc[dwo]), dw1 = DBG_LD(pc[dwo + GROUP]);
 		const uint32_t *pcw = reinterpret_cast<const uint32_t *>(pc);
@@ -605,12 +606,21 @@ hipError_t launch_update(const UpdateParams &p, int mode, hipStream_t stream) {
 	if (p.nunits <= 0) return hipSuccess;
 	const int per_block = threads_of(mode) / GROUP;
 	const dim3 grid((p.nunits + per_block - 1) / per_block), block(threads_of(mode));
-	if (p.jdst) { // -J: only the v_cmpx and generic kernels carry the coupling path
-		if (mode == 1) hipLaunchKernelGGL((update_k<1, true>), grid, block, 0, stream, p);
-		else           hipLaunchKernelGGL((update_k<0, true>), dim3((p.nunits + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(THREADS), 0, stream, p);
-	} else if (mode == 0) hipLaunchKernelGGL((update_k<0, false>), grid, block, 0, stream, p);
-	else if (mode == 1)   hipLaunchKernelGGL((update_k<1, false>), grid, block, 0, stream, p);
-	else                  hipLaunchKernelGGL((update_k<2, false>), grid, block, 0, stream, p);
+	const dim3 g0((p.nunits + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), b0(THREADS);
+	const bool J = p.jdst != nullptr, S = p.slY != 0;
+	if (J || S) { // -J / sub-lattices: only the v_cmpx and generic kernels carry those paths
+		if (mode == 1) {
+			if (J && S)  hipLaunchKernelGGL((update_k<1, true, true>), g0, b0, 0, stream, p);
+			else if (J)  hipLaunchKernelGGL((update_k<1, true, false>), g0, b0, 0, stream, p);
+			else         hipLaunchKernelGGL((update_k<1, false, true>), g0, b0, 0, stream, p);
+		} else {
+			if (J && S)  hipLaunchKernelGGL((update_k<0, true, true>), g0, b0, 0, stream, p);
+			else if (J)  hipLaunchKernelGGL((update_k<0, true, false>), g0, b0, 0, stream, p);
+			else         hipLaunchKernelGGL((update_k<0, false, true>), g0, b0, 0, stream, p);
+		}
+	} else if (mode == 0) hipLaunchKernelGGL((update_k<0, false, false>), grid, block, 0, stream, p);
+	else if (mode == 1)   hipLaunchKernelGGL((update_k<1, false, false>), grid, block, 0, stream, p);
+	else                  hipLaunchKernelGGL((update_k<2, false, false>), grid, block, 0, stream, p);
 	return hipGetLastError();
 }
 
