@@ -54,7 +54,7 @@ enum {
 
 /* device layout of the spin arrays.  The C-ABI always speaks the reference's packed layout (read/write/dump convert). */
 enum {
-	ISING_LAYOUT_AUTO = 0,   /* dense unless a feature needs the nibble layout (-J couplings) */
+	ISING_LAYOUT_AUTO = 0,   /* dense */
 	ISING_LAYOUT_NIBBLE = 1, /* the reference's: 4 bits per spin, 16 spins per 64-bit word (optimized/main.cu:40, :1243) */
 	ISING_LAYOUT_DENSE = 2   /* 1 bit per spin, 32 spins per 32-bit word = one reference 128-bit vector per word */
 };

@@ -3,7 +3,7 @@
 //
 // Supported: -x -y -n/--nit -s/--seed -d/--devs -a/--alpha -t/--temp -p/--print -e/--exppr -m/--magn -u/--update
 //            -o/--out -h, plus --energy (build-side addition: prints the energy per spin next to each
-//            magnetisation line) and --devmap a,b,.. (place slab k on device devmap[k]; lets a 1-GPU box run -d N).
+//            magnetisation line) and --devmap a,b,.. (place slab k on device devmap[k]; lets a 1-GPU box run -d N), --layout dense|nibble.
 //            --xsl/--ysl (independent periodic sub-lattices, optimized/main.cu:1423-1462),
 //            -c/--corr (two-point correlations file, optimized/main.cu:1072-1138).
 //            -J <PROB> (random anti-ferromagnetic bonds, optimized/main.cu:153-331, :575-618).
@@ -58,6 +58,7 @@ void usage(const char *pname) {
 	        "\t-o|--out               dump the lattice whenever the magnetization is printed\n"
 	        "\t   --energy            also print the energy per spin (not in the reference)\n"
 	        "\t   --devmap <a,b,...>  device ordinal of each slab (default 0..NUM_DEVS-1)\n"
+	        "\t   --layout <dense|nibble> device layout of the spin arrays: 1 bit/spin (default) or the reference's 4\n"
 	        "\t   --xsl <HORIZ_SUB_DIM> horizontal sub-lattice dimension (divisor of -x, multiple of %d)\n"
 	        "\t   --ysl <VERT_SUB_DIM>  vertical sub-lattice dimension (divisor of -y, multiple of %d)\n"
 	        "\t-c|--corr              append the 128 two-point correlations to corr_{Y}x{X}_T_{TEMP}_{SEED} at every print\n"
@@ -121,6 +122,7 @@ int main(int argc, char **argv) {
 	int useGenHamilt = 0;
 	float hamiltPerc1 = 0.0f;
 	std::vector<int> devmap;
+	int layout = ISING_LAYOUT_AUTO;
 
 	static struct option long_options[] = {
 	    {"x", required_argument, 0, 'x'},      {"y", required_argument, 0, 'y'},     {"nit", required_argument, 0, 'n'},
@@ -129,7 +131,7 @@ int main(int argc, char **argv) {
 	    {"update", required_argument, 0, 'u'}, {"magn", required_argument, 0, 'm'},  {"exppr", no_argument, 0, 'e'},
 	    {"corr", no_argument, 0, 'c'},         {"J", required_argument, 0, 'J'},     {"xsl", required_argument, 0, 1},
 	    {"ysl", required_argument, 0, 2},      {"help", required_argument, 0, 'h'},  {"energy", no_argument, 0, 3},
-	    {"devmap", required_argument, 0, 4},   {0, 0, 0, 0}};
+	    {"devmap", required_argument, 0, 4},   {"layout", required_argument, 0, 5},  {0, 0, 0, 0}};
 	while (1) {
 		int option_index = 0;
 		const int och = getopt_long(argc, argv, "x:y:n:ohs:d:a:t:p:u:m:ecJ:r:", long_options, &option_index);
@@ -171,6 +173,11 @@ int main(int argc, char **argv) {
 		case 3: printEnergy = 1; break;
 		case 4:
 			for (char *tok = strtok(optarg, ","); tok; tok = strtok(NULL, ",")) devmap.push_back(atoi(tok));
+			break;
+		case 5:
+			if (!strcmp(optarg, "dense")) layout = ISING_LAYOUT_DENSE;
+			else if (!strcmp(optarg, "nibble")) layout = ISING_LAYOUT_NIBBLE;
+			else { fprintf(stderr, "error: --layout takes dense or nibble\n"); exit(EXIT_FAILURE); }
 			break;
 		case '?': exit(EXIT_FAILURE);
 		default: fprintf(stderr, "unknown option: %c\n", och); exit(EXIT_FAILURE);
@@ -267,7 +274,7 @@ int main(int argc, char **argv) {
 		ising_config cfg;
 		memset(&cfg, 0, sizeof(cfg));
 		cfg.X = X; cfg.Y = Y; cfg.nslabs = ndev; cfg.slab = i; cfg.seed = seed; cfg.temp = temp; cfg.device = devmap[i];
-		cfg.strip_rows = 0; cfg.kernel = ISING_KERNEL_AUTO;
+		cfg.strip_rows = 0; cfg.kernel = ISING_KERNEL_AUTO; cfg.layout = layout;
 		cfg.XSL = useSubLatt ? XSL : 0; cfg.YSL = useSubLatt ? YSL : 0;
 		cfg.use_J = useGenHamilt; cfg.J_prob = hamiltPerc1;
 		ising_ctx *c = nullptr;

@@ -64,7 +64,8 @@ struct ising_ctx {
 	int nstrips = 0;
 	size_t color_words = 0;
 	uint64_t *d_lat = nullptr;          // [2 colours][Y + 2 rows][lld]: row -1 and row Y of each colour are halo rows
-	uint64_t *d_ham = nullptr;          // -J: [hamB, hamW] in the same shape
+	uint64_t *d_ham = nullptr;          // -J: [hamB, hamW], [Y + 2 rows][lld_packed] each (4 bits per site in both layouts)
+	bool ham_planes = false;            // dense layout: the coupling vectors have been transposed into four bit-planes
 	unsigned long long *d_acc = nullptr; // 2 counters
 	uint32_t *d_bits = nullptr;          // correlations: (Y + d_bits_extra) x lld words, one bit per spin
 	int d_bits_extra = 0;
@@ -85,9 +86,12 @@ struct ising_ctx {
 	uint64_t *lat(int color) const { return d_lat + (size_t)color * (color_words + 2 * (size_t)lld) + lld; }
 	uint64_t *halo(int color, int which) const { return which == 0 ? lat(color) - lld : lat(color) + color_words; }
 	size_t alloc_words() const { return 2 * (color_words + 2 * (size_t)lld); }
-	uint64_t *ham(int which) const { return d_ham + (size_t)which * (color_words + 2 * (size_t)lld) + lld; }
-	// "colour" 0/1 = spin arrays, 2 = black couplings
+	size_t ham_words() const { return (size_t)cfg.Y * lld_packed; } // per coupling array, without its two halo rows
+	size_t ham_alloc_words() const { return 2 * (ham_words() + 2 * (size_t)lld_packed); }
+	uint64_t *ham(int which) const { return d_ham + (size_t)which * (ham_words() + 2 * (size_t)lld_packed) + lld_packed; }
+	// "colour" 0/1 = spin arrays, 2 = black couplings; row stride and row count-words of that array
 	uint64_t *plane(int kind) const { return kind == ISING_HAM_BLACK ? ham(0) : lat(kind); }
+	int plane_ld(int kind) const { return kind == ISING_HAM_BLACK ? lld_packed : lld; }
 };
 
 namespace {
@@ -169,6 +173,21 @@ void packed_to_dense(const uint64_t *packed, uint32_t *dense, size_t nvec) {
 	}
 }
 
+// Inverse of ham_planes_k (ising_dense.hip), in place: four coupling bit-planes per vector -> 32 nibbles.
+void planes_to_nibbles(uint64_t *vecs, size_t nvec) {
+	for (size_t v = 0; v < nvec; v++) {
+		uint32_t pl[4];
+		memcpy(pl, vecs + 2 * v, sizeof(pl));
+		uint64_t w[2] = {0, 0};
+		for (int s = 0; s < 32; s++) {
+			const uint64_t nib = ((pl[0] >> s) & 1u) | (((pl[1] >> s) & 1u) << 1) | (((pl[2] >> s) & 1u) << 2) | (((pl[3] >> s) & 1u) << 3);
+			w[s >> 4] |= nib << (4 * (s & 15));
+		}
+		vecs[2 * v] = w[0];
+		vecs[2 * v + 1] = w[1];
+	}
+}
+
 int choose_strip_rows(int gx, int Y, bool dense) {
 	// Enough (column-group x strip) units to give every SIMD several waves, while keeping strips tall so the two
 	// halo rows per strip stay a small fraction of the source traffic (measured optimum: 32 rows for the nibble
@@ -236,12 +255,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		delete c;
 		return fail(ISING_E_ARG, "bad layout %d", cfg->layout);
 	}
-	const bool needs_nibble = cfg->use_J != 0;
-	if (cfg->layout == ISING_LAYOUT_DENSE && needs_nibble) {
-		delete c;
-		return fail(ISING_E_ARG, "-J couplings need the nibble layout");
-	}
-	c->dense = cfg->layout == ISING_LAYOUT_DENSE || (cfg->layout == ISING_LAYOUT_AUTO && !needs_nibble);
+	c->dense = cfg->layout != ISING_LAYOUT_NIBBLE;
 	c->lld_packed = cfg->X / 32;
 	c->lld = c->dense ? cfg->X / 128 : cfg->X / 32;
 	c->gx = cfg->X / 2048;
@@ -261,8 +275,8 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (e == hipSuccess) e = hipMalloc((void **)&c->d_lut, 65536);
 	if (e == hipSuccess && cfg->use_J) {
 		if (cfg->coupling_mem) c->d_ham = static_cast<uint64_t *>(cfg->coupling_mem);
-		else e = hipMalloc((void **)&c->d_ham, c->alloc_words() * sizeof(uint64_t));
-		if (e == hipSuccess) e = hipMemset(c->d_ham, 0, c->alloc_words() * sizeof(uint64_t)); // optimized/main.cu:1609
+		else e = hipMalloc((void **)&c->d_ham, c->ham_alloc_words() * sizeof(uint64_t));
+		if (e == hipSuccess) e = hipMemset(c->d_ham, 0, c->ham_alloc_words() * sizeof(uint64_t)); // optimized/main.cu:1609
 	}
 	if (e != hipSuccess) {
 		const int rc = fail(ISING_E_HIP, "device allocation failed: %s", hipGetErrorString(e));
@@ -436,11 +450,12 @@ int ising_halo_ptrs(ising_ctx *c, int color, void **send_top, void **send_bot, v
 	if (color == ISING_HAM_BLACK && !c->cfg.use_J) return fail(ISING_E_STATE, "couplings are not enabled (use_J)");
 	if (c->cfg.nslabs == 1) return fail(ISING_E_STATE, "no halo buffers with nslabs == 1 (rows wrap inside the slab)");
 	uint64_t *base = c->plane(color);
+	const size_t ld = (size_t)c->plane_ld(color);
 	if (send_top) *send_top = base;
-	if (send_bot) *send_bot = base + (size_t)(c->cfg.Y - 1) * c->lld;
-	if (recv_top) *recv_top = base - c->lld;
-	if (recv_bot) *recv_bot = base + c->color_words;
-	if (row_bytes) *row_bytes = (size_t)c->lld * sizeof(uint64_t);
+	if (send_bot) *send_bot = base + (size_t)(c->cfg.Y - 1) * ld;
+	if (recv_top) *recv_top = base - ld;
+	if (recv_bot) *recv_bot = base + (size_t)c->cfg.Y * ld;
+	if (row_bytes) *row_bytes = ld * sizeof(uint64_t);
 	return ISING_OK;
 }
 
@@ -588,6 +603,7 @@ int ising_init_couplings_black(ising_ctx *c) {
 	if (thr >= (1ull << 32)) return fail(ISING_E_ARG, "J probability %g sets every bit", (double)prob); // unreachable: u <= 1 and prob <= 1 gives at most 2^32 - 1... see below
 	p.thr = (uint32_t)thr;
 	HIP_TRY(ising::launch_ham_init_black(p, c->stream));
+	c->ham_planes = false; // nibble form until the white couplings have been assembled from it
 	return ISING_OK;
 }
 
@@ -598,13 +614,19 @@ int ising_init_couplings_white(ising_ctx *c) {
 	ising::HamWhiteParams p{};
 	p.hamB = c->ham(0);
 	p.hamW = c->ham(1);
-	p.lld = c->lld;
+	if (c->ham_planes) return fail(ISING_E_STATE, "ising_init_couplings_white needs a fresh ising_init_couplings_black");
+	p.lld = c->lld_packed;
 	p.Y = c->cfg.Y;
 	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
-	p.slW = c->cfg.XSL ? c->cfg.XSL / 32 : c->lld;
+	p.slW = c->cfg.XSL ? c->cfg.XSL / 32 : c->lld_packed;
 	p.slY = c->cfg.XSL ? c->cfg.YSL : 0;
 	p.wrap = c->cfg.nslabs == 1;
 	HIP_TRY(ising::launch_ham_init_white(p, c->stream));
+	if (c->dense) {
+		// the dense update reads four coupling bit-planes per 32-site word: transpose both arrays in place
+		for (int w = 0; w < 2; w++) HIP_TRY(ising::launch_ham_planes(c->ham(w), c->ham_words() / 2, c->stream));
+		c->ham_planes = true;
+	}
 	return ISING_OK;
 }
 
@@ -619,8 +641,10 @@ int ising_read_couplings(ising_ctx *c, int which, int64_t row0, int64_t nrows, u
 	if (int rc = check_rows(c, which, row0, nrows, dst_host)) return rc;
 	if (!c->cfg.use_J) return fail(ISING_E_STATE, "couplings are not enabled (use_J)");
 	if (int rc = bind(c)) return rc;
-	HIP_TRY(hipMemcpyAsync(dst_host, c->ham(which) + (size_t)row0 * c->lld, (size_t)nrows * c->lld * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+	const size_t nw = (size_t)nrows * c->lld_packed;
+	HIP_TRY(hipMemcpyAsync(dst_host, c->ham(which) + (size_t)row0 * c->lld_packed, nw * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (c->ham_planes) planes_to_nibbles(dst_host, nw / 2);
 	return ISING_OK;
 }
 
@@ -666,13 +690,13 @@ static int ring_events(ising_ctx *c) {
 static int ring_send(ising_ctx **ctxs, int n, int k, int color) {
 	ising_ctx *c = ctxs[k], *prev = ctxs[(k + n - 1) % n], *next = ctxs[(k + 1) % n];
 	if (c->cfg.XSL) return ISING_OK; // sub-lattices never reach across slabs
-	const size_t nb = (size_t)c->lld * sizeof(uint64_t);
+	const size_t ld = (size_t)c->plane_ld(color), nb = ld * sizeof(uint64_t);
 	if (int rc = ring_events(c)) return rc;
 	ring_enable_peers(c, prev, next);
 	if (int rc = bind(c)) return rc;
 	// next slab's top halo <- my last row ; previous slab's bottom halo <- my first row
-	HIP_TRY(hipMemcpyPeerAsync(next->plane(color) - next->lld, next->cfg.device, c->plane(color) + (size_t)(c->cfg.Y - 1) * c->lld, c->cfg.device, nb, c->stream));
-	HIP_TRY(hipMemcpyPeerAsync(prev->plane(color) + prev->color_words, prev->cfg.device, c->plane(color), c->cfg.device, nb, c->stream));
+	HIP_TRY(hipMemcpyPeerAsync(next->plane(color) - ld, next->cfg.device, c->plane(color) + (size_t)(c->cfg.Y - 1) * ld, c->cfg.device, nb, c->stream));
+	HIP_TRY(hipMemcpyPeerAsync(prev->plane(color) + (size_t)prev->cfg.Y * ld, prev->cfg.device, c->plane(color), c->cfg.device, nb, c->stream));
 	if (color != ISING_HAM_BLACK) HIP_TRY(hipEventRecord(c->ev_sent[color], c->stream));
 	return ISING_OK;
 }

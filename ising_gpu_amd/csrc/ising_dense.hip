@@ -53,11 +53,20 @@ __device__ __forceinline__ void accept_bits(uint32_t &c3, uint32_t &c4, uint32_t
 }
 
 // Bit-sliced count of up neighbours of 32 spins: (n2 n1 n0) = up + down + centre + side, each a 0/1 plane.
+// USEJ: J = coupling planes {x: right, y: left, z: down, w: up} of the destination sites; a set bit flips that
+// neighbour's contribution (optimized/main.cu:575-618).
+template <bool USEJ = false>
 __device__ __forceinline__ void neighbour_planes(uint32_t up, uint32_t ct, uint32_t dw, uint32_t side_word, bool back,
-                                                 uint32_t &n0, uint32_t &n1, uint32_t &n2) {
+                                                 uint32_t &n0, uint32_t &n1, uint32_t &n2, const uint4 &J = uint4()) {
 	// the side neighbour of spin k is spin k-1 (back) or k+1 of the same row; the bit that falls off the word comes from
 	// the adjacent word (optimized/main.cu:546-573 does the same with nibbles)
-	const uint32_t sd = back ? __builtin_amdgcn_alignbit(ct, side_word, 31) : __builtin_amdgcn_alignbit(side_word, ct, 1);
+	uint32_t sd = back ? __builtin_amdgcn_alignbit(ct, side_word, 31) : __builtin_amdgcn_alignbit(side_word, ct, 1);
+	if (USEJ) {
+		// the same-index word holds the right neighbours when `back` (the shifted one the left), and vice versa
+		up ^= J.w; dw ^= J.z;
+		ct ^= back ? J.x : J.y;
+		sd ^= back ? J.y : J.x;
+	}
 	const uint32_t x = up ^ dw, y = up & dw, z = ct ^ sd, w = ct & sd;
 	const uint32_t c1 = x & z;
 	n0 = x ^ z;
@@ -99,7 +108,7 @@ constexpr int dense_threads(int mode) { return mode == 2 ? DENSE_LUT_THREADS : T
 // 64 KiB LDS table indexed by the top 16 bits of a draw: entry = [x<n3] | [x<n4]<<1 (0, 1 or 3), or 2 where the top
 // half does not decide; sixteen sites accumulate as 2-bit fields with one v_lshl_or each, undecided sites are redone
 // with exact compares.
-template <int MODE, bool SUBL = false>
+template <int MODE, bool SUBL = false, bool USEJ = false>
 __global__ void __launch_bounds__(dense_threads(MODE)) dense_update_k(const UpdateParams p) {
 	constexpr bool GENERIC = MODE == 1;
 	__shared__ float sh_tab[10];
@@ -136,6 +145,8 @@ __global__ void __launch_bounds__(dense_threads(MODE)) dense_update_k(const Upda
 
 	const uint32_t *pc = reinterpret_cast<const uint32_t *>(p.src) + ((ptrdiff_t)r0 * wpr + col0);
 	uint32_t *pm = reinterpret_cast<uint32_t *>(p.dst) + ((ptrdiff_t)r0 * wpr + col0);
+	// -J: four coupling bit-planes per destination word, {right, left, down, up} (ham_planes_k)
+	const uint4 *pj = USEJ ? reinterpret_cast<const uint4 *>(p.jdst) + ((ptrdiff_t)r0 * wpr + col0) : nullptr;
 	const ptrdiff_t wrap_bot = (ptrdiff_t)p.Y * wpr;
 
 	const uint32_t k2y = p.seed_hi + 2u * PHILOX_W1;
@@ -158,6 +169,8 @@ __global__ void __launch_bounds__(dense_threads(MODE)) dense_update_k(const Upda
 		const uint32_t side0 = pc[back ? offL0 : offR0];
 		const uint32_t side1 = pc[back ? offL1 : offR1];
 		uint32_t me0 = pm[0], me1 = pm[GROUP];
+		uint4 j0 = uint4(), j1 = uint4();
+		if (USEJ) { j0 = pj[0]; j1 = pj[GROUP]; pj += wpr; }
 
 		const uint32_t tid = ((grow >> 4) * (uint32_t)p.gx + (uint32_t)bx) * 256u + (grow & 15u) * 16u + (uint32_t)tx;
 		const PhiloxRow pr = philox_row_setup(tid, seed_lo_cy, k2y);
@@ -209,14 +222,14 @@ __global__ void __launch_bounds__(dense_threads(MODE)) dense_update_k(const Upda
 				accept_bits<m>(c3[j], c4[j], o[0], o[1], o[2], o[3], p.n3, p.n4);
 			});
 			uint32_t n0, n1, n2;
-			neighbour_planes(up0, ct0, dw0, side0, back, n0, n1, n2);
+			neighbour_planes<USEJ>(up0, ct0, dw0, side0, back, n0, n1, n2, j0);
 			me0 ^= flip_mask(me0, n0, n1, n2, c3[0], c4[0]);
-			neighbour_planes(up1, ct1, dw1, side1, back, n0, n1, n2);
+			neighbour_planes<USEJ>(up1, ct1, dw1, side1, back, n0, n1, n2, j1);
 			me1 ^= flip_mask(me1, n0, n1, n2, c3[1], c4[1]);
 		} else {
 			uint32_t me[2] = {me0, me1}, n0[2], n1[2], n2[2], flip[2] = {0u, 0u};
-			neighbour_planes(up0, ct0, dw0, side0, back, n0[0], n1[0], n2[0]);
-			neighbour_planes(up1, ct1, dw1, side1, back, n0[1], n1[1], n2[1]);
+			neighbour_planes<USEJ>(up0, ct0, dw0, side0, back, n0[0], n1[0], n2[0], j0);
+			neighbour_planes<USEJ>(up1, ct1, dw1, side1, back, n0[1], n1[1], n2[1], j1);
 #pragma unroll
 			for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -354,6 +367,29 @@ __global__ void __launch_bounds__(THREADS) dense_pack_bits_k(const uint32_t *__r
 	}
 }
 
+// -J with the dense layout: the coupling arrays are generated in the reference's nibble form (ham_init_*_k) and then
+// transposed in place, 16 bytes at a time: 32 nibbles <right, left, down, up> = bits 0..3 -> four 32-bit planes
+// {x: right, y: left, z: down, w: up}, bit s = site s of the vector (the dense spin word's bit order).
+__global__ void __launch_bounds__(THREADS) ham_planes_k(uint4 *__restrict__ ham, size_t nvec) {
+	for (size_t v = (size_t)blockIdx.x * THREADS + threadIdx.x; v < nvec; v += (size_t)gridDim.x * THREADS) {
+		const uint4 n = ham[v];
+		const uint32_t w[4] = {n.x, n.y, n.z, n.w};
+		uint32_t pl[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+#pragma unroll
+			for (int b = 0; b < 4; ++b) {
+				uint32_t t = (w[k] >> b) & 0x11111111u; // bit b of 8 nibbles, at positions 0, 4, ..., 28
+				t = (t | (t >> 3)) & 0x03030303u;
+				t = (t | (t >> 6)) & 0x000F000Fu;
+				t = (t | (t >> 12)) & 0xFFu;
+				pl[b] |= t << (8 * k);
+			}
+		}
+		ham[v] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+	}
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------------------------- launchers
@@ -361,13 +397,29 @@ hipError_t launch_dense_update(const UpdateParams &p, int mode, hipStream_t stre
 	if (p.nunits <= 0) return hipSuccess;
 	const int per_block = dense_threads(mode) / GROUP;
 	const dim3 grid((p.nunits + per_block - 1) / per_block), block(dense_threads(mode));
-	if (p.slY) { // sub-lattices: the v_cmpx and generic forms carry the seam logic
-		const dim3 g0((p.nunits + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), b0(THREADS);
-		if (mode == 1) hipLaunchKernelGGL((dense_update_k<1, true>), g0, b0, 0, stream, p);
-		else           hipLaunchKernelGGL((dense_update_k<0, true>), g0, b0, 0, stream, p);
-	} else if (mode == 1) hipLaunchKernelGGL((dense_update_k<1, false>), grid, block, 0, stream, p);
+	const dim3 g0((p.nunits + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), b0(THREADS);
+	const bool generic = mode == 1;
+	if (p.jdst) { // -J couplings: the v_cmpx and generic forms read the coupling planes
+		if (p.slY) {
+			if (generic) hipLaunchKernelGGL((dense_update_k<1, true, true>), g0, b0, 0, stream, p);
+			else         hipLaunchKernelGGL((dense_update_k<0, true, true>), g0, b0, 0, stream, p);
+		} else {
+			if (generic) hipLaunchKernelGGL((dense_update_k<1, false, true>), g0, b0, 0, stream, p);
+			else         hipLaunchKernelGGL((dense_update_k<0, false, true>), g0, b0, 0, stream, p);
+		}
+	} else if (p.slY) { // sub-lattices: the v_cmpx and generic forms carry the seam logic
+		if (generic) hipLaunchKernelGGL((dense_update_k<1, true>), g0, b0, 0, stream, p);
+		else         hipLaunchKernelGGL((dense_update_k<0, true>), g0, b0, 0, stream, p);
+	} else if (generic)   hipLaunchKernelGGL((dense_update_k<1, false>), grid, block, 0, stream, p);
 	else if (mode == 2)   hipLaunchKernelGGL((dense_update_k<2, false>), grid, block, 0, stream, p);
 	else                  hipLaunchKernelGGL((dense_update_k<0, false>), grid, block, 0, stream, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_ham_planes(uint64_t *ham, size_t nvec, hipStream_t stream) {
+	size_t blocks = (nvec + THREADS - 1) / THREADS;
+	if (blocks > 8192) blocks = 8192;
+	hipLaunchKernelGGL(ham_planes_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, reinterpret_cast<uint4 *>(ham), nvec);
 	return hipGetLastError();
 }
 

@@ -12,13 +12,17 @@ import ising_gpu_amd as ig
 
 pytestmark = pytest.mark.gpu
 CLI = os.path.join(os.path.dirname(ig.LIB_PATH), "cuIsing")
+# the coupling arrays are nibble-packed on the device with the reference's layout and four bit-planes with the dense one
+LAYOUTS = pytest.mark.parametrize("layout", [ig.LAYOUT_DENSE, ig.LAYOUT_NIBBLE], ids=["dense", "nibble"])
 
 
 @pytest.mark.parametrize("X,Y,prob,kernel", [(2048, 32, 0.3, ig.KERNEL_AUTO), (4096, 64, 0.5, ig.KERNEL_GENERIC), (6144, 48, 1.0, ig.KERNEL_AUTO),
                                              (2048, 16, 0.0, ig.KERNEL_AUTO)])
-def test_couplings_and_update_bit_exact(gpu, oracle_mod, X, Y, prob, kernel):
+@LAYOUTS
+def test_couplings_and_update_bit_exact(gpu, oracle_mod, X, Y, prob, kernel, layout):
     orc = oracle_mod.OracleLattice(X, Y, seed=1234, temp=1.8).init().init_couplings(prob)
-    with ig.IsingSlab(X, Y, seed=1234, temp=1.8, J_prob=prob, kernel=kernel) as s:
+    with ig.IsingSlab(X, Y, seed=1234, temp=1.8, J_prob=prob, kernel=kernel, layout=layout) as s:
+        assert s.layout == layout
         s.init().init_couplings()
         assert np.array_equal(s.read_couplings(ig.BLACK), orc.hamB)
         assert np.array_equal(s.read_couplings(ig.WHITE), orc.hamW)
@@ -28,10 +32,11 @@ def test_couplings_and_update_bit_exact(gpu, oracle_mod, X, Y, prob, kernel):
             assert np.array_equal(s.read(ig.BLACK), orc.black) and np.array_equal(s.read(ig.WHITE), orc.white), (prob, s.it)
 
 
-def test_couplings_with_sublattices(gpu, oracle_mod):
+@LAYOUTS
+def test_couplings_with_sublattices(gpu, oracle_mod, layout):
     X, Y = 4096, 64
     orc = oracle_mod.OracleLattice(X, Y, seed=9, temp=1.2, XSL=2048, YSL=32).init().init_couplings(0.4)
-    with ig.IsingSlab(X, Y, seed=9, temp=1.2, XSL=2048, YSL=32, J_prob=0.4) as s:
+    with ig.IsingSlab(X, Y, seed=9, temp=1.2, XSL=2048, YSL=32, J_prob=0.4, layout=layout) as s:
         s.init().init_couplings()
         assert np.array_equal(s.read_couplings(ig.WHITE), orc.hamW)
         s.sweep(3)
@@ -39,12 +44,13 @@ def test_couplings_with_sublattices(gpu, oracle_mod):
         assert np.array_equal(s.read(ig.BLACK), orc.black) and np.array_equal(s.read(ig.WHITE), orc.white)
 
 
-def test_couplings_ring_matches_single_slab(gpu):
+@LAYOUTS
+def test_couplings_ring_matches_single_slab(gpu, layout):
     X, Y, n = 4096, 192, 3
-    with ig.IsingSlab(X, Y, seed=4, temp=1.5, J_prob=0.35) as one:
+    with ig.IsingSlab(X, Y, seed=4, temp=1.5, J_prob=0.35, layout=layout) as one:
         one.init().init_couplings().sweep(4)
         ref = (one.read(ig.BLACK), one.read(ig.WHITE), one.read_couplings(ig.WHITE))
-    slabs = [ig.IsingSlab(X, Y // n, seed=4, temp=1.5, nslabs=n, slab=k, J_prob=0.35) for k in range(n)]
+    slabs = [ig.IsingSlab(X, Y // n, seed=4, temp=1.5, nslabs=n, slab=k, J_prob=0.35, layout=layout) for k in range(n)]
     try:
         ring = ig.LocalRing([ig.HipSlabBackend(s) for s in slabs]).init()
         ring.sweep(4)
@@ -54,11 +60,20 @@ def test_couplings_ring_matches_single_slab(gpu):
     finally:
         for s in slabs:
             s.close()
+    # the same with torch-owned spin and coupling buffers (what SlabRing hands to RCCL)
+    backs = [ig.HipSlabBackend.create(X, Y // n, seed=4, temp=1.5, nslabs=n, slab=k, J_prob=0.35, layout=layout) for k in range(n)]
+    try:
+        ig.LocalRing(backs).init().sweep(4)
+        assert np.array_equal(np.concatenate([b.slab.read_couplings(ig.WHITE) for b in backs]), ref[2])
+        assert np.array_equal(np.concatenate([b.slab.read(ig.WHITE) for b in backs]), ref[1])
+    finally:
+        for b in backs:
+            b.slab.close()
 
 
 def test_cli_J_transcript(gpu, oracle_mod):
     X, Y, seed = 2048, 64, 606
-    for ndev, ylocal, extra in ((1, Y, []), (2, Y // 2, ["--devmap", "0,0"])):
+    for ndev, ylocal, extra in ((1, Y, []), (1, Y, ["--layout", "nibble"]), (2, Y // 2, ["--devmap", "0,0"])):
         r = subprocess.run([CLI, "-x", str(X), "-y", str(ylocal), "-d", str(ndev), "-n", "6", "-p", "3", "-t", "1.0", "-s", str(seed), "-J", "0.25"] + extra,
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
