@@ -16,7 +16,7 @@ HAM_BLACK = 2  # the black coupling array as a third plane for halo exchange
 CRIT_TEMP_F32 = 2.2691853046417236  # float32(2.26918531421f), CRIT_TEMP optimized/main.cu:42
 SEED_DEF = 463463564571  # optimized/main.cu:63
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST, KERNEL_LUT = 0, 1, 2, 3
-LAYOUT_AUTO, LAYOUT_NIBBLE, LAYOUT_DENSE = 0, 1, 2
+LAYOUT_AUTO, LAYOUT_NIBBLE, LAYOUT_DENSE, LAYOUT_BALLOT = 0, 1, 2, 3
 
 
 class IsingConfig(C.Structure):

@@ -1,0 +1,274 @@
+// ising_ballot.hip -- the "ballot" device layout: 1 bit per spin, bits ordered the way the wave produces them.
+//
+// The dense layout (ising_dense.hip) keeps the reference's thread<->vector mapping, so every lane has to collect the
+// accept decisions of its own 64 sites into its own registers: 8 v_cmpx + 8 masked ORs per draw block, ~30 % of the
+// kernel's VALU cycles.  A plain v_cmp hands the same 64 decisions -- one per lane -- to the scalar unit as a 64-bit
+// lane mask ("ballot") for free.  This layout makes that mask THE storage word:
+//
+//   word (row, wc, p),  p = 32 j + 4 m + q   <->  draw block B = 8 j + m, Philox output q of that block
+//   bit l = 16 g + tx of the word             <->  the lane that drew it: vector column (4 wc + g) 32 + 16 j + tx,
+//                                                  site s(m, q) = {2m, 16+2m, 2m+1, 17+2m}[q] of that vector
+//
+// i.e. a row is X/8192 "wave columns" of 64 words of 64 bits (X/16 bytes per colour row, the same as the dense
+// layout); the Philox stream assignment (tid, counter, output -> site) is the reference's, untouched.
+//
+// Update of one row by one wave:
+//   draw phase   16 Philox blocks per lane as everywhere else; per block 8 v_cmp (2 thresholds x 4 outputs) whose
+//                SGPR-pair results go to a per-wave scratch slot with scalar stores (no VALU, no EXEC games);
+//                s_dcache_wb once per row pushes the slot to L2.
+//   word phase   one row later (the write-back has long finished), lane p owns word p of the row: it reads its two
+//                accept masks back (16 bytes, L1-bypassing load), the words above/below from memory and its side word
+//                from another lane (ds_bpermute: site s-1 / s+1 of the same vector is the same bit of another word;
+//                only sites 0 / 31 reach into the neighbouring vector = the neighbouring lane bit, 2 words per row),
+//                then the same bit-sliced adder and Metropolis mask as the dense kernel, 64 sites per lane.
+//
+// Scope: the integer-threshold fast path without sub-lattices and couplings, X a multiple of 8192.  Everything else
+// (generic FP32 kernel, -J, --xsl) runs on the dense layout; ising_capi.cpp converts with the two kernels at the end
+// of this file and uses the dense kernels for the observables that need neighbour geometry.
+#include "ising_device.hpp"
+
+namespace ising {
+namespace {
+
+constexpr uint64_t LANE0 = 0x0001000100010001ull;  // tx = 0 of each 16-lane group
+constexpr uint64_t LANE15 = 0x8000800080008000ull; // tx = 15
+
+__device__ __forceinline__ constexpr int word_of(int j, int m, int q) { return 32 * j + 4 * m + q; }
+
+__device__ __forceinline__ uint64_t bperm64(int src_lane, uint64_t v) {
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)v);
+	const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)(v >> 32));
+	return ((uint64_t)hi << 32) | lo;
+}
+
+// 64 sites at once; same logic as neighbour_planes + flip_mask of ising_dense.hip
+__device__ __forceinline__ uint64_t flips64(uint64_t me, uint64_t up, uint64_t ct, uint64_t dw, uint64_t sd, uint64_t c3, uint64_t c4) {
+	const uint64_t x = up ^ dw, y = up & dw, z = ct ^ sd, w = ct & sd;
+	const uint64_t c1 = x & z;
+	const uint64_t n0 = x ^ z, n1 = y ^ w ^ c1, n2 = (y & w) | (c1 & (y ^ w));
+	const uint64_t is3 = (me & n1 & n0) | (~me & n0 & ~n1 & ~n2);
+	const uint64_t is4 = (me & n2) | (~me & ~(n0 | n1 | n2));
+	return ~(is3 | is4) | (is3 & c3) | (is4 & c4);
+}
+
+__global__ void __launch_bounds__(THREADS) ballot_update_k(const UpdateParams p) {
+	const int lane = threadIdx.x & 63;
+	const int tx = threadIdx.x & (GROUP - 1), g = (threadIdx.x >> 4) & 3;
+	const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6));
+	const int unit0 = wave * 4; // a wave covers 4 consecutive 32-vector column groups of one strip (gx % 4 == 0)
+	if (unit0 >= p.nunits) return;
+	const int rng = unit0 >= p.nunits0;
+	const int u = unit0 - (rng ? p.nunits0 : 0);
+	const int sidx = u / p.gx;
+	const int bx0 = u - sidx * p.gx;
+	const int nwc = p.gx >> 2, wc = bx0 >> 2;
+	const int bx = bx0 + g;
+	const int r0 = p.row_lo[rng] + sidx * p.H;
+	const int nrows = min(p.H, p.row_hi[rng] - r0);
+	const int wpr = nwc * 64; // 64-bit words per colour row
+
+	// word phase: this lane owns word p = lane of every row
+	const int j = lane >> 5, m = (lane >> 2) & 7, q = lane & 3;
+	int backA, fwdA; // lane holding the word with site s-1 / s+1 of the same vectors
+	if (q == 2) backA = word_of(j, m, 0);
+	else if (q == 3) backA = word_of(j, m, 1);
+	else if (q == 0) backA = m ? word_of(j, m - 1, 2) : word_of(j, 7, 3);
+	else backA = m ? word_of(j, m - 1, 3) : word_of(j, 7, 2);
+	if (q == 0) fwdA = word_of(j, m, 2);
+	else if (q == 1) fwdA = word_of(j, m, 3);
+	else if (q == 2) fwdA = m < 7 ? word_of(j, m + 1, 0) : word_of(j, 0, 1);
+	else fwdA = m < 7 ? word_of(j, m + 1, 1) : word_of(j, 0, 0);
+	// site 0 (back) / site 31 (forward) have their side neighbour in the adjacent vector = the adjacent lane's bit of
+	// word (., 7, 3) / (., 0, 0); lanes tx = 0 / 15 cross into the other j, the next group or the next wave column
+	const bool sp_back = m == 0 && q == 0, sp_fwd = m == 7 && q == 3;
+	const int backB = word_of(1 - j, 7, 3), fwdB = word_of(1 - j, 0, 0);
+	const int prev_off = ((wc ? wc - 1 : nwc - 1) - wc) * 64 + word_of(1, 7, 3) - lane; // from this lane's own word
+	const int next_off = ((wc + 1 < nwc ? wc + 1 : 0) - wc) * 64 + word_of(0, 0, 0) - lane;
+
+	const uint64_t *ps = p.src + ((ptrdiff_t)r0 * wpr + wc * 64 + lane);
+	uint64_t *pd = p.dst + ((ptrdiff_t)r0 * wpr + wc * 64 + lane);
+	const ptrdiff_t wrap_bot = (ptrdiff_t)p.Y * wpr;
+
+	// per-wave scratch: two slots of 64 x (c3, c4) masks
+	const uint64_t *slot_v = p.scratch + (size_t)wave * 256;
+	const uint32_t slot_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)slot_v);
+	const uint32_t slot_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)slot_v >> 32));
+	uint64_t *slot = reinterpret_cast<uint64_t *>(((uintptr_t)slot_hi << 32) | slot_lo);
+
+	const uint32_t k2y = p.seed_hi + 2u * PHILOX_W1;
+	const uint32_t cx_base = 16u * (2u * p.it + p.color);
+	const uint32_t seed_lo_cy = p.seed_lo ^ (uint32_t)((2ull * p.it + p.color) >> 28); // see dense_update_k
+
+	uint64_t up = ps[-(ptrdiff_t)wpr], ct = ps[0];
+
+	for (int r = 0; r <= nrows; ++r) {
+		if (r < nrows) {
+			// ---- draw phase, row r0 + r
+			const uint32_t grow = p.row_base + (uint32_t)(r0 + r);
+			const uint32_t tid = ((grow >> 4) * (uint32_t)p.gx + (uint32_t)bx) * 256u + (grow & 15u) * 16u + (uint32_t)tx;
+			const PhiloxRow pr = philox_row_setup(tid, seed_lo_cy, k2y);
+			uint64_t *cur = slot + (r & 1) * 128;
+			static_for<16>([&](auto B) {
+				uint32_t o0, o1, o2, o3;
+				philox_block(pr, cx_base + (uint32_t)B.value, p.seed_lo, p.seed_hi, o0, o1, o2, o3);
+#if defined(ISING_BAL_X2) // A/B: compiler-allocated SGPR pairs, eight 8-byte scalar stores per block
+				unsigned long long a0, a1, a2, a3, a4, a5, a6, a7;
+				asm volatile("v_cmp_gt_u32_e64 %0, %8, %10\n\tv_cmp_gt_u32_e64 %1, %9, %10\n\t"
+				             "v_cmp_gt_u32_e64 %2, %8, %11\n\tv_cmp_gt_u32_e64 %3, %9, %11\n\t"
+				             "v_cmp_gt_u32_e64 %4, %8, %12\n\tv_cmp_gt_u32_e64 %5, %9, %12\n\t"
+				             "v_cmp_gt_u32_e64 %6, %8, %13\n\tv_cmp_gt_u32_e64 %7, %9, %13"
+				             : "=&s"(a0), "=&s"(a1), "=&s"(a2), "=&s"(a3), "=&s"(a4), "=&s"(a5), "=&s"(a6), "=&s"(a7)
+				             : "s"(p.n3), "s"(p.n4), "v"(o0), "v"(o1), "v"(o2), "v"(o3));
+				const uint64_t *dstp = cur + 8 * B.value; // words p = 4B .. 4B+3, (c3, c4) each
+				asm volatile("s_store_dwordx2 %0, %8, 0x0\n\ts_store_dwordx2 %1, %8, 0x8\n\t"
+				             "s_store_dwordx2 %2, %8, 0x10\n\ts_store_dwordx2 %3, %8, 0x18\n\t"
+				             "s_store_dwordx2 %4, %8, 0x20\n\ts_store_dwordx2 %5, %8, 0x28\n\t"
+				             "s_store_dwordx2 %6, %8, 0x30\n\ts_store_dwordx2 %7, %8, 0x38"
+				             :: "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6), "s"(a7), "s"(dstp) : "memory");
+#else
+				// (c3, c4) of one output = four consecutive SGPRs = one 16-byte scalar store: word p = 4B + q of the slot.
+				// Fixed registers: inline asm cannot name halves of an SGPR tuple operand.
+				const uint64_t *dstp = cur + 8 * B.value;
+				asm volatile("v_cmp_gt_u32_e64 s[84:85], %0, %2\n\tv_cmp_gt_u32_e64 s[86:87], %1, %2\n\t"
+				             "v_cmp_gt_u32_e64 s[88:89], %0, %3\n\tv_cmp_gt_u32_e64 s[90:91], %1, %3\n\t"
+				             "v_cmp_gt_u32_e64 s[92:93], %0, %4\n\tv_cmp_gt_u32_e64 s[94:95], %1, %4\n\t"
+				             "v_cmp_gt_u32_e64 s[96:97], %0, %5\n\tv_cmp_gt_u32_e64 s[98:99], %1, %5\n\t"
+#if defined(ISING_BAL_GLC)
+				             "s_store_dwordx4 s[84:87], %6, 0x0 glc\n\ts_store_dwordx4 s[88:91], %6, 0x10 glc\n\t"
+				             "s_store_dwordx4 s[92:95], %6, 0x20 glc\n\ts_store_dwordx4 s[96:99], %6, 0x30 glc"
+#else
+				             "s_store_dwordx4 s[84:87], %6, 0x0\n\ts_store_dwordx4 s[88:91], %6, 0x10\n\t"
+				             "s_store_dwordx4 s[92:95], %6, 0x20\n\ts_store_dwordx4 s[96:99], %6, 0x30"
+#endif
+				             :: "s"(p.n3), "s"(p.n4), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(dstp)
+				             : "memory", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97",
+				               "s98", "s99");
+#endif
+			});
+		}
+		if (r > 0) {
+			// ---- word phase, row r0 + r - 1; its masks were written back during the draw phase above
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			const int lr = r0 + r - 1;
+			const uint32_t grow = p.row_base + (uint32_t)lr;
+			const bool back = (p.color == 0) ? !(grow & 1u) : (grow & 1u); // readBack, optimized/main.cu:542
+			const uint64_t *msk = slot + ((r - 1) & 1) * 128 + 2 * lane;
+			const uint64_t c3 = __hip_atomic_load(msk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const uint64_t c4 = __hip_atomic_load(msk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const uint64_t dw = ps[wpr];
+			const uint64_t me = pd[0];
+#if defined(ISING_DBG_NOWORD) // perf investigation only
+			pd[0] = me ^ (c3 & c4 & dw & ct);
+			up = ct; ct = dw; ps += wpr; pd += wpr;
+			if (r < nrows) asm volatile("s_dcache_wb" ::: "memory");
+			continue;
+#endif
+			const uint64_t A = bperm64(back ? backA : fwdA, ct);
+			const uint64_t Bw = bperm64(back ? backB : fwdB, ct);
+			uint64_t sd = A;
+			if (back) {
+				if (sp_back) {
+					if (j == 0) sd = ((A << 1) & ~LANE0) | ((Bw << 1) & LANE0 & ~1ull) | (ps[prev_off] >> 63);
+					else        sd = ((A << 1) & ~LANE0) | ((Bw >> 15) & LANE0);
+				}
+			} else {
+				if (sp_fwd) {
+					if (j == 0) sd = ((A >> 1) & ~LANE15) | ((Bw << 15) & LANE15);
+					else        sd = ((A >> 1) & ~LANE15) | ((Bw >> 1) & LANE15 & ~(1ull << 63)) | (ps[next_off] << 63);
+				}
+			}
+			const uint64_t nw = me ^ flips64(me, up, ct, dw, sd, c3, c4);
+			pd[0] = nw;
+			if (p.wrap) { // single slab: keep this colour's own halo rows equal to the opposite edge rows
+				if (lr == 0) pd[wrap_bot] = nw;
+				if (lr == p.Y - 1) pd[-wrap_bot] = nw;
+			}
+			up = ct;
+			ct = dw;
+			ps += wpr;
+			pd += wpr;
+		}
+#if !defined(ISING_DBG_NOWB) && !defined(ISING_BAL_GLC)
+		if (r < nrows) asm volatile("s_dcache_wb" ::: "memory");
+#endif
+	}
+}
+
+// ---- layout conversion, one wave per (row, wave column): 64 ballot words <-> 128 dense 32-bit words
+__device__ __forceinline__ int word_of_site(int j, int s) {
+	const int m = (s & 15) >> 1;
+	const int q = ((s & 1) << 1) | (s >> 4); // s = 2m, 16+2m, 2m+1, 17+2m  ->  q = 0, 1, 2, 3
+	return word_of(j, m, q);
+}
+
+__global__ void __launch_bounds__(THREADS) ballot_to_dense_k(const uint64_t *__restrict__ bal, uint32_t *__restrict__ dense, long long ngroups) {
+	__shared__ uint64_t sh[THREADS / 64][64];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	for (long long grp = (long long)blockIdx.x * (THREADS / 64) + wv; grp < ngroups; grp += (long long)gridDim.x * (THREADS / 64)) {
+		sh[wv][lane] = bal[grp * 64 + lane];
+		__builtin_amdgcn_wave_barrier();
+		__threadfence_block();
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const int v = lane + 64 * h; // vector within the wave column: 32 g + 16 j + tx
+			const int l = ((v >> 5) << 4) | (v & 15), j = (v >> 4) & 1;
+			uint32_t d = 0;
+#pragma unroll
+			for (int s = 0; s < 32; ++s) d |= (uint32_t)((sh[wv][word_of_site(j, s)] >> l) & 1ull) << s;
+			dense[grp * 128 + v] = d;
+		}
+		__builtin_amdgcn_wave_barrier();
+		__threadfence_block();
+	}
+}
+
+__global__ void __launch_bounds__(THREADS) dense_to_ballot_k(const uint32_t *__restrict__ dense, uint64_t *__restrict__ bal, long long ngroups) {
+	__shared__ uint32_t sh[THREADS / 64][128];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int j = lane >> 5, m = (lane >> 2) & 7, q = lane & 3;
+	const int s = (q & 1) * 16 + 2 * m + (q >> 1);
+	for (long long grp = (long long)blockIdx.x * (THREADS / 64) + wv; grp < ngroups; grp += (long long)gridDim.x * (THREADS / 64)) {
+		sh[wv][lane] = dense[grp * 128 + lane];
+		sh[wv][lane + 64] = dense[grp * 128 + lane + 64];
+		__builtin_amdgcn_wave_barrier();
+		__threadfence_block();
+		uint64_t w = 0;
+#pragma unroll 8
+		for (int l = 0; l < 64; ++l) {
+			const int v = ((l >> 4) << 5) | (j << 4) | (l & 15);
+			w |= (uint64_t)((sh[wv][v] >> s) & 1u) << l;
+		}
+		bal[grp * 64 + lane] = w;
+		__builtin_amdgcn_wave_barrier();
+		__threadfence_block();
+	}
+}
+
+} // namespace
+
+hipError_t launch_ballot_update(const UpdateParams &p, hipStream_t stream) {
+	if (p.nunits <= 0) return hipSuccess;
+	hipLaunchKernelGGL(ballot_update_k, dim3((p.nunits + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(THREADS), 0, stream, p);
+	return hipGetLastError();
+}
+
+// rows x (gx/4) groups of 64 ballot words <-> 128 dense words; both buffers hold `rows` rows of gx*128 bytes
+hipError_t launch_ballot_to_dense(const uint64_t *bal, uint32_t *dense, int gx, long long rows, hipStream_t stream) {
+	const long long ngroups = rows * (gx / 4);
+	if (ngroups <= 0) return hipSuccess;
+	long long blocks = (ngroups + THREADS / 64 - 1) / (THREADS / 64);
+	if (blocks > 16384) blocks = 16384;
+	hipLaunchKernelGGL(ballot_to_dense_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, bal, dense, ngroups);
+	return hipGetLastError();
+}
+
+hipError_t launch_dense_to_ballot(const uint32_t *dense, uint64_t *bal, int gx, long long rows, hipStream_t stream) {
+	const long long ngroups = rows * (gx / 4);
+	if (ngroups <= 0) return hipSuccess;
+	long long blocks = (ngroups + THREADS / 64 - 1) / (THREADS / 64);
+	if (blocks > 16384) blocks = 16384;
+	hipLaunchKernelGGL(dense_to_ballot_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, dense, bal, ngroups);
+	return hipGetLastError();
+}
+
+} // namespace ising

@@ -57,6 +57,9 @@ uint64_t draw_prefix(float p, bool le) {
 struct ising_ctx {
 	ising_config cfg{};
 	bool dense = false; // 1 bit per spin on the device (ising_dense.hip); false = the reference's nibble layout
+	bool ballot = false; // dense, with the bits of a row in wave-ballot order (ising_ballot.hip)
+	uint64_t *d_tmp = nullptr;     // ballot layout: dense-order image of d_lat (same shape) for conversions and observables
+	uint64_t *d_scratch = nullptr; // ballot layout: accept-mask slots, 2 KiB per wave of the largest launch
 	int lld_packed = 0; // 64-bit words per colour row in the reference's packed layout (X/32)
 	int lld = 0;      // 64-bit words per colour row in the DEVICE layout (X/32 nibble, X/128 dense)
 	int gx = 0;       // X/2048
@@ -86,6 +89,7 @@ struct ising_ctx {
 	uint64_t *lat(int color) const { return d_lat + (size_t)color * (color_words + 2 * (size_t)lld) + lld; }
 	uint64_t *halo(int color, int which) const { return which == 0 ? lat(color) - lld : lat(color) + color_words; }
 	size_t alloc_words() const { return 2 * (color_words + 2 * (size_t)lld); }
+	uint64_t *tmp(int color) const { return d_tmp + (size_t)color * (color_words + 2 * (size_t)lld) + lld; }
 	size_t ham_words() const { return (size_t)cfg.Y * lld_packed; } // per coupling array, without its two halo rows
 	size_t ham_alloc_words() const { return 2 * (ham_words() + 2 * (size_t)lld_packed); }
 	uint64_t *ham(int which) const { return d_ham + (size_t)which * (ham_words() + 2 * (size_t)lld_packed) + lld_packed; }
@@ -98,6 +102,29 @@ namespace {
 
 int bind(const ising_ctx *c) {
 	HIP_TRY(hipSetDevice(c->cfg.device));
+	return ISING_OK;
+}
+
+// ballot layout: convert rows [row_lo, row_hi) of `color` (rows -1 and Y are the halo rows) between d_lat and d_tmp
+int ballot_rows(const ising_ctx *c, int color, long long row_lo, long long row_hi, bool to_dense) {
+	uint64_t *lat = c->lat(color) + row_lo * c->lld, *tmp = c->tmp(color) + row_lo * c->lld;
+	if (to_dense) HIP_TRY(ising::launch_ballot_to_dense(lat, reinterpret_cast<uint32_t *>(tmp), c->gx, row_hi - row_lo, c->stream));
+	else HIP_TRY(ising::launch_dense_to_ballot(reinterpret_cast<const uint32_t *>(tmp), lat, c->gx, row_hi - row_lo, c->stream));
+	return ISING_OK;
+}
+
+// ballot layout: refresh the dense-order image (both colours, halo rows included)
+int ballot_image(const ising_ctx *c) {
+	for (int color = 0; color < 2; color++)
+		if (int rc = ballot_rows(c, color, -1, (long long)c->cfg.Y + 1, true)) return rc;
+	return ISING_OK;
+}
+
+// ballot -> dense for good (a temperature without integer thresholds was requested): the slab keeps its buffer
+int ballot_leave(ising_ctx *c) {
+	if (int rc = ballot_image(c)) return rc;
+	HIP_TRY(hipMemcpyAsync(c->d_lat, c->d_tmp, c->alloc_words() * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+	c->ballot = false;
 	return ISING_OK;
 }
 
@@ -251,11 +278,19 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 
 	ising_ctx *c = new ising_ctx();
 	c->cfg = *cfg;
-	if (cfg->layout != ISING_LAYOUT_AUTO && cfg->layout != ISING_LAYOUT_NIBBLE && cfg->layout != ISING_LAYOUT_DENSE) {
+	if (cfg->layout != ISING_LAYOUT_AUTO && cfg->layout != ISING_LAYOUT_NIBBLE && cfg->layout != ISING_LAYOUT_DENSE && cfg->layout != ISING_LAYOUT_BALLOT) {
 		delete c;
 		return fail(ISING_E_ARG, "bad layout %d", cfg->layout);
 	}
 	c->dense = cfg->layout != ISING_LAYOUT_NIBBLE;
+	// the ballot layout covers the integer-threshold update without sub-lattices and couplings, 8192-column granularity
+	const bool ballot_ok = (cfg->X % 8192) == 0 && !cfg->XSL && !cfg->use_J &&
+	                       (cfg->kernel == ISING_KERNEL_AUTO || cfg->kernel == ISING_KERNEL_FAST);
+	if (cfg->layout == ISING_LAYOUT_BALLOT && !ballot_ok) {
+		delete c;
+		return fail(ISING_E_ARG, "the ballot layout needs X %% 8192 == 0, no sub-lattices, no -J and the integer-threshold kernel");
+	}
+	c->ballot = cfg->layout == ISING_LAYOUT_BALLOT;
 	c->lld_packed = cfg->X / 32;
 	c->lld = c->dense ? cfg->X / 128 : cfg->X / 32;
 	c->gx = cfg->X / 2048;
@@ -264,6 +299,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	c->nstrips = cfg->Y / c->H;
 	c->color_words = (size_t)cfg->Y * c->lld;
 	compute_tables(c, cfg->temp);
+	if (cfg->layout == ISING_LAYOUT_AUTO && ballot_ok && c->fast_ok && !getenv("ISING_NO_BALLOT")) c->ballot = true;
 
 	hipError_t e = hipSetDevice(cfg->device);
 	if (e == hipSuccess) {
@@ -273,6 +309,8 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (e == hipSuccess) e = hipMemset(c->d_lat, 0, c->alloc_words() * sizeof(uint64_t)); // optimized/main.cu:1603
 	if (e == hipSuccess) e = hipMalloc((void **)&c->d_acc, 2 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMalloc((void **)&c->d_lut, 65536);
+	if (e == hipSuccess && c->ballot) e = hipMalloc((void **)&c->d_tmp, c->alloc_words() * sizeof(uint64_t));
+	if (e == hipSuccess && c->ballot) e = hipMalloc((void **)&c->d_scratch, (size_t)(c->gx / 4) * (c->nstrips + 2) * 2048);
 	if (e == hipSuccess && cfg->use_J) {
 		if (cfg->coupling_mem) c->d_ham = static_cast<uint64_t *>(cfg->coupling_mem);
 		else e = hipMalloc((void **)&c->d_ham, c->ham_alloc_words() * sizeof(uint64_t));
@@ -293,6 +331,8 @@ int ising_destroy(ising_ctx *c) {
 	if (c->d_lat && !c->cfg.lattice_mem) (void)hipFree(c->d_lat);
 	if (c->d_acc) (void)hipFree(c->d_acc);
 	if (c->d_lut) (void)hipFree(c->d_lut);
+	if (c->d_tmp) (void)hipFree(c->d_tmp);
+	if (c->d_scratch) (void)hipFree(c->d_scratch);
 	if (c->d_ham && !c->cfg.coupling_mem) (void)hipFree(c->d_ham);
 	if (c->d_bits) (void)hipFree(c->d_bits);
 	if (c->d_corr) (void)hipFree(c->d_corr);
@@ -320,7 +360,7 @@ int ising_init_lattice(ising_ctx *c) {
 	const uint64_t half = draw_prefix(0.5f, false); // curand_uniform(x) < 0.5f, optimized/main.cu:133
 	for (int color = 0; color < 2; color++) {
 		ising::InitParams p{};
-		p.dst = c->lat(color);
+		p.dst = c->ballot ? c->tmp(color) : c->lat(color);
 		p.seed_lo = (uint32_t)c->cfg.seed;
 		p.seed_hi = (uint32_t)(c->cfg.seed >> 32);
 		p.color = (uint32_t)color;
@@ -330,6 +370,7 @@ int ising_init_lattice(ising_ctx *c) {
 		p.wrap = c->cfg.nslabs == 1;
 		p.thr_half = (uint32_t)half;
 		HIP_TRY(c->dense ? ising::launch_dense_init(p, c->stream) : ising::launch_init(p, c->stream));
+		if (c->ballot) if (int rc = ballot_rows(c, color, -1, (long long)c->cfg.Y + 1, false)) return rc;
 	}
 	return ISING_OK;
 }
@@ -364,6 +405,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 		mode = 1;
 	}
 	if (int rc = bind(c)) return rc;
+	if (c->ballot && mode == 1) if (int rc = ballot_leave(c)) return rc; // no integer thresholds at this temperature
 	if (mode == 2 && c->lut_dirty) {
 		std::vector<uint8_t> tab(65536);
 		build_rank_table(c, tab.data());
@@ -396,6 +438,11 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	p.lut = c->d_lut;
 	// the reference hands hamW to the BLACK update and hamB to the WHITE one (optimized/main.cu:1774, :1795)
 	p.jdst = c->cfg.use_J ? c->ham(other) : nullptr;
+	p.scratch = c->d_scratch;
+	if (c->ballot) {
+		HIP_TRY(ising::launch_ballot_update(p, c->stream));
+		return ISING_OK;
+	}
 	if (c->dense) {
 		HIP_TRY(ising::launch_dense_update(p, mode, c->stream));
 		return ISING_OK;
@@ -476,9 +523,10 @@ int ising_count(ising_ctx *c, uint64_t *up, uint64_t *down) {
 int ising_bond_equal(ising_ctx *c, int64_t *A) {
 	if (!c || !A) return fail(ISING_E_ARG, "null argument");
 	if (int rc = bind(c)) return rc;
+	if (c->ballot) if (int rc = ballot_image(c)) return rc;
 	ising::BondParams p{};
-	p.black = c->lat(ISING_BLACK);
-	p.white = c->lat(ISING_WHITE);
+	p.black = c->ballot ? c->tmp(ISING_BLACK) : c->lat(ISING_BLACK);
+	p.white = c->ballot ? c->tmp(ISING_WHITE) : c->lat(ISING_WHITE);
 	p.gx = c->gx;
 	p.Y = c->cfg.Y;
 	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
@@ -507,7 +555,9 @@ int ising_read_packed(ising_ctx *c, int color, int64_t row0, int64_t nrows, uint
 	if (c->dense) {
 		const size_t nvec = (size_t)nrows * c->lld * 2; // 32-bit words = reference vectors
 		std::vector<uint32_t> tmp(nvec);
-		HIP_TRY(hipMemcpyAsync(tmp.data(), c->lat(color) + (size_t)row0 * c->lld, nvec * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+		if (c->ballot) if (int rc = ballot_rows(c, color, row0, row0 + nrows, true)) return rc;
+		const uint64_t *img = c->ballot ? c->tmp(color) : c->lat(color);
+		HIP_TRY(hipMemcpyAsync(tmp.data(), img + (size_t)row0 * c->lld, nvec * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		dense_to_packed(tmp.data(), dst_host, nvec);
 		return ISING_OK;
@@ -528,12 +578,20 @@ int ising_write_packed(ising_ctx *c, int color, int64_t row0, int64_t nrows, con
 		packed_to_dense(src_host, tmp.data(), tmp.size());
 		src = tmp.data();
 	}
-	HIP_TRY(hipMemcpyAsync(c->lat(color) + (size_t)row0 * c->lld, src, (size_t)nrows * row_bytes, hipMemcpyHostToDevice, c->stream));
+	uint64_t *img = c->ballot ? c->tmp(color) : c->lat(color); // ballot layout: through the dense-order image
+	HIP_TRY(hipMemcpyAsync(img + (size_t)row0 * c->lld, src, (size_t)nrows * row_bytes, hipMemcpyHostToDevice, c->stream));
+	if (c->ballot) if (int rc = ballot_rows(c, color, row0, row0 + nrows, false)) return rc;
 	// single slab: the halo rows mirror the opposite edge rows
 	if (c->cfg.nslabs == 1 && nrows > 0) {
 		const char *b = static_cast<const char *>(src);
-		if (row0 == 0) HIP_TRY(hipMemcpyAsync(c->lat(color) + c->color_words, b, row_bytes, hipMemcpyHostToDevice, c->stream));
-		if (row0 + nrows == c->cfg.Y) HIP_TRY(hipMemcpyAsync(c->lat(color) - c->lld, b + (size_t)(nrows - 1) * row_bytes, row_bytes, hipMemcpyHostToDevice, c->stream));
+		if (row0 == 0) {
+			HIP_TRY(hipMemcpyAsync(img + c->color_words, b, row_bytes, hipMemcpyHostToDevice, c->stream));
+			if (c->ballot) if (int rc = ballot_rows(c, color, c->cfg.Y, (long long)c->cfg.Y + 1, false)) return rc;
+		}
+		if (row0 + nrows == c->cfg.Y) {
+			HIP_TRY(hipMemcpyAsync(img - c->lld, b + (size_t)(nrows - 1) * row_bytes, row_bytes, hipMemcpyHostToDevice, c->stream));
+			if (c->ballot) if (int rc = ballot_rows(c, color, -1, 0, false)) return rc;
+		}
 	}
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	return ISING_OK;
@@ -541,7 +599,7 @@ int ising_write_packed(ising_ctx *c, int color, int64_t row0, int64_t nrows, con
 
 int ising_layout(ising_ctx *c, int *layout) {
 	if (!c || !layout) return fail(ISING_E_ARG, "null argument");
-	*layout = c->dense ? ISING_LAYOUT_DENSE : ISING_LAYOUT_NIBBLE;
+	*layout = c->ballot ? ISING_LAYOUT_BALLOT : (c->dense ? ISING_LAYOUT_DENSE : ISING_LAYOUT_NIBBLE);
 	return ISING_OK;
 }
 
@@ -770,7 +828,10 @@ int ising_ring_correlations(ising_ctx **ctxs, int n, int ncorr, int64_t *sums) {
 		}
 		if (!c->d_corr) HIP_TRY(hipMalloc((void **)&c->d_corr, 128 * sizeof(long long)));
 		// bit matrix: X bits = lld_packed 32-bit words per row
-		if (c->dense) HIP_TRY(ising::launch_dense_pack_bits(c->lat(ISING_BLACK), c->lat(ISING_WHITE), c->gx * 32, c->cfg.Y,
+		if (c->ballot) if (int rc = ballot_image(c)) return rc;
+		if (c->ballot) HIP_TRY(ising::launch_dense_pack_bits(c->tmp(ISING_BLACK), c->tmp(ISING_WHITE), c->gx * 32, c->cfg.Y,
+		                                                     (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y, c->d_bits, c->stream));
+		else if (c->dense) HIP_TRY(ising::launch_dense_pack_bits(c->lat(ISING_BLACK), c->lat(ISING_WHITE), c->gx * 32, c->cfg.Y,
 		                                                    (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y, c->d_bits, c->stream));
 		else HIP_TRY(ising::launch_pack_bits(c->lat(ISING_BLACK), c->lat(ISING_WHITE), c->lld_packed, c->cfg.Y,
 		                                     (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y, c->d_bits, c->stream));

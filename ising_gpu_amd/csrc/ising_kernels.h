@@ -31,6 +31,7 @@ struct UpdateParams {
 	float tab[10];            // exp table exp_h[2][5] (generic kernel)
 	const uint8_t *lut;       // 64 KiB rank table indexed by the top 16 bits of a draw (mode 2)
 	const uint64_t *jdst;     // coupling words read for the rows being updated (NULL without -J); same shape as dst
+	uint64_t *scratch;        // ballot layout: 2 KiB of accept-mask slots per wave of the launch
 };
 
 // mode: 0 = integer thresholds via v_cmpx, 1 = generic FP32-table kernel, 2 = integer thresholds via the LDS rank table
@@ -88,6 +89,11 @@ hipError_t launch_ham_planes(uint64_t *ham, size_t nvec, hipStream_t stream);
 hipError_t launch_dense_bond_equal(const BondParams &p, hipStream_t stream);
 hipError_t launch_dense_pack_bits(const uint64_t *black, const uint64_t *white, int wpr, int Y, uint32_t row_base, uint32_t *bits,
                                   hipStream_t stream);
+
+// ballot layout (1 bit per spin in wave-ballot order, ising_ballot.hip): integer-threshold update, conversions
+hipError_t launch_ballot_update(const UpdateParams &p, hipStream_t stream);
+hipError_t launch_ballot_to_dense(const uint64_t *bal, uint32_t *dense, int gx, long long rows, hipStream_t stream);
+hipError_t launch_dense_to_ballot(const uint32_t *dense, uint64_t *bal, int gx, long long rows, hipStream_t stream);
 
 // one-bit-per-spin image of a slab in lattice-column order: bits[Y][lld] 32-bit words
 hipError_t launch_pack_bits(const uint64_t *black, const uint64_t *white, int lld, int Y, uint32_t row_base, uint32_t *bits,

@@ -92,6 +92,13 @@ class IsingSlab:
         check(self._lib.ising_read_couplings(self._h, which, 0, self.Y, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def current_layout(self) -> int:
+        """Device layout right now (a ballot slab turns dense when a temperature has no integer thresholds)."""
+        lay = C.c_int()
+        check(self._lib.ising_layout(self._h, C.byref(lay)))
+        self.layout = lay.value
+        return self.layout
+
     def set_temperature(self, temp: float):
         check(self._lib.ising_set_temperature(self._h, C.c_float(float(np.float32(temp)))))
 

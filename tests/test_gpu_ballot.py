@@ -1,0 +1,111 @@
+"""The ballot device layout (ising_ballot.hip: 1 bit per spin, row bits in the update kernel's wave-ballot order, accept
+decisions handed over as v_cmp lane masks through scalar stores) against the CPU oracle, bit for bit.
+
+It needs X % 8192 == 0, so it has its own size table; everything that crosses the C-ABI is still the reference's
+packed layout."""
+import numpy as np
+import pytest
+
+import ising_gpu_amd as ig
+from test_gpu_parity import _compare
+
+pytestmark = pytest.mark.gpu
+TC = ig.CRIT_TEMP_F32
+BAL = ig.LAYOUT_BALLOT
+
+
+@pytest.mark.parametrize("X,Y,strip", [(8192, 16, 0), (8192, 64, 4), (16384, 48, 16), (24576, 32, 1), (8192, 272, 16)])
+@pytest.mark.parametrize("temp,seed", [(1.5, ig.SEED_DEF), (TC, 1234)])
+def test_state_bit_exact(gpu, oracle_mod, X, Y, strip, temp, seed):
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=temp).init()
+    with ig.IsingSlab(X, Y, seed=seed, temp=temp, strip_rows=strip, layout=BAL) as s:
+        assert s.layout == BAL
+        s.init()
+        _compare(s, orc, "init")
+        assert s.count() == orc.count()
+        done = 0
+        for upto in (1, 2, 9):
+            s.sweep(upto - done)
+            orc.sweep(upto - done)
+            done = upto
+            _compare(s, orc, f"after {upto} sweeps (strip {s.strip_rows})")
+            assert s.count() == orc.count()
+            assert s.bond_equal() == orc.bond_equal()
+
+
+def test_auto_layout_picks_ballot_where_it_applies(gpu):
+    with ig.IsingSlab(8192, 32, temp=1.5) as s:
+        assert s.layout == BAL
+    with ig.IsingSlab(4096, 32, temp=1.5) as s:
+        assert s.layout == ig.LAYOUT_DENSE
+    with ig.IsingSlab(8192, 32, temp=1.5, XSL=2048, YSL=16) as s:
+        assert s.layout == ig.LAYOUT_DENSE
+    with ig.IsingSlab(8192, 32, temp=1.5, J_prob=0.1) as s:
+        assert s.layout == ig.LAYOUT_DENSE
+    with pytest.raises(ig.IsingError):
+        ig.IsingSlab(4096, 32, temp=1.5, layout=BAL)
+
+
+def test_row_partition_and_edges(gpu, oracle_mod):
+    """Any partition of the rows into launches gives the same state (what the slab ring relies on)."""
+    X, Y = 8192, 96
+    orc = oracle_mod.OracleLattice(X, Y, seed=5, temp=2.0).init()
+    with ig.IsingSlab(X, Y, seed=5, temp=2.0, layout=BAL) as s:
+        s.init()
+        for it in (1, 2, 3):
+            for color in (ig.BLACK, ig.WHITE):
+                s.update_edges(it, color)
+                s.update_color(it, color, 1, 40)
+                s.update_color(it, color, 40, 41)
+                s.update_color(it, color, 41, Y - 1)
+            s.it = it
+            orc.sweep(1)
+            _compare(s, orc, f"it {it}")
+
+
+def test_ring_of_slabs_matches_oracle(gpu, oracle_mod):
+    X, Y, n = 8192, 192, 3
+    orc = oracle_mod.OracleLattice(X, Y, seed=77, temp=TC).init()
+    orc.sweep(6)
+    backs = [ig.HipSlabBackend.create(X, Y // n, seed=77, temp=TC, nslabs=n, slab=k, layout=BAL) for k in range(n)]
+    try:
+        ring = ig.LocalRing(backs).init()
+        ring.sweep(6)
+        assert np.array_equal(np.concatenate([b.slab.read(ig.BLACK) for b in backs]), orc.black)
+        assert np.array_equal(np.concatenate([b.slab.read(ig.WHITE) for b in backs]), orc.white)
+        assert ring.count() == orc.count()
+        assert ring.bond_equal() == orc.bond_equal()
+    finally:
+        for b in backs:
+            b.slab.close()
+
+
+def test_write_read_resume_and_correlations(gpu, oracle_mod):
+    X, Y = 8192, 256
+    orc = oracle_mod.OracleLattice(X, Y, seed=3, temp=2.1).init()
+    orc.sweep(3)
+    with ig.IsingSlab(X, Y, seed=3, temp=2.1, layout=BAL) as s:
+        s.write(ig.BLACK, orc.black)
+        s.write(ig.WHITE, orc.white)
+        s.it = orc.it
+        assert np.array_equal(s.read(ig.BLACK), orc.black)
+        s.sweep(2)
+        orc.sweep(2)
+        _compare(s, orc, "resumed")
+        assert np.array_equal(s.correlations(128), orc.corr(128))
+
+
+def test_temperature_without_thresholds_turns_dense(gpu, oracle_mod):
+    """-u style ramp through a temperature the integer thresholds cannot express: the slab migrates to the dense layout."""
+    X, Y = 8192, 32
+    orc = oracle_mod.OracleLattice(X, Y, seed=11, temp=1.5).init()
+    with ig.IsingSlab(X, Y, seed=11, temp=1.5, layout=BAL) as s:
+        s.init().sweep(2)
+        orc.sweep(2)
+        for temp in (0.0, 2.5):
+            s.set_temperature(temp)
+            orc.temp = float(np.float32(temp))
+            s.sweep(2)
+            orc.sweep(2)
+            _compare(s, orc, f"T={temp}")
+        assert s.current_layout() == ig.LAYOUT_DENSE
