@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--y", type=int, default=65536, help="rows per GPU")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--strip-rows", type=int, default=0)
-    ap.add_argument("--layout", choices=["auto", "nibble", "dense"], default="auto", help="device layout of the spin arrays")
+    ap.add_argument("--layout", choices=["auto", "nibble", "dense", "ballot"], default="auto", help="device layout of the spin arrays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -97,7 +97,7 @@ def main():
     # torch owns the slab's device buffer, so the rows RCCL sends/receives are slices of an ordinary torch tensor
     backend = ig.HipSlabBackend.create(args.x, args.y, device=local_rank, seed=args.seed, temp=ig.CRIT_TEMP_F32,
                                        nslabs=world, slab=rank, strip_rows=args.strip_rows,
-                                       layout={"auto": ig.LAYOUT_AUTO, "nibble": ig.LAYOUT_NIBBLE, "dense": ig.LAYOUT_DENSE}[args.layout])
+                                       layout={"auto": ig.LAYOUT_AUTO, "nibble": ig.LAYOUT_NIBBLE, "dense": ig.LAYOUT_DENSE, "ballot": ig.LAYOUT_BALLOT}[args.layout])
     slab = backend.slab
     ring = ig.SlabRing(backend)
     ring.init()
@@ -127,7 +127,11 @@ def main():
     total_flips = float(spins_per_gpu) * world * args.steps
     value = total_flips / (dt * 1e9)
 
-    dense = slab.layout == ig.LAYOUT_DENSE
+    layout_name, layout_text, kernel_name = {
+        ig.LAYOUT_NIBBLE: ("nibble", "reference 4 bit/spin", "update_k<0>"),
+        ig.LAYOUT_DENSE: ("dense", "dense 1 bit/spin", "dense_update_k<0>"),
+        ig.LAYOUT_BALLOT: ("ballot", "1 bit/spin in wave-ballot order", "ballot_update_k"),
+    }[slab.current_layout()]
     if rank == 0:
         # dominant kernel: update_k; 2 full-slab launches per step (with N>1 each colour adds one tiny edge-row launch)
         launches = 2 * args.steps
@@ -140,7 +144,7 @@ def main():
             try:
                 with open(prof) as f:
                     tj = json.load(f)
-                if tj.get("x") == args.x and tj.get("y") == args.y and tj.get("device_layout") == ("dense" if dense else "nibble"):
+                if tj.get("x") == args.x and tj.get("y") == args.y and tj.get("device_layout") == layout_name:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -150,13 +154,13 @@ def main():
             "ms_per_step": round(dt * 1e3 / args.steps, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{args.y * world}x{args.x} lattice ({args.y}x{args.x} per GPU), T=Tc, seed {args.seed}, "
-                                   "Philox4x32-10 per site; device layout " + ("dense 1 bit/spin" if dense else "reference 4 bit/spin")
+                                   "Philox4x32-10 per site; device layout " + layout_text
                                    + ", results identical to the reference's packed state", "x": args.x, "y_per_gpu": args.y,
-                       "parallelism": f"slab{world}", "strip_rows": slab.strip_rows, "device_layout": "dense" if dense else "nibble",
+                       "parallelism": f"slab{world}", "strip_rows": slab.strip_rows, "device_layout": layout_name,
                        "up": up, "down": down},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "dense_update_k<0>" if dense else "update_k<0>", "avg_launch_ms": round(avg_launch_ms, 5),
+                         "kernel": kernel_name, "avg_launch_ms": round(avg_launch_ms, 5),
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:

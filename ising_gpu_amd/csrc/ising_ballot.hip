@@ -30,6 +30,10 @@
 namespace ising {
 namespace {
 
+#if !defined(ISING_BAL_THREADS)
+#define ISING_BAL_THREADS 256
+#endif
+constexpr int BAL_THREADS = ISING_BAL_THREADS; // waves of a workgroup share one scalar-cache write-back per row
 constexpr uint64_t LANE0 = 0x0001000100010001ull;  // tx = 0 of each 16-lane group
 constexpr uint64_t LANE15 = 0x8000800080008000ull; // tx = 15
 
@@ -51,10 +55,10 @@ __device__ __forceinline__ uint64_t flips64(uint64_t me, uint64_t up, uint64_t c
 	return ~(is3 | is4) | (is3 & c3) | (is4 & c4);
 }
 
-__global__ void __launch_bounds__(THREADS) ballot_update_k(const UpdateParams p) {
+__global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParams p) {
 	const int lane = threadIdx.x & 63;
 	const int tx = threadIdx.x & (GROUP - 1), g = (threadIdx.x >> 4) & 3;
-	const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6));
+	const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BAL_THREADS / 64) + (threadIdx.x >> 6));
 	const int unit0 = wave * 4; // a wave covers 4 consecutive 32-vector column groups of one strip (gx % 4 == 0)
 	if (unit0 >= p.nunits) return;
 	const int rng = unit0 >= p.nunits0;
@@ -101,7 +105,14 @@ __global__ void __launch_bounds__(THREADS) ballot_update_k(const UpdateParams p)
 
 	uint64_t up = ps[-(ptrdiff_t)wpr], ct = ps[0];
 
-	for (int r = 0; r <= nrows; ++r) {
+#if !defined(ISING_BAL_WAVEWB)
+	// one write-back per workgroup and row: every wave runs the same number of iterations and meets at a barrier
+	const int rmax = p.H;
+	const bool wb_wave = threadIdx.x < 64;
+#else
+	const int rmax = nrows;
+#endif
+	for (int r = 0; r <= rmax; ++r) {
 		if (r < nrows) {
 			// ---- draw phase, row r0 + r
 			const uint32_t grow = p.row_base + (uint32_t)(r0 + r);
@@ -133,20 +144,18 @@ __global__ void __launch_bounds__(THREADS) ballot_update_k(const UpdateParams p)
 				             "v_cmp_gt_u32_e64 s[88:89], %0, %3\n\tv_cmp_gt_u32_e64 s[90:91], %1, %3\n\t"
 				             "v_cmp_gt_u32_e64 s[92:93], %0, %4\n\tv_cmp_gt_u32_e64 s[94:95], %1, %4\n\t"
 				             "v_cmp_gt_u32_e64 s[96:97], %0, %5\n\tv_cmp_gt_u32_e64 s[98:99], %1, %5\n\t"
-#if defined(ISING_BAL_GLC)
-				             "s_store_dwordx4 s[84:87], %6, 0x0 glc\n\ts_store_dwordx4 s[88:91], %6, 0x10 glc\n\t"
-				             "s_store_dwordx4 s[92:95], %6, 0x20 glc\n\ts_store_dwordx4 s[96:99], %6, 0x30 glc"
-#else
 				             "s_store_dwordx4 s[84:87], %6, 0x0\n\ts_store_dwordx4 s[88:91], %6, 0x10\n\t"
 				             "s_store_dwordx4 s[92:95], %6, 0x20\n\ts_store_dwordx4 s[96:99], %6, 0x30"
-#endif
 				             :: "s"(p.n3), "s"(p.n4), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(dstp)
 				             : "memory", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97",
 				               "s98", "s99");
 #endif
 			});
 		}
-		if (r > 0) {
+#if !defined(ISING_BAL_WAVEWB)
+		asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+		if (r > 0 && r <= nrows) {
 			// ---- word phase, row r0 + r - 1; its masks were written back during the draw phase above
 			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 			const int lr = r0 + r - 1;
@@ -188,7 +197,9 @@ __global__ void __launch_bounds__(THREADS) ballot_update_k(const UpdateParams p)
 			ps += wpr;
 			pd += wpr;
 		}
-#if !defined(ISING_DBG_NOWB) && !defined(ISING_BAL_GLC)
+#if !defined(ISING_BAL_WAVEWB)
+		if (wb_wave && r < rmax) asm volatile("s_dcache_wb" ::: "memory");
+#elif !defined(ISING_DBG_NOWB)
 		if (r < nrows) asm volatile("s_dcache_wb" ::: "memory");
 #endif
 	}
@@ -248,7 +259,7 @@ __global__ void __launch_bounds__(THREADS) dense_to_ballot_k(const uint32_t *__r
 
 hipError_t launch_ballot_update(const UpdateParams &p, hipStream_t stream) {
 	if (p.nunits <= 0) return hipSuccess;
-	hipLaunchKernelGGL(ballot_update_k, dim3((p.nunits + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(THREADS), 0, stream, p);
+	hipLaunchKernelGGL(ballot_update_k, dim3((p.nunits + BAL_THREADS / GROUP - 1) / (BAL_THREADS / GROUP)), dim3(BAL_THREADS), 0, stream, p);
 	return hipGetLastError();
 }
 

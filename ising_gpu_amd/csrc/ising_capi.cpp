@@ -215,12 +215,12 @@ void planes_to_nibbles(uint64_t *vecs, size_t nvec) {
 	}
 }
 
-int choose_strip_rows(int gx, int Y, bool dense) {
+int choose_strip_rows(int gx, int Y, bool dense, bool ballot = false) {
 	// Enough (column-group x strip) units to give every SIMD several waves, while keeping strips tall so the two
 	// halo rows per strip stay a small fraction of the source traffic (measured optimum: 32 rows for the nibble
-	// layout, 8-16 for the dense one, whose traffic is 4x smaller).
+	// layout, 8-16 for the dense one, whose traffic is 4x smaller, 8 for the ballot one).
 	const long long want_units = 4LL * 8192; // 4 units per wave, ~8 waves on each of 1024 SIMDs
-	int H = dense ? 16 : 32;
+	int H = ballot ? 8 : (dense ? 16 : 32);
 	while (H > 1 && ((Y % H) != 0 || (long long)gx * (Y / H) < want_units)) H >>= 1;
 	return H;
 }
@@ -294,12 +294,12 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	c->lld_packed = cfg->X / 32;
 	c->lld = c->dense ? cfg->X / 128 : cfg->X / 32;
 	c->gx = cfg->X / 2048;
-	c->H = cfg->strip_rows > 0 ? cfg->strip_rows : choose_strip_rows(c->gx, cfg->Y, c->dense);
+	compute_tables(c, cfg->temp);
+	if (cfg->layout == ISING_LAYOUT_AUTO && ballot_ok && c->fast_ok && !getenv("ISING_NO_BALLOT")) c->ballot = true;
+	c->H = cfg->strip_rows > 0 ? cfg->strip_rows : choose_strip_rows(c->gx, cfg->Y, c->dense, c->ballot);
 	if (cfg->Y % c->H) { const int h = c->H; delete c; return fail(ISING_E_ARG, "strip_rows %d does not divide Y %d", h, cfg->Y); }
 	c->nstrips = cfg->Y / c->H;
 	c->color_words = (size_t)cfg->Y * c->lld;
-	compute_tables(c, cfg->temp);
-	if (cfg->layout == ISING_LAYOUT_AUTO && ballot_ok && c->fast_ok && !getenv("ISING_NO_BALLOT")) c->ballot = true;
 
 	hipError_t e = hipSetDevice(cfg->device);
 	if (e == hipSuccess) {
