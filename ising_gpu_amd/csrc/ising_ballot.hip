@@ -34,6 +34,7 @@ namespace {
 #define ISING_BAL_THREADS 256
 #endif
 constexpr int BAL_THREADS = ISING_BAL_THREADS; // waves of a workgroup share one scalar-cache write-back per row
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr uint64_t LANE0 = 0x0001000100010001ull;  // tx = 0 of each 16-lane group
 constexpr uint64_t LANE15 = 0x8000800080008000ull; // tx = 15
 
@@ -45,14 +46,36 @@ __device__ __forceinline__ uint64_t bperm64(int src_lane, uint64_t v) {
 	return ((uint64_t)hi << 32) | lo;
 }
 
-// 64 sites at once; same logic as neighbour_planes + flip_mask of ising_dense.hip
+// truth table of a 3-input bit function for v_bitop3_b32: bit (a << 2 | b << 1 | c) = f(a, b, c)
+template <typename F>
+constexpr uint32_t tt3(F f) {
+	uint32_t t = 0;
+	for (int i = 0; i < 8; ++i) t |= (f((i >> 2) & 1, (i >> 1) & 1, i & 1) ? 1u : 0u) << i;
+	return t;
+}
+#define BITOP3(a, b, c, ...) __builtin_amdgcn_bitop3_b32((a), (b), (c), tt3([](int x, int y, int z) { return (__VA_ARGS__); }))
+
+// Metropolis flips of 32 sites: bit-sliced neighbour count n = up + dw + ct + sd (n0, k1 + k2 = the two carries into
+// bit 1), a = aligned neighbours = n for an up spin, 4 - n for a down spin; a <= 2 always flips, a = 3 / 4 flips
+// where the draw was below n3 / n4 (masks c3 / c4).  Same function as neighbour_planes + flip_mask of
+// ising_dense.hip, arranged as six 3-input operations and six 2-input ones.
+__device__ __forceinline__ uint32_t flips32(uint32_t me, uint32_t up, uint32_t ct, uint32_t dw, uint32_t sd, uint32_t c3, uint32_t c4) {
+	const uint32_t s1 = BITOP3(up, dw, ct, x ^ y ^ z);
+	const uint32_t k1 = BITOP3(up, dw, ct, (x & y) | (z & (x ^ y)));
+	const uint32_t n0 = s1 ^ sd, k2 = s1 & sd;            // n1 = k1 ^ k2, n2 = k1 & k2
+	// a == 3: n0 set and bit 1 of n equal to the spin (n = 3 up, n = 1 down)
+	const uint32_t is3 = n0 & BITOP3(me, k1, k2, !(x ^ y ^ z));
+	// a == 4: n == 4 for an up spin, n == 0 for a down spin
+	const uint32_t p4 = BITOP3(me, k1, k2, x ? (y & z) : !(y | z));
+	const uint32_t not4 = BITOP3(p4, me, n0, !(x & (y | !z)));
+	return BITOP3(is3, c3, not4 | c4, x ? y : z);
+}
+
 __device__ __forceinline__ uint64_t flips64(uint64_t me, uint64_t up, uint64_t ct, uint64_t dw, uint64_t sd, uint64_t c3, uint64_t c4) {
-	const uint64_t x = up ^ dw, y = up & dw, z = ct ^ sd, w = ct & sd;
-	const uint64_t c1 = x & z;
-	const uint64_t n0 = x ^ z, n1 = y ^ w ^ c1, n2 = (y & w) | (c1 & (y ^ w));
-	const uint64_t is3 = (me & n1 & n0) | (~me & n0 & ~n1 & ~n2);
-	const uint64_t is4 = (me & n2) | (~me & ~(n0 | n1 | n2));
-	return ~(is3 | is4) | (is3 & c3) | (is4 & c4);
+	const uint32_t lo = flips32((uint32_t)me, (uint32_t)up, (uint32_t)ct, (uint32_t)dw, (uint32_t)sd, (uint32_t)c3, (uint32_t)c4);
+	const uint32_t hi = flips32((uint32_t)(me >> 32), (uint32_t)(up >> 32), (uint32_t)(ct >> 32), (uint32_t)(dw >> 32), (uint32_t)(sd >> 32),
+	                            (uint32_t)(c3 >> 32), (uint32_t)(c4 >> 32));
+	return ((uint64_t)hi << 32) | lo;
 }
 
 __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParams p) {
@@ -83,14 +106,24 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 	else if (q == 2) fwdA = m < 7 ? word_of(j, m + 1, 0) : word_of(j, 0, 1);
 	else fwdA = m < 7 ? word_of(j, m + 1, 1) : word_of(j, 0, 0);
 	// site 0 (back) / site 31 (forward) have their side neighbour in the adjacent vector = the adjacent lane's bit of
-	// word (., 7, 3) / (., 0, 0); lanes tx = 0 / 15 cross into the other j, the next group or the next wave column
+	// word (., 7, 3) / (., 0, 0); lanes tx = 0 / 15 cross into the other j, the next group or the next wave column.
+	// Branch-free: every lane evaluates  (A & keep) | (shift(A) & sa) | (shift1(B) & b1) | (shift15(B) & b15) | carry(C)
+	// with per-lane constant masks that are zero except on those two lanes (A, B: words of this row held by other
+	// lanes, C: one word of the neighbouring wave column).
 	const bool sp_back = m == 0 && q == 0, sp_fwd = m == 7 && q == 3;
 	const int backB = word_of(1 - j, 7, 3), fwdB = word_of(1 - j, 0, 0);
-	const int prev_off = ((wc ? wc - 1 : nwc - 1) - wc) * 64 + word_of(1, 7, 3) - lane; // from this lane's own word
-	const int next_off = ((wc + 1 < nwc ? wc + 1 : 0) - wc) * 64 + word_of(0, 0, 0) - lane;
+	const uint64_t bk_keep = sp_back ? 0ull : ~0ull, bk_sa = sp_back ? ~LANE0 : 0ull;
+	const uint64_t bk_b1 = (sp_back && j == 0) ? (LANE0 & ~1ull) : 0ull, bk_b15 = (sp_back && j == 1) ? LANE0 : 0ull;
+	const uint32_t bk_c = (sp_back && j == 0) ? 1u : 0u;
+	const uint64_t fw_keep = sp_fwd ? 0ull : ~0ull, fw_sa = sp_fwd ? ~LANE15 : 0ull;
+	const uint64_t fw_b15 = (sp_fwd && j == 0) ? LANE15 : 0ull, fw_b1 = (sp_fwd && j == 1) ? (LANE15 & ~(1ull << 63)) : 0ull;
+	const uint32_t fw_c = (sp_fwd && j == 1) ? 0x80000000u : 0u;
+	// word offsets from the wave's own 64 words of a row: this lane's word, and the word C comes from
+	const int back_c = (sp_back && j == 0) ? ((wc ? wc - 1 : nwc - 1) - wc) * 64 + word_of(1, 7, 3) : lane;
+	const int fwd_c = (sp_fwd && j == 1) ? ((wc + 1 < nwc ? wc + 1 : 0) - wc) * 64 + word_of(0, 0, 0) : lane;
 
-	const uint64_t *ps = p.src + ((ptrdiff_t)r0 * wpr + wc * 64 + lane);
-	uint64_t *pd = p.dst + ((ptrdiff_t)r0 * wpr + wc * 64 + lane);
+	const uint64_t *rs = p.src + ((ptrdiff_t)r0 * wpr + wc * 64); // wave-uniform row pointers, lanes index them
+	uint64_t *rd = p.dst + ((ptrdiff_t)r0 * wpr + wc * 64);
 	const ptrdiff_t wrap_bot = (ptrdiff_t)p.Y * wpr;
 
 	// per-wave scratch: two slots of 64 x (c3, c4) masks
@@ -103,7 +136,7 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 	const uint32_t cx_base = 16u * (2u * p.it + p.color);
 	const uint32_t seed_lo_cy = p.seed_lo ^ (uint32_t)((2ull * p.it + p.color) >> 28); // see dense_update_k
 
-	uint64_t up = ps[-(ptrdiff_t)wpr], ct = ps[0];
+	uint64_t up = rs[lane - wpr], ct = rs[lane];
 
 #if !defined(ISING_BAL_WAVEWB)
 	// one write-back per workgroup and row: every wave runs the same number of iterations and meets at a barrier
@@ -161,41 +194,34 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 			const int lr = r0 + r - 1;
 			const uint32_t grow = p.row_base + (uint32_t)lr;
 			const bool back = (p.color == 0) ? !(grow & 1u) : (grow & 1u); // readBack, optimized/main.cu:542
-			const uint64_t *msk = slot + ((r - 1) & 1) * 128 + 2 * lane;
-			const uint64_t c3 = __hip_atomic_load(msk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			const uint64_t c4 = __hip_atomic_load(msk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			const uint64_t dw = ps[wpr];
-			const uint64_t me = pd[0];
-#if defined(ISING_DBG_NOWORD) // perf investigation only
-			pd[0] = me ^ (c3 & c4 & dw & ct);
-			up = ct; ct = dw; ps += wpr; pd += wpr;
-			if (r < nrows) asm volatile("s_dcache_wb" ::: "memory");
-			continue;
-#endif
+			// this lane's two accept masks: 16 bytes at slot + 16 lane, past the (non-coherent) vector L1
+			const uint64_t *msk = slot + ((r - 1) & 1) * 128;
+			u32x4 mk;
+			asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(mk) : "v"(lane * 16), "s"(msk) : "memory");
+			const uint64_t dw = rs[wpr + lane];
+			const uint64_t me = rd[lane];
+			const uint64_t cw = rs[back ? back_c : fwd_c];
 			const uint64_t A = bperm64(back ? backA : fwdA, ct);
 			const uint64_t Bw = bperm64(back ? backB : fwdB, ct);
-			uint64_t sd = A;
-			if (back) {
-				if (sp_back) {
-					if (j == 0) sd = ((A << 1) & ~LANE0) | ((Bw << 1) & LANE0 & ~1ull) | (ps[prev_off] >> 63);
-					else        sd = ((A << 1) & ~LANE0) | ((Bw >> 15) & LANE0);
-				}
-			} else {
-				if (sp_fwd) {
-					if (j == 0) sd = ((A >> 1) & ~LANE15) | ((Bw << 15) & LANE15);
-					else        sd = ((A >> 1) & ~LANE15) | ((Bw >> 1) & LANE15 & ~(1ull << 63)) | (ps[next_off] << 63);
-				}
-			}
+			uint64_t sd;
+			if (back) sd = (A & bk_keep) | ((A << 1) & bk_sa) | ((Bw << 1) & bk_b1) | ((Bw >> 15) & bk_b15) | (uint64_t)((uint32_t)(cw >> 63) & bk_c);
+			else      sd = (A & fw_keep) | ((A >> 1) & fw_sa) | ((Bw << 15) & fw_b15) | ((Bw >> 1) & fw_b1) | ((uint64_t)((uint32_t)(cw << 31) & fw_c) << 32);
+			asm volatile("s_waitcnt vmcnt(0)" : "+v"(mk) :: "memory");
+			const uint64_t c3 = ((uint64_t)mk.y << 32) | mk.x, c4 = ((uint64_t)mk.w << 32) | mk.z;
+#if defined(ISING_DBG_NOWORD) // perf investigation only
+			const uint64_t nw = me ^ (c3 & c4 & dw & ct & sd);
+#else
 			const uint64_t nw = me ^ flips64(me, up, ct, dw, sd, c3, c4);
-			pd[0] = nw;
+#endif
+			rd[lane] = nw;
 			if (p.wrap) { // single slab: keep this colour's own halo rows equal to the opposite edge rows
-				if (lr == 0) pd[wrap_bot] = nw;
-				if (lr == p.Y - 1) pd[-wrap_bot] = nw;
+				if (lr == 0) rd[wrap_bot + lane] = nw;
+				if (lr == p.Y - 1) rd[lane - wrap_bot] = nw;
 			}
 			up = ct;
 			ct = dw;
-			ps += wpr;
-			pd += wpr;
+			rs += wpr;
+			rd += wpr;
 		}
 #if !defined(ISING_BAL_WAVEWB)
 		if (wb_wave && r < rmax) asm volatile("s_dcache_wb" ::: "memory");
