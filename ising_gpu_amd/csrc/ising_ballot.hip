@@ -46,31 +46,6 @@ __device__ __forceinline__ uint64_t bperm64(int src_lane, uint64_t v) {
 	return ((uint64_t)hi << 32) | lo;
 }
 
-// truth table of a 3-input bit function for v_bitop3_b32: bit (a << 2 | b << 1 | c) = f(a, b, c)
-template <typename F>
-constexpr uint32_t tt3(F f) {
-	uint32_t t = 0;
-	for (int i = 0; i < 8; ++i) t |= (f((i >> 2) & 1, (i >> 1) & 1, i & 1) ? 1u : 0u) << i;
-	return t;
-}
-#define BITOP3(a, b, c, ...) __builtin_amdgcn_bitop3_b32((a), (b), (c), tt3([](int x, int y, int z) { return (__VA_ARGS__); }))
-
-// Metropolis flips of 32 sites: bit-sliced neighbour count n = up + dw + ct + sd (n0, k1 + k2 = the two carries into
-// bit 1), a = aligned neighbours = n for an up spin, 4 - n for a down spin; a <= 2 always flips, a = 3 / 4 flips
-// where the draw was below n3 / n4 (masks c3 / c4).  Same function as neighbour_planes + flip_mask of
-// ising_dense.hip, arranged as six 3-input operations and six 2-input ones.
-__device__ __forceinline__ uint32_t flips32(uint32_t me, uint32_t up, uint32_t ct, uint32_t dw, uint32_t sd, uint32_t c3, uint32_t c4) {
-	const uint32_t s1 = BITOP3(up, dw, ct, x ^ y ^ z);
-	const uint32_t k1 = BITOP3(up, dw, ct, (x & y) | (z & (x ^ y)));
-	const uint32_t n0 = s1 ^ sd, k2 = s1 & sd;            // n1 = k1 ^ k2, n2 = k1 & k2
-	// a == 3: n0 set and bit 1 of n equal to the spin (n = 3 up, n = 1 down)
-	const uint32_t is3 = n0 & BITOP3(me, k1, k2, !(x ^ y ^ z));
-	// a == 4: n == 4 for an up spin, n == 0 for a down spin
-	const uint32_t p4 = BITOP3(me, k1, k2, x ? (y & z) : !(y | z));
-	const uint32_t not4 = BITOP3(p4, me, n0, !(x & (y | !z)));
-	return BITOP3(is3, c3, not4 | c4, x ? y : z);
-}
-
 __device__ __forceinline__ uint64_t flips64(uint64_t me, uint64_t up, uint64_t ct, uint64_t dw, uint64_t sd, uint64_t c3, uint64_t c4) {
 	const uint32_t lo = flips32((uint32_t)me, (uint32_t)up, (uint32_t)ct, (uint32_t)dw, (uint32_t)sd, (uint32_t)c3, (uint32_t)c4);
 	const uint32_t hi = flips32((uint32_t)(me >> 32), (uint32_t)(up >> 32), (uint32_t)(ct >> 32), (uint32_t)(dw >> 32), (uint32_t)(sd >> 32),

@@ -74,12 +74,17 @@ __device__ __forceinline__ void neighbour_planes(uint32_t up, uint32_t ct, uint3
 	n2 = (y & w) | (c1 & (y ^ w));
 }
 
-// Metropolis decision for 32 spins at once.  a = aligned neighbours = n for an up spin, 4 - n for a down spin;
-// a <= 2 always flips, a = 3 / 4 flips where the draw was below n3 / n4 (planes c3 / c4).
-__device__ __forceinline__ uint32_t flip_mask(uint32_t me, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t c3, uint32_t c4) {
-	const uint32_t is3 = (me & n1 & n0) | (~me & n0 & ~n1 & ~n2);
-	const uint32_t is4 = (me & n2) | (~me & ~(n0 | n1 | n2));
-	return ~(is3 | is4) | (is3 & c3) | (is4 & c4);
+// The integer-threshold forms go straight from the four neighbour words to the flips (flips32, ising_device.hpp).
+template <bool USEJ = false>
+__device__ __forceinline__ uint32_t word_flips(uint32_t me, uint32_t up, uint32_t ct, uint32_t dw, uint32_t side_word, bool back,
+                                               uint32_t c3, uint32_t c4, const uint4 &J = uint4()) {
+	uint32_t sd = back ? __builtin_amdgcn_alignbit(ct, side_word, 31) : __builtin_amdgcn_alignbit(side_word, ct, 1);
+	if (USEJ) { // as in neighbour_planes
+		up ^= J.w; dw ^= J.z;
+		ct ^= back ? J.x : J.y;
+		sd ^= back ? J.y : J.x;
+	}
+	return flips32(me, up, ct, dw, sd, c3, c4);
 }
 
 // cuRAND's curand_uniform: x*2^-32 + 2^-33 in FP32, one rounding (the product is exact).
@@ -208,11 +213,8 @@ __global__ void __launch_bounds__(dense_threads(MODE)) dense_update_k(const Upda
 				c3[j] = compact_even(A[j][0]) | (compact_even(A[j][1]) << 16);
 				c4[j] = compact_even(A[j][0] >> 1) | (compact_even(A[j][1] >> 1) << 16);
 			}
-			uint32_t n0, n1, n2;
-			neighbour_planes(up0, ct0, dw0, side0, back, n0, n1, n2);
-			me0 ^= flip_mask(me0, n0, n1, n2, c3[0], c4[0]);
-			neighbour_planes(up1, ct1, dw1, side1, back, n0, n1, n2);
-			me1 ^= flip_mask(me1, n0, n1, n2, c3[1], c4[1]);
+			me0 ^= word_flips(me0, up0, ct0, dw0, side0, back, c3[0], c4[0]);
+			me1 ^= word_flips(me1, up1, ct1, dw1, side1, back, c3[1], c4[1]);
 		} else if (!GENERIC) {
 			uint32_t c3[2] = {0u, 0u}, c4[2] = {0u, 0u};
 			static_for<16>([&](auto B) {
@@ -221,11 +223,8 @@ __global__ void __launch_bounds__(dense_threads(MODE)) dense_update_k(const Upda
 				philox_block(pr, cx_base + (uint32_t)B.value, p.seed_lo, p.seed_hi, o[0], o[1], o[2], o[3]);
 				accept_bits<m>(c3[j], c4[j], o[0], o[1], o[2], o[3], p.n3, p.n4);
 			});
-			uint32_t n0, n1, n2;
-			neighbour_planes<USEJ>(up0, ct0, dw0, side0, back, n0, n1, n2, j0);
-			me0 ^= flip_mask(me0, n0, n1, n2, c3[0], c4[0]);
-			neighbour_planes<USEJ>(up1, ct1, dw1, side1, back, n0, n1, n2, j1);
-			me1 ^= flip_mask(me1, n0, n1, n2, c3[1], c4[1]);
+			me0 ^= word_flips<USEJ>(me0, up0, ct0, dw0, side0, back, c3[0], c4[0], j0);
+			me1 ^= word_flips<USEJ>(me1, up1, ct1, dw1, side1, back, c3[1], c4[1], j1);
 		} else {
 			uint32_t me[2] = {me0, me1}, n0[2], n1[2], n2[2], flip[2] = {0u, 0u};
 			neighbour_planes<USEJ>(up0, ct0, dw0, side0, back, n0[0], n1[0], n2[0], j0);
