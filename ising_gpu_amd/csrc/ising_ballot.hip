@@ -129,7 +129,12 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 			uint64_t *cur = slot + (r & 1) * 128;
 			static_for<16>([&](auto B) {
 				uint32_t o0, o1, o2, o3;
-				philox_block(pr, cx_base + (uint32_t)B.value, p.seed_lo, p.seed_hi, o0, o1, o2, o3);
+				// The counter is made opaque so that the block-constant (scalar) first two Philox rounds are recomputed on
+				// the scalar unit every row instead of being hoisted out of the row loop: hoisted, 16 blocks x 5 values
+				// overflow the SGPR file and come back through v_readlane (VALU); recomputed, they cost idle SALU slots.
+				uint32_t cx = cx_base + (uint32_t)B.value;
+				asm volatile("" : "+s"(cx));
+				philox_block(pr, cx, p.seed_lo, p.seed_hi, o0, o1, o2, o3);
 #if defined(ISING_BAL_X2) // A/B: compiler-allocated SGPR pairs, eight 8-byte scalar stores per block
 				unsigned long long a0, a1, a2, a3, a4, a5, a6, a7;
 				asm volatile("v_cmp_gt_u32_e64 %0, %8, %10\n\tv_cmp_gt_u32_e64 %1, %9, %10\n\t"
