@@ -3,7 +3,7 @@
 //
 // Supported: -x -y -n/--nit -s/--seed -d/--devs -a/--alpha -t/--temp -p/--print -e/--exppr -m/--magn -u/--update
 //            -o/--out -h, plus --energy (build-side addition: prints the energy per spin next to each
-//            magnetisation line) and --devmap a,b,.. (place slab k on device devmap[k]; lets a 1-GPU box run -d N), --layout dense|nibble.
+//            magnetisation line) and --devmap a,b,.. (place slab k on device devmap[k]; lets a 1-GPU box run -d N), --layout ballot|dense|nibble.
 //            --xsl/--ysl (independent periodic sub-lattices, optimized/main.cu:1423-1462),
 //            -c/--corr (two-point correlations file, optimized/main.cu:1072-1138).
 //            -J <PROB> (random anti-ferromagnetic bonds, optimized/main.cu:153-331, :575-618).
@@ -58,7 +58,8 @@ void usage(const char *pname) {
 	        "\t-o|--out               dump the lattice whenever the magnetization is printed\n"
 	        "\t   --energy            also print the energy per spin (not in the reference)\n"
 	        "\t   --devmap <a,b,...>  device ordinal of each slab (default 0..NUM_DEVS-1)\n"
-	        "\t   --layout <dense|nibble> device layout of the spin arrays: 1 bit/spin (default) or the reference's 4\n"
+	        "\t   --layout <ballot|dense|nibble> device layout of the spin arrays: 1 bit/spin (two bit orders; default:\n"
+	        "\t                       chosen by the library) or the reference's 4 bit/spin\n"
 	        "\t   --xsl <HORIZ_SUB_DIM> horizontal sub-lattice dimension (divisor of -x, multiple of %d)\n"
 	        "\t   --ysl <VERT_SUB_DIM>  vertical sub-lattice dimension (divisor of -y, multiple of %d)\n"
 	        "\t-c|--corr              append the 128 two-point correlations to corr_{Y}x{X}_T_{TEMP}_{SEED} at every print\n"
@@ -175,9 +176,10 @@ int main(int argc, char **argv) {
 			for (char *tok = strtok(optarg, ","); tok; tok = strtok(NULL, ",")) devmap.push_back(atoi(tok));
 			break;
 		case 5:
-			if (!strcmp(optarg, "dense")) layout = ISING_LAYOUT_DENSE;
+			if (!strcmp(optarg, "ballot")) layout = ISING_LAYOUT_BALLOT;
+			else if (!strcmp(optarg, "dense")) layout = ISING_LAYOUT_DENSE;
 			else if (!strcmp(optarg, "nibble")) layout = ISING_LAYOUT_NIBBLE;
-			else { fprintf(stderr, "error: --layout takes dense or nibble\n"); exit(EXIT_FAILURE); }
+			else { fprintf(stderr, "error: --layout takes ballot, dense or nibble\n"); exit(EXIT_FAILURE); }
 			break;
 		case '?': exit(EXIT_FAILURE);
 		default: fprintf(stderr, "unknown option: %c\n", och); exit(EXIT_FAILURE);

@@ -295,7 +295,9 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	c->lld = c->dense ? cfg->X / 128 : cfg->X / 32;
 	c->gx = cfg->X / 2048;
 	compute_tables(c, cfg->temp);
-	if (cfg->layout == ISING_LAYOUT_AUTO && ballot_ok && c->fast_ok && !getenv("ISING_NO_BALLOT")) c->ballot = true;
+	// AUTO: the ballot kernel's two-phase row pipeline wins from ~1e8 spins per slab up (8192^2: dense 5 % ahead)
+	if (cfg->layout == ISING_LAYOUT_AUTO && ballot_ok && c->fast_ok && (long long)cfg->X * cfg->Y >= (1LL << 27) && !getenv("ISING_NO_BALLOT"))
+		c->ballot = true;
 	c->H = cfg->strip_rows > 0 ? cfg->strip_rows : choose_strip_rows(c->gx, cfg->Y, c->dense, c->ballot);
 	if (cfg->Y % c->H) { const int h = c->H; delete c; return fail(ISING_E_ARG, "strip_rows %d does not divide Y %d", h, cfg->Y); }
 	c->nstrips = cfg->Y / c->H;

@@ -34,13 +34,17 @@ def test_state_bit_exact(gpu, oracle_mod, X, Y, strip, temp, seed):
 
 
 def test_auto_layout_picks_ballot_where_it_applies(gpu):
-    with ig.IsingSlab(8192, 32, temp=1.5) as s:
+    with ig.IsingSlab(16384, 8192, temp=1.5) as s:      # from 2^27 spins per slab up
         assert s.layout == BAL
-    with ig.IsingSlab(4096, 32, temp=1.5) as s:
+    with ig.IsingSlab(8192, 8192, temp=1.5) as s:       # small slabs: the dense kernel is ahead
         assert s.layout == ig.LAYOUT_DENSE
-    with ig.IsingSlab(8192, 32, temp=1.5, XSL=2048, YSL=16) as s:
+    with ig.IsingSlab(20480, 8192, temp=1.5) as s:      # X not a multiple of 8192
         assert s.layout == ig.LAYOUT_DENSE
-    with ig.IsingSlab(8192, 32, temp=1.5, J_prob=0.1) as s:
+    with ig.IsingSlab(16384, 8192, temp=1.5, XSL=2048, YSL=16) as s:
+        assert s.layout == ig.LAYOUT_DENSE
+    with ig.IsingSlab(16384, 8192, temp=1.5, J_prob=0.1) as s:
+        assert s.layout == ig.LAYOUT_DENSE
+    with ig.IsingSlab(16384, 8192, temp=0.0) as s:      # no integer thresholds at T = 0
         assert s.layout == ig.LAYOUT_DENSE
     with pytest.raises(ig.IsingError):
         ig.IsingSlab(4096, 32, temp=1.5, layout=BAL)
