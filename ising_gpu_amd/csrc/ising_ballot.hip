@@ -22,8 +22,8 @@
 //                only sites 0 / 31 reach into the neighbouring vector = the neighbouring lane bit, 2 words per row),
 //                then the same bit-sliced adder and Metropolis mask as the dense kernel, 64 sites per lane.
 //
-// Scope: the integer-threshold fast path without sub-lattices and couplings, X a multiple of 8192.  Everything else
-// (generic FP32 kernel, -J, --xsl) runs on the dense layout; ising_capi.cpp converts with the two kernels at the end
+// Scope: the integer-threshold fast path without couplings, X a multiple of 8192, sub-lattice widths of 2048, 4096 or a
+// multiple of 8192.  Everything else (generic FP32 kernel, -J, other widths) runs on the dense layout; ising_capi.cpp converts with the two kernels at the end
 // of this file and uses the dense kernels for the observables that need neighbour geometry.
 #include "ising_device.hpp"
 
@@ -53,6 +53,7 @@ __device__ __forceinline__ uint64_t flips64(uint64_t me, uint64_t up, uint64_t c
 	return ((uint64_t)hi << 32) | lo;
 }
 
+template <bool SUBL>
 __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParams p) {
 	const int lane = threadIdx.x & 63;
 	const int tx = threadIdx.x & (GROUP - 1), g = (threadIdx.x >> 4) & 3;
@@ -82,20 +83,40 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 	else fwdA = m < 7 ? word_of(j, m + 1, 1) : word_of(j, 0, 0);
 	// site 0 (back) / site 31 (forward) have their side neighbour in the adjacent vector = the adjacent lane's bit of
 	// word (., 7, 3) / (., 0, 0); lanes tx = 0 / 15 cross into the other j, the next group or the next wave column.
-	// Branch-free: every lane evaluates  (A & keep) | (shift(A) & sa) | (shift1(B) & b1) | (shift15(B) & b15) | carry(C)
+	// Branch-free: every lane evaluates
+	//     (A & keep) | (shift(A) & sa) | (shift1(B) & b1) | (shift15(B) & b15) | (shiftW(B) & bw) | carry(C)
 	// with per-lane constant masks that are zero except on those two lanes (A, B: words of this row held by other
-	// lanes, C: one word of the neighbouring wave column).
+	// lanes, C: one word of another wave column).  The row is periodic every k = slV/32 column groups (k = gx without
+	// sub-lattices, optimized/main.cu:413-459): the first vector of a period takes its back neighbour from the
+	// period's last vector -- for k = 1, 2 a lane of this wave (shiftW = 15, 31, SUBL only), for k = 4n a lane of
+	// wave column wc + n - 1 instead of wc - 1 (same C term, other address).  Forward is the mirror image.
 	const bool sp_back = m == 0 && q == 0, sp_fwd = m == 7 && q == 3;
 	const int backB = word_of(1 - j, 7, 3), fwdB = word_of(1 - j, 0, 0);
+	const int k = p.slV >> 5;                       // column groups per period
+	const bool inwave = SUBL && k < 4;              // periods shorter than a wave column
+	const int wsh = k == 1 ? 15 : 31;               // shiftW
+	uint64_t first = 0, last = 0;                    // bit 16g (16g + 15): group g opens (closes) a period
+#pragma unroll
+	for (int gg = 0; gg < 4; ++gg) {
+		if ((bx0 + gg) % k == 0) first |= 1ull << (16 * gg);
+		if ((bx0 + gg) % k == k - 1) last |= 1ull << (16 * gg + 15);
+	}
+	const bool bk0 = sp_back && j == 0, fw1 = sp_fwd && j == 1; // the two lanes whose neighbour vector is in another group
 	const uint64_t bk_keep = sp_back ? 0ull : ~0ull, bk_sa = sp_back ? ~LANE0 : 0ull;
-	const uint64_t bk_b1 = (sp_back && j == 0) ? (LANE0 & ~1ull) : 0ull, bk_b15 = (sp_back && j == 1) ? LANE0 : 0ull;
-	const uint32_t bk_c = (sp_back && j == 0) ? 1u : 0u;
+	const uint64_t bk_b1 = bk0 ? (LANE0 & ~1ull & ~first) : 0ull, bk_b15 = (sp_back && j == 1) ? LANE0 : 0ull;
+	const uint64_t bk_bw = (inwave && bk0) ? first : 0ull;
+	const uint32_t bk_c = (bk0 && !inwave) ? 1u : 0u;
 	const uint64_t fw_keep = sp_fwd ? 0ull : ~0ull, fw_sa = sp_fwd ? ~LANE15 : 0ull;
-	const uint64_t fw_b15 = (sp_fwd && j == 0) ? LANE15 : 0ull, fw_b1 = (sp_fwd && j == 1) ? (LANE15 & ~(1ull << 63)) : 0ull;
-	const uint32_t fw_c = (sp_fwd && j == 1) ? 0x80000000u : 0u;
+	const uint64_t fw_b15 = (sp_fwd && j == 0) ? LANE15 : 0ull, fw_b1 = fw1 ? (LANE15 & ~(1ull << 63) & ~last) : 0ull;
+	const uint64_t fw_bw = (inwave && fw1) ? last : 0ull;
+	const uint32_t fw_c = (fw1 && !inwave) ? 0x80000000u : 0u;
 	// word offsets from the wave's own 64 words of a row: this lane's word, and the word C comes from
-	const int back_c = (sp_back && j == 0) ? ((wc ? wc - 1 : nwc - 1) - wc) * 64 + word_of(1, 7, 3) : lane;
-	const int fwd_c = (sp_fwd && j == 1) ? ((wc + 1 < nwc ? wc + 1 : 0) - wc) * 64 + word_of(0, 0, 0) : lane;
+	const int n = max(k >> 2, 1); // wave columns per period
+	const int back_c = bk0 ? ((wc % n ? wc - 1 : wc + n - 1) - wc) * 64 + word_of(1, 7, 3) : lane;
+	const int fwd_c = fw1 ? ((wc % n == n - 1 ? wc - n + 1 : wc + 1) - wc) * 64 + word_of(0, 0, 0) : lane;
+	// rows are periodic every slY rows (SUBL; otherwise rows -1 and Y are the halo rows)
+	const int slY = SUBL ? p.slY : 0;
+	int seam = slY ? slY - r0 % slY : 0x7fffffff; // rows left in the current period, this one included
 
 	const uint64_t *rs = p.src + ((ptrdiff_t)r0 * wpr + wc * 64); // wave-uniform row pointers, lanes index them
 	uint64_t *rd = p.dst + ((ptrdiff_t)r0 * wpr + wc * 64);
@@ -111,7 +132,7 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 	const uint32_t cx_base = 16u * (2u * p.it + p.color);
 	const uint32_t seed_lo_cy = p.seed_lo ^ (uint32_t)((2ull * p.it + p.color) >> 28); // see dense_update_k
 
-	uint64_t up = rs[lane - wpr], ct = rs[lane];
+	uint64_t up = rs[lane + ((slY && r0 % slY == 0) ? (ptrdiff_t)(slY - 1) * wpr : -(ptrdiff_t)wpr)], ct = rs[lane];
 
 #if !defined(ISING_BAL_WAVEWB)
 	// one write-back per workgroup and row: every wave runs the same number of iterations and meets at a barrier
@@ -178,7 +199,8 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 			const uint64_t *msk = slot + ((r - 1) & 1) * 128;
 			u32x4 mk;
 			asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(mk) : "v"(lane * 16), "s"(msk) : "memory");
-			const uint64_t dw = rs[wpr + lane];
+			const bool sl_last = SUBL && seam == 1; // the row below is the period's first row (:422)
+			const uint64_t dw = rs[(sl_last ? (ptrdiff_t)(1 - slY) * wpr : (ptrdiff_t)wpr) + lane];
 			const uint64_t me = rd[lane];
 			const uint64_t cw = rs[back ? back_c : fwd_c];
 			const uint64_t A = bperm64(back ? backA : fwdA, ct);
@@ -186,6 +208,7 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 			uint64_t sd;
 			if (back) sd = (A & bk_keep) | ((A << 1) & bk_sa) | ((Bw << 1) & bk_b1) | ((Bw >> 15) & bk_b15) | (uint64_t)((uint32_t)(cw >> 63) & bk_c);
 			else      sd = (A & fw_keep) | ((A >> 1) & fw_sa) | ((Bw << 15) & fw_b15) | ((Bw >> 1) & fw_b1) | ((uint64_t)((uint32_t)(cw << 31) & fw_c) << 32);
+			if (SUBL) sd |= back ? ((Bw >> wsh) & bk_bw) : ((Bw << wsh) & fw_bw);
 			asm volatile("s_waitcnt vmcnt(0)" : "+v"(mk) :: "memory");
 			const uint64_t c3 = ((uint64_t)mk.y << 32) | mk.x, c4 = ((uint64_t)mk.w << 32) | mk.z;
 #if defined(ISING_DBG_NOWORD) // perf investigation only
@@ -198,10 +221,16 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 				if (lr == 0) rd[wrap_bot + lane] = nw;
 				if (lr == p.Y - 1) rd[lane - wrap_bot] = nw;
 			}
-			up = ct;
-			ct = dw;
 			rs += wpr;
 			rd += wpr;
+			if (sl_last) { // the next row opens a new period: the register window does not slide across the seam
+				seam = slY;
+				if (r < nrows) { up = rs[(ptrdiff_t)(slY - 1) * wpr + lane]; ct = rs[lane]; }
+			} else {
+				up = ct;
+				ct = dw;
+				--seam;
+			}
 		}
 #if !defined(ISING_BAL_WAVEWB)
 		if (wb_wave && r < rmax) asm volatile("s_dcache_wb" ::: "memory");
@@ -265,7 +294,9 @@ __global__ void __launch_bounds__(THREADS) dense_to_ballot_k(const uint32_t *__r
 
 hipError_t launch_ballot_update(const UpdateParams &p, hipStream_t stream) {
 	if (p.nunits <= 0) return hipSuccess;
-	hipLaunchKernelGGL(ballot_update_k, dim3((p.nunits + BAL_THREADS / GROUP - 1) / (BAL_THREADS / GROUP)), dim3(BAL_THREADS), 0, stream, p);
+	const dim3 grid((p.nunits + BAL_THREADS / GROUP - 1) / (BAL_THREADS / GROUP)), block(BAL_THREADS);
+	if (p.slY) hipLaunchKernelGGL(ballot_update_k<true>, grid, block, 0, stream, p);
+	else       hipLaunchKernelGGL(ballot_update_k<false>, grid, block, 0, stream, p);
 	return hipGetLastError();
 }
 

@@ -284,11 +284,12 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	}
 	c->dense = cfg->layout != ISING_LAYOUT_NIBBLE;
 	// the ballot layout covers the integer-threshold update without sub-lattices and couplings, 8192-column granularity
-	const bool ballot_ok = (cfg->X % 8192) == 0 && !cfg->XSL && !cfg->use_J &&
+	// (sub-lattice widths: 2048, 4096 or a multiple of 8192 columns)
+	const bool ballot_ok = (cfg->X % 8192) == 0 && !cfg->use_J && (!cfg->XSL || cfg->XSL <= 4096 || (cfg->XSL % 8192) == 0) &&
 	                       (cfg->kernel == ISING_KERNEL_AUTO || cfg->kernel == ISING_KERNEL_FAST);
 	if (cfg->layout == ISING_LAYOUT_BALLOT && !ballot_ok) {
 		delete c;
-		return fail(ISING_E_ARG, "the ballot layout needs X %% 8192 == 0, no sub-lattices, no -J and the integer-threshold kernel");
+		return fail(ISING_E_ARG, "the ballot layout needs X %% 8192 == 0, sub-lattice widths of 2048, 4096 or a multiple of 8192, no -J and the integer-threshold kernel");
 	}
 	c->ballot = cfg->layout == ISING_LAYOUT_BALLOT;
 	c->lld_packed = cfg->X / 32;

@@ -33,6 +33,38 @@ def test_state_bit_exact(gpu, oracle_mod, X, Y, strip, temp, seed):
             assert s.bond_equal() == orc.bond_equal()
 
 
+@pytest.mark.parametrize("X,Y,XSL,YSL,strip", [(8192, 64, 2048, 16, 0), (8192, 96, 4096, 32, 16), (16384, 48, 8192, 48, 0), (16384, 64, 16384, 16, 8),
+                                               (32768, 32, 16384, 32, 4), (24576, 48, 8192, 16, 1), (8192, 64, 8192, 32, 0)])
+def test_sublattices_bit_exact(gpu, oracle_mod, X, Y, XSL, YSL, strip):
+    """--xsl/--ysl: every XSL x YSL block is an independent torus (loadTile wrap arguments, optimized/main.cu:413-459);
+    widths of one, two, four and more column groups take different paths through the side-word masks."""
+    orc = oracle_mod.OracleLattice(X, Y, seed=8, temp=2.0, XSL=XSL, YSL=YSL).init()
+    with ig.IsingSlab(X, Y, seed=8, temp=2.0, XSL=XSL, YSL=YSL, strip_rows=strip, layout=BAL) as s:
+        assert s.layout == BAL
+        s.init()
+        for n in (1, 4):
+            s.sweep(n)
+            orc.sweep(n)
+            _compare(s, orc, f"sub-lattices {XSL}x{YSL} after {s.it}")
+        assert s.bond_equal() == orc.bond_equal()
+        assert np.array_equal(s.correlations(128), orc.corr(128)) if YSL >= 128 else True
+
+
+def test_sublattice_row_ranges(gpu, oracle_mod):
+    """Row ranges that start and end inside sub-lattices (strips straddle the seams)."""
+    X, Y, XSL, YSL = 8192, 96, 2048, 32
+    orc = oracle_mod.OracleLattice(X, Y, seed=21, temp=1.9, XSL=XSL, YSL=YSL).init()
+    with ig.IsingSlab(X, Y, seed=21, temp=1.9, XSL=XSL, YSL=YSL, strip_rows=16, layout=BAL) as s:
+        s.init()
+        for it in (1, 2):
+            for color in (ig.BLACK, ig.WHITE):
+                for lo, hi in ((0, 5), (5, 31), (31, 33), (33, 96)):
+                    s.update_color(it, color, lo, hi)
+            s.it = it
+            orc.sweep(1)
+            _compare(s, orc, f"it {it}")
+
+
 def test_auto_layout_picks_ballot_where_it_applies(gpu):
     with ig.IsingSlab(16384, 8192, temp=1.5) as s:      # from 2^27 spins per slab up
         assert s.layout == BAL
@@ -41,6 +73,8 @@ def test_auto_layout_picks_ballot_where_it_applies(gpu):
     with ig.IsingSlab(20480, 8192, temp=1.5) as s:      # X not a multiple of 8192
         assert s.layout == ig.LAYOUT_DENSE
     with ig.IsingSlab(16384, 8192, temp=1.5, XSL=2048, YSL=16) as s:
+        assert s.layout == BAL
+    with ig.IsingSlab(24576, 8192, temp=1.5, XSL=6144, YSL=16) as s:   # sub-lattice width of three column groups
         assert s.layout == ig.LAYOUT_DENSE
     with ig.IsingSlab(16384, 8192, temp=1.5, J_prob=0.1) as s:
         assert s.layout == ig.LAYOUT_DENSE
