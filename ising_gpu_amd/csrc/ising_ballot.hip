@@ -23,8 +23,9 @@
 //                then the same bit-sliced adder and Metropolis mask as the dense kernel, 64 sites per lane.
 //
 // Scope: the integer-threshold fast path without couplings, X a multiple of 8192, sub-lattice widths of 2048, 4096 or a
-// multiple of 8192.  Everything else (generic FP32 kernel, -J, other widths) runs on the dense layout; ising_capi.cpp converts with the two kernels at the end
-// of this file and uses the dense kernels for the observables that need neighbour geometry.
+// multiple of 8192.  Everything else (generic FP32 kernel, -J, other widths) runs on the dense layout; ising_capi.cpp
+// converts with the two kernels at the end of this file and uses the dense kernels for the observables that need
+// neighbour geometry.
 #include "ising_device.hpp"
 
 namespace ising {
