@@ -58,7 +58,7 @@ enum {
 	ISING_LAYOUT_NIBBLE = 1, /* the reference's: 4 bits per spin, 16 spins per 64-bit word (optimized/main.cu:40, :1243) */
 	ISING_LAYOUT_DENSE = 2,  /* 1 bit per spin, 32 spins per 32-bit word = one reference 128-bit vector per word */
 	ISING_LAYOUT_BALLOT = 3  /* 1 bit per spin, 64-bit words in the update kernel's wave-ballot order (ising_ballot.hip);
-	                            needs X % 8192 == 0, sub-lattice widths of 2048, 4096 or a multiple of 8192, no -J; a temperature without integer accept
+	                            needs X % 8192 == 0 and sub-lattice widths of 2048, 4096 or a multiple of 8192; a temperature without integer accept
 	                            thresholds turns the slab into ISING_LAYOUT_DENSE at the next update */
 };
 

@@ -22,8 +22,8 @@
 //                only sites 0 / 31 reach into the neighbouring vector = the neighbouring lane bit, 2 words per row),
 //                then the same bit-sliced adder and Metropolis mask as the dense kernel, 64 sites per lane.
 //
-// Scope: the integer-threshold fast path without couplings, X a multiple of 8192, sub-lattice widths of 2048, 4096 or a
-// multiple of 8192.  Everything else (generic FP32 kernel, -J, other widths) runs on the dense layout; ising_capi.cpp
+// Scope: the integer-threshold fast path (with or without -J couplings), X a multiple of 8192, sub-lattice widths of 2048,
+// 4096 or a multiple of 8192.  Everything else (generic FP32 kernel, other widths) runs on the dense layout; ising_capi.cpp
 // converts with the two kernels at the end of this file and uses the dense kernels for the observables that need
 // neighbour geometry.
 #include "ising_device.hpp"
@@ -54,7 +54,7 @@ __device__ __forceinline__ uint64_t flips64(uint64_t me, uint64_t up, uint64_t c
 	return ((uint64_t)hi << 32) | lo;
 }
 
-template <bool SUBL>
+template <bool SUBL, bool USEJ>
 __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParams p) {
 	const int lane = threadIdx.x & 63;
 	const int tx = threadIdx.x & (GROUP - 1), g = (threadIdx.x >> 4) & 3;
@@ -121,6 +121,8 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 
 	const uint64_t *rs = p.src + ((ptrdiff_t)r0 * wpr + wc * 64); // wave-uniform row pointers, lanes index them
 	uint64_t *rd = p.dst + ((ptrdiff_t)r0 * wpr + wc * 64);
+	// -J: per row and wave column four coupling planes {right, left, down, up} of 64 ballot-order words each
+	const uint64_t *rj = USEJ ? p.jdst + 4 * ((ptrdiff_t)r0 * wpr + wc * 64) : nullptr;
 	const ptrdiff_t wrap_bot = (ptrdiff_t)p.Y * wpr;
 
 	// per-wave scratch: two slots of 64 x (c3, c4) masks
@@ -215,7 +217,15 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 #if defined(ISING_DBG_NOWORD) // perf investigation only
 			const uint64_t nw = me ^ (c3 & c4 & dw & ct & sd);
 #else
-			const uint64_t nw = me ^ flips64(me, up, ct, dw, sd, c3, c4);
+			uint64_t nu = up, nc = ct, nd = dw;
+			if (USEJ) { // a set coupling bit flips that neighbour's contribution (optimized/main.cu:575-618)
+				const uint64_t jr = rj[lane], jl = rj[64 + lane], jd = rj[128 + lane], ju = rj[192 + lane];
+				nu ^= ju; nd ^= jd;
+				nc ^= back ? jr : jl; // the same-index word holds the right neighbours when `back`, the side word the left
+				sd ^= back ? jl : jr;
+				rj += 4 * wpr;
+			}
+			const uint64_t nw = me ^ flips64(me, nu, nc, nd, sd, c3, c4);
 #endif
 			rd[lane] = nw;
 			if (p.wrap) { // single slab: keep this colour's own halo rows equal to the opposite edge rows
@@ -291,13 +301,100 @@ __global__ void __launch_bounds__(THREADS) dense_to_ballot_k(const uint32_t *__r
 	}
 }
 
+// ---- -J coupling arrays, in place, one wave per (row, wave column) = 128 vectors = 2 KiB.
+// nibble form (32 nibbles <right, left, down, up> = bits 0..3 per 16-byte vector, as ham_init_*_k write them) ->
+// four planes of 64 ballot-order words: [plane][word p], bit l of word p = coupling bit of the site that bit l of spin
+// word p holds.
+__global__ void __launch_bounds__(THREADS) ham_nibbles_to_ballot_k(uint64_t *__restrict__ ham, long long ngroups) {
+	__shared__ uint32_t sh[THREADS / 64][128 * 4];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int j = lane >> 5, m = (lane >> 2) & 7, q = lane & 3;
+	const int s = (q & 1) * 16 + 2 * m + (q >> 1);
+	for (long long grp = (long long)blockIdx.x * (THREADS / 64) + wv; grp < ngroups; grp += (long long)gridDim.x * (THREADS / 64)) {
+		uint4 *g4 = reinterpret_cast<uint4 *>(ham + grp * 256);
+		const uint4 a = g4[lane], b = g4[lane + 64];
+		uint32_t *d = sh[wv];
+		d[4 * lane] = a.x; d[4 * lane + 1] = a.y; d[4 * lane + 2] = a.z; d[4 * lane + 3] = a.w;
+		d[4 * (lane + 64)] = b.x; d[4 * (lane + 64) + 1] = b.y; d[4 * (lane + 64) + 2] = b.z; d[4 * (lane + 64) + 3] = b.w;
+		__builtin_amdgcn_wave_barrier();
+		__threadfence_block();
+		uint64_t w[4] = {0, 0, 0, 0};
+#pragma unroll 4
+		for (int l = 0; l < 64; ++l) {
+			const int v = ((l >> 4) << 5) | (j << 4) | (l & 15);
+			const uint32_t nib = (d[4 * v + (s >> 3)] >> (4 * (s & 7))) & 0xFu;
+#pragma unroll
+			for (int pl = 0; pl < 4; ++pl) w[pl] |= (uint64_t)((nib >> pl) & 1u) << l;
+		}
+		__builtin_amdgcn_wave_barrier();
+		__threadfence_block();
+#pragma unroll
+		for (int pl = 0; pl < 4; ++pl) ham[grp * 256 + 64 * pl + lane] = w[pl];
+	}
+}
+
+// ballot planes -> the dense layout's per-vector planes (uint4 {right, left, down, up}, ham_planes_k's output)
+__global__ void __launch_bounds__(THREADS) ham_ballot_to_planes_k(uint64_t *__restrict__ ham, long long ngroups) {
+	__shared__ uint64_t sh[THREADS / 64][256];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	for (long long grp = (long long)blockIdx.x * (THREADS / 64) + wv; grp < ngroups; grp += (long long)gridDim.x * (THREADS / 64)) {
+#pragma unroll
+		for (int pl = 0; pl < 4; ++pl) sh[wv][64 * pl + lane] = ham[grp * 256 + 64 * pl + lane];
+		__builtin_amdgcn_wave_barrier();
+		__threadfence_block();
+		uint4 out[2];
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const int v = lane + 64 * h;
+			const int l = ((v >> 5) << 4) | (v & 15), j = (v >> 4) & 1;
+			uint32_t pw[4] = {0, 0, 0, 0};
+#pragma unroll 4
+			for (int s = 0; s < 32; ++s) {
+				const int p = word_of_site(j, s);
+#pragma unroll
+				for (int pl = 0; pl < 4; ++pl) pw[pl] |= (uint32_t)((sh[wv][64 * pl + p] >> l) & 1ull) << s;
+			}
+			out[h] = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+		}
+		__builtin_amdgcn_wave_barrier();
+		__threadfence_block();
+		uint4 *g4 = reinterpret_cast<uint4 *>(ham + grp * 256);
+		g4[lane] = out[0];
+		g4[lane + 64] = out[1];
+	}
+}
+
 } // namespace
 
 hipError_t launch_ballot_update(const UpdateParams &p, hipStream_t stream) {
 	if (p.nunits <= 0) return hipSuccess;
 	const dim3 grid((p.nunits + BAL_THREADS / GROUP - 1) / (BAL_THREADS / GROUP)), block(BAL_THREADS);
-	if (p.slY) hipLaunchKernelGGL(ballot_update_k<true>, grid, block, 0, stream, p);
-	else       hipLaunchKernelGGL(ballot_update_k<false>, grid, block, 0, stream, p);
+	if (p.jdst) {
+		if (p.slY) hipLaunchKernelGGL((ballot_update_k<true, true>), grid, block, 0, stream, p);
+		else       hipLaunchKernelGGL((ballot_update_k<false, true>), grid, block, 0, stream, p);
+	} else {
+		if (p.slY) hipLaunchKernelGGL((ballot_update_k<true, false>), grid, block, 0, stream, p);
+		else       hipLaunchKernelGGL((ballot_update_k<false, false>), grid, block, 0, stream, p);
+	}
+	return hipGetLastError();
+}
+
+// -J coupling rows (X/4 bytes each) between the nibble / dense-plane forms and the ballot planes, in place
+hipError_t launch_ham_to_ballot(uint64_t *ham, int gx, long long rows, hipStream_t stream) {
+	const long long ngroups = rows * (gx / 4);
+	if (ngroups <= 0) return hipSuccess;
+	long long blocks = (ngroups + THREADS / 64 - 1) / (THREADS / 64);
+	if (blocks > 16384) blocks = 16384;
+	hipLaunchKernelGGL(ham_nibbles_to_ballot_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, ham, ngroups);
+	return hipGetLastError();
+}
+
+hipError_t launch_ham_ballot_to_planes(uint64_t *ham, int gx, long long rows, hipStream_t stream) {
+	const long long ngroups = rows * (gx / 4);
+	if (ngroups <= 0) return hipSuccess;
+	long long blocks = (ngroups + THREADS / 64 - 1) / (THREADS / 64);
+	if (blocks > 16384) blocks = 16384;
+	hipLaunchKernelGGL(ham_ballot_to_planes_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, ham, ngroups);
 	return hipGetLastError();
 }
 

@@ -68,7 +68,7 @@ struct ising_ctx {
 	size_t color_words = 0;
 	uint64_t *d_lat = nullptr;          // [2 colours][Y + 2 rows][lld]: row -1 and row Y of each colour are halo rows
 	uint64_t *d_ham = nullptr;          // -J: [hamB, hamW], [Y + 2 rows][lld_packed] each (4 bits per site in both layouts)
-	bool ham_planes = false;            // dense layout: the coupling vectors have been transposed into four bit-planes
+	int ham_form = 0;                   // 0: nibbles as generated; 1: per-vector bit-planes (dense); 2: ballot-order planes
 	unsigned long long *d_acc = nullptr; // 2 counters
 	uint32_t *d_bits = nullptr;          // correlations: (Y + d_bits_extra) x lld words, one bit per spin
 	int d_bits_extra = 0;
@@ -124,6 +124,10 @@ int ballot_image(const ising_ctx *c) {
 int ballot_leave(ising_ctx *c) {
 	if (int rc = ballot_image(c)) return rc;
 	HIP_TRY(hipMemcpyAsync(c->d_lat, c->d_tmp, c->alloc_words() * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+	if (c->ham_form == 2) {
+		for (int w = 0; w < 2; w++) HIP_TRY(ising::launch_ham_ballot_to_planes(c->ham(w), c->gx, c->cfg.Y, c->stream));
+		c->ham_form = 1;
+	}
 	c->ballot = false;
 	return ISING_OK;
 }
@@ -215,6 +219,27 @@ void planes_to_nibbles(uint64_t *vecs, size_t nvec) {
 	}
 }
 
+// Host mirror of ham_ballot_to_planes_k (ising_ballot.hip), in place: groups of 4 planes x 64 ballot-order words ->
+// 128 vectors of four 32-bit planes.
+void ballot_planes_to_planes(uint64_t *ham, size_t ngroups) {
+	std::vector<uint64_t> in(256);
+	for (size_t g = 0; g < ngroups; g++) {
+		uint64_t *grp = ham + g * 256;
+		memcpy(in.data(), grp, 256 * sizeof(uint64_t));
+		uint32_t *out = reinterpret_cast<uint32_t *>(grp);
+		for (int v = 0; v < 128; v++) {
+			const int l = ((v >> 5) << 4) | (v & 15), j = (v >> 4) & 1;
+			uint32_t pw[4] = {0, 0, 0, 0};
+			for (int s = 0; s < 32; s++) {
+				const int m = (s & 15) >> 1, q = ((s & 1) << 1) | (s >> 4);
+				const int p = 32 * j + 4 * m + q;
+				for (int pl = 0; pl < 4; pl++) pw[pl] |= (uint32_t)((in[64 * pl + p] >> l) & 1ull) << s;
+			}
+			memcpy(out + 4 * v, pw, sizeof(pw));
+		}
+	}
+}
+
 int choose_strip_rows(int gx, int Y, bool dense, bool ballot = false) {
 	// Enough (column-group x strip) units to give every SIMD several waves, while keeping strips tall so the two
 	// halo rows per strip stay a small fraction of the source traffic (measured optimum: 32 rows for the nibble
@@ -285,11 +310,11 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	c->dense = cfg->layout != ISING_LAYOUT_NIBBLE;
 	// the ballot layout covers the integer-threshold update without sub-lattices and couplings, 8192-column granularity
 	// (sub-lattice widths: 2048, 4096 or a multiple of 8192 columns)
-	const bool ballot_ok = (cfg->X % 8192) == 0 && !cfg->use_J && (!cfg->XSL || cfg->XSL <= 4096 || (cfg->XSL % 8192) == 0) &&
+	const bool ballot_ok = (cfg->X % 8192) == 0 && (!cfg->XSL || cfg->XSL <= 4096 || (cfg->XSL % 8192) == 0) &&
 	                       (cfg->kernel == ISING_KERNEL_AUTO || cfg->kernel == ISING_KERNEL_FAST);
 	if (cfg->layout == ISING_LAYOUT_BALLOT && !ballot_ok) {
 		delete c;
-		return fail(ISING_E_ARG, "the ballot layout needs X %% 8192 == 0, sub-lattice widths of 2048, 4096 or a multiple of 8192, no -J and the integer-threshold kernel");
+		return fail(ISING_E_ARG, "the ballot layout needs X %% 8192 == 0, sub-lattice widths of 2048, 4096 or a multiple of 8192 and the integer-threshold kernel");
 	}
 	c->ballot = cfg->layout == ISING_LAYOUT_BALLOT;
 	c->lld_packed = cfg->X / 32;
@@ -664,7 +689,7 @@ int ising_init_couplings_black(ising_ctx *c) {
 	if (thr >= (1ull << 32)) return fail(ISING_E_ARG, "J probability %g sets every bit", (double)prob); // unreachable: u <= 1 and prob <= 1 gives at most 2^32 - 1... see below
 	p.thr = (uint32_t)thr;
 	HIP_TRY(ising::launch_ham_init_black(p, c->stream));
-	c->ham_planes = false; // nibble form until the white couplings have been assembled from it
+	c->ham_form = 0; // nibble form until the white couplings have been assembled from it
 	return ISING_OK;
 }
 
@@ -675,7 +700,7 @@ int ising_init_couplings_white(ising_ctx *c) {
 	ising::HamWhiteParams p{};
 	p.hamB = c->ham(0);
 	p.hamW = c->ham(1);
-	if (c->ham_planes) return fail(ISING_E_STATE, "ising_init_couplings_white needs a fresh ising_init_couplings_black");
+	if (c->ham_form) return fail(ISING_E_STATE, "ising_init_couplings_white needs a fresh ising_init_couplings_black");
 	p.lld = c->lld_packed;
 	p.Y = c->cfg.Y;
 	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
@@ -683,10 +708,14 @@ int ising_init_couplings_white(ising_ctx *c) {
 	p.slY = c->cfg.XSL ? c->cfg.YSL : 0;
 	p.wrap = c->cfg.nslabs == 1;
 	HIP_TRY(ising::launch_ham_init_white(p, c->stream));
-	if (c->dense) {
+	if (c->ballot) {
+		// the ballot update reads four planes of ballot-order coupling words per row and wave column
+		for (int w = 0; w < 2; w++) HIP_TRY(ising::launch_ham_to_ballot(c->ham(w), c->gx, c->cfg.Y, c->stream));
+		c->ham_form = 2;
+	} else if (c->dense) {
 		// the dense update reads four coupling bit-planes per 32-site word: transpose both arrays in place
 		for (int w = 0; w < 2; w++) HIP_TRY(ising::launch_ham_planes(c->ham(w), c->ham_words() / 2, c->stream));
-		c->ham_planes = true;
+		c->ham_form = 1;
 	}
 	return ISING_OK;
 }
@@ -705,7 +734,8 @@ int ising_read_couplings(ising_ctx *c, int which, int64_t row0, int64_t nrows, u
 	const size_t nw = (size_t)nrows * c->lld_packed;
 	HIP_TRY(hipMemcpyAsync(dst_host, c->ham(which) + (size_t)row0 * c->lld_packed, nw * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
-	if (c->ham_planes) planes_to_nibbles(dst_host, nw / 2);
+	if (c->ham_form == 2) ballot_planes_to_planes(dst_host, nw / 256);
+	if (c->ham_form) planes_to_nibbles(dst_host, nw / 2);
 	return ISING_OK;
 }
 

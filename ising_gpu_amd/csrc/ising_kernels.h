@@ -94,6 +94,9 @@ hipError_t launch_dense_pack_bits(const uint64_t *black, const uint64_t *white, 
 hipError_t launch_ballot_update(const UpdateParams &p, hipStream_t stream);
 hipError_t launch_ballot_to_dense(const uint64_t *bal, uint32_t *dense, int gx, long long rows, hipStream_t stream);
 hipError_t launch_dense_to_ballot(const uint32_t *dense, uint64_t *bal, int gx, long long rows, hipStream_t stream);
+// -J coupling rows in place: nibble form -> ballot planes; ballot planes -> the dense layout's per-vector planes
+hipError_t launch_ham_to_ballot(uint64_t *ham, int gx, long long rows, hipStream_t stream);
+hipError_t launch_ham_ballot_to_planes(uint64_t *ham, int gx, long long rows, hipStream_t stream);
 
 // one-bit-per-spin image of a slab in lattice-column order: bits[Y][lld] 32-bit words
 hipError_t launch_pack_bits(const uint64_t *black, const uint64_t *white, int lld, int Y, uint32_t row_base, uint32_t *bits,

@@ -65,6 +65,49 @@ def test_sublattice_row_ranges(gpu, oracle_mod):
             _compare(s, orc, f"it {it}")
 
 
+@pytest.mark.parametrize("X,Y,prob,sl", [(8192, 32, 0.3, None), (16384, 64, 0.5, None), (8192, 48, 1.0, None), (8192, 16, 0.0, None),
+                                          (16384, 64, 0.4, (2048, 32)), (16384, 32, 0.25, (8192, 16))])
+def test_couplings_bit_exact(gpu, oracle_mod, X, Y, prob, sl):
+    """-J: coupling arrays (read back through the boundary format) and the coupled update, with and without sub-lattices."""
+    kw = dict(XSL=sl[0], YSL=sl[1]) if sl else {}
+    orc = oracle_mod.OracleLattice(X, Y, seed=1234, temp=1.8, **kw).init().init_couplings(prob)
+    with ig.IsingSlab(X, Y, seed=1234, temp=1.8, J_prob=prob, layout=BAL, **kw) as s:
+        assert s.layout == BAL
+        s.init().init_couplings()
+        assert np.array_equal(s.read_couplings(ig.BLACK), orc.hamB)
+        assert np.array_equal(s.read_couplings(ig.WHITE), orc.hamW)
+        for n in (1, 5):
+            s.sweep(n)
+            orc.sweep(n)
+            _compare(s, orc, f"-J {prob} after {s.it}")
+
+
+def test_couplings_ring_and_migration(gpu, oracle_mod):
+    """-J on a ring of ballot slabs (the white couplings need the neighbours' black edge rows), then a temperature
+    without integer thresholds: spins and couplings turn dense together."""
+    X, Y, n = 8192, 96, 3
+    orc = oracle_mod.OracleLattice(X, Y, seed=4, temp=1.5).init().init_couplings(0.35)
+    backs = [ig.HipSlabBackend.create(X, Y // n, seed=4, temp=1.5, nslabs=n, slab=k, J_prob=0.35, layout=BAL) for k in range(n)]
+    try:
+        ring = ig.LocalRing(backs).init()
+        ring.sweep(3)
+        orc.sweep(3)
+        assert np.array_equal(np.concatenate([b.slab.read_couplings(ig.WHITE) for b in backs]), orc.hamW)
+        assert np.array_equal(np.concatenate([b.slab.read(ig.WHITE) for b in backs]), orc.white)
+        for b in backs:
+            b.slab.set_temperature(0.0)
+        orc.temp = 0.0
+        ring.sweep(2)
+        orc.sweep(2)
+        assert all(b.slab.current_layout() == ig.LAYOUT_DENSE for b in backs)
+        assert np.array_equal(np.concatenate([b.slab.read_couplings(ig.BLACK) for b in backs]), orc.hamB)
+        assert np.array_equal(np.concatenate([b.slab.read(ig.BLACK) for b in backs]), orc.black)
+        assert np.array_equal(np.concatenate([b.slab.read(ig.WHITE) for b in backs]), orc.white)
+    finally:
+        for b in backs:
+            b.slab.close()
+
+
 def test_auto_layout_picks_ballot_where_it_applies(gpu):
     with ig.IsingSlab(16384, 8192, temp=1.5) as s:      # from 2^27 spins per slab up
         assert s.layout == BAL
@@ -77,7 +120,7 @@ def test_auto_layout_picks_ballot_where_it_applies(gpu):
     with ig.IsingSlab(24576, 8192, temp=1.5, XSL=6144, YSL=16) as s:   # sub-lattice width of three column groups
         assert s.layout == ig.LAYOUT_DENSE
     with ig.IsingSlab(16384, 8192, temp=1.5, J_prob=0.1) as s:
-        assert s.layout == ig.LAYOUT_DENSE
+        assert s.layout == BAL
     with ig.IsingSlab(16384, 8192, temp=0.0) as s:      # no integer thresholds at T = 0
         assert s.layout == ig.LAYOUT_DENSE
     with pytest.raises(ig.IsingError):
