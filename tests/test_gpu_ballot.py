@@ -190,3 +190,39 @@ def test_temperature_without_thresholds_turns_dense(gpu, oracle_mod):
             orc.sweep(2)
             _compare(s, orc, f"T={temp}")
         assert s.current_layout() == ig.LAYOUT_DENSE
+
+
+def test_large_iteration_index_counter_carry(gpu, oracle_mod):
+    """From iteration 2^27 on the 64-bit Philox block counter carries into its second word (optimized/main.cu:621)."""
+    X, Y, seed, temp = 8192, 32, 55, 2.0
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=temp).init()
+    with ig.IsingSlab(X, Y, seed=seed, temp=temp, layout=BAL) as s:
+        s.init()
+        for it in (2**27 - 1, 2**27, 2**30 + 12345, 2**31 - 1):
+            for color in (ig.BLACK, ig.WHITE):
+                s.update_color(it, color)
+                orc.update_color(it, color)
+            _compare(s, orc, f"it={it}")
+
+
+def test_wide_lattice_and_empty_ranges(gpu, oracle_mod):
+    """X = 262144 (32 wave columns) on the minimum height, empty row ranges, and a strip height that does not divide
+    the range (ragged last strip)."""
+    X, Y = 262144, 16
+    orc = oracle_mod.OracleLattice(X, Y, seed=3, temp=TC).init()
+    with ig.IsingSlab(X, Y, seed=3, temp=TC, layout=BAL, strip_rows=8) as s:
+        s.init()
+        assert s.count() == orc.count()
+        s.update_color(1, ig.BLACK, 5, 5)   # empty range
+        s.update_color(1, ig.BLACK, 0, 0)
+        _compare(s, orc, "after empty launches")
+        for color in (ig.BLACK, ig.WHITE):
+            s.update_color(1, color, 0, 11)  # strips of 8 + 3 rows
+            s.update_color(1, color, 11, 16)
+        s.it = 1
+        orc.sweep(1)
+        _compare(s, orc, "ragged strips")
+        s.sweep(2)
+        orc.sweep(2)
+        _compare(s, orc, "wide lattice")
+        assert s.bond_equal() == orc.bond_equal()
