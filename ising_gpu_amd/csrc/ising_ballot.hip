@@ -135,6 +135,18 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 	const uint32_t cx_base = 16u * (2u * p.it + p.color);
 	const uint32_t seed_lo_cy = p.seed_lo ^ (uint32_t)((2ull * p.it + p.color) >> 28); // see dense_update_k
 
+	// The block-constant (wave-uniform) first two Philox rounds of the 16 draw blocks, three values each, live in LDS:
+	// as SGPRs they overflow the register file or, recomputed per row, make the XORs that consume them 4-cycle
+	// SGPR-operand instructions; from LDS they arrive in VGPRs (2-cycle XORs, +1.5 %).  One private copy per wave
+	// (no workgroup barrier: waves may have left).
+	__shared__ uint4 blk_const_all[BAL_THREADS / 64][16];
+	uint4 *blk_const = blk_const_all[threadIdx.x >> 6];
+	if (lane < 16) {
+		const PhiloxBlockConst kc = philox_block_const(cx_base + (uint32_t)lane, p.seed_lo, p.seed_hi);
+		blk_const[lane] = make_uint4(kc.s0, kc.s1, kc.s2, 0u);
+	}
+	__builtin_amdgcn_wave_barrier();
+	__threadfence_block();
 	uint64_t up = rs[lane + ((slY && r0 % slY == 0) ? (ptrdiff_t)(slY - 1) * wpr : -(ptrdiff_t)wpr)], ct = rs[lane];
 
 #if !defined(ISING_BAL_WAVEWB)
@@ -151,14 +163,18 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 			const uint32_t tid = ((grow >> 4) * (uint32_t)p.gx + (uint32_t)bx) * 256u + (grow & 15u) * 16u + (uint32_t)tx;
 			const PhiloxRow pr = philox_row_setup(tid, seed_lo_cy, k2y);
 			uint64_t *cur = slot + (r & 1) * 128;
+			uint4 kc_next = blk_const[0];
 			static_for<16>([&](auto B) {
 				uint32_t o0, o1, o2, o3;
 				// The counter is made opaque so that the block-constant (scalar) first two Philox rounds are recomputed on
 				// the scalar unit every row instead of being hoisted out of the row loop: hoisted, 16 blocks x 5 values
 				// overflow the SGPR file and come back through v_readlane (VALU); recomputed, they cost idle SALU slots.
-				uint32_t cx = cx_base + (uint32_t)B.value;
-				asm volatile("" : "+s"(cx));
-				philox_block(pr, cx, p.seed_lo, p.seed_hi, o0, o1, o2, o3);
+				// constants of the next block are fetched from LDS while this block's rounds run, and waited for before
+				// this block's scalar stores go out (LDS and scalar memory share one counter)
+				const uint4 kc = kc_next;
+				if (B.value < 15) kc_next = blk_const[B.value + 1];
+				philox_block_pre(pr, PhiloxBlockConst{kc.x, kc.y, kc.z}, p.seed_lo, p.seed_hi, o0, o1, o2, o3);
+				if (B.value < 15) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kc_next.x), "+v"(kc_next.y), "+v"(kc_next.z) :: "memory");
 #if defined(ISING_BAL_X2) // A/B: compiler-allocated SGPR pairs, eight 8-byte scalar stores per block
 				unsigned long long a0, a1, a2, a3, a4, a5, a6, a7;
 				asm volatile("v_cmp_gt_u32_e64 %0, %8, %10\n\tv_cmp_gt_u32_e64 %1, %9, %10\n\t"

@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(dense_threads(MODE)) dense_update_k(const Upda
 				constexpr int j = B.value >> 3, m = B.value & 7;
 				uint32_t o[4];
 				uint32_t cx = cx_base + (uint32_t)B.value;
-				asm volatile("" : "+s"(cx)); // recompute the scalar rounds per row instead of spilling SGPRs (see ising_ballot.hip)
+				asm volatile("" : "+s"(cx)); // recompute the scalar rounds per row instead of spilling SGPRs (an LDS table, as in ising_ballot.hip, is slower here)
 				philox_block(pr, cx, p.seed_lo, p.seed_hi, o[0], o[1], o[2], o[3]);
 				accept_bits<m>(c3[j], c4[j], o[0], o[1], o[2], o[3], p.n3, p.n4);
 			});

@@ -99,6 +99,48 @@ __device__ __forceinline__ void philox_block(const PhiloxRow &pr, uint32_t cx, u
 	o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
 
+// The three block-constant values of philox_block (rounds 1-2 of the wave-uniform counter word, folded with the keys),
+// for callers that keep them somewhere else than in SGPRs (an LDS table: a VGPR-VGPR v_xor costs 2 cycles, one with
+// an SGPR operand 4).
+struct PhiloxBlockConst { uint32_t s0, s1, s2; };
+__device__ __forceinline__ PhiloxBlockConst philox_block_const(uint32_t cx, uint32_t seed_lo, uint32_t seed_hi) {
+	uint32_t s_hi0, s_lo0, s_hi1, s_lo1;
+	mul_hilo(PHILOX_M0, cx, s_hi0, s_lo0);
+	mul_hilo(PHILOX_M1, s_hi0 ^ seed_hi, s_hi1, s_lo1);
+	PhiloxBlockConst k;
+	k.s0 = s_hi1 ^ (seed_lo + PHILOX_W0);
+	k.s1 = s_lo0 ^ (seed_hi + PHILOX_W1);
+	k.s2 = s_lo1 ^ (seed_lo + 2u * PHILOX_W0);
+	return k;
+}
+__device__ __forceinline__ void philox_block_pre(const PhiloxRow &pr, const PhiloxBlockConst &k, uint32_t seed_lo, uint32_t seed_hi,
+                                                 uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
+	uint32_t c0 = k.s0 ^ pr.t_lo1, c2 = pr.t_hi0 ^ k.s1, c1, c3 = pr.t_lo0;
+	uint32_t kx = seed_lo + 2u * PHILOX_W0, ky = seed_hi + 2u * PHILOX_W1;
+	{
+		uint32_t hi0, lo0, hi1, lo1;
+		mul_hilo(PHILOX_M0, c0, hi0, lo0);
+		mul_hilo(PHILOX_M1, c2, hi1, lo1);
+		c0 = hi1 ^ k.s2;
+		c1 = lo1;
+		c2 = hi0 ^ pr.t_e;
+		c3 = lo0;
+	}
+#pragma unroll
+	for (int r = 3; r < 10; ++r) {
+		kx += PHILOX_W0;
+		ky += PHILOX_W1;
+		uint32_t hi0, lo0, hi1, lo1;
+		mul_hilo(PHILOX_M0, c0, hi0, lo0);
+		mul_hilo(PHILOX_M1, c2, hi1, lo1);
+		c0 = xor3(hi1, c1, kx);
+		c1 = lo1;
+		c2 = xor3(hi0, c3, ky);
+		c3 = lo0;
+	}
+	o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
 	for (int off = 32; off; off >>= 1) v += __shfl_down(v, off, 64);
