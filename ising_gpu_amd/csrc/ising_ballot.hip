@@ -19,8 +19,9 @@
 //   word phase   one row later (the write-back has long finished), lane p owns word p of the row: it reads its two
 //                accept masks back (16 bytes, L1-bypassing load), the words above/below from memory and its side word
 //                from another lane (ds_bpermute: site s-1 / s+1 of the same vector is the same bit of another word;
-//                only sites 0 / 31 reach into the neighbouring vector = the neighbouring lane bit, 2 words per row),
-//                then the same bit-sliced adder and Metropolis mask as the dense kernel, 64 sites per lane.
+//                only sites 0 / 31 reach into the neighbouring vector = the neighbouring lane bit: those 2 words per
+//                row are put together on the scalar unit and dropped in with v_writelane), then the same bit-sliced
+//                adder and Metropolis mask as the dense kernel, 64 sites per lane.
 //
 // Scope: the integer-threshold fast path (with or without -J couplings), X a multiple of 8192, sub-lattice widths of 2048,
 // 4096 or a multiple of 8192.  Everything else (generic FP32 kernel, other widths) runs on the dense layout; ising_capi.cpp
@@ -82,42 +83,34 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 	else if (q == 1) fwdA = word_of(j, m, 3);
 	else if (q == 2) fwdA = m < 7 ? word_of(j, m + 1, 0) : word_of(j, 0, 1);
 	else fwdA = m < 7 ? word_of(j, m + 1, 1) : word_of(j, 0, 0);
-	// site 0 (back) / site 31 (forward) have their side neighbour in the adjacent vector = the adjacent lane's bit of
-	// word (., 7, 3) / (., 0, 0); lanes tx = 0 / 15 cross into the other j, the next group or the next wave column.
-	// Branch-free: every lane evaluates
-	//     (A & keep) | (shift(A) & sa) | (shift1(B) & b1) | (shift15(B) & b15) | (shiftW(B) & bw) | carry(C)
-	// with per-lane constant masks that are zero except on those two lanes (A, B: words of this row held by other
-	// lanes, C: one word of another wave column).  The row is periodic every k = slV/32 column groups (k = gx without
-	// sub-lattices, optimized/main.cu:413-459): the first vector of a period takes its back neighbour from the
-	// period's last vector -- for k = 1, 2 a lane of this wave (shiftW = 15, 31, SUBL only), for k = 4n a lane of
-	// wave column wc + n - 1 instead of wc - 1 (same C term, other address).  Forward is the mirror image.
-	const bool sp_back = m == 0 && q == 0, sp_fwd = m == 7 && q == 3;
-	const int backB = word_of(1 - j, 7, 3), fwdB = word_of(1 - j, 0, 0);
+	// Sites 0 (back) / 31 (forward) have their side neighbour in the adjacent vector = the adjacent lane's bit of word
+	// (., 7, 3) / (., 0, 0), where lanes tx = 0 / 15 cross into the other j, the next group or the next wave column:
+	// two words per row and direction -- (0,0,0), (1,0,0) back, (0,7,3), (1,7,3) forward -- are assembled from two
+	// words of this row (A0, A1) and one word of another wave column (C).  That is a handful of 64-bit shifts and
+	// masks on wave-uniform data: the scalar unit does it (scalar loads of the three source words, s_lshl/s_and/s_or)
+	// and v_writelane drops the results into the two lanes; every other lane takes its ds_bpermute word as it is.
+	// The row is periodic every k = slV/32 column groups (k = gx without sub-lattices, optimized/main.cu:413-459): the
+	// first vector of a period takes its back neighbour from the period's last vector -- for k = 1, 2 a bit of this
+	// wave's own words (shift 15 / 31, SUBL only), for k = 4n a bit of wave column wc + n - 1 instead of wc - 1 (same
+	// C term, other address).  Forward is the mirror image.
 	const int k = p.slV >> 5;                       // column groups per period
 	const bool inwave = SUBL && k < 4;              // periods shorter than a wave column
-	const int wsh = k == 1 ? 15 : 31;               // shiftW
+	const int wsh = k == 1 ? 15 : 31;
 	uint64_t first = 0, last = 0;                    // bit 16g (16g + 15): group g opens (closes) a period
 #pragma unroll
 	for (int gg = 0; gg < 4; ++gg) {
 		if ((bx0 + gg) % k == 0) first |= 1ull << (16 * gg);
 		if ((bx0 + gg) % k == k - 1) last |= 1ull << (16 * gg + 15);
 	}
-	const bool bk0 = sp_back && j == 0, fw1 = sp_fwd && j == 1; // the two lanes whose neighbour vector is in another group
-	const uint64_t bk_keep = sp_back ? 0ull : ~0ull, bk_sa = sp_back ? ~LANE0 : 0ull;
-	const uint64_t bk_b1 = bk0 ? (LANE0 & ~1ull & ~first) : 0ull, bk_b15 = (sp_back && j == 1) ? LANE0 : 0ull;
-	const uint64_t bk_bw = (inwave && bk0) ? first : 0ull;
-	const uint32_t bk_c = (bk0 && !inwave) ? 1u : 0u;
-	const uint64_t fw_keep = sp_fwd ? 0ull : ~0ull, fw_sa = sp_fwd ? ~LANE15 : 0ull;
-	const uint64_t fw_b15 = (sp_fwd && j == 0) ? LANE15 : 0ull, fw_b1 = fw1 ? (LANE15 & ~(1ull << 63) & ~last) : 0ull;
-	const uint64_t fw_bw = (inwave && fw1) ? last : 0ull;
-	const uint32_t fw_c = (fw1 && !inwave) ? 0x80000000u : 0u;
-	// word offsets from the wave's own 64 words of a row: this lane's word, and the word C comes from
+	const uint64_t u_b1 = LANE0 & ~1ull & ~first, u_f1 = LANE15 & ~(1ull << 63) & ~last;
+	const uint64_t u_bw = inwave ? first : 0ull, u_fw = inwave ? last : 0ull;
 	const int n = max(k >> 2, 1); // wave columns per period
-	const int back_c = bk0 ? ((wc % n ? wc - 1 : wc + n - 1) - wc) * 64 + word_of(1, 7, 3) : lane;
-	const int fwd_c = fw1 ? ((wc % n == n - 1 ? wc - n + 1 : wc + 1) - wc) * 64 + word_of(0, 0, 0) : lane;
+	const int u_cb = ((wc % n ? wc - 1 : wc + n - 1) - wc) * 64 + word_of(1, 7, 3); // C, in words from this wave's row start
+	const int u_cf = ((wc % n == n - 1 ? wc - n + 1 : wc + 1) - wc) * 64 + word_of(0, 0, 0);
 	// rows are periodic every slY rows (SUBL; otherwise rows -1 and Y are the halo rows)
 	const int slY = SUBL ? p.slY : 0;
-	int seam = slY ? slY - r0 % slY : 0x7fffffff; // rows left in the current period, this one included
+	const int r0_in_sl = SUBL ? r0 % p.slY : 1;
+	int seam = SUBL ? slY - r0_in_sl : 0x7fffffff; // rows left in the current period, this one included
 
 	const uint64_t *rs = p.src + ((ptrdiff_t)r0 * wpr + wc * 64); // wave-uniform row pointers, lanes index them
 	uint64_t *rd = p.dst + ((ptrdiff_t)r0 * wpr + wc * 64);
@@ -147,7 +140,7 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 	}
 	__builtin_amdgcn_wave_barrier();
 	__threadfence_block();
-	uint64_t up = rs[lane + ((slY && r0 % slY == 0) ? (ptrdiff_t)(slY - 1) * wpr : -(ptrdiff_t)wpr)], ct = rs[lane];
+	uint64_t up = rs[lane + ((SUBL && r0_in_sl == 0) ? (ptrdiff_t)(slY - 1) * wpr : -(ptrdiff_t)wpr)], ct = rs[lane];
 
 #if !defined(ISING_BAL_WAVEWB)
 	// one write-back per workgroup and row: every wave runs the same number of iterations and meets at a barrier
@@ -157,6 +150,18 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 	const int rmax = nrows;
 #endif
 	for (int r = 0; r <= rmax; ++r) {
+		// The two words per row whose side neighbours sit in another vector (sites 0 / 31) are assembled on the scalar
+		// unit: three scalar loads of source-colour words of row r0 + r - 1, issued before the draw phase of row r0 + r.
+		unsigned long long sA0 = 0, sA1 = 0, sC = 0;
+		if (r > 0 && r <= nrows) {
+			const uint32_t grow = p.row_base + (uint32_t)(r0 + r - 1);
+			const bool back = (p.color == 0) ? !(grow & 1u) : (grow & 1u);
+			const uint64_t *q0 = rs + (back ? word_of(0, 7, 3) : word_of(0, 0, 0));
+			const uint64_t *q1 = rs + (back ? word_of(1, 7, 3) : word_of(1, 0, 0));
+			const uint64_t *qc = rs + (back ? u_cb : u_cf);
+			asm volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dwordx2 %1, %4, 0x0\n\ts_load_dwordx2 %2, %5, 0x0"
+			             : "=&s"(sA0), "=&s"(sA1), "=&s"(sC) : "s"(q0), "s"(q1), "s"(qc) : "memory");
+		}
 		if (r < nrows) {
 			// ---- draw phase, row r0 + r
 			const uint32_t grow = p.row_base + (uint32_t)(r0 + r);
@@ -221,13 +226,28 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 			const bool sl_last = SUBL && seam == 1; // the row below is the period's first row (:422)
 			const uint64_t dw = rs[(sl_last ? (ptrdiff_t)(1 - slY) * wpr : (ptrdiff_t)wpr) + lane];
 			const uint64_t me = rd[lane];
-			const uint64_t cw = rs[back ? back_c : fwd_c];
+			asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sA0), "+s"(sA1), "+s"(sC) :: "memory");
+			uint64_t w0, w1; // side words of lanes (0,0,0), (1,0,0) [back] / (0,7,3), (1,7,3) [forward]
+			if (back) {
+				w0 = ((sA0 << 1) & ~LANE0) | ((sA1 << 1) & u_b1) | (inwave ? 0ull : (sC >> 63));
+				if (SUBL) w0 |= (sA1 >> wsh) & u_bw;
+				w1 = ((sA1 << 1) & ~LANE0) | ((sA0 >> 15) & LANE0);
+			} else {
+				w0 = ((sA0 >> 1) & ~LANE15) | ((sA1 << 15) & LANE15);
+				w1 = ((sA1 >> 1) & ~LANE15) | ((sA0 >> 1) & u_f1) | (inwave ? 0ull : (sC << 63));
+				if (SUBL) w1 |= (sA0 << wsh) & u_fw;
+			}
 			const uint64_t A = bperm64(back ? backA : fwdA, ct);
-			const uint64_t Bw = bperm64(back ? backB : fwdB, ct);
-			uint64_t sd;
-			if (back) sd = (A & bk_keep) | ((A << 1) & bk_sa) | ((Bw << 1) & bk_b1) | ((Bw >> 15) & bk_b15) | (uint64_t)((uint32_t)(cw >> 63) & bk_c);
-			else      sd = (A & fw_keep) | ((A >> 1) & fw_sa) | ((Bw << 15) & fw_b15) | ((Bw >> 1) & fw_b1) | ((uint64_t)((uint32_t)(cw << 31) & fw_c) << 32);
-			if (SUBL) sd |= back ? ((Bw >> wsh) & bk_bw) : ((Bw << wsh) & fw_bw);
+			uint32_t sdl = (uint32_t)A, sdh = (uint32_t)(A >> 32);
+			// (v_writelane takes its lane from an immediate: one SGPR operand per instruction on gfx9)
+			if (back) {
+				asm("v_writelane_b32 %0, %2, 0\n\tv_writelane_b32 %1, %3, 0" : "+v"(sdl), "+v"(sdh) : "s"((uint32_t)w0), "s"((uint32_t)(w0 >> 32)));
+				asm("v_writelane_b32 %0, %2, 32\n\tv_writelane_b32 %1, %3, 32" : "+v"(sdl), "+v"(sdh) : "s"((uint32_t)w1), "s"((uint32_t)(w1 >> 32)));
+			} else {
+				asm("v_writelane_b32 %0, %2, 31\n\tv_writelane_b32 %1, %3, 31" : "+v"(sdl), "+v"(sdh) : "s"((uint32_t)w0), "s"((uint32_t)(w0 >> 32)));
+				asm("v_writelane_b32 %0, %2, 63\n\tv_writelane_b32 %1, %3, 63" : "+v"(sdl), "+v"(sdh) : "s"((uint32_t)w1), "s"((uint32_t)(w1 >> 32)));
+			}
+			uint64_t sd = ((uint64_t)sdh << 32) | sdl;
 			asm volatile("s_waitcnt vmcnt(0)" : "+v"(mk) :: "memory");
 			const uint64_t c3 = ((uint64_t)mk.y << 32) | mk.x, c4 = ((uint64_t)mk.w << 32) | mk.z;
 #if defined(ISING_DBG_NOWORD) // perf investigation only
