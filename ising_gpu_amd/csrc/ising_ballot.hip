@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 			u32x4 mk;
 			asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(mk) : "v"(lane * 16), "s"(msk) : "memory");
 			const bool sl_last = SUBL && seam == 1; // the row below is the period's first row (:422)
-			const uint64_t dw = rs[(sl_last ? (ptrdiff_t)(1 - slY) * wpr : (ptrdiff_t)wpr) + lane];
+			const uint64_t dw = (rs + (sl_last ? (ptrdiff_t)(1 - slY) * wpr : (ptrdiff_t)wpr))[lane]; // scalar base + lane offset
 			const uint64_t me = rd[lane];
 			asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sA0), "+s"(sA1), "+s"(sC) :: "memory");
 			uint64_t w0, w1; // side words of lanes (0,0,0), (1,0,0) [back] / (0,7,3), (1,7,3) [forward]
@@ -265,14 +265,14 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 #endif
 			rd[lane] = nw;
 			if (p.wrap) { // single slab: keep this colour's own halo rows equal to the opposite edge rows
-				if (lr == 0) rd[wrap_bot + lane] = nw;
-				if (lr == p.Y - 1) rd[lane - wrap_bot] = nw;
+				if (lr == 0) (rd + wrap_bot)[lane] = nw;
+				if (lr == p.Y - 1) (rd - wrap_bot)[lane] = nw;
 			}
 			rs += wpr;
 			rd += wpr;
 			if (sl_last) { // the next row opens a new period: the register window does not slide across the seam
 				seam = slY;
-				if (r < nrows) { up = rs[(ptrdiff_t)(slY - 1) * wpr + lane]; ct = rs[lane]; }
+				if (r < nrows) { up = (rs + (ptrdiff_t)(slY - 1) * wpr)[lane]; ct = rs[lane]; }
 			} else {
 				up = ct;
 				ct = dw;
