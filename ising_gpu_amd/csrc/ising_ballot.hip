@@ -171,32 +171,15 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 			uint4 kc_next = blk_const[0];
 			static_for<16>([&](auto B) {
 				uint32_t o0, o1, o2, o3;
-				// The counter is made opaque so that the block-constant (scalar) first two Philox rounds are recomputed on
-				// the scalar unit every row instead of being hoisted out of the row loop: hoisted, 16 blocks x 5 values
-				// overflow the SGPR file and come back through v_readlane (VALU); recomputed, they cost idle SALU slots.
 				// constants of the next block are fetched from LDS while this block's rounds run, and waited for before
 				// this block's scalar stores go out (LDS and scalar memory share one counter)
 				const uint4 kc = kc_next;
 				if (B.value < 15) kc_next = blk_const[B.value + 1];
 				philox_block_pre(pr, PhiloxBlockConst{kc.x, kc.y, kc.z}, p.seed_lo, p.seed_hi, o0, o1, o2, o3);
 				if (B.value < 15) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kc_next.x), "+v"(kc_next.y), "+v"(kc_next.z) :: "memory");
-#if defined(ISING_BAL_X2) // A/B: compiler-allocated SGPR pairs, eight 8-byte scalar stores per block
-				unsigned long long a0, a1, a2, a3, a4, a5, a6, a7;
-				asm volatile("v_cmp_gt_u32_e64 %0, %8, %10\n\tv_cmp_gt_u32_e64 %1, %9, %10\n\t"
-				             "v_cmp_gt_u32_e64 %2, %8, %11\n\tv_cmp_gt_u32_e64 %3, %9, %11\n\t"
-				             "v_cmp_gt_u32_e64 %4, %8, %12\n\tv_cmp_gt_u32_e64 %5, %9, %12\n\t"
-				             "v_cmp_gt_u32_e64 %6, %8, %13\n\tv_cmp_gt_u32_e64 %7, %9, %13"
-				             : "=&s"(a0), "=&s"(a1), "=&s"(a2), "=&s"(a3), "=&s"(a4), "=&s"(a5), "=&s"(a6), "=&s"(a7)
-				             : "s"(p.n3), "s"(p.n4), "v"(o0), "v"(o1), "v"(o2), "v"(o3));
-				const uint64_t *dstp = cur + 8 * B.value; // words p = 4B .. 4B+3, (c3, c4) each
-				asm volatile("s_store_dwordx2 %0, %8, 0x0\n\ts_store_dwordx2 %1, %8, 0x8\n\t"
-				             "s_store_dwordx2 %2, %8, 0x10\n\ts_store_dwordx2 %3, %8, 0x18\n\t"
-				             "s_store_dwordx2 %4, %8, 0x20\n\ts_store_dwordx2 %5, %8, 0x28\n\t"
-				             "s_store_dwordx2 %6, %8, 0x30\n\ts_store_dwordx2 %7, %8, 0x38"
-				             :: "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6), "s"(a7), "s"(dstp) : "memory");
-#else
 				// (c3, c4) of one output = four consecutive SGPRs = one 16-byte scalar store: word p = 4B + q of the slot.
-				// Fixed registers: inline asm cannot name halves of an SGPR tuple operand.
+				// Fixed registers: inline asm cannot name halves of an SGPR tuple operand.  (Eight 8-byte stores from
+				// compiler-allocated pairs: -6 %.)
 				const uint64_t *dstp = cur + 8 * B.value;
 				asm volatile("v_cmp_gt_u32_e64 s[84:85], %0, %2\n\tv_cmp_gt_u32_e64 s[86:87], %1, %2\n\t"
 				             "v_cmp_gt_u32_e64 s[88:89], %0, %3\n\tv_cmp_gt_u32_e64 s[90:91], %1, %3\n\t"
@@ -207,7 +190,6 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 				             :: "s"(p.n3), "s"(p.n4), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(dstp)
 				             : "memory", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97",
 				               "s98", "s99");
-#endif
 			});
 		}
 #if !defined(ISING_BAL_WAVEWB)
