@@ -226,3 +226,27 @@ def test_wide_lattice_and_empty_ranges(gpu, oracle_mod):
         orc.sweep(2)
         _compare(s, orc, "wide lattice")
         assert s.bond_equal() == orc.bond_equal()
+
+
+def test_ring_correlations_and_cli_layout_flag(gpu, oracle_mod):
+    """Correlations over a ring of ballot slabs (the vertical part needs the next slab's first rows), and the CLI's
+    --layout flag: identical transcripts for all three layouts."""
+    import os
+    import subprocess
+    X, Y, n = 8192, 384, 3
+    orc = oracle_mod.OracleLattice(X, Y, seed=5, temp=2.0).init().sweep(3)
+    slabs = [ig.IsingSlab(X, Y // n, seed=5, temp=2.0, nslabs=n, slab=k, layout=BAL) for k in range(n)]
+    try:
+        ig.LocalRing([ig.HipSlabBackend(s) for s in slabs]).init().sweep(3)
+        assert np.array_equal(ig.ring_correlations(slabs, 128), orc.corr(128))
+    finally:
+        for s in slabs:
+            s.close()
+    cli = os.path.join(os.path.dirname(ig.LIB_PATH), "cuIsing")
+    outs = []
+    for layout in ("ballot", "dense", "nibble"):
+        r = subprocess.run([cli, "-x", "8192", "-y", "64", "-n", "8", "-p", "4", "-t", "2.0", "-s", "99", "--energy", "--layout", layout],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append([ln for ln in r.stdout.splitlines() if "up_s" in ln or "energy" in ln])
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) >= 6
