@@ -26,7 +26,7 @@ def main():
     out = {}
     tr = glob.glob(os.path.join(src, "trace", "*.db"))
     if tr:
-        lines.append("== kernel-trace --stats (bench.py --steps 32 --warmup 4), per kernel ==")
+        lines.append("== kernel-trace --stats (bench.py, default 128 steps + 16 warm-up), per kernel ==")
         lines.append(f"{'kernel':28s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
         rows = q(tr[0], "select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc")
         tot = sum(r[2] for r in rows)
