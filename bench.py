@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--layout", choices=["auto", "nibble", "dense", "ballot"], default="auto", help="device layout of the spin arrays")
+    ap.add_argument("--exchange", choices=["p2p", "allgather"], default=None,
+                    help="N > 1: how the edge rows travel (default p2p send/recv, or ISING_RING_EXCHANGE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -99,7 +101,7 @@ def main():
                                        nslabs=world, slab=rank, strip_rows=args.strip_rows,
                                        layout={"auto": ig.LAYOUT_AUTO, "nibble": ig.LAYOUT_NIBBLE, "dense": ig.LAYOUT_DENSE, "ballot": ig.LAYOUT_BALLOT}[args.layout])
     slab = backend.slab
-    ring = ig.SlabRing(backend)
+    ring = ig.SlabRing(backend, exchange=args.exchange)
     ring.init()
 
     def barrier():
@@ -156,7 +158,7 @@ def main():
             "config": {"workload": f"{args.y * world}x{args.x} lattice ({args.y}x{args.x} per GPU), T=Tc, seed {args.seed}, "
                                    "Philox4x32-10 per site; device layout " + layout_text
                                    + ", results identical to the reference's packed state", "x": args.x, "y_per_gpu": args.y,
-                       "parallelism": f"slab{world}", "strip_rows": slab.strip_rows, "device_layout": layout_name,
+                       "parallelism": f"slab{world}" + (f" ({ring.exchange} row exchange)" if world > 1 else ""), "strip_rows": slab.strip_rows, "device_layout": layout_name,
                        "up": up, "down": down},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

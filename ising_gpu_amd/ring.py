@@ -113,9 +113,18 @@ class HipSlabBackend:
 class SlabRing:
     """Drives one slab of a ring of `world` slabs (world = torch.distributed world size)."""
 
-    def __init__(self, backend: SlabBackend, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, backend: SlabBackend, group: Optional[dist.ProcessGroup] = None, exchange: Optional[str] = None):
+        """exchange: "p2p" (default; one send/recv pair per neighbour = one xGMI link each) or "allgather" (every rank
+        contributes its two edge rows to one all-gather and picks its neighbours' rows out of the result: 2*world rows
+        instead of 2, still a few KiB -- the same schedule on the most travelled collective, kept as a fallback).
+        The environment variable ISING_RING_EXCHANGE overrides the default."""
+        import os
         self.b = backend
         self.group = group
+        self.exchange = exchange or os.environ.get("ISING_RING_EXCHANGE", "p2p")
+        if self.exchange not in ("p2p", "allgather"):
+            raise ValueError(f"unknown ring exchange {self.exchange!r}")
+        self._gather = {}
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.prev = (self.rank - 1) % self.world
@@ -124,7 +133,21 @@ class SlabRing:
         self._pending: List[Optional[list]] = [None, None, None]  # per plane (black, white, black couplings)
 
     # -- halo exchange -----------------------------------------------------------------------------------
+    def _post_allgather(self, color: int):
+        send_top, send_bot, recv_top, recv_bot = self.b.halo_tensors(color)
+        nb = send_top.numel()
+        if color not in self._gather:  # [world][2][row] staging, allocated once per plane on the rows' device
+            self._gather[color] = (torch.empty(2 * nb, dtype=send_top.dtype, device=send_top.device),
+                                   torch.empty(self.world * 2 * nb, dtype=send_top.dtype, device=send_top.device))
+        mine, everyone = self._gather[color]
+        mine[:nb].copy_(send_top)
+        mine[nb:].copy_(send_bot)
+        work = dist.all_gather_into_tensor(everyone, mine, group=self.group, async_op=True)
+        self._pending[color] = [work, (everyone, nb, recv_top, recv_bot)]
+
     def _post(self, color: int):
+        if self.exchange == "allgather":
+            return self._post_allgather(color)
         send_top, send_bot, recv_top, recv_bot = self.b.halo_tensors(color)
         # Order matters when prev == next (world == 2): the peer's first receive (its recv_top, "from prev")
         # must match our LAST row, so the bottom row is sent first.
@@ -139,8 +162,15 @@ class SlabRing:
     def _wait(self, color: int):
         works = self._pending[color]
         if works:
-            for w in works:
-                w.wait()  # NCCL: the current stream waits; gloo: host blocks
+            if self.exchange == "allgather":
+                work, (everyone, nb, recv_top, recv_bot) = works
+                work.wait()
+                rows = everyone.view(self.world, 2, nb)
+                recv_top.copy_(rows[self.prev, 1])  # previous slab's last row
+                recv_bot.copy_(rows[self.next, 0])  # next slab's first row
+            else:
+                for w in works:
+                    w.wait()  # NCCL: the current stream waits; gloo: host blocks
         self._pending[color] = None
 
     # -- driver steps ------------------------------------------------------------------------------------

@@ -49,13 +49,13 @@ class OracleBackend:
         return self.s.bond_equal()
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, exchange="p2p"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     oracle.set_threads(1)
     try:
         slab = oracle.OracleSlab(X, YTOT // world, SEED, TEMP, world, rank)
-        ring = SlabRing(OracleBackend(slab)).init()
+        ring = SlabRing(OracleBackend(slab), exchange=exchange).init()
         ring.sweep(SWEEPS)
         up, down = ring.count()
         bond = ring.bond_equal()
@@ -72,12 +72,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_ring_matches_single_lattice(world):
+@pytest.mark.parametrize("world,exchange", [(2, "p2p"), (3, "p2p"), (2, "allgather"), (3, "allgather")])
+def test_ring_matches_single_lattice(world, exchange):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
