@@ -1,0 +1,59 @@
+"""Randomised parity sweep: random lattice shapes, temperatures, seeds, strip heights, layouts, sub-lattices, couplings
+and row partitions (fixed RNG seed, so the cases are the same on every run) against the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+import ising_gpu_amd as ig
+from test_gpu_parity import _compare
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases(n):
+    rng = np.random.default_rng(20260928)
+    out = []
+    for k in range(n):
+        layout = [ig.LAYOUT_BALLOT, ig.LAYOUT_DENSE, ig.LAYOUT_NIBBLE][k % 3]
+        gx = int(rng.choice([4, 8, 12, 16])) if layout == ig.LAYOUT_BALLOT else int(rng.integers(1, 9))
+        X = 2048 * gx
+        Y = 16 * int(rng.integers(1, 9))
+        temp = float(np.float32(rng.choice([0.4, 1.0, 1.5, 2.0, float(ig.CRIT_TEMP_F32), 2.6, 3.5, 6.0])))
+        seed = int(rng.integers(1, 2**40))
+        strip = int(rng.choice([0, 1, 2, 4, 8, 16]))
+        if Y % max(strip, 1):
+            strip = 0
+        sl = None
+        if rng.random() < 0.35:
+            xs = [w for w in (2048, 4096, 8192, 16384) if X % w == 0 and (layout != ig.LAYOUT_BALLOT or w <= 4096 or w % 8192 == 0)]
+            ys = [h for h in (16, 32, 48, 64) if Y % h == 0]
+            sl = (int(rng.choice(xs)), int(rng.choice(ys)))
+        jp = float(rng.choice([0.1, 0.5, 0.9])) if rng.random() < 0.3 else None
+        sweeps = int(rng.integers(1, 5))
+        out.append(pytest.param(layout, X, Y, temp, seed, strip, sl, jp, sweeps, id=f"{k}-L{layout}-{X}x{Y}-T{temp:.2f}-s{strip}-sl{sl}-J{jp}"))
+    return out
+
+
+@pytest.mark.parametrize("layout,X,Y,temp,seed,strip,sl,jp,sweeps", _cases(36))
+def test_random_configuration(gpu, oracle_mod, layout, X, Y, temp, seed, strip, sl, jp, sweeps):
+    kw = dict(XSL=sl[0], YSL=sl[1]) if sl else {}
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=temp, **kw).init()
+    if jp is not None:
+        orc.init_couplings(jp)
+    with ig.IsingSlab(X, Y, seed=seed, temp=temp, strip_rows=strip, layout=layout, J_prob=jp, **kw) as s:
+        s.init()
+        if jp is not None:
+            s.init_couplings()
+        # first sweep as a random partition of the rows into launches, the rest as whole-colour launches
+        cuts = sorted(set([0, Y] + [int(c) for c in np.random.default_rng(seed).integers(0, Y + 1, size=3)]))
+        for color in (ig.BLACK, ig.WHITE):
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                s.update_color(1, color, lo, hi)
+        s.it = 1
+        orc.sweep(1)
+        _compare(s, orc, "partitioned sweep")
+        s.sweep(sweeps)
+        orc.sweep(sweeps)
+        _compare(s, orc, "after sweeps")
+        assert s.count() == orc.count()
+        if jp is None:
+            assert s.bond_equal() == orc.bond_equal()
