@@ -269,6 +269,49 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 	}
 }
 
+// ---- init (latticeInit_k, optimized/main.cu:92-151): one wave per (row, wave column).  A spin starts up where
+// curand_uniform(x) < 0.5f, i.e. x < thr_half: the lane mask of that compare for output q of draw block B *is* word
+// 4B + q of the row, so the lattice is written by the scalar unit alone -- 16 blocks x (4 v_cmp + two 16-byte scalar
+// stores) per row and wave column, no vector store, no word phase.
+__global__ void __launch_bounds__(THREADS) ballot_init_k(const InitParams p) {
+	const int tx = threadIdx.x & (GROUP - 1), g = (threadIdx.x >> 4) & 3;
+	const int nwc = p.gx >> 2;
+	const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6));
+	if (wave >= nwc * p.Y) return;
+	const int lr = wave / nwc, wc = wave - lr * nwc;
+	const uint32_t grow = p.row_base + (uint32_t)lr;
+	const uint32_t tid = ((grow >> 4) * (uint32_t)p.gx + (uint32_t)(4 * wc + g)) * 256u + (grow & 15u) * 16u + (uint32_t)tx;
+	const PhiloxRow pr = philox_row_setup(tid, p.seed_lo, p.seed_hi + 2u * PHILOX_W1);
+	const uint32_t cx_base = 16u * p.color; // it = 0, optimized/main.cu:116
+	const ptrdiff_t wpr = (ptrdiff_t)nwc * 64;
+	uint64_t *row = p.dst + ((ptrdiff_t)lr * wpr + wc * 64);
+	// single slab: rows 0 and Y - 1 are mirrored into the halo rows Y and -1 (periodic wrap)
+	uint64_t *mirror = !p.wrap ? nullptr : (lr == 0 ? row + (ptrdiff_t)p.Y * wpr : (lr == p.Y - 1 ? row - (ptrdiff_t)p.Y * wpr : nullptr));
+	static_for<16>([&](auto B) {
+		uint32_t o0, o1, o2, o3;
+		uint32_t cx = cx_base + (uint32_t)B.value;
+		asm volatile("" : "+s"(cx));
+		philox_block(pr, cx, p.seed_lo, p.seed_hi, o0, o1, o2, o3);
+		const uint64_t *dstp = row + 4 * B.value;
+		if (!mirror) {
+			asm volatile("v_cmp_gt_u32_e64 s[84:85], %0, %1\n\tv_cmp_gt_u32_e64 s[86:87], %0, %2\n\t"
+			             "v_cmp_gt_u32_e64 s[88:89], %0, %3\n\tv_cmp_gt_u32_e64 s[90:91], %0, %4\n\t"
+			             "s_store_dwordx4 s[84:87], %5, 0x0\n\ts_store_dwordx4 s[88:91], %5, 0x10"
+			             :: "s"(p.thr_half), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(dstp)
+			             : "memory", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91");
+		} else {
+			const uint64_t *dstm = mirror + 4 * B.value;
+			asm volatile("v_cmp_gt_u32_e64 s[84:85], %0, %1\n\tv_cmp_gt_u32_e64 s[86:87], %0, %2\n\t"
+			             "v_cmp_gt_u32_e64 s[88:89], %0, %3\n\tv_cmp_gt_u32_e64 s[90:91], %0, %4\n\t"
+			             "s_store_dwordx4 s[84:87], %5, 0x0\n\ts_store_dwordx4 s[88:91], %5, 0x10\n\t"
+			             "s_store_dwordx4 s[84:87], %6, 0x0\n\ts_store_dwordx4 s[88:91], %6, 0x10"
+			             :: "s"(p.thr_half), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(dstp), "s"(dstm)
+			             : "memory", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91");
+		}
+	});
+	asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // ---- layout conversion, one wave per (row, wave column): 64 ballot words <-> 128 dense 32-bit words
 __device__ __forceinline__ int word_of_site(int j, int s) {
 	const int m = (s & 15) >> 1;
@@ -394,6 +437,12 @@ hipError_t launch_ballot_update(const UpdateParams &p, hipStream_t stream) {
 		if (p.slY) hipLaunchKernelGGL((ballot_update_k<true, false>), grid, block, 0, stream, p);
 		else       hipLaunchKernelGGL((ballot_update_k<false, false>), grid, block, 0, stream, p);
 	}
+	return hipGetLastError();
+}
+
+hipError_t launch_ballot_init(const InitParams &p, hipStream_t stream) {
+	const long long waves = (long long)(p.gx / 4) * p.Y;
+	hipLaunchKernelGGL(ballot_init_k, dim3((unsigned)((waves + THREADS / 64 - 1) / (THREADS / 64))), dim3(THREADS), 0, stream, p);
 	return hipGetLastError();
 }
 

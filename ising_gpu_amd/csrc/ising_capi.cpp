@@ -58,7 +58,8 @@ struct ising_ctx {
 	ising_config cfg{};
 	bool dense = false; // 1 bit per spin on the device (ising_dense.hip); false = the reference's nibble layout
 	bool ballot = false; // dense, with the bits of a row in wave-ballot order (ising_ballot.hip)
-	uint64_t *d_tmp = nullptr;     // ballot layout: dense-order image of d_lat (same shape) for conversions and observables
+	uint64_t *d_tmp = nullptr;     // ballot layout: dense-order image of d_lat (same shape) for conversions and observables;
+	                               // allocated by the first call that needs it (sweeping and counting never do)
 	uint64_t *d_scratch = nullptr; // ballot layout: accept-mask slots, 2 KiB per wave of the largest launch
 	int lld_packed = 0; // 64-bit words per colour row in the reference's packed layout (X/32)
 	int lld = 0;      // 64-bit words per colour row in the DEVICE layout (X/32 nibble, X/128 dense)
@@ -106,7 +107,13 @@ int bind(const ising_ctx *c) {
 }
 
 // ballot layout: convert rows [row_lo, row_hi) of `color` (rows -1 and Y are the halo rows) between d_lat and d_tmp
-int ballot_rows(const ising_ctx *c, int color, long long row_lo, long long row_hi, bool to_dense) {
+int ballot_tmp(ising_ctx *c) { // the dense-order image is allocated by the first call that needs one
+	if (!c->d_tmp) HIP_TRY(hipMalloc((void **)&c->d_tmp, c->alloc_words() * sizeof(uint64_t)));
+	return ISING_OK;
+}
+
+int ballot_rows(ising_ctx *c, int color, long long row_lo, long long row_hi, bool to_dense) {
+	if (int rc = ballot_tmp(c)) return rc;
 	uint64_t *lat = c->lat(color) + row_lo * c->lld, *tmp = c->tmp(color) + row_lo * c->lld;
 	if (to_dense) HIP_TRY(ising::launch_ballot_to_dense(lat, reinterpret_cast<uint32_t *>(tmp), c->gx, row_hi - row_lo, c->stream));
 	else HIP_TRY(ising::launch_dense_to_ballot(reinterpret_cast<const uint32_t *>(tmp), lat, c->gx, row_hi - row_lo, c->stream));
@@ -114,7 +121,7 @@ int ballot_rows(const ising_ctx *c, int color, long long row_lo, long long row_h
 }
 
 // ballot layout: refresh the dense-order image (both colours, halo rows included)
-int ballot_image(const ising_ctx *c) {
+int ballot_image(ising_ctx *c) {
 	for (int color = 0; color < 2; color++)
 		if (int rc = ballot_rows(c, color, -1, (long long)c->cfg.Y + 1, true)) return rc;
 	return ISING_OK;
@@ -337,7 +344,6 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (e == hipSuccess) e = hipMemset(c->d_lat, 0, c->alloc_words() * sizeof(uint64_t)); // optimized/main.cu:1603
 	if (e == hipSuccess) e = hipMalloc((void **)&c->d_acc, 2 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMalloc((void **)&c->d_lut, 65536);
-	if (e == hipSuccess && c->ballot) e = hipMalloc((void **)&c->d_tmp, c->alloc_words() * sizeof(uint64_t));
 	if (e == hipSuccess && c->ballot) e = hipMalloc((void **)&c->d_scratch, (size_t)(c->gx / 4) * (c->nstrips + 2) * 2048);
 	if (e == hipSuccess && cfg->use_J) {
 		if (cfg->coupling_mem) c->d_ham = static_cast<uint64_t *>(cfg->coupling_mem);
@@ -388,7 +394,7 @@ int ising_init_lattice(ising_ctx *c) {
 	const uint64_t half = draw_prefix(0.5f, false); // curand_uniform(x) < 0.5f, optimized/main.cu:133
 	for (int color = 0; color < 2; color++) {
 		ising::InitParams p{};
-		p.dst = c->ballot ? c->tmp(color) : c->lat(color);
+		p.dst = c->lat(color);
 		p.seed_lo = (uint32_t)c->cfg.seed;
 		p.seed_hi = (uint32_t)(c->cfg.seed >> 32);
 		p.color = (uint32_t)color;
@@ -397,8 +403,7 @@ int ising_init_lattice(ising_ctx *c) {
 		p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
 		p.wrap = c->cfg.nslabs == 1;
 		p.thr_half = (uint32_t)half;
-		HIP_TRY(c->dense ? ising::launch_dense_init(p, c->stream) : ising::launch_init(p, c->stream));
-		if (c->ballot) if (int rc = ballot_rows(c, color, -1, (long long)c->cfg.Y + 1, false)) return rc;
+		HIP_TRY(c->ballot ? ising::launch_ballot_init(p, c->stream) : (c->dense ? ising::launch_dense_init(p, c->stream) : ising::launch_init(p, c->stream)));
 	}
 	return ISING_OK;
 }
@@ -606,6 +611,7 @@ int ising_write_packed(ising_ctx *c, int color, int64_t row0, int64_t nrows, con
 		packed_to_dense(src_host, tmp.data(), tmp.size());
 		src = tmp.data();
 	}
+	if (c->ballot) if (int rc = ballot_tmp(c)) return rc;
 	uint64_t *img = c->ballot ? c->tmp(color) : c->lat(color); // ballot layout: through the dense-order image
 	HIP_TRY(hipMemcpyAsync(img + (size_t)row0 * c->lld, src, (size_t)nrows * row_bytes, hipMemcpyHostToDevice, c->stream));
 	if (c->ballot) if (int rc = ballot_rows(c, color, row0, row0 + nrows, false)) return rc;

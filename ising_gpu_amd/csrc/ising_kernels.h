@@ -92,6 +92,7 @@ hipError_t launch_dense_pack_bits(const uint64_t *black, const uint64_t *white, 
 
 // ballot layout (1 bit per spin in wave-ballot order, ising_ballot.hip): integer-threshold update, conversions
 hipError_t launch_ballot_update(const UpdateParams &p, hipStream_t stream);
+hipError_t launch_ballot_init(const InitParams &p, hipStream_t stream);
 hipError_t launch_ballot_to_dense(const uint64_t *bal, uint32_t *dense, int gx, long long rows, hipStream_t stream);
 hipError_t launch_dense_to_ballot(const uint32_t *dense, uint64_t *bal, int gx, long long rows, hipStream_t stream);
 // -J coupling rows in place: nibble form -> ballot planes; ballot planes -> the dense layout's per-vector planes
