@@ -106,12 +106,13 @@ int bind(const ising_ctx *c) {
 	return ISING_OK;
 }
 
-// ballot layout: convert rows [row_lo, row_hi) of `color` (rows -1 and Y are the halo rows) between d_lat and d_tmp
-int ballot_tmp(ising_ctx *c) { // the dense-order image is allocated by the first call that needs one
+// ballot layout: the dense-order image is allocated by the first call that needs one
+int ballot_tmp(ising_ctx *c) {
 	if (!c->d_tmp) HIP_TRY(hipMalloc((void **)&c->d_tmp, c->alloc_words() * sizeof(uint64_t)));
 	return ISING_OK;
 }
 
+// ballot layout: convert rows [row_lo, row_hi) of `color` (rows -1 and Y are the halo rows) between d_lat and d_tmp
 int ballot_rows(ising_ctx *c, int color, long long row_lo, long long row_hi, bool to_dense) {
 	if (int rc = ballot_tmp(c)) return rc;
 	uint64_t *lat = c->lat(color) + row_lo * c->lld, *tmp = c->tmp(color) + row_lo * c->lld;
