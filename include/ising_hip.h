@@ -40,7 +40,10 @@ enum {
 	ISING_E_ARG = 1,      /* bad argument (sizes not multiples of 2048 / 16, null pointer, ...) */
 	ISING_E_HIP = 2,      /* a HIP runtime call failed */
 	ISING_E_STATE = 3,    /* call sequence error (e.g. sweep with nslabs > 1) */
-	ISING_E_NOGPU = 4     /* no usable gfx950 device / kernel image */
+	ISING_E_NOGPU = 4,    /* no usable gfx950 device / kernel image */
+	ISING_E_RCCL = 5,     /* RCCL could not be opened or an RCCL call failed (ring transports) */
+	ISING_E_TIMEOUT = 6,  /* ising_rank_wait: the exchange did not complete in time */
+	ISING_E_IO = 7        /* checkpoint / dump file error */
 };
 
 /* kernel selection for ising_update_color / ising_sweep (A/B and fallback); all variants give identical results */
@@ -86,6 +89,11 @@ typedef struct ising_config {
 	int32_t layout;   /* ISING_LAYOUT_* */
 	int32_t use_J;    /* -J given: allocate coupling arrays and apply them in every update (useGenHamilt, :1368-1372) */
 	float J_prob;     /* -J <PROB>: probability that a bond is anti-ferromagnetic, clamped to [0,1] (:1370) */
+	int32_t ring_halo; /* nslabs == 1 only: 1 = treat the slab as a ring of one, i.e. rows -1 / Y are halo rows that the ring
+	                      transport fills with the slab's own last / first row instead of mirrors the kernels maintain (runs
+	                      the transports, RCCL included, on a single GPU); ignored for nslabs > 1 */
+	size_t lattice_mem_bytes;  /* size of lattice_mem / coupling_mem when given (checked against ising_required_bytes_layout; */
+	size_t coupling_mem_bytes; /* 0 = trust the caller, as the reference trusts cudaMalloc) */
 } ising_config;
 
 const char *ising_last_error(void);
@@ -95,8 +103,12 @@ int ising_device_count(int *count);
 /* Device description for the "Using GPUs" block (optimized/main.cu:1482-1490). */
 int ising_device_info(int device, char *name, size_t name_len, int *cus, int *max_threads_per_cu, int *major, int *minor);
 
-/* Bytes of one device buffer (spins; the coupling buffer has the same size): 2 colours x (Y + 2) rows x X/4 bytes. */
+/* Bytes of one caller-supplied device buffer.  ising_required_bytes: 2 colours x (Y + 2) rows x X/4 bytes -- the
+ * reference's 4 bit/spin, enough for every layout and the size of the coupling buffer (coupling_mem).
+ * ising_required_bytes_layout: what the spin arrays of a given device layout occupy (ISING_LAYOUT_NIBBLE: the same;
+ * ISING_LAYOUT_DENSE / _BALLOT / _AUTO: a quarter -- AUTO only ever picks one of the two 1 bit/spin layouts). */
 size_t ising_required_bytes(int32_t X, int32_t Y);
+size_t ising_required_bytes_layout(int32_t X, int32_t Y, int32_t layout);
 
 /* Allocates the slab (both colours, zeroed), halo-receive rows and the threshold/exp tables.
  * Replaces the cudaMalloc/cudaMallocManaged + memset + exp_d upload of optimized/main.cu:1599-1703. */
@@ -181,20 +193,53 @@ int ising_layout(ising_ctx *ctx, int *layout);
  * hex digit per spin, colours interleaved by row parity. */
 int ising_dump_text(ising_ctx *ctx, const char *prefix);
 
-/* ---- single-process multi-device ring (the reference's own process model: one host thread drives ndev GPUs,
- * optimized/main.cu:1763-1805).  ctxs[k] must be slab k of nslabs == n contexts (any device placement).
- * Halo rows move by peer-to-peer device copies ordered with HIP events instead of the reference's managed-memory
- * remote loads + cudaDeviceSynchronize on every device (:1779-1784, :1800-1805). */
+/* ---- the slab ring (replaces optimized/main.cu:1599-1658 managed memory + remote loads and the
+ * cudaDeviceSynchronize barriers :1779-1784, :1800-1805).  Per colour half-sweep every slab updates its two edge rows
+ * first, then its first / last row travel to the previous / next slab's halo rows on a second HIP stream per slab while
+ * the interior rows are updated on the first; HIP events order the two streams (ising_ring.cpp).
+ * Transports: RCCL (ncclSend / ncclRecv pairs inside one group; librccl is opened at run time) when every slab has its
+ * own device, peer-to-peer device copies otherwise.  ISING_RING_TRANSPORT=copy|rccl|auto overrides AUTO. */
+enum {
+	ISING_TRANSPORT_AUTO = 0, /* RCCL when every slab has its own device and librccl opens, else copies */
+	ISING_TRANSPORT_COPY = 1, /* hipMemcpyPeerAsync on the comm stream (single process only) */
+	ISING_TRANSPORT_RCCL = 2  /* ncclSend / ncclRecv on the comm stream */
+};
 
-/* Delivers colour `color`'s first/last rows of every slab into the neighbours' halo buffers (asynchronous). */
+/* -- single process, n devices (the reference's process model: one host thread drives ndev GPUs, :1763-1805).
+ * ctxs[k] must be slab k of nslabs == n contexts of one layout (any device placement). */
+int ising_ring_set_transport(ising_ctx **ctxs, int n, int transport); /* optional; before the first exchange */
+int ising_ring_transport(ising_ctx **ctxs, int n, int *transport);     /* the transport in use */
+/* Delivers colour `color`'s first/last rows of every slab into the neighbours' halo rows (asynchronous): after
+ * ising_init_lattice / ising_write_packed, for both colours, before the first sweep. */
 int ising_ring_exchange(ising_ctx **ctxs, int n, int color);
 /* -J for a whole ring: black couplings on every slab, their edge rows to the neighbours, then the white couplings. */
 int ising_ring_init_couplings(ising_ctx **ctxs, int n);
-/* `nsweeps` full sweeps over all slabs, iterations first_it .. first_it+nsweeps-1: per colour, the two edge rows
- * first, then the halo copies, then the interior rows (which overlap with the copies).  Asynchronous. */
+/* `nsweeps` full sweeps over all slabs, iterations first_it .. first_it+nsweeps-1 (the hot loop).  Asynchronous. */
 int ising_ring_sweep(ising_ctx **ctxs, int n, int first_it, int nsweeps);
-/* Blocks until every slab's stream is idle. */
+/* Blocks until every slab's compute and comm streams are idle. */
 int ising_ring_synchronize(ising_ctx **ctxs, int n);
+/* Totals over the ring: countSpins (:831-868) and the bond sum of ising_bond_equal.  Blocking. */
+int ising_ring_count(ising_ctx **ctxs, int n, uint64_t *up, uint64_t *down);
+int ising_ring_bond_equal(ising_ctx **ctxs, int n, int64_t *A);
+
+/* -- one process per GPU (torchrun / mpirun style launch): this process holds slab cfg.slab of cfg.nslabs.  Rank 0
+ * creates an id, the launcher's own channel (torch.distributed, MPI, a file) carries its ISING_RCCL_ID_BYTES bytes to
+ * every rank, every rank attaches (collective).  Afterwards the ising_rank_* calls are collective in the same sense as
+ * the ring calls above: every rank makes the same calls in the same order. */
+#define ISING_RCCL_ID_BYTES 128
+int ising_rccl_available(int *version);            /* ISING_OK when librccl could be opened; its version code */
+int ising_rccl_unique_id(void *id_out);            /* ncclGetUniqueId */
+int ising_rank_attach(ising_ctx *ctx, const void *id_in); /* ncclCommInitRank(nslabs, id, slab) */
+int ising_rank_detach(ising_ctx *ctx, int abort_pending);  /* ncclCommDestroy, or ncclCommAbort after a time-out */
+int ising_rank_exchange(ising_ctx *ctx, int color);
+int ising_rank_init_couplings(ising_ctx *ctx);
+int ising_rank_sweep(ising_ctx *ctx, int first_it, int nsweeps);
+/* Waits until both streams of the slab are idle; timeout_ms >= 0 polls and returns ISING_E_TIMEOUT when the time is up
+ * (a hung exchange can then be abandoned with ising_rank_detach(ctx, 1)); < 0 blocks. */
+int ising_rank_wait(ising_ctx *ctx, int timeout_ms);
+/* Whole-lattice totals, ncclAllReduce over the ranks.  Blocking. */
+int ising_rank_count(ising_ctx *ctx, uint64_t *up, uint64_t *down);
+int ising_rank_bond_equal(ising_ctx *ctx, int64_t *A);
 
 /* Two-point correlations, getCorr2D_k + computeCorr (optimized/main.cu:870-965, :1072-1138): for j = 1..ncorr
  * (ncorr <= 128 = MAX_CORR_LEN, :70)  sums[j-1] = sum over all sites of [s(r,c)==s(r,c+j) ? +1 : -1] +

@@ -17,6 +17,9 @@ CRIT_TEMP_F32 = 2.2691853046417236  # float32(2.26918531421f), CRIT_TEMP optimiz
 SEED_DEF = 463463564571  # optimized/main.cu:63
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST, KERNEL_LUT = 0, 1, 2, 3
 LAYOUT_AUTO, LAYOUT_NIBBLE, LAYOUT_DENSE, LAYOUT_BALLOT = 0, 1, 2, 3
+TRANSPORT_AUTO, TRANSPORT_COPY, TRANSPORT_RCCL = 0, 1, 2
+E_ARG, E_HIP, E_STATE, E_NOGPU, E_RCCL, E_TIMEOUT, E_IO = 1, 2, 3, 4, 5, 6, 7
+RCCL_ID_BYTES = 128
 
 
 class IsingConfig(C.Structure):
@@ -25,12 +28,15 @@ class IsingConfig(C.Structure):
         ("seed", C.c_uint64), ("temp", C.c_float), ("device", C.c_int32),
         ("strip_rows", C.c_int32), ("kernel", C.c_int32), ("XSL", C.c_int32), ("YSL", C.c_int32),
         ("lattice_mem", C.c_void_p), ("coupling_mem", C.c_void_p),
-        ("layout", C.c_int32), ("use_J", C.c_int32), ("J_prob", C.c_float),
+        ("layout", C.c_int32), ("use_J", C.c_int32), ("J_prob", C.c_float), ("ring_halo", C.c_int32),
+        ("lattice_mem_bytes", C.c_size_t), ("coupling_mem_bytes", C.c_size_t),
     ]
 
 
 class IsingError(RuntimeError):
-    pass
+    def __init__(self, msg, code=0):
+        super().__init__(msg)
+        self.code = code
 
 
 _lib = None
@@ -42,6 +48,7 @@ PROTOTYPES = {
     "ising_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ising_required_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "ising_required_bytes_layout": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "ising_create": (C.c_int, [C.POINTER(IsingConfig), C.POINTER(C.c_void_p)]),
     "ising_destroy": (C.c_int, [C.c_void_p]),
     "ising_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -67,6 +74,20 @@ PROTOTYPES = {
     "ising_device_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "ising_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "ising_dump_text": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "ising_ring_set_transport": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "ising_ring_transport": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]),
+    "ising_ring_count": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "ising_ring_bond_equal": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int64)]),
+    "ising_rccl_available": (C.c_int, [C.POINTER(C.c_int)]),
+    "ising_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "ising_rank_attach": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ising_rank_detach": (C.c_int, [C.c_void_p, C.c_int]),
+    "ising_rank_exchange": (C.c_int, [C.c_void_p, C.c_int]),
+    "ising_rank_init_couplings": (C.c_int, [C.c_void_p]),
+    "ising_rank_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "ising_rank_wait": (C.c_int, [C.c_void_p, C.c_int]),
+    "ising_rank_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "ising_rank_bond_equal": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ising_ring_exchange": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "ising_ring_sweep": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
     "ising_ring_synchronize": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
@@ -93,4 +114,4 @@ def load() -> C.CDLL:
 def check(rc: int):
     if rc != 0:
         msg = load().ising_last_error()
-        raise IsingError(f"libising_hip error {rc}: {msg.decode() if msg else '?'}")
+        raise IsingError(f"libising_hip error {rc}: {msg.decode() if msg else '?'}", rc)

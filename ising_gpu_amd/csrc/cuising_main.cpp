@@ -87,22 +87,16 @@ struct Ring {
 	int n() const { return (int)ctx.size(); }
 
 	void count(unsigned long long *up, unsigned long long *dw) {
-		*up = *dw = 0;
-		for (ising_ctx *c : ctx) {
-			uint64_t u = 0, d = 0;
-			CHECK(ising_count(c, &u, &d));
-			*up += u; *dw += d;
-		}
+		uint64_t u = 0, d = 0;
+		CHECK(ising_ring_count(ctx.data(), n(), &u, &d));
+		*up = u; *dw = d;
 	}
-	double energy(size_t nspins) {
-		long long A = 0;
-		for (ising_ctx *c : ctx) {
-			int64_t a = 0;
-			CHECK(ising_bond_equal(c, &a));
-			A += a;
-		}
-		return -(2.0 * (double)A - 2.0 * (double)nspins) / (double)nspins;
+	long long bond_equal() {
+		int64_t A = 0;
+		CHECK(ising_ring_bond_equal(ctx.data(), n(), &A));
+		return A;
 	}
+	double energy(size_t nspins) { return -(2.0 * (double)bond_equal() - 2.0 * (double)nspins) / (double)nspins; }
 	void dump(const char *prefix) {
 		for (ising_ctx *c : ctx) CHECK(ising_dump_text(c, prefix));
 	}

@@ -1,10 +1,7 @@
 // ising_capi.cpp -- the C-ABI of libising_hip.so (see include/ising_hip.h for the reference file:line each
 // entry point replaces).  Host side only: owns device memory, tables and launch order; all arithmetic on the
 // lattice happens in ising_kernels.hip.
-#include "../../include/ising_hip.h"
-#include "ising_kernels.h"
-
-#include <hip/hip_runtime_api.h>
+#include "ising_ctx.hpp"
 
 #include <cmath>
 #include <cstdarg>
@@ -15,8 +12,10 @@
 #include <vector>
 
 namespace {
-
 thread_local std::string g_err;
+}
+
+namespace ising_host {
 
 int fail(int code, const char *fmt, ...) {
 	char buf[512];
@@ -28,11 +27,17 @@ int fail(int code, const char *fmt, ...) {
 	return code;
 }
 
-#define HIP_TRY(expr)                                                                                       \
-	do {                                                                                                    \
-		hipError_t e_ = (expr);                                                                             \
-		if (e_ != hipSuccess) return fail(ISING_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-	} while (0)
+int bind(const ising_ctx *c) {
+	HIP_TRY(hipSetDevice(c->cfg.device));
+	return ISING_OK;
+}
+
+} // namespace ising_host
+
+using ising_host::bind;
+using ising_host::fail;
+
+namespace {
 
 // cuRAND's curand_uniform on the host: x*2^-32 + 2^-33 in FP32 (product exact, one rounding).
 inline float u01(uint32_t x) { return (float)x * 0x1p-32f + 0x1p-33f; }
@@ -52,60 +57,6 @@ uint64_t draw_prefix(float p, bool le) {
 	return hi;
 }
 
-} // namespace
-
-struct ising_ctx {
-	ising_config cfg{};
-	bool dense = false; // 1 bit per spin on the device (ising_dense.hip); false = the reference's nibble layout
-	bool ballot = false; // dense, with the bits of a row in wave-ballot order (ising_ballot.hip)
-	uint64_t *d_tmp = nullptr;     // ballot layout: dense-order image of d_lat (same shape) for conversions and observables;
-	                               // allocated by the first call that needs it (sweeping and counting never do)
-	uint64_t *d_scratch = nullptr; // ballot layout: accept-mask slots, 2 KiB per wave of the largest launch
-	int lld_packed = 0; // 64-bit words per colour row in the reference's packed layout (X/32)
-	int lld = 0;      // 64-bit words per colour row in the DEVICE layout (X/32 nibble, X/128 dense)
-	int gx = 0;       // X/2048
-	int H = 0;        // rows per strip
-	int nstrips = 0;
-	size_t color_words = 0;
-	uint64_t *d_lat = nullptr;          // [2 colours][Y + 2 rows][lld]: row -1 and row Y of each colour are halo rows
-	uint64_t *d_ham = nullptr;          // -J: [hamB, hamW], [Y + 2 rows][lld_packed] each (4 bits per site in both layouts)
-	int ham_form = 0;                   // 0: nibbles as generated; 1: per-vector bit-planes (dense); 2: ballot-order planes
-	unsigned long long *d_acc = nullptr; // 2 counters
-	uint32_t *d_bits = nullptr;          // correlations: (Y + d_bits_extra) x lld words, one bit per spin
-	int d_bits_extra = 0;
-	long long *d_corr = nullptr;         // correlations: 128 sums
-	uint8_t *d_lut = nullptr;            // 64 KiB accept-rank table (see build_rank_table)
-	bool lut_dirty = true;
-	float tab[10]{};
-	uint64_t thr[5]{};
-	bool fast_ok = false;
-	hipStream_t stream = nullptr;
-	hipEvent_t ev_sent[2] = {nullptr, nullptr}; // ring mode: "my boundary rows of colour c have been copied out"
-	bool peers_enabled = false;                  // ring mode: direct xGMI copies to the neighbours' devices
-
-	// Row 0 of a colour.  The halo rows sit directly above (row -1: global row slab*Y-1) and below (row Y) so the
-	// kernels address rows -1..Y uniformly.  With one slab they mirror the slab's own last / first row (periodic
-	// wrap, maintained by the kernels that write edge rows); with several slabs the neighbours' rows are delivered
-	// into them (ising_halo_ptrs / ising_ring_exchange).
-	uint64_t *lat(int color) const { return d_lat + (size_t)color * (color_words + 2 * (size_t)lld) + lld; }
-	uint64_t *halo(int color, int which) const { return which == 0 ? lat(color) - lld : lat(color) + color_words; }
-	size_t alloc_words() const { return 2 * (color_words + 2 * (size_t)lld); }
-	uint64_t *tmp(int color) const { return d_tmp + (size_t)color * (color_words + 2 * (size_t)lld) + lld; }
-	size_t ham_words() const { return (size_t)cfg.Y * lld_packed; } // per coupling array, without its two halo rows
-	size_t ham_alloc_words() const { return 2 * (ham_words() + 2 * (size_t)lld_packed); }
-	uint64_t *ham(int which) const { return d_ham + (size_t)which * (ham_words() + 2 * (size_t)lld_packed) + lld_packed; }
-	// "colour" 0/1 = spin arrays, 2 = black couplings; row stride and row count-words of that array
-	uint64_t *plane(int kind) const { return kind == ISING_HAM_BLACK ? ham(0) : lat(kind); }
-	int plane_ld(int kind) const { return kind == ISING_HAM_BLACK ? lld_packed : lld; }
-};
-
-namespace {
-
-int bind(const ising_ctx *c) {
-	HIP_TRY(hipSetDevice(c->cfg.device));
-	return ISING_OK;
-}
-
 // ballot layout: the dense-order image is allocated by the first call that needs one
 int ballot_tmp(ising_ctx *c) {
 	if (!c->d_tmp) HIP_TRY(hipMalloc((void **)&c->d_tmp, c->alloc_words() * sizeof(uint64_t)));
@@ -121,16 +72,19 @@ int ballot_rows(ising_ctx *c, int color, long long row_lo, long long row_hi, boo
 	return ISING_OK;
 }
 
+} // namespace
+
 // ballot layout: refresh the dense-order image (both colours, halo rows included)
-int ballot_image(ising_ctx *c) {
+int ising_host::ballot_image(ising_ctx *c) {
 	for (int color = 0; color < 2; color++)
 		if (int rc = ballot_rows(c, color, -1, (long long)c->cfg.Y + 1, true)) return rc;
 	return ISING_OK;
 }
 
 // ballot -> dense for good (a temperature without integer thresholds was requested): the slab keeps its buffer
-int ballot_leave(ising_ctx *c) {
-	if (int rc = ballot_image(c)) return rc;
+int ising_host::ballot_leave(ising_ctx *c) {
+	if (!c->ballot) return ISING_OK;
+	if (int rc = ising_host::ballot_image(c)) return rc;
 	HIP_TRY(hipMemcpyAsync(c->d_lat, c->d_tmp, c->alloc_words() * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
 	if (c->ham_form == 2) {
 		for (int w = 0; w < 2; w++) HIP_TRY(ising::launch_ham_ballot_to_planes(c->ham(w), c->gx, c->cfg.Y, c->stream));
@@ -139,6 +93,12 @@ int ballot_leave(ising_ctx *c) {
 	c->ballot = false;
 	return ISING_OK;
 }
+
+bool ising_host::needs_generic(const ising_ctx *c) {
+	return c->cfg.kernel == ISING_KERNEL_GENERIC || (c->cfg.kernel == ISING_KERNEL_AUTO && !c->fast_ok);
+}
+
+namespace {
 
 // exp table exactly as optimized/main.cu:1684-1697 evaluates it (FP32, left to right), then the integer
 // thresholds per number of aligned neighbours.
@@ -290,6 +250,28 @@ size_t ising_required_bytes(int32_t X, int32_t Y) {
 	return 2 * ((size_t)Y + 2) * (size_t)(X / 32) * sizeof(uint64_t);
 }
 
+size_t ising_required_bytes_layout(int32_t X, int32_t Y, int32_t layout) {
+	const size_t full = ising_required_bytes(X, Y);
+	return layout == ISING_LAYOUT_NIBBLE ? full : full / 4;
+}
+
+// A caller-owned buffer must be device memory of the slab's device and, when the caller states its size, large enough.
+static int check_caller_buffer(const void *ptr, size_t have, size_t need, int device, const char *what) {
+	hipPointerAttribute_t attr;
+	memset(&attr, 0, sizeof(attr));
+	const hipError_t e = hipPointerGetAttributes(&attr, ptr);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		return fail(ISING_E_ARG, "%s (%p) is not a HIP allocation: %s", what, ptr, hipGetErrorString(e));
+	}
+	if (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged)
+		return fail(ISING_E_ARG, "%s (%p) is not device memory", what, ptr);
+	if (attr.type == hipMemoryTypeDevice && attr.device != device)
+		return fail(ISING_E_ARG, "%s (%p) lives on device %d, the slab on device %d", what, ptr, attr.device, device);
+	if (have && have < need) return fail(ISING_E_ARG, "%s holds %zu bytes, the slab needs %zu", what, have, need);
+	return ISING_OK;
+}
+
 int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (!cfg || !out) return fail(ISING_E_ARG, "null argument");
 	*out = nullptr;
@@ -332,18 +314,25 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// AUTO: the ballot kernel's two-phase row pipeline wins from ~1e8 spins per slab up (8192^2: dense 5 % ahead)
 	if (cfg->layout == ISING_LAYOUT_AUTO && ballot_ok && c->fast_ok && (long long)cfg->X * cfg->Y >= (1LL << 27) && !getenv("ISING_NO_BALLOT"))
 		c->ballot = true;
+	c->wrap = cfg->nslabs == 1 && !cfg->ring_halo;
 	c->H = cfg->strip_rows > 0 ? cfg->strip_rows : choose_strip_rows(c->gx, cfg->Y, c->dense, c->ballot);
 	if (cfg->Y % c->H) { const int h = c->H; delete c; return fail(ISING_E_ARG, "strip_rows %d does not divide Y %d", h, cfg->Y); }
 	c->nstrips = cfg->Y / c->H;
 	c->color_words = (size_t)cfg->Y * c->lld;
 
 	hipError_t e = hipSetDevice(cfg->device);
+	if (e == hipSuccess && cfg->lattice_mem) {
+		if (int rc = check_caller_buffer(cfg->lattice_mem, cfg->lattice_mem_bytes, c->alloc_words() * sizeof(uint64_t), cfg->device, "lattice_mem")) { delete c; return rc; }
+	}
+	if (e == hipSuccess && cfg->use_J && cfg->coupling_mem) {
+		if (int rc = check_caller_buffer(cfg->coupling_mem, cfg->coupling_mem_bytes, c->ham_alloc_words() * sizeof(uint64_t), cfg->device, "coupling_mem")) { delete c; return rc; }
+	}
 	if (e == hipSuccess) {
 		if (cfg->lattice_mem) c->d_lat = static_cast<uint64_t *>(cfg->lattice_mem);
 		else e = hipMalloc((void **)&c->d_lat, c->alloc_words() * sizeof(uint64_t));
 	}
 	if (e == hipSuccess) e = hipMemset(c->d_lat, 0, c->alloc_words() * sizeof(uint64_t)); // optimized/main.cu:1603
-	if (e == hipSuccess) e = hipMalloc((void **)&c->d_acc, 2 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMalloc((void **)&c->d_acc, 4 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMalloc((void **)&c->d_lut, 65536);
 	if (e == hipSuccess && c->ballot) e = hipMalloc((void **)&c->d_scratch, (size_t)(c->gx / 4) * (c->nstrips + 2) * 2048);
 	if (e == hipSuccess && cfg->use_J) {
@@ -363,6 +352,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 int ising_destroy(ising_ctx *c) {
 	if (!c) return ISING_OK;
 	(void)hipSetDevice(c->cfg.device);
+	ising_host::ring_release(c);
 	if (c->d_lat && !c->cfg.lattice_mem) (void)hipFree(c->d_lat);
 	if (c->d_acc) (void)hipFree(c->d_acc);
 	if (c->d_lut) (void)hipFree(c->d_lut);
@@ -371,7 +361,8 @@ int ising_destroy(ising_ctx *c) {
 	if (c->d_ham && !c->cfg.coupling_mem) (void)hipFree(c->d_ham);
 	if (c->d_bits) (void)hipFree(c->d_bits);
 	if (c->d_corr) (void)hipFree(c->d_corr);
-	for (int k = 0; k < 2; k++) if (c->ev_sent[k]) (void)hipEventDestroy(c->ev_sent[k]);
+	if (c->d_slotctl) (void)hipFree(c->d_slotctl);
+	if (c->d_pack) (void)hipFree(c->d_pack);
 	delete c;
 	return ISING_OK;
 }
@@ -402,7 +393,7 @@ int ising_init_lattice(ising_ctx *c) {
 		p.gx = c->gx;
 		p.Y = c->cfg.Y;
 		p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
-		p.wrap = c->cfg.nslabs == 1;
+		p.wrap = c->wrap;
 		p.thr_half = (uint32_t)half;
 		HIP_TRY(c->ballot ? ising::launch_ballot_init(p, c->stream) : (c->dense ? ising::launch_dense_init(p, c->stream) : ising::launch_init(p, c->stream)));
 	}
@@ -439,7 +430,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 		mode = 1;
 	}
 	if (int rc = bind(c)) return rc;
-	if (c->ballot && mode == 1) if (int rc = ballot_leave(c)) return rc; // no integer thresholds at this temperature
+	if (c->ballot && mode == 1) if (int rc = ising_host::ballot_leave(c)) return rc; // no integer thresholds at this temperature
 	if (mode == 2 && c->lut_dirty) {
 		std::vector<uint8_t> tab(65536);
 		build_rank_table(c, tab.data());
@@ -451,7 +442,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	ising::UpdateParams p{};
 	p.dst = c->lat(color);
 	p.src = c->lat(other);
-	p.wrap = c->cfg.nslabs == 1; // periodic wrap of loadTile (optimized/main.cu:414,:422) through mirrored halo rows
+	p.wrap = c->wrap; // periodic wrap of loadTile (optimized/main.cu:414,:422) through mirrored halo rows
 	p.seed_lo = (uint32_t)c->cfg.seed;
 	p.seed_hi = (uint32_t)(c->cfg.seed >> 32);
 	p.it = (uint32_t)it;
@@ -498,7 +489,7 @@ int ising_update_edges(ising_ctx *c, int it, int color) {
 
 int ising_sweep(ising_ctx *c, int first_it, int nsweeps) {
 	if (!c) return fail(ISING_E_ARG, "null context");
-	if (c->cfg.nslabs != 1) return fail(ISING_E_STATE, "ising_sweep needs nslabs == 1; drive slabs with ising_update_color + halo exchange");
+	if (!c->wrap) return fail(ISING_E_STATE, "ising_sweep needs a single slab without ring halo rows; drive slabs with ising_ring_sweep / ising_rank_sweep or ising_update_color + halo exchange");
 	for (int it = first_it; it < first_it + nsweeps; it++) {
 		if (int rc = ising_update_color(c, it, ISING_BLACK, 0, c->cfg.Y)) return rc;
 		if (int rc = ising_update_color(c, it, ISING_WHITE, 0, c->cfg.Y)) return rc;
@@ -529,7 +520,7 @@ int ising_halo_ptrs(ising_ctx *c, int color, void **send_top, void **send_bot, v
 	if (!c) return fail(ISING_E_ARG, "null context");
 	if (color != ISING_BLACK && color != ISING_WHITE && color != ISING_HAM_BLACK) return fail(ISING_E_ARG, "bad colour %d", color);
 	if (color == ISING_HAM_BLACK && !c->cfg.use_J) return fail(ISING_E_STATE, "couplings are not enabled (use_J)");
-	if (c->cfg.nslabs == 1) return fail(ISING_E_STATE, "no halo buffers with nslabs == 1 (rows wrap inside the slab)");
+	if (c->wrap) return fail(ISING_E_STATE, "no halo buffers with nslabs == 1 (rows wrap inside the slab)");
 	uint64_t *base = c->plane(color);
 	const size_t ld = (size_t)c->plane_ld(color);
 	if (send_top) *send_top = base;
@@ -557,7 +548,8 @@ int ising_count(ising_ctx *c, uint64_t *up, uint64_t *down) {
 int ising_bond_equal(ising_ctx *c, int64_t *A) {
 	if (!c || !A) return fail(ISING_E_ARG, "null argument");
 	if (int rc = bind(c)) return rc;
-	if (c->ballot) if (int rc = ballot_image(c)) return rc;
+	if (int rc = ising_host::halo_ready(c, ISING_WHITE)) return rc; // black sites of rows 0 / Y-1 read the white halo rows
+	if (c->ballot) if (int rc = ising_host::ballot_image(c)) return rc;
 	ising::BondParams p{};
 	p.black = c->ballot ? c->tmp(ISING_BLACK) : c->lat(ISING_BLACK);
 	p.white = c->ballot ? c->tmp(ISING_WHITE) : c->lat(ISING_WHITE);
@@ -617,7 +609,7 @@ int ising_write_packed(ising_ctx *c, int color, int64_t row0, int64_t nrows, con
 	HIP_TRY(hipMemcpyAsync(img + (size_t)row0 * c->lld, src, (size_t)nrows * row_bytes, hipMemcpyHostToDevice, c->stream));
 	if (c->ballot) if (int rc = ballot_rows(c, color, row0, row0 + nrows, false)) return rc;
 	// single slab: the halo rows mirror the opposite edge rows
-	if (c->cfg.nslabs == 1 && nrows > 0) {
+	if (c->wrap && nrows > 0) {
 		const char *b = static_cast<const char *>(src);
 		if (row0 == 0) {
 			HIP_TRY(hipMemcpyAsync(img + c->color_words, b, row_bytes, hipMemcpyHostToDevice, c->stream));
@@ -691,7 +683,7 @@ int ising_init_couplings_black(ising_ctx *c) {
 	p.gx = c->gx;
 	p.Y = c->cfg.Y;
 	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
-	p.wrap = c->cfg.nslabs == 1;
+	p.wrap = c->wrap;
 	const uint64_t thr = draw_prefix(prob, false); // curand_uniform(x) < tgtProb, :193
 	if (thr >= (1ull << 32)) return fail(ISING_E_ARG, "J probability %g sets every bit", (double)prob); // unreachable: u <= 1 and prob <= 1 gives at most 2^32 - 1... see below
 	p.thr = (uint32_t)thr;
@@ -713,7 +705,7 @@ int ising_init_couplings_white(ising_ctx *c) {
 	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
 	p.slW = c->cfg.XSL ? c->cfg.XSL / 32 : c->lld_packed;
 	p.slY = c->cfg.XSL ? c->cfg.YSL : 0;
-	p.wrap = c->cfg.nslabs == 1;
+	p.wrap = c->wrap;
 	HIP_TRY(ising::launch_ham_init_white(p, c->stream));
 	if (c->ballot) {
 		// the ballot update reads four planes of ballot-order coupling words per row and wave column
@@ -729,7 +721,7 @@ int ising_init_couplings_white(ising_ctx *c) {
 
 int ising_init_couplings(ising_ctx *c) {
 	if (!c) return fail(ISING_E_ARG, "null context");
-	if (c->cfg.nslabs != 1 && !c->cfg.XSL) return fail(ISING_E_STATE, "ising_init_couplings needs nslabs == 1; use the _black/_white pair around a halo exchange");
+	if (!c->wrap && !c->cfg.XSL) return fail(ISING_E_STATE, "ising_init_couplings needs nslabs == 1; use the _black/_white pair around a halo exchange");
 	if (int rc = ising_init_couplings_black(c)) return rc;
 	return ising_init_couplings_white(c);
 }
@@ -744,166 +736,6 @@ int ising_read_couplings(ising_ctx *c, int which, int64_t row0, int64_t nrows, u
 	if (c->ham_form == 2) ballot_planes_to_planes(dst_host, nw / 256);
 	if (c->ham_form) planes_to_nibbles(dst_host, nw / 2);
 	return ISING_OK;
-}
-
-// ------------------------------------------------------------------------------------------------ ring mode
-static int ring_check(ising_ctx **ctxs, int n) {
-	if (!ctxs || n < 1) return fail(ISING_E_ARG, "bad ring");
-	for (int k = 0; k < n; k++) {
-		if (!ctxs[k]) return fail(ISING_E_ARG, "ring slot %d is null", k);
-		if (ctxs[k]->cfg.nslabs != n || ctxs[k]->cfg.slab != k) return fail(ISING_E_ARG, "ring slot %d holds slab %d of %d", k, ctxs[k]->cfg.slab, ctxs[k]->cfg.nslabs);
-		if (ctxs[k]->lld != ctxs[0]->lld || ctxs[k]->cfg.Y != ctxs[0]->cfg.Y) return fail(ISING_E_ARG, "ring slabs differ in shape");
-	}
-	return ISING_OK;
-}
-
-// The reference requires and enables all-to-all peer access (optimized/main.cu:1507-1537); a ring only needs the two
-// neighbours.  Failure to enable is not fatal: hipMemcpyPeerAsync then stages through the host.
-static void ring_enable_peers(ising_ctx *c, const ising_ctx *prev, const ising_ctx *next) {
-	if (c->peers_enabled) return;
-	c->peers_enabled = true;
-	if (hipSetDevice(c->cfg.device) != hipSuccess) return;
-	const int peers[2] = {prev->cfg.device, next->cfg.device};
-	for (int k = 0; k < 2; k++) {
-		if (peers[k] == c->cfg.device || (k == 1 && peers[1] == peers[0])) continue;
-		int can = 0;
-		if (hipDeviceCanAccessPeer(&can, c->cfg.device, peers[k]) == hipSuccess && can) {
-			const hipError_t e = hipDeviceEnablePeerAccess(peers[k], 0);
-			if (e != hipSuccess) (void)hipGetLastError(); // already enabled or unsupported: fall back silently
-		}
-	}
-}
-
-static int ring_events(ising_ctx *c) {
-	for (int k = 0; k < 2; k++) {
-		if (!c->ev_sent[k]) {
-			if (int rc = bind(c)) return rc;
-			HIP_TRY(hipEventCreateWithFlags(&c->ev_sent[k], hipEventDisableTiming));
-		}
-	}
-	return ISING_OK;
-}
-
-// copies out slab k's first/last row of `color` and records ev_sent[color] on its stream
-static int ring_send(ising_ctx **ctxs, int n, int k, int color) {
-	ising_ctx *c = ctxs[k], *prev = ctxs[(k + n - 1) % n], *next = ctxs[(k + 1) % n];
-	if (c->cfg.XSL) return ISING_OK; // sub-lattices never reach across slabs
-	const size_t ld = (size_t)c->plane_ld(color), nb = ld * sizeof(uint64_t);
-	if (int rc = ring_events(c)) return rc;
-	ring_enable_peers(c, prev, next);
-	if (int rc = bind(c)) return rc;
-	// next slab's top halo <- my last row ; previous slab's bottom halo <- my first row
-	HIP_TRY(hipMemcpyPeerAsync(next->plane(color) - ld, next->cfg.device, c->plane(color) + (size_t)(c->cfg.Y - 1) * ld, c->cfg.device, nb, c->stream));
-	HIP_TRY(hipMemcpyPeerAsync(prev->plane(color) + (size_t)prev->cfg.Y * ld, prev->cfg.device, c->plane(color), c->cfg.device, nb, c->stream));
-	if (color != ISING_HAM_BLACK) HIP_TRY(hipEventRecord(c->ev_sent[color], c->stream));
-	return ISING_OK;
-}
-
-// slab k's stream waits until both neighbours have delivered their rows of `color`
-static int ring_wait(ising_ctx **ctxs, int n, int k, int color) {
-	ising_ctx *c = ctxs[k], *prev = ctxs[(k + n - 1) % n], *next = ctxs[(k + 1) % n];
-	if (int rc = bind(c)) return rc;
-	if (prev->ev_sent[color]) HIP_TRY(hipStreamWaitEvent(c->stream, prev->ev_sent[color], 0));
-	if (next != prev && next->ev_sent[color]) HIP_TRY(hipStreamWaitEvent(c->stream, next->ev_sent[color], 0));
-	return ISING_OK;
-}
-
-int ising_ring_exchange(ising_ctx **ctxs, int n, int color) {
-	if (int rc = ring_check(ctxs, n)) return rc;
-	if (color != ISING_BLACK && color != ISING_WHITE && color != ISING_HAM_BLACK) return fail(ISING_E_ARG, "bad colour %d", color);
-	if (n == 1) return ISING_OK;
-	for (int k = 0; k < n; k++) if (int rc = ring_send(ctxs, n, k, color)) return rc;
-	return ISING_OK;
-}
-
-int ising_ring_sweep(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
-	if (int rc = ring_check(ctxs, n)) return rc;
-	if (n == 1) return ising_sweep(ctxs[0], first_it, nsweeps);
-	for (int it = first_it; it < first_it + nsweeps; it++) {
-		for (int color = 0; color < 2; color++) {
-			for (int k = 0; k < n; k++) {
-				ising_ctx *c = ctxs[k];
-				if (int rc = ring_wait(ctxs, n, k, 1 - color)) return rc; // halo rows of the source colour
-				if (int rc = ising_update_edges(c, it, color)) return rc;
-				if (int rc = ring_send(ctxs, n, k, color)) return rc;
-				if (int rc = ising_update_color(c, it, color, 1, c->cfg.Y - 1)) return rc;
-			}
-		}
-	}
-	return ISING_OK;
-}
-
-int ising_ring_init_couplings(ising_ctx **ctxs, int n) {
-	if (int rc = ring_check(ctxs, n)) return rc;
-	for (int k = 0; k < n; k++) if (int rc = ising_init_couplings_black(ctxs[k])) return rc;
-	if (n > 1 && !ctxs[0]->cfg.XSL) {
-		for (int k = 0; k < n; k++) if (int rc = ring_send(ctxs, n, k, ISING_HAM_BLACK)) return rc;
-		// the copies run on the senders' streams: make every slab's stream wait for both of its neighbours
-		for (int k = 0; k < n; k++) if (int rc = ising_synchronize(ctxs[k])) return rc;
-	}
-	for (int k = 0; k < n; k++) if (int rc = ising_init_couplings_white(ctxs[k])) return rc;
-	return ISING_OK;
-}
-
-int ising_ring_synchronize(ising_ctx **ctxs, int n) {
-	if (int rc = ring_check(ctxs, n)) return rc;
-	for (int k = 0; k < n; k++) if (int rc = ising_synchronize(ctxs[k])) return rc;
-	return ISING_OK;
-}
-
-// ------------------------------------------------------------------------------------------------ correlations
-int ising_ring_correlations(ising_ctx **ctxs, int n, int ncorr, int64_t *sums) {
-	if (int rc = ring_check(ctxs, n)) return rc;
-	if (!sums || ncorr < 1 || ncorr > 128) return fail(ISING_E_ARG, "ncorr must be in [1,128]");
-	for (int k = 0; k < n; k++) {
-		ising_ctx *c = ctxs[k];
-		if (c->cfg.XSL && c->cfg.YSL < ncorr) return fail(ISING_E_ARG, "sub-lattices need at least %d rows for %d correlation distances", ncorr, ncorr);
-		if (c->cfg.Y < ncorr) return fail(ISING_E_ARG, "each slab needs at least %d rows for %d correlation distances", ncorr, ncorr);
-		if (int rc = bind(c)) return rc;
-		if (!c->d_bits || c->d_bits_extra < ncorr) {
-			if (c->d_bits) HIP_TRY(hipFree(c->d_bits));
-			c->d_bits = nullptr;
-			HIP_TRY(hipMalloc((void **)&c->d_bits, (size_t)(c->cfg.Y + 128) * c->lld_packed * sizeof(uint32_t)));
-			c->d_bits_extra = 128;
-		}
-		if (!c->d_corr) HIP_TRY(hipMalloc((void **)&c->d_corr, 128 * sizeof(long long)));
-		// bit matrix: X bits = lld_packed 32-bit words per row
-		if (c->ballot) if (int rc = ballot_image(c)) return rc;
-		if (c->ballot) HIP_TRY(ising::launch_dense_pack_bits(c->tmp(ISING_BLACK), c->tmp(ISING_WHITE), c->gx * 32, c->cfg.Y,
-		                                                     (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y, c->d_bits, c->stream));
-		else if (c->dense) HIP_TRY(ising::launch_dense_pack_bits(c->lat(ISING_BLACK), c->lat(ISING_WHITE), c->gx * 32, c->cfg.Y,
-		                                                    (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y, c->d_bits, c->stream));
-		else HIP_TRY(ising::launch_pack_bits(c->lat(ISING_BLACK), c->lat(ISING_WHITE), c->lld_packed, c->cfg.Y,
-		                                     (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y, c->d_bits, c->stream));
-		HIP_TRY(hipMemsetAsync(c->d_corr, 0, 128 * sizeof(long long), c->stream));
-	}
-	for (int k = 0; k < n; k++) if (int rc = ising_synchronize(ctxs[k])) return rc;
-	// rows that follow slab k (vertical partners of its last ncorr rows): the first ncorr bit-rows of slab k+1
-	for (int k = 0; k < n; k++) {
-		ising_ctx *c = ctxs[k], *next = ctxs[(k + 1) % n];
-		if (int rc = bind(c)) return rc;
-		if (!c->cfg.XSL) // sub-lattices never look past their own rows
-			HIP_TRY(hipMemcpyPeerAsync(c->d_bits + (size_t)c->cfg.Y * c->lld_packed, c->cfg.device, next->d_bits, next->cfg.device,
-			                           (size_t)ncorr * c->lld_packed * sizeof(uint32_t), c->stream));
-		HIP_TRY(ising::launch_corr(c->d_bits, c->lld_packed, c->cfg.Y, ncorr, c->cfg.XSL ? c->cfg.XSL / 32 : c->lld_packed,
-		                           c->cfg.XSL ? c->cfg.YSL : 0, c->d_corr, c->stream));
-	}
-	std::vector<long long> h(ncorr);
-	for (int j = 0; j < ncorr; j++) sums[j] = 0;
-	for (int k = 0; k < n; k++) {
-		ising_ctx *c = ctxs[k];
-		if (int rc = bind(c)) return rc;
-		HIP_TRY(hipMemcpyAsync(h.data(), c->d_corr, (size_t)ncorr * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
-		HIP_TRY(hipStreamSynchronize(c->stream));
-		for (int j = 0; j < ncorr; j++) sums[j] += h[j];
-	}
-	return ISING_OK;
-}
-
-int ising_correlations(ising_ctx *c, int ncorr, int64_t *sums) {
-	if (!c) return fail(ISING_E_ARG, "null context");
-	if (c->cfg.nslabs != 1) return fail(ISING_E_STATE, "ising_correlations needs nslabs == 1; use ising_ring_correlations");
-	return ising_ring_correlations(&c, 1, ncorr, sums);
 }
 
 } // extern "C"

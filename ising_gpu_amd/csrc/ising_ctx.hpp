@@ -1,0 +1,98 @@
+// ising_ctx.hpp -- the context object behind the C-ABI handle and the helpers the host-side translation units of
+// libising_hip.so share (ising_capi.cpp: slab life cycle, updates, observables, boundary formats; ising_ring.cpp: the
+// slab ring and its transports).  Internal to the library.
+#pragma once
+#include "../../include/ising_hip.h"
+#include "ising_kernels.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+
+struct ising_ctx {
+	ising_config cfg{};
+	bool dense = false; // 1 bit per spin on the device (ising_dense.hip); false = the reference's nibble layout
+	bool ballot = false; // dense, with the bits of a row in wave-ballot order (ising_ballot.hip)
+	uint64_t *d_tmp = nullptr;     // ballot layout: dense-order image of d_lat (same shape) for conversions and observables;
+	                               // allocated by the first call that needs it (sweeping and counting never do)
+	uint64_t *d_scratch = nullptr; // ballot layout: accept-mask slots of the update kernel (see ising_ballot.hip)
+	uint32_t *d_slotctl = nullptr; // ballot layout: slot tickets and busy flags
+	uint64_t *d_pack = nullptr;    // staging for device-side conversion to / from the packed boundary format
+	size_t pack_words = 0;
+	int lld_packed = 0; // 64-bit words per colour row in the reference's packed layout (X/32)
+	int lld = 0;      // 64-bit words per colour row in the DEVICE layout (X/32 nibble, X/128 dense)
+	int gx = 0;       // X/2048
+	int H = 0;        // rows per strip
+	int nstrips = 0;
+	size_t color_words = 0;
+	uint64_t *d_lat = nullptr;          // [2 colours][Y + 2 rows][lld]: row -1 and row Y of each colour are halo rows
+	uint64_t *d_ham = nullptr;          // -J: [hamB, hamW], [Y + 2 rows][lld_packed] each (4 bits per site in both layouts)
+	int ham_form = 0;                   // 0: nibbles as generated; 1: per-vector bit-planes (dense); 2: ballot-order planes
+	unsigned long long *d_acc = nullptr; // counters: [0] up spins, [1] bond-equal, [2..3] all-reduce staging
+	uint32_t *d_bits = nullptr;          // correlations: (Y + d_bits_extra) x lld words, one bit per spin
+	int d_bits_extra = 0;
+	long long *d_corr = nullptr;         // correlations: 128 sums
+	uint8_t *d_lut = nullptr;            // 64 KiB accept-rank table (see build_rank_table)
+	bool lut_dirty = true;
+	float tab[10]{};
+	uint64_t thr[5]{};
+	bool fast_ok = false;
+	hipStream_t stream = nullptr;
+
+	// ---- ring state (ising_ring.cpp).  The halo rows of colour c travel on `comm`, a second stream per slab:
+	//   compute: [wait: halo rows of 1-c have arrived] edge rows of c -> record ev_edge[c] -> interior rows of c
+	//   comm:    wait ev_edge[c] -> deliver my first/last row of c (peer copies, or RCCL send/recv) -> record ev_sent[c]
+	bool wrap = true;                            // rows -1 / Y mirror the slab's own edge rows (a single slab that is not a ring)
+	hipStream_t comm = nullptr;
+	hipEvent_t ev_edge[2] = {nullptr, nullptr};
+	hipEvent_t ev_sent[2] = {nullptr, nullptr};
+	int transport = 0;                           // ISING_TRANSPORT_* in use (0 = not decided yet)
+	ising_ctx *ring_prev = nullptr, *ring_next = nullptr; // neighbours in a single-process ring
+	void *rccl_comm = nullptr;                   // ncclComm_t of this slab's rank
+	bool rccl_owner = false;                     // the communicator was created for this context (destroy it with the context)
+	bool rank_mode = false;                      // one slab per process: the neighbours live in other processes
+	bool peers_enabled = false;
+
+	// Row 0 of a colour.  The halo rows sit directly above (row -1: global row slab*Y-1) and below (row Y) so the
+	// kernels address rows -1..Y uniformly.  With one slab they mirror the slab's own last / first row (periodic
+	// wrap, maintained by the kernels that write edge rows); with several slabs the neighbours' rows are delivered
+	// into them (ising_halo_ptrs / ising_ring_exchange).
+	uint64_t *lat(int color) const { return d_lat + (size_t)color * (color_words + 2 * (size_t)lld) + lld; }
+	uint64_t *halo(int color, int which) const { return which == 0 ? lat(color) - lld : lat(color) + color_words; }
+	size_t alloc_words() const { return 2 * (color_words + 2 * (size_t)lld); }
+	uint64_t *tmp(int color) const { return d_tmp + (size_t)color * (color_words + 2 * (size_t)lld) + lld; }
+	size_t ham_words() const { return (size_t)cfg.Y * lld_packed; } // per coupling array, without its two halo rows
+	size_t ham_alloc_words() const { return 2 * (ham_words() + 2 * (size_t)lld_packed); }
+	uint64_t *ham(int which) const { return d_ham + (size_t)which * (ham_words() + 2 * (size_t)lld_packed) + lld_packed; }
+	// "colour" 0/1 = spin arrays, 2 = black couplings; row stride and row count-words of that array
+	uint64_t *plane(int kind) const { return kind == ISING_HAM_BLACK ? ham(0) : lat(kind); }
+	int plane_ld(int kind) const { return kind == ISING_HAM_BLACK ? lld_packed : lld; }
+	int layout() const { return ballot ? ISING_LAYOUT_BALLOT : (dense ? ISING_LAYOUT_DENSE : ISING_LAYOUT_NIBBLE); }
+};
+
+namespace ising_host {
+
+// records the message for ising_last_error() and returns `code`
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIP_TRY(expr)                                                                                       \
+	do {                                                                                                    \
+		hipError_t e_ = (expr);                                                                             \
+		if (e_ != hipSuccess) return ising_host::fail(ISING_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+	} while (0)
+
+int bind(const ising_ctx *c); // hipSetDevice(c->cfg.device)
+
+// true when the next update of this slab cannot use the integer-threshold kernels (and a ballot slab turns dense)
+bool needs_generic(const ising_ctx *c);
+// ballot -> dense for good, on the slab's stream
+int ballot_leave(ising_ctx *c);
+// ballot layout: refresh the dense-order image d_tmp (both colours, halo rows included)
+int ballot_image(ising_ctx *c);
+// makes the slab's stream wait until the halo rows of `color` delivered by the ring are in place
+int halo_ready(ising_ctx *c, int color);
+// called by ising_destroy
+void ring_release(ising_ctx *c);
+
+} // namespace ising_host

@@ -1,0 +1,640 @@
+// ising_ring.cpp -- the slab ring: 1-D slabs along Y, periodic, one row of each colour to each neighbour per colour
+// half-sweep.  Replaces the reference's multi-GPU mechanism -- one managed allocation, remote loads of the
+// two rows outside each slab, cudaDeviceSynchronize on every device after each colour (optimized/main.cu:1599-1658,
+// loadTile :413-428, barriers :1779-1784 / :1800-1805) -- with explicit halo rows delivered on a SECOND stream per slab
+// while the interior rows are being updated:
+//
+//   compute stream of slab k                              comm stream of slab k
+//   ------------------------                              ---------------------
+//   wait: halo rows of colour 1-c are in place
+//   update rows 0 and Y-1 of colour c   (tiny launch)
+//   record ev_edge[c]  ------------------------------->   wait ev_edge[c]
+//   update rows 1 .. Y-2 of colour c    (the launch)       first row -> previous slab's bottom halo row
+//                                                          last row  -> next slab's top halo row
+//                                                          record ev_sent[c]
+//
+// Two transports move the rows:
+//   RCCL  ncclSend/ncclRecv to the two ring neighbours inside one group (xGMI between GPUs).  Used when every slab has
+//         its own device: by a single process driving n devices (ising_ring_*: ncclCommInitAll) and by one process per
+//         GPU (ising_rank_*: ncclCommInitRank, the unique id travels through the caller's launcher).  librccl is opened
+//         at run time (dlopen), so single-GPU users of libising_hip.so do not load it.
+//   COPY  hipMemcpyPeerAsync on the comm stream (single process only): several slabs on one device, or no RCCL.
+// Results do not depend on the decomposition or the transport: the Philox stream id uses the global row
+// (optimized/main.cu:514).
+#include "ising_ctx.hpp"
+
+#include <rccl/rccl.h> // types and prototypes only: the library itself is opened with dlopen
+#include <dlfcn.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+using ising_host::bind;
+using ising_host::fail;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ RCCL at run time
+struct RcclApi {
+	void *handle = nullptr;
+	std::string error;
+	decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+	decltype(&ncclCommInitRank) CommInitRank = nullptr;
+	decltype(&ncclCommInitAll) CommInitAll = nullptr;
+	decltype(&ncclCommDestroy) CommDestroy = nullptr;
+	decltype(&ncclCommAbort) CommAbort = nullptr;
+	decltype(&ncclGroupStart) GroupStart = nullptr;
+	decltype(&ncclGroupEnd) GroupEnd = nullptr;
+	decltype(&ncclSend) Send = nullptr;
+	decltype(&ncclRecv) Recv = nullptr;
+	decltype(&ncclAllReduce) AllReduce = nullptr;
+	decltype(&ncclGetErrorString) GetErrorString = nullptr;
+	decltype(&ncclGetVersion) GetVersion = nullptr;
+};
+
+RcclApi &rccl_state() {
+	static RcclApi api;
+	return api;
+}
+
+RcclApi *rccl() {
+	RcclApi &api = rccl_state();
+	static bool tried = false;
+	if (tried) return api.handle ? &api : nullptr;
+	tried = true;
+	// a copy the process has already loaded (e.g. the one torch ships) wins: one RCCL per process
+	const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+	void *h = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD);
+	if (const char *env = getenv("ISING_RCCL_LIB")) h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+	for (int i = 0; !h && i < 3; i++) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+	if (!h) {
+		const char *e = dlerror();
+		api.error = std::string("cannot open librccl.so.1: ") + (e ? e : "?");
+		return nullptr;
+	}
+	bool ok = true;
+	auto sym = [&](const char *name) -> void * {
+		void *p = dlsym(h, name);
+		if (!p) { ok = false; api.error = std::string("librccl lacks ") + name; }
+		return p;
+	};
+#define RCCL_SYM(field, name) api.field = reinterpret_cast<decltype(api.field)>(sym(name))
+	RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+	RCCL_SYM(CommInitRank, "ncclCommInitRank");
+	RCCL_SYM(CommInitAll, "ncclCommInitAll");
+	RCCL_SYM(CommDestroy, "ncclCommDestroy");
+	RCCL_SYM(CommAbort, "ncclCommAbort");
+	RCCL_SYM(GroupStart, "ncclGroupStart");
+	RCCL_SYM(GroupEnd, "ncclGroupEnd");
+	RCCL_SYM(Send, "ncclSend");
+	RCCL_SYM(Recv, "ncclRecv");
+	RCCL_SYM(AllReduce, "ncclAllReduce");
+	RCCL_SYM(GetErrorString, "ncclGetErrorString");
+	RCCL_SYM(GetVersion, "ncclGetVersion");
+#undef RCCL_SYM
+	if (!ok) return nullptr;
+	api.handle = h;
+	return &api;
+}
+
+#define RCCL_TRY(expr)                                                                                              \
+	do {                                                                                                            \
+		ncclResult_t r_ = (expr);                                                                                   \
+		if (r_ != ncclSuccess) return fail(ISING_E_RCCL, "%s failed: %s (%s:%d)", #expr, rccl()->GetErrorString(r_), __FILE__, __LINE__); \
+	} while (0)
+
+// ------------------------------------------------------------------------------------------------ per-slab resources
+int ring_resources(ising_ctx *c) {
+	if (int rc = bind(c)) return rc;
+	if (!c->comm) {
+		int least = 0, greatest = 0; // numerically lower = higher priority
+		HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+		HIP_TRY(hipStreamCreateWithPriority(&c->comm, hipStreamNonBlocking, greatest));
+	}
+	for (int k = 0; k < 2; k++) {
+		if (!c->ev_edge[k]) HIP_TRY(hipEventCreateWithFlags(&c->ev_edge[k], hipEventDisableTiming));
+		if (!c->ev_sent[k]) HIP_TRY(hipEventCreateWithFlags(&c->ev_sent[k], hipEventDisableTiming));
+	}
+	return ISING_OK;
+}
+
+// The reference requires and enables all-to-all peer access (optimized/main.cu:1507-1537); a ring only needs the two
+// neighbours.  Failure to enable is not fatal: hipMemcpyPeerAsync then stages through the host.
+void ring_enable_peers(ising_ctx *c) {
+	if (c->peers_enabled || !c->ring_prev) return;
+	c->peers_enabled = true;
+	if (hipSetDevice(c->cfg.device) != hipSuccess) return;
+	const int peers[2] = {c->ring_prev->cfg.device, c->ring_next->cfg.device};
+	for (int k = 0; k < 2; k++) {
+		if (peers[k] == c->cfg.device || (k == 1 && peers[1] == peers[0])) continue;
+		int can = 0;
+		if (hipDeviceCanAccessPeer(&can, c->cfg.device, peers[k]) == hipSuccess && can) {
+			const hipError_t e = hipDeviceEnablePeerAccess(peers[k], 0);
+			if (e != hipSuccess) (void)hipGetLastError(); // already enabled or unsupported: fall back silently
+		}
+	}
+}
+
+int ring_check(ising_ctx **ctxs, int n) {
+	if (!ctxs || n < 1) return fail(ISING_E_ARG, "bad ring");
+	for (int k = 0; k < n; k++) {
+		const ising_ctx *c = ctxs[k];
+		if (!c) return fail(ISING_E_ARG, "ring slot %d is null", k);
+		if (c->cfg.nslabs != n || c->cfg.slab != k) return fail(ISING_E_ARG, "ring slot %d holds slab %d of %d", k, c->cfg.slab, c->cfg.nslabs);
+		if (c->rank_mode) return fail(ISING_E_STATE, "slab %d is attached to a multi-process ring (ising_rank_attach)", k);
+		if (c->lld != ctxs[0]->lld || c->cfg.Y != ctxs[0]->cfg.Y || c->cfg.X != ctxs[0]->cfg.X) return fail(ISING_E_ARG, "ring slabs differ in shape");
+		// ballot and dense rows have the same size but another bit order: a mixed ring would exchange garbage silently
+		if (c->layout() != ctxs[0]->layout()) return fail(ISING_E_ARG, "ring slabs differ in device layout (slab %d: %d, slab 0: %d)", k, c->layout(), ctxs[0]->layout());
+		if (c->cfg.use_J != ctxs[0]->cfg.use_J || c->cfg.XSL != ctxs[0]->cfg.XSL || c->cfg.YSL != ctxs[0]->cfg.YSL)
+			return fail(ISING_E_ARG, "ring slabs differ in couplings / sub-lattices");
+	}
+	return ISING_OK;
+}
+
+bool devices_distinct(ising_ctx **ctxs, int n) {
+	for (int a = 0; a < n; a++)
+		for (int b = a + 1; b < n; b++)
+			if (ctxs[a]->cfg.device == ctxs[b]->cfg.device) return false;
+	return true;
+}
+
+int rccl_init_all(ising_ctx **ctxs, int n) {
+	RcclApi *api = rccl();
+	if (!api) return fail(ISING_E_RCCL, "RCCL is not available: %s", rccl_state().error.c_str());
+	std::vector<ncclComm_t> comms(n);
+	std::vector<int> devs(n);
+	for (int k = 0; k < n; k++) devs[k] = ctxs[k]->cfg.device;
+	RCCL_TRY(api->CommInitAll(comms.data(), n, devs.data()));
+	for (int k = 0; k < n; k++) {
+		ctxs[k]->rccl_comm = comms[k];
+		ctxs[k]->rccl_owner = true;
+	}
+	return ISING_OK;
+}
+
+void rccl_drop(ising_ctx *c, bool abort) {
+	if (c->rccl_comm && c->rccl_owner) {
+		if (RcclApi *api = rccl()) {
+			(void)hipSetDevice(c->cfg.device);
+			if (abort) (void)api->CommAbort(static_cast<ncclComm_t>(c->rccl_comm));
+			else (void)api->CommDestroy(static_cast<ncclComm_t>(c->rccl_comm));
+		}
+	}
+	c->rccl_comm = nullptr;
+	c->rccl_owner = false;
+}
+
+// Decides the transport of a single-process ring (once) and wires the neighbours.
+int ring_bind(ising_ctx **ctxs, int n, int want = ISING_TRANSPORT_AUTO) {
+	if (int rc = ring_check(ctxs, n)) return rc;
+	for (int k = 0; k < n; k++) {
+		ising_ctx *c = ctxs[k];
+		c->ring_prev = ctxs[(k + n - 1) % n];
+		c->ring_next = ctxs[(k + 1) % n];
+		if (c->wrap) continue; // a single slab that wraps in place needs no transport
+		if (int rc = ring_resources(c)) return rc;
+	}
+	if (n == 1 && ctxs[0]->wrap) return ISING_OK;
+	if (ctxs[0]->transport && want == ISING_TRANSPORT_AUTO) return ISING_OK; // decided earlier
+	if (want == ISING_TRANSPORT_AUTO) {
+		if (const char *env = getenv("ISING_RING_TRANSPORT")) {
+			if (!strcmp(env, "copy")) want = ISING_TRANSPORT_COPY;
+			else if (!strcmp(env, "rccl")) want = ISING_TRANSPORT_RCCL;
+			else if (strcmp(env, "auto")) return fail(ISING_E_ARG, "ISING_RING_TRANSPORT must be auto, copy or rccl (got %s)", env);
+		}
+	}
+	int use = want;
+	if (want == ISING_TRANSPORT_AUTO) use = (n > 1 && devices_distinct(ctxs, n) && rccl()) ? ISING_TRANSPORT_RCCL : ISING_TRANSPORT_COPY;
+	if (use == ISING_TRANSPORT_RCCL) {
+		if (!devices_distinct(ctxs, n)) return fail(ISING_E_ARG, "the RCCL transport needs one device per slab (RCCL refuses two ranks on one GPU)");
+		bool have = true;
+		for (int k = 0; k < n; k++) have = have && ctxs[k]->rccl_comm;
+		if (!have) {
+			for (int k = 0; k < n; k++) rccl_drop(ctxs[k], false);
+			const int rc = rccl_init_all(ctxs, n);
+			if (rc != ISING_OK) {
+				if (want == ISING_TRANSPORT_RCCL) return rc;
+				use = ISING_TRANSPORT_COPY; // AUTO: the copies always work
+			}
+		}
+	}
+	if (use == ISING_TRANSPORT_COPY) {
+		for (int k = 0; k < n; k++) {
+			rccl_drop(ctxs[k], false);
+			ring_enable_peers(ctxs[k]);
+		}
+	}
+	for (int k = 0; k < n; k++) ctxs[k]->transport = use;
+	return ISING_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ the half-sweep stages
+// rows of plane `color` (a spin colour or ISING_HAM_BLACK): first row, last row, the halo row above, the halo row below
+struct EdgeRows {
+	uint64_t *first, *last, *halo_top, *halo_bot;
+	size_t bytes;
+};
+EdgeRows edge_rows(const ising_ctx *c, int color) {
+	const size_t ld = (size_t)c->plane_ld(color);
+	uint64_t *base = c->plane(color);
+	return {base, base + (size_t)(c->cfg.Y - 1) * ld, base - ld, base + (size_t)c->cfg.Y * ld, ld * sizeof(uint64_t)};
+}
+
+// Delivers the first/last rows of `color` of the local slabs on their comm streams; `after_edges`: the comm streams first
+// wait for the slabs' edge-row kernels (ev_edge[color]).  Records ev_sent[color] (spin colours only).
+int transfer(ising_ctx **ctxs, int n, int color, bool after_edges) {
+	if (ctxs[0]->cfg.XSL) return ISING_OK; // sub-lattices never reach across slabs
+	const bool spin = color != ISING_HAM_BLACK;
+	for (int k = 0; k < n; k++) {
+		ising_ctx *c = ctxs[k];
+		if (int rc = bind(c)) return rc;
+		if (after_edges && spin) HIP_TRY(hipStreamWaitEvent(c->comm, c->ev_edge[color], 0));
+	}
+	if (ctxs[0]->transport == ISING_TRANSPORT_RCCL) {
+		RcclApi *api = rccl();
+		if (!api) return fail(ISING_E_RCCL, "RCCL is not available: %s", rccl_state().error.c_str());
+		RCCL_TRY(api->GroupStart());
+		for (int k = 0; k < n; k++) {
+			ising_ctx *c = ctxs[k];
+			ncclComm_t comm = static_cast<ncclComm_t>(c->rccl_comm);
+			const int nr = c->cfg.nslabs, me = c->cfg.slab, next = (me + 1) % nr, prev = (me + nr - 1) % nr;
+			const EdgeRows e = edge_rows(c, color);
+			if (int rc = bind(c)) { (void)api->GroupEnd(); return rc; }
+			// With two ranks prev == next: the peer's first receive (its top halo row, "from prev") must match our LAST
+			// row, so the last row is sent first; receives are posted in the same order.
+			ncclResult_t r = api->Send(e.last, e.bytes, ncclUint8, next, comm, c->comm);
+			if (r == ncclSuccess) r = api->Send(e.first, e.bytes, ncclUint8, prev, comm, c->comm);
+			if (r == ncclSuccess) r = api->Recv(e.halo_top, e.bytes, ncclUint8, prev, comm, c->comm);
+			if (r == ncclSuccess) r = api->Recv(e.halo_bot, e.bytes, ncclUint8, next, comm, c->comm);
+			if (r != ncclSuccess) {
+				(void)api->GroupEnd();
+				return fail(ISING_E_RCCL, "ncclSend/ncclRecv failed: %s", api->GetErrorString(r));
+			}
+		}
+		RCCL_TRY(api->GroupEnd());
+	} else {
+		for (int k = 0; k < n; k++) {
+			ising_ctx *c = ctxs[k], *prev = c->ring_prev, *next = c->ring_next;
+			if (!prev || !next) return fail(ISING_E_STATE, "slab %d is not part of a single-process ring", c->cfg.slab);
+			const EdgeRows e = edge_rows(c, color), ep = edge_rows(prev, color), en = edge_rows(next, color);
+			if (int rc = bind(c)) return rc;
+			// next slab's top halo <- my last row ; previous slab's bottom halo <- my first row
+			HIP_TRY(hipMemcpyPeerAsync(en.halo_top, next->cfg.device, e.last, c->cfg.device, e.bytes, c->comm));
+			HIP_TRY(hipMemcpyPeerAsync(ep.halo_bot, prev->cfg.device, e.first, c->cfg.device, e.bytes, c->comm));
+		}
+	}
+	if (spin) {
+		for (int k = 0; k < n; k++) {
+			ising_ctx *c = ctxs[k];
+			if (int rc = bind(c)) return rc;
+			HIP_TRY(hipEventRecord(c->ev_sent[color], c->comm));
+		}
+	}
+	return ISING_OK;
+}
+
+int stage_edges(ising_ctx *c, int it, int color) {
+	if (int rc = ising_host::halo_ready(c, 1 - color)) return rc; // the edge rows read the other colour's halo rows
+	if (int rc = ising_update_edges(c, it, color)) return rc;
+	if (int rc = bind(c)) return rc;
+	HIP_TRY(hipEventRecord(c->ev_edge[color], c->stream));
+	return ISING_OK;
+}
+
+// A ballot slab turns dense when its temperature has no integer thresholds (ising_capi.cpp: launch_ranges).  In a ring
+// that must happen on every slab before the first edge row of the sweep is sent, or neighbours would exchange rows in
+// two bit orders.
+int settle_layout(ising_ctx **ctxs, int n) {
+	bool leave = false;
+	for (int k = 0; k < n; k++) leave = leave || (ctxs[k]->ballot && ising_host::needs_generic(ctxs[k]));
+	if (!leave) return ISING_OK;
+	for (int k = 0; k < n; k++) {
+		ising_ctx *c = ctxs[k];
+		for (int color = 0; color < 2; color++) if (int rc = ising_host::halo_ready(c, color)) return rc;
+		if (int rc = ising_host::ballot_leave(c)) return rc;
+	}
+	for (int k = 0; k < n; k++) if (int rc = ising_synchronize(ctxs[k])) return rc;
+	return ISING_OK;
+}
+
+int sweep_local(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
+	if (int rc = settle_layout(ctxs, n)) return rc;
+	for (int it = first_it; it < first_it + nsweeps; it++) {
+		for (int color = 0; color < 2; color++) {
+			for (int k = 0; k < n; k++) if (int rc = stage_edges(ctxs[k], it, color)) return rc;
+			if (int rc = transfer(ctxs, n, color, true)) return rc;
+			for (int k = 0; k < n; k++) if (int rc = ising_update_color(ctxs[k], it, color, 1, ctxs[k]->cfg.Y - 1)) return rc;
+		}
+	}
+	return ISING_OK;
+}
+
+int sync_both(ising_ctx *c) {
+	if (int rc = bind(c)) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (c->comm) HIP_TRY(hipStreamSynchronize(c->comm));
+	return ISING_OK;
+}
+
+// -J: black couplings everywhere, their edge rows to the neighbours, then the white couplings (which gather from them)
+int couplings_local(ising_ctx **ctxs, int n) {
+	for (int k = 0; k < n; k++) if (int rc = ising_init_couplings_black(ctxs[k])) return rc;
+	if (!ctxs[0]->wrap && !ctxs[0]->cfg.XSL) {
+		for (int k = 0; k < n; k++) if (int rc = sync_both(ctxs[k])) return rc;
+		if (int rc = transfer(ctxs, n, ISING_HAM_BLACK, false)) return rc;
+		for (int k = 0; k < n; k++) if (int rc = sync_both(ctxs[k])) return rc;
+	}
+	for (int k = 0; k < n; k++) if (int rc = ising_init_couplings_white(ctxs[k])) return rc;
+	return ISING_OK;
+}
+
+int rank_check(ising_ctx *c) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (!c->rank_mode || !c->rccl_comm) return fail(ISING_E_STATE, "the slab is not attached to a multi-process ring (ising_rank_attach)");
+	return ISING_OK;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------ library-internal
+int ising_host::halo_ready(ising_ctx *c, int color) {
+	if (c->wrap || c->cfg.XSL || !c->transport) return ISING_OK;
+	if (int rc = bind(c)) return rc;
+	if (c->transport == ISING_TRANSPORT_RCCL) {
+		// the receives are part of this slab's own group on its comm stream
+		if (c->ev_sent[color]) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_sent[color], 0));
+		return ISING_OK;
+	}
+	ising_ctx *prev = c->ring_prev, *next = c->ring_next;
+	if (prev && prev->ev_sent[color]) HIP_TRY(hipStreamWaitEvent(c->stream, prev->ev_sent[color], 0));
+	if (next && next != prev && next->ev_sent[color]) HIP_TRY(hipStreamWaitEvent(c->stream, next->ev_sent[color], 0));
+	return ISING_OK;
+}
+
+void ising_host::ring_release(ising_ctx *c) {
+	(void)hipSetDevice(c->cfg.device);
+	rccl_drop(c, false);
+	if (c->comm) (void)hipStreamDestroy(c->comm);
+	for (int k = 0; k < 2; k++) {
+		if (c->ev_edge[k]) (void)hipEventDestroy(c->ev_edge[k]);
+		if (c->ev_sent[k]) (void)hipEventDestroy(c->ev_sent[k]);
+	}
+	c->comm = nullptr;
+}
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------------ single-process ring
+int ising_ring_set_transport(ising_ctx **ctxs, int n, int transport) {
+	if (transport != ISING_TRANSPORT_AUTO && transport != ISING_TRANSPORT_COPY && transport != ISING_TRANSPORT_RCCL)
+		return fail(ISING_E_ARG, "bad transport %d", transport);
+	if (int rc = ring_check(ctxs, n)) return rc;
+	for (int k = 0; k < n; k++) if (int rc = sync_both(ctxs[k])) return rc;
+	for (int k = 0; k < n; k++) ctxs[k]->transport = 0;
+	return ring_bind(ctxs, n, transport);
+}
+
+int ising_ring_transport(ising_ctx **ctxs, int n, int *transport) {
+	if (!transport) return fail(ISING_E_ARG, "null argument");
+	if (int rc = ring_bind(ctxs, n)) return rc;
+	*transport = ctxs[0]->transport;
+	return ISING_OK;
+}
+
+int ising_ring_exchange(ising_ctx **ctxs, int n, int color) {
+	if (color != ISING_BLACK && color != ISING_WHITE && color != ISING_HAM_BLACK) return fail(ISING_E_ARG, "bad colour %d", color);
+	if (int rc = ring_bind(ctxs, n)) return rc;
+	if (ctxs[0]->wrap) return ISING_OK;
+	// whatever the slabs' streams hold (initialisation, host writes) must be complete before the rows travel
+	for (int k = 0; k < n; k++) {
+		ising_ctx *c = ctxs[k];
+		if (int rc = bind(c)) return rc;
+		if (color != ISING_HAM_BLACK) HIP_TRY(hipEventRecord(c->ev_edge[color], c->stream));
+		else HIP_TRY(hipStreamSynchronize(c->stream));
+	}
+	return transfer(ctxs, n, color, true);
+}
+
+int ising_ring_sweep(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
+	if (int rc = ring_bind(ctxs, n)) return rc;
+	if (ctxs[0]->wrap) return ising_sweep(ctxs[0], first_it, nsweeps);
+	return sweep_local(ctxs, n, first_it, nsweeps);
+}
+
+int ising_ring_init_couplings(ising_ctx **ctxs, int n) {
+	if (int rc = ring_bind(ctxs, n)) return rc;
+	return couplings_local(ctxs, n);
+}
+
+int ising_ring_synchronize(ising_ctx **ctxs, int n) {
+	if (int rc = ring_check(ctxs, n)) return rc;
+	for (int k = 0; k < n; k++) if (int rc = sync_both(ctxs[k])) return rc;
+	return ISING_OK;
+}
+
+int ising_ring_count(ising_ctx **ctxs, int n, uint64_t *up, uint64_t *down) {
+	if (!up || !down) return fail(ISING_E_ARG, "null argument");
+	if (int rc = ring_check(ctxs, n)) return rc;
+	*up = *down = 0;
+	for (int k = 0; k < n; k++) {
+		uint64_t u = 0, d = 0;
+		if (int rc = ising_count(ctxs[k], &u, &d)) return rc;
+		*up += u;
+		*down += d;
+	}
+	return ISING_OK;
+}
+
+int ising_ring_bond_equal(ising_ctx **ctxs, int n, int64_t *A) {
+	if (!A) return fail(ISING_E_ARG, "null argument");
+	if (int rc = ring_bind(ctxs, n)) return rc;
+	*A = 0;
+	for (int k = 0; k < n; k++) {
+		int64_t a = 0;
+		if (int rc = ising_bond_equal(ctxs[k], &a)) return rc; // waits for the white halo rows (halo_ready)
+		*A += a;
+	}
+	return ISING_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ one slab per process
+int ising_rccl_available(int *version) {
+	RcclApi *api = rccl();
+	if (!api) return fail(ISING_E_RCCL, "RCCL is not available: %s", rccl_state().error.c_str());
+	if (version) {
+		int v = 0;
+		RCCL_TRY(api->GetVersion(&v));
+		*version = v;
+	}
+	return ISING_OK;
+}
+
+int ising_rccl_unique_id(void *id_out) {
+	if (!id_out) return fail(ISING_E_ARG, "null argument");
+	RcclApi *api = rccl();
+	if (!api) return fail(ISING_E_RCCL, "RCCL is not available: %s", rccl_state().error.c_str());
+	ncclUniqueId id;
+	RCCL_TRY(api->GetUniqueId(&id));
+	static_assert(sizeof(id) == ISING_RCCL_ID_BYTES, "ncclUniqueId size");
+	memcpy(id_out, &id, sizeof(id));
+	return ISING_OK;
+}
+
+int ising_rank_attach(ising_ctx *c, const void *id_in) {
+	if (!c || !id_in) return fail(ISING_E_ARG, "null argument");
+	if (c->wrap) return fail(ISING_E_STATE, "a slab that wraps in place has no halo rows to exchange (nslabs == 1 without ring_halo)");
+	if (c->rank_mode || c->rccl_comm) return fail(ISING_E_STATE, "the slab is already attached");
+	RcclApi *api = rccl();
+	if (!api) return fail(ISING_E_RCCL, "RCCL is not available: %s", rccl_state().error.c_str());
+	if (int rc = ring_resources(c)) return rc;
+	ncclUniqueId id;
+	memcpy(&id, id_in, sizeof(id));
+	ncclComm_t comm = nullptr;
+	RCCL_TRY(api->CommInitRank(&comm, c->cfg.nslabs, id, c->cfg.slab)); // collective over all ranks of the ring
+	c->rccl_comm = comm;
+	c->rccl_owner = true;
+	c->rank_mode = true;
+	c->transport = ISING_TRANSPORT_RCCL;
+	c->ring_prev = c->ring_next = nullptr;
+	return ISING_OK;
+}
+
+int ising_rank_detach(ising_ctx *c, int abort_pending) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (!c->rank_mode) return ISING_OK;
+	if (!abort_pending) if (int rc = sync_both(c)) return rc;
+	rccl_drop(c, abort_pending != 0);
+	c->rank_mode = false;
+	c->transport = 0;
+	return ISING_OK;
+}
+
+int ising_rank_exchange(ising_ctx *c, int color) {
+	if (int rc = rank_check(c)) return rc;
+	if (color != ISING_BLACK && color != ISING_WHITE && color != ISING_HAM_BLACK) return fail(ISING_E_ARG, "bad colour %d", color);
+	if (int rc = bind(c)) return rc;
+	if (color != ISING_HAM_BLACK) HIP_TRY(hipEventRecord(c->ev_edge[color], c->stream));
+	else HIP_TRY(hipStreamSynchronize(c->stream));
+	return transfer(&c, 1, color, true);
+}
+
+int ising_rank_sweep(ising_ctx *c, int first_it, int nsweeps) {
+	if (int rc = rank_check(c)) return rc;
+	return sweep_local(&c, 1, first_it, nsweeps);
+}
+
+int ising_rank_init_couplings(ising_ctx *c) {
+	if (int rc = rank_check(c)) return rc;
+	return couplings_local(&c, 1);
+}
+
+int ising_rank_wait(ising_ctx *c, int timeout_ms) {
+	if (int rc = rank_check(c)) return rc;
+	if (int rc = bind(c)) return rc;
+	if (timeout_ms < 0) return sync_both(c);
+	const auto t0 = std::chrono::steady_clock::now();
+	for (;;) {
+		const hipError_t a = hipStreamQuery(c->stream), b = hipStreamQuery(c->comm);
+		if (a == hipSuccess && b == hipSuccess) return ISING_OK;
+		if ((a != hipSuccess && a != hipErrorNotReady) || (b != hipSuccess && b != hipErrorNotReady))
+			return fail(ISING_E_HIP, "stream query failed: %s", hipGetErrorString(a != hipSuccess && a != hipErrorNotReady ? a : b));
+		if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > timeout_ms)
+			return fail(ISING_E_TIMEOUT, "the ring exchange did not complete within %d ms", timeout_ms);
+		std::this_thread::sleep_for(std::chrono::microseconds(200));
+	}
+}
+
+// totals over all ranks: ncclAllReduce of the slab's counter on the compute stream
+static int rank_allreduce_u64(ising_ctx *c, unsigned long long *d_val, unsigned long long *host_out) {
+	RcclApi *api = rccl();
+	if (!api) return fail(ISING_E_RCCL, "RCCL is not available: %s", rccl_state().error.c_str());
+	RCCL_TRY(api->AllReduce(d_val, c->d_acc + 2, 1, ncclUint64, ncclSum, static_cast<ncclComm_t>(c->rccl_comm), c->stream));
+	HIP_TRY(hipMemcpyAsync(host_out, c->d_acc + 2, sizeof(*host_out), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return ISING_OK;
+}
+
+int ising_rank_count(ising_ctx *c, uint64_t *up, uint64_t *down) {
+	if (int rc = rank_check(c)) return rc;
+	if (!up || !down) return fail(ISING_E_ARG, "null argument");
+	uint64_t u = 0, d = 0;
+	if (int rc = ising_count(c, &u, &d)) return rc; // leaves the slab's up count in d_acc[0]
+	unsigned long long tot = 0;
+	if (int rc = rank_allreduce_u64(c, c->d_acc, &tot)) return rc;
+	*up = tot;
+	*down = (uint64_t)c->cfg.X * (uint64_t)c->cfg.Y * (uint64_t)c->cfg.nslabs - tot;
+	return ISING_OK;
+}
+
+int ising_rank_bond_equal(ising_ctx *c, int64_t *A) {
+	if (int rc = rank_check(c)) return rc;
+	if (!A) return fail(ISING_E_ARG, "null argument");
+	int64_t a = 0;
+	if (int rc = ising_bond_equal(c, &a)) return rc; // leaves the slab's sum in d_acc[1]
+	unsigned long long tot = 0;
+	if (int rc = rank_allreduce_u64(c, c->d_acc + 1, &tot)) return rc;
+	*A = (int64_t)tot;
+	return ISING_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ correlations
+int ising_ring_correlations(ising_ctx **ctxs, int n, int ncorr, int64_t *sums) {
+	if (int rc = ring_bind(ctxs, n)) return rc;
+	if (!sums || ncorr < 1 || ncorr > 128) return fail(ISING_E_ARG, "ncorr must be in [1,128]");
+	for (int k = 0; k < n; k++) {
+		ising_ctx *c = ctxs[k];
+		if (c->cfg.XSL && c->cfg.YSL < ncorr) return fail(ISING_E_ARG, "sub-lattices need at least %d rows for %d correlation distances", ncorr, ncorr);
+		if (c->cfg.Y < ncorr) return fail(ISING_E_ARG, "each slab needs at least %d rows for %d correlation distances", ncorr, ncorr);
+		if (int rc = bind(c)) return rc;
+		if (!c->d_bits || c->d_bits_extra < ncorr) {
+			if (c->d_bits) HIP_TRY(hipFree(c->d_bits));
+			c->d_bits = nullptr;
+			HIP_TRY(hipMalloc((void **)&c->d_bits, (size_t)(c->cfg.Y + 128) * c->lld_packed * sizeof(uint32_t)));
+			c->d_bits_extra = 128;
+		}
+		if (!c->d_corr) HIP_TRY(hipMalloc((void **)&c->d_corr, 128 * sizeof(long long)));
+		// bit matrix: X bits = lld_packed 32-bit words per row
+		if (c->ballot) if (int rc = ising_host::ballot_image(c)) return rc;
+		if (c->ballot) HIP_TRY(ising::launch_dense_pack_bits(c->tmp(ISING_BLACK), c->tmp(ISING_WHITE), c->gx * 32, c->cfg.Y,
+		                                                     (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y, c->d_bits, c->stream));
+		else if (c->dense) HIP_TRY(ising::launch_dense_pack_bits(c->lat(ISING_BLACK), c->lat(ISING_WHITE), c->gx * 32, c->cfg.Y,
+		                                                    (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y, c->d_bits, c->stream));
+		else HIP_TRY(ising::launch_pack_bits(c->lat(ISING_BLACK), c->lat(ISING_WHITE), c->lld_packed, c->cfg.Y,
+		                                     (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y, c->d_bits, c->stream));
+		HIP_TRY(hipMemsetAsync(c->d_corr, 0, 128 * sizeof(long long), c->stream));
+	}
+	for (int k = 0; k < n; k++) if (int rc = ising_synchronize(ctxs[k])) return rc;
+	// rows that follow slab k (vertical partners of its last ncorr rows): the first ncorr bit-rows of slab k+1
+	for (int k = 0; k < n; k++) {
+		ising_ctx *c = ctxs[k], *next = ctxs[(k + 1) % n];
+		if (int rc = bind(c)) return rc;
+		if (!c->cfg.XSL) // sub-lattices never look past their own rows
+			HIP_TRY(hipMemcpyPeerAsync(c->d_bits + (size_t)c->cfg.Y * c->lld_packed, c->cfg.device, next->d_bits, next->cfg.device,
+			                           (size_t)ncorr * c->lld_packed * sizeof(uint32_t), c->stream));
+		HIP_TRY(ising::launch_corr(c->d_bits, c->lld_packed, c->cfg.Y, ncorr, c->cfg.XSL ? c->cfg.XSL / 32 : c->lld_packed,
+		                           c->cfg.XSL ? c->cfg.YSL : 0, c->d_corr, c->stream));
+	}
+	std::vector<long long> h(ncorr);
+	for (int j = 0; j < ncorr; j++) sums[j] = 0;
+	for (int k = 0; k < n; k++) {
+		ising_ctx *c = ctxs[k];
+		if (int rc = bind(c)) return rc;
+		HIP_TRY(hipMemcpyAsync(h.data(), c->d_corr, (size_t)ncorr * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		for (int j = 0; j < ncorr; j++) sums[j] += h[j];
+	}
+	return ISING_OK;
+}
+
+int ising_correlations(ising_ctx *c, int ncorr, int64_t *sums) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (c->cfg.nslabs != 1) return fail(ISING_E_STATE, "ising_correlations needs nslabs == 1; use ising_ring_correlations");
+	return ising_ring_correlations(&c, 1, ncorr, sums);
+}
+
+} // extern "C"

@@ -27,12 +27,15 @@ class IsingSlab:
     def __init__(self, X: int, Y: int, seed: int = _lib.SEED_DEF, temp: float = 0.1 * _lib.CRIT_TEMP_F32,
                  nslabs: int = 1, slab: int = 0, device: int = 0, strip_rows: int = 0, kernel: int = _lib.KERNEL_AUTO,
                  XSL: int = 0, YSL: int = 0, J_prob: float | None = None, lattice_mem: int = 0, coupling_mem: int = 0,
-                 layout: int = _lib.LAYOUT_AUTO):
+                 layout: int = _lib.LAYOUT_AUTO, ring_halo: bool = False, lattice_mem_bytes: int = 0,
+                 coupling_mem_bytes: int = 0):
         self._lib = _lib.load()
         self.cfg = IsingConfig(X=X, Y=Y, nslabs=nslabs, slab=slab, seed=seed, temp=float(np.float32(temp)),
                                device=device, strip_rows=strip_rows, kernel=kernel, XSL=XSL, YSL=YSL,
                                lattice_mem=lattice_mem or None, coupling_mem=coupling_mem or None, layout=layout,
-                               use_J=0 if J_prob is None else 1, J_prob=0.0 if J_prob is None else float(J_prob))
+                               use_J=0 if J_prob is None else 1, J_prob=0.0 if J_prob is None else float(J_prob),
+                               ring_halo=1 if ring_halo else 0, lattice_mem_bytes=lattice_mem_bytes,
+                               coupling_mem_bytes=coupling_mem_bytes)
         self.use_J = J_prob is not None
         self._h = C.c_void_p()
         check(self._lib.ising_create(C.byref(self.cfg), C.byref(self._h)))
@@ -165,10 +168,127 @@ class IsingSlab:
     def dump(self, prefix: str):
         check(self._lib.ising_dump_text(self._h, prefix.encode()))
 
+    # -- one slab per process: the ring over RCCL inside the library (ising_rank_*) -------------------------
+    def rank_attach(self, unique_id: bytes):
+        """ncclCommInitRank(nslabs, id, slab): collective over all ranks of the ring."""
+        if len(unique_id) != _lib.RCCL_ID_BYTES:
+            raise ValueError("the RCCL unique id has %d bytes" % _lib.RCCL_ID_BYTES)
+        buf = C.create_string_buffer(bytes(unique_id), _lib.RCCL_ID_BYTES)
+        check(self._lib.ising_rank_attach(self._h, buf))
 
-def required_bytes(X: int, Y: int) -> int:
-    """Size of the device buffer a slab needs for its spin arrays (and, again, for its coupling arrays)."""
-    return int(_lib.load().ising_required_bytes(X, Y))
+    def rank_detach(self, abort: bool = False):
+        check(self._lib.ising_rank_detach(self._h, 1 if abort else 0))
+
+    def rank_exchange(self, color: int):
+        check(self._lib.ising_rank_exchange(self._h, color))
+
+    def rank_init_couplings(self):
+        check(self._lib.ising_rank_init_couplings(self._h))
+
+    def rank_sweep(self, n: int = 1):
+        check(self._lib.ising_rank_sweep(self._h, self.it + 1, n))
+        self.it += n
+        return self
+
+    def rank_wait(self, timeout_ms: int = -1):
+        check(self._lib.ising_rank_wait(self._h, timeout_ms))
+
+    def rank_count(self):
+        up, dw = C.c_uint64(), C.c_uint64()
+        check(self._lib.ising_rank_count(self._h, C.byref(up), C.byref(dw)))
+        return int(up.value), int(dw.value)
+
+    def rank_bond_equal(self) -> int:
+        a = C.c_int64()
+        check(self._lib.ising_rank_bond_equal(self._h, C.byref(a)))
+        return int(a.value)
+
+
+def rccl_version() -> int:
+    """Version code of the RCCL the library opened at run time; raises IsingError when there is none."""
+    v = C.c_int()
+    check(_lib.load().ising_rccl_available(C.byref(v)))
+    return v.value
+
+
+def rccl_unique_id() -> bytes:
+    buf = C.create_string_buffer(_lib.RCCL_ID_BYTES)
+    check(_lib.load().ising_rccl_unique_id(buf))
+    return buf.raw
+
+
+def required_bytes(X: int, Y: int, layout: int | None = None) -> int:
+    """Size of a caller-owned device buffer: the coupling arrays (layout None: 4 bit per site in every layout) or the
+    spin arrays of a given device layout (a quarter of that for the 1 bit/spin layouts)."""
+    if layout is None:
+        return int(_lib.load().ising_required_bytes(X, Y))
+    return int(_lib.load().ising_required_bytes_layout(X, Y, layout))
+
+
+class SlabSet:
+    """All slabs of a ring in ONE process (the reference's own process model, optimized/main.cu:1763-1805), driven through
+    the ising_ring_* entry points: edge rows, halo delivery on the slabs' comm streams (RCCL between devices, copies
+    on one device), interior rows."""
+
+    def __init__(self, slabs):
+        self.slabs = list(slabs)
+        self._lib = _lib.load()
+        self._arr = (C.c_void_p * len(self.slabs))(*[s._h for s in self.slabs])
+        self.n = len(self.slabs)
+        self.it = 0
+
+    def set_transport(self, transport: int):
+        check(self._lib.ising_ring_set_transport(self._arr, self.n, transport))
+        return self
+
+    @property
+    def transport(self) -> int:
+        t = C.c_int()
+        check(self._lib.ising_ring_transport(self._arr, self.n, C.byref(t)))
+        return t.value
+
+    def init(self):
+        for s in self.slabs:
+            s.init()
+        self.it = 0
+        for color in (BLACK, WHITE):
+            check(self._lib.ising_ring_exchange(self._arr, self.n, color))
+        if self.slabs[0].use_J:
+            check(self._lib.ising_ring_init_couplings(self._arr, self.n))
+        return self
+
+    def exchange(self):
+        for color in (BLACK, WHITE):
+            check(self._lib.ising_ring_exchange(self._arr, self.n, color))
+        return self
+
+    def sweep(self, n: int = 1):
+        check(self._lib.ising_ring_sweep(self._arr, self.n, self.it + 1, n))
+        self.it += n
+        for s in self.slabs:
+            s.it = self.it
+        return self
+
+    def synchronize(self):
+        check(self._lib.ising_ring_synchronize(self._arr, self.n))
+
+    def count(self):
+        up, dw = C.c_uint64(), C.c_uint64()
+        check(self._lib.ising_ring_count(self._arr, self.n, C.byref(up), C.byref(dw)))
+        return int(up.value), int(dw.value)
+
+    def bond_equal(self) -> int:
+        a = C.c_int64()
+        check(self._lib.ising_ring_bond_equal(self._arr, self.n, C.byref(a)))
+        return int(a.value)
+
+    def set_temperature(self, temp: float):
+        for s in self.slabs:
+            s.set_temperature(temp)
+
+    def close(self):
+        for s in self.slabs:
+            s.close()
 
 
 def magnetization(up: int, down: int) -> float:

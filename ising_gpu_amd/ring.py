@@ -25,7 +25,7 @@ from typing import List, Optional, Protocol
 import torch
 import torch.distributed as dist
 
-from ._lib import BLACK, WHITE, HAM_BLACK
+from ._lib import BLACK, WHITE, HAM_BLACK, LAYOUT_AUTO, IsingError
 
 
 class SlabBackend(Protocol):
@@ -71,16 +71,20 @@ class HipSlabBackend:
                     self._halo[color] = tuple(torch.as_tensor(_DevMem(p, nb), device=self.device) for p in ptrs)
 
     @classmethod
-    def create(cls, X, Y, device=0, J_prob=None, **kw):
+    def create(cls, X, Y, device=0, J_prob=None, layout=LAYOUT_AUTO, **kw):
         from .lattice import IsingSlab, required_bytes
         dev = torch.device("cuda", device)
-        nbytes = required_bytes(X, Y)
-        bufs = {"lattice": torch.empty(nbytes, dtype=torch.uint8, device=dev)}
+        bufs = {"lattice": torch.empty(required_bytes(X, Y, layout), dtype=torch.uint8, device=dev)}
         if J_prob is not None:
-            bufs["coupling"] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        slab = IsingSlab(X, Y, device=device, J_prob=J_prob, lattice_mem=bufs["lattice"].data_ptr(),
-                         coupling_mem=bufs["coupling"].data_ptr() if "coupling" in bufs else 0, **kw)
+            bufs["coupling"] = torch.empty(required_bytes(X, Y), dtype=torch.uint8, device=dev)
+        slab = IsingSlab(X, Y, device=device, J_prob=J_prob, layout=layout, lattice_mem=bufs["lattice"].data_ptr(),
+                         lattice_mem_bytes=bufs["lattice"].numel(),
+                         coupling_mem=bufs["coupling"].data_ptr() if "coupling" in bufs else 0,
+                         coupling_mem_bytes=bufs["coupling"].numel() if "coupling" in bufs else 0, **kw)
         return cls(slab, bufs)
+
+    def layout_id(self):
+        return self.slab.current_layout()
 
     def init(self):
         self.slab.init()
@@ -174,7 +178,22 @@ class SlabRing:
         self._pending[color] = None
 
     # -- driver steps ------------------------------------------------------------------------------------
+    def _check_layouts(self):
+        """Ballot and dense rows have the same size but another bit order: every rank must hold the same layout."""
+        lay = getattr(self.b, "layout_id", None)
+        if lay is None or self.world == 1:
+            return
+        t = torch.tensor([lay()], dtype=torch.int64)
+        if dist.get_backend(self.group) == "nccl":
+            t = t.cuda()
+        lo, hi = t.clone(), t.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if int(lo[0]) != int(hi[0]):
+            raise IsingError(f"ring slabs differ in device layout (this rank: {int(t[0])}, ring: {int(lo[0])}..{int(hi[0])})")
+
     def init(self):
+        self._check_layouts()
         self.b.init()
         self.it = 0
         if self.world > 1:
@@ -288,3 +307,113 @@ class LocalRing:
 
     def bond_equal(self) -> int:
         return sum(b.bond_equal() for b in self.b)
+
+
+class NativeRing:
+    """One slab per process, the whole half-sweep schedule inside libising_hip.so (ising_rank_*): the library owns a
+    second HIP stream and an RCCL communicator per slab; torch.distributed only carries the 128-byte RCCL id once.
+    Same driver surface as SlabRing (init / sweep / count / bond_equal / quiesce)."""
+
+    exchange = "rccl-native"
+
+    def __init__(self, slab, group: Optional[dist.ProcessGroup] = None, probe_timeout_ms: int = 60000):
+        self.slab = slab
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if slab.nslabs != self.world or slab.slab != self.rank:
+            raise ValueError(f"slab {slab.slab} of {slab.nslabs} on rank {self.rank} of {self.world}")
+        self.probe_timeout_ms = probe_timeout_ms
+        self.it = 0
+        self._attach()
+
+    def _attach(self):
+        from .lattice import rccl_unique_id
+        if self.world == 1:
+            uid = rccl_unique_id()
+        else:
+            nccl = dist.get_backend(self.group) == "nccl"
+            t = torch.zeros(128, dtype=torch.uint8, device="cuda" if nccl else "cpu")
+            if self.rank == 0:
+                t.copy_(torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8))
+            dist.broadcast(t, src=0, group=self.group)
+            uid = bytes(t.cpu().numpy().tobytes())
+        self.slab.rank_attach(uid)
+
+    def init(self):
+        self.slab.init()
+        self.it = 0
+        self.slab.rank_exchange(BLACK)
+        self.slab.rank_exchange(WHITE)
+        # the first exchange also builds RCCL's connections: bounded wait, so that a transport that cannot come up
+        # surfaces as an error the caller can fall back from instead of a hang
+        self.slab.rank_wait(self.probe_timeout_ms)
+        if self.slab.use_J:
+            self.slab.rank_init_couplings()
+        return self
+
+    def sweep(self, nsweeps: int = 1):
+        self.slab.it = self.it
+        self.slab.rank_sweep(nsweeps)
+        self.it += nsweeps
+        return self
+
+    def quiesce(self):
+        self.slab.rank_wait(-1)
+
+    def count(self):
+        return self.slab.rank_count()
+
+    def bond_equal(self) -> int:
+        return self.slab.rank_bond_equal()
+
+    def close(self, abort: bool = False):
+        self.slab.rank_detach(abort)
+
+
+def open_ring(backend: "HipSlabBackend", prefer: str = "native", exchange: Optional[str] = None, log=None):
+    """The ring a multi-process driver (bench.py) should use: the library's own RCCL ring when it comes up, otherwise
+    the torch.distributed one (p2p, then all-gather).  Every rank takes the same decision: the outcome of each attempt is
+    agreed on with an all-reduce before anyone moves on.  Returns (ring, name)."""
+    log = log or (lambda *a: None)
+    world = dist.get_world_size() if dist.is_initialized() else 1
+
+    def agreed(ok: bool) -> bool:
+        if world == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t[0]))
+
+    attempts = []
+    if world > 1 and prefer == "native" and exchange is None:
+        attempts.append("rccl-native")
+    attempts += [exchange] if exchange else ["p2p", "allgather"]
+    last = None
+    for name in attempts:
+        ring = None
+        try:
+            if name == "rccl-native":
+                ring = NativeRing(backend.slab)
+            else:
+                ring = SlabRing(backend, exchange=name)
+            ring.init()
+            if world > 1:
+                ring.sweep(1)  # one real half-sweep pair through the transport before it is trusted
+                ring.quiesce()
+                torch.cuda.synchronize()
+            ok = True
+        except Exception as e:  # noqa: BLE001 -- any transport failure means: try the next one
+            last = e
+            ok = False
+            log(f"ring transport {name} failed on this rank: {e}")
+        if agreed(ok):
+            return ring, name
+        if ring is not None and name == "rccl-native":
+            try:
+                ring.close(abort=True)
+            except Exception:  # noqa: BLE001
+                pass
+    raise IsingError(f"no ring transport came up (last error: {last})")

@@ -1,0 +1,120 @@
+"""BASELINE.json configurations at FULL size against the committed oracle goldens (tests/golden/make_golden_big.py):
+  config 2  16384 x 16384, T = Tc, seed 1234         -- SHA-256 of the packed state, counts, bond sums
+  config 3  65536 x 65536, T = Tc, seed 1234         -- the bench.py workload: counts and bond sums (0 .. 144 sweeps)
+  config 4  131072 x 131072 as 8 slabs of 16384 rows -- counts, bond sums, per-slab counts; through the C-ABI ring
+            (SlabSet), the torch-side LocalRing and `cuIsing -d 8` (all slabs on device 0 of a 1-GPU box)
+plus a live comparison of config 2 with the oracle run on this box's host cores."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ising_gpu_amd as ig
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CLI = os.path.join(os.path.dirname(ig.LIB_PATH), "cuIsing")
+
+
+def _gold(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+def _f32(bits):
+    return float(np.uint32(bits).view(np.float32))
+
+
+@pytest.mark.parametrize("layout", [ig.LAYOUT_AUTO, ig.LAYOUT_BALLOT, ig.LAYOUT_DENSE])
+def test_config2_16384_golden_states(gpu, layout):
+    fx = _gold("config2_16384.json")
+    with ig.IsingSlab(fx["X"], fx["Ytot"], seed=fx["seed"], temp=_f32(fx["temp_bits"]), layout=layout) as s:
+        s.init()
+        for pt in fx["points"]:
+            s.sweep(pt["sweeps"] - s.it)
+            assert s.count() == (pt["up"], pt["down"]), pt["sweeps"]
+            assert s.bond_equal() == pt["bond_equal"], pt["sweeps"]
+            if pt["sweeps"] in (0, 2, 256):
+                h = hashlib.sha256()
+                h.update(s.read(ig.BLACK).tobytes())
+                h.update(s.read(ig.WHITE).tobytes())
+                assert h.hexdigest() == pt["sha256"], pt["sweeps"]
+
+
+def test_config2_16384_full_state_vs_live_oracle(gpu, oracle_mod):
+    X = Y = 16384
+    orc = oracle_mod.OracleLattice(X, Y, seed=1234, temp=oracle_mod.CRIT_TEMP).init()
+    with ig.IsingSlab(X, Y, seed=1234, temp=ig.CRIT_TEMP_F32) as s:
+        s.init()
+        for upto in (0, 1, 3):
+            s.sweep(upto - s.it)
+            orc.sweep(upto - orc.it)
+            assert np.array_equal(s.read(ig.BLACK), orc.black), upto
+            assert np.array_equal(s.read(ig.WHITE), orc.white), upto
+            assert s.count() == orc.count() and s.bond_equal() == orc.bond_equal()
+
+
+def test_config3_bench_workload_golden(gpu):
+    """65536^2 at T = Tc, seed 1234 -- exactly what bench.py times; 25 = the driver's 5 + 20 sweeps, 144 = the default
+    16 + 128."""
+    fx = _gold("bench_65536_tc.json")
+    with ig.IsingSlab(fx["X"], fx["Ytot"], seed=fx["seed"], temp=_f32(fx["temp_bits"])) as s:
+        assert s.layout == ig.LAYOUT_BALLOT
+        s.init()
+        for pt in fx["points"]:
+            s.sweep(pt["sweeps"] - s.it)
+            assert s.count() == (pt["up"], pt["down"]), pt["sweeps"]
+            if pt["sweeps"] in (0, 25, 144):
+                assert s.bond_equal() == pt["bond_equal"], pt["sweeps"]
+
+
+def _config4_slabs(fx, **kw):
+    n = fx["nslabs"]
+    return [ig.IsingSlab(fx["X"], fx["Ytot"] // n, seed=fx["seed"], temp=_f32(fx["temp_bits"]), nslabs=n, slab=k, **kw) for k in range(n)]
+
+
+def test_config4_131072_eight_slabs_capi_ring(gpu):
+    fx = _gold("config4_131072.json")
+    ring = ig.SlabSet(_config4_slabs(fx))
+    try:
+        ring.init()
+        for pt in fx["points"]:
+            ring.sweep(pt["sweeps"] - ring.it)
+            assert [s.count()[0] for s in ring.slabs] == pt["slab_up"], pt["sweeps"]
+            assert ring.count() == (pt["up"], pt["down"]), pt["sweeps"]
+            assert ring.bond_equal() == pt["bond_equal"], pt["sweeps"]
+    finally:
+        ring.close()
+
+
+def test_config4_131072_eight_slabs_local_ring(gpu):
+    fx = _gold("config4_131072.json")
+    slabs = _config4_slabs(fx)
+    try:
+        ring = ig.LocalRing([ig.HipSlabBackend(s) for s in slabs]).init()
+        for pt in fx["points"]:
+            ring.sweep(pt["sweeps"] - ring.it)
+            assert ring.count() == (pt["up"], pt["down"]), pt["sweeps"]
+            assert ring.bond_equal() == pt["bond_equal"], pt["sweeps"]
+    finally:
+        for s in slabs:
+            s.close()
+
+
+def test_config4_131072_cli_eight_devices_mapped_to_one(gpu):
+    """`cuIsing -x 131072 -y 16384 -d 8 -a 1 -s 1234 -n 2 -p 1` (BASELINE config 4's command line) with every slab on
+    device 0: the reference's transcript lines with the oracle's counts."""
+    fx = _gold("config4_131072.json")
+    r = subprocess.run([CLI, "-x", "131072", "-y", "16384", "-d", "8", "-a", "1", "-s", "1234", "-n", "2", "-p", "1",
+                        "--devmap", "0,0,0,0,0,0,0,0"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    n = fx["X"] * fx["Ytot"]
+    p0, p1, p2 = fx["points"]
+    assert f"\ttotal lattice size:        131072 x   131072\n" in r.stdout
+    assert f"Initial magnetization: {abs(p0['up'] - p0['down']) / n:9.6f}, up_s: {p0['up']:12d}, dw_s: {p0['down']:12d}\n" in r.stdout
+    for pt in (p1, p2):
+        assert (f"        magnetization: {abs(pt['up'] - pt['down']) / n:9.6f}, up_s: {pt['up']:12d}, dw_s: {pt['down']:12d} "
+                f"(iter: {pt['sweeps']:8d})\n") in r.stdout

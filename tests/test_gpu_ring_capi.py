@@ -1,0 +1,149 @@
+"""The slab ring inside the C-ABI (ising_ring_* / ising_rank_*, csrc/ising_ring.cpp): edge rows, halo delivery on a
+second stream per slab, interior rows.  On one GPU the copy transport carries n slabs of one device and the RCCL
+transport carries a ring of ONE slab (ncclSend/ncclRecv to itself: RCCL refuses two ranks on one device); with two or
+more GPUs the tests at the end run the real thing (they skip on a 1-GPU box)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import ising_gpu_amd as ig
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _single(X, Y, seed, temp, sweeps, **kw):
+    with ig.IsingSlab(X, Y, seed=seed, temp=temp, **kw) as one:
+        one.init().sweep(sweeps)
+        return one.read(ig.BLACK), one.read(ig.WHITE), one.count(), one.bond_equal()
+
+
+@pytest.mark.parametrize("layout", [ig.LAYOUT_BALLOT, ig.LAYOUT_DENSE, ig.LAYOUT_NIBBLE])
+@pytest.mark.parametrize("nslabs", [2, 3, 8])
+def test_capi_ring_copy_transport_matches_single_slab(gpu, nslabs, layout):
+    X, Yk, seed, temp, sweeps = 8192, 32, 99, ig.CRIT_TEMP_F32, 6
+    ref_b, ref_w, ref_cnt, ref_bond = _single(X, Yk * nslabs, seed, temp, sweeps, layout=layout)
+    ring = ig.SlabSet([ig.IsingSlab(X, Yk, seed=seed, temp=temp, nslabs=nslabs, slab=k, layout=layout) for k in range(nslabs)])
+    try:
+        ring.init()
+        assert ring.transport == ig.TRANSPORT_COPY
+        ring.sweep(2).sweep(sweeps - 2)
+        assert ring.count() == ref_cnt
+        assert ring.bond_equal() == ref_bond
+        assert np.array_equal(np.concatenate([s.read(ig.BLACK) for s in ring.slabs]), ref_b)
+        assert np.array_equal(np.concatenate([s.read(ig.WHITE) for s in ring.slabs]), ref_w)
+    finally:
+        ring.close()
+
+
+def test_capi_ring_rejects_mixed_layouts(gpu):
+    slabs = [ig.IsingSlab(8192, 32, nslabs=2, slab=0, layout=ig.LAYOUT_BALLOT), ig.IsingSlab(8192, 32, nslabs=2, slab=1, layout=ig.LAYOUT_DENSE)]
+    ring = ig.SlabSet(slabs)
+    try:
+        with pytest.raises(ig.IsingError, match="layout"):
+            ring.init()
+    finally:
+        ring.close()
+
+
+def test_capi_ring_ballot_slabs_turn_dense_together(gpu, oracle_mod):
+    """T <= 0 has no integer thresholds: every ballot slab of the ring must become dense before the first row travels."""
+    X, Yk, n, seed = 8192, 32, 3, 5
+    ring = ig.SlabSet([ig.IsingSlab(X, Yk, seed=seed, temp=1.5, nslabs=n, slab=k, layout=ig.LAYOUT_BALLOT) for k in range(n)])
+    try:
+        ring.init().sweep(2)
+        ring.set_temperature(-1.0)
+        ring.sweep(2)
+        assert all(s.current_layout() == ig.LAYOUT_DENSE for s in ring.slabs)
+        orc = oracle_mod.OracleLattice(X, Yk * n, seed=seed, temp=1.5).init().sweep(2)
+        orc.temp = -1.0
+        orc.sweep(2)
+        assert ring.count() == orc.count()
+        assert np.array_equal(np.concatenate([s.read(ig.BLACK) for s in ring.slabs]), orc.black)
+    finally:
+        ring.close()
+
+
+@pytest.mark.parametrize("layout", [ig.LAYOUT_BALLOT, ig.LAYOUT_DENSE])
+def test_ring_of_one_over_rccl(gpu, layout):
+    """ising_rank_*: the library's RCCL ring with one rank -- the slab's own edge rows travel through ncclSend/ncclRecv on
+    the comm stream into its halo rows (ring_halo), instead of the mirror rows the kernels keep for a plain single slab."""
+    import torch  # noqa: F401  (the RCCL copy torch ships is the one the process already holds)
+    assert ig.rccl_version() > 0
+    X, Y, seed, temp, sweeps = 8192, 64, 31, ig.CRIT_TEMP_F32, 7
+    ref_b, ref_w, ref_cnt, ref_bond = _single(X, Y, seed, temp, sweeps, layout=layout)
+    with ig.IsingSlab(X, Y, seed=seed, temp=temp, layout=layout, ring_halo=True) as s:
+        ring = ig.NativeRing(s).init()
+        ring.sweep(3).sweep(sweeps - 3)
+        ring.quiesce()
+        assert ring.count() == ref_cnt
+        assert ring.bond_equal() == ref_bond
+        assert np.array_equal(s.read(ig.BLACK), ref_b) and np.array_equal(s.read(ig.WHITE), ref_w)
+        ring.close()
+
+
+def test_ring_of_one_copy_transport_and_transport_switch(gpu):
+    X, Y, seed, temp, sweeps = 4096, 48, 8, 2.0, 5
+    ref_b, ref_w, ref_cnt, _ = _single(X, Y, seed, temp, sweeps)
+    with ig.IsingSlab(X, Y, seed=seed, temp=temp, ring_halo=True) as s:
+        ring = ig.SlabSet([s]).init()
+        assert ring.transport == ig.TRANSPORT_COPY
+        ring.sweep(sweeps)
+        assert ring.count() == ref_cnt
+        assert np.array_equal(s.read(ig.BLACK), ref_b) and np.array_equal(s.read(ig.WHITE), ref_w)
+        with pytest.raises(ig.IsingError):  # a plain sweep would need the kernels' mirror rows
+            s.sweep(1)
+
+
+def test_caller_buffers_are_validated(gpu):
+    import torch
+    small = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    with pytest.raises(ig.IsingError, match="needs"):
+        ig.IsingSlab(8192, 64, lattice_mem=small.data_ptr(), lattice_mem_bytes=small.numel())
+    host = np.zeros(1 << 20, dtype=np.uint8)
+    with pytest.raises(ig.IsingError):
+        ig.IsingSlab(8192, 64, lattice_mem=host.ctypes.data)
+    assert ig.required_bytes(8192, 64, ig.LAYOUT_BALLOT) * 4 == ig.required_bytes(8192, 64) == ig.required_bytes(8192, 64, ig.LAYOUT_NIBBLE)
+
+
+# ---- two or more GPUs (the driver's multi-GPU node; skipped on the 1-GPU box) ---------------------------------------
+def _ngpu():
+    return ig.device_count()
+
+
+@pytest.mark.parametrize("transport", [ig.TRANSPORT_RCCL, ig.TRANSPORT_COPY])
+def test_multi_device_ring_single_process(gpu, oracle_mod, transport):
+    n = min(_ngpu(), 4)
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs")
+    X, Yk, seed, temp, sweeps = 8192, 64, 2024, ig.CRIT_TEMP_F32, 6
+    orc = oracle_mod.OracleLattice(X, Yk * n, seed=seed, temp=temp).init().sweep(sweeps)
+    ring = ig.SlabSet([ig.IsingSlab(X, Yk, seed=seed, temp=temp, nslabs=n, slab=k, device=k) for k in range(n)])
+    try:
+        ring.set_transport(transport)
+        ring.init().sweep(sweeps)
+        assert ring.transport == transport
+        assert ring.count() == orc.count()
+        assert ring.bond_equal() == orc.bond_equal()
+        assert np.array_equal(np.concatenate([s.read(ig.BLACK) for s in ring.slabs]), orc.black)
+        assert np.array_equal(np.concatenate([s.read(ig.WHITE) for s in ring.slabs]), orc.white)
+    finally:
+        ring.close()
+
+
+@pytest.mark.parametrize("mode", ["native", "p2p", "allgather"])
+def test_multi_process_ring_over_nccl(gpu, mode):
+    """One process per GPU under torch.distributed.run, backend nccl (= RCCL): the library's own RCCL ring (NativeRing)
+    and the unmodified torch.distributed SlabRing (p2p and all-gather exchange), every rank against the CPU oracle."""
+    n = min(_ngpu(), 4)
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(ROOT, "tools", "ring_ranks_nccl.py"), mode],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("slab == oracle rows") == 2 * n and "!=" not in r.stdout, r.stdout[-3000:]
