@@ -182,6 +182,11 @@ int ising_bond_equal(ising_ctx *ctx, int64_t *A);
 int ising_read_packed(ising_ctx *ctx, int color, int64_t row0, int64_t nrows, uint64_t *dst_host);
 int ising_write_packed(ising_ctx *ctx, int color, int64_t row0, int64_t nrows, const uint64_t *src_host);
 
+/* The same rows at 1 bit per spin: X/64 32-bit words per row, one word per reference 128-bit vector (ulonglong2, :1716):
+ * bit k = nibble k of its word x (k < 16) / nibble k-16 of its word y.  A quarter of the packed size. */
+int ising_read_bits(ising_ctx *ctx, int color, int64_t row0, int64_t nrows, uint32_t *dst_host);
+int ising_write_bits(ising_ctx *ctx, int color, int64_t row0, int64_t nrows, const uint32_t *src_host);
+
 /* Device pointer to row 0 of a colour array of this slab in its DEVICE layout (see ising_layout) for zero-copy
  * consumers: nibble layout = [Y][X/32] 64-bit words exactly as the reference's buffers; dense = [Y][X/64] 32-bit words;
  * ballot = [Y][X/128] 64-bit words in the bit order described in ising_ballot.hip. */
@@ -192,6 +197,24 @@ int ising_layout(ising_ctx *ctx, int *layout);
 /* dumpLattice (optimized/main.cu:1140-1209): writes "<prefix><slab>.txt", one text row per lattice row, one
  * hex digit per spin, colours interleaved by row parity. */
 int ising_dump_text(ising_ctx *ctx, const char *prefix);
+
+/* ---- binary checkpoint (the reference has none: its only dump is the text file above).  One file for the
+ * whole lattice: a 136-byte header (X, total rows, seed, completed sweeps `it`, temperature, sub-lattice / coupling
+ * settings), all black rows then all white rows in GLOBAL row order at 1 bit per spin (the ising_read_bits format), and
+ * the number of up spins as a check -- so a file written by 8 slabs can be loaded into 1, 2, 4 ... slabs of the same
+ * lattice.  Couplings (-J) are not stored: they are regenerated from the seed.  ctxs[k] = slab k of n (n = 1: &ctx).
+ * save: blocking, writes "<path>.part" and renames.  load: checks geometry, seed and settings, fills every slab, verifies
+ * the up-spin count on the device; the caller then delivers the halo rows (ising_ring_exchange, both colours) and
+ * continues with first_it = *it + 1. */
+typedef struct ising_checkpoint_info {
+	int32_t X, Y_total, nslabs_written, XSL, YSL, use_J;
+	float temp, J_prob;
+	uint64_t seed;
+	int64_t it;
+} ising_checkpoint_info;
+int ising_checkpoint_info_read(const char *path, ising_checkpoint_info *info);
+int ising_ring_checkpoint_save(ising_ctx **ctxs, int n, const char *path, int64_t it);
+int ising_ring_checkpoint_load(ising_ctx **ctxs, int n, const char *path, int64_t *it);
 
 /* ---- the slab ring (replaces optimized/main.cu:1599-1658 managed memory + remote loads and the
  * cudaDeviceSynchronize barriers :1779-1784, :1800-1805).  Per colour half-sweep every slab updates its two edge rows

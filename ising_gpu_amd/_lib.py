@@ -71,6 +71,11 @@ PROTOTYPES = {
     "ising_bond_equal": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ising_read_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
     "ising_write_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
+    "ising_read_bits": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
+    "ising_write_bits": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
+    "ising_checkpoint_info_read": (C.c_int, [C.c_char_p, C.c_void_p]),
+    "ising_ring_checkpoint_save": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_int64]),
+    "ising_ring_checkpoint_load": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.POINTER(C.c_int64)]),
     "ising_device_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "ising_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "ising_dump_text": (C.c_int, [C.c_void_p, C.c_char_p]),
@@ -96,6 +101,26 @@ PROTOTYPES = {
 }
 
 
+def _share_torch_hip_runtime():
+    """A torch ROCm wheel ships its own libamdhip64.so (and librccl.so on top of it) with the same SONAME as the
+    system's.  libising_hip.so binds to whichever copy the process loaded first, so a process that loads this library
+    BEFORE torch ends up with two HIP runtimes -- and stream handles, events and allocation records of one mean nothing
+    to the other.  When torch is installed (it need not be imported) its copy is loaded first, so that the library,
+    torch and torch's RCCL share one runtime.  ISING_HIP_RUNTIME=system keeps the system runtime instead."""
+    if os.environ.get("ISING_HIP_RUNTIME", "auto") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001 -- best effort: the library still works on its own runtime
+        pass
+
+
 def load() -> C.CDLL:
     """Load libising_hip.so; raises IsingError (never falls back) when it is missing."""
     global _lib
@@ -103,6 +128,7 @@ def load() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise IsingError(f"{LIB_PATH} is missing: build it with `make -C ising_gpu_amd/csrc` "
                              "(or __graft_entry__.build()); there is no CPU fallback")
+        _share_torch_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported

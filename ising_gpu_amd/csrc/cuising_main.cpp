@@ -7,6 +7,9 @@
 //            --xsl/--ysl (independent periodic sub-lattices, optimized/main.cu:1423-1462),
 //            -c/--corr (two-point correlations file, optimized/main.cu:1072-1138).
 //            -J <PROB> (random anti-ferromagnetic bonds, optimized/main.cu:153-331, :575-618).
+// Build-side additions: --tsweep T0,T1,dT[,nequil[,nmeas[,stride]]] (temperature-sweep driver with <|m|>, <m^2>,
+//            susceptibility, Binder cumulant, energy and specific heat per point; --tsweep-anneal, --tsweep-out PREFIX),
+//            --checkpoint FILE / --resume FILE (binary checkpoint, ising_ring_checkpoint_*), --transport copy|rccl.
 #include "../../include/ising_hip.h"
 
 #include <getopt.h>
@@ -102,6 +105,100 @@ struct Ring {
 	}
 };
 
+// ---- temperature sweep (BASELINE config 5).  Every measurement is a pair of exact integers: M = up - down
+// and the bond sum E = 2N - 2A (A = ising_bond_equal: sum over black sites of aligned neighbours).  The moments are
+// accumulated exactly (128-bit integers; M^4 as long double of the exact M^2) and only the final ratios are floating
+// point:  chi = N (<m^2> - <|m|>^2) / T,  U4 = 1 - <m^4> / (3 <m^2>^2),  Cv = N (<e^2> - <e>^2) / T^2.
+struct TsweepSpec {
+	double t0 = 0, t1 = 0, dt = 0;
+	int nequil = 16, nmeas = 16, stride = 1;
+	bool anneal = false;
+	const char *out = nullptr;
+};
+
+std::string i128_str(__int128 v) {
+	if (v == 0) return "0";
+	const bool neg = v < 0;
+	unsigned __int128 u = neg ? -(unsigned __int128)v : (unsigned __int128)v;
+	std::string r;
+	while (u) { r.insert(r.begin(), (char)('0' + (int)(u % 10))); u /= 10; }
+	return neg ? "-" + r : r;
+}
+
+struct Moments {
+	__int128 sM = 0, sAbsM = 0, sM2 = 0, sE = 0, sE2 = 0;
+	long double sM4 = 0;
+	int n = 0;
+	void add(long long M, long long E) {
+		const __int128 m2 = (__int128)M * M;
+		sM += M; sAbsM += M < 0 ? -M : M; sM2 += m2; sM4 += (long double)m2 * (long double)m2;
+		sE += E; sE2 += (__int128)E * E; n++;
+	}
+};
+
+int run_tsweep(Ring &ring, const TsweepSpec &ts, size_t nspins, bool useJ) {
+	const int ndev = ring.n();
+	const int npts = (int)floor((ts.t1 - ts.t0) / ts.dt + 1e-9) + 1;
+	printf("\nTemperature sweep: %d points, T = %f .. %f step %f, %d equilibration + %d x %d measurement sweeps per point, %s\n",
+	       npts, ts.t0, ts.t0 + (npts - 1) * ts.dt, ts.dt, ts.nequil, ts.nmeas, ts.stride, ts.anneal ? "annealing" : "fresh start per point");
+	FILE *fcsv = nullptr, *fser = nullptr;
+	if (ts.out) {
+		fcsv = fopen((std::string(ts.out) + ".csv").c_str(), "w");
+		fser = fopen((std::string(ts.out) + ".series.csv").c_str(), "w");
+		if (!fcsv || !fser) { fprintf(stderr, "cannot open %s.csv / .series.csv for writing\n", ts.out); exit(EXIT_FAILURE); }
+		fprintf(fcsv, "temp_bits,temp,nmeas,first_iter,last_iter,sum_M,sum_absM,sum_M2,sum_M4,sum_E,sum_E2,m_abs,m2,chi,U4,e,Cv\n");
+		fprintf(fser, "temp_bits,iter,up,down,bond_equal\n");
+	}
+	const long double N = (long double)nspins;
+	long long total_sweeps = 0;
+	int it = 0;
+	const auto t0 = std::chrono::steady_clock::now();
+	for (int k = 0; k < npts; k++) {
+		const float temp = (float)(ts.t0 + k * ts.dt);
+		uint32_t tbits;
+		memcpy(&tbits, &temp, 4);
+		for (ising_ctx *c : ring.ctx) CHECK(ising_set_temperature(c, temp));
+		if (!ts.anneal || k == 0) {
+			for (ising_ctx *c : ring.ctx) CHECK(ising_init_lattice(c));
+			CHECK(ising_ring_exchange(ring.ctx.data(), ndev, ISING_BLACK));
+			CHECK(ising_ring_exchange(ring.ctx.data(), ndev, ISING_WHITE));
+			if (useJ && k == 0) CHECK(ising_ring_init_couplings(ring.ctx.data(), ndev));
+			it = 0;
+		}
+		if (ts.nequil) CHECK(ising_ring_sweep(ring.ctx.data(), ndev, it + 1, ts.nequil));
+		it += ts.nequil;
+		Moments mo;
+		const int first = it + ts.stride;
+		for (int m = 0; m < ts.nmeas; m++) {
+			CHECK(ising_ring_sweep(ring.ctx.data(), ndev, it + 1, ts.stride));
+			it += ts.stride;
+			unsigned long long up = 0, dw = 0;
+			ring.count(&up, &dw);
+			const long long A = ring.bond_equal();
+			mo.add((long long)up - (long long)dw, 2 * (long long)nspins - 2 * A);
+			if (fser) fprintf(fser, "%u,%d,%llu,%llu,%lld\n", tbits, it, up, dw, A);
+		}
+		total_sweeps += ts.nequil + (long long)ts.nmeas * ts.stride;
+		const long double n = mo.n;
+		const long double mabs = (long double)mo.sAbsM / (n * N), m2 = (long double)mo.sM2 / (n * N * N), m4 = mo.sM4 / (n * N * N * N * N);
+		const long double e1 = (long double)mo.sE / (n * N), e2 = (long double)mo.sE2 / (n * N * N);
+		const long double chi = N * (m2 - mabs * mabs) / temp, u4 = 1.0L - m4 / (3.0L * m2 * m2), cv = N * (e2 - e1 * e1) / ((long double)temp * temp);
+		printf("T = %f: <|m|> = %9.6f, <m^2> = %E, chi = %E, U4 = %9.6f, <e> = %9.6f, Cv = %E (iters %d-%d)\n", temp, (double)mabs, (double)m2,
+		       (double)chi, (double)u4, (double)e1, (double)cv, first, it);
+		if (fcsv)
+			fprintf(fcsv, "%u,%.9g,%d,%d,%d,%s,%s,%s,%.21Lg,%s,%s,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g\n", tbits, (double)temp, mo.n, first, it,
+			        i128_str(mo.sM).c_str(), i128_str(mo.sAbsM).c_str(), i128_str(mo.sM2).c_str(), mo.sM4, i128_str(mo.sE).c_str(),
+			        i128_str(mo.sE2).c_str(), (double)mabs, (double)m2, (double)chi, (double)u4, (double)e1, (double)cv);
+	}
+	CHECK(ising_ring_synchronize(ring.ctx.data(), ndev));
+	const double et = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	if (fcsv) fclose(fcsv);
+	if (fser) fclose(fser);
+	printf("\nTemperature sweep: %lld update steps in %E ms, %.2lf flips/ns (initialisation and measurements included)\n\n", total_sweeps, et,
+	       (double)nspins * (double)total_sweeps / (et * 1.0E+6));
+	return 0;
+}
+
 } // namespace
 
 int main(int argc, char **argv) {
@@ -117,7 +214,10 @@ int main(int argc, char **argv) {
 	int useGenHamilt = 0;
 	float hamiltPerc1 = 0.0f;
 	std::vector<int> devmap;
-	int layout = ISING_LAYOUT_AUTO;
+	int layout = ISING_LAYOUT_AUTO, transport = ISING_TRANSPORT_AUTO;
+	TsweepSpec ts;
+	bool doTsweep = false, seedGiven = false;
+	const char *ckptOut = nullptr, *ckptIn = nullptr;
 
 	static struct option long_options[] = {
 	    {"x", required_argument, 0, 'x'},      {"y", required_argument, 0, 'y'},     {"nit", required_argument, 0, 'n'},
@@ -126,7 +226,9 @@ int main(int argc, char **argv) {
 	    {"update", required_argument, 0, 'u'}, {"magn", required_argument, 0, 'm'},  {"exppr", no_argument, 0, 'e'},
 	    {"corr", no_argument, 0, 'c'},         {"J", required_argument, 0, 'J'},     {"xsl", required_argument, 0, 1},
 	    {"ysl", required_argument, 0, 2},      {"help", required_argument, 0, 'h'},  {"energy", no_argument, 0, 3},
-	    {"devmap", required_argument, 0, 4},   {"layout", required_argument, 0, 5},  {0, 0, 0, 0}};
+	    {"devmap", required_argument, 0, 4},   {"layout", required_argument, 0, 5},  {"tsweep", required_argument, 0, 6},
+	    {"tsweep-anneal", no_argument, 0, 7},  {"tsweep-out", required_argument, 0, 8}, {"checkpoint", required_argument, 0, 9},
+	    {"resume", required_argument, 0, 10},  {"transport", required_argument, 0, 11}, {0, 0, 0, 0}};
 	while (1) {
 		int option_index = 0;
 		const int och = getopt_long(argc, argv, "x:y:n:ohs:d:a:t:p:u:m:ecJ:r:", long_options, &option_index);
@@ -140,6 +242,7 @@ int main(int argc, char **argv) {
 		case 'h': usage(argv[0]); break;
 		case 's':
 			seed = atoll(optarg);
+			seedGiven = true;
 			if (seed == 0) seed = ((getpid() * rand()) & 0x7FFFFFFFF); // optimized/main.cu:1331-1333
 			break;
 		case 'd': ndev = atoi(optarg); break;
@@ -175,11 +278,45 @@ int main(int argc, char **argv) {
 			else if (!strcmp(optarg, "nibble")) layout = ISING_LAYOUT_NIBBLE;
 			else { fprintf(stderr, "error: --layout takes ballot, dense or nibble\n"); exit(EXIT_FAILURE); }
 			break;
+		case 6: {
+			double v[6] = {0, 0, 0, 16, 16, 1};
+			int nv = 0;
+			for (char *tok = strtok(optarg, ","); tok && nv < 6; tok = strtok(NULL, ",")) v[nv++] = atof(tok);
+			if (nv < 3 || v[2] <= 0 || v[1] < v[0] || v[3] < 0 || v[4] < 1 || v[5] < 1) {
+				fprintf(stderr, "error: --tsweep takes T0,T1,DT[,NEQUIL[,NMEAS[,STRIDE]]] with T1 >= T0, DT > 0\n");
+				exit(EXIT_FAILURE);
+			}
+			ts.t0 = v[0]; ts.t1 = v[1]; ts.dt = v[2]; ts.nequil = (int)v[3]; ts.nmeas = (int)v[4]; ts.stride = (int)v[5];
+			doTsweep = true;
+		} break;
+		case 7: ts.anneal = true; break;
+		case 8: ts.out = optarg; break;
+		case 9: ckptOut = optarg; break;
+		case 10: ckptIn = optarg; break;
+		case 11:
+			if (!strcmp(optarg, "copy")) transport = ISING_TRANSPORT_COPY;
+			else if (!strcmp(optarg, "rccl")) transport = ISING_TRANSPORT_RCCL;
+			else if (!strcmp(optarg, "auto")) transport = ISING_TRANSPORT_AUTO;
+			else { fprintf(stderr, "error: --transport takes copy, rccl or auto\n"); exit(EXIT_FAILURE); }
+			break;
 		case '?': exit(EXIT_FAILURE);
 		default: fprintf(stderr, "unknown option: %c\n", och); exit(EXIT_FAILURE);
 		}
 	}
 
+	ising_checkpoint_info ck;
+	memset(&ck, 0, sizeof(ck));
+	if (ckptIn) { // geometry, seed and temperature default to the checkpoint's
+		if (doTsweep) { fprintf(stderr, "error: --resume and --tsweep exclude each other\n"); exit(EXIT_FAILURE); }
+		CHECK(ising_checkpoint_info_read(ckptIn, &ck));
+		if (ndev < 1 || (ck.Y_total % ndev)) { fprintf(stderr, "error: %d checkpoint rows do not split over %d devices\n", ck.Y_total, ndev); exit(EXIT_FAILURE); }
+		if (!X) X = ck.X;
+		if (!Y) Y = ck.Y_total / ndev;
+		if (!seedGiven) seed = ck.seed;
+		if (temp == -1.0f && alpha == -1.0f) temp = ck.temp;
+		if (!useSubLatt && ck.XSL) { useSubLatt = 1; XSL = ck.XSL; YSL = ck.YSL; }
+		if (!useGenHamilt && ck.use_J) { useGenHamilt = 1; hamiltPerc1 = ck.J_prob; }
+	}
 	// defaults and divisibility rules, optimized/main.cu:1395-1421
 	if (!X || !Y) {
 		if (!X) X = (Y && !(Y % X_MULT)) ? Y : X_MULT;
@@ -211,7 +348,11 @@ int main(int argc, char **argv) {
 	}
 	if (temp == -1.0f) temp = (alpha == -1.0f) ? ALPHA_DEF * ISING_CRIT_TEMP : alpha * ISING_CRIT_TEMP; // :1465-1471
 	if (printExp && printFreq) printFreq = 0;
-	if (printExp) generate_times(nsteps, printExpSteps);
+	const int j0 = ckptIn ? (int)ck.it : 0, jend = j0 + nsteps; // --resume: iterations continue where the checkpoint stopped
+	if (printExp) {
+		generate_times(jend, printExpSteps);
+		while (printExpCur < MAX_EXP_TIME - 1 && (long long)printExpSteps[printExpCur] + 1 <= j0) printExpCur++;
+	}
 	if (ndev < 1) { fprintf(stderr, "error: need at least one device\n"); exit(EXIT_FAILURE); }
 
 	int visible = 0;
@@ -284,14 +425,29 @@ int main(int argc, char **argv) {
 		snprintf(cname, sizeof(cname), "corr_%dx%d_T_%f_%llu", Y, X, temp, seed);
 		remove(cname);
 	}
-	for (ising_ctx *c : ring.ctx) CHECK(ising_init_lattice(c));
-	if (ndev > 1) {
-		CHECK(ising_ring_exchange(ring.ctx.data(), ndev, ISING_BLACK));
-		CHECK(ising_ring_exchange(ring.ctx.data(), ndev, ISING_WHITE));
-	}
-	if (useGenHamilt) CHECK(ising_ring_init_couplings(ring.ctx.data(), ndev)); // optimized/main.cu:1729-1742
-
+	if (transport != ISING_TRANSPORT_AUTO) CHECK(ising_ring_set_transport(ring.ctx.data(), ndev, transport));
 	const size_t nspins = llen * SPIN_X_WORD;
+	if (doTsweep) {
+		run_tsweep(ring, ts, nspins, useGenHamilt);
+		for (ising_ctx *c : ring.ctx) ising_destroy(c);
+		return 0;
+	}
+	if (ckptIn) {
+		int64_t it = 0;
+		CHECK(ising_ring_checkpoint_load(ring.ctx.data(), ndev, ckptIn, &it));
+		printf("\nResumed from %s: %lld iterations done\n", ckptIn, (long long)it);
+	} else {
+		for (ising_ctx *c : ring.ctx) CHECK(ising_init_lattice(c));
+	}
+	CHECK(ising_ring_exchange(ring.ctx.data(), ndev, ISING_BLACK));
+	CHECK(ising_ring_exchange(ring.ctx.data(), ndev, ISING_WHITE));
+	if (useGenHamilt) CHECK(ising_ring_init_couplings(ring.ctx.data(), ndev)); // optimized/main.cu:1729-1742
+	if (ndev > 1) {
+		int tr = 0;
+		CHECK(ising_ring_transport(ring.ctx.data(), ndev, &tr));
+		fprintf(stderr, "halo rows travel by %s on a second stream per GPU\n", tr == ISING_TRANSPORT_RCCL ? "RCCL send/recv" : "peer-to-peer copies");
+	}
+
 	unsigned long long cntPos = 0, cntNeg = 0;
 	ring.count(&cntPos, &cntNeg);
 	printf("\nInitial magnetization: %9.6lf, up_s: %12llu, dw_s: %12llu\n",
@@ -326,11 +482,11 @@ int main(int argc, char **argv) {
 	// hot loop, optimized/main.cu:1756-1871.  Sweeps between two host-side events (print, ramp) are enqueued as
 	// one batch; the launches are asynchronous, so the GPU never waits for the host.
 	const auto t0 = std::chrono::steady_clock::now();
-	int j = 0;
-	while (j < nsteps) {
-		int next = nsteps; // first iteration index (1-based count) at which the host must look at the lattice
+	int j = j0;
+	while (j < jend) {
+		int next = jend; // first iteration index (1-based count) at which the host must look at the lattice
 		if (printFreq) next = std::min(next, (j / printFreq + 1) * printFreq);
-		if (printExp) next = std::min<long long>(next, (long long)printExpSteps[printExpCur] + 1 > j ? (long long)printExpSteps[printExpCur] + 1 : nsteps);
+		if (printExp) next = std::min<long long>(next, (long long)printExpSteps[printExpCur] + 1 > j ? (long long)printExpSteps[printExpCur] + 1 : jend);
 		if (tempUpdFreq) next = std::min(next, (j / tempUpdFreq + 1) * tempUpdFreq);
 		if (next <= j) next = j + 1;
 		CHECK(ising_ring_sweep(ring.ctx.data(), ndev, j + 1, next - j));
@@ -361,14 +517,19 @@ int main(int argc, char **argv) {
 	if (printEnergy) printf("Final   energy/spin:   %9.6lf\n\n", ring.energy(nspins));
 
 	// optimized/main.cu:1884-1890 (1.5 bytes per flip + the 20-byte table per reference block)
-	printf("Kernel execution time for %d update steps: %E ms, %.2lf flips/ns (BW: %.2lf GB/s)\n", j, et,
-	       (double)nspins * j / (et * 1.0E+6),
-	       (2ull * j * (8.0 * ((llen / 2) + (llen / 2) + (llen / 2)) + 4.0 * 5 * gridX * gridY) / 1.0E+9) / (et / 1.0E+3));
+	const int jrun = j - j0;
+	printf("Kernel execution time for %d update steps: %E ms, %.2lf flips/ns (BW: %.2lf GB/s)\n", jrun, et,
+	       (double)nspins * jrun / (et * 1.0E+6),
+	       (2ull * jrun * (8.0 * ((llen / 2) + (llen / 2) + (llen / 2)) + 4.0 * 5 * gridX * gridY) / 1.0E+9) / (et / 1.0E+3));
 
 	if (dumpOut) {
 		char fname[256];
 		snprintf(fname, sizeof(fname), "lattice_%dx%d_T_%f_IT_%08d_", Y, X, temp, j);
 		ring.dump(fname);
+	}
+	if (ckptOut) {
+		CHECK(ising_ring_checkpoint_save(ring.ctx.data(), ndev, ckptOut, j));
+		printf("Checkpoint written to %s (%d iterations done)\n", ckptOut, j);
 	}
 	for (ising_ctx *c : ring.ctx) ising_destroy(c);
 	return 0;

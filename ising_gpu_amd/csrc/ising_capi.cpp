@@ -57,22 +57,22 @@ uint64_t draw_prefix(float p, bool le) {
 	return hi;
 }
 
+} // namespace
+
 // ballot layout: the dense-order image is allocated by the first call that needs one
-int ballot_tmp(ising_ctx *c) {
+int ising_host::ballot_tmp(ising_ctx *c) {
 	if (!c->d_tmp) HIP_TRY(hipMalloc((void **)&c->d_tmp, c->alloc_words() * sizeof(uint64_t)));
 	return ISING_OK;
 }
 
 // ballot layout: convert rows [row_lo, row_hi) of `color` (rows -1 and Y are the halo rows) between d_lat and d_tmp
-int ballot_rows(ising_ctx *c, int color, long long row_lo, long long row_hi, bool to_dense) {
+int ising_host::ballot_rows(ising_ctx *c, int color, long long row_lo, long long row_hi, bool to_dense) {
 	if (int rc = ballot_tmp(c)) return rc;
 	uint64_t *lat = c->lat(color) + row_lo * c->lld, *tmp = c->tmp(color) + row_lo * c->lld;
 	if (to_dense) HIP_TRY(ising::launch_ballot_to_dense(lat, reinterpret_cast<uint32_t *>(tmp), c->gx, row_hi - row_lo, c->stream));
 	else HIP_TRY(ising::launch_dense_to_ballot(reinterpret_cast<const uint32_t *>(tmp), lat, c->gx, row_hi - row_lo, c->stream));
 	return ISING_OK;
 }
-
-} // namespace
 
 // ballot layout: refresh the dense-order image (both colours, halo rows included)
 int ising_host::ballot_image(ising_ctx *c) {
@@ -142,33 +142,6 @@ void build_rank_table(const ising_ctx *c, uint8_t *tab) {
 		const bool ok = ok3 && ok4;
 		if (c->dense) tab[h] = ok ? (uint8_t)(a | (b << 1)) : (uint8_t)2; // fields (c3, c4); "c4 without c3" marks undecided
 		else tab[h] = ok ? (uint8_t)(a + b) : (uint8_t)4;
-	}
-}
-
-// Dense device rows <-> the reference's packed rows, on the host (the C-ABI boundary always speaks the packed layout).
-// One dense 32-bit word = one reference 128-bit vector: bit k -> nibble k of word x (k < 16) / nibble k-16 of word y.
-void dense_to_packed(const uint32_t *dense, uint64_t *packed, size_t nvec) {
-	for (size_t v = 0; v < nvec; v++) {
-		const uint32_t d = dense[v];
-		uint64_t x = 0, y = 0;
-		for (int k = 0; k < 16; k++) {
-			x |= (uint64_t)((d >> k) & 1u) << (4 * k);
-			y |= (uint64_t)((d >> (16 + k)) & 1u) << (4 * k);
-		}
-		packed[2 * v] = x;
-		packed[2 * v + 1] = y;
-	}
-}
-
-void packed_to_dense(const uint64_t *packed, uint32_t *dense, size_t nvec) {
-	for (size_t v = 0; v < nvec; v++) {
-		const uint64_t x = packed[2 * v], y = packed[2 * v + 1];
-		uint32_t d = 0;
-		for (int k = 0; k < 16; k++) {
-			d |= (uint32_t)((x >> (4 * k)) & 1u) << k;
-			d |= (uint32_t)((y >> (4 * k)) & 1u) << (16 + k);
-		}
-		dense[v] = d;
 	}
 }
 
@@ -568,62 +541,6 @@ int ising_bond_equal(ising_ctx *c, int64_t *A) {
 	return ISING_OK;
 }
 
-static int check_rows(ising_ctx *c, int color, int64_t row0, int64_t nrows, const void *host) {
-	if (!c || !host) return fail(ISING_E_ARG, "null argument");
-	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
-	if (row0 < 0 || nrows < 0 || row0 + nrows > c->cfg.Y) return fail(ISING_E_ARG, "rows [%lld,%lld) outside slab of %d rows", (long long)row0, (long long)(row0 + nrows), c->cfg.Y);
-	return ISING_OK;
-}
-
-int ising_read_packed(ising_ctx *c, int color, int64_t row0, int64_t nrows, uint64_t *dst_host) {
-	if (int rc = check_rows(c, color, row0, nrows, dst_host)) return rc;
-	if (int rc = bind(c)) return rc;
-	if (c->dense) {
-		const size_t nvec = (size_t)nrows * c->lld * 2; // 32-bit words = reference vectors
-		std::vector<uint32_t> tmp(nvec);
-		if (c->ballot) if (int rc = ballot_rows(c, color, row0, row0 + nrows, true)) return rc;
-		const uint64_t *img = c->ballot ? c->tmp(color) : c->lat(color);
-		HIP_TRY(hipMemcpyAsync(tmp.data(), img + (size_t)row0 * c->lld, nvec * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-		HIP_TRY(hipStreamSynchronize(c->stream));
-		dense_to_packed(tmp.data(), dst_host, nvec);
-		return ISING_OK;
-	}
-	HIP_TRY(hipMemcpyAsync(dst_host, c->lat(color) + (size_t)row0 * c->lld, (size_t)nrows * c->lld * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));
-	return ISING_OK;
-}
-
-int ising_write_packed(ising_ctx *c, int color, int64_t row0, int64_t nrows, const uint64_t *src_host) {
-	if (int rc = check_rows(c, color, row0, nrows, src_host)) return rc;
-	if (int rc = bind(c)) return rc;
-	std::vector<uint32_t> tmp;
-	const void *src = src_host;
-	size_t row_bytes = (size_t)c->lld * sizeof(uint64_t);
-	if (c->dense) {
-		tmp.resize((size_t)nrows * c->lld * 2);
-		packed_to_dense(src_host, tmp.data(), tmp.size());
-		src = tmp.data();
-	}
-	if (c->ballot) if (int rc = ballot_tmp(c)) return rc;
-	uint64_t *img = c->ballot ? c->tmp(color) : c->lat(color); // ballot layout: through the dense-order image
-	HIP_TRY(hipMemcpyAsync(img + (size_t)row0 * c->lld, src, (size_t)nrows * row_bytes, hipMemcpyHostToDevice, c->stream));
-	if (c->ballot) if (int rc = ballot_rows(c, color, row0, row0 + nrows, false)) return rc;
-	// single slab: the halo rows mirror the opposite edge rows
-	if (c->wrap && nrows > 0) {
-		const char *b = static_cast<const char *>(src);
-		if (row0 == 0) {
-			HIP_TRY(hipMemcpyAsync(img + c->color_words, b, row_bytes, hipMemcpyHostToDevice, c->stream));
-			if (c->ballot) if (int rc = ballot_rows(c, color, c->cfg.Y, (long long)c->cfg.Y + 1, false)) return rc;
-		}
-		if (row0 + nrows == c->cfg.Y) {
-			HIP_TRY(hipMemcpyAsync(img - c->lld, b + (size_t)(nrows - 1) * row_bytes, row_bytes, hipMemcpyHostToDevice, c->stream));
-			if (c->ballot) if (int rc = ballot_rows(c, color, -1, 0, false)) return rc;
-		}
-	}
-	HIP_TRY(hipStreamSynchronize(c->stream));
-	return ISING_OK;
-}
-
 int ising_layout(ising_ctx *c, int *layout) {
 	if (!c || !layout) return fail(ISING_E_ARG, "null argument");
 	*layout = c->ballot ? ISING_LAYOUT_BALLOT : (c->dense ? ISING_LAYOUT_DENSE : ISING_LAYOUT_NIBBLE);
@@ -635,37 +552,6 @@ int ising_device_ptr(ising_ctx *c, int color, void **ptr, size_t *bytes) {
 	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
 	*ptr = c->lat(color);
 	if (bytes) *bytes = c->color_words * sizeof(uint64_t);
-	return ISING_OK;
-}
-
-int ising_dump_text(ising_ctx *c, const char *prefix) {
-	if (!c || !prefix) return fail(ISING_E_ARG, "null argument");
-	if (int rc = bind(c)) return rc;
-	const size_t pw = (size_t)c->cfg.Y * c->lld_packed; // packed words per colour
-	std::vector<uint64_t> h(2 * pw);
-	for (int color = 0; color < 2; color++)
-		if (int rc = ising_read_packed(c, color, 0, c->cfg.Y, h.data() + color * pw)) return rc;
-	char fname[512];
-	snprintf(fname, sizeof(fname), "%s%d.txt", prefix, c->cfg.slab); // optimized/main.cu:1157,:1185
-	FILE *fp = fopen(fname, "w");
-	if (!fp) return fail(ISING_E_ARG, "cannot open %s for writing", fname);
-	static const char hex[] = "0123456789ABCDEF";
-	std::string line((size_t)c->cfg.X + 1, '\n');
-	const uint64_t *b = h.data(), *w = h.data() + pw;
-	const int lp = c->lld_packed;
-	for (int i = 0; i < c->cfg.Y; i++) {
-		char *q = &line[0];
-		// local row parity decides the interleave, as in the reference's per-device loop (optimized/main.cu:1188-1201)
-		for (int j = 0; j < lp; j++) {
-			const uint64_t vb = b[(size_t)i * lp + j], vw = w[(size_t)i * lp + j];
-			for (int k = 0; k < 64; k += 4) {
-				const char cb = hex[(vb >> k) & 0xF], cw = hex[(vw >> k) & 0xF];
-				if (i & 1) { *q++ = cw; *q++ = cb; } else { *q++ = cb; *q++ = cw; }
-			}
-		}
-		fwrite(line.data(), 1, line.size(), fp);
-	}
-	fclose(fp);
 	return ISING_OK;
 }
 
@@ -727,7 +613,9 @@ int ising_init_couplings(ising_ctx *c) {
 }
 
 int ising_read_couplings(ising_ctx *c, int which, int64_t row0, int64_t nrows, uint64_t *dst_host) {
-	if (int rc = check_rows(c, which, row0, nrows, dst_host)) return rc;
+	if (!c || !dst_host) return fail(ISING_E_ARG, "null argument");
+	if (which != ISING_BLACK && which != ISING_WHITE) return fail(ISING_E_ARG, "bad coupling array %d", which);
+	if (row0 < 0 || nrows < 0 || row0 + nrows > c->cfg.Y) return fail(ISING_E_ARG, "rows [%lld,%lld) outside slab of %d rows", (long long)row0, (long long)(row0 + nrows), c->cfg.Y);
 	if (!c->cfg.use_J) return fail(ISING_E_STATE, "couplings are not enabled (use_J)");
 	if (int rc = bind(c)) return rc;
 	const size_t nw = (size_t)nrows * c->lld_packed;

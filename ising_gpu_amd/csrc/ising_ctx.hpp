@@ -90,6 +90,9 @@ bool needs_generic(const ising_ctx *c);
 int ballot_leave(ising_ctx *c);
 // ballot layout: refresh the dense-order image d_tmp (both colours, halo rows included)
 int ballot_image(ising_ctx *c);
+// ballot layout: allocate d_tmp; convert rows [row_lo, row_hi) of `color` between d_lat and d_tmp (rows -1 / Y = halo rows)
+int ballot_tmp(ising_ctx *c);
+int ballot_rows(ising_ctx *c, int color, long long row_lo, long long row_hi, bool to_dense);
 // makes the slab's stream wait until the halo rows of `color` delivered by the ring are in place
 int halo_ready(ising_ctx *c, int color);
 // called by ising_destroy

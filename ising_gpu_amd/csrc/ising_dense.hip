@@ -391,9 +391,58 @@ __global__ void __launch_bounds__(THREADS) ham_planes_k(uint4 *__restrict__ ham,
 	}
 }
 
+// ---- boundary format.  The C-ABI speaks the reference's packed layout (16 spins per 64-bit word, bit 0 of each nibble);
+// one dense 32-bit word is one reference 128-bit vector: bit k -> nibble k of word x (k < 16) / nibble k-16 of word y.
+__device__ __forceinline__ unsigned long long nibbles_of(uint32_t bits16) { // 16 bits -> 16 nibbles
+	unsigned long long x = bits16 & 0xFFFFu;
+	x = (x | (x << 24)) & 0x000000FF000000FFull;
+	x = (x | (x << 12)) & 0x000F000F000F000Full;
+	x = (x | (x << 6)) & 0x0303030303030303ull;
+	x = (x | (x << 3)) & 0x1111111111111111ull;
+	return x;
+}
+__device__ __forceinline__ uint32_t bits_of(unsigned long long x) { // bit 0 of each of 16 nibbles -> 16 bits
+	x &= 0x1111111111111111ull;
+	x = (x | (x >> 3)) & 0x0303030303030303ull;
+	x = (x | (x >> 6)) & 0x000F000F000F000Full;
+	x = (x | (x >> 12)) & 0x000000FF000000FFull;
+	x = (x | (x >> 24)) & 0xFFFFull;
+	return (uint32_t)x;
+}
+
+__global__ void __launch_bounds__(THREADS) dense_to_packed_k(const uint32_t *__restrict__ dense, ulonglong2 *__restrict__ packed, size_t nvec) {
+	for (size_t v = (size_t)blockIdx.x * THREADS + threadIdx.x; v < nvec; v += (size_t)gridDim.x * THREADS) {
+		const uint32_t d = dense[v];
+		packed[v] = make_ulonglong2(nibbles_of(d), nibbles_of(d >> 16));
+	}
+}
+
+__global__ void __launch_bounds__(THREADS) packed_to_dense_k(const ulonglong2 *__restrict__ packed, uint32_t *__restrict__ dense, size_t nvec) {
+	for (size_t v = (size_t)blockIdx.x * THREADS + threadIdx.x; v < nvec; v += (size_t)gridDim.x * THREADS) {
+		const ulonglong2 p = packed[v];
+		dense[v] = bits_of(p.x) | (bits_of(p.y) << 16);
+	}
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------------------------- launchers
+hipError_t launch_dense_to_packed(const uint32_t *dense, uint64_t *packed, size_t nvec, hipStream_t stream) {
+	if (!nvec) return hipSuccess;
+	size_t blocks = (nvec + THREADS - 1) / THREADS;
+	if (blocks > 16384) blocks = 16384;
+	hipLaunchKernelGGL(dense_to_packed_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, dense, reinterpret_cast<ulonglong2 *>(packed), nvec);
+	return hipGetLastError();
+}
+
+hipError_t launch_packed_to_dense(const uint64_t *packed, uint32_t *dense, size_t nvec, hipStream_t stream) {
+	if (!nvec) return hipSuccess;
+	size_t blocks = (nvec + THREADS - 1) / THREADS;
+	if (blocks > 16384) blocks = 16384;
+	hipLaunchKernelGGL(packed_to_dense_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, reinterpret_cast<const ulonglong2 *>(packed), dense, nvec);
+	return hipGetLastError();
+}
+
 hipError_t launch_dense_update(const UpdateParams &p, int mode, hipStream_t stream) {
 	if (p.nunits <= 0) return hipSuccess;
 	const int per_block = dense_threads(mode) / GROUP;

@@ -90,6 +90,10 @@ hipError_t launch_dense_bond_equal(const BondParams &p, hipStream_t stream);
 hipError_t launch_dense_pack_bits(const uint64_t *black, const uint64_t *white, int wpr, int Y, uint32_t row_base, uint32_t *bits,
                                   hipStream_t stream);
 
+// boundary format: `nvec` dense 32-bit words (one reference 128-bit vector each) <-> 2 * nvec packed 64-bit words
+hipError_t launch_dense_to_packed(const uint32_t *dense, uint64_t *packed, size_t nvec, hipStream_t stream);
+hipError_t launch_packed_to_dense(const uint64_t *packed, uint32_t *dense, size_t nvec, hipStream_t stream);
+
 // ballot layout (1 bit per spin in wave-ballot order, ising_ballot.hip): integer-threshold update, conversions
 hipError_t launch_ballot_update(const UpdateParams &p, hipStream_t stream);
 hipError_t launch_ballot_init(const InitParams &p, hipStream_t stream);

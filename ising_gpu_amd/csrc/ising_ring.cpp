@@ -42,7 +42,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------ RCCL at run time
 struct RcclApi {
 	void *handle = nullptr;
-	std::string error;
+	std::string error, path;
 	decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
 	decltype(&ncclCommInitRank) CommInitRank = nullptr;
 	decltype(&ncclCommInitAll) CommInitAll = nullptr;
@@ -67,10 +67,25 @@ RcclApi *rccl() {
 	static bool tried = false;
 	if (tried) return api.handle ? &api : nullptr;
 	tried = true;
-	// a copy the process has already loaded (e.g. the one torch ships) wins: one RCCL per process
-	const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-	void *h = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD);
+	// RCCL must sit on the SAME HIP runtime as this library: a process can hold two (torch wheels ship their own
+	// libamdhip64.so + librccl.so next to the system's), and streams / events of one mean nothing to the other.  So
+	// the first candidates are the librccl files next to the libamdhip64 this library is bound to.
+	void *h = nullptr;
 	if (const char *env = getenv("ISING_RCCL_LIB")) h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+	Dl_info info;
+	if (!h && dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &info) && info.dli_fname) {
+		std::string dir(info.dli_fname);
+		const size_t slash = dir.rfind('/');
+		if (slash != std::string::npos) {
+			dir.resize(slash + 1);
+			for (const char *leaf : {"librccl.so.1", "librccl.so"}) {
+				if (h) break;
+				h = dlopen((dir + leaf).c_str(), RTLD_NOW | RTLD_LOCAL);
+				if (h) api.path = dir + leaf;
+			}
+		}
+	}
+	const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
 	for (int i = 0; !h && i < 3; i++) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
 	if (!h) {
 		const char *e = dlerror();

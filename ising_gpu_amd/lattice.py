@@ -165,6 +165,17 @@ class IsingSlab:
         rows = np.ascontiguousarray(rows, dtype=np.uint64)
         check(self._lib.ising_write_packed(self._h, color, row0, rows.shape[0], rows.ctypes.data_as(C.c_void_p)))
 
+    def read_bits(self, color: int, row0: int = 0, nrows: int | None = None) -> np.ndarray:
+        """Rows at 1 bit per spin: X/64 uint32 per row, one word per reference 128-bit vector (ising_read_bits)."""
+        nrows = self.Y - row0 if nrows is None else nrows
+        out = np.empty((nrows, self.X // 64), dtype=np.uint32)
+        check(self._lib.ising_read_bits(self._h, color, row0, nrows, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def write_bits(self, color: int, rows: np.ndarray, row0: int = 0):
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        check(self._lib.ising_write_bits(self._h, color, row0, rows.shape[0], rows.ctypes.data_as(C.c_void_p)))
+
     def dump(self, prefix: str):
         check(self._lib.ising_dump_text(self._h, prefix.encode()))
 
@@ -285,6 +296,17 @@ class SlabSet:
     def set_temperature(self, temp: float):
         for s in self.slabs:
             s.set_temperature(temp)
+
+    def checkpoint_save(self, path: str):
+        check(self._lib.ising_ring_checkpoint_save(self._arr, self.n, str(path).encode(), self.it))
+
+    def checkpoint_load(self, path: str):
+        it = C.c_int64()
+        check(self._lib.ising_ring_checkpoint_load(self._arr, self.n, str(path).encode(), C.byref(it)))
+        self.it = int(it.value)
+        for s in self.slabs:
+            s.it = self.it
+        return self.exchange()
 
     def close(self):
         for s in self.slabs:

@@ -1,0 +1,154 @@
+"""the temperature-sweep driver of cuIsing (susceptibility, Binder cumulant, specific heat from exact
+integer moments) against the oracle's committed config-5 series, and the binary checkpoint (resume == uninterrupted)."""
+import csv
+import json
+import os
+import subprocess
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+import ising_gpu_amd as ig
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CLI = os.path.join(os.path.dirname(ig.LIB_PATH), "cuIsing")
+
+
+def run(args, cwd=None):
+    r = subprocess.run([CLI] + [str(a) for a in args], capture_output=True, text=True, cwd=cwd, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def test_tsweep_config5_against_oracle_series(gpu, tmp_path):
+    """BASELINE config 5 in ONE process: 8192^2, seed 1234, T = 1.50 .. 3.00 step 0.05 (31 points), per point a fresh
+    lattice, 4 equilibration sweeps and 4 measurements 4 sweeps apart = the oracle's golden points at sweeps 4/8/12/16
+    (tests/golden/tsweep_8192.json).  Every (up, down, bond) triple must match; the derived averages are recomputed here
+    from the golden integers in exact rational arithmetic."""
+    fx = json.load(open(os.path.join(GOLD, "tsweep_8192.json")))
+    out = run(["-x", fx["X"], "-y", fx["Y"], "-s", fx["seed"], "--tsweep", "1.5,3.0,0.05,4,4,4", "--tsweep-out", "ts"], cwd=tmp_path)
+    assert "Temperature sweep: 31 points" in out
+    series = list(csv.DictReader(open(tmp_path / "ts.series.csv")))
+    points = list(csv.DictReader(open(tmp_path / "ts.csv")))
+    assert len(points) == 31 and len(series) == 31 * 4
+    N = fx["X"] * fx["Y"]
+    for k, ser in enumerate(fx["series"]):
+        rows = series[4 * k:4 * k + 4]
+        gold = [p for p in ser["points"] if p["sweeps"] in (4, 8, 12, 16)]
+        for row, g in zip(rows, gold):
+            assert int(row["temp_bits"]) == ser["temp_bits"], (k, row)
+            assert (int(row["iter"]), int(row["up"]), int(row["down"]), int(row["bond_equal"])) == (g["sweeps"], g["up"], g["down"], g["bond_equal"])
+        Ms = [g["up"] - g["down"] for g in gold]
+        Es = [2 * N - 2 * g["bond_equal"] for g in gold]
+        pt = points[k]
+        assert int(pt["temp_bits"]) == ser["temp_bits"] and int(pt["nmeas"]) == 4
+        assert int(pt["sum_M"]) == sum(Ms) and int(pt["sum_absM"]) == sum(abs(m) for m in Ms)
+        assert int(pt["sum_M2"]) == sum(m * m for m in Ms)
+        assert int(pt["sum_E"]) == sum(Es) and int(pt["sum_E2"]) == sum(e * e for e in Es)
+        T = Fraction(float(np.uint32(ser["temp_bits"]).view(np.float32)))
+        n = 4
+        mabs, m2 = Fraction(sum(abs(m) for m in Ms), n * N), Fraction(sum(m * m for m in Ms), n * N * N)
+        m4 = Fraction(sum(m ** 4 for m in Ms), n * N ** 4)
+        e1, e2 = Fraction(sum(Es), n * N), Fraction(sum(e * e for e in Es), n * N * N)
+        want = {"m_abs": mabs, "m2": m2, "chi": N * (m2 - mabs * mabs) / T, "U4": 1 - m4 / (3 * m2 * m2), "e": e1,
+                "Cv": N * (e2 - e1 * e1) / (T * T)}
+        for key, val in want.items():
+            assert float(pt[key]) == pytest.approx(float(val), rel=1e-9, abs=1e-12), (k, key)  # FP tolerance of the final ratios
+        assert f"T = {float(T):f}: <|m|> = {float(mabs):9.6f}," in out
+    # lower temperature -> lower energy after the same number of sweeps
+    es = [float(p["e"]) for p in points]
+    assert es[0] < es[-1] < 0
+
+
+def test_tsweep_anneal_matches_set_temperature_sequence(gpu, tmp_path):
+    X, Y, seed = 4096, 256, 77
+    run(["-x", X, "-y", Y, "-s", seed, "--tsweep", "2.0,2.5,0.25,3,2,2", "--tsweep-anneal", "--tsweep-out", "an"], cwd=tmp_path)
+    series = list(csv.DictReader(open(tmp_path / "an.series.csv")))
+    with ig.IsingSlab(X, Y, seed=seed, temp=2.0) as s:
+        s.init()
+        got = []
+        for t in (2.0, 2.25, 2.5):
+            s.set_temperature(t)
+            s.sweep(3)
+            for _ in range(2):
+                s.sweep(2)
+                got.append((s.it,) + s.count() + (s.bond_equal(),))
+    assert [(int(r["iter"]), int(r["up"]), int(r["down"]), int(r["bond_equal"])) for r in series] == got
+
+
+@pytest.mark.parametrize("layout", ["ballot", "dense", "nibble"])
+def test_cli_checkpoint_resume_equals_uninterrupted(gpu, tmp_path, layout):
+    X, Y, seed = 8192, 128, 4242
+    base = ["-x", X, "-y", Y, "-s", seed, "-a", "1", "--layout", layout, "--energy"]
+    full = run(base + ["-n", 16, "-p", 4, "-o"], cwd=tmp_path)
+    (tmp_path / "part").mkdir()
+    first = run(base + ["-n", 10, "-p", 4, "--checkpoint", "state.ckpt"], cwd=tmp_path / "part")
+    assert "Checkpoint written to state.ckpt (10 iterations done)" in first
+    second = run(["--resume", "state.ckpt", "-n", 6, "-p", 4, "-o", "--layout", layout, "--energy"], cwd=tmp_path / "part")
+    assert "Resumed from state.ckpt: 10 iterations done" in second
+    lines = lambda out: [ln for ln in out.splitlines() if "(iter:" in ln]  # noqa: E731
+    assert lines(full)[-4:] == [ln for ln in lines(second) if "iter:       12)" in ln or "iter:       16)" in ln]
+    dump = f"lattice_{Y}x{X}_T_{ig.CRIT_TEMP_F32:f}_IT_{16:08d}_0.txt"
+    assert (tmp_path / dump).read_bytes() == (tmp_path / "part" / dump).read_bytes()
+
+
+def test_checkpoint_is_decomposition_independent(gpu, tmp_path):
+    """Written by 4 slabs, loaded into 1 and into 2 slabs: identical continuation."""
+    X, Ytot, seed, temp = 8192, 256, 9, ig.CRIT_TEMP_F32
+    ring4 = ig.SlabSet([ig.IsingSlab(X, Ytot // 4, seed=seed, temp=temp, nslabs=4, slab=k) for k in range(4)]).init()
+    ring4.sweep(5)
+    path = tmp_path / "four.ckpt"
+    ring4.checkpoint_save(path)
+    ring4.sweep(3)
+    want = (ring4.count(), ring4.bond_equal())
+    ring4.close()
+    for n in (1, 2):
+        ring = ig.SlabSet([ig.IsingSlab(X, Ytot // n, seed=seed, temp=temp, nslabs=n, slab=k) for k in range(n)])
+        ring.checkpoint_load(path)
+        assert ring.it == 5
+        ring.sweep(3)
+        assert (ring.count(), ring.bond_equal()) == want
+        ring.close()
+    with ig.IsingSlab(X, Ytot, seed=seed + 1, temp=temp) as s:  # another seed: the Philox streams would not continue
+        with pytest.raises(ig.IsingError, match="seed"):
+            ig.SlabSet([s]).checkpoint_load(path)
+    bad = tmp_path / "bad.ckpt"
+    data = bytearray(path.read_bytes())
+    data[4096] ^= 0x10
+    bad.write_bytes(bytes(data))
+    with ig.IsingSlab(X, Ytot, seed=seed, temp=temp) as s:
+        with pytest.raises(ig.IsingError, match="damaged"):
+            ig.SlabSet([s]).checkpoint_load(bad)
+
+
+@pytest.mark.parametrize("layout", [ig.LAYOUT_BALLOT, ig.LAYOUT_DENSE, ig.LAYOUT_NIBBLE])
+def test_bits_and_packed_boundary_formats_round_trip(gpu, oracle_mod, layout):
+    X, Y, seed = 8192, 96, 3
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=2.0).init().sweep(2)
+
+    def bits_of(packed):  # oracle packed rows -> the 1 bit/spin boundary format
+        nib = ((packed[..., None] >> (4 * np.arange(16, dtype=np.uint64))) & np.uint64(1)).astype(np.uint32)  # [Y][lld][16]
+        half = (nib << np.arange(16, dtype=np.uint32)).sum(axis=-1, dtype=np.uint32)                            # 16 bits per word
+        return half[:, 0::2] | (half[:, 1::2] << np.uint32(16))
+
+    with ig.IsingSlab(X, Y, seed=seed, temp=2.0, layout=layout) as s:
+        s.init().sweep(2)
+        for color, ref in ((ig.BLACK, orc.black), (ig.WHITE, orc.white)):
+            assert np.array_equal(s.read(color), ref)
+            assert np.array_equal(s.read_bits(color), bits_of(ref))
+            assert np.array_equal(s.read(color, 17, 40), ref[17:57])
+    # write the oracle's state into a fresh slab through either format, continue, compare
+    orc.sweep(3)
+    for writer in ("packed", "bits"):
+        ref = oracle_mod.OracleLattice(X, Y, seed=seed, temp=2.0).init().sweep(2)
+        with ig.IsingSlab(X, Y, seed=seed, temp=2.0, layout=layout) as s:
+            for color, rows in ((ig.BLACK, ref.black), (ig.WHITE, ref.white)):
+                if writer == "packed":
+                    s.write(color, rows[:50]); s.write(color, rows[50:], 50)
+                else:
+                    s.write_bits(color, bits_of(rows))
+            s.it = 2
+            s.sweep(3)
+            assert np.array_equal(s.read(ig.BLACK), orc.black) and np.array_equal(s.read(ig.WHITE), orc.white)
