@@ -24,11 +24,11 @@ def run(args, cwd=None):
 
 def test_tsweep_config5_against_oracle_series(gpu, tmp_path):
     """BASELINE config 5 in ONE process: 8192^2, seed 1234, T = 1.50 .. 3.00 step 0.05 (31 points), per point a fresh
-    lattice, 4 equilibration sweeps and 4 measurements 4 sweeps apart = the oracle's golden points at sweeps 4/8/12/16
+    lattice and 4 measurements 4 sweeps apart = the oracle's golden points at sweeps 4/8/12/16
     (tests/golden/tsweep_8192.json).  Every (up, down, bond) triple must match; the derived averages are recomputed here
     from the golden integers in exact rational arithmetic."""
     fx = json.load(open(os.path.join(GOLD, "tsweep_8192.json")))
-    out = run(["-x", fx["X"], "-y", fx["Y"], "-s", fx["seed"], "--tsweep", "1.5,3.0,0.05,4,4,4", "--tsweep-out", "ts"], cwd=tmp_path)
+    out = run(["-x", fx["X"], "-y", fx["Y"], "-s", fx["seed"], "--tsweep", "1.5,3.0,0.05,0,4,4", "--tsweep-out", "ts"], cwd=tmp_path)
     assert "Temperature sweep: 31 points" in out
     series = list(csv.DictReader(open(tmp_path / "ts.series.csv")))
     points = list(csv.DictReader(open(tmp_path / "ts.csv")))
@@ -88,8 +88,11 @@ def test_cli_checkpoint_resume_equals_uninterrupted(gpu, tmp_path, layout):
     assert "Checkpoint written to state.ckpt (10 iterations done)" in first
     second = run(["--resume", "state.ckpt", "-n", 6, "-p", 4, "-o", "--layout", layout, "--energy"], cwd=tmp_path / "part")
     assert "Resumed from state.ckpt: 10 iterations done" in second
-    lines = lambda out: [ln for ln in out.splitlines() if "(iter:" in ln]  # noqa: E731
-    assert lines(full)[-4:] == [ln for ln in lines(second) if "iter:       12)" in ln or "iter:       16)" in ln]
+    def lines(out):  # the magnetisation and energy lines of iterations 12 and 16 (without the "Final" repetition)
+        return [ln for ln in out.splitlines() if ln.startswith("        ") and ("(iter:       12)" in ln or "(iter:       16)" in ln)]
+    assert len(lines(full)) == 4 and lines(full) == lines(second)
+    final = [ln for ln in full.splitlines() if ln.startswith("Final")]
+    assert final and final == [ln for ln in second.splitlines() if ln.startswith("Final")]
     dump = f"lattice_{Y}x{X}_T_{ig.CRIT_TEMP_F32:f}_IT_{16:08d}_0.txt"
     assert (tmp_path / dump).read_bytes() == (tmp_path / "part" / dump).read_bytes()
 
