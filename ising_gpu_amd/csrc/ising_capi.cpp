@@ -3,6 +3,7 @@
 // lattice happens in ising_kernels.hip.
 #include "ising_ctx.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -38,6 +39,8 @@ using ising_host::bind;
 using ising_host::fail;
 
 namespace {
+
+constexpr size_t SLOTCTL_TICKET_BYTES = 9 * 64;
 
 // cuRAND's curand_uniform on the host: x*2^-32 + 2^-33 in FP32 (product exact, one rounding).
 inline float u01(uint32_t x) { return (float)x * 0x1p-32f + 0x1p-33f; }
@@ -307,7 +310,19 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (e == hipSuccess) e = hipMemset(c->d_lat, 0, c->alloc_words() * sizeof(uint64_t)); // optimized/main.cu:1603
 	if (e == hipSuccess) e = hipMalloc((void **)&c->d_acc, 4 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMalloc((void **)&c->d_lut, 65536);
-	if (e == hipSuccess && c->ballot) e = hipMalloc((void **)&c->d_scratch, (size_t)(c->gx / 4) * (c->nstrips + 2) * 2048);
+	if (e == hipSuccess && c->ballot) {
+		// accept-mask slots, 2 KiB per wave: of every wave of the largest plain launch (one workgroup per unit), and of
+		// every workgroup slot of a fused launch (4 waves each)
+		const size_t plain = (size_t)(c->gx / 4) * (c->nstrips + 2) * 2048 + 8192, fused = (size_t)ising::ballot_max_wgs() * 4 * 2048;
+		e = hipMalloc((void **)&c->d_scratch, std::max(plain, fused));
+		// ticket words (chunk counter + 8 queue words, 64 bytes apart) + one completion counter per strip (fused launches)
+		const size_t ctl_bytes = SLOTCTL_TICKET_BYTES + (size_t)c->nstrips * sizeof(uint32_t);
+		if (e == hipSuccess) e = hipMalloc((void **)&c->d_slotctl, ctl_bytes);
+		if (e == hipSuccess) e = hipMemset(c->d_slotctl, 0, ctl_bytes);
+		// fused sweeps (ising_sweep): on a par with per-colour launches from 32768^2 up, slower below
+		const char *fz = getenv("ISING_FUSED");
+		c->fused = fz ? atoi(fz) != 0 : (long long)cfg->X * cfg->Y >= (1LL << 29);
+	}
 	if (e == hipSuccess && cfg->use_J) {
 		if (cfg->coupling_mem) c->d_ham = static_cast<uint64_t *>(cfg->coupling_mem);
 		else e = hipMalloc((void **)&c->d_ham, c->ham_alloc_words() * sizeof(uint64_t));
@@ -394,7 +409,9 @@ int ising_strip_info(ising_ctx *c, int *strip_rows, int *nstrips) {
 }
 
 // launches update_k over up to two row ranges
-static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int lo1, int hi1) {
+// `nlevels` > 1 (ballot layout only): one fused launch of that many colour half-sweeps over the whole slab, starting with
+// `color` at iteration `it`
+static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int lo1, int hi1, int nlevels = 1) {
 	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
 	if (it < 0) return fail(ISING_E_ARG, "negative iteration %d", it);
 	int mode = c->cfg.kernel == ISING_KERNEL_GENERIC ? 1 : (c->cfg.kernel == ISING_KERNEL_LUT ? 2 : 0); // AUTO, FAST -> 0
@@ -438,7 +455,24 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	p.jdst = c->cfg.use_J ? c->ham(other) : nullptr;
 	p.scratch = c->d_scratch;
 	if (c->ballot) {
-		HIP_TRY(ising::launch_ballot_update(p, c->stream));
+		p.ticket = reinterpret_cast<unsigned long long *>(c->d_slotctl);
+		p.nlevels = nlevels;
+		if (nlevels > 1) {
+			HIP_TRY(hipMemsetAsync(c->d_slotctl, 0, SLOTCTL_TICKET_BYTES, c->stream)); // ticket words start from zero
+			if (c->done_base > (1u << 30)) { // keep the monotone completion counters far from wrapping
+				HIP_TRY(hipMemsetAsync(c->d_slotctl + SLOTCTL_TICKET_BYTES / 4, 0, (size_t)c->nstrips * sizeof(uint32_t), c->stream));
+				c->done_base = 0;
+			}
+			p.lat[0] = c->lat(ISING_BLACK);
+			p.lat[1] = c->lat(ISING_WHITE);
+			p.jham[0] = c->cfg.use_J ? c->ham(1) : nullptr;
+			p.jham[1] = c->cfg.use_J ? c->ham(0) : nullptr;
+			p.done = c->d_slotctl + SLOTCTL_TICKET_BYTES / 4;
+			p.done_base = c->done_base;
+		}
+		int grid = 0;
+		HIP_TRY(ising::launch_ballot_update(p, c->stream, &grid));
+		if (nlevels > 1) c->done_base += (uint32_t)nlevels * (uint32_t)(c->gx / 4);
 		return ISING_OK;
 	}
 	if (c->dense) {
@@ -463,6 +497,16 @@ int ising_update_edges(ising_ctx *c, int it, int color) {
 int ising_sweep(ising_ctx *c, int first_it, int nsweeps) {
 	if (!c) return fail(ISING_E_ARG, "null context");
 	if (!c->wrap) return fail(ISING_E_STATE, "ising_sweep needs a single slab without ring halo rows; drive slabs with ising_ring_sweep / ising_rank_sweep or ising_update_color + halo exchange");
+	// ballot layout: up to 32 sweeps (64 colour half-sweeps) per fused launch -- the chip does not drain between colours
+	if (c->ballot && c->fused && !c->cfg.XSL && !ising_host::needs_generic(c)) {
+		for (int it = first_it, left = nsweeps; left > 0;) {
+			const int ns = std::min(left, 32);
+			if (int rc = launch_ranges(c, it, ISING_BLACK, 0, c->cfg.Y, 0, 0, 2 * ns)) return rc;
+			it += ns;
+			left -= ns;
+		}
+		return ISING_OK;
+	}
 	for (int it = first_it; it < first_it + nsweeps; it++) {
 		if (int rc = ising_update_color(c, it, ISING_BLACK, 0, c->cfg.Y)) return rc;
 		if (int rc = ising_update_color(c, it, ISING_WHITE, 0, c->cfg.Y)) return rc;

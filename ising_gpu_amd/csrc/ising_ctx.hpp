@@ -17,7 +17,9 @@ struct ising_ctx {
 	uint64_t *d_tmp = nullptr;     // ballot layout: dense-order image of d_lat (same shape) for conversions and observables;
 	                               // allocated by the first call that needs it (sweeping and counting never do)
 	uint64_t *d_scratch = nullptr; // ballot layout: accept-mask slots of the update kernel (see ising_ballot.hip)
-	uint32_t *d_slotctl = nullptr; // ballot layout: slot tickets and busy flags
+	uint32_t *d_slotctl = nullptr; // ballot layout, fused launches: ticket words (576 bytes) + per-strip completion counters
+	uint32_t done_base = 0;        // value of every completion counter once everything launched so far has run
+	bool fused = false;            // ising_sweep batches colour half-sweeps into fused launches
 	uint64_t *d_pack = nullptr;    // staging for device-side conversion to / from the packed boundary format
 	size_t pack_words = 0;
 	int lld_packed = 0; // 64-bit words per colour row in the reference's packed layout (X/32)

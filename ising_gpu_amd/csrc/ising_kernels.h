@@ -31,7 +31,16 @@ struct UpdateParams {
 	float tab[10];            // exp table exp_h[2][5] (generic kernel)
 	const uint8_t *lut;       // 64 KiB rank table indexed by the top 16 bits of a draw (mode 2)
 	const uint64_t *jdst;     // coupling words read for the rows being updated (NULL without -J); same shape as dst
-	uint64_t *scratch;        // ballot layout: 2 KiB of accept-mask slots per wave of the launch
+	uint64_t *scratch;        // ballot layout: 2 KiB of accept-mask slots per wave of the GRID (ballot_max_wgs() x 4 waves)
+	// ballot layout, persistent launches
+	unsigned long long *ticket; // fused: ticket words (chunk counter + 8 queue words, 64 bytes apart), zero when the launch starts
+	int32_t nwg;              // workgroup units per level (set by the launcher)
+	int32_t nlevels;          // colour half-sweeps in this launch.  > 1 = fused: level L updates colour (color + L) & 1 at
+	                          // iteration it + (color + L) / 2 over rows [row_lo[0], row_hi[0]) = the whole slab (wrap)
+	uint64_t *lat[2];         // fused: row-0 pointers of both colours
+	const uint64_t *jham[2];  // fused, -J: coupling words read when colour c is updated
+	uint32_t *done;           // fused: completed wave columns per strip (monotone); reads `done_base` when the launch starts
+	uint32_t done_base;
 };
 
 // mode: 0 = integer thresholds via v_cmpx, 1 = generic FP32-table kernel, 2 = integer thresholds via the LDS rank table
@@ -95,7 +104,9 @@ hipError_t launch_dense_to_packed(const uint32_t *dense, uint64_t *packed, size_
 hipError_t launch_packed_to_dense(const uint64_t *packed, uint32_t *dense, size_t nvec, hipStream_t stream);
 
 // ballot layout (1 bit per spin in wave-ballot order, ising_ballot.hip): integer-threshold update, conversions
-hipError_t launch_ballot_update(const UpdateParams &p, hipStream_t stream);
+// `p` is completed by the launcher (nwg); *grid_out = workgroups launched
+hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_out);
+int ballot_max_wgs();
 hipError_t launch_ballot_init(const InitParams &p, hipStream_t stream);
 hipError_t launch_ballot_to_dense(const uint64_t *bal, uint32_t *dense, int gx, long long rows, hipStream_t stream);
 hipError_t launch_dense_to_ballot(const uint32_t *dense, uint64_t *bal, int gx, long long rows, hipStream_t stream);
