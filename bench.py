@@ -1,12 +1,20 @@
 #!/usr/bin/env python3
 """bench.py -- spin-flips/ns of the checkerboard-Metropolis hot loop on N MI355X (weak scaling).
 
-A "step" is one full lattice sweep (black half-sweep + white half-sweep = two launches of the update kernel,
-the reference's hot loop optimized/main.cu:1763-1805) over this rank's slab.  Per-GPU workload (fixed as N
-grows => weak scaling): X = 65536 columns x Y = 65536 rows at T = T_c (CRIT_TEMP, optimized/main.cu:42),
-the 65536^2 lattice BASELINE.json's target is quoted on; with N ranks the lattice is (N*65536) x 65536, slabs
-along Y, one RCCL row exchange per colour half-sweep (ising_gpu_amd/ring.py).  The lattice is generated on the
-device from the seed (there is no input data): "synthetic".
+A "step" is one full lattice sweep (black half-sweep + white half-sweep, the reference's hot loop
+optimized/main.cu:1763-1805) over this rank's slab.  Per-GPU workload (fixed as N grows => weak scaling):
+X = 65536 columns x Y = 65536 rows at T = T_c (CRIT_TEMP, optimized/main.cu:42), the 65536^2 lattice BASELINE.json's
+target is quoted on (configs[2]); with N ranks the lattice is (N*65536) x 65536, slabs along Y, one row of each colour
+to each ring neighbour per half-sweep.  The lattice is generated on the device from the seed: "synthetic".
+
+  N = 1   the slab sweeps itself (ising_sweep); on the default (ballot) layout that is a sequence of fused launches, each
+          carrying `batch` sweeps = 2 * batch colour half-sweeps (batch = gcd(steps, warmup, 16), so that every launch of
+          the run -- warm-up included -- is the same piece of work and the rocprofv3 per-kernel average agrees with the
+          HIP-event average reported here).
+  N > 1   one process per GPU; the ring lives inside libising_hip.so (ising_rank_*: second HIP stream + RCCL send/recv);
+          if that transport does not come up the torch.distributed ring (p2p, then all-gather) takes over and the JSON
+          line says which one ran.  The counts after warm-up + steps are compared with the oracle's committed goldens
+          (tests/golden/bench_65536_tc.json, ring_65536_tc.json) when the run hits one of their points.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -17,6 +25,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -63,6 +72,24 @@ def cpu_baseline(args):
     return out
 
 
+def golden_counts(x, y_per_gpu, seed, world, sweeps):
+    """(up, down) the oracle found for this workload after `sweeps` sweeps, or None (tests/golden/make_golden_big.py)."""
+    gold = os.path.join(ROOT, "tests", "golden")
+    try:
+        if world == 1:
+            recs = [json.load(open(os.path.join(gold, "bench_65536_tc.json")))]
+        else:
+            recs = [r for r in json.load(open(os.path.join(gold, "ring_65536_tc.json")))["rings"] if r["nslabs"] == world]
+        for fx in recs:
+            if fx["X"] == x and fx["Ytot"] == y_per_gpu * world and fx["seed"] == seed:
+                for pt in fx["points"]:
+                    if pt["sweeps"] == sweeps:
+                        return pt["up"], pt["down"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,9 +100,15 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--layout", choices=["auto", "nibble", "dense", "ballot"], default="auto", help="device layout of the spin arrays")
+    ap.add_argument("--ring", choices=["native", "torch"], default="native",
+                    help="N > 1: the ring inside libising_hip.so (RCCL on a second stream) or the torch.distributed one")
     ap.add_argument("--exchange", choices=["p2p", "allgather"], default=None,
-                    help="N > 1: how the edge rows travel (default p2p send/recv, or ISING_RING_EXCHANGE)")
+                    help="N > 1, torch ring: how the edge rows travel (forces --ring torch)")
+    ap.add_argument("--preheat-ms", type=float, default=150.0,
+                    help="untimed sweeps before the warm-up until this much wall time has passed (the lattice is initialised "
+                         "again afterwards): from a cold start the GPU needs ~35 ms under load to reach its steady clock")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alu-probe", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -96,60 +129,128 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    # torch owns the slab's device buffer, so the rows RCCL sends/receives are slices of an ordinary torch tensor
-    backend = ig.HipSlabBackend.create(args.x, args.y, device=local_rank, seed=args.seed, temp=ig.CRIT_TEMP_F32,
-                                       nslabs=world, slab=rank, strip_rows=args.strip_rows,
-                                       layout={"auto": ig.LAYOUT_AUTO, "nibble": ig.LAYOUT_NIBBLE, "dense": ig.LAYOUT_DENSE, "ballot": ig.LAYOUT_BALLOT}[args.layout])
-    slab = backend.slab
-    ring = ig.SlabRing(backend, exchange=args.exchange)
-    ring.init()
+    layout = {"auto": ig.LAYOUT_AUTO, "nibble": ig.LAYOUT_NIBBLE, "dense": ig.LAYOUT_DENSE, "ballot": ig.LAYOUT_BALLOT}[args.layout]
+    log = (lambda m: print(f"[bench rank {rank}] {m}", file=sys.stderr, flush=True))
+    if world == 1:
+        slab = ig.IsingSlab(args.x, args.y, device=local_rank, seed=args.seed, temp=ig.CRIT_TEMP_F32, strip_rows=args.strip_rows, layout=layout)
+        ring, ring_name = None, "none"
+        slab.init()
+    else:
+        # torch owns the slab's device buffer, so the rows the torch ring hands to RCCL are slices of an ordinary tensor
+        backend = ig.HipSlabBackend.create(args.x, args.y, device=local_rank, seed=args.seed, temp=ig.CRIT_TEMP_F32,
+                                           nslabs=world, slab=rank, strip_rows=args.strip_rows, layout=layout)
+        slab = backend.slab
+        ring, ring_name = ig.open_ring(backend, prefer="torch" if args.exchange else args.ring, exchange=args.exchange, log=log)
+
+    batch = math.gcd(math.gcd(args.steps, args.warmup) if args.warmup else args.steps, 16) or 1
+
+    def advance(n):
+        """n sweeps in pieces of `batch`, all asynchronous"""
+        if ring is not None:
+            ring.sweep(n)
+            return
+        for _ in range(n // batch):
+            slab.sweep(batch)
+        if n % batch:
+            slab.sweep(n % batch)
+
+    def restart():
+        if ring is not None:
+            ring.init()
+        else:
+            slab.init()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    ring.sweep(args.warmup)
+    # clock warm-up (untimed, then forgotten: the lattice starts over)
+    preheat_sweeps = 0
+    if args.preheat_ms > 0:
+        barrier()
+        t0 = time.perf_counter()
+        advance(batch)
+        torch.cuda.synchronize()
+        more = max(0, math.ceil(args.preheat_ms / max((time.perf_counter() - t0) * 1e3, 1e-3)) - 1)
+        if world > 1:  # every rank must do the same number of sweeps: rank 0's estimate counts
+            t = torch.tensor([more], dtype=torch.int64, device="cuda")
+            dist.broadcast(t, src=0)
+            more = int(t[0])
+        more = min(more, 4096)
+        for _ in range(more):
+            advance(batch)
+        preheat_sweeps = (1 + more) * batch
+        restart()
+
+    advance(args.warmup)
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()
-    ring.sweep(args.steps)
+    ev0.record()  # HIP events on the stream the kernels are launched on (torch's current stream = the slab's stream)
+    advance(args.steps)
     ev1.record()
     barrier()
     dt = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels were launched on (torch's current stream)
+    ev_ms = ev0.elapsed_time(ev1)
     if world > 1:
         t = torch.tensor([dt, ev_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, ev_ms = float(t[0]), float(t[1])
 
-    up, down = ring.count()
+    up, down = ring.count() if ring is not None else slab.count()
+    rank_up = [slab.count()[0]]
+    if world > 1:
+        g = [None] * world
+        dist.all_gather_object(g, rank_up[0])
+        rank_up = g
     spins_per_gpu = args.x * args.y
     total_flips = float(spins_per_gpu) * world * args.steps
     value = total_flips / (dt * 1e9)
+    gold = golden_counts(args.x, args.y, args.seed, world, args.warmup + args.steps)
+    parity = None if gold is None else (gold == (up, down))
 
-    layout_name, layout_text, kernel_name = {
-        ig.LAYOUT_NIBBLE: ("nibble", "reference 4 bit/spin", "update_k<0>"),
-        ig.LAYOUT_DENSE: ("dense", "dense 1 bit/spin", "dense_update_k<0>"),
-        ig.LAYOUT_BALLOT: ("ballot", "1 bit/spin in wave-ballot order", "ballot_update_k"),
+    layout_name, layout_text = {
+        ig.LAYOUT_NIBBLE: ("nibble", "reference 4 bit/spin"),
+        ig.LAYOUT_DENSE: ("dense", "dense 1 bit/spin"),
+        ig.LAYOUT_BALLOT: ("ballot", "1 bit/spin in wave-ballot order"),
     }[slab.current_layout()]
     if rank == 0:
-        # dominant kernel: update_k; 2 full-slab launches per step (with N>1 each colour adds one tiny edge-row launch)
-        launches = 2 * args.steps
+        # dominant kernel = the update kernel.  N = 1 on the ballot layout: fused launches of `batch` sweeps; otherwise two
+        # full-slab launches per step (with N > 1 each colour adds one tiny edge-row launch).
+        fused = world == 1 and layout_name == "ballot" and slab.fused
+        half_sweeps_per_launch = 2 * batch if fused else 1
+        launches = args.steps // batch + (1 if args.steps % batch else 0) if fused else 2 * args.steps
         avg_launch_ms = ev_ms / launches
-        alg_bytes_per_launch = BYTES_PER_FLIP * spins_per_gpu / 2.0  # src read + dst read + dst write of one colour
+        alg_bytes_per_launch = BYTES_PER_FLIP * spins_per_gpu / 2.0 * half_sweeps_per_launch  # per colour: src read + dst read + dst write
         achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
-        traffic = None
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": {"ballot": "ballot_update_k", "dense": "dense_update_k", "nibble": "update_k"}[layout_name] + ("<fused>" if fused else ""),
+                "avg_launch_ms": round(avg_launch_ms, 5), "launches": launches, "half_sweeps_per_launch": half_sweeps_per_launch,
+                "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                "note": "achieved = the reference's 1.5 B/flip (4 bit/spin) accounting / launch time; the kernel is bound by the "
+                        "vector ALU (one Philox4x32-10 output per site), see alu_ceiling; its own HBM traffic is `traffic`"}
+        # HBM bytes per launch from the PMC passes of tools/profile.sh (separate runs; FETCH_SIZE / WRITE_SIZE per the guide)
         prof = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(prof):
+        try:
+            tj = json.load(open(prof))
+            if tj.get("x") == args.x and tj.get("y") == args.y and tj.get("device_layout") == layout_name and tj.get("fused", False) == fused:
+                per_half = tj["hbm_bytes_per_half_sweep"]
+                roof["traffic"] = per_half * half_sweeps_per_launch
+                roof["traffic_source"] = tj.get("tag", "profiles/traffic.json") + " (PMC passes of an earlier run, not this one)"
+                roof["hbm_real_GBs"] = round(roof["traffic"] / (avg_launch_ms * 1e-3) / 1e9, 1)
+                roof["device_algorithmic_bytes_per_launch"] = tj.get("device_bytes_algorithmic_per_half_sweep", 0) * half_sweeps_per_launch
+        except (OSError, ValueError, KeyError):
+            pass
+        if not args.no_alu_probe:
             try:
-                with open(prof) as f:
-                    tj = json.load(f)
-                if tj.get("x") == args.x and tj.get("y") == args.y and tj.get("device_layout") == layout_name:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                ceil = ig.philox_ceiling(local_rank)
+                roof["alu_ceiling"] = {"value": round(ceil, 1), "unit": "sites/ns per GPU",
+                                       "what": "draw-only kernel (Philox4x32-10, one output per site), same job",
+                                       "frac": round(value / world / ceil, 4)}
+            except ig.IsingError as e:
+                roof["alu_ceiling"] = {"error": str(e)}
         line = {
             "metric": "spin-flips/ns (whole node) at T=Tc", "value": round(value, 2), "unit": "flips/ns",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -158,13 +259,14 @@ def main():
             "config": {"workload": f"{args.y * world}x{args.x} lattice ({args.y}x{args.x} per GPU), T=Tc, seed {args.seed}, "
                                    "Philox4x32-10 per site; device layout " + layout_text
                                    + ", results identical to the reference's packed state", "x": args.x, "y_per_gpu": args.y,
-                       "parallelism": f"slab{world}" + (f" ({ring.exchange} row exchange)" if world > 1 else ""), "strip_rows": slab.strip_rows, "device_layout": layout_name,
-                       "up": up, "down": down},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": kernel_name, "avg_launch_ms": round(avg_launch_ms, 5),
-                         "algorithmic_bytes_per_launch": alg_bytes_per_launch},
+                       "parallelism": f"slab{world}", "nranks": world, "exchange": ring_name, "strip_rows": slab.strip_rows,
+                       "device_layout": layout_name, "sweeps_per_call": batch, "preheat_ms": args.preheat_ms, "preheat_sweeps": preheat_sweeps,
+                       "up": up, "down": down, "rank_up": rank_up, "parity_checked": parity,
+                       "parity_source": None if gold is None else "tests/golden (CPU oracle, same seed, same number of sweeps)"},
+            "roofline": roof,
         }
+        if parity is False:
+            line["config"]["parity_expected"] = list(gold)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), flush=True)
@@ -172,6 +274,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if parity is False:
+        raise SystemExit(f"bench: counts {(up, down)} differ from the oracle's {gold}")
 
 
 if __name__ == "__main__":

@@ -103,6 +103,11 @@ int ising_device_count(int *count);
 /* Device description for the "Using GPUs" block (optimized/main.cu:1482-1490). */
 int ising_device_info(int device, char *name, size_t name_len, int *cus, int *max_threads_per_cu, int *major, int *minor);
 
+/* Measurement aid for the bench's roofline object: sites per nanosecond of a kernel that only DRAWS -- one Philox4x32-10
+ * output per site exactly as the update kernels generate them, no accept test, no lattice, no memory traffic.  The
+ * update kernels are bound by the vector ALU, so this is their ceiling at bit-exact parity.  Blocking (~30 ms). */
+int ising_philox_ceiling(int device, double *sites_per_ns);
+
 /* Bytes of one caller-supplied device buffer.  ising_required_bytes: 2 colours x (Y + 2) rows x X/4 bytes -- the
  * reference's 4 bit/spin, enough for every layout and the size of the coupling buffer (coupling_mem).
  * ising_required_bytes_layout: what the spin arrays of a given device layout occupy (ISING_LAYOUT_NIBBLE: the same;
@@ -156,6 +161,10 @@ int ising_strip_info(ising_ctx *ctx, int *strip_rows, int *nstrips);
 /* nslabs == 1 only: `nsweeps` full sweeps, black then white, iterations first_it .. first_it+nsweeps-1
  * (the hot loop, optimized/main.cu:1763-1805). */
 int ising_sweep(ising_ctx *ctx, int first_it, int nsweeps);
+/* How ising_sweep launches right now: *fused = 1 when it issues fused launches (ballot layout from 32768^2 up, or
+ * ISING_FUSED=1: one launch carries up to *max_sweeps_per_launch sweeps = twice as many colour half-sweeps, handed out to
+ * a chip-filling grid through in-order tickets; ising_ballot.hip), 0 when it issues one launch per colour. */
+int ising_sweep_info(ising_ctx *ctx, int *fused, int *max_sweeps_per_launch);
 /* Same, bracketed by HIP events on the context's stream; returns elapsed milliseconds (blocking). */
 int ising_sweep_timed(ising_ctx *ctx, int first_it, int nsweeps, float *elapsed_ms);
 

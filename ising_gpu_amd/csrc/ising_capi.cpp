@@ -221,6 +221,35 @@ int ising_device_info(int device, char *name, size_t name_len, int *cus, int *ma
 	return ISING_OK;
 }
 
+int ising_philox_ceiling(int device, double *sites_per_ns) {
+	if (!sites_per_ns) return fail(ISING_E_ARG, "null argument");
+	HIP_TRY(hipSetDevice(device));
+	int cus = 0;
+	HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+	const int blocks = cus * 32, nrows = 64; // 8 waves per SIMD over four rounds of blocks; ~2e10 sites per launch
+	uint32_t *out = nullptr;
+	HIP_TRY(hipMalloc((void **)&out, (size_t)blocks * 256 * sizeof(uint32_t)));
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	hipError_t e = hipEventCreate(&e0);
+	if (e == hipSuccess) e = hipEventCreate(&e1);
+	double best = 0;
+	for (int rep = 0; rep < 4 && e == hipSuccess; rep++) { // the first launch also warms the clocks up
+		e = hipEventRecord(e0, nullptr);
+		if (e == hipSuccess) e = ising::launch_philox_ceiling(out, blocks, nrows, nullptr);
+		if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+		if (e == hipSuccess) e = hipEventSynchronize(e1);
+		float ms = 0;
+		if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+		if (e == hipSuccess && ms > 0) best = std::max(best, (double)blocks * 256.0 * nrows * 64.0 / (ms * 1e6));
+	}
+	if (e0) (void)hipEventDestroy(e0);
+	if (e1) (void)hipEventDestroy(e1);
+	(void)hipFree(out);
+	if (e != hipSuccess) return fail(ISING_E_HIP, "philox ceiling probe failed: %s", hipGetErrorString(e));
+	*sites_per_ns = best;
+	return ISING_OK;
+}
+
 size_t ising_required_bytes(int32_t X, int32_t Y) {
 	if (X <= 0 || Y <= 0) return 0;
 	return 2 * ((size_t)Y + 2) * (size_t)(X / 32) * sizeof(uint64_t);
@@ -511,6 +540,14 @@ int ising_sweep(ising_ctx *c, int first_it, int nsweeps) {
 		if (int rc = ising_update_color(c, it, ISING_BLACK, 0, c->cfg.Y)) return rc;
 		if (int rc = ising_update_color(c, it, ISING_WHITE, 0, c->cfg.Y)) return rc;
 	}
+	return ISING_OK;
+}
+
+int ising_sweep_info(ising_ctx *c, int *fused, int *max_sweeps_per_launch) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	const bool f = c->wrap && c->ballot && c->fused && !c->cfg.XSL && !ising_host::needs_generic(c);
+	if (fused) *fused = f ? 1 : 0;
+	if (max_sweeps_per_launch) *max_sweeps_per_launch = f ? 32 : 0;
 	return ISING_OK;
 }
 

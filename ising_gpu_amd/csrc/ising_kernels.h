@@ -57,6 +57,9 @@ struct InitParams {
 };
 hipError_t launch_init(const InitParams &p, hipStream_t stream);
 
+// measurement aid: `blocks` x 256 lanes x nrows x 16 Philox blocks (= 64 sites each); out holds blocks * 256 words
+hipError_t launch_philox_ceiling(uint32_t *out, int blocks, int nrows, hipStream_t stream);
+
 // up-spin count of `nwords` packed words, accumulated into *acc (one 64-bit atomic per block)
 hipError_t launch_popcount(const uint64_t *v, size_t nwords, unsigned long long *acc, hipStream_t stream);
 

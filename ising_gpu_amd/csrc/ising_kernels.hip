@@ -450,6 +450,26 @@ __global__ void __launch_bounds__(THREADS) ham_init_white_k(const HamWhiteParams
 
 // ---------------------------------------------------------------------------------------------- popcount
 
+// ---- measurement aid (bench.py "alu_ceiling"): the draw of the update kernels and nothing else -- per lane `nrows` x 16
+// Philox4x32-10 blocks exactly as the update kernels generate them (philox_row_setup + philox_block: rounds 1-2 of
+// the wave-uniform counter word on the scalar unit), outputs XOR-folded into one word per lane.  sites/ns of this
+// kernel is what a half-sweep could reach if accept test, word logic and memory cost nothing.
+__global__ void __launch_bounds__(THREADS) philox_ceiling_k(uint32_t *__restrict__ out, uint32_t seed_lo, uint32_t seed_hi, int nrows) {
+	const uint32_t tid0 = blockIdx.x * THREADS + threadIdx.x;
+	uint32_t acc = 0;
+	for (int r = 0; r < nrows; ++r) {
+		const PhiloxRow pr = philox_row_setup(tid0 + (uint32_t)r * 0x10000u, seed_lo, seed_hi + 2u * PHILOX_W1);
+		static_for<16>([&](auto B) {
+			uint32_t o0, o1, o2, o3;
+			uint32_t cx = 16u * (uint32_t)r + (uint32_t)B.value;
+			asm volatile("" : "+s"(cx));
+			philox_block(pr, cx, seed_lo, seed_hi, o0, o1, o2, o3);
+			acc ^= xor3(o0, o1, o2) ^ o3;
+		});
+	}
+	out[tid0] = acc;
+}
+
 __global__ void __launch_bounds__(THREADS) popcount_k(const uint4 *__restrict__ v, size_t nvec, unsigned long long *acc) {
 	__shared__ unsigned long long part[THREADS / 64];
 	unsigned long long c = 0;
@@ -641,6 +661,11 @@ hipError_t launch_init(const InitParams &p, hipStream_t stream) {
 	const long long units = (long long)p.gx * p.Y;
 	const dim3 grid((unsigned)((units + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)), block(THREADS);
 	hipLaunchKernelGGL(init_k, grid, block, 0, stream, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_philox_ceiling(uint32_t *out, int blocks, int nrows, hipStream_t stream) {
+	hipLaunchKernelGGL(philox_ceiling_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, out, 0x1234567u, 0x89abcdeu, nrows);
 	return hipGetLastError();
 }
 

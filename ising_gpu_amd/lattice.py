@@ -122,6 +122,13 @@ class IsingSlab:
         self.it += n
         return self
 
+    @property
+    def fused(self) -> bool:
+        """True when sweep() issues fused launches (several colour half-sweeps per launch, ising_sweep_info)."""
+        f, m = C.c_int(), C.c_int()
+        check(self._lib.ising_sweep_info(self._h, C.byref(f), C.byref(m)))
+        return bool(f.value)
+
     def sweep_timed(self, n: int) -> float:
         ms = C.c_float()
         check(self._lib.ising_sweep_timed(self._h, self.it + 1, n, C.byref(ms)))
@@ -213,6 +220,13 @@ class IsingSlab:
         a = C.c_int64()
         check(self._lib.ising_rank_bond_equal(self._h, C.byref(a)))
         return int(a.value)
+
+
+def philox_ceiling(device: int = 0) -> float:
+    """sites/ns of a draw-only kernel (one Philox4x32-10 output per site, nothing else): the update kernels' VALU ceiling."""
+    v = C.c_double()
+    check(_lib.load().ising_philox_ceiling(device, C.byref(v)))
+    return v.value
 
 
 def rccl_version() -> int:
