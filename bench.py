@@ -8,7 +8,7 @@ target is quoted on (configs[2]); with N ranks the lattice is (N*65536) x 65536,
 to each ring neighbour per half-sweep.  The lattice is generated on the device from the seed: "synthetic".
 
   N = 1   the slab sweeps itself (ising_sweep); on the default (ballot) layout that is a sequence of fused launches, each
-          carrying `batch` sweeps = 2 * batch colour half-sweeps (batch = gcd(steps, warmup, 16), so that every launch of
+          carrying `batch` sweeps = 2 * batch colour half-sweeps (batch = the largest divisor <= 32 of gcd(steps, warmup), so that every launch of
           the run -- warm-up included -- is the same piece of work and the rocprofv3 per-kernel average agrees with the
           HIP-event average reported here).
   N > 1   one process per GPU; the ring lives inside libising_hip.so (ising_rank_*: second HIP stream + RCCL send/recv);
@@ -142,7 +142,9 @@ def main():
         slab = backend.slab
         ring, ring_name = ig.open_ring(backend, prefer="torch" if args.exchange else args.ring, exchange=args.exchange, log=log)
 
-    batch = math.gcd(math.gcd(args.steps, args.warmup) if args.warmup else args.steps, 16) or 1
+    # sweeps per ising_sweep call: the largest common divisor of steps and warm-up that one fused launch can carry (32)
+    g = math.gcd(args.steps, args.warmup) if args.warmup else args.steps
+    batch = max(d for d in range(1, 33) if g % d == 0)
 
     def advance(n):
         """n sweeps in pieces of `batch`, all asynchronous"""
