@@ -523,6 +523,18 @@ int ising_update_edges(ising_ctx *c, int it, int color) {
 	return launch_ranges(c, it, color, 0, 1, c->cfg.Y - 1, c->cfg.Y);
 }
 
+} // extern "C"
+
+int ising_host::update_edges_on(ising_ctx *c, int it, int color, hipStream_t s) {
+	hipStream_t keep = c->stream; // (a context is driven by one host thread)
+	c->stream = s;
+	const int rc = launch_ranges(c, it, color, 0, 1, c->cfg.Y - 1, c->cfg.Y);
+	c->stream = keep;
+	return rc;
+}
+
+extern "C" {
+
 int ising_sweep(ising_ctx *c, int first_it, int nsweeps) {
 	if (!c) return fail(ISING_E_ARG, "null context");
 	if (!c->wrap) return fail(ISING_E_STATE, "ising_sweep needs a single slab without ring halo rows; drive slabs with ising_ring_sweep / ising_rank_sweep or ising_update_color + halo exchange");

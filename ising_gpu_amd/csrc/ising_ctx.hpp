@@ -49,12 +49,14 @@ struct ising_ctx {
 	hipStream_t comm = nullptr;
 	hipEvent_t ev_edge[2] = {nullptr, nullptr};
 	hipEvent_t ev_sent[2] = {nullptr, nullptr};
+	hipEvent_t ev_int[2] = {nullptr, nullptr};  // compute stream: the interior rows of colour c are done
 	int transport = 0;                           // ISING_TRANSPORT_* in use (0 = not decided yet)
 	ising_ctx *ring_prev = nullptr, *ring_next = nullptr; // neighbours in a single-process ring
 	void *rccl_comm = nullptr;                   // ncclComm_t of this slab's rank
 	bool rccl_owner = false;                     // the communicator was created for this context (destroy it with the context)
 	bool rank_mode = false;                      // one slab per process: the neighbours live in other processes
 	bool peers_enabled = false;
+	bool copy_inline = false;                    // COPY transport, both neighbours on this slab's device: copies on the compute stream
 
 	// Row 0 of a colour.  The halo rows sit directly above (row -1: global row slab*Y-1) and below (row Y) so the
 	// kernels address rows -1..Y uniformly.  With one slab they mirror the slab's own last / first row (periodic
@@ -95,8 +97,11 @@ int ballot_image(ising_ctx *c);
 // ballot layout: allocate d_tmp; convert rows [row_lo, row_hi) of `color` between d_lat and d_tmp (rows -1 / Y = halo rows)
 int ballot_tmp(ising_ctx *c);
 int ballot_rows(ising_ctx *c, int color, long long row_lo, long long row_hi, bool to_dense);
-// makes the slab's stream wait until the halo rows of `color` delivered by the ring are in place
+// makes the slab's stream (or stream `s`) wait until the halo rows of `color` delivered by the ring are in place
 int halo_ready(ising_ctx *c, int color);
+int halo_ready_on(ising_ctx *c, int color, hipStream_t s);
+// ising_update_edges on another stream of the slab's device
+int update_edges_on(ising_ctx *c, int it, int color, hipStream_t s);
 // called by ising_destroy
 void ring_release(ising_ctx *c);
 

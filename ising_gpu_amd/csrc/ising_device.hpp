@@ -56,10 +56,6 @@ __device__ __forceinline__ PhiloxRow philox_row_setup(uint32_t tid, uint32_t k0x
 // ops instead of 4-cycle SGPR-operand ops -- costs 48 VGPRs and ran 3.5 % slower.)
 __device__ __forceinline__ void philox_block(const PhiloxRow &pr, uint32_t cx, uint32_t seed_lo, uint32_t seed_hi,
                                              uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
-#if defined(ISING_DBG_NORNG) // perf investigation only: not Philox, results are wrong by design
-	o0 = pr.t_lo1 + cx; o1 = pr.t_hi0 ^ cx; o2 = pr.t_lo0 + seed_lo; o3 = pr.t_e ^ seed_hi;
-	return;
-#endif
 	// round 1 (key 0), scalar half
 	uint32_t s_hi0, s_lo0;
 	mul_hilo(PHILOX_M0, cx, s_hi0, s_lo0);

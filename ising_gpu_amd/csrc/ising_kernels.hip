@@ -218,16 +218,9 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 	// 2^27 on) enters round 1 next to key word 0, so it folds into the seed operand of the per-row setup.
 	const uint32_t seed_lo_cy = p.seed_lo ^ (uint32_t)((2ull * p.it + p.color) >> 28);
 
-#if defined(ISING_DBG_NOMEM) // perf investigation only: no global traffic, results are wrong by design
-#define DBG_LD(expr) make_uint4(threadIdx.x, blockIdx.x, p.it, 0x01010101u)
-#define DBG_LDW(expr) (threadIdx.x * 0x10101u)
-#else
-#define DBG_LD(expr) (expr)
-#define DBG_LDW(expr) (expr)
-#endif
 	const ptrdiff_t uo = (slY && r0_in_sl == 0) ? (ptrdiff_t)(slY - 1) * vecs : -(ptrdiff_t)vecs;
-	uint4 up0 = DBG_LD(pc[uo]), up1 = DBG_LD(pc[uo + GROUP]);
-	uint4 ct0 = DBG_LD(pc[0]), ct1 = DBG_LD(pc[GROUP]);
+	uint4 up0 = pc[uo], up1 = pc[uo + GROUP];
+	uint4 ct0 = pc[0], ct1 = pc[GROUP];
 
 	for (int r = 0; r < nrows; ++r) {
 		const int lr = r0 + r;
@@ -236,11 +229,11 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 		// issue this row's loads; they are consumed only after the 16 Philox blocks below
 		const bool sl_last = SUBL && seam == 1; // last row of its sub-lattice: the row below is the sub-lattice's first row
 		const ptrdiff_t dwo = sl_last ? (ptrdiff_t)(1 - slY) * vecs : (ptrdiff_t)vecs;
-		const uint4 dw0 = DBG_LD(pc[dwo]), dw1 = DBG_LD(pc[dwo + GROUP]);
+		const uint4 dw0 = pc[dwo], dw1 = pc[dwo + GROUP];
 		const uint32_t *pcw = reinterpret_cast<const uint32_t *>(pc);
-		const uint32_t side0 = DBG_LDW(pcw[back ? offL0 : offR0]);
-		const uint32_t side1 = DBG_LDW(pcw[back ? offL1 : offR1]);
-		uint4 me0 = DBG_LD(pm[0]), me1 = DBG_LD(pm[GROUP]);
+		const uint32_t side0 = pcw[back ? offL0 : offR0];
+		const uint32_t side1 = pcw[back ? offL1 : offR1];
+		uint4 me0 = pm[0], me1 = pm[GROUP];
 		uint4 j0 = uint4(), j1 = uint4();
 		if (USEJ) { j0 = pj[0]; j1 = pj[GROUP]; pj += vecs; }
 
@@ -317,13 +310,8 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 			me0 = make_uint4(mv[0][0], mv[0][1], mv[0][2], mv[0][3]);
 			me1 = make_uint4(mv[1][0], mv[1][1], mv[1][2], mv[1][3]);
 		}
-#if defined(ISING_DBG_NOMEM)
-		if ((me0.x ^ me1.y) == 0x12345678u && me0.z == 0x9abcdef0u) // practically never: keeps the arithmetic alive
-#endif
-		{
-			pm[0] = me0;
-			pm[GROUP] = me1;
-		}
+		pm[0] = me0;
+		pm[GROUP] = me1;
 		if (p.wrap) { // single slab: keep this colour's own halo rows equal to the opposite edge rows
 			if (lr == 0) { pm[wrap_bot] = me0; pm[wrap_bot + GROUP] = me1; }
 			if (lr == p.Y - 1) { pm[-wrap_bot] = me0; pm[-wrap_bot + GROUP] = me1; }

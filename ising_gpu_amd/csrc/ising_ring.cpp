@@ -134,6 +134,7 @@ int ring_resources(ising_ctx *c) {
 	for (int k = 0; k < 2; k++) {
 		if (!c->ev_edge[k]) HIP_TRY(hipEventCreateWithFlags(&c->ev_edge[k], hipEventDisableTiming));
 		if (!c->ev_sent[k]) HIP_TRY(hipEventCreateWithFlags(&c->ev_sent[k], hipEventDisableTiming));
+		if (!c->ev_int[k]) HIP_TRY(hipEventCreateWithFlags(&c->ev_int[k], hipEventDisableTiming));
 	}
 	return ISING_OK;
 }
@@ -240,9 +241,14 @@ int ring_bind(ising_ctx **ctxs, int n, int want = ISING_TRANSPORT_AUTO) {
 	}
 	if (use == ISING_TRANSPORT_COPY) {
 		for (int k = 0; k < n; k++) {
-			rccl_drop(ctxs[k], false);
-			ring_enable_peers(ctxs[k]);
+			ising_ctx *c = ctxs[k];
+			rccl_drop(c, false);
+			ring_enable_peers(c);
+			c->copy_inline = c->ring_prev->cfg.device == c->cfg.device && c->ring_next->cfg.device == c->cfg.device;
+			if (const char *e = getenv("ISING_RING_INLINE")) c->copy_inline = c->copy_inline && atoi(e) != 0; // 0: exercise the two-stream schedule on one device
 		}
+	} else {
+		for (int k = 0; k < n; k++) ctxs[k]->copy_inline = false;
 	}
 	for (int k = 0; k < n; k++) ctxs[k]->transport = use;
 	return ISING_OK;
@@ -265,10 +271,13 @@ EdgeRows edge_rows(const ising_ctx *c, int color) {
 int transfer(ising_ctx **ctxs, int n, int color, bool after_edges) {
 	if (ctxs[0]->cfg.XSL) return ISING_OK; // sub-lattices never reach across slabs
 	const bool spin = color != ISING_HAM_BLACK;
+	// Copies between slabs of ONE device go on the slab's compute stream: a second stream buys nothing there (the copy
+	// needs the same CUs / DMA engines the kernels hold) and every cross-stream event on a shared device is a bubble.
+	auto lane = [](const ising_ctx *c) { return c->copy_inline ? c->stream : c->comm; };
 	for (int k = 0; k < n; k++) {
 		ising_ctx *c = ctxs[k];
 		if (int rc = bind(c)) return rc;
-		if (after_edges && spin) HIP_TRY(hipStreamWaitEvent(c->comm, c->ev_edge[color], 0));
+		if (after_edges && spin && !c->copy_inline) HIP_TRY(hipStreamWaitEvent(c->comm, c->ev_edge[color], 0));
 	}
 	if (ctxs[0]->transport == ISING_TRANSPORT_RCCL) {
 		RcclApi *api = rccl();
@@ -299,15 +308,15 @@ int transfer(ising_ctx **ctxs, int n, int color, bool after_edges) {
 			const EdgeRows e = edge_rows(c, color), ep = edge_rows(prev, color), en = edge_rows(next, color);
 			if (int rc = bind(c)) return rc;
 			// next slab's top halo <- my last row ; previous slab's bottom halo <- my first row
-			HIP_TRY(hipMemcpyPeerAsync(en.halo_top, next->cfg.device, e.last, c->cfg.device, e.bytes, c->comm));
-			HIP_TRY(hipMemcpyPeerAsync(ep.halo_bot, prev->cfg.device, e.first, c->cfg.device, e.bytes, c->comm));
+			HIP_TRY(hipMemcpyPeerAsync(en.halo_top, next->cfg.device, e.last, c->cfg.device, e.bytes, lane(c)));
+			HIP_TRY(hipMemcpyPeerAsync(ep.halo_bot, prev->cfg.device, e.first, c->cfg.device, e.bytes, lane(c)));
 		}
 	}
 	if (spin) {
 		for (int k = 0; k < n; k++) {
 			ising_ctx *c = ctxs[k];
 			if (int rc = bind(c)) return rc;
-			HIP_TRY(hipEventRecord(c->ev_sent[color], c->comm));
+			HIP_TRY(hipEventRecord(c->ev_sent[color], lane(c)));
 		}
 	}
 	return ISING_OK;
@@ -316,6 +325,7 @@ int transfer(ising_ctx **ctxs, int n, int color, bool after_edges) {
 int stage_edges(ising_ctx *c, int it, int color) {
 	if (int rc = ising_host::halo_ready(c, 1 - color)) return rc; // the edge rows read the other colour's halo rows
 	if (int rc = ising_update_edges(c, it, color)) return rc;
+	if (c->copy_inline) return ISING_OK;
 	if (int rc = bind(c)) return rc;
 	HIP_TRY(hipEventRecord(c->ev_edge[color], c->stream));
 	return ISING_OK;
@@ -337,8 +347,55 @@ int settle_layout(ising_ctx **ctxs, int n) {
 	return ISING_OK;
 }
 
+// Slabs with a comm stream of their own run the edge rows THERE, next to the interior rows on the compute stream:
+//
+//   compute stream                                   comm stream
+//   wait ev_edge[1-c]  (rows 0, Y-1 of the source)     wait ev_int[1-c]  (rows 1, Y-2 of the source; and the interior of
+//   interior rows 1 .. Y-2 of colour c                                    1-c has finished reading rows 0, Y-1 of c)
+//   record ev_int[c]                                   wait: halo rows of 1-c have arrived
+//                                                      edge rows 0, Y-1 of colour c (tiny launch) -> record ev_edge[c]
+//                                                      deliver them (RCCL / peer copies)          -> record ev_sent[c]
+//
+// Both kernels start when the interior of the previous half-sweep ends and run side by side, so the ~20 us a two-row
+// launch takes (its latency, not its work) is off the critical path: with the edge rows in front of the interior launch
+// on one stream a 65536-row slab loses ~3 % per half-sweep.
+int sweep_two_streams(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
+	for (int k = 0; k < n; k++) { // whatever the compute stream holds so far (initialisation, host writes, an earlier sweep)
+		ising_ctx *c = ctxs[k];
+		if (int rc = bind(c)) return rc;
+		HIP_TRY(hipEventRecord(c->ev_int[ISING_WHITE], c->stream));
+	}
+	for (int it = first_it; it < first_it + nsweeps; it++) {
+		for (int color = 0; color < 2; color++) {
+			for (int k = 0; k < n; k++) {
+				ising_ctx *c = ctxs[k];
+				if (int rc = bind(c)) return rc;
+				HIP_TRY(hipStreamWaitEvent(c->comm, c->ev_int[1 - color], 0));
+				if (int rc = ising_host::halo_ready_on(c, 1 - color, c->comm)) return rc;
+				if (int rc = ising_host::update_edges_on(c, it, color, c->comm)) return rc;
+				HIP_TRY(hipEventRecord(c->ev_edge[color], c->comm));
+			}
+			if (int rc = transfer(ctxs, n, color, false)) return rc;
+			for (int k = 0; k < n; k++) {
+				ising_ctx *c = ctxs[k];
+				if (int rc = bind(c)) return rc;
+				if (it > first_it || color == ISING_WHITE) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_edge[1 - color], 0));
+				if (int rc = ising_update_color(c, it, color, 1, c->cfg.Y - 1)) return rc;
+				HIP_TRY(hipEventRecord(c->ev_int[color], c->stream));
+			}
+		}
+	}
+	for (int k = 0; k < n; k++) { // later work on the compute stream (counts, reads, the next sweep) sees every row
+		ising_ctx *c = ctxs[k];
+		if (int rc = bind(c)) return rc;
+		HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_edge[ISING_WHITE], 0));
+	}
+	return ISING_OK;
+}
+
 int sweep_local(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 	if (int rc = settle_layout(ctxs, n)) return rc;
+	if (nsweeps > 0 && !ctxs[0]->copy_inline && !ctxs[0]->cfg.XSL) return sweep_two_streams(ctxs, n, first_it, nsweeps);
 	for (int it = first_it; it < first_it + nsweeps; it++) {
 		for (int color = 0; color < 2; color++) {
 			for (int k = 0; k < n; k++) if (int rc = stage_edges(ctxs[k], it, color)) return rc;
@@ -377,17 +434,21 @@ int rank_check(ising_ctx *c) {
 } // namespace
 
 // ------------------------------------------------------------------------------------------------ library-internal
-int ising_host::halo_ready(ising_ctx *c, int color) {
+int ising_host::halo_ready(ising_ctx *c, int color) { return halo_ready_on(c, color, c->stream); }
+
+int ising_host::halo_ready_on(ising_ctx *c, int color, hipStream_t s) {
 	if (c->wrap || c->cfg.XSL || !c->transport) return ISING_OK;
 	if (int rc = bind(c)) return rc;
 	if (c->transport == ISING_TRANSPORT_RCCL) {
 		// the receives are part of this slab's own group on its comm stream
-		if (c->ev_sent[color]) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_sent[color], 0));
+		if (c->ev_sent[color] && s != c->comm) HIP_TRY(hipStreamWaitEvent(s, c->ev_sent[color], 0));
 		return ISING_OK;
 	}
+	// (a neighbour that delivers on the very stream this slab computes on is ordered by the stream itself)
 	ising_ctx *prev = c->ring_prev, *next = c->ring_next;
-	if (prev && prev->ev_sent[color]) HIP_TRY(hipStreamWaitEvent(c->stream, prev->ev_sent[color], 0));
-	if (next && next != prev && next->ev_sent[color]) HIP_TRY(hipStreamWaitEvent(c->stream, next->ev_sent[color], 0));
+	auto same_lane = [&](const ising_ctx *o) { return o->copy_inline && o->stream == s && o->cfg.device == c->cfg.device; };
+	if (prev && prev->ev_sent[color] && !same_lane(prev)) HIP_TRY(hipStreamWaitEvent(s, prev->ev_sent[color], 0));
+	if (next && next != prev && next->ev_sent[color] && !same_lane(next)) HIP_TRY(hipStreamWaitEvent(s, next->ev_sent[color], 0));
 	return ISING_OK;
 }
 
@@ -398,6 +459,7 @@ void ising_host::ring_release(ising_ctx *c) {
 	for (int k = 0; k < 2; k++) {
 		if (c->ev_edge[k]) (void)hipEventDestroy(c->ev_edge[k]);
 		if (c->ev_sent[k]) (void)hipEventDestroy(c->ev_sent[k]);
+		if (c->ev_int[k]) (void)hipEventDestroy(c->ev_int[k]);
 	}
 	c->comm = nullptr;
 }

@@ -8,17 +8,20 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_sessionstart(session):
+    # the suite must exercise the in-tree product library, not an A/B build picked up through ISING_LIB
+    assert "ISING_LIB" not in os.environ, "unset ISING_LIB: the tests run against ising_gpu_amd/libising_hip.so"
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running oracle pinning (opt-in via ISING_SLOW=1)")
 
 
 def _have_gpu() -> bool:
-    try:
-        import ising_gpu_amd as ig
-        return ig.device_count() > 0
-    except Exception:
-        return False
+    import ising_gpu_amd as ig  # an import or load failure is an error of its own, not "no GPU"
+    assert os.path.dirname(ig.LIB_PATH) == os.path.join(ROOT, "ising_gpu_amd")
+    return ig.device_count() > 0
 
 
 @pytest.fixture(scope="session")

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Cost of the slab-ring schedule (edge rows launch + row exchange + interior launch per colour) on ONE GPU: n slabs
-of one device driven by LocalRing against the same lattice as a single slab.  Usage: ring_overhead_probe.py [X Ytot n sweeps]"""
+"""Cost of the slab-ring schedule (edge rows launch + halo delivery on the comm streams + interior launch per colour) on
+ONE GPU: n slabs of one device through the C-ABI ring (ising_ring_sweep: copy transport, second stream per slab) and
+through the torch-side LocalRing (copies on the compute stream), against the same lattice as a single slab driven by
+per-colour launches and by fused launches.  Usage: ring_overhead_probe.py [X Ytot n sweeps]"""
+import os
 import sys
 import time
 
@@ -12,22 +15,32 @@ import ising_gpu_amd as ig  # noqa: E402
 X, Y, n, sweeps = (int(v) for v in (sys.argv[1:5] if len(sys.argv) >= 5 else (65536, 65536, 2, 64)))
 
 
-def timed(fn):
-    fn(8)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    fn(sweeps)
-    torch.cuda.synchronize()
-    return time.perf_counter() - t0
+def timed(fn, sync):
+    fn(16)
+    sync()
+    best = 0.0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        fn(sweeps)
+        sync()
+        best = max(best, X * Y * sweeps / (time.perf_counter() - t0) * 1e-9)
+    return best
 
 
-with ig.IsingSlab(X, Y, seed=1, temp=ig.CRIT_TEMP_F32) as s:
-    s.init()
-    dt = timed(lambda k: (s.sweep(k), s.synchronize()))
-    print(f"single slab {Y}x{X}: {X * Y * sweeps / dt * 1e-9:8.1f} flips/ns  layout {s.layout}")
+for fused in ("0", "1"):
+    os.environ["ISING_FUSED"] = fused
+    with ig.IsingSlab(X, Y, seed=1, temp=ig.CRIT_TEMP_F32) as s:
+        s.init()
+        v = timed(lambda k: s.sweep(k), s.synchronize)
+        print(f"single slab {Y}x{X}, {'fused' if s.fused else 'per-colour'} launches: {v:8.1f} flips/ns  layout {s.layout}")
+        base = v if fused == "0" else base
+ring = ig.SlabSet([ig.IsingSlab(X, Y // n, seed=1, temp=ig.CRIT_TEMP_F32, nslabs=n, slab=k) for k in range(n)]).init()
+v = timed(lambda k: ring.sweep(k), ring.synchronize)
+print(f"{n} slabs of {Y // n}x{X} on one device, C-ABI ring (edges, copies on the comm streams, interior): {v:8.1f} flips/ns = {100 * (v / base - 1):+.2f} % vs per-colour single slab")
+ring.close()
 backs = [ig.HipSlabBackend.create(X, Y // n, seed=1, temp=ig.CRIT_TEMP_F32, nslabs=n, slab=k) for k in range(n)]
-ring = ig.LocalRing(backs).init()
-dt = timed(lambda k: ring.sweep(k))
-print(f"{n} slabs of {Y // n}x{X} on one device (edges + copies + interior): {X * Y * sweeps / dt * 1e-9:8.1f} flips/ns")
+lring = ig.LocalRing(backs).init()
+v = timed(lambda k: lring.sweep(k), torch.cuda.synchronize)
+print(f"{n} slabs of {Y // n}x{X} on one device, torch-side LocalRing (copies on the compute stream):   {v:8.1f} flips/ns = {100 * (v / base - 1):+.2f} %")
 for b in backs:
     b.slab.close()

@@ -14,7 +14,9 @@ echo
 echo "### config 4 as 8 slabs on ONE device (decomposition check of the 131072x131072 lattice, 2 sweeps only)"
 $CLI -x 131072 -y 16384 -d 8 --devmap 0,0,0,0,0,0,0,0 -n 2 -a 1 -s 1234 | grep -E "magnetization|Kernel execution|total lattice size"
 echo
-echo "### config 5: 8192x8192, seed 1234, T = 1.50 .. 3.00 step 0.05, 2000 sweeps each: final |m| and E/N"
-for T in $(seq 1.50 0.05 3.001); do
-  $CLI -x 8192 -y 8192 -d 1 -n 2000 -t $T -s 1234 --energy | awk -v T=$T '/Final   magnetization/ {m=$3} /Final   energy/ {e=$3} /Kernel execution/ {f=$(NF-4)} END {printf "T=%s |m|=%s E/N=%s flips/ns=%s\n", T, m, e, f}'
-done
+echo "### config 4 as 8 slabs on ONE device, 128 sweeps: the C-ABI ring (second stream per slab) at full length"
+$CLI -x 131072 -y 16384 -d 8 --devmap 0,0,0,0,0,0,0,0 -n 128 -a 1 -s 1234 | grep -E "magnetization|Kernel execution|total lattice size"
+echo
+echo "### config 5: 8192x8192, seed 1234, T = 1.50 .. 3.00 step 0.05 in ONE process (--tsweep): per point a fresh lattice,"
+echo "### 1000 equilibration sweeps, 100 measurements 10 sweeps apart: <|m|>, <m^2>, chi, U4, <e>, Cv"
+$CLI -x 8192 -y 8192 -d 1 -s 1234 --tsweep 1.5,3.0,0.05,1000,100,10 | grep -E "^T = |Temperature sweep"
