@@ -173,9 +173,12 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 		// FUSED: strips are taken from both ends of the slab inwards (0, N-1, 1, N-2, ...), so that the periodic
 		// neighbours strip 0 and strip N-1 wait for are the first tickets of the previous level, not its last
 		const int nstr = (p.row_hi[0] - p.row_lo[0] + p.H - 1) / p.H;
-		const int sidx = FUSED ? uni((pos & 1) ? nstr - 1 - (pos >> 1) : (pos >> 1)) : pos;
+		// (also when a plain launch publishes its edge rows, p.edge_signal: the two edge strips go first)
+		const bool zigzag = FUSED || (p.edge_signal != nullptr && rng == 0);
+		const int sidx = zigzag ? uni((pos & 1) ? nstr - 1 - (pos >> 1) : (pos >> 1)) : pos;
 		const int r0 = p.row_lo[rng] + sidx * p.H;
 		const int nrows = idle ? 0 : min(p.H, p.row_hi[rng] - r0);
+		const bool publish = !FUSED && p.edge_signal != nullptr && !idle && rng == 0 && (r0 == 0 || r0 + nrows == p.Y);
 		const uint32_t color = FUSED ? uni((p.color + (uint32_t)level) & 1u) : p.color;
 		const uint32_t it = FUSED ? uni(p.it + ((p.color + (uint32_t)level) >> 1)) : p.it;
 		const uint64_t *src = FUSED ? (color ? p.lat[0] : p.lat[1]) : p.src;
@@ -343,7 +346,7 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 					rj += 4 * wpr;
 				}
 				const uint64_t nw = me ^ flips64(me, nu, nc, nd, sd, c3, c4);
-				st_word<FUSED>(rd + lane, nw);
+				if (FUSED || publish) st_word<true>(rd + lane, nw); else st_word<false>(rd + lane, nw);
 				if (p.wrap) { // single slab: keep this colour's own halo rows equal to the opposite edge rows
 					if (lr == 0) st_word<FUSED>(rd + wrap_bot + lane, nw);
 					if (lr == p.Y - 1) st_word<FUSED>(rd - wrap_bot + lane, nw);
@@ -360,6 +363,12 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 				}
 			}
 			if (wb_wave && r < rmax) asm volatile("s_dcache_wb" ::: "memory");
+		}
+		if (publish) {
+			// ring: rows 0 / Y-1 of this colour are what the neighbours wait for.  The strip was written through; once this
+			// wave's stores have left it, the slab's comm stream may send (hipStreamWaitValue32 on the counter)
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if (lane == 0) __hip_atomic_fetch_add(p.edge_signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 		if (FUSED && !idle) {
 			// publish: this wave's stores were written through (sc1); once they have left the wave the strip's counter

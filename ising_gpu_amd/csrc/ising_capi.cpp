@@ -379,6 +379,7 @@ int ising_destroy(ising_ctx *c) {
 	if (c->d_bits) (void)hipFree(c->d_bits);
 	if (c->d_corr) (void)hipFree(c->d_corr);
 	if (c->d_slotctl) (void)hipFree(c->d_slotctl);
+	for (int k = 0; k < 2; k++) if (c->d_signal[k]) (void)hipFree(c->d_signal[k]);
 	if (c->d_pack) (void)hipFree(c->d_pack);
 	delete c;
 	return ISING_OK;
@@ -440,7 +441,7 @@ int ising_strip_info(ising_ctx *c, int *strip_rows, int *nstrips) {
 // launches update_k over up to two row ranges
 // `nlevels` > 1 (ballot layout only): one fused launch of that many colour half-sweeps over the whole slab, starting with
 // `color` at iteration `it`
-static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int lo1, int hi1, int nlevels = 1) {
+static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int lo1, int hi1, int nlevels = 1, bool publish = false) {
 	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
 	if (it < 0) return fail(ISING_E_ARG, "negative iteration %d", it);
 	int mode = c->cfg.kernel == ISING_KERNEL_GENERIC ? 1 : (c->cfg.kernel == ISING_KERNEL_LUT ? 2 : 0); // AUTO, FAST -> 0
@@ -499,6 +500,10 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			p.done = c->d_slotctl + SLOTCTL_TICKET_BYTES / 4;
 			p.done_base = c->done_base;
 		}
+		if (publish) {
+			p.edge_signal = c->d_signal[color];
+			c->edge_target[color] += (uint32_t)(c->gx / 4) * (c->nstrips == 1 ? 1u : 2u); // wave columns of the strips with row 0 / Y-1
+		}
 		int grid = 0;
 		HIP_TRY(ising::launch_ballot_update(p, c->stream, &grid));
 		if (nlevels > 1) c->done_base += (uint32_t)nlevels * (uint32_t)(c->gx / 4);
@@ -531,6 +536,11 @@ int ising_host::update_edges_on(ising_ctx *c, int it, int color, hipStream_t s) 
 	const int rc = launch_ranges(c, it, color, 0, 1, c->cfg.Y - 1, c->cfg.Y);
 	c->stream = keep;
 	return rc;
+}
+
+int ising_host::update_full_published(ising_ctx *c, int it, int color) {
+	if (!c->ballot || !c->d_signal[color]) return fail(ISING_E_STATE, "published edge rows need the ballot layout and signal memory");
+	return launch_ranges(c, it, color, 0, c->cfg.Y, 0, 0, 1, true);
 }
 
 extern "C" {

@@ -56,6 +56,9 @@ struct ising_ctx {
 	bool rccl_owner = false;                     // the communicator was created for this context (destroy it with the context)
 	bool rank_mode = false;                      // one slab per process: the neighbours live in other processes
 	bool peers_enabled = false;
+	uint32_t *d_signal[2] = {nullptr, nullptr};  // per colour: counter the published edge strips of a full-slab launch bump
+	                                             // (hipMallocSignalMemory: the comm stream waits on it, hipStreamWaitValue32)
+	uint32_t edge_target[2] = {0, 0};            // value of the counter once every launch issued so far has published
 	bool copy_inline = false;                    // COPY transport, both neighbours on this slab's device: copies on the compute stream
 
 	// Row 0 of a colour.  The halo rows sit directly above (row -1: global row slab*Y-1) and below (row Y) so the
@@ -102,6 +105,8 @@ int halo_ready(ising_ctx *c, int color);
 int halo_ready_on(ising_ctx *c, int color, hipStream_t s);
 // ising_update_edges on another stream of the slab's device
 int update_edges_on(ising_ctx *c, int it, int color, hipStream_t s);
+// ballot layout: one launch over rows [0, Y) whose edge strips go first and publish rows 0 / Y-1 through d_signal[color]
+int update_full_published(ising_ctx *c, int it, int color);
 // called by ising_destroy
 void ring_release(ising_ctx *c);
 

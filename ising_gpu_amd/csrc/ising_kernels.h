@@ -41,6 +41,8 @@ struct UpdateParams {
 	const uint64_t *jham[2];  // fused, -J: coupling words read when colour c is updated
 	uint32_t *done;           // fused: completed wave columns per strip (monotone); reads `done_base` when the launch starts
 	uint32_t done_base;
+	uint32_t *edge_signal;    // plain launch over rows [0, Y) of a ring slab: the wave columns of the strips holding row 0
+	                          // and row Y-1 go first, write through, and each adds 1 here when its rows are out (NULL: off)
 };
 
 // mode: 0 = integer thresholds via v_cmpx, 1 = generic FP32-table kernel, 2 = integer thresholds via the LDS rank table

@@ -131,6 +131,18 @@ int ring_resources(ising_ctx *c) {
 		HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
 		HIP_TRY(hipStreamCreateWithPriority(&c->comm, hipStreamNonBlocking, greatest));
 	}
+	int can_wait = 0;
+	if (hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, c->cfg.device) != hipSuccess) { can_wait = 0; (void)hipGetLastError(); }
+	// A/B, off by default: measured 1-2 % SLOWER than the two-row launch on the comm stream (tools/ring_of_one_probe.py)
+	const char *pub_env = getenv("ISING_RING_PUBLISH");
+	can_wait = can_wait && pub_env && atoi(pub_env) != 0;
+	for (int k = 0; k < 2 && can_wait && c->ballot && !c->d_signal[k]; k++) {
+		void *p = nullptr;
+		if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) != hipSuccess) { (void)hipGetLastError(); break; }
+		c->d_signal[k] = static_cast<uint32_t *>(p);
+		HIP_TRY(hipMemset(p, 0, 8));
+		c->edge_target[k] = 0;
+	}
 	for (int k = 0; k < 2; k++) {
 		if (!c->ev_edge[k]) HIP_TRY(hipEventCreateWithFlags(&c->ev_edge[k], hipEventDisableTiming));
 		if (!c->ev_sent[k]) HIP_TRY(hipEventCreateWithFlags(&c->ev_sent[k], hipEventDisableTiming));
@@ -393,9 +405,50 @@ int sweep_two_streams(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 	return ISING_OK;
 }
 
+// (ISING_RING_PUBLISH=1.)  Ballot slabs with a comm stream of their own need no separate launch for the edge rows: ONE launch per colour covers
+// the slab, the strips that hold row 0 and row Y-1 go first, write through and bump a counter when their rows are out
+// (ballot_update_k, p.edge_signal), and the comm stream waits for the counter (hipStreamWaitValue32) before it sends.
+//
+//   compute stream                                        comm stream
+//   wait: halo rows of colour 1-c have arrived              wait: counter of colour c >= what this launch brings it to
+//   rows 0 .. Y-1 of colour c, edge strips first            (peer copies: the neighbours' launches of 1-c, which read the
+//   record ev_int[c]                                         halo rows about to be overwritten, are done: their ev_int[1-c])
+//                                                            deliver rows 0 / Y-1                      record ev_sent[c]
+int sweep_published(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
+	const bool copies = ctxs[0]->transport != ISING_TRANSPORT_RCCL;
+	for (int it = first_it; it < first_it + nsweeps; it++) {
+		for (int color = 0; color < 2; color++) {
+			for (int k = 0; k < n; k++) {
+				ising_ctx *c = ctxs[k];
+				if (int rc = ising_host::halo_ready(c, 1 - color)) return rc;
+				if (int rc = bind(c)) return rc;
+				// rows 0 / Y-1 of colour c are about to be overwritten: what the comm stream sent of them last sweep has left
+				if (copies && c->ev_sent[color]) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_sent[color], 0));
+				if (int rc = ising_host::update_full_published(c, it, color)) return rc;
+				HIP_TRY(hipEventRecord(c->ev_int[color], c->stream));
+			}
+			for (int k = 0; k < n; k++) {
+				ising_ctx *c = ctxs[k];
+				if (int rc = bind(c)) return rc;
+				HIP_TRY(hipStreamWaitValue32(c->comm, c->d_signal[color], c->edge_target[color], hipStreamWaitValueGte, 0xFFFFFFFFu));
+				if (copies) {
+					ising_ctx *prev = c->ring_prev, *next = c->ring_next;
+					if (prev != c) HIP_TRY(hipStreamWaitEvent(c->comm, prev->ev_int[1 - color], 0));
+					if (next != c && next != prev) HIP_TRY(hipStreamWaitEvent(c->comm, next->ev_int[1 - color], 0));
+				}
+			}
+			if (int rc = transfer(ctxs, n, color, false)) return rc;
+		}
+	}
+	return ISING_OK;
+}
+
 int sweep_local(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 	if (int rc = settle_layout(ctxs, n)) return rc;
-	if (nsweeps > 0 && !ctxs[0]->copy_inline && !ctxs[0]->cfg.XSL) return sweep_two_streams(ctxs, n, first_it, nsweeps);
+	bool two = nsweeps > 0 && !ctxs[0]->copy_inline && !ctxs[0]->cfg.XSL, pub = two;
+	for (int k = 0; k < n; k++) pub = pub && ctxs[k]->ballot && ctxs[k]->d_signal[0] && ctxs[k]->d_signal[1] && ctxs[k]->edge_target[0] < (1u << 30);
+	if (pub) return sweep_published(ctxs, n, first_it, nsweeps);
+	if (two) return sweep_two_streams(ctxs, n, first_it, nsweeps);
 	for (int it = first_it; it < first_it + nsweeps; it++) {
 		for (int color = 0; color < 2; color++) {
 			for (int k = 0; k < n; k++) if (int rc = stage_edges(ctxs[k], it, color)) return rc;
