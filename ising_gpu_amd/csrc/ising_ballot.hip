@@ -93,8 +93,8 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 // same).  The chip never drains between colours.  Measured: equal to plain launches from 32768^2 up, slower
 // below -- one counter hands out at most ~88 tickets per us and a unit carries ~19 us of latency (ticket, completion
 // counters, write-through stores) that small strips do not amortise.
-template <bool SUBL, bool USEJ, bool FUSED>
-__global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParams p) {
+template <bool SUBL, bool USEJ, bool FUSED, int NT = BAL_THREADS>
+__global__ void __launch_bounds__(NT) ballot_update_k(const UpdateParams p) {
 	const int lane = threadIdx.x & 63;
 	const int tx = threadIdx.x & (GROUP - 1), g = (threadIdx.x >> 4) & 3;
 	const int wi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 	const ptrdiff_t wrap_bot = (ptrdiff_t)p.Y * wpr;
 
 	// this workgroup slot's scratch: per wave two slots of 64 x (c3, c4) masks
-	const uint64_t *slot_v = p.scratch + ((size_t)blockIdx.x * (BAL_THREADS / 64) + wi) * 256;
+	const uint64_t *slot_v = p.scratch + ((size_t)blockIdx.x * (NT / 64) + wi) * 256;
 	const uint32_t slot_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)slot_v);
 	const uint32_t slot_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)slot_v >> 32));
 	uint64_t *slot = reinterpret_cast<uint64_t *>(((uintptr_t)slot_hi << 32) | slot_lo);
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 	// The block-constant (wave-uniform) first two Philox rounds of the 16 draw blocks, three values each, live in LDS:
 	// as SGPRs they overflow the register file or, recomputed per row, make the XORs that consume them 4-cycle
 	// SGPR-operand instructions; from LDS they arrive in VGPRs (2-cycle XORs, +1.5 %).  One private copy per wave.
-	__shared__ uint4 blk_const_all[BAL_THREADS / 64][16];
+	__shared__ uint4 blk_const_all[NT / 64][16];
 	__shared__ unsigned long long ticket_sh[2];
 	uint4 *blk_const = blk_const_all[wi];
 	const unsigned long long total = (unsigned long long)p.nlevels * (unsigned long long)p.nwg;
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(BAL_THREADS) ballot_update_k(const UpdateParam
 		}
 		if (tk >= total) break;
 		const int level = FUSED ? uni((int)(tk / (unsigned)p.nwg)) : 0;
-		const int wave = uni(((int)(tk - (unsigned long long)level * (unsigned)p.nwg)) * (BAL_THREADS / 64) + wi);
+		const int wave = uni(((int)(tk - (unsigned long long)level * (unsigned)p.nwg)) * (NT / 64) + wi);
 		const int unit0 = wave * 4; // a wave covers 4 consecutive 32-vector column groups of one strip (gx % 4 == 0)
 		const bool idle = unit0 >= p.nunits; // the last workgroup of a level may be partly empty; it still meets the barriers
 		const int rng = unit0 >= p.nunits0;
@@ -538,58 +538,66 @@ __global__ void __launch_bounds__(THREADS) ham_ballot_to_planes_k(uint64_t *__re
 } // namespace
 
 // Workgroups the chip holds at once for kernel variant `v` on the current device (occupancy x compute units).
-static int ballot_resident_wgs(int v, const void *fn) {
-	static int cache[16][8];
+static int ballot_resident_wgs(int v, const void *fn, int threads) {
+	static int cache[16][16];
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
 	if (!cache[dev][v]) {
 		int per_cu = 0, cus = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, BAL_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
 		if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
 		cache[dev][v] = per_cu * cus;
 	}
 	return cache[dev][v];
 }
 
-int ballot_max_wgs() { return 256 * 8; } // upper bound of the grid of any ballot launch (scratch sizing): 8 workgroups per CU at most
+int ballot_max_wgs() { return 256 * 8; } // upper bound of the grid of any ballot launch (scratch sizing): 8 workgroups of 4 waves per CU at most
 
-hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_out) {
-	if (grid_out) *grid_out = 0;
-	if (p.nunits <= 0) return hipSuccess;
-	p.nwg = (p.nunits + BAL_THREADS / GROUP - 1) / (BAL_THREADS / GROUP);
-	if (p.nlevels < 1) p.nlevels = 1;
+template <int NT>
+static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, int *grid_out) {
+	p.nwg = (p.nunits + NT / GROUP - 1) / (NT / GROUP);
 	const bool fused = p.nlevels > 1;
 	const bool usej = fused ? p.jham[0] != nullptr : p.jdst != nullptr;
 	const bool subl = p.slY != 0;
-	if (fused && subl) return hipErrorInvalidValue; // a sub-lattice seam reaches beyond the neighbouring strips
 	const void *fn;
 	const int v = (fused ? 4 : 0) | (subl ? 2 : 0) | (usej ? 1 : 0);
 	switch (v) {
-	case 0: fn = (const void *)ballot_update_k<false, false, false>; break;
-	case 1: fn = (const void *)ballot_update_k<false, true, false>; break;
-	case 2: fn = (const void *)ballot_update_k<true, false, false>; break;
-	case 3: fn = (const void *)ballot_update_k<true, true, false>; break;
-	case 4: fn = (const void *)ballot_update_k<false, false, true>; break;
-	default: fn = (const void *)ballot_update_k<false, true, true>; break;
+	case 0: fn = (const void *)ballot_update_k<false, false, false, NT>; break;
+	case 1: fn = (const void *)ballot_update_k<false, true, false, NT>; break;
+	case 2: fn = (const void *)ballot_update_k<true, false, false, NT>; break;
+	case 3: fn = (const void *)ballot_update_k<true, true, false, NT>; break;
+	case 4: fn = (const void *)ballot_update_k<false, false, true, NT>; break;
+	default: fn = (const void *)ballot_update_k<false, true, true, NT>; break;
 	}
 	// Plain launches: one workgroup per unit, handed out by the hardware dispatcher (a persistent grid striding over the
 	// units runs all workgroups in lockstep -- every wave in its draw phase, then every wave in its word phase -- and
 	// measured 11 % slower).  Fused launches: as many workgroups as the chip holds; a few more are harmless (they find
 	// the tickets gone), so the occupancy query need not be exact.
 	const long long total = (long long)p.nwg * p.nlevels;
-	long long grid = fused ? std::min<long long>(std::min(ballot_resident_wgs(v, fn), ballot_max_wgs()), total) : total;
+	long long grid = fused ? std::min<long long>(std::min(ballot_resident_wgs(v + (NT == 256 ? 0 : 8), fn, NT), ballot_max_wgs() * 256 / NT), total) : total;
 	if (grid < 1) grid = 1;
-	const dim3 g((unsigned)grid), block(BAL_THREADS);
+	const dim3 g((unsigned)grid), block(NT);
 	switch (v) {
-	case 0: hipLaunchKernelGGL((ballot_update_k<false, false, false>), g, block, 0, stream, p); break;
-	case 1: hipLaunchKernelGGL((ballot_update_k<false, true, false>), g, block, 0, stream, p); break;
-	case 2: hipLaunchKernelGGL((ballot_update_k<true, false, false>), g, block, 0, stream, p); break;
-	case 3: hipLaunchKernelGGL((ballot_update_k<true, true, false>), g, block, 0, stream, p); break;
-	case 4: hipLaunchKernelGGL((ballot_update_k<false, false, true>), g, block, 0, stream, p); break;
-	default: hipLaunchKernelGGL((ballot_update_k<false, true, true>), g, block, 0, stream, p); break;
+	case 0: hipLaunchKernelGGL((ballot_update_k<false, false, false, NT>), g, block, 0, stream, p); break;
+	case 1: hipLaunchKernelGGL((ballot_update_k<false, true, false, NT>), g, block, 0, stream, p); break;
+	case 2: hipLaunchKernelGGL((ballot_update_k<true, false, false, NT>), g, block, 0, stream, p); break;
+	case 3: hipLaunchKernelGGL((ballot_update_k<true, true, false, NT>), g, block, 0, stream, p); break;
+	case 4: hipLaunchKernelGGL((ballot_update_k<false, false, true, NT>), g, block, 0, stream, p); break;
+	default: hipLaunchKernelGGL((ballot_update_k<false, true, true, NT>), g, block, 0, stream, p); break;
 	}
 	if (grid_out) *grid_out = (int)grid;
 	return hipGetLastError();
+}
+
+hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_out) {
+	if (grid_out) *grid_out = 0;
+	if (p.nunits <= 0) return hipSuccess;
+	if (p.nlevels < 1) p.nlevels = 1;
+	if (p.nlevels > 1 && p.slY != 0) return hipErrorInvalidValue; // a sub-lattice seam reaches beyond the neighbouring strips
+	// A/B (ISING_FUSED_WIDE=1): 8-wave workgroups for fused launches -- half the tickets per row of work; +10 % at 8192^2,
+	// +2 % at 16384^2, -4 % at 65536^2 against 4-wave workgroups
+	if (p.nlevels > 1 && p.wide) return launch_ballot_update_nt<512>(p, stream, grid_out);
+	return launch_ballot_update_nt<BAL_THREADS>(p, stream, grid_out);
 }
 
 hipError_t launch_ballot_init(const InitParams &p, hipStream_t stream) {

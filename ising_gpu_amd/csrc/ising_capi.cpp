@@ -351,6 +351,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		// fused sweeps (ising_sweep): on a par with per-colour launches from 32768^2 up, slower below
 		const char *fz = getenv("ISING_FUSED");
 		c->fused = fz ? atoi(fz) != 0 : (long long)cfg->X * cfg->Y >= (1LL << 29);
+		if (const char *e = getenv("ISING_FUSED_WIDE")) c->fused_wide = atoi(e);
 	}
 	if (e == hipSuccess && cfg->use_J) {
 		if (cfg->coupling_mem) c->d_ham = static_cast<uint64_t *>(cfg->coupling_mem);
@@ -498,6 +499,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			p.jham[0] = c->cfg.use_J ? c->ham(1) : nullptr;
 			p.jham[1] = c->cfg.use_J ? c->ham(0) : nullptr;
 			p.done = c->d_slotctl + SLOTCTL_TICKET_BYTES / 4;
+			p.wide = c->fused_wide;
 			p.done_base = c->done_base;
 		}
 		if (publish) {

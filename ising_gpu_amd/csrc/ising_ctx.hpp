@@ -20,6 +20,7 @@ struct ising_ctx {
 	uint32_t *d_slotctl = nullptr; // ballot layout, fused launches: ticket words (576 bytes) + per-strip completion counters
 	uint32_t done_base = 0;        // value of every completion counter once everything launched so far has run
 	bool fused = false;            // ising_sweep batches colour half-sweeps into fused launches
+	int fused_wide = 0;            // ... with 512-thread workgroups
 	uint64_t *d_pack = nullptr;    // staging for device-side conversion to / from the packed boundary format
 	size_t pack_words = 0;
 	int lld_packed = 0; // 64-bit words per colour row in the reference's packed layout (X/32)

@@ -35,6 +35,7 @@ struct UpdateParams {
 	// ballot layout, persistent launches
 	unsigned long long *ticket; // fused: ticket words (chunk counter + 8 queue words, 64 bytes apart), zero when the launch starts
 	int32_t nwg;              // workgroup units per level (set by the launcher)
+	int32_t wide;             // fused: 512-thread workgroups (8 waves per ticket)
 	int32_t nlevels;          // colour half-sweeps in this launch.  > 1 = fused: level L updates colour (color + L) & 1 at
 	                          // iteration it + (color + L) / 2 over rows [row_lo[0], row_hi[0]) = the whole slab (wrap)
 	uint64_t *lat[2];         // fused: row-0 pointers of both colours
