@@ -1,0 +1,117 @@
+"""The fused launch form of the ballot kernel (ising_sweep: several colour half-sweeps per launch, in-order tickets,
+per-strip completion counters, write-through hand-over between workgroups -- csrc/ising_ballot.hip).  By default only
+lattices from 32768^2 up take it (tests/test_gpu_fullsize.py, the 65536^2 README runs); here it is forced on smaller
+ones (ISING_FUSED=1 is read when a slab is created) so that every seam of it is compared with the oracle word for word:
+strip order from both ends, periodic wrap through the mirror rows, launches of 1 .. 32 sweeps and the cuts between them,
+one wave column (X = 8192, four strips per workgroup) and several, partly empty workgroups, -J, temperature changes
+between launches, and the 8-wave workgroup variant."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import ising_gpu_amd as ig
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture
+def fused(monkeypatch):
+    monkeypatch.setenv("ISING_FUSED", "1")
+
+
+def _same(s, orc):
+    return np.array_equal(s.read(ig.BLACK), orc.black) and np.array_equal(s.read(ig.WHITE), orc.white)
+
+
+@pytest.mark.parametrize("X,Y,strip", [(8192, 16, 0), (8192, 48, 8), (8192, 272, 1), (16384, 160, 4), (24576, 96, 2), (32768, 1024, 8)])
+def test_fused_matches_oracle_state(gpu, oracle_mod, fused, X, Y, strip):
+    seed, temp = 2025, ig.CRIT_TEMP_F32
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=temp).init()
+    with ig.IsingSlab(X, Y, seed=seed, temp=temp, layout=ig.LAYOUT_BALLOT, strip_rows=strip) as s:
+        assert s.fused
+        s.init()
+        for n in (1, 2, 3, 1, 7):  # launches of 2, 4, 6, 2, 14 levels; the iteration counter runs on across them
+            s.sweep(n)
+            orc.sweep(n)
+            assert _same(s, orc), (X, Y, s.it)
+            assert s.count() == orc.count() and s.bond_equal() == orc.bond_equal()
+
+
+def test_fused_batches_of_32_sweeps_and_the_cut_between_them(gpu, oracle_mod, fused):
+    X, Y, seed = 8192, 64, 11
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=2.0).init().sweep(70)
+    with ig.IsingSlab(X, Y, seed=seed, temp=2.0, layout=ig.LAYOUT_BALLOT) as s:
+        s.init().sweep(70)  # 32 + 32 + 6 sweeps = three launches
+        assert _same(s, orc) and s.count() == orc.count()
+
+
+def test_fused_with_couplings_and_temperature_changes(gpu, oracle_mod, fused):
+    X, Y, seed = 16384, 64, 5
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=1.5).init().init_couplings(0.3)
+    with ig.IsingSlab(X, Y, seed=seed, temp=1.5, layout=ig.LAYOUT_BALLOT, J_prob=0.3) as s:
+        s.init().init_couplings()
+        assert s.fused
+        for t in (1.5, 2.5, 0.9):
+            s.set_temperature(t)
+            orc.temp = float(np.float32(t))
+            s.sweep(3)
+            orc.sweep(3)
+            assert _same(s, orc), t
+    # a temperature without integer thresholds ends the fused form (and the ballot layout) on the spot
+    with ig.IsingSlab(X, Y, seed=seed, temp=1.5, layout=ig.LAYOUT_BALLOT) as s:
+        s.init().sweep(2)
+        s.set_temperature(-1.0)
+        assert not s.fused
+        s.sweep(2)
+        orc2 = oracle_mod.OracleLattice(X, Y, seed=seed, temp=1.5).init().sweep(2)
+        orc2.temp = -1.0
+        orc2.sweep(2)
+        assert s.current_layout() == ig.LAYOUT_DENSE and _same(s, orc2)
+
+
+def test_fused_wide_workgroups(gpu, oracle_mod, fused, monkeypatch):
+    monkeypatch.setenv("ISING_FUSED_WIDE", "1")
+    for X, Y, strip in ((8192, 80, 1), (16384, 96, 2), (8192, 1024, 4)):
+        orc = oracle_mod.OracleLattice(X, Y, seed=3, temp=ig.CRIT_TEMP_F32).init().sweep(9)
+        with ig.IsingSlab(X, Y, seed=3, temp=ig.CRIT_TEMP_F32, layout=ig.LAYOUT_BALLOT, strip_rows=strip) as s:
+            s.init().sweep(4).sweep(5)
+            assert _same(s, orc), (X, Y)
+
+
+def test_fused_equals_plain_at_16384_full_size(gpu, monkeypatch):
+    """BASELINE config 2's lattice on both launch forms: identical packed state after 40 sweeps."""
+    got = {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("ISING_FUSED", form)
+        with ig.IsingSlab(16384, 16384, seed=1234, temp=ig.CRIT_TEMP_F32, layout=ig.LAYOUT_BALLOT) as s:
+            assert s.fused == (form == "1")
+            s.init().sweep(40)
+            got[form] = (s.count(), s.bond_equal(), s.read_bits(ig.BLACK).tobytes(), s.read_bits(ig.WHITE).tobytes())
+    assert got["0"] == got["1"]
+
+
+def test_bench_line_on_a_small_lattice(gpu):
+    """bench.py end to end (the driver's command shape) on a lattice that takes a second: one JSON line with the contract's
+    keys, the roofline and cpu_baseline objects, and counts equal to the oracle's."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--x", "8192", "--y", "8192",
+                        "--preheat-ms", "5", "--cpu-threads", "8"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    b = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in b, key
+    assert b["n_gpus"] == 1 and b["steps"] == 4 and b["warmup"] == 2 and b["unit"] == "flips/ns" and b["value"] > 100
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "alu_ceiling"):
+        assert key in b["roofline"], key
+    assert abs(b["roofline"]["frac"] - b["roofline"]["achieved"] / b["roofline"]["peak"]) < 1e-3
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in b["cpu_baseline"], key
+    import oracle
+    orc = oracle.OracleLattice(8192, 8192, seed=1234, temp=oracle.CRIT_TEMP).init().sweep(6)
+    assert (b["config"]["up"], b["config"]["down"]) == orc.count()
