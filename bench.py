@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--preheat-ms", type=float, default=150.0,
                     help="untimed sweeps before the warm-up until this much wall time has passed (the lattice is initialised "
                          "again afterwards): from a cold start the GPU needs ~35 ms under load to reach its steady clock")
+    ap.add_argument("--force-ring", action="store_true",
+                    help="N = 1: run the N > 1 code path anyway -- torch.distributed + the library's RCCL ring with a ring of "
+                         "ONE slab (its edge rows travel through ncclSend/ncclRecv to itself); what a 1-GPU box can test of it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alu-probe", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -126,19 +129,22 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    ringed = world > 1 or args.force_ring
+    if ringed:
+        if "MASTER_ADDR" not in os.environ:  # --force-ring without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29577"), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     layout = {"auto": ig.LAYOUT_AUTO, "nibble": ig.LAYOUT_NIBBLE, "dense": ig.LAYOUT_DENSE, "ballot": ig.LAYOUT_BALLOT}[args.layout]
     log = (lambda m: print(f"[bench rank {rank}] {m}", file=sys.stderr, flush=True))
-    if world == 1:
+    if not ringed:
         slab = ig.IsingSlab(args.x, args.y, device=local_rank, seed=args.seed, temp=ig.CRIT_TEMP_F32, strip_rows=args.strip_rows, layout=layout)
         ring, ring_name = None, "none"
         slab.init()
     else:
         # torch owns the slab's device buffer, so the rows the torch ring hands to RCCL are slices of an ordinary tensor
         backend = ig.HipSlabBackend.create(args.x, args.y, device=local_rank, seed=args.seed, temp=ig.CRIT_TEMP_F32,
-                                           nslabs=world, slab=rank, strip_rows=args.strip_rows, layout=layout)
+                                           nslabs=world, slab=rank, strip_rows=args.strip_rows, layout=layout, ring_halo=world == 1)
         slab = backend.slab
         ring, ring_name = ig.open_ring(backend, prefer="torch" if args.exchange else args.ring, exchange=args.exchange, log=log)
 
@@ -163,7 +169,7 @@ def main():
             slab.init()
 
     def barrier():
-        if world > 1:
+        if ringed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -175,7 +181,7 @@ def main():
         advance(batch)
         torch.cuda.synchronize()
         more = max(0, math.ceil(args.preheat_ms / max((time.perf_counter() - t0) * 1e3, 1e-3)) - 1)
-        if world > 1:  # every rank must do the same number of sweeps: rank 0's estimate counts
+        if ringed:  # every rank must do the same number of sweeps: rank 0's estimate counts
             t = torch.tensor([more], dtype=torch.int64, device="cuda")
             dist.broadcast(t, src=0)
             more = int(t[0])
@@ -195,14 +201,14 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
+    if ringed:
         t = torch.tensor([dt, ev_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, ev_ms = float(t[0]), float(t[1])
 
     up, down = ring.count() if ring is not None else slab.count()
     rank_up = [slab.count()[0]]
-    if world > 1:
+    if ringed:
         g = [None] * world
         dist.all_gather_object(g, rank_up[0])
         rank_up = g
@@ -220,7 +226,7 @@ def main():
     if rank == 0:
         # dominant kernel = the update kernel.  N = 1 on the ballot layout: fused launches of `batch` sweeps; otherwise two
         # full-slab launches per step (with N > 1 each colour adds one tiny edge-row launch).
-        fused = world == 1 and layout_name == "ballot" and slab.fused
+        fused = not ringed and layout_name == "ballot" and slab.fused
         half_sweeps_per_launch = 2 * batch if fused else 1
         launches = args.steps // batch + (1 if args.steps % batch else 0) if fused else 2 * args.steps
         avg_launch_ms = ev_ms / launches
@@ -269,11 +275,11 @@ def main():
         }
         if parity is False:
             line["config"]["parity_expected"] = list(gold)
-        if world == 1 and not args.no_cpu_baseline:
+        if not ringed and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if ringed:
         dist.barrier()
         dist.destroy_process_group()
     if parity is False:

@@ -38,6 +38,23 @@ namespace {
 #if !defined(ISING_BAL_THREADS)
 #define ISING_BAL_THREADS 256
 #endif
+// The 16 scalar registers the draw phase's compares write and its scalar stores read are named in the asm text (inline asm
+// cannot name halves of an SGPR tuple operand): s[BASE .. BASE+15], BASE a multiple of 4.
+#if !defined(ISING_BAL_SGPR_BASE)
+#define ISING_BAL_SGPR_BASE 84
+#endif
+#define ISING_STR2(x) #x
+#define ISING_STR(x) ISING_STR2(x)
+#define SG(a, b) "s[" ISING_STR(ISING_BAL_SGPR_BASE) "+" #a ":" ISING_STR(ISING_BAL_SGPR_BASE) "+" #b "]"
+#if ISING_BAL_SGPR_BASE == 84
+#define BAL_CLOB8 "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91"
+#define BAL_CLOB16 BAL_CLOB8, "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
+#elif ISING_BAL_SGPR_BASE == 40
+#define BAL_CLOB8 "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47"
+#define BAL_CLOB16 BAL_CLOB8, "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55"
+#else
+#error "ISING_BAL_SGPR_BASE: 84 or 40"
+#endif
 constexpr int BAL_THREADS = ISING_BAL_THREADS; // waves of a workgroup share one scalar-cache write-back per row
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr uint64_t LANE0 = 0x0001000100010001ull;  // tx = 0 of each 16-lane group
@@ -93,8 +110,13 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 // same).  The chip never drains between colours.  Measured: equal to plain launches from 32768^2 up, slower
 // below -- one counter hands out at most ~88 tickets per us and a unit carries ~19 us of latency (ticket, completion
 // counters, write-through stores) that small strips do not amortise.
+#if defined(ISING_BAL_NUM_SGPR) // A/B: cap the scalar registers (80: eight workgroups per CU instead of six)
+#define BAL_SGPR_ATTR __attribute__((amdgpu_num_sgpr(ISING_BAL_NUM_SGPR)))
+#else
+#define BAL_SGPR_ATTR
+#endif
 template <bool SUBL, bool USEJ, bool FUSED, int NT = BAL_THREADS>
-__global__ void __launch_bounds__(NT) ballot_update_k(const UpdateParams p) {
+__global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const UpdateParams p) {
 	const int lane = threadIdx.x & 63;
 	const int tx = threadIdx.x & (GROUP - 1), g = (threadIdx.x >> 4) & 3;
 	const int wi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -274,15 +296,14 @@ __global__ void __launch_bounds__(NT) ballot_update_k(const UpdateParams p) {
 					// Fixed registers: inline asm cannot name halves of an SGPR tuple operand.  (Eight 8-byte stores from
 					// compiler-allocated pairs: -6 %.)
 					const uint64_t *dstp = cur + 8 * B.value;
-					asm volatile("v_cmp_gt_u32_e64 s[84:85], %0, %2\n\tv_cmp_gt_u32_e64 s[86:87], %1, %2\n\t"
-					             "v_cmp_gt_u32_e64 s[88:89], %0, %3\n\tv_cmp_gt_u32_e64 s[90:91], %1, %3\n\t"
-					             "v_cmp_gt_u32_e64 s[92:93], %0, %4\n\tv_cmp_gt_u32_e64 s[94:95], %1, %4\n\t"
-					             "v_cmp_gt_u32_e64 s[96:97], %0, %5\n\tv_cmp_gt_u32_e64 s[98:99], %1, %5\n\t"
-					             "s_store_dwordx4 s[84:87], %6, 0x0\n\ts_store_dwordx4 s[88:91], %6, 0x10\n\t"
-					             "s_store_dwordx4 s[92:95], %6, 0x20\n\ts_store_dwordx4 s[96:99], %6, 0x30"
+					asm volatile("v_cmp_gt_u32_e64 " SG(0, 1) ", %0, %2\n\tv_cmp_gt_u32_e64 " SG(2, 3) ", %1, %2\n\t"
+					             "v_cmp_gt_u32_e64 " SG(4, 5) ", %0, %3\n\tv_cmp_gt_u32_e64 " SG(6, 7) ", %1, %3\n\t"
+					             "v_cmp_gt_u32_e64 " SG(8, 9) ", %0, %4\n\tv_cmp_gt_u32_e64 " SG(10, 11) ", %1, %4\n\t"
+					             "v_cmp_gt_u32_e64 " SG(12, 13) ", %0, %5\n\tv_cmp_gt_u32_e64 " SG(14, 15) ", %1, %5\n\t"
+					             "s_store_dwordx4 " SG(0, 3) ", %6, 0x0\n\ts_store_dwordx4 " SG(4, 7) ", %6, 0x10\n\t"
+					             "s_store_dwordx4 " SG(8, 11) ", %6, 0x20\n\ts_store_dwordx4 " SG(12, 15) ", %6, 0x30"
 					             :: "s"(p.n3), "s"(p.n4), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(dstp)
-					             : "memory", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97",
-					               "s98", "s99");
+					             : "memory", BAL_CLOB16);
 				});
 			}
 			if (FUSED && r == 0 && wi == 0) { // wave-uniform branch; read by the workgroup after this unit's last barrier
@@ -404,19 +425,19 @@ __global__ void __launch_bounds__(THREADS) ballot_init_k(const InitParams p) {
 		philox_block(pr, cx, p.seed_lo, p.seed_hi, o0, o1, o2, o3);
 		const uint64_t *dstp = row + 4 * B.value;
 		if (!mirror) {
-			asm volatile("v_cmp_gt_u32_e64 s[84:85], %0, %1\n\tv_cmp_gt_u32_e64 s[86:87], %0, %2\n\t"
-			             "v_cmp_gt_u32_e64 s[88:89], %0, %3\n\tv_cmp_gt_u32_e64 s[90:91], %0, %4\n\t"
-			             "s_store_dwordx4 s[84:87], %5, 0x0\n\ts_store_dwordx4 s[88:91], %5, 0x10"
+			asm volatile("v_cmp_gt_u32_e64 " SG(0, 1) ", %0, %1\n\tv_cmp_gt_u32_e64 " SG(2, 3) ", %0, %2\n\t"
+			             "v_cmp_gt_u32_e64 " SG(4, 5) ", %0, %3\n\tv_cmp_gt_u32_e64 " SG(6, 7) ", %0, %4\n\t"
+			             "s_store_dwordx4 " SG(0, 3) ", %5, 0x0\n\ts_store_dwordx4 " SG(4, 7) ", %5, 0x10"
 			             :: "s"(p.thr_half), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(dstp)
-			             : "memory", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91");
+			             : "memory", BAL_CLOB8);
 		} else {
 			const uint64_t *dstm = mirror + 4 * B.value;
-			asm volatile("v_cmp_gt_u32_e64 s[84:85], %0, %1\n\tv_cmp_gt_u32_e64 s[86:87], %0, %2\n\t"
-			             "v_cmp_gt_u32_e64 s[88:89], %0, %3\n\tv_cmp_gt_u32_e64 s[90:91], %0, %4\n\t"
-			             "s_store_dwordx4 s[84:87], %5, 0x0\n\ts_store_dwordx4 s[88:91], %5, 0x10\n\t"
-			             "s_store_dwordx4 s[84:87], %6, 0x0\n\ts_store_dwordx4 s[88:91], %6, 0x10"
+			asm volatile("v_cmp_gt_u32_e64 " SG(0, 1) ", %0, %1\n\tv_cmp_gt_u32_e64 " SG(2, 3) ", %0, %2\n\t"
+			             "v_cmp_gt_u32_e64 " SG(4, 5) ", %0, %3\n\tv_cmp_gt_u32_e64 " SG(6, 7) ", %0, %4\n\t"
+			             "s_store_dwordx4 " SG(0, 3) ", %5, 0x0\n\ts_store_dwordx4 " SG(4, 7) ", %5, 0x10\n\t"
+			             "s_store_dwordx4 " SG(0, 3) ", %6, 0x0\n\ts_store_dwordx4 " SG(4, 7) ", %6, 0x10"
 			             :: "s"(p.thr_half), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(dstp), "s"(dstm)
-			             : "memory", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91");
+			             : "memory", BAL_CLOB8);
 		}
 	});
 	asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");

@@ -388,9 +388,10 @@ def open_ring(backend: "HipSlabBackend", prefer: str = "native", exchange: Optio
         return bool(int(t[0]))
 
     attempts = []
-    if world > 1 and prefer == "native" and exchange is None:
+    if prefer == "native" and exchange is None:
         attempts.append("rccl-native")
-    attempts += [exchange] if exchange else ["p2p", "allgather"]
+    if world > 1:  # (a ring of one exists only inside the library: SlabRing sweeps a lone slab in place)
+        attempts += [exchange] if exchange else ["p2p", "allgather"]
     last = None
     for name in attempts:
         ring = None
@@ -400,10 +401,9 @@ def open_ring(backend: "HipSlabBackend", prefer: str = "native", exchange: Optio
             else:
                 ring = SlabRing(backend, exchange=name)
             ring.init()
-            if world > 1:
-                ring.sweep(1)  # one real half-sweep pair through the transport before it is trusted
-                ring.quiesce()
-                torch.cuda.synchronize()
+            ring.sweep(1)  # one real sweep through the transport before it is trusted
+            ring.quiesce()
+            torch.cuda.synchronize()
             ok = True
         except Exception as e:  # noqa: BLE001 -- any transport failure means: try the next one
             last = e

@@ -95,7 +95,7 @@ def test_fused_equals_plain_at_16384_full_size(gpu, monkeypatch):
     assert got["0"] == got["1"]
 
 
-def test_bench_line_on_a_small_lattice(gpu):
+def test_bench_line_on_a_small_lattice(gpu, oracle_mod):
     """bench.py end to end (the driver's command shape) on a lattice that takes a second: one JSON line with the contract's
     keys, the roofline and cpu_baseline objects, and counts equal to the oracle's."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--x", "8192", "--y", "8192",
@@ -112,6 +112,20 @@ def test_bench_line_on_a_small_lattice(gpu):
     assert abs(b["roofline"]["frac"] - b["roofline"]["achieved"] / b["roofline"]["peak"]) < 1e-3
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in b["cpu_baseline"], key
-    import oracle
-    orc = oracle.OracleLattice(8192, 8192, seed=1234, temp=oracle.CRIT_TEMP).init().sweep(6)
+    orc = oracle_mod.OracleLattice(8192, 8192, seed=1234, temp=oracle_mod.CRIT_TEMP).init().sweep(6)
     assert (b["config"]["up"], b["config"]["down"]) == orc.count()
+
+
+def test_bench_ring_code_path_with_one_rank(gpu, oracle_mod):
+    """bench.py's N > 1 code path as far as one GPU can run it: under torch.distributed.run with ONE rank and --force-ring the
+    slab is a ring of one -- torch.distributed (nccl) is initialised, torch owns the slab buffer, the library attaches its
+    RCCL communicator with the id torch broadcast, and the edge rows travel through ncclSend/ncclRecv on the comm stream."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port",
+                        "29551", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-ring", "--steps", "4", "--warmup", "2", "--x", "8192", "--y", "8192",
+                        "--preheat-ms", "5"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    b = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert b["config"]["exchange"] == "rccl-native" and b["config"]["nranks"] == 1
+    orc = oracle_mod.OracleLattice(8192, 8192, seed=1234, temp=oracle_mod.CRIT_TEMP).init().sweep(6)
+    assert (b["config"]["up"], b["config"]["down"]) == orc.count() and b["config"]["rank_up"] == [orc.count()[0]]
