@@ -19,7 +19,7 @@ LAYOUTS = pytest.mark.parametrize("layout", [ig.LAYOUT_DENSE, ig.LAYOUT_NIBBLE],
 @pytest.mark.parametrize("X,Y,prob,kernel", [(2048, 32, 0.3, ig.KERNEL_AUTO), (4096, 64, 0.5, ig.KERNEL_GENERIC), (6144, 48, 1.0, ig.KERNEL_AUTO),
                                              (2048, 16, 0.0, ig.KERNEL_AUTO)])
 @LAYOUTS
-def test_couplings_and_update_bit_exact(gpu, oracle_mod, X, Y, prob, kernel, layout):
+def test_couplings_and_update_vs_unpinned_oracle(gpu, oracle_mod, X, Y, prob, kernel, layout):
     orc = oracle_mod.OracleLattice(X, Y, seed=1234, temp=1.8).init().init_couplings(prob)
     with ig.IsingSlab(X, Y, seed=1234, temp=1.8, J_prob=prob, kernel=kernel, layout=layout) as s:
         assert s.layout == layout
@@ -33,7 +33,7 @@ def test_couplings_and_update_bit_exact(gpu, oracle_mod, X, Y, prob, kernel, lay
 
 
 @LAYOUTS
-def test_couplings_with_sublattices(gpu, oracle_mod, layout):
+def test_couplings_with_sublattices_vs_unpinned_oracle(gpu, oracle_mod, layout):
     X, Y = 4096, 64
     orc = oracle_mod.OracleLattice(X, Y, seed=9, temp=1.2, XSL=2048, YSL=32).init().init_couplings(0.4)
     with ig.IsingSlab(X, Y, seed=9, temp=1.2, XSL=2048, YSL=32, J_prob=0.4, layout=layout) as s:
@@ -71,7 +71,7 @@ def test_couplings_ring_matches_single_slab(gpu, layout):
             b.slab.close()
 
 
-def test_cli_J_transcript(gpu, oracle_mod):
+def test_cli_J_transcript_vs_unpinned_oracle(gpu, oracle_mod):
     X, Y, seed = 2048, 64, 606
     for ndev, ylocal, extra in ((1, Y, []), (1, Y, ["--layout", "nibble"]), (2, Y // 2, ["--devmap", "0,0"])):
         r = subprocess.run([CLI, "-x", str(X), "-y", str(ylocal), "-d", str(ndev), "-n", "6", "-p", "3", "-t", "1.0", "-s", str(seed), "-J", "0.25"] + extra,
