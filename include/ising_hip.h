@@ -60,10 +60,12 @@ enum {
 	ISING_LAYOUT_AUTO = 0,   /* ballot where it applies and pays (from 2^27 spins per slab), else dense */
 	ISING_LAYOUT_NIBBLE = 1, /* the reference's: 4 bits per spin, 16 spins per 64-bit word (optimized/main.cu:40, :1243) */
 	ISING_LAYOUT_DENSE = 2,  /* 1 bit per spin, 32 spins per 32-bit word = one reference 128-bit vector per word */
-	ISING_LAYOUT_BALLOT = 3  /* 1 bit per spin, 64-bit words in the update kernel's wave-ballot order (ising_ballot.hip);
-	                            needs X % 8192 == 0 and sub-lattice widths of 2048, 4096 or a multiple of 8192; a
-	                            temperature without integer accept thresholds turns the slab into ISING_LAYOUT_DENSE at
-	                            the next update */
+	ISING_LAYOUT_BALLOT = 3  /* 1 bit per spin, 64-bit words in the update kernel's wave-ballot order (ising_ballot.hip),
+	                            rows padded to whole wave columns of 8192 lattice columns; with sub-lattices, -J or a
+	                            caller-owned buffer X % 8192 == 0 is required (sub-lattice widths of 2048, 4096 or a
+	                            multiple of 8192); a temperature without integer accept thresholds turns the slab into
+	                            ISING_LAYOUT_DENSE at the next update (pointers from ising_halo_ptrs / ising_device_ptr
+	                            are void after that when the rows were padded) */
 };
 
 typedef struct ising_ctx ising_ctx;
@@ -198,7 +200,7 @@ int ising_write_bits(ising_ctx *ctx, int color, int64_t row0, int64_t nrows, con
 
 /* Device pointer to row 0 of a colour array of this slab in its DEVICE layout (see ising_layout) for zero-copy
  * consumers: nibble layout = [Y][X/32] 64-bit words exactly as the reference's buffers; dense = [Y][X/64] 32-bit words;
- * ballot = [Y][X/128] 64-bit words in the bit order described in ising_ballot.hip. */
+ * ballot = [Y][64 * ceil(X/8192)] 64-bit words in the bit order described in ising_ballot.hip. */
 int ising_device_ptr(ising_ctx *ctx, int color, void **ptr, size_t *bytes);
 /* The layout in use right now (ISING_LAYOUT_NIBBLE, _DENSE or _BALLOT). */
 int ising_layout(ising_ctx *ctx, int *layout);

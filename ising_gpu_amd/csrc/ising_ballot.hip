@@ -120,7 +120,10 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	const int lane = threadIdx.x & 63;
 	const int tx = threadIdx.x & (GROUP - 1), g = (threadIdx.x >> 4) & 3;
 	const int wi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int nwc = p.gx >> 2;
+	// A row holds ceil(gx / 4) wave columns of 64 words; when gx is not a multiple of 4 the last one is partly dead: its
+	// lanes of column groups >= gx draw and compute like the others, but their bits stay zero in memory.
+	const int nwc = (p.gx + 3) >> 2;
+	const int gxp = nwc << 2; // column groups including the dead ones
 	const int wpr = nwc * 64; // 64-bit words per colour row
 
 	// word phase: this lane owns word p = lane of every row
@@ -147,7 +150,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	const int k = p.slV >> 5;                       // column groups per period
 	const bool inwave = SUBL && k < 4;              // periods shorter than a wave column
 	const int wsh = k == 1 ? 15 : 31;
-	const int n = max(k >> 2, 1); // wave columns per period
+	const int n = SUBL ? max(k >> 2, 1) : nwc; // wave columns per period
 	const ptrdiff_t wrap_bot = (ptrdiff_t)p.Y * wpr;
 
 	// this workgroup slot's scratch: per wave two slots of 64 x (c3, c4) masks
@@ -188,8 +191,8 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		const bool idle = unit0 >= p.nunits; // the last workgroup of a level may be partly empty; it still meets the barriers
 		const int rng = unit0 >= p.nunits0;
 		const int u = idle ? 0 : unit0 - (rng ? p.nunits0 : 0);
-		const int pos = uni(u / p.gx);
-		const int bx0 = u - pos * p.gx;
+		const int pos = uni(u / gxp);
+		const int bx0 = u - pos * gxp;
 		const int wc = bx0 >> 2;
 		const int bx = bx0 + g;
 		// FUSED: strips are taken from both ends of the slab inwards (0, N-1, 1, N-2, ...), so that the periodic
@@ -213,6 +216,13 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			if ((bx0 + gg) % k == k - 1) last |= 1ull << (16 * gg + 15);
 		}
 		const uint64_t u_b1 = LANE0 & ~1ull & ~first, u_f1 = LANE15 & ~(1ull << 63) & ~last;
+		// lanes of this wave that exist (all of them unless this is the partly dead last wave column), the bit of the row's
+		// last vector in a word of THIS wave column and in one of the wave column the back neighbour of lane 0 comes from
+		const int alive = min(4, p.gx - bx0);
+		const uint64_t live = alive >= 4 ? ~0ull : ((1ull << (16 * alive)) - 1ull);
+		const int end_here = 16 * alive - 1;
+		const int src_b = wc % n ? wc - 1 : wc + n - 1;
+		const int end_src = 16 * min(4, p.gx - 4 * src_b) - 1;
 		const uint64_t u_bw = inwave ? first : 0ull, u_fw = inwave ? last : 0ull;
 		const int u_cb = ((wc % n ? wc - 1 : wc + n - 1) - wc) * 64 + word_of(1, 7, 3); // C, in words from this wave's row start
 		const int u_cf = ((wc % n == n - 1 ? wc - n + 1 : wc + 1) - wc) * 64 + word_of(0, 0, 0);
@@ -333,12 +343,12 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				}
 				uint64_t w0, w1; // side words of lanes (0,0,0), (1,0,0) [back] / (0,7,3), (1,7,3) [forward]
 				if (back) {
-					w0 = ((sA0 << 1) & ~LANE0) | ((sA1 << 1) & u_b1) | (inwave ? 0ull : (sC >> 63));
+					w0 = ((sA0 << 1) & ~LANE0) | ((sA1 << 1) & u_b1) | (inwave ? 0ull : ((sC >> end_src) & 1ull));
 					if (SUBL) w0 |= (sA1 >> wsh) & u_bw;
 					w1 = ((sA1 << 1) & ~LANE0) | ((sA0 >> 15) & LANE0);
 				} else {
 					w0 = ((sA0 >> 1) & ~LANE15) | ((sA1 << 15) & LANE15);
-					w1 = ((sA1 >> 1) & ~LANE15) | ((sA0 >> 1) & u_f1) | (inwave ? 0ull : (sC << 63));
+					w1 = ((sA1 >> 1) & ~LANE15) | ((sA0 >> 1) & u_f1) | (inwave ? 0ull : ((sC & 1ull) << end_here));
 					if (SUBL) w1 |= (sA0 << wsh) & u_fw;
 				}
 				const uint64_t A = bperm64(back ? backA : fwdA, ct);
@@ -366,7 +376,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 					sd ^= back ? jl : jr;
 					rj += 4 * wpr;
 				}
-				const uint64_t nw = me ^ flips64(me, nu, nc, nd, sd, c3, c4);
+				const uint64_t nw = me ^ (flips64(me, nu, nc, nd, sd, c3, c4) & live);
 				if (FUSED || publish) st_word<true>(rd + lane, nw); else st_word<false>(rd + lane, nw);
 				if (p.wrap) { // single slab: keep this colour's own halo rows equal to the opposite edge rows
 					if (lr == 0) st_word<FUSED>(rd + wrap_bot + lane, nw);
@@ -406,10 +416,12 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 // stores) per row and wave column, no vector store, no word phase.
 __global__ void __launch_bounds__(THREADS) ballot_init_k(const InitParams p) {
 	const int tx = threadIdx.x & (GROUP - 1), g = (threadIdx.x >> 4) & 3;
-	const int nwc = p.gx >> 2;
+	const int nwc = (p.gx + 3) >> 2;
 	const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6));
 	if (wave >= nwc * p.Y) return;
 	const int lr = wave / nwc, wc = wave - lr * nwc;
+	const int alive = min(4, p.gx - 4 * wc); // column groups of this wave column that exist
+	const unsigned long long live = alive >= 4 ? ~0ull : ((1ull << (16 * alive)) - 1ull);
 	const uint32_t grow = p.row_base + (uint32_t)lr;
 	const uint32_t tid = ((grow >> 4) * (uint32_t)p.gx + (uint32_t)(4 * wc + g)) * 256u + (grow & 15u) * 16u + (uint32_t)tx;
 	const PhiloxRow pr = philox_row_setup(tid, p.seed_lo, p.seed_hi + 2u * PHILOX_W1);
@@ -424,7 +436,17 @@ __global__ void __launch_bounds__(THREADS) ballot_init_k(const InitParams p) {
 		asm volatile("" : "+s"(cx));
 		philox_block(pr, cx, p.seed_lo, p.seed_hi, o0, o1, o2, o3);
 		const uint64_t *dstp = row + 4 * B.value;
-		if (!mirror) {
+		if (alive < 4) { // the partly dead last wave column: dead lanes stay zero in memory
+			const uint64_t *dstm = mirror ? mirror + 4 * B.value : dstp;
+			asm volatile("v_cmp_gt_u32_e64 " SG(0, 1) ", %0, %1\n\tv_cmp_gt_u32_e64 " SG(2, 3) ", %0, %2\n\t"
+			             "v_cmp_gt_u32_e64 " SG(4, 5) ", %0, %3\n\tv_cmp_gt_u32_e64 " SG(6, 7) ", %0, %4\n\t"
+			             "s_and_b64 " SG(0, 1) ", " SG(0, 1) ", %7\n\ts_and_b64 " SG(2, 3) ", " SG(2, 3) ", %7\n\t"
+			             "s_and_b64 " SG(4, 5) ", " SG(4, 5) ", %7\n\ts_and_b64 " SG(6, 7) ", " SG(6, 7) ", %7\n\t"
+			             "s_store_dwordx4 " SG(0, 3) ", %5, 0x0\n\ts_store_dwordx4 " SG(4, 7) ", %5, 0x10\n\t"
+			             "s_store_dwordx4 " SG(0, 3) ", %6, 0x0\n\ts_store_dwordx4 " SG(4, 7) ", %6, 0x10"
+			             :: "s"(p.thr_half), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(dstp), "s"(dstm), "s"(live)
+			             : "memory", "scc", BAL_CLOB8);
+		} else if (!mirror) {
 			asm volatile("v_cmp_gt_u32_e64 " SG(0, 1) ", %0, %1\n\tv_cmp_gt_u32_e64 " SG(2, 3) ", %0, %2\n\t"
 			             "v_cmp_gt_u32_e64 " SG(4, 5) ", %0, %3\n\tv_cmp_gt_u32_e64 " SG(6, 7) ", %0, %4\n\t"
 			             "s_store_dwordx4 " SG(0, 3) ", %5, 0x0\n\ts_store_dwordx4 " SG(4, 7) ", %5, 0x10"
@@ -450,10 +472,16 @@ __device__ __forceinline__ int word_of_site(int j, int s) {
 	return word_of(j, m, q);
 }
 
-__global__ void __launch_bounds__(THREADS) ballot_to_dense_k(const uint64_t *__restrict__ bal, uint32_t *__restrict__ dense, long long ngroups) {
+// (ballot rows: nwc = ceil(gx / 4) wave columns of 64 words; dense rows: gx * 32 words -- the vectors of the dead column
+// groups of a partly dead last wave column do not exist there)
+__global__ void __launch_bounds__(THREADS) ballot_to_dense_k(const uint64_t *__restrict__ bal, uint32_t *__restrict__ dense, long long ngroups, int gx) {
 	__shared__ uint64_t sh[THREADS / 64][64];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int nwc = (gx + 3) >> 2;
 	for (long long grp = (long long)blockIdx.x * (THREADS / 64) + wv; grp < ngroups; grp += (long long)gridDim.x * (THREADS / 64)) {
+		const long long row = grp / nwc;
+		const int wc = (int)(grp - row * nwc), nvec = min(4, gx - 4 * wc) * 32;
+		uint32_t *drow = dense + row * gx * 32 + wc * 128;
 		sh[wv][lane] = bal[grp * 64 + lane];
 		__builtin_amdgcn_wave_barrier();
 		__threadfence_block();
@@ -464,21 +492,25 @@ __global__ void __launch_bounds__(THREADS) ballot_to_dense_k(const uint64_t *__r
 			uint32_t d = 0;
 #pragma unroll
 			for (int s = 0; s < 32; ++s) d |= (uint32_t)((sh[wv][word_of_site(j, s)] >> l) & 1ull) << s;
-			dense[grp * 128 + v] = d;
+			if (v < nvec) drow[v] = d;
 		}
 		__builtin_amdgcn_wave_barrier();
 		__threadfence_block();
 	}
 }
 
-__global__ void __launch_bounds__(THREADS) dense_to_ballot_k(const uint32_t *__restrict__ dense, uint64_t *__restrict__ bal, long long ngroups) {
+__global__ void __launch_bounds__(THREADS) dense_to_ballot_k(const uint32_t *__restrict__ dense, uint64_t *__restrict__ bal, long long ngroups, int gx) {
 	__shared__ uint32_t sh[THREADS / 64][128];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const int j = lane >> 5, m = (lane >> 2) & 7, q = lane & 3;
 	const int s = (q & 1) * 16 + 2 * m + (q >> 1);
+	const int nwc = (gx + 3) >> 2;
 	for (long long grp = (long long)blockIdx.x * (THREADS / 64) + wv; grp < ngroups; grp += (long long)gridDim.x * (THREADS / 64)) {
-		sh[wv][lane] = dense[grp * 128 + lane];
-		sh[wv][lane + 64] = dense[grp * 128 + lane + 64];
+		const long long row = grp / nwc;
+		const int wc = (int)(grp - row * nwc), nvec = min(4, gx - 4 * wc) * 32;
+		const uint32_t *drow = dense + row * gx * 32 + wc * 128;
+		sh[wv][lane] = lane < nvec ? drow[lane] : 0u;
+		sh[wv][lane + 64] = lane + 64 < nvec ? drow[lane + 64] : 0u;
 		__builtin_amdgcn_wave_barrier();
 		__threadfence_block();
 		uint64_t w = 0;
@@ -576,7 +608,7 @@ int ballot_max_wgs() { return 256 * 8; } // upper bound of the grid of any ballo
 
 template <int NT>
 static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, int *grid_out) {
-	p.nwg = (p.nunits + NT / GROUP - 1) / (NT / GROUP);
+	p.nwg = (p.nunits + NT / GROUP - 1) / (NT / GROUP); // (p.nunits counts column groups incl. the dead ones: 4 per wave)
 	const bool fused = p.nlevels > 1;
 	const bool usej = fused ? p.jham[0] != nullptr : p.jdst != nullptr;
 	const bool subl = p.slY != 0;
@@ -622,7 +654,7 @@ hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_o
 }
 
 hipError_t launch_ballot_init(const InitParams &p, hipStream_t stream) {
-	const long long waves = (long long)(p.gx / 4) * p.Y;
+	const long long waves = (long long)((p.gx + 3) / 4) * p.Y;
 	hipLaunchKernelGGL(ballot_init_k, dim3((unsigned)((waves + THREADS / 64 - 1) / (THREADS / 64))), dim3(THREADS), 0, stream, p);
 	return hipGetLastError();
 }
@@ -648,20 +680,20 @@ hipError_t launch_ham_ballot_to_planes(uint64_t *ham, int gx, long long rows, hi
 
 // rows x (gx/4) groups of 64 ballot words <-> 128 dense words; both buffers hold `rows` rows of gx*128 bytes
 hipError_t launch_ballot_to_dense(const uint64_t *bal, uint32_t *dense, int gx, long long rows, hipStream_t stream) {
-	const long long ngroups = rows * (gx / 4);
+	const long long ngroups = rows * ((gx + 3) / 4);
 	if (ngroups <= 0) return hipSuccess;
 	long long blocks = (ngroups + THREADS / 64 - 1) / (THREADS / 64);
 	if (blocks > 16384) blocks = 16384;
-	hipLaunchKernelGGL(ballot_to_dense_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, bal, dense, ngroups);
+	hipLaunchKernelGGL(ballot_to_dense_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, bal, dense, ngroups, gx);
 	return hipGetLastError();
 }
 
 hipError_t launch_dense_to_ballot(const uint32_t *dense, uint64_t *bal, int gx, long long rows, hipStream_t stream) {
-	const long long ngroups = rows * (gx / 4);
+	const long long ngroups = rows * ((gx + 3) / 4);
 	if (ngroups <= 0) return hipSuccess;
 	long long blocks = (ngroups + THREADS / 64 - 1) / (THREADS / 64);
 	if (blocks > 16384) blocks = 16384;
-	hipLaunchKernelGGL(dense_to_ballot_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, dense, bal, ngroups);
+	hipLaunchKernelGGL(dense_to_ballot_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, dense, bal, ngroups, gx);
 	return hipGetLastError();
 }
 

@@ -64,14 +64,14 @@ uint64_t draw_prefix(float p, bool le) {
 
 // ballot layout: the dense-order image is allocated by the first call that needs one
 int ising_host::ballot_tmp(ising_ctx *c) {
-	if (!c->d_tmp) HIP_TRY(hipMalloc((void **)&c->d_tmp, c->alloc_words() * sizeof(uint64_t)));
+	if (!c->d_tmp) HIP_TRY(hipMalloc((void **)&c->d_tmp, c->tmp_words() * sizeof(uint64_t)));
 	return ISING_OK;
 }
 
 // ballot layout: convert rows [row_lo, row_hi) of `color` (rows -1 and Y are the halo rows) between d_lat and d_tmp
 int ising_host::ballot_rows(ising_ctx *c, int color, long long row_lo, long long row_hi, bool to_dense) {
 	if (int rc = ballot_tmp(c)) return rc;
-	uint64_t *lat = c->lat(color) + row_lo * c->lld, *tmp = c->tmp(color) + row_lo * c->lld;
+	uint64_t *lat = c->lat(color) + row_lo * c->lld, *tmp = c->tmp(color) + row_lo * c->lld_dense;
 	if (to_dense) HIP_TRY(ising::launch_ballot_to_dense(lat, reinterpret_cast<uint32_t *>(tmp), c->gx, row_hi - row_lo, c->stream));
 	else HIP_TRY(ising::launch_dense_to_ballot(reinterpret_cast<const uint32_t *>(tmp), lat, c->gx, row_hi - row_lo, c->stream));
 	return ISING_OK;
@@ -88,7 +88,11 @@ int ising_host::ballot_image(ising_ctx *c) {
 int ising_host::ballot_leave(ising_ctx *c) {
 	if (!c->ballot) return ISING_OK;
 	if (int rc = ising_host::ballot_image(c)) return rc;
-	HIP_TRY(hipMemcpyAsync(c->d_lat, c->d_tmp, c->alloc_words() * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+	// the dense-order image becomes the slab (same buffer; when X is not a multiple of 8192 the rows get shorter and the
+	// colour arrays move up: pointers handed out by ising_halo_ptrs / ising_device_ptr before are void)
+	HIP_TRY(hipMemcpyAsync(c->d_lat, c->d_tmp, c->tmp_words() * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+	c->lld = c->lld_dense;
+	c->color_words = (size_t)c->cfg.Y * c->lld;
 	if (c->ham_form == 2) {
 		for (int w = 0; w < 2; w++) HIP_TRY(ising::launch_ham_ballot_to_planes(c->ham(w), c->gx, c->cfg.Y, c->stream));
 		c->ham_form = 1;
@@ -257,7 +261,7 @@ size_t ising_required_bytes(int32_t X, int32_t Y) {
 
 size_t ising_required_bytes_layout(int32_t X, int32_t Y, int32_t layout) {
 	const size_t full = ising_required_bytes(X, Y);
-	return layout == ISING_LAYOUT_NIBBLE ? full : full / 4;
+	return layout == ISING_LAYOUT_NIBBLE ? full : full / 4; // (caller-owned buffers never hold padded ballot rows)
 }
 
 // A caller-owned buffer must be device memory of the slab's device and, when the caller states its size, large enough.
@@ -305,21 +309,30 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	c->dense = cfg->layout != ISING_LAYOUT_NIBBLE;
 	// the ballot layout covers the integer-threshold update without sub-lattices and couplings, 8192-column granularity
 	// (sub-lattice widths: 2048, 4096 or a multiple of 8192 columns)
-	const bool ballot_ok = (cfg->X % 8192) == 0 && (!cfg->XSL || cfg->XSL <= 4096 || (cfg->XSL % 8192) == 0) &&
+	// X not a multiple of 8192: the last wave column of a row is partly dead (padded rows).  Not with sub-lattices or -J
+	// (their period / plane logic counts whole wave columns), and not in a caller-owned buffer (the halo rows the caller
+	// sliced out of it would move if the slab ever had to turn dense).
+	const bool whole = (cfg->X % 8192) == 0;
+	const bool ballot_ok = (whole ? (!cfg->XSL || cfg->XSL <= 4096 || (cfg->XSL % 8192) == 0) : (!cfg->XSL && !cfg->use_J && !cfg->lattice_mem)) &&
 	                       (cfg->kernel == ISING_KERNEL_AUTO || cfg->kernel == ISING_KERNEL_FAST);
 	if (cfg->layout == ISING_LAYOUT_BALLOT && !ballot_ok) {
 		delete c;
-		return fail(ISING_E_ARG, "the ballot layout needs X %% 8192 == 0, sub-lattice widths of 2048, 4096 or a multiple of 8192 and the integer-threshold kernel");
+		return fail(ISING_E_ARG, "the ballot layout needs the integer-threshold kernel; with sub-lattices, -J or a caller-owned buffer also X %% 8192 == 0 (sub-lattice widths of 2048, 4096 or a multiple of 8192)");
 	}
 	c->ballot = cfg->layout == ISING_LAYOUT_BALLOT;
 	c->lld_packed = cfg->X / 32;
 	c->lld = c->dense ? cfg->X / 128 : cfg->X / 32;
+	c->lld_dense = cfg->X / 128;
 	c->gx = cfg->X / 2048;
 	compute_tables(c, cfg->temp);
 	// AUTO: the ballot kernel's two-phase row pipeline wins from ~1e8 spins per slab up (8192^2: dense 5 % ahead)
-	if (cfg->layout == ISING_LAYOUT_AUTO && ballot_ok && c->fast_ok && (long long)cfg->X * cfg->Y >= (1LL << 27) && !getenv("ISING_NO_BALLOT"))
+	// (a partly dead last wave column wastes its dead lanes' draws: worth it while they are under a tenth of the row --
+	// the dense kernel is 12 % behind)
+	const bool ballot_pays = whole || 10 * c->gx > 9 * 4 * c->nwc();
+	if (cfg->layout == ISING_LAYOUT_AUTO && ballot_ok && ballot_pays && c->fast_ok && (long long)cfg->X * cfg->Y >= (1LL << 27) && !getenv("ISING_NO_BALLOT"))
 		c->ballot = true;
 	c->wrap = cfg->nslabs == 1 && !cfg->ring_halo;
+	if (c->ballot) c->lld = c->nwc() * 64;
 	c->H = cfg->strip_rows > 0 ? cfg->strip_rows : choose_strip_rows(c->gx, cfg->Y, c->dense, c->ballot);
 	if (cfg->Y % c->H) { const int h = c->H; delete c; return fail(ISING_E_ARG, "strip_rows %d does not divide Y %d", h, cfg->Y); }
 	c->nstrips = cfg->Y / c->H;
@@ -342,7 +355,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (e == hipSuccess && c->ballot) {
 		// accept-mask slots, 2 KiB per wave: of every wave of the largest plain launch (one workgroup per unit), and of
 		// every workgroup slot of a fused launch (4 waves each)
-		const size_t plain = (size_t)(c->gx / 4) * (c->nstrips + 2) * 2048 + 8192, fused = (size_t)ising::ballot_max_wgs() * 4 * 2048;
+		const size_t plain = (size_t)c->nwc() * (c->nstrips + 2) * 2048 + 8192, fused = (size_t)ising::ballot_max_wgs() * 4 * 2048;
 		e = hipMalloc((void **)&c->d_scratch, std::max(plain, fused));
 		// ticket words (chunk counter + 8 queue words, 64 bytes apart) + one completion counter per strip (fused launches)
 		const size_t ctl_bytes = SLOTCTL_TICKET_BYTES + (size_t)c->nstrips * sizeof(uint32_t);
@@ -476,8 +489,9 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	p.H = c->H;
 	p.row_lo[0] = lo0; p.row_hi[0] = hi0;
 	p.row_lo[1] = lo1; p.row_hi[1] = hi1;
-	p.nunits0 = c->gx * ((hi0 - lo0 + c->H - 1) / c->H);
-	p.nunits = p.nunits0 + c->gx * ((hi1 - lo1 + c->H - 1) / c->H);
+	const int ugx = c->ballot ? 4 * c->nwc() : c->gx; // column groups per strip as the kernel counts them (ballot: 4 per wave column)
+	p.nunits0 = ugx * ((hi0 - lo0 + c->H - 1) / c->H);
+	p.nunits = p.nunits0 + ugx * ((hi1 - lo1 + c->H - 1) / c->H);
 	p.n3 = (uint32_t)c->thr[3];
 	p.n4 = (uint32_t)c->thr[4];
 	memcpy(p.tab, c->tab, sizeof(p.tab));
@@ -504,11 +518,11 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 		}
 		if (publish) {
 			p.edge_signal = c->d_signal[color];
-			c->edge_target[color] += (uint32_t)(c->gx / 4) * (c->nstrips == 1 ? 1u : 2u); // wave columns of the strips with row 0 / Y-1
+			c->edge_target[color] += (uint32_t)c->nwc() * (c->nstrips == 1 ? 1u : 2u); // wave columns of the strips with row 0 / Y-1
 		}
 		int grid = 0;
 		HIP_TRY(ising::launch_ballot_update(p, c->stream, &grid));
-		if (nlevels > 1) c->done_base += (uint32_t)nlevels * (uint32_t)(c->gx / 4);
+		if (nlevels > 1) c->done_base += (uint32_t)nlevels * (uint32_t)c->nwc();
 		return ISING_OK;
 	}
 	if (c->dense) {

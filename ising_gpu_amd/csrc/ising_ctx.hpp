@@ -24,7 +24,9 @@ struct ising_ctx {
 	uint64_t *d_pack = nullptr;    // staging for device-side conversion to / from the packed boundary format
 	size_t pack_words = 0;
 	int lld_packed = 0; // 64-bit words per colour row in the reference's packed layout (X/32)
-	int lld = 0;      // 64-bit words per colour row in the DEVICE layout (X/32 nibble, X/128 dense)
+	int lld = 0;      // 64-bit words per colour row in the DEVICE layout: X/32 nibble, X/128 dense, ballot: 64 per wave column
+	                  // of 8192 lattice columns, i.e. X/128 rounded up to a multiple of 64 (dead lanes of the last one stay zero)
+	int lld_dense = 0; // X/128: row size of the dense layout and of the ballot layout's dense-order image d_tmp
 	int gx = 0;       // X/2048
 	int H = 0;        // rows per strip
 	int nstrips = 0;
@@ -69,7 +71,9 @@ struct ising_ctx {
 	uint64_t *lat(int color) const { return d_lat + (size_t)color * (color_words + 2 * (size_t)lld) + lld; }
 	uint64_t *halo(int color, int which) const { return which == 0 ? lat(color) - lld : lat(color) + color_words; }
 	size_t alloc_words() const { return 2 * (color_words + 2 * (size_t)lld); }
-	uint64_t *tmp(int color) const { return d_tmp + (size_t)color * (color_words + 2 * (size_t)lld) + lld; }
+	size_t tmp_words() const { return 2 * ((size_t)cfg.Y + 2) * (size_t)lld_dense; }
+	uint64_t *tmp(int color) const { return d_tmp + (size_t)color * ((size_t)cfg.Y + 2) * lld_dense + lld_dense; }
+	int nwc() const { return (gx + 3) / 4; } // ballot layout: wave columns per row
 	size_t ham_words() const { return (size_t)cfg.Y * lld_packed; } // per coupling array, without its two halo rows
 	size_t ham_alloc_words() const { return 2 * (ham_words() + 2 * (size_t)lld_packed); }
 	uint64_t *ham(int which) const { return d_ham + (size_t)which * (ham_words() + 2 * (size_t)lld_packed) + lld_packed; }

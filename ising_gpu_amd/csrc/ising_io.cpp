@@ -64,7 +64,7 @@ int read_rows(ising_ctx *c, int color, int64_t row0, int64_t nrows, void *host, 
 		const uint32_t *bits = nullptr; // dense-order words of the chunk on the device
 		if (c->ballot) {
 			if (int rc = ising_host::ballot_rows(c, color, r, r + nr, true)) return rc;
-			bits = reinterpret_cast<const uint32_t *>(c->tmp(color) + (size_t)r * c->lld);
+			bits = reinterpret_cast<const uint32_t *>(c->tmp(color) + (size_t)r * c->lld_dense);
 		} else if (c->dense) {
 			bits = reinterpret_cast<const uint32_t *>(c->lat(color) + (size_t)r * c->lld);
 		} else { // nibble layout, BITS wanted
@@ -96,7 +96,7 @@ int write_rows(ising_ctx *c, int color, int64_t row0, int64_t nrows, const void 
 			const int64_t nr = std::min(chunk, row0 + nrows - r);
 			const size_t nvec = (size_t)nr * nvec_row;
 			// where the chunk's dense-order words go: the slab itself (dense), the dense-order image (ballot), staging (nibble)
-			uint32_t *bits = c->ballot ? reinterpret_cast<uint32_t *>(c->tmp(color) + (size_t)r * c->lld)
+			uint32_t *bits = c->ballot ? reinterpret_cast<uint32_t *>(c->tmp(color) + (size_t)r * c->lld_dense)
 			                 : (c->dense ? reinterpret_cast<uint32_t *>(c->lat(color) + (size_t)r * c->lld) : nullptr);
 			if (fmt == PACKED) { // 1 bit/spin layouts
 				HIP_TRY(hipMemcpyAsync(c->d_pack, static_cast<const uint64_t *>(host) + (size_t)(r - row0) * c->lld_packed, nvec * 16, hipMemcpyHostToDevice, c->stream));

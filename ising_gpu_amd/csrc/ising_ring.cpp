@@ -125,6 +125,7 @@ RcclApi *rccl() {
 
 // ------------------------------------------------------------------------------------------------ per-slab resources
 int ring_resources(ising_ctx *c) {
+	if (c->comm && c->ev_int[1]) return ISING_OK; // all there (created once per slab)
 	if (int rc = bind(c)) return rc;
 	if (!c->comm) {
 		int least = 0, greatest = 0; // numerically lower = higher priority

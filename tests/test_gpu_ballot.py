@@ -113,7 +113,7 @@ def test_auto_layout_picks_ballot_where_it_applies(gpu):
         assert s.layout == BAL
     with ig.IsingSlab(8192, 8192, temp=1.5) as s:       # small slabs: the dense kernel is ahead
         assert s.layout == ig.LAYOUT_DENSE
-    with ig.IsingSlab(20480, 8192, temp=1.5) as s:      # X not a multiple of 8192
+    with ig.IsingSlab(20480, 8192, temp=1.5) as s:      # 10 column groups = 2.5 wave columns: too many dead lanes
         assert s.layout == ig.LAYOUT_DENSE
     with ig.IsingSlab(16384, 8192, temp=1.5, XSL=2048, YSL=16) as s:
         assert s.layout == BAL
@@ -123,8 +123,12 @@ def test_auto_layout_picks_ballot_where_it_applies(gpu):
         assert s.layout == BAL
     with ig.IsingSlab(16384, 8192, temp=0.0) as s:      # no integer thresholds at T = 0
         assert s.layout == ig.LAYOUT_DENSE
+    with ig.IsingSlab(4096, 32, temp=1.5, layout=BAL) as s:   # on request: any width (tests/test_gpu_ballot_partial.py) ...
+        assert s.layout == BAL
+    with pytest.raises(ig.IsingError):                         # ... but not with sub-lattices or -J on top of a partial wave column
+        ig.IsingSlab(4096, 32, temp=1.5, layout=BAL, XSL=2048, YSL=16)
     with pytest.raises(ig.IsingError):
-        ig.IsingSlab(4096, 32, temp=1.5, layout=BAL)
+        ig.IsingSlab(4096, 32, temp=1.5, layout=BAL, J_prob=0.2)
 
 
 def test_row_partition_and_edges(gpu, oracle_mod):
