@@ -188,9 +188,14 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		const int level = FUSED ? uni((int)(tk / (unsigned)p.nwg)) : 0;
 		const int wave = uni(((int)(tk - (unsigned long long)level * (unsigned)p.nwg)) * (NT / 64) + wi);
 		const int unit0 = wave * 4; // a wave covers 4 consecutive 32-vector column groups of one strip (gx % 4 == 0)
-		const bool idle = unit0 >= p.nunits; // the last workgroup of a level may be partly empty; it still meets the barriers
+		// Two row ranges per launch: the two edge rows of a ring slab, or (tail strips) the bulk of the slab in strips of H
+		// rows followed by its last rows in strips of H2 < H rows -- the hardware dispatches workgroups in index order, so
+		// the launch ends on many short units instead of a few long ones.  Range 0 is padded to whole workgroups (nunits0
+		// vs nreal0) so that the waves of a workgroup share one strip height.
 		const int rng = unit0 >= p.nunits0;
+		const bool idle = rng ? unit0 >= p.nunits : unit0 >= p.nreal0; // partly empty workgroups still meet the barriers
 		const int u = idle ? 0 : unit0 - (rng ? p.nunits0 : 0);
+		const int Hr = (rng && p.H2) ? p.H2 : p.H; // strip height of this range (uniform over the workgroup)
 		const int pos = uni(u / gxp);
 		const int bx0 = u - pos * gxp;
 		const int wc = bx0 >> 2;
@@ -201,8 +206,8 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		// (also when a plain launch publishes its edge rows, p.edge_signal: the two edge strips go first)
 		const bool zigzag = FUSED || (p.edge_signal != nullptr && rng == 0);
 		const int sidx = zigzag ? uni((pos & 1) ? nstr - 1 - (pos >> 1) : (pos >> 1)) : pos;
-		const int r0 = p.row_lo[rng] + sidx * p.H;
-		const int nrows = idle ? 0 : min(p.H, p.row_hi[rng] - r0);
+		const int r0 = p.row_lo[rng] + sidx * Hr;
+		const int nrows = idle ? 0 : min(Hr, p.row_hi[rng] - r0);
 		const bool publish = !FUSED && p.edge_signal != nullptr && !idle && rng == 0 && (r0 == 0 || r0 + nrows == p.Y);
 		const uint32_t color = FUSED ? uni((p.color + (uint32_t)level) & 1u) : p.color;
 		const uint32_t it = FUSED ? uni(p.it + ((p.color + (uint32_t)level) >> 1)) : p.it;
@@ -264,7 +269,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		}
 
 		// one scalar-cache write-back per workgroup and row: every wave runs the same number of iterations and meets at a barrier
-		const int rmax = p.H;
+		const int rmax = Hr;
 		const bool wb_wave = threadIdx.x < 64;
 		for (int r = 0; r <= rmax; ++r) {
 			// The two words per row whose side neighbours sit in another vector (sites 0 / 31) are assembled on the scalar

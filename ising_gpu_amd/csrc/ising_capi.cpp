@@ -355,16 +355,36 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (e == hipSuccess && c->ballot) {
 		// accept-mask slots, 2 KiB per wave: of every wave of the largest plain launch (one workgroup per unit), and of
 		// every workgroup slot of a fused launch (4 waves each)
-		const size_t plain = (size_t)c->nwc() * (c->nstrips + 2) * 2048 + 8192, fused = (size_t)ising::ballot_max_wgs() * 4 * 2048;
+		// Tail strips of plain launches (launch_ranges): the last rows of a launch go in strips of one row, so that the
+		// launch ends on many short units that fill the gaps the last round of H-row units leaves -- about two thirds of
+		// one H-row unit per workgroup slot (6 workgroups per CU), measured: +6 % at 16384^2, +3.5 % at 32768^2, +1 % at
+		// 65536^2, nothing at 8192^2 (tools/tail_probe.py).  ISING_TAIL=<rows>[,<strip height>] overrides, 0 disables.
+		if (c->H > 1) {
+			int cus = 256;
+			(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device);
+			long long rows = 2LL * (6LL * cus) * c->H / (3LL * c->nwc());
+			rows = rows / c->H * c->H;
+			c->tail_rows = (int)std::min<long long>(rows, cfg->Y / 4 / c->H * c->H);
+			c->tail_h = 1;
+		}
+		if (const char *e = getenv("ISING_TAIL")) {
+			int rows = 0, h = 1;
+			const int got = sscanf(e, "%d,%d", &rows, &h);
+			if (got >= 1 && rows == 0) c->tail_rows = 0;
+			else if (got >= 1 && rows > 0 && h > 0 && rows % c->H == 0 && rows % h == 0 && h < c->H && 2 * rows < cfg->Y) { c->tail_rows = rows; c->tail_h = h; }
+		}
+		const size_t strips = c->tail_rows ? (size_t)(cfg->Y - c->tail_rows) / c->H + (size_t)c->tail_rows / c->tail_h : (size_t)c->nstrips;
+		const size_t plain = (size_t)c->nwc() * (strips + 2) * 2048 + 16 * 2048, fused = (size_t)ising::ballot_max_wgs() * 4 * 2048;
 		e = hipMalloc((void **)&c->d_scratch, std::max(plain, fused));
 		// ticket words (chunk counter + 8 queue words, 64 bytes apart) + one completion counter per strip (fused launches)
 		const size_t ctl_bytes = SLOTCTL_TICKET_BYTES + (size_t)c->nstrips * sizeof(uint32_t);
 		if (e == hipSuccess) e = hipMalloc((void **)&c->d_slotctl, ctl_bytes);
 		if (e == hipSuccess) e = hipMemset(c->d_slotctl, 0, ctl_bytes);
-		// fused sweeps (ising_sweep): on a par with per-colour launches from 32768^2 up, slower below
+		// fused sweeps (ising_sweep): on a par with per-colour launches (with tail strips) at 65536^2, slower below
 		const char *fz = getenv("ISING_FUSED");
-		c->fused = fz ? atoi(fz) != 0 : (long long)cfg->X * cfg->Y >= (1LL << 29);
+		c->fused = fz ? atoi(fz) != 0 : (long long)cfg->X * cfg->Y >= (1LL << 32);
 		if (const char *e = getenv("ISING_FUSED_WIDE")) c->fused_wide = atoi(e);
+
 	}
 	if (e == hipSuccess && cfg->use_J) {
 		if (cfg->coupling_mem) c->d_ham = static_cast<uint64_t *>(cfg->coupling_mem);
@@ -490,8 +510,19 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	p.row_lo[0] = lo0; p.row_hi[0] = hi0;
 	p.row_lo[1] = lo1; p.row_hi[1] = hi1;
 	const int ugx = c->ballot ? 4 * c->nwc() : c->gx; // column groups per strip as the kernel counts them (ballot: 4 per wave column)
-	p.nunits0 = ugx * ((hi0 - lo0 + c->H - 1) / c->H);
-	p.nunits = p.nunits0 + ugx * ((hi1 - lo1 + c->H - 1) / c->H);
+	// tail strips (ballot layout, plain full-slab launch): the last rows of the slab in strips of H2 rows
+	int H2 = 0;
+	if (c->ballot && nlevels == 1 && !publish && c->tail_rows > 0 && hi1 == lo1 && hi0 - lo0 >= 4 * c->tail_rows) {
+		H2 = c->tail_h;
+		lo1 = hi0 - c->tail_rows;
+		hi1 = hi0;
+		hi0 = lo1;
+		p.row_hi[0] = hi0; p.row_lo[1] = lo1; p.row_hi[1] = hi1;
+	}
+	p.H2 = H2;
+	p.nreal0 = ugx * ((hi0 - lo0 + c->H - 1) / c->H);
+	p.nunits0 = (c->ballot && H2) ? (p.nreal0 + 15) / 16 * 16 : p.nreal0;
+	p.nunits = p.nunits0 + ugx * ((hi1 - lo1 + (H2 ? H2 : c->H) - 1) / (H2 ? H2 : c->H));
 	p.n3 = (uint32_t)c->thr[3];
 	p.n4 = (uint32_t)c->thr[4];
 	memcpy(p.tab, c->tab, sizeof(p.tab));

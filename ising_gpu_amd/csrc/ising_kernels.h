@@ -25,6 +25,8 @@ struct UpdateParams {
 	int32_t slY;              // periodic extent in Y in rows; 0 = no sub-lattices (rows -1 / Y are the halo rows)
 	int32_t H;                // rows each lane marches (a "strip"; the last strip of a range may be shorter)
 	int32_t row_lo[2], row_hi[2]; // up to two row ranges per launch (the two edge rows of a slab go in one launch)
+	int32_t H2;               // ballot layout: rows per strip in range 1 when it differs from H (tail strips); 0 = H
+	int32_t nreal0;           // ballot layout: units of range 0 that exist (nunits0 may be padded to whole workgroups)
 	int32_t nunits0;          // units (column group x strip) of range 0
 	int32_t nunits;           // units of both ranges
 	uint32_t n3, n4;          // integer accept thresholds for 3 / 4 aligned neighbours (fast kernel)
