@@ -28,6 +28,7 @@
 // converts with the two kernels at the end of this file and uses the dense kernels for the observables that need
 // neighbour geometry.
 #include "ising_device.hpp"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdlib>
@@ -612,7 +613,7 @@ static int ballot_resident_wgs(int v, const void *fn, int threads) {
 int ballot_max_wgs() { return 256 * 8; } // upper bound of the grid of any ballot launch (scratch sizing): 8 workgroups of 4 waves per CU at most
 
 template <int NT>
-static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, int *grid_out) {
+static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, int *grid_out, hipEvent_t stop) {
 	p.nwg = (p.nunits + NT / GROUP - 1) / (NT / GROUP); // (p.nunits counts column groups incl. the dead ones: 4 per wave)
 	const bool fused = p.nlevels > 1;
 	const bool usej = fused ? p.jham[0] != nullptr : p.jdst != nullptr;
@@ -635,27 +636,29 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	long long grid = fused ? std::min<long long>(std::min(ballot_resident_wgs(v + (NT == 256 ? 0 : 8), fn, NT), ballot_max_wgs() * 256 / NT), total) : total;
 	if (grid < 1) grid = 1;
 	const dim3 g((unsigned)grid), block(NT);
+	// `stop`: an event that fires when this launch is done, hung on the dispatch packet itself (hipExtLaunchKernelGGL) --
+	// a hipEventRecord behind the launch is a packet of its own that drains the queue: 7 us between two 650 us launches
 	switch (v) {
-	case 0: hipLaunchKernelGGL((ballot_update_k<false, false, false, NT>), g, block, 0, stream, p); break;
-	case 1: hipLaunchKernelGGL((ballot_update_k<false, true, false, NT>), g, block, 0, stream, p); break;
-	case 2: hipLaunchKernelGGL((ballot_update_k<true, false, false, NT>), g, block, 0, stream, p); break;
-	case 3: hipLaunchKernelGGL((ballot_update_k<true, true, false, NT>), g, block, 0, stream, p); break;
-	case 4: hipLaunchKernelGGL((ballot_update_k<false, false, true, NT>), g, block, 0, stream, p); break;
-	default: hipLaunchKernelGGL((ballot_update_k<false, true, true, NT>), g, block, 0, stream, p); break;
+	case 0: hipExtLaunchKernelGGL((ballot_update_k<false, false, false, NT>), g, block, 0, stream, nullptr, stop, 0, p); break;
+	case 1: hipExtLaunchKernelGGL((ballot_update_k<false, true, false, NT>), g, block, 0, stream, nullptr, stop, 0, p); break;
+	case 2: hipExtLaunchKernelGGL((ballot_update_k<true, false, false, NT>), g, block, 0, stream, nullptr, stop, 0, p); break;
+	case 3: hipExtLaunchKernelGGL((ballot_update_k<true, true, false, NT>), g, block, 0, stream, nullptr, stop, 0, p); break;
+	case 4: hipExtLaunchKernelGGL((ballot_update_k<false, false, true, NT>), g, block, 0, stream, nullptr, stop, 0, p); break;
+	default: hipExtLaunchKernelGGL((ballot_update_k<false, true, true, NT>), g, block, 0, stream, nullptr, stop, 0, p); break;
 	}
 	if (grid_out) *grid_out = (int)grid;
 	return hipGetLastError();
 }
 
-hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_out) {
+hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_out, hipEvent_t stop) {
 	if (grid_out) *grid_out = 0;
-	if (p.nunits <= 0) return hipSuccess;
+	if (p.nunits <= 0) return stop ? hipEventRecord(stop, stream) : hipSuccess;
 	if (p.nlevels < 1) p.nlevels = 1;
 	if (p.nlevels > 1 && p.slY != 0) return hipErrorInvalidValue; // a sub-lattice seam reaches beyond the neighbouring strips
 	// A/B (ISING_FUSED_WIDE=1): 8-wave workgroups for fused launches -- half the tickets per row of work; +10 % at 8192^2,
 	// +2 % at 16384^2, -4 % at 65536^2 against 4-wave workgroups
-	if (p.nlevels > 1 && p.wide) return launch_ballot_update_nt<512>(p, stream, grid_out);
-	return launch_ballot_update_nt<BAL_THREADS>(p, stream, grid_out);
+	if (p.nlevels > 1 && p.wide) return launch_ballot_update_nt<512>(p, stream, grid_out, stop);
+	return launch_ballot_update_nt<BAL_THREADS>(p, stream, grid_out, stop);
 }
 
 hipError_t launch_ballot_init(const InitParams &p, hipStream_t stream) {

@@ -475,7 +475,8 @@ int ising_strip_info(ising_ctx *c, int *strip_rows, int *nstrips) {
 // launches update_k over up to two row ranges
 // `nlevels` > 1 (ballot layout only): one fused launch of that many colour half-sweeps over the whole slab, starting with
 // `color` at iteration `it`
-static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int lo1, int hi1, int nlevels = 1, bool publish = false) {
+// `stop` (optional): an event that fires when the launch is done
+static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int lo1, int hi1, int nlevels = 1, bool publish = false, hipEvent_t stop = nullptr) {
 	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
 	if (it < 0) return fail(ISING_E_ARG, "negative iteration %d", it);
 	int mode = c->cfg.kernel == ISING_KERNEL_GENERIC ? 1 : (c->cfg.kernel == ISING_KERNEL_LUT ? 2 : 0); // AUTO, FAST -> 0
@@ -552,15 +553,13 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			c->edge_target[color] += (uint32_t)c->nwc() * (c->nstrips == 1 ? 1u : 2u); // wave columns of the strips with row 0 / Y-1
 		}
 		int grid = 0;
-		HIP_TRY(ising::launch_ballot_update(p, c->stream, &grid));
+		HIP_TRY(ising::launch_ballot_update(p, c->stream, &grid, stop));
 		if (nlevels > 1) c->done_base += (uint32_t)nlevels * (uint32_t)c->nwc();
 		return ISING_OK;
 	}
-	if (c->dense) {
-		HIP_TRY(ising::launch_dense_update(p, mode, c->stream));
-		return ISING_OK;
-	}
-	HIP_TRY(ising::launch_update(p, mode, c->stream));
+	if (c->dense) HIP_TRY(ising::launch_dense_update(p, mode, c->stream));
+	else HIP_TRY(ising::launch_update(p, mode, c->stream));
+	if (stop) HIP_TRY(hipEventRecord(stop, c->stream)); // (the other layouts' launchers take no event: a packet of its own)
 	return ISING_OK;
 }
 
@@ -577,12 +576,16 @@ int ising_update_edges(ising_ctx *c, int it, int color) {
 
 } // extern "C"
 
-int ising_host::update_edges_on(ising_ctx *c, int it, int color, hipStream_t s) {
+int ising_host::update_edges_on(ising_ctx *c, int it, int color, hipStream_t s, hipEvent_t stop) {
 	hipStream_t keep = c->stream; // (a context is driven by one host thread)
 	c->stream = s;
-	const int rc = launch_ranges(c, it, color, 0, 1, c->cfg.Y - 1, c->cfg.Y);
+	const int rc = launch_ranges(c, it, color, 0, 1, c->cfg.Y - 1, c->cfg.Y, 1, false, stop);
 	c->stream = keep;
 	return rc;
+}
+
+int ising_host::update_interior(ising_ctx *c, int it, int color, hipEvent_t stop) {
+	return launch_ranges(c, it, color, 1, c->cfg.Y - 1, 0, 0, 1, false, stop);
 }
 
 int ising_host::update_full_published(ising_ctx *c, int it, int color) {

@@ -109,8 +109,9 @@ int ballot_rows(ising_ctx *c, int color, long long row_lo, long long row_hi, boo
 // makes the slab's stream (or stream `s`) wait until the halo rows of `color` delivered by the ring are in place
 int halo_ready(ising_ctx *c, int color);
 int halo_ready_on(ising_ctx *c, int color, hipStream_t s);
-// ising_update_edges on another stream of the slab's device
-int update_edges_on(ising_ctx *c, int it, int color, hipStream_t s);
+// ising_update_edges on another stream of the slab's device / the interior rows 1 .. Y-2; `stop` fires when the launch is done
+int update_edges_on(ising_ctx *c, int it, int color, hipStream_t s, hipEvent_t stop);
+int update_interior(ising_ctx *c, int it, int color, hipEvent_t stop);
 // ballot layout: one launch over rows [0, Y) whose edge strips go first and publish rows 0 / Y-1 through d_signal[color]
 int update_full_published(ising_ctx *c, int it, int color);
 // called by ising_destroy

@@ -113,7 +113,8 @@ hipError_t launch_packed_to_dense(const uint64_t *packed, uint32_t *dense, size_
 
 // ballot layout (1 bit per spin in wave-ballot order, ising_ballot.hip): integer-threshold update, conversions
 // `p` is completed by the launcher (nwg); *grid_out = workgroups launched
-hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_out);
+// `stop` (optional): an event that fires when the launch is done
+hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_out, hipEvent_t stop = nullptr);
 int ballot_max_wgs();
 hipError_t launch_ballot_init(const InitParams &p, hipStream_t stream);
 hipError_t launch_ballot_to_dense(const uint64_t *bal, uint32_t *dense, int gx, long long rows, hipStream_t stream);

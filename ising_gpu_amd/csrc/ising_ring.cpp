@@ -385,16 +385,15 @@ int sweep_two_streams(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 				if (int rc = bind(c)) return rc;
 				HIP_TRY(hipStreamWaitEvent(c->comm, c->ev_int[1 - color], 0));
 				if (int rc = ising_host::halo_ready_on(c, 1 - color, c->comm)) return rc;
-				if (int rc = ising_host::update_edges_on(c, it, color, c->comm)) return rc;
-				HIP_TRY(hipEventRecord(c->ev_edge[color], c->comm));
+				if (int rc = ising_host::update_edges_on(c, it, color, c->comm, c->ev_edge[color])) return rc;
 			}
 			if (int rc = transfer(ctxs, n, color, false)) return rc;
 			for (int k = 0; k < n; k++) {
 				ising_ctx *c = ctxs[k];
 				if (int rc = bind(c)) return rc;
 				if (it > first_it || color == ISING_WHITE) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_edge[1 - color], 0));
-				if (int rc = ising_update_color(c, it, color, 1, c->cfg.Y - 1)) return rc;
-				HIP_TRY(hipEventRecord(c->ev_int[color], c->stream));
+				// (ev_int[c] rides on the launch itself: a record behind it would cost 7 us between two launches)
+				if (int rc = ising_host::update_interior(c, it, color, c->ev_int[color])) return rc;
 			}
 		}
 	}
