@@ -63,3 +63,23 @@ def test_product_never_imports_oracle():
                 if re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M) or "ising_oracle" in txt or "oracle/" in txt:
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_bench_helpers_and_full_size_goldens():
+    """bench.py's golden lookup (the counts it checks itself against) and the committed full-size fixtures."""
+    import json
+    import bench
+    gold = os.path.join(ROOT, "tests", "golden")
+    # the point the round-1 driver run hit: 65536^2, T_c, seed 1234, 5 + 20 sweeps (VERDICT r01)
+    assert bench.golden_counts(65536, 65536, 1234, 1, 25) == (2146725784, 2148241512)
+    assert bench.golden_counts(65536, 65536, 1234, 1, 0) == (2147471050, 2147496246)
+    assert bench.golden_counts(65536, 65536, 1234, 1, 26) is None and bench.golden_counts(65536, 65536, 99, 1, 25) is None
+    for n in (2, 4, 8):
+        up, down = bench.golden_counts(65536, 65536, 1234, n, 25)
+        assert up + down == n * 65536 * 65536
+    c4 = json.load(open(os.path.join(gold, "config4_131072.json")))
+    for pt in c4["points"]:
+        assert sum(pt["slab_up"]) == pt["up"] and pt["up"] + pt["down"] == 131072 * 131072
+    # the 8-slab ring's initial state is the single lattice's: same counts as config 4's?  (other geometry: 524288 x 65536)
+    r8 = [r for r in json.load(open(os.path.join(gold, "ring_65536_tc.json")))["rings"] if r["nslabs"] == 8][0]
+    assert r8["Ytot"] == 524288 and r8["points"][0]["sweeps"] == 0
