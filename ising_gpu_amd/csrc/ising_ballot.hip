@@ -152,7 +152,9 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	const bool inwave = SUBL && k < 4;              // periods shorter than a wave column
 	const int wsh = k == 1 ? 15 : 31;
 	const int n = SUBL ? max(k >> 2, 1) : nwc; // wave columns per period
-	const ptrdiff_t wrap_bot = (ptrdiff_t)p.Y * wpr;
+	// where copies of row 0 / row Y-1 of the updated colour go, as offsets from those rows: this slab's own halo rows
+	// Y / -1 (single slab: periodic wrap) or the neighbouring slabs' halo rows (ring on one device: no copies needed)
+	const ptrdiff_t mir0 = (ptrdiff_t)(p.mir0_bytes / 8), mirL = (ptrdiff_t)(p.mirL_bytes / 8);
 
 	// this workgroup slot's scratch: per wave two slots of 64 x (c3, c4) masks
 	const uint64_t *slot_v = p.scratch + ((size_t)blockIdx.x * (NT / 64) + wi) * 256;
@@ -384,9 +386,9 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				}
 				const uint64_t nw = me ^ (flips64(me, nu, nc, nd, sd, c3, c4) & live);
 				if (FUSED || publish) st_word<true>(rd + lane, nw); else st_word<false>(rd + lane, nw);
-				if (p.wrap) { // single slab: keep this colour's own halo rows equal to the opposite edge rows
-					if (lr == 0) st_word<FUSED>(rd + wrap_bot + lane, nw);
-					if (lr == p.Y - 1) st_word<FUSED>(rd - wrap_bot + lane, nw);
+				if (p.wrap) { // the halo rows that mirror this colour's edge rows
+					if (lr == 0) st_word<FUSED>(rd + mir0 + lane, nw);
+					if (lr == p.Y - 1) st_word<FUSED>(rd + mirL + lane, nw);
 				}
 				rs += wpr;
 				rd += wpr;

@@ -497,7 +497,19 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	ising::UpdateParams p{};
 	p.dst = c->lat(color);
 	p.src = c->lat(other);
-	p.wrap = c->wrap; // periodic wrap of loadTile (optimized/main.cu:414,:422) through mirrored halo rows
+	// periodic wrap of loadTile (optimized/main.cu:414,:422) through mirrored halo rows: the launch that writes an edge row
+	// also writes its mirror -- this slab's own halo rows, or (ring on one device, ising_ring.cpp) the neighbours'
+	const size_t rowb = (size_t)c->lld * sizeof(uint64_t);
+	if (c->wrap) {
+		p.wrap = 1;
+		p.mir0_bytes = (long long)c->cfg.Y * (long long)rowb;
+		p.mirL_bytes = -(long long)c->cfg.Y * (long long)rowb;
+	} else if (c->store_ring && c->ring_prev && c->ring_next && !c->cfg.XSL) {
+		const char *row0 = reinterpret_cast<const char *>(c->lat(color)), *rowL = row0 + (size_t)(c->cfg.Y - 1) * rowb;
+		p.wrap = 1;
+		p.mir0_bytes = reinterpret_cast<const char *>(c->ring_prev->lat(color) + c->ring_prev->color_words) - row0;
+		p.mirL_bytes = reinterpret_cast<const char *>(c->ring_next->lat(color)) - (long long)rowb - rowL;
+	}
 	p.seed_lo = (uint32_t)c->cfg.seed;
 	p.seed_hi = (uint32_t)(c->cfg.seed >> 32);
 	p.it = (uint32_t)it;

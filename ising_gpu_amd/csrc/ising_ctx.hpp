@@ -63,6 +63,8 @@ struct ising_ctx {
 	uint32_t *d_signal[2] = {nullptr, nullptr};  // per colour: counter the published edge strips of a full-slab launch bump
 	                                             // (hipMallocSignalMemory: the comm stream waits on it, hipStreamWaitValue32)
 	uint32_t edge_target[2] = {0, 0};            // value of the counter once every launch issued so far has published
+	bool store_ring = false;                     // ring on ONE device and one stream: every launch writes its edge rows straight into the
+	                                             // neighbouring slabs' halo rows (UpdateParams.mir0/mirL_bytes): no edge launch, no copies
 	bool copy_inline = false;                    // COPY transport, both neighbours on this slab's device: copies on the compute stream
 
 	// Row 0 of a colour.  The halo rows sit directly above (row -1: global row slab*Y-1) and below (row Y) so the

@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(dense_threads(MODE)) dense_update_k(const Upda
 	uint32_t *pm = reinterpret_cast<uint32_t *>(p.dst) + ((ptrdiff_t)r0 * wpr + col0);
 	// -J: four coupling bit-planes per destination word, {right, left, down, up} (ham_planes_k)
 	const uint4 *pj = USEJ ? reinterpret_cast<const uint4 *>(p.jdst) + ((ptrdiff_t)r0 * wpr + col0) : nullptr;
-	const ptrdiff_t wrap_bot = (ptrdiff_t)p.Y * wpr;
+	const ptrdiff_t mir0 = (ptrdiff_t)(p.mir0_bytes / 4), mirL = (ptrdiff_t)(p.mirL_bytes / 4); // see ballot_update_k
 
 	const uint32_t k2y = p.seed_hi + 2u * PHILOX_W1;
 	const uint32_t cx_base = 16u * (2u * p.it + p.color);
@@ -252,9 +252,9 @@ __global__ void __launch_bounds__(dense_threads(MODE)) dense_update_k(const Upda
 
 		pm[0] = me0;
 		pm[GROUP] = me1;
-		if (p.wrap) { // single slab: keep this colour's own halo rows equal to the opposite edge rows
-			if (lr == 0) { pm[wrap_bot] = me0; pm[wrap_bot + GROUP] = me1; }
-			if (lr == p.Y - 1) { pm[-wrap_bot] = me0; pm[-wrap_bot + GROUP] = me1; }
+		if (p.wrap) { // the halo rows that mirror this colour's edge rows
+			if (lr == 0) { pm[mir0] = me0; pm[mir0 + GROUP] = me1; }
+			if (lr == p.Y - 1) { pm[mirL] = me0; pm[mirL + GROUP] = me1; }
 		}
 		pc += wpr;
 		pm += wpr;

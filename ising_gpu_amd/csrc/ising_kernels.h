@@ -14,7 +14,9 @@ constexpr uint32_t PHILOX_W1 = 0xBB67AE85u;
 struct UpdateParams {
 	uint64_t *dst;            // colour being updated: pointer to row 0 of [-1..Y][lld] words (rows -1, Y = halo rows)
 	const uint64_t *src;      // opposite colour, same shape; its rows -1 and Y must be current
-	int32_t wrap;             // single slab: mirror updated edge rows into dst's own halo rows (periodic wrap)
+	int32_t wrap;             // copy the updated rows 0 / Y-1 into the halo rows that mirror them:
+	long long mir0_bytes;     //   row 0's copy goes mir0_bytes behind row 0 (single slab: its own row Y; ring on one device: the
+	long long mirL_bytes;     //   previous slab's row Y), row Y-1's copy mirL_bytes behind row Y-1 (own row -1 / next slab's row -1)
 	uint32_t seed_lo, seed_hi;
 	uint32_t it;              // reference's 1-based iteration index (0 for init)
 	uint32_t color;           // 0 black, 1 white

@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 	const uint4 *pc = reinterpret_cast<const uint4 *>(p.src) + ((ptrdiff_t)r0 * vecs + col0); // centre row, own vector
 	uint4 *pm = reinterpret_cast<uint4 *>(p.dst) + ((ptrdiff_t)r0 * vecs + col0);
 	const uint4 *pj = USEJ ? reinterpret_cast<const uint4 *>(p.jdst) + ((ptrdiff_t)r0 * vecs + col0) : nullptr;
-	const ptrdiff_t wrap_bot = (ptrdiff_t)p.Y * vecs; // row 0 mirrors to row Y, row Y-1 to row -1 (single slab)
+	const ptrdiff_t mir0 = (ptrdiff_t)(p.mir0_bytes / 16), mirL = (ptrdiff_t)(p.mirL_bytes / 16); // see ballot_update_k
 
 	const uint32_t k2y = p.seed_hi + 2u * PHILOX_W1;
 	const uint32_t cx_base = 16u * (2u * p.it + p.color);
@@ -312,9 +312,9 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 		}
 		pm[0] = me0;
 		pm[GROUP] = me1;
-		if (p.wrap) { // single slab: keep this colour's own halo rows equal to the opposite edge rows
-			if (lr == 0) { pm[wrap_bot] = me0; pm[wrap_bot + GROUP] = me1; }
-			if (lr == p.Y - 1) { pm[-wrap_bot] = me0; pm[-wrap_bot + GROUP] = me1; }
+		if (p.wrap) { // the halo rows that mirror this colour's edge rows
+			if (lr == 0) { pm[mir0] = me0; pm[mir0 + GROUP] = me1; }
+			if (lr == p.Y - 1) { pm[mirL] = me0; pm[mirL + GROUP] = me1; }
 		}
 		pc += vecs;
 		pm += vecs;

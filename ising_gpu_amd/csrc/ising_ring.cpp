@@ -260,8 +260,14 @@ int ring_bind(ising_ctx **ctxs, int n, int want = ISING_TRANSPORT_AUTO) {
 			c->copy_inline = c->ring_prev->cfg.device == c->cfg.device && c->ring_next->cfg.device == c->cfg.device;
 			if (const char *e = getenv("ISING_RING_INLINE")) c->copy_inline = c->copy_inline && atoi(e) != 0; // 0: exercise the two-stream schedule on one device
 		}
+		// All slabs on one device and one stream (the test configurations; `cuIsing -d N --devmap 0,0,...`): the stream
+		// orders everything, so a launch can write rows 0 / Y-1 straight into the neighbours' halo rows.
+		bool one = true;
+		for (int k = 0; k < n; k++) one = one && ctxs[k]->copy_inline && ctxs[k]->stream == ctxs[0]->stream && ctxs[k]->cfg.device == ctxs[0]->cfg.device;
+		if (const char *e = getenv("ISING_RING_STORE")) one = one && atoi(e) != 0; // 0: keep edge launch + copies (A/B)
+		for (int k = 0; k < n; k++) ctxs[k]->store_ring = one;
 	} else {
-		for (int k = 0; k < n; k++) ctxs[k]->copy_inline = false;
+		for (int k = 0; k < n; k++) ctxs[k]->copy_inline = ctxs[k]->store_ring = false;
 	}
 	for (int k = 0; k < n; k++) ctxs[k]->transport = use;
 	return ISING_OK;
@@ -425,7 +431,9 @@ int sweep_published(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 				// rows 0 / Y-1 of colour c are about to be overwritten: what the comm stream sent of them last sweep has left
 				if (copies && c->ev_sent[color]) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_sent[color], 0));
 				if (int rc = ising_host::update_full_published(c, it, color)) return rc;
-				HIP_TRY(hipEventRecord(c->ev_int[color], c->stream));
+				// (peer copies only: the neighbours must know when this launch no longer reads the halo rows they will
+				// overwrite next -- a record behind the launch, 7 us; RCCL receives are posted by this slab itself)
+				if (copies) HIP_TRY(hipEventRecord(c->ev_int[color], c->stream));
 			}
 			for (int k = 0; k < n; k++) {
 				ising_ctx *c = ctxs[k];
@@ -445,6 +453,12 @@ int sweep_published(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 
 int sweep_local(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 	if (int rc = settle_layout(ctxs, n)) return rc;
+	if (ctxs[0]->store_ring && !ctxs[0]->cfg.XSL) { // one launch per slab and colour; the stream orders the rest
+		for (int it = first_it; it < first_it + nsweeps; it++)
+			for (int color = 0; color < 2; color++)
+				for (int k = 0; k < n; k++) if (int rc = ising_update_color(ctxs[k], it, color, 0, ctxs[k]->cfg.Y)) return rc;
+		return ISING_OK;
+	}
 	bool two = nsweeps > 0 && !ctxs[0]->copy_inline && !ctxs[0]->cfg.XSL, pub = two;
 	for (int k = 0; k < n; k++) pub = pub && ctxs[k]->ballot && ctxs[k]->d_signal[0] && ctxs[k]->d_signal[1] && ctxs[k]->edge_target[0] < (1u << 30);
 	if (pub) return sweep_published(ctxs, n, first_it, nsweeps);
@@ -506,6 +520,10 @@ int ising_host::halo_ready_on(ising_ctx *c, int color, hipStream_t s) {
 }
 
 void ising_host::ring_release(ising_ctx *c) {
+	// neighbours of a single-process ring must not keep pointing at a slab that is going away
+	if (c->ring_prev && c->ring_prev->ring_next == c) { c->ring_prev->ring_next = nullptr; c->ring_prev->store_ring = false; }
+	if (c->ring_next && c->ring_next->ring_prev == c) { c->ring_next->ring_prev = nullptr; c->ring_next->store_ring = false; }
+	c->ring_prev = c->ring_next = nullptr;
 	(void)hipSetDevice(c->cfg.device);
 	rccl_drop(c, false);
 	if (c->comm) (void)hipStreamDestroy(c->comm);

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Cost of the slab-ring schedule (edge rows launch + halo delivery on the comm streams + interior launch per colour) on
-ONE GPU: n slabs of one device through the C-ABI ring (ising_ring_sweep: copy transport, second stream per slab) and
-through the torch-side LocalRing (copies on the compute stream), against the same lattice as a single slab driven by
-per-colour launches and by fused launches.  Usage: ring_overhead_probe.py [X Ytot n sweeps]"""
+ONE GPU: n slabs of one device through the C-ABI ring (ising_ring_sweep: on one device every launch writes its edge rows
+straight into the neighbouring slabs' halo rows; ISING_RING_STORE=0: edge-row launch + copies + interior launch) and
+through the torch-side LocalRing (edge launch, copies, interior launch on the compute stream), against the same lattice
+as a single slab driven by per-colour launches and by fused launches.  Usage: ring_overhead_probe.py [X Ytot n sweeps]"""
 import os
 import sys
 import time
@@ -36,7 +37,7 @@ for fused in ("0", "1"):
         base = v if fused == "0" else base
 ring = ig.SlabSet([ig.IsingSlab(X, Y // n, seed=1, temp=ig.CRIT_TEMP_F32, nslabs=n, slab=k) for k in range(n)]).init()
 v = timed(lambda k: ring.sweep(k), ring.synchronize)
-print(f"{n} slabs of {Y // n}x{X} on one device, C-ABI ring (edges, copies on the comm streams, interior): {v:8.1f} flips/ns = {100 * (v / base - 1):+.2f} % vs per-colour single slab")
+print(f"{n} slabs of {Y // n}x{X} on one device, C-ABI ring: {v:8.1f} flips/ns = {100 * (v / base - 1):+.2f} % vs per-colour single slab")
 ring.close()
 backs = [ig.HipSlabBackend.create(X, Y // n, seed=1, temp=ig.CRIT_TEMP_F32, nslabs=n, slab=k) for k in range(n)]
 lring = ig.LocalRing(backs).init()
