@@ -325,15 +325,30 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	c->lld_dense = cfg->X / 128;
 	c->gx = cfg->X / 2048;
 	compute_tables(c, cfg->temp);
-	// AUTO: the ballot kernel's two-phase row pipeline wins from ~1e8 spins per slab up (8192^2: dense 5 % ahead)
-	// (a partly dead last wave column wastes its dead lanes' draws: worth it while they are under a tenth of the row --
-	// the dense kernel is 12 % behind)
-	const bool ballot_pays = whole || 10 * c->gx > 9 * 4 * c->nwc();
-	if (cfg->layout == ISING_LAYOUT_AUTO && ballot_ok && ballot_pays && c->fast_ok && (long long)cfg->X * cfg->Y >= (1LL << 27) && !getenv("ISING_NO_BALLOT"))
-		c->ballot = true;
 	c->wrap = cfg->nslabs == 1 && !cfg->ring_halo;
+	// How ising_sweep launches on the ballot layout (measured, DESIGN 4.1 / tools/small_probe.py, shape_probe.py):
+	//   2^26 .. 2^28 spins   fused launches with 8-wave workgroups and one-row strips: a colour is 10-40 us of work and the
+	//                        chip must not drain in between (+6..11 % over the dense layout's plain launches at 2^26,
+	//                        +2.5 % over ballot plain launches at 2^27)
+	//   2^28 .. 2^32         one launch per colour, ending on one-row tail strips
+	//   from 2^32 (65536^2)  fused launches again, 4-wave workgroups: as fast as plain, a fifth less HBM traffic
+	// ISING_FUSED=0/1 and ISING_FUSED_WIDE=0/1 override.  Fused launches need a slab that wraps in place, no sub-lattices.
+	const long long spins = (long long)cfg->X * cfg->Y;
+	const bool fused_can = c->wrap && !cfg->XSL;
+	const char *fz = getenv("ISING_FUSED"), *fw = getenv("ISING_FUSED_WIDE");
+	const bool small = spins >= (1LL << 26) && spins < (1LL << 28);
+	c->fused = fz ? atoi(fz) != 0 : (spins >= (1LL << 32) || small);
+	c->fused_wide = fw ? atoi(fw) : (small ? 1 : 0);
+	// AUTO: the ballot kernel's two-phase row pipeline wins from 2^27 spins per slab up -- from 2^26 where fused launches
+	// apply; below, and for 2^26 .. 2^27 in a ring, the dense kernel is ahead.  (A partly dead last wave column wastes its
+	// dead lanes' draws: worth it while they are under a tenth of the row -- the dense kernel is 12 % behind.)
+	const bool ballot_pays = whole || 10 * c->gx > 9 * 4 * c->nwc();
+	const long long ballot_from = (c->fused && fused_can) ? (1LL << 26) : (1LL << 27);
+	if (cfg->layout == ISING_LAYOUT_AUTO && ballot_ok && ballot_pays && c->fast_ok && spins >= ballot_from && !getenv("ISING_NO_BALLOT"))
+		c->ballot = true;
 	if (c->ballot) c->lld = c->nwc() * 64;
-	c->H = cfg->strip_rows > 0 ? cfg->strip_rows : choose_strip_rows(c->gx, cfg->Y, c->dense, c->ballot);
+	c->H = cfg->strip_rows > 0 ? cfg->strip_rows
+	       : ((c->ballot && c->fused && c->fused_wide && fused_can) ? 1 : choose_strip_rows(c->gx, cfg->Y, c->dense, c->ballot));
 	if (cfg->Y % c->H) { const int h = c->H; delete c; return fail(ISING_E_ARG, "strip_rows %d does not divide Y %d", h, cfg->Y); }
 	c->nstrips = cfg->Y / c->H;
 	c->color_words = (size_t)cfg->Y * c->lld;
@@ -380,10 +395,6 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		const size_t ctl_bytes = SLOTCTL_TICKET_BYTES + (size_t)c->nstrips * sizeof(uint32_t);
 		if (e == hipSuccess) e = hipMalloc((void **)&c->d_slotctl, ctl_bytes);
 		if (e == hipSuccess) e = hipMemset(c->d_slotctl, 0, ctl_bytes);
-		// fused sweeps (ising_sweep): on a par with per-colour launches (with tail strips) at 65536^2, slower below
-		const char *fz = getenv("ISING_FUSED");
-		c->fused = fz ? atoi(fz) != 0 : (long long)cfg->X * cfg->Y >= (1LL << 32);
-		if (const char *e = getenv("ISING_FUSED_WIDE")) c->fused_wide = atoi(e);
 
 	}
 	if (e == hipSuccess && cfg->use_J) {

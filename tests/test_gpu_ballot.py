@@ -111,7 +111,11 @@ def test_couplings_ring_and_migration(gpu, oracle_mod):
 def test_auto_layout_picks_ballot_where_it_applies(gpu):
     with ig.IsingSlab(16384, 8192, temp=1.5) as s:      # from 2^27 spins per slab up
         assert s.layout == BAL
-    with ig.IsingSlab(8192, 8192, temp=1.5) as s:       # small slabs: the dense kernel is ahead
+    with ig.IsingSlab(8192, 8192, temp=1.5) as s:       # from 2^26 spins where ising_sweep's fused launches apply ...
+        assert s.layout == BAL and s.fused and s.strip_rows == 1
+    with ig.IsingSlab(8192, 8192, temp=1.5, ring_halo=True) as s:   # ... not for a ring slab of that size
+        assert s.layout == ig.LAYOUT_DENSE
+    with ig.IsingSlab(8192, 4096, temp=1.5) as s:       # small slabs: the dense kernel is ahead
         assert s.layout == ig.LAYOUT_DENSE
     with ig.IsingSlab(20480, 8192, temp=1.5) as s:      # 10 column groups = 2.5 wave columns: too many dead lanes
         assert s.layout == ig.LAYOUT_DENSE
