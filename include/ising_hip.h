@@ -57,7 +57,8 @@ enum {
 
 /* device layout of the spin arrays.  The C-ABI always speaks the reference's packed layout (read/write/dump convert). */
 enum {
-	ISING_LAYOUT_AUTO = 0,   /* ballot where it applies and pays (from 2^27 spins per slab), else dense */
+	ISING_LAYOUT_AUTO = 0,   /* ballot where it applies and pays (from 2^27 spins per slab; from 2^26 for a slab that wraps in
+	                            place and can use ising_sweep's fused launches), else dense */
 	ISING_LAYOUT_NIBBLE = 1, /* the reference's: 4 bits per spin, 16 spins per 64-bit word (optimized/main.cu:40, :1243) */
 	ISING_LAYOUT_DENSE = 2,  /* 1 bit per spin, 32 spins per 32-bit word = one reference 128-bit vector per word */
 	ISING_LAYOUT_BALLOT = 3  /* 1 bit per spin, 64-bit words in the update kernel's wave-ballot order (ising_ballot.hip),
@@ -123,7 +124,8 @@ int ising_create(const ising_config *cfg, ising_ctx **out);
 /* Frees everything the context owns (optimized/main.cu:1900-1924). */
 int ising_destroy(ising_ctx *ctx);
 
-/* Use an externally created hipStream_t (e.g. torch's current stream) for all subsequent work. */
+/* Use an externally created hipStream_t (e.g. torch's current stream) for all subsequent work.  Call it on an idle
+ * context (ising_synchronize first): work already enqueued is not re-ordered behind the new stream. */
 int ising_set_stream(ising_ctx *ctx, void *hip_stream);
 /* Blocks until all work enqueued by this context has finished (cudaDeviceSynchronize, optimized/main.cu:1751-1754). */
 int ising_synchronize(ising_ctx *ctx);
