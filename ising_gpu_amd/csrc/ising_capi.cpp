@@ -193,6 +193,9 @@ int choose_strip_rows(int gx, int Y, bool dense, bool ballot = false) {
 	// halo rows per strip stay a small fraction of the source traffic (measured optimum: 32 rows for the nibble
 	// layout, 8-16 for the dense one, whose traffic is 4x smaller, 8 for the ballot one).
 	const long long want_units = 4LL * 8192; // 4 units per wave, ~8 waves on each of 1024 SIMDs
+	// ballot layout (launches end on one-row tail strips): 16 rows while that still makes ~2.5 rounds of workgroups (16
+	// units each, 1536 resident), else 8 -- measured +0.6..1.3 % from 2^31 spins up, -0.4..-2 % below (tools/big_probe.py)
+	if (ballot && (Y % 16) == 0 && (long long)gx * (Y / 16) >= 61440) return 16;
 	int H = ballot ? 8 : (dense ? 16 : 32);
 	while (H > 1 && ((Y % H) != 0 || (long long)gx * (Y / H) < want_units)) H >>= 1;
 	return H;
@@ -330,14 +333,14 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	//   2^26 .. 2^28 spins   fused launches with 8-wave workgroups and one-row strips: a colour is 10-40 us of work and the
 	//                        chip must not drain in between (+6..11 % over the dense layout's plain launches at 2^26,
 	//                        +2.5 % over ballot plain launches at 2^27)
-	//   2^28 .. 2^32         one launch per colour, ending on one-row tail strips
-	//   from 2^32 (65536^2)  fused launches again, 4-wave workgroups: as fast as plain, a fifth less HBM traffic
+	//   from 2^28            one launch per colour, ending on one-row tail strips.  (Fused launches with 4-wave workgroups,
+	//                        ISING_FUSED=1, move a fifth less HBM traffic there and are 1 % slower at 65536^2, 5-9 % at 2^30.)
 	// ISING_FUSED=0/1 and ISING_FUSED_WIDE=0/1 override.  Fused launches need a slab that wraps in place, no sub-lattices.
 	const long long spins = (long long)cfg->X * cfg->Y;
 	const bool fused_can = c->wrap && !cfg->XSL;
 	const char *fz = getenv("ISING_FUSED"), *fw = getenv("ISING_FUSED_WIDE");
 	const bool small = spins >= (1LL << 26) && spins < (1LL << 28);
-	c->fused = fz ? atoi(fz) != 0 : (spins >= (1LL << 32) || small);
+	c->fused = fz ? atoi(fz) != 0 : small;
 	c->fused_wide = fw ? atoi(fw) : (small ? 1 : 0);
 	// AUTO: the ballot kernel's two-phase row pipeline wins from 2^27 spins per slab up -- from 2^26 where fused launches
 	// apply; below, and for 2^26 .. 2^27 in a ring, the dense kernel is ahead.  (A partly dead last wave column wastes its
