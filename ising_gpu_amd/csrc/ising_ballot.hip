@@ -32,6 +32,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstdlib>
 
 namespace ising {
 namespace {
@@ -111,6 +112,25 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 // same).  The chip never drains between colours.  Measured: equal to plain launches from 32768^2 up, slower
 // below -- one counter hands out at most ~88 tickets per us and a unit carries ~19 us of latency (ticket, completion
 // counters, write-through stores) that small strips do not amortise.
+// A/B (make variant DEFS=-DISING_FUSED_LOOKAHEAD=1): draw the next ticket during a unit's FIRST row (its latency hidden,
+// the round-2 form) instead of its last.  A ticket drawn a unit ahead sits reserved while its workgroup finishes the
+// current unit and later tickets start before it: units of the next level then find their parents unfinished.  Measured
+// (tools/trace_probe.py): 65536^2, H = 8: 0.93 M polls that slept per 2.1 M units -> none, +1 %; 16384^2, 8-wave
+// workgroups, H = 2: 2.0 M -> 0.1 M, +3 %.
+#ifndef ISING_FUSED_LOOKAHEAD
+#define ISING_FUSED_LOOKAHEAD 0
+#endif
+// Measurement build (make variant DEFS=-DISING_FUSED_TRACE): wave 0 of every workgroup of a fused launch clocks where its
+// time goes (s_memtime between the marks below); ballot_trace_dump() prints the chip-wide sums when the slab is
+// destroyed.  Never in the product library.
+#if defined(ISING_FUSED_TRACE)
+__device__ unsigned long long g_trace[16];
+#define TRC(i) do { if (FUSED && wi == 0) { const long long t_ = clock64(); if (lane == 0) tr[i] += (unsigned long long)(t_ - tlast); tlast = t_; } } while (0)
+#define TRN(i, n) do { if (FUSED && wi == 0 && lane == 0) tr[i] += (unsigned long long)(n); } while (0)
+#else
+#define TRC(i) do {} while (0)
+#define TRN(i, n) do {} while (0)
+#endif
 #if defined(ISING_BAL_NUM_SGPR) // A/B: cap the scalar registers (80: eight workgroups per CU instead of six)
 #define BAL_SGPR_ATTR __attribute__((amdgpu_num_sgpr(ISING_BAL_NUM_SGPR)))
 #else
@@ -171,9 +191,16 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	const unsigned long long total = (unsigned long long)p.nlevels * (unsigned long long)p.nwg;
 	const uint32_t k2y = p.seed_hi + 2u * PHILOX_W1;
 
-	// Fused launches draw tickets one unit ahead: thread 0 draws the NEXT ticket during the first row of a unit and leaves
-	// it in LDS before that row's barrier, where the workgroup picks it up after the unit's last barrier.  (Built with
-	// -amdgpu-atomic-optimizer-strategy=None: the wave-aggregating rewrite of atomicAdd needs the result on the spot.)
+#if defined(ISING_FUSED_TRACE)
+	__shared__ unsigned long long tr[16];
+	if (threadIdx.x < 16) tr[threadIdx.x] = 0;
+	__syncthreads();
+	long long tlast = clock64();
+	const long long tstart = tlast;
+#endif
+	// Fused launches: thread 0 draws the NEXT ticket in a unit's last iteration and leaves it in LDS before that
+	// iteration's barrier, where the workgroup picks it up.  (Built with -amdgpu-atomic-optimizer-strategy=None: the
+	// wave-aggregating rewrite of atomicAdd needs the result on the spot.)
 	if (FUSED) {
 		if (threadIdx.x == 0) ticket_sh[0] = atomicAdd(p.ticket, 1ull);
 		__syncthreads();
@@ -188,6 +215,8 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			tk = round ? total : (unsigned long long)blockIdx.x; // plain: one unit per workgroup
 		}
 		if (tk >= total) break;
+		TRC(0); // ticket pick-up
+		TRN(8, 1);
 		const int level = FUSED ? uni((int)(tk / (unsigned)p.nwg)) : 0;
 		const int wave = uni(((int)(tk - (unsigned long long)level * (unsigned)p.nwg)) * (NT / 64) + wi);
 		const int unit0 = wave * 4; // a wave covers 4 consecutive 32-vector column groups of one strip (gx % 4 == 0)
@@ -253,11 +282,16 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			int sd = sidx + (lane == 0 ? -1 : (lane == 1 ? 0 : 1));
 			sd = sd < 0 ? sd + nstr : (sd >= nstr ? sd - nstr : sd);
 			const uint32_t *dp = p.done + sd;
+			TRC(1); // unit decode
+			[[maybe_unused]] int nsleep = 0;
 			for (;;) { // few, patient polls: every poll is a trip to memory that competes with the lattice traffic
 				const uint32_t v = lane < 3 ? __hip_atomic_load(dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
 				if (__all((int32_t)(v - need) >= 0)) break;
+				TRN(9, 1);
+				TRN(15, nsleep++ == 0);
 				__builtin_amdgcn_s_sleep(32);
 			}
+			TRC(2); // completion counters
 		}
 		if (lane < 16) {
 			const PhiloxBlockConst kc = philox_block_const(cx_base + (uint32_t)lane, p.seed_lo, p.seed_hi);
@@ -274,6 +308,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		// one scalar-cache write-back per workgroup and row: every wave runs the same number of iterations and meets at a barrier
 		const int rmax = Hr;
 		const bool wb_wave = threadIdx.x < 64;
+		const int r_ticket = ISING_FUSED_LOOKAHEAD ? 0 : rmax;
 		for (int r = 0; r <= rmax; ++r) {
 			// The two words per row whose side neighbours sit in another vector (sites 0 / 31) are assembled on the scalar
 			// unit from three source-colour words of row r0 + r - 1: A0, A1 of this wave's own 64 words, C from the
@@ -295,6 +330,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 					             : "=&s"(sA0), "=&s"(sA1), "=&s"(sC) : "s"(q0), "s"(q1), "s"(qc) : "memory");
 				}
 			}
+			TRC(3); // row prologue
 			if (r < nrows) {
 				// ---- draw phase, row r0 + r
 				const uint32_t grow = p.row_base + (uint32_t)(r0 + r);
@@ -324,10 +360,13 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 					             : "memory", BAL_CLOB16);
 				});
 			}
-			if (FUSED && r == 0 && wi == 0) { // wave-uniform branch; read by the workgroup after this unit's last barrier
+			TRC(4); // draw phase
+			if (FUSED && r == r_ticket && wi == 0) { // wave-uniform branch; read by the workgroup after this unit's last barrier
 				if (lane == 0) ticket_sh[(round + 1) & 1] = atomicAdd(p.ticket, 1ull);
 			}
+			TRC(5); // next ticket
 			asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+			TRC(6); // barrier (scalar stores, write-back of the previous row, the slowest wave)
 			if (r > 0 && r <= nrows) {
 				// ---- word phase, row r0 + r - 1; its masks were written back during the draw phase above
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -374,7 +413,9 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 					asm("v_writelane_b32 %0, %2, 63\n\tv_writelane_b32 %1, %3, 63" : "+v"(sdl), "+v"(sdh) : "s"(w1l), "s"(w1h));
 				}
 				uint64_t sd = ((uint64_t)sdh << 32) | sdl;
+				TRC(7); // word phase up to the wait for its loads
 				asm volatile("s_waitcnt vmcnt(0)" : "+v"(mk) :: "memory");
+				TRC(10); // wait for masks and words
 				const uint64_t c3 = ((uint64_t)mk.y << 32) | mk.x, c4 = ((uint64_t)mk.w << 32) | mk.z;
 				uint64_t nu = up, nc = ct, nd = dw;
 				if (USEJ) { // a set coupling bit flips that neighbour's contribution (optimized/main.cu:575-618)
@@ -401,6 +442,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 					--seam;
 				}
 			}
+			TRC(11); // flips, stores
 			if (wb_wave && r < rmax) asm volatile("s_dcache_wb" ::: "memory");
 		}
 		if (publish) {
@@ -413,9 +455,18 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			// publish: this wave's stores were written through (sc1); once they have left the wave the strip's counter
 			// may move (every storing wave drains its own stores and signals its own unit)
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			TRC(13); // store drain
 			if (lane == 0) __hip_atomic_fetch_add(p.done + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
+#if defined(ISING_FUSED_TRACE)
+	if (FUSED) {
+		__syncthreads();
+		if (threadIdx.x == 0) tr[14] = (unsigned long long)(clock64() - tstart);
+		__syncthreads();
+		if (threadIdx.x < 16) atomicAdd(&g_trace[threadIdx.x], tr[threadIdx.x]);
+	}
+#endif
 }
 
 // ---- init (latticeInit_k, optimized/main.cu:92-151): one wave per (row, wave column).  A spin starts up where
@@ -636,6 +687,18 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	// the tickets gone), so the occupancy query need not be exact.
 	const long long total = (long long)p.nwg * p.nlevels;
 	long long grid = fused ? std::min<long long>(std::min(ballot_resident_wgs(v + (NT == 256 ? 0 : 8), fn, NT), ballot_max_wgs() * 256 / NT), total) : total;
+	if (fused) {
+		// Fewer workgroups than the chip holds when a level has few tickets: a unit's parents are one level = p.nwg tickets
+		// back, and a workgroup that finds them unfinished holds its slot asleep (ising_create picks wg_per_cu)
+		static int cu_count[16];
+		int dev = 0;
+		if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+		if (!cu_count[dev] && (hipDeviceGetAttribute(&cu_count[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu_count[dev] < 1)) cu_count[dev] = 256;
+		const int cus = cu_count[dev];
+		if (p.wg_per_cu > 0) grid = std::min<long long>(grid, (long long)p.wg_per_cu * cus);
+		static const long long cap = getenv("ISING_FUSED_WGS") ? atoll(getenv("ISING_FUSED_WGS")) : 0; // A/B: explicit grid
+		if (cap > 0) grid = std::min(grid, cap);
+	}
 	if (grid < 1) grid = 1;
 	const dim3 g((unsigned)grid), block(NT);
 	// `stop`: an event that fires when this launch is done, hung on the dispatch packet itself (hipExtLaunchKernelGGL) --
@@ -652,6 +715,21 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	return hipGetLastError();
 }
 
+#if defined(ISING_FUSED_TRACE)
+void ballot_trace_dump() {
+	static const char *name[16] = {"ticket pick-up", "decode", "completion counters", "row prologue", "draw", "next ticket", "barrier", "word: issue",
+	                               "", "", "word: wait loads", "word: flips+store", "", "drain", "TOTAL", ""};
+	unsigned long long h[16];
+	if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace), sizeof(h)) != hipSuccess) return;
+	fprintf(stderr, "fused trace (wave 0 of every workgroup): %llu units, %llu polls that slept in %llu units\n", h[8], h[9], h[15]);
+	for (int i = 0; i < 15; ++i) {
+		if (!name[i][0]) continue;
+		fprintf(stderr, "  %-22s %6.2f %% of workgroup time, %8.1f cycles per unit\n", name[i], 100.0 * (double)h[i] / (double)h[14], (double)h[i] / (double)(h[8] ? h[8] : 1));
+	}
+	for (auto &v : h) v = 0;
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), h, sizeof(h));
+}
+#endif
 hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_out, hipEvent_t stop) {
 	if (grid_out) *grid_out = 0;
 	if (p.nunits <= 0) return stop ? hipEventRecord(stop, stream) : hipSuccess;

@@ -188,6 +188,15 @@ void ballot_planes_to_planes(uint64_t *ham, size_t ngroups) {
 	}
 }
 
+// fused launches: tickets per level, and the strip height that keeps a level at >= 8192 tickets (ising_create)
+long long fused_tickets(int nwc, int Y, int H, bool wide) { return ((long long)nwc * ((Y + H - 1) / H) + (wide ? 7 : 3)) / (wide ? 8 : 4); }
+int choose_fused_strip_rows(int nwc, int Y, bool wide) {
+	if (wide || (long long)nwc * Y < 12288) return (Y % 2) == 0 ? 2 : 1; // up to 2^27 spins
+	for (int H = 16; H > 4; H >>= 1)
+		if ((Y % H) == 0 && fused_tickets(nwc, Y, H, false) >= 8192) return H;
+	return (Y % 4) == 0 ? 4 : ((Y % 2) == 0 ? 2 : 1);
+}
+
 int choose_strip_rows(int gx, int Y, bool dense, bool ballot = false) {
 	// Enough (column-group x strip) units to give every SIMD several waves, while keeping strips tall so the two
 	// halo rows per strip stay a small fraction of the source traffic (measured optimum: 32 rows for the nibble
@@ -329,19 +338,23 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	c->gx = cfg->X / 2048;
 	compute_tables(c, cfg->temp);
 	c->wrap = cfg->nslabs == 1 && !cfg->ring_halo;
-	// How ising_sweep launches on the ballot layout (measured, DESIGN 4.1 / tools/small_probe.py, shape_probe.py):
-	//   2^26 .. 2^28 spins   fused launches with 8-wave workgroups and one-row strips: a colour is 10-40 us of work and the
-	//                        chip must not drain in between (+6..11 % over the dense layout's plain launches at 2^26,
-	//                        +2.5 % over ballot plain launches at 2^27)
-	//   from 2^28            one launch per colour, ending on one-row tail strips.  (Fused launches with 4-wave workgroups,
-	//                        ISING_FUSED=1, move a fifth less HBM traffic there and are 1 % slower at 65536^2, 5-9 % at 2^30.)
-	// ISING_FUSED=0/1 and ISING_FUSED_WIDE=0/1 override.  Fused launches need a slab that wraps in place, no sub-lattices.
+	// How ising_sweep launches on the ballot layout: fused launches (one launch = up to 32 sweeps, in-order tickets,
+	// per-strip completion counters; ising_ballot.hip) from 2^26 spins up, on a slab that wraps in place and has no
+	// sub-lattices.  A unit's parents are one level = T tickets back, so a level must hold a few times more tickets than
+	// workgroups run, or units find their parents unfinished and hold their slots asleep: the strip height H follows
+	// from T = wave rows / (H x waves per workgroup), and small lattices run FEWER workgroups than the chip holds.
+	// Measured (tools/grid_probe.py, grid_probe2.py), flips/ns fused vs one launch per colour + tail strips:
+	//   2^26 (8192^2)    4-wave workgroups, H = 2, 3 per CU (T = 1024)      2375-2405 vs 2080 (dense layout 2160)
+	//   2^27             8-wave workgroups, H = 2, 2 per CU (T = 1024)      2690-2790 vs 2500
+	//   2^28 (16384^2)   4-wave, H = 4, 4 per CU (T = 2048)                 3060 vs 2940-2975
+	//   2^29 ...         4-wave, the tallest H of 16, 8, 4 with T >= 8192 (else 4), 5 per CU (6 from T = 16384):
+	//                    32768^2 3340 vs 3300, 65536 x 32768 3427 vs 3311, 65536^2 3398 vs 3302, 131072^2 3414 vs 3341
+	// ISING_FUSED=0/1, ISING_FUSED_WIDE=0/1, cfg.strip_rows and ISING_FUSED_WGS (grid) override.
 	const long long spins = (long long)cfg->X * cfg->Y;
 	const bool fused_can = c->wrap && !cfg->XSL;
 	const char *fz = getenv("ISING_FUSED"), *fw = getenv("ISING_FUSED_WIDE");
-	const bool small = spins >= (1LL << 26) && spins < (1LL << 28);
-	c->fused = fz ? atoi(fz) != 0 : small;
-	c->fused_wide = fw ? atoi(fw) : (small ? 1 : 0);
+	c->fused = fz ? atoi(fz) != 0 : spins >= (1LL << 26);
+	c->fused_wide = fw ? atoi(fw) : (spins >= 3 * (1LL << 25) && spins < (1LL << 28) ? 1 : 0);
 	// AUTO: the ballot kernel's two-phase row pipeline wins from 2^27 spins per slab up -- from 2^26 where fused launches
 	// apply; below, and for 2^26 .. 2^27 in a ring, the dense kernel is ahead.  (A partly dead last wave column wastes its
 	// dead lanes' draws: worth it while they are under a tenth of the row -- the dense kernel is 12 % behind.)
@@ -350,11 +363,16 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (cfg->layout == ISING_LAYOUT_AUTO && ballot_ok && ballot_pays && c->fast_ok && spins >= ballot_from && !getenv("ISING_NO_BALLOT"))
 		c->ballot = true;
 	if (c->ballot) c->lld = c->nwc() * 64;
+	const bool fused_shape = c->ballot && c->fused && fused_can;
 	c->H = cfg->strip_rows > 0 ? cfg->strip_rows
-	       : ((c->ballot && c->fused && c->fused_wide && fused_can) ? 1 : choose_strip_rows(c->gx, cfg->Y, c->dense, c->ballot));
+	       : (fused_shape ? choose_fused_strip_rows(c->nwc(), cfg->Y, c->fused_wide != 0) : choose_strip_rows(c->gx, cfg->Y, c->dense, c->ballot));
 	if (cfg->Y % c->H) { const int h = c->H; delete c; return fail(ISING_E_ARG, "strip_rows %d does not divide Y %d", h, cfg->Y); }
 	c->nstrips = cfg->Y / c->H;
 	c->color_words = (size_t)cfg->Y * c->lld;
+	if (fused_shape) { // workgroups per CU of a fused launch (the chip holds 6 of 4 waves, 3 of 8)
+		const long long T = fused_tickets(c->nwc(), cfg->Y, c->H, c->fused_wide != 0);
+		c->fused_wg_per_cu = c->fused_wide ? (T >= 2048 ? 3 : 2) : (T >= 16384 ? 6 : (T >= 4096 ? 5 : (T >= 2048 ? 4 : 3)));
+	}
 
 	hipError_t e = hipSetDevice(cfg->device);
 	if (e == hipSuccess && cfg->lattice_mem) {
@@ -415,6 +433,9 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 }
 
 int ising_destroy(ising_ctx *c) {
+#if defined(ISING_FUSED_TRACE)
+	if (c && c->ballot && c->fused) { (void)hipDeviceSynchronize(); ising::ballot_trace_dump(); }
+#endif
 	if (!c) return ISING_OK;
 	(void)hipSetDevice(c->cfg.device);
 	ising_host::ring_release(c);
@@ -572,6 +593,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			p.jham[1] = c->cfg.use_J ? c->ham(0) : nullptr;
 			p.done = c->d_slotctl + SLOTCTL_TICKET_BYTES / 4;
 			p.wide = c->fused_wide;
+			p.wg_per_cu = c->fused_wg_per_cu;
 			p.done_base = c->done_base;
 		}
 		if (publish) {

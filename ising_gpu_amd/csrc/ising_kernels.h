@@ -40,6 +40,7 @@ struct UpdateParams {
 	unsigned long long *ticket; // fused: ticket words (chunk counter + 8 queue words, 64 bytes apart), zero when the launch starts
 	int32_t nwg;              // workgroup units per level (set by the launcher)
 	int32_t wide;             // fused: 512-thread workgroups (8 waves per ticket)
+	int32_t wg_per_cu;        // fused: cap of the persistent grid, workgroups per CU (0: what the chip holds; host side only)
 	int32_t nlevels;          // colour half-sweeps in this launch.  > 1 = fused: level L updates colour (color + L) & 1 at
 	                          // iteration it + (color + L) / 2 over rows [row_lo[0], row_hi[0]) = the whole slab (wrap)
 	uint64_t *lat[2];         // fused: row-0 pointers of both colours
@@ -116,6 +117,9 @@ hipError_t launch_packed_to_dense(const uint64_t *packed, uint32_t *dense, size_
 // ballot layout (1 bit per spin in wave-ballot order, ising_ballot.hip): integer-threshold update, conversions
 // `p` is completed by the launcher (nwg); *grid_out = workgroups launched
 // `stop` (optional): an event that fires when the launch is done
+#if defined(ISING_FUSED_TRACE)
+void ballot_trace_dump(); // measurement builds only (ising_ballot.hip)
+#endif
 hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_out, hipEvent_t stop = nullptr);
 int ballot_max_wgs();
 hipError_t launch_ballot_init(const InitParams &p, hipStream_t stream);
