@@ -8,10 +8,10 @@ target is quoted on (configs[2]); with N ranks the lattice is (N*65536) x 65536,
 to each ring neighbour per half-sweep.  The lattice is generated on the device from the seed: "synthetic".
 
   N = 1   the slab sweeps itself (ising_sweep), `batch` sweeps per call (batch = the largest divisor <= 32 of
-          gcd(steps, warmup)).  At the default size that is one launch per colour; where ising_sweep issues fused launches
-          (2^26 .. 2^28 spins, or ISING_FUSED=1) every call is ONE launch of 2 * batch colour half-sweeps, so that every
-          launch of the run -- warm-up included -- is the same piece of work and the rocprofv3 per-kernel average agrees
-          with the HIP-event average reported here.
+          gcd(steps, warmup)).  ising_sweep issues fused launches from 2^26 spins up (ISING_FUSED=0: one launch per
+          colour): every call is ONE launch of 2 * batch colour half-sweeps, so that every launch of the run -- warm-up
+          included -- is the same piece of work and the rocprofv3 per-kernel average agrees with the HIP-event average
+          reported here.
   N > 1   one process per GPU; the ring lives inside libising_hip.so (ising_rank_*: second HIP stream + RCCL send/recv);
           if that transport does not come up the torch.distributed ring (p2p, then all-gather) takes over and the JSON
           line says which one ran.  The counts after warm-up + steps are compared with the oracle's committed goldens

@@ -165,7 +165,7 @@ int ising_strip_info(ising_ctx *ctx, int *strip_rows, int *nstrips);
 /* nslabs == 1 only: `nsweeps` full sweeps, black then white, iterations first_it .. first_it+nsweeps-1
  * (the hot loop, optimized/main.cu:1763-1805). */
 int ising_sweep(ising_ctx *ctx, int first_it, int nsweeps);
-/* How ising_sweep launches right now: *fused = 1 when it issues fused launches (ballot layout from 32768^2 up, or
+/* How ising_sweep launches right now: *fused = 1 when it issues fused launches (ballot layout from 2^26 spins up, or
  * ISING_FUSED=1: one launch carries up to *max_sweeps_per_launch sweeps = twice as many colour half-sweeps, handed out to
  * a chip-filling grid through in-order tickets; ising_ballot.hip), 0 when it issues one launch per colour. */
 int ising_sweep_info(ising_ctx *ctx, int *fused, int *max_sweeps_per_launch);

@@ -108,12 +108,12 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 // ticket waits for has a lower number, so the lowest unfinished ticket is always being worked on by a running
 // workgroup: no deadlock whatever the residency or whatever else runs on the chip.  The accept-mask slots belong to the
 // workgroup SLOT (blockIdx): ~12 MB that stay in the L2s, where a plain launch of 65536^2 spreads 134 MB of slots that
-// spill to HBM (0.43 GB of extra traffic per launch, free of charge under a saturated vector ALU but traffic all the
-// same).  The chip never drains between colours.  Measured: equal to plain launches from 32768^2 up, slower
-// below -- one counter hands out at most ~88 tickets per us and a unit carries ~19 us of latency (ticket, completion
-// counters, write-through stores) that small strips do not amortise.
+// spill to HBM (0.95 vs 1.14 GB of traffic per colour half-sweep, free of charge under a saturated vector ALU but traffic
+// all the same).  The chip never drains between colours.  A unit's parents are one level of tickets back: the host picks
+// strip height and grid size so that they are done when the unit starts (ising_create); from 2^26 spins up
+// this form is what ising_sweep launches.
 // A/B (make variant DEFS=-DISING_FUSED_LOOKAHEAD=1): draw the next ticket during a unit's FIRST row (its latency hidden,
-// the round-2 form) instead of its last.  A ticket drawn a unit ahead sits reserved while its workgroup finishes the
+// the form this kernel had first) instead of its last.  A ticket drawn a unit ahead sits reserved while its workgroup finishes the
 // current unit and later tickets start before it: units of the next level then find their parents unfinished.  Measured
 // (tools/trace_probe.py): 65536^2, H = 8: 0.93 M polls that slept per 2.1 M units -> none, +1 %; 16384^2, 8-wave
 // workgroups, H = 2: 2.0 M -> 0.1 M, +3 %.
