@@ -90,6 +90,16 @@ __device__ __forceinline__ void st_word(uint64_t *q, uint64_t v) {
 	if (COH) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	else *q = v;
 }
+// The row loop of a fused launch issues its lattice loads and stores as inline assembly and waits for them by hand
+// (vmcnt counts in order).  With compiler-tracked atomic loads / stores in that loop the compiler protected registers of
+// pending operations with s_waitcnt vmcnt(0) at the top of every row -- a wait for the previous row's write-through
+// stores, which have nothing to do with the draw phase that follows.  `base` is wave-uniform, `off` the lane's byte offset.
+__device__ __forceinline__ void ld64_coh_issue(uint64_t &v, const uint64_t *base, int off) {
+	asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=&v"(v) : "v"(off), "s"(base) : "memory");
+}
+__device__ __forceinline__ void st64_coh_issue(uint64_t *base, int off, uint64_t v) {
+	asm volatile("global_store_dwordx2 %0, %1, %2 sc1" :: "v"(off), "v"(v), "s"(base) : "memory");
+}
 // wave-uniform values the compiler may have left in vector registers (ticket arithmetic): pin them to the scalar unit
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -112,13 +122,15 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 // all the same).  The chip never drains between colours.  A unit's parents are one level of tickets back: the host picks
 // strip height and grid size so that they are done when the unit starts (ising_create); from 2^26 spins up
 // this form is what ising_sweep launches.
-// A/B (make variant DEFS=-DISING_FUSED_LOOKAHEAD=1): draw the next ticket during a unit's FIRST row (its latency hidden,
-// the form this kernel had first) instead of its last.  A ticket drawn a unit ahead sits reserved while its workgroup finishes the
-// current unit and later tickets start before it: units of the next level then find their parents unfinished.  Measured
-// (tools/trace_probe.py): 65536^2, H = 8: 0.93 M polls that slept per 2.1 M units -> none, +1 %; 16384^2, 8-wave
-// workgroups, H = 2: 2.0 M -> 0.1 M, +3 %.
+// When a workgroup draws its next ticket.  2 (default): in a unit's last iteration, waited for on the spot (~2 us per
+// unit).  0: requested at the end of the second-last word phase and picked up one iteration later -- hides half of
+// the wait and brings back a third of the sleeping polls: no gain (16384^2: 1.1 M -> 2.8 M polls that slept).  1: during
+// a unit's FIRST row, the form this kernel had first: a ticket drawn a unit ahead sits reserved while its workgroup
+// finishes the current unit and later tickets start before it, so units of the next level find their parents unfinished.
+// Measured (tools/trace_probe.py, `make variant DEFS=-DISING_FUSED_LOOKAHEAD=1`): 65536^2, H = 16: 1.5 M polls that
+// slept per 2.1 M units -> none with 2; 16384^2, H = 4: 7.1 M -> 1.1 M, 2880 -> 3000 flips/ns (trace builds).
 #ifndef ISING_FUSED_LOOKAHEAD
-#define ISING_FUSED_LOOKAHEAD 0
+#define ISING_FUSED_LOOKAHEAD 2
 #endif
 // Measurement build (make variant DEFS=-DISING_FUSED_TRACE): wave 0 of every workgroup of a fused launch clocks where its
 // time goes (s_memtime between the marks below); ballot_trace_dump() prints the chip-wide sums when the slab is
@@ -201,14 +213,20 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	// Fused launches: thread 0 draws the NEXT ticket in a unit's last iteration and leaves it in LDS before that
 	// iteration's barrier, where the workgroup picks it up.  (Built with -amdgpu-atomic-optimizer-strategy=None: the
 	// wave-aggregating rewrite of atomicAdd needs the result on the spot.)
+	unsigned long long tkv = 0; // this workgroup's ticket as read from LDS (every lane the same value)
 	if (FUSED) {
 		if (threadIdx.x == 0) ticket_sh[0] = atomicAdd(p.ticket, 1ull);
 		__syncthreads();
+		tkv = ticket_sh[0];
 	}
+	// a workgroup's tickets grow, so its level is a running count (no 64-bit division per unit)
+	int level = 0;
+	unsigned long long level_base = 0;
+	[[maybe_unused]] unsigned long long tk_next = 0; // (set once, here: a write per unit would have to wait for the unit's first loads)
+	const int nwc_sh = (nwc & (nwc - 1)) == 0 ? __builtin_ctz((unsigned)nwc) + 2 : -1; // gxp = 4 nwc as a shift where it is one
 	for (int round = 0;; ++round) {
 		unsigned long long tk;
 		if (FUSED) {
-			const unsigned long long tkv = ticket_sh[round & 1];
 			const uint32_t tk_lo = __builtin_amdgcn_readfirstlane((uint32_t)tkv), tk_hi = __builtin_amdgcn_readfirstlane((uint32_t)(tkv >> 32));
 			tk = ((unsigned long long)tk_hi << 32) | tk_lo;
 		} else {
@@ -217,8 +235,13 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		if (tk >= total) break;
 		TRC(0); // ticket pick-up
 		TRN(8, 1);
-		const int level = FUSED ? uni((int)(tk / (unsigned)p.nwg)) : 0;
-		const int wave = uni(((int)(tk - (unsigned long long)level * (unsigned)p.nwg)) * (NT / 64) + wi);
+		if (FUSED) {
+			while (tk >= level_base + (unsigned)p.nwg) {
+				level_base += (unsigned)p.nwg;
+				++level;
+			}
+		}
+		const int wave = uni((int)(tk - level_base) * (NT / 64) + wi);
 		const int unit0 = wave * 4; // a wave covers 4 consecutive 32-vector column groups of one strip (gx % 4 == 0)
 		// Two row ranges per launch: the two edge rows of a ring slab, or (tail strips) the bulk of the slab in strips of H
 		// rows followed by its last rows in strips of H2 < H rows -- the hardware dispatches workgroups in index order, so
@@ -228,7 +251,9 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		const bool idle = rng ? unit0 >= p.nunits : unit0 >= p.nreal0; // partly empty workgroups still meet the barriers
 		const int u = idle ? 0 : unit0 - (rng ? p.nunits0 : 0);
 		const int Hr = (rng && p.H2) ? p.H2 : p.H; // strip height of this range (uniform over the workgroup)
-		const int pos = uni(u / gxp);
+		int pos;
+		if (nwc_sh >= 0) pos = u >> nwc_sh;
+		else pos = uni(u / gxp);
 		const int bx0 = u - pos * gxp;
 		const int wc = bx0 >> 2;
 		const int bx = bx0 + g;
@@ -248,9 +273,9 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 
 		uint64_t first = 0, last = 0;                    // bit 16g (16g + 15): group g opens (closes) a period
 #pragma unroll
-		for (int gg = 0; gg < 4; ++gg) {
-			if ((bx0 + gg) % k == 0) first |= 1ull << (16 * gg);
-			if ((bx0 + gg) % k == k - 1) last |= 1ull << (16 * gg + 15);
+		for (int gg = 0; gg < 4; ++gg) { // (without sub-lattices the period is the row: k = gx)
+			if (SUBL ? (bx0 + gg) % k == 0 : bx0 + gg == 0) first |= 1ull << (16 * gg);
+			if (SUBL ? (bx0 + gg) % k == k - 1 : bx0 + gg == p.gx - 1) last |= 1ull << (16 * gg + 15);
 		}
 		const uint64_t u_b1 = LANE0 & ~1ull & ~first, u_f1 = LANE15 & ~(1ull << 63) & ~last;
 		// lanes of this wave that exist (all of them unless this is the partly dead last wave column), the bit of the row's
@@ -258,11 +283,12 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		const int alive = min(4, p.gx - bx0);
 		const uint64_t live = alive >= 4 ? ~0ull : ((1ull << (16 * alive)) - 1ull);
 		const int end_here = 16 * alive - 1;
-		const int src_b = wc % n ? wc - 1 : wc + n - 1;
+		const int wcn = SUBL ? wc % n : wc; // wave column within its period (n = nwc without sub-lattices)
+		const int src_b = wcn ? wc - 1 : wc + n - 1;
 		const int end_src = 16 * min(4, p.gx - 4 * src_b) - 1;
 		const uint64_t u_bw = inwave ? first : 0ull, u_fw = inwave ? last : 0ull;
-		const int u_cb = ((wc % n ? wc - 1 : wc + n - 1) - wc) * 64 + word_of(1, 7, 3); // C, in words from this wave's row start
-		const int u_cf = ((wc % n == n - 1 ? wc - n + 1 : wc + 1) - wc) * 64 + word_of(0, 0, 0);
+		const int u_cb = (src_b - wc) * 64 + word_of(1, 7, 3); // C, in words from this wave's row start
+		const int u_cf = ((wcn == n - 1 ? wc - n + 1 : wc + 1) - wc) * 64 + word_of(0, 0, 0);
 		// rows are periodic every slY rows (SUBL; otherwise rows -1 and Y are the halo rows)
 		const int slY = SUBL ? p.slY : 0;
 		const int r0_in_sl = SUBL ? r0 % p.slY : 1;
@@ -276,39 +302,58 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		const uint32_t cx_base = 16u * (2u * it + color);
 		const uint32_t seed_lo_cy = p.seed_lo ^ (uint32_t)((2ull * it + color) >> 28); // see dense_update_k
 
-		if (FUSED && level > 0 && !idle) {
-			// wait until strips s-1, s, s+1 (periodic) have completed level - 1: `nwc` wave columns each per level
-			const uint32_t need = p.done_base + (uint32_t)level * (uint32_t)nwc;
+		// FUSED: wait until strips s-1, s, s+1 (periodic) have completed level - 1, `nwc` wave columns each per level.  The
+		// first look at their counters travels while the block constants are made.
+		const bool must_wait = FUSED && level > 0 && !idle;
+		const uint32_t need = p.done_base + (uint32_t)level * (uint32_t)nwc;
+		const uint32_t *dp = nullptr;
+		uint32_t seen = need;
+		TRC(1); // unit decode
+		if (must_wait) {
 			int sd = sidx + (lane == 0 ? -1 : (lane == 1 ? 0 : 1));
 			sd = sd < 0 ? sd + nstr : (sd >= nstr ? sd - nstr : sd);
-			const uint32_t *dp = p.done + sd;
-			TRC(1); // unit decode
-			[[maybe_unused]] int nsleep = 0;
-			for (;;) { // few, patient polls: every poll is a trip to memory that competes with the lattice traffic
-				const uint32_t v = lane < 3 ? __hip_atomic_load(dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
-				if (__all((int32_t)(v - need) >= 0)) break;
-				TRN(9, 1);
-				TRN(15, nsleep++ == 0);
-				__builtin_amdgcn_s_sleep(32);
-			}
-			TRC(2); // completion counters
+			dp = p.done + sd;
+			// (inline assembly like the row loop's loads: a tracked load here makes the compiler guard `seen`'s register with
+			// vmcnt(0) waits all through the row loop)
+			if (lane < 3) asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(seen) : "v"(dp) : "memory");
 		}
 		if (lane < 16) {
 			const PhiloxBlockConst kc = philox_block_const(cx_base + (uint32_t)lane, p.seed_lo, p.seed_hi);
 			blk_const[lane] = make_uint4(kc.s0, kc.s1, kc.s2, 0u);
 		}
+		if (must_wait) {
+			[[maybe_unused]] int nsleep = 0;
+			for (;;) { // few, patient polls: every poll is a trip to memory that competes with the lattice traffic
+				asm volatile("s_waitcnt vmcnt(0)" : "+v"(seen) :: "memory");
+				if (__all((int32_t)(seen - need) >= 0)) break;
+				TRN(9, 1);
+				TRN(15, nsleep++ == 0);
+				__builtin_amdgcn_s_sleep(32);
+				if (lane < 3) asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(seen) : "v"(dp) : "memory");
+			}
+			TRC(2); // completion counters (+ block constants)
+		}
 		__builtin_amdgcn_wave_barrier();
 		__threadfence_block();
 		uint64_t up = 0, ct = 0;
+		// FUSED: the unit's first two rows as requested here; they enter the row window (up, ct) in the first word phase,
+		// behind that phase's wait -- values loaded by inline assembly must not be loop-carried before they were waited for
+		// (the compiler believes them ready and may copy them early)
+		uint64_t up0 = 0, ct0 = 0;
 		if (!idle) {
-			up = ld_word<FUSED>(rs + lane + ((SUBL && r0_in_sl == 0) ? (ptrdiff_t)(slY - 1) * wpr : -(ptrdiff_t)wpr));
-			ct = ld_word<FUSED>(rs + lane);
+			if (FUSED) {
+				ld64_coh_issue(up0, rs - wpr, lane * 8);
+				ld64_coh_issue(ct0, rs, lane * 8);
+			} else {
+				up = ld_word<false>(rs + lane + ((SUBL && r0_in_sl == 0) ? (ptrdiff_t)(slY - 1) * wpr : -(ptrdiff_t)wpr));
+				ct = ld_word<false>(rs + lane);
+			}
 		}
 
 		// one scalar-cache write-back per workgroup and row: every wave runs the same number of iterations and meets at a barrier
 		const int rmax = Hr;
 		const bool wb_wave = threadIdx.x < 64;
-		const int r_ticket = ISING_FUSED_LOOKAHEAD ? 0 : rmax;
+		const int r_ticket = ISING_FUSED_LOOKAHEAD == 1 ? 0 : rmax;
 		for (int r = 0; r <= rmax; ++r) {
 			// The two words per row whose side neighbours sit in another vector (sites 0 / 31) are assembled on the scalar
 			// unit from three source-colour words of row r0 + r - 1: A0, A1 of this wave's own 64 words, C from the
@@ -322,7 +367,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				const bool back = (color == 0) ? !(grow & 1u) : (grow & 1u);
 				const uint64_t *qc = rs + (back ? u_cb : u_cf);
 				if (FUSED) {
-					vC = ld_word<true>(qc);
+					ld64_coh_issue(vC, qc, 0);
 				} else {
 					const uint64_t *q0 = rs + (back ? word_of(0, 7, 3) : word_of(0, 0, 0));
 					const uint64_t *q1 = rs + (back ? word_of(1, 7, 3) : word_of(1, 0, 0));
@@ -362,11 +407,17 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			}
 			TRC(4); // draw phase
 			if (FUSED && r == r_ticket && wi == 0) { // wave-uniform branch; read by the workgroup after this unit's last barrier
-				if (lane == 0) ticket_sh[(round + 1) & 1] = atomicAdd(p.ticket, 1ull);
+				if (lane == 0) ticket_sh[(round + 1) & 1] = ISING_FUSED_LOOKAHEAD == 0 ? tk_next : atomicAdd(p.ticket, 1ull);
 			}
 			TRC(5); // next ticket
 			asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 			TRC(6); // barrier (scalar stores, write-back of the previous row, the slowest wave)
+			// the next ticket: requested by wave 0 at the end of the unit's second-last word phase, behind everything that
+			// phase waits for (vmcnt counts in order), picked up in the last iteration -- its 2 us pass under the write-back,
+			// the barrier and the top of the last iteration
+			const bool ticket_iter = FUSED && ISING_FUSED_LOOKAHEAD == 0 && r == rmax - 1 && wi == 0;
+			const bool ticket_in_word = ticket_iter && r > 0 && r <= nrows;
+			if (ticket_iter && !ticket_in_word && lane == 0) tk_next = atomicAdd(p.ticket, 1ull);
 			if (r > 0 && r <= nrows) {
 				// ---- word phase, row r0 + r - 1; its masks were written back during the draw phase above
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -378,14 +429,24 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				u32x4 mk;
 				asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(mk) : "v"(lane * 16), "s"(msk) : "memory");
 				const bool sl_last = SUBL && seam == 1; // the row below is the period's first row (:422)
-				const uint64_t dw = ld_word<FUSED>(rs + (sl_last ? (ptrdiff_t)(1 - slY) * wpr : (ptrdiff_t)wpr) + lane); // scalar base + lane offset
-				const uint64_t me = ld_word<FUSED>(rd + lane);
+				uint64_t dw, me;
 				if (FUSED) {
+					ld64_coh_issue(dw, rs + wpr, lane * 8);
+					ld64_coh_issue(me, rd, lane * 8);
+					// everything older than this phase's three loads: the word from the neighbouring wave column, in a unit's
+					// first word phase also its first two rows
+					asm volatile("s_waitcnt vmcnt(3)" : "+v"(vC), "+v"(up0), "+v"(ct0) :: "memory");
+					if (r == 1) { // (a branch taken once per unit, not four selects per row: the empty asm keeps it one)
+						asm volatile("" ::: "memory");
+						up = up0;
+						ct = ct0;
+					}
 					sA0 = readlane64(ct, back ? word_of(0, 7, 3) : word_of(0, 0, 0));
 					sA1 = readlane64(ct, back ? word_of(1, 7, 3) : word_of(1, 0, 0));
-					asm volatile("s_waitcnt vmcnt(2)" : "+v"(vC) :: "memory"); // older than this phase's three loads
 					sC = readlane64(vC, 0);
 				} else {
+					dw = ld_word<false>(rs + (sl_last ? (ptrdiff_t)(1 - slY) * wpr : (ptrdiff_t)wpr) + lane); // scalar base + lane offset
+					me = ld_word<false>(rd + lane);
 					asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sA0), "+s"(sA1), "+s"(sC) :: "memory");
 				}
 				uint64_t w0, w1; // side words of lanes (0,0,0), (1,0,0) [back] / (0,7,3), (1,7,3) [forward]
@@ -414,7 +475,8 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				}
 				uint64_t sd = ((uint64_t)sdh << 32) | sdl;
 				TRC(7); // word phase up to the wait for its loads
-				asm volatile("s_waitcnt vmcnt(0)" : "+v"(mk) :: "memory");
+				if (FUSED) asm volatile("s_waitcnt vmcnt(0)" : "+v"(mk), "+v"(dw), "+v"(me) :: "memory");
+				else asm volatile("s_waitcnt vmcnt(0)" : "+v"(mk) :: "memory");
 				TRC(10); // wait for masks and words
 				const uint64_t c3 = ((uint64_t)mk.y << 32) | mk.x, c4 = ((uint64_t)mk.w << 32) | mk.z;
 				uint64_t nu = up, nc = ct, nd = dw;
@@ -426,11 +488,20 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 					rj += 4 * wpr;
 				}
 				const uint64_t nw = me ^ (flips64(me, nu, nc, nd, sd, c3, c4) & live);
-				if (FUSED || publish) st_word<true>(rd + lane, nw); else st_word<false>(rd + lane, nw);
-				if (p.wrap) { // the halo rows that mirror this colour's edge rows
-					if (lr == 0) st_word<FUSED>(rd + mir0 + lane, nw);
-					if (lr == p.Y - 1) st_word<FUSED>(rd + mirL + lane, nw);
+				if (FUSED) {
+					st64_coh_issue(rd, lane * 8, nw);
+					if (p.wrap) { // the halo rows that mirror this colour's edge rows
+						if (lr == 0) st64_coh_issue(rd + mir0, lane * 8, nw);
+						if (lr == p.Y - 1) st64_coh_issue(rd + mirL, lane * 8, nw);
+					}
+				} else {
+					if (publish) st_word<true>(rd + lane, nw); else st_word<false>(rd + lane, nw);
+					if (p.wrap) {
+						if (lr == 0) st_word<false>(rd + mir0 + lane, nw);
+						if (lr == p.Y - 1) st_word<false>(rd + mirL + lane, nw);
+					}
 				}
+				if (ticket_in_word && lane == 0) tk_next = atomicAdd(p.ticket, 1ull); // (behind this row's stores)
 				rs += wpr;
 				rd += wpr;
 				if (sl_last) { // the next row opens a new period: the register window does not slide across the seam
@@ -451,6 +522,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			if (lane == 0) __hip_atomic_fetch_add(p.edge_signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
+		if (FUSED) tkv = ticket_sh[(round + 1) & 1]; // (on its way while the stores drain)
 		if (FUSED && !idle) {
 			// publish: this wave's stores were written through (sc1); once they have left the wave the strip's counter
 			// may move (every storing wave drains its own stores and signals its own unit)

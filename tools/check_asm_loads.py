@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Build-time check of the fused ballot kernels' hand-waited loads (ising_ballot.hip issues them as inline assembly, so the
+compiler does not know they are in flight): in the generated ISA no instruction may touch a register an inline-assembly
+global_load_dwordx2 / x4 (lattice words, accept masks) wrote before the inline-assembly s_waitcnt vmcnt that covers it.
+The scan is linear in text order, which is program order for the row loop these loads live in (the completion-counter
+poll, a dword load in a spin loop of its own, is waited for right behind its issue and is not part of the scan).
+usage: check_asm_loads.py ising_ballot.s   (hipcc -S --cuda-device-only output)"""
+import re, sys
+
+def regs(tok):
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+def operands(line):
+    out = set()
+    for tok in re.findall(r"v\[\d+:\d+\]|v\d+\b", line):
+        out |= regs(tok)
+    return out
+
+bad = 0
+kern = None
+lines = open(sys.argv[1]).read().split("\n")
+i = 0
+while i < len(lines):
+    ln = lines[i]
+    m = re.match(r"^(_Z\w*ballot_update_k\w*):", ln)
+    if m:
+        kern, pending, nloads = m.group(1), {}, 0
+    if kern and "s_endpgm" in ln:
+        print(f"{kern}: {nloads} inline-assembly loads checked")
+        kern = None
+    if kern:
+        in_asm = i > 0 and "#ASMSTART" in lines[i - 1] or (i > 1 and "#ASMSTART" in lines[i - 2] and "#ASMEND" not in lines[i - 1])
+        body = ln.split(";")[0].strip()
+        if body and not body.endswith(":"):
+            if in_asm and (body.startswith("global_load_dwordx2") or body.startswith("global_load_dwordx4")):
+                dst = regs(body.split()[1].rstrip(","))
+                for r in dst:
+                    pending[r] = i + 1
+                nloads += 1
+                used = operands(body.split(",", 1)[1])  # address operands of the load itself
+            elif in_asm and body.startswith("s_waitcnt") and "vmcnt" in body:
+                n = int(re.search(r"vmcnt\((\d+)\)", body).group(1))
+                if n == 0:
+                    pending.clear()
+                else:  # the n youngest loads may stay out: drop all but the registers of the n most recent loads
+                    order = sorted(set(pending.values()))
+                    keep = set(order[-n:]) if n <= len(order) else set(order)
+                    pending = {r: l for r, l in pending.items() if l in keep}
+                used = set()
+            else:
+                used = operands(body)
+            for r in used & set(pending):
+                print(f"{kern}: line {i + 1} touches v{r}, loaded by inline assembly at line {pending[r]} and not yet waited for: {body}")
+                bad += 1
+    i += 1
+sys.exit(1 if bad else 0)
