@@ -344,11 +344,11 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// workgroups run, or units find their parents unfinished and hold their slots asleep: the strip height H follows
 	// from T = wave rows / (H x waves per workgroup), and small lattices run FEWER workgroups than the chip holds.
 	// Measured (tools/grid_probe.py, grid_probe2.py), flips/ns fused vs one launch per colour + tail strips:
-	//   2^26 (8192^2)    4-wave workgroups, H = 2, 3 per CU (T = 1024)      2375-2405 vs 2080 (dense layout 2160)
-	//   2^27             8-wave workgroups, H = 2, 2 per CU (T = 1024)      2690-2790 vs 2500
-	//   2^28 (16384^2)   4-wave, H = 4, 4 per CU (T = 2048)                 3060 vs 2940-2975
-	//   2^29 ...         4-wave, the tallest H of 16, 8, 4 with T >= 8192 (else 4), 5 per CU (6 from T = 16384):
-	//                    32768^2 3340 vs 3300, 65536 x 32768 3427 vs 3311, 65536^2 3398 vs 3302, 131072^2 3414 vs 3341
+	//   2^26 (8192^2)    4-wave workgroups, H = 2, 3 per CU (T = 1024)      2455 vs 2125 (dense layout 2150)
+	//   2^27             8-wave workgroups, H = 2, 2 per CU (T = 1024)      2908 vs 2580
+	//   2^28 (16384^2)   4-wave, H = 4, 4 per CU (T = 2048)                 3099 vs 3048
+	//   2^29 ...         4-wave, the tallest H of 16, 8, 4 with T >= 8192 (else 4), 5 per CU (6 from T = 16384, 4 below 8192):
+	//                    24576^2 3234 vs 3182, 32768^2 3383 vs 3407, 65536 x 32768 3437 vs 3463, 65536^2 3490-3500 vs 3490-3500 (profiles/policy_probe_r02.txt)
 	// ISING_FUSED=0/1, ISING_FUSED_WIDE=0/1, cfg.strip_rows and ISING_FUSED_WGS (grid) override.
 	const long long spins = (long long)cfg->X * cfg->Y;
 	const bool fused_can = c->wrap && !cfg->XSL;
@@ -371,7 +371,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	c->color_words = (size_t)cfg->Y * c->lld;
 	if (fused_shape) { // workgroups per CU of a fused launch (the chip holds 6 of 4 waves, 3 of 8)
 		const long long T = fused_tickets(c->nwc(), cfg->Y, c->H, c->fused_wide != 0);
-		c->fused_wg_per_cu = c->fused_wide ? (T >= 2048 ? 3 : 2) : (T >= 16384 ? 6 : (T >= 4096 ? 5 : (T >= 2048 ? 4 : 3)));
+		c->fused_wg_per_cu = c->fused_wide ? (T >= 2048 ? 3 : 2) : (T >= 16384 ? 6 : (T >= 8192 ? 5 : (T >= 2048 ? 4 : 3)));
 	}
 
 	hipError_t e = hipSetDevice(cfg->device);
