@@ -94,11 +94,18 @@ __device__ __forceinline__ void st_word(uint64_t *q, uint64_t v) {
 // (vmcnt counts in order).  With compiler-tracked atomic loads / stores in that loop the compiler protected registers of
 // pending operations with s_waitcnt vmcnt(0) at the top of every row -- a wait for the previous row's write-through
 // stores, which have nothing to do with the draw phase that follows.  `base` is wave-uniform, `off` the lane's byte offset.
+// STREAM: the lattice words carry the non-temporal hint, so that a lattice larger than the memory-side cache does not push
+// the accept-mask slots out of the L2s on its way through (65536^2: 0.930 -> 0.889 GB of HBM traffic per colour half-sweep,
+// same speed; a lattice that fits the 256 MB cache is re-read from it every level and must not be marked: -4 % at 2^27).
+template <bool STREAM>
 __device__ __forceinline__ void ld64_coh_issue(uint64_t &v, const uint64_t *base, int off) {
-	asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=&v"(v) : "v"(off), "s"(base) : "memory");
+	if (STREAM) asm volatile("global_load_dwordx2 %0, %1, %2 sc1 nt" : "=&v"(v) : "v"(off), "s"(base) : "memory");
+	else asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=&v"(v) : "v"(off), "s"(base) : "memory");
 }
+template <bool STREAM>
 __device__ __forceinline__ void st64_coh_issue(uint64_t *base, int off, uint64_t v) {
-	asm volatile("global_store_dwordx2 %0, %1, %2 sc1" :: "v"(off), "v"(v), "s"(base) : "memory");
+	if (STREAM) asm volatile("global_store_dwordx2 %0, %1, %2 sc1 nt" :: "v"(off), "v"(v), "s"(base) : "memory");
+	else asm volatile("global_store_dwordx2 %0, %1, %2 sc1" :: "v"(off), "v"(v), "s"(base) : "memory");
 }
 // wave-uniform values the compiler may have left in vector registers (ticket arithmetic): pin them to the scalar unit
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -148,7 +155,7 @@ __device__ unsigned long long g_trace[16];
 #else
 #define BAL_SGPR_ATTR
 #endif
-template <bool SUBL, bool USEJ, bool FUSED, int NT = BAL_THREADS>
+template <bool SUBL, bool USEJ, bool FUSED, int NT = BAL_THREADS, bool STREAM = false>
 __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const UpdateParams p) {
 	const int lane = threadIdx.x & 63;
 	const int tx = threadIdx.x & (GROUP - 1), g = (threadIdx.x >> 4) & 3;
@@ -342,8 +349,8 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		uint64_t up0 = 0, ct0 = 0;
 		if (!idle) {
 			if (FUSED) {
-				ld64_coh_issue(up0, rs - wpr, lane * 8);
-				ld64_coh_issue(ct0, rs, lane * 8);
+				ld64_coh_issue<STREAM>(up0, rs - wpr, lane * 8);
+				ld64_coh_issue<STREAM>(ct0, rs, lane * 8);
 			} else {
 				up = ld_word<false>(rs + lane + ((SUBL && r0_in_sl == 0) ? (ptrdiff_t)(slY - 1) * wpr : -(ptrdiff_t)wpr));
 				ct = ld_word<false>(rs + lane);
@@ -367,7 +374,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				const bool back = (color == 0) ? !(grow & 1u) : (grow & 1u);
 				const uint64_t *qc = rs + (back ? u_cb : u_cf);
 				if (FUSED) {
-					ld64_coh_issue(vC, qc, 0);
+					ld64_coh_issue<STREAM>(vC, qc, 0);
 				} else {
 					const uint64_t *q0 = rs + (back ? word_of(0, 7, 3) : word_of(0, 0, 0));
 					const uint64_t *q1 = rs + (back ? word_of(1, 7, 3) : word_of(1, 0, 0));
@@ -431,8 +438,8 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				const bool sl_last = SUBL && seam == 1; // the row below is the period's first row (:422)
 				uint64_t dw, me;
 				if (FUSED) {
-					ld64_coh_issue(dw, rs + wpr, lane * 8);
-					ld64_coh_issue(me, rd, lane * 8);
+					ld64_coh_issue<STREAM>(dw, rs + wpr, lane * 8);
+					ld64_coh_issue<STREAM>(me, rd, lane * 8);
 					// everything older than this phase's three loads: the word from the neighbouring wave column, in a unit's
 					// first word phase also its first two rows
 					asm volatile("s_waitcnt vmcnt(3)" : "+v"(vC), "+v"(up0), "+v"(ct0) :: "memory");
@@ -489,10 +496,10 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				}
 				const uint64_t nw = me ^ (flips64(me, nu, nc, nd, sd, c3, c4) & live);
 				if (FUSED) {
-					st64_coh_issue(rd, lane * 8, nw);
+					st64_coh_issue<STREAM>(rd, lane * 8, nw);
 					if (p.wrap) { // the halo rows that mirror this colour's edge rows
-						if (lr == 0) st64_coh_issue(rd + mir0, lane * 8, nw);
-						if (lr == p.Y - 1) st64_coh_issue(rd + mirL, lane * 8, nw);
+						if (lr == 0) st64_coh_issue<STREAM>(rd + mir0, lane * 8, nw);
+						if (lr == p.Y - 1) st64_coh_issue<STREAM>(rd + mirL, lane * 8, nw);
 					}
 				} else {
 					if (publish) st_word<true>(rd + lane, nw); else st_word<false>(rd + lane, nw);
@@ -744,14 +751,17 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	const bool usej = fused ? p.jham[0] != nullptr : p.jdst != nullptr;
 	const bool subl = p.slY != 0;
 	const void *fn;
-	const int v = (fused ? 4 : 0) | (subl ? 2 : 0) | (usej ? 1 : 0);
+	const bool streamed = fused && p.nt_stream && NT == BAL_THREADS; // (8-wave workgroups serve lattices that fit the cache)
+	const int v = (streamed ? 6 : (fused ? 4 : 0)) | (subl ? 2 : 0) | (usej ? 1 : 0);
 	switch (v) {
 	case 0: fn = (const void *)ballot_update_k<false, false, false, NT>; break;
 	case 1: fn = (const void *)ballot_update_k<false, true, false, NT>; break;
 	case 2: fn = (const void *)ballot_update_k<true, false, false, NT>; break;
 	case 3: fn = (const void *)ballot_update_k<true, true, false, NT>; break;
 	case 4: fn = (const void *)ballot_update_k<false, false, true, NT>; break;
-	default: fn = (const void *)ballot_update_k<false, true, true, NT>; break;
+	case 5: fn = (const void *)ballot_update_k<false, true, true, NT>; break;
+	case 6: fn = (const void *)ballot_update_k<false, false, true, BAL_THREADS, true>; break;
+	default: fn = (const void *)ballot_update_k<false, true, true, BAL_THREADS, true>; break;
 	}
 	// Plain launches: one workgroup per unit, handed out by the hardware dispatcher (a persistent grid striding over the
 	// units runs all workgroups in lockstep -- every wave in its draw phase, then every wave in its word phase -- and
@@ -781,7 +791,9 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	case 2: hipExtLaunchKernelGGL((ballot_update_k<true, false, false, NT>), g, block, 0, stream, nullptr, stop, 0, p); break;
 	case 3: hipExtLaunchKernelGGL((ballot_update_k<true, true, false, NT>), g, block, 0, stream, nullptr, stop, 0, p); break;
 	case 4: hipExtLaunchKernelGGL((ballot_update_k<false, false, true, NT>), g, block, 0, stream, nullptr, stop, 0, p); break;
-	default: hipExtLaunchKernelGGL((ballot_update_k<false, true, true, NT>), g, block, 0, stream, nullptr, stop, 0, p); break;
+	case 5: hipExtLaunchKernelGGL((ballot_update_k<false, true, true, NT>), g, block, 0, stream, nullptr, stop, 0, p); break;
+	case 6: hipExtLaunchKernelGGL((ballot_update_k<false, false, true, BAL_THREADS, true>), g, block, 0, stream, nullptr, stop, 0, p); break;
+	default: hipExtLaunchKernelGGL((ballot_update_k<false, true, true, BAL_THREADS, true>), g, block, 0, stream, nullptr, stop, 0, p); break;
 	}
 	if (grid_out) *grid_out = (int)grid;
 	return hipGetLastError();

@@ -369,6 +369,10 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (cfg->Y % c->H) { const int h = c->H; delete c; return fail(ISING_E_ARG, "strip_rows %d does not divide Y %d", h, cfg->Y); }
 	c->nstrips = cfg->Y / c->H;
 	c->color_words = (size_t)cfg->Y * c->lld;
+	// lattices larger than the memory-side cache (256 MB = 2^31 spins at 1 bit per spin) stream through it: their words
+	// carry the non-temporal hint, which keeps the accept-mask slots in the L2s (ISING_FUSED_NT=0/1 overrides)
+	if (const char *e = getenv("ISING_FUSED_NT")) c->fused_nt = atoi(e) != 0;
+	else c->fused_nt = spins > (1LL << 31);
 	if (fused_shape) { // workgroups per CU of a fused launch (the chip holds 6 of 4 waves, 3 of 8)
 		const long long T = fused_tickets(c->nwc(), cfg->Y, c->H, c->fused_wide != 0);
 		c->fused_wg_per_cu = c->fused_wide ? (T >= 2048 ? 3 : 2) : (T >= 16384 ? 6 : (T >= 8192 ? 5 : (T >= 2048 ? 4 : 3)));
@@ -594,6 +598,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			p.done = c->d_slotctl + SLOTCTL_TICKET_BYTES / 4;
 			p.wide = c->fused_wide;
 			p.wg_per_cu = c->fused_wg_per_cu;
+			p.nt_stream = c->fused_nt;
 			p.done_base = c->done_base;
 		}
 		if (publish) {

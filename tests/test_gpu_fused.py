@@ -1,6 +1,6 @@
 """The fused launch form of the ballot kernel (ising_sweep: several colour half-sweeps per launch, in-order tickets,
 per-strip completion counters, write-through hand-over between workgroups -- csrc/ising_ballot.hip).  By default only
-lattices from 32768^2 up take it (tests/test_gpu_fullsize.py, the 65536^2 README runs); here it is forced on smaller
+lattices from 2^26 spins up take it (tests/test_gpu_fullsize.py, the 65536^2 README runs); here it is forced on smaller
 ones (ISING_FUSED=1 is read when a slab is created) so that every seam of it is compared with the oracle word for word:
 strip order from both ends, periodic wrap through the mirror rows, launches of 1 .. 32 sweeps and the cuts between them,
 one wave column (X = 8192, four strips per workgroup) and several, partly empty workgroups, -J, temperature changes
@@ -40,6 +40,25 @@ def test_fused_matches_oracle_state(gpu, oracle_mod, fused, X, Y, strip):
             orc.sweep(n)
             assert _same(s, orc), (X, Y, s.it)
             assert s.count() == orc.count() and s.bond_equal() == orc.bond_equal()
+
+
+@pytest.mark.parametrize("J", [0.0, 0.3])
+def test_fused_streaming_variant_matches_oracle(gpu, oracle_mod, fused, monkeypatch, J):
+    """Lattices larger than the memory-side cache mark their lattice words non-temporal (a kernel instantiation of its
+    own, ISING_FUSED_NT forces it): same results."""
+    monkeypatch.setenv("ISING_FUSED_NT", "1")
+    X, Y, seed = 16384, 160, 77
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=ig.CRIT_TEMP_F32).init()
+    with ig.IsingSlab(X, Y, seed=seed, temp=ig.CRIT_TEMP_F32, layout=ig.LAYOUT_BALLOT, strip_rows=4, J_prob=J) as s:
+        s.init()
+        if J:
+            orc.init_couplings(J)
+            s.init_couplings()
+        assert s.fused
+        for n in (1, 3, 5):
+            s.sweep(n)
+            orc.sweep(n)
+            assert _same(s, orc) and s.count() == orc.count() and s.bond_equal() == orc.bond_equal()
 
 
 def test_fused_batches_of_32_sweeps_and_the_cut_between_them(gpu, oracle_mod, fused):
