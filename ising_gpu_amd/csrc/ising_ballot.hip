@@ -819,8 +819,8 @@ hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_o
 	if (p.nunits <= 0) return stop ? hipEventRecord(stop, stream) : hipSuccess;
 	if (p.nlevels < 1) p.nlevels = 1;
 	if (p.nlevels > 1 && p.slY != 0) return hipErrorInvalidValue; // a sub-lattice seam reaches beyond the neighbouring strips
-	// A/B (ISING_FUSED_WIDE=1): 8-wave workgroups for fused launches -- half the tickets per row of work; +10 % at 8192^2,
-	// +2 % at 16384^2, -4 % at 65536^2 against 4-wave workgroups
+	// 8-wave workgroups for fused launches (ising_create: lattices of ~2^27 spins; ISING_FUSED_WIDE=0/1): half the tickets
+	// per row of work
 	if (p.nlevels > 1 && p.wide) return launch_ballot_update_nt<512>(p, stream, grid_out, stop);
 	return launch_ballot_update_nt<BAL_THREADS>(p, stream, grid_out, stop);
 }
