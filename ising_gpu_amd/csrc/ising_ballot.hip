@@ -125,7 +125,7 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 // ticket waits for has a lower number, so the lowest unfinished ticket is always being worked on by a running
 // workgroup: no deadlock whatever the residency or whatever else runs on the chip.  The accept-mask slots belong to the
 // workgroup SLOT (blockIdx): ~12 MB that stay in the L2s, where a plain launch of 65536^2 spreads 134 MB of slots that
-// spill to HBM (0.95 vs 1.14 GB of traffic per colour half-sweep, free of charge under a saturated vector ALU but traffic
+// spill to HBM (0.89 vs 1.14 GB of traffic per colour half-sweep, free of charge under a saturated vector ALU but traffic
 // all the same).  The chip never drains between colours.  A unit's parents are one level of tickets back: the host picks
 // strip height and grid size so that they are done when the unit starts (ising_create); from 2^26 spins up
 // this form is what ising_sweep launches.
@@ -134,8 +134,9 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 // the wait and brings back a third of the sleeping polls: no gain (16384^2: 1.1 M -> 2.8 M polls that slept).  1: during
 // a unit's FIRST row, the form this kernel had first: a ticket drawn a unit ahead sits reserved while its workgroup
 // finishes the current unit and later tickets start before it, so units of the next level find their parents unfinished.
-// Measured (tools/trace_probe.py, `make variant DEFS=-DISING_FUSED_LOOKAHEAD=1`): 65536^2, H = 16: 1.5 M polls that
-// slept per 2.1 M units -> none with 2; 16384^2, H = 4: 7.1 M -> 1.1 M, 2880 -> 3000 flips/ns (trace builds).
+// Measured (tools/trace_probe.py, `make variant DEFS=-DISING_FUSED_LOOKAHEAD=1`, profiles/fused_trace_r02.txt): 65536^2,
+// H = 16: 11.6 M polls that slept per 2.1 M units -> none with 2, 3381 -> 3472 flips/ns; 16384^2, H = 4: 9.6 M -> 3.4 M,
+// 2916 -> 3049 (trace builds).
 #ifndef ISING_FUSED_LOOKAHEAD
 #define ISING_FUSED_LOOKAHEAD 2
 #endif
