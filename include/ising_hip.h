@@ -127,6 +127,11 @@ int ising_destroy(ising_ctx *ctx);
 /* Use an externally created hipStream_t (e.g. torch's current stream) for all subsequent work.  Call it on an idle
  * context (ising_synchronize first): work already enqueued is not re-ordered behind the new stream. */
 int ising_set_stream(ising_ctx *ctx, void *hip_stream);
+/* Gives the context a non-blocking stream of its own (created here, destroyed with the context).  Contexts share the
+ * device's default stream otherwise and their launches serialise; independent lattices on one GPU (replicas at other
+ * temperatures: cuIsing --tsweep) run side by side on private streams -- a lattice of 8192^2 fills 70 % of the chip, two
+ * or three of them 90 %.  (New: the reference runs one lattice per process, optimized/main.cu:1596-1598.) */
+int ising_use_private_stream(ising_ctx *ctx);
 /* Blocks until all work enqueued by this context has finished (cudaDeviceSynchronize, optimized/main.cu:1751-1754). */
 int ising_synchronize(ising_ctx *ctx);
 
@@ -204,6 +209,13 @@ int ising_write_bits(ising_ctx *ctx, int color, int64_t row0, int64_t nrows, con
  * consumers: nibble layout = [Y][X/32] 64-bit words exactly as the reference's buffers; dense = [Y][X/64] 32-bit words;
  * ballot = [Y][64 * ceil(X/8192)] 64-bit words in the bit order described in ising_ballot.hip. */
 int ising_device_ptr(ising_ctx *ctx, int color, void **ptr, size_t *bytes);
+/* Asynchronous measurement: enqueues the up count (ising_count) and the bond sum (ising_bond_equal) of the state the
+ * context's stream holds at this point; nothing waits.  ising_measure_fetch waits for the stream and hands back all pending
+ * results in enqueue order (at most 4096 may be pending).  A (sweeps, measurement) series then runs without a host round
+ * trip in between -- the reference reads its counters back at every print point (optimized/main.cu:1806-1810). */
+int ising_measure_enqueue(ising_ctx *ctx);
+int ising_measure_fetch(ising_ctx *ctx, uint64_t *up, int64_t *bond_equal, int max_n, int *n);
+
 /* The layout in use right now (ISING_LAYOUT_NIBBLE, _DENSE or _BALLOT). */
 int ising_layout(ising_ctx *ctx, int *layout);
 

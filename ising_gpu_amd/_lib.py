@@ -97,6 +97,9 @@ PROTOTYPES = {
     "ising_rank_bond_equal": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ising_ring_exchange": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "ising_ring_sweep": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
+    "ising_use_private_stream": (C.c_int, [C.c_void_p]),
+    "ising_measure_enqueue": (C.c_int, [C.c_void_p]),
+    "ising_measure_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int)]),
     "ising_ring_synchronize": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "ising_correlations": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
     "ising_ring_correlations": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_int64)]),

@@ -8,7 +8,8 @@
 //            -c/--corr (two-point correlations file, optimized/main.cu:1072-1138).
 //            -J <PROB> (random anti-ferromagnetic bonds, optimized/main.cu:153-331, :575-618).
 // Build-side additions: --tsweep T0,T1,dT[,nequil[,nmeas[,stride]]] (temperature-sweep driver with <|m|>, <m^2>,
-//            susceptibility, Binder cumulant, energy and specific heat per point; --tsweep-anneal, --tsweep-out PREFIX),
+//            susceptibility, Binder cumulant, energy and specific heat per point; --tsweep-anneal, --tsweep-out PREFIX,
+//            --tsweep-replicas K: K temperature points side by side on one GPU, 0 = by lattice size),
 //            --checkpoint FILE / --resume FILE (binary checkpoint, ising_ring_checkpoint_*), --transport copy|rccl.
 #include "../../include/ising_hip.h"
 
@@ -114,6 +115,7 @@ struct TsweepSpec {
 	int nequil = 16, nmeas = 16, stride = 1;
 	bool anneal = false;
 	const char *out = nullptr;
+	int replicas = 0; // temperature points simulated side by side (fresh-start mode, one device); 0 = by lattice size
 };
 
 std::string i128_str(__int128 v) {
@@ -136,11 +138,21 @@ struct Moments {
 	}
 };
 
-int run_tsweep(Ring &ring, const TsweepSpec &ts, size_t nspins, bool useJ) {
+// Fresh-start mode on one device simulates several temperature points side by side: one context per replica, each on a
+// stream of its own (ising_use_private_stream), launches interleaved 32 sweeps at a time.  A lattice of 8192^2 alone
+// fills 70 % of an MI355X, two or three of them 90 %; and while the host reads one replica's counts the
+// others keep the GPU busy.  Every point's series is what a run of its own gives (tests/test_gpu_tsweep_ckpt.py).
+int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_t nspins, bool useJ) {
 	const int ndev = ring.n();
 	const int npts = (int)floor((ts.t1 - ts.t0) / ts.dt + 1e-9) + 1;
+	int nrep = 1;
+	if (ndev == 1 && !ts.anneal) {
+		nrep = ts.replicas > 0 ? ts.replicas : (nspins < (1ull << 29) ? 2 : 1); // (measured: 8192^2 x 31 points 2.16 s alone, 1.73 s with 2, 1.78 s with 3)
+		nrep = std::max(1, std::min(nrep, npts));
+	}
 	printf("\nTemperature sweep: %d points, T = %f .. %f step %f, %d equilibration + %d x %d measurement sweeps per point, %s\n",
 	       npts, ts.t0, ts.t0 + (npts - 1) * ts.dt, ts.dt, ts.nequil, ts.nmeas, ts.stride, ts.anneal ? "annealing" : "fresh start per point");
+	if (nrep > 1) fprintf(stderr, "temperature sweep: %d points side by side, one stream each\n", nrep);
 	FILE *fcsv = nullptr, *fser = nullptr;
 	if (ts.out) {
 		fcsv = fopen((std::string(ts.out) + ".csv").c_str(), "w");
@@ -149,51 +161,107 @@ int run_tsweep(Ring &ring, const TsweepSpec &ts, size_t nspins, bool useJ) {
 		fprintf(fcsv, "temp_bits,temp,nmeas,first_iter,last_iter,sum_M,sum_absM,sum_M2,sum_M4,sum_E,sum_E2,m_abs,m2,chi,U4,e,Cv\n");
 		fprintf(fser, "temp_bits,iter,up,down,bond_equal\n");
 	}
+	// replica r > 0: a context of its own with the same configuration
+	std::vector<Ring> reps(nrep);
+	reps[0] = ring;
+	for (int r = 1; r < nrep; r++) {
+		ising_ctx *c = nullptr;
+		CHECK(ising_create(&base, &c));
+		reps[r].ctx.push_back(c);
+	}
+	if (nrep > 1)
+		for (Ring &rp : reps) CHECK(ising_use_private_stream(rp.ctx[0]));
+	std::vector<bool> have_J(nrep, false);
+	struct SeriesRow { int it; unsigned long long up, dw; long long A; };
 	const long double N = (long double)nspins;
 	long long total_sweeps = 0;
 	int it = 0;
 	const auto t0 = std::chrono::steady_clock::now();
-	for (int k = 0; k < npts; k++) {
-		const float temp = (float)(ts.t0 + k * ts.dt);
-		uint32_t tbits;
-		memcpy(&tbits, &temp, 4);
-		for (ising_ctx *c : ring.ctx) CHECK(ising_set_temperature(c, temp));
-		if (!ts.anneal || k == 0) {
-			for (ising_ctx *c : ring.ctx) CHECK(ising_init_lattice(c));
-			CHECK(ising_ring_exchange(ring.ctx.data(), ndev, ISING_BLACK));
-			CHECK(ising_ring_exchange(ring.ctx.data(), ndev, ISING_WHITE));
-			if (useJ && k == 0) CHECK(ising_ring_init_couplings(ring.ctx.data(), ndev));
-			it = 0;
+	for (int k0 = 0; k0 < npts; k0 += nrep) {
+		const int nb = std::min(nrep, npts - k0);
+		std::vector<float> temps(nb);
+		for (int j = 0; j < nb; j++) {
+			temps[j] = (float)(ts.t0 + (k0 + j) * ts.dt);
+			Ring &rp = reps[j];
+			for (ising_ctx *c : rp.ctx) CHECK(ising_set_temperature(c, temps[j]));
+			if (!ts.anneal || k0 == 0) {
+				for (ising_ctx *c : rp.ctx) CHECK(ising_init_lattice(c));
+				CHECK(ising_ring_exchange(rp.ctx.data(), rp.n(), ISING_BLACK));
+				CHECK(ising_ring_exchange(rp.ctx.data(), rp.n(), ISING_WHITE));
+				if (useJ && !have_J[j]) { CHECK(ising_ring_init_couplings(rp.ctx.data(), rp.n())); have_J[j] = true; }
+				it = 0;
+			}
 		}
-		if (ts.nequil) CHECK(ising_ring_sweep(ring.ctx.data(), ndev, it + 1, ts.nequil));
+		// equilibration, 32 sweeps (one fused launch) per replica at a time so that the replicas' launches alternate
+		for (int done = 0; done < ts.nequil;) {
+			const int n = nb > 1 ? std::min(32, ts.nequil - done) : ts.nequil - done;
+			for (int j = 0; j < nb; j++) CHECK(ising_ring_sweep(reps[j].ctx.data(), reps[j].n(), it + done + 1, n));
+			done += n;
+		}
 		it += ts.nequil;
-		Moments mo;
+		std::vector<Moments> mo(nb);
+		std::vector<std::vector<SeriesRow>> rows(nb);
 		const int first = it + ts.stride;
+		// One device: measurements are enqueued behind their sweeps (ising_measure_enqueue) and read back in one go, so the
+		// whole series of a point runs without a host round trip.  A ring of slabs reads its counters at every point.
+		const bool async = ndev == 1;
+		const int it_meas0 = it;
+		auto take = [&](int j, int iter, unsigned long long up, long long A) {
+			const unsigned long long dw = (unsigned long long)nspins - up;
+			mo[j].add((long long)up - (long long)dw, 2 * (long long)nspins - 2 * A);
+			if (fser) rows[j].push_back({iter, up, dw, A});
+		};
+		std::vector<int> fetched(nb, 0);
+		auto fetch = [&](int j) {
+			std::vector<uint64_t> ups(4096);
+			std::vector<int64_t> As(4096);
+			int n = 0;
+			CHECK(ising_measure_fetch(reps[j].ctx[0], ups.data(), As.data(), 4096, &n));
+			for (int i = 0; i < n; i++, fetched[j]++) take(j, it_meas0 + (fetched[j] + 1) * ts.stride, ups[i], As[i]);
+		};
 		for (int m = 0; m < ts.nmeas; m++) {
-			CHECK(ising_ring_sweep(ring.ctx.data(), ndev, it + 1, ts.stride));
+			for (int j = 0; j < nb; j++) {
+				CHECK(ising_ring_sweep(reps[j].ctx.data(), reps[j].n(), it + 1, ts.stride));
+				if (async) CHECK(ising_measure_enqueue(reps[j].ctx[0]));
+			}
 			it += ts.stride;
-			unsigned long long up = 0, dw = 0;
-			ring.count(&up, &dw);
-			const long long A = ring.bond_equal();
-			mo.add((long long)up - (long long)dw, 2 * (long long)nspins - 2 * A);
-			if (fser) fprintf(fser, "%u,%d,%llu,%llu,%lld\n", tbits, it, up, dw, A);
+			for (int j = 0; j < nb; j++) {
+				if (async) {
+					if ((m + 1) % 4096 == 0) fetch(j);
+				} else {
+					unsigned long long up = 0, dw = 0;
+					reps[j].count(&up, &dw);
+					take(j, it, up, reps[j].bond_equal());
+				}
+			}
 		}
-		total_sweeps += ts.nequil + (long long)ts.nmeas * ts.stride;
-		const long double n = mo.n;
-		const long double mabs = (long double)mo.sAbsM / (n * N), m2 = (long double)mo.sM2 / (n * N * N), m4 = mo.sM4 / (n * N * N * N * N);
-		const long double e1 = (long double)mo.sE / (n * N), e2 = (long double)mo.sE2 / (n * N * N);
-		const long double chi = N * (m2 - mabs * mabs) / temp, u4 = 1.0L - m4 / (3.0L * m2 * m2), cv = N * (e2 - e1 * e1) / ((long double)temp * temp);
-		printf("T = %f: <|m|> = %9.6f, <m^2> = %E, chi = %E, U4 = %9.6f, <e> = %9.6f, Cv = %E (iters %d-%d)\n", temp, (double)mabs, (double)m2,
-		       (double)chi, (double)u4, (double)e1, (double)cv, first, it);
-		if (fcsv)
-			fprintf(fcsv, "%u,%.9g,%d,%d,%d,%s,%s,%s,%.21Lg,%s,%s,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g\n", tbits, (double)temp, mo.n, first, it,
-			        i128_str(mo.sM).c_str(), i128_str(mo.sAbsM).c_str(), i128_str(mo.sM2).c_str(), mo.sM4, i128_str(mo.sE).c_str(),
-			        i128_str(mo.sE2).c_str(), (double)mabs, (double)m2, (double)chi, (double)u4, (double)e1, (double)cv);
+		if (async)
+			for (int j = 0; j < nb; j++) fetch(j);
+		for (int j = 0; j < nb; j++) {
+			const float temp = temps[j];
+			uint32_t tbits;
+			memcpy(&tbits, &temp, 4);
+			if (fser)
+				for (const SeriesRow &r : rows[j]) fprintf(fser, "%u,%d,%llu,%llu,%lld\n", tbits, r.it, r.up, r.dw, r.A);
+			total_sweeps += ts.nequil + (long long)ts.nmeas * ts.stride;
+			const Moments &q = mo[j];
+			const long double n = q.n;
+			const long double mabs = (long double)q.sAbsM / (n * N), m2 = (long double)q.sM2 / (n * N * N), m4 = q.sM4 / (n * N * N * N * N);
+			const long double e1 = (long double)q.sE / (n * N), e2 = (long double)q.sE2 / (n * N * N);
+			const long double chi = N * (m2 - mabs * mabs) / temp, u4 = 1.0L - m4 / (3.0L * m2 * m2), cv = N * (e2 - e1 * e1) / ((long double)temp * temp);
+			printf("T = %f: <|m|> = %9.6f, <m^2> = %E, chi = %E, U4 = %9.6f, <e> = %9.6f, Cv = %E (iters %d-%d)\n", temp, (double)mabs, (double)m2,
+			       (double)chi, (double)u4, (double)e1, (double)cv, first, it);
+			if (fcsv)
+				fprintf(fcsv, "%u,%.9g,%d,%d,%d,%s,%s,%s,%.21Lg,%s,%s,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g\n", tbits, (double)temp, q.n, first, it,
+				        i128_str(q.sM).c_str(), i128_str(q.sAbsM).c_str(), i128_str(q.sM2).c_str(), q.sM4, i128_str(q.sE).c_str(),
+				        i128_str(q.sE2).c_str(), (double)mabs, (double)m2, (double)chi, (double)u4, (double)e1, (double)cv);
+		}
 	}
-	CHECK(ising_ring_synchronize(ring.ctx.data(), ndev));
+	for (Ring &rp : reps) CHECK(ising_ring_synchronize(rp.ctx.data(), rp.n()));
 	const double et = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	if (fcsv) fclose(fcsv);
 	if (fser) fclose(fser);
+	for (int r = 1; r < nrep; r++) ising_destroy(reps[r].ctx[0]);
 	printf("\nTemperature sweep: %lld update steps in %E ms, %.2lf flips/ns (initialisation and measurements included)\n\n", total_sweeps, et,
 	       (double)nspins * (double)total_sweeps / (et * 1.0E+6));
 	return 0;
@@ -228,7 +296,8 @@ int main(int argc, char **argv) {
 	    {"ysl", required_argument, 0, 2},      {"help", required_argument, 0, 'h'},  {"energy", no_argument, 0, 3},
 	    {"devmap", required_argument, 0, 4},   {"layout", required_argument, 0, 5},  {"tsweep", required_argument, 0, 6},
 	    {"tsweep-anneal", no_argument, 0, 7},  {"tsweep-out", required_argument, 0, 8}, {"checkpoint", required_argument, 0, 9},
-	    {"resume", required_argument, 0, 10},  {"transport", required_argument, 0, 11}, {0, 0, 0, 0}};
+	    {"resume", required_argument, 0, 10},  {"transport", required_argument, 0, 11}, {"tsweep-replicas", required_argument, 0, 12},
+	    {0, 0, 0, 0}};
 	while (1) {
 		int option_index = 0;
 		const int och = getopt_long(argc, argv, "x:y:n:ohs:d:a:t:p:u:m:ecJ:r:", long_options, &option_index);
@@ -298,6 +367,10 @@ int main(int argc, char **argv) {
 			else if (!strcmp(optarg, "rccl")) transport = ISING_TRANSPORT_RCCL;
 			else if (!strcmp(optarg, "auto")) transport = ISING_TRANSPORT_AUTO;
 			else { fprintf(stderr, "error: --transport takes copy, rccl or auto\n"); exit(EXIT_FAILURE); }
+			break;
+		case 12:
+			ts.replicas = atoi(optarg);
+			if (ts.replicas < 0 || ts.replicas > 64) { fprintf(stderr, "error: --tsweep-replicas takes 0 (by lattice size) .. 64\n"); exit(EXIT_FAILURE); }
 			break;
 		case '?': exit(EXIT_FAILURE);
 		default: fprintf(stderr, "unknown option: %c\n", och); exit(EXIT_FAILURE);
@@ -406,6 +479,8 @@ int main(int argc, char **argv) {
 	printf("\tmemory: %.2lf MB (%.2lf MB per GPU)\n", (llen * 8) / (1024.0 * 1024.0), llenLoc * 2 * 8 / (1024.0 * 1024.0));
 
 	Ring ring;
+	ising_config cfg0; // (slab 0's configuration: --tsweep creates its replicas from it)
+	memset(&cfg0, 0, sizeof(cfg0));
 	if (ndev > 1) { printf("\nSetting up multi-gpu configuration:\n"); fflush(stdout); }
 	for (int i = 0; i < ndev; i++) {
 		ising_config cfg;
@@ -417,6 +492,7 @@ int main(int argc, char **argv) {
 		ising_ctx *c = nullptr;
 		CHECK(ising_create(&cfg, &c));
 		ring.ctx.push_back(c);
+		if (i == 0) cfg0 = cfg;
 		if (ndev > 1) { printf("\tGPU %2d done\n", i); fflush(stdout); }
 	}
 
@@ -428,7 +504,7 @@ int main(int argc, char **argv) {
 	if (transport != ISING_TRANSPORT_AUTO) CHECK(ising_ring_set_transport(ring.ctx.data(), ndev, transport));
 	const size_t nspins = llen * SPIN_X_WORD;
 	if (doTsweep) {
-		run_tsweep(ring, ts, nspins, useGenHamilt);
+		run_tsweep(ring, cfg0, ts, nspins, useGenHamilt);
 		for (ising_ctx *c : ring.ctx) ising_destroy(c);
 		return 0;
 	}

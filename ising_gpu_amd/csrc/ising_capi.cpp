@@ -442,6 +442,8 @@ int ising_destroy(ising_ctx *c) {
 #endif
 	if (!c) return ISING_OK;
 	(void)hipSetDevice(c->cfg.device);
+	if (c->own_stream) { (void)hipStreamSynchronize(c->own_stream); (void)hipStreamDestroy(c->own_stream); }
+	if (c->h_meas) (void)hipHostFree(c->h_meas);
 	ising_host::ring_release(c);
 	if (c->d_lat && !c->cfg.lattice_mem) (void)hipFree(c->d_lat);
 	if (c->d_acc) (void)hipFree(c->d_acc);
@@ -461,6 +463,16 @@ int ising_destroy(ising_ctx *c) {
 int ising_set_stream(ising_ctx *c, void *hip_stream) {
 	if (!c) return fail(ISING_E_ARG, "null context");
 	c->stream = static_cast<hipStream_t>(hip_stream);
+	return ISING_OK;
+}
+
+int ising_use_private_stream(ising_ctx *c) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (c->own_stream) { c->stream = c->own_stream; return ISING_OK; }
+	if (int rc = bind(c)) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream)); // nothing of this context may still run on the stream it leaves
+	HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+	c->stream = c->own_stream;
 	return ISING_OK;
 }
 
@@ -744,6 +756,48 @@ int ising_bond_equal(ising_ctx *c, int64_t *A) {
 	HIP_TRY(hipMemcpyAsync(&h, c->d_acc + 1, sizeof(h), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	*A = (int64_t)h;
+	return ISING_OK;
+}
+
+// Asynchronous measurements: count + bond sum of the state the stream holds at this point, into a pinned host array the
+// context owns; nothing waits until ising_measure_fetch.  A series of (sweeps, measurement) pairs then runs without a
+// single host round trip in between (cuIsing --tsweep: 100 measurements per temperature point).
+int ising_measure_enqueue(ising_ctx *c) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (int rc = bind(c)) return rc;
+	if (!c->h_meas) HIP_TRY(hipHostMalloc((void **)&c->h_meas, (size_t)ising_ctx::MEAS_CAP * 2 * sizeof(unsigned long long), hipHostMallocDefault));
+	if (c->meas_pending >= ising_ctx::MEAS_CAP) return fail(ISING_E_STATE, "%d measurements pending: ising_measure_fetch first", c->meas_pending);
+	if (int rc = ising_host::halo_ready(c, ISING_WHITE)) return rc;
+	HIP_TRY(hipMemsetAsync(c->d_acc, 0, 2 * sizeof(unsigned long long), c->stream));
+	HIP_TRY(ising::launch_popcount(c->lat(ISING_BLACK), c->color_words, c->d_acc, c->stream));
+	HIP_TRY(ising::launch_popcount(c->lat(ISING_WHITE), c->color_words, c->d_acc, c->stream));
+	if (c->ballot) if (int rc = ising_host::ballot_image(c)) return rc;
+	ising::BondParams p{};
+	p.black = c->ballot ? c->tmp(ISING_BLACK) : c->lat(ISING_BLACK);
+	p.white = c->ballot ? c->tmp(ISING_WHITE) : c->lat(ISING_WHITE);
+	p.gx = c->gx;
+	p.Y = c->cfg.Y;
+	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
+	p.slV = c->cfg.XSL ? c->cfg.XSL / 64 : c->gx * 32;
+	p.slY = c->cfg.XSL ? c->cfg.YSL : 0;
+	p.acc = c->d_acc + 1;
+	HIP_TRY(c->dense ? ising::launch_dense_bond_equal(p, c->stream) : ising::launch_bond_equal(p, c->stream));
+	HIP_TRY(hipMemcpyAsync(c->h_meas + 2 * (size_t)c->meas_pending, c->d_acc, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+	c->meas_pending++;
+	return ISING_OK;
+}
+
+int ising_measure_fetch(ising_ctx *c, uint64_t *up, int64_t *bond_equal, int max_n, int *n) {
+	if (!c || !up || !bond_equal || !n || max_n < 0) return fail(ISING_E_ARG, "bad argument");
+	if (int rc = bind(c)) return rc;
+	if (c->meas_pending > max_n) return fail(ISING_E_ARG, "%d measurements pending, room for %d", c->meas_pending, max_n);
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	for (int i = 0; i < c->meas_pending; i++) {
+		up[i] = c->h_meas[2 * i];
+		bond_equal[i] = (int64_t)c->h_meas[2 * i + 1];
+	}
+	*n = c->meas_pending;
+	c->meas_pending = 0;
 	return ISING_OK;
 }
 

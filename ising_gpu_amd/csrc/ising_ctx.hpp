@@ -47,6 +47,10 @@ struct ising_ctx {
 	uint64_t thr[5]{};
 	bool fast_ok = false;
 	hipStream_t stream = nullptr;
+	hipStream_t own_stream = nullptr; // created by ising_use_private_stream, destroyed with the context
+	static constexpr int MEAS_CAP = 4096;
+	unsigned long long *h_meas = nullptr; // pinned: (up count, bond sum) of the measurements enqueued and not yet fetched
+	int meas_pending = 0;
 
 	// ---- ring state (ising_ring.cpp).  The halo rows of colour c travel on `comm`, a second stream per slab:
 	//   compute: [wait: halo rows of 1-c have arrived] edge rows of c -> record ev_edge[c] -> interior rows of c

@@ -71,6 +71,24 @@ class IsingSlab:
     def set_stream(self, hip_stream: int):
         check(self._lib.ising_set_stream(self._h, C.c_void_p(hip_stream)))
 
+    def measure_enqueue(self):
+        """Enqueue (up count, bond sum) of the state at this point of the stream; nothing waits (measure_fetch does)."""
+        check(self._lib.ising_measure_enqueue(self._h))
+        return self
+
+    def measure_fetch(self):
+        """Wait for the stream; [(up, down, bond_equal), ...] of all measurements enqueued since the last fetch."""
+        cap = 4096
+        up, bond, n = (C.c_uint64 * cap)(), (C.c_int64 * cap)(), C.c_int()
+        check(self._lib.ising_measure_fetch(self._h, up, bond, cap, C.byref(n)))
+        tot = self.X * self.Y
+        return [(int(up[i]), tot - int(up[i]), int(bond[i])) for i in range(n.value)]
+
+    def use_private_stream(self):
+        """A non-blocking stream of this slab's own: independent slabs on one GPU then run side by side."""
+        check(self._lib.ising_use_private_stream(self._h))
+        return self
+
     def synchronize(self):
         check(self._lib.ising_synchronize(self._h))
 

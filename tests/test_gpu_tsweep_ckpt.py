@@ -62,6 +62,49 @@ def test_tsweep_config5_against_oracle_series(gpu, tmp_path):
     assert es[0] < es[-1] < 0
 
 
+@pytest.mark.parametrize("extra", [["--tsweep-replicas", "1"], ["--tsweep-replicas", "4"], ["-J", "0.25"]])
+def test_tsweep_replicas_give_every_point_the_series_of_a_run_of_its_own(gpu, tmp_path, extra):
+    """Fresh-start mode simulates several temperature points side by side (one context and stream per replica); the
+    transcript and both CSV files must not depend on how many (default here: 3 at this size)."""
+    args = ["-x", 8192, "-y", 512, "-s", 99, "--tsweep", "1.8,2.7,0.1,33,3,5"]
+    ref = run(args + ["--tsweep-out", "a"], cwd=tmp_path)
+    if extra[0] == "-J":
+        args += extra
+        ref = run(args + ["--tsweep-replicas", "1", "--tsweep-out", "a"], cwd=tmp_path)
+        got = run(args + ["--tsweep-replicas", "3", "--tsweep-out", "b"], cwd=tmp_path)
+    else:
+        got = run(args + extra + ["--tsweep-out", "b"], cwd=tmp_path)
+    pick = lambda out: [ln for ln in out.splitlines() if ln.startswith("T = ")]
+    assert len(pick(ref)) == 10 and pick(got) == pick(ref)
+    for ext in (".csv", ".series.csv"):
+        assert open(tmp_path / ("a" + ext)).read() == open(tmp_path / ("b" + ext)).read()
+
+
+@pytest.mark.parametrize("layout", [ig.LAYOUT_BALLOT, ig.LAYOUT_DENSE])
+def test_enqueued_measurements_equal_count_and_bond_sum(gpu, layout):
+    """ising_measure_enqueue / _fetch (what --tsweep reads its series with): same integers as the blocking calls, for
+    slabs side by side on private streams."""
+    slabs = [ig.IsingSlab(8192, 96, seed=5 + k, temp=2.0 + 0.2 * k, layout=layout).use_private_stream().init() for k in range(3)]
+    try:
+        want = [[] for _ in slabs]
+        for m in range(5):
+            for k, s in enumerate(slabs):
+                s.sweep(3)
+                s.measure_enqueue()
+        got = [s.measure_fetch() for s in slabs]
+        assert all(s.measure_fetch() == [] for s in slabs)
+        for k, s in enumerate(slabs):  # the same runs again, read with the blocking calls
+            with ig.IsingSlab(8192, 96, seed=5 + k, temp=2.0 + 0.2 * k, layout=layout) as r:
+                r.init()
+                for m in range(5):
+                    r.sweep(3)
+                    want[k].append(r.count() + (r.bond_equal(),))
+        assert got == want
+    finally:
+        for s in slabs:
+            s.close()
+
+
 def test_tsweep_anneal_matches_set_temperature_sequence(gpu, tmp_path):
     X, Y, seed = 4096, 256, 77
     run(["-x", X, "-y", Y, "-s", seed, "--tsweep", "2.0,2.5,0.25,3,2,2", "--tsweep-anneal", "--tsweep-out", "an"], cwd=tmp_path)
