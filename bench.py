@@ -11,7 +11,9 @@ to each ring neighbour per half-sweep.  The lattice is generated on the device f
           gcd(steps, warmup)).  ising_sweep issues fused launches from 2^26 spins up (ISING_FUSED=0: one launch per
           colour): every call is ONE launch of 2 * batch colour half-sweeps, so that every launch of the run -- warm-up
           included -- is the same piece of work and the rocprofv3 per-kernel average agrees with the HIP-event average
-          reported here.
+          reported here (the default 128 + 16: pieces of 16).  Where that common piece would be under 16 sweeps (--steps 20
+          --warmup 5) the timed steps and the warm-up are cut on their own (one call of 20, one of 5): `config.sweeps_per_call`
+          and `roofline.half_sweeps_per_launch` describe the timed launches.
   N > 1   one process per GPU; the ring lives inside libising_hip.so (ising_rank_*: second HIP stream + RCCL send/recv);
           if that transport does not come up the torch.distributed ring (p2p, then all-gather) takes over and the JSON
           line says which one ran.  The counts after warm-up + steps are compared with the oracle's committed goldens
@@ -149,19 +151,26 @@ def main():
         slab = backend.slab
         ring, ring_name = ig.open_ring(backend, prefer="torch" if args.exchange else args.ring, exchange=args.exchange, log=log)
 
-    # sweeps per ising_sweep call: the largest common divisor of steps and warm-up that one fused launch can carry (32)
-    g = math.gcd(args.steps, args.warmup) if args.warmup else args.steps
-    batch = max(d for d in range(1, 33) if g % d == 0)
+    # sweeps per ising_sweep call: the largest common divisor of steps and warm-up that one fused launch can carry (32), so
+    # that every launch of the run is the same piece of work -- unless that leaves pieces under 16 sweeps (the driver's
+    # --steps 20 --warmup 5): then each phase is cut on its own (a fused launch costs ~60 us whatever it carries)
+    def largest_piece(n):
+        return max(d for d in range(1, 33) if n % d == 0)
+    batch = largest_piece(math.gcd(args.steps, args.warmup) if args.warmup else args.steps)
+    batch_warm = batch
+    if batch < 16:
+        batch, batch_warm = largest_piece(args.steps), (largest_piece(args.warmup) if args.warmup else 1)
 
-    def advance(n):
-        """n sweeps in pieces of `batch`, all asynchronous"""
+    def advance(n, piece=None):
+        """n sweeps in pieces of `piece` (default: the timed phase's), all asynchronous"""
+        piece = piece or batch
         if ring is not None:
             ring.sweep(n)
             return
-        for _ in range(n // batch):
-            slab.sweep(batch)
-        if n % batch:
-            slab.sweep(n % batch)
+        for _ in range(n // piece):
+            slab.sweep(piece)
+        if n % piece:
+            slab.sweep(n % piece)
 
     def restart():
         if ring is not None:
@@ -192,7 +201,7 @@ def main():
         preheat_sweeps = (1 + more) * batch
         restart()
 
-    advance(args.warmup)
+    advance(args.warmup, batch_warm)
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -269,7 +278,7 @@ def main():
                                    "Philox4x32-10 per site; device layout " + layout_text
                                    + ", results identical to the reference's packed state", "x": args.x, "y_per_gpu": args.y,
                        "parallelism": f"slab{world}", "nranks": world, "exchange": ring_name, "strip_rows": slab.strip_rows,
-                       "device_layout": layout_name, "sweeps_per_call": batch, "preheat_ms": args.preheat_ms, "preheat_sweeps": preheat_sweeps,
+                       "device_layout": layout_name, "sweeps_per_call": batch, "warmup_sweeps_per_call": batch_warm, "preheat_ms": args.preheat_ms, "preheat_sweeps": preheat_sweeps,
                        "up": up, "down": down, "rank_up": rank_up, "parity_checked": parity,
                        "parity_source": None if gold is None else "tests/golden (CPU oracle, same seed, same number of sweeps)"},
             "roofline": roof,

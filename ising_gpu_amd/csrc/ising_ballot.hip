@@ -221,9 +221,13 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	// Fused launches: thread 0 draws the NEXT ticket in a unit's last iteration and leaves it in LDS before that
 	// iteration's barrier, where the workgroup picks it up.  (Built with -amdgpu-atomic-optimizer-strategy=None: the
 	// wave-aggregating rewrite of atomicAdd needs the result on the spot.)
+	// The counter is never reset: a launch's tickets start at p.ticket_base = where the launches before it left the counter
+	// (each of their `grid` workgroups drew exactly one ticket past its launch's last), which the host keeps count of --
+	// a memset in front of every launch is a fill kernel of its own and two more dependencies in the stream.
+	auto draw_ticket = [&]() { return atomicAdd(p.ticket, 1ull) - p.ticket_base; };
 	unsigned long long tkv = 0; // this workgroup's ticket as read from LDS (every lane the same value)
 	if (FUSED) {
-		if (threadIdx.x == 0) ticket_sh[0] = atomicAdd(p.ticket, 1ull);
+		if (threadIdx.x == 0) ticket_sh[0] = draw_ticket();
 		__syncthreads();
 		tkv = ticket_sh[0];
 	}
@@ -415,7 +419,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			}
 			TRC(4); // draw phase
 			if (FUSED && r == r_ticket && wi == 0) { // wave-uniform branch; read by the workgroup after this unit's last barrier
-				if (lane == 0) ticket_sh[(round + 1) & 1] = ISING_FUSED_LOOKAHEAD == 0 ? tk_next : atomicAdd(p.ticket, 1ull);
+				if (lane == 0) ticket_sh[(round + 1) & 1] = ISING_FUSED_LOOKAHEAD == 0 ? tk_next : draw_ticket();
 			}
 			TRC(5); // next ticket
 			asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -425,7 +429,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			// the barrier and the top of the last iteration
 			const bool ticket_iter = FUSED && ISING_FUSED_LOOKAHEAD == 0 && r == rmax - 1 && wi == 0;
 			const bool ticket_in_word = ticket_iter && r > 0 && r <= nrows;
-			if (ticket_iter && !ticket_in_word && lane == 0) tk_next = atomicAdd(p.ticket, 1ull);
+			if (ticket_iter && !ticket_in_word && lane == 0) tk_next = draw_ticket();
 			if (r > 0 && r <= nrows) {
 				// ---- word phase, row r0 + r - 1; its masks were written back during the draw phase above
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -509,7 +513,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 						if (lr == p.Y - 1) st_word<false>(rd + mirL + lane, nw);
 					}
 				}
-				if (ticket_in_word && lane == 0) tk_next = atomicAdd(p.ticket, 1ull); // (behind this row's stores)
+				if (ticket_in_word && lane == 0) tk_next = draw_ticket(); // (behind this row's stores)
 				rs += wpr;
 				rd += wpr;
 				if (sl_last) { // the next row opens a new period: the register window does not slide across the seam

@@ -598,7 +598,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 		p.ticket = reinterpret_cast<unsigned long long *>(c->d_slotctl);
 		p.nlevels = nlevels;
 		if (nlevels > 1) {
-			HIP_TRY(hipMemsetAsync(c->d_slotctl, 0, SLOTCTL_TICKET_BYTES, c->stream)); // ticket words start from zero
+			p.ticket_base = c->ticket_base; // (the counter is never reset, ising_ballot.hip)
 			if (c->done_base > (1u << 30)) { // keep the monotone completion counters far from wrapping
 				HIP_TRY(hipMemsetAsync(c->d_slotctl + SLOTCTL_TICKET_BYTES / 4, 0, (size_t)c->nstrips * sizeof(uint32_t), c->stream));
 				c->done_base = 0;
@@ -619,7 +619,10 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 		}
 		int grid = 0;
 		HIP_TRY(ising::launch_ballot_update(p, c->stream, &grid, stop));
-		if (nlevels > 1) c->done_base += (uint32_t)nlevels * (uint32_t)c->nwc();
+		if (nlevels > 1) {
+			c->done_base += (uint32_t)nlevels * (uint32_t)c->nwc();
+			c->ticket_base += (unsigned long long)p.nwg * (unsigned long long)nlevels + (unsigned long long)grid; // every workgroup drew one ticket too many
+		}
 		return ISING_OK;
 	}
 	if (c->dense) HIP_TRY(ising::launch_dense_update(p, mode, c->stream));
