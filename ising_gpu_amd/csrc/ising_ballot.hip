@@ -140,6 +140,9 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 #ifndef ISING_FUSED_LOOKAHEAD
 #define ISING_FUSED_LOOKAHEAD 2
 #endif
+#ifndef ISING_FUSED_STAGGER // s_sleep units (64 cycles each) between the start of successive dispatch rounds of a fused launch
+#define ISING_FUSED_STAGGER 100
+#endif
 // Measurement build (make variant DEFS=-DISING_FUSED_TRACE): wave 0 of every workgroup of a fused launch clocks where its
 // time goes (s_memtime between the marks below); ballot_trace_dump() prints the chip-wide sums when the slab is
 // destroyed.  Never in the product library.
@@ -226,6 +229,11 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	// a memset in front of every launch is a fill kernel of its own and two more dependencies in the stream.
 	auto draw_ticket = [&]() { return atomicAdd(p.ticket, 1ull) - p.ticket_base; };
 	unsigned long long tkv = 0; // this workgroup's ticket as read from LDS (every lane the same value)
+	// The workgroups of a launch start a fraction of a row apart (by the round of 256 they were dispatched in) instead of
+	// in lockstep -- all drawing, then all waiting: +0.3..0.6 % on whole runs, more on short launches (4-wave form;
+	// -DISING_FUSED_STAGGER=0 switches it off, 8-wave workgroups measured -2 % with it).
+	if (FUSED && NT == 256 && ISING_FUSED_STAGGER > 0)
+		for (unsigned i = 0; i < (blockIdx.x >> 8) % 6u; ++i) __builtin_amdgcn_s_sleep(ISING_FUSED_STAGGER);
 	if (FUSED) {
 		if (threadIdx.x == 0) ticket_sh[0] = draw_ticket();
 		__syncthreads();
