@@ -135,8 +135,8 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 // a unit's FIRST row, the form this kernel had first: a ticket drawn a unit ahead sits reserved while its workgroup
 // finishes the current unit and later tickets start before it, so units of the next level find their parents unfinished.
 // Measured (tools/trace_probe.py, `make variant DEFS=-DISING_FUSED_LOOKAHEAD=1`, profiles/fused_trace_r02.txt): 65536^2,
-// H = 16: 11.6 M polls that slept per 2.1 M units -> none with 2, 3381 -> 3472 flips/ns; 16384^2, H = 4: 9.6 M -> 3.4 M,
-// 2916 -> 3049 (trace builds).
+// H = 16: 12.5 M polls that slept per 2.1 M units -> none with 2, 3360 -> 3463 flips/ns; 16384^2, H = 4: 9.7 M -> 3.5 M,
+// 2892 -> 3047 (trace builds).
 #ifndef ISING_FUSED_LOOKAHEAD
 #define ISING_FUSED_LOOKAHEAD 2
 #endif
