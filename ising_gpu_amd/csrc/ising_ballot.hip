@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	unsigned long long tkv = 0; // this workgroup's ticket as read from LDS (every lane the same value)
 	// The workgroups of a launch start a fraction of a row apart (by the round of 256 they were dispatched in) instead of
 	// in lockstep -- all drawing, then all waiting: +0.3..0.6 % on whole runs, more on short launches (4-wave form;
-	// -DISING_FUSED_STAGGER=0 switches it off, 8-wave workgroups measured -2 % with it).
+	// -DISING_FUSED_STAGGER=0 switches it off; 8-wave workgroups measured -2 % with it, plain launches -0.3 %).
 	if (FUSED && NT == 256 && ISING_FUSED_STAGGER > 0)
 		for (unsigned i = 0; i < (blockIdx.x >> 8) % 6u; ++i) __builtin_amdgcn_s_sleep(ISING_FUSED_STAGGER);
 	if (FUSED) {
