@@ -790,7 +790,8 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 		if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
 		if (!cu_count[dev] && (hipDeviceGetAttribute(&cu_count[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu_count[dev] < 1)) cu_count[dev] = 256;
 		const int cus = cu_count[dev];
-		static const long long cap = getenv("ISING_FUSED_WGS") ? atoll(getenv("ISING_FUSED_WGS")) : 0; // A/B: explicit grid
+		const char *wgs = getenv("ISING_FUSED_WGS"); // A/B and tests: explicit grid (read at every launch)
+		const long long cap = wgs ? atoll(wgs) : 0;
 		if (cap > 0) grid = std::min(grid, cap);
 		else if (p.wg_per_cu > 0) grid = std::min<long long>(grid, (long long)p.wg_per_cu * cus);
 	}

@@ -57,3 +57,51 @@ def test_random_configuration(gpu, oracle_mod, layout, X, Y, temp, seed, strip, 
         assert s.count() == orc.count()
         if jp is None:
             assert s.bond_equal() == orc.bond_equal()
+
+
+def _fused_cases(n):
+    rng = np.random.default_rng(777)
+    out = []
+    for k in range(n):
+        X = int(rng.choice([8192, 8192, 16384, 24576, 12288, 32768]))
+        Y = int(rng.choice([16, 32, 48, 64, 96, 112, 160, 256, 272]))
+        strip = int(rng.choice([0, 1, 2, 4, 8]))
+        if Y % max(strip, 1):
+            strip = 0
+        wide = int(rng.random() < 0.4)
+        nt = int(rng.random() < 0.4)
+        wgs = rng.choice(["", "1", "2", "3", "5", "17", "64"])
+        jp = float(rng.choice([0.2, 0.7])) if (rng.random() < 0.3 and X % 8192 == 0) else None
+        temp = float(np.float32(rng.choice([1.0, 2.0, float(ig.CRIT_TEMP_F32), 3.0])))
+        seed = int(rng.integers(1, 2**40))
+        out.append(pytest.param(X, Y, strip, wide, nt, str(wgs), jp, temp, seed, id=f"{k}-{X}x{Y}-s{strip}-w{wide}-nt{nt}-g{wgs or 'auto'}-J{jp}-T{temp:.2f}"))
+    return out
+
+
+@pytest.mark.parametrize("X,Y,strip,wide,nt,wgs,jp,temp,seed", _fused_cases(28))
+def test_random_fused_configuration(gpu, oracle_mod, monkeypatch, X, Y, strip, wide, nt, wgs, jp, temp, seed):
+    """The fused launch form under random shapes and switches: 4- and 8-wave workgroups, streaming instantiation, strip
+    heights, grids from one workgroup (every unit waits for its parents, one after the other) to what the chip holds,
+    launches of 1 .. 9 sweeps."""
+    monkeypatch.setenv("ISING_FUSED", "1")
+    monkeypatch.setenv("ISING_FUSED_WIDE", str(wide))
+    monkeypatch.setenv("ISING_FUSED_NT", str(nt))
+    if wgs:
+        monkeypatch.setenv("ISING_FUSED_WGS", wgs)
+    else:
+        monkeypatch.delenv("ISING_FUSED_WGS", raising=False)
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=temp).init()
+    if jp is not None:
+        orc.init_couplings(jp)
+    with ig.IsingSlab(X, Y, seed=seed, temp=temp, strip_rows=strip, layout=ig.LAYOUT_BALLOT, J_prob=jp) as s:
+        s.init()
+        if jp is not None:
+            s.init_couplings()
+        assert s.fused
+        for n in (1, 9, 2):
+            s.sweep(n)
+            orc.sweep(n)
+            _compare(s, orc, f"after {s.it} sweeps")
+        assert s.count() == orc.count()
+        if jp is None:
+            assert s.bond_equal() == orc.bond_equal()
