@@ -281,11 +281,15 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		// neighbours strip 0 and strip N-1 wait for are the first tickets of the previous level, not its last
 		const int nstr = (p.row_hi[0] - p.row_lo[0] + p.H - 1) / p.H;
 		// (also when a plain launch publishes its edge rows, p.edge_signal: the two edge strips go first)
-		const bool zigzag = FUSED || (p.edge_signal != nullptr && rng == 0);
+		const bool zigzag = FUSED || (rng == 0 && (p.zigzag0 || (p.edge_signal != nullptr && p.sync_wait == nullptr)));
 		const int sidx = zigzag ? uni((pos & 1) ? nstr - 1 - (pos >> 1) : (pos >> 1)) : pos;
 		const int r0 = p.row_lo[rng] + sidx * Hr;
 		const int nrows = idle ? 0 : min(Hr, p.row_hi[rng] - r0);
-		const bool publish = !FUSED && p.edge_signal != nullptr && !idle && rng == 0 && (r0 == 0 || r0 + nrows == p.Y);
+		// ring slab, flag-synchronised schedule: this unit holds a row next to rows the slab's other launch (edge rows <->
+		// interior) writes
+		const bool synced = !FUSED && p.sync_wait != nullptr && !idle &&
+		                    ((p.sync_row[0] >= r0 && p.sync_row[0] < r0 + nrows) || (p.sync_row[1] >= r0 && p.sync_row[1] < r0 + nrows));
+		const bool publish = synced || (!FUSED && p.sync_wait == nullptr && p.edge_signal != nullptr && !idle && rng == 0 && (r0 == 0 || r0 + nrows == p.Y));
 		const uint32_t color = FUSED ? uni((p.color + (uint32_t)level) & 1u) : p.color;
 		const uint32_t it = FUSED ? uni(p.it + ((p.color + (uint32_t)level) >> 1)) : p.it;
 		const uint64_t *src = FUSED ? (color ? p.lat[0] : p.lat[1]) : p.src;
@@ -352,6 +356,16 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				if (lane < 3) asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(seen) : "v"(dp) : "memory");
 			}
 			TRC(2); // completion counters (+ block constants)
+		}
+		if (synced) {
+			// the other launch's rows next to this unit's (and its reads of the rows this unit is about to overwrite) are
+			// done once its counter says so; its stores were written through, nothing of them was read here before
+			uint32_t got = p.sync_need;
+			for (;;) {
+				if (lane == 0) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(got) : "v"(p.sync_wait) : "memory");
+				if (__all((int32_t)(got - p.sync_need) >= 0)) break;
+				__builtin_amdgcn_s_sleep(127);
+			}
 		}
 		__builtin_amdgcn_wave_barrier();
 		__threadfence_block();
@@ -538,7 +552,8 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		}
 		if (publish) {
 			// ring: rows 0 / Y-1 of this colour are what the neighbours wait for.  The strip was written through; once this
-			// wave's stores have left it, the slab's comm stream may send (hipStreamWaitValue32 on the counter)
+			// wave's stores have left it, the slab's comm stream may send (hipStreamWaitValue32 on the counter) -- or, in
+			// the flag-synchronised schedule, the slab's other launch may read and overwrite next to it
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			if (lane == 0) __hip_atomic_fetch_add(p.edge_signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}

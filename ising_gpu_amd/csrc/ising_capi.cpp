@@ -414,7 +414,8 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 			else if (got >= 1 && rows > 0 && h > 0 && rows % c->H == 0 && rows % h == 0 && h < c->H && 2 * rows < cfg->Y) { c->tail_rows = rows; c->tail_h = h; }
 		}
 		const size_t strips = c->tail_rows ? (size_t)(cfg->Y - c->tail_rows) / c->H + (size_t)c->tail_rows / c->tail_h : (size_t)c->nstrips;
-		const size_t plain = (size_t)c->nwc() * (strips + 2) * 2048 + 16 * 2048, fused = (size_t)ising::ballot_max_wgs() * 4 * 2048;
+		// (+ H: the flag-synchronised ring schedule may turn one more H-row strip into one-row strips, launch_ranges)
+		const size_t plain = (size_t)c->nwc() * (strips + 2 + (size_t)c->H) * 2048 + 16 * 2048, fused = (size_t)ising::ballot_max_wgs() * 4 * 2048;
 		e = hipMalloc((void **)&c->d_scratch, std::max(plain, fused));
 		// ticket words (chunk counter + 8 queue words, 64 bytes apart) + one completion counter per strip (fused launches)
 		const size_t ctl_bytes = SLOTCTL_TICKET_BYTES + (size_t)c->nstrips * sizeof(uint32_t);
@@ -455,6 +456,7 @@ int ising_destroy(ising_ctx *c) {
 	if (c->d_corr) (void)hipFree(c->d_corr);
 	if (c->d_slotctl) (void)hipFree(c->d_slotctl);
 	for (int k = 0; k < 2; k++) if (c->d_signal[k]) (void)hipFree(c->d_signal[k]);
+	if (c->d_flags) (void)hipFree(c->d_flags);
 	if (c->d_pack) (void)hipFree(c->d_pack);
 	delete c;
 	return ISING_OK;
@@ -585,6 +587,25 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	}
 	p.H2 = H2;
 	p.nreal0 = ugx * ((hi0 - lo0 + c->H - 1) / c->H);
+	// Flag-synchronised ring schedule, interior rows: the strips are taken from both ends inwards, so that the two boundary
+	// strips are the launch's first units (the edge-row launch of the next colour waits for them), and the one-row tail
+	// strips are the MIDDLE rows, which that order reaches last.
+	const bool middle_tail = c->ballot && c->sync_mode == 1 && c->d_flags && nlevels == 1 && H2 && (c->tail_rows % c->H) == 0;
+	if (middle_tail) {
+		const int lo = lo0, hi = hi1, N = (hi - lo + c->H - 1) / c->H; // strips of the whole span
+		int mid = c->tail_rows / c->H;                                    // strips that become one-row units
+		if ((N - mid) & 1) mid++;
+		const int a = (N - mid) / 2;
+		if (a >= 1 && mid >= 1) {
+			p.row_lo[0] = lo; p.row_hi[0] = hi;                           // the kernel numbers range 0's strips over the whole span ...
+			p.nreal0 = ugx * 2 * a;                                        // ... and visits a from each end
+			lo1 = lo + a * c->H;
+			hi1 = std::min(hi, lo + (N - a) * c->H);
+			p.row_lo[1] = lo1; p.row_hi[1] = hi1;
+			p.zigzag0 = 1;
+			hi0 = lo0 + 2 * a * c->H; // (only its length is used below: units of range 0)
+		}
+	}
 	p.nunits0 = (c->ballot && H2) ? (p.nreal0 + 15) / 16 * 16 : p.nreal0;
 	p.nunits = p.nunits0 + ugx * ((hi1 - lo1 + (H2 ? H2 : c->H) - 1) / (H2 ? H2 : c->H));
 	p.n3 = (uint32_t)c->thr[3];
@@ -617,6 +638,24 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			p.edge_signal = c->d_signal[color];
 			c->edge_target[color] += (uint32_t)c->nwc() * (c->nstrips == 1 ? 1u : 2u); // wave columns of the strips with row 0 / Y-1
 		}
+		if (c->sync_mode && c->d_flags && nlevels == 1) {
+			// flag-synchronised ring schedule (ising_ring.cpp): interior rows wait for the edge-row launches so far and count
+			// their two boundary strips; edge rows the other way round
+			const int mine = c->sync_mode == 1 ? 0 : 1;
+			p.sync_wait = c->d_flags + (1 - mine);
+			p.sync_need = c->flag_target[1 - mine];
+			p.edge_signal = c->d_flags + mine;
+			const int last_hi = p.zigzag0 ? p.row_hi[0] : (hi1 > lo1 ? hi1 : hi0);
+			p.sync_row[0] = c->sync_mode == 1 ? lo0 : 0;
+			p.sync_row[1] = c->sync_mode == 1 ? last_hi - 1 : c->cfg.Y - 1;
+			unsigned units = 0; // units (strip x wave column) that hold one of the two rows
+			if (hi0 > lo0 || hi1 > lo1) {
+				if (c->sync_mode == 2) units = (lo1 < hi1 && hi0 > lo0) ? 2u : 1u;
+				else units = (p.zigzag0 || hi1 > lo1 || (hi0 - lo0 + c->H - 1) / c->H > 1) ? 2u : 1u;
+			}
+			c->flag_target[mine] += units * (uint32_t)c->nwc();
+		}
+		c->sync_mode = 0;
 		int grid = 0;
 		HIP_TRY(ising::launch_ballot_update(p, c->stream, &grid, stop));
 		if (nlevels > 1) {

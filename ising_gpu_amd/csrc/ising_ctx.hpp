@@ -70,6 +70,12 @@ struct ising_ctx {
 	uint32_t *d_signal[2] = {nullptr, nullptr};  // per colour: counter the published edge strips of a full-slab launch bump
 	                                             // (hipMallocSignalMemory: the comm stream waits on it, hipStreamWaitValue32)
 	uint32_t edge_target[2] = {0, 0};            // value of the counter once every launch issued so far has published
+	// flag-synchronised ring schedule: d_flags[0] counts the interior launches' boundary strips, d_flags[1] the edge-row
+	// launches; flag_target[] = their values once everything launched so far has run; sync_mode is set by the schedule for
+	// the next launch (0 none, 1 interior rows, 2 edge rows) and cleared by it
+	uint32_t *d_flags = nullptr;
+	uint32_t flag_target[2] = {0, 0};
+	int sync_mode = 0;
 	bool store_ring = false;                     // ring on ONE device and one stream: every launch writes its edge rows straight into the
 	                                             // neighbouring slabs' halo rows (UpdateParams.mir0/mirL_bytes): no edge launch, no copies
 	bool copy_inline = false;                    // COPY transport, both neighbours on this slab's device: copies on the compute stream

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One GPU of a ring under rocprofv3 --kernel-trace: a ring of one slab (ring_halo) sweeping through the library's ring
 schedule.  Usage: rocprofv3 --kernel-trace -d DIR -o trace -- python tools/ring_trace.py [rccl|copy] [X Y sweeps]
-Then: python tools/ring_trace.py --analyze DIR  (gaps between consecutive interior launches, where the edge-row launch sits)."""
+Then: python tools/ring_trace.py --analyze DIR  (gaps between consecutive interior launches, where the edge-row launch sits)
+      python tools/ring_trace.py --window DIR   (the kernels of two colours in time order).  ISING_RING_FLAGS=1: flag-synchronised schedule."""
 import glob
 import os
 import sqlite3
@@ -9,6 +10,15 @@ import sys
 
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 
+if len(sys.argv) > 2 and sys.argv[1] == "--window":  # every kernel between the 40th and the 42nd interior launch, in time order
+    db = glob.glob(os.path.join(sys.argv[2], "**", "*.db"), recursive=True)[0]
+    rows = sqlite3.connect(db).execute("select name, start, end, grid_x, stream_id from kernels order by start").fetchall()
+    big = [r for r in rows if "update_k" in r[0] and r[3] > 100000]
+    t0, t1 = big[40][1], big[42][2]
+    for r in rows:
+        if t0 <= r[1] <= t1:
+            print(f"{(r[1] - t0) / 1e3:9.1f} us  +{(r[2] - r[1]) / 1e3:7.1f} us  grid {r[3]:8d}  stream {r[4]}  {r[0][:64]}")
+    sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[1] == "--analyze":
     db = glob.glob(os.path.join(sys.argv[2], "**", "*.db"), recursive=True)[0]
     con = sqlite3.connect(db)
