@@ -227,6 +227,13 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	// The counter is never reset: a launch's tickets start at p.ticket_base = where the launches before it left the counter
 	// (each of their `grid` workgroups drew exactly one ticket past its launch's last), which the host keeps count of --
 	// a memset in front of every launch is a fill kernel of its own and two more dependencies in the stream.
+	// Row of the whole lattice behind slab row r.  Ghost rows of a ring slab (r < 0, r >= Y: ising_ring.cpp, sweep_deep) are
+	// rows of the neighbouring slabs, around the ring: their draws must be the ones their owners make.
+	auto global_row = [&](int r) -> uint32_t {
+		int gr = (int)p.row_base + r;
+		if (p.total_rows) gr = gr < 0 ? gr + p.total_rows : (gr >= p.total_rows ? gr - p.total_rows : gr);
+		return (uint32_t)gr;
+	};
 	auto draw_ticket = [&]() { return atomicAdd(p.ticket, 1ull) - p.ticket_base; };
 	unsigned long long tkv = 0; // this workgroup's ticket as read from LDS (every lane the same value)
 	// The workgroups of a launch start a fraction of a row apart (by the round of 256 they were dispatched in) instead of
@@ -397,7 +404,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			unsigned long long sA0 = 0, sA1 = 0, sC = 0;
 			uint64_t vC = 0;
 			if (r > 0 && r <= nrows) {
-				const uint32_t grow = p.row_base + (uint32_t)(r0 + r - 1);
+				const uint32_t grow = global_row(r0 + r - 1);
 				const bool back = (color == 0) ? !(grow & 1u) : (grow & 1u);
 				const uint64_t *qc = rs + (back ? u_cb : u_cf);
 				if (FUSED) {
@@ -412,7 +419,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			TRC(3); // row prologue
 			if (r < nrows) {
 				// ---- draw phase, row r0 + r
-				const uint32_t grow = p.row_base + (uint32_t)(r0 + r);
+				const uint32_t grow = global_row(r0 + r);
 				const uint32_t tid = ((grow >> 4) * (uint32_t)p.gx + (uint32_t)bx) * 256u + (grow & 15u) * 16u + (uint32_t)tx;
 				const PhiloxRow pr = philox_row_setup(tid, seed_lo_cy, k2y);
 				uint64_t *cur = slot + (r & 1) * 128;
@@ -456,7 +463,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				// ---- word phase, row r0 + r - 1; its masks were written back during the draw phase above
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 				const int lr = r0 + r - 1;
-				const uint32_t grow = p.row_base + (uint32_t)lr;
+				const uint32_t grow = global_row(lr);
 				const bool back = (color == 0) ? !(grow & 1u) : (grow & 1u); // readBack, optimized/main.cu:542
 				// this lane's two accept masks: 16 bytes at slot + 16 lane, past the (non-coherent) vector L1
 				const uint64_t *msk = slot + ((r - 1) & 1) * 128;

@@ -377,6 +377,20 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		const long long T = fused_tickets(c->nwc(), cfg->Y, c->H, c->fused_wide != 0);
 		c->fused_wg_per_cu = c->fused_wide ? (T >= 2048 ? 3 : 2) : (T >= 16384 ? 6 : (T >= 8192 ? 5 : (T >= 2048 ? 4 : 3)));
 	}
+	// A ring slab on the ballot layout keeps G ghost rows on either side (ising_ctx::ghost_rows; ising_ring.cpp: sweep_deep):
+	// G rows of both colours travel every G colour half-sweeps, fused launches of G levels run in between.  Not with -J
+	// (the couplings of the ghost rows would have to travel too), sub-lattices, or a caller-owned buffer (fixed shape).
+	if (c->ballot && !c->wrap && !cfg->XSL && !cfg->use_J && !cfg->lattice_mem) {
+		int G = 32;
+		if (const char *e = getenv("ISING_RING_GHOST")) G = atoi(e);
+		G = std::min(G, cfg->Y / 2) & ~1;
+		c->ghost_rows = G >= 2 ? G : 1;
+		if (c->ghost_rows > 1) { // the fused launches of the ring: 4-wave workgroups, the strip height of the per-colour launches
+			c->fused_wide = 0;
+			const long long T = fused_tickets(c->nwc(), cfg->Y + 2 * c->ghost_rows, c->H, false);
+			c->fused_wg_per_cu = T >= 16384 ? 6 : (T >= 8192 ? 5 : (T >= 2048 ? 4 : 3));
+		}
+	}
 
 	hipError_t e = hipSetDevice(cfg->device);
 	if (e == hipSuccess && cfg->lattice_mem) {
@@ -417,8 +431,12 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		// (+ H: the flag-synchronised ring schedule may turn one more H-row strip into one-row strips, launch_ranges)
 		const size_t plain = (size_t)c->nwc() * (strips + 2 + (size_t)c->H) * 2048 + 16 * 2048, fused = (size_t)ising::ballot_max_wgs() * 4 * 2048;
 		e = hipMalloc((void **)&c->d_scratch, std::max(plain, fused));
+		// The ring's edge-row launches (two rows, comm stream) run next to the interior launch of the same colour (compute
+		// stream): slots of their own, or the two launches overwrite each other's accept masks -- which they did: the
+		// two-stream schedule gave wrong spins at 65536^2 (tools/ring_parity_probe.py), unnoticed at test sizes.
+		if (e == hipSuccess) e = hipMalloc((void **)&c->d_scratch_edge, ((size_t)2 * c->nwc() + 8) * 2048);
 		// ticket words (chunk counter + 8 queue words, 64 bytes apart) + one completion counter per strip (fused launches)
-		const size_t ctl_bytes = SLOTCTL_TICKET_BYTES + (size_t)c->nstrips * sizeof(uint32_t);
+		const size_t ctl_bytes = SLOTCTL_TICKET_BYTES + ((size_t)c->nstrips + 2 * (size_t)c->ghost_rows + 2) * sizeof(uint32_t); // (+ strips of the ghost rows)
 		if (e == hipSuccess) e = hipMalloc((void **)&c->d_slotctl, ctl_bytes);
 		if (e == hipSuccess) e = hipMemset(c->d_slotctl, 0, ctl_bytes);
 
@@ -457,6 +475,7 @@ int ising_destroy(ising_ctx *c) {
 	if (c->d_slotctl) (void)hipFree(c->d_slotctl);
 	for (int k = 0; k < 2; k++) if (c->d_signal[k]) (void)hipFree(c->d_signal[k]);
 	if (c->d_flags) (void)hipFree(c->d_flags);
+	if (c->d_scratch_edge) (void)hipFree(c->d_scratch_edge);
 	if (c->d_pack) (void)hipFree(c->d_pack);
 	delete c;
 	return ISING_OK;
@@ -488,6 +507,7 @@ int ising_synchronize(ising_ctx *c) {
 int ising_init_lattice(ising_ctx *c) {
 	if (!c) return fail(ISING_E_ARG, "null context");
 	if (int rc = bind(c)) return rc;
+	c->ghost_depth[0] = c->ghost_depth[1] = 0;
 	const uint64_t half = draw_prefix(0.5f, false); // curand_uniform(x) < 0.5f, optimized/main.cu:133
 	for (int color = 0; color < 2; color++) {
 		ising::InitParams p{};
@@ -539,6 +559,8 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	}
 	if (int rc = bind(c)) return rc;
 	if (c->ballot && mode == 1) if (int rc = ising_host::ballot_leave(c)) return rc; // no integer thresholds at this temperature
+	c->ghost_depth[color] = 0; // (the neighbours' copies of this slab's rows are stale from here on -- and theirs here, by symmetry)
+	if (nlevels > 1) c->ghost_depth[1 - color] = 0;
 	if (mode == 2 && c->lut_dirty) {
 		std::vector<uint8_t> tab(65536);
 		build_rank_table(c, tab.data());
@@ -614,14 +636,15 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	p.lut = c->d_lut;
 	// the reference hands hamW to the BLACK update and hamB to the WHITE one (optimized/main.cu:1774, :1795)
 	p.jdst = c->cfg.use_J ? c->ham(other) : nullptr;
-	p.scratch = c->d_scratch;
+	p.scratch = (c->edge_scratch_next && c->d_scratch_edge) ? c->d_scratch_edge : c->d_scratch;
+	c->edge_scratch_next = false;
 	if (c->ballot) {
 		p.ticket = reinterpret_cast<unsigned long long *>(c->d_slotctl);
 		p.nlevels = nlevels;
 		if (nlevels > 1) {
 			p.ticket_base = c->ticket_base; // (the counter is never reset, ising_ballot.hip)
 			if (c->done_base > (1u << 30)) { // keep the monotone completion counters far from wrapping
-				HIP_TRY(hipMemsetAsync(c->d_slotctl + SLOTCTL_TICKET_BYTES / 4, 0, (size_t)c->nstrips * sizeof(uint32_t), c->stream));
+				HIP_TRY(hipMemsetAsync(c->d_slotctl + SLOTCTL_TICKET_BYTES / 4, 0, ((size_t)c->nstrips + 2 * (size_t)c->ghost_rows + 2) * sizeof(uint32_t), c->stream));
 				c->done_base = 0;
 			}
 			p.lat[0] = c->lat(ISING_BLACK);
@@ -633,6 +656,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			p.wg_per_cu = c->fused_wg_per_cu;
 			p.nt_stream = c->fused_nt;
 			p.done_base = c->done_base;
+			if (lo0 < 0 || hi0 > c->cfg.Y) p.total_rows = c->cfg.nslabs * c->cfg.Y; // ghost rows are rows of the neighbouring slabs
 		}
 		if (publish) {
 			p.edge_signal = c->d_signal[color];
@@ -686,6 +710,7 @@ int ising_update_edges(ising_ctx *c, int it, int color) {
 int ising_host::update_edges_on(ising_ctx *c, int it, int color, hipStream_t s, hipEvent_t stop) {
 	hipStream_t keep = c->stream; // (a context is driven by one host thread)
 	c->stream = s;
+	c->edge_scratch_next = s != keep; // on another stream than the slab's own: it may run next to an interior launch
 	const int rc = launch_ranges(c, it, color, 0, 1, c->cfg.Y - 1, c->cfg.Y, 1, false, stop);
 	c->stream = keep;
 	return rc;
@@ -693,6 +718,15 @@ int ising_host::update_edges_on(ising_ctx *c, int it, int color, hipStream_t s, 
 
 int ising_host::update_interior(ising_ctx *c, int it, int color, hipEvent_t stop) {
 	return launch_ranges(c, it, color, 1, c->cfg.Y - 1, 0, 0, 1, false, stop);
+}
+
+// Ring slab with G > 1 ghost rows: `nlevels` colour half-sweeps (black first) in one fused launch over rows
+// [-(G-1), Y+G-1).  The ghost rows are updated like the slab's own -- their draws are the ones the neighbours make --, and
+// what is not valid in them any more (one row per level and side) never reaches a row that is.
+int ising_host::update_deep(ising_ctx *c, int it, int nlevels) {
+	const int G = c->ghost();
+	if (G < 2 || nlevels > G || nlevels < 2 || c->store_ring) return fail(ISING_E_STATE, "deep launch of %d levels on a slab with %d ghost rows", nlevels, G);
+	return launch_ranges(c, it, ISING_BLACK, -(G - 1), c->cfg.Y + G - 1, 0, 0, nlevels);
 }
 
 int ising_host::update_full_published(ising_ctx *c, int it, int color) {

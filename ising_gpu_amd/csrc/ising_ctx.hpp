@@ -2,6 +2,7 @@
 // libising_hip.so share (ising_capi.cpp: slab life cycle, updates, observables, boundary formats; ising_ring.cpp: the
 // slab ring and its transports).  Internal to the library.
 #pragma once
+#include <algorithm>
 #include "../../include/ising_hip.h"
 #include "ising_kernels.h"
 
@@ -17,6 +18,8 @@ struct ising_ctx {
 	uint64_t *d_tmp = nullptr;     // ballot layout: dense-order image of d_lat (same shape) for conversions and observables;
 	                               // allocated by the first call that needs it (sweeping and counting never do)
 	uint64_t *d_scratch = nullptr; // ballot layout: accept-mask slots of the update kernel (see ising_ballot.hip)
+	uint64_t *d_scratch_edge = nullptr; // ... of the ring's edge-row launches, which run on the comm stream NEXT TO an interior launch
+	bool edge_scratch_next = false;     // the next launch is such a one (set by update_edges_on, cleared by launch_ranges)
 	uint32_t *d_slotctl = nullptr; // ballot layout, fused launches: ticket words (576 bytes) + per-strip completion counters
 	uint32_t done_base = 0;        // value of every completion counter once everything launched so far has run
 	bool fused = false;            // ising_sweep batches colour half-sweeps into fused launches
@@ -84,9 +87,16 @@ struct ising_ctx {
 	// kernels address rows -1..Y uniformly.  With one slab they mirror the slab's own last / first row (periodic
 	// wrap, maintained by the kernels that write edge rows); with several slabs the neighbours' rows are delivered
 	// into them (ising_halo_ptrs / ising_ring_exchange).
-	uint64_t *lat(int color) const { return d_lat + (size_t)color * (color_words + 2 * (size_t)lld) + lld; }
+	// Ring slabs on the ballot layout keep `ghost_rows` halo rows on either side (rows -G .. -1 and Y .. Y+G-1): the ring
+	// then exchanges G rows of both colours every G colour half-sweeps and runs fused launches in between, which update the
+	// ghost rows redundantly (ising_ring.cpp: sweep_deep).  Rows -1 and Y are where they always were relative to row 0.
+	int ghost_rows = 1;
+	int ghost_depth[2] = {0, 0}; // per colour: how deep the ghost rows hold the neighbours' current rows (0: not even row -1 / Y;
+	                             // set by the ring's transfers, cleared by whatever changes spins)
+	int ghost() const { return ballot ? ghost_rows : 1; }
+	uint64_t *lat(int color) const { return d_lat + (size_t)color * (color_words + 2 * (size_t)ghost() * lld) + (size_t)ghost() * lld; }
 	uint64_t *halo(int color, int which) const { return which == 0 ? lat(color) - lld : lat(color) + color_words; }
-	size_t alloc_words() const { return 2 * (color_words + 2 * (size_t)lld); }
+	size_t alloc_words() const { return 2 * (color_words + 2 * (size_t)std::max(ghost_rows, 1) * (size_t)lld); }
 	size_t tmp_words() const { return 2 * ((size_t)cfg.Y + 2) * (size_t)lld_dense; }
 	uint64_t *tmp(int color) const { return d_tmp + (size_t)color * ((size_t)cfg.Y + 2) * lld_dense + lld_dense; }
 	int nwc() const { return (gx + 3) / 4; } // ballot layout: wave columns per row
@@ -129,6 +139,8 @@ int update_edges_on(ising_ctx *c, int it, int color, hipStream_t s, hipEvent_t s
 int update_interior(ising_ctx *c, int it, int color, hipEvent_t stop);
 // ballot layout: one launch over rows [0, Y) whose edge strips go first and publish rows 0 / Y-1 through d_signal[color]
 int update_full_published(ising_ctx *c, int it, int color);
+// ring slab with ghost rows: one fused launch of `nlevels` (even, <= ghost rows) colour half-sweeps, ghost rows included
+int update_deep(ising_ctx *c, int it, int nlevels);
 // called by ising_destroy
 void ring_release(ising_ctx *c);
 

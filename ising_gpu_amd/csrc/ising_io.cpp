@@ -83,6 +83,7 @@ int read_rows(ising_ctx *c, int color, int64_t row0, int64_t nrows, void *host, 
 }
 
 int write_rows(ising_ctx *c, int color, int64_t row0, int64_t nrows, const void *host, Format fmt) {
+	if (color == ISING_BLACK || color == ISING_WHITE) c->ghost_depth[color] = 0; // (the ring's ghost rows of this colour are stale now)
 	if (int rc = bind(c)) return rc;
 	const size_t nvec_row = (size_t)c->lld_packed / 2;
 	const size_t row_bytes = (size_t)c->lld * sizeof(uint64_t); // device row

@@ -59,6 +59,7 @@ struct UpdateParams {
 	uint32_t sync_need;
 	int32_t sync_row[2];
 	int32_t zigzag0;          // range 0's strips are numbered over [row_lo[0], row_hi[0]) and taken from both ends inwards; nreal0 says how many
+	int32_t total_rows;       // rows of the whole lattice when this launch covers ghost rows (their global row wraps around the ring); 0: off
 };
 
 // mode: 0 = integer thresholds via v_cmpx, 1 = generic FP32-table kernel, 2 = integer thresholds via the LDS rank table

@@ -285,17 +285,19 @@ struct EdgeRows {
 	uint64_t *first, *last, *halo_top, *halo_bot;
 	size_t bytes;
 };
-EdgeRows edge_rows(const ising_ctx *c, int color) {
-	const size_t ld = (size_t)c->plane_ld(color);
+// `depth` rows on either side (1: the halo rows every schedule keeps current; G = the slab's ghost rows: sweep_deep)
+EdgeRows edge_rows(const ising_ctx *c, int color, int depth = 1) {
+	const size_t ld = (size_t)c->plane_ld(color), d = (size_t)depth;
 	uint64_t *base = c->plane(color);
-	return {base, base + (size_t)(c->cfg.Y - 1) * ld, base - ld, base + (size_t)c->cfg.Y * ld, ld * sizeof(uint64_t)};
+	return {base, base + ((size_t)c->cfg.Y - d) * ld, base - d * ld, base + (size_t)c->cfg.Y * ld, d * ld * sizeof(uint64_t)};
 }
 
 // Delivers the first/last rows of `color` of the local slabs on their comm streams; `after_edges`: the comm streams first
 // wait for the slabs' edge-row kernels (ev_edge[color]).  Records ev_sent[color] (spin colours only).
-int transfer(ising_ctx **ctxs, int n, int color, bool after_edges) {
+int transfer(ising_ctx **ctxs, int n, int color, bool after_edges, int depth = 1) {
 	if (ctxs[0]->cfg.XSL) return ISING_OK; // sub-lattices never reach across slabs
 	const bool spin = color != ISING_HAM_BLACK;
+	if (spin) for (int k = 0; k < n; k++) ctxs[k]->ghost_depth[color] = depth;
 	// Copies between slabs of ONE device go on the slab's compute stream: a second stream buys nothing there (the copy
 	// needs the same CUs / DMA engines the kernels hold) and every cross-stream event on a shared device is a bubble.
 	auto lane = [](const ising_ctx *c) { return c->copy_inline ? c->stream : c->comm; };
@@ -312,7 +314,7 @@ int transfer(ising_ctx **ctxs, int n, int color, bool after_edges) {
 			ising_ctx *c = ctxs[k];
 			ncclComm_t comm = static_cast<ncclComm_t>(c->rccl_comm);
 			const int nr = c->cfg.nslabs, me = c->cfg.slab, next = (me + 1) % nr, prev = (me + nr - 1) % nr;
-			const EdgeRows e = edge_rows(c, color);
+			const EdgeRows e = edge_rows(c, color, depth);
 			if (int rc = bind(c)) { (void)api->GroupEnd(); return rc; }
 			// With two ranks prev == next: the peer's first receive (its top halo row, "from prev") must match our LAST
 			// row, so the last row is sent first; receives are posted in the same order.
@@ -330,7 +332,7 @@ int transfer(ising_ctx **ctxs, int n, int color, bool after_edges) {
 		for (int k = 0; k < n; k++) {
 			ising_ctx *c = ctxs[k], *prev = c->ring_prev, *next = c->ring_next;
 			if (!prev || !next) return fail(ISING_E_STATE, "slab %d is not part of a single-process ring", c->cfg.slab);
-			const EdgeRows e = edge_rows(c, color), ep = edge_rows(prev, color), en = edge_rows(next, color);
+			const EdgeRows e = edge_rows(c, color, depth), ep = edge_rows(prev, color, depth), en = edge_rows(next, color, depth);
 			if (int rc = bind(c)) return rc;
 			// next slab's top halo <- my last row ; previous slab's bottom halo <- my first row
 			HIP_TRY(hipMemcpyPeerAsync(en.halo_top, next->cfg.device, e.last, c->cfg.device, e.bytes, lane(c)));
@@ -504,8 +506,60 @@ int sweep_published(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 	return ISING_OK;
 }
 
+// Every slab's first / last `depth` rows of `color` to its neighbours' ghost rows, behind whatever the compute streams hold.
+int exchange_rows(ising_ctx **ctxs, int n, int color, int depth) {
+	for (int k = 0; k < n; k++) {
+		ising_ctx *c = ctxs[k];
+		if (int rc = bind(c)) return rc;
+		HIP_TRY(hipEventRecord(c->ev_edge[color], c->stream));
+	}
+	if (ctxs[0]->transport != ISING_TRANSPORT_RCCL) {
+		// peer copies write into the neighbours' ghost rows: their launches, which read those rows, must be done too
+		for (int k = 0; k < n; k++) {
+			ising_ctx *c = ctxs[k], *prev = c->ring_prev, *next = c->ring_next;
+			if (int rc = bind(c)) return rc;
+			hipStream_t lane = c->copy_inline ? c->stream : c->comm;
+			if (prev && prev != c) HIP_TRY(hipStreamWaitEvent(lane, prev->ev_edge[color], 0));
+			if (next && next != c && next != prev) HIP_TRY(hipStreamWaitEvent(lane, next->ev_edge[color], 0));
+			if (c->copy_inline) HIP_TRY(hipStreamWaitEvent(lane, c->ev_edge[color], 0));
+		}
+	}
+	return transfer(ctxs, n, color, true, depth);
+}
+
+// Ballot slabs with G > 1 ghost rows (ising_ctx::ghost_rows): G rows of both colours travel every G colour half-sweeps, and
+// ONE fused launch of G levels runs in between -- over the slab's rows and its ghost rows, whose draws are the ones their
+// owners make (the generator is counter-based: global row, column, iteration), so both sides of a cut compute the same
+// bits and what a level can no longer know of a ghost row never reaches a row it does.  The ring then costs one
+// exchange and one launch boundary per G/2 sweeps instead of two launches, a send/recv pair and their events per colour;
+// the bytes per sweep are the same.  The reference exchanges one row per colour half-sweep (optimized/main.cu:1779-1805).
+int sweep_deep(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
+	const int G = ctxs[0]->ghost();
+	bool current = true;
+	for (int k = 0; k < n; k++) current = current && ctxs[k]->ghost_depth[0] >= G && ctxs[k]->ghost_depth[1] >= G;
+	if (!current)
+		for (int color = 0; color < 2; color++) if (int rc = exchange_rows(ctxs, n, color, G)) return rc;
+	for (int it = first_it, left = nsweeps; left > 0;) {
+		const int ns = std::min(left, G / 2);
+		for (int k = 0; k < n; k++) {
+			ising_ctx *c = ctxs[k];
+			for (int color = 0; color < 2; color++) if (int rc = ising_host::halo_ready(c, color)) return rc;
+			if (int rc = ising_host::update_deep(c, it, 2 * ns)) return rc;
+		}
+		for (int color = 0; color < 2; color++) if (int rc = exchange_rows(ctxs, n, color, G)) return rc;
+		it += ns;
+		left -= ns;
+	}
+	return ISING_OK;
+}
+
 int sweep_local(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 	if (int rc = settle_layout(ctxs, n)) return rc;
+	{
+		bool deep = nsweeps > 0 && !ctxs[0]->store_ring && !ctxs[0]->cfg.XSL && ctxs[0]->ghost() > 1;
+		for (int k = 0; k < n; k++) deep = deep && ctxs[k]->ballot && ctxs[k]->ghost() == ctxs[0]->ghost() && !ising_host::needs_generic(ctxs[k]) && !ctxs[k]->store_ring;
+		if (deep) return sweep_deep(ctxs, n, first_it, nsweeps);
+	}
 	if (ctxs[0]->store_ring && !ctxs[0]->cfg.XSL) { // one launch per slab and colour; the stream orders the rest
 		for (int it = first_it; it < first_it + nsweeps; it++)
 			for (int color = 0; color < 2; color++)
@@ -623,7 +677,9 @@ int ising_ring_exchange(ising_ctx **ctxs, int n, int color) {
 		if (color != ISING_HAM_BLACK) HIP_TRY(hipEventRecord(c->ev_edge[color], c->stream));
 		else HIP_TRY(hipStreamSynchronize(c->stream));
 	}
-	return transfer(ctxs, n, color, true);
+	int depth = color == ISING_HAM_BLACK ? 1 : ctxs[0]->ghost(); // spin colours: as deep as the slabs' ghost rows go
+	for (int k = 0; k < n; k++) if (ctxs[k]->ghost() != ctxs[0]->ghost()) depth = 1;
+	return transfer(ctxs, n, color, true, depth);
 }
 
 int ising_ring_sweep(ising_ctx **ctxs, int n, int first_it, int nsweeps) {

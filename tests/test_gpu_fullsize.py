@@ -118,3 +118,47 @@ def test_config4_131072_cli_eight_devices_mapped_to_one(gpu):
     for pt in (p1, p2):
         assert (f"        magnetization: {abs(pt['up'] - pt['down']) / n:9.6f}, up_s: {pt['up']:12d}, dw_s: {pt['down']:12d} "
                 f"(iter: {pt['sweeps']:8d})\n") in r.stdout
+
+
+_RING_OF_ONE = {
+    "rccl, ghost rows 32 deep (default)": ("native", {}),
+    "rccl, one halo row, event schedule": ("native", {"ISING_RING_GHOST": "1"}),
+    "rccl, one halo row, flag schedule": ("native", {"ISING_RING_GHOST": "1", "ISING_RING_FLAGS": "1"}),
+    "rccl, caller-owned buffer": ("native-torch", {}),
+    "copies, ghost rows, two streams": ("copy", {"ISING_RING_INLINE": "0", "ISING_RING_STORE": "0"}),
+    "copies, one halo row, two streams": ("copy", {"ISING_RING_GHOST": "1", "ISING_RING_INLINE": "0", "ISING_RING_STORE": "0"}),
+    "copies, one halo row, one stream": ("copy", {"ISING_RING_GHOST": "1", "ISING_RING_INLINE": "1", "ISING_RING_STORE": "0"}),
+}
+
+
+@pytest.mark.parametrize("case", list(_RING_OF_ONE))
+def test_ring_of_one_at_the_bench_size_every_schedule(gpu, monkeypatch, case):
+    """One GPU of a ring at the size bench.py runs (65536^2, T_c, seed 1234), through every schedule, transport and buffer
+    owner of the slab ring, against the oracle's counts after 5, 21 and 25 sweeps.  At this size the edge-row launch on the
+    comm stream really runs next to the interior launch on the compute stream -- which is where the two launches once
+    shared their accept-mask slots (wrong spins at 65536^2, right ones at every test size)."""
+    kind, env = _RING_OF_ONE[case]
+    for k in ("ISING_RING_GHOST", "ISING_RING_FLAGS", "ISING_RING_INLINE", "ISING_RING_STORE"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    fx = json.load(open(os.path.join(GOLD, "bench_65536_tc.json")))
+    gold = {p["sweeps"]: (p["up"], p["down"]) for p in fx["points"]}
+    X, Y, seed = fx["X"], fx["Ytot"], fx["seed"]
+    if kind == "native-torch":
+        import torch  # noqa: F401
+        slab = ig.HipSlabBackend.create(X, Y, device=0, seed=seed, temp=ig.CRIT_TEMP_F32, nslabs=1, slab=0, ring_halo=True).slab
+    else:
+        slab = ig.IsingSlab(X, Y, seed=seed, temp=ig.CRIT_TEMP_F32, ring_halo=True)
+    try:
+        ring = ig.NativeRing(slab) if kind.startswith("native") else ig.SlabSet([slab])
+        ring.init()
+        done = 0
+        for upto in (5, 21, 25):
+            ring.sweep(upto - done)
+            done = upto
+            assert ring.count() == gold[upto], (case, upto)
+        if kind.startswith("native"):
+            ring.close()
+    finally:
+        slab.close()
