@@ -15,8 +15,9 @@ to each ring neighbour per half-sweep.  The lattice is generated on the device f
           --warmup 5) the timed steps and the warm-up are cut on their own (one call of 20, one of 5): `config.sweeps_per_call`
           and `roofline.half_sweeps_per_launch` describe the timed launches.
   N > 1   one process per GPU; the ring lives inside libising_hip.so (ising_rank_*: second HIP stream + RCCL send/recv);
-          if that transport does not come up the torch.distributed ring (p2p, then all-gather) takes over and the JSON
-          line says which one ran.  The counts after warm-up + steps are compared with the oracle's committed goldens
+          ballot ring slabs keep ghost rows 32 deep, exchange 32 rows of both colours every 16 sweeps and run one fused launch
+          in between (sweep_deep); if that transport does not come up the torch.distributed ring (p2p, then all-gather, one
+          row per colour half-sweep on a torch-owned slab) takes over and the JSON line says which one ran.  The counts after warm-up + steps are compared with the oracle's committed goldens
           (tests/golden/bench_65536_tc.json, ring_65536_tc.json) when the run hits one of their points.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
@@ -145,11 +146,21 @@ def main():
         ring, ring_name = None, "none"
         slab.init()
     else:
-        # torch owns the slab's device buffer, so the rows the torch ring hands to RCCL are slices of an ordinary tensor
-        backend = ig.HipSlabBackend.create(args.x, args.y, device=local_rank, seed=args.seed, temp=ig.CRIT_TEMP_F32,
-                                           nslabs=world, slab=rank, strip_rows=args.strip_rows, layout=layout, ring_halo=world == 1)
-        slab = backend.slab
-        ring, ring_name = ig.open_ring(backend, prefer="torch" if args.exchange else args.ring, exchange=args.exchange, log=log)
+        ring = None
+        if args.ring == "native" and not args.exchange:
+            # the library's own ring on a slab that owns its buffer: ballot ring slabs then keep ghost rows 32 deep, exchange
+            # every 16 sweeps and run fused launches in between (csrc/ising_ring.cpp: sweep_deep)
+            slab = ig.IsingSlab(args.x, args.y, device=local_rank, seed=args.seed, temp=ig.CRIT_TEMP_F32, nslabs=world, slab=rank,
+                                strip_rows=args.strip_rows, layout=layout, ring_halo=world == 1)
+            ring, ring_name = ig.open_native_ring(slab, log=log), "rccl-native"
+            if ring is None:
+                slab.close()
+        if ring is None:
+            # torch owns the slab's device buffer, so the rows the torch ring hands to RCCL are slices of an ordinary tensor
+            backend = ig.HipSlabBackend.create(args.x, args.y, device=local_rank, seed=args.seed, temp=ig.CRIT_TEMP_F32,
+                                               nslabs=world, slab=rank, strip_rows=args.strip_rows, layout=layout, ring_halo=world == 1)
+            slab = backend.slab
+            ring, ring_name = ig.open_ring(backend, prefer="torch", exchange=args.exchange, log=log)
 
     # sweeps per ising_sweep call: the largest common divisor of steps and warm-up that one fused launch can carry (32), so
     # that every launch of the run is the same piece of work -- unless that leaves pieces under 16 sweeps (the driver's
@@ -236,9 +247,14 @@ def main():
     if rank == 0:
         # dominant kernel = the update kernel.  N = 1 on the ballot layout: fused launches of `batch` sweeps; otherwise two
         # full-slab launches per step (with N > 1 each colour adds one tiny edge-row launch).
-        fused = not ringed and layout_name == "ballot" and slab.fused
-        half_sweeps_per_launch = 2 * batch if fused else 1
-        launches = args.steps // batch + (1 if args.steps % batch else 0) if fused else 2 * args.steps
+        fused = layout_name == "ballot" and slab.fused
+        if fused and ringed:  # the library's ring on ghost rows: fused launches of up to max_sweeps_per_launch sweeps between exchanges
+            per = max(1, slab.max_sweeps_per_launch)
+            launches = (args.steps + per - 1) // per
+            half_sweeps_per_launch = 2.0 * args.steps / launches
+        else:
+            half_sweeps_per_launch = 2 * batch if fused else 1
+            launches = args.steps // batch + (1 if args.steps % batch else 0) if fused else 2 * args.steps
         avg_launch_ms = ev_ms / launches
         alg_bytes_per_launch = BYTES_PER_FLIP * spins_per_gpu / 2.0 * half_sweeps_per_launch  # per colour: src read + dst read + dst write
         achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9

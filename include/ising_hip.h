@@ -172,7 +172,8 @@ int ising_strip_info(ising_ctx *ctx, int *strip_rows, int *nstrips);
 int ising_sweep(ising_ctx *ctx, int first_it, int nsweeps);
 /* How ising_sweep launches right now: *fused = 1 when it issues fused launches (ballot layout from 2^26 spins up, or
  * ISING_FUSED=1: one launch carries up to *max_sweeps_per_launch sweeps = twice as many colour half-sweeps, handed out to
- * a chip-filling grid through in-order tickets; ising_ballot.hip), 0 when it issues one launch per colour. */
+ * a chip-filling grid through in-order tickets; ising_ballot.hip), 0 when it issues one launch per colour.  For a ring slab
+ * with ghost rows G deep (ballot layout): how the ring sweeps it -- fused launches of up to G/2 sweeps between exchanges. */
 int ising_sweep_info(ising_ctx *ctx, int *fused, int *max_sweeps_per_launch);
 /* Same, bracketed by HIP events on the context's stream; returns elapsed milliseconds (blocking). */
 int ising_sweep_timed(ising_ctx *ctx, int first_it, int nsweeps, float *elapsed_ms);

@@ -759,8 +759,10 @@ int ising_sweep(ising_ctx *c, int first_it, int nsweeps) {
 int ising_sweep_info(ising_ctx *c, int *fused, int *max_sweeps_per_launch) {
 	if (!c) return fail(ISING_E_ARG, "null context");
 	const bool f = c->wrap && c->ballot && c->fused && !c->cfg.XSL && !ising_host::needs_generic(c);
-	if (fused) *fused = f ? 1 : 0;
-	if (max_sweeps_per_launch) *max_sweeps_per_launch = f ? 32 : 0;
+	// (a ring slab with ghost rows G deep: the ring's sweeps are fused launches of G/2 sweeps between two exchanges)
+	const bool deep = !c->wrap && c->ballot && c->ghost() > 1 && !c->store_ring && !c->cfg.XSL && !ising_host::needs_generic(c);
+	if (fused) *fused = (f || deep) ? 1 : 0;
+	if (max_sweeps_per_launch) *max_sweeps_per_launch = f ? 32 : (deep ? c->ghost() / 2 : 0);
 	return ISING_OK;
 }
 

@@ -628,6 +628,10 @@ int ising_host::halo_ready_on(ising_ctx *c, int color, hipStream_t s) {
 	auto same_lane = [&](const ising_ctx *o) { return o->copy_inline && o->stream == s && o->cfg.device == c->cfg.device; };
 	if (prev && prev->ev_sent[color] && !same_lane(prev)) HIP_TRY(hipStreamWaitEvent(s, prev->ev_sent[color], 0));
 	if (next && next != prev && next->ev_sent[color] && !same_lane(next)) HIP_TRY(hipStreamWaitEvent(s, next->ev_sent[color], 0));
+	// this slab's own copies (its rows to the neighbours' halo rows, on its comm stream) must be done before stream `s`
+	// overwrites the rows they read -- a fused launch over the whole slab (sweep_deep), a layout change -- unless they
+	// travel on `s` itself
+	if (c != prev && c != next && c->ev_sent[color] && !same_lane(c) && !(s == c->comm)) HIP_TRY(hipStreamWaitEvent(s, c->ev_sent[color], 0));
 	return ISING_OK;
 }
 

@@ -147,6 +147,14 @@ class IsingSlab:
         check(self._lib.ising_sweep_info(self._h, C.byref(f), C.byref(m)))
         return bool(f.value)
 
+    @property
+    def max_sweeps_per_launch(self) -> int:
+        """Sweeps one fused launch carries at most (0: one launch per colour); for a ring slab with ghost rows: between
+        two exchanges of the ring."""
+        f, m = C.c_int(), C.c_int()
+        check(self._lib.ising_sweep_info(self._h, C.byref(f), C.byref(m)))
+        return int(m.value)
+
     def sweep_timed(self, n: int) -> float:
         ms = C.c_float()
         check(self._lib.ising_sweep_timed(self._h, self.it + 1, n, C.byref(ms)))

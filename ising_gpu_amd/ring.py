@@ -371,6 +371,39 @@ class NativeRing:
         self.slab.rank_detach(abort)
 
 
+def open_native_ring(slab, log=None):
+    """The library's own RCCL ring on a slab that owns its buffer (ring slabs on the ballot layout then keep ghost rows
+    32 deep and exchange every 16 sweeps, csrc/ising_ring.cpp: sweep_deep) -- or None when it does not come up on every
+    rank (the caller then builds a torch-owned slab and calls open_ring for the torch.distributed rings)."""
+    log = log or (lambda *a: None)
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    ring = None
+    try:
+        ring = NativeRing(slab)
+        ring.init()
+        ring.sweep(1)  # one real sweep through the transport before it is trusted
+        ring.quiesce()
+        torch.cuda.synchronize()
+        ok = True
+    except Exception as e:  # noqa: BLE001 -- any transport failure means: the caller tries the next one
+        log(f"ring transport rccl-native failed on this rank: {e}")
+        ok = False
+    if world > 1:
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(int(t[0]))
+    if ok:
+        return ring
+    if ring is not None:
+        try:
+            ring.close(abort=True)
+        except Exception:  # noqa: BLE001
+            pass
+    return None
+
+
 def open_ring(backend: "HipSlabBackend", prefer: str = "native", exchange: Optional[str] = None, log=None):
     """The ring a multi-process driver (bench.py) should use: the library's own RCCL ring when it comes up, otherwise
     the torch.distributed one (p2p, then all-gather).  Every rank takes the same decision: the outcome of each attempt is
