@@ -21,8 +21,15 @@ rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int
 torch.cuda.set_device(local)
 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 X, Y, seed, temp, sweeps = 8192, 64, 2024, ig.CRIT_TEMP_F32, 5
-for layout in (ig.LAYOUT_BALLOT, ig.LAYOUT_DENSE):
-    backend = ig.HipSlabBackend.create(X, Y, device=local, seed=seed, temp=temp, nslabs=world, slab=rank, layout=layout)
+# native: a slab that owns its buffer (ballot layout: ghost rows 32 deep, one exchange per 16 sweeps) and a torch-owned one (one halo row)
+cases = [(lay, own) for lay in (ig.LAYOUT_BALLOT, ig.LAYOUT_DENSE) for own in ((True, False) if mode == "native" else (False,))]
+for layout, own in cases:
+    if own:
+        class _B:  # same shape as HipSlabBackend for what follows
+            slab = ig.IsingSlab(X, Y, device=local, seed=seed, temp=temp, nslabs=world, slab=rank, layout=layout)
+        backend = _B
+    else:
+        backend = ig.HipSlabBackend.create(X, Y, device=local, seed=seed, temp=temp, nslabs=world, slab=rank, layout=layout)
     ring = ig.NativeRing(backend.slab) if mode == "native" else ig.SlabRing(backend, exchange=mode)
     ring.init()
     ring.sweep(2).sweep(sweeps - 2)
@@ -33,7 +40,7 @@ for layout in (ig.LAYOUT_BALLOT, ig.LAYOUT_DENSE):
     ok = np.array_equal(backend.slab.read(ig.BLACK), orc.black[lo:hi]) and np.array_equal(backend.slab.read(ig.WHITE), orc.white[lo:hi])
     tot, bond = ring.count(), ring.bond_equal()
     good = ok and tot == orc.count() and bond == orc.bond_equal()
-    print(f"rank {rank} {mode} layout {layout}: slab {'==' if ok else '!='} oracle rows [{lo},{hi}); counts {tot} bond {bond} "
+    print(f"rank {rank} {mode} layout {layout} {'library-owned' if own else 'torch-owned'} buffer: slab {'==' if ok else '!='} oracle rows [{lo},{hi}); counts {tot} bond {bond} "
           f"{'==' if good else '!='} oracle", flush=True)
     assert good
     if mode == "native":
