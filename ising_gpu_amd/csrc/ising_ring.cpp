@@ -786,7 +786,7 @@ int ising_rank_exchange(ising_ctx *c, int color) {
 	if (int rc = bind(c)) return rc;
 	if (color != ISING_HAM_BLACK) HIP_TRY(hipEventRecord(c->ev_edge[color], c->stream));
 	else HIP_TRY(hipStreamSynchronize(c->stream));
-	return transfer(&c, 1, color, true);
+	return transfer(&c, 1, color, true, color == ISING_HAM_BLACK ? 1 : c->ghost()); // (spin colours: as deep as the ghost rows go)
 }
 
 int ising_rank_sweep(ising_ctx *c, int first_it, int nsweeps) {
