@@ -550,6 +550,11 @@ int ising_strip_info(ising_ctx *c, int *strip_rows, int *nstrips) {
 // `color` at iteration `it`
 // `stop` (optional): an event that fires when the launch is done
 static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int lo1, int hi1, int nlevels = 1, bool publish = false, hipEvent_t stop = nullptr) {
+	// one-shot requests of the ring schedules for THIS launch (taken here, so that an early return cannot leave them set)
+	const bool edge_scratch = c->edge_scratch_next;
+	const int sync_mode = c->sync_mode;
+	c->edge_scratch_next = false;
+	c->sync_mode = 0;
 	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
 	if (it < 0) return fail(ISING_E_ARG, "negative iteration %d", it);
 	int mode = c->cfg.kernel == ISING_KERNEL_GENERIC ? 1 : (c->cfg.kernel == ISING_KERNEL_LUT ? 2 : 0); // AUTO, FAST -> 0
@@ -612,7 +617,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	// Flag-synchronised ring schedule, interior rows: the strips are taken from both ends inwards, so that the two boundary
 	// strips are the launch's first units (the edge-row launch of the next colour waits for them), and the one-row tail
 	// strips are the MIDDLE rows, which that order reaches last.
-	const bool middle_tail = c->ballot && c->sync_mode == 1 && c->d_flags && nlevels == 1 && H2 && (c->tail_rows % c->H) == 0;
+	const bool middle_tail = c->ballot && sync_mode == 1 && c->d_flags && nlevels == 1 && H2 && (c->tail_rows % c->H) == 0;
 	if (middle_tail) {
 		const int lo = lo0, hi = hi1, N = (hi - lo + c->H - 1) / c->H; // strips of the whole span
 		int mid = c->tail_rows / c->H;                                    // strips that become one-row units
@@ -636,8 +641,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	p.lut = c->d_lut;
 	// the reference hands hamW to the BLACK update and hamB to the WHITE one (optimized/main.cu:1774, :1795)
 	p.jdst = c->cfg.use_J ? c->ham(other) : nullptr;
-	p.scratch = (c->edge_scratch_next && c->d_scratch_edge) ? c->d_scratch_edge : c->d_scratch;
-	c->edge_scratch_next = false;
+	p.scratch = (edge_scratch && c->d_scratch_edge) ? c->d_scratch_edge : c->d_scratch;
 	if (c->ballot) {
 		p.ticket = reinterpret_cast<unsigned long long *>(c->d_slotctl);
 		p.nlevels = nlevels;
@@ -662,24 +666,23 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			p.edge_signal = c->d_signal[color];
 			c->edge_target[color] += (uint32_t)c->nwc() * (c->nstrips == 1 ? 1u : 2u); // wave columns of the strips with row 0 / Y-1
 		}
-		if (c->sync_mode && c->d_flags && nlevels == 1) {
+		if (sync_mode && c->d_flags && nlevels == 1) {
 			// flag-synchronised ring schedule (ising_ring.cpp): interior rows wait for the edge-row launches so far and count
 			// their two boundary strips; edge rows the other way round
-			const int mine = c->sync_mode == 1 ? 0 : 1;
+			const int mine = sync_mode == 1 ? 0 : 1;
 			p.sync_wait = c->d_flags + (1 - mine);
 			p.sync_need = c->flag_target[1 - mine];
 			p.edge_signal = c->d_flags + mine;
 			const int last_hi = p.zigzag0 ? p.row_hi[0] : (hi1 > lo1 ? hi1 : hi0);
-			p.sync_row[0] = c->sync_mode == 1 ? lo0 : 0;
-			p.sync_row[1] = c->sync_mode == 1 ? last_hi - 1 : c->cfg.Y - 1;
+			p.sync_row[0] = sync_mode == 1 ? lo0 : 0;
+			p.sync_row[1] = sync_mode == 1 ? last_hi - 1 : c->cfg.Y - 1;
 			unsigned units = 0; // units (strip x wave column) that hold one of the two rows
 			if (hi0 > lo0 || hi1 > lo1) {
-				if (c->sync_mode == 2) units = (lo1 < hi1 && hi0 > lo0) ? 2u : 1u;
+				if (sync_mode == 2) units = (lo1 < hi1 && hi0 > lo0) ? 2u : 1u;
 				else units = (p.zigzag0 || hi1 > lo1 || (hi0 - lo0 + c->H - 1) / c->H > 1) ? 2u : 1u;
 			}
 			c->flag_target[mine] += units * (uint32_t)c->nwc();
 		}
-		c->sync_mode = 0;
 		int grid = 0;
 		HIP_TRY(ising::launch_ballot_update(p, c->stream, &grid, stop));
 		if (nlevels > 1) {
