@@ -147,3 +147,25 @@ def test_multi_process_ring_over_nccl(gpu, mode):
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("slab == oracle rows") == 2 * n and "!=" not in r.stdout, r.stdout[-3000:]
+
+
+def test_ring_slabs_keep_ghost_rows_where_they_can(gpu, monkeypatch):
+    """Ballot ring slabs that own their buffer keep ghost rows (min(32, Y/2) deep; ising_sweep_info: the ring sweeps them in
+    fused launches of half as many sweeps); the dense layout, -J, a caller-owned buffer and ISING_RING_GHOST=1 do not."""
+    import torch  # noqa: F401
+    with ig.IsingSlab(8192, 128, nslabs=2, slab=0, layout=ig.LAYOUT_BALLOT) as s:
+        assert s.fused and s.max_sweeps_per_launch == 16
+    with ig.IsingSlab(8192, 32, nslabs=2, slab=0, layout=ig.LAYOUT_BALLOT) as s:
+        assert s.fused and s.max_sweeps_per_launch == 8
+    with ig.IsingSlab(8192, 128, nslabs=2, slab=0, layout=ig.LAYOUT_DENSE) as s:
+        assert not s.fused and s.max_sweeps_per_launch == 0
+    with ig.IsingSlab(8192, 128, nslabs=2, slab=0, layout=ig.LAYOUT_BALLOT, J_prob=0.2) as s:
+        assert not s.fused
+    b = ig.HipSlabBackend.create(8192, 128, device=0, nslabs=2, slab=0, layout=ig.LAYOUT_BALLOT)
+    try:
+        assert not b.slab.fused
+    finally:
+        b.slab.close()
+    monkeypatch.setenv("ISING_RING_GHOST", "1")
+    with ig.IsingSlab(8192, 128, nslabs=2, slab=0, layout=ig.LAYOUT_BALLOT) as s:
+        assert not s.fused
