@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	// Fused launches: thread 0 draws the NEXT ticket in a unit's last iteration and leaves it in LDS before that
 	// iteration's barrier, where the workgroup picks it up.  (Built with -amdgpu-atomic-optimizer-strategy=None: the
 	// wave-aggregating rewrite of atomicAdd needs the result on the spot.)
-	// The counter is never reset: a launch's tickets start at p.ticket_base = where the launches before it left the counter
+	// The counter is never reset: a launch's tickets start at p.ticket_base2[] = where the launches before it left the counter
 	// (each of their `grid` workgroups drew exactly one ticket past its launch's last), which the host keeps count of --
 	// a memset in front of every launch is a fill kernel of its own and two more dependencies in the stream.
 	// Row of the whole lattice behind slab row r.  Ghost rows of a ring slab (r < 0, r >= Y: ising_ring.cpp, sweep_deep) are
@@ -234,7 +234,15 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		if (p.total_rows) gr = gr < 0 ? gr + p.total_rows : (gr >= p.total_rows ? gr - p.total_rows : gr);
 		return (uint32_t)gr;
 	};
-	auto draw_ticket = [&]() { return atomicAdd(p.ticket, 1ull) - p.ticket_base; };
+	// Small lattices with short units draw tickets faster than one counter hands them out (~80 per us chip-wide): then two
+	// counters (p.tickets2, 64 bytes apart) -- workgroups with an even blockIdx hand out the even unit numbers in order, the
+	// odd ones the odd numbers.  The lowest unfinished unit is still held by a running workgroup of its class or about to be
+	// drawn by one, so nothing waits for ever.  8192^2: 2460 -> 2527 flips/ns; from 2^27 spins up one counter is faster.
+	const unsigned cls = p.tickets2 ? (blockIdx.x & 1u) : 0u;
+	auto draw_ticket = [&]() {
+		const unsigned long long t = atomicAdd(p.ticket + 8 * cls, 1ull) - p.ticket_base2[cls];
+		return p.tickets2 ? 2ull * t + cls : t;
+	};
 	unsigned long long tkv = 0; // this workgroup's ticket as read from LDS (every lane the same value)
 	// The workgroups of a launch start a fraction of a row apart (by the round of 256 they were dispatched in) instead of
 	// in lockstep -- all drawing, then all waiting: +0.3..0.6 % on whole runs, more on short launches (4-wave form;
@@ -818,6 +826,7 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 		else if (p.wg_per_cu > 0) grid = std::min<long long>(grid, (long long)p.wg_per_cu * cus);
 	}
 	if (grid < 1) grid = 1;
+	if (grid < 2 || total < 2) p.tickets2 = 0; // (two counters need a workgroup of either parity)
 	const dim3 g((unsigned)grid), block(NT);
 	// `stop`: an event that fires when this launch is done, hung on the dispatch packet itself (hipExtLaunchKernelGGL) --
 	// a hipEventRecord behind the launch is a packet of its own that drains the queue: 7 us between two 650 us launches

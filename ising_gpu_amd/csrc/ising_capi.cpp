@@ -381,6 +381,10 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (fused_shape) { // workgroups per CU of a fused launch (the chip holds 6 of 4 waves, 3 of 8)
 		const long long T = fused_tickets(c->nwc(), cfg->Y, c->H, c->fused_wide != 0);
 		c->fused_wg_per_cu = c->fused_wide ? (T >= 2048 ? 3 : 2) : (T >= 16384 ? 6 : (T >= 8192 ? 5 : (T >= 2048 ? 4 : 3)));
+		// two ticket counters where 4-wave workgroups draw two-row units (2^26 spins): one counter hands out ~80 tickets
+		// per us, 8192^2 at 2500 flips/ns needs 76 (ISING_FUSED_TICKETS2=0/1 overrides)
+		c->fused_tickets2 = !c->fused_wide && T <= 1024 && c->H <= 2;
+		if (const char *e2 = getenv("ISING_FUSED_TICKETS2")) c->fused_tickets2 = atoi(e2) != 0;
 	}
 	// A ring slab on the ballot layout keeps G ghost rows on either side (ising_ctx::ghost_rows; ising_ring.cpp: sweep_deep):
 	// G rows of both colours travel every G colour half-sweeps, fused launches of G levels run in between.  Not with -J
@@ -651,7 +655,9 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 		p.ticket = reinterpret_cast<unsigned long long *>(c->d_slotctl);
 		p.nlevels = nlevels;
 		if (nlevels > 1) {
-			p.ticket_base = c->ticket_base; // (the counter is never reset, ising_ballot.hip)
+			p.ticket_base2[0] = c->ticket_base2[0]; // (the counters are never reset, ising_ballot.hip)
+			p.ticket_base2[1] = c->ticket_base2[1];
+			p.tickets2 = c->fused_tickets2;
 			if (c->done_base > (1u << 30)) { // keep the monotone completion counters far from wrapping
 				HIP_TRY(hipMemsetAsync(c->d_slotctl + SLOTCTL_TICKET_BYTES / 4, 0, ((size_t)c->nstrips + 2 * (size_t)c->ghost_rows + 2) * sizeof(uint32_t), c->stream));
 				c->done_base = 0;
@@ -692,7 +698,14 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 		HIP_TRY(ising::launch_ballot_update(p, c->stream, &grid, stop));
 		if (nlevels > 1) {
 			c->done_base += (uint32_t)nlevels * (uint32_t)c->nwc();
-			c->ticket_base += (unsigned long long)p.nwg * (unsigned long long)nlevels + (unsigned long long)grid; // every workgroup drew one ticket too many
+			// where the launch leaves the counter(s): its units, and every workgroup drew one ticket too many
+			const unsigned long long total = (unsigned long long)p.nwg * (unsigned long long)nlevels;
+			if (p.tickets2) {
+				c->ticket_base2[0] += (total + 1) / 2 + ((unsigned long long)grid + 1) / 2;
+				c->ticket_base2[1] += total / 2 + (unsigned long long)grid / 2;
+			} else {
+				c->ticket_base2[0] += total + (unsigned long long)grid;
+			}
 		}
 		return ISING_OK;
 	}
