@@ -344,7 +344,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// workgroups run, or units find their parents unfinished and hold their slots asleep: the strip height H follows
 	// from T = wave rows / (H x waves per workgroup), and small lattices run FEWER workgroups than the chip holds.
 	// Measured (tools/grid_probe.py, grid_probe2.py), flips/ns fused vs one launch per colour + tail strips:
-	//   2^26 (8192^2)    4-wave workgroups, H = 2, 3 per CU (T = 1024)      2455 vs 2125 (dense layout 2150)
+	//   2^26 (8192^2)    4-wave workgroups, H = 2, 3 per CU (T = 1024), two ticket counters      2527 vs 2125 (dense layout 2150)
 	//   2^27             8-wave workgroups, H = 2, 2 per CU (T = 1024)      2908 vs 2580
 	//   2^28 (16384^2)   4-wave, H = 4, 4 per CU (T = 2048)                 3099 vs 3048
 	//   2^29 ...         4-wave, the tallest H of 16, 8, 4 with T >= 8192 (else 4), 5 per CU (6 from T = 16384, 4 below 8192):
