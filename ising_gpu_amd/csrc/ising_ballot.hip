@@ -238,10 +238,11 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	// counters (p.tickets2, 64 bytes apart) -- workgroups with an even blockIdx hand out the even unit numbers in order, the
 	// odd ones the odd numbers.  The lowest unfinished unit is still held by a running workgroup of its class or about to be
 	// drawn by one, so nothing waits for ever.  8192^2: 2460 -> 2527 flips/ns; from 2^27 spins up one counter is faster.
-	const unsigned cls = p.tickets2 ? (blockIdx.x & 1u) : 0u;
+	const unsigned ncnt = p.tickets2 > 1 ? (unsigned)p.tickets2 : 1u; // 1, 2 or 4 counters
+	const unsigned cls = blockIdx.x & (ncnt - 1u);
 	auto draw_ticket = [&]() {
 		const unsigned long long t = atomicAdd(p.ticket + 8 * cls, 1ull) - p.ticket_base2[cls];
-		return p.tickets2 ? 2ull * t + cls : t;
+		return (unsigned long long)ncnt * t + cls;
 	};
 	unsigned long long tkv = 0; // this workgroup's ticket as read from LDS (every lane the same value)
 	// The workgroups of a launch start a fraction of a row apart (by the round of 256 they were dispatched in) instead of
@@ -826,7 +827,7 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 		else if (p.wg_per_cu > 0) grid = std::min<long long>(grid, (long long)p.wg_per_cu * cus);
 	}
 	if (grid < 1) grid = 1;
-	if (grid < 2 || total < 2) p.tickets2 = 0; // (two counters need a workgroup of either parity)
+	if (grid < p.tickets2 || total < p.tickets2) p.tickets2 = 0; // (k counters need a workgroup of every class)
 	const dim3 g((unsigned)grid), block(NT);
 	// `stop`: an event that fires when this launch is done, hung on the dispatch packet itself (hipExtLaunchKernelGGL) --
 	// a hipEventRecord behind the launch is a packet of its own that drains the queue: 7 us between two 650 us launches

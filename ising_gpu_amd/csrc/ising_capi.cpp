@@ -191,7 +191,8 @@ void ballot_planes_to_planes(uint64_t *ham, size_t ngroups) {
 // fused launches: tickets per level, and the strip height that keeps a level at >= 8192 tickets (ising_create)
 long long fused_tickets(int nwc, int Y, int H, bool wide) { return ((long long)nwc * ((Y + H - 1) / H) + (wide ? 7 : 3)) / (wide ? 8 : 4); }
 int choose_fused_strip_rows(int nwc, int Y, bool wide) {
-	if (wide || (long long)nwc * Y < 12288) return (Y % 2) == 0 ? 2 : 1; // up to 2^27 spins
+	if (!wide && (long long)nwc * Y < 12288) return 1;    // 2^26 spins: one-row units (four ticket counters, ising_create)
+	if (wide) return (Y % 2) == 0 ? 2 : 1;                  // 2^27 spins
 	for (int H = 16; H > 4; H >>= 1)
 		if ((Y % H) == 0 && fused_tickets(nwc, Y, H, false) >= 8192) return H;
 	return (Y % 4) == 0 ? 4 : ((Y % 2) == 0 ? 2 : 1);
@@ -344,7 +345,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// workgroups run, or units find their parents unfinished and hold their slots asleep: the strip height H follows
 	// from T = wave rows / (H x waves per workgroup), and small lattices run FEWER workgroups than the chip holds.
 	// Measured (tools/grid_probe.py, grid_probe2.py), flips/ns fused vs one launch per colour + tail strips:
-	//   2^26 (8192^2)    4-wave workgroups, H = 2, 3 per CU (T = 1024), two ticket counters      2527 vs 2125 (dense layout 2150)
+	//   2^26 (8192^2)    4-wave workgroups, H = 1, 4 per CU (T = 2048), four ticket counters     2606 vs 2125 (dense layout 2150)
 	//   2^27             8-wave workgroups, H = 2, 2 per CU (T = 1024)      2908 vs 2580
 	//   2^28 (16384^2)   4-wave, H = 4, 4 per CU (T = 2048)                 3099 vs 3048
 	//   2^29 ...         4-wave, the tallest H of 16, 8, 4 with T >= 8192 (else 4), 5 per CU (6 from T = 16384, 4 below 8192):
@@ -381,10 +382,11 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (fused_shape) { // workgroups per CU of a fused launch (the chip holds 6 of 4 waves, 3 of 8)
 		const long long T = fused_tickets(c->nwc(), cfg->Y, c->H, c->fused_wide != 0);
 		c->fused_wg_per_cu = c->fused_wide ? (T >= 2048 ? 3 : 2) : (T >= 16384 ? 6 : (T >= 8192 ? 5 : (T >= 2048 ? 4 : 3)));
-		// two ticket counters where 4-wave workgroups draw two-row units (2^26 spins): one counter hands out ~80 tickets
-		// per us, 8192^2 at 2500 flips/ns needs 76 (ISING_FUSED_TICKETS2=0/1 overrides)
-		c->fused_tickets2 = !c->fused_wide && T <= 1024 && c->H <= 2;
-		if (const char *e2 = getenv("ISING_FUSED_TICKETS2")) c->fused_tickets2 = atoi(e2) != 0;
+		// Several ticket counters where 4-wave workgroups draw one- or two-row units (2^26 spins): one counter hands out
+		// ~80 tickets per us; 8192^2 with one-row units at 2600 flips/ns needs 159 (four counters), with two-row units
+		// 79 (two).  ISING_FUSED_TICKETS2=0/2/4 overrides.
+		c->fused_tickets2 = (!c->fused_wide && T <= 2048 && c->H == 1) ? 4 : ((!c->fused_wide && T <= 1024 && c->H == 2) ? 2 : 0);
+		if (const char *e2 = getenv("ISING_FUSED_TICKETS2")) { const int k = atoi(e2); c->fused_tickets2 = (k == 2 || k == 4) ? k : (k ? 2 : 0); }
 	}
 	// A ring slab on the ballot layout keeps G ghost rows on either side (ising_ctx::ghost_rows; ising_ring.cpp: sweep_deep):
 	// G rows of both colours travel every G colour half-sweeps, fused launches of G levels run in between.  Not with -J
@@ -655,8 +657,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 		p.ticket = reinterpret_cast<unsigned long long *>(c->d_slotctl);
 		p.nlevels = nlevels;
 		if (nlevels > 1) {
-			p.ticket_base2[0] = c->ticket_base2[0]; // (the counters are never reset, ising_ballot.hip)
-			p.ticket_base2[1] = c->ticket_base2[1];
+			for (int k = 0; k < 4; k++) p.ticket_base2[k] = c->ticket_base2[k]; // (the counters are never reset, ising_ballot.hip)
 			p.tickets2 = c->fused_tickets2;
 			if (c->done_base > (1u << 30)) { // keep the monotone completion counters far from wrapping
 				HIP_TRY(hipMemsetAsync(c->d_slotctl + SLOTCTL_TICKET_BYTES / 4, 0, ((size_t)c->nstrips + 2 * (size_t)c->ghost_rows + 2) * sizeof(uint32_t), c->stream));
@@ -700,9 +701,9 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			c->done_base += (uint32_t)nlevels * (uint32_t)c->nwc();
 			// where the launch leaves the counter(s): its units, and every workgroup drew one ticket too many
 			const unsigned long long total = (unsigned long long)p.nwg * (unsigned long long)nlevels;
-			if (p.tickets2) {
-				c->ticket_base2[0] += (total + 1) / 2 + ((unsigned long long)grid + 1) / 2;
-				c->ticket_base2[1] += total / 2 + (unsigned long long)grid / 2;
+			if (p.tickets2 > 1) { // units and workgroups of class k = those numbered k mod K
+				const unsigned long long K = (unsigned long long)p.tickets2;
+				for (unsigned long long k = 0; k < K; k++) c->ticket_base2[k] += (total + K - 1 - k) / K + ((unsigned long long)grid + K - 1 - k) / K;
 			} else {
 				c->ticket_base2[0] += total + (unsigned long long)grid;
 			}

@@ -26,7 +26,7 @@ struct ising_ctx {
 	int fused_wide = 0;            // ... with 512-thread workgroups
 	int fused_wg_per_cu = 0;       // ... and this many workgroups per CU (0: as many as the chip holds)
 	int fused_nt = 0;              // ... whose lattice words carry the non-temporal hint (lattice larger than the 256 MB memory-side cache)
-	unsigned long long ticket_base2[2] = {0, 0}; // fused launches: where the launches so far left the ticket counter(s)
+	unsigned long long ticket_base2[4] = {0, 0, 0, 0}; // fused launches: where the launches so far left the ticket counter(s)
 	int fused_tickets2 = 0;                      // ... two counters (small lattices: one cannot hand tickets out fast enough)
 	int tail_rows = 0, tail_h = 0; // plain full-slab launches: the last tail_rows rows go in strips of tail_h rows
 	uint64_t *d_pack = nullptr;    // staging for device-side conversion to / from the packed boundary format

@@ -42,8 +42,8 @@ struct UpdateParams {
 	int32_t wide;             // fused: 512-thread workgroups (8 waves per ticket)
 	int32_t wg_per_cu;        // fused: cap of the persistent grid, workgroups per CU (0: what the chip holds; host side only)
 	int32_t nt_stream;        // fused: lattice words with the non-temporal hint (lattices larger than the memory-side cache; host side only)
-	unsigned long long ticket_base2[2]; // fused: value of the ticket counter(s) when this launch starts ([1]: the second counter, 64 bytes on)
-	int32_t tickets2;         // fused: two counters (even / odd unit numbers, by the parity of blockIdx)
+	unsigned long long ticket_base2[4]; // fused: value of the ticket counter(s) when this launch starts (counter k: 64 k bytes on)
+	int32_t tickets2;         // fused: 0 / 1 = one counter; 2 or 4: that many (unit numbers by class = blockIdx mod 2 or 4)
 	int32_t nlevels;          // colour half-sweeps in this launch.  > 1 = fused: level L updates colour (color + L) & 1 at
 	                          // iteration it + (color + L) / 2 over rows [row_lo[0], row_hi[0]) = the whole slab (wrap)
 	uint64_t *lat[2];         // fused: row-0 pointers of both colours

@@ -112,7 +112,7 @@ def test_auto_layout_picks_ballot_where_it_applies(gpu):
     with ig.IsingSlab(16384, 8192, temp=1.5) as s:      # from 2^27 spins per slab up
         assert s.layout == BAL
     with ig.IsingSlab(8192, 8192, temp=1.5) as s:       # from 2^26 spins where ising_sweep's fused launches apply ...
-        assert s.layout == BAL and s.fused and s.strip_rows == 2
+        assert s.layout == BAL and s.fused and s.strip_rows == 1
     with ig.IsingSlab(16384, 16384, temp=1.5) as s:     # fused launches all the way up, strip height by tickets per level
         assert s.layout == BAL and s.fused and s.strip_rows == 4
     with ig.IsingSlab(8192, 8192, temp=1.5, ring_halo=True) as s:   # ... not for a ring slab of that size
