@@ -32,7 +32,6 @@
 
 #include <algorithm>
 #include <cstdlib>
-#include <cstdlib>
 
 namespace ising {
 namespace {
