@@ -155,6 +155,18 @@ def main():
             ring, ring_name = ig.open_native_ring(slab, log=log), "rccl-native"
             if ring is None:
                 slab.close()
+        if ring is None and args.exchange in (None, "p2p"):
+            # torch.distributed send/recv on a slab that owns its buffer: the same deep schedule (ghost rows, one exchange per
+            # 16 sweeps: SlabRing._sweep_deep), the rows wrapped zero-copy as tensors
+            slab = ig.IsingSlab(args.x, args.y, device=local_rank, seed=args.seed, temp=ig.CRIT_TEMP_F32, nslabs=world, slab=rank,
+                                strip_rows=args.strip_rows, layout=layout, ring_halo=world == 1)
+            try:
+                ring, ring_name = ig.open_ring(ig.HipSlabBackend(slab), prefer="torch", exchange="p2p", log=log)
+                if ring.ghost_rows > 1:
+                    ring_name += f"-ghost{ring.ghost_rows}"
+            except ig.IsingError as e:  # (every rank gets here together: open_ring agrees on each attempt's outcome)
+                log(f"torch ring on a library-owned slab did not come up: {e}")
+                slab.close()
         if ring is None:
             # torch owns the slab's device buffer, so the rows the torch ring hands to RCCL are slices of an ordinary tensor
             backend = ig.HipSlabBackend.create(args.x, args.y, device=local_rank, seed=args.seed, temp=ig.CRIT_TEMP_F32,

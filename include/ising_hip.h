@@ -186,6 +186,21 @@ int ising_sweep_timed(ising_ctx *ctx, int first_it, int nsweeps, float *elapsed_
  *                         first row before a half-sweep of the OTHER colour touches rows 0 / Y-1. */
 int ising_halo_ptrs(ising_ctx *ctx, int color, void **send_top, void **send_bot, void **recv_top, void **recv_bot,
                     size_t *row_bytes);
+/* The same surface for the DEEP exchange the library's own ring uses (ising_ring_sweep / ising_rank_sweep), for callers
+ * that bring their own transport (MPI, torch.distributed, ...).  A ring slab on the ballot layout that owns its buffer
+ * keeps *depth = G ghost rows on either side (32, or Y/2 on flat slabs; 1 = no such rows: use the one-row surface above):
+ *   send_top / send_bot : this slab's first / last G rows of `color` (block_bytes each, contiguous) -> previous / next slab;
+ *   recv_top / recv_bot : the ghost rows above row 0 / below row Y-1 <- the previous slab's last / the next slab's first G rows.
+ * Once both blocks of a colour have been filled -- by work ordered before the context's stream --, say so with
+ * ising_ghost_delivered.  With both colours delivered, ising_sweep_ghost runs `nsweeps` <= G/2 full sweeps as ONE fused
+ * launch over the slab and its ghost rows (whose draws are the ones their owners make: the generator is counter-based), so
+ * that the ring costs one exchange of G rows per colour every G/2 sweeps instead of one row per colour half-sweep
+ * (optimized/main.cu:1779-1805 synchronises all devices after every colour).  Whatever changes the spins (a sweep, an
+ * init, a write) makes the ghost rows stale: ising_sweep_ghost then fails with ISING_E_STATE until they are delivered again. */
+int ising_ghost_ptrs(ising_ctx *ctx, int color, int *depth, void **send_top, void **send_bot, void **recv_top, void **recv_bot,
+                     size_t *block_bytes);
+int ising_ghost_delivered(ising_ctx *ctx, int color);
+int ising_sweep_ghost(ising_ctx *ctx, int first_it, int nsweeps);
 
 /* countSpins / getMagn_k for this slab (optimized/main.cu:701-734, :831-868): number of up and down spins.
  * Blocking (copies two 64-bit counters back, as :860-866 does). */

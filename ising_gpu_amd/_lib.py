@@ -69,6 +69,9 @@ PROTOTYPES = {
     "ising_sweep_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ising_sweep_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "ising_halo_ptrs": (C.c_int, [C.c_void_p, C.c_int] + [C.POINTER(C.c_void_p)] * 4 + [C.POINTER(C.c_size_t)]),
+    "ising_ghost_ptrs": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)] + [C.POINTER(C.c_void_p)] * 4 + [C.POINTER(C.c_size_t)]),
+    "ising_ghost_delivered": (C.c_int, [C.c_void_p, C.c_int]),
+    "ising_sweep_ghost": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ising_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ising_bond_equal": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ising_read_packed": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),

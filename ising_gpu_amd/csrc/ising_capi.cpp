@@ -742,6 +742,11 @@ int ising_host::update_interior(ising_ctx *c, int it, int color, hipEvent_t stop
 	return launch_ranges(c, it, color, 1, c->cfg.Y - 1, 0, 0, 1, false, stop);
 }
 
+// true when the ring sweeps this slab through its ghost rows right now (ising_ring.cpp: sweep_local takes the same decision)
+static bool ghost_sweeps(const ising_ctx *c) {
+	return !c->wrap && c->ballot && c->ghost() > 1 && !c->store_ring && !c->cfg.XSL && !ising_host::needs_generic(c);
+}
+
 // Ring slab with G > 1 ghost rows: `nlevels` colour half-sweeps (black first) in one fused launch over rows
 // [-(G-1), Y+G-1).  The ghost rows are updated like the slab's own -- their draws are the ones the neighbours make --, and
 // what is not valid in them any more (one row per level and side) never reaches a row that is.
@@ -782,7 +787,7 @@ int ising_sweep_info(ising_ctx *c, int *fused, int *max_sweeps_per_launch) {
 	if (!c) return fail(ISING_E_ARG, "null context");
 	const bool f = c->wrap && c->ballot && c->fused && !c->cfg.XSL && !ising_host::needs_generic(c);
 	// (a ring slab with ghost rows G deep: the ring's sweeps are fused launches of G/2 sweeps between two exchanges)
-	const bool deep = !c->wrap && c->ballot && c->ghost() > 1 && !c->store_ring && !c->cfg.XSL && !ising_host::needs_generic(c);
+	const bool deep = ghost_sweeps(c);
 	if (fused) *fused = (f || deep) ? 1 : 0;
 	if (max_sweeps_per_launch) *max_sweeps_per_launch = f ? 32 : (deep ? c->ghost() / 2 : 0);
 	return ISING_OK;
@@ -820,6 +825,40 @@ int ising_halo_ptrs(ising_ctx *c, int color, void **send_top, void **send_bot, v
 	if (recv_bot) *recv_bot = base + (size_t)c->cfg.Y * ld;
 	if (row_bytes) *row_bytes = ld * sizeof(uint64_t);
 	return ISING_OK;
+}
+
+int ising_ghost_ptrs(ising_ctx *c, int color, int *depth, void **send_top, void **send_bot, void **recv_top, void **recv_bot, size_t *block_bytes) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
+	if (c->wrap) return fail(ISING_E_STATE, "no halo buffers with nslabs == 1 (rows wrap inside the slab)");
+	const size_t ld = (size_t)c->lld, G = ghost_sweeps(c) ? (size_t)c->ghost() : 1;
+	uint64_t *base = c->lat(color);
+	if (depth) *depth = (int)G;
+	if (send_top) *send_top = base;
+	if (send_bot) *send_bot = base + ((size_t)c->cfg.Y - G) * ld;
+	if (recv_top) *recv_top = base - G * ld;
+	if (recv_bot) *recv_bot = base + (size_t)c->cfg.Y * ld;
+	if (block_bytes) *block_bytes = G * ld * sizeof(uint64_t);
+	return ISING_OK;
+}
+
+int ising_ghost_delivered(ising_ctx *c, int color) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
+	if (c->wrap) return fail(ISING_E_STATE, "no halo buffers with nslabs == 1 (rows wrap inside the slab)");
+	c->ghost_depth[color] = ghost_sweeps(c) ? c->ghost() : 1;
+	return ISING_OK;
+}
+
+int ising_sweep_ghost(ising_ctx *c, int first_it, int nsweeps) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (!ghost_sweeps(c)) return fail(ISING_E_STATE, "the slab does not sweep through ghost rows (ising_ghost_ptrs: depth 1); use ising_update_edges / ising_update_color");
+	const int G = c->ghost();
+	if (nsweeps < 1 || 2 * nsweeps > G) return fail(ISING_E_ARG, "%d sweeps on ghost rows %d deep (at most %d per exchange)", nsweeps, G, G / 2);
+	if (c->ghost_depth[0] < G || c->ghost_depth[1] < G)
+		return fail(ISING_E_STATE, "the ghost rows are not current: deliver both colours (ising_ghost_ptrs, ising_ghost_delivered) after whatever changed the spins");
+	for (int color = 0; color < 2; color++) if (int rc = ising_host::halo_ready(c, color)) return rc; // (a no-op unless the library's own transport is attached too)
+	return ising_host::update_deep(c, first_it, 2 * nsweeps);
 }
 
 int ising_count(ising_ctx *c, uint64_t *up, uint64_t *down) {

@@ -183,6 +183,23 @@ class IsingSlab:
         check(self._lib.ising_halo_ptrs(self._h, color, *[C.byref(x) for x in p], C.byref(nb)))
         return [x.value for x in p], nb.value
 
+    def ghost_ptrs(self, color: int):
+        """-> (depth G, [send_top, send_bot, recv_top, recv_bot], bytes per block): the deep exchange surface
+        (ising_ghost_ptrs); G == 1 when the slab keeps no ghost rows."""
+        p = [C.c_void_p() for _ in range(4)]
+        nb, depth = C.c_size_t(), C.c_int()
+        check(self._lib.ising_ghost_ptrs(self._h, color, C.byref(depth), *[C.byref(x) for x in p], C.byref(nb)))
+        return depth.value, [x.value for x in p], nb.value
+
+    def ghost_delivered(self, color: int):
+        check(self._lib.ising_ghost_delivered(self._h, color))
+
+    def sweep_ghost(self, n: int = 1):
+        """n <= G/2 sweeps as one fused launch over the slab and its ghost rows (both colours delivered first)."""
+        check(self._lib.ising_sweep_ghost(self._h, self.it + 1, n))
+        self.it += n
+        return self
+
     def device_ptr(self, color: int):
         p, nb = C.c_void_p(), C.c_size_t()
         check(self._lib.ising_device_ptr(self._h, color, C.byref(p), C.byref(nb)))

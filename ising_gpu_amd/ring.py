@@ -15,6 +15,10 @@ edge rows of a colour are updated and hidden behind the interior rows' kernel:
 
 Results do not depend on the decomposition: the Philox stream id uses the global row (optimized/main.cu:514).
 
+A backend that keeps ghost rows G deep (a library-owned slab on the ballot layout: ising_ghost_ptrs) is driven the way the
+library's own ring drives it instead: G rows of both colours travel every G/2 sweeps, one fused launch runs in between
+(SlabRing._sweep_deep; csrc/ising_ring.cpp: sweep_deep).
+
 The orchestration only needs a *slab backend* with the small interface below, so the same code runs on GPUs
 (IsingSlab + NCCL) and, in tests, on CPU tensors with gloo.
 """
@@ -37,6 +41,10 @@ class SlabBackend(Protocol):
         """-> (send_top, send_bot, recv_top, recv_bot): 1-D uint8 tensors of one colour row each."""
     def count_up_down(self): ...
     def bond_equal(self) -> int: ...
+    # optional -- the deep exchange (ising_ghost_ptrs): a backend that keeps G > 1 ghost rows on either side
+    #   ghost_depth() -> G;  ghost_tensors(color) -> (send_top, send_bot, recv_top, recv_bot), G rows each;
+    #   ghost_delivered(color);  sweep_ghost(first_it, nsweeps <= G/2): the sweeps as one launch, ghost rows included
+    # optional -- ring_of_one: True when a lone slab's rows -1 / Y are halo rows (it sends its edge rows to itself)
 
 
 class _DevMem:
@@ -58,17 +66,20 @@ class HipSlabBackend:
         self.device = torch.device("cuda", slab.cfg.device)
         slab.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self._buffers = buffers or {}
-        self._halo = {}
+        self._halo = {}   # (colour, pointers, bytes) -> tensors: a library-owned slab moves its rows when it changes layout
         self.use_J = bool(getattr(slab, "use_J", False))
-        if slab.nslabs > 1:
-            for color in (BLACK, WHITE) + ((HAM_BLACK,) if self.use_J else ()):
-                ptrs, nb = slab.halo_ptrs(color)
-                buf = self._buffers.get("coupling" if color == HAM_BLACK else "lattice")
-                if buf is not None:
-                    base = buf.data_ptr()
-                    self._halo[color] = tuple(buf[p - base:p - base + nb] for p in ptrs)
-                else:
-                    self._halo[color] = tuple(torch.as_tensor(_DevMem(p, nb), device=self.device) for p in ptrs)
+        self.ring_of_one = slab.nslabs == 1 and bool(slab.cfg.ring_halo)
+
+    def _tensors(self, color, ptrs, nb):
+        key = (color, tuple(ptrs), nb)
+        if key not in self._halo:
+            buf = self._buffers.get("coupling" if color == HAM_BLACK else "lattice")
+            if buf is not None:
+                base = buf.data_ptr()
+                self._halo[key] = tuple(buf[p - base:p - base + nb] for p in ptrs)
+            else:
+                self._halo[key] = tuple(torch.as_tensor(_DevMem(p, nb), device=self.device) for p in ptrs)
+        return self._halo[key]
 
     @classmethod
     def create(cls, X, Y, device=0, J_prob=None, layout=LAYOUT_AUTO, **kw):
@@ -105,7 +116,22 @@ class HipSlabBackend:
         self.slab.update_color(it, color, 1, self.slab.Y - 1)
 
     def halo_tensors(self, color):
-        return self._halo[color]
+        ptrs, nb = self.slab.halo_ptrs(color)
+        return self._tensors(color, ptrs, nb)
+
+    def ghost_depth(self):
+        return self.slab.ghost_ptrs(BLACK)[0]
+
+    def ghost_tensors(self, color):
+        _, ptrs, nb = self.slab.ghost_ptrs(color)
+        return self._tensors(color, ptrs, nb)
+
+    def ghost_delivered(self, color):
+        self.slab.ghost_delivered(color)
+
+    def sweep_ghost(self, first_it, nsweeps):
+        self.slab.it = first_it - 1
+        self.slab.sweep_ghost(nsweeps)
 
     def count_up_down(self):
         return self.slab.count()
@@ -135,6 +161,13 @@ class SlabRing:
         self.next = (self.rank + 1) % self.world
         self.it = 0
         self._pending: List[Optional[list]] = [None, None, None]  # per plane (black, white, black couplings)
+        # a lone slab whose rows -1 / Y are halo rows is a ring of one: it exchanges with itself
+        self.ringed = self.world > 1 or bool(getattr(backend, "ring_of_one", False))
+        # Deep exchange (backends with ghost rows G deep, p2p only): G rows of both colours every G/2 sweeps and ONE launch
+        # in between, the schedule of the library's own ring (csrc/ising_ring.cpp: sweep_deep).  _deep_posted: the ghost
+        # rows hold (or are about to receive) the neighbours' current rows.
+        self._pending_deep: List[Optional[list]] = [None, None]
+        self._deep_posted = False
 
     # -- halo exchange -----------------------------------------------------------------------------------
     def _post_allgather(self, color: int):
@@ -163,7 +196,54 @@ class SlabRing:
         ]
         self._pending[color] = dist.batch_isend_irecv(ops)
 
+    def _depth(self) -> int:
+        g = getattr(self.b, "ghost_depth", None)
+        return int(g()) if (g is not None and self.ringed and self.exchange == "p2p") else 1
+
+    @property
+    def ghost_rows(self) -> int:
+        """Rows per colour and neighbour of one exchange: G > 1 = the deep schedule (one exchange per G/2 sweeps), 1 = one row
+        per colour half-sweep."""
+        return self._depth()
+
+    def _post_deep(self):
+        for color in (BLACK, WHITE):
+            send_top, send_bot, recv_top, recv_bot = self.b.ghost_tensors(color)
+            ops = [  # (same order as _post: with two ranks the peer's first receive must match our LAST rows)
+                dist.P2POp(dist.isend, send_bot, self.next, self.group),
+                dist.P2POp(dist.isend, send_top, self.prev, self.group),
+                dist.P2POp(dist.irecv, recv_top, self.prev, self.group),
+                dist.P2POp(dist.irecv, recv_bot, self.next, self.group),
+            ]
+            self._pending_deep[color] = dist.batch_isend_irecv(ops)
+        self._deep_posted = True
+
+    def _wait_deep(self):
+        for color in (BLACK, WHITE):
+            works = self._pending_deep[color]
+            if works:
+                for w in works:
+                    w.wait()
+                self.b.ghost_delivered(color)
+            self._pending_deep[color] = None
+
+    def _sweep_deep(self, nsweeps: int, G: int):
+        self._wait(BLACK)  # (one-row exchanges of an earlier phase: consumed before anything else touches those rows)
+        self._wait(WHITE)
+        left = nsweeps
+        while left > 0:
+            ns = min(left, G // 2)
+            if not self._deep_posted:
+                self._post_deep()
+            self._wait_deep()
+            self.b.sweep_ghost(self.it + 1, ns)
+            self.it += ns
+            left -= ns
+            self._post_deep()  # rows -1 / Y current again: observables and the next call find them in place
+
     def _wait(self, color: int):
+        if color in (BLACK, WHITE) and self._pending_deep[color]:
+            self._wait_deep()
         works = self._pending[color]
         if works:
             if self.exchange == "allgather":
@@ -194,22 +274,27 @@ class SlabRing:
 
     def init(self):
         self._check_layouts()
+        self.quiesce()
         self.b.init()
         self.it = 0
-        if self.world > 1:
-            self._post(BLACK)
-            self._post(WHITE)
+        self._deep_posted = False
+        if self.ringed:
+            if self._depth() > 1:
+                self._post_deep()
+            else:
+                self._post(BLACK)
+                self._post(WHITE)
         if getattr(self.b, "use_J", False):
             # -J: the white couplings are assembled from the black ones, including the neighbours' edge rows
             self.b.init_couplings_black()
-            if self.world > 1:
+            if self.ringed:
                 self._post(HAM_BLACK)
                 self._wait(HAM_BLACK)
             self.b.init_couplings_white()
         return self
 
     def _half_sweep(self, it: int, color: int):
-        if self.world == 1:
+        if not self.ringed:
             self.b.update_all(it, color)
             return
         self._wait(1 - color)
@@ -218,6 +303,17 @@ class SlabRing:
         self.b.update_interior(it, color)
 
     def sweep(self, nsweeps: int = 1):
+        G = self._depth()
+        if G > 1 and nsweeps > 0:
+            self._sweep_deep(nsweeps, G)
+            return self
+        if self._deep_posted and self.ringed and nsweeps > 0:
+            # the backend stopped sweeping through ghost rows (e.g. a temperature without integer thresholds): back to one
+            # row per colour half-sweep, starting from rows delivered the one-row way
+            self._wait_deep()
+            self._deep_posted = False
+            self._post(BLACK)
+            self._post(WHITE)
         for _ in range(nsweeps):
             self.it += 1
             self._half_sweep(self.it, BLACK)
@@ -228,6 +324,7 @@ class SlabRing:
         """Make sure every posted exchange has been consumed by the current stream / host."""
         self._wait(BLACK)
         self._wait(WHITE)
+        self._wait_deep()
 
     def count(self):
         """Global (up, down) over all slabs (the host-side sum of countSpins, optimized/main.cu:860-866)."""
@@ -241,7 +338,7 @@ class SlabRing:
         return up, down
 
     def bond_equal(self) -> int:
-        if self.world > 1:
+        if self.ringed:
             self._wait(WHITE)  # black sites read the white halo rows
             self._pending[WHITE] = None
         a = self.b.bond_equal()
@@ -423,8 +520,10 @@ def open_ring(backend: "HipSlabBackend", prefer: str = "native", exchange: Optio
     attempts = []
     if prefer == "native" and exchange is None:
         attempts.append("rccl-native")
-    if world > 1:  # (a ring of one exists only inside the library: SlabRing sweeps a lone slab in place)
+    if world > 1:
         attempts += [exchange] if exchange else ["p2p", "allgather"]
+    elif getattr(backend, "ring_of_one", False):  # a lone slab with halo rows sends its edge rows to itself
+        attempts += [exchange or "p2p"]
     last = None
     for name in attempts:
         ring = None

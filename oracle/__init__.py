@@ -6,5 +6,5 @@ file:line map and ``basic_cpu.c`` for the byte-per-spin baseline.
 """
 from .pyoracle import (  # noqa: F401
     BLACK, WHITE, CRIT_TEMP, SEED_DEF, build, lib, OracleLattice, philox4x32_10, uniform, exp_table,
-    site_draw, BasicCpuIsing, OracleSlab, set_threads, max_threads,
+    site_draw, BasicCpuIsing, OracleSlab, OracleGhostSlab, set_threads, max_threads,
 )

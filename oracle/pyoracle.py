@@ -249,3 +249,40 @@ class OracleSlab:
     def bond_equal(self) -> int:
         return int(lib().orc_bond_equal_slab(_u64(self.lat[0]), _u64(self.lat[1]), _u64(self.halo[1, 0]),
                                              _u64(self.halo[1, 1]), self.X, self.Y, self.slab * self.Y))
+
+
+class OracleGhostSlab(OracleSlab):
+    """OracleSlab with G ghost rows on either side (the CPU counterpart of a ring slab of the product's ballot layout,
+    csrc/ising_ring.cpp: sweep_deep): rows [-G, Y+G) of both colours in one array, rows -G..-1 / Y..Y+G-1 being copies of the
+    neighbouring slabs' rows.  sweep_ghost() updates rows [-(G-1), Y+G-1) level by level -- the ghost rows with the draws
+    their owners make (global row, around the ring) -- which leaves the slab's own rows exact for up to G levels."""
+
+    def __init__(self, X: int, Y: int, seed: int, temp: float, nslabs: int, slab: int, ghost: int):
+        super().__init__(X, Y, seed, temp, nslabs, slab)
+        self.G = ghost
+        self.ext = np.zeros((2, Y + 2 * ghost, self.lld), dtype=np.uint64)
+        self.lat = self.ext[:, ghost:ghost + Y]  # the slab's own rows, in place
+
+    def _level(self, it: int, color: int):
+        tab = (C.c_float * 10)()
+        lib().orc_exp_table(C.c_float(self.temp), tab)
+        total, G, n = self.nslabs * self.Y, self.G, self.Y + 2 * self.G
+        other = 1 - color
+        e = 1
+        while e < n - 1:  # blocks of consecutive global rows (the ring closes inside the ghost rows of the end slabs)
+            g0 = (self.slab * self.Y + e - G) % total
+            rows = min(n - 1 - e, total - g0)
+            # rows [e, e + rows) as the first rows of a "slab" that starts at global row g0 (the oracle wants a row count that
+            # is a multiple of 16; only [0, rows) of it is updated, which reads rows e - 1 .. e + rows)
+            k16 = -(-rows // 16) * 16
+            rc = lib().orc_update_color_slab(_u64(self.ext[color, e:]), _u64(self.ext[other, e:]), _u64(self.ext[other, e - 1]),
+                                             _u64(self.ext[other, e + rows]), self.X, k16, g0, C.c_uint64(self.seed), it, color,
+                                             tab, 0, rows)
+            assert rc == 0, rc
+            e += rows
+
+    def sweep_ghost(self, first_it: int, nsweeps: int):
+        assert 2 * nsweeps <= self.G
+        for level in range(2 * nsweeps):
+            self._level(first_it + level // 2, level & 1)
+

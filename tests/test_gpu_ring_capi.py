@@ -169,3 +169,76 @@ def test_ring_slabs_keep_ghost_rows_where_they_can(gpu, monkeypatch):
     monkeypatch.setenv("ISING_RING_GHOST", "1")
     with ig.IsingSlab(8192, 128, nslabs=2, slab=0, layout=ig.LAYOUT_BALLOT) as s:
         assert not s.fused
+
+
+def _deliver(slabs, torch):
+    """The caller's own transport for the deep exchange surface: device-to-device copies between the slabs' ghost blocks."""
+    from ising_gpu_amd.ring import _DevMem
+    dev = torch.device("cuda", 0)
+    n = len(slabs)
+    for s in slabs:
+        s.synchronize()
+    for color in (ig.BLACK, ig.WHITE):
+        blocks = []
+        for s in slabs:
+            depth, ptrs, nb = s.ghost_ptrs(color)
+            blocks.append([torch.as_tensor(_DevMem(p, nb), device=dev) for p in ptrs])
+        for k in range(n):
+            send_top, send_bot, _, _ = blocks[k]
+            blocks[(k + 1) % n][2].copy_(send_bot)  # next slab's rows above row 0 <- my last rows
+            blocks[(k - 1) % n][3].copy_(send_top)  # previous slab's rows below row Y-1 <- my first rows
+        for s in slabs:
+            s.ghost_delivered(color)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("nslabs,Yk,sweeps", [(2, 64, (16, 5, 1)), (3, 32, (8, 8, 3)), (1, 64, (7, 16))])
+def test_deep_exchange_surface_with_a_callers_own_copies(gpu, nslabs, Yk, sweeps):
+    """ising_ghost_ptrs / ising_ghost_delivered / ising_sweep_ghost: what a caller with its own transport (MPI, ...) drives.
+    Here the 'transport' is a device copy; the slabs of one lattice, swept G/2 sweeps per exchange, equal the single slab."""
+    import torch
+    X, seed, temp = 8192, 4242, ig.CRIT_TEMP_F32
+    total = sum(sweeps)
+    ref_b, ref_w, ref_cnt, _ = _single(X, Yk * nslabs, seed, temp, total, layout=ig.LAYOUT_BALLOT)
+    slabs = [ig.IsingSlab(X, Yk, seed=seed, temp=temp, nslabs=nslabs, slab=k, layout=ig.LAYOUT_BALLOT, ring_halo=nslabs == 1) for k in range(nslabs)]
+    try:
+        G = slabs[0].ghost_ptrs(ig.BLACK)[0]
+        assert G == min(32, Yk // 2)
+        for s in slabs:
+            s.init()
+        with pytest.raises(ig.IsingError, match="not current"):
+            slabs[0].sweep_ghost(1)  # nothing delivered yet
+        for n in sweeps:
+            left = n
+            while left:
+                ns = min(left, G // 2)
+                _deliver(slabs, torch)
+                for s in slabs:
+                    s.sweep_ghost(ns)
+                left -= ns
+        with pytest.raises(ig.IsingError, match="not current"):
+            slabs[0].sweep_ghost(1)  # the launch made the ghost rows stale
+        _deliver(slabs, torch)
+        with pytest.raises(ig.IsingError, match="at most"):
+            slabs[0].sweep_ghost(G // 2 + 1)
+        assert np.array_equal(np.concatenate([s.read(ig.BLACK) for s in slabs]), ref_b)
+        assert np.array_equal(np.concatenate([s.read(ig.WHITE) for s in slabs]), ref_w)
+        ups = sum(s.count()[0] for s in slabs)
+        assert ups == ref_cnt[0]
+    finally:
+        for s in slabs:
+            s.close()
+
+
+def test_deep_exchange_surface_is_one_row_deep_without_ghost_rows(gpu):
+    with ig.IsingSlab(8192, 32, nslabs=2, slab=0, layout=ig.LAYOUT_DENSE) as s:
+        depth, ptrs, nb = s.ghost_ptrs(ig.WHITE)
+        assert depth == 1 and (ptrs, nb) == s.halo_ptrs(ig.WHITE)
+        s.init()
+        s.ghost_delivered(ig.BLACK)
+        s.ghost_delivered(ig.WHITE)
+        with pytest.raises(ig.IsingError, match="ghost rows"):
+            s.sweep_ghost(1)
+    with ig.IsingSlab(8192, 32, layout=ig.LAYOUT_BALLOT) as s:  # a lone slab wraps in place
+        with pytest.raises(ig.IsingError, match="wrap"):
+            s.ghost_ptrs(ig.BLACK)

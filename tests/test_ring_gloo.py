@@ -49,14 +49,48 @@ class OracleBackend:
         return self.s.bond_equal()
 
 
-def _worker(rank, world, port, q, exchange="p2p"):
+class OracleGhostBackend(OracleBackend):
+    """The same with ghost rows G deep: the optional deep-exchange part of the protocol (ising_ghost_ptrs and friends)."""
+
+    def __init__(self, slab):
+        super().__init__(slab)
+        G, Y = slab.G, slab.Y
+        self.delivered = [0, 0]
+        self._g = {c: tuple(torch.from_numpy(slab.ext[c, a:b].reshape(-1).view(np.uint8))
+                            for a, b in ((G, 2 * G), (Y, Y + G), (0, G), (Y + G, Y + 2 * G))) for c in (0, 1)}
+
+    def ghost_depth(self):
+        return self.s.G
+
+    def ghost_tensors(self, color):
+        return self._g[color]
+
+    def ghost_delivered(self, color):
+        self.delivered[color] += 1
+
+    def sweep_ghost(self, first_it, nsweeps):
+        assert self.delivered[0] and self.delivered[1], "launch before both colours were delivered"
+        self.delivered = [0, 0]
+        self.s.sweep_ghost(first_it, nsweeps)
+
+    def bond_equal(self):
+        G, Y = self.s.G, self.s.Y
+        self.s.halo[1, 0], self.s.halo[1, 1] = self.s.ext[1, G - 1], self.s.ext[1, Y + G]  # rows -1 / Y of the ghost rows
+        return self.s.bond_equal()
+
+
+def _worker(rank, world, port, q, exchange="p2p", ghost=0, sweeps=SWEEPS):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     oracle.set_threads(1)
     try:
-        slab = oracle.OracleSlab(X, YTOT // world, SEED, TEMP, world, rank)
-        ring = SlabRing(OracleBackend(slab), exchange=exchange).init()
-        ring.sweep(SWEEPS)
+        if ghost:
+            slab = oracle.OracleGhostSlab(X, YTOT // world, SEED, TEMP, world, rank, ghost)
+            ring = SlabRing(OracleGhostBackend(slab), exchange=exchange).init()
+        else:
+            slab = oracle.OracleSlab(X, YTOT // world, SEED, TEMP, world, rank)
+            ring = SlabRing(OracleBackend(slab), exchange=exchange).init()
+        ring.sweep(sweeps)
         up, down = ring.count()
         bond = ring.bond_equal()
         ring.quiesce()
@@ -72,19 +106,21 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,exchange", [(2, "p2p"), (3, "p2p"), (2, "allgather"), (3, "allgather")])
-def test_ring_matches_single_lattice(world, exchange):
+@pytest.mark.parametrize("world,exchange,ghost,sweeps", [(2, "p2p", 0, SWEEPS), (3, "p2p", 0, SWEEPS), (2, "allgather", 0, SWEEPS),
+                                                        (3, "allgather", 0, SWEEPS), (2, "p2p", 8, 9), (3, "p2p", 8, 9), (3, "p2p", 16, 5)])
+def test_ring_matches_single_lattice(world, exchange, ghost, sweeps):
+    """ghost > 0: the deep exchange -- `ghost` rows of both colours every ghost/2 sweeps, one multi-level update in between."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, ghost, sweeps)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    ref = oracle.OracleLattice(X, YTOT, seed=SEED, temp=TEMP).init().sweep(SWEEPS)
+    ref = oracle.OracleLattice(X, YTOT, seed=SEED, temp=TEMP).init().sweep(sweeps)
     full = np.concatenate([r[1] for r in res], axis=1)
     assert np.array_equal(full[0], ref.black)
     assert np.array_equal(full[1], ref.white)
