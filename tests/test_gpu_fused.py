@@ -135,16 +135,18 @@ def test_bench_line_on_a_small_lattice(gpu, oracle_mod):
     assert (b["config"]["up"], b["config"]["down"]) == orc.count()
 
 
-def test_bench_ring_code_path_with_one_rank(gpu, oracle_mod):
+@pytest.mark.parametrize("ring,port,exchange", [("native", 29551, "rccl-native"), ("torch", 29552, "p2p-ghost32")])
+def test_bench_ring_code_path_with_one_rank(gpu, oracle_mod, ring, port, exchange):
     """bench.py's N > 1 code path as far as one GPU can run it: under torch.distributed.run with ONE rank and --force-ring the
-    slab is a ring of one -- torch.distributed (nccl) is initialised, torch owns the slab buffer, the library attaches its
-    RCCL communicator with the id torch broadcast, and the edge rows travel through ncclSend/ncclRecv on the comm stream."""
+    slab is a ring of one -- torch.distributed (nccl) is initialised, and either the library attaches its RCCL communicator
+    with the id torch broadcast and the ghost rows travel through ncclSend/ncclRecv on the comm stream (native), or the
+    fallback behind it runs: the same deep schedule with torch.distributed send/recv on the library-owned rows."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port",
-                        "29551", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-ring", "--steps", "4", "--warmup", "2", "--x", "8192", "--y", "8192",
-                        "--preheat-ms", "5"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                        str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-ring", "--ring", ring, "--steps", "4", "--warmup", "2",
+                        "--x", "8192", "--y", "8192", "--preheat-ms", "5", "--layout", "ballot"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     b = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-    assert b["config"]["exchange"] == "rccl-native" and b["config"]["nranks"] == 1
+    assert b["config"]["exchange"] == exchange and b["config"]["nranks"] == 1
     orc = oracle_mod.OracleLattice(8192, 8192, seed=1234, temp=oracle_mod.CRIT_TEMP).init().sweep(6)
     assert (b["config"]["up"], b["config"]["down"]) == orc.count() and b["config"]["rank_up"] == [orc.count()[0]]

@@ -1,6 +1,7 @@
 """One process per GPU over the nccl (= RCCL) backend: tools/ring_ranks_nccl.py native|p2p|allgather.
 native    -> ising_gpu_amd.NativeRing (the ring inside libising_hip.so: second stream + ncclSend/ncclRecv)
-p2p       -> the unmodified ising_gpu_amd.SlabRing over torch.distributed batch_isend_irecv
+p2p       -> the unmodified ising_gpu_amd.SlabRing over torch.distributed batch_isend_irecv: a library-owned slab (ballot layout:
+             ghost rows 32 deep through ising_ghost_ptrs / ising_sweep_ghost) and a torch-owned one (one row per colour half-sweep)
 allgather -> SlabRing(exchange="allgather")
 Every rank compares its slab and the global counts with the CPU oracle, for the ballot and the dense layout.
 Launch: python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 --master-port 29541 tools/ring_ranks_nccl.py native"""
@@ -22,16 +23,20 @@ torch.cuda.set_device(local)
 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 X, Y, seed, temp, sweeps = 8192, 64, 2024, ig.CRIT_TEMP_F32, 5
 # native: a slab that owns its buffer (ballot layout: ghost rows 32 deep, one exchange per 16 sweeps) and a torch-owned one (one halo row)
-cases = [(lay, own) for lay in (ig.LAYOUT_BALLOT, ig.LAYOUT_DENSE) for own in ((True, False) if mode == "native" else (False,))]
+cases = [(lay, own) for lay in (ig.LAYOUT_BALLOT, ig.LAYOUT_DENSE) for own in ((True, False) if mode in ("native", "p2p") else (False,))]
 for layout, own in cases:
-    if own:
+    if own and mode == "native":
         class _B:  # same shape as HipSlabBackend for what follows
             slab = ig.IsingSlab(X, Y, device=local, seed=seed, temp=temp, nslabs=world, slab=rank, layout=layout)
         backend = _B
+    elif own:
+        backend = ig.HipSlabBackend(ig.IsingSlab(X, Y, device=local, seed=seed, temp=temp, nslabs=world, slab=rank, layout=layout))
     else:
         backend = ig.HipSlabBackend.create(X, Y, device=local, seed=seed, temp=temp, nslabs=world, slab=rank, layout=layout)
     ring = ig.NativeRing(backend.slab) if mode == "native" else ig.SlabRing(backend, exchange=mode)
     ring.init()
+    if own and mode == "p2p":
+        assert ring.ghost_rows == (32 if layout == ig.LAYOUT_BALLOT else 1), ring.ghost_rows
     ring.sweep(2).sweep(sweeps - 2)
     ring.quiesce()
     torch.cuda.synchronize()
