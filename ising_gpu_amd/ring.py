@@ -242,8 +242,12 @@ class SlabRing:
             self._post_deep()  # rows -1 / Y current again: observables and the next call find them in place
 
     def _wait(self, color: int):
+        """The rows of `color` posted last -- one row or the deep exchange -- are in place for what the current stream does next."""
         if color in (BLACK, WHITE) and self._pending_deep[color]:
             self._wait_deep()
+        self._wait_rows(color)
+
+    def _wait_rows(self, color: int):
         works = self._pending[color]
         if works:
             if self.exchange == "allgather":

@@ -107,7 +107,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,exchange,ghost,sweeps", [(2, "p2p", 0, SWEEPS), (3, "p2p", 0, SWEEPS), (2, "allgather", 0, SWEEPS),
-                                                        (3, "allgather", 0, SWEEPS), (2, "p2p", 8, 9), (3, "p2p", 8, 9), (3, "p2p", 16, 5)])
+                                                        (3, "allgather", 0, SWEEPS), (2, "p2p", 8, 8), (3, "p2p", 8, 9), (3, "p2p", 16, 5)])
 def test_ring_matches_single_lattice(world, exchange, ghost, sweeps):
     """ghost > 0: the deep exchange -- `ghost` rows of both colours every ghost/2 sweeps, one multi-level update in between."""
     ctx = mp.get_context("spawn")

@@ -28,7 +28,7 @@ class StagedSlabRing(ig.SlabRing):
                dist.P2POp(dist.irecv, host[2], self.prev, self.group), dist.P2POp(dist.irecv, host[3], self.next, self.group)]
         self._pending[color] = (dist.batch_isend_irecv(ops), host, recv_top, recv_bot)
 
-    def _wait(self, color):
+    def _wait_rows(self, color):
         pend = self._pending[color]
         if pend:
             works, host, recv_top, recv_bot = pend
@@ -83,8 +83,9 @@ for layout in (ig.LAYOUT_BALLOT, ig.LAYOUT_DENSE):
 
 # Library-owned ballot slabs keep ghost rows (here Y/2 = 32 deep): 32 rows of both colours every 16 sweeps, one fused launch
 # in between (ising_ghost_ptrs / ising_ghost_delivered / ising_sweep_ghost under SlabRing._sweep_deep).  21 sweeps = two
-# launches (16 + 5) with an exchange between them, then 3 more on ghost rows that the last exchange left current.
-sweeps = (21, 3)
+# launches (16 + 5) with an exchange between them, then 16 more on ghost rows that the last exchange left current: a launch
+# of all 32 levels, after which no ghost row is valid until the next exchange (the bond sum reads rows -1 / Y).
+sweeps = (21, 16)
 slab = ig.IsingSlab(X, Y, device=0, seed=seed, temp=temp, nslabs=world, slab=rank, layout=ig.LAYOUT_BALLOT)
 ring = StagedSlabRing(ig.HipSlabBackend(slab)).init()
 assert ring.ghost_rows == 32, ring.ghost_rows
