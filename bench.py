@@ -5,7 +5,7 @@ A "step" is one full lattice sweep (black half-sweep + white half-sweep, the ref
 optimized/main.cu:1763-1805) over this rank's slab.  Per-GPU workload (fixed as N grows => weak scaling):
 X = 65536 columns x Y = 65536 rows at T = T_c (CRIT_TEMP, optimized/main.cu:42), the 65536^2 lattice BASELINE.json's
 target is quoted on (configs[2]); with N ranks the lattice is (N*65536) x 65536, slabs along Y, 32 rows of each
-colour to each ring neighbour every 16 sweeps (ghost rows; one row per colour half-sweep on the fallback ring).  The lattice is generated on the device from the seed: "synthetic".
+colour to each ring neighbour every 32 sweeps (ghost rows; one row per colour half-sweep on the fallback ring).  The lattice is generated on the device from the seed: "synthetic".
 
   N = 1   the slab sweeps itself (ising_sweep), `batch` sweeps per call (batch = the largest divisor <= 32 of
           gcd(steps, warmup)).  ising_sweep issues fused launches from 2^26 spins up (ISING_FUSED=0: one launch per
@@ -15,7 +15,7 @@ colour to each ring neighbour every 16 sweeps (ghost rows; one row per colour ha
           --warmup 5) the timed steps and the warm-up are cut on their own (one call of 20, one of 5): `config.sweeps_per_call`
           and `roofline.half_sweeps_per_launch` describe the timed launches.
   N > 1   one process per GPU; the ring lives inside libising_hip.so (ising_rank_*: second HIP stream + RCCL send/recv);
-          ballot ring slabs keep ghost rows 32 deep, exchange 32 rows of both colours every 16 sweeps and run one fused launch
+          ballot ring slabs keep ghost rows 64 deep, exchange 64 rows of both colours every 32 sweeps and run one fused launch
           in between (sweep_deep); if that transport does not come up the torch.distributed ring (p2p, then all-gather, one
           row per colour half-sweep on a torch-owned slab) takes over and the JSON line says which one ran.  The counts after warm-up + steps are compared with the oracle's committed goldens
           (tests/golden/bench_65536_tc.json, ring_65536_tc.json) when the run hits one of their points.
@@ -148,8 +148,8 @@ def main():
     else:
         ring = None
         if args.ring == "native" and not args.exchange:
-            # the library's own ring on a slab that owns its buffer: ballot ring slabs then keep ghost rows 32 deep, exchange
-            # every 16 sweeps and run fused launches in between (csrc/ising_ring.cpp: sweep_deep)
+            # the library's own ring on a slab that owns its buffer: ballot ring slabs then keep ghost rows 64 deep, exchange
+            # every 32 sweeps and run fused launches in between (csrc/ising_ring.cpp: sweep_deep)
             slab = ig.IsingSlab(args.x, args.y, device=local_rank, seed=args.seed, temp=ig.CRIT_TEMP_F32, nslabs=world, slab=rank,
                                 strip_rows=args.strip_rows, layout=layout, ring_halo=world == 1)
             ring, ring_name = ig.open_native_ring(slab, log=log), "rccl-native"
@@ -157,7 +157,7 @@ def main():
                 slab.close()
         if ring is None and args.exchange in (None, "p2p"):
             # torch.distributed send/recv on a slab that owns its buffer: the same deep schedule (ghost rows, one exchange per
-            # 16 sweeps: SlabRing._sweep_deep), the rows wrapped zero-copy as tensors
+            # 32 sweeps: SlabRing._sweep_deep), the rows wrapped zero-copy as tensors
             slab = ig.IsingSlab(args.x, args.y, device=local_rank, seed=args.seed, temp=ig.CRIT_TEMP_F32, nslabs=world, slab=rank,
                                 strip_rows=args.strip_rows, layout=layout, ring_halo=world == 1)
             try:

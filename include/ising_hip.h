@@ -57,8 +57,8 @@ enum {
 
 /* device layout of the spin arrays.  The C-ABI always speaks the reference's packed layout (read/write/dump convert). */
 enum {
-	ISING_LAYOUT_AUTO = 0,   /* ballot where it applies and pays (from 2^27 spins per slab; from 2^26 for a slab that wraps in
-	                            place and can use ising_sweep's fused launches), else dense */
+	ISING_LAYOUT_AUTO = 0,   /* ballot where it applies and pays (from 2^26 spins per slab where fused launches apply: a slab that wraps
+	                            in place, a ring slab that can keep ghost rows; from 2^27 otherwise), else dense */
 	ISING_LAYOUT_NIBBLE = 1, /* the reference's: 4 bits per spin, 16 spins per 64-bit word (optimized/main.cu:40, :1243) */
 	ISING_LAYOUT_DENSE = 2,  /* 1 bit per spin, 32 spins per 32-bit word = one reference 128-bit vector per word */
 	ISING_LAYOUT_BALLOT = 3  /* 1 bit per spin, 64-bit words in the update kernel's wave-ballot order (ising_ballot.hip),
@@ -188,7 +188,7 @@ int ising_halo_ptrs(ising_ctx *ctx, int color, void **send_top, void **send_bot,
                     size_t *row_bytes);
 /* The same surface for the DEEP exchange the library's own ring uses (ising_ring_sweep / ising_rank_sweep), for callers
  * that bring their own transport (MPI, torch.distributed, ...).  A ring slab on the ballot layout that owns its buffer
- * keeps *depth = G ghost rows on either side (32, or Y/2 on flat slabs; 1 = no such rows: use the one-row surface above):
+ * keeps *depth = G ghost rows on either side (64, or Y/2 on flat slabs; 1 = no such rows: use the one-row surface above):
  *   send_top / send_bot : this slab's first / last G rows of `color` (block_bytes each, contiguous) -> previous / next slab;
  *   recv_top / recv_bot : the ghost rows above row 0 / below row Y-1 <- the previous slab's last / the next slab's first G rows.
  * Once both blocks of a colour have been filled -- by work ordered before the context's stream --, say so with

@@ -193,8 +193,11 @@ long long fused_tickets(int nwc, int Y, int H, bool wide) { return ((long long)n
 int choose_fused_strip_rows(int nwc, int Y, bool wide) {
 	if (!wide && (long long)nwc * Y < 12288) return 1;    // 2^26 spins: one-row units (four ticket counters, ising_create)
 	if (wide) return (Y % 2) == 0 ? 2 : 1;                  // 2^27 spins
-	for (int H = 16; H > 4; H >>= 1)
-		if ((Y % H) == 0 && fused_tickets(nwc, Y, H, false) >= 8192) return H;
+	// (tools/h_probe.py, grid_probe2.py at the end of round 2: 16 rows need 8192 tickets a level -- 49152^2 with 4608: -0.8 %,
+	// 57344^2 with 6272: -1.0 % against 8 rows --, 8 rows 4096: 32768^2 3356 -> 3394 flips/ns against 4 rows, 65536 x 16384
+	// 3317 -> 3380, 24576 x 49152 3361 -> 3412, 40960^2 3385 -> 3421; with 2304 (24576^2) 3288 -> 3149)
+	if ((Y % 16) == 0 && fused_tickets(nwc, Y, 16, false) >= 8192) return 16;
+	if ((Y % 8) == 0 && fused_tickets(nwc, Y, 8, false) >= 4096) return 8;
 	return (Y % 4) == 0 ? 4 : ((Y % 2) == 0 ? 2 : 1);
 }
 
@@ -348,7 +351,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	//   2^26 (8192^2)    4-wave workgroups, H = 1, 4 per CU (T = 2048), four ticket counters     2606 vs 2125 (dense layout 2150)
 	//   2^27             8-wave workgroups, H = 2, 2 per CU (T = 1024)      2908 vs 2580
 	//   2^28 (16384^2)   4-wave, H = 4, 4 per CU (T = 2048)                 3099 vs 3048
-	//   2^29 ...         4-wave, the tallest H of 16, 8, 4 with T >= 8192 (else 4), 5 per CU (6 from T = 16384, 4 below 8192):
+	//   2^29 ...         4-wave, H = 16 where T >= 8192, else 8 where T >= 4096, else 4; 5 per CU (6 from T = 16384, 4 below 8192):
 	//                    24576^2 3234 vs 3182, 32768^2 3383 vs 3407, 65536 x 32768 3437 vs 3463, 65536^2 3490-3500 vs 3490-3500 (profiles/policy_probe_r02.txt)
 	// ISING_FUSED=0/1, ISING_FUSED_WIDE=0/1, cfg.strip_rows and ISING_FUSED_WGS (grid) override.
 	const long long spins = (long long)cfg->X * cfg->Y;
@@ -360,18 +363,37 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// apply; below, and for 2^26 .. 2^27 in a ring, the dense kernel is ahead.  (A partly dead last wave column wastes its
 	// dead lanes' draws: worth it while they are under a tenth of the row -- the dense kernel is 12 % behind.)
 	const bool ballot_pays = whole || 10 * c->gx > 9 * 4 * c->nwc();
-	const long long ballot_from = (c->fused && fused_can) ? (1LL << 26) : (1LL << 27);
+	// (a ring slab that can keep ghost rows sweeps in fused launches as well, see below)
+	const bool deep_can = !c->wrap && !cfg->XSL && !cfg->use_J && !cfg->lattice_mem && cfg->Y >= 4 &&
+	                      !(getenv("ISING_RING_GHOST") && atoi(getenv("ISING_RING_GHOST")) < 2);
+	const long long ballot_from = ((c->fused && fused_can) || deep_can) ? (1LL << 26) : (1LL << 27);
 	if (cfg->layout == ISING_LAYOUT_AUTO && ballot_ok && ballot_pays && c->fast_ok && spins >= ballot_from && !getenv("ISING_NO_BALLOT"))
 		c->ballot = true;
 	if (c->ballot) c->lld = c->nwc() * 64;
 	const bool fused_shape = c->ballot && c->fused && fused_can;
-	// (a ring slab that will keep ghost rows, below: its sweeps are fused launches too -- 4-wave workgroups)
-	const bool deep_ring = c->ballot && !c->wrap && !cfg->XSL && !cfg->use_J && !cfg->lattice_mem && cfg->Y >= 4 &&
-	                       !(getenv("ISING_RING_GHOST") && atoi(getenv("ISING_RING_GHOST")) < 2);
+	// A ring slab on the ballot layout keeps G ghost rows on either side (ising_ctx::ghost_rows; ising_ring.cpp: sweep_deep):
+	// G rows of both colours travel every G colour half-sweeps, fused launches of G levels run in between.  Not with -J
+	// (the couplings of the ghost rows would have to travel too), sub-lattices, or a caller-owned buffer (fixed shape).
+	if (c->ballot && deep_can) {
+		// (64 = the levels one fused launch carries.  Ring of one over RCCL, 32 -> 64 rows: 8192^2 2231 -> 2380 flips/ns,
+		// 8192 x 16384 2497 -> 2712, 16384^2 2915 -> 2980, 32768^2 3317 -> 3340, 65536^2 3413 -> 3424: the launch boundary
+		// and the exchange come half as often, the redundant rows are 128 of Y)
+		int G = 64;
+		if (const char *e = getenv("ISING_RING_GHOST")) G = atoi(e);
+		G = std::min(G, cfg->Y / 2) & ~1;
+		c->ghost_rows = G >= 2 ? G : 1;
+	}
+	const bool deep_ring = c->ghost_rows > 1;
+	// Its fused launches take the single slab's shape below 2^28 spins (one- and two-row units, 8-wave workgroups at 2^27:
+	// a ring of one at 8192^2 2124 -> 2231 flips/ns, 8192 x 16384 2415 -> 2615; the dense layout with one halo row per colour
+	// half-sweep, which AUTO used to pick for ring slabs of 2^26 spins: 1157); from there up 4-wave workgroups and the strip
+	// height of the per-colour launches (131072 x 16384 measured -0.8 % against a single slab with H = 16, -1.7 % with the
+	// H = 8 the single-slab rule would pick).  ISING_RING_SHAPE=single|plain overrides.
+	bool deep_single = deep_ring && spins < (1LL << 28);
+	if (const char *e = getenv("ISING_RING_SHAPE")) deep_single = deep_ring && !strcmp(e, "single");
+	if (deep_ring && !deep_single) c->fused_wide = 0;
 	c->H = cfg->strip_rows > 0 ? cfg->strip_rows
-	       : (fused_shape ? choose_fused_strip_rows(c->nwc(), cfg->Y, c->fused_wide != 0) : choose_strip_rows(c->gx, cfg->Y, c->dense, c->ballot));
-	// (ring slabs keep the strip height of the per-colour launches for their fused launches too: 131072 x 16384 measured
-	// -0.8 % against a single slab with H = 16, -1.7 % with the H = 8 the single-slab rule would pick)
+	       : ((fused_shape || deep_single) ? choose_fused_strip_rows(c->nwc(), cfg->Y, c->fused_wide != 0) : choose_strip_rows(c->gx, cfg->Y, c->dense, c->ballot));
 	if (cfg->Y % c->H) { const int h = c->H; delete c; return fail(ISING_E_ARG, "strip_rows %d does not divide Y %d", h, cfg->Y); }
 	c->nstrips = cfg->Y / c->H;
 	c->color_words = (size_t)cfg->Y * c->lld;
@@ -379,28 +401,17 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// carry the non-temporal hint, which keeps the accept-mask slots in the L2s (ISING_FUSED_NT=0/1 overrides)
 	if (const char *e = getenv("ISING_FUSED_NT")) c->fused_nt = atoi(e) != 0;
 	else c->fused_nt = spins > (1LL << 31);
-	if (fused_shape) { // workgroups per CU of a fused launch (the chip holds 6 of 4 waves, 3 of 8)
-		const long long T = fused_tickets(c->nwc(), cfg->Y, c->H, c->fused_wide != 0);
-		c->fused_wg_per_cu = c->fused_wide ? (T >= 2048 ? 3 : 2) : (T >= 16384 ? 6 : (T >= 8192 ? 5 : (T >= 2048 ? 4 : 3)));
+	if (fused_shape || deep_ring) { // workgroups per CU of a fused launch (the chip holds 6 of 4 waves, 3 of 8)
+		const long long T = fused_tickets(c->nwc(), deep_ring ? cfg->Y + 2 * c->ghost_rows : cfg->Y, c->H, c->fused_wide != 0);
+		// (8-row strips want a little more than 8192 tickets for the fifth workgroup: 131072 x 16384 with exactly 8192: 3327 with
+		// five, 3407 with four; 49152^2 with 9216: 3455 with five, 3376 with four)
+		c->fused_wg_per_cu = c->fused_wide ? (T >= 2048 ? 3 : 2) : (T >= 16384 ? 6 : (T >= (c->H == 8 ? 9216 : 8192) ? 5 : (T >= 2048 ? 4 : 3)));
 		// Several ticket counters where 4-wave workgroups draw one- or two-row units (2^26 spins): one counter hands out
 		// ~80 tickets per us; 8192^2 with one-row units at 2600 flips/ns needs 159 (four counters), with two-row units
 		// 79 (two).  ISING_FUSED_TICKETS2=0/2/4 overrides.
-		c->fused_tickets2 = (!c->fused_wide && T <= 2048 && c->H == 1) ? 4 : ((!c->fused_wide && T <= 1024 && c->H == 2) ? 2 : 0);
+		const long long T0 = fused_tickets(c->nwc(), cfg->Y, c->H, c->fused_wide != 0); // (without a ring slab's ghost rows)
+		c->fused_tickets2 = (!c->fused_wide && T0 <= 2048 && c->H == 1) ? 4 : ((!c->fused_wide && T0 <= 1024 && c->H == 2) ? 2 : 0);
 		if (const char *e2 = getenv("ISING_FUSED_TICKETS2")) { const int k = atoi(e2); c->fused_tickets2 = (k == 2 || k == 4) ? k : (k ? 2 : 0); }
-	}
-	// A ring slab on the ballot layout keeps G ghost rows on either side (ising_ctx::ghost_rows; ising_ring.cpp: sweep_deep):
-	// G rows of both colours travel every G colour half-sweeps, fused launches of G levels run in between.  Not with -J
-	// (the couplings of the ghost rows would have to travel too), sub-lattices, or a caller-owned buffer (fixed shape).
-	if (deep_ring) {
-		int G = 32;
-		if (const char *e = getenv("ISING_RING_GHOST")) G = atoi(e);
-		G = std::min(G, cfg->Y / 2) & ~1;
-		c->ghost_rows = G >= 2 ? G : 1;
-		if (c->ghost_rows > 1) { // the fused launches of the ring: 4-wave workgroups, the strip height of the per-colour launches
-			c->fused_wide = 0;
-			const long long T = fused_tickets(c->nwc(), cfg->Y + 2 * c->ghost_rows, c->H, false);
-			c->fused_wg_per_cu = T >= 16384 ? 6 : (T >= 8192 ? 5 : (T >= 2048 ? 4 : 3));
-		}
 	}
 
 	hipError_t e = hipSetDevice(cfg->device);

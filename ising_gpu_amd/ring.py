@@ -474,7 +474,7 @@ class NativeRing:
 
 def open_native_ring(slab, log=None):
     """The library's own RCCL ring on a slab that owns its buffer (ring slabs on the ballot layout then keep ghost rows
-    32 deep and exchange every 16 sweeps, csrc/ising_ring.cpp: sweep_deep) -- or None when it does not come up on every
+    64 deep and exchange every 32 sweeps, csrc/ising_ring.cpp: sweep_deep) -- or None when it does not come up on every
     rank (the caller then builds a torch-owned slab and calls open_ring for the torch.distributed rings)."""
     log = log or (lambda *a: None)
     world = dist.get_world_size() if dist.is_initialized() else 1

@@ -121,7 +121,7 @@ def test_config4_131072_cli_eight_devices_mapped_to_one(gpu):
 
 
 _RING_OF_ONE = {
-    "rccl, ghost rows 32 deep (default)": ("native", {}),
+    "rccl, ghost rows 64 deep (default)": ("native", {}),
     "rccl, one halo row, event schedule": ("native", {"ISING_RING_GHOST": "1"}),
     "rccl, one halo row, flag schedule": ("native", {"ISING_RING_GHOST": "1", "ISING_RING_FLAGS": "1"}),
     "rccl, caller-owned buffer": ("native-torch", {}),

@@ -135,7 +135,7 @@ def test_bench_line_on_a_small_lattice(gpu, oracle_mod):
     assert (b["config"]["up"], b["config"]["down"]) == orc.count()
 
 
-@pytest.mark.parametrize("ring,port,exchange", [("native", 29551, "rccl-native"), ("torch", 29552, "p2p-ghost32")])
+@pytest.mark.parametrize("ring,port,exchange", [("native", 29551, "rccl-native"), ("torch", 29552, "p2p-ghost64")])
 def test_bench_ring_code_path_with_one_rank(gpu, oracle_mod, ring, port, exchange):
     """bench.py's N > 1 code path as far as one GPU can run it: under torch.distributed.run with ONE rank and --force-ring the
     slab is a ring of one -- torch.distributed (nccl) is initialised, and either the library attaches its RCCL communicator

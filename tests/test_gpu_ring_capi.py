@@ -150,11 +150,11 @@ def test_multi_process_ring_over_nccl(gpu, mode):
 
 
 def test_ring_slabs_keep_ghost_rows_where_they_can(gpu, monkeypatch):
-    """Ballot ring slabs that own their buffer keep ghost rows (min(32, Y/2) deep; ising_sweep_info: the ring sweeps them in
+    """Ballot ring slabs that own their buffer keep ghost rows (min(64, Y/2) deep; ising_sweep_info: the ring sweeps them in
     fused launches of half as many sweeps); the dense layout, -J, a caller-owned buffer and ISING_RING_GHOST=1 do not."""
     import torch  # noqa: F401
-    with ig.IsingSlab(8192, 128, nslabs=2, slab=0, layout=ig.LAYOUT_BALLOT) as s:
-        assert s.fused and s.max_sweeps_per_launch == 16
+    with ig.IsingSlab(8192, 256, nslabs=2, slab=0, layout=ig.LAYOUT_BALLOT) as s:
+        assert s.fused and s.max_sweeps_per_launch == 32
     with ig.IsingSlab(8192, 32, nslabs=2, slab=0, layout=ig.LAYOUT_BALLOT) as s:
         assert s.fused and s.max_sweeps_per_launch == 8
     with ig.IsingSlab(8192, 128, nslabs=2, slab=0, layout=ig.LAYOUT_DENSE) as s:
@@ -203,7 +203,7 @@ def test_deep_exchange_surface_with_a_callers_own_copies(gpu, nslabs, Yk, sweeps
     slabs = [ig.IsingSlab(X, Yk, seed=seed, temp=temp, nslabs=nslabs, slab=k, layout=ig.LAYOUT_BALLOT, ring_halo=nslabs == 1) for k in range(nslabs)]
     try:
         G = slabs[0].ghost_ptrs(ig.BLACK)[0]
-        assert G == min(32, Yk // 2)
+        assert G == min(64, Yk // 2)
         for s in slabs:
             s.init()
         with pytest.raises(ig.IsingError, match="not current"):
