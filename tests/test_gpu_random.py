@@ -105,3 +105,60 @@ def test_random_fused_configuration(gpu, oracle_mod, monkeypatch, X, Y, strip, w
         assert s.count() == orc.count()
         if jp is None:
             assert s.bond_equal() == orc.bond_equal()
+
+
+def _ring_cases(n):
+    rng = np.random.default_rng(4711)
+    out = []
+    for k in range(n):
+        nslabs = int(rng.choice([1, 2, 3, 4]))
+        X = int(rng.choice([8192, 16384, 24576, 12288]))
+        Yk = int(rng.choice([16, 32, 48, 64, 96, 160]))
+        ghost = str(rng.choice(["", "4", "8", "16", "64"]))
+        shape = str(rng.choice(["single", "plain"]))
+        wide = int(rng.random() < 0.4)
+        t2 = str(rng.choice(["", "0", "2", "4"]))
+        wgs = str(rng.choice(["", "1", "3", "17"]))
+        strip = int(rng.choice([0, 1, 2, 4, 8]))
+        if Yk % max(strip, 1):
+            strip = 0
+        inline = str(rng.choice(["0", "1"]))
+        temp = float(np.float32(rng.choice([1.0, 2.0, float(ig.CRIT_TEMP_F32), 3.0])))
+        seed = int(rng.integers(1, 2**40))
+        sweeps = (int(rng.integers(1, 20)), int(rng.integers(1, 40)))
+        out.append(pytest.param(nslabs, X, Yk, ghost, shape, wide, t2, wgs, strip, inline, temp, seed, sweeps,
+                                id=f"{k}-{nslabs}x{X}x{Yk}-G{ghost or 'auto'}-{shape}-w{wide}-t{t2 or 'auto'}-g{wgs or 'auto'}-s{strip}-i{inline}-n{sweeps[0]}+{sweeps[1]}"))
+    return out
+
+
+@pytest.mark.parametrize("nslabs,X,Yk,ghost,shape,wide,t2,wgs,strip,inline,temp,seed,sweeps", _ring_cases(24))
+def test_random_ring_with_ghost_rows(gpu, oracle_mod, monkeypatch, nslabs, X, Yk, ghost, shape, wide, t2, wgs, strip, inline, temp, seed, sweeps):
+    """Ring slabs with ghost rows under random shapes and switches: 1 .. 4 slabs of one device (copy transport on the comm
+    streams or inline; a ring of one sends to itself), ghost rows 4 .. 64 deep, the single slab's launch shape (one- and
+    two-row units, several ticket counters, 8-wave workgroups) or the per-colour launches' strips, grids from one workgroup
+    up, two sweep calls whose lengths do not line up with the exchange period -- against the oracle's single lattice."""
+    monkeypatch.setenv("ISING_RING_STORE", "0")  # (slabs of one device would otherwise store straight into each other's halo rows)
+    monkeypatch.setenv("ISING_RING_INLINE", inline)
+    monkeypatch.setenv("ISING_RING_SHAPE", shape)
+    monkeypatch.setenv("ISING_FUSED_WIDE", str(wide))
+    for name, val in (("ISING_RING_GHOST", ghost), ("ISING_FUSED_TICKETS2", t2), ("ISING_FUSED_WGS", wgs)):
+        if val:
+            monkeypatch.setenv(name, val)
+        else:
+            monkeypatch.delenv(name, raising=False)
+    orc = oracle_mod.OracleLattice(X, Yk * nslabs, seed=seed, temp=temp).init()
+    ring = ig.SlabSet([ig.IsingSlab(X, Yk, seed=seed, temp=temp, nslabs=nslabs, slab=k, layout=ig.LAYOUT_BALLOT, strip_rows=strip, ring_halo=nslabs == 1)
+                       for k in range(nslabs)])
+    try:
+        ring.init()
+        G = ring.slabs[0].ghost_ptrs(ig.BLACK)[0]
+        assert G == (min(int(ghost or 64), Yk // 2) & ~1) and ring.slabs[0].max_sweeps_per_launch == G // 2
+        for n in sweeps:
+            ring.sweep(n)
+            orc.sweep(n)
+            assert np.array_equal(np.concatenate([s.read(ig.BLACK) for s in ring.slabs]), orc.black), f"black after {ring.it} sweeps"
+            assert np.array_equal(np.concatenate([s.read(ig.WHITE) for s in ring.slabs]), orc.white), f"white after {ring.it} sweeps"
+        assert ring.count() == orc.count()
+        assert ring.bond_equal() == orc.bond_equal()
+    finally:
+        ring.close()
