@@ -4,7 +4,7 @@
 A "step" is one full lattice sweep (black half-sweep + white half-sweep, the reference's hot loop
 optimized/main.cu:1763-1805) over this rank's slab.  Per-GPU workload (fixed as N grows => weak scaling):
 X = 65536 columns x Y = 65536 rows at T = T_c (CRIT_TEMP, optimized/main.cu:42), the 65536^2 lattice BASELINE.json's
-target is quoted on (configs[2]); with N ranks the lattice is (N*65536) x 65536, slabs along Y, 32 rows of each
+target is quoted on (configs[2]); with N ranks the lattice is (N*65536) x 65536, slabs along Y, 64 rows of each
 colour to each ring neighbour every 32 sweeps (ghost rows; one row per colour half-sweep on the fallback ring).  The lattice is generated on the device from the seed: "synthetic".
 
   N = 1   the slab sweeps itself (ising_sweep), `batch` sweeps per call (batch = the largest divisor <= 32 of

@@ -1,7 +1,7 @@
 """One process per GPU over the nccl (= RCCL) backend: tools/ring_ranks_nccl.py native|p2p|allgather.
 native    -> ising_gpu_amd.NativeRing (the ring inside libising_hip.so: second stream + ncclSend/ncclRecv)
 p2p       -> the unmodified ising_gpu_amd.SlabRing over torch.distributed batch_isend_irecv: a library-owned slab (ballot layout:
-             ghost rows 32 deep through ising_ghost_ptrs / ising_sweep_ghost) and a torch-owned one (one row per colour half-sweep)
+             ghost rows Y/2 = 32 deep here, through ising_ghost_ptrs / ising_sweep_ghost) and a torch-owned one (one row per colour half-sweep)
 allgather -> SlabRing(exchange="allgather")
 Every rank compares its slab and the global counts with the CPU oracle, for the ballot and the dense layout.
 Launch: python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 --master-port 29541 tools/ring_ranks_nccl.py native"""
@@ -22,7 +22,7 @@ rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int
 torch.cuda.set_device(local)
 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 X, Y, seed, temp, sweeps = 8192, 64, 2024, ig.CRIT_TEMP_F32, 5
-# native: a slab that owns its buffer (ballot layout: ghost rows 32 deep, one exchange per 16 sweeps) and a torch-owned one (one halo row)
+# native: a slab that owns its buffer (ballot layout: ghost rows Y/2 = 32 deep here, one exchange per 16 sweeps) and a torch-owned one (one halo row)
 cases = [(lay, own) for lay in (ig.LAYOUT_BALLOT, ig.LAYOUT_DENSE) for own in ((True, False) if mode in ("native", "p2p") else (False,))]
 for layout, own in cases:
     if own and mode == "native":
