@@ -364,7 +364,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// dead lanes' draws: worth it while they are under a tenth of the row -- the dense kernel is 12 % behind.)
 	const bool ballot_pays = whole || 10 * c->gx > 9 * 4 * c->nwc();
 	// (a ring slab that can keep ghost rows sweeps in fused launches as well, see below)
-	const bool deep_can = !c->wrap && !cfg->XSL && !cfg->use_J && !cfg->lattice_mem && cfg->Y >= 4 &&
+	const bool deep_can = !c->wrap && !cfg->XSL && !(cfg->use_J && cfg->coupling_mem) && !cfg->lattice_mem && cfg->Y >= 4 &&
 	                      !(getenv("ISING_RING_GHOST") && atoi(getenv("ISING_RING_GHOST")) < 2);
 	const long long ballot_from = ((c->fused && fused_can) || deep_can) ? (1LL << 26) : (1LL << 27);
 	if (cfg->layout == ISING_LAYOUT_AUTO && ballot_ok && ballot_pays && c->fast_ok && spins >= ballot_from && !getenv("ISING_NO_BALLOT"))
@@ -372,8 +372,8 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (c->ballot) c->lld = c->nwc() * 64;
 	const bool fused_shape = c->ballot && c->fused && fused_can;
 	// A ring slab on the ballot layout keeps G ghost rows on either side (ising_ctx::ghost_rows; ising_ring.cpp: sweep_deep):
-	// G rows of both colours travel every G colour half-sweeps, fused launches of G levels run in between.  Not with -J
-	// (the couplings of the ghost rows would have to travel too), sub-lattices, or a caller-owned buffer (fixed shape).
+	// G rows of both colours travel every G colour half-sweeps, fused launches of G levels run in between.  Not with
+	// sub-lattices (nothing crosses slabs) or a caller-owned buffer (fixed shape).
 	if (c->ballot && deep_can) {
 		// (64 = the levels one fused launch carries.  Ring of one over RCCL, 32 -> 64 rows: 8192^2 2231 -> 2380 flips/ns,
 		// 8192 x 16384 2497 -> 2712, 16384^2 2915 -> 2980, 32768^2 3317 -> 3340, 65536^2 3413 -> 3424: the launch boundary
@@ -382,6 +382,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		if (const char *e = getenv("ISING_RING_GHOST")) G = atoi(e);
 		G = std::min(G, cfg->Y / 2) & ~1;
 		c->ghost_rows = G >= 2 ? G : 1;
+		if (c->ghost_rows > 1 && cfg->use_J) c->ham_ghost = c->ghost_rows + 1; // -J: the ghost rows' couplings are generated in place
 	}
 	const bool deep_ring = c->ghost_rows > 1;
 	// Its fused launches take the single slab's shape below 2^28 spins (one- and two-row units, 8-wave workgroups at 2^27:
@@ -980,6 +981,13 @@ int ising_init_couplings_black(ising_ctx *c) {
 	p.Y = c->cfg.Y;
 	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
 	p.wrap = c->wrap;
+	if (c->ham_ghost > 1) { // ring slab with ghost rows: rows [-hg, Y + hg), each with the draws of its global row
+		const uint32_t total = (uint32_t)c->cfg.nslabs * (uint32_t)c->cfg.Y, hg = (uint32_t)c->ham_ghost;
+		p.hamB = c->ham(0) - (size_t)hg * c->lld_packed;
+		p.Y = c->cfg.Y + 2 * (int)hg;
+		p.row_base = (p.row_base + total - hg % total) % total;
+		p.total_rows = total;
+	}
 	const uint64_t thr = draw_prefix(prob, false); // curand_uniform(x) < tgtProb, :193
 	if (thr >= (1ull << 32)) return fail(ISING_E_ARG, "J probability %g sets every bit", (double)prob); // unreachable: u <= 1 and prob <= 1 gives at most 2^32 - 1... see below
 	p.thr = (uint32_t)thr;
@@ -1002,10 +1010,17 @@ int ising_init_couplings_white(ising_ctx *c) {
 	p.slW = c->cfg.XSL ? c->cfg.XSL / 32 : c->lld_packed;
 	p.slY = c->cfg.XSL ? c->cfg.YSL : 0;
 	p.wrap = c->wrap;
+	const int g = c->ham_ghost - 1; // coupling rows beyond the slab's own that the update reads (ghost rows of a ring slab)
+	if (g > 0) {                    // white rows [-g, Y + g) from black rows [-g - 1, Y + g + 1); only the row parity counts here
+		p.hamB -= (size_t)g * c->lld_packed;
+		p.hamW -= (size_t)g * c->lld_packed;
+		p.Y += 2 * g;
+		p.row_base += (uint32_t)(g & 1);
+	}
 	HIP_TRY(ising::launch_ham_init_white(p, c->stream));
 	if (c->ballot) {
 		// the ballot update reads four planes of ballot-order coupling words per row and wave column
-		for (int w = 0; w < 2; w++) HIP_TRY(ising::launch_ham_to_ballot(c->ham(w), c->gx, c->cfg.Y, c->stream));
+		for (int w = 0; w < 2; w++) HIP_TRY(ising::launch_ham_to_ballot(c->ham(w) - (size_t)g * c->lld_packed, c->gx, c->cfg.Y + 2 * g, c->stream));
 		c->ham_form = 2;
 	} else if (c->dense) {
 		// the dense update reads four coupling bit-planes per 32-site word: transpose both arrays in place

@@ -102,8 +102,12 @@ struct ising_ctx {
 	uint64_t *tmp(int color) const { return d_tmp + (size_t)color * ((size_t)cfg.Y + 2) * lld_dense + lld_dense; }
 	int nwc() const { return (gx + 3) / 4; } // ballot layout: wave columns per row
 	size_t ham_words() const { return (size_t)cfg.Y * lld_packed; } // per coupling array, without its two halo rows
-	size_t ham_alloc_words() const { return 2 * (ham_words() + 2 * (size_t)lld_packed); }
-	uint64_t *ham(int which) const { return d_ham + (size_t)which * (ham_words() + 2 * (size_t)lld_packed) + lld_packed; }
+	// Rows each coupling array keeps above row 0 / below row Y-1: the halo row, or -- ring slab with ghost rows -- the couplings
+	// of the ghost rows plus one row (they are generated in place like the slab's own, global row around the ring; the white
+	// ones gather from the black rows one further out).  Fixed at creation.
+	int ham_ghost = 1;
+	size_t ham_alloc_words() const { return 2 * (ham_words() + 2 * (size_t)ham_ghost * lld_packed); }
+	uint64_t *ham(int which) const { return d_ham + (size_t)which * (ham_words() + 2 * (size_t)ham_ghost * lld_packed) + (size_t)ham_ghost * lld_packed; }
 	// "colour" 0/1 = spin arrays, 2 = black couplings; row stride and row count-words of that array
 	uint64_t *plane(int kind) const { return kind == ISING_HAM_BLACK ? ham(0) : lat(kind); }
 	int plane_ld(int kind) const { return kind == ISING_HAM_BLACK ? lld_packed : lld; }

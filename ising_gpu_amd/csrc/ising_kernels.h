@@ -100,6 +100,7 @@ struct HamInitParams {
 	uint32_t row_base;
 	int32_t wrap;
 	uint32_t thr;          // number of draws x with curand_uniform(x) < prob
+	uint32_t total_rows;   // rows of the whole lattice when the range runs around the ring (ghost rows of a ring slab), else 0
 };
 hipError_t launch_ham_init_black(const HamInitParams &p, hipStream_t stream);
 // hamiltInitW_k as a gather: every white coupling word is assembled from the black words at the other ends of its bonds

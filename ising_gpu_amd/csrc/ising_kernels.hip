@@ -380,7 +380,8 @@ __global__ void __launch_bounds__(THREADS) ham_init_black_k(const HamInitParams 
 	const int lr = unit / p.gx;
 	const int bx = unit - lr * p.gx;
 	const int vecs = p.gx * 32;
-	const uint32_t grow = p.row_base + (uint32_t)lr;
+	uint32_t grow = p.row_base + (uint32_t)lr;
+	if (p.total_rows) grow %= p.total_rows; // (a ring of one wraps more than once: its ghost rows are its own rows)
 	const uint32_t tid = ((grow >> 4) * (uint32_t)p.gx + (uint32_t)bx) * 256u + (grow & 15u) * 16u + (uint32_t)tx;
 	const PhiloxRow pr = philox_row_setup(tid, p.seed_lo, p.seed_hi + 2u * PHILOX_W1);
 	uint4 *row = reinterpret_cast<uint4 *>(p.hamB) + (size_t)lr * vecs;

@@ -126,17 +126,18 @@ def _ring_cases(n):
         temp = float(np.float32(rng.choice([1.0, 2.0, float(ig.CRIT_TEMP_F32), 3.0])))
         seed = int(rng.integers(1, 2**40))
         sweeps = (int(rng.integers(1, 20)), int(rng.integers(1, 40)))
-        out.append(pytest.param(nslabs, X, Yk, ghost, shape, wide, t2, wgs, strip, inline, temp, seed, sweeps,
-                                id=f"{k}-{nslabs}x{X}x{Yk}-G{ghost or 'auto'}-{shape}-w{wide}-t{t2 or 'auto'}-g{wgs or 'auto'}-s{strip}-i{inline}-n{sweeps[0]}+{sweeps[1]}"))
+        jp = float(rng.choice([0.2, 0.7])) if (rng.random() < 0.35 and X % 8192 == 0) else None
+        out.append(pytest.param(nslabs, X, Yk, ghost, shape, wide, t2, wgs, strip, inline, temp, seed, sweeps, jp,
+                                id=f"{k}-{nslabs}x{X}x{Yk}-G{ghost or 'auto'}-{shape}-w{wide}-t{t2 or 'auto'}-g{wgs or 'auto'}-s{strip}-i{inline}-n{sweeps[0]}+{sweeps[1]}-J{jp}"))
     return out
 
 
-@pytest.mark.parametrize("nslabs,X,Yk,ghost,shape,wide,t2,wgs,strip,inline,temp,seed,sweeps", _ring_cases(24))
-def test_random_ring_with_ghost_rows(gpu, oracle_mod, monkeypatch, nslabs, X, Yk, ghost, shape, wide, t2, wgs, strip, inline, temp, seed, sweeps):
+@pytest.mark.parametrize("nslabs,X,Yk,ghost,shape,wide,t2,wgs,strip,inline,temp,seed,sweeps,jp", _ring_cases(32))
+def test_random_ring_with_ghost_rows(gpu, oracle_mod, monkeypatch, nslabs, X, Yk, ghost, shape, wide, t2, wgs, strip, inline, temp, seed, sweeps, jp):
     """Ring slabs with ghost rows under random shapes and switches: 1 .. 4 slabs of one device (copy transport on the comm
     streams or inline; a ring of one sends to itself), ghost rows 4 .. 64 deep, the single slab's launch shape (one- and
     two-row units, several ticket counters, 8-wave workgroups) or the per-colour launches' strips, grids from one workgroup
-    up, two sweep calls whose lengths do not line up with the exchange period -- against the oracle's single lattice."""
+    up, -J couplings, two sweep calls whose lengths do not line up with the exchange period -- against the oracle's single lattice."""
     monkeypatch.setenv("ISING_RING_STORE", "0")  # (slabs of one device would otherwise store straight into each other's halo rows)
     monkeypatch.setenv("ISING_RING_INLINE", inline)
     monkeypatch.setenv("ISING_RING_SHAPE", shape)
@@ -147,10 +148,15 @@ def test_random_ring_with_ghost_rows(gpu, oracle_mod, monkeypatch, nslabs, X, Yk
         else:
             monkeypatch.delenv(name, raising=False)
     orc = oracle_mod.OracleLattice(X, Yk * nslabs, seed=seed, temp=temp).init()
-    ring = ig.SlabSet([ig.IsingSlab(X, Yk, seed=seed, temp=temp, nslabs=nslabs, slab=k, layout=ig.LAYOUT_BALLOT, strip_rows=strip, ring_halo=nslabs == 1)
-                       for k in range(nslabs)])
+    if jp is not None:
+        orc.init_couplings(jp)
+    ring = ig.SlabSet([ig.IsingSlab(X, Yk, seed=seed, temp=temp, nslabs=nslabs, slab=k, layout=ig.LAYOUT_BALLOT, strip_rows=strip, ring_halo=nslabs == 1,
+                                    J_prob=jp) for k in range(nslabs)])
     try:
         ring.init()
+        if jp is not None:  # (-J, part of SlabSet.init: the ghost rows' couplings are generated in place, global row around the ring)
+            assert np.array_equal(np.concatenate([s.read_couplings(ig.BLACK) for s in ring.slabs]), orc.hamB)
+            assert np.array_equal(np.concatenate([s.read_couplings(ig.WHITE) for s in ring.slabs]), orc.hamW)
         G = ring.slabs[0].ghost_ptrs(ig.BLACK)[0]
         assert G == (min(int(ghost or 64), Yk // 2) & ~1) and ring.slabs[0].max_sweeps_per_launch == G // 2
         for n in sweeps:
@@ -159,6 +165,7 @@ def test_random_ring_with_ghost_rows(gpu, oracle_mod, monkeypatch, nslabs, X, Yk
             assert np.array_equal(np.concatenate([s.read(ig.BLACK) for s in ring.slabs]), orc.black), f"black after {ring.it} sweeps"
             assert np.array_equal(np.concatenate([s.read(ig.WHITE) for s in ring.slabs]), orc.white), f"white after {ring.it} sweeps"
         assert ring.count() == orc.count()
-        assert ring.bond_equal() == orc.bond_equal()
+        if jp is None:
+            assert ring.bond_equal() == orc.bond_equal()
     finally:
         ring.close()

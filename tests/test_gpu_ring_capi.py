@@ -151,7 +151,8 @@ def test_multi_process_ring_over_nccl(gpu, mode):
 
 def test_ring_slabs_keep_ghost_rows_where_they_can(gpu, monkeypatch):
     """Ballot ring slabs that own their buffer keep ghost rows (min(64, Y/2) deep; ising_sweep_info: the ring sweeps them in
-    fused launches of half as many sweeps); the dense layout, -J, a caller-owned buffer and ISING_RING_GHOST=1 do not."""
+    fused launches of half as many sweeps), with -J too (the ghost rows' couplings are generated in place); the dense layout, a
+    caller-owned buffer and ISING_RING_GHOST=1 do not."""
     import torch  # noqa: F401
     with ig.IsingSlab(8192, 256, nslabs=2, slab=0, layout=ig.LAYOUT_BALLOT) as s:
         assert s.fused and s.max_sweeps_per_launch == 32
@@ -160,7 +161,7 @@ def test_ring_slabs_keep_ghost_rows_where_they_can(gpu, monkeypatch):
     with ig.IsingSlab(8192, 128, nslabs=2, slab=0, layout=ig.LAYOUT_DENSE) as s:
         assert not s.fused and s.max_sweeps_per_launch == 0
     with ig.IsingSlab(8192, 128, nslabs=2, slab=0, layout=ig.LAYOUT_BALLOT, J_prob=0.2) as s:
-        assert not s.fused
+        assert s.fused and s.max_sweeps_per_launch == 32
     b = ig.HipSlabBackend.create(8192, 128, device=0, nslabs=2, slab=0, layout=ig.LAYOUT_BALLOT)
     try:
         assert not b.slab.fused
