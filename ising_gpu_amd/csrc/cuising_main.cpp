@@ -489,7 +489,7 @@ int main(int argc, char **argv) {
 		cfg.strip_rows = 0; cfg.kernel = ISING_KERNEL_AUTO; cfg.layout = layout;
 		// --tsweep with two lattices of ~2^26 spins side by side: two-row strips (3 workgroups per CU each: both fit the
 		// chip) instead of the one-row strips a lone lattice of that size gets (4 per CU) -- 1.60 s against 1.65 s for config 5
-		if (doTsweep && ndev == 1 && !ts.anneal && ts.replicas != 1 && (long long)X * Y < 3 * (1LL << 25) && (Y % 2) == 0) cfg.strip_rows = 2;
+		if (doTsweep && ndev == 1 && !ts.anneal && ts.replicas != 1 && (long long)X * Y >= (1LL << 26) && (long long)X * Y < 3 * (1LL << 25) && (Y % 2) == 0) cfg.strip_rows = 2;
 		cfg.XSL = useSubLatt ? XSL : 0; cfg.YSL = useSubLatt ? YSL : 0;
 		cfg.use_J = useGenHamilt; cfg.J_prob = hamiltPerc1;
 		ising_ctx *c = nullptr;

@@ -191,7 +191,7 @@ void ballot_planes_to_planes(uint64_t *ham, size_t ngroups) {
 // fused launches: tickets per level, and the strip height that keeps a level at >= 8192 tickets (ising_create)
 long long fused_tickets(int nwc, int Y, int H, bool wide) { return ((long long)nwc * ((Y + H - 1) / H) + (wide ? 7 : 3)) / (wide ? 8 : 4); }
 int choose_fused_strip_rows(int nwc, int Y, bool wide) {
-	if (!wide && (long long)nwc * Y < 12288) return 1;    // 2^26 spins: one-row units (four ticket counters, ising_create)
+	if (!wide && (long long)nwc * Y < 12288) return 1;    // 2^25 .. 2^26 spins: one-row units (four ticket counters, ising_create)
 	if (wide) return (Y % 2) == 0 ? 2 : 1;                  // 2^27 spins
 	// (tools/h_probe.py, grid_probe2.py at the end of round 2: 16 rows need 8192 tickets a level -- 49152^2 with 4608: -0.8 %,
 	// 57344^2 with 6272: -1.0 % against 8 rows --, 8 rows 4096: 32768^2 3356 -> 3394 flips/ns against 4 rows, 65536 x 16384
@@ -343,11 +343,13 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	compute_tables(c, cfg->temp);
 	c->wrap = cfg->nslabs == 1 && !cfg->ring_halo;
 	// How ising_sweep launches on the ballot layout: fused launches (one launch = up to 32 sweeps, in-order tickets,
-	// per-strip completion counters; ising_ballot.hip) from 2^26 spins up, on a slab that wraps in place and has no
+	// per-strip completion counters; ising_ballot.hip) from 2^25 spins up, on a slab that wraps in place and has no
 	// sub-lattices.  A unit's parents are one level = T tickets back, so a level must hold a few times more tickets than
 	// workgroups run, or units find their parents unfinished and hold their slots asleep: the strip height H follows
 	// from T = wave rows / (H x waves per workgroup), and small lattices run FEWER workgroups than the chip holds.
 	// Measured (tools/grid_probe.py, grid_probe2.py), flips/ns fused vs one launch per colour + tail strips:
+	//   2^25 (8192 x 4096) 4-wave workgroups, H = 1, 3 per CU (T = 1024), four ticket counters   2184 vs the dense layout's 1827
+	//                    (tools/small_fused_probe.py; 8192 x 6144, T = 1536, 4 per CU: 2440 vs 2015; 2^24: 1369 vs 1415, so dense)
 	//   2^26 (8192^2)    4-wave workgroups, H = 1, 4 per CU (T = 2048), four ticket counters     2606 vs 2125 (dense layout 2150)
 	//   2^27             8-wave workgroups, H = 2, 2 per CU (T = 1024)      2908 vs 2580
 	//   2^28 (16384^2)   4-wave, H = 4, 4 per CU (T = 2048)                 3099 vs 3048
@@ -357,16 +359,16 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	const long long spins = (long long)cfg->X * cfg->Y;
 	const bool fused_can = c->wrap && !cfg->XSL;
 	const char *fz = getenv("ISING_FUSED"), *fw = getenv("ISING_FUSED_WIDE");
-	c->fused = fz ? atoi(fz) != 0 : spins >= (1LL << 26);
+	c->fused = fz ? atoi(fz) != 0 : spins >= (1LL << 25);
 	c->fused_wide = fw ? atoi(fw) : (spins >= 3 * (1LL << 25) && spins < (1LL << 28) ? 1 : 0);
-	// AUTO: the ballot kernel's two-phase row pipeline wins from 2^27 spins per slab up -- from 2^26 where fused launches
-	// apply; below, and for 2^26 .. 2^27 in a ring, the dense kernel is ahead.  (A partly dead last wave column wastes its
+	// AUTO: the ballot kernel's two-phase row pipeline wins from 2^27 spins per slab up -- from 2^25 where fused launches
+	// apply (a slab that wraps in place, a ring slab that can keep ghost rows); below, the dense kernel is ahead.  (A partly dead last wave column wastes its
 	// dead lanes' draws: worth it while they are under a tenth of the row -- the dense kernel is 12 % behind.)
 	const bool ballot_pays = whole || 10 * c->gx > 9 * 4 * c->nwc();
 	// (a ring slab that can keep ghost rows sweeps in fused launches as well, see below)
 	const bool deep_can = !c->wrap && !cfg->XSL && !(cfg->use_J && cfg->coupling_mem) && !cfg->lattice_mem && cfg->Y >= 4 &&
 	                      !(getenv("ISING_RING_GHOST") && atoi(getenv("ISING_RING_GHOST")) < 2);
-	const long long ballot_from = ((c->fused && fused_can) || deep_can) ? (1LL << 26) : (1LL << 27);
+	const long long ballot_from = ((c->fused && fused_can) || deep_can) ? (1LL << 25) : (1LL << 27);
 	if (cfg->layout == ISING_LAYOUT_AUTO && ballot_ok && ballot_pays && c->fast_ok && spins >= ballot_from && !getenv("ISING_NO_BALLOT"))
 		c->ballot = true;
 	if (c->ballot) c->lld = c->nwc() * 64;
@@ -406,7 +408,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		const long long T = fused_tickets(c->nwc(), deep_ring ? cfg->Y + 2 * c->ghost_rows : cfg->Y, c->H, c->fused_wide != 0);
 		// (8-row strips want a little more than 8192 tickets for the fifth workgroup: 131072 x 16384 with exactly 8192: 3327 with
 		// five, 3407 with four; 49152^2 with 9216: 3455 with five, 3376 with four)
-		c->fused_wg_per_cu = c->fused_wide ? (T >= 2048 ? 3 : 2) : (T >= 16384 ? 6 : (T >= (c->H == 8 ? 9216 : 8192) ? 5 : (T >= 2048 ? 4 : 3)));
+		c->fused_wg_per_cu = c->fused_wide ? (T >= 2048 ? 3 : 2) : (T >= 16384 ? 6 : (T >= (c->H == 8 ? 9216 : 8192) ? 5 : (T >= 1536 ? 4 : 3)));
 		// Several ticket counters where 4-wave workgroups draw one- or two-row units (2^26 spins): one counter hands out
 		// ~80 tickets per us; 8192^2 with one-row units at 2600 flips/ns needs 159 (four counters), with two-row units
 		// 79 (two).  ISING_FUSED_TICKETS2=0/2/4 overrides.

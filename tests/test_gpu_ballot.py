@@ -119,7 +119,9 @@ def test_auto_layout_picks_ballot_where_it_applies(gpu):
         assert s.layout == BAL and s.fused and s.strip_rows == 1 and s.ghost_ptrs(ig.BLACK)[0] == 64
     with ig.IsingSlab(8192, 8192, temp=1.5, nslabs=2, J_prob=0.2) as s:   # (with -J too)
         assert s.layout == BAL and s.fused
-    with ig.IsingSlab(8192, 4096, temp=1.5) as s:       # small slabs: the dense kernel is ahead
+    with ig.IsingSlab(8192, 4096, temp=1.5) as s:       # ... down to 2^25 spins
+        assert s.layout == BAL and s.fused and s.strip_rows == 1
+    with ig.IsingSlab(8192, 2048, temp=1.5) as s:       # small slabs: the dense kernel is ahead
         assert s.layout == ig.LAYOUT_DENSE
     with ig.IsingSlab(20480, 8192, temp=1.5) as s:      # 10 column groups = 2.5 wave columns: too many dead lanes
         assert s.layout == ig.LAYOUT_DENSE
