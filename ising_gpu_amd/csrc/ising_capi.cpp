@@ -353,7 +353,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	//   2^26 (8192^2)    4-wave workgroups, H = 1, 4 per CU (T = 2048), four ticket counters     2606 vs 2125 (dense layout 2150)
 	//   2^27             8-wave workgroups, H = 2, 2 per CU (T = 1024)      2908 vs 2580
 	//   2^28 (16384^2)   4-wave, H = 4, 4 per CU (T = 2048)                 3099 vs 3048
-	//   2^29 ...         4-wave, H = 16 where T >= 8192, else 8 where T >= 4096, else 4; 5 per CU (6 from T = 16384, 4 below 8192):
+	//   2^29 ...         4-wave, H = 16 where T >= 8192, else 8 where T >= 4096, else 4; 5 per CU (6 from T = 32768, 4 below 8192):
 	//                    24576^2 3234 vs 3182, 32768^2 3383 vs 3407, 65536 x 32768 3437 vs 3463, 65536^2 3490-3500 vs 3490-3500 (profiles/policy_probe_r02.txt)
 	// ISING_FUSED=0/1, ISING_FUSED_WIDE=0/1, cfg.strip_rows and ISING_FUSED_WGS (grid) override.
 	const long long spins = (long long)cfg->X * cfg->Y;
@@ -406,9 +406,11 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	else c->fused_nt = spins > (1LL << 31);
 	if (fused_shape || deep_ring) { // workgroups per CU of a fused launch (the chip holds 6 of 4 waves, 3 of 8)
 		const long long T = fused_tickets(c->nwc(), deep_ring ? cfg->Y + 2 * c->ghost_rows : cfg->Y, c->H, c->fused_wide != 0);
+		// (the sixth workgroup pays from 32768 tickets: 131072^2 3513 -> 3535 flips/ns; with 16384, 131072 x 65536 either way,
+		// it costs: 3515 / 3510 with five, 3465 / 3489 with six; 98304^2, 18432 tickets: 3509 / 3491)
 		// (8-row strips want a little more than 8192 tickets for the fifth workgroup: 131072 x 16384 with exactly 8192: 3327 with
 		// five, 3407 with four; 49152^2 with 9216: 3455 with five, 3376 with four)
-		c->fused_wg_per_cu = c->fused_wide ? (T >= 2048 ? 3 : 2) : (T >= 16384 ? 6 : (T >= (c->H == 8 ? 9216 : 8192) ? 5 : (T >= 1536 ? 4 : 3)));
+		c->fused_wg_per_cu = c->fused_wide ? (T >= 2048 ? 3 : 2) : (T >= 32768 ? 6 : (T >= (c->H == 8 ? 9216 : 8192) ? 5 : (T >= 1536 ? 4 : 3)));
 		// Several ticket counters where 4-wave workgroups draw one- or two-row units (2^26 spins): one counter hands out
 		// ~80 tickets per us; 8192^2 with one-row units at 2600 flips/ns needs 159 (four counters), with two-row units
 		// 79 (two).  ISING_FUSED_TICKETS2=0/2/4 overrides.
