@@ -598,8 +598,9 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 __global__ void __launch_bounds__(THREADS) ballot_init_k(const InitParams p) {
 	const int tx = threadIdx.x & (GROUP - 1), g = (threadIdx.x >> 4) & 3;
 	const int nwc = (p.gx + 3) >> 2;
-	const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6));
-	if (wave >= nwc * p.Y) return;
+	const long long wave_ll = flat_block() * (THREADS / 64) + (threadIdx.x >> 6);
+	if (wave_ll >= (long long)nwc * p.Y) return;
+	const int wave = __builtin_amdgcn_readfirstlane((int)wave_ll);
 	const int lr = wave / nwc, wc = wave - lr * nwc;
 	const int alive = min(4, p.gx - 4 * wc); // column groups of this wave column that exist
 	const unsigned long long live = alive >= 4 ? ~0ull : ((1ull << (16 * alive)) - 1ull);
@@ -872,7 +873,7 @@ hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_o
 
 hipError_t launch_ballot_init(const InitParams &p, hipStream_t stream) {
 	const long long waves = (long long)((p.gx + 3) / 4) * p.Y;
-	hipLaunchKernelGGL(ballot_init_k, dim3((unsigned)((waves + THREADS / 64 - 1) / (THREADS / 64))), dim3(THREADS), 0, stream, p);
+	hipLaunchKernelGGL(ballot_init_k, flat_grid((waves + THREADS / 64 - 1) / (THREADS / 64)), dim3(THREADS), 0, stream, p);
 	return hipGetLastError();
 }
 

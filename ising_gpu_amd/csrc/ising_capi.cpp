@@ -359,7 +359,10 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	const long long spins = (long long)cfg->X * cfg->Y;
 	const bool fused_can = c->wrap && !cfg->XSL;
 	const char *fz = getenv("ISING_FUSED"), *fw = getenv("ISING_FUSED_WIDE");
-	c->fused = fz ? atoi(fz) != 0 : spins >= (1LL << 25);
+	// (rows of a million columns and more -- 128 wave columns -- run 1-2 % faster one launch per colour, whatever their number:
+	// 1048576 x 65536 3461 vs 3429 fused, x 524288 3536 vs 3465, 2097152 x 131072 3464 vs 3397; 524288 x 1048576 3484 vs 3513;
+	// tools/huge_probe.py)
+	c->fused = fz ? atoi(fz) != 0 : (spins >= (1LL << 25) && c->nwc() < 128);
 	c->fused_wide = fw ? atoi(fw) : (spins >= 3 * (1LL << 25) && spins < (1LL << 28) ? 1 : 0);
 	// AUTO: the ballot kernel's two-phase row pipeline wins from 2^27 spins per slab up -- from 2^25 where fused launches
 	// apply (a slab that wraps in place, a ring slab that can keep ghost rows); below, the dense kernel is ahead.  (A partly dead last wave column wastes its

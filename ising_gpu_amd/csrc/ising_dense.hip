@@ -277,8 +277,9 @@ __global__ void __launch_bounds__(dense_threads(MODE)) dense_update_k(const Upda
 // ---------------------------------------------------------------------------------------------- init
 __global__ void __launch_bounds__(THREADS) dense_init_k(const InitParams p) {
 	const int tx = threadIdx.x & (GROUP - 1);
-	const int unit = blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x >> 4); // (row, bx)
-	if (unit >= p.gx * p.Y) return;
+	const long long unit_ll = flat_block() * GROUPS_PER_BLOCK + (threadIdx.x >> 4); // (row, bx)
+	if (unit_ll >= (long long)p.gx * p.Y) return;
+	const int unit = (int)unit_ll;
 	const int lr = unit / p.gx;
 	const int bx = unit - lr * p.gx;
 	const int wpr = p.gx * 32;
@@ -475,7 +476,7 @@ hipError_t launch_ham_planes(uint64_t *ham, size_t nvec, hipStream_t stream) {
 
 hipError_t launch_dense_init(const InitParams &p, hipStream_t stream) {
 	const long long units = (long long)p.gx * p.Y;
-	hipLaunchKernelGGL(dense_init_k, dim3((unsigned)((units + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)), dim3(THREADS), 0, stream, p);
+	hipLaunchKernelGGL(dense_init_k, flat_grid((units + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(THREADS), 0, stream, p);
 	return hipGetLastError();
 }
 

@@ -11,6 +11,14 @@ namespace {
 constexpr int GROUP = 16;                 // lanes per reference block-row (BLOCK_X, optimized/main.cu:55)
 constexpr int THREADS = 256;
 constexpr int GROUPS_PER_BLOCK = THREADS / GROUP;
+// One workgroup per unit of work, more workgroups than one grid dimension carries (HIP wants grid x block < 2^32 threads per
+// dimension; the init kernels of a 2^39-spin lattice have 2^32): the grid folds into two dimensions.
+constexpr unsigned FLAT_GRID_X = 1u << 20;
+inline dim3 flat_grid(long long blocks) {
+	if (blocks <= (long long)FLAT_GRID_X) return dim3((unsigned)(blocks > 0 ? blocks : 1));
+	return dim3(FLAT_GRID_X, (unsigned)((blocks + FLAT_GRID_X - 1) / FLAT_GRID_X));
+}
+__device__ __forceinline__ long long flat_block() { return (long long)blockIdx.y * gridDim.x + blockIdx.x; }
 
 template <int... Is, typename F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {

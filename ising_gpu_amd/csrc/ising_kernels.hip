@@ -337,8 +337,9 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 // ---------------------------------------------------------------------------------------------- init
 __global__ void __launch_bounds__(THREADS) init_k(const InitParams p) {
 	const int tx = threadIdx.x & (GROUP - 1);
-	const int unit = blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x >> 4); // (row, bx)
-	if (unit >= p.gx * p.Y) return;
+	const long long unit_ll = flat_block() * GROUPS_PER_BLOCK + (threadIdx.x >> 4); // (row, bx)
+	if (unit_ll >= (long long)p.gx * p.Y) return;
+	const int unit = (int)unit_ll;
 	const int lr = unit / p.gx;
 	const int bx = unit - lr * p.gx;
 	const int vecs = p.gx * 32;
@@ -375,8 +376,9 @@ __global__ void __launch_bounds__(THREADS) init_k(const InitParams p) {
 // b = 32 j + 2 z + h of vector j feeds bits 4z+2h and 4z+2h+1 of word x (outputs 0, 2) and word y (outputs 1, 3).
 __global__ void __launch_bounds__(THREADS) ham_init_black_k(const HamInitParams p) {
 	const int tx = threadIdx.x & (GROUP - 1);
-	const int unit = blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x >> 4); // (row, bx)
-	if (unit >= p.gx * p.Y) return;
+	const long long unit_ll = flat_block() * GROUPS_PER_BLOCK + (threadIdx.x >> 4); // (row, bx)
+	if (unit_ll >= (long long)p.gx * p.Y) return;
+	const int unit = (int)unit_ll;
 	const int lr = unit / p.gx;
 	const int bx = unit - lr * p.gx;
 	const int vecs = p.gx * 32;
@@ -635,7 +637,7 @@ hipError_t launch_update(const UpdateParams &p, int mode, hipStream_t stream) {
 
 hipError_t launch_ham_init_black(const HamInitParams &p, hipStream_t stream) {
 	const long long units = (long long)p.gx * p.Y;
-	hipLaunchKernelGGL(ham_init_black_k, dim3((unsigned)((units + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)), dim3(THREADS), 0, stream, p);
+	hipLaunchKernelGGL(ham_init_black_k, flat_grid((units + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), dim3(THREADS), 0, stream, p);
 	return hipGetLastError();
 }
 
@@ -648,7 +650,7 @@ hipError_t launch_ham_init_white(const HamWhiteParams &p, hipStream_t stream) {
 
 hipError_t launch_init(const InitParams &p, hipStream_t stream) {
 	const long long units = (long long)p.gx * p.Y;
-	const dim3 grid((unsigned)((units + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK)), block(THREADS);
+	const dim3 grid = flat_grid((units + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), block(THREADS);
 	hipLaunchKernelGGL(init_k, grid, block, 0, stream, p);
 	return hipGetLastError();
 }

@@ -162,3 +162,29 @@ def test_ring_of_one_at_the_bench_size_every_schedule(gpu, monkeypatch, case):
             ring.close()
     finally:
         slab.close()
+
+
+def test_lattices_beyond_2_to_the_32_threads_and_a_million_columns(gpu):
+    """2^37 spins (16 GiB on the device) in rows of 2^20 columns: the init kernels' grids fold into two dimensions (HIP carries
+    2^32 threads per grid dimension; at 2^39 spins they need that many), and the three update forms -- fused ballot launches,
+    one ballot launch per colour (what ising_create picks for rows this wide), the dense kernel -- agree on counts and bond sum."""
+    import os
+    X, Y = 1 << 20, 1 << 17
+    res = {}
+    for name, lay, env in (("fused", ig.LAYOUT_BALLOT, "1"), ("per colour", ig.LAYOUT_BALLOT, None), ("dense", ig.LAYOUT_DENSE, None)):
+        old = os.environ.pop("ISING_FUSED", None)
+        if env:
+            os.environ["ISING_FUSED"] = env
+        try:
+            with ig.IsingSlab(X, Y, seed=4321, temp=ig.CRIT_TEMP_F32, layout=lay) as s:
+                assert s.fused == (name == "fused")
+                s.init()
+                c0 = s.count()
+                s.sweep(2)
+                res[name] = (c0, s.count(), s.bond_equal())
+        finally:
+            os.environ.pop("ISING_FUSED", None)
+            if old is not None:
+                os.environ["ISING_FUSED"] = old
+    assert res["fused"] == res["per colour"] == res["dense"]
+    assert res["dense"][0] == (68719501639, 68719451833)  # (tools/huge_probe.py: the same on every run and form)
