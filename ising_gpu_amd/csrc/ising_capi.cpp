@@ -361,7 +361,9 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	const char *fz = getenv("ISING_FUSED"), *fw = getenv("ISING_FUSED_WIDE");
 	// (rows of a million columns and more -- 128 wave columns -- run 1-2 % faster one launch per colour, whatever their number:
 	// 1048576 x 65536 3461 vs 3429 fused, x 524288 3536 vs 3465, 2097152 x 131072 3464 vs 3397; 524288 x 1048576 3484 vs 3513;
-	// tools/huge_probe.py)
+	// tools/huge_probe.py.  At 2^37 spins, 8 sweeps: one launch per colour 3506 .. 3528 at every width; fused 3538 up to 32 wave
+	// columns, 3512 at 64, 3445 at 128, 3386 at 256, 3186 at 512: a strip's completion counter takes one atomic per wave column
+	// and level, all at about the same time, and three polls per unit of the next)
 	c->fused = fz ? atoi(fz) != 0 : (spins >= (1LL << 25) && c->nwc() < 128);
 	c->fused_wide = fw ? atoi(fw) : (spins >= 3 * (1LL << 25) && spins < (1LL << 28) ? 1 : 0);
 	// AUTO: the ballot kernel's two-phase row pipeline wins from 2^27 spins per slab up -- from 2^25 where fused launches
