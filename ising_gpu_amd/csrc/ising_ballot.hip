@@ -139,6 +139,18 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 #ifndef ISING_FUSED_LOOKAHEAD
 #define ISING_FUSED_LOOKAHEAD 2
 #endif
+// Wave priorities in fused launches.  The SIMD's arbiter serves its waves oldest first, and the waves of a persistent grid
+// keep their age: under a saturated vector ALU the youngest wave of a SIMD gets what the others leave.  Units of the same work
+// then take 1x .. 5x as long (a -DISING_FUSED_TRACE -DISING_FUSED_TRACE_COUNTS build: 43 % of the units of 65536^2 in 100-130 k
+// cycles, 9 % in more than 490 k), and the slow ones are the parents the next level finds unfinished: 6 % of the units slept
+// ~90 polls each at five workgroups per CU, more at six.  2 (default): every wave steps through the four priorities row by
+// row, offset by its dispatch round (= its rank on the SIMD), so the waves of a SIMD take turns at the front: no sleeping
+// polls left at 65536^2 (3479 -> 3515 flips/ns, 3534 with six workgroups per CU), 16384^2 3082 -> 3291, 16384 x 8192 with
+// 4-wave workgroups 2709 -> 3041.  1: feedback once per unit from the tickets drawn meanwhile (a slow workgroup raises its
+// priority for the next unit): the same spread, alternating.  0: none.
+#ifndef ISING_FUSED_PRIO
+#define ISING_FUSED_PRIO 2
+#endif
 #ifndef ISING_FUSED_STAGGER // s_sleep units (64 cycles each) between the start of successive dispatch rounds of a fused launch
 #define ISING_FUSED_STAGGER 100
 #endif
@@ -147,7 +159,12 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 // destroyed.  Never in the product library.
 #if defined(ISING_FUSED_TRACE)
 __device__ unsigned long long g_trace[16];
+__device__ unsigned long long g_hist[32];
+#if defined(ISING_FUSED_TRACE_COUNTS) // counts only (units, sleeping polls): no clock reads, the product kernel's residency
+#define TRC(i) do {} while (0)
+#else
 #define TRC(i) do { if (FUSED && wi == 0) { const long long t_ = clock64(); if (lane == 0) tr[i] += (unsigned long long)(t_ - tlast); tlast = t_; } } while (0)
+#endif
 #define TRN(i, n) do { if (FUSED && wi == 0 && lane == 0) tr[i] += (unsigned long long)(n); } while (0)
 #else
 #define TRC(i) do {} while (0)
@@ -215,9 +232,13 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 
 #if defined(ISING_FUSED_TRACE)
 	__shared__ unsigned long long tr[16];
+#if defined(ISING_FUSED_TRACE_COUNTS)
+	__shared__ unsigned int hist_sh[2][16];
+	if (threadIdx.x < 32) hist_sh[threadIdx.x >> 4][threadIdx.x & 15] = 0;
+#endif
 	if (threadIdx.x < 16) tr[threadIdx.x] = 0;
 	__syncthreads();
-	long long tlast = clock64();
+	[[maybe_unused]] long long tlast = clock64();
 	const long long tstart = tlast;
 #endif
 	// Fused launches: thread 0 draws the NEXT ticket in a unit's last iteration and leaves it in LDS before that
@@ -259,6 +280,9 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	unsigned long long level_base = 0;
 	[[maybe_unused]] unsigned long long tk_next = 0; // (set once, here: a write per unit would have to wait for the unit's first loads)
 	const int nwc_sh = (nwc & (nwc - 1)) == 0 ? __builtin_ctz((unsigned)nwc) + 2 : -1; // gxp = 4 nwc as a shift where it is one
+#if ISING_FUSED_PRIO == 1
+	[[maybe_unused]] unsigned long long tk_prev = 0;
+#endif
 	for (int round = 0;; ++round) {
 		unsigned long long tk;
 		if (FUSED) {
@@ -268,7 +292,24 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			tk = round ? total : (unsigned long long)blockIdx.x; // plain: one unit per workgroup
 		}
 		if (tk >= total) break;
+#if ISING_FUSED_PRIO == 1
+		// feedback: the tickets drawn chip-wide while this workgroup worked on its last unit say how slow it was (gridDim.x when
+		// everybody is equally fast); slow workgroups raise their priority for the next unit
+		if (FUSED && round > 0) {
+			const unsigned long long lag = tk - tk_prev;
+			const unsigned g = gridDim.x;
+			if (lag * 4 > 7ull * g) __builtin_amdgcn_s_setprio(3);
+			else if (lag * 4 > 5ull * g) __builtin_amdgcn_s_setprio(2);
+			else if (lag * 4 > 3ull * g) __builtin_amdgcn_s_setprio(1);
+			else __builtin_amdgcn_s_setprio(0);
+		}
+		tk_prev = tk;
+#endif
 		TRC(0); // ticket pick-up
+#if defined(ISING_FUSED_TRACE) && defined(ISING_FUSED_TRACE_COUNTS)
+		const long long t_unit0 = clock64();
+		long long t_unit1 = t_unit0;
+#endif
 		TRN(8, 1);
 		if (FUSED) {
 			while (tk >= level_base + (unsigned)p.nwg) {
@@ -367,6 +408,18 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				if (__all((int32_t)(seen - need) >= 0)) break;
 				TRN(9, 1);
 				TRN(15, nsleep++ == 0);
+#if defined(ISING_FUSED_TRACE_COUNTS) // where the sleeping units are: by position in the level's visiting order and by level
+				if (nsleep == 1) {
+					TRN(0, pos < nstr / 8);
+					TRN(1, pos >= nstr - nstr / 8);
+					TRN(2, level == 1);
+					TRN(3, level == p.nlevels - 1);
+					TRN(4, pos < 8);
+					TRN(5, (pos & 1) == 0);
+				}
+				TRN(6, (nsleep == 64));  // units that slept 64 polls and more
+				TRN(7, (nsleep == 256));
+#endif
 				__builtin_amdgcn_s_sleep(32);
 				if (lane < 3) asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(seen) : "v"(dp) : "memory");
 			}
@@ -382,6 +435,9 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				__builtin_amdgcn_s_sleep(127);
 			}
 		}
+#if defined(ISING_FUSED_TRACE) && defined(ISING_FUSED_TRACE_COUNTS)
+		t_unit1 = clock64(); // (behind the wait for the parents)
+#endif
 		__builtin_amdgcn_wave_barrier();
 		__threadfence_block();
 		uint64_t up = 0, ct = 0;
@@ -404,6 +460,17 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		const bool wb_wave = threadIdx.x < 64;
 		const int r_ticket = ISING_FUSED_LOOKAHEAD == 1 ? 0 : rmax;
 		for (int r = 0; r <= rmax; ++r) {
+#if ISING_FUSED_PRIO == 2
+			// rotating priorities: the waves that share a SIMD (one per dispatch round of 256 workgroups) take turns at the front
+			if (FUSED) {
+				switch ((r + (int)(blockIdx.x >> 8)) & 3) {
+				case 0: __builtin_amdgcn_s_setprio(0); break;
+				case 1: __builtin_amdgcn_s_setprio(1); break;
+				case 2: __builtin_amdgcn_s_setprio(2); break;
+				default: __builtin_amdgcn_s_setprio(3); break;
+				}
+			}
+#endif
 			// The two words per row whose side neighbours sit in another vector (sites 0 / 31) are assembled on the scalar
 			// unit from three source-colour words of row r0 + r - 1: A0, A1 of this wave's own 64 words, C from the
 			// neighbouring wave column.  Plain launches: three scalar loads issued before the draw phase of row r0 + r.
@@ -578,6 +645,13 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			// may move (every storing wave drains its own stores and signals its own unit)
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			TRC(13); // store drain
+#if defined(ISING_FUSED_TRACE) && defined(ISING_FUSED_TRACE_COUNTS)
+			if (wi == 0 && lane == 0) { // unit durations with and without the wait, in units of 1/8 of the mean (h[10] accumulates the work time)
+				const long long te = clock64();
+				hist_sh[0][min(15ll, (te - t_unit1) / (16384ll * p.H / 8))]++;
+				hist_sh[1][min(15ll, (te - t_unit0) / (16384ll * p.H / 8))]++;
+			}
+#endif
 			if (lane == 0) __hip_atomic_fetch_add(p.done + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
@@ -587,6 +661,9 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		if (threadIdx.x == 0) tr[14] = (unsigned long long)(clock64() - tstart);
 		__syncthreads();
 		if (threadIdx.x < 16) atomicAdd(&g_trace[threadIdx.x], tr[threadIdx.x]);
+#if defined(ISING_FUSED_TRACE_COUNTS)
+		if (threadIdx.x < 32) atomicAdd(&g_hist[threadIdx.x], (unsigned long long)hist_sh[threadIdx.x >> 4][threadIdx.x & 15]);
+#endif
 	}
 #endif
 }
@@ -852,6 +929,24 @@ void ballot_trace_dump() {
 	unsigned long long h[16];
 	if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace), sizeof(h)) != hipSuccess) return;
 	fprintf(stderr, "fused trace (wave 0 of every workgroup): %llu units, %llu polls that slept in %llu units\n", h[8], h[9], h[15]);
+#if defined(ISING_FUSED_TRACE_COUNTS)
+	fprintf(stderr, "  sleeping units: %llu in the first eighth of a level's visiting order, %llu in the last; %llu at level 1, %llu at the last level; %llu at positions 0..7; "
+	                "%llu on even positions; %llu slept 64 polls or more, %llu 256 or more\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+	{
+		unsigned long long g[32];
+		if (hipMemcpyFromSymbol(g, HIP_SYMBOL(g_hist), sizeof(g)) != hipSuccess) return;
+		for (int k = 0; k < 2; k++) {
+			fprintf(stderr, "  unit durations %s, bins of 2048 cycles per row:", k ? "from ticket pick-up" : "behind the wait for the parents");
+			for (int i = 0; i < 16; i++) fprintf(stderr, " %llu", g[16 * k + i]);
+			fprintf(stderr, "\n");
+		}
+		for (auto &v : g) v = 0;
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_hist), g, sizeof(g));
+		for (auto &v : h) v = 0;
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), h, sizeof(h));
+	}
+	return;
+#endif
 	for (int i = 0; i < 15; ++i) {
 		if (!name[i][0]) continue;
 		fprintf(stderr, "  %-22s %6.2f %% of workgroup time, %8.1f cycles per unit\n", name[i], 100.0 * (double)h[i] / (double)h[14], (double)h[i] / (double)(h[8] ? h[8] : 1));

@@ -188,17 +188,34 @@ void ballot_planes_to_planes(uint64_t *ham, size_t ngroups) {
 	}
 }
 
-// fused launches: tickets per level, and the strip height that keeps a level at >= 8192 tickets (ising_create)
+// Fused launches: T = tickets (workgroups) per level for strips of H rows; and the launch shape ising_create picks.
 long long fused_tickets(int nwc, int Y, int H, bool wide) { return ((long long)nwc * ((Y + H - 1) / H) + (wide ? 7 : 3)) / (wide ? 8 : 4); }
-int choose_fused_strip_rows(int nwc, int Y, bool wide) {
-	if (!wide && (long long)nwc * Y < 12288) return 1;    // 2^25 .. 2^26 spins: one-row units (four ticket counters, ising_create)
-	if (wide) return (Y % 2) == 0 ? 2 : 1;                  // 2^27 spins
-	// (tools/h_probe.py, grid_probe2.py at the end of round 2: 16 rows need 8192 tickets a level -- 49152^2 with 4608: -0.8 %,
-	// 57344^2 with 6272: -1.0 % against 8 rows --, 8 rows 4096: 32768^2 3356 -> 3394 flips/ns against 4 rows, 65536 x 16384
-	// 3317 -> 3380, 24576 x 49152 3361 -> 3412, 40960^2 3385 -> 3421; with 2304 (24576^2) 3288 -> 3149)
-	if ((Y % 16) == 0 && fused_tickets(nwc, Y, 16, false) >= 8192) return 16;
-	if ((Y % 8) == 0 && fused_tickets(nwc, Y, 8, false) >= 4096) return 8;
-	return (Y % 4) == 0 ? 4 : ((Y % 2) == 0 ? 2 : 1);
+// Workgroups of 4 waves per CU a level of T tickets carries without its units running into unfinished parents (with the waves'
+// rotating priorities, ising_ballot.hip: a level wants 1.33 x the grid at three per CU, 2 x at four, 3.2 x at five, 5.3 x at
+// six -- 65536^2, T = 8192: 3512 flips/ns with five, 3533 with six; 131072 x 16384, T = 4096 at H = 16: 3504 with five, 3373
+// with six; 16384^2, T = 2048 at H = 4: 3285 with four, 3217 with five; 16384 x 8192, T = 1024: 3038 with three, 2858 with four).
+int fused_wgs_for(long long T) { return T >= 8192 ? 6 : (T >= 4096 ? 5 : (T >= 2048 ? 4 : (T >= 1024 ? 3 : (T >= 684 ? 2 : 1)))); }
+// flips/ns of strips of H rows at wg workgroups per CU where T is ample (tools/grid_probe2.py on 65536^2 .. 131072^2, 24576^2,
+// 32768 x 16384, 16384^2, 8192^2 at the end of round 2).  One- and two-row units draw tickets from several counters.
+int fused_score(int H, int wg) {
+	static const int S[5][7] = {                // wg:  1     2     3     4     5     6
+		/* H = 1  */ {0, 900, 1850, 2300, 2650, 2640, 2560},
+		/* H = 2  */ {0, 1200, 2270, 2760, 2690, 2680, 2680},
+		/* H = 4  */ {0, 1300, 2500, 3060, 3290, 3375, 3415},
+		/* H = 8  */ {0, 1400, 2650, 3200, 3385, 3460, 3498},
+		/* H = 16 */ {0, 1450, 2740, 3260, 3440, 3512, 3535}};
+	const int h = H >= 16 ? 4 : (H >= 8 ? 3 : (H >= 4 ? 2 : (H >= 2 ? 1 : 0)));
+	return S[h][wg < 1 ? 1 : (wg > 6 ? 6 : wg)];
+}
+// the strip height whose level still feeds the most productive grid (`rows`: the rows a launch covers, ghost rows included)
+int choose_fused_strip_rows(int nwc, int Y, int rows) {
+	int best = 1, best_score = -1;
+	for (int H = 1; H <= 16; H <<= 1) {
+		if (Y % H) break;
+		const int score = fused_score(H, fused_wgs_for(fused_tickets(nwc, rows, H, false)));
+		if (score >= best_score) { best = H; best_score = score; }
+	}
+	return best;
 }
 
 int choose_strip_rows(int gx, int Y, bool dense, bool ballot = false) {
@@ -347,14 +364,17 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// sub-lattices.  A unit's parents are one level = T tickets back, so a level must hold a few times more tickets than
 	// workgroups run, or units find their parents unfinished and hold their slots asleep: the strip height H follows
 	// from T = wave rows / (H x waves per workgroup), and small lattices run FEWER workgroups than the chip holds.
-	// Measured (tools/grid_probe.py, grid_probe2.py), flips/ns fused vs one launch per colour + tail strips:
-	//   2^25 (8192 x 4096) 4-wave workgroups, H = 1, 3 per CU (T = 1024), four ticket counters   2184 vs the dense layout's 1827
-	//                    (tools/small_fused_probe.py; 8192 x 6144, T = 1536, 4 per CU: 2440 vs 2015; 2^24: 1369 vs 1415, so dense)
-	//   2^26 (8192^2)    4-wave workgroups, H = 1, 4 per CU (T = 2048), four ticket counters     2606 vs 2125 (dense layout 2150)
-	//   2^27             8-wave workgroups, H = 2, 2 per CU (T = 1024)      2908 vs 2580
-	//   2^28 (16384^2)   4-wave, H = 4, 4 per CU (T = 2048)                 3099 vs 3048
-	//   2^29 ...         4-wave, H = 16 where T >= 8192, else 8 where T >= 4096, else 4; 5 per CU (6 from T = 32768, 4 below 8192):
-	//                    24576^2 3234 vs 3182, 32768^2 3383 vs 3407, 65536 x 32768 3437 vs 3463, 65536^2 3490-3500 vs 3490-3500 (profiles/policy_probe_r02.txt)
+	// Measured (tools/grid_probe.py, grid_probe2.py), flips/ns fused vs one launch per colour + tail strips (4-wave workgroups):
+	//   8192 x 4096 (2^25)   H = 1, 3 per CU (T = 1024), four ticket counters     2260 vs the dense layout's 1827 (2^24: 1369 vs 1415, so dense)
+	//   8192^2               H = 2, 3 per CU (T = 1024), two ticket counters      2755 vs 2125 (dense layout 2150)
+	//   16384 x 8192         H = 4, 3 per CU (T = 1024)                           3040 vs 2580
+	//   16384^2              H = 4, 4 per CU (T = 2048)                           3285 vs 3048
+	//   24576^2              H = 8, 4 per CU (T = 2304)                           3386 vs 3182
+	//   32768^2              H = 8, 5 per CU (T = 4096)                           3455 vs 3407
+	//   131072 x 16384       H = 16, 5 per CU (T = 4096)                          3504 vs 3410
+	//   65536^2, 131072^2    H = 16, 6 per CU (T >= 8192)                         3533, 3541 vs 3461, 3502
+	// (choose_fused_strip_rows / fused_wgs_for above; before the waves' priorities rotated -- ising_ballot.hip -- the same lattices
+	// wanted two to four times as many tickets a level and ran 3082 at 16384^2, 3479 at 65536^2.)
 	// ISING_FUSED=0/1, ISING_FUSED_WIDE=0/1, cfg.strip_rows and ISING_FUSED_WGS (grid) override.
 	const long long spins = (long long)cfg->X * cfg->Y;
 	const bool fused_can = c->wrap && !cfg->XSL;
@@ -365,7 +385,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// columns, 3512 at 64, 3445 at 128, 3386 at 256, 3186 at 512: a strip's completion counter takes one atomic per wave column
 	// and level, all at about the same time, and three polls per unit of the next)
 	c->fused = fz ? atoi(fz) != 0 : (spins >= (1LL << 25) && c->nwc() < 128);
-	c->fused_wide = fw ? atoi(fw) : (spins >= 3 * (1LL << 25) && spins < (1LL << 28) ? 1 : 0);
+	c->fused_wide = fw ? atoi(fw) : 0; // (8-wave workgroups: an A/B switch since the priorities rotate; 16384 x 8192: 3070 vs 3040 with 4 waves)
 	// AUTO: the ballot kernel's two-phase row pipeline wins from 2^27 spins per slab up -- from 2^25 where fused launches
 	// apply (a slab that wraps in place, a ring slab that can keep ghost rows); below, the dense kernel is ahead.  (A partly dead last wave column wastes its
 	// dead lanes' draws: worth it while they are under a tenth of the row -- the dense kernel is 12 % behind.)
@@ -392,16 +412,11 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		if (c->ghost_rows > 1 && cfg->use_J) c->ham_ghost = c->ghost_rows + 1; // -J: the ghost rows' couplings are generated in place
 	}
 	const bool deep_ring = c->ghost_rows > 1;
-	// Its fused launches take the single slab's shape below 2^28 spins (one- and two-row units, 8-wave workgroups at 2^27:
-	// a ring of one at 8192^2 2124 -> 2231 flips/ns, 8192 x 16384 2415 -> 2615; the dense layout with one halo row per colour
-	// half-sweep, which AUTO used to pick for ring slabs of 2^26 spins: 1157); from there up 4-wave workgroups and the strip
-	// height of the per-colour launches (131072 x 16384 measured -0.8 % against a single slab with H = 16, -1.7 % with the
-	// H = 8 the single-slab rule would pick).  ISING_RING_SHAPE=single|plain overrides.
-	bool deep_single = deep_ring && spins < (1LL << 28);
-	if (const char *e = getenv("ISING_RING_SHAPE")) deep_single = deep_ring && !strcmp(e, "single");
-	if (deep_ring && !deep_single) c->fused_wide = 0;
+	// (its fused launches take the shape a single slab of Y + 2 G rows would)
+	const int launch_rows = deep_ring ? cfg->Y + 2 * c->ghost_rows : cfg->Y;
 	c->H = cfg->strip_rows > 0 ? cfg->strip_rows
-	       : ((fused_shape || deep_single) ? choose_fused_strip_rows(c->nwc(), cfg->Y, c->fused_wide != 0) : choose_strip_rows(c->gx, cfg->Y, c->dense, c->ballot));
+	       : ((fused_shape || deep_ring) ? (c->fused_wide ? ((cfg->Y % 2) == 0 ? 2 : 1) : choose_fused_strip_rows(c->nwc(), cfg->Y, launch_rows))
+	                                     : choose_strip_rows(c->gx, cfg->Y, c->dense, c->ballot));
 	if (cfg->Y % c->H) { const int h = c->H; delete c; return fail(ISING_E_ARG, "strip_rows %d does not divide Y %d", h, cfg->Y); }
 	c->nstrips = cfg->Y / c->H;
 	c->color_words = (size_t)cfg->Y * c->lld;
@@ -410,12 +425,8 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (const char *e = getenv("ISING_FUSED_NT")) c->fused_nt = atoi(e) != 0;
 	else c->fused_nt = spins > (1LL << 31);
 	if (fused_shape || deep_ring) { // workgroups per CU of a fused launch (the chip holds 6 of 4 waves, 3 of 8)
-		const long long T = fused_tickets(c->nwc(), deep_ring ? cfg->Y + 2 * c->ghost_rows : cfg->Y, c->H, c->fused_wide != 0);
-		// (the sixth workgroup pays from 32768 tickets: 131072^2 3513 -> 3535 flips/ns; with 16384, 131072 x 65536 either way,
-		// it costs: 3515 / 3510 with five, 3465 / 3489 with six; 98304^2, 18432 tickets: 3509 / 3491)
-		// (8-row strips want a little more than 8192 tickets for the fifth workgroup: 131072 x 16384 with exactly 8192: 3327 with
-		// five, 3407 with four; 49152^2 with 9216: 3455 with five, 3376 with four)
-		c->fused_wg_per_cu = c->fused_wide ? (T >= 2048 ? 3 : 2) : (T >= 32768 ? 6 : (T >= (c->H == 8 ? 9216 : 8192) ? 5 : (T >= 1536 ? 4 : 3)));
+		const long long T = fused_tickets(c->nwc(), launch_rows, c->H, c->fused_wide != 0);
+		c->fused_wg_per_cu = c->fused_wide ? (T >= 2048 ? 3 : 2) : fused_wgs_for(T);
 		// Several ticket counters where 4-wave workgroups draw one- or two-row units (2^26 spins): one counter hands out
 		// ~80 tickets per us; 8192^2 with one-row units at 2600 flips/ns needs 159 (four counters), with two-row units
 		// 79 (two).  ISING_FUSED_TICKETS2=0/2/4 overrides.
