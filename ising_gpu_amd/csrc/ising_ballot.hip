@@ -147,9 +147,14 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 // row, offset by its dispatch round (= its rank on the SIMD), so the waves of a SIMD take turns at the front: no sleeping
 // polls left at 65536^2 (3479 -> 3515 flips/ns, 3534 with six workgroups per CU), 16384^2 3082 -> 3291, 16384 x 8192 with
 // 4-wave workgroups 2709 -> 3041.  1: feedback once per unit from the tickets drawn meanwhile (a slow workgroup raises its
-// priority for the next unit): the same spread, alternating.  0: none.
+// priority for the next unit): the same spread, alternating.  0: none.  (Four steps per row instead of one: 3487 at 65536^2; a
+// row count that runs on across units: -1.5 % with one- to four-row units; the rotation in one-launch-per-colour launches,
+// ISING_PLAIN_PRIO: 3458 -> 3389 -- their workgroups are not a persistent grid, and nothing waits for a slow one but the launch's end.)
 #ifndef ISING_FUSED_PRIO
 #define ISING_FUSED_PRIO 2
+#endif
+#ifndef ISING_PLAIN_PRIO // the same rotation in one-launch-per-colour launches (no parents there, but a launch ends on its slowest waves)
+#define ISING_PLAIN_PRIO 0
 #endif
 #ifndef ISING_FUSED_STAGGER // s_sleep units (64 cycles each) between the start of successive dispatch rounds of a fused launch
 #define ISING_FUSED_STAGGER 100
@@ -462,7 +467,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		for (int r = 0; r <= rmax; ++r) {
 #if ISING_FUSED_PRIO == 2
 			// rotating priorities: the waves that share a SIMD (one per dispatch round of 256 workgroups) take turns at the front
-			if (FUSED) {
+			if (FUSED || ISING_PLAIN_PRIO) {
 				switch ((r + (int)(blockIdx.x >> 8)) & 3) {
 				case 0: __builtin_amdgcn_s_setprio(0); break;
 				case 1: __builtin_amdgcn_s_setprio(1); break;
