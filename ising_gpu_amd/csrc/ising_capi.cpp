@@ -194,7 +194,9 @@ long long fused_tickets(int nwc, int Y, int H, bool wide) { return ((long long)n
 // rotating priorities, ising_ballot.hip: a level wants 1.33 x the grid at three per CU, 2 x at four, 3.2 x at five, 5.3 x at
 // six -- 65536^2, T = 8192: 3512 flips/ns with five, 3533 with six; 131072 x 16384, T = 4096 at H = 16: 3504 with five, 3373
 // with six; 16384^2, T = 2048 at H = 4: 3285 with four, 3217 with five; 16384 x 8192, T = 1024: 3038 with three, 2858 with four).
-int fused_wgs_for(long long T) { return T >= 8192 ? 6 : (T >= 4096 ? 5 : (T >= 2048 ? 4 : (T >= 1024 ? 3 : (T >= 684 ? 2 : 1)))); }
+// The sixth workgroup per CU waits for 16384 tickets: at 8192 (65536^2) it is worth 0.6 % (3503 -> 3526) and costs 2.7 % more HBM
+// traffic (0.892 -> 0.916 GB per colour half-sweep: 20 % more accept-mask slots in the L2s, more of them written back).
+int fused_wgs_for(long long T) { return T >= 16384 ? 6 : (T >= 4096 ? 5 : (T >= 2048 ? 4 : (T >= 1024 ? 3 : (T >= 684 ? 2 : 1)))); }
 // flips/ns of strips of H rows at wg workgroups per CU where T is ample (tools/grid_probe2.py on 65536^2 .. 131072^2, 24576^2,
 // 32768 x 16384, 16384^2, 8192^2 at the end of round 2).  One- and two-row units draw tickets from several counters.
 int fused_score(int H, int wg) {
@@ -372,7 +374,8 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	//   24576^2              H = 8, 4 per CU (T = 2304)                           3386 vs 3182
 	//   32768^2              H = 8, 5 per CU (T = 4096)                           3455 vs 3407
 	//   131072 x 16384       H = 16, 5 per CU (T = 4096)                          3504 vs 3410
-	//   65536^2, 131072^2    H = 16, 6 per CU (T >= 8192)                         3533, 3541 vs 3461, 3502
+	//   65536^2              H = 16, 5 per CU (T = 8192)                          3512 vs 3461 (six per CU: 3533, with 2.7 % more HBM traffic)
+	//   131072^2             H = 16, 6 per CU (T = 32768)                         3541 vs 3502
 	// (choose_fused_strip_rows / fused_wgs_for above; before the waves' priorities rotated -- ising_ballot.hip -- the same lattices
 	// wanted two to four times as many tickets a level and ran 3082 at 16384^2, 3479 at 65536^2.)
 	// ISING_FUSED=0/1, ISING_FUSED_WIDE=0/1, cfg.strip_rows and ISING_FUSED_WGS (grid) override.
