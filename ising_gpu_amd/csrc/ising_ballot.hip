@@ -149,7 +149,8 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 // 4-wave workgroups 2709 -> 3041.  1: feedback once per unit from the tickets drawn meanwhile (a slow workgroup raises its
 // priority for the next unit): the same spread, alternating.  0: none.  (Four steps per row instead of one: 3487 at 65536^2; a
 // row count that runs on across units: -1.5 % with one- to four-row units; the rotation in one-launch-per-colour launches,
-// ISING_PLAIN_PRIO: 3458 -> 3389 -- their workgroups are not a persistent grid, and nothing waits for a slow one but the launch's end.)
+// ISING_PLAIN_PRIO: 3458 -> 3389 -- their workgroups are not a persistent grid, and nothing waits for a slow one but the launch's end;
+// the fifth and sixth wave of a SIMD -- four levels, so they share one with the first and second -- stepping the other way round: -0.3 %.)
 #ifndef ISING_FUSED_PRIO
 #define ISING_FUSED_PRIO 2
 #endif
