@@ -57,7 +57,7 @@ enum {
 
 /* device layout of the spin arrays.  The C-ABI always speaks the reference's packed layout (read/write/dump convert). */
 enum {
-	ISING_LAYOUT_AUTO = 0,   /* ballot where it applies and pays (from 2^25 spins per slab where fused launches apply: a slab that wraps
+	ISING_LAYOUT_AUTO = 0,   /* ballot where it applies and pays (from 1.5 * 2^24 spins per slab where fused launches apply: a slab that wraps
 	                            in place, a ring slab that can keep ghost rows; from 2^27 otherwise), else dense */
 	ISING_LAYOUT_NIBBLE = 1, /* the reference's: 4 bits per spin, 16 spins per 64-bit word (optimized/main.cu:40, :1243) */
 	ISING_LAYOUT_DENSE = 2,  /* 1 bit per spin, 32 spins per 32-bit word = one reference 128-bit vector per word */
@@ -170,7 +170,7 @@ int ising_strip_info(ising_ctx *ctx, int *strip_rows, int *nstrips);
 /* nslabs == 1 only: `nsweeps` full sweeps, black then white, iterations first_it .. first_it+nsweeps-1
  * (the hot loop, optimized/main.cu:1763-1805). */
 int ising_sweep(ising_ctx *ctx, int first_it, int nsweeps);
-/* How ising_sweep launches right now: *fused = 1 when it issues fused launches (ballot layout from 2^25 spins up, or
+/* How ising_sweep launches right now: *fused = 1 when it issues fused launches (ballot layout from 1.5 * 2^24 spins up, or
  * ISING_FUSED=1: one launch carries up to *max_sweeps_per_launch sweeps = twice as many colour half-sweeps, handed out to
  * a chip-filling grid through in-order tickets; ising_ballot.hip), 0 when it issues one launch per colour.  For a ring slab
  * with ghost rows G deep (ballot layout): how the ring sweeps it -- fused launches of up to G/2 sweeps between exchanges. */

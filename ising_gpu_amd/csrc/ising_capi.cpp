@@ -387,7 +387,8 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// tools/huge_probe.py.  At 2^37 spins, 8 sweeps: one launch per colour 3506 .. 3528 at every width; fused 3538 up to 32 wave
 	// columns, 3512 at 64, 3445 at 128, 3386 at 256, 3186 at 512: a strip's completion counter takes one atomic per wave column
 	// and level, all at about the same time, and three polls per unit of the next)
-	c->fused = fz ? atoi(fz) != 0 : (spins >= (1LL << 25) && c->nwc() < 128);
+	// (from 768 tickets a level: 8192 x 3072 1834 vs the dense layout's 1658; 8192 x 2048, 512 tickets: 1330 vs 1416)
+	c->fused = fz ? atoi(fz) != 0 : (spins >= 3 * (1LL << 23) && c->nwc() < 128);
 	c->fused_wide = fw ? atoi(fw) : 0; // (8-wave workgroups: an A/B switch since the priorities rotate; 16384 x 8192: 3070 vs 3040 with 4 waves)
 	// AUTO: the ballot kernel's two-phase row pipeline wins from 2^27 spins per slab up -- from 2^25 where fused launches
 	// apply (a slab that wraps in place, a ring slab that can keep ghost rows); below, the dense kernel is ahead.  (A partly dead last wave column wastes its
@@ -396,7 +397,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// (a ring slab that can keep ghost rows sweeps in fused launches as well, see below)
 	const bool deep_can = !c->wrap && !cfg->XSL && !(cfg->use_J && cfg->coupling_mem) && !cfg->lattice_mem && cfg->Y >= 4 &&
 	                      !(getenv("ISING_RING_GHOST") && atoi(getenv("ISING_RING_GHOST")) < 2);
-	const long long ballot_from = ((c->fused && fused_can) || deep_can) ? (1LL << 25) : (1LL << 27);
+	const long long ballot_from = ((c->fused && fused_can) || deep_can) ? 3 * (1LL << 23) : (1LL << 27);
 	if (cfg->layout == ISING_LAYOUT_AUTO && ballot_ok && ballot_pays && c->fast_ok && spins >= ballot_from && !getenv("ISING_NO_BALLOT"))
 		c->ballot = true;
 	if (c->ballot) c->lld = c->nwc() * 64;
