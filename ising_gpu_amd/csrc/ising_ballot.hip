@@ -126,7 +126,7 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 // workgroup SLOT (blockIdx): ~12 MB that stay in the L2s, where a plain launch of 65536^2 spreads 134 MB of slots that
 // spill to HBM (0.89 vs 1.14 GB of traffic per colour half-sweep, free of charge under a saturated vector ALU but traffic
 // all the same).  The chip never drains between colours.  A unit's parents are one level of tickets back: the host picks
-// strip height and grid size so that they are done when the unit starts (ising_create); from 2^25 spins up
+// strip height and grid size so that they are done when the unit starts (ising_create); from 1.5 * 2^24 spins up
 // this form is what ising_sweep launches.
 // When a workgroup draws its next ticket.  2 (default): in a unit's last iteration, waited for on the spot (~2 us per
 // unit).  0: requested at the end of the second-last word phase and picked up one iteration later -- hides half of

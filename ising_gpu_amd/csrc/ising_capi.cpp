@@ -362,7 +362,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	compute_tables(c, cfg->temp);
 	c->wrap = cfg->nslabs == 1 && !cfg->ring_halo;
 	// How ising_sweep launches on the ballot layout: fused launches (one launch = up to 32 sweeps, in-order tickets,
-	// per-strip completion counters; ising_ballot.hip) from 2^25 spins up, on a slab that wraps in place and has no
+	// per-strip completion counters; ising_ballot.hip) from 1.5 * 2^24 spins up, on a slab that wraps in place and has no
 	// sub-lattices.  A unit's parents are one level = T tickets back, so a level must hold a few times more tickets than
 	// workgroups run, or units find their parents unfinished and hold their slots asleep: the strip height H follows
 	// from T = wave rows / (H x waves per workgroup), and small lattices run FEWER workgroups than the chip holds.
