@@ -150,7 +150,9 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 // priority for the next unit): the same spread, alternating.  0: none.  (Four steps per row instead of one: 3487 at 65536^2; a
 // row count that runs on across units: -1.5 % with one- to four-row units; the rotation in one-launch-per-colour launches,
 // ISING_PLAIN_PRIO: 3458 -> 3389 -- their workgroups are not a persistent grid, and nothing waits for a slow one but the launch's end;
-// the fifth and sixth wave of a SIMD -- four levels, so they share one with the first and second -- stepping the other way round: -0.3 %.)
+// the fifth and sixth wave of a SIMD -- four levels, so they share one with the first and second -- stepping the other way round: -0.3 %; as many positions as
+// the SIMD has waves, the ones past the third sharing level 0: -0.5 .. -1.5 %.  What remains uneven: the fifth and sixth wave still own all
+// the units that take three times the median, 7 % of the units at 65536^2.)
 #ifndef ISING_FUSED_PRIO
 #define ISING_FUSED_PRIO 2
 #endif
@@ -656,6 +658,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				const long long te = clock64();
 				hist_sh[0][min(15ll, (te - t_unit1) / (16384ll * p.H / 8))]++;
 				hist_sh[1][min(15ll, (te - t_unit0) / (16384ll * p.H / 8))]++;
+				if ((te - t_unit1) / (16384ll * p.H / 8) >= 12) tr[10 + min(3u, blockIdx.x >> 8)] += 1; // long units by dispatch round (3: fourth and later)
 			}
 #endif
 			if (lane == 0) __hip_atomic_fetch_add(p.done + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -941,6 +944,7 @@ void ballot_trace_dump() {
 	{
 		unsigned long long g[32];
 		if (hipMemcpyFromSymbol(g, HIP_SYMBOL(g_hist), sizeof(g)) != hipSuccess) return;
+		fprintf(stderr, "  units of 12 bins and more by dispatch round: %llu %llu %llu, fourth and later %llu\n", h[10], h[11], h[12], h[13]);
 		for (int k = 0; k < 2; k++) {
 			fprintf(stderr, "  unit durations %s, bins of 2048 cycles per row:", k ? "from ticket pick-up" : "behind the wait for the parents");
 			for (int i = 0; i < 16; i++) fprintf(stderr, " %llu", g[16 * k + i]);
