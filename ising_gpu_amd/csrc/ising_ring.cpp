@@ -270,7 +270,13 @@ int ring_bind(ising_ctx **ctxs, int n, int want = ISING_TRANSPORT_AUTO) {
 		// orders everything, so a launch can write rows 0 / Y-1 straight into the neighbours' halo rows.
 		bool one = true;
 		for (int k = 0; k < n; k++) one = one && ctxs[k]->copy_inline && ctxs[k]->stream == ctxs[0]->stream && ctxs[k]->cfg.device == ctxs[0]->cfg.device;
-		if (const char *e = getenv("ISING_RING_STORE")) one = one && atoi(e) != 0; // 0: keep edge launch + copies (A/B)
+		// Slabs with ghost rows sweep faster in fused launches that take turns on the device, with copies of the ghost rows in
+		// between (8 slabs of 131072 x 16384: 3455 vs 3394 flips/ns with the direct stores, 2 of 65536 x 32768: 3457 vs 3369), so the
+		// direct stores are for slabs without them (dense / nibble layouts, caller-owned buffers).  ISING_RING_STORE=0/1 forces.
+		bool ghosts = true;
+		for (int k = 0; k < n; k++) ghosts = ghosts && ctxs[k]->ballot && ctxs[k]->ghost() > 1 && !ctxs[k]->cfg.XSL;
+		if (const char *e = getenv("ISING_RING_STORE")) one = one && atoi(e) != 0;
+		else one = one && !ghosts;
 		for (int k = 0; k < n; k++) ctxs[k]->store_ring = one;
 	} else {
 		for (int k = 0; k < n; k++) ctxs[k]->copy_inline = ctxs[k]->store_ring = false;

@@ -23,7 +23,13 @@ def _single(X, Y, seed, temp, sweeps, **kw):
 
 @pytest.mark.parametrize("layout", [ig.LAYOUT_BALLOT, ig.LAYOUT_DENSE, ig.LAYOUT_NIBBLE])
 @pytest.mark.parametrize("nslabs", [2, 3, 8])
-def test_capi_ring_copy_transport_matches_single_slab(gpu, nslabs, layout):
+@pytest.mark.parametrize("store", [None, "1"])
+def test_capi_ring_copy_transport_matches_single_slab(gpu, monkeypatch, nslabs, layout, store):
+    """Slabs of one device: with ghost rows (the ballot layout's default) fused launches that take turns, with copies of the
+    ghost rows in between; without them -- or with ISING_RING_STORE=1 -- every launch stores its edge rows straight into the
+    neighbours' halo rows."""
+    if store:
+        monkeypatch.setenv("ISING_RING_STORE", store)
     X, Yk, seed, temp, sweeps = 8192, 32, 99, ig.CRIT_TEMP_F32, 6
     ref_b, ref_w, ref_cnt, ref_bond = _single(X, Yk * nslabs, seed, temp, sweeps, layout=layout)
     ring = ig.SlabSet([ig.IsingSlab(X, Yk, seed=seed, temp=temp, nslabs=nslabs, slab=k, layout=layout) for k in range(nslabs)])
