@@ -16,8 +16,12 @@ colour to each ring neighbour every 32 sweeps (ghost rows; one row per colour ha
           and `roofline.half_sweeps_per_launch` describe the timed launches.
   N > 1   one process per GPU; the ring lives inside libising_hip.so (ising_rank_*: second HIP stream + RCCL send/recv);
           ballot ring slabs keep ghost rows 64 deep, exchange 64 rows of both colours every 32 sweeps and run one fused launch
-          in between (sweep_deep); if that transport does not come up the torch.distributed ring (p2p, then all-gather, one
-          row per colour half-sweep on a torch-owned slab) takes over and the JSON line says which one ran.  The counts after warm-up + steps are compared with the oracle's committed goldens
+          in between (sweep_deep).  Transports, in this order, every rank agreeing on each outcome: the library's RCCL ring,
+          the library's RCCL-free peer ring (hipIpcMemHandle-mapped ghost rows, ISING_TRANSPORT_IPC), the torch.distributed
+          ring (p2p on ghost rows, p2p / all-gather with one row per colour half-sweep on a torch-owned slab); the JSON line
+          says which one ran.  With more ranks than GPUs (a 1-GPU box running --gpus 2) the ranks share devices: gloo carries
+          the control plane and the peer ring the rows (RCCL refuses two ranks per device).  `python bench.py --gpus N`
+          without a launcher starts itself under torch.distributed.run.  The counts after warm-up + steps are compared with the oracle's committed goldens
           (tests/golden/bench_65536_tc.json, ring_65536_tc.json) when the run hits one of their points.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
@@ -106,6 +110,9 @@ def main():
     ap.add_argument("--layout", choices=["auto", "nibble", "dense", "ballot"], default="auto", help="device layout of the spin arrays")
     ap.add_argument("--ring", choices=["native", "torch"], default="native",
                     help="N > 1: the ring inside libising_hip.so (RCCL on a second stream) or the torch.distributed one")
+    ap.add_argument("--transport", choices=["auto", "rccl", "ipc"], default="auto",
+                    help="N > 1, native ring: RCCL send/recv, the RCCL-free peer transport over hipIpcMemHandle, or (auto) the first "
+                         "of the two that comes up on every rank")
     ap.add_argument("--exchange", choices=["p2p", "allgather"], default=None,
                     help="N > 1, torch ring: how the edge rows travel (forces --ring torch)")
     ap.add_argument("--preheat-ms", type=float, default=150.0,
@@ -121,6 +128,16 @@ def main():
 
     # must be in the environment before the HIP/HSA runtime initialises (RCCL P2P needs dmabuf IPC on this host driver)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start one process per rank ourselves (the contract's own command line, on a free port)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     import torch
     import torch.distributed as dist
     import ising_gpu_amd as ig
@@ -132,12 +149,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
-    torch.cuda.set_device(local_rank)
+    # more ranks than GPUs (what a 1-GPU box can run of an N-rank job): ranks share devices round robin
+    ndev = torch.cuda.device_count()
+    shared = world > ndev
+    device = local_rank % ndev
+    torch.cuda.set_device(device)
     ringed = world > 1 or args.force_ring
+    # control plane (ids, blobs, barriers, checksums): RCCL through torch when every rank has a device of its own, gloo otherwise
+    ctl = "cpu" if shared else "cuda"
     if ringed:
         if "MASTER_ADDR" not in os.environ:  # --force-ring without a launcher
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29577"), RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+    local_rank = device
 
     layout = {"auto": ig.LAYOUT_AUTO, "nibble": ig.LAYOUT_NIBBLE, "dense": ig.LAYOUT_DENSE, "ballot": ig.LAYOUT_BALLOT}[args.layout]
     log = (lambda m: print(f"[bench rank {rank}] {m}", file=sys.stderr, flush=True))
@@ -152,9 +179,14 @@ def main():
             # every 32 sweeps and run fused launches in between (csrc/ising_ring.cpp: sweep_deep)
             slab = ig.IsingSlab(args.x, args.y, device=local_rank, seed=args.seed, temp=ig.CRIT_TEMP_F32, nslabs=world, slab=rank,
                                 strip_rows=args.strip_rows, layout=layout, ring_halo=world == 1)
-            ring, ring_name = ig.open_native_ring(slab, log=log), "rccl-native"
+            transports = {"auto": ("ipc",) if shared else ("rccl", "ipc"), "rccl": ("rccl",), "ipc": ("ipc",)}[args.transport]
+            ring = ig.open_native_ring(slab, log=log, transports=transports)
             if ring is None:
                 slab.close()
+            else:
+                ring_name = ring.exchange
+        if ring is None and shared:
+            raise SystemExit("bench: ranks share a device and the library's peer ring did not come up (torch's rings need RCCL, which refuses two ranks per device)")
         if ring is None and args.exchange in (None, "p2p"):
             # torch.distributed send/recv on a slab that owns its buffer: the same deep schedule (ghost rows, one exchange per
             # 32 sweeps: SlabRing._sweep_deep), the rows wrapped zero-copy as tensors
@@ -215,7 +247,7 @@ def main():
         torch.cuda.synchronize()
         more = max(0, math.ceil(args.preheat_ms / max((time.perf_counter() - t0) * 1e3, 1e-3)) - 1)
         if ringed:  # every rank must do the same number of sweeps: rank 0's estimate counts
-            t = torch.tensor([more], dtype=torch.int64, device="cuda")
+            t = torch.tensor([more], dtype=torch.int64, device=ctl)
             dist.broadcast(t, src=0)
             more = int(t[0])
         more = min(more, 4096)
@@ -235,7 +267,7 @@ def main():
     dt = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
     if ringed:
-        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, ev_ms = float(t[0]), float(t[1])
 

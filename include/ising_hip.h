@@ -266,7 +266,9 @@ int ising_ring_checkpoint_load(ising_ctx **ctxs, int n, const char *path, int64_
 enum {
 	ISING_TRANSPORT_AUTO = 0, /* RCCL when every slab has its own device and librccl opens, else copies */
 	ISING_TRANSPORT_COPY = 1, /* hipMemcpyPeerAsync on the comm stream (single process only) */
-	ISING_TRANSPORT_RCCL = 2  /* ncclSend / ncclRecv on the comm stream */
+	ISING_TRANSPORT_RCCL = 2, /* ncclSend / ncclRecv on the comm stream */
+	ISING_TRANSPORT_IPC = 3   /* one process per slab, no RCCL: every rank copies its edge rows straight into the neighbours' halo / ghost
+	                             rows, which it has mapped through hipIpcMemHandle (ising_ipc_export / ising_ipc_attach below) */
 };
 
 /* -- single process, n devices (the reference's process model: one host thread drives ndev GPUs, :1763-1805).
@@ -294,7 +296,8 @@ int ising_ring_bond_equal(ising_ctx **ctxs, int n, int64_t *A);
 int ising_rccl_available(int *version);            /* ISING_OK when librccl could be opened; its version code */
 int ising_rccl_unique_id(void *id_out);            /* ncclGetUniqueId */
 int ising_rank_attach(ising_ctx *ctx, const void *id_in); /* ncclCommInitRank(nslabs, id, slab) */
-int ising_rank_detach(ising_ctx *ctx, int abort_pending);  /* ncclCommDestroy, or ncclCommAbort after a time-out */
+int ising_rank_detach(ising_ctx *ctx, int abort_pending);  /* ncclCommDestroy, or ncclCommAbort after a time-out (ISING_TRANSPORT_IPC:
+                                                              unmaps the neighbours; abort_pending ends this rank's polling kernels) */
 int ising_rank_exchange(ising_ctx *ctx, int color);
 int ising_rank_init_couplings(ising_ctx *ctx);
 int ising_rank_sweep(ising_ctx *ctx, int first_it, int nsweeps);
@@ -304,6 +307,22 @@ int ising_rank_wait(ising_ctx *ctx, int timeout_ms);
 /* Whole-lattice totals, ncclAllReduce over the ranks.  Blocking. */
 int ising_rank_count(ising_ctx *ctx, uint64_t *up, uint64_t *down);
 int ising_rank_bond_equal(ising_ctx *ctx, int64_t *A);
+
+/* -- one process per slab WITHOUT RCCL: direct peer access, the reference's own multi-GPU mechanism
+ * (cudaDeviceCanAccessPeer / cudaDeviceEnablePeerAccess, optimized/main.cu:1496-1537; remote loads of the two rows outside
+ * each slab, :1637-1642, loadTile :413-428), across processes.  Every rank exports a description of its slab's buffers
+ * (hipIpcGetMemHandle of the spin and coupling arrays, the name of a 4 KiB POSIX shared-memory segment holding its flags),
+ * the launcher's own channel (torch.distributed, MPI, a file) gathers the nslabs blobs in slab order, every rank attaches:
+ * it maps the previous and the next slab's arrays (hipIpcOpenMemHandle; a neighbour in the same process is used directly)
+ * and all ranks' flag segments.  From then on the ising_rank_* calls above run on ISING_TRANSPORT_IPC: a rank pushes its
+ * first / last rows into its neighbours' halo or ghost rows with device-to-device copies on its comm stream and tells them
+ * so through monotone epoch counters in their flag segments, which small kernels on the waiting streams poll -- no host
+ * round trip inside a sweep, no stream or event shared between processes; totals (ising_rank_count) are summed by the
+ * hosts through the same segments.  Ranks may share a device (several processes on one GPU: what a 1-GPU box can run of
+ * an N-rank ring) or own one each (peer access over xGMI). */
+#define ISING_IPC_BLOB_BYTES 256
+int ising_ipc_export(ising_ctx *ctx, void *blob_out);                  /* ISING_IPC_BLOB_BYTES bytes describing this rank's slab */
+int ising_ipc_attach(ising_ctx *ctx, const void *blobs, int nblobs);   /* nblobs == nslabs blobs in slab order; collective */
 
 /* Two-point correlations, getCorr2D_k + computeCorr (optimized/main.cu:870-965, :1072-1138): for j = 1..ncorr
  * (ncorr <= 128 = MAX_CORR_LEN, :70)  sums[j-1] = sum over all sites of [s(r,c)==s(r,c+j) ? +1 : -1] +

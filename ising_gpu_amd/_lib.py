@@ -17,9 +17,10 @@ CRIT_TEMP_F32 = 2.2691853046417236  # float32(2.26918531421f), CRIT_TEMP optimiz
 SEED_DEF = 463463564571  # optimized/main.cu:63
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST, KERNEL_LUT = 0, 1, 2, 3
 LAYOUT_AUTO, LAYOUT_NIBBLE, LAYOUT_DENSE, LAYOUT_BALLOT = 0, 1, 2, 3
-TRANSPORT_AUTO, TRANSPORT_COPY, TRANSPORT_RCCL = 0, 1, 2
+TRANSPORT_AUTO, TRANSPORT_COPY, TRANSPORT_RCCL, TRANSPORT_IPC = 0, 1, 2, 3
 E_ARG, E_HIP, E_STATE, E_NOGPU, E_RCCL, E_TIMEOUT, E_IO = 1, 2, 3, 4, 5, 6, 7
 RCCL_ID_BYTES = 128
+IPC_BLOB_BYTES = 256
 
 
 class IsingConfig(C.Structure):
@@ -91,6 +92,8 @@ PROTOTYPES = {
     "ising_rccl_available": (C.c_int, [C.POINTER(C.c_int)]),
     "ising_rccl_unique_id": (C.c_int, [C.c_void_p]),
     "ising_rank_attach": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ising_ipc_export": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ising_ipc_attach": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ising_rank_detach": (C.c_int, [C.c_void_p, C.c_int]),
     "ising_rank_exchange": (C.c_int, [C.c_void_p, C.c_int]),
     "ising_rank_init_couplings": (C.c_int, [C.c_void_p]),

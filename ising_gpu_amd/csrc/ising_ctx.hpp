@@ -70,6 +70,8 @@ struct ising_ctx {
 	void *rccl_comm = nullptr;                   // ncclComm_t of this slab's rank
 	bool rccl_owner = false;                     // the communicator was created for this context (destroy it with the context)
 	bool rank_mode = false;                      // one slab per process: the neighbours live in other processes
+	struct ising_ipc *ipc = nullptr;             // ISING_TRANSPORT_IPC: the neighbours' rows mapped through hipIpcMemHandle, flags in
+	                                             // POSIX shared memory (ising_ring.cpp)
 	bool peers_enabled = false;
 	uint32_t *d_signal[2] = {nullptr, nullptr};  // per colour: counter the published edge strips of a full-slab launch bump
 	                                             // (hipMallocSignalMemory: the comm stream waits on it, hipStreamWaitValue32)

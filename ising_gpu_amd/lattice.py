@@ -237,6 +237,20 @@ class IsingSlab:
         buf = C.create_string_buffer(bytes(unique_id), _lib.RCCL_ID_BYTES)
         check(self._lib.ising_rank_attach(self._h, buf))
 
+    def ipc_export(self) -> bytes:
+        """This rank's blob for the IPC transport (ising_ipc_export): hipIpcMemHandles of its arrays + its flag segment."""
+        buf = C.create_string_buffer(_lib.IPC_BLOB_BYTES)
+        check(self._lib.ising_ipc_export(self._h, buf))
+        return buf.raw
+
+    def ipc_attach(self, blobs):
+        """Every rank's blob in slab order (ising_ipc_attach): maps the neighbours' rows; the rank_* calls then run on them."""
+        blobs = list(blobs)
+        if any(len(b) != _lib.IPC_BLOB_BYTES for b in blobs):
+            raise ValueError("an IPC blob has %d bytes" % _lib.IPC_BLOB_BYTES)
+        buf = C.create_string_buffer(b"".join(bytes(b) for b in blobs), _lib.IPC_BLOB_BYTES * len(blobs))
+        check(self._lib.ising_ipc_attach(self._h, buf, len(blobs)))
+
     def rank_detach(self, abort: bool = False):
         check(self._lib.ising_rank_detach(self._h, 1 if abort else 0))
 

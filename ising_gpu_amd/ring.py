@@ -412,24 +412,39 @@ class LocalRing:
 
 class NativeRing:
     """One slab per process, the whole half-sweep schedule inside libising_hip.so (ising_rank_*): the library owns a
-    second HIP stream and an RCCL communicator per slab; torch.distributed only carries the 128-byte RCCL id once.
+    second HIP stream per slab and moves the rows itself; torch.distributed only carries the attachment data once.
+    transport "rccl": an RCCL communicator per slab (the 128-byte id travels through torch.distributed);
+    transport "ipc":  no RCCL -- every rank maps its neighbours' rows through hipIpcMemHandle and pushes its edge rows
+                      into them (ising_ipc_export / ising_ipc_attach; the blobs travel through torch.distributed).  Ranks
+                      may share a device, which RCCL refuses.
     Same driver surface as SlabRing (init / sweep / count / bond_equal / quiesce)."""
 
-    exchange = "rccl-native"
-
-    def __init__(self, slab, group: Optional[dist.ProcessGroup] = None, probe_timeout_ms: int = 60000):
+    def __init__(self, slab, group: Optional[dist.ProcessGroup] = None, probe_timeout_ms: int = 60000, transport: str = "rccl"):
         self.slab = slab
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         if slab.nslabs != self.world or slab.slab != self.rank:
             raise ValueError(f"slab {slab.slab} of {slab.nslabs} on rank {self.rank} of {self.world}")
+        if transport not in ("rccl", "ipc"):
+            raise ValueError(f"unknown native transport {transport!r}")
+        self.transport = transport
+        self.exchange = "rccl-native" if transport == "rccl" else "ipc-native"
         self.probe_timeout_ms = probe_timeout_ms
         self.it = 0
         self._attach()
 
     def _attach(self):
         from .lattice import rccl_unique_id
+        if self.transport == "ipc":
+            mine = self.slab.ipc_export()
+            if self.world == 1:
+                blobs = [mine]
+            else:
+                blobs = [None] * self.world
+                dist.all_gather_object(blobs, mine, group=self.group)
+            self.slab.ipc_attach(blobs)
+            return
         if self.world == 1:
             uid = rccl_unique_id()
         else:
@@ -446,7 +461,7 @@ class NativeRing:
         self.it = 0
         self.slab.rank_exchange(BLACK)
         self.slab.rank_exchange(WHITE)
-        # the first exchange also builds RCCL's connections: bounded wait, so that a transport that cannot come up
+        # the first exchange also builds the transport's connections: bounded wait, so that a transport that cannot come up
         # surfaces as an error the caller can fall back from instead of a hang
         self.slab.rank_wait(self.probe_timeout_ms)
         if self.slab.use_J:
@@ -472,36 +487,49 @@ class NativeRing:
         self.slab.rank_detach(abort)
 
 
-def open_native_ring(slab, log=None):
-    """The library's own RCCL ring on a slab that owns its buffer (ring slabs on the ballot layout then keep ghost rows
-    64 deep and exchange every 32 sweeps, csrc/ising_ring.cpp: sweep_deep) -- or None when it does not come up on every
-    rank (the caller then builds a torch-owned slab and calls open_ring for the torch.distributed rings)."""
-    log = log or (lambda *a: None)
+def _agree(ok: bool) -> bool:
+    """True when `ok` holds on every rank (one small all-reduce on whatever backend carries the control plane)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    ring = None
-    try:
-        ring = NativeRing(slab)
-        ring.init()
-        ring.sweep(1)  # one real sweep through the transport before it is trusted
-        ring.quiesce()
-        torch.cuda.synchronize()
-        ok = True
-    except Exception as e:  # noqa: BLE001 -- any transport failure means: the caller tries the next one
-        log(f"ring transport rccl-native failed on this rank: {e}")
-        ok = False
-    if world > 1:
-        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
-        if dist.get_backend() == "nccl":
-            t = t.cuda()
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        ok = bool(int(t[0]))
-    if ok:
-        return ring
-    if ring is not None:
+    if world == 1:
+        return ok
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t[0]))
+
+
+def open_native_ring(slab, log=None, transports=("rccl", "ipc")):
+    """The library's own ring on a slab that owns its buffer (ring slabs on the ballot layout then keep ghost rows 64 deep
+    and exchange every 32 sweeps, csrc/ising_ring.cpp: sweep_deep): RCCL send/recv first, then the RCCL-free peer transport
+    over hipIpcMemHandle (`transports`; ranks sharing a device go straight to the second -- RCCL refuses them).  Every
+    rank takes the same decision: the outcome of each attempt is agreed on before anyone moves on.  None when no transport
+    comes up on every rank (the caller then builds a torch-owned slab and calls open_ring for the torch.distributed rings)."""
+    log = log or (lambda *a: None)
+    for tr in transports:
+        ring = None
         try:
-            ring.close(abort=True)
-        except Exception:  # noqa: BLE001
-            pass
+            ring = NativeRing(slab, transport=tr)
+            ring.init()
+            ring.sweep(1)  # one real sweep through the transport before it is trusted
+            ring.quiesce()
+            torch.cuda.synchronize()
+            ok = True
+        except Exception as e:  # noqa: BLE001 -- any transport failure means: the caller tries the next one
+            log(f"ring transport {tr}-native failed on this rank: {e}")
+            ok = False
+        if _agree(ok):
+            return ring
+        if ring is not None:
+            try:
+                ring.close(abort=True)
+            except Exception:  # noqa: BLE001
+                pass
+        elif slab is not None:
+            try:
+                slab.rank_detach(True)  # (an attachment that half came up)
+            except Exception:  # noqa: BLE001
+                pass
     return None
 
 

@@ -1,0 +1,86 @@
+"""The N > 1 path of the C-ABI with REAL processes on a 1-GPU box: ising_rank_* over ISING_TRANSPORT_IPC (the reference's
+own multi-GPU mechanism -- direct peer access to the neighbours' rows, optimized/main.cu:1496-1537, :1637-1642 -- across
+processes: hipIpcMemHandle-mapped ghost rows, epoch counters in POSIX shared memory; csrc/ising_ring.cpp).  2 and 3
+processes share device 0 (RCCL refuses that; this transport does not): every rank compares its slab, the global counts
+and the bond sum with the CPU oracle on small slabs (deep schedule with ghost rows, one halo row on two streams, -J), and
+two ranks holding the bench's 65536^2 slabs reproduce the oracle's golden ring counts after 0 / 5 / 21 / 25 sweeps."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _launch(world, port, mode, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("ISING_RING_GHOST", None)
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), os.path.join(ROOT, "tools", "ring_ranks_ipc.py"), mode],
+                          capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+@pytest.mark.parametrize("world,port", [(2, 29551), (3, 29552)])
+def test_rank_ring_over_ipc_processes_share_one_gpu(gpu, world, port):
+    r = _launch(world, port, "small")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    # 5 configurations, 3 + 2 + 2 + 2 + 1 sweep calls, every rank reports each; nothing differs
+    assert r.stdout.count("== oracle") >= 2 * 10 * world and "!=" not in r.stdout, r.stdout[-3000:]
+    assert r.stdout.count("ghost rows 32") == 5 * world, r.stdout[-3000:]
+
+
+def test_two_ranks_over_ipc_reproduce_the_bench_ring_golden(gpu):
+    r = _launch(2, 29553, "golden")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("== oracle golden") == 2 * 4 and "!=" not in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("layout_name", ["ballot", "dense"])
+def test_ring_of_one_over_ipc_in_process(gpu, oracle_mod, layout_name):
+    """A ring of ONE slab attached to itself: its edge rows travel through the transport's copies and counters into its own
+    halo / ghost rows -- what one rank of a ring executes, without a second process."""
+    import ising_gpu_amd as ig
+    layout = {"ballot": ig.LAYOUT_BALLOT, "dense": ig.LAYOUT_DENSE}[layout_name]
+    X, Y, seed = 8192, 128, 77
+    slab = ig.IsingSlab(X, Y, seed=seed, temp=ig.CRIT_TEMP_F32, layout=layout, ring_halo=True)
+    slab.ipc_attach([slab.ipc_export()])
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=oracle_mod.CRIT_TEMP).init()
+    slab.init()
+    slab.rank_exchange(ig.BLACK)
+    slab.rank_exchange(ig.WHITE)
+    for n in (3, 40):
+        slab.rank_sweep(n)
+        orc.sweep(n)
+        assert slab.rank_bond_equal() == orc.bond_equal()
+        assert slab.rank_count() == orc.count()
+        slab.rank_wait(-1)
+        assert np.array_equal(slab.read(ig.BLACK), orc.black) and np.array_equal(slab.read(ig.WHITE), orc.white)
+    slab.rank_detach()
+    # detached: the rank calls are refused, a fresh export / attach works again
+    with pytest.raises(ig.IsingError):
+        slab.rank_sweep(1)
+    slab.ipc_attach([slab.ipc_export()])
+    slab.init()
+    slab.rank_exchange(ig.BLACK)
+    slab.rank_exchange(ig.WHITE)
+    slab.rank_sweep(2)
+    assert slab.rank_count() == oracle_mod.OracleLattice(X, Y, seed=seed, temp=oracle_mod.CRIT_TEMP).init().sweep(2).count()
+    slab.close()
+
+
+def test_ipc_attach_rejects_foreign_blobs(gpu):
+    import ising_gpu_amd as ig
+    a = ig.IsingSlab(8192, 64, nslabs=2, slab=0, layout=ig.LAYOUT_DENSE)
+    b = ig.IsingSlab(8192, 128, nslabs=2, slab=1, layout=ig.LAYOUT_DENSE)  # another shape
+    blobs = [a.ipc_export(), b.ipc_export()]
+    with pytest.raises(ig.IsingError):
+        a.ipc_attach(blobs)
+    with pytest.raises(ig.IsingError):
+        a.ipc_attach(blobs[:1])
+    with pytest.raises(ig.IsingError):
+        a.ipc_attach([bytes(256), bytes(256)])
+    a.close()
+    b.close()
