@@ -332,8 +332,8 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		// the launch ends on many short units instead of a few long ones.  Range 0 is padded to whole workgroups (nunits0
 		// vs nreal0) so that the waves of a workgroup share one strip height.
 		const int rng = unit0 >= p.nunits0;
-		const bool idle = rng ? unit0 >= p.nunits : unit0 >= p.nreal0; // partly empty workgroups still meet the barriers
-		const int u = idle ? 0 : unit0 - (rng ? p.nunits0 : 0);
+		const bool absent = rng ? unit0 >= p.nunits : unit0 >= p.nreal0; // partly empty workgroups still meet the barriers
+		const int u = absent ? 0 : unit0 - (rng ? p.nunits0 : 0);
 		const int Hr = (rng && p.H2) ? p.H2 : p.H; // strip height of this range (uniform over the workgroup)
 		int pos;
 		if (nwc_sh >= 0) pos = u >> nwc_sh;
@@ -348,7 +348,15 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		const bool zigzag = FUSED || (rng == 0 && (p.zigzag0 || (p.edge_signal != nullptr && p.sync_wait == nullptr)));
 		const int sidx = zigzag ? uni((pos & 1) ? nstr - 1 - (pos >> 1) : (pos >> 1)) : pos;
 		const int r0 = p.row_lo[rng] + sidx * Hr;
-		const int nrows = idle ? 0 : min(Hr, p.row_hi[rng] - r0);
+		const int nrows0 = absent ? 0 : min(Hr, p.row_hi[rng] - r0);
+		// ring slab with ghost rows: at this level only rows within `keep` of the slab's own can still reach one of them; a strip
+		// wholly further out has nothing to do (it still waits for its parents and counts as complete: its counter is a count)
+		const int keep = uni(p.nlevels - 1 - level); // (pinned: the compiler takes the running level count for lane-dependent)
+		const bool skip = FUSED && p.trapezoid != 0 && !absent && (r0 + nrows0 <= -keep || r0 >= p.Y + keep);
+		const bool idle = absent || skip;
+		const int nrows = skip ? 0 : nrows0;
+		// ... and, exchange overlapped with the launches: a unit that touches rows the exchange reads or writes
+		const bool edge_unit = FUSED && p.edge_go != nullptr && !absent && (r0 < p.edge_lo || r0 + nrows0 > p.edge_hi);
 		// ring slab, flag-synchronised schedule: this unit holds a row next to rows the slab's other launch (edge rows <->
 		// interior) writes
 		const bool synced = !FUSED && p.sync_wait != nullptr && !idle &&
@@ -392,7 +400,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 
 		// FUSED: wait until strips s-1, s, s+1 (periodic) have completed level - 1, `nwc` wave columns each per level.  The
 		// first look at their counters travels while the block constants are made.
-		const bool must_wait = FUSED && level > 0 && !idle;
+		const bool must_wait = FUSED && level > 0 && !absent;
 		const uint32_t need = p.done_base + (uint32_t)level * (uint32_t)nwc;
 		const uint32_t *dp = nullptr;
 		uint32_t seen = need;
@@ -432,6 +440,18 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				if (lane < 3) asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(seen) : "v"(dp) : "memory");
 			}
 			TRC(2); // completion counters (+ block constants)
+		}
+		if (edge_unit && level == 0) {
+			// the exchange that follows the previous launch has read this slab's first / last rows and filled its ghost rows
+			// once the comm stream has moved the counter (usually long ago: the exchange starts when the previous launch's
+			// edge strips finish their last level, a level before the launch ends)
+			uint32_t got = p.edge_go_need;
+			for (;;) {
+				if (lane == 0) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(got) : "v"(p.edge_go) : "memory");
+				if (__all((int32_t)(got - p.edge_go_need) >= 0)) break;
+				__builtin_amdgcn_s_sleep(127);
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // rows written by another kernel / a copy engine while this launch ran
 		}
 		if (synced) {
 			// the other launch's rows next to this unit's (and its reads of the rows this unit is about to overwrite) are
@@ -648,7 +668,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			if (lane == 0) __hip_atomic_fetch_add(p.edge_signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 		if (FUSED) tkv = ticket_sh[(round + 1) & 1]; // (on its way while the stores drain)
-		if (FUSED && !idle) {
+		if (FUSED && !absent) {
 			// publish: this wave's stores were written through (sc1); once they have left the wave the strip's counter
 			// may move (every storing wave drains its own stores and signals its own unit)
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -662,6 +682,8 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			}
 #endif
 			if (lane == 0) __hip_atomic_fetch_add(p.done + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			// last level: the rows the next exchange sends are final and the ghost rows no longer read
+			if (edge_unit && level == p.nlevels - 1 && lane == 0) __hip_atomic_fetch_add(p.edge_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
 #if defined(ISING_FUSED_TRACE)

@@ -522,6 +522,7 @@ int ising_destroy(ising_ctx *c) {
 	if (c->d_slotctl) (void)hipFree(c->d_slotctl);
 	for (int k = 0; k < 2; k++) if (c->d_signal[k]) (void)hipFree(c->d_signal[k]);
 	if (c->d_flags) (void)hipFree(c->d_flags);
+	if (c->d_edge) (void)hipFree(c->d_edge);
 	if (c->d_scratch_edge) (void)hipFree(c->d_scratch_edge);
 	if (c->d_pack) (void)hipFree(c->d_pack);
 	delete c;
@@ -600,8 +601,10 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	// one-shot requests of the ring schedules for THIS launch (taken here, so that an early return cannot leave them set)
 	const bool edge_scratch = c->edge_scratch_next;
 	const int sync_mode = c->sync_mode;
+	const bool overlap = c->overlap_next;
 	c->edge_scratch_next = false;
 	c->sync_mode = 0;
+	c->overlap_next = false;
 	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
 	if (it < 0) return fail(ISING_E_ARG, "negative iteration %d", it);
 	int mode = c->cfg.kernel == ISING_KERNEL_GENERIC ? 1 : (c->cfg.kernel == ISING_KERNEL_LUT ? 2 : 0); // AUTO, FAST -> 0
@@ -708,7 +711,23 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			p.wg_per_cu = c->fused_wg_per_cu;
 			p.nt_stream = c->fused_nt;
 			p.done_base = c->done_base;
-			if (lo0 < 0 || hi0 > c->cfg.Y) p.total_rows = c->cfg.nslabs * c->cfg.Y; // ghost rows are rows of the neighbouring slabs
+			if (lo0 < 0 || hi0 > c->cfg.Y) { // ghost rows are rows of the neighbouring slabs
+				p.total_rows = c->cfg.nslabs * c->cfg.Y;
+				static const bool trap = !(getenv("ISING_RING_TRAPEZOID") && atoi(getenv("ISING_RING_TRAPEZOID")) == 0);
+				p.trapezoid = trap ? 1 : 0;
+				if (overlap && c->d_edge) {
+					// the exchange touches the first / last G rows (read by the sends) and the ghost rows (written by the receives)
+					const int G = c->ghost();
+					p.edge_lo = G;
+					p.edge_hi = c->cfg.Y - G;
+					p.edge_go = c->d_edge + 16;
+					p.edge_go_need = c->edge_go_epoch;
+					p.edge_done = c->d_edge;
+					unsigned strips = 0; // strips of this launch that touch such a row
+					for (int r0 = lo0; r0 < hi0; r0 += c->H) if (r0 < p.edge_lo || std::min(r0 + c->H, hi0) > p.edge_hi) strips++;
+					c->edge_done_target += strips * (uint32_t)c->nwc();
+				}
+			}
 		}
 		if (publish) {
 			p.edge_signal = c->d_signal[color];
@@ -786,9 +805,10 @@ static bool ghost_sweeps(const ising_ctx *c) {
 // Ring slab with G > 1 ghost rows: `nlevels` colour half-sweeps (black first) in one fused launch over rows
 // [-(G-1), Y+G-1).  The ghost rows are updated like the slab's own -- their draws are the ones the neighbours make --, and
 // what is not valid in them any more (one row per level and side) never reaches a row that is.
-int ising_host::update_deep(ising_ctx *c, int it, int nlevels) {
+int ising_host::update_deep(ising_ctx *c, int it, int nlevels, bool overlapped) {
 	const int G = c->ghost();
 	if (G < 2 || nlevels > G || nlevels < 2 || c->store_ring) return fail(ISING_E_STATE, "deep launch of %d levels on a slab with %d ghost rows", nlevels, G);
+	c->overlap_next = overlapped;
 	return launch_ranges(c, it, ISING_BLACK, -(G - 1), c->cfg.Y + G - 1, 0, 0, nlevels);
 }
 

@@ -82,6 +82,13 @@ struct ising_ctx {
 	uint32_t *d_flags = nullptr;
 	uint32_t flag_target[2] = {0, 0};
 	int sync_mode = 0;
+	// deep exchange overlapped with the launches (ising_ring.cpp: sweep_deep_overlapped; UpdateParams.edge_go / edge_done)
+	uint32_t *d_edge = nullptr;                  // [0]: units of the launches' last levels that have left the exchange's rows (a count),
+	                                             // [16]: epoch of the last exchange that is complete for this slab (set by the comm stream)
+	uint32_t edge_done_target = 0;               // value of d_edge[0] once every launch issued so far has run
+	uint32_t edge_go_epoch = 0;                  // value d_edge[16] is (being) brought to
+	bool go_set = false;                         // ... and it stands for the exchange that delivered the current ghost rows
+	bool overlap_next = false;                   // one-shot request to launch_ranges: the next deep launch takes part in the overlap
 	bool store_ring = false;                     // ring on ONE device and one stream: every launch writes its edge rows straight into the
 	                                             // neighbouring slabs' halo rows (UpdateParams.mir0/mirL_bytes): no edge launch, no copies
 	bool copy_inline = false;                    // COPY transport, both neighbours on this slab's device: copies on the compute stream
@@ -146,8 +153,9 @@ int update_edges_on(ising_ctx *c, int it, int color, hipStream_t s, hipEvent_t s
 int update_interior(ising_ctx *c, int it, int color, hipEvent_t stop);
 // ballot layout: one launch over rows [0, Y) whose edge strips go first and publish rows 0 / Y-1 through d_signal[color]
 int update_full_published(ising_ctx *c, int it, int color);
-// ring slab with ghost rows: one fused launch of `nlevels` (even, <= ghost rows) colour half-sweeps, ghost rows included
-int update_deep(ising_ctx *c, int it, int nlevels);
+// ring slab with ghost rows: one fused launch of `nlevels` (even, <= ghost rows) colour half-sweeps, ghost rows included;
+// `overlapped`: its edge strips wait for / announce the exchange themselves (ising_ring.cpp: sweep_deep_overlapped)
+int update_deep(ising_ctx *c, int it, int nlevels, bool overlapped = false);
 // called by ising_destroy
 void ring_release(ising_ctx *c);
 

@@ -61,6 +61,19 @@ struct UpdateParams {
 	int32_t sync_row[2];
 	int32_t zigzag0;          // range 0's strips are numbered over [row_lo[0], row_hi[0]) and taken from both ends inwards; nreal0 says how many
 	int32_t total_rows;       // rows of the whole lattice when this launch covers ghost rows (their global row wraps around the ring); 0: off
+	// Ring slab with ghost rows, fused launch (ising_ring.cpp: sweep_deep).
+	// trapezoid: level L of a launch of nlevels only needs the rows within nlevels - 1 - L of the slab's own [0, Y) -- what lies
+	// further out could not reach a row of the slab any more -- so strips wholly outside that range do nothing at that level.
+	int32_t trapezoid;
+	// Exchange overlapped with the launches: units that touch a row outside [edge_lo, edge_hi) -- rows the exchange reads (the
+	// slab's first / last G rows) or writes (the ghost rows) -- wait at level 0 until *edge_go has reached edge_go_need (the comm
+	// stream sets it when this slab's rows have been sent and the neighbours' have arrived), and at the LAST level each adds 1
+	// per wave column to *edge_done once its rows are out: the comm stream waits for that count and starts the next exchange
+	// while the launch is still working on the slab's interior.  (edge_go NULL: off)
+	const uint32_t *edge_go;
+	uint32_t edge_go_need;
+	uint32_t *edge_done;
+	int32_t edge_lo, edge_hi;
 };
 
 // mode: 0 = integer thresholds via v_cmpx, 1 = generic FP32-table kernel, 2 = integer thresholds via the LDS rank table

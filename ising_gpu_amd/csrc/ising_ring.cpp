@@ -219,6 +219,26 @@ __global__ void __launch_bounds__(64) ipc_set_k(uint32_t *a, uint32_t va, uint32
 	}
 }
 
+// one lane waits until a counter in device memory has reached `need` (written by a running launch of another stream)
+__global__ void __launch_bounds__(64) counter_wait_k(const uint32_t *a, uint32_t need, const uint32_t *abort_flag) {
+	if (threadIdx.x == 0) {
+		for (unsigned n = 1;; ++n) {
+			const uint32_t va = __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if ((int32_t)(va - need) >= 0) break;
+			if (abort_flag && (n & 63u) == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;
+			__builtin_amdgcn_s_sleep(64);
+		}
+		__atomic_thread_fence(__ATOMIC_ACQUIRE);
+	}
+}
+
+__global__ void __launch_bounds__(64) counter_set_k(uint32_t *a, uint32_t v) {
+	if (threadIdx.x == 0) {
+		__atomic_thread_fence(__ATOMIC_RELEASE);
+		__hip_atomic_store(a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
+
 int ipc_wait_on(ising_ctx *c, hipStream_t s, const uint32_t *a, uint32_t na, const uint32_t *b, uint32_t nb) {
 	hipLaunchKernelGGL(ipc_wait_k, dim3(1), dim3(64), 0, s, a, na, b, nb, (const uint32_t *)c->ipc->mine_abort);
 	HIP_TRY(hipGetLastError());
@@ -243,11 +263,11 @@ int ipc_wait_plane(ising_ctx *c, int plane, hipStream_t s) {
 
 // Deep exchange: everything this slab's compute stream holds so far is done with the slab's ghost rows of `color` once the
 // stream gets here -- the neighbours may overwrite them with the next epoch.
-int ipc_release_ghosts(ising_ctx *c, int color) {
+int ipc_release_ghosts(ising_ctx *c, int color, hipStream_t s = nullptr) {
 	ising_ipc *ipc = c->ipc;
 	const uint32_t fe = ++ipc->free_epoch[color];
 	// in the PREVIOUS rank's segment I am its next neighbour, in the next rank's its previous one
-	return ipc_set_on(c->stream, ipc->nb_flags[0] + ipc_flag(color, F_FREE_NEXT), fe, ipc->nb_flags[1] + ipc_flag(color, F_FREE_PREV), fe);
+	return ipc_set_on(s ? s : c->stream, ipc->nb_flags[0] + ipc_flag(color, F_FREE_NEXT), fe, ipc->nb_flags[1] + ipc_flag(color, F_FREE_PREV), fe);
 }
 
 void ipc_unmap(ising_ctx *c) {
@@ -327,6 +347,12 @@ int ring_resources(ising_ctx *c) {
 		HIP_TRY(hipMalloc((void **)&c->d_flags, 2 * sizeof(uint32_t)));
 		HIP_TRY(hipMemset(c->d_flags, 0, 2 * sizeof(uint32_t)));
 		c->flag_target[0] = c->flag_target[1] = 0;
+	}
+	if (c->ballot && c->ghost() > 1 && !c->d_edge) { // deep exchange overlapped with the launches: two counters, a line apart
+		HIP_TRY(hipMalloc((void **)&c->d_edge, 32 * sizeof(uint32_t)));
+		HIP_TRY(hipMemset(c->d_edge, 0, 32 * sizeof(uint32_t)));
+		c->edge_done_target = c->edge_go_epoch = 0;
+		c->go_set = false;
 	}
 	for (int k = 0; k < 2; k++) {
 		if (!c->ev_edge[k]) HIP_TRY(hipEventCreateWithFlags(&c->ev_edge[k], hipEventDisableTiming));
@@ -493,7 +519,7 @@ EdgeRows edge_rows(const ising_ctx *c, int color, int depth = 1) {
 int transfer(ising_ctx **ctxs, int n, int color, bool after_edges, int depth = 1) {
 	if (ctxs[0]->cfg.XSL) return ISING_OK; // sub-lattices never reach across slabs
 	const bool spin = color != ISING_HAM_BLACK;
-	if (spin) for (int k = 0; k < n; k++) ctxs[k]->ghost_depth[color] = depth;
+	if (spin) for (int k = 0; k < n; k++) { ctxs[k]->ghost_depth[color] = depth; ctxs[k]->go_set = false; }
 	// Copies between slabs of ONE device go on the slab's compute stream: a second stream buys nothing there (the copy
 	// needs the same CUs / DMA engines the kernels hold) and every cross-stream event on a shared device is a bubble.
 	auto lane = [](const ising_ctx *c) { return c->copy_inline ? c->stream : c->comm; };
@@ -768,11 +794,86 @@ int sweep_deep(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 	return ISING_OK;
 }
 
+// The comm stream of slab c, behind the transfers of the exchange that delivered the current ghost rows: wait until the
+// neighbours' rows are in place as well (RCCL: the receives are this stream's own; IPC: the neighbours' counters; copies:
+// their events), then move the slab's edge_go counter -- the edge strips of the next launch poll it (UpdateParams.edge_go).
+int post_go(ising_ctx *c) {
+	if (int rc = bind(c)) return rc;
+	if (c->transport == ISING_TRANSPORT_IPC) {
+		for (int color = 0; color < 2; color++) if (int rc = ipc_wait_plane(c, color, c->comm)) return rc;
+	} else if (c->transport == ISING_TRANSPORT_COPY) {
+		ising_ctx *prev = c->ring_prev, *next = c->ring_next;
+		for (int color = 0; color < 2; color++) {
+			if (prev && prev != c) HIP_TRY(hipStreamWaitEvent(c->comm, prev->ev_sent[color], 0));
+			if (next && next != c && next != prev) HIP_TRY(hipStreamWaitEvent(c->comm, next->ev_sent[color], 0));
+		}
+	}
+	c->edge_go_epoch++;
+	hipLaunchKernelGGL(counter_set_k, dim3(1), dim3(64), 0, c->comm, c->d_edge + 16, c->edge_go_epoch);
+	HIP_TRY(hipGetLastError());
+	c->go_set = true;
+	return ISING_OK;
+}
+
+// sweep_deep with the exchange taken off the compute streams (north_star: "overlapped with interior updates on a second HIP
+// stream"; the reference synchronises every device after every colour, optimized/main.cu:1779-1805).  The fused launches
+// follow each other on the compute stream with nothing in between; the comm stream learns from a counter when the edge
+// strips of a launch have finished their LAST level (they are each level's first tickets, so that is a level before the
+// launch ends), exchanges while the launch works on the interior, and moves a second counter that the next launch's edge
+// strips poll at level 0 -- normally long since set.
+//
+//   compute stream                                   comm stream
+//   launch e   (edge strips, last level: +1 each)      wait: edge_done == all edge strips of launch e
+//   launch e+1 (edge strips, level 0: poll edge_go)    [IPC: tell the neighbours their pushes may come; wait for their word]
+//   ...                                                first / last G rows of both colours -> neighbours   (record ev_sent)
+//                                                      wait: the neighbours' rows are here; edge_go = e + 1
+int sweep_deep_overlapped(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
+	const int G = ctxs[0]->ghost();
+	bool current = true;
+	for (int k = 0; k < n; k++) current = current && ctxs[k]->ghost_depth[0] >= G && ctxs[k]->ghost_depth[1] >= G;
+	if (!current)
+		for (int color = 0; color < 2; color++) if (int rc = exchange_rows(ctxs, n, color, G)) return rc;
+	for (int k = 0; k < n; k++) if (!ctxs[k]->go_set) if (int rc = post_go(ctxs[k])) return rc;
+	const bool copies = ctxs[0]->transport == ISING_TRANSPORT_COPY, ipc = ctxs[0]->transport == ISING_TRANSPORT_IPC;
+	for (int it = first_it, left = nsweeps; left > 0;) {
+		const int ns = std::min(left, G / 2);
+		for (int k = 0; k < n; k++) if (int rc = ising_host::update_deep(ctxs[k], it, 2 * ns, true)) return rc;
+		for (int k = 0; k < n; k++) {
+			ising_ctx *c = ctxs[k];
+			if (int rc = bind(c)) return rc;
+			hipLaunchKernelGGL(counter_wait_k, dim3(1), dim3(64), 0, c->comm, (const uint32_t *)c->d_edge, c->edge_done_target,
+			                   (const uint32_t *)(c->ipc ? c->ipc->mine_abort : nullptr));
+			HIP_TRY(hipGetLastError());
+			// this slab's launches are done with its ghost rows: the neighbours may overwrite them
+			if (ipc) for (int color = 0; color < 2; color++) if (int rc = ipc_release_ghosts(c, color, c->comm)) return rc;
+			if (copies) HIP_TRY(hipEventRecord(c->ev_int[0], c->comm));
+		}
+		if (copies) {
+			for (int k = 0; k < n; k++) {
+				ising_ctx *c = ctxs[k], *prev = c->ring_prev, *next = c->ring_next;
+				if (int rc = bind(c)) return rc;
+				if (prev && prev != c) HIP_TRY(hipStreamWaitEvent(c->comm, prev->ev_int[0], 0));
+				if (next && next != c && next != prev) HIP_TRY(hipStreamWaitEvent(c->comm, next->ev_int[0], 0));
+			}
+		}
+		for (int color = 0; color < 2; color++) if (int rc = transfer(ctxs, n, color, false, G)) return rc;
+		for (int k = 0; k < n; k++) if (int rc = post_go(ctxs[k])) return rc;
+		it += ns;
+		left -= ns;
+	}
+	return ISING_OK;
+}
+
 int sweep_local(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 	if (int rc = settle_layout(ctxs, n)) return rc;
 	{
 		bool deep = nsweeps > 0 && !ctxs[0]->store_ring && !ctxs[0]->cfg.XSL && ctxs[0]->ghost() > 1;
 		for (int k = 0; k < n; k++) deep = deep && ctxs[k]->ballot && ctxs[k]->ghost() == ctxs[0]->ghost() && !ising_host::needs_generic(ctxs[k]) && !ctxs[k]->store_ring;
+		// the exchange overlaps with the launches where the rows travel on the slabs' comm streams (ISING_RING_OVERLAP=0: between launches)
+		static const bool overlap_on = !(getenv("ISING_RING_OVERLAP") && atoi(getenv("ISING_RING_OVERLAP")) == 0);
+		bool overlap = deep && overlap_on;
+		for (int k = 0; k < n; k++) overlap = overlap && !ctxs[k]->copy_inline && ctxs[k]->d_edge && ctxs[k]->comm;
+		if (overlap) return sweep_deep_overlapped(ctxs, n, first_it, nsweeps);
 		if (deep) return sweep_deep(ctxs, n, first_it, nsweeps);
 	}
 	if (ctxs[0]->store_ring && !ctxs[0]->cfg.XSL) { // one launch per slab and colour; the stream orders the rest

@@ -92,3 +92,64 @@ def test_cli_sublattices_transcript(gpu):
     assert "\t\tno. of sub-lattices (total):     1024\n" in out
     assert "\t\tsub-lattices size:              2048 x    2048\n" in out
     assert "        magnetization:  0.000052, up_s:   2147594634, dw_s:   2147372662 (iter:       16)\n" in out  # README.md:188
+
+
+# ---- the reference's multi-GPU transcripts, every magnetisation line (optimized/README.md:240-249 and :307-316) -----------
+README_2GPU = [  # ./cuIsing -y 65536 -x 65536 -n 128 -p 16 -d 2 -t 1.5   (2 x A100, README.md:205-252; 2 x H100 :327-370)
+    "Initial magnetization:  0.000005, up_s:   4294989182, dw_s:   4294945410\n",
+    "        magnetization:  0.000082, up_s:   4294617248, dw_s:   4295317344 (iter:       16)\n",
+    "        magnetization:  0.000249, up_s:   4293898346, dw_s:   4296036246 (iter:       32)\n",
+    "        magnetization:  0.000503, up_s:   4292806461, dw_s:   4297128131 (iter:       48)\n",
+    "        magnetization:  0.000725, up_s:   4291852263, dw_s:   4298082329 (iter:       64)\n",
+    "        magnetization:  0.000904, up_s:   4291086016, dw_s:   4298848576 (iter:       80)\n",
+    "        magnetization:  0.001097, up_s:   4290256223, dw_s:   4299678369 (iter:       96)\n",
+    "        magnetization:  0.001245, up_s:   4289621029, dw_s:   4300313563 (iter:      112)\n",
+    "        magnetization:  0.001418, up_s:   4288877118, dw_s:   4301057474 (iter:      128)\n",
+    "Final   magnetization:  0.001418, up_s:   4288877118, dw_s:   4301057474 (iter:      128)\n",
+]
+README_8GPU = [  # ./cuIsing -y 65536 -x 65536 -n 128 -p 16 -d 8 -t 1.5   (8 x A100, README.md:255-319; 8 x H100 :375-436)
+    "Initial magnetization:  0.000010, up_s:  17179689306, dw_s:  17180049062\n",
+    "        magnetization:  0.000203, up_s:  17176389528, dw_s:  17183348840 (iter:       16)\n",
+    "        magnetization:  0.000402, up_s:  17172963073, dw_s:  17186775295 (iter:       32)\n",
+    "        magnetization:  0.000539, up_s:  17170610910, dw_s:  17189127458 (iter:       48)\n",
+    "        magnetization:  0.000642, up_s:  17168843228, dw_s:  17190895140 (iter:       64)\n",
+    "        magnetization:  0.000749, up_s:  17167009008, dw_s:  17192729360 (iter:       80)\n",
+    "        magnetization:  0.000865, up_s:  17165014291, dw_s:  17194724077 (iter:       96)\n",
+    "        magnetization:  0.000941, up_s:  17163708078, dw_s:  17196030290 (iter:      112)\n",
+    "        magnetization:  0.001023, up_s:  17162287230, dw_s:  17197451138 (iter:      128)\n",
+    "Final   magnetization:  0.001023, up_s:  17162287230, dw_s:  17197451138 (iter:      128)\n",
+]
+
+
+def test_readme_two_gpu_transcript_every_line_at_its_own_decomposition(gpu):
+    """README.md:205-252 at the reference's own decomposition: 2 slabs of 65536 x 65536 (both on device 0; one MI355X holds
+    the whole 131072 x 65536 lattice).  All nine magnetisation lines and the final one, character for character."""
+    out = run(["-y", "65536", "-x", "65536", "-n", "128", "-p", "16", "-d", "2", "-t", "1.5", "--devmap", "0,0"])
+    for line in README_2GPU + ["\tspins: 8589934592\n", "\tgrid  (X, Y): 32, 4096\n", "\tlocal lattice size:         65536 x    65536\n",
+                               "\ttotal lattice size:        131072 x    65536\n", "\tlocal lattice shape: 2 x    65536 x     2048 (   268435456 ulls)\n",
+                               "\ttotal lattice shape: 2 x   131072 x     2048 (   536870912 ulls)\n", "\tmemory: 4096.00 MB (2048.00 MB per GPU)\n",
+                               "Setting up multi-gpu configuration:\n", "\tGPU  0 done\n", "\tGPU  1 done\n"]:
+        assert line in out, line
+
+
+def test_readme_two_gpu_transcript_as_one_slab(gpu):
+    """The same lattice as ONE slab of 131072 rows (fused launches, no ring): the counts do not depend on the decomposition."""
+    out = run(["-y", "131072", "-x", "65536", "-n", "128", "-p", "16", "-t", "1.5"])
+    for line in README_2GPU:
+        assert line in out, line
+
+
+def test_readme_eight_gpu_transcript_every_line_at_its_own_decomposition(gpu):
+    """README.md:255-319: 8 slabs of 65536 x 65536 = 2^35 spins (4 GiB at 1 bit per spin: all eight slabs on device 0), 128
+    sweeps, printed every 16: all nine magnetisation lines and the final one, character for character."""
+    out = run(["-y", "65536", "-x", "65536", "-n", "128", "-p", "16", "-d", "8", "-t", "1.5", "--devmap", "0,0,0,0,0,0,0,0"])
+    for line in README_8GPU + ["\tspins: 34359738368\n", "\ttotal lattice size:        524288 x    65536\n",
+                               "\ttotal lattice shape: 2 x   524288 x     2048 (  2147483648 ulls)\n", "\tmemory: 16384.00 MB (2048.00 MB per GPU)\n",
+                               "\tGPU  7 done\n"]:
+        assert line in out, line
+
+
+def test_readme_eight_gpu_transcript_as_one_slab(gpu):
+    out = run(["-y", "524288", "-x", "65536", "-n", "128", "-p", "16", "-t", "1.5"])
+    for line in README_8GPU:
+        assert line in out, line
