@@ -483,6 +483,12 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			}
 		}
 
+		// Global row and Philox stream id of the row the draw phase handles next, advanced by hand: consecutive rows are 16
+		// stream ids apart, a new block row of 16 starts gx * 256 further on, and a ghost row range may run around the ring
+		// once.  (Recomputed from the row number every iteration -- which the wrap forces on the compiler -- the id costs
+		// five vector instructions per row: ring slabs ran 0.45 % behind a lone slab for that alone.)
+		uint32_t grow_d = global_row(r0), grow_w = grow_d; // grow_w: the row of the word phase (one behind)
+		uint32_t tid_d = ((grow_d >> 4) * (uint32_t)p.gx + (uint32_t)bx) * 256u + (grow_d & 15u) * 16u + (uint32_t)tx;
 		// one scalar-cache write-back per workgroup and row: every wave runs the same number of iterations and meets at a barrier
 		const int rmax = Hr;
 		const bool wb_wave = threadIdx.x < 64;
@@ -506,8 +512,9 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			// `ct` registers, C is a coherent vector load of one word.
 			unsigned long long sA0 = 0, sA1 = 0, sC = 0;
 			uint64_t vC = 0;
+			const uint32_t grow_p = grow_w; // global row of row r0 + r - 1, this iteration's word phase (the draw phase below moves grow_w on)
 			if (r > 0 && r <= nrows) {
-				const uint32_t grow = global_row(r0 + r - 1);
+				const uint32_t grow = grow_p;
 				const bool back = (color == 0) ? !(grow & 1u) : (grow & 1u);
 				const uint64_t *qc = rs + (back ? u_cb : u_cf);
 				if (FUSED) {
@@ -522,9 +529,17 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			TRC(3); // row prologue
 			if (r < nrows) {
 				// ---- draw phase, row r0 + r
-				const uint32_t grow = global_row(r0 + r);
-				const uint32_t tid = ((grow >> 4) * (uint32_t)p.gx + (uint32_t)bx) * 256u + (grow & 15u) * 16u + (uint32_t)tx;
-				const PhiloxRow pr = philox_row_setup(tid, seed_lo_cy, k2y);
+				const PhiloxRow pr = philox_row_setup(tid_d, seed_lo_cy, k2y);
+				{
+					uint32_t inc = (grow_d & 15u) == 15u ? (uint32_t)p.gx * 256u - 240u : 16u, g1 = grow_d + 1u;
+					if (p.total_rows && g1 == (uint32_t)p.total_rows) { // around the ring: row 0 follows the lattice's last row
+						g1 = 0u;
+						inc -= ((uint32_t)p.total_rows >> 4) * (uint32_t)p.gx * 256u;
+					}
+					grow_w = grow_d;
+					grow_d = g1;
+					tid_d += inc;
+				}
 				uint64_t *cur = slot + (r & 1) * 128;
 				uint4 kc_next = blk_const[0];
 				static_for<16>([&](auto B) {
@@ -566,7 +581,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				// ---- word phase, row r0 + r - 1; its masks were written back during the draw phase above
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 				const int lr = r0 + r - 1;
-				const uint32_t grow = global_row(lr);
+				const uint32_t grow = grow_p;
 				const bool back = (color == 0) ? !(grow & 1u) : (grow & 1u); // readBack, optimized/main.cu:542
 				// this lane's two accept masks: 16 bytes at slot + 16 lane, past the (non-coherent) vector L1
 				const uint64_t *msk = slot + ((r - 1) & 1) * 128;

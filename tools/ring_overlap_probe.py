@@ -22,12 +22,13 @@ if mode == "all":
             ("ring of one, RCCL, exchange between launches + trapezoid", "rccl", {"ISING_RING_OVERLAP": "0"}),
             ("ring of one, RCCL, round 2's schedule", "rccl", {"ISING_RING_OVERLAP": "0", "ISING_RING_TRAPEZOID": "0"}),
             ("ring of one, IPC peer transport, overlapped + trapezoid", "ipc", {}),
-            ("ring of one, IPC peer transport, round 2's schedule", "ipc", {"ISING_RING_OVERLAP": "0", "ISING_RING_TRAPEZOID": "0"})]
+            ("ring of one, IPC peer transport, round 2's schedule", "ipc", {"ISING_RING_OVERLAP": "0", "ISING_RING_TRAPEZOID": "0"}),
+            ("single slab, fused launches (again: drift of the box over the table)", "single", {})]
     base = None
     for name, m, env in rows:
         r = subprocess.run([sys.executable, __file__, m, str(X), str(Y), str(sweeps)], env=dict(os.environ, **env), capture_output=True, text=True)
         try:
-            v = float(r.stdout.strip().splitlines()[-1])
+            v = float([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1].split()[1])
         except (ValueError, IndexError):
             print(f"{name}: FAILED {r.stderr[-400:]}")
             continue
@@ -56,9 +57,10 @@ def timed(fn, sync):
 if mode == "single":
     with ig.IsingSlab(X, Y, seed=1, temp=ig.CRIT_TEMP_F32) as s:
         s.init()
-        print(timed(lambda k: s.sweep(k), s.synchronize))
+        print("RESULT", timed(lambda k: s.sweep(k), s.synchronize))
 else:
     with ig.IsingSlab(X, Y, seed=1, temp=ig.CRIT_TEMP_F32, ring_halo=True) as s:
         ring = ig.NativeRing(s, transport=mode).init()
-        print(timed(lambda k: ring.sweep(k), ring.quiesce))
+        v = timed(lambda k: ring.sweep(k), ring.quiesce)
         ring.close()
+        print("RESULT", v)
