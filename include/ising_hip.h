@@ -308,6 +308,25 @@ int ising_rank_wait(ising_ctx *ctx, int timeout_ms);
 int ising_rank_count(ising_ctx *ctx, uint64_t *up, uint64_t *down);
 int ising_rank_bond_equal(ising_ctx *ctx, int64_t *A);
 
+/* ---- a batch of independent lattices advancing together (the temperature-sweep driver; BASELINE config 5).  The
+ * reference runs one lattice per process and temperature (optimized/main.cu:1596-1598, :1465-1471).  Contexts of one shape
+ * (nslabs == 1, ballot layout -- ISING_LAYOUT_BALLOT or what AUTO picked --, no sub-lattices, no couplings) on one device and
+ * one stream form a batch: ising_batch_sweep advances ALL of them by `nsweeps` sweeps (iterations first_it ..
+ * first_it + nsweeps - 1, each lattice with its own seed and its own temperature as of ising_set_temperature) in fused
+ * launches whose levels hold the tickets of every lattice, so that lattices too small to fill the chip with tall strips
+ * (8192^2: 2766 flips/ns alone) run at the large-lattice rate; ising_batch_measure_enqueue adds ONE launch that takes the
+ * up count and the bond sum (ising_count, ising_bond_equal) of every member.  Each member's spins are bit for bit what
+ * ising_sweep on that context gives, and the members stay ordinary contexts (init, read, sweep them alone in between: same
+ * stream).  Asynchronous like ising_sweep; the fetch blocks. */
+typedef struct ising_batch ising_batch;
+int ising_batch_create(ising_ctx **ctxs, int n, ising_batch **out);
+int ising_batch_destroy(ising_batch *b);
+int ising_batch_info(ising_batch *b, int *strip_rows, int *wg_per_cu, int *lattices); /* launch shape chosen for the batch */
+int ising_batch_sweep(ising_batch *b, int first_it, int nsweeps);
+int ising_batch_measure_enqueue(ising_batch *b);
+/* up[k * lattices + r], bond_equal[...]: measurement k (enqueue order) of member r; at most 4096 measurements may be pending */
+int ising_batch_measure_fetch(ising_batch *b, uint64_t *up, int64_t *bond_equal, int max_n, int *n);
+
 /* -- one process per slab WITHOUT RCCL: direct peer access, the reference's own multi-GPU mechanism
  * (cudaDeviceCanAccessPeer / cudaDeviceEnablePeerAccess, optimized/main.cu:1496-1537; remote loads of the two rows outside
  * each slab, :1637-1642, loadTile :413-428), across processes.  Every rank exports a description of its slab's buffers

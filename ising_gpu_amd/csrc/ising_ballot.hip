@@ -183,8 +183,10 @@ __device__ unsigned long long g_hist[32];
 #else
 #define BAL_SGPR_ATTR
 #endif
-template <bool SUBL, bool USEJ, bool FUSED, int NT = BAL_THREADS, bool STREAM = false>
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+template <bool SUBL, bool USEJ, bool FUSED, int NT = BAL_THREADS, bool STREAM = false, bool BATCH = false>
 __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const UpdateParams p) {
+	static_assert(!BATCH || (FUSED && !SUBL && !USEJ), "batched launches: fused, no sub-lattices, no couplings");
 	const int lane = threadIdx.x & 63;
 	const int tx = threadIdx.x & (GROUP - 1), g = (threadIdx.x >> 4) & 3;
 	const int wi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -236,7 +238,6 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	__shared__ unsigned long long ticket_sh[2];
 	uint4 *blk_const = blk_const_all[wi];
 	const unsigned long long total = (unsigned long long)p.nlevels * (unsigned long long)p.nwg;
-	const uint32_t k2y = p.seed_hi + 2u * PHILOX_W1;
 
 #if defined(ISING_FUSED_TRACE)
 	__shared__ unsigned long long tr[16];
@@ -325,7 +326,23 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				++level;
 			}
 		}
-		const int wave = uni((int)(tk - level_base) * (NT / 64) + wi);
+		// batched launch: which lattice this unit belongs to, and that lattice's record (scalar cache: invalidated at kernel start)
+		int wgi = (int)(tk - level_base), rep = 0;
+		u32x8 rb = {0, 0, 0, 0, 0, 0, 0, 0};
+		if (BATCH) {
+			int q = (int)__umulhi((uint32_t)wgi, p.rep_magic);
+			if (q * p.nwg_rep > wgi) --q; // (the reciprocal rounds up: at most one too many)
+			rep = uni(q);                 // (pinned to the scalar unit: the compiler takes the running level count for lane-dependent)
+			wgi = uni(wgi - rep * p.nwg_rep);
+			const uintptr_t ra = reinterpret_cast<uintptr_t>(p.rep + rep);
+			const ReplicaParams *rp = reinterpret_cast<const ReplicaParams *>(((uintptr_t)uni((uint32_t)(ra >> 32)) << 32) | uni((uint32_t)ra));
+			asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rb) : "s"(rp) : "memory");
+		}
+		// (not const: a const integer is not captured by the generic lambda of the draw phase)
+		uint32_t seed_lo = BATCH ? rb[6] : p.seed_lo, seed_hi = BATCH ? rb[7] : p.seed_hi;
+		uint32_t thr3 = BATCH ? rb[4] : p.n3, thr4 = BATCH ? rb[5] : p.n4;
+		const uint32_t k2y = seed_hi + 2u * PHILOX_W1;
+		const int wave = uni(wgi * (NT / 64) + wi);
 		const int unit0 = wave * 4; // a wave covers 4 consecutive 32-vector column groups of one strip (gx % 4 == 0)
 		// Two row ranges per launch: the two edge rows of a ring slab, or (tail strips) the bulk of the slab in strips of H
 		// rows followed by its last rows in strips of H2 < H rows -- the hardware dispatches workgroups in index order, so
@@ -364,8 +381,10 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		const bool publish = synced || (!FUSED && p.sync_wait == nullptr && p.edge_signal != nullptr && !idle && rng == 0 && (r0 == 0 || r0 + nrows == p.Y));
 		const uint32_t color = FUSED ? uni((p.color + (uint32_t)level) & 1u) : p.color;
 		const uint32_t it = FUSED ? uni(p.it + ((p.color + (uint32_t)level) >> 1)) : p.it;
-		const uint64_t *src = FUSED ? (color ? p.lat[0] : p.lat[1]) : p.src;
-		uint64_t *dst = FUSED ? (color ? p.lat[1] : p.lat[0]) : p.dst;
+		uint64_t *const lat0 = BATCH ? reinterpret_cast<uint64_t *>(((uintptr_t)rb[1] << 32) | rb[0]) : p.lat[0];
+		uint64_t *const lat1 = BATCH ? reinterpret_cast<uint64_t *>(((uintptr_t)rb[3] << 32) | rb[2]) : p.lat[1];
+		const uint64_t *src = FUSED ? (color ? lat0 : lat1) : p.src;
+		uint64_t *dst = FUSED ? (color ? lat1 : lat0) : p.dst;
 
 		uint64_t first = 0, last = 0;                    // bit 16g (16g + 15): group g opens (closes) a period
 #pragma unroll
@@ -396,7 +415,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		const uint64_t *rj = USEJ ? (FUSED ? (color ? p.jham[1] : p.jham[0]) : p.jdst) + 4 * ((ptrdiff_t)r0 * wpr + wc * 64) : nullptr;
 
 		const uint32_t cx_base = 16u * (2u * it + color);
-		const uint32_t seed_lo_cy = p.seed_lo ^ (uint32_t)((2ull * it + color) >> 28); // see dense_update_k
+		const uint32_t seed_lo_cy = seed_lo ^ (uint32_t)((2ull * it + color) >> 28); // see dense_update_k
 
 		// FUSED: wait until strips s-1, s, s+1 (periodic) have completed level - 1, `nwc` wave columns each per level.  The
 		// first look at their counters travels while the block constants are made.
@@ -408,13 +427,13 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		if (must_wait) {
 			int sd = sidx + (lane == 0 ? -1 : (lane == 1 ? 0 : 1));
 			sd = sd < 0 ? sd + nstr : (sd >= nstr ? sd - nstr : sd);
-			dp = p.done + sd;
+			dp = p.done + (BATCH ? rep * p.done_stride : 0) + sd;
 			// (inline assembly like the row loop's loads: a tracked load here makes the compiler guard `seen`'s register with
 			// vmcnt(0) waits all through the row loop)
 			if (lane < 3) asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(seen) : "v"(dp) : "memory");
 		}
 		if (lane < 16) {
-			const PhiloxBlockConst kc = philox_block_const(cx_base + (uint32_t)lane, p.seed_lo, p.seed_hi);
+			const PhiloxBlockConst kc = philox_block_const(cx_base + (uint32_t)lane, seed_lo, seed_hi);
 			blk_const[lane] = make_uint4(kc.s0, kc.s1, kc.s2, 0u);
 		}
 		if (must_wait) {
@@ -548,19 +567,20 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 					// this block's scalar stores go out (LDS and scalar memory share one counter)
 					const uint4 kc = kc_next;
 					if (B.value < 15) kc_next = blk_const[B.value + 1];
-					philox_block_pre(pr, PhiloxBlockConst{kc.x, kc.y, kc.z}, p.seed_lo, p.seed_hi, o0, o1, o2, o3);
+					philox_block_pre(pr, PhiloxBlockConst{kc.x, kc.y, kc.z}, seed_lo, seed_hi, o0, o1, o2, o3);
 					if (B.value < 15) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kc_next.x), "+v"(kc_next.y), "+v"(kc_next.z) :: "memory");
 					// (c3, c4) of one output = four consecutive SGPRs = one 16-byte scalar store: word p = 4B + q of the slot.
 					// Fixed registers: inline asm cannot name halves of an SGPR tuple operand.  (Eight 8-byte stores from
 					// compiler-allocated pairs: -6 %.)
 					const uint64_t *dstp = cur + 8 * B.value;
+					const uint32_t t3 = thr3, t4 = thr4; // (named here: asm operands alone do not make the lambda capture them)
 					asm volatile("v_cmp_gt_u32_e64 " SG(0, 1) ", %0, %2\n\tv_cmp_gt_u32_e64 " SG(2, 3) ", %1, %2\n\t"
 					             "v_cmp_gt_u32_e64 " SG(4, 5) ", %0, %3\n\tv_cmp_gt_u32_e64 " SG(6, 7) ", %1, %3\n\t"
 					             "v_cmp_gt_u32_e64 " SG(8, 9) ", %0, %4\n\tv_cmp_gt_u32_e64 " SG(10, 11) ", %1, %4\n\t"
 					             "v_cmp_gt_u32_e64 " SG(12, 13) ", %0, %5\n\tv_cmp_gt_u32_e64 " SG(14, 15) ", %1, %5\n\t"
 					             "s_store_dwordx4 " SG(0, 3) ", %6, 0x0\n\ts_store_dwordx4 " SG(4, 7) ", %6, 0x10\n\t"
 					             "s_store_dwordx4 " SG(8, 11) ", %6, 0x20\n\ts_store_dwordx4 " SG(12, 15) ", %6, 0x30"
-					             :: "s"(p.n3), "s"(p.n4), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(dstp)
+					             :: "s"(t3), "s"(t4), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(dstp)
 					             : "memory", BAL_CLOB16);
 				});
 			}
@@ -696,7 +716,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				if ((te - t_unit1) / (16384ll * p.H / 8) >= 12) tr[10 + min(3u, blockIdx.x >> 8)] += 1; // long units by dispatch round (3: fourth and later)
 			}
 #endif
-			if (lane == 0) __hip_atomic_fetch_add(p.done + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (lane == 0) __hip_atomic_fetch_add(p.done + (BATCH ? rep * p.done_stride : 0) + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			// last level: the rows the next exchange sends are final and the ghost rows no longer read
 			if (edge_unit && level == p.nlevels - 1 && lane == 0) __hip_atomic_fetch_add(p.edge_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
@@ -768,6 +788,97 @@ __global__ void __launch_bounds__(THREADS) ballot_init_k(const InitParams p) {
 		}
 	});
 	asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// ---- observables on the ballot layout itself, for a batch of lattices in ONE launch (ising_batch_measure_enqueue): up spins
+// (countSpins, optimized/main.cu:831-868) and A = number of (black site, white neighbour) pairs with equal spins
+// (ising_bond_equal) of every lattice of the batch.  One wave per (lattice, strip of R rows, wave column); lane p owns word p
+// of a row and meets its four neighbour words exactly as the update kernel's word phase does (above / same index / below
+// from memory, the side word from another lane, the two row-end words put together from three wave-uniform words); then
+// 4 x 64 bonds are one XOR + popcount each.  Rows -1 and Y of the white array must mirror rows Y-1 and 0 (single slabs).
+__global__ void __launch_bounds__(THREADS) ballot_measure_k(const ReplicaParams *__restrict__ reps, int nrep, int gx, int Y, int R, unsigned long long *__restrict__ acc) {
+	const int lane = threadIdx.x & 63;
+	const int nwc = (gx + 3) >> 2;
+	const ptrdiff_t wpr = (ptrdiff_t)nwc * 64;
+	const int strips = (Y + R - 1) / R;
+	const long long per_rep = (long long)strips * nwc;
+	const long long wave_ll = flat_block() * (THREADS / 64) + (threadIdx.x >> 6);
+	if (wave_ll >= per_rep * nrep) return;
+	const int rep = uni((int)(wave_ll / per_rep));
+	const int u = uni((int)(wave_ll - (long long)rep * per_rep));
+	const int strip = u / nwc, wc = u - strip * nwc;
+	const uint64_t *black = reps[rep].lat[0], *white = reps[rep].lat[1];
+	// lane geometry of the word phase (ballot_update_k)
+	const int j = lane >> 5, m = (lane >> 2) & 7, q = lane & 3;
+	int backA, fwdA;
+	if (q == 2) backA = word_of(j, m, 0);
+	else if (q == 3) backA = word_of(j, m, 1);
+	else if (q == 0) backA = m ? word_of(j, m - 1, 2) : word_of(j, 7, 3);
+	else backA = m ? word_of(j, m - 1, 3) : word_of(j, 7, 2);
+	if (q == 0) fwdA = word_of(j, m, 2);
+	else if (q == 1) fwdA = word_of(j, m, 3);
+	else if (q == 2) fwdA = m < 7 ? word_of(j, m + 1, 0) : word_of(j, 0, 1);
+	else fwdA = m < 7 ? word_of(j, m + 1, 1) : word_of(j, 0, 0);
+	const int bx0 = 4 * wc;
+	uint64_t first = 0, last = 0;
+#pragma unroll
+	for (int gg = 0; gg < 4; ++gg) {
+		if (bx0 + gg == 0) first |= 1ull << (16 * gg);
+		if (bx0 + gg == gx - 1) last |= 1ull << (16 * gg + 15);
+	}
+	const uint64_t u_b1 = LANE0 & ~1ull & ~first, u_f1 = LANE15 & ~(1ull << 63) & ~last;
+	const int alive = min(4, gx - bx0);
+	const uint64_t live = alive >= 4 ? ~0ull : ((1ull << (16 * alive)) - 1ull);
+	const int end_here = 16 * alive - 1;
+	const int src_b = wc ? wc - 1 : nwc - 1;
+	const int end_src = 16 * min(4, gx - 4 * src_b) - 1;
+	const int u_cb = (src_b - wc) * 64 + word_of(1, 7, 3);
+	const int u_cf = ((wc == nwc - 1 ? 0 : wc + 1) - wc) * 64 + word_of(0, 0, 0);
+
+	const int r0 = strip * R, nrows = min(R, Y - r0);
+	const uint64_t *rw = white + ((ptrdiff_t)r0 * wpr + wc * 64), *rb = black + ((ptrdiff_t)r0 * wpr + wc * 64);
+	uint64_t up = rw[lane - wpr], ct = rw[lane];
+	unsigned long long n_up = 0, n_eq = 0;
+	for (int i = 0; i < nrows; ++i) {
+		const bool back = !((r0 + i) & 1); // black sites of even rows have their side neighbour one white site back (readBack, optimized/main.cu:542)
+		const uint64_t dw = rw[lane + wpr], me = rb[lane];
+		const uint64_t vC = rw[back ? u_cb : u_cf]; // (one word, the same for every lane)
+		const uint64_t sA0 = readlane64(ct, back ? word_of(0, 7, 3) : word_of(0, 0, 0));
+		const uint64_t sA1 = readlane64(ct, back ? word_of(1, 7, 3) : word_of(1, 0, 0));
+		const uint64_t sC = readlane64(vC, 0);
+		uint64_t w0, w1;
+		if (back) {
+			w0 = ((sA0 << 1) & ~LANE0) | ((sA1 << 1) & u_b1) | ((sC >> end_src) & 1ull);
+			w1 = ((sA1 << 1) & ~LANE0) | ((sA0 >> 15) & LANE0);
+		} else {
+			w0 = ((sA0 >> 1) & ~LANE15) | ((sA1 << 15) & LANE15);
+			w1 = ((sA1 >> 1) & ~LANE15) | ((sA0 >> 1) & u_f1) | ((sC & 1ull) << end_here);
+		}
+		const uint64_t A = bperm64(back ? backA : fwdA, ct);
+		uint32_t sdl = (uint32_t)A, sdh = (uint32_t)(A >> 32);
+		const uint32_t w0l = __builtin_amdgcn_readfirstlane((uint32_t)w0), w0h = __builtin_amdgcn_readfirstlane((uint32_t)(w0 >> 32));
+		const uint32_t w1l = __builtin_amdgcn_readfirstlane((uint32_t)w1), w1h = __builtin_amdgcn_readfirstlane((uint32_t)(w1 >> 32));
+		if (back) {
+			asm("v_writelane_b32 %0, %2, 0\n\tv_writelane_b32 %1, %3, 0" : "+v"(sdl), "+v"(sdh) : "s"(w0l), "s"(w0h));
+			asm("v_writelane_b32 %0, %2, 32\n\tv_writelane_b32 %1, %3, 32" : "+v"(sdl), "+v"(sdh) : "s"(w1l), "s"(w1h));
+		} else {
+			asm("v_writelane_b32 %0, %2, 31\n\tv_writelane_b32 %1, %3, 31" : "+v"(sdl), "+v"(sdh) : "s"(w0l), "s"(w0h));
+			asm("v_writelane_b32 %0, %2, 63\n\tv_writelane_b32 %1, %3, 63" : "+v"(sdl), "+v"(sdh) : "s"(w1l), "s"(w1h));
+		}
+		const uint64_t sd = ((uint64_t)sdh << 32) | sdl;
+		n_eq += (unsigned)(__popcll(~(me ^ up) & live) + __popcll(~(me ^ ct) & live) + __popcll(~(me ^ dw) & live) + __popcll(~(me ^ sd) & live));
+		n_up += (unsigned)(__popcll(me) + __popcll(ct));
+		rw += wpr;
+		rb += wpr;
+		up = ct;
+		ct = dw;
+	}
+	n_up = wave_sum(n_up);
+	n_eq = wave_sum(n_eq);
+	if (lane == 0) {
+		atomicAdd(acc + 2 * rep, n_up);
+		atomicAdd(acc + 2 * rep + 1, n_eq);
+	}
 }
 
 // ---- layout conversion, one wave per (row, wave column): 64 ballot words <-> 128 dense 32-bit words
@@ -897,7 +1008,7 @@ __global__ void __launch_bounds__(THREADS) ham_ballot_to_planes_k(uint64_t *__re
 
 // Workgroups the chip holds at once for kernel variant `v` on the current device (occupancy x compute units).
 static int ballot_resident_wgs(int v, const void *fn, int threads) {
-	static int cache[16][16];
+	static int cache[16][32];
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
 	if (!cache[dev][v]) {
@@ -919,8 +1030,17 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	const bool subl = p.slY != 0;
 	const void *fn;
 	const bool streamed = fused && p.nt_stream && NT == BAL_THREADS; // (8-wave workgroups serve lattices that fit the cache)
-	const int v = (streamed ? 6 : (fused ? 4 : 0)) | (subl ? 2 : 0) | (usej ? 1 : 0);
+	const bool batch = fused && p.nrep > 0;
+	if (batch && (usej || subl || NT != BAL_THREADS)) return hipErrorInvalidValue;
+	if (batch) { // a level = the units of all lattices
+		p.nwg_rep = p.nwg;
+		p.nwg = p.nwg_rep * p.nrep;
+		p.rep_magic = (uint32_t)((0x100000000ull + (unsigned long long)p.nwg_rep - 1) / (unsigned long long)p.nwg_rep);
+	}
+	const int v = batch ? (streamed ? 9 : 8) : ((streamed ? 6 : (fused ? 4 : 0)) | (subl ? 2 : 0) | (usej ? 1 : 0));
 	switch (v) {
+	case 8: fn = (const void *)ballot_update_k<false, false, true, BAL_THREADS, false, true>; break;
+	case 9: fn = (const void *)ballot_update_k<false, false, true, BAL_THREADS, true, true>; break;
 	case 0: fn = (const void *)ballot_update_k<false, false, false, NT>; break;
 	case 1: fn = (const void *)ballot_update_k<false, true, false, NT>; break;
 	case 2: fn = (const void *)ballot_update_k<true, false, false, NT>; break;
@@ -935,7 +1055,7 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	// measured 11 % slower).  Fused launches: as many workgroups as the chip holds; a few more are harmless (they find
 	// the tickets gone), so the occupancy query need not be exact.
 	const long long total = (long long)p.nwg * p.nlevels;
-	long long grid = fused ? std::min<long long>(std::min(ballot_resident_wgs(v + (NT == 256 ? 0 : 8), fn, NT), ballot_max_wgs() * 256 / NT), total) : total;
+	long long grid = fused ? std::min<long long>(std::min(ballot_resident_wgs(v + (NT == 256 ? 0 : 16), fn, NT), ballot_max_wgs() * 256 / NT), total) : total;
 	if (fused) {
 		// Fewer workgroups than the chip holds when a level has few tickets: a unit's parents are one level = p.nwg tickets
 		// back, and a workgroup that finds them unfinished holds its slot asleep (ising_create picks wg_per_cu)
@@ -955,6 +1075,8 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	// `stop`: an event that fires when this launch is done, hung on the dispatch packet itself (hipExtLaunchKernelGGL) --
 	// a hipEventRecord behind the launch is a packet of its own that drains the queue: 7 us between two 650 us launches
 	switch (v) {
+	case 8: hipExtLaunchKernelGGL((ballot_update_k<false, false, true, BAL_THREADS, false, true>), g, block, 0, stream, nullptr, stop, 0, p); break;
+	case 9: hipExtLaunchKernelGGL((ballot_update_k<false, false, true, BAL_THREADS, true, true>), g, block, 0, stream, nullptr, stop, 0, p); break;
 	case 0: hipExtLaunchKernelGGL((ballot_update_k<false, false, false, NT>), g, block, 0, stream, nullptr, stop, 0, p); break;
 	case 1: hipExtLaunchKernelGGL((ballot_update_k<false, true, false, NT>), g, block, 0, stream, nullptr, stop, 0, p); break;
 	case 2: hipExtLaunchKernelGGL((ballot_update_k<true, false, false, NT>), g, block, 0, stream, nullptr, stop, 0, p); break;
@@ -1011,6 +1133,13 @@ hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_o
 	// per row of work
 	if (p.nlevels > 1 && p.wide) return launch_ballot_update_nt<512>(p, stream, grid_out, stop);
 	return launch_ballot_update_nt<BAL_THREADS>(p, stream, grid_out, stop);
+}
+
+hipError_t launch_ballot_measure(const ReplicaParams *reps, int nrep, int gx, int Y, unsigned long long *acc, hipStream_t stream) {
+	const int R = 8; // rows a wave marches: the (above, same, below) window slides, two loads per row instead of four
+	const long long waves = (long long)nrep * ((gx + 3) / 4) * ((Y + R - 1) / R);
+	hipLaunchKernelGGL(ballot_measure_k, flat_grid((waves + THREADS / 64 - 1) / (THREADS / 64)), dim3(THREADS), 0, stream, reps, nrep, gx, Y, R, acc);
+	return hipGetLastError();
 }
 
 hipError_t launch_ballot_init(const InitParams &p, hipStream_t stream) {

@@ -40,7 +40,7 @@ using ising_host::fail;
 
 namespace {
 
-constexpr size_t SLOTCTL_TICKET_BYTES = 9 * 64;
+using ising_host::SLOTCTL_TICKET_BYTES;
 
 // cuRAND's curand_uniform on the host: x*2^-32 + 2^-33 in FP32 (product exact, one rounding).
 inline float u01(uint32_t x) { return (float)x * 0x1p-32f + 0x1p-33f; }
@@ -219,6 +219,24 @@ int choose_fused_strip_rows(int nwc, int Y, int rows) {
 	}
 	return best;
 }
+
+} // namespace
+
+// strip height and workgroups per CU of fused launches over `rows` rows of wave columns in all (ising_batch.cpp: the rows of
+// every lattice of a batch), strips dividing Y
+void ising_host::fused_shape(int nwc, int Y, long long rows, int *H, int *wg_per_cu) {
+	int best = 1, best_score = -1;
+	for (int h = 1; h <= 16; h <<= 1) {
+		if (Y % h) break;
+		const long long T = ((long long)nwc * ((rows + h - 1) / h) + 3) / 4;
+		const int score = fused_score(h, fused_wgs_for(T));
+		if (score >= best_score) { best = h; best_score = score; }
+	}
+	*H = best;
+	*wg_per_cu = fused_wgs_for(((long long)nwc * ((rows + best - 1) / best) + 3) / 4);
+}
+
+namespace {
 
 int choose_strip_rows(int gx, int Y, bool dense, bool ballot = false) {
 	// Enough (column-group x strip) units to give every SIMD several waves, while keeping strips tall so the two

@@ -158,5 +158,8 @@ int update_full_published(ising_ctx *c, int it, int color);
 int update_deep(ising_ctx *c, int it, int nlevels, bool overlapped = false);
 // called by ising_destroy
 void ring_release(ising_ctx *c);
+// launch shape of fused launches by tickets per level (ising_capi.cpp)
+void fused_shape(int nwc, int Y, long long rows, int *H, int *wg_per_cu);
+constexpr size_t SLOTCTL_TICKET_BYTES = 9 * 64; // ticket words in front of the completion counters (d_slotctl)
 
 } // namespace ising_host

@@ -74,6 +74,21 @@ struct UpdateParams {
 	uint32_t edge_go_need;
 	uint32_t *edge_done;
 	int32_t edge_lo, edge_hi;
+	// Batched fused launch (ising_batch_*): `nrep` independent lattices of one shape share the launch's tickets -- a level has
+	// nrep x nwg_rep of them, workgroup unit u of a level belongs to lattice u / nwg_rep -- so that small lattices (8192^2: a
+	// level of 128 .. 1024 tickets) fill the chip with tall strips.  Per lattice: a 32-byte record in device memory (both
+	// colours' row-0 pointers, its accept thresholds, its seed) read with one scalar load per unit; completion counters
+	// done + r * done_stride; lattice words, mirror offsets, iteration and everything else as in the single launch.
+	const struct ReplicaParams *rep;
+	int32_t nrep, nwg_rep;
+	uint32_t rep_magic;       // ceil(2^32 / nwg_rep)
+	int32_t done_stride;
+};
+
+struct ReplicaParams { // 32 bytes, 32-byte aligned: one s_load_dwordx8
+	uint64_t *lat[2];
+	uint32_t n3, n4;
+	uint32_t seed_lo, seed_hi;
 };
 
 // mode: 0 = integer thresholds via v_cmpx, 1 = generic FP32-table kernel, 2 = integer thresholds via the LDS rank table
@@ -148,6 +163,8 @@ void ballot_trace_dump(); // measurement builds only (ising_ballot.hip)
 #endif
 hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_out, hipEvent_t stop = nullptr);
 int ballot_max_wgs();
+// up-spin count and black-site bond sum of `nrep` ballot lattices (gx, Y each; reps[r].lat[]) added to acc[2 r], acc[2 r + 1]
+hipError_t launch_ballot_measure(const ReplicaParams *reps, int nrep, int gx, int Y, unsigned long long *acc, hipStream_t stream);
 hipError_t launch_ballot_init(const InitParams &p, hipStream_t stream);
 hipError_t launch_ballot_to_dense(const uint64_t *bal, uint32_t *dense, int gx, long long rows, hipStream_t stream);
 hipError_t launch_dense_to_ballot(const uint32_t *dense, uint64_t *bal, int gx, long long rows, hipStream_t stream);

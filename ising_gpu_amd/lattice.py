@@ -279,6 +279,58 @@ class IsingSlab:
         return int(a.value)
 
 
+class IsingBatch:
+    """Independent lattices of one shape on one GPU advancing together (ising_batch_*): one fused launch carries a level of
+    every member, one more launch measures all of them.  The members stay ordinary IsingSlab objects."""
+
+    def __init__(self, slabs):
+        self.slabs = list(slabs)
+        self._lib = _lib.load()
+        arr = (C.c_void_p * len(self.slabs))(*[s._h for s in self.slabs])
+        self._h = C.c_void_p()
+        check(self._lib.ising_batch_create(arr, len(self.slabs), C.byref(self._h)))
+        self.it = 0
+        h, w, n = C.c_int(), C.c_int(), C.c_int()
+        check(self._lib.ising_batch_info(self._h, C.byref(h), C.byref(w), C.byref(n)))
+        self.strip_rows, self.wg_per_cu, self.n = h.value, w.value, n.value
+
+    def close(self):
+        if self._h:
+            self._lib.ising_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def init(self):
+        for s in self.slabs:
+            s.init()
+        self.it = 0
+        return self
+
+    def sweep(self, n: int = 1):
+        check(self._lib.ising_batch_sweep(self._h, self.it + 1, n))
+        self.it += n
+        for s in self.slabs:
+            s.it = self.it
+        return self
+
+    def measure_enqueue(self):
+        check(self._lib.ising_batch_measure_enqueue(self._h))
+        return self
+
+    def measure_fetch(self):
+        """[[(up, down, bond_equal) per member] per measurement], in enqueue order."""
+        cap = 4096
+        up, bond, k = (C.c_uint64 * (cap * self.n))(), (C.c_int64 * (cap * self.n))(), C.c_int()
+        check(self._lib.ising_batch_measure_fetch(self._h, up, bond, cap, C.byref(k)))
+        tot = self.slabs[0].X * self.slabs[0].Y
+        return [[(int(up[i * self.n + r]), tot - int(up[i * self.n + r]), int(bond[i * self.n + r])) for r in range(self.n)] for i in range(k.value)]
+
+
 def philox_ceiling(device: int = 0) -> float:
     """sites/ns of a draw-only kernel (one Philox4x32-10 output per site, nothing else): the update kernels' VALU ceiling."""
     v = C.c_double()
