@@ -324,7 +324,7 @@ int ising_batch_destroy(ising_batch *b);
 int ising_batch_info(ising_batch *b, int *strip_rows, int *wg_per_cu, int *lattices); /* launch shape chosen for the batch */
 int ising_batch_sweep(ising_batch *b, int first_it, int nsweeps);
 int ising_batch_measure_enqueue(ising_batch *b);
-/* up[k * lattices + r], bond_equal[...]: measurement k (enqueue order) of member r; at most 4096 measurements may be pending */
+/* up[k * lattices + r], bond_equal[...]: measurement k (enqueue order) of member r; at most 1024 measurements may be pending */
 int ising_batch_measure_fetch(ising_batch *b, uint64_t *up, int64_t *bond_equal, int max_n, int *n);
 
 /* -- one process per slab WITHOUT RCCL: direct peer access, the reference's own multi-GPU mechanism

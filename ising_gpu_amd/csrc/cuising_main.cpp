@@ -9,7 +9,8 @@
 //            -J <PROB> (random anti-ferromagnetic bonds, optimized/main.cu:153-331, :575-618).
 // Build-side additions: --tsweep T0,T1,dT[,nequil[,nmeas[,stride]]] (temperature-sweep driver with <|m|>, <m^2>,
 //            susceptibility, Binder cumulant, energy and specific heat per point; --tsweep-anneal, --tsweep-out PREFIX,
-//            --tsweep-replicas K: K temperature points side by side on one GPU, 0 = by lattice size),
+//            --tsweep-replicas K: K temperature points per batched launch on one GPU, 0 = by lattice size; --tsweep-no-batch: two
+//            points side by side on streams of their own instead, round 2's form),
 //            --checkpoint FILE / --resume FILE (binary checkpoint, ising_ring_checkpoint_*), --transport copy|rccl.
 #include "../../include/ising_hip.h"
 
@@ -116,6 +117,7 @@ struct TsweepSpec {
 	bool anneal = false;
 	const char *out = nullptr;
 	int replicas = 0; // temperature points simulated side by side (fresh-start mode, one device); 0 = by lattice size
+	bool no_batch = false; // --tsweep-no-batch: the points side by side on streams of their own instead of batched launches (A/B)
 };
 
 std::string i128_str(__int128 v) {
@@ -146,13 +148,24 @@ int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_
 	const int ndev = ring.n();
 	const int npts = (int)floor((ts.t1 - ts.t0) / ts.dt + 1e-9) + 1;
 	int nrep = 1;
+	// Fresh-start mode on one device runs the temperature points as a BATCH: lattices of one shape share the tickets of every
+	// fused launch (ising_batch_sweep) and one launch measures all of them -- 8192^2 alone fills 70 % of an MI355X, 31 of them
+	// in one launch run at the large-lattice rate.  As many points at a time as fit 2^35 spins (4 GiB at 1 bit per spin), 64
+	// at most; --tsweep-replicas K forces K.  Lattices the batch cannot carry (dense layout: under 1.5 * 2^24 spins; -J)
+	// run two at a time on streams of their own, as in round 2.
+	bool batched = false;
 	if (ndev == 1 && !ts.anneal) {
-		nrep = ts.replicas > 0 ? ts.replicas : (nspins < (1ull << 29) ? 2 : 1); // (measured: 8192^2 x 31 points 2.16 s alone, 1.73 s with 2, 1.78 s with 3)
+		const int fit = (int)std::max<unsigned long long>(1, std::min<unsigned long long>(64, (1ull << 35) / nspins));
+		nrep = ts.replicas > 0 ? ts.replicas : fit;
 		nrep = std::max(1, std::min(nrep, npts));
+		batched = !useJ && !ts.no_batch;
+		if (!batched && ts.replicas == 0) nrep = std::min(nrep, nspins < (1ull << 29) ? 2 : 1); // (streams of their own: two fill the chip)
 	}
 	printf("\nTemperature sweep: %d points, T = %f .. %f step %f, %d equilibration + %d x %d measurement sweeps per point, %s\n",
 	       npts, ts.t0, ts.t0 + (npts - 1) * ts.dt, ts.dt, ts.nequil, ts.nmeas, ts.stride, ts.anneal ? "annealing" : "fresh start per point");
-	if (nrep > 1) fprintf(stderr, "temperature sweep: %d points side by side, one stream each\n", nrep);
+	// (every point starts from the same seed: the points share their initial lattice and their random numbers, so the curves'
+	// statistical errors are correlated across T -- common random numbers; an annealing run chains the points instead)
+	if (!ts.anneal) printf("Temperature sweep: all points use seed %llu (common random numbers across T)\n", (unsigned long long)base.seed);
 	FILE *fcsv = nullptr, *fser = nullptr;
 	if (ts.out) {
 		fcsv = fopen((std::string(ts.out) + ".csv").c_str(), "w");
@@ -169,8 +182,34 @@ int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_
 		CHECK(ising_create(&base, &c));
 		reps[r].ctx.push_back(c);
 	}
-	if (nrep > 1)
+	ising_batch *batch = nullptr;
+	int batch_n = 0;
+	auto make_batch = [&](int nb) -> bool { // a batch over the first nb lattices (the last group of points may be smaller)
+		if (batch && batch_n == nb) return true;
+		if (batch) { ising_batch_destroy(batch); batch = nullptr; }
+		std::vector<ising_ctx *> mem;
+		for (int j = 0; j < nb; j++) mem.push_back(reps[j].ctx[0]);
+		if (ising_batch_create(mem.data(), nb, &batch) != ISING_OK) { batch = nullptr; return false; }
+		batch_n = nb;
+		return true;
+	};
+	if (batched && !make_batch(std::min(nrep, npts))) {
+		fprintf(stderr, "temperature sweep: no batched launches (%s)\n", ising_last_error());
+		batched = false;
+		// (two at a time on private streams: what round 2 did; more lattices than that only wait for each other)
+		const int keep = ts.replicas > 0 ? nrep : std::min(nrep, nspins < (1ull << 29) ? 2 : 1);
+		for (int r = keep; r < nrep; r++) ising_destroy(reps[r].ctx[0]);
+		nrep = keep;
+		reps.resize(nrep);
+	}
+	if (batched) {
+		int h = 0, w = 0;
+		CHECK(ising_batch_info(batch, &h, &w, nullptr));
+		fprintf(stderr, "temperature sweep: %d points per batched launch (strips of %d rows, %d workgroups per CU)\n", nrep, h, w);
+	} else if (nrep > 1) {
+		fprintf(stderr, "temperature sweep: %d points side by side, one stream each\n", nrep);
 		for (Ring &rp : reps) CHECK(ising_use_private_stream(rp.ctx[0]));
+	}
 	std::vector<bool> have_J(nrep, false);
 	struct SeriesRow { int it; unsigned long long up, dw; long long A; };
 	const long double N = (long double)nspins;
@@ -192,8 +231,10 @@ int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_
 				it = 0;
 			}
 		}
+		if (batched && !make_batch(nb)) { fprintf(stderr, "cannot batch %d lattices: %s\n", nb, ising_last_error()); exit(EXIT_FAILURE); }
 		// equilibration, 32 sweeps (one fused launch) per replica at a time so that the replicas' launches alternate
-		for (int done = 0; done < ts.nequil;) {
+		if (batched) CHECK(ising_batch_sweep(batch, it + 1, ts.nequil));
+		for (int done = batched ? ts.nequil : 0; done < ts.nequil;) {
 			const int n = nb > 1 ? std::min(32, ts.nequil - done) : ts.nequil - done;
 			for (int j = 0; j < nb; j++) CHECK(ising_ring_sweep(reps[j].ctx.data(), reps[j].n(), it + done + 1, n));
 			done += n;
@@ -219,7 +260,24 @@ int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_
 			CHECK(ising_measure_fetch(reps[j].ctx[0], ups.data(), As.data(), 4096, &n));
 			for (int i = 0; i < n; i++, fetched[j]++) take(j, it_meas0 + (fetched[j] + 1) * ts.stride, ups[i], As[i]);
 		};
-		for (int m = 0; m < ts.nmeas; m++) {
+		// batched: one launch per `stride` sweeps of ALL points, one more for their measurements; read back every 1024
+		auto fetch_batch = [&]() {
+			std::vector<uint64_t> ups((size_t)1024 * nb);
+			std::vector<int64_t> As((size_t)1024 * nb);
+			int n = 0;
+			CHECK(ising_batch_measure_fetch(batch, ups.data(), As.data(), 1024, &n));
+			for (int i = 0; i < n; i++)
+				for (int j = 0; j < nb; j++) take(j, it_meas0 + (fetched[j] + i + 1) * ts.stride, ups[(size_t)i * nb + j], As[(size_t)i * nb + j]);
+			for (int j = 0; j < nb; j++) fetched[j] += n;
+		};
+		for (int m = 0; batched && m < ts.nmeas; m++) {
+			CHECK(ising_batch_sweep(batch, it + 1, ts.stride));
+			CHECK(ising_batch_measure_enqueue(batch));
+			it += ts.stride;
+			if ((m + 1) % 1024 == 0) fetch_batch();
+		}
+		if (batched) fetch_batch();
+		for (int m = 0; !batched && m < ts.nmeas; m++) {
 			for (int j = 0; j < nb; j++) {
 				CHECK(ising_ring_sweep(reps[j].ctx.data(), reps[j].n(), it + 1, ts.stride));
 				if (async) CHECK(ising_measure_enqueue(reps[j].ctx[0]));
@@ -235,7 +293,7 @@ int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_
 				}
 			}
 		}
-		if (async)
+		if (async && !batched)
 			for (int j = 0; j < nb; j++) fetch(j);
 		for (int j = 0; j < nb; j++) {
 			const float temp = temps[j];
@@ -261,6 +319,7 @@ int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_
 	const double et = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	if (fcsv) fclose(fcsv);
 	if (fser) fclose(fser);
+	if (batch) ising_batch_destroy(batch);
 	for (int r = 1; r < nrep; r++) ising_destroy(reps[r].ctx[0]);
 	printf("\nTemperature sweep: %lld update steps in %E ms, %.2lf flips/ns (initialisation and measurements included)\n\n", total_sweeps, et,
 	       (double)nspins * (double)total_sweeps / (et * 1.0E+6));
@@ -297,6 +356,7 @@ int main(int argc, char **argv) {
 	    {"devmap", required_argument, 0, 4},   {"layout", required_argument, 0, 5},  {"tsweep", required_argument, 0, 6},
 	    {"tsweep-anneal", no_argument, 0, 7},  {"tsweep-out", required_argument, 0, 8}, {"checkpoint", required_argument, 0, 9},
 	    {"resume", required_argument, 0, 10},  {"transport", required_argument, 0, 11}, {"tsweep-replicas", required_argument, 0, 12},
+	    {"tsweep-no-batch", no_argument, 0, 13},
 	    {0, 0, 0, 0}};
 	while (1) {
 		int option_index = 0;
@@ -372,6 +432,7 @@ int main(int argc, char **argv) {
 			ts.replicas = atoi(optarg);
 			if (ts.replicas < 0 || ts.replicas > 64) { fprintf(stderr, "error: --tsweep-replicas takes 0 (by lattice size) .. 64\n"); exit(EXIT_FAILURE); }
 			break;
+		case 13: ts.no_batch = true; break;
 		case '?': exit(EXIT_FAILURE);
 		default: fprintf(stderr, "unknown option: %c\n", och); exit(EXIT_FAILURE);
 		}

@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		int wgi = (int)(tk - level_base), rep = 0;
 		u32x8 rb = {0, 0, 0, 0, 0, 0, 0, 0};
 		if (BATCH) {
-			int q = (int)__umulhi((uint32_t)wgi, p.rep_magic);
+			int q = p.nwg_rep == 1 ? wgi : (int)__umulhi((uint32_t)wgi, p.rep_magic); // (the reciprocal of 1 does not fit 32 bits)
 			if (q * p.nwg_rep > wgi) --q; // (the reciprocal rounds up: at most one too many)
 			rep = uni(q);                 // (pinned to the scalar unit: the compiler takes the running level count for lane-dependent)
 			wgi = uni(wgi - rep * p.nwg_rep);
@@ -796,6 +796,7 @@ __global__ void __launch_bounds__(THREADS) ballot_init_k(const InitParams p) {
 // of a row and meets its four neighbour words exactly as the update kernel's word phase does (above / same index / below
 // from memory, the side word from another lane, the two row-end words put together from three wave-uniform words); then
 // 4 x 64 bonds are one XOR + popcount each.  Rows -1 and Y of the white array must mirror rows Y-1 and 0 (single slabs).
+constexpr int MEASURE_SLOTS = BALLOT_MEASURE_SLOTS;
 __global__ void __launch_bounds__(THREADS) ballot_measure_k(const ReplicaParams *__restrict__ reps, int nrep, int gx, int Y, int R, unsigned long long *__restrict__ acc) {
 	const int lane = threadIdx.x & 63;
 	const int nwc = (gx + 3) >> 2;
@@ -803,7 +804,7 @@ __global__ void __launch_bounds__(THREADS) ballot_measure_k(const ReplicaParams 
 	const int strips = (Y + R - 1) / R;
 	const long long per_rep = (long long)strips * nwc;
 	const long long wave_ll = flat_block() * (THREADS / 64) + (threadIdx.x >> 6);
-	if (wave_ll >= per_rep * nrep) return;
+	if (wave_ll >= per_rep * nrep) return; // (whole waves leave; nobody meets at a barrier)
 	const int rep = uni((int)(wave_ll / per_rep));
 	const int u = uni((int)(wave_ll - (long long)rep * per_rep));
 	const int strip = u / nwc, wc = u - strip * nwc;
@@ -875,9 +876,12 @@ __global__ void __launch_bounds__(THREADS) ballot_measure_k(const ReplicaParams 
 	}
 	n_up = wave_sum(n_up);
 	n_eq = wave_sum(n_eq);
+	// MEASURE_SLOTS accumulator pairs per lattice, a line apart (the host adds them up): a thousand waves adding to one
+	// address queue up at the L2 for longer than they spend counting
 	if (lane == 0) {
-		atomicAdd(acc + 2 * rep, n_up);
-		atomicAdd(acc + 2 * rep + 1, n_eq);
+		unsigned long long *a = acc + ((size_t)rep * MEASURE_SLOTS + (size_t)(u & (MEASURE_SLOTS - 1))) * 8;
+		atomicAdd(a, n_up);
+		atomicAdd(a + 1, n_eq);
 	}
 }
 
@@ -1136,7 +1140,7 @@ hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_o
 }
 
 hipError_t launch_ballot_measure(const ReplicaParams *reps, int nrep, int gx, int Y, unsigned long long *acc, hipStream_t stream) {
-	const int R = 8; // rows a wave marches: the (above, same, below) window slides, two loads per row instead of four
+	const int R = Y >= 4096 ? 16 : 8; // rows a wave marches: the (above, same, below) window slides, two loads per row instead of four
 	const long long waves = (long long)nrep * ((gx + 3) / 4) * ((Y + R - 1) / R);
 	hipLaunchKernelGGL(ballot_measure_k, flat_grid((waves + THREADS / 64 - 1) / (THREADS / 64)), dim3(THREADS), 0, stream, reps, nrep, gx, Y, R, acc);
 	return hipGetLastError();

@@ -24,8 +24,9 @@ struct ising_batch {
 	uint32_t *d_ctl = nullptr;                               // ticket words, then nrep x (nstrips + 2) completion counters
 	uint32_t done_base = 0;
 	unsigned long long ticket_base = 0;
-	static constexpr int MEAS_CAP = 4096;
-	unsigned long long *d_meas = nullptr, *h_meas = nullptr; // [measurement][lattice][up, bond sum]
+	static constexpr int MEAS_CAP = 1024;
+	static constexpr size_t MEAS_WORDS = (size_t)ising::BALLOT_MEASURE_SLOTS * 8; // per measurement and lattice: 16 partial (up, bond sum) pairs, a line each
+	unsigned long long *d_meas = nullptr, *h_meas = nullptr; // [measurement][lattice][slot][8]
 	int meas_pending = 0;
 	int n() const { return (int)m.size(); }
 	hipStream_t stream() const { return m[0]->stream; }
@@ -90,9 +91,10 @@ int ising_batch_create(ising_ctx **ctxs, int n, ising_batch **out) {
 	if (e == hipSuccess) { memset(b->h_rep, 0, (size_t)n * sizeof(ising::ReplicaParams)); e = hipEventCreateWithFlags(&b->ev_upload, hipEventDisableTiming); }
 	if (e == hipSuccess) e = hipMalloc((void **)&b->d_ctl, ctl_bytes);
 	if (e == hipSuccess) e = hipMemset(b->d_ctl, 0, ctl_bytes);
-	if (e == hipSuccess) e = hipMalloc((void **)&b->d_meas, (size_t)ising_batch::MEAS_CAP * n * 2 * sizeof(unsigned long long));
-	if (e == hipSuccess) e = hipMemset(b->d_meas, 0, (size_t)ising_batch::MEAS_CAP * n * 2 * sizeof(unsigned long long));
-	if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_meas, (size_t)ising_batch::MEAS_CAP * n * 2 * sizeof(unsigned long long), hipHostMallocDefault);
+	const size_t meas_bytes = (size_t)ising_batch::MEAS_CAP * n * ising_batch::MEAS_WORDS * sizeof(unsigned long long);
+	if (e == hipSuccess) e = hipMalloc((void **)&b->d_meas, meas_bytes);
+	if (e == hipSuccess) e = hipMemset(b->d_meas, 0, meas_bytes);
+	if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_meas, meas_bytes, hipHostMallocDefault);
 	if (e != hipSuccess) {
 		const int rc = fail(ISING_E_HIP, "batch allocation failed: %s", hipGetErrorString(e));
 		ising_batch_destroy(b);
@@ -177,7 +179,7 @@ int ising_batch_measure_enqueue(ising_batch *b) {
 	if (b->meas_pending >= ising_batch::MEAS_CAP) return fail(ISING_E_STATE, "%d measurements pending: ising_batch_measure_fetch first", b->meas_pending);
 	if (int rc = refresh_records(b)) return rc;
 	const ising_ctx *c0 = b->m[0];
-	HIP_TRY(ising::launch_ballot_measure(b->d_rep, b->n(), c0->gx, c0->cfg.Y, b->d_meas + (size_t)b->meas_pending * b->n() * 2, b->stream()));
+	HIP_TRY(ising::launch_ballot_measure(b->d_rep, b->n(), c0->gx, c0->cfg.Y, b->d_meas + (size_t)b->meas_pending * b->n() * ising_batch::MEAS_WORDS, b->stream()));
 	b->meas_pending++;
 	return ISING_OK;
 }
@@ -186,15 +188,17 @@ int ising_batch_measure_fetch(ising_batch *b, uint64_t *up, int64_t *bond_equal,
 	if (!b || !up || !bond_equal || !n || max_n < 0) return fail(ISING_E_ARG, "bad argument");
 	HIP_TRY(hipSetDevice(b->device));
 	if (b->meas_pending > max_n) return fail(ISING_E_ARG, "%d measurements pending, room for %d", b->meas_pending, max_n);
-	const size_t words = (size_t)b->meas_pending * b->n() * 2;
+	const size_t pairs = (size_t)b->meas_pending * b->n(), words = pairs * ising_batch::MEAS_WORDS;
 	if (words) {
 		HIP_TRY(hipMemcpyAsync(b->h_meas, b->d_meas, words * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream()));
 		HIP_TRY(hipMemsetAsync(b->d_meas, 0, words * sizeof(unsigned long long), b->stream())); // the accumulators of the next round
 	}
 	HIP_TRY(hipStreamSynchronize(b->stream()));
-	for (size_t i = 0; i < words / 2; i++) {
-		up[i] = b->h_meas[2 * i];
-		bond_equal[i] = (int64_t)b->h_meas[2 * i + 1];
+	for (size_t i = 0; i < pairs; i++) {
+		unsigned long long u = 0, a = 0;
+		for (int s = 0; s < ising::BALLOT_MEASURE_SLOTS; s++) { u += b->h_meas[i * ising_batch::MEAS_WORDS + 8 * s]; a += b->h_meas[i * ising_batch::MEAS_WORDS + 8 * s + 1]; }
+		up[i] = u;
+		bond_equal[i] = (int64_t)a;
 	}
 	*n = b->meas_pending;
 	b->meas_pending = 0;

@@ -163,7 +163,9 @@ void ballot_trace_dump(); // measurement builds only (ising_ballot.hip)
 #endif
 hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_out, hipEvent_t stop = nullptr);
 int ballot_max_wgs();
-// up-spin count and black-site bond sum of `nrep` ballot lattices (gx, Y each; reps[r].lat[]) added to acc[2 r], acc[2 r + 1]
+// up-spin count and black-site bond sum of `nrep` ballot lattices (gx, Y each; reps[r].lat[]), spread over BALLOT_MEASURE_SLOTS
+// accumulator pairs per lattice, 64 bytes apart: acc[(r * SLOTS + s) * 8 + {0, 1}]
+constexpr int BALLOT_MEASURE_SLOTS = 16;
 hipError_t launch_ballot_measure(const ReplicaParams *reps, int nrep, int gx, int Y, unsigned long long *acc, hipStream_t stream);
 hipError_t launch_ballot_init(const InitParams &p, hipStream_t stream);
 hipError_t launch_ballot_to_dense(const uint64_t *bal, uint32_t *dense, int gx, long long rows, hipStream_t stream);

@@ -324,7 +324,7 @@ class IsingBatch:
 
     def measure_fetch(self):
         """[[(up, down, bond_equal) per member] per measurement], in enqueue order."""
-        cap = 4096
+        cap = 1024
         up, bond, k = (C.c_uint64 * (cap * self.n))(), (C.c_int64 * (cap * self.n))(), C.c_int()
         check(self._lib.ising_batch_measure_fetch(self._h, up, bond, cap, C.byref(k)))
         tot = self.slabs[0].X * self.slabs[0].Y

@@ -62,10 +62,12 @@ def test_tsweep_config5_against_oracle_series(gpu, tmp_path):
     assert es[0] < es[-1] < 0
 
 
-@pytest.mark.parametrize("extra", [["--tsweep-replicas", "1"], ["--tsweep-replicas", "4"], ["-J", "0.25"]])
+@pytest.mark.parametrize("extra", [["--tsweep-replicas", "1"], ["--tsweep-replicas", "4"], ["-J", "0.25"],
+                                   ["--layout", "ballot"], ["--layout", "ballot", "--tsweep-replicas", "4"], ["--layout", "ballot", "--tsweep-no-batch"]])
 def test_tsweep_replicas_give_every_point_the_series_of_a_run_of_its_own(gpu, tmp_path, extra):
-    """Fresh-start mode simulates several temperature points side by side (one context and stream per replica); the
-    transcript and both CSV files must not depend on how many (default here: 3 at this size)."""
+    """Fresh-start mode simulates several temperature points together -- batched launches on the ballot layout (all ten
+    points in one batch, or 4 + 4 + 2), otherwise side by side on streams of their own; the transcript and both CSV files
+    must not depend on which, nor on how many at a time."""
     args = ["-x", 8192, "-y", 512, "-s", 99, "--tsweep", "1.8,2.7,0.1,33,3,5"]
     ref = run(args + ["--tsweep-out", "a"], cwd=tmp_path)
     if extra[0] == "-J":
