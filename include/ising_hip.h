@@ -39,7 +39,8 @@ enum {
 	ISING_OK = 0,
 	ISING_E_ARG = 1,      /* bad argument (sizes not multiples of 2048 / 16, null pointer, ...) */
 	ISING_E_HIP = 2,      /* a HIP runtime call failed */
-	ISING_E_STATE = 3,    /* call sequence error (e.g. sweep with nslabs > 1) */
+	ISING_E_STATE = 3,    /* call sequence error (e.g. sweep with nslabs > 1); also: a fused launch gave up waiting for completion
+	                         counters that never came (reported by the next call that synchronises; tickets and counters are reset) */
 	ISING_E_NOGPU = 4,    /* no usable gfx950 device / kernel image */
 	ISING_E_RCCL = 5,     /* RCCL could not be opened or an RCCL call failed (ring transports) */
 	ISING_E_TIMEOUT = 6,  /* ising_rank_wait: the exchange did not complete in time */
@@ -231,6 +232,11 @@ int ising_device_ptr(ising_ctx *ctx, int color, void **ptr, size_t *bytes);
  * trip in between -- the reference reads its counters back at every print point (optimized/main.cu:1806-1810). */
 int ising_measure_enqueue(ising_ctx *ctx);
 int ising_measure_fetch(ising_ctx *ctx, uint64_t *up, int64_t *bond_equal, int max_n, int *n);
+
+/* Test aid: what = 1 leaves the host's record of a slab's completion counters out of step with the device, as a faulted
+ * launch would; the next fused launch then gives up after `arg` polls (0: the default bound, ~10 s) and the call that
+ * synchronises next returns ISING_E_STATE with tickets and counters reset (tests/test_gpu_fused.py). */
+int ising_debug_fault(ising_ctx *ctx, int what, int arg);
 
 /* The layout in use right now (ISING_LAYOUT_NIBBLE, _DENSE or _BALLOT). */
 int ising_layout(ising_ctx *ctx, int *layout);

@@ -84,6 +84,7 @@ PROTOTYPES = {
     "ising_ring_checkpoint_load": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.POINTER(C.c_int64)]),
     "ising_device_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "ising_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "ising_debug_fault": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ising_dump_text": (C.c_int, [C.c_void_p, C.c_char_p]),
     "ising_ring_set_transport": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "ising_ring_transport": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]),

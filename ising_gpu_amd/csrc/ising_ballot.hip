@@ -32,6 +32,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 namespace ising {
 namespace {
@@ -128,37 +129,24 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 // all the same).  The chip never drains between colours.  A unit's parents are one level of tickets back: the host picks
 // strip height and grid size so that they are done when the unit starts (ising_create); from 1.5 * 2^24 spins up
 // this form is what ising_sweep launches.
-// When a workgroup draws its next ticket.  2 (default): in a unit's last iteration, waited for on the spot (~2 us per
-// unit).  0: requested at the end of the second-last word phase and picked up one iteration later -- hides half of
-// the wait and brings back a third of the sleeping polls: no gain (16384^2: 1.1 M -> 2.8 M polls that slept).  1: during
-// a unit's FIRST row, the form this kernel had first: a ticket drawn a unit ahead sits reserved while its workgroup
-// finishes the current unit and later tickets start before it, so units of the next level find their parents unfinished.
-// Measured (tools/trace_probe.py, `make variant DEFS=-DISING_FUSED_LOOKAHEAD=1`, profiles/fused_trace_r02.txt): 65536^2,
-// H = 16: 12.5 M polls that slept per 2.1 M units -> none with 2, 3360 -> 3463 flips/ns; 16384^2, H = 4: 9.7 M -> 3.5 M,
-// 2892 -> 3047 (trace builds).
-#ifndef ISING_FUSED_LOOKAHEAD
-#define ISING_FUSED_LOOKAHEAD 2
-#endif
+// When a workgroup draws its next ticket: in a unit's LAST iteration, waited for on the spot (~2 us per unit).  Drawn a unit
+// ahead -- during the unit's first row, this kernel's first form -- a ticket sits reserved while its workgroup finishes the
+// current unit and later tickets start before it, so units of the next level find their parents unfinished (65536^2, H = 16:
+// 12.5 M polls that slept per 2.1 M units -> none, 3360 -> 3463 flips/ns; 16384^2, H = 4: 9.7 M -> 3.5 M, 2892 -> 3047;
+// requested one word phase early: no gain.  tools/trace_probe.py, profiles/fused_trace_r02.txt; the variants are in the
+// history of this file up to round 2.)
 // Wave priorities in fused launches.  The SIMD's arbiter serves its waves oldest first, and the waves of a persistent grid
 // keep their age: under a saturated vector ALU the youngest wave of a SIMD gets what the others leave.  Units of the same work
 // then take 1x .. 5x as long (a -DISING_FUSED_TRACE -DISING_FUSED_TRACE_COUNTS build: 43 % of the units of 65536^2 in 100-130 k
 // cycles, 9 % in more than 490 k), and the slow ones are the parents the next level finds unfinished: 6 % of the units slept
-// ~90 polls each at five workgroups per CU, more at six.  2 (default): every wave steps through the four priorities row by
+// ~90 polls each at five workgroups per CU, more at six.  Every wave therefore steps through the four priorities row by
 // row, offset by its dispatch round (= its rank on the SIMD), so the waves of a SIMD take turns at the front: no sleeping
 // polls left at 65536^2 (3479 -> 3515 flips/ns, 3534 with six workgroups per CU), 16384^2 3082 -> 3291, 16384 x 8192 with
-// 4-wave workgroups 2709 -> 3041.  1: feedback once per unit from the tickets drawn meanwhile (a slow workgroup raises its
-// priority for the next unit): the same spread, alternating.  0: none.  (Four steps per row instead of one: 3487 at 65536^2; a
-// row count that runs on across units: -1.5 % with one- to four-row units; the rotation in one-launch-per-colour launches,
-// ISING_PLAIN_PRIO: 3458 -> 3389 -- their workgroups are not a persistent grid, and nothing waits for a slow one but the launch's end;
-// the fifth and sixth wave of a SIMD -- four levels, so they share one with the first and second -- stepping the other way round: -0.3 %; as many positions as
-// the SIMD has waves, the ones past the third sharing level 0: -0.5 .. -1.5 %.  What remains uneven: the fifth and sixth wave still own all
-// the units that take three times the median, 7 % of the units at 65536^2.)
-#ifndef ISING_FUSED_PRIO
-#define ISING_FUSED_PRIO 2
-#endif
-#ifndef ISING_PLAIN_PRIO // the same rotation in one-launch-per-colour launches (no parents there, but a launch ends on its slowest waves)
-#define ISING_PLAIN_PRIO 0
-#endif
+// 4-wave workgroups 2709 -> 3041.  (Measured and dropped, round 2: feedback once per unit from the tickets drawn meanwhile --
+// the same spread, alternating; four steps per row; a row count that runs on across units; the rotation in
+// one-launch-per-colour launches, 3458 -> 3389: their workgroups are not a persistent grid; the fifth and sixth wave of a SIMD
+// stepping the other way round.  What remains uneven: the fifth and sixth wave still own all the units that take three times
+// the median, 7 % of the units at 65536^2.)
 #ifndef ISING_FUSED_STAGGER // s_sleep units (64 cycles each) between the start of successive dispatch rounds of a fused launch
 #define ISING_FUSED_STAGGER 100
 #endif
@@ -277,8 +265,9 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	// The workgroups of a launch start a fraction of a row apart (by the round of 256 they were dispatched in) instead of
 	// in lockstep -- all drawing, then all waiting: +0.3..0.6 % on whole runs, more on short launches (4-wave form;
 	// -DISING_FUSED_STAGGER=0 switches it off; 8-wave workgroups measured -2 % with it, plain launches -0.3 %).
+	const unsigned dround = uni((int)(blockIdx.x / (unsigned)p.cus)); // dispatch round = this workgroup's rank on its CU (a grid of k x CUs lands k per CU)
 	if (FUSED && NT == 256 && ISING_FUSED_STAGGER > 0)
-		for (unsigned i = 0; i < (blockIdx.x >> 8) % 6u; ++i) __builtin_amdgcn_s_sleep(ISING_FUSED_STAGGER);
+		for (unsigned i = 0; i < dround % 6u; ++i) __builtin_amdgcn_s_sleep(ISING_FUSED_STAGGER);
 	if (FUSED) {
 		if (threadIdx.x == 0) ticket_sh[0] = draw_ticket();
 		__syncthreads();
@@ -287,11 +276,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	// a workgroup's tickets grow, so its level is a running count (no 64-bit division per unit)
 	int level = 0;
 	unsigned long long level_base = 0;
-	[[maybe_unused]] unsigned long long tk_next = 0; // (set once, here: a write per unit would have to wait for the unit's first loads)
 	const int nwc_sh = (nwc & (nwc - 1)) == 0 ? __builtin_ctz((unsigned)nwc) + 2 : -1; // gxp = 4 nwc as a shift where it is one
-#if ISING_FUSED_PRIO == 1
-	[[maybe_unused]] unsigned long long tk_prev = 0;
-#endif
 	for (int round = 0;; ++round) {
 		unsigned long long tk;
 		if (FUSED) {
@@ -301,19 +286,6 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			tk = round ? total : (unsigned long long)blockIdx.x; // plain: one unit per workgroup
 		}
 		if (tk >= total) break;
-#if ISING_FUSED_PRIO == 1
-		// feedback: the tickets drawn chip-wide while this workgroup worked on its last unit say how slow it was (gridDim.x when
-		// everybody is equally fast); slow workgroups raise their priority for the next unit
-		if (FUSED && round > 0) {
-			const unsigned long long lag = tk - tk_prev;
-			const unsigned g = gridDim.x;
-			if (lag * 4 > 7ull * g) __builtin_amdgcn_s_setprio(3);
-			else if (lag * 4 > 5ull * g) __builtin_amdgcn_s_setprio(2);
-			else if (lag * 4 > 3ull * g) __builtin_amdgcn_s_setprio(1);
-			else __builtin_amdgcn_s_setprio(0);
-		}
-		tk_prev = tk;
-#endif
 		TRC(0); // ticket pick-up
 #if defined(ISING_FUSED_TRACE) && defined(ISING_FUSED_TRACE_COUNTS)
 		const long long t_unit0 = clock64();
@@ -438,9 +410,23 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		}
 		if (must_wait) {
 			[[maybe_unused]] int nsleep = 0;
+			uint32_t npoll = 0;
 			for (;;) { // few, patient polls: every poll is a trip to memory that competes with the lattice traffic
 				asm volatile("s_waitcnt vmcnt(0)" : "+v"(seen) :: "memory");
 				if (__all((int32_t)(seen - need) >= 0)) break;
+				// counters that never come (bases out of step with the device after a faulted launch): give the launch up.  The
+				// flag lives in pinned host memory -- the host sees it at its next synchronise -- and is looked at every 64th poll.
+				if (p.abort_flag != nullptr && (++npoll & 63u) == 0u) {
+					uint32_t ab = 0;
+					if (npoll >= p.abort_polls) { ab = 1u; if (lane == 0) __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+					else ab = __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					if (uni(ab) != 0u) {
+						// no ticket is handed on by this workgroup any more: whoever reads the slots finds the work gone (the barriers
+						// of the row loop count the waves that are still there)
+						if (lane == 0) ticket_sh[0] = ticket_sh[1] = ~0ull;
+						__builtin_amdgcn_endpgm();
+					}
+				}
 				TRN(9, 1);
 				TRN(15, nsleep++ == 0);
 #if defined(ISING_FUSED_TRACE_COUNTS) // where the sleeping units are: by position in the level's visiting order and by level
@@ -464,10 +450,15 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			// the exchange that follows the previous launch has read this slab's first / last rows and filled its ghost rows
 			// once the comm stream has moved the counter (usually long ago: the exchange starts when the previous launch's
 			// edge strips finish their last level, a level before the launch ends)
-			uint32_t got = p.edge_go_need;
+			uint32_t got = p.edge_go_need, ngo = 0;
 			for (;;) {
 				if (lane == 0) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(got) : "v"(p.edge_go) : "memory");
 				if (__all((int32_t)(got - p.edge_go_need) >= 0)) break;
+				// (no bound of its own -- a neighbour may be seconds behind --, but the host can call the launch off)
+				if (p.abort_flag != nullptr && (++ngo & 63u) == 0u && uni(__hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0u) {
+					if (lane == 0) ticket_sh[0] = ticket_sh[1] = ~0ull;
+					__builtin_amdgcn_endpgm();
+				}
 				__builtin_amdgcn_s_sleep(127);
 			}
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // rows written by another kernel / a copy engine while this launch ran
@@ -511,19 +502,16 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		// one scalar-cache write-back per workgroup and row: every wave runs the same number of iterations and meets at a barrier
 		const int rmax = Hr;
 		const bool wb_wave = threadIdx.x < 64;
-		const int r_ticket = ISING_FUSED_LOOKAHEAD == 1 ? 0 : rmax;
 		for (int r = 0; r <= rmax; ++r) {
-#if ISING_FUSED_PRIO == 2
-			// rotating priorities: the waves that share a SIMD (one per dispatch round of 256 workgroups) take turns at the front
-			if (FUSED || ISING_PLAIN_PRIO) {
-				switch ((r + (int)(blockIdx.x >> 8)) & 3) {
+			// rotating priorities: the waves that share a SIMD (one per dispatch round) take turns at the front
+			if (FUSED) {
+				switch ((r + (int)dround) & 3) {
 				case 0: __builtin_amdgcn_s_setprio(0); break;
 				case 1: __builtin_amdgcn_s_setprio(1); break;
 				case 2: __builtin_amdgcn_s_setprio(2); break;
 				default: __builtin_amdgcn_s_setprio(3); break;
 				}
 			}
-#endif
 			// The two words per row whose side neighbours sit in another vector (sites 0 / 31) are assembled on the scalar
 			// unit from three source-colour words of row r0 + r - 1: A0, A1 of this wave's own 64 words, C from the
 			// neighbouring wave column.  Plain launches: three scalar loads issued before the draw phase of row r0 + r.
@@ -585,18 +573,12 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				});
 			}
 			TRC(4); // draw phase
-			if (FUSED && r == r_ticket && wi == 0) { // wave-uniform branch; read by the workgroup after this unit's last barrier
-				if (lane == 0) ticket_sh[(round + 1) & 1] = ISING_FUSED_LOOKAHEAD == 0 ? tk_next : draw_ticket();
+			if (FUSED && r == rmax && wi == 0) { // wave-uniform branch; read by the workgroup after this unit's last barrier
+				if (lane == 0) ticket_sh[(round + 1) & 1] = draw_ticket();
 			}
 			TRC(5); // next ticket
 			asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 			TRC(6); // barrier (scalar stores, write-back of the previous row, the slowest wave)
-			// the next ticket: requested by wave 0 at the end of the unit's second-last word phase, behind everything that
-			// phase waits for (vmcnt counts in order), picked up in the last iteration -- its 2 us pass under the write-back,
-			// the barrier and the top of the last iteration
-			const bool ticket_iter = FUSED && ISING_FUSED_LOOKAHEAD == 0 && r == rmax - 1 && wi == 0;
-			const bool ticket_in_word = ticket_iter && r > 0 && r <= nrows;
-			if (ticket_iter && !ticket_in_word && lane == 0) tk_next = draw_ticket();
 			if (r > 0 && r <= nrows) {
 				// ---- word phase, row r0 + r - 1; its masks were written back during the draw phase above
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -680,7 +662,6 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 						if (lr == p.Y - 1) st_word<false>(rd + mirL + lane, nw);
 					}
 				}
-				if (ticket_in_word && lane == 0) tk_next = draw_ticket(); // (behind this row's stores)
 				rs += wpr;
 				rd += wpr;
 				if (sl_last) { // the next row opens a new period: the register window does not slide across the seam
@@ -713,7 +694,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				const long long te = clock64();
 				hist_sh[0][min(15ll, (te - t_unit1) / (16384ll * p.H / 8))]++;
 				hist_sh[1][min(15ll, (te - t_unit0) / (16384ll * p.H / 8))]++;
-				if ((te - t_unit1) / (16384ll * p.H / 8) >= 12) tr[10 + min(3u, blockIdx.x >> 8)] += 1; // long units by dispatch round (3: fourth and later)
+				if ((te - t_unit1) / (16384ll * p.H / 8) >= 12) tr[10 + min(3u, dround)] += 1; // long units by dispatch round (3: fourth and later)
 			}
 #endif
 			if (lane == 0) __hip_atomic_fetch_add(p.done + (BATCH ? rep * p.done_stride : 0) + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1011,20 +992,22 @@ __global__ void __launch_bounds__(THREADS) ham_ballot_to_planes_k(uint64_t *__re
 } // namespace
 
 // Workgroups the chip holds at once for kernel variant `v` on the current device (occupancy x compute units).
-static int ballot_resident_wgs(int v, const void *fn, int threads) {
+// (contexts may be driven from several host threads, one each: the cache is filled under a lock)
+static int ballot_resident_wgs(int v, const void *fn, int threads, int cus) {
+	static std::mutex mu;
 	static int cache[16][32];
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+	std::lock_guard<std::mutex> lock(mu);
 	if (!cache[dev][v]) {
-		int per_cu = 0, cus = 0;
+		int per_cu = 0;
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-		if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-		cache[dev][v] = per_cu * cus;
+		cache[dev][v] = per_cu;
 	}
-	return cache[dev][v];
+	return cache[dev][v] * cus;
 }
 
-int ballot_max_wgs() { return 256 * 8; } // upper bound of the grid of any ballot launch (scratch sizing): 8 workgroups of 4 waves per CU at most
+int ballot_max_wgs(int cus) { return (cus > 0 ? cus : 256) * 8; } // 8 workgroups of 4 waves per CU at most
 
 template <int NT>
 static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, int *grid_out, hipEvent_t stop) {
@@ -1059,18 +1042,17 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	// measured 11 % slower).  Fused launches: as many workgroups as the chip holds; a few more are harmless (they find
 	// the tickets gone), so the occupancy query need not be exact.
 	const long long total = (long long)p.nwg * p.nlevels;
-	long long grid = fused ? std::min<long long>(std::min(ballot_resident_wgs(v + (NT == 256 ? 0 : 16), fn, NT), ballot_max_wgs() * 256 / NT), total) : total;
+	if (p.cus <= 0) { // (callers pass the slab's device's count; a bare UpdateParams asks)
+		int dev = 0, n = 0;
+		if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+		p.cus = n;
+	}
+	const int cus = p.cus;
+	long long grid = fused ? std::min<long long>(std::min(ballot_resident_wgs(v + (NT == 256 ? 0 : 16), fn, NT, cus), ballot_max_wgs(cus) * 256 / NT), total) : total;
 	if (fused) {
 		// Fewer workgroups than the chip holds when a level has few tickets: a unit's parents are one level = p.nwg tickets
 		// back, and a workgroup that finds them unfinished holds its slot asleep (ising_create picks wg_per_cu)
-		static int cu_count[16];
-		int dev = 0;
-		if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-		if (!cu_count[dev] && (hipDeviceGetAttribute(&cu_count[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu_count[dev] < 1)) cu_count[dev] = 256;
-		const int cus = cu_count[dev];
-		const char *wgs = getenv("ISING_FUSED_WGS"); // A/B and tests: explicit grid (read at every launch)
-		const long long cap = wgs ? atoll(wgs) : 0;
-		if (cap > 0) grid = std::min(grid, cap);
+		if (p.grid_cap > 0) grid = std::min<long long>(grid, p.grid_cap); // (ISING_FUSED_WGS, read when the context was created)
 		else if (p.wg_per_cu > 0) grid = std::min<long long>(grid, (long long)p.wg_per_cu * cus);
 	}
 	if (grid < 1) grid = 1;

@@ -159,6 +159,10 @@ int ising_batch_sweep(ising_batch *b, int first_it, int nsweeps) {
 		p.nt_stream = b->nt;
 		p.rep = b->d_rep;
 		p.nrep = b->n();
+		p.cus = c0->cus;
+		p.grid_cap = c0->pol.fused_wgs;
+		p.abort_flag = c0->h_abort; // (member 0 keeps the word a launch that gives up raises)
+		p.abort_polls = c0->pol.abort_polls;
 		if (b->done_base > (1u << 30)) { // keep the monotone completion counters far from wrapping
 			HIP_TRY(hipMemsetAsync(b->d_ctl + ising_host::SLOTCTL_TICKET_BYTES / 4, 0, (size_t)b->n() * p.done_stride * sizeof(uint32_t), b->stream()));
 			b->done_base = p.done_base = 0;
@@ -194,6 +198,13 @@ int ising_batch_measure_fetch(ising_batch *b, uint64_t *up, int64_t *bond_equal,
 		HIP_TRY(hipMemsetAsync(b->d_meas, 0, words * sizeof(unsigned long long), b->stream())); // the accumulators of the next round
 	}
 	HIP_TRY(hipStreamSynchronize(b->stream()));
+	if (b->m[0]->h_abort && __atomic_load_n(b->m[0]->h_abort, __ATOMIC_ACQUIRE)) { // a batched launch gave up: its own tickets and counters start over too
+		(void)hipMemset(b->d_ctl, 0, ising_host::SLOTCTL_TICKET_BYTES + (size_t)b->n() * ((size_t)b->nstrips + 2) * sizeof(uint32_t));
+		b->done_base = 0;
+		b->ticket_base = 0;
+		b->meas_pending = 0;
+		return ising_host::check_abort(b->m[0]);
+	}
 	for (size_t i = 0; i < pairs; i++) {
 		unsigned long long u = 0, a = 0;
 		for (int s = 0; s < ising::BALLOT_MEASURE_SLOTS; s++) { u += b->h_meas[i * ising_batch::MEAS_WORDS + 8 * s]; a += b->h_meas[i * ising_batch::MEAS_WORDS + 8 * s + 1]; }

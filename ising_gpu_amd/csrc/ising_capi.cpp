@@ -33,6 +33,61 @@ int bind(const ising_ctx *c) {
 	return ISING_OK;
 }
 
+// every switch the library takes from the environment, read in one place
+int read_policy(ising_policy *pol) {
+	auto num = [](const char *name, int *out) { if (const char *e = getenv(name)) { *out = atoi(e); return true; } return false; };
+	int v = 0;
+	if (num("ISING_FUSED", &v)) pol->fused = v != 0;
+	if (num("ISING_FUSED_WIDE", &v)) pol->fused_wide = v;
+	if (num("ISING_FUSED_NT", &v)) pol->fused_nt = v != 0;
+	if (num("ISING_FUSED_TICKETS2", &v)) pol->fused_tickets2 = (v == 2 || v == 4) ? v : (v ? 2 : 0);
+	if (num("ISING_FUSED_WGS", &v)) pol->fused_wgs = v > 0 ? v : 0;
+	if (num("ISING_RING_GHOST", &v)) pol->ring_ghost = v;
+	pol->no_ballot = getenv("ISING_NO_BALLOT") != nullptr;
+	if (const char *e = getenv("ISING_TAIL")) {
+		int rows = 0, h = 1;
+		const int got = sscanf(e, "%d,%d", &rows, &h);
+		if (got >= 1 && rows >= 0 && h > 0) { pol->tail_rows = rows; pol->tail_h = h; }
+	}
+	if (num("ISING_RING_TRAPEZOID", &v)) pol->trapezoid = v != 0;
+	if (num("ISING_RING_OVERLAP", &v)) pol->overlap = v != 0;
+	if (num("ISING_RING_INLINE", &v)) pol->ring_inline = v != 0;
+	if (num("ISING_RING_STORE", &v)) pol->ring_store = v != 0;
+	if (num("ISING_RING_FLAGS", &v)) pol->ring_flags = v != 0;
+	if (num("ISING_RING_PUBLISH", &v)) pol->ring_publish = v != 0;
+	if (num("ISING_RING_COMM_PRIORITY", &v)) pol->comm_priority = v != 0;
+	if (num("ISING_ABORT_POLLS", &v) && v > 0) pol->abort_polls = (uint32_t)v;
+	if (const char *e = getenv("ISING_RING_TRANSPORT")) {
+		if (!strcmp(e, "copy")) pol->ring_transport = ISING_TRANSPORT_COPY;
+		else if (!strcmp(e, "rccl")) pol->ring_transport = ISING_TRANSPORT_RCCL;
+		else if (!strcmp(e, "auto")) pol->ring_transport = ISING_TRANSPORT_AUTO;
+		else return fail(ISING_E_ARG, "ISING_RING_TRANSPORT must be auto, copy or rccl (got %s)", e);
+	}
+	return ISING_OK;
+}
+
+// A fused launch that gave up (ising_ballot.hip: UpdateParams.abort_flag) leaves tickets half drawn and counters half
+// bumped: everything starts from zero again -- the spins are whatever the launch left, the caller initialises or loads.
+int check_abort(ising_ctx *c) {
+	if (!c->h_abort || !__atomic_load_n(c->h_abort, __ATOMIC_ACQUIRE)) return ISING_OK;
+	(void)hipStreamSynchronize(c->stream);
+	if (c->d_slotctl) (void)hipMemset(c->d_slotctl, 0, c->slotctl_bytes);
+	if (c->d_edge) (void)hipMemset(c->d_edge, 0, 32 * sizeof(uint32_t));
+	for (auto &t : c->ticket_base2) t = 0;
+	c->done_base = 0;
+	c->edge_done_target = c->edge_go_epoch = 0;
+	c->go_set = false;
+	c->ghost_depth[0] = c->ghost_depth[1] = 0;
+	__atomic_store_n(c->h_abort, 0u, __ATOMIC_RELEASE);
+	return fail(ISING_E_STATE, "a fused launch gave up: its units' parents never completed (completion counters out of step with the device after a faulted "
+	                           "launch?); tickets and counters have been reset, the lattice is undefined -- initialise or load it again");
+}
+
+int sync_checked(ising_ctx *c) {
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return check_abort(c);
+}
+
 } // namespace ising_host
 
 using ising_host::bind;
@@ -355,6 +410,9 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 
 	ising_ctx *c = new ising_ctx();
 	c->cfg = *cfg;
+	if (int rc = ising_host::read_policy(&c->pol)) { delete c; return rc; }
+	if (hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || c->cus < 1) { (void)hipGetLastError(); c->cus = 256; }
+	const ising_policy &pol = c->pol;
 	if (cfg->layout != ISING_LAYOUT_AUTO && cfg->layout != ISING_LAYOUT_NIBBLE && cfg->layout != ISING_LAYOUT_DENSE && cfg->layout != ISING_LAYOUT_BALLOT) {
 		delete c;
 		return fail(ISING_E_ARG, "bad layout %d", cfg->layout);
@@ -399,24 +457,24 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// ISING_FUSED=0/1, ISING_FUSED_WIDE=0/1, cfg.strip_rows and ISING_FUSED_WGS (grid) override.
 	const long long spins = (long long)cfg->X * cfg->Y;
 	const bool fused_can = c->wrap && !cfg->XSL;
-	const char *fz = getenv("ISING_FUSED"), *fw = getenv("ISING_FUSED_WIDE");
+
 	// (rows of a million columns and more -- 128 wave columns -- run 1-2 % faster one launch per colour, whatever their number:
 	// 1048576 x 65536 3461 vs 3429 fused, x 524288 3536 vs 3465, 2097152 x 131072 3464 vs 3397; 524288 x 1048576 3484 vs 3513;
 	// tools/huge_probe.py.  At 2^37 spins, 8 sweeps: one launch per colour 3506 .. 3528 at every width; fused 3538 up to 32 wave
 	// columns, 3512 at 64, 3445 at 128, 3386 at 256, 3186 at 512: a strip's completion counter takes one atomic per wave column
 	// and level, all at about the same time, and three polls per unit of the next)
 	// (from 768 tickets a level: 8192 x 3072 1834 vs the dense layout's 1658; 8192 x 2048, 512 tickets: 1330 vs 1416)
-	c->fused = fz ? atoi(fz) != 0 : (spins >= 3 * (1LL << 23) && c->nwc() < 128);
-	c->fused_wide = fw ? atoi(fw) : 0; // (8-wave workgroups: an A/B switch since the priorities rotate; 16384 x 8192: 3070 vs 3040 with 4 waves)
+	c->fused = pol.fused >= 0 ? pol.fused != 0 : (spins >= 3 * (1LL << 23) && c->nwc() < 128);
+	c->fused_wide = pol.fused_wide; // (8-wave workgroups: an A/B switch since the priorities rotate; 16384 x 8192: 3070 vs 3040 with 4 waves)
 	// AUTO: the ballot kernel's two-phase row pipeline wins from 2^27 spins per slab up -- from 2^25 where fused launches
 	// apply (a slab that wraps in place, a ring slab that can keep ghost rows); below, the dense kernel is ahead.  (A partly dead last wave column wastes its
 	// dead lanes' draws: worth it while they are under a tenth of the row -- the dense kernel is 12 % behind.)
 	const bool ballot_pays = whole || 10 * c->gx > 9 * 4 * c->nwc();
 	// (a ring slab that can keep ghost rows sweeps in fused launches as well, see below)
 	const bool deep_can = !c->wrap && !cfg->XSL && !(cfg->use_J && cfg->coupling_mem) && !cfg->lattice_mem && cfg->Y >= 4 &&
-	                      !(getenv("ISING_RING_GHOST") && atoi(getenv("ISING_RING_GHOST")) < 2);
+	                      !(pol.ring_ghost >= 0 && pol.ring_ghost < 2);
 	const long long ballot_from = ((c->fused && fused_can) || deep_can) ? 3 * (1LL << 23) : (1LL << 27);
-	if (cfg->layout == ISING_LAYOUT_AUTO && ballot_ok && ballot_pays && c->fast_ok && spins >= ballot_from && !getenv("ISING_NO_BALLOT"))
+	if (cfg->layout == ISING_LAYOUT_AUTO && ballot_ok && ballot_pays && c->fast_ok && spins >= ballot_from && !pol.no_ballot)
 		c->ballot = true;
 	if (c->ballot) c->lld = c->nwc() * 64;
 	const bool fused_shape = c->ballot && c->fused && fused_can;
@@ -428,7 +486,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		// 8192 x 16384 2497 -> 2712, 16384^2 2915 -> 2980, 32768^2 3317 -> 3340, 65536^2 3413 -> 3424: the launch boundary
 		// and the exchange come half as often, the redundant rows are 128 of Y)
 		int G = 64;
-		if (const char *e = getenv("ISING_RING_GHOST")) G = atoi(e);
+		if (pol.ring_ghost >= 0) G = pol.ring_ghost;
 		G = std::min(G, cfg->Y / 2) & ~1;
 		c->ghost_rows = G >= 2 ? G : 1;
 		if (c->ghost_rows > 1 && cfg->use_J) c->ham_ghost = c->ghost_rows + 1; // -J: the ghost rows' couplings are generated in place
@@ -444,8 +502,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	c->color_words = (size_t)cfg->Y * c->lld;
 	// lattices larger than the memory-side cache (256 MB = 2^31 spins at 1 bit per spin) stream through it: their words
 	// carry the non-temporal hint, which keeps the accept-mask slots in the L2s (ISING_FUSED_NT=0/1 overrides)
-	if (const char *e = getenv("ISING_FUSED_NT")) c->fused_nt = atoi(e) != 0;
-	else c->fused_nt = spins > (1LL << 31);
+	c->fused_nt = pol.fused_nt >= 0 ? pol.fused_nt : (spins > (1LL << 31));
 	if (fused_shape || deep_ring) { // workgroups per CU of a fused launch (the chip holds 6 of 4 waves, 3 of 8)
 		const long long T = fused_tickets(c->nwc(), launch_rows, c->H, c->fused_wide != 0);
 		c->fused_wg_per_cu = c->fused_wide ? (T >= 2048 ? 3 : 2) : fused_wgs_for(T);
@@ -454,7 +511,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		// 79 (two).  ISING_FUSED_TICKETS2=0/2/4 overrides.
 		const long long T0 = fused_tickets(c->nwc(), cfg->Y, c->H, c->fused_wide != 0); // (without a ring slab's ghost rows)
 		c->fused_tickets2 = (!c->fused_wide && T0 <= 2048 && c->H == 1) ? 4 : ((!c->fused_wide && T0 <= 1024 && c->H == 2) ? 2 : 0);
-		if (const char *e2 = getenv("ISING_FUSED_TICKETS2")) { const int k = atoi(e2); c->fused_tickets2 = (k == 2 || k == 4) ? k : (k ? 2 : 0); }
+		if (pol.fused_tickets2 >= 0) c->fused_tickets2 = pol.fused_tickets2;
 	}
 
 	hipError_t e = hipSetDevice(cfg->device);
@@ -486,15 +543,11 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 			c->tail_rows = (int)std::min<long long>(rows, cfg->Y / 4 / c->H * c->H);
 			c->tail_h = 1;
 		}
-		if (const char *e = getenv("ISING_TAIL")) {
-			int rows = 0, h = 1;
-			const int got = sscanf(e, "%d,%d", &rows, &h);
-			if (got >= 1 && rows == 0) c->tail_rows = 0;
-			else if (got >= 1 && rows > 0 && h > 0 && rows % c->H == 0 && rows % h == 0 && h < c->H && 2 * rows < cfg->Y) { c->tail_rows = rows; c->tail_h = h; }
-		}
+		if (pol.tail_rows == 0) c->tail_rows = 0;
+		else if (pol.tail_rows > 0 && pol.tail_rows % c->H == 0 && pol.tail_rows % pol.tail_h == 0 && pol.tail_h < c->H && 2 * pol.tail_rows < cfg->Y) { c->tail_rows = pol.tail_rows; c->tail_h = pol.tail_h; }
 		const size_t strips = c->tail_rows ? (size_t)(cfg->Y - c->tail_rows) / c->H + (size_t)c->tail_rows / c->tail_h : (size_t)c->nstrips;
 		// (+ H: the flag-synchronised ring schedule may turn one more H-row strip into one-row strips, launch_ranges)
-		const size_t plain = (size_t)c->nwc() * (strips + 2 + (size_t)c->H) * 2048 + 16 * 2048, fused = (size_t)ising::ballot_max_wgs() * 4 * 2048;
+		const size_t plain = (size_t)c->nwc() * (strips + 2 + (size_t)c->H) * 2048 + 16 * 2048, fused = (size_t)ising::ballot_max_wgs(c->cus) * 4 * 2048;
 		e = hipMalloc((void **)&c->d_scratch, std::max(plain, fused));
 		// The ring's edge-row launches (two rows, comm stream) run next to the interior launch of the same colour (compute
 		// stream): slots of their own, or the two launches overwrite each other's accept masks -- which they did: the
@@ -504,6 +557,10 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		const size_t ctl_bytes = SLOTCTL_TICKET_BYTES + ((size_t)c->nstrips + 2 * (size_t)c->ghost_rows + 2) * sizeof(uint32_t); // (+ strips of the ghost rows)
 		if (e == hipSuccess) e = hipMalloc((void **)&c->d_slotctl, ctl_bytes);
 		if (e == hipSuccess) e = hipMemset(c->d_slotctl, 0, ctl_bytes);
+		c->slotctl_bytes = ctl_bytes;
+		// the word a fused launch that gives up raises (pinned: the host reads it without a copy, the kernel only when it waits)
+		if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_abort, 64, hipHostMallocMapped);
+		if (e == hipSuccess) memset(c->h_abort, 0, 64);
 
 	}
 	if (e == hipSuccess && cfg->use_J) {
@@ -528,6 +585,7 @@ int ising_destroy(ising_ctx *c) {
 	(void)hipSetDevice(c->cfg.device);
 	if (c->own_stream) { (void)hipStreamSynchronize(c->own_stream); (void)hipStreamDestroy(c->own_stream); }
 	if (c->h_meas) (void)hipHostFree(c->h_meas);
+	if (c->h_abort) (void)hipHostFree(c->h_abort);
 	ising_host::ring_release(c);
 	if (c->d_lat && !c->cfg.lattice_mem) (void)hipFree(c->d_lat);
 	if (c->d_acc) (void)hipFree(c->d_acc);
@@ -566,8 +624,7 @@ int ising_use_private_stream(ising_ctx *c) {
 int ising_synchronize(ising_ctx *c) {
 	if (!c) return fail(ISING_E_ARG, "null context");
 	if (int rc = bind(c)) return rc;
-	HIP_TRY(hipStreamSynchronize(c->stream));
-	return ISING_OK;
+	return ising_host::sync_checked(c);
 }
 
 int ising_init_lattice(ising_ctx *c) {
@@ -713,7 +770,11 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	if (c->ballot) {
 		p.ticket = reinterpret_cast<unsigned long long *>(c->d_slotctl);
 		p.nlevels = nlevels;
+		p.cus = c->cus;
 		if (nlevels > 1) {
+			p.grid_cap = c->pol.fused_wgs;
+			p.abort_flag = c->h_abort;
+			p.abort_polls = c->pol.abort_polls;
 			for (int k = 0; k < 4; k++) p.ticket_base2[k] = c->ticket_base2[k]; // (the counters are never reset, ising_ballot.hip)
 			p.tickets2 = c->fused_tickets2;
 			if (c->done_base > (1u << 30)) { // keep the monotone completion counters far from wrapping
@@ -731,8 +792,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			p.done_base = c->done_base;
 			if (lo0 < 0 || hi0 > c->cfg.Y) { // ghost rows are rows of the neighbouring slabs
 				p.total_rows = c->cfg.nslabs * c->cfg.Y;
-				static const bool trap = !(getenv("ISING_RING_TRAPEZOID") && atoi(getenv("ISING_RING_TRAPEZOID")) == 0);
-				p.trapezoid = trap ? 1 : 0;
+				p.trapezoid = c->pol.trapezoid ? 1 : 0;
 				if (overlap && c->d_edge) {
 					// the exchange touches the first / last G rows (read by the sends) and the ghost rows (written by the receives)
 					const int G = c->ghost();
@@ -769,7 +829,11 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			c->flag_target[mine] += units * (uint32_t)c->nwc();
 		}
 		int grid = 0;
-		HIP_TRY(ising::launch_ballot_update(p, c->stream, &grid, stop));
+		if (const hipError_t le = ising::launch_ballot_update(p, c->stream, &grid, stop); le != hipSuccess) {
+			// nothing ran: tickets and counters are where the launches before left them, but to be safe they start over
+			if (nlevels > 1) { __atomic_store_n(c->h_abort, 1u, __ATOMIC_RELEASE); (void)ising_host::check_abort(c); }
+			return fail(ISING_E_HIP, "kernel launch failed: %s", hipGetErrorString(le));
+		}
 		if (nlevels > 1) {
 			c->done_base += (uint32_t)nlevels * (uint32_t)c->nwc();
 			// where the launch leaves the counter(s): its units, and every workgroup drew one ticket too many
@@ -880,6 +944,7 @@ int ising_sweep_timed(ising_ctx *c, int first_it, int nsweeps, float *elapsed_ms
 		if (e == hipSuccess) e = hipEventSynchronize(e1);
 		if (e == hipSuccess) e = hipEventElapsedTime(elapsed_ms, e0, e1);
 		if (e != hipSuccess) rc = fail(ISING_E_HIP, "event timing failed: %s", hipGetErrorString(e));
+		else rc = ising_host::check_abort(c);
 	}
 	(void)hipEventDestroy(e0);
 	(void)hipEventDestroy(e1);
@@ -943,7 +1008,7 @@ int ising_count(ising_ctx *c, uint64_t *up, uint64_t *down) {
 	HIP_TRY(ising::launch_popcount(c->lat(ISING_WHITE), c->color_words, c->d_acc, c->stream));
 	unsigned long long h = 0;
 	HIP_TRY(hipMemcpyAsync(&h, c->d_acc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (int rc = ising_host::sync_checked(c)) return rc;
 	*up = h;
 	*down = (uint64_t)c->cfg.X * (uint64_t)c->cfg.Y - h; // SPIN_X_WORD - popc per word, optimized/main.cu:722-723
 	return ISING_OK;
@@ -967,7 +1032,7 @@ int ising_bond_equal(ising_ctx *c, int64_t *A) {
 	HIP_TRY(c->dense ? ising::launch_dense_bond_equal(p, c->stream) : ising::launch_bond_equal(p, c->stream));
 	unsigned long long h = 0;
 	HIP_TRY(hipMemcpyAsync(&h, c->d_acc + 1, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (int rc = ising_host::sync_checked(c)) return rc;
 	*A = (int64_t)h;
 	return ISING_OK;
 }
@@ -1004,13 +1069,24 @@ int ising_measure_fetch(ising_ctx *c, uint64_t *up, int64_t *bond_equal, int max
 	if (!c || !up || !bond_equal || !n || max_n < 0) return fail(ISING_E_ARG, "bad argument");
 	if (int rc = bind(c)) return rc;
 	if (c->meas_pending > max_n) return fail(ISING_E_ARG, "%d measurements pending, room for %d", c->meas_pending, max_n);
-	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (int rc = ising_host::sync_checked(c)) { c->meas_pending = 0; return rc; }
 	for (int i = 0; i < c->meas_pending; i++) {
 		up[i] = c->h_meas[2 * i];
 		bond_equal[i] = (int64_t)c->h_meas[2 * i + 1];
 	}
 	*n = c->meas_pending;
 	c->meas_pending = 0;
+	return ISING_OK;
+}
+
+// Test aid (tests/test_gpu_fused.py): what = 1 puts the host's idea of the completion counters out of step with the device,
+// as a faulted launch would leave it -- the next fused launch's units wait for counts that never come -- and lowers the
+// bound after which they give up to `arg` polls (0: keep).
+int ising_debug_fault(ising_ctx *c, int what, int arg) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (what != 1) return fail(ISING_E_ARG, "unknown fault %d", what);
+	c->done_base += 1u << 20;
+	if (arg > 0) c->pol.abort_polls = (uint32_t)arg;
 	return ISING_OK;
 }
 

@@ -11,8 +11,34 @@
 #include <cstddef>
 #include <cstdint>
 
+// A/B and test switches.  The environment is read ONCE per context, in ising_create, into this record; nothing
+// in the library calls getenv afterwards (ISING_RCCL_LIB, the path of the RCCL to open, is process-wide and read once).
+struct ising_policy {
+	int fused = -1;          // ISING_FUSED=0/1: one launch per colour / fused launches (-1: by lattice size)
+	int fused_wide = 0;      // ISING_FUSED_WIDE=1: 8-wave workgroups
+	int fused_nt = -1;       // ISING_FUSED_NT=0/1: non-temporal lattice words (-1: lattices above 2^31 spins)
+	int fused_tickets2 = -1; // ISING_FUSED_TICKETS2=0/2/4: ticket counters (-1: by strip height)
+	int fused_wgs = 0;       // ISING_FUSED_WGS=n: persistent grid of n workgroups (0: by tickets per level)
+	int ring_ghost = -1;     // ISING_RING_GHOST=n: ghost rows of ballot ring slabs (-1: 64)
+	bool no_ballot = false;  // ISING_NO_BALLOT: layout AUTO never picks the ballot layout
+	int tail_rows = -1, tail_h = 1; // ISING_TAIL=rows[,h]: one-row tail strips of one-launch-per-colour launches (-1: automatic, 0: off)
+	bool trapezoid = true;   // ISING_RING_TRAPEZOID=0: every ghost row at every level
+	bool overlap = true;     // ISING_RING_OVERLAP=0: the deep exchange between launches instead of next to them
+	int ring_inline = -1;    // ISING_RING_INLINE=0/1: peer copies on the comm / the compute stream (-1: by device placement)
+	int ring_store = -1;     // ISING_RING_STORE=0/1: never / always store edge rows into the neighbours' halo rows (-1: automatic)
+	bool ring_flags = false, ring_publish = false; // ISING_RING_FLAGS=1, ISING_RING_PUBLISH=1: alternative one-row schedules
+	bool comm_priority = true;                     // ISING_RING_COMM_PRIORITY=0: comm streams at default priority
+	int ring_transport = 0;  // ISING_RING_TRANSPORT=copy/rccl/auto -> ISING_TRANSPORT_*
+	uint32_t abort_polls = 1u << 22; // ISING_ABORT_POLLS: polls (~2.5 us each) a unit of a fused launch waits for its parents before it
+	                                 // gives the launch up (~10 s: nothing legitimate waits a level's time that long)
+};
+
 struct ising_ctx {
 	ising_config cfg{};
+	ising_policy pol{};
+	int cus = 256;                 // compute units of the slab's device
+	uint32_t *h_abort = nullptr;   // pinned, device-visible: [0] != 0 = a fused launch gave up (or the host wants the polling kernels to);
+	                               // checked after every synchronise (ising_host::sync_checked)
 	bool dense = false; // 1 bit per spin on the device (ising_dense.hip); false = the reference's nibble layout
 	bool ballot = false; // dense, with the bits of a row in wave-ballot order (ising_ballot.hip)
 	uint64_t *d_tmp = nullptr;     // ballot layout: dense-order image of d_lat (same shape) for conversions and observables;
@@ -21,6 +47,7 @@ struct ising_ctx {
 	uint64_t *d_scratch_edge = nullptr; // ... of the ring's edge-row launches, which run on the comm stream NEXT TO an interior launch
 	bool edge_scratch_next = false;     // the next launch is such a one (set by update_edges_on, cleared by launch_ranges)
 	uint32_t *d_slotctl = nullptr; // ballot layout, fused launches: ticket words (576 bytes) + per-strip completion counters
+	size_t slotctl_bytes = 0;
 	uint32_t done_base = 0;        // value of every completion counter once everything launched so far has run
 	bool fused = false;            // ising_sweep batches colour half-sweeps into fused launches
 	int fused_wide = 0;            // ... with 512-thread workgroups
@@ -158,6 +185,12 @@ int update_full_published(ising_ctx *c, int it, int color);
 int update_deep(ising_ctx *c, int it, int nlevels, bool overlapped = false);
 // called by ising_destroy
 void ring_release(ising_ctx *c);
+// hipStreamSynchronize(c->stream), then: did a fused launch give up (completion counters that never came: UpdateParams.abort_flag)?
+// If so its tickets, counters and their host-side bases start from zero again and ISING_E_STATE is returned.
+int sync_checked(ising_ctx *c);
+int check_abort(ising_ctx *c);
+// the switches of DESIGN 8a from the environment (ISING_E_ARG for a value that means nothing)
+int read_policy(ising_policy *pol);
 // launch shape of fused launches by tickets per level (ising_capi.cpp)
 void fused_shape(int nwc, int Y, long long rows, int *H, int *wg_per_cu);
 constexpr size_t SLOTCTL_TICKET_BYTES = 9 * 64; // ticket words in front of the completion counters (d_slotctl)

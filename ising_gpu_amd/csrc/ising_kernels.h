@@ -79,6 +79,13 @@ struct UpdateParams {
 	// level of 128 .. 1024 tickets) fill the chip with tall strips.  Per lattice: a 32-byte record in device memory (both
 	// colours' row-0 pointers, its accept thresholds, its seed) read with one scalar load per unit; completion counters
 	// done + r * done_stride; lattice words, mirror offsets, iteration and everything else as in the single launch.
+	// fused launches: a unit that has polled its parents' counters abort_polls times sets *abort_flag (pinned host memory) and
+	// leaves, as does every unit that finds it set (looked at every 64th poll): a launch whose counters can never arrive
+	// -- bases out of step after a faulted launch -- ends within seconds instead of at the watchdog (NULL: polls for ever)
+	uint32_t *abort_flag;
+	uint32_t abort_polls;
+	int32_t cus;              // compute units of the device: workgroup b of a persistent grid is in dispatch round b / cus (host: 0 = ask)
+	int32_t grid_cap;         // fused: explicit size of the persistent grid (tests, A/B; 0: by wg_per_cu; host side only)
 	const struct ReplicaParams *rep;
 	int32_t nrep, nwg_rep;
 	uint32_t rep_magic;       // ceil(2^32 / nwg_rep)
@@ -162,7 +169,7 @@ hipError_t launch_packed_to_dense(const uint64_t *packed, uint32_t *dense, size_
 void ballot_trace_dump(); // measurement builds only (ising_ballot.hip)
 #endif
 hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_out, hipEvent_t stop = nullptr);
-int ballot_max_wgs();
+int ballot_max_wgs(int cus); // upper bound of the grid of any ballot launch (scratch sizing)
 // up-spin count and black-site bond sum of `nrep` ballot lattices (gx, Y each; reps[r].lat[]), spread over BALLOT_MEASURE_SLOTS
 // accumulator pairs per lattice, 64 bytes apart: acc[(r * SLOTS + s) * 8 + {0, 1}]
 constexpr int BALLOT_MEASURE_SLOTS = 16;

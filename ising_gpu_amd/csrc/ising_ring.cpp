@@ -328,14 +328,12 @@ int ring_resources(ising_ctx *c) {
 	if (!c->comm) {
 		int least = 0, greatest = 0; // numerically lower = higher priority
 		HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-		const char *pe = getenv("ISING_RING_COMM_PRIORITY"); // A/B: 0 = default priority instead of the highest
-		HIP_TRY(hipStreamCreateWithPriority(&c->comm, hipStreamNonBlocking, (pe && atoi(pe) == 0) ? 0 : greatest));
+		HIP_TRY(hipStreamCreateWithPriority(&c->comm, hipStreamNonBlocking, c->pol.comm_priority ? greatest : 0)); // (A/B: default priority instead of the highest)
 	}
 	int can_wait = 0;
 	if (hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, c->cfg.device) != hipSuccess) { can_wait = 0; (void)hipGetLastError(); }
 	// A/B, off by default: measured 1-2 % SLOWER than the two-row launch on the comm stream (tools/ring_of_one_probe.py)
-	const char *pub_env = getenv("ISING_RING_PUBLISH");
-	can_wait = can_wait && pub_env && atoi(pub_env) != 0;
+	can_wait = can_wait && c->pol.ring_publish;
 	for (int k = 0; k < 2 && can_wait && c->ballot && !c->d_signal[k]; k++) {
 		void *p = nullptr;
 		if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) != hipSuccess) { (void)hipGetLastError(); break; }
@@ -437,7 +435,7 @@ void decide_copy_lanes(ising_ctx **ctxs, int n) {
 		ising_ctx *c = ctxs[k];
 		ring_enable_peers(c);
 		c->copy_inline = c->ring_prev->cfg.device == c->cfg.device && c->ring_next->cfg.device == c->cfg.device;
-		if (const char *e = getenv("ISING_RING_INLINE")) c->copy_inline = c->copy_inline && atoi(e) != 0; // 0: exercise the two-stream schedule on one device
+		if (c->pol.ring_inline >= 0) c->copy_inline = c->copy_inline && c->pol.ring_inline != 0; // 0: exercise the two-stream schedule on one device
 	}
 	// All slabs on one device and one stream (the test configurations; `cuIsing -d N --devmap 0,0,...`): the stream
 	// orders everything, so a launch can write rows 0 / Y-1 straight into the neighbours' halo rows.
@@ -448,7 +446,7 @@ void decide_copy_lanes(ising_ctx **ctxs, int n) {
 	// direct stores are for slabs without them (dense / nibble layouts, caller-owned buffers).  ISING_RING_STORE=0/1 forces.
 	bool ghosts = true;
 	for (int k = 0; k < n; k++) ghosts = ghosts && ctxs[k]->ballot && ctxs[k]->ghost() > 1 && !ctxs[k]->cfg.XSL;
-	if (const char *e = getenv("ISING_RING_STORE")) one = one && atoi(e) != 0;
+	if (ctxs[0]->pol.ring_store >= 0) one = one && ctxs[0]->pol.ring_store != 0;
 	else one = one && !ghosts;
 	for (int k = 0; k < n; k++) ctxs[k]->store_ring = one;
 }
@@ -468,13 +466,7 @@ int ring_bind(ising_ctx **ctxs, int n, int want = ISING_TRANSPORT_AUTO) {
 		if (ctxs[0]->transport == ISING_TRANSPORT_COPY) decide_copy_lanes(ctxs, n);
 		return ISING_OK;
 	}
-	if (want == ISING_TRANSPORT_AUTO) {
-		if (const char *env = getenv("ISING_RING_TRANSPORT")) {
-			if (!strcmp(env, "copy")) want = ISING_TRANSPORT_COPY;
-			else if (!strcmp(env, "rccl")) want = ISING_TRANSPORT_RCCL;
-			else if (strcmp(env, "auto")) return fail(ISING_E_ARG, "ISING_RING_TRANSPORT must be auto, copy or rccl (got %s)", env);
-		}
-	}
+	if (want == ISING_TRANSPORT_AUTO) want = ctxs[0]->pol.ring_transport; // (ISING_RING_TRANSPORT, as read when slab 0 was created)
 	if (want == ISING_TRANSPORT_IPC) return fail(ISING_E_ARG, "the IPC transport serves one slab per process (ising_ipc_export / ising_ipc_attach)");
 	int use = want;
 	if (want == ISING_TRANSPORT_AUTO) use = (n > 1 && devices_distinct(ctxs, n) && rccl()) ? ISING_TRANSPORT_RCCL : ISING_TRANSPORT_COPY;
@@ -842,7 +834,7 @@ int sweep_deep_overlapped(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 			ising_ctx *c = ctxs[k];
 			if (int rc = bind(c)) return rc;
 			hipLaunchKernelGGL(counter_wait_k, dim3(1), dim3(64), 0, c->comm, (const uint32_t *)c->d_edge, c->edge_done_target,
-			                   (const uint32_t *)(c->ipc ? c->ipc->mine_abort : nullptr));
+			                   (const uint32_t *)c->h_abort); // (a launch that gave up never brings the counter there)
 			HIP_TRY(hipGetLastError());
 			// this slab's launches are done with its ghost rows: the neighbours may overwrite them
 			if (ipc) for (int color = 0; color < 2; color++) if (int rc = ipc_release_ghosts(c, color, c->comm)) return rc;
@@ -870,8 +862,7 @@ int sweep_local(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 		bool deep = nsweeps > 0 && !ctxs[0]->store_ring && !ctxs[0]->cfg.XSL && ctxs[0]->ghost() > 1;
 		for (int k = 0; k < n; k++) deep = deep && ctxs[k]->ballot && ctxs[k]->ghost() == ctxs[0]->ghost() && !ising_host::needs_generic(ctxs[k]) && !ctxs[k]->store_ring;
 		// the exchange overlaps with the launches where the rows travel on the slabs' comm streams (ISING_RING_OVERLAP=0: between launches)
-		static const bool overlap_on = !(getenv("ISING_RING_OVERLAP") && atoi(getenv("ISING_RING_OVERLAP")) == 0);
-		bool overlap = deep && overlap_on;
+		bool overlap = deep && ctxs[0]->pol.overlap;
 		for (int k = 0; k < n; k++) overlap = overlap && !ctxs[k]->copy_inline && ctxs[k]->d_edge && ctxs[k]->comm;
 		if (overlap) return sweep_deep_overlapped(ctxs, n, first_it, nsweeps);
 		if (deep) return sweep_deep(ctxs, n, first_it, nsweeps);
@@ -885,9 +876,7 @@ int sweep_local(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 	bool two = nsweeps > 0 && !ctxs[0]->copy_inline && !ctxs[0]->cfg.XSL, pub = two;
 	for (int k = 0; k < n; k++) pub = pub && ctxs[k]->ballot && ctxs[k]->d_signal[0] && ctxs[k]->d_signal[1] && ctxs[k]->edge_target[0] < (1u << 30);
 	if (pub) return sweep_published(ctxs, n, first_it, nsweeps);
-	bool flags = two;
-	if (const char *e = getenv("ISING_RING_FLAGS")) flags = flags && atoi(e) != 0;
-	else flags = false; // (opt-in until measured)
+	bool flags = two && ctxs[0]->pol.ring_flags; // (opt-in: measured, no gain)
 	for (int k = 0; k < n; k++) flags = flags && ctxs[k]->ballot && ctxs[k]->d_flags && ctxs[k]->cfg.Y >= 4 && !ising_host::needs_generic(ctxs[k]);
 	if (flags) return sweep_flagged(ctxs, n, first_it, nsweeps);
 	if (two) return sweep_two_streams(ctxs, n, first_it, nsweeps);
@@ -905,7 +894,7 @@ int sync_both(ising_ctx *c) {
 	if (int rc = bind(c)) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	if (c->comm) HIP_TRY(hipStreamSynchronize(c->comm));
-	return ISING_OK;
+	return ising_host::check_abort(c);
 }
 
 // -J: black couplings everywhere, their edge rows to the neighbours, then the white couplings (which gather from them)

@@ -200,6 +200,10 @@ class IsingSlab:
         self.it += n
         return self
 
+    def debug_fault(self, what: int = 1, arg: int = 0):
+        """Test aid (ising_debug_fault): leave the host's record of the completion counters out of step with the device."""
+        check(self._lib.ising_debug_fault(self._h, what, arg))
+
     def device_ptr(self, color: int):
         p, nb = C.c_void_p(), C.c_size_t()
         check(self._lib.ising_device_ptr(self._h, color, C.byref(p), C.byref(nb)))

@@ -150,3 +150,46 @@ def test_bench_ring_code_path_with_one_rank(gpu, oracle_mod, ring, port, exchang
     assert b["config"]["exchange"] == exchange and b["config"]["nranks"] == 1
     orc = oracle_mod.OracleLattice(8192, 8192, seed=1234, temp=oracle_mod.CRIT_TEMP).init().sweep(6)
     assert (b["config"]["up"], b["config"]["down"]) == orc.count() and b["config"]["rank_up"] == [orc.count()[0]]
+
+
+def test_fused_launch_gives_up_instead_of_hanging(gpu, oracle_mod, monkeypatch):
+    """Completion counters that can never arrive (the host's bases out of step with the device, as after a faulted launch):
+    the units' polls are bounded, the launch ends, the next synchronise reports ISING_E_STATE within a second -- not the
+    watchdog --, tickets and counters start over and the slab sweeps correctly again."""
+    import time
+    from ising_gpu_amd import _lib
+    monkeypatch.setenv("ISING_FUSED", "1")
+    X, Y, seed = 8192, 2048, 31
+    with ig.IsingSlab(X, Y, seed=seed, temp=ig.CRIT_TEMP_F32, layout=ig.LAYOUT_BALLOT) as s:
+        assert s.fused
+        s.init().sweep(3)
+        s.synchronize()
+        s.debug_fault(1, 1 << 13)  # level 1 waits for counts 2^20 too high; give up after 8192 polls (a few tens of ms)
+        t0 = time.perf_counter()
+        s.sweep(4)
+        with pytest.raises(ig.IsingError) as e:
+            s.synchronize()
+        assert e.value.code == _lib.E_STATE and "gave up" in str(e.value)
+        assert time.perf_counter() - t0 < 1.0
+        s.synchronize()  # the error was consumed, the context is usable
+        orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=oracle_mod.CRIT_TEMP).init().sweep(5)
+        s.init().sweep(5)
+        assert np.array_equal(s.read(ig.BLACK), orc.black) and np.array_equal(s.read(ig.WHITE), orc.white)
+        assert s.count() == orc.count()
+    # the same through a blocking observable, on a batch
+    slabs = [ig.IsingSlab(X, 256, seed=k, temp=2.0, layout=ig.LAYOUT_BALLOT) for k in (1, 2)]
+    with ig.IsingBatch(slabs) as b:
+        b.init().sweep(2)
+        slabs[0].synchronize()
+        slabs[0].debug_fault(1, 1 << 13)
+        b.sweep(2)  # (the batch has counters of its own: nothing wrong with them, this launch completes)
+        b.measure_enqueue()
+        assert len(b.measure_fetch()) == 1
+        slabs[0].it = 4
+        slabs[0].sweep(2)  # member 0 alone, on ITS counters: gives up
+        with pytest.raises(ig.IsingError):
+            slabs[0].count()
+        slabs[0].init().sweep(1)
+        assert slabs[0].count() == oracle_mod.OracleLattice(X, 256, seed=1, temp=2.0).init().sweep(1).count()
+    for s in slabs:
+        s.close()
