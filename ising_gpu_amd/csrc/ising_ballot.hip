@@ -416,15 +416,21 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				if (__all((int32_t)(seen - need) >= 0)) break;
 				// counters that never come (bases out of step with the device after a faulted launch): give the launch up.  The
 				// flag lives in pinned host memory -- the host sees it at its next synchronise -- and is looked at every 64th poll.
-				if (p.abort_flag != nullptr && (++npoll & 63u) == 0u) {
-					uint32_t ab = 0;
-					if (npoll >= p.abort_polls) { ab = 1u; if (lane == 0) __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-					else ab = __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-					if (uni(ab) != 0u) {
-						// no ticket is handed on by this workgroup any more: whoever reads the slots finds the work gone (the barriers
-						// of the row loop count the waves that are still there)
-						if (lane == 0) ticket_sh[0] = ticket_sh[1] = ~0ull;
-						__builtin_amdgcn_endpgm();
+				// Counters that never come (bases out of step with the device after a faulted launch): stop waiting.  The unit
+				// that has polled abort_polls times raises a flag in pinned host memory, every waiting unit looks at it every 64th
+				// poll, and whoever finds it set goes on as if its parents were done: the launch runs to its end at full speed on
+				// a lattice that is garbage from here on, and the host finds the flag at its next synchronise.  (The two
+				// parameters are fetched from the kernel arguments here, not at kernel entry: two scalar registers less to keep
+				// alive through the row loop, which is short of them.)
+				if ((++npoll & 63u) == 0u) {
+					uint64_t fp;
+					uint32_t bound;
+					asm volatile("s_load_dwordx2 %0, %2, %3\n\ts_load_dword %1, %2, %4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(fp), "=&s"(bound)
+					             : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(offsetof(UpdateParams, abort_flag)), "n"(offsetof(UpdateParams, abort_polls)) : "memory");
+					uint32_t *flag = reinterpret_cast<uint32_t *>(fp);
+					if (flag != nullptr) {
+						if (npoll >= bound && lane == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+						if (npoll >= bound || uni(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0u) break;
 					}
 				}
 				TRN(9, 1);
@@ -455,9 +461,11 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				if (lane == 0) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(got) : "v"(p.edge_go) : "memory");
 				if (__all((int32_t)(got - p.edge_go_need) >= 0)) break;
 				// (no bound of its own -- a neighbour may be seconds behind --, but the host can call the launch off)
-				if (p.abort_flag != nullptr && (++ngo & 63u) == 0u && uni(__hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0u) {
-					if (lane == 0) ticket_sh[0] = ticket_sh[1] = ~0ull;
-					__builtin_amdgcn_endpgm();
+				if ((++ngo & 63u) == 0u) {
+					uint64_t fp;
+					asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(fp) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(offsetof(UpdateParams, abort_flag)) : "memory");
+					const uint32_t *flag = reinterpret_cast<const uint32_t *>(fp);
+					if (flag != nullptr && uni(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0u) break;
 				}
 				__builtin_amdgcn_s_sleep(127);
 			}

@@ -80,8 +80,8 @@ struct UpdateParams {
 	// colours' row-0 pointers, its accept thresholds, its seed) read with one scalar load per unit; completion counters
 	// done + r * done_stride; lattice words, mirror offsets, iteration and everything else as in the single launch.
 	// fused launches: a unit that has polled its parents' counters abort_polls times sets *abort_flag (pinned host memory) and
-	// leaves, as does every unit that finds it set (looked at every 64th poll): a launch whose counters can never arrive
-	// -- bases out of step after a faulted launch -- ends within seconds instead of at the watchdog (NULL: polls for ever)
+	// stops waiting, as does every unit that finds it set (looked at every 64th poll): a launch whose counters can never
+	// arrive -- bases out of step after a faulted launch -- runs to its end instead of to the watchdog (NULL: polls for ever)
 	uint32_t *abort_flag;
 	uint32_t abort_polls;
 	int32_t cus;              // compute units of the device: workgroup b of a persistent grid is in dispatch round b / cus (host: 0 = ask)
