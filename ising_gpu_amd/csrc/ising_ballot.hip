@@ -175,6 +175,7 @@ typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 template <bool SUBL, bool USEJ, bool FUSED, int NT = BAL_THREADS, bool STREAM = false, bool BATCH = false>
 __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const UpdateParams p) {
 	static_assert(!BATCH || (FUSED && !SUBL && !USEJ), "batched launches: fused, no sub-lattices, no couplings");
+	static_assert(!(FUSED && SUBL && USEJ), "fused launches with sub-lattices: no couplings");
 	const int lane = threadIdx.x & 63;
 	const int tx = threadIdx.x & (GROUP - 1), g = (threadIdx.x >> 4) & 3;
 	const int wi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -398,7 +399,12 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		TRC(1); // unit decode
 		if (must_wait) {
 			int sd = sidx + (lane == 0 ? -1 : (lane == 1 ? 0 : 1));
-			sd = sd < 0 ? sd + nstr : (sd >= nstr ? sd - nstr : sd);
+			if (SUBL) { // rows are periodic every slY rows (a multiple of the strip height): the neighbours wrap inside the sub-lattice's strips
+				const int nb = p.slY / p.H, lo = sidx - sidx % nb;
+				sd = sd < lo ? sd + nb : (sd >= lo + nb ? sd - nb : sd);
+			} else {
+				sd = sd < 0 ? sd + nstr : (sd >= nstr ? sd - nstr : sd);
+			}
 			dp = p.done + (BATCH ? rep * p.done_stride : 0) + sd;
 			// (inline assembly like the row loop's loads: a tracked load here makes the compiler guard `seen`'s register with
 			// vmcnt(0) waits all through the row loop)
@@ -493,7 +499,9 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		uint64_t up0 = 0, ct0 = 0;
 		if (!idle) {
 			if (FUSED) {
-				ld64_coh_issue<STREAM>(up0, rs - wpr, lane * 8);
+				// (sub-lattices, fused: strips never straddle a period -- slY is a multiple of H --, so the row above a strip's
+				// first row is the only one that may lie a period away, :414)
+				ld64_coh_issue<STREAM>(up0, rs + ((SUBL && r0_in_sl == 0) ? (ptrdiff_t)(slY - 1) * wpr : -(ptrdiff_t)wpr), lane * 8);
 				ld64_coh_issue<STREAM>(ct0, rs, lane * 8);
 			} else {
 				up = ld_word<false>(rs + lane + ((SUBL && r0_in_sl == 0) ? (ptrdiff_t)(slY - 1) * wpr : -(ptrdiff_t)wpr));
@@ -600,7 +608,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				const bool sl_last = SUBL && seam == 1; // the row below is the period's first row (:422)
 				uint64_t dw, me;
 				if (FUSED) {
-					ld64_coh_issue<STREAM>(dw, rs + wpr, lane * 8);
+					ld64_coh_issue<STREAM>(dw, rs + (sl_last ? (ptrdiff_t)(1 - slY) * wpr : (ptrdiff_t)wpr), lane * 8);
 					ld64_coh_issue<STREAM>(me, rd, lane * 8);
 					// everything older than this phase's three loads: the word from the neighbouring wave column, in a unit's
 					// first word phase also its first two rows
@@ -1003,7 +1011,7 @@ __global__ void __launch_bounds__(THREADS) ham_ballot_to_planes_k(uint64_t *__re
 // (contexts may be driven from several host threads, one each: the cache is filled under a lock)
 static int ballot_resident_wgs(int v, const void *fn, int threads, int cus) {
 	static std::mutex mu;
-	static int cache[16][32];
+	static int cache[16][64];
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
 	std::lock_guard<std::mutex> lock(mu);
@@ -1023,27 +1031,37 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	const bool fused = p.nlevels > 1;
 	const bool usej = fused ? p.jham[0] != nullptr : p.jdst != nullptr;
 	const bool subl = p.slY != 0;
-	const void *fn;
 	const bool streamed = fused && p.nt_stream && NT == BAL_THREADS; // (8-wave workgroups serve lattices that fit the cache)
 	const bool batch = fused && p.nrep > 0;
 	if (batch && (usej || subl || NT != BAL_THREADS)) return hipErrorInvalidValue;
+	if (fused && subl && (usej || NT != BAL_THREADS || p.slY % p.H != 0)) return hipErrorInvalidValue; // (ising_capi.cpp keeps those on one launch per colour)
 	if (batch) { // a level = the units of all lattices
 		p.nwg_rep = p.nwg;
 		p.nwg = p.nwg_rep * p.nrep;
 		p.rep_magic = (uint32_t)((0x100000000ull + (unsigned long long)p.nwg_rep - 1) / (unsigned long long)p.nwg_rep);
 	}
-	const int v = batch ? (streamed ? 9 : 8) : ((streamed ? 6 : (fused ? 4 : 0)) | (subl ? 2 : 0) | (usej ? 1 : 0));
+	// kernel instance: bit 0 couplings, 1 sub-lattices, 2 fused, 3 non-temporal lattice words, 4 batched
+	const int v = (usej ? 1 : 0) | (subl ? 2 : 0) | (fused ? 4 : 0) | (streamed ? 8 : 0) | (batch ? 16 : 0);
+	// (the launch is `LAUNCH(instance)`: hipExtLaunchKernelGGL needs the template arguments as written)
+#define BAL_INSTANCES(X)                                                                                              \
+	X(0, (ballot_update_k<false, false, false, NT>))                                                                   \
+	X(1, (ballot_update_k<false, true, false, NT>))                                                                    \
+	X(2, (ballot_update_k<true, false, false, NT>))                                                                    \
+	X(3, (ballot_update_k<true, true, false, NT>))                                                                     \
+	X(4, (ballot_update_k<false, false, true, NT>))                                                                    \
+	X(5, (ballot_update_k<false, true, true, NT>))                                                                     \
+	X(6, (ballot_update_k<true, false, true, BAL_THREADS>))                                                            \
+	X(12, (ballot_update_k<false, false, true, BAL_THREADS, true>))                                                    \
+	X(13, (ballot_update_k<false, true, true, BAL_THREADS, true>))                                                     \
+	X(14, (ballot_update_k<true, false, true, BAL_THREADS, true>))                                                     \
+	X(20, (ballot_update_k<false, false, true, BAL_THREADS, false, true>))                                             \
+	X(28, (ballot_update_k<false, false, true, BAL_THREADS, true, true>))
+	const void *fn = nullptr;
 	switch (v) {
-	case 8: fn = (const void *)ballot_update_k<false, false, true, BAL_THREADS, false, true>; break;
-	case 9: fn = (const void *)ballot_update_k<false, false, true, BAL_THREADS, true, true>; break;
-	case 0: fn = (const void *)ballot_update_k<false, false, false, NT>; break;
-	case 1: fn = (const void *)ballot_update_k<false, true, false, NT>; break;
-	case 2: fn = (const void *)ballot_update_k<true, false, false, NT>; break;
-	case 3: fn = (const void *)ballot_update_k<true, true, false, NT>; break;
-	case 4: fn = (const void *)ballot_update_k<false, false, true, NT>; break;
-	case 5: fn = (const void *)ballot_update_k<false, true, true, NT>; break;
-	case 6: fn = (const void *)ballot_update_k<false, false, true, BAL_THREADS, true>; break;
-	default: fn = (const void *)ballot_update_k<false, true, true, BAL_THREADS, true>; break;
+#define BAL_FN(code, inst) case code: fn = (const void *)inst; break;
+	BAL_INSTANCES(BAL_FN)
+#undef BAL_FN
+	default: return hipErrorInvalidValue;
 	}
 	// Plain launches: one workgroup per unit, handed out by the hardware dispatcher (a persistent grid striding over the
 	// units runs all workgroups in lockstep -- every wave in its draw phase, then every wave in its word phase -- and
@@ -1056,7 +1074,7 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 		p.cus = n;
 	}
 	const int cus = p.cus;
-	long long grid = fused ? std::min<long long>(std::min(ballot_resident_wgs(v + (NT == 256 ? 0 : 16), fn, NT, cus), ballot_max_wgs(cus) * 256 / NT), total) : total;
+	long long grid = fused ? std::min<long long>(std::min(ballot_resident_wgs(v + (NT == 256 ? 0 : 32), fn, NT, cus), ballot_max_wgs(cus) * 256 / NT), total) : total;
 	if (fused) {
 		// Fewer workgroups than the chip holds when a level has few tickets: a unit's parents are one level = p.nwg tickets
 		// back, and a workgroup that finds them unfinished holds its slot asleep (ising_create picks wg_per_cu)
@@ -1069,17 +1087,12 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	// `stop`: an event that fires when this launch is done, hung on the dispatch packet itself (hipExtLaunchKernelGGL) --
 	// a hipEventRecord behind the launch is a packet of its own that drains the queue: 7 us between two 650 us launches
 	switch (v) {
-	case 8: hipExtLaunchKernelGGL((ballot_update_k<false, false, true, BAL_THREADS, false, true>), g, block, 0, stream, nullptr, stop, 0, p); break;
-	case 9: hipExtLaunchKernelGGL((ballot_update_k<false, false, true, BAL_THREADS, true, true>), g, block, 0, stream, nullptr, stop, 0, p); break;
-	case 0: hipExtLaunchKernelGGL((ballot_update_k<false, false, false, NT>), g, block, 0, stream, nullptr, stop, 0, p); break;
-	case 1: hipExtLaunchKernelGGL((ballot_update_k<false, true, false, NT>), g, block, 0, stream, nullptr, stop, 0, p); break;
-	case 2: hipExtLaunchKernelGGL((ballot_update_k<true, false, false, NT>), g, block, 0, stream, nullptr, stop, 0, p); break;
-	case 3: hipExtLaunchKernelGGL((ballot_update_k<true, true, false, NT>), g, block, 0, stream, nullptr, stop, 0, p); break;
-	case 4: hipExtLaunchKernelGGL((ballot_update_k<false, false, true, NT>), g, block, 0, stream, nullptr, stop, 0, p); break;
-	case 5: hipExtLaunchKernelGGL((ballot_update_k<false, true, true, NT>), g, block, 0, stream, nullptr, stop, 0, p); break;
-	case 6: hipExtLaunchKernelGGL((ballot_update_k<false, false, true, BAL_THREADS, true>), g, block, 0, stream, nullptr, stop, 0, p); break;
-	default: hipExtLaunchKernelGGL((ballot_update_k<false, true, true, BAL_THREADS, true>), g, block, 0, stream, nullptr, stop, 0, p); break;
+#define BAL_LAUNCH(code, inst) case code: hipExtLaunchKernelGGL(inst, g, block, 0, stream, nullptr, stop, 0, p); break;
+	BAL_INSTANCES(BAL_LAUNCH)
+#undef BAL_LAUNCH
+	default: return hipErrorInvalidValue;
 	}
+#undef BAL_INSTANCES
 	if (grid_out) *grid_out = (int)grid;
 	return hipGetLastError();
 }
@@ -1122,7 +1135,7 @@ hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_o
 	if (grid_out) *grid_out = 0;
 	if (p.nunits <= 0) return stop ? hipEventRecord(stop, stream) : hipSuccess;
 	if (p.nlevels < 1) p.nlevels = 1;
-	if (p.nlevels > 1 && p.slY != 0) return hipErrorInvalidValue; // a sub-lattice seam reaches beyond the neighbouring strips
+	if (p.nlevels > 1 && p.slY != 0 && p.wide) return hipErrorInvalidValue; // (sub-lattices: 4-wave workgroups only)
 	// 8-wave workgroups for fused launches (ising_create: lattices of ~2^27 spins; ISING_FUSED_WIDE=0/1): half the tickets
 	// per row of work
 	if (p.nlevels > 1 && p.wide) return launch_ballot_update_nt<512>(p, stream, grid_out, stop);

@@ -456,7 +456,9 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// wanted two to four times as many tickets a level and ran 3082 at 16384^2, 3479 at 65536^2.)
 	// ISING_FUSED=0/1, ISING_FUSED_WIDE=0/1, cfg.strip_rows and ISING_FUSED_WGS (grid) override.
 	const long long spins = (long long)cfg->X * cfg->Y;
-	const bool fused_can = c->wrap && !cfg->XSL;
+	// (sub-lattices: every XSL x YSL block is a periodic system of its own -- nothing crosses slabs, so ring slabs qualify too --;
+	// their strips must not straddle a block, and the fused kernels carry no couplings next to sub-lattices)
+	const bool fused_can = cfg->XSL ? !cfg->use_J : c->wrap;
 
 	// (rows of a million columns and more -- 128 wave columns -- run 1-2 % faster one launch per colour, whatever their number:
 	// 1048576 x 65536 3461 vs 3429 fused, x 524288 3536 vs 3465, 2097152 x 131072 3464 vs 3397; 524288 x 1048576 3484 vs 3513;
@@ -465,7 +467,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// and level, all at about the same time, and three polls per unit of the next)
 	// (from 768 tickets a level: 8192 x 3072 1834 vs the dense layout's 1658; 8192 x 2048, 512 tickets: 1330 vs 1416)
 	c->fused = pol.fused >= 0 ? pol.fused != 0 : (spins >= 3 * (1LL << 23) && c->nwc() < 128);
-	c->fused_wide = pol.fused_wide; // (8-wave workgroups: an A/B switch since the priorities rotate; 16384 x 8192: 3070 vs 3040 with 4 waves)
+	c->fused_wide = cfg->XSL ? 0 : pol.fused_wide; // (8-wave workgroups: an A/B switch since the priorities rotate; 16384 x 8192: 3070 vs 3040 with 4 waves)
 	// AUTO: the ballot kernel's two-phase row pipeline wins from 2^27 spins per slab up -- from 2^25 where fused launches
 	// apply (a slab that wraps in place, a ring slab that can keep ghost rows); below, the dense kernel is ahead.  (A partly dead last wave column wastes its
 	// dead lanes' draws: worth it while they are under a tenth of the row -- the dense kernel is 12 % behind.)
@@ -495,7 +497,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// (its fused launches take the shape a single slab of Y + 2 G rows would)
 	const int launch_rows = deep_ring ? cfg->Y + 2 * c->ghost_rows : cfg->Y;
 	c->H = cfg->strip_rows > 0 ? cfg->strip_rows
-	       : ((fused_shape || deep_ring) ? (c->fused_wide ? ((cfg->Y % 2) == 0 ? 2 : 1) : choose_fused_strip_rows(c->nwc(), cfg->Y, launch_rows))
+	       : ((fused_shape || deep_ring) ? (c->fused_wide ? ((cfg->Y % 2) == 0 ? 2 : 1) : choose_fused_strip_rows(c->nwc(), cfg->XSL ? cfg->YSL : cfg->Y, launch_rows))
 	                                     : choose_strip_rows(c->gx, cfg->Y, c->dense, c->ballot));
 	if (cfg->Y % c->H) { const int h = c->H; delete c; return fail(ISING_E_ARG, "strip_rows %d does not divide Y %d", h, cfg->Y); }
 	c->nstrips = cfg->Y / c->H;
@@ -899,13 +901,25 @@ int ising_host::update_full_published(ising_ctx *c, int it, int color) {
 	return launch_ranges(c, it, color, 0, c->cfg.Y, 0, 0, 1, true);
 }
 
-extern "C" {
 
-int ising_sweep(ising_ctx *c, int first_it, int nsweeps) {
+// fused launches carry this slab's sweeps (ballot layout, integer thresholds; with sub-lattices: strips inside the blocks, no couplings)
+static bool sweeps_fused(const ising_ctx *c) {
+	if (!c->ballot || !c->fused || ising_host::needs_generic(c)) return false;
+	if (c->cfg.XSL) return !c->cfg.use_J && !c->fused_wide && (c->cfg.YSL % c->H) == 0;
+	return c->wrap;
+}
+
+extern "C" int ising_sweep(ising_ctx *c, int first_it, int nsweeps) {
 	if (!c) return fail(ISING_E_ARG, "null context");
 	if (!c->wrap) return fail(ISING_E_STATE, "ising_sweep needs a single slab without ring halo rows; drive slabs with ising_ring_sweep / ising_rank_sweep or ising_update_color + halo exchange");
+	return ising_host::sweep_alone(c, first_it, nsweeps);
+}
+
+// `nsweeps` sweeps of a slab that needs nothing from its neighbours: a single slab that wraps in place, or a slab of
+// sub-lattices (also one of several: nothing crosses slabs, optimized/main.cu:1423-1462)
+int ising_host::sweep_alone(ising_ctx *c, int first_it, int nsweeps) {
 	// ballot layout: up to 32 sweeps (64 colour half-sweeps) per fused launch -- the chip does not drain between colours
-	if (c->ballot && c->fused && !c->cfg.XSL && !ising_host::needs_generic(c)) {
+	if (sweeps_fused(c)) {
 		for (int it = first_it, left = nsweeps; left > 0;) {
 			const int ns = std::min(left, 32);
 			if (int rc = launch_ranges(c, it, ISING_BLACK, 0, c->cfg.Y, 0, 0, 2 * ns)) return rc;
@@ -921,9 +935,11 @@ int ising_sweep(ising_ctx *c, int first_it, int nsweeps) {
 	return ISING_OK;
 }
 
+extern "C" {
+
 int ising_sweep_info(ising_ctx *c, int *fused, int *max_sweeps_per_launch) {
 	if (!c) return fail(ISING_E_ARG, "null context");
-	const bool f = c->wrap && c->ballot && c->fused && !c->cfg.XSL && !ising_host::needs_generic(c);
+	const bool f = (c->wrap || c->cfg.XSL) && sweeps_fused(c);
 	// (a ring slab with ghost rows G deep: the ring's sweeps are fused launches of G/2 sweeps between two exchanges)
 	const bool deep = ghost_sweeps(c);
 	if (fused) *fused = (f || deep) ? 1 : 0;

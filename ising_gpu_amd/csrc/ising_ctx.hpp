@@ -191,6 +191,8 @@ int sync_checked(ising_ctx *c);
 int check_abort(ising_ctx *c);
 // the switches of DESIGN 8a from the environment (ISING_E_ARG for a value that means nothing)
 int read_policy(ising_policy *pol);
+// sweeps of a slab that needs nothing from its neighbours (a single slab that wraps in place, a slab of sub-lattices)
+int sweep_alone(ising_ctx *c, int first_it, int nsweeps);
 // launch shape of fused launches by tickets per level (ising_capi.cpp)
 void fused_shape(int nwc, int Y, long long rows, int *H, int *wg_per_cu);
 constexpr size_t SLOTCTL_TICKET_BYTES = 9 * 64; // ticket words in front of the completion counters (d_slotctl)

@@ -858,6 +858,10 @@ int sweep_deep_overlapped(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 
 int sweep_local(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 	if (int rc = settle_layout(ctxs, n)) return rc;
+	if (ctxs[0]->cfg.XSL) { // sub-lattices never reach across slabs (optimized/main.cu:1423-1462): every slab sweeps on its own
+		for (int k = 0; k < n; k++) if (int rc = ising_host::sweep_alone(ctxs[k], first_it, nsweeps)) return rc;
+		return ISING_OK;
+	}
 	{
 		bool deep = nsweeps > 0 && !ctxs[0]->store_ring && !ctxs[0]->cfg.XSL && ctxs[0]->ghost() > 1;
 		for (int k = 0; k < n; k++) deep = deep && ctxs[k]->ballot && ctxs[k]->ghost() == ctxs[0]->ghost() && !ising_host::needs_generic(ctxs[k]) && !ctxs[k]->store_ring;

@@ -94,5 +94,5 @@ def test_hand_waited_loads_of_the_fused_kernels_pass_the_isa_check():
     subprocess.check_call(["make", "-s", "-C", csrc, "check-asm"])   # (no-op when the library was built from these sources)
     report = open(os.path.join(csrc, ".ising_ballot.s.report")).read().splitlines()
     fused = [ln for ln in report if "Lb1ELi" in ln]                  # ballot_update_k<SUBL, USEJ, FUSED = true, NT>
-    assert len(fused) == 8 and all(ln.endswith("6 inline-assembly loads checked") for ln in fused), report
+    assert len(fused) == 10 and all(ln.endswith("6 inline-assembly loads checked") for ln in fused), report
     assert not any("touches" in ln for ln in report)

@@ -193,3 +193,37 @@ def test_fused_launch_gives_up_instead_of_hanging(gpu, oracle_mod, monkeypatch):
         assert slabs[0].count() == oracle_mod.OracleLattice(X, 256, seed=1, temp=2.0).init().sweep(1).count()
     for s in slabs:
         s.close()
+
+
+@pytest.mark.parametrize("nt", ["0", "1"])
+@pytest.mark.parametrize("X,Y,XSL,YSL,strip", [(16384, 256, 2048, 16, 0), (16384, 256, 4096, 64, 8), (16384, 256, 8192, 128, 0), (16384, 256, 16384, 256, 16),
+                                               (8192, 128, 2048, 32, 2), (32768, 64, 16384, 16, 1), (32768, 96, 32768, 48, 0)])
+def test_fused_launches_carry_sublattices(gpu, oracle_mod, fused, monkeypatch, X, Y, XSL, YSL, strip, nt):
+    """Sub-lattices (--xsl / --ysl, optimized/main.cu:1423-1462) in fused launches: a strip's parents wrap inside its block's
+    strips, the row above a block's first row is the block's last.  Widths of 2048 / 4096 (periods inside a wave), 8192 and
+    more; strips as tall as a block and shorter; both lattice-word flavours."""
+    monkeypatch.setenv("ISING_FUSED_NT", nt)
+    seed, temp = 414, ig.CRIT_TEMP_F32
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=temp, XSL=XSL, YSL=YSL).init()
+    with ig.IsingSlab(X, Y, seed=seed, temp=temp, layout=ig.LAYOUT_BALLOT, strip_rows=strip, XSL=XSL, YSL=YSL) as s:
+        assert s.fused and YSL % s.strip_rows == 0
+        s.init()
+        for n in (1, 2, 9, 33):
+            s.sweep(n)
+            orc.sweep(n)
+            assert _same(s, orc), (X, Y, XSL, YSL, s.it)
+            assert s.count() == orc.count() and s.bond_equal() == orc.bond_equal()
+
+
+def test_ring_slabs_of_sublattices_sweep_alone_in_fused_launches(gpu, oracle_mod, fused):
+    """Nothing crosses slabs when there are sub-lattices: the ring sweeps every slab on its own, in fused launches."""
+    X, Y, n, XSL, YSL, seed = 16384, 128, 2, 4096, 64, 5
+    orc = oracle_mod.OracleLattice(X, Y * n, seed=seed, temp=1.5, XSL=XSL, YSL=YSL).init().sweep(7)
+    slabs = [ig.IsingSlab(X, Y, seed=seed, temp=1.5, nslabs=n, slab=k, layout=ig.LAYOUT_BALLOT, XSL=XSL, YSL=YSL) for k in range(n)]
+    assert all(s.fused for s in slabs)
+    ring = ig.SlabSet(slabs).init()
+    ring.sweep(3).sweep(4)
+    assert ring.count() == orc.count()
+    for k, s in enumerate(slabs):
+        assert np.array_equal(s.read(ig.BLACK), orc.black[k * Y:(k + 1) * Y]) and np.array_equal(s.read(ig.WHITE), orc.white[k * Y:(k + 1) * Y])
+    ring.close()
