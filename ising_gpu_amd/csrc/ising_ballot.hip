@@ -1142,6 +1142,29 @@ hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_o
 	return launch_ballot_update_nt<BAL_THREADS>(p, stream, grid_out, stop);
 }
 
+// the BALLOT_MEASURE_SLOTS partial sums of lattice 0 into out[0] (up spins), out[1] (bond sum), and the slots back to zero
+__global__ void __launch_bounds__(64) measure_fold_k(unsigned long long *__restrict__ acc, unsigned long long *__restrict__ out) {
+	const int lane = threadIdx.x;
+	unsigned long long u = 0, a = 0;
+	if (lane < MEASURE_SLOTS) {
+		u = acc[lane * 8];
+		a = acc[lane * 8 + 1];
+		acc[lane * 8] = 0;
+		acc[lane * 8 + 1] = 0;
+	}
+	u = wave_sum(u);
+	a = wave_sum(a);
+	if (lane == 0) {
+		out[0] = u;
+		out[1] = a;
+	}
+}
+
+hipError_t launch_measure_fold(unsigned long long *acc, unsigned long long *out, hipStream_t stream) {
+	hipLaunchKernelGGL(measure_fold_k, dim3(1), dim3(64), 0, stream, acc, out);
+	return hipGetLastError();
+}
+
 hipError_t launch_ballot_measure(const ReplicaParams *reps, int nrep, int gx, int Y, unsigned long long *acc, hipStream_t stream) {
 	const int R = Y >= 4096 ? 16 : 8; // rows a wave marches: the (above, same, below) window slides, two loads per row instead of four
 	const long long waves = (long long)nrep * ((gx + 3) / 4) * ((Y + R - 1) / R);

@@ -123,6 +123,37 @@ int ising_host::ballot_tmp(ising_ctx *c) {
 	return ISING_OK;
 }
 
+void ising_host::ballot_tmp_release(ising_ctx *c) {
+	if (!c->d_tmp) return;
+	(void)hipStreamSynchronize(c->stream);
+	(void)hipFree(c->d_tmp);
+	c->d_tmp = nullptr;
+}
+
+// The observables read the ballot words as they are where the geometry is the plain one (no sub-lattices): no dense-order
+// image, no second copy of the slab -- a slab that fills the device can still be measured.
+bool ising_host::ballot_native_observables(const ising_ctx *c) { return c->ballot && !c->cfg.XSL; }
+
+int ising_host::ballot_measure_into_acc(ising_ctx *c) {
+	if (!c->d_self) {
+		HIP_TRY(hipMalloc((void **)&c->d_self, sizeof(ising::ReplicaParams)));
+		HIP_TRY(hipMalloc((void **)&c->d_mslots, (size_t)ising::BALLOT_MEASURE_SLOTS * 8 * sizeof(unsigned long long)));
+		HIP_TRY(hipMemsetAsync(c->d_mslots, 0, (size_t)ising::BALLOT_MEASURE_SLOTS * 8 * sizeof(unsigned long long), c->stream));
+	}
+	if (c->self_lat[0] != c->lat(ISING_BLACK) || c->self_lat[1] != c->lat(ISING_WHITE)) {
+		ising::ReplicaParams r{};
+		r.lat[0] = c->lat(ISING_BLACK);
+		r.lat[1] = c->lat(ISING_WHITE);
+		HIP_TRY(hipMemcpyAsync(c->d_self, &r, sizeof(r), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipStreamSynchronize(c->stream)); // (`r` is on the stack; once per slab)
+		c->self_lat[0] = r.lat[0];
+		c->self_lat[1] = r.lat[1];
+	}
+	HIP_TRY(ising::launch_ballot_measure(c->d_self, 1, c->gx, c->cfg.Y, c->d_mslots, c->stream));
+	HIP_TRY(ising::launch_measure_fold(c->d_mslots, c->d_acc, c->stream));
+	return ISING_OK;
+}
+
 // ballot layout: convert rows [row_lo, row_hi) of `color` (rows -1 and Y are the halo rows) between d_lat and d_tmp
 int ising_host::ballot_rows(ising_ctx *c, int color, long long row_lo, long long row_hi, bool to_dense) {
 	if (int rc = ballot_tmp(c)) return rc;
@@ -153,6 +184,7 @@ int ising_host::ballot_leave(ising_ctx *c) {
 		c->ham_form = 1;
 	}
 	c->ballot = false;
+	ising_host::ballot_tmp_release(c);
 	return ISING_OK;
 }
 
@@ -603,6 +635,9 @@ int ising_destroy(ising_ctx *c) {
 	if (c->d_edge) (void)hipFree(c->d_edge);
 	if (c->d_scratch_edge) (void)hipFree(c->d_scratch_edge);
 	if (c->d_pack) (void)hipFree(c->d_pack);
+	if (c->d_conv) (void)hipFree(c->d_conv);
+	if (c->d_self) (void)hipFree(c->d_self);
+	if (c->d_mslots) (void)hipFree(c->d_mslots);
 	delete c;
 	return ISING_OK;
 }
@@ -1034,6 +1069,14 @@ int ising_bond_equal(ising_ctx *c, int64_t *A) {
 	if (!c || !A) return fail(ISING_E_ARG, "null argument");
 	if (int rc = bind(c)) return rc;
 	if (int rc = ising_host::halo_ready(c, ISING_WHITE)) return rc; // black sites of rows 0 / Y-1 read the white halo rows
+	if (ising_host::ballot_native_observables(c)) {
+		if (int rc = ising_host::ballot_measure_into_acc(c)) return rc;
+		unsigned long long h2 = 0;
+		HIP_TRY(hipMemcpyAsync(&h2, c->d_acc + 1, sizeof(h2), hipMemcpyDeviceToHost, c->stream));
+		if (int rc = ising_host::sync_checked(c)) return rc;
+		*A = (int64_t)h2;
+		return ISING_OK;
+	}
 	if (c->ballot) if (int rc = ising_host::ballot_image(c)) return rc;
 	ising::BondParams p{};
 	p.black = c->ballot ? c->tmp(ISING_BLACK) : c->lat(ISING_BLACK);
@@ -1050,6 +1093,7 @@ int ising_bond_equal(ising_ctx *c, int64_t *A) {
 	HIP_TRY(hipMemcpyAsync(&h, c->d_acc + 1, sizeof(h), hipMemcpyDeviceToHost, c->stream));
 	if (int rc = ising_host::sync_checked(c)) return rc;
 	*A = (int64_t)h;
+	ising_host::ballot_tmp_release(c);
 	return ISING_OK;
 }
 
@@ -1062,6 +1106,12 @@ int ising_measure_enqueue(ising_ctx *c) {
 	if (!c->h_meas) HIP_TRY(hipHostMalloc((void **)&c->h_meas, (size_t)ising_ctx::MEAS_CAP * 2 * sizeof(unsigned long long), hipHostMallocDefault));
 	if (c->meas_pending >= ising_ctx::MEAS_CAP) return fail(ISING_E_STATE, "%d measurements pending: ising_measure_fetch first", c->meas_pending);
 	if (int rc = ising_host::halo_ready(c, ISING_WHITE)) return rc;
+	if (ising_host::ballot_native_observables(c)) { // two launches on the slab's own words
+		if (int rc = ising_host::ballot_measure_into_acc(c)) return rc;
+		HIP_TRY(hipMemcpyAsync(c->h_meas + 2 * (size_t)c->meas_pending, c->d_acc, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+		c->meas_pending++;
+		return ISING_OK;
+	}
 	HIP_TRY(hipMemsetAsync(c->d_acc, 0, 2 * sizeof(unsigned long long), c->stream));
 	HIP_TRY(ising::launch_popcount(c->lat(ISING_BLACK), c->color_words, c->d_acc, c->stream));
 	HIP_TRY(ising::launch_popcount(c->lat(ISING_WHITE), c->color_words, c->d_acc, c->stream));

@@ -58,6 +58,11 @@ struct ising_ctx {
 	int tail_rows = 0, tail_h = 0; // plain full-slab launches: the last tail_rows rows go in strips of tail_h rows
 	uint64_t *d_pack = nullptr;    // staging for device-side conversion to / from the packed boundary format
 	size_t pack_words = 0;
+	uint64_t *d_conv = nullptr;    // ballot layout: the same chunk of rows in dense order (ising_io.cpp: ballot <-> dense <-> packed)
+	size_t conv_words = 0;
+	struct ising::ReplicaParams *d_self = nullptr; // ballot layout: this slab's record for the ballot-native observables (ballot_measure_k)
+	unsigned long long *d_mslots = nullptr;        // ... and their partial sums (BALLOT_MEASURE_SLOTS pairs, a line each)
+	const uint64_t *self_lat[2] = {nullptr, nullptr}; // what d_self holds
 	int lld_packed = 0; // 64-bit words per colour row in the reference's packed layout (X/32)
 	int lld = 0;      // 64-bit words per colour row in the DEVICE layout: X/32 nibble, X/128 dense, ballot: 64 per wave column
 	                  // of 8192 lattice columns, i.e. X/128 rounded up to a multiple of 64 (dead lanes of the last one stay zero)
@@ -172,6 +177,10 @@ int ballot_image(ising_ctx *c);
 // ballot layout: allocate d_tmp; convert rows [row_lo, row_hi) of `color` between d_lat and d_tmp (rows -1 / Y = halo rows)
 int ballot_tmp(ising_ctx *c);
 int ballot_rows(ising_ctx *c, int color, long long row_lo, long long row_hi, bool to_dense);
+void ballot_tmp_release(ising_ctx *c); // the image is held only while an observable that needs it runs (it doubles the slab's memory)
+// ballot layout without sub-lattices: up spins and bond sum into d_acc[0], d_acc[1] on the slab's own words (ballot_measure_k)
+bool ballot_native_observables(const ising_ctx *c);
+int ballot_measure_into_acc(ising_ctx *c);
 // makes the slab's stream (or stream `s`) wait until the halo rows of `color` delivered by the ring are in place
 int halo_ready(ising_ctx *c, int color);
 int halo_ready_on(ising_ctx *c, int color, hipStream_t s);

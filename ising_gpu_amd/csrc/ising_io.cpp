@@ -2,9 +2,9 @@
 // D2H copy of dumpLattice, optimized/main.cu:1150-1152), the text dump (dumpLattice :1140-1209) and a binary checkpoint
 // the reference does not have ("so 10^5-sweep runs can resume").
 //
-// Whatever the device layout, rows are converted ON THE DEVICE in bounded chunks (a staging buffer of at most 32 MiB):
+// Whatever the device layout, rows are converted ON THE DEVICE in bounded chunks (two staging buffers of at most 32 + 8 MiB):
 //   ballot -> dense-order rows (ballot_to_dense_k) -> packed nibbles (dense_to_packed_k) -> host
-// so a 65536^2 slab is neither expanded by a scalar host loop nor held twice in host memory.
+// so a 65536^2 slab is neither expanded by a scalar host loop nor held twice -- in host memory or on the device.
 #include "ising_ctx.hpp"
 
 #include <cerrno>
@@ -41,7 +41,24 @@ int stage(ising_ctx *c, int64_t *chunk_rows) {
 		HIP_TRY(hipMalloc((void **)&c->d_pack, words * sizeof(uint64_t)));
 		c->pack_words = words;
 	}
+	// ballot layout: the chunk in dense order on its way between the slab's words and the packed form (a quarter of the size)
+	const size_t cwords = (size_t)rows * c->lld_dense;
+	if (c->ballot && c->conv_words < cwords) {
+		if (c->d_conv) HIP_TRY(hipFree(c->d_conv));
+		c->d_conv = nullptr;
+		c->conv_words = 0;
+		HIP_TRY(hipMalloc((void **)&c->d_conv, cwords * sizeof(uint64_t)));
+		c->conv_words = cwords;
+	}
 	*chunk_rows = rows;
+	return ISING_OK;
+}
+
+// ballot layout: rows [r, r + nr) of `color` between the slab and the dense-order staging chunk
+int ballot_chunk(ising_ctx *c, int color, int64_t r, int64_t nr, bool to_dense) {
+	uint64_t *lat = c->lat(color) + r * c->lld;
+	if (to_dense) HIP_TRY(ising::launch_ballot_to_dense(lat, reinterpret_cast<uint32_t *>(c->d_conv), c->gx, nr, c->stream));
+	else HIP_TRY(ising::launch_dense_to_ballot(reinterpret_cast<const uint32_t *>(c->d_conv), lat, c->gx, nr, c->stream));
 	return ISING_OK;
 }
 
@@ -63,8 +80,8 @@ int read_rows(ising_ctx *c, int color, int64_t row0, int64_t nrows, void *host, 
 		const size_t nvec = (size_t)nr * nvec_row;
 		const uint32_t *bits = nullptr; // dense-order words of the chunk on the device
 		if (c->ballot) {
-			if (int rc = ising_host::ballot_rows(c, color, r, r + nr, true)) return rc;
-			bits = reinterpret_cast<const uint32_t *>(c->tmp(color) + (size_t)r * c->lld_dense);
+			if (int rc = ballot_chunk(c, color, r, nr, true)) return rc;
+			bits = reinterpret_cast<const uint32_t *>(c->d_conv);
 		} else if (c->dense) {
 			bits = reinterpret_cast<const uint32_t *>(c->lat(color) + (size_t)r * c->lld);
 		} else { // nibble layout, BITS wanted
@@ -92,12 +109,11 @@ int write_rows(ising_ctx *c, int color, int64_t row0, int64_t nrows, const void 
 	} else {
 		int64_t chunk = 0;
 		if (int rc = stage(c, &chunk)) return rc;
-		if (c->ballot) if (int rc = ising_host::ballot_tmp(c)) return rc;
 		for (int64_t r = row0; r < row0 + nrows; r += chunk) {
 			const int64_t nr = std::min(chunk, row0 + nrows - r);
 			const size_t nvec = (size_t)nr * nvec_row;
 			// where the chunk's dense-order words go: the slab itself (dense), the dense-order image (ballot), staging (nibble)
-			uint32_t *bits = c->ballot ? reinterpret_cast<uint32_t *>(c->tmp(color) + (size_t)r * c->lld_dense)
+			uint32_t *bits = c->ballot ? reinterpret_cast<uint32_t *>(c->d_conv)
 			                 : (c->dense ? reinterpret_cast<uint32_t *>(c->lat(color) + (size_t)r * c->lld) : nullptr);
 			if (fmt == PACKED) { // 1 bit/spin layouts
 				HIP_TRY(hipMemcpyAsync(c->d_pack, static_cast<const uint64_t *>(host) + (size_t)(r - row0) * c->lld_packed, nvec * 16, hipMemcpyHostToDevice, c->stream));
@@ -109,7 +125,7 @@ int write_rows(ising_ctx *c, int color, int64_t row0, int64_t nrows, const void 
 				HIP_TRY(hipMemcpyAsync(st, static_cast<const uint32_t *>(host) + (size_t)(r - row0) * nvec_row, nvec * 4, hipMemcpyHostToDevice, c->stream));
 				HIP_TRY(ising::launch_dense_to_packed(st, c->lat(color) + (size_t)r * c->lld, nvec, c->stream));
 			}
-			if (c->ballot) if (int rc = ising_host::ballot_rows(c, color, r, r + nr, false)) return rc;
+			if (c->ballot) if (int rc = ballot_chunk(c, color, r, nr, false)) return rc;
 			HIP_TRY(hipStreamSynchronize(c->stream));
 		}
 	}

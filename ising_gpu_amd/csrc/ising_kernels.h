@@ -174,6 +174,8 @@ int ballot_max_wgs(int cus); // upper bound of the grid of any ballot launch (sc
 // accumulator pairs per lattice, 64 bytes apart: acc[(r * SLOTS + s) * 8 + {0, 1}]
 constexpr int BALLOT_MEASURE_SLOTS = 16;
 hipError_t launch_ballot_measure(const ReplicaParams *reps, int nrep, int gx, int Y, unsigned long long *acc, hipStream_t stream);
+// one lattice: its slots' sums into out[0] (up spins) and out[1] (bond sum); the slots are zero again afterwards
+hipError_t launch_measure_fold(unsigned long long *acc, unsigned long long *out, hipStream_t stream);
 hipError_t launch_ballot_init(const InitParams &p, hipStream_t stream);
 hipError_t launch_ballot_to_dense(const uint64_t *bal, uint32_t *dense, int gx, long long rows, hipStream_t stream);
 hipError_t launch_dense_to_ballot(const uint32_t *dense, uint64_t *bal, int gx, long long rows, hipStream_t stream);

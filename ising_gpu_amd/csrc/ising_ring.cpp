@@ -1363,6 +1363,7 @@ int ising_ring_correlations(ising_ctx **ctxs, int n, int ncorr, int64_t *sums) {
 		HIP_TRY(hipMemcpyAsync(h.data(), c->d_corr, (size_t)ncorr * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
 		HIP_TRY(hipStreamSynchronize(c->stream));
 		for (int j = 0; j < ncorr; j++) sums[j] += h[j];
+		ising_host::ballot_tmp_release(c); // (ballot layout: the dense-order image doubled the slab's memory while this ran)
 	}
 	return ISING_OK;
 }
