@@ -262,6 +262,11 @@ typedef struct ising_checkpoint_info {
 int ising_checkpoint_info_read(const char *path, ising_checkpoint_info *info);
 int ising_ring_checkpoint_save(ising_ctx **ctxs, int n, const char *path, int64_t it);
 int ising_ring_checkpoint_load(ising_ctx **ctxs, int n, const char *path, int64_t *it);
+/* The same file from / into a ring of processes (ising_rank_*): collective; every rank writes / reads its own rows at their
+ * place in the global row order, so the file is the one a single process would write.  `path` must name the same file for every
+ * rank.  After a load: ising_rank_exchange for both colours, continue with first_it = *it + 1. */
+int ising_rank_checkpoint_save(ising_ctx *ctx, const char *path, int64_t it);
+int ising_rank_checkpoint_load(ising_ctx *ctx, const char *path, int64_t *it);
 
 /* ---- the slab ring (replaces optimized/main.cu:1599-1658 managed memory + remote loads and the
  * cudaDeviceSynchronize barriers :1779-1784, :1800-1805).  Per colour half-sweep every slab updates its two edge rows
@@ -310,6 +315,9 @@ int ising_rank_sweep(ising_ctx *ctx, int first_it, int nsweeps);
 /* Waits until both streams of the slab are idle; timeout_ms >= 0 polls and returns ISING_E_TIMEOUT when the time is up
  * (a hung exchange can then be abandoned with ising_rank_detach(ctx, 1)); < 0 blocks. */
 int ising_rank_wait(ising_ctx *ctx, int timeout_ms);
+/* (Whatever makes a slab's ghost rows stale -- ising_init_lattice, ising_write_packed / _bits, ising_update_color -- is collective
+ * in the same sense: ising_rank_sweep decides from the local state whether an exchange comes first, and ranks that disagree
+ * wait for each other until ising_rank_wait times out.) */
 /* Whole-lattice totals, ncclAllReduce over the ranks.  Blocking. */
 int ising_rank_count(ising_ctx *ctx, uint64_t *up, uint64_t *down);
 int ising_rank_bond_equal(ising_ctx *ctx, int64_t *A);

@@ -82,6 +82,8 @@ PROTOTYPES = {
     "ising_checkpoint_info_read": (C.c_int, [C.c_char_p, C.c_void_p]),
     "ising_ring_checkpoint_save": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_int64]),
     "ising_ring_checkpoint_load": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.POINTER(C.c_int64)]),
+    "ising_rank_checkpoint_save": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "ising_rank_checkpoint_load": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     "ising_device_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "ising_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "ising_debug_fault": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

@@ -341,4 +341,105 @@ int ising_ring_checkpoint_load(ising_ctx **ctxs, int n, const char *path, int64_
 	return rc;
 }
 
+// ---- the same file from a ring of PROCESSES (ising_rank_*: one slab per process).  Global row order makes every rank's rows a
+// contiguous range per colour: rank 0 lays the file out (header, size, the total's trailer), every rank writes / reads its own
+// two ranges in place, the collective count is the barrier between the phases and the check at the end.  The path must name
+// the same file for every rank (one node, or a shared file system).
+static int rank_header(const ising_ctx *c, int64_t it, CheckpointHeader *h) {
+	memset(h, 0, sizeof(*h));
+	memcpy(h->magic, CKPT_MAGIC, 8);
+	h->header_bytes = sizeof(*h);
+	h->encoding = 1;
+	h->X = c->cfg.X;
+	h->Y_total = c->cfg.Y * c->cfg.nslabs;
+	h->nslabs_written = c->cfg.nslabs;
+	h->XSL = c->cfg.XSL;
+	h->YSL = c->cfg.YSL;
+	h->use_J = c->cfg.use_J;
+	memcpy(&h->temp_bits, &c->cfg.temp, 4);
+	memcpy(&h->J_prob_bits, &c->cfg.J_prob, 4);
+	h->seed = c->cfg.seed;
+	h->it = it;
+	h->payload_bytes = 2ull * h->Y_total * (uint64_t)(c->cfg.X / 64) * 4;
+	return ISING_OK;
+}
+
+int ising_rank_checkpoint_save(ising_ctx *c, const char *path, int64_t it) {
+	if (!c || !path) return fail(ISING_E_ARG, "null argument");
+	if (!c->rank_mode) return fail(ISING_E_STATE, "the slab is not attached to a multi-process ring (single-process rings: ising_ring_checkpoint_save)");
+	if (int rc = ising_rank_wait(c, -1)) return rc;
+	uint64_t up = 0, down = 0;
+	if (int rc = ising_rank_count(c, &up, &down)) return rc; // the total for the trailer; every rank has stopped sweeping
+	CheckpointHeader h;
+	rank_header(c, it, &h);
+	const std::string tmp = std::string(path) + ".part";
+	const size_t row_bytes = (size_t)c->cfg.X / 64 * 4;
+	int rc = ISING_OK;
+	if (c->cfg.slab == 0) { // lay the file out
+		FILE *fp = fopen(tmp.c_str(), "wb");
+		if (!fp) rc = fail(ISING_E_IO, "cannot open %s for writing: %s", tmp.c_str(), strerror(errno));
+		if (rc == ISING_OK && fwrite(&h, sizeof(h), 1, fp) != 1) rc = fail(ISING_E_IO, "write to %s failed", tmp.c_str());
+		if (rc == ISING_OK && (fseeko(fp, (off_t)(sizeof(h) + h.payload_bytes), SEEK_SET) != 0 || fwrite(&up, sizeof(up), 1, fp) != 1)) rc = fail(ISING_E_IO, "cannot size %s: %s", tmp.c_str(), strerror(errno));
+		if (fp && fclose(fp) != 0 && rc == ISING_OK) rc = fail(ISING_E_IO, "closing %s failed: %s", tmp.c_str(), strerror(errno));
+	}
+	uint64_t t0 = 0, t1 = 0;
+	if (int rc2 = ising_rank_count(c, &t0, &t1)) return rc2; // (barrier: the file exists)
+	if (rc == ISING_OK) {
+		FILE *fp = fopen(tmp.c_str(), "r+b");
+		if (!fp) rc = fail(ISING_E_IO, "cannot open %s: %s", tmp.c_str(), strerror(errno));
+		const int64_t chunk = std::max<int64_t>(1, (int64_t)(STAGE_BYTES / row_bytes));
+		std::vector<uint32_t> buf((size_t)std::min<int64_t>(chunk, c->cfg.Y) * (row_bytes / 4));
+		for (int color = 0; color < 2 && rc == ISING_OK; color++) {
+			const off_t base = (off_t)(sizeof(h) + ((uint64_t)color * h.Y_total + (uint64_t)c->cfg.slab * c->cfg.Y) * row_bytes);
+			for (int64_t r = 0; r < c->cfg.Y && rc == ISING_OK; r += chunk) {
+				const int64_t nr = std::min<int64_t>(chunk, c->cfg.Y - r);
+				rc = read_rows(c, color, r, nr, buf.data(), BITS);
+				if (rc == ISING_OK && (fseeko(fp, base + (off_t)((uint64_t)r * row_bytes), SEEK_SET) != 0 || fwrite(buf.data(), row_bytes, (size_t)nr, fp) != (size_t)nr))
+					rc = fail(ISING_E_IO, "write to %s failed: %s", tmp.c_str(), strerror(errno));
+			}
+		}
+		if (fp && fclose(fp) != 0 && rc == ISING_OK) rc = fail(ISING_E_IO, "closing %s failed: %s", tmp.c_str(), strerror(errno));
+	}
+	if (int rc2 = ising_rank_count(c, &t0, &t1)) return rc2; // (barrier: every rank's rows are in the file)
+	if (rc == ISING_OK && c->cfg.slab == 0 && rename(tmp.c_str(), path) != 0) rc = fail(ISING_E_IO, "cannot rename %s to %s: %s", tmp.c_str(), path, strerror(errno));
+	if (int rc2 = ising_rank_count(c, &t0, &t1)) return rc2; // (barrier: the file has its name)
+	return rc;
+}
+
+int ising_rank_checkpoint_load(ising_ctx *c, const char *path, int64_t *it) {
+	if (!c || !path) return fail(ISING_E_ARG, "null argument");
+	if (!c->rank_mode) return fail(ISING_E_STATE, "the slab is not attached to a multi-process ring (single-process rings: ising_ring_checkpoint_load)");
+	if (int rc = ising_rank_wait(c, -1)) return rc;
+	FILE *fp = fopen(path, "rb");
+	if (!fp) return fail(ISING_E_IO, "cannot open %s: %s", path, strerror(errno));
+	CheckpointHeader h;
+	int rc = read_header(fp, path, &h);
+	if (rc == ISING_OK && (h.X != c->cfg.X || h.Y_total != c->cfg.Y * c->cfg.nslabs))
+		rc = fail(ISING_E_ARG, "%s holds a %d x %d lattice, the ring is %d x %d", path, h.Y_total, h.X, c->cfg.Y * c->cfg.nslabs, c->cfg.X);
+	if (rc == ISING_OK && h.seed != c->cfg.seed) rc = fail(ISING_E_ARG, "%s was written with seed %llu, the ring uses %llu", path, (unsigned long long)h.seed, (unsigned long long)c->cfg.seed);
+	if (rc == ISING_OK && (h.XSL != c->cfg.XSL || h.YSL != c->cfg.YSL || h.use_J != c->cfg.use_J || (h.use_J && memcmp(&h.J_prob_bits, &c->cfg.J_prob, 4))))
+		rc = fail(ISING_E_ARG, "%s was written with other sub-lattice / coupling settings", path);
+	const size_t row_bytes = (size_t)c->cfg.X / 64 * 4;
+	const int64_t chunk = std::max<int64_t>(1, (int64_t)(STAGE_BYTES / row_bytes));
+	std::vector<uint32_t> buf((size_t)std::min<int64_t>(chunk, c->cfg.Y) * (row_bytes / 4));
+	for (int color = 0; color < 2 && rc == ISING_OK; color++) {
+		const off_t base = (off_t)(sizeof(h) + ((uint64_t)color * h.Y_total + (uint64_t)c->cfg.slab * c->cfg.Y) * row_bytes);
+		for (int64_t r = 0; r < c->cfg.Y && rc == ISING_OK; r += chunk) {
+			const int64_t nr = std::min<int64_t>(chunk, c->cfg.Y - r);
+			if (fseeko(fp, base + (off_t)((uint64_t)r * row_bytes), SEEK_SET) != 0 || fread(buf.data(), row_bytes, (size_t)nr, fp) != (size_t)nr) { rc = fail(ISING_E_IO, "%s: short read", path); break; }
+			rc = write_rows(c, color, r, nr, buf.data(), BITS);
+		}
+	}
+	uint64_t up_file = 0;
+	if (rc == ISING_OK && (fseeko(fp, (off_t)(sizeof(h) + h.payload_bytes), SEEK_SET) != 0 || fread(&up_file, sizeof(up_file), 1, fp) != 1)) rc = fail(ISING_E_IO, "%s: short read", path);
+	fclose(fp);
+	// (every rank takes part in the count whatever happened to it: the ranks stay in step)
+	uint64_t up = 0, down = 0;
+	const int rc2 = ising_rank_count(c, &up, &down);
+	if (rc == ISING_OK) rc = rc2;
+	if (rc == ISING_OK && up != up_file) rc = fail(ISING_E_IO, "%s is damaged or was not read whole: the ring holds %llu up spins, the file records %llu", path, (unsigned long long)up, (unsigned long long)up_file);
+	if (rc == ISING_OK && it) *it = h.it;
+	return rc;
+}
+
 } // extern "C"

@@ -277,6 +277,15 @@ class IsingSlab:
         check(self._lib.ising_rank_count(self._h, C.byref(up), C.byref(dw)))
         return int(up.value), int(dw.value)
 
+    def rank_checkpoint_save(self, path: str):
+        check(self._lib.ising_rank_checkpoint_save(self._h, str(path).encode(), self.it))
+
+    def rank_checkpoint_load(self, path: str) -> int:
+        it = C.c_int64()
+        check(self._lib.ising_rank_checkpoint_load(self._h, str(path).encode(), C.byref(it)))
+        self.it = int(it.value)
+        return self.it
+
     def rank_bond_equal(self) -> int:
         a = C.c_int64()
         check(self._lib.ising_rank_bond_equal(self._h, C.byref(a)))
@@ -427,9 +436,13 @@ class SlabSet:
     def checkpoint_save(self, path: str):
         check(self._lib.ising_ring_checkpoint_save(self._arr, self.n, str(path).encode(), self.it))
 
-    def checkpoint_load(self, path: str):
+    def checkpoint_load(self, path: str, apply_temperature: bool = True):
+        """Loads the spins; the run continues at the temperature the checkpoint was written at (apply_temperature=False keeps
+        the slabs' own), so a resume cannot silently go on at another T."""
         it = C.c_int64()
         check(self._lib.ising_ring_checkpoint_load(self._arr, self.n, str(path).encode(), C.byref(it)))
+        if apply_temperature:
+            self.set_temperature(checkpoint_info(path)["temp"])
         self.it = int(it.value)
         for s in self.slabs:
             s.it = self.it
@@ -438,6 +451,18 @@ class SlabSet:
     def close(self):
         for s in self.slabs:
             s.close()
+
+
+class _CheckpointInfo(C.Structure):
+    _fields_ = [("X", C.c_int32), ("Y_total", C.c_int32), ("nslabs_written", C.c_int32), ("XSL", C.c_int32), ("YSL", C.c_int32),
+                ("use_J", C.c_int32), ("temp", C.c_float), ("J_prob", C.c_float), ("seed", C.c_uint64), ("it", C.c_int64)]
+
+
+def checkpoint_info(path: str) -> dict:
+    """Header of a binary checkpoint (ising_checkpoint_info_read): geometry, seed, completed sweeps, temperature, settings."""
+    info = _CheckpointInfo()
+    check(_lib.load().ising_checkpoint_info_read(str(path).encode(), C.byref(info)))
+    return {name: getattr(info, name) for name, _ in _CheckpointInfo._fields_}
 
 
 def magnetization(up: int, down: int) -> float:

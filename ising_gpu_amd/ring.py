@@ -483,6 +483,21 @@ class NativeRing:
     def bond_equal(self) -> int:
         return self.slab.rank_bond_equal()
 
+    def checkpoint_save(self, path):
+        """Collective: the decomposition-independent checkpoint file (ising_rank_checkpoint_save), every rank its own rows."""
+        self.slab.it = self.it
+        self.slab.rank_checkpoint_save(path)
+
+    def checkpoint_load(self, path, apply_temperature: bool = True):
+        """Collective: spins from the file, the halo / ghost rows exchanged again; continues at the checkpoint's temperature."""
+        from .lattice import checkpoint_info
+        self.it = self.slab.rank_checkpoint_load(path)
+        if apply_temperature:
+            self.slab.set_temperature(checkpoint_info(path)["temp"])
+        self.slab.rank_exchange(BLACK)
+        self.slab.rank_exchange(WHITE)
+        return self
+
     def close(self, abort: bool = False):
         self.slab.rank_detach(abort)
 

@@ -8,7 +8,7 @@ up to 17 GiB of host memory; outputs are numbers only).
   config4_131072.json  -- BASELINE config 4: 131072 x 131072 (8 slabs of 16384 rows), T = CRIT_TEMP, seed 1234:
                           counts, bond-equal and the up-count of each of the 8 slabs after 0, 1, 2 sweeps
   config2_16384.json   -- BASELINE config 2: 16384 x 16384, T = CRIT_TEMP, seed 1234: counts / bond / SHA-256 of the
-                          packed state after 0, 1, 2, 4, 16, 64, 256 sweeps (prefix of the 10^5-sweep run)
+                          packed state after 0, 1, 2, 4, 16, 64, 256, 1024, 4096 sweeps (prefix of the 10^5-sweep run)
 
 Usage: make_golden_big.py [bench] [ring] [config4] [config2]   (default: all)
 """
@@ -83,7 +83,7 @@ def config2():
         h.update(L.white.tobytes())
         return {"sha256": h.hexdigest()}
     out = _hdr(16384, 16384)
-    out["points"] = _series(16384, 16384, 1234, oracle.CRIT_TEMP, (0, 1, 2, 4, 16, 64, 256), extra=sha)
+    out["points"] = _series(16384, 16384, 1234, oracle.CRIT_TEMP, (0, 1, 2, 4, 16, 64, 256, 1024, 4096), extra=sha)  # (4096: ~15 min on 8 cores)
     json.dump(out, open(os.path.join(HERE, "config2_16384.json"), "w"), indent=1)
 
 

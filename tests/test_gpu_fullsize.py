@@ -37,7 +37,7 @@ def test_config2_16384_golden_states(gpu, layout):
             s.sweep(pt["sweeps"] - s.it)
             assert s.count() == (pt["up"], pt["down"]), pt["sweeps"]
             assert s.bond_equal() == pt["bond_equal"], pt["sweeps"]
-            if pt["sweeps"] in (0, 2, 256):
+            if pt["sweeps"] in (0, 2, 256, 4096):
                 h = hashlib.sha256()
                 h.update(s.read(ig.BLACK).tobytes())
                 h.update(s.read(ig.WHITE).tobytes())
@@ -187,4 +187,9 @@ def test_lattices_beyond_2_to_the_32_threads_and_a_million_columns(gpu):
             if old is not None:
                 os.environ["ISING_FUSED"] = old
     assert res["fused"] == res["per colour"] == res["dense"]
-    assert res["dense"][0] == (68719501639, 68719451833)  # (tools/huge_probe.py: the same on every run and form)
+    # ... and with the pinned CPU oracle, streamed over the lattice in chunks of rows (tests/golden/make_golden_huge.py)
+    gold = json.load(open(os.path.join(GOLD, "huge_1048576x131072.json")))
+    assert (gold["X"], gold["Ytot"], gold["seed"]) == (X, Y, 4321)
+    p0, p2 = gold["points"]
+    assert p0["sweeps"] == 0 and p2["sweeps"] == 2
+    assert res["dense"] == ((p0["up"], p0["down"]), (p2["up"], p2["down"]), p2["bond_equal"])

@@ -152,8 +152,10 @@ def test_checkpoint_is_decomposition_independent(gpu, tmp_path):
     ring4.sweep(3)
     want = (ring4.count(), ring4.bond_equal())
     ring4.close()
+    assert ig.checkpoint_info(path)["it"] == 5 and ig.checkpoint_info(path)["Y_total"] == Ytot
     for n in (1, 2):
-        ring = ig.SlabSet([ig.IsingSlab(X, Ytot // n, seed=seed, temp=temp, nslabs=n, slab=k) for k in range(n)])
+        # created at ANOTHER temperature: the load continues at the checkpoint's (a resume must not silently change T)
+        ring = ig.SlabSet([ig.IsingSlab(X, Ytot // n, seed=seed, temp=(1.5 if n == 2 else temp), nslabs=n, slab=k) for k in range(n)])
         ring.checkpoint_load(path)
         assert ring.it == 5
         ring.sweep(3)

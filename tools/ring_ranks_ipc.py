@@ -32,7 +32,11 @@ dist.init_process_group("gloo")
 
 
 def check_small():
+    import tempfile
     import oracle
+    ckdir = [tempfile.mkdtemp(prefix="ising_ckpt_") if rank == 0 else None]
+    dist.broadcast_object_list(ckdir, src=0)
+    ckdir = ckdir[0]
     oracle.set_threads(min(16, os.cpu_count() or 1))
     X, Y, seed, temp = 8192, 64, 2024, ig.CRIT_TEMP_F32
     # (layout, ISING_RING_GHOST, J_prob, sweep calls)
@@ -64,6 +68,28 @@ def check_small():
             print(f"rank {rank} ipc layout {layout} ghost rows {depth} J {jprob} after {ring.it} sweeps: slab {'==' if ok else '!='} oracle rows [{lo},{hi}); "
                   f"counts {tot} bond {bond} {'==' if good else '!='} oracle", flush=True)
             assert good
+        if jprob is None:
+            # checkpoint written by the ranks together, continued, loaded back: the continuation repeats itself; and the file
+            # is the one a single process writes (global row order): rank 0 loads it into ONE slab and compares the counts
+            path = os.path.join(ckdir, f"ring_{layout}_{ghost_env}.ckpt")
+            ring.checkpoint_save(path)
+            at = ring.it
+            ring.sweep(3)
+            want = (ring.count(), ring.bond_equal())
+            ring.checkpoint_load(path)
+            assert ring.it == at
+            ring.sweep(3)
+            got = (ring.count(), ring.bond_equal())
+            orc.sweep(3)
+            ok = got == want == (orc.count(), orc.bond_equal())
+            print(f"rank {rank} ipc layout {layout} ghost rows {depth}: checkpoint at {at}, continuation {'==' if ok else '!='} oracle", flush=True)
+            assert ok
+            if rank == 0:
+                with ig.IsingSlab(X, Y * world, device=dev, seed=seed, temp=temp, layout=ig.LAYOUT_DENSE) as one:
+                    single = ig.SlabSet([one])
+                    single.checkpoint_load(path)
+                    single.sweep(3)
+                    assert single.it == at + 3 and single.count() == want[0]
         ring.close()
         slab.close()
     os.environ.pop("ISING_RING_GHOST", None)
