@@ -134,8 +134,9 @@ int ising_batch_sweep(ising_batch *b, int first_it, int nsweeps) {
 	ising_ctx *c0 = b->m[0];
 	const int nwc = c0->nwc(), Y = c0->cfg.Y;
 	const size_t rowb = (size_t)c0->lld * sizeof(uint64_t);
+	const int per_launch = ising_host::fused_sweeps_per_launch(c0->pol, (long long)c0->cfg.X * Y * b->n());
 	for (int it = first_it, left = nsweeps; left > 0;) {
-		const int ns = std::min(left, 32);
+		const int ns = std::min(left, per_launch);
 		ising::UpdateParams p{};
 		p.wrap = 1; // every lattice wraps in place: the launch that writes an edge row also writes its mirror
 		p.mir0_bytes = (long long)Y * (long long)rowb;

@@ -42,6 +42,7 @@ int read_policy(ising_policy *pol) {
 	if (num("ISING_FUSED_NT", &v)) pol->fused_nt = v != 0;
 	if (num("ISING_FUSED_TICKETS2", &v)) pol->fused_tickets2 = (v == 2 || v == 4) ? v : (v ? 2 : 0);
 	if (num("ISING_FUSED_WGS", &v)) pol->fused_wgs = v > 0 ? v : 0;
+	if (num("ISING_FUSED_MAX_SWEEPS", &v)) pol->fused_max_sweeps = v > 0 ? v : 0;
 	if (num("ISING_RING_GHOST", &v)) pol->ring_ghost = v;
 	pol->no_ballot = getenv("ISING_NO_BALLOT") != nullptr;
 	if (const char *e = getenv("ISING_TAIL")) {
@@ -308,6 +309,18 @@ int choose_fused_strip_rows(int nwc, int Y, int rows) {
 }
 
 } // namespace
+
+// A fused launch costs ~60 us whatever it carries (the grid's staggered start, and a tail in which the last units finish
+// unevenly and the chip drains before the next launch may start): 0.15 % of a 32-sweep launch at 65536^2 (40 ms), 2.3 % at
+// 16384^2 (2.6 ms), 7.7 % at 8192^2 (0.78 ms).  Single slabs and batches therefore carry ~50 ms of sweeps per launch (at
+// 3.4 flips/ns), between 32 and 4096 of them -- a ring slab's launches are tied to its ghost rows (32 sweeps).  The counters a
+// launch moves stay far from wrapping: 4096 sweeps x 127 wave columns = 2^20 per strip.
+int ising_host::fused_sweeps_per_launch(const ising_policy &pol, long long spins) {
+	if (pol.fused_max_sweeps > 0) return std::min(pol.fused_max_sweeps, 4096);
+	const double per_sweep_ms = (double)spins / 3.4e6;
+	const long long n = (long long)(50.0 / std::max(per_sweep_ms, 1e-6));
+	return (int)std::min<long long>(4096, std::max<long long>(32, n / 32 * 32));
+}
 
 // strip height and workgroups per CU of fused launches over `rows` rows of wave columns in all (ising_batch.cpp: the rows of
 // every lattice of a batch), strips dividing Y
@@ -953,10 +966,11 @@ extern "C" int ising_sweep(ising_ctx *c, int first_it, int nsweeps) {
 // `nsweeps` sweeps of a slab that needs nothing from its neighbours: a single slab that wraps in place, or a slab of
 // sub-lattices (also one of several: nothing crosses slabs, optimized/main.cu:1423-1462)
 int ising_host::sweep_alone(ising_ctx *c, int first_it, int nsweeps) {
-	// ballot layout: up to 32 sweeps (64 colour half-sweeps) per fused launch -- the chip does not drain between colours
+	// ballot layout: many sweeps per fused launch (32 at 65536^2, more on smaller lattices) -- the chip does not drain between colours
 	if (sweeps_fused(c)) {
+		const int per_launch = ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y);
 		for (int it = first_it, left = nsweeps; left > 0;) {
-			const int ns = std::min(left, 32);
+			const int ns = std::min(left, per_launch);
 			if (int rc = launch_ranges(c, it, ISING_BLACK, 0, c->cfg.Y, 0, 0, 2 * ns)) return rc;
 			it += ns;
 			left -= ns;
@@ -978,7 +992,7 @@ int ising_sweep_info(ising_ctx *c, int *fused, int *max_sweeps_per_launch) {
 	// (a ring slab with ghost rows G deep: the ring's sweeps are fused launches of G/2 sweeps between two exchanges)
 	const bool deep = ghost_sweeps(c);
 	if (fused) *fused = (f || deep) ? 1 : 0;
-	if (max_sweeps_per_launch) *max_sweeps_per_launch = f ? 32 : (deep ? c->ghost() / 2 : 0);
+	if (max_sweeps_per_launch) *max_sweeps_per_launch = f ? ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y) : (deep ? c->ghost() / 2 : 0);
 	return ISING_OK;
 }
 

@@ -19,6 +19,7 @@ struct ising_policy {
 	int fused_nt = -1;       // ISING_FUSED_NT=0/1: non-temporal lattice words (-1: lattices above 2^31 spins)
 	int fused_tickets2 = -1; // ISING_FUSED_TICKETS2=0/2/4: ticket counters (-1: by strip height)
 	int fused_wgs = 0;       // ISING_FUSED_WGS=n: persistent grid of n workgroups (0: by tickets per level)
+	int fused_max_sweeps = 0; // ISING_FUSED_MAX_SWEEPS=n: sweeps one fused launch of a single slab carries at most (0: ~50 ms worth, 32 .. 4096)
 	int ring_ghost = -1;     // ISING_RING_GHOST=n: ghost rows of ballot ring slabs (-1: 64)
 	bool no_ballot = false;  // ISING_NO_BALLOT: layout AUTO never picks the ballot layout
 	int tail_rows = -1, tail_h = 1; // ISING_TAIL=rows[,h]: one-row tail strips of one-launch-per-colour launches (-1: automatic, 0: off)
@@ -202,6 +203,9 @@ int check_abort(ising_ctx *c);
 int read_policy(ising_policy *pol);
 // sweeps of a slab that needs nothing from its neighbours (a single slab that wraps in place, a slab of sub-lattices)
 int sweep_alone(ising_ctx *c, int first_it, int nsweeps);
+// sweeps one fused launch of `spins` spins (all lattices of a batch) carries at most: a launch costs ~60 us whatever it
+// carries, so small lattices get long launches (ising_capi.cpp)
+int fused_sweeps_per_launch(const ising_policy &pol, long long spins);
 // launch shape of fused launches by tickets per level (ising_capi.cpp)
 void fused_shape(int nwc, int Y, long long rows, int *H, int *wg_per_cu);
 constexpr size_t SLOTCTL_TICKET_BYTES = 9 * 64; // ticket words in front of the completion counters (d_slotctl)

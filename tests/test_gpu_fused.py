@@ -227,3 +227,17 @@ def test_ring_slabs_of_sublattices_sweep_alone_in_fused_launches(gpu, oracle_mod
     for k, s in enumerate(slabs):
         assert np.array_equal(s.read(ig.BLACK), orc.black[k * Y:(k + 1) * Y]) and np.array_equal(s.read(ig.WHITE), orc.white[k * Y:(k + 1) * Y])
     ring.close()
+
+
+@pytest.mark.parametrize("cap", [None, "5", "64"])
+def test_fused_launches_longer_than_32_sweeps(gpu, oracle_mod, fused, monkeypatch, cap):
+    """Small lattices carry many sweeps per launch (~50 ms worth, up to 4096: a launch costs ~60 us whatever it carries);
+    ISING_FUSED_MAX_SWEEPS caps it.  150 sweeps as one launch, as 30 and as 3 launches: the same spins."""
+    if cap:
+        monkeypatch.setenv("ISING_FUSED_MAX_SWEEPS", cap)
+    X, Y, seed = 8192, 128, 606
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=ig.CRIT_TEMP_F32).init().sweep(150)
+    with ig.IsingSlab(X, Y, seed=seed, temp=ig.CRIT_TEMP_F32, layout=ig.LAYOUT_BALLOT) as s:
+        assert s.fused and s.max_sweeps_per_launch == (int(cap) if cap else 4096)
+        s.init().sweep(150)
+        assert _same(s, orc) and s.count() == orc.count()
