@@ -310,14 +310,15 @@ int choose_fused_strip_rows(int nwc, int Y, int rows) {
 
 } // namespace
 
-// A fused launch costs ~60 us whatever it carries (the grid's staggered start, and a tail in which the last units finish
-// unevenly and the chip drains before the next launch may start): 0.15 % of a 32-sweep launch at 65536^2 (40 ms), 2.3 % at
-// 16384^2 (2.6 ms), 7.7 % at 8192^2 (0.78 ms).  Single slabs and batches therefore carry ~50 ms of sweeps per launch (at
-// 3.4 flips/ns), between 32 and 4096 of them -- a ring slab's launches are tied to its ghost rows (32 sweeps).  The counters a
-// launch moves stay far from wrapping: 4096 sweeps x 127 wave columns = 2^20 per strip.
+// A fused launch has a fixed cost (the grid's staggered start, and a tail in which the last units finish unevenly and the chip
+// drains before the next launch may start): tools/launch_len_probe.py, 32 against 1024 sweeps per launch: 8192 x 4096 2285 ->
+// 2332 flips/ns, 8192^2 2763 -> 2801, 16384 x 8192 3055 -> 3086, 16384^2 3293 -> 3318, 32768^2 3471 -> 3483, 65536^2 3512 -> 3518
+// (~20 us per launch).  Single slabs and batches therefore carry ~50 ms of sweeps per launch (at 3.4 flips/ns), between 32 and
+// 4096 of them -- a ring slab's launches are tied to its ghost rows (32 sweeps).  The counters a launch moves stay far from
+// wrapping: 4096 sweeps x 127 wave columns = 2^20 per strip.
 int ising_host::fused_sweeps_per_launch(const ising_policy &pol, long long spins) {
 	if (pol.fused_max_sweeps > 0) return std::min(pol.fused_max_sweeps, 4096);
-	const double per_sweep_ms = (double)spins / 3.4e6;
+	const double per_sweep_ms = (double)spins / 3.4e9; // (3.4 flips/ns = 3.4e9 per ms)
 	const long long n = (long long)(50.0 / std::max(per_sweep_ms, 1e-6));
 	return (int)std::min<long long>(4096, std::max<long long>(32, n / 32 * 32));
 }
