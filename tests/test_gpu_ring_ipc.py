@@ -40,6 +40,15 @@ def test_two_ranks_over_ipc_reproduce_the_bench_ring_golden(gpu):
     assert r.stdout.count("== oracle golden") == 2 * 4 and "!=" not in r.stdout, r.stdout[-3000:]
 
 
+@pytest.mark.parametrize("world,port", [(2, 29554), (3, 29555)])
+def test_ranks_over_ipc_soak_against_the_lone_slab(gpu, world, port):
+    """24000 sweeps = 750+ overlapped exchanges between real processes, uneven call lengths: counts and bond sum of the ring ==
+    the whole lattice swept as one slab, at six checkpoints."""
+    r = _launch(world, port, "soak")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("== lone slab") == 6 * world and "!=" not in r.stdout, r.stdout[-3000:]
+
+
 @pytest.mark.parametrize("layout_name", ["ballot", "dense"])
 def test_ring_of_one_over_ipc_in_process(gpu, oracle_mod, layout_name):
     """A ring of ONE slab attached to itself: its edge rows travel through the transport's copies and counters into its own

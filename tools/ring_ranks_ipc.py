@@ -10,7 +10,9 @@ RCCL refuses that, this transport does not -- or owning one GPU each (LOCAL_RANK
   golden  the bench's slabs (65536 x 65536 per rank, T_c, seed 1234): counts after 0 / 5 / 21 / 25 sweeps against the oracle's
           golden ring counts (tests/golden/ring_65536_tc.json, N = world).
 
-Launch: python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 --master-port 29551 tools/ring_ranks_ipc.py small|golden"""
+  soak    32768 x 2048 per rank, 24000 sweeps in uneven calls: counts and bond sum against the whole lattice as one slab.
+
+Launch: python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 --master-port 29551 tools/ring_ranks_ipc.py small|golden|soak"""
 import json
 import os
 import sys
@@ -112,8 +114,37 @@ def check_golden():
     slab.close()
 
 
+def check_soak():
+    """Thousands of exchanges between real processes next to running fused launches (small slabs: the exchange has ~1 ms per
+    launch), uneven call lengths; counts and bond sum at every checkpoint against the whole lattice as ONE slab (rank 0 runs it)."""
+    X, Y, seed, total, ncheck = 32768, 2048, 31, 24000, 6
+    slab = ig.IsingSlab(X, Y, device=dev, seed=seed, temp=ig.CRIT_TEMP_F32, nslabs=world, slab=rank, layout=ig.LAYOUT_BALLOT)
+    ring = ig.NativeRing(slab, transport="ipc").init()
+    ref = ig.IsingSlab(X, Y * world, device=dev, seed=seed, temp=ig.CRIT_TEMP_F32, layout=ig.LAYOUT_BALLOT).init() if rank == 0 else None
+    step = total // ncheck
+    for k in range(ncheck):
+        n = 0
+        while n < step:
+            m = min(step - n, (97, 32, 5, 64, 1, 33)[(n + k) % 6])
+            ring.sweep(m)
+            n += m
+        got = [ring.count(), ring.bond_equal()]
+        want = [None]
+        if rank == 0:
+            ref.sweep(step)
+            want = [[ref.count(), ref.bond_equal()]]
+        dist.broadcast_object_list(want, src=0)
+        ok = [tuple(got[0]), got[1]] == [tuple(want[0][0]), want[0][1]]
+        print(f"rank {rank} ipc soak N={world} after {ring.it} sweeps: counts and bond sum {'==' if ok else '!='} lone slab", flush=True)
+        assert ok
+    ring.close()
+    slab.close()
+
+
 if mode == "golden":
     check_golden()
+elif mode == "soak":
+    check_soak()
 else:
     check_small()
 dist.barrier()
