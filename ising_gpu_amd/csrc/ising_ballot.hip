@@ -467,11 +467,19 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				if (lane == 0) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(got) : "v"(p.edge_go) : "memory");
 				if (__all((int32_t)(got - p.edge_go_need) >= 0)) break;
 				// (no bound of its own -- a neighbour may be seconds behind --, but the host can call the launch off)
+				// (a neighbour may be seconds behind, so the bound is 16 times the one for a unit's parents -- but there is one:
+				// an exchange that never completes ends the launch with an error, not at the watchdog)
 				if ((++ngo & 63u) == 0u) {
 					uint64_t fp;
-					asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(fp) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(offsetof(UpdateParams, abort_flag)) : "memory");
-					const uint32_t *flag = reinterpret_cast<const uint32_t *>(fp);
-					if (flag != nullptr && uni(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0u) break;
+					uint32_t bound;
+					asm volatile("s_load_dwordx2 %0, %2, %3\n\ts_load_dword %1, %2, %4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(fp), "=&s"(bound)
+					             : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(offsetof(UpdateParams, abort_flag)), "n"(offsetof(UpdateParams, abort_polls)) : "memory");
+					uint32_t *flag = reinterpret_cast<uint32_t *>(fp);
+					if (flag != nullptr) {
+						const bool late = (ngo >> 4) >= bound; // (a poll here sleeps four times as long as one for the parents)
+						if (late && lane == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+						if (late || uni(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0u) break;
+					}
 				}
 				__builtin_amdgcn_s_sleep(127);
 			}

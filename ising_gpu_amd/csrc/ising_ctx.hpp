@@ -24,7 +24,10 @@ struct ising_policy {
 	bool no_ballot = false;  // ISING_NO_BALLOT: layout AUTO never picks the ballot layout
 	int tail_rows = -1, tail_h = 1; // ISING_TAIL=rows[,h]: one-row tail strips of one-launch-per-colour launches (-1: automatic, 0: off)
 	bool trapezoid = true;   // ISING_RING_TRAPEZOID=0: every ghost row at every level
-	bool overlap = true;     // ISING_RING_OVERLAP=0: the deep exchange between launches instead of next to them
+	int overlap = 1;         // ISING_RING_OVERLAP: 0 = the deep exchange between two launches (round 2); 1 (default) = started by the
+	                         // running launch's edge strips and hidden in its tail, the next launch waits for it on the stream;
+	                         // 2 = free-running: the next launch starts regardless and only its edge strips wait (copies / IPC
+	                         // only: a transport whose kernels cannot be placed next to a chip-filling launch would never finish)
 	int ring_inline = -1;    // ISING_RING_INLINE=0/1: peer copies on the comm / the compute stream (-1: by device placement)
 	int ring_store = -1;     // ISING_RING_STORE=0/1: never / always store edge rows into the neighbours' halo rows (-1: automatic)
 	bool ring_flags = false, ring_publish = false; // ISING_RING_FLAGS=1, ISING_RING_PUBLISH=1: alternative one-row schedules
@@ -98,6 +101,7 @@ struct ising_ctx {
 	hipEvent_t ev_edge[2] = {nullptr, nullptr};
 	hipEvent_t ev_sent[2] = {nullptr, nullptr};
 	hipEvent_t ev_int[2] = {nullptr, nullptr};  // compute stream: the interior rows of colour c are done
+	hipEvent_t ev_go = nullptr;                 // comm stream: the exchange is complete for this slab and edge_go has moved (sweep_deep_overlapped)
 	int transport = 0;                           // ISING_TRANSPORT_* in use (0 = not decided yet)
 	ising_ctx *ring_prev = nullptr, *ring_next = nullptr; // neighbours in a single-process ring
 	void *rccl_comm = nullptr;                   // ncclComm_t of this slab's rank

@@ -357,6 +357,7 @@ int ring_resources(ising_ctx *c) {
 		if (!c->ev_sent[k]) HIP_TRY(hipEventCreateWithFlags(&c->ev_sent[k], hipEventDisableTiming));
 		if (!c->ev_int[k]) HIP_TRY(hipEventCreateWithFlags(&c->ev_int[k], hipEventDisableTiming));
 	}
+	if (!c->ev_go) HIP_TRY(hipEventCreateWithFlags(&c->ev_go, hipEventDisableTiming));
 	return ISING_OK;
 }
 
@@ -803,6 +804,7 @@ int post_go(ising_ctx *c) {
 	c->edge_go_epoch++;
 	hipLaunchKernelGGL(counter_set_k, dim3(1), dim3(64), 0, c->comm, c->d_edge + 16, c->edge_go_epoch);
 	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(c->ev_go, c->comm));
 	c->go_set = true;
 	return ISING_OK;
 }
@@ -816,9 +818,17 @@ int post_go(ising_ctx *c) {
 //
 //   compute stream                                   comm stream
 //   launch e   (edge strips, last level: +1 each)      wait: edge_done == all edge strips of launch e
-//   launch e+1 (edge strips, level 0: poll edge_go)    [IPC: tell the neighbours their pushes may come; wait for their word]
-//   ...                                                first / last G rows of both colours -> neighbours   (record ev_sent)
-//                                                      wait: the neighbours' rows are here; edge_go = e + 1
+//   [wait ev_go]                                       [IPC: tell the neighbours their pushes may come; wait for their word]
+//   launch e+1 (edge strips, level 0: poll edge_go)    first / last G rows of both colours -> neighbours   (record ev_sent)
+//   ...                                                wait: the neighbours' rows are here; edge_go = e + 1; record ev_go
+//
+// The wait for ev_go in front of the next launch is what keeps this free of deadlock whatever the transport needs: a
+// persistent launch fills the chip, and a transport kernel that cannot be placed next to it (RCCL's send/recv kernel wants
+// more registers than five resident workgroups per CU leave: under rocprofv3 it runs when the launch's workgroups begin to
+// retire) would never finish if the NEXT launch took the freed slots while its edge strips wait for that very kernel -- which
+// is what happened with a ring of one over RCCL at 65536 x 8192 after ~3000 sweeps (tools/soak_overlap.py).  With the wait the
+// exchange still runs in the tail of the launch whose rows it carries, and the gap between two launches is an event, not an
+// exchange.  ISING_RING_OVERLAP=2 drops the wait (copies and the IPC transport: their kernels are one wave each).
 int sweep_deep_overlapped(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 	const int G = ctxs[0]->ghost();
 	bool current = true;
@@ -829,7 +839,14 @@ int sweep_deep_overlapped(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 	const bool copies = ctxs[0]->transport == ISING_TRANSPORT_COPY, ipc = ctxs[0]->transport == ISING_TRANSPORT_IPC;
 	for (int it = first_it, left = nsweeps; left > 0;) {
 		const int ns = std::min(left, G / 2);
-		for (int k = 0; k < n; k++) if (int rc = ising_host::update_deep(ctxs[k], it, 2 * ns, true)) return rc;
+		for (int k = 0; k < n; k++) {
+			ising_ctx *c = ctxs[k];
+			if (c->pol.overlap != 2 || c->transport == ISING_TRANSPORT_RCCL) {
+				if (int rc = bind(c)) return rc;
+				HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_go, 0));
+			}
+			if (int rc = ising_host::update_deep(c, it, 2 * ns, true)) return rc;
+		}
 		for (int k = 0; k < n; k++) {
 			ising_ctx *c = ctxs[k];
 			if (int rc = bind(c)) return rc;
@@ -866,7 +883,7 @@ int sweep_local(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 		bool deep = nsweeps > 0 && !ctxs[0]->store_ring && !ctxs[0]->cfg.XSL && ctxs[0]->ghost() > 1;
 		for (int k = 0; k < n; k++) deep = deep && ctxs[k]->ballot && ctxs[k]->ghost() == ctxs[0]->ghost() && !ising_host::needs_generic(ctxs[k]) && !ctxs[k]->store_ring;
 		// the exchange overlaps with the launches where the rows travel on the slabs' comm streams (ISING_RING_OVERLAP=0: between launches)
-		bool overlap = deep && ctxs[0]->pol.overlap;
+		bool overlap = deep && ctxs[0]->pol.overlap != 0;
 		for (int k = 0; k < n; k++) overlap = overlap && !ctxs[k]->copy_inline && ctxs[k]->d_edge && ctxs[k]->comm;
 		if (overlap) return sweep_deep_overlapped(ctxs, n, first_it, nsweeps);
 		if (deep) return sweep_deep(ctxs, n, first_it, nsweeps);
@@ -965,6 +982,8 @@ void ising_host::ring_release(ising_ctx *c) {
 		if (c->ev_sent[k]) (void)hipEventDestroy(c->ev_sent[k]);
 		if (c->ev_int[k]) (void)hipEventDestroy(c->ev_int[k]);
 	}
+	if (c->ev_go) (void)hipEventDestroy(c->ev_go);
+	c->ev_go = nullptr;
 	c->comm = nullptr;
 }
 

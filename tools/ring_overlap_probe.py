@@ -18,6 +18,7 @@ X, Y, sweeps = (int(v) for v in (sys.argv[2:5] if len(sys.argv) >= 5 else (65536
 if mode == "all":
     rows = [("single slab, fused launches", "single", {}),
             ("ring of one, RCCL, overlapped + trapezoid (default)", "rccl", {}),
+            ("ring of one, IPC, free-running overlap (no stream wait)", "ipc", {"ISING_RING_OVERLAP": "2"}),
             ("ring of one, RCCL, overlapped, all ghost rows every level", "rccl", {"ISING_RING_TRAPEZOID": "0"}),
             ("ring of one, RCCL, exchange between launches + trapezoid", "rccl", {"ISING_RING_OVERLAP": "0"}),
             ("ring of one, RCCL, round 2's schedule", "rccl", {"ISING_RING_OVERLAP": "0", "ISING_RING_TRAPEZOID": "0"}),
