@@ -72,12 +72,6 @@ int read_policy(ising_policy *pol) {
 int check_abort(ising_ctx *c) {
 	if (!c->h_abort || !__atomic_load_n(c->h_abort, __ATOMIC_ACQUIRE)) return ISING_OK;
 	(void)hipStreamSynchronize(c->stream);
-	if (getenv("ISING_DEBUG_ABORT") && c->d_edge) { // TEMPORARY diagnostics
-		uint32_t e[32] = {0};
-		(void)hipMemcpy(e, c->d_edge, sizeof(e), hipMemcpyDeviceToHost);
-		fprintf(stderr, "[ising abort] slab %d: edge_done %u (target %u), edge_go %u (epoch %u), done_base %u, comm query %d\n", c->cfg.slab, e[0], c->edge_done_target, e[16],
-		        c->edge_go_epoch, c->done_base, c->comm ? (int)hipStreamQuery(c->comm) : -1);
-	}
 	if (c->d_slotctl) (void)hipMemset(c->d_slotctl, 0, c->slotctl_bytes);
 	if (c->d_edge) (void)hipMemset(c->d_edge, 0, 32 * sizeof(uint32_t));
 	for (auto &t : c->ticket_base2) t = 0;

@@ -30,6 +30,8 @@ if len(sys.argv) > 2 and sys.argv[1] == "--analyze":
                 inside_all += where == "inside the launch"
                 outside_all += where != "inside the launch"
                 print(f"      {r[0][:56]:56s} {(r[1] - b[2]) / 1e3:+10.1f} .. {(r[2] - b[2]) / 1e3:+10.1f} us from the launch's end  ({where})")
+    for name, v, sg, lds, wg in sqlite3.connect(db).execute("select distinct name, vgpr_count, sgpr_count, lds_size, workgroup_x from kernels where name like '%rccl%' or name like '%ballot_update_k%' or name like '%copyBuffer%' or name like '%counter_%' or name like '%ipc_%'").fetchall():
+        print(f"   registers: {name[:60]:60s} vgpr {v} sgpr {sg} lds {lds} workgroup {wg}")
     gaps = [(b2[1] - b1[2]) / 1e3 for b1, b2 in zip(big, big[1:])]
     print(f"{len(big)} fused launches; gaps between consecutive ones (us): {[round(g, 1) for g in gaps]}")
     print(f"kernels of the comm stream inside a launch's interval: {inside_all}, straddling its end or after it: {outside_all}")
