@@ -334,7 +334,7 @@ int ising_rank_bond_equal(ising_ctx *ctx, int64_t *A);
  * stream).  Asynchronous like ising_sweep; the fetch blocks. */
 typedef struct ising_batch ising_batch;
 int ising_batch_create(ising_ctx **ctxs, int n, ising_batch **out);
-int ising_batch_destroy(ising_batch *b);
+int ising_batch_destroy(ising_batch *b);                              /* before its members are destroyed */
 int ising_batch_info(ising_batch *b, int *strip_rows, int *wg_per_cu, int *lattices); /* launch shape chosen for the batch */
 int ising_batch_sweep(ising_batch *b, int first_it, int nsweeps);
 int ising_batch_measure_enqueue(ising_batch *b);

@@ -72,6 +72,7 @@ int read_policy(ising_policy *pol) {
 int check_abort(ising_ctx *c) {
 	if (!c->h_abort || !__atomic_load_n(c->h_abort, __ATOMIC_ACQUIRE)) return ISING_OK;
 	(void)hipStreamSynchronize(c->stream);
+	ising_host::ring_abort_drain(c); // (while the word is still set: the comm stream's waiting kernels leave)
 	if (c->d_slotctl) (void)hipMemset(c->d_slotctl, 0, c->slotctl_bytes);
 	if (c->d_edge) (void)hipMemset(c->d_edge, 0, 32 * sizeof(uint32_t));
 	for (auto &t : c->ticket_base2) t = 0;

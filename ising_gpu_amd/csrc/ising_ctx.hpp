@@ -199,6 +199,9 @@ int update_full_published(ising_ctx *c, int it, int color);
 int update_deep(ising_ctx *c, int it, int nlevels, bool overlapped = false);
 // called by ising_destroy
 void ring_release(ising_ctx *c);
+// a fused launch gave up: the slab's comm stream may hold kernels that wait for counters which will never move -- they see the
+// abort word(s) and leave; returns once the comm stream is idle
+void ring_abort_drain(ising_ctx *c);
 // hipStreamSynchronize(c->stream), then: did a fused launch give up (completion counters that never came: UpdateParams.abort_flag)?
 // If so its tickets, counters and their host-side bases start from zero again and ISING_E_STATE is returned.
 int sync_checked(ising_ctx *c);

@@ -968,6 +968,13 @@ int ising_host::halo_ready_on(ising_ctx *c, int color, hipStream_t s) {
 	return ISING_OK;
 }
 
+void ising_host::ring_abort_drain(ising_ctx *c) {
+	if (!c->comm) return;
+	if (c->ipc && c->ipc->mine) __atomic_store_n(&c->ipc->mine->abort, 1u, __ATOMIC_RELEASE); // (the polling kernels of the IPC transport look at this one)
+	(void)hipStreamSynchronize(c->comm);
+	if (c->ipc && c->ipc->mine) __atomic_store_n(&c->ipc->mine->abort, 0u, __ATOMIC_RELEASE);
+}
+
 void ising_host::ring_release(ising_ctx *c) {
 	// neighbours of a single-process ring must not keep pointing at a slab that is going away
 	if (c->ring_prev && c->ring_prev->ring_next == c) { c->ring_prev->ring_next = nullptr; c->ring_prev->store_ring = false; }

@@ -49,6 +49,27 @@ def test_ranks_over_ipc_soak_against_the_lone_slab(gpu, world, port):
     assert r.stdout.count("== lone slab") == 6 * world and "!=" not in r.stdout, r.stdout[-3000:]
 
 
+@pytest.mark.parametrize("transport", ["ipc", "rccl"])
+@pytest.mark.parametrize("overlap", ["0", "1", "2"])
+def test_deep_exchange_schedules_agree(gpu, oracle_mod, monkeypatch, transport, overlap):
+    """ISING_RING_OVERLAP: the exchange between two launches (0), in the running launch's tail with the next launch waiting on
+    the stream (1, default), free-running (2; RCCL keeps the wait whatever is asked): same spins, uneven call lengths."""
+    import ising_gpu_amd as ig
+    monkeypatch.setenv("ISING_RING_OVERLAP", overlap)
+    X, Y, seed = 16384, 512, 12
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=oracle_mod.CRIT_TEMP).init()
+    slab = ig.IsingSlab(X, Y, seed=seed, temp=ig.CRIT_TEMP_F32, layout=ig.LAYOUT_BALLOT, ring_halo=True)
+    ring = ig.NativeRing(slab, transport=transport).init()
+    for n in (33, 1, 64, 7):
+        ring.sweep(n)
+        orc.sweep(n)
+        assert ring.count() == orc.count() and ring.bond_equal() == orc.bond_equal()
+    ring.quiesce()
+    assert np.array_equal(slab.read(ig.BLACK), orc.black) and np.array_equal(slab.read(ig.WHITE), orc.white)
+    ring.close()
+    slab.close()
+
+
 @pytest.mark.parametrize("layout_name", ["ballot", "dense"])
 def test_ring_of_one_over_ipc_in_process(gpu, oracle_mod, layout_name):
     """A ring of ONE slab attached to itself: its edge rows travel through the transport's copies and counters into its own
