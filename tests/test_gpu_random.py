@@ -171,3 +171,85 @@ def test_random_ring_with_ghost_rows(gpu, oracle_mod, monkeypatch, nslabs, X, Yk
             assert ring.bond_equal() == orc.bond_equal()
     finally:
         ring.close()
+
+
+def _batch_cases(n):
+    rng = np.random.default_rng(4242 + _SEED)
+    out = []
+    for k in range(n):
+        X = int(rng.choice([8192, 8192, 10240, 16384, 24576]))
+        Y = int(rng.choice([16, 32, 48, 64, 96, 128, 256]))
+        nlat = int(rng.integers(1, 7))
+        temps = [float(np.float32(t)) for t in rng.choice([1.0, 1.7, 2.0, float(ig.CRIT_TEMP_F32), 2.6, 3.4], size=nlat)]
+        seeds = [int(v) for v in rng.integers(1, 2**40, size=nlat)]
+        wgs = str(rng.choice(["", "1", "2", "5", "33"]))
+        cap = str(rng.choice(["", "2", "7", "40"]))
+        nt = int(rng.random() < 0.3)
+        calls = [int(v) for v in rng.integers(1, 46, size=int(rng.integers(1, 4)))]
+        out.append(pytest.param(X, Y, temps, seeds, wgs, cap, nt, calls, id=f"{k}-{nlat}x{X}x{Y}-g{wgs or 'auto'}-cap{cap or 'auto'}-nt{nt}-{calls}"))
+    return out
+
+
+@pytest.mark.parametrize("X,Y,temps,seeds,wgs,cap,nt,calls", _batch_cases(24 * _SCALE))
+def test_random_batch_configuration(gpu, oracle_mod, monkeypatch, X, Y, temps, seeds, wgs, cap, nt, calls):
+    """Batched fused launches under random shapes: 1 .. 6 lattices with their own temperatures and seeds, grids from one
+    workgroup up, launches cut at 2 / 7 / 40 sweeps or not at all, both lattice-word flavours; every member = its oracle, and
+    the one-launch measurement = count + bond sum of every member."""
+    for name, val in (("ISING_FUSED_WGS", wgs), ("ISING_FUSED_MAX_SWEEPS", cap)):
+        if val:
+            monkeypatch.setenv(name, val)
+        else:
+            monkeypatch.delenv(name, raising=False)
+    monkeypatch.setenv("ISING_FUSED_NT", str(nt))
+    slabs = [ig.IsingSlab(X, Y, seed=s, temp=t, layout=ig.LAYOUT_BALLOT) for t, s in zip(temps, seeds)]
+    orcs = [oracle_mod.OracleLattice(X, Y, seed=s, temp=t).init() for t, s in zip(temps, seeds)]
+    with ig.IsingBatch(slabs) as b:
+        b.init()
+        for n in calls:
+            b.sweep(n).measure_enqueue()
+            for o in orcs:
+                o.sweep(n)
+        meas = b.measure_fetch()
+        assert len(meas) == len(calls)
+        for r, (s, o) in enumerate(zip(slabs, orcs)):
+            _compare(s, o, f"member {r}")
+            assert meas[-1][r] == (*o.count(), o.bond_equal())
+    for s in slabs:
+        s.close()
+
+
+def _subl_fused_cases(n):
+    rng = np.random.default_rng(9090 + _SEED)
+    out = []
+    for k in range(n):
+        X = int(rng.choice([8192, 16384, 32768]))
+        XSL = int(rng.choice([w for w in (2048, 4096, 8192, 16384, 32768) if X % w == 0]))
+        YSL = int(rng.choice([16, 32, 48, 64, 128]))
+        Y = YSL * int(rng.integers(1, 5))
+        strip = int(rng.choice([h for h in (0, 1, 2, 4, 8, 16) if h == 0 or YSL % h == 0]))
+        wgs = str(rng.choice(["", "1", "3", "9"]))
+        nt = int(rng.random() < 0.4)
+        temp = float(np.float32(rng.choice([1.2, 2.0, float(ig.CRIT_TEMP_F32), 3.0])))
+        seed = int(rng.integers(1, 2**40))
+        calls = [int(v) for v in rng.integers(1, 12, size=2)]
+        out.append(pytest.param(X, Y, XSL, YSL, strip, wgs, nt, temp, seed, calls, id=f"{k}-{X}x{Y}-sl{XSL}x{YSL}-s{strip}-g{wgs or 'auto'}-nt{nt}"))
+    return out
+
+
+@pytest.mark.parametrize("X,Y,XSL,YSL,strip,wgs,nt,temp,seed,calls", _subl_fused_cases(24 * _SCALE))
+def test_random_sublattices_in_fused_launches(gpu, oracle_mod, monkeypatch, X, Y, XSL, YSL, strip, wgs, nt, temp, seed, calls):
+    monkeypatch.setenv("ISING_FUSED", "1")
+    monkeypatch.setenv("ISING_FUSED_NT", str(nt))
+    if wgs:
+        monkeypatch.setenv("ISING_FUSED_WGS", wgs)
+    else:
+        monkeypatch.delenv("ISING_FUSED_WGS", raising=False)
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=temp, XSL=XSL, YSL=YSL).init()
+    with ig.IsingSlab(X, Y, seed=seed, temp=temp, strip_rows=strip, layout=ig.LAYOUT_BALLOT, XSL=XSL, YSL=YSL) as s:
+        assert s.fused
+        s.init()
+        for n in calls:
+            s.sweep(n)
+            orc.sweep(n)
+            _compare(s, orc, f"after {s.it} sweeps")
+            assert s.count() == orc.count() and s.bond_equal() == orc.bond_equal()
