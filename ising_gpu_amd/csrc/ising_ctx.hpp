@@ -107,8 +107,8 @@ struct ising_ctx {
 	void *rccl_comm = nullptr;                   // ncclComm_t of this slab's rank
 	bool rccl_owner = false;                     // the communicator was created for this context (destroy it with the context)
 	bool rank_mode = false;                      // one slab per process: the neighbours live in other processes
-	struct ising_ipc *ipc = nullptr;             // ISING_TRANSPORT_IPC: the neighbours' rows mapped through hipIpcMemHandle, flags in
-	                                             // POSIX shared memory (ising_ring.cpp)
+	struct ising_ipc_state *ipc = nullptr;       // ISING_TRANSPORT_IPC: the neighbours' rows mapped through hipIpcMemHandle, flags in
+	                                             // POSIX shared memory (ising_ipc.cpp)
 	bool peers_enabled = false;
 	uint32_t *d_signal[2] = {nullptr, nullptr};  // per colour: counter the published edge strips of a full-slab launch bump
 	                                             // (hipMallocSignalMemory: the comm stream waits on it, hipStreamWaitValue32)
@@ -199,6 +199,8 @@ int update_full_published(ising_ctx *c, int it, int color);
 int update_deep(ising_ctx *c, int it, int nlevels, bool overlapped = false);
 // called by ising_destroy
 void ring_release(ising_ctx *c);
+// a ring slab's second stream, events and counters (created once per slab)
+int ring_resources(ising_ctx *c);
 // a fused launch gave up: the slab's comm stream may hold kernels that wait for counters which will never move -- they see the
 // abort word(s) and leave; returns once the comm stream is idle
 void ring_abort_drain(ising_ctx *c);

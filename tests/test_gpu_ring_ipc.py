@@ -1,6 +1,6 @@
 """The N > 1 path of the C-ABI with REAL processes on a 1-GPU box: ising_rank_* over ISING_TRANSPORT_IPC (the reference's
 own multi-GPU mechanism -- direct peer access to the neighbours' rows, optimized/main.cu:1496-1537, :1637-1642 -- across
-processes: hipIpcMemHandle-mapped ghost rows, epoch counters in POSIX shared memory; csrc/ising_ring.cpp).  2 and 3
+processes: hipIpcMemHandle-mapped ghost rows, epoch counters in POSIX shared memory; csrc/ising_ipc.cpp).  2 and 3
 processes share device 0 (RCCL refuses that; this transport does not): every rank compares its slab, the global counts
 and the bond sum with the CPU oracle on small slabs (deep schedule with ghost rows, one halo row on two streams, -J), and
 two ranks holding the bench's 65536^2 slabs reproduce the oracle's golden ring counts after 0 / 5 / 21 / 25 sweeps."""

@@ -1,5 +1,5 @@
 """One process per slab over the library's RCCL-free peer transport (ISING_TRANSPORT_IPC: hipIpcMemHandle-mapped ghost rows,
-epoch counters in POSIX shared memory; csrc/ising_ring.cpp), with the ranks SHARING device 0 when the box has one GPU --
+epoch counters in POSIX shared memory; csrc/ising_ipc.cpp), with the ranks SHARING device 0 when the box has one GPU --
 RCCL refuses that, this transport does not -- or owning one GPU each (LOCAL_RANK < device count).  torch.distributed
 (gloo) is only the launcher's channel: it carries the attachment blobs once and the barrier at the end.
 
