@@ -97,6 +97,7 @@ def golden_counts(x, y_per_gpu, seed, world, sweeps):
             recs = [json.load(open(os.path.join(gold, "bench_65536_tc.json")))]
         else:
             recs = [r for r in json.load(open(os.path.join(gold, "ring_65536_tc.json")))["rings"] if r["nslabs"] == world]
+        recs.append(json.load(open(os.path.join(gold, "config4_131072.json"))))  # 131072^2 (8 slabs of 16384 rows): 0, 1, 2 sweeps
         for fx in recs:
             if fx["X"] == x and fx["Ytot"] == y_per_gpu * world and fx["seed"] == seed:
                 for pt in fx["points"]:
@@ -112,9 +113,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--x", type=int, default=65536, help="columns (per-GPU slab and total)")
-    ap.add_argument("--y", type=int, default=65536, help="rows per GPU")
+    ap.add_argument("--x", type=int, default=0, help="columns (per-GPU slab and total)")
+    ap.add_argument("--y", type=int, default=0, help="rows per GPU")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--workload", choices=["config3", "config4"], default="config3",
+                    help="per-GPU slab: config3 = 65536 x 65536 (the size BASELINE's metric is quoted on; default), config4 = 131072 columns x "
+                         "16384 rows (BASELINE config 4: 131072^2 over 8 GPUs, the same slab at every N); --x / --y override")
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--layout", choices=["auto", "nibble", "dense", "ballot"], default="auto", help="device layout of the spin arrays")
     ap.add_argument("--ring", choices=["native", "torch"], default="native",
@@ -134,6 +138,8 @@ def main():
     ap.add_argument("--no-alu-probe", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
+    wx, wy = {"config3": (65536, 65536), "config4": (131072, 16384)}[args.workload]
+    args.x, args.y = args.x or wx, args.y or wy
 
     # must be in the environment before the HIP/HSA runtime initialises (RCCL P2P needs dmabuf IPC on this host driver)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
