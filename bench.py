@@ -279,6 +279,8 @@ def main():
             advance(batch)
         preheat_sweeps = (1 + more) * batch
         restart()
+    elif ring is not None:
+        restart()  # (opening a ring runs one sweep through the transport before it is trusted: start over)
 
     advance(args.warmup, batch_warm)
     barrier()
