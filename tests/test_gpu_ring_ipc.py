@@ -28,7 +28,8 @@ def test_rank_ring_over_ipc_processes_share_one_gpu(gpu, world, port):
     r = _launch(world, port, "small")
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     # 5 configurations, 3 + 2 + 2 + 2 + 1 sweep calls, every rank reports each; nothing differs
-    assert r.stdout.count("== oracle") >= 2 * 10 * world and "!=" not in r.stdout, r.stdout[-3000:]
+    assert r.stdout.count("== oracle") >= (2 * 10 + 1) * world and "!=" not in r.stdout, r.stdout[-3000:]
+    assert r.stdout.count("== oracle (sub-lattice run)") == world, r.stdout[-3000:]
     # ... and the three configurations without couplings checkpoint, continue, load and continue again
     assert r.stdout.count("continuation == oracle") == 3 * world, r.stdout[-3000:]
     assert r.stdout.count("ghost rows 32") == 6 * world, r.stdout[-3000:]  # (5 sweep reports + the checkpoint report of the deep configurations)

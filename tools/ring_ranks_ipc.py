@@ -44,6 +44,17 @@ def check_small():
     # (layout, ISING_RING_GHOST, J_prob, sweep calls)
     cases = [(ig.LAYOUT_BALLOT, None, None, (2, 19, 16)), (ig.LAYOUT_DENSE, None, None, (2, 3)), (ig.LAYOUT_BALLOT, "1", None, (2, 3)),
              (ig.LAYOUT_BALLOT, None, 0.3, (5, 17)), (ig.LAYOUT_DENSE, None, 0.3, (4,))]
+    # sub-lattices: nothing crosses slabs, every rank sweeps on its own (fused launches); only the totals are collective
+    with ig.IsingSlab(X, Y, device=dev, seed=seed, temp=temp, nslabs=world, slab=rank, layout=ig.LAYOUT_BALLOT, XSL=4096, YSL=32) as sl:
+        ring = ig.NativeRing(sl, transport="ipc").init()
+        orc = oracle.OracleLattice(X, Y * world, seed=seed, temp=temp, XSL=4096, YSL=32).init().sweep(6)
+        ring.sweep(2).sweep(4)
+        tot, bond = ring.count(), ring.bond_equal()
+        lo, hi = rank * Y, (rank + 1) * Y
+        ok = np.array_equal(sl.read(ig.BLACK), orc.black[lo:hi]) and np.array_equal(sl.read(ig.WHITE), orc.white[lo:hi]) and tot == orc.count() and bond == orc.bond_equal()
+        print(f"rank {rank} ipc sub-lattices 4096 x 32 after 6 sweeps: slab, counts, bond sum {'==' if ok else '!='} oracle (sub-lattice run)", flush=True)
+        assert ok
+        ring.close()
     for layout, ghost_env, jprob, calls in cases:
         if ghost_env is None:
             os.environ.pop("ISING_RING_GHOST", None)
