@@ -285,7 +285,10 @@ long long fused_tickets(int nwc, int Y, int H, bool wide) { return ((long long)n
 // with six; 16384^2, T = 2048 at H = 4: 3285 with four, 3217 with five; 16384 x 8192, T = 1024: 3038 with three, 2858 with four).
 // The sixth workgroup per CU waits for 16384 tickets: at 8192 (65536^2) it is worth 0.6 % (3503 -> 3526) and costs 2.7 % more HBM
 // traffic (0.892 -> 0.916 GB per colour half-sweep: 20 % more accept-mask slots in the L2s, more of them written back).
-int fused_wgs_for(long long T) { return T >= 16384 ? 6 : (T >= 4096 ? 5 : (T >= 2048 ? 4 : (T >= 1024 ? 3 : (T >= 684 ? 2 : 1)))); }
+// (round 3: the sixth from 8192 tickets -- the throughput is what counts, and the accept-mask slots' extra traffic is far from any
+// limit: 65536^2 3500 -> 3525 flips/ns, --steps 20 --warmup 5 3490 -> 3510, three alternating runs each on one box.  Ring slabs keep
+// five below 16384 tickets: their transport's kernels want room next to the launch, RCCL's 132 vector registers per lane.)
+int fused_wgs_for(long long T) { return T >= 8192 ? 6 : (T >= 4096 ? 5 : (T >= 2048 ? 4 : (T >= 1024 ? 3 : (T >= 684 ? 2 : 1)))); }
 // flips/ns of strips of H rows at wg workgroups per CU where T is ample (tools/grid_probe2.py on 65536^2 .. 131072^2, 24576^2,
 // 32768 x 16384, 16384^2, 8192^2 at the end of round 2).  One- and two-row units draw tickets from several counters.
 int fused_score(int H, int wg) {
@@ -555,6 +558,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (fused_shape || deep_ring) { // workgroups per CU of a fused launch (the chip holds 6 of 4 waves, 3 of 8)
 		const long long T = fused_tickets(c->nwc(), launch_rows, c->H, c->fused_wide != 0);
 		c->fused_wg_per_cu = c->fused_wide ? (T >= 2048 ? 3 : 2) : fused_wgs_for(T);
+		if (deep_ring && !c->fused_wide && T < 16384) c->fused_wg_per_cu = std::min(c->fused_wg_per_cu, 5);
 		// Several ticket counters where 4-wave workgroups draw one- or two-row units (2^26 spins): one counter hands out
 		// ~80 tickets per us; 8192^2 with one-row units at 2600 flips/ns needs 159 (four counters), with two-row units
 		// 79 (two).  ISING_FUSED_TICKETS2=0/2/4 overrides.
