@@ -5,13 +5,19 @@ import re
 import subprocess
 
 import numpy as np
+import pytest
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 EXE = os.path.join(ROOT, "oracle", "ising_basic_cpu")
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])  # (a no-op when __graft_entry__.build() ran)
+    assert os.path.exists(EXE)
+
+
 def test_basic_front_report_block_and_lattice_file(tmp_path, oracle_mod):
-    assert os.path.exists(EXE), "oracle/ising_basic_cpu not built (make -C oracle)"
     n, m, w, it, seed = 64, 96, 5, 20, 77
     r = subprocess.run([EXE, "-x", str(n), "-y", str(m), "-w", str(w), "-n", str(it), "-a", "0.9", "-s", str(seed), "-o", "-t", "2"],
                        capture_output=True, text=True, cwd=tmp_path, timeout=120)
