@@ -500,9 +500,9 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	//   24576^2              H = 8, 4 per CU (T = 2304)                           3386 vs 3182
 	//   32768^2              H = 8, 5 per CU (T = 4096)                           3455 vs 3407
 	//   131072 x 16384       H = 16, 5 per CU (T = 4096)                          3504 vs 3410
-	//   65536^2              H = 16, 5 per CU (T = 8192)                          3512 vs 3461 (six per CU: 3533, with 2.7 % more HBM traffic)
+	//   65536^2              H = 16, 6 per CU (T = 8192)                          3533 vs 3461 (five per CU, rounds 1-2: 3512, 2.7 % less HBM traffic)
 	//   131072^2             H = 16, 6 per CU (T = 32768)                         3541 vs 3502
-	// (choose_fused_strip_rows / fused_wgs_for above; before the waves' priorities rotated -- ising_ballot.hip -- the same lattices
+	// (choose_fused_strip_rows / fused_wgs_for above; tools/midsize_probe.py re-measures the neighbours of these choices; before the waves' priorities rotated -- ising_ballot.hip -- the same lattices
 	// wanted two to four times as many tickets a level and ran 3082 at 16384^2, 3479 at 65536^2.)
 	// ISING_FUSED=0/1, ISING_FUSED_WIDE=0/1, cfg.strip_rows and ISING_FUSED_WGS (grid) override.
 	const long long spins = (long long)cfg->X * cfg->Y;
