@@ -334,9 +334,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		// FUSED: strips are taken from both ends of the slab inwards (0, N-1, 1, N-2, ...), so that the periodic
 		// neighbours strip 0 and strip N-1 wait for are the first tickets of the previous level, not its last
 		const int nstr = (p.row_hi[0] - p.row_lo[0] + p.H - 1) / p.H;
-		// (also when a plain launch publishes its edge rows, p.edge_signal: the two edge strips go first)
-		const bool zigzag = FUSED || (rng == 0 && (p.zigzag0 || (p.edge_signal != nullptr && p.sync_wait == nullptr)));
-		const int sidx = zigzag ? uni((pos & 1) ? nstr - 1 - (pos >> 1) : (pos >> 1)) : pos;
+		const int sidx = FUSED ? uni((pos & 1) ? nstr - 1 - (pos >> 1) : (pos >> 1)) : pos;
 		const int r0 = p.row_lo[rng] + sidx * Hr;
 		const int nrows0 = absent ? 0 : min(Hr, p.row_hi[rng] - r0);
 		// ring slab with ghost rows: at this level only rows within `keep` of the slab's own can still reach one of them; a strip
@@ -347,11 +345,6 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		const int nrows = skip ? 0 : nrows0;
 		// ... and, exchange overlapped with the launches: a unit that touches rows the exchange reads or writes
 		const bool edge_unit = FUSED && p.edge_go != nullptr && !absent && (r0 < p.edge_lo || r0 + nrows0 > p.edge_hi);
-		// ring slab, flag-synchronised schedule: this unit holds a row next to rows the slab's other launch (edge rows <->
-		// interior) writes
-		const bool synced = !FUSED && p.sync_wait != nullptr && !idle &&
-		                    ((p.sync_row[0] >= r0 && p.sync_row[0] < r0 + nrows) || (p.sync_row[1] >= r0 && p.sync_row[1] < r0 + nrows));
-		const bool publish = synced || (!FUSED && p.sync_wait == nullptr && p.edge_signal != nullptr && !idle && rng == 0 && (r0 == 0 || r0 + nrows == p.Y));
 		const uint32_t color = FUSED ? uni((p.color + (uint32_t)level) & 1u) : p.color;
 		const uint32_t it = FUSED ? uni(p.it + ((p.color + (uint32_t)level) >> 1)) : p.it;
 		uint64_t *const lat0 = BATCH ? reinterpret_cast<uint64_t *>(((uintptr_t)rb[1] << 32) | rb[0]) : p.lat[0];
@@ -484,16 +477,6 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				__builtin_amdgcn_s_sleep(127);
 			}
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // rows written by another kernel / a copy engine while this launch ran
-		}
-		if (synced) {
-			// the other launch's rows next to this unit's (and its reads of the rows this unit is about to overwrite) are
-			// done once its counter says so; its stores were written through, nothing of them was read here before
-			uint32_t got = p.sync_need;
-			for (;;) {
-				if (lane == 0) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(got) : "v"(p.sync_wait) : "memory");
-				if (__all((int32_t)(got - p.sync_need) >= 0)) break;
-				__builtin_amdgcn_s_sleep(127);
-			}
 		}
 #if defined(ISING_FUSED_TRACE) && defined(ISING_FUSED_TRACE_COUNTS)
 		t_unit1 = clock64(); // (behind the wait for the parents)
@@ -680,10 +663,10 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 						if (lr == p.Y - 1) st64_coh_issue<STREAM>(rd + mirL, lane * 8, nw);
 					}
 				} else {
-					if (publish) st_word<true>(rd + lane, nw); else st_word<false>(rd + lane, nw);
+					rd[lane] = nw;
 					if (p.wrap) {
-						if (lr == 0) st_word<false>(rd + mir0 + lane, nw);
-						if (lr == p.Y - 1) st_word<false>(rd + mirL + lane, nw);
+						if (lr == 0) rd[mir0 + lane] = nw;
+						if (lr == p.Y - 1) rd[mirL + lane] = nw;
 					}
 				}
 				rs += wpr;
@@ -699,13 +682,6 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			}
 			TRC(11); // flips, stores
 			if (wb_wave && r < rmax) asm volatile("s_dcache_wb" ::: "memory");
-		}
-		if (publish) {
-			// ring: rows 0 / Y-1 of this colour are what the neighbours wait for.  The strip was written through; once this
-			// wave's stores have left it, the slab's comm stream may send (hipStreamWaitValue32 on the counter) -- or, in
-			// the flag-synchronised schedule, the slab's other launch may read and overwrite next to it
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			if (lane == 0) __hip_atomic_fetch_add(p.edge_signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 		if (FUSED) tkv = ticket_sh[(round + 1) & 1]; // (on its way while the stores drain)
 		if (FUSED && !absent) {

@@ -54,8 +54,6 @@ int read_policy(ising_policy *pol) {
 	if (num("ISING_RING_OVERLAP", &v)) pol->overlap = v < 0 ? 0 : (v > 2 ? 2 : v);
 	if (num("ISING_RING_INLINE", &v)) pol->ring_inline = v != 0;
 	if (num("ISING_RING_STORE", &v)) pol->ring_store = v != 0;
-	if (num("ISING_RING_FLAGS", &v)) pol->ring_flags = v != 0;
-	if (num("ISING_RING_PUBLISH", &v)) pol->ring_publish = v != 0;
 	if (num("ISING_RING_COMM_PRIORITY", &v)) pol->comm_priority = v != 0;
 	if (num("ISING_ABORT_POLLS", &v) && v > 0) pol->abort_polls = (uint32_t)v;
 	if (const char *e = getenv("ISING_RING_TRANSPORT")) {
@@ -649,8 +647,6 @@ int ising_destroy(ising_ctx *c) {
 	if (c->d_bits) (void)hipFree(c->d_bits);
 	if (c->d_corr) (void)hipFree(c->d_corr);
 	if (c->d_slotctl) (void)hipFree(c->d_slotctl);
-	for (int k = 0; k < 2; k++) if (c->d_signal[k]) (void)hipFree(c->d_signal[k]);
-	if (c->d_flags) (void)hipFree(c->d_flags);
 	if (c->d_edge) (void)hipFree(c->d_edge);
 	if (c->d_scratch_edge) (void)hipFree(c->d_scratch_edge);
 	if (c->d_pack) (void)hipFree(c->d_pack);
@@ -728,13 +724,11 @@ int ising_strip_info(ising_ctx *c, int *strip_rows, int *nstrips) {
 // `nlevels` > 1 (ballot layout only): one fused launch of that many colour half-sweeps over the whole slab, starting with
 // `color` at iteration `it`
 // `stop` (optional): an event that fires when the launch is done
-static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int lo1, int hi1, int nlevels = 1, bool publish = false, hipEvent_t stop = nullptr) {
+static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int lo1, int hi1, int nlevels = 1, hipEvent_t stop = nullptr) {
 	// one-shot requests of the ring schedules for THIS launch (taken here, so that an early return cannot leave them set)
 	const bool edge_scratch = c->edge_scratch_next;
-	const int sync_mode = c->sync_mode;
 	const bool overlap = c->overlap_next;
 	c->edge_scratch_next = false;
-	c->sync_mode = 0;
 	c->overlap_next = false;
 	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
 	if (it < 0) return fail(ISING_E_ARG, "negative iteration %d", it);
@@ -786,7 +780,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	const int ugx = c->ballot ? 4 * c->nwc() : c->gx; // column groups per strip as the kernel counts them (ballot: 4 per wave column)
 	// tail strips (ballot layout, plain full-slab launch): the last rows of the slab in strips of H2 rows
 	int H2 = 0;
-	if (c->ballot && nlevels == 1 && !publish && c->tail_rows > 0 && hi1 == lo1 && hi0 - lo0 >= 4 * c->tail_rows) {
+	if (c->ballot && nlevels == 1 && c->tail_rows > 0 && hi1 == lo1 && hi0 - lo0 >= 4 * c->tail_rows) {
 		H2 = c->tail_h;
 		lo1 = hi0 - c->tail_rows;
 		hi1 = hi0;
@@ -795,25 +789,6 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	}
 	p.H2 = H2;
 	p.nreal0 = ugx * ((hi0 - lo0 + c->H - 1) / c->H);
-	// Flag-synchronised ring schedule, interior rows: the strips are taken from both ends inwards, so that the two boundary
-	// strips are the launch's first units (the edge-row launch of the next colour waits for them), and the one-row tail
-	// strips are the MIDDLE rows, which that order reaches last.
-	const bool middle_tail = c->ballot && sync_mode == 1 && c->d_flags && nlevels == 1 && H2 && (c->tail_rows % c->H) == 0;
-	if (middle_tail) {
-		const int lo = lo0, hi = hi1, N = (hi - lo + c->H - 1) / c->H; // strips of the whole span
-		int mid = c->tail_rows / c->H;                                    // strips that become one-row units
-		if ((N - mid) & 1) mid++;
-		const int a = (N - mid) / 2;
-		if (a >= 1 && mid >= 1) {
-			p.row_lo[0] = lo; p.row_hi[0] = hi;                           // the kernel numbers range 0's strips over the whole span ...
-			p.nreal0 = ugx * 2 * a;                                        // ... and visits a from each end
-			lo1 = lo + a * c->H;
-			hi1 = std::min(hi, lo + (N - a) * c->H);
-			p.row_lo[1] = lo1; p.row_hi[1] = hi1;
-			p.zigzag0 = 1;
-			hi0 = lo0 + 2 * a * c->H; // (only its length is used below: units of range 0)
-		}
-	}
 	p.nunits0 = (c->ballot && H2) ? (p.nreal0 + 15) / 16 * 16 : p.nreal0;
 	p.nunits = p.nunits0 + ugx * ((hi1 - lo1 + (H2 ? H2 : c->H) - 1) / (H2 ? H2 : c->H));
 	p.n3 = (uint32_t)c->thr[3];
@@ -863,27 +838,6 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 				}
 			}
 		}
-		if (publish) {
-			p.edge_signal = c->d_signal[color];
-			c->edge_target[color] += (uint32_t)c->nwc() * (c->nstrips == 1 ? 1u : 2u); // wave columns of the strips with row 0 / Y-1
-		}
-		if (sync_mode && c->d_flags && nlevels == 1) {
-			// flag-synchronised ring schedule (ising_ring.cpp): interior rows wait for the edge-row launches so far and count
-			// their two boundary strips; edge rows the other way round
-			const int mine = sync_mode == 1 ? 0 : 1;
-			p.sync_wait = c->d_flags + (1 - mine);
-			p.sync_need = c->flag_target[1 - mine];
-			p.edge_signal = c->d_flags + mine;
-			const int last_hi = p.zigzag0 ? p.row_hi[0] : (hi1 > lo1 ? hi1 : hi0);
-			p.sync_row[0] = sync_mode == 1 ? lo0 : 0;
-			p.sync_row[1] = sync_mode == 1 ? last_hi - 1 : c->cfg.Y - 1;
-			unsigned units = 0; // units (strip x wave column) that hold one of the two rows
-			if (hi0 > lo0 || hi1 > lo1) {
-				if (sync_mode == 2) units = (lo1 < hi1 && hi0 > lo0) ? 2u : 1u;
-				else units = (p.zigzag0 || hi1 > lo1 || (hi0 - lo0 + c->H - 1) / c->H > 1) ? 2u : 1u;
-			}
-			c->flag_target[mine] += units * (uint32_t)c->nwc();
-		}
 		int grid = 0;
 		if (const hipError_t le = ising::launch_ballot_update(p, c->stream, &grid, stop); le != hipSuccess) {
 			// nothing ran: tickets and counters are where the launches before left them, but to be safe they start over
@@ -926,13 +880,13 @@ int ising_host::update_edges_on(ising_ctx *c, int it, int color, hipStream_t s, 
 	hipStream_t keep = c->stream; // (a context is driven by one host thread)
 	c->stream = s;
 	c->edge_scratch_next = s != keep; // on another stream than the slab's own: it may run next to an interior launch
-	const int rc = launch_ranges(c, it, color, 0, 1, c->cfg.Y - 1, c->cfg.Y, 1, false, stop);
+	const int rc = launch_ranges(c, it, color, 0, 1, c->cfg.Y - 1, c->cfg.Y, 1, stop);
 	c->stream = keep;
 	return rc;
 }
 
 int ising_host::update_interior(ising_ctx *c, int it, int color, hipEvent_t stop) {
-	return launch_ranges(c, it, color, 1, c->cfg.Y - 1, 0, 0, 1, false, stop);
+	return launch_ranges(c, it, color, 1, c->cfg.Y - 1, 0, 0, 1, stop);
 }
 
 // true when the ring sweeps this slab through its ghost rows right now (ising_ring.cpp: sweep_local takes the same decision)
@@ -949,12 +903,6 @@ int ising_host::update_deep(ising_ctx *c, int it, int nlevels, bool overlapped) 
 	c->overlap_next = overlapped;
 	return launch_ranges(c, it, ISING_BLACK, -(G - 1), c->cfg.Y + G - 1, 0, 0, nlevels);
 }
-
-int ising_host::update_full_published(ising_ctx *c, int it, int color) {
-	if (!c->ballot || !c->d_signal[color]) return fail(ISING_E_STATE, "published edge rows need the ballot layout and signal memory");
-	return launch_ranges(c, it, color, 0, c->cfg.Y, 0, 0, 1, true);
-}
-
 
 // fused launches carry this slab's sweeps (ballot layout, integer thresholds; with sub-lattices: strips inside the blocks, no couplings)
 static bool sweeps_fused(const ising_ctx *c) {

@@ -30,7 +30,6 @@ struct ising_policy {
 	                         // only: a transport whose kernels cannot be placed next to a chip-filling launch would never finish)
 	int ring_inline = -1;    // ISING_RING_INLINE=0/1: peer copies on the comm / the compute stream (-1: by device placement)
 	int ring_store = -1;     // ISING_RING_STORE=0/1: never / always store edge rows into the neighbours' halo rows (-1: automatic)
-	bool ring_flags = false, ring_publish = false; // ISING_RING_FLAGS=1, ISING_RING_PUBLISH=1: alternative one-row schedules
 	bool comm_priority = true;                     // ISING_RING_COMM_PRIORITY=0: comm streams at default priority
 	int ring_transport = 0;  // ISING_RING_TRANSPORT=copy/rccl/auto -> ISING_TRANSPORT_*
 	uint32_t abort_polls = 1u << 22; // ISING_ABORT_POLLS: polls (~2.5 us each) a unit of a fused launch waits for its parents before it
@@ -110,15 +109,6 @@ struct ising_ctx {
 	struct ising_ipc_state *ipc = nullptr;       // ISING_TRANSPORT_IPC: the neighbours' rows mapped through hipIpcMemHandle, flags in
 	                                             // POSIX shared memory (ising_ipc.cpp)
 	bool peers_enabled = false;
-	uint32_t *d_signal[2] = {nullptr, nullptr};  // per colour: counter the published edge strips of a full-slab launch bump
-	                                             // (hipMallocSignalMemory: the comm stream waits on it, hipStreamWaitValue32)
-	uint32_t edge_target[2] = {0, 0};            // value of the counter once every launch issued so far has published
-	// flag-synchronised ring schedule: d_flags[0] counts the interior launches' boundary strips, d_flags[1] the edge-row
-	// launches; flag_target[] = their values once everything launched so far has run; sync_mode is set by the schedule for
-	// the next launch (0 none, 1 interior rows, 2 edge rows) and cleared by it
-	uint32_t *d_flags = nullptr;
-	uint32_t flag_target[2] = {0, 0};
-	int sync_mode = 0;
 	// deep exchange overlapped with the launches (ising_ring.cpp: sweep_deep_overlapped; UpdateParams.edge_go / edge_done)
 	uint32_t *d_edge = nullptr;                  // [0]: units of the launches' last levels that have left the exchange's rows (a count),
 	                                             // [16]: epoch of the last exchange that is complete for this slab (set by the comm stream)
@@ -192,8 +182,6 @@ int halo_ready_on(ising_ctx *c, int color, hipStream_t s);
 // ising_update_edges on another stream of the slab's device / the interior rows 1 .. Y-2; `stop` fires when the launch is done
 int update_edges_on(ising_ctx *c, int it, int color, hipStream_t s, hipEvent_t stop);
 int update_interior(ising_ctx *c, int it, int color, hipEvent_t stop);
-// ballot layout: one launch over rows [0, Y) whose edge strips go first and publish rows 0 / Y-1 through d_signal[color]
-int update_full_published(ising_ctx *c, int it, int color);
 // ring slab with ghost rows: one fused launch of `nlevels` (even, <= ghost rows) colour half-sweeps, ghost rows included;
 // `overlapped`: its edge strips wait for / announce the exchange themselves (ising_ring.cpp: sweep_deep_overlapped)
 int update_deep(ising_ctx *c, int it, int nlevels, bool overlapped = false);

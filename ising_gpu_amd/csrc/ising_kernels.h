@@ -50,16 +50,6 @@ struct UpdateParams {
 	const uint64_t *jham[2];  // fused, -J: coupling words read when colour c is updated
 	uint32_t *done;           // fused: completed wave columns per strip (monotone); reads `done_base` when the launch starts
 	uint32_t done_base;
-	uint32_t *edge_signal;    // plain launch over rows [0, Y) of a ring slab: the wave columns of the strips holding row 0
-	                          // and row Y-1 go first, write through, and each adds 1 here when its rows are out (NULL: off)
-	// Ring slabs, flag-synchronised schedule (ising_ring.cpp: sweep_flagged): the edge-row launch (comm stream) and the
-	// interior launch (compute stream) of a slab hand rows to each other through two monotone counters instead of stream
-	// events.  A unit that holds `sync_row[0]` or `sync_row[1]` waits until *sync_wait >= sync_need before it touches a
-	// row, writes its rows through, and adds 1 per wave column to *edge_signal when they are out.  (sync_wait NULL: off)
-	const uint32_t *sync_wait;
-	uint32_t sync_need;
-	int32_t sync_row[2];
-	int32_t zigzag0;          // range 0's strips are numbered over [row_lo[0], row_hi[0]) and taken from both ends inwards; nreal0 says how many
 	int32_t total_rows;       // rows of the whole lattice when this launch covers ghost rows (their global row wraps around the ring); 0: off
 	// Ring slab with ghost rows, fused launch (ising_ring.cpp: sweep_deep).
 	// trapezoid: level L of a launch of nlevels only needs the rows within nlevels - 1 - L of the slab's own [0, Y) -- what lies

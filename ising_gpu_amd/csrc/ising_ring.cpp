@@ -139,22 +139,6 @@ int ising_host::ring_resources(ising_ctx *c) {
 		HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
 		HIP_TRY(hipStreamCreateWithPriority(&c->comm, hipStreamNonBlocking, c->pol.comm_priority ? greatest : 0)); // (A/B: default priority instead of the highest)
 	}
-	int can_wait = 0;
-	if (hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, c->cfg.device) != hipSuccess) { can_wait = 0; (void)hipGetLastError(); }
-	// A/B, off by default: measured 1-2 % SLOWER than the two-row launch on the comm stream (tools/ring_of_one_probe.py)
-	can_wait = can_wait && c->pol.ring_publish;
-	for (int k = 0; k < 2 && can_wait && c->ballot && !c->d_signal[k]; k++) {
-		void *p = nullptr;
-		if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) != hipSuccess) { (void)hipGetLastError(); break; }
-		c->d_signal[k] = static_cast<uint32_t *>(p);
-		HIP_TRY(hipMemset(p, 0, 8));
-		c->edge_target[k] = 0;
-	}
-	if (c->ballot && !c->d_flags) {
-		HIP_TRY(hipMalloc((void **)&c->d_flags, 2 * sizeof(uint32_t)));
-		HIP_TRY(hipMemset(c->d_flags, 0, 2 * sizeof(uint32_t)));
-		c->flag_target[0] = c->flag_target[1] = 0;
-	}
 	if (c->ballot && c->ghost() > 1 && !c->d_edge) { // deep exchange overlapped with the launches: two counters, a line apart
 		HIP_TRY(hipMalloc((void **)&c->d_edge, 32 * sizeof(uint32_t)));
 		HIP_TRY(hipMemset(c->d_edge, 0, 32 * sizeof(uint32_t)));
@@ -450,93 +434,6 @@ int sweep_two_streams(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 	return ISING_OK;
 }
 
-// Flag-synchronised schedule (ballot layout; ISING_RING_FLAGS=0 keeps the event schedule above).  The same two launches per
-// colour, but they hand rows to each other on the device: the interior launch's two boundary strips wait until the
-// edge-row launches so far are done (a counter the edge-row kernels bump), write through and bump a counter of their own,
-// which the next edge-row launch waits for.  Neither stream waits for the other inside a sweep: the interior launches
-// follow each other as on a single slab -- the event schedule costs 11 us per colour between them (a stream wait, and
-// a completion signal that has to be visible before the next dispatch) --, and the edge rows of the next colour are
-// updated and sent while the interior launch of this one is still running.
-//
-//   compute stream                                        comm stream
-//                                                           (peer copies: the neighbours' halo rows of 1-c have arrived)
-//   rows 1 .. Y-2 of colour c; the strips holding row 1     rows 0, Y-1 of colour c: waits for the boundary strips of the
-//   and row Y-2 wait for the edge-row launch of 1-c         interior launch of 1-c, writes through, bumps its counter
-//                                                           deliver rows 0 / Y-1                      record ev_sent[c]
-int sweep_flagged(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
-	for (int k = 0; k < n; k++) { // whatever the compute stream holds so far (initialisation, host writes, an earlier sweep)
-		ising_ctx *c = ctxs[k];
-		if (int rc = bind(c)) return rc;
-		HIP_TRY(hipEventRecord(c->ev_int[ISING_WHITE], c->stream));
-		HIP_TRY(hipStreamWaitEvent(c->comm, c->ev_int[ISING_WHITE], 0));
-	}
-	for (int it = first_it; it < first_it + nsweeps; it++) {
-		for (int color = 0; color < 2; color++) {
-			for (int k = 0; k < n; k++) {
-				ising_ctx *c = ctxs[k];
-				if (int rc = bind(c)) return rc;
-				if (int rc = ising_host::halo_ready_on(c, 1 - color, c->comm)) return rc;
-				c->sync_mode = 2;
-				if (int rc = ising_host::update_edges_on(c, it, color, c->comm, nullptr)) return rc;
-			}
-			if (int rc = transfer(ctxs, n, color, false)) return rc;
-			for (int k = 0; k < n; k++) {
-				ising_ctx *c = ctxs[k];
-				if (int rc = bind(c)) return rc;
-				c->sync_mode = 1;
-				if (int rc = ising_host::update_interior(c, it, color, nullptr)) return rc;
-			}
-		}
-	}
-	for (int k = 0; k < n; k++) { // later work on the compute stream (counts, reads, the next sweep) sees every row
-		ising_ctx *c = ctxs[k];
-		if (int rc = bind(c)) return rc;
-		HIP_TRY(hipEventRecord(c->ev_edge[ISING_WHITE], c->comm));
-		HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_edge[ISING_WHITE], 0));
-	}
-	return ISING_OK;
-}
-
-// (ISING_RING_PUBLISH=1.)  Ballot slabs with a comm stream of their own need no separate launch for the edge rows: ONE launch per colour covers
-// the slab, the strips that hold row 0 and row Y-1 go first, write through and bump a counter when their rows are out
-// (ballot_update_k, p.edge_signal), and the comm stream waits for the counter (hipStreamWaitValue32) before it sends.
-//
-//   compute stream                                        comm stream
-//   wait: halo rows of colour 1-c have arrived              wait: counter of colour c >= what this launch brings it to
-//   rows 0 .. Y-1 of colour c, edge strips first            (peer copies: the neighbours' launches of 1-c, which read the
-//   record ev_int[c]                                         halo rows about to be overwritten, are done: their ev_int[1-c])
-//                                                            deliver rows 0 / Y-1                      record ev_sent[c]
-int sweep_published(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
-	const bool copies = ctxs[0]->transport != ISING_TRANSPORT_RCCL;
-	for (int it = first_it; it < first_it + nsweeps; it++) {
-		for (int color = 0; color < 2; color++) {
-			for (int k = 0; k < n; k++) {
-				ising_ctx *c = ctxs[k];
-				if (int rc = ising_host::halo_ready(c, 1 - color)) return rc;
-				if (int rc = bind(c)) return rc;
-				// rows 0 / Y-1 of colour c are about to be overwritten: what the comm stream sent of them last sweep has left
-				if (copies && c->ev_sent[color]) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_sent[color], 0));
-				if (int rc = ising_host::update_full_published(c, it, color)) return rc;
-				// (peer copies only: the neighbours must know when this launch no longer reads the halo rows they will
-				// overwrite next -- a record behind the launch, 7 us; RCCL receives are posted by this slab itself)
-				if (copies) HIP_TRY(hipEventRecord(c->ev_int[color], c->stream));
-			}
-			for (int k = 0; k < n; k++) {
-				ising_ctx *c = ctxs[k];
-				if (int rc = bind(c)) return rc;
-				HIP_TRY(hipStreamWaitValue32(c->comm, c->d_signal[color], c->edge_target[color], hipStreamWaitValueGte, 0xFFFFFFFFu));
-				if (copies) {
-					ising_ctx *prev = c->ring_prev, *next = c->ring_next;
-					if (prev != c) HIP_TRY(hipStreamWaitEvent(c->comm, prev->ev_int[1 - color], 0));
-					if (next != c && next != prev) HIP_TRY(hipStreamWaitEvent(c->comm, next->ev_int[1 - color], 0));
-				}
-			}
-			if (int rc = transfer(ctxs, n, color, false)) return rc;
-		}
-	}
-	return ISING_OK;
-}
-
 // Every slab's first / last `depth` rows of `color` to its neighbours' ghost rows, behind whatever the compute streams hold.
 int exchange_rows(ising_ctx **ctxs, int n, int color, int depth) {
 	for (int k = 0; k < n; k++) {
@@ -690,12 +587,7 @@ int sweep_local(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 				for (int k = 0; k < n; k++) if (int rc = ising_update_color(ctxs[k], it, color, 0, ctxs[k]->cfg.Y)) return rc;
 		return ISING_OK;
 	}
-	bool two = nsweeps > 0 && !ctxs[0]->copy_inline && !ctxs[0]->cfg.XSL, pub = two;
-	for (int k = 0; k < n; k++) pub = pub && ctxs[k]->ballot && ctxs[k]->d_signal[0] && ctxs[k]->d_signal[1] && ctxs[k]->edge_target[0] < (1u << 30);
-	if (pub) return sweep_published(ctxs, n, first_it, nsweeps);
-	bool flags = two && ctxs[0]->pol.ring_flags; // (opt-in: measured, no gain)
-	for (int k = 0; k < n; k++) flags = flags && ctxs[k]->ballot && ctxs[k]->d_flags && ctxs[k]->cfg.Y >= 4 && !ising_host::needs_generic(ctxs[k]);
-	if (flags) return sweep_flagged(ctxs, n, first_it, nsweeps);
+	const bool two = nsweeps > 0 && !ctxs[0]->copy_inline && !ctxs[0]->cfg.XSL;
 	if (two) return sweep_two_streams(ctxs, n, first_it, nsweeps);
 	for (int it = first_it; it < first_it + nsweeps; it++) {
 		for (int color = 0; color < 2; color++) {

@@ -123,7 +123,6 @@ def test_config4_131072_cli_eight_devices_mapped_to_one(gpu):
 _RING_OF_ONE = {
     "rccl, ghost rows 64 deep (default)": ("native", {}),
     "rccl, one halo row, event schedule": ("native", {"ISING_RING_GHOST": "1"}),
-    "rccl, one halo row, flag schedule": ("native", {"ISING_RING_GHOST": "1", "ISING_RING_FLAGS": "1"}),
     "rccl, caller-owned buffer": ("native-torch", {}),
     "copies, ghost rows, two streams": ("copy", {"ISING_RING_INLINE": "0", "ISING_RING_STORE": "0"}),
     "copies, one halo row, two streams": ("copy", {"ISING_RING_GHOST": "1", "ISING_RING_INLINE": "0", "ISING_RING_STORE": "0"}),
@@ -138,7 +137,7 @@ def test_ring_of_one_at_the_bench_size_every_schedule(gpu, monkeypatch, case):
     comm stream really runs next to the interior launch on the compute stream -- which is where the two launches once
     shared their accept-mask slots (wrong spins at 65536^2, right ones at every test size)."""
     kind, env = _RING_OF_ONE[case]
-    for k in ("ISING_RING_GHOST", "ISING_RING_FLAGS", "ISING_RING_INLINE", "ISING_RING_STORE"):
+    for k in ("ISING_RING_GHOST", "ISING_RING_INLINE", "ISING_RING_STORE"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)

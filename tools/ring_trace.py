@@ -2,7 +2,7 @@
 """One GPU of a ring under rocprofv3 --kernel-trace: a ring of one slab (ring_halo) sweeping through the library's ring
 schedule.  Usage: rocprofv3 --kernel-trace -d DIR -o trace -- python tools/ring_trace.py [rccl|copy] [X Y sweeps]
 Then: python tools/ring_trace.py --analyze DIR  (gaps between consecutive interior launches, where the edge-row launch sits)
-      python tools/ring_trace.py --window DIR   (the kernels of two colours in time order).  ISING_RING_FLAGS=1: flag-synchronised schedule."""
+      python tools/ring_trace.py --window DIR   (the kernels of two colours in time order)."""
 import glob
 import os
 import sqlite3
