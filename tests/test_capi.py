@@ -55,6 +55,37 @@ def test_argument_validation_messages_without_gpu():
         assert "multiple of" in str(e.value) or "no HIP device" in str(e.value)
 
 
+def test_header_is_plain_c_and_a_c_caller_links(tmp_path):
+    """The boundary is a C ABI: include/ising_hip.h compiles as pedantic C99, and a C program (what a cgo / JNI / ctypes-free host
+    would be) links against libising_hip.so and calls it -- only entry points that need no device here."""
+    src = tmp_path / "caller.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include <string.h>
+#include "ising_hip.h"
+int main(void) {
+	ising_config cfg;
+	memset(&cfg, 0, sizeof cfg);
+	cfg.nslabs = 1; cfg.temp = 2.0f;
+	/* optimized/main.cu:1412-1421: X must be a multiple of 2048 -- refused before any device work */
+	cfg.X = 1000; cfg.Y = 16;
+	ising_ctx *ctx = NULL;
+	int rc = ising_create(&cfg, &ctx);
+	printf("%zu %zu %d %d\n", ising_required_bytes(2048, 16), ising_required_bytes_layout(2048, 16, ISING_LAYOUT_DENSE), rc != ISING_OK,
+	       ising_last_error()[0] != 0);
+	return 0;
+}
+""")
+    exe = tmp_path / "caller"
+    lib = os.path.join(ROOT, "ising_gpu_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", lib, "-lising_hip", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    full = 2 * (16 + 2) * (2048 // 32) * 8
+    assert out.stdout.split() == [str(full), str(full // 4), "1", "1"], out.stdout
+
+
 def test_product_never_imports_oracle():
     bad = []
     for dirpath, _, files in os.walk(os.path.join(ROOT, "ising_gpu_amd")):
