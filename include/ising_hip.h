@@ -235,7 +235,10 @@ int ising_measure_fetch(ising_ctx *ctx, uint64_t *up, int64_t *bond_equal, int m
 
 /* Test aid: what = 1 leaves the host's record of a slab's completion counters out of step with the device, as a faulted
  * launch would; the next fused launch then gives up after `arg` polls (0: the default bound, ~10 s) and the call that
- * synchronises next returns ISING_E_STATE with tickets and counters reset (tests/test_gpu_fused.py). */
+ * synchronises next returns ISING_E_STATE with tickets and counters reset (tests/test_gpu_fused.py).  what = 2 ages the
+ * slab's monotone counters (device and host record together) as billions of sweeps would: the completion counters past the
+ * point where the next launch starts them over, the overlapped exchange's counters a few counts before 2^32; results must
+ * not change. */
 int ising_debug_fault(ising_ctx *ctx, int what, int arg);
 
 /* The layout in use right now (ISING_LAYOUT_NIBBLE, _DENSE or _BALLOT). */

@@ -413,8 +413,6 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			for (;;) { // few, patient polls: every poll is a trip to memory that competes with the lattice traffic
 				asm volatile("s_waitcnt vmcnt(0)" : "+v"(seen) :: "memory");
 				if (__all((int32_t)(seen - need) >= 0)) break;
-				// counters that never come (bases out of step with the device after a faulted launch): give the launch up.  The
-				// flag lives in pinned host memory -- the host sees it at its next synchronise -- and is looked at every 64th poll.
 				// Counters that never come (bases out of step with the device after a faulted launch): stop waiting.  The unit
 				// that has polled abort_polls times raises a flag in pinned host memory, every waiting unit looks at it every 64th
 				// poll, and whoever finds it set goes on as if its parents were done: the launch runs to its end at full speed on

@@ -1113,11 +1113,36 @@ int ising_measure_fetch(ising_ctx *c, uint64_t *up, int64_t *bond_equal, int max
 	return ISING_OK;
 }
 
-// Test aid (tests/test_gpu_fused.py): what = 1 puts the host's idea of the completion counters out of step with the device,
+// Test aids (tests/test_gpu_fused.py).  what = 1 puts the host's idea of the completion counters out of step with the device,
 // as a faulted launch would leave it -- the next fused launch's units wait for counts that never come -- and lowers the
-// bound after which they give up to `arg` polls (0: keep).
+// bound after which they give up to `arg` polls (0: keep).  what = 2 ages every monotone counter of the slab, device and
+// host record together, as billions of sweeps would: the completion counters stand past the point where the next launch
+// starts them over, the exchange's counters (units that have left the edge rows, epochs) a few counts before 2^32.
 int ising_debug_fault(ising_ctx *c, int what, int arg) {
 	if (!c) return fail(ISING_E_ARG, "null context");
+	if (what == 2) {
+		if (int rc = ising_synchronize(c)) return rc;
+		if (c->comm) HIP_TRY(hipStreamSynchronize(c->comm));
+		if (c->d_slotctl && c->slotctl_bytes > SLOTCTL_TICKET_BYTES) {
+			const uint32_t add = (1u << 30) + 12345u - c->done_base; // (counters of strips that lag a level keep their distance)
+			std::vector<uint32_t> h((c->slotctl_bytes - SLOTCTL_TICKET_BYTES) / 4);
+			HIP_TRY(hipMemcpy(h.data(), c->d_slotctl + SLOTCTL_TICKET_BYTES / 4, h.size() * 4, hipMemcpyDeviceToHost));
+			for (auto &v : h) v += add;
+			HIP_TRY(hipMemcpy(c->d_slotctl + SLOTCTL_TICKET_BYTES / 4, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+			c->done_base += add;
+		}
+		if (c->d_edge) {
+			uint32_t h[32];
+			HIP_TRY(hipMemcpy(h, c->d_edge, sizeof(h), hipMemcpyDeviceToHost));
+			const uint32_t add_done = 0xFFFFFFF0u - c->edge_done_target, add_go = 0xFFFFFFFDu - c->edge_go_epoch;
+			h[0] += add_done;
+			h[16] += add_go;
+			HIP_TRY(hipMemcpy(c->d_edge, h, sizeof(h), hipMemcpyHostToDevice));
+			c->edge_done_target += add_done;
+			c->edge_go_epoch += add_go;
+		}
+		return ISING_OK;
+	}
 	if (what != 1) return fail(ISING_E_ARG, "unknown fault %d", what);
 	c->done_base += 1u << 20;
 	if (arg > 0) c->pol.abort_polls = (uint32_t)arg;

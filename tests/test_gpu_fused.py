@@ -195,6 +195,32 @@ def test_fused_launch_gives_up_instead_of_hanging(gpu, oracle_mod, monkeypatch):
         s.close()
 
 
+@pytest.mark.parametrize("transport", [None, "rccl", "ipc"])
+def test_aged_counters_change_nothing(gpu, oracle_mod, fused, transport):
+    """The fused launches' completion counters are monotone and start over past 2^30; the overlapped exchange's counters (edge
+    units done, exchange epochs) are compared by signed difference and wrap at 2^32.  ising_debug_fault(2) ages them all as
+    billions of sweeps would (device and host record together): a lone slab and a ring of one (both transports) go on bit for
+    bit."""
+    X, Y, seed = 16384, 512, 515
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=oracle_mod.CRIT_TEMP).init()
+    with ig.IsingSlab(X, Y, seed=seed, temp=ig.CRIT_TEMP_F32, layout=ig.LAYOUT_BALLOT, ring_halo=transport is not None) as s:
+        ring = ig.NativeRing(s, transport=transport).init() if transport else None
+        drv = ring if ring else s.init()
+        for n, age in ((33, True), (70, True), (5, False)):
+            drv.sweep(n)
+            orc.sweep(n)
+            if age:
+                if ring:
+                    ring.quiesce()
+                s.debug_fault(2, 0)
+            assert drv.count() == orc.count() and drv.bond_equal() == orc.bond_equal()
+        if ring:
+            ring.quiesce()
+        assert np.array_equal(s.read(ig.BLACK), orc.black) and np.array_equal(s.read(ig.WHITE), orc.white)
+        if ring:
+            ring.close()
+
+
 @pytest.mark.parametrize("nt", ["0", "1"])
 @pytest.mark.parametrize("X,Y,XSL,YSL,strip", [(16384, 256, 2048, 16, 0), (16384, 256, 4096, 64, 8), (16384, 256, 8192, 128, 0), (16384, 256, 16384, 256, 16),
                                                (8192, 128, 2048, 32, 2), (32768, 64, 16384, 16, 1), (32768, 96, 32768, 48, 0)])
