@@ -195,6 +195,42 @@ def test_fused_launch_gives_up_instead_of_hanging(gpu, oracle_mod, monkeypatch):
         s.close()
 
 
+def test_contexts_driven_from_threads_of_their_own(gpu, oracle_mod, fused):
+    """One context per thread, each on a private stream (ctypes drops the GIL, so the C-ABI calls really overlap): the fused
+    launches of four lattices share the chip -- a workgroup only draws a ticket once it runs, so the launches cannot starve each
+    other's parents --, the launcher's per-device caches are asked for the first time from four threads at once, and every
+    thread's errors stay its own (ising_last_error is per thread)."""
+    import threading
+    shapes = [(8192, 512, 11, 2.0), (16384, 256, 12, 2.269), (8192, 1024, 13, 2.5), (24576, 128, 14, 1.8)]
+    want = [oracle_mod.OracleLattice(X, Y, seed=sd, temp=t).init().sweep(9) for X, Y, sd, t in shapes]
+    out, errs = [None] * len(shapes), []
+    gate = threading.Barrier(len(shapes))
+
+    def run(k):
+        try:
+            X, Y, sd, t = shapes[k]
+            gate.wait()
+            with ig.IsingSlab(X, Y, seed=sd, temp=t, layout=ig.LAYOUT_BALLOT).use_private_stream() as s:
+                assert s.fused
+                s.init().sweep(4).sweep(5)
+                with pytest.raises(ig.IsingError) as e:  # an error of this thread's own ...
+                    s.update_color(0, 7, 0, Y)
+                assert "colour" in str(e.value)
+                out[k] = (s.read(ig.BLACK), s.read(ig.WHITE), s.count(), s.bond_equal())
+        except BaseException as ex:  # noqa: BLE001
+            errs.append((k, repr(ex)))
+
+    th = [threading.Thread(target=run, args=(k,)) for k in range(len(shapes))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    assert not errs and not any(t.is_alive() for t in th), errs
+    for k, o in enumerate(want):
+        assert np.array_equal(out[k][0], o.black) and np.array_equal(out[k][1], o.white)
+        assert out[k][2] == o.count() and out[k][3] == o.bond_equal()
+
+
 @pytest.mark.parametrize("transport", [None, "rccl", "ipc"])
 def test_aged_counters_change_nothing(gpu, oracle_mod, fused, transport):
     """The fused launches' completion counters are monotone and start over past 2^30; the overlapped exchange's counters (edge
