@@ -128,7 +128,7 @@ def check_golden():
 def check_soak():
     """Thousands of exchanges between real processes next to running fused launches (small slabs: the exchange has ~1 ms per
     launch), uneven call lengths; counts and bond sum at every checkpoint against the whole lattice as ONE slab (rank 0 runs it)."""
-    X, Y, seed, total, ncheck = 32768, 2048, 31, 24000, 6
+    X, Y, seed, total, ncheck = 32768, 2048, 31, int(os.environ.get("ISING_SOAK_SWEEPS", "24000")), 6  # (ISING_SOAK_SWEEPS: a longer one-off hunt)
     slab = ig.IsingSlab(X, Y, device=dev, seed=seed, temp=ig.CRIT_TEMP_F32, nslabs=world, slab=rank, layout=ig.LAYOUT_BALLOT)
     ring = ig.NativeRing(slab, transport="ipc").init()
     ref = ig.IsingSlab(X, Y * world, device=dev, seed=seed, temp=ig.CRIT_TEMP_F32, layout=ig.LAYOUT_BALLOT).init() if rank == 0 else None
