@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak test of the ballot kernel's scalar-store / write-back / L1-bypass protocol: a long run on the ballot layout next
 to the same run on the dense layout (v_cmpx kernel, no scratch traffic); counts and bond sums must agree at every
-checkpoint and the final states word for word.  Usage: soak_ballot.py [X Y sweeps checkpoints]"""
+checkpoint and the final states word for word.  Usage: soak_ballot.py [X Y sweeps checkpoints [seed]]"""
 import sys
 import time
 
@@ -11,7 +11,8 @@ sys.path.insert(0, __file__.rsplit("/", 2)[0])
 import ising_gpu_amd as ig  # noqa: E402
 
 X, Y, sweeps, cps = (int(v) for v in (sys.argv[1:5] if len(sys.argv) >= 5 else (65536, 65536, 10000, 20)))
-slabs = {name: ig.IsingSlab(X, Y, seed=777, temp=ig.CRIT_TEMP_F32, layout=lay).init()
+seed = int(sys.argv[5]) if len(sys.argv) > 5 else 777
+slabs = {name: ig.IsingSlab(X, Y, seed=seed, temp=ig.CRIT_TEMP_F32, layout=lay).init()
          for name, lay in (("ballot", ig.LAYOUT_BALLOT), ("dense", ig.LAYOUT_DENSE))}
 t0 = time.time()
 for k in range(cps):
