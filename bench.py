@@ -45,6 +45,15 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X
 BYTES_PER_FLIP = 1.5         # reference accounting, optimized/main.cu:1887-1889
 
 
+def cgroup_cpus():
+    """CPUs' worth of time the container's cgroup grants (cgroup v2 cpu.max), or None."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else round(int(quota) / int(period), 2)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(args):
     """Reported CPU baseline on the host cores of this box (rank 0, N=1 only): the byte-per-spin algorithm of
     basic_python/ising_basic.py restated in oracle/basic_cpu.c, BASELINE.json configs[0] (1024x1024, alpha 1,
@@ -75,6 +84,7 @@ def cpu_baseline(args):
                   f"|m|={abs(m):.4f} e={e:.4f}; fastest of the teams tried",
         "by_threads": {str(t): v[0] for t, v in by_team.items()},
         "host_cpus": ncpu,
+        "cgroup_cpus": cgroup_cpus(),  # what the container may actually use (cpu.max quota / period); None: no limit found
     }
     # second figure: the packed bit-exact oracle (same results as the GPU engine), 8192^2 x 4 sweeps
     threads2 = max(1, min(ncpu, 64))

@@ -10,7 +10,8 @@
 // Build-side additions: --tsweep T0,T1,dT[,nequil[,nmeas[,stride]]] (temperature-sweep driver with <|m|>, <m^2>,
 //            susceptibility, Binder cumulant, energy and specific heat per point; --tsweep-anneal, --tsweep-out PREFIX,
 //            --tsweep-replicas K: K temperature points per batched launch on one GPU, 0 = by lattice size; --tsweep-no-batch: two
-//            points side by side on streams of their own instead, round 2's form),
+//            points side by side on streams of their own instead, round 2's form; --tsweep-cold: every point starts from the
+//            ordered lattice -- the start that equilibrates below T_c, where a random one coarsens for ages),
 //            --checkpoint FILE / --resume FILE (binary checkpoint, ising_ring_checkpoint_*), --transport copy|rccl.
 #include "../../include/ising_hip.h"
 
@@ -117,6 +118,7 @@ struct TsweepSpec {
 	bool anneal = false;
 	const char *out = nullptr;
 	int replicas = 0; // temperature points simulated side by side (fresh-start mode, one device); 0 = by lattice size
+	bool cold = false;     // --tsweep-cold: every point starts from the ordered lattice (all spins up) instead of the random one
 	bool no_batch = false; // --tsweep-no-batch: the points side by side on streams of their own instead of batched launches (A/B)
 };
 
@@ -162,7 +164,7 @@ int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_
 		if (!batched && ts.replicas == 0) nrep = std::min(nrep, nspins < (1ull << 29) ? 2 : 1); // (streams of their own: two fill the chip)
 	}
 	printf("\nTemperature sweep: %d points, T = %f .. %f step %f, %d equilibration + %d x %d measurement sweeps per point, %s\n",
-	       npts, ts.t0, ts.t0 + (npts - 1) * ts.dt, ts.dt, ts.nequil, ts.nmeas, ts.stride, ts.anneal ? "annealing" : "fresh start per point");
+	       npts, ts.t0, ts.t0 + (npts - 1) * ts.dt, ts.dt, ts.nequil, ts.nmeas, ts.stride, ts.anneal ? (ts.cold ? "annealing from the ordered lattice" : "annealing") : (ts.cold ? "ordered start per point" : "fresh start per point"));
 	// (every point starts from the same seed: the points share their initial lattice and their random numbers, so the curves'
 	// statistical errors are correlated across T -- common random numbers; an annealing run chains the points instead)
 	if (!ts.anneal) printf("Temperature sweep: all points use seed %llu (common random numbers across T)\n", (unsigned long long)base.seed);
@@ -211,6 +213,7 @@ int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_
 		for (Ring &rp : reps) CHECK(ising_use_private_stream(rp.ctx[0]));
 	}
 	std::vector<bool> have_J(nrep, false);
+	std::vector<uint32_t> all_up; // --tsweep-cold: one slab's rows at 1 bit per spin, every spin up
 	struct SeriesRow { int it; unsigned long long up, dw; long long A; };
 	const long double N = (long double)nspins;
 	long long total_sweeps = 0;
@@ -225,6 +228,11 @@ int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_
 			for (ising_ctx *c : rp.ctx) CHECK(ising_set_temperature(c, temps[j]));
 			if (!ts.anneal || k0 == 0) {
 				for (ising_ctx *c : rp.ctx) CHECK(ising_init_lattice(c));
+				if (ts.cold) { // the ordered start: below T_c a random start coarsens for ages, this one equilibrates in a few correlation times
+					if (all_up.empty()) all_up.assign((size_t)base.Y * (size_t)(base.X / 64), 0xFFFFFFFFu);
+					for (ising_ctx *c : rp.ctx)
+						for (int color = 0; color < 2; color++) CHECK(ising_write_bits(c, color, 0, base.Y, all_up.data()));
+				}
 				CHECK(ising_ring_exchange(rp.ctx.data(), rp.n(), ISING_BLACK));
 				CHECK(ising_ring_exchange(rp.ctx.data(), rp.n(), ISING_WHITE));
 				if (useJ && !have_J[j]) { CHECK(ising_ring_init_couplings(rp.ctx.data(), rp.n())); have_J[j] = true; }
@@ -356,7 +364,7 @@ int main(int argc, char **argv) {
 	    {"devmap", required_argument, 0, 4},   {"layout", required_argument, 0, 5},  {"tsweep", required_argument, 0, 6},
 	    {"tsweep-anneal", no_argument, 0, 7},  {"tsweep-out", required_argument, 0, 8}, {"checkpoint", required_argument, 0, 9},
 	    {"resume", required_argument, 0, 10},  {"transport", required_argument, 0, 11}, {"tsweep-replicas", required_argument, 0, 12},
-	    {"tsweep-no-batch", no_argument, 0, 13},
+	    {"tsweep-no-batch", no_argument, 0, 13}, {"tsweep-cold", no_argument, 0, 14},
 	    {0, 0, 0, 0}};
 	while (1) {
 		int option_index = 0;
@@ -433,6 +441,7 @@ int main(int argc, char **argv) {
 			if (ts.replicas < 0 || ts.replicas > 64) { fprintf(stderr, "error: --tsweep-replicas takes 0 (by lattice size) .. 64\n"); exit(EXIT_FAILURE); }
 			break;
 		case 13: ts.no_batch = true; break;
+		case 14: ts.cold = true; break;
 		case '?': exit(EXIT_FAILURE);
 		default: fprintf(stderr, "unknown option: %c\n", och); exit(EXIT_FAILURE);
 		}

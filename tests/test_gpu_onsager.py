@@ -40,3 +40,62 @@ def test_energy_above_tc_matches_onsager(gpu, tmp_path):
     for row in rows:
         T, e = float(row[it]), float(row[ie])
         assert abs(e - onsager_energy(T)) < TOL, (T, e, onsager_energy(T))
+
+
+def yang_magnetisation(T):
+    """Spontaneous magnetisation of the infinite square lattice below T_c (Yang 1952): (1 - sinh(2/T)^-4)^(1/8)."""
+    return (1.0 - math.sinh(2.0 / T) ** -4) ** 0.125
+
+
+def test_cold_start_below_tc_matches_yang_and_onsager(gpu):
+    """Below T_c a random start coarsens for ages, an ordered one does not: three 8192^2 lattices written all-up through the
+    1-bit host format (ising_write_bits), swept together in batched launches at T = 1.8, 2.0, 2.1 (correlation length <= 7 sites,
+    relaxation within ~100 sweeps): |m| against Yang's exact spontaneous magnetisation and e against Onsager's energy, both
+    averaged over 20 batched measurements 10 sweeps apart."""
+    import numpy as np
+    assert abs(yang_magnetisation(2.0) - 0.911319) < 1e-5 and yang_magnetisation(2.269) < 0.4
+    X = Y = 8192
+    temps = (1.8, 2.0, 2.1)
+    slabs = [ig.IsingSlab(X, Y, seed=4242 + k, temp=t, layout=ig.LAYOUT_BALLOT) for k, t in enumerate(temps)]
+    ones = np.full((Y, X // 64), 0xFFFFFFFF, dtype=np.uint32)
+    for s in slabs:
+        s.init()
+        s.write_bits(ig.BLACK, ones)
+        s.write_bits(ig.WHITE, ones)
+        assert s.count() == (X * Y, 0)
+    with ig.IsingBatch(slabs) as b:
+        b.sweep(400)
+        for _ in range(20):
+            b.sweep(10).measure_enqueue()
+        meas = b.measure_fetch()
+    n = float(X * Y)
+    for r, t in enumerate(temps):
+        m = sum(abs(p[r][0] - p[r][1]) for p in meas) / (len(meas) * n)
+        e = sum(2.0 - 2.0 * p[r][2] / n for p in meas) / len(meas)  # bond_equal counts the parallel ones of the 2N bonds
+        assert abs(m - yang_magnetisation(t)) < TOL, (t, m, yang_magnetisation(t))
+        assert abs(e - onsager_energy(t)) < TOL, (t, e, onsager_energy(t))
+    for s in slabs:
+        s.close()
+
+
+def test_whole_curve_from_the_ordered_start(gpu, tmp_path):
+    """BASELINE config 5's temperature series (T = 1.5 .. 3.0 step 0.05, 8192^2) from the ordered lattice (--tsweep-cold; the 31
+    points share batched launches): <|m|> on Yang's curve and <e> on Onsager's below T_c, <e> on Onsager's above -- away from the
+    critical region (2.2 .. 2.45), where the relaxation time outgrows any fixed number of sweeps."""
+    r = subprocess.run([CLI, "-x", "8192", "-y", "8192", "-s", "777", "--tsweep", "1.5,3.0,0.05,1000,20,10", "--tsweep-cold", "--tsweep-out", "cold"],
+                       capture_output=True, text=True, cwd=tmp_path, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "ordered start per point" in r.stdout
+    rows = [ln.split(",") for ln in open(tmp_path / "cold.csv").read().splitlines()]
+    head, rows = rows[0], rows[1:]
+    assert len(rows) == 31
+    it, im, ie = head.index("temp"), head.index("m_abs"), head.index("e")
+    checked = 0
+    for row in rows:
+        T, m, e = float(row[it]), float(row[im]), float(row[ie])
+        if T < 2.175:
+            assert abs(m - yang_magnetisation(T)) < TOL, (T, m, yang_magnetisation(T))
+        if T < 2.175 or T > 2.475:
+            assert abs(e - onsager_energy(T)) < TOL, (T, e, onsager_energy(T))
+            checked += 1
+    assert checked == 14 + 11
