@@ -18,6 +18,7 @@
 #include <getopt.h>
 #include <unistd.h>
 
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -118,6 +119,7 @@ struct TsweepSpec {
 	bool anneal = false;
 	const char *out = nullptr;
 	int replicas = 0; // temperature points simulated side by side (fresh-start mode, one device); 0 = by lattice size
+	int chains = 1;        // --tsweep-chains K: K independent lattices per temperature (seeds seed .. seed + K - 1): means with standard errors
 	bool cold = false;     // --tsweep-cold: every point starts from the ordered lattice (all spins up) instead of the random one
 	bool no_batch = false; // --tsweep-no-batch: the points side by side on streams of their own instead of batched launches (A/B)
 };
@@ -149,6 +151,12 @@ struct Moments {
 int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_t nspins, bool useJ) {
 	const int ndev = ring.n();
 	const int npts = (int)floor((ts.t1 - ts.t0) / ts.dt + 1e-9) + 1;
+	// --tsweep-chains K: every temperature is simulated K times from seeds seed .. seed + K - 1 -- independent lattices and random
+	// numbers --, so that the spread of the K averages is an honest standard error (the points of ONE chain share their random
+	// numbers across T).  A job = (point, chain); the K chains of a point always sit in the same group of lattices.
+	const int K = std::max(1, ts.chains);
+	if (K > 1 && (ndev != 1 || ts.anneal)) { fprintf(stderr, "error: --tsweep-chains needs one device and fresh starts\n"); exit(EXIT_FAILURE); }
+	const int njobs = npts * K;
 	int nrep = 1;
 	// Fresh-start mode on one device runs the temperature points as a BATCH: lattices of one shape share the tickets of every
 	// fused launch (ising_batch_sweep) and one launch measures all of them -- 8192^2 alone fills 70 % of an MI355X, 31 of them
@@ -158,30 +166,39 @@ int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_
 	bool batched = false;
 	if (ndev == 1 && !ts.anneal) {
 		const int fit = (int)std::max<unsigned long long>(1, std::min<unsigned long long>(64, (1ull << 35) / nspins));
-		nrep = ts.replicas > 0 ? ts.replicas : fit;
-		nrep = std::max(1, std::min(nrep, npts));
+		nrep = ts.replicas > 0 ? ts.replicas * K : fit;
+		nrep = std::max(K, std::min(nrep, njobs) / K * K); // (whole points: a multiple of K)
 		batched = !useJ && !ts.no_batch;
-		if (!batched && ts.replicas == 0) nrep = std::min(nrep, nspins < (1ull << 29) ? 2 : 1); // (streams of their own: two fill the chip)
+		if (!batched && ts.replicas == 0 && K == 1) nrep = std::min(nrep, nspins < (1ull << 29) ? 2 : 1); // (streams of their own: two fill the chip)
 	}
 	printf("\nTemperature sweep: %d points, T = %f .. %f step %f, %d equilibration + %d x %d measurement sweeps per point, %s\n",
 	       npts, ts.t0, ts.t0 + (npts - 1) * ts.dt, ts.dt, ts.nequil, ts.nmeas, ts.stride, ts.anneal ? (ts.cold ? "annealing from the ordered lattice" : "annealing") : (ts.cold ? "ordered start per point" : "fresh start per point"));
 	// (every point starts from the same seed: the points share their initial lattice and their random numbers, so the curves'
 	// statistical errors are correlated across T -- common random numbers; an annealing run chains the points instead)
-	if (!ts.anneal) printf("Temperature sweep: all points use seed %llu (common random numbers across T)\n", (unsigned long long)base.seed);
-	FILE *fcsv = nullptr, *fser = nullptr;
+	if (!ts.anneal && K == 1) printf("Temperature sweep: all points use seed %llu (common random numbers across T)\n", (unsigned long long)base.seed);
+	if (K > 1) printf("Temperature sweep: %d independent chains per point (seeds %llu .. %llu): mean +- standard error of the chains' averages\n", K,
+	                  (unsigned long long)base.seed, (unsigned long long)base.seed + K - 1);
+	FILE *fcsv = nullptr, *fser = nullptr, *fchn = nullptr;
 	if (ts.out) {
 		fcsv = fopen((std::string(ts.out) + ".csv").c_str(), "w");
 		fser = fopen((std::string(ts.out) + ".series.csv").c_str(), "w");
 		if (!fcsv || !fser) { fprintf(stderr, "cannot open %s.csv / .series.csv for writing\n", ts.out); exit(EXIT_FAILURE); }
-		fprintf(fcsv, "temp_bits,temp,nmeas,first_iter,last_iter,sum_M,sum_absM,sum_M2,sum_M4,sum_E,sum_E2,m_abs,m2,chi,U4,e,Cv\n");
-		fprintf(fser, "temp_bits,iter,up,down,bond_equal\n");
+		fprintf(fcsv, "temp_bits,temp,nmeas,first_iter,last_iter,sum_M,sum_absM,sum_M2,sum_M4,sum_E,sum_E2,m_abs,m2,chi,U4,e,Cv%s\n", K > 1 ? ",chain,seed" : "");
+		fprintf(fser, "temp_bits,iter,up,down,bond_equal%s\n", K > 1 ? ",chain" : "");
+		if (K > 1) {
+			fchn = fopen((std::string(ts.out) + ".chains.csv").c_str(), "w");
+			if (!fchn) { fprintf(stderr, "cannot open %s.chains.csv for writing\n", ts.out); exit(EXIT_FAILURE); }
+			fprintf(fchn, "temp_bits,temp,chains,m_abs,m_abs_err,m2,m2_err,chi,chi_err,U4,U4_err,e,e_err,Cv,Cv_err\n");
+		}
 	}
 	// replica r > 0: a context of its own with the same configuration
 	std::vector<Ring> reps(nrep);
 	reps[0] = ring;
 	for (int r = 1; r < nrep; r++) {
 		ising_ctx *c = nullptr;
-		CHECK(ising_create(&base, &c));
+		ising_config cfg = base;
+		cfg.seed = base.seed + (uint64_t)(r % K); // lattice r always carries chain r % K
+		CHECK(ising_create(&cfg, &c));
 		reps[r].ctx.push_back(c);
 	}
 	ising_batch *batch = nullptr;
@@ -195,11 +212,11 @@ int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_
 		batch_n = nb;
 		return true;
 	};
-	if (batched && !make_batch(std::min(nrep, npts))) {
+	if (batched && !make_batch(std::min(nrep, njobs))) {
 		fprintf(stderr, "temperature sweep: no batched launches (%s)\n", ising_last_error());
 		batched = false;
 		// (two at a time on private streams: what round 2 did; more lattices than that only wait for each other)
-		const int keep = ts.replicas > 0 ? nrep : std::min(nrep, nspins < (1ull << 29) ? 2 : 1);
+		const int keep = (ts.replicas > 0 || K > 1) ? nrep : std::min(nrep, nspins < (1ull << 29) ? 2 : 1);
 		for (int r = keep; r < nrep; r++) ising_destroy(reps[r].ctx[0]);
 		nrep = keep;
 		reps.resize(nrep);
@@ -207,23 +224,24 @@ int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_
 	if (batched) {
 		int h = 0, w = 0;
 		CHECK(ising_batch_info(batch, &h, &w, nullptr));
-		fprintf(stderr, "temperature sweep: %d points per batched launch (strips of %d rows, %d workgroups per CU)\n", nrep, h, w);
+		fprintf(stderr, "temperature sweep: %d %s per batched launch (strips of %d rows, %d workgroups per CU)\n", nrep, K > 1 ? "lattices" : "points", h, w);
 	} else if (nrep > 1) {
 		fprintf(stderr, "temperature sweep: %d points side by side, one stream each\n", nrep);
 		for (Ring &rp : reps) CHECK(ising_use_private_stream(rp.ctx[0]));
 	}
 	std::vector<bool> have_J(nrep, false);
+	std::vector<std::array<long double, 6>> chain_vals; // --tsweep-chains: the chains' averages of the point being completed
 	std::vector<uint32_t> all_up; // --tsweep-cold: one slab's rows at 1 bit per spin, every spin up
 	struct SeriesRow { int it; unsigned long long up, dw; long long A; };
 	const long double N = (long double)nspins;
 	long long total_sweeps = 0;
 	int it = 0;
 	const auto t0 = std::chrono::steady_clock::now();
-	for (int k0 = 0; k0 < npts; k0 += nrep) {
-		const int nb = std::min(nrep, npts - k0);
+	for (int k0 = 0; k0 < njobs; k0 += nrep) {
+		const int nb = std::min(nrep, njobs - k0);
 		std::vector<float> temps(nb);
 		for (int j = 0; j < nb; j++) {
-			temps[j] = (float)(ts.t0 + (k0 + j) * ts.dt);
+			temps[j] = (float)(ts.t0 + ((k0 + j) / K) * ts.dt);
 			Ring &rp = reps[j];
 			for (ising_ctx *c : rp.ctx) CHECK(ising_set_temperature(c, temps[j]));
 			if (!ts.anneal || k0 == 0) {
@@ -308,25 +326,56 @@ int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_
 			uint32_t tbits;
 			memcpy(&tbits, &temp, 4);
 			if (fser)
-				for (const SeriesRow &r : rows[j]) fprintf(fser, "%u,%d,%llu,%llu,%lld\n", tbits, r.it, r.up, r.dw, r.A);
+				for (const SeriesRow &r : rows[j]) {
+					fprintf(fser, "%u,%d,%llu,%llu,%lld", tbits, r.it, r.up, r.dw, r.A);
+					if (K > 1) fprintf(fser, ",%d", j % K);
+					fprintf(fser, "\n");
+				}
 			total_sweeps += ts.nequil + (long long)ts.nmeas * ts.stride;
 			const Moments &q = mo[j];
 			const long double n = q.n;
 			const long double mabs = (long double)q.sAbsM / (n * N), m2 = (long double)q.sM2 / (n * N * N), m4 = q.sM4 / (n * N * N * N * N);
 			const long double e1 = (long double)q.sE / (n * N), e2 = (long double)q.sE2 / (n * N * N);
 			const long double chi = N * (m2 - mabs * mabs) / temp, u4 = 1.0L - m4 / (3.0L * m2 * m2), cv = N * (e2 - e1 * e1) / ((long double)temp * temp);
-			printf("T = %f: <|m|> = %9.6f, <m^2> = %E, chi = %E, U4 = %9.6f, <e> = %9.6f, Cv = %E (iters %d-%d)\n", temp, (double)mabs, (double)m2,
-			       (double)chi, (double)u4, (double)e1, (double)cv, first, it);
-			if (fcsv)
-				fprintf(fcsv, "%u,%.9g,%d,%d,%d,%s,%s,%s,%.21Lg,%s,%s,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g\n", tbits, (double)temp, q.n, first, it,
+			if (K == 1)
+				printf("T = %f: <|m|> = %9.6f, <m^2> = %E, chi = %E, U4 = %9.6f, <e> = %9.6f, Cv = %E (iters %d-%d)\n", temp, (double)mabs, (double)m2,
+				       (double)chi, (double)u4, (double)e1, (double)cv, first, it);
+			if (fcsv) {
+				fprintf(fcsv, "%u,%.9g,%d,%d,%d,%s,%s,%s,%.21Lg,%s,%s,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g", tbits, (double)temp, q.n, first, it,
 				        i128_str(q.sM).c_str(), i128_str(q.sAbsM).c_str(), i128_str(q.sM2).c_str(), q.sM4, i128_str(q.sE).c_str(),
 				        i128_str(q.sE2).c_str(), (double)mabs, (double)m2, (double)chi, (double)u4, (double)e1, (double)cv);
+				if (K > 1) fprintf(fcsv, ",%d,%llu", j % K, (unsigned long long)base.seed + (unsigned long long)(j % K));
+				fprintf(fcsv, "\n");
+			}
+			if (K > 1) { // the point is complete with its last chain: mean and standard error of the chains' averages
+				if (j % K == 0) chain_vals.clear();
+				chain_vals.push_back({mabs, m2, chi, u4, e1, cv});
+				if (j % K == K - 1) {
+					long double mean[6], err[6];
+					for (int q6 = 0; q6 < 6; q6++) {
+						long double sum = 0, dev2 = 0;
+						for (const auto &cv6 : chain_vals) sum += cv6[q6];
+						mean[q6] = sum / K;
+						for (const auto &cv6 : chain_vals) dev2 += (cv6[q6] - mean[q6]) * (cv6[q6] - mean[q6]);
+						err[q6] = sqrtl(dev2 / (K - 1) / K);
+					}
+					printf("T = %f: <|m|> = %9.6f +- %8.6f, chi = %E +- %.1E, U4 = %9.6f +- %8.6f, <e> = %9.6f +- %8.6f, Cv = %E +- %.1E (%d chains, iters %d-%d)\n",
+					       temp, (double)mean[0], (double)err[0], (double)mean[2], (double)err[2], (double)mean[3], (double)err[3], (double)mean[4], (double)err[4],
+					       (double)mean[5], (double)err[5], K, first, it);
+					if (fchn) {
+						fprintf(fchn, "%u,%.9g,%d", tbits, (double)temp, K);
+						for (int q6 = 0; q6 < 6; q6++) fprintf(fchn, ",%.17g,%.17g", (double)mean[q6], (double)err[q6]);
+						fprintf(fchn, "\n");
+					}
+				}
+			}
 		}
 	}
 	for (Ring &rp : reps) CHECK(ising_ring_synchronize(rp.ctx.data(), rp.n()));
 	const double et = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	if (fcsv) fclose(fcsv);
 	if (fser) fclose(fser);
+	if (fchn) fclose(fchn);
 	if (batch) ising_batch_destroy(batch);
 	for (int r = 1; r < nrep; r++) ising_destroy(reps[r].ctx[0]);
 	printf("\nTemperature sweep: %lld update steps in %E ms, %.2lf flips/ns (initialisation and measurements included)\n\n", total_sweeps, et,
@@ -364,7 +413,7 @@ int main(int argc, char **argv) {
 	    {"devmap", required_argument, 0, 4},   {"layout", required_argument, 0, 5},  {"tsweep", required_argument, 0, 6},
 	    {"tsweep-anneal", no_argument, 0, 7},  {"tsweep-out", required_argument, 0, 8}, {"checkpoint", required_argument, 0, 9},
 	    {"resume", required_argument, 0, 10},  {"transport", required_argument, 0, 11}, {"tsweep-replicas", required_argument, 0, 12},
-	    {"tsweep-no-batch", no_argument, 0, 13}, {"tsweep-cold", no_argument, 0, 14},
+	    {"tsweep-no-batch", no_argument, 0, 13}, {"tsweep-cold", no_argument, 0, 14}, {"tsweep-chains", required_argument, 0, 15},
 	    {0, 0, 0, 0}};
 	while (1) {
 		int option_index = 0;
@@ -442,6 +491,10 @@ int main(int argc, char **argv) {
 			break;
 		case 13: ts.no_batch = true; break;
 		case 14: ts.cold = true; break;
+		case 15:
+			ts.chains = atoi(optarg);
+			if (ts.chains < 1 || ts.chains > 64) { fprintf(stderr, "error: --tsweep-chains takes 1 .. 64\n"); exit(EXIT_FAILURE); }
+			break;
 		case '?': exit(EXIT_FAILURE);
 		default: fprintf(stderr, "unknown option: %c\n", och); exit(EXIT_FAILURE);
 		}

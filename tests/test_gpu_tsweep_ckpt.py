@@ -82,6 +82,39 @@ def test_tsweep_replicas_give_every_point_the_series_of_a_run_of_its_own(gpu, tm
         assert open(tmp_path / ("a" + ext)).read() == open(tmp_path / ("b" + ext)).read()
 
 
+@pytest.mark.parametrize("extra", [[], ["--layout", "ballot"], ["--layout", "ballot", "--tsweep-no-batch"], ["--layout", "ballot", "--tsweep-replicas", "2"]])
+def test_tsweep_chains_are_runs_of_their_own_with_error_bars(gpu, tmp_path, extra):
+    """--tsweep-chains K simulates every temperature K times from seeds s .. s + K - 1 (all lattices in the same batched launches
+    where the layout allows): chain c's rows of both CSV files are those of a single-chain run with seed s + c, and the summary
+    file holds the mean of the chains' averages with their standard error."""
+    import math
+    base = ["-x", 8192, "-y", 512, "--tsweep", "2.4,2.6,0.1,33,4,5"] + extra
+    K, seed = 3, 70
+    run(base + ["-s", seed, "--tsweep-chains", K, "--tsweep-out", "all"], cwd=tmp_path)
+    rows = [ln.split(",") for ln in open(tmp_path / "all.csv").read().splitlines()]
+    head, rows = rows[0], rows[1:]
+    assert head[-2:] == ["chain", "seed"] and len(rows) == 3 * K
+    series = [ln.split(",") for ln in open(tmp_path / "all.series.csv").read().splitlines()[1:]]
+    for c in range(K):
+        run(base + ["-s", seed + c, "--tsweep-out", f"one{c}"], cwd=tmp_path)
+        one = [ln.split(",") for ln in open(tmp_path / f"one{c}.csv").read().splitlines()[1:]]
+        mine = [r[:-2] for r in rows if r[-2:] == [str(c), str(seed + c)]]
+        assert mine == one, c
+        one_series = [ln.split(",") for ln in open(tmp_path / f"one{c}.series.csv").read().splitlines()[1:]]
+        assert [r[:-1] for r in series if r[-1] == str(c)] == one_series, c
+    summ = [ln.split(",") for ln in open(tmp_path / "all.chains.csv").read().splitlines()]
+    shead, summ = summ[0], summ[1:]
+    assert len(summ) == 3
+    for k, srow in enumerate(summ):
+        assert int(srow[shead.index("chains")]) == K
+        for name in ("m_abs", "e", "chi", "Cv", "U4", "m2"):
+            vals = [float(r[head.index(name)]) for r in rows[k * K:(k + 1) * K]]
+            mean = sum(vals) / K
+            err = math.sqrt(sum((v - mean) ** 2 for v in vals) / (K - 1) / K)
+            assert abs(float(srow[shead.index(name)]) - mean) <= 1e-12 * max(1.0, abs(mean)), name
+            assert abs(float(srow[shead.index(name + "_err")]) - err) <= 1e-9 * abs(mean) + 1e-6 * err, name
+
+
 @pytest.mark.parametrize("layout", [ig.LAYOUT_BALLOT, ig.LAYOUT_DENSE])
 def test_enqueued_measurements_equal_count_and_bond_sum(gpu, layout):
     """ising_measure_enqueue / _fetch (what --tsweep reads its series with): same integers as the blocking calls, for
