@@ -153,3 +153,21 @@ def test_readme_eight_gpu_transcript_as_one_slab(gpu):
     out = run(["-y", "524288", "-x", "65536", "-n", "128", "-p", "16", "-t", "1.5"])
     for line in README_8GPU:
         assert line in out, line
+
+
+def test_baseline_config2_command_line_at_full_length(gpu):
+    """BASELINE config 2 as a user types it -- 16384 x 16384, T = T_c (-a 1), seed 1234, 10^5 sweeps, a line every 10000 -- against
+    the oracle's full-length golden: every magnetisation line, character for character."""
+    import json
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config2_16384_full.json")))
+    out = run(["-x", "16384", "-y", "16384", "-n", "100000", "-a", "1", "-s", "1234", "-p", "10000"])
+    n = 16384 * 16384
+    pts = {p["sweeps"]: p for p in fx["points"]}
+    for it in range(10000, 100001, 10000):
+        p = pts[it]
+        assert (f"        magnetization: {abs(p['up'] - p['down']) / n:9.6f}, up_s: {p['up']:12d}, dw_s: {p['down']:12d} "
+                f"(iter: {it:8d})\n") in out, it
+    p = pts[100000]
+    assert f"Final   magnetization: {abs(p['up'] - p['down']) / n:9.6f}, up_s: {p['up']:12d}, dw_s: {p['down']:12d} (iter:   100000)\n" in out
+    m = re.search(r"Kernel execution time for 100000 update steps: \S+ ms, (\d+\.\d\d) flips/ns", out)
+    assert m and float(m.group(1)) > 2500.0, out[-400:]  # (3300 on an idle MI355X; the floor only catches a fall back to a slow path)

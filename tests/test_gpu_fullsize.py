@@ -44,6 +44,26 @@ def test_config2_16384_golden_states(gpu, layout):
                 assert h.hexdigest() == pt["sha256"], pt["sweeps"]
 
 
+def test_config2_full_length_against_the_oracle(gpu):
+    """BASELINE config 2 end to end: all 10^5 sweeps of the 16384^2 lattice, counts and bond sums at every point the oracle
+    recorded on the way (tests/golden/make_golden_config2_full.py: 2.7e13 spin updates on the CPU), SHA-256 of the packed state
+    half way and at the end."""
+    fx = _gold("config2_16384_full.json")
+    assert fx["points"][-1]["sweeps"] == 100000 and len(fx["points"]) >= 20
+    with ig.IsingSlab(fx["X"], fx["Ytot"], seed=fx["seed"], temp=_f32(fx["temp_bits"])) as s:
+        assert s.fused
+        s.init()
+        for pt in fx["points"]:
+            s.sweep(pt["sweeps"] - s.it)
+            assert s.count() == (pt["up"], pt["down"]), pt["sweeps"]
+            assert s.bond_equal() == pt["bond_equal"], pt["sweeps"]
+            if pt["sweeps"] in (50000, 100000):
+                h = hashlib.sha256()
+                h.update(s.read(ig.BLACK).tobytes())
+                h.update(s.read(ig.WHITE).tobytes())
+                assert h.hexdigest() == pt["sha256"], pt["sweeps"]
+
+
 def test_config2_16384_full_state_vs_live_oracle(gpu, oracle_mod):
     X = Y = 16384
     orc = oracle_mod.OracleLattice(X, Y, seed=1234, temp=oracle_mod.CRIT_TEMP).init()
