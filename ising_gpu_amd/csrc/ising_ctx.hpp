@@ -179,6 +179,8 @@ int ballot_measure_into_acc(ising_ctx *c);
 // makes the slab's stream (or stream `s`) wait until the halo rows of `color` delivered by the ring are in place
 int halo_ready(ising_ctx *c, int color);
 int halo_ready_on(ising_ctx *c, int color, hipStream_t s);
+// one slab per process: the sum of a host value over all ranks (collective; also the ranks' barrier)
+int rank_sum_u64(ising_ctx *c, unsigned long long mine, unsigned long long *sum);
 // ising_update_edges on another stream of the slab's device / the interior rows 1 .. Y-2; `stop` fires when the launch is done
 int update_edges_on(ising_ctx *c, int it, int color, hipStream_t s, hipEvent_t stop);
 int update_interior(ising_ctx *c, int it, int color, hipEvent_t stop);

@@ -382,8 +382,11 @@ int ising_rank_checkpoint_save(ising_ctx *c, const char *path, int64_t it) {
 		if (rc == ISING_OK && (fseeko(fp, (off_t)(sizeof(h) + h.payload_bytes), SEEK_SET) != 0 || fwrite(&up, sizeof(up), 1, fp) != 1)) rc = fail(ISING_E_IO, "cannot size %s: %s", tmp.c_str(), strerror(errno));
 		if (fp && fclose(fp) != 0 && rc == ISING_OK) rc = fail(ISING_E_IO, "closing %s failed: %s", tmp.c_str(), strerror(errno));
 	}
-	uint64_t t0 = 0, t1 = 0;
-	if (int rc2 = ising_rank_count(c, &t0, &t1)) return rc2; // (barrier: the file exists)
+	// the ranks agree on every stage's outcome (a sum of failure flags, which is also their barrier): nobody writes into a file
+	// that could not be laid out, and a file some rank could not fill never gets its name
+	unsigned long long bad = 0;
+	if (int rc2 = ising_host::rank_sum_u64(c, rc != ISING_OK, &bad)) return rc2; // (the file exists)
+	if (bad && rc == ISING_OK) rc = fail(ISING_E_IO, "rank 0 could not create %s", tmp.c_str());
 	if (rc == ISING_OK) {
 		FILE *fp = fopen(tmp.c_str(), "r+b");
 		if (!fp) rc = fail(ISING_E_IO, "cannot open %s: %s", tmp.c_str(), strerror(errno));
@@ -400,9 +403,14 @@ int ising_rank_checkpoint_save(ising_ctx *c, const char *path, int64_t it) {
 		}
 		if (fp && fclose(fp) != 0 && rc == ISING_OK) rc = fail(ISING_E_IO, "closing %s failed: %s", tmp.c_str(), strerror(errno));
 	}
-	if (int rc2 = ising_rank_count(c, &t0, &t1)) return rc2; // (barrier: every rank's rows are in the file)
-	if (rc == ISING_OK && c->cfg.slab == 0 && rename(tmp.c_str(), path) != 0) rc = fail(ISING_E_IO, "cannot rename %s to %s: %s", tmp.c_str(), path, strerror(errno));
-	if (int rc2 = ising_rank_count(c, &t0, &t1)) return rc2; // (barrier: the file has its name)
+	if (int rc2 = ising_host::rank_sum_u64(c, rc != ISING_OK, &bad)) return rc2; // (every rank's rows are in the file)
+	if (bad && rc == ISING_OK) rc = fail(ISING_E_IO, "%llu rank(s) could not write their rows into %s", bad, tmp.c_str());
+	if (c->cfg.slab == 0) {
+		if (rc == ISING_OK && rename(tmp.c_str(), path) != 0) rc = fail(ISING_E_IO, "cannot rename %s to %s: %s", tmp.c_str(), path, strerror(errno));
+		else if (rc != ISING_OK) (void)remove(tmp.c_str());
+	}
+	if (int rc2 = ising_host::rank_sum_u64(c, rc != ISING_OK, &bad)) return rc2; // (the file has its name)
+	if (bad && rc == ISING_OK) rc = fail(ISING_E_IO, "rank 0 could not give %s its name", path);
 	return rc;
 }
 
@@ -410,10 +418,12 @@ int ising_rank_checkpoint_load(ising_ctx *c, const char *path, int64_t *it) {
 	if (!c || !path) return fail(ISING_E_ARG, "null argument");
 	if (!c->rank_mode) return fail(ISING_E_STATE, "the slab is not attached to a multi-process ring (single-process rings: ising_ring_checkpoint_load)");
 	if (int rc = ising_rank_wait(c, -1)) return rc;
+	// (a rank that fails still takes part in the collectives below: the ranks stay in step and all of them report the failure)
 	FILE *fp = fopen(path, "rb");
-	if (!fp) return fail(ISING_E_IO, "cannot open %s: %s", path, strerror(errno));
+	int rc = fp ? ISING_OK : fail(ISING_E_IO, "cannot open %s: %s", path, strerror(errno));
 	CheckpointHeader h;
-	int rc = read_header(fp, path, &h);
+	memset(&h, 0, sizeof(h));
+	if (rc == ISING_OK) rc = read_header(fp, path, &h);
 	if (rc == ISING_OK && (h.X != c->cfg.X || h.Y_total != c->cfg.Y * c->cfg.nslabs))
 		rc = fail(ISING_E_ARG, "%s holds a %d x %d lattice, the ring is %d x %d", path, h.Y_total, h.X, c->cfg.Y * c->cfg.nslabs, c->cfg.X);
 	if (rc == ISING_OK && h.seed != c->cfg.seed) rc = fail(ISING_E_ARG, "%s was written with seed %llu, the ring uses %llu", path, (unsigned long long)h.seed, (unsigned long long)c->cfg.seed);
@@ -432,12 +442,13 @@ int ising_rank_checkpoint_load(ising_ctx *c, const char *path, int64_t *it) {
 	}
 	uint64_t up_file = 0;
 	if (rc == ISING_OK && (fseeko(fp, (off_t)(sizeof(h) + h.payload_bytes), SEEK_SET) != 0 || fread(&up_file, sizeof(up_file), 1, fp) != 1)) rc = fail(ISING_E_IO, "%s: short read", path);
-	fclose(fp);
-	// (every rank takes part in the count whatever happened to it: the ranks stay in step)
+	if (fp) fclose(fp);
 	uint64_t up = 0, down = 0;
-	const int rc2 = ising_rank_count(c, &up, &down);
-	if (rc == ISING_OK) rc = rc2;
+	if (int rc2 = ising_rank_count(c, &up, &down)) return rc2;
 	if (rc == ISING_OK && up != up_file) rc = fail(ISING_E_IO, "%s is damaged or was not read whole: the ring holds %llu up spins, the file records %llu", path, (unsigned long long)up, (unsigned long long)up_file);
+	unsigned long long bad = 0;
+	if (int rc2 = ising_host::rank_sum_u64(c, rc != ISING_OK, &bad)) return rc2;
+	if (bad && rc == ISING_OK) rc = fail(ISING_E_IO, "%llu rank(s) could not load their rows from %s: the ring's state is undefined", bad, path);
 	if (rc == ISING_OK && it) *it = h.it;
 	return rc;
 }

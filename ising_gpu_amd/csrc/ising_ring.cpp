@@ -951,3 +951,11 @@ int ising_correlations(ising_ctx *c, int ncorr, int64_t *sums) {
 }
 
 } // extern "C"
+
+int ising_host::rank_sum_u64(ising_ctx *c, unsigned long long mine, unsigned long long *sum) {
+	if (int rc = rank_check(c)) return rc;
+	if (c->transport == ISING_TRANSPORT_IPC) return ising_ipc::allreduce_u64(c, mine, sum);
+	if (int rc = bind(c)) return rc;
+	HIP_TRY(hipMemcpyAsync(c->d_acc + 3, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
+	return rank_allreduce_u64(c, c->d_acc + 3, sum);
+}

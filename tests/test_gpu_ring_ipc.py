@@ -32,7 +32,8 @@ def test_rank_ring_over_ipc_processes_share_one_gpu(gpu, world, port):
     assert r.stdout.count("== oracle (sub-lattice run)") == world, r.stdout[-3000:]
     # ... and the three configurations without couplings checkpoint, continue, load and continue again
     assert r.stdout.count("continuation == oracle") == 3 * world, r.stdout[-3000:]
-    assert r.stdout.count("ghost rows 32") == 6 * world, r.stdout[-3000:]  # (5 sweep reports + the checkpoint report of the deep configurations)
+    assert r.stdout.count("ghost rows 32") == 7 * world, r.stdout[-3000:]  # (5 sweep reports + the two checkpoint reports of the deep configurations)
+    assert r.stdout.count("doomed checkpoint calls failed on this rank, the ring went on") == 3 * world, r.stdout[-3000:]
 
 
 def test_two_ranks_over_ipc_reproduce_the_bench_ring_golden(gpu):
@@ -67,6 +68,35 @@ def test_deep_exchange_schedules_agree(gpu, oracle_mod, monkeypatch, transport, 
         assert ring.count() == orc.count() and ring.bond_equal() == orc.bond_equal()
     ring.quiesce()
     assert np.array_equal(slab.read(ig.BLACK), orc.black) and np.array_equal(slab.read(ig.WHITE), orc.white)
+    ring.close()
+    slab.close()
+
+
+@pytest.mark.parametrize("transport", ["rccl", "ipc"])
+def test_ring_of_one_checkpoints_through_the_rank_calls(gpu, oracle_mod, tmp_path, transport):
+    """ising_rank_checkpoint_save / _load on a ring of one (their stage outcomes travel through the transport's all-reduce): the
+    continuation repeats itself, and calls that cannot succeed return errors instead of hanging."""
+    import ising_gpu_amd as ig
+    X, Y, seed = 8192, 256, 5
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=oracle_mod.CRIT_TEMP).init()
+    slab = ig.IsingSlab(X, Y, seed=seed, temp=ig.CRIT_TEMP_F32, layout=ig.LAYOUT_BALLOT, ring_halo=True)
+    ring = ig.NativeRing(slab, transport=transport).init()
+    ring.sweep(7)
+    path = str(tmp_path / "one.ckpt")
+    ring.checkpoint_save(path)
+    ring.sweep(40)
+    ring.checkpoint_load(path)
+    assert ring.it == 7
+    ring.sweep(40)
+    orc.sweep(47)
+    assert ring.count() == orc.count() and ring.bond_equal() == orc.bond_equal()
+    with pytest.raises(ig.IsingError):
+        ring.checkpoint_load(str(tmp_path / "missing.ckpt"))
+    with pytest.raises(ig.IsingError):
+        ring.checkpoint_save(str(tmp_path / "no_such_dir" / "x.ckpt"))
+    ring.sweep(2)
+    orc.sweep(2)
+    assert ring.count() == orc.count()
     ring.close()
     slab.close()
 

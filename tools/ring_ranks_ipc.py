@@ -97,6 +97,18 @@ def check_small():
             ok = got == want == (orc.count(), orc.bond_equal())
             print(f"rank {rank} ipc layout {layout} ghost rows {depth}: checkpoint at {at}, continuation {'==' if ok else '!='} oracle", flush=True)
             assert ok
+            # calls that cannot succeed fail on EVERY rank, at once (the ranks agree on each stage's outcome), and leave the ring usable
+            for doomed in (lambda: ring.checkpoint_load(os.path.join(ckdir, "missing.ckpt")),
+                           lambda: ring.checkpoint_save(os.path.join(ckdir, "no_such_dir", "x.ckpt"))):
+                try:
+                    doomed()
+                    raise SystemExit("a checkpoint call that cannot succeed returned")
+                except ig.IsingError:
+                    pass
+            ring.sweep(1)
+            orc.sweep(1)
+            assert (ring.count(), ring.bond_equal()) == (orc.count(), orc.bond_equal())
+            print(f"rank {rank} ipc layout {layout} ghost rows {depth}: doomed checkpoint calls failed on this rank, the ring went on", flush=True)
             if rank == 0:
                 with ig.IsingSlab(X, Y * world, device=dev, seed=seed, temp=temp, layout=ig.LAYOUT_DENSE) as one:
                     single = ig.SlabSet([one])
