@@ -267,7 +267,9 @@ int ising_ring_checkpoint_save(ising_ctx **ctxs, int n, const char *path, int64_
 int ising_ring_checkpoint_load(ising_ctx **ctxs, int n, const char *path, int64_t *it);
 /* The same file from / into a ring of processes (ising_rank_*): collective; every rank writes / reads its own rows at their
  * place in the global row order, so the file is the one a single process would write.  `path` must name the same file for every
- * rank.  After a load: ising_rank_exchange for both colours, continue with first_it = *it + 1. */
+ * rank.  After a load: ising_rank_exchange for both colours, continue with first_it = *it + 1.  The ranks agree on the outcome of
+ * every stage: a call that fails on one rank returns an error on all of them (nobody is left waiting), and a file some rank could
+ * not fill is removed instead of getting its name; after a failed load the ring's spins are undefined. */
 int ising_rank_checkpoint_save(ising_ctx *ctx, const char *path, int64_t it);
 int ising_rank_checkpoint_load(ising_ctx *ctx, const char *path, int64_t *it);
 
