@@ -55,6 +55,21 @@ def test_argument_validation_messages_without_gpu():
         assert "multiple of" in str(e.value) or "no HIP device" in str(e.value)
 
 
+def test_integration_doc_maps_every_entry_point():
+    """INTEGRATION.md's table says, for every function of the header, which reference interface it replaces (or that it is new).
+    Families are abbreviated there (`ising_batch_create` / `_sweep`, `ising_init_couplings*`, `ising_required_bytes[_layout]`)."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    doc += " ".join(m.group(1) + m.group(2) for m in re.finditer(r"(ising_[a-z_0-9]+)\[(_[a-z_0-9]+)\]", doc))
+    missing = []
+    for sym in header_symbols():
+        family, tail = sym.rsplit("_", 1)
+        lines = [ln for ln in doc.splitlines() if family in ln]
+        if sym in doc or (family + "*") in doc or any(("`_" + tail + "`") in ln or ("/ `_" + tail) in ln or ("_" + tail + "`") in ln for ln in lines):
+            continue
+        missing.append(sym)
+    assert not missing, missing
+
+
 def test_header_is_plain_c_and_a_c_caller_links(tmp_path):
     """The boundary is a C ABI: include/ising_hip.h compiles as pedantic C99, and a C program (what a cgo / JNI / ctypes-free host
     would be) links against libising_hip.so and calls it -- only entry points that need no device here."""
