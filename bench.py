@@ -376,12 +376,15 @@ def main():
             "config": {"workload": f"{args.y * world}x{args.x} lattice ({args.y}x{args.x} per GPU), T=Tc, seed {args.seed}, "
                                    "Philox4x32-10 per site; device layout " + layout_text
                                    + ", results identical to the reference's packed state", "x": args.x, "y_per_gpu": args.y,
-                       "parallelism": f"slab{world}", "nranks": world, "exchange": ring_name, "strip_rows": slab.strip_rows,
+                       "parallelism": f"slab{world}", "nranks": world, "physical_gpus": min(world, ndev), "exchange": ring_name, "strip_rows": slab.strip_rows,
                        "device_layout": layout_name, "sweeps_per_call": batch, "warmup_sweeps_per_call": batch_warm, "preheat_ms": args.preheat_ms, "preheat_sweeps": preheat_sweeps,
                        "up": up, "down": down, "rank_up": rank_up, "parity_checked": parity,
                        "parity_source": None if gold is None else "tests/golden (CPU oracle, same seed, same number of sweeps)"},
             "roofline": roof,
         }
+        if shared:  # more ranks than devices: `value` is what the physical GPUs delivered together, not a scaling point
+            line["config"]["note"] = (f"{world} ranks share {ndev} physical GPU(s): the N > 1 path (processes, peer transport, ring schedule) executed and "
+                                      "checked, not a scaling measurement")
         if parity is False:
             line["config"]["parity_expected"] = list(gold)
         if not ringed and not args.no_cpu_baseline:
