@@ -953,20 +953,20 @@ int ising_sweep_info(ising_ctx *c, int *fused, int *max_sweeps_per_launch) {
 int ising_sweep_timed(ising_ctx *c, int first_it, int nsweeps, float *elapsed_ms) {
 	if (!c || !elapsed_ms) return fail(ISING_E_ARG, "null argument");
 	if (int rc = bind(c)) return rc;
-	hipEvent_t e0, e1;
-	HIP_TRY(hipEventCreate(&e0));
-	HIP_TRY(hipEventCreate(&e1));
-	HIP_TRY(hipEventRecord(e0, c->stream));
-	int rc = ising_sweep(c, first_it, nsweeps);
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	hipError_t e = hipEventCreate(&e0);
+	if (e == hipSuccess) e = hipEventCreate(&e1);
+	if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
+	int rc = e == hipSuccess ? ising_sweep(c, first_it, nsweeps) : fail(ISING_E_HIP, "event timing failed: %s", hipGetErrorString(e));
 	if (rc == ISING_OK) {
-		hipError_t e = hipEventRecord(e1, c->stream);
+		e = hipEventRecord(e1, c->stream);
 		if (e == hipSuccess) e = hipEventSynchronize(e1);
 		if (e == hipSuccess) e = hipEventElapsedTime(elapsed_ms, e0, e1);
 		if (e != hipSuccess) rc = fail(ISING_E_HIP, "event timing failed: %s", hipGetErrorString(e));
 		else rc = ising_host::check_abort(c);
 	}
-	(void)hipEventDestroy(e0);
-	(void)hipEventDestroy(e1);
+	if (e0) (void)hipEventDestroy(e0);
+	if (e1) (void)hipEventDestroy(e1);
 	return rc;
 }
 
