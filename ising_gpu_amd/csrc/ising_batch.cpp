@@ -107,7 +107,7 @@ int ising_batch_create(ising_ctx **ctxs, int n, ising_batch **out) {
 int ising_batch_destroy(ising_batch *b) {
 	if (!b) return ISING_OK;
 	(void)hipSetDevice(b->device);
-	if (!b->m.empty()) (void)hipStreamSynchronize(b->stream());
+	(void)hipDeviceSynchronize(); // (not the members' stream: a caller may have destroyed them first, against the header's advice)
 	if (b->d_rep) (void)hipFree(b->d_rep);
 	if (b->h_rep) (void)hipHostFree(b->h_rep);
 	if (b->ev_upload) (void)hipEventDestroy(b->ev_upload);

@@ -312,6 +312,12 @@ class IsingBatch:
             self._lib.ising_batch_destroy(self._h)
             self._h = C.c_void_p()
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def __enter__(self):
         return self
 
