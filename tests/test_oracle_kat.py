@@ -140,3 +140,47 @@ def test_basic_cpu_baseline_statistics():
     b2.sweeps(50)
     m2, e2 = b2.observables()
     assert abs(m2) < 0.05 and e2 > -0.6
+
+
+@pytest.mark.parametrize("sub", [None, (2048, 32)])
+def test_correlation_sums_against_a_second_restatement_and_the_energy(sub):
+    """The reference publishes no -c output, so orc_corr (which walks the packed words like getCorr2D_k, optimized/main.cu:870-965)
+    is checked against a second, independent restatement: the lattice unpacked to one spin per site through the text-dump path
+    (dumpLattice's order, :1140-1209) and correlated with whole-array shifts -- periodic in X and Y, or inside every sub-lattice
+    (getCorr2DRepl_k, :967-1070).  And distance 1 is the energy: sums[0] = (parallel - antiparallel bonds) = 2 A - 2 N."""
+    X, Y = 4096, 64
+    kw = dict(XSL=sub[0], YSL=sub[1]) if sub else {}
+    L = oracle.OracleLattice(X, Y, seed=314, temp=2.0, **kw).init().sweep(4)
+    rows = L.dump_rows(0, Y).decode().split("\n")[:Y]
+    s = np.array([[int(ch, 16) for ch in row] for row in rows], dtype=np.int8)
+    assert s.shape == (Y, X) and set(np.unique(s)) <= {0, 1}
+    xs, ys = sub if sub else (X, Y)
+    blocks = s.reshape(Y // ys, ys, X // xs, xs)  # [block row, row in block, block column, column in block]
+    want = []
+    for j in range(1, 9):
+        right = np.where(blocks == np.roll(blocks, -j, axis=3), 1, -1).sum()
+        below = np.where(blocks == np.roll(blocks, -j, axis=1), 1, -1).sum()
+        want.append(int(right + below))
+    assert L.corr(8) == want
+    assert want[0] == 2 * L.bond_equal() - 2 * X * Y
+
+
+def test_coupling_path_against_the_plain_path():
+    """The reference publishes no -J output, so orc_update_color_J is tied to the pinned plain path through two exact maps.
+    All bonds ferromagnetic (coupling bits 0): the same trajectory.  All bonds antiferromagnetic (every bit set: each of the four
+    neighbours enters flipped, optimized/main.cu:588-612): the gauge transformation that flips one colour maps the antiferromagnet
+    onto the ferromagnet -- energy differences, hence acceptances with the same random numbers, are the same -- so the trajectory
+    from the black-complemented start is the black-complemented plain trajectory."""
+    X, Y, seed, temp, n = 4096, 64, 2718, 2.0, 4
+    plain = oracle.OracleLattice(X, Y, seed=seed, temp=temp).init().sweep(n)
+    ferro = oracle.OracleLattice(X, Y, seed=seed, temp=temp).init().init_couplings(0.0)
+    assert not ferro.hamB.any() and not ferro.hamW.any()
+    ferro.sweep(n)
+    assert np.array_equal(ferro.black, plain.black) and np.array_equal(ferro.white, plain.white)
+    ones = np.uint64(0x1111111111111111)
+    anti = oracle.OracleLattice(X, Y, seed=seed, temp=temp).init().init_couplings(1.0)
+    anti.hamB[:] = np.uint64(0xFFFFFFFFFFFFFFFF)  # (a uniform draw may round to 1.0f and leave a bit of init_couplings(1.0) unset)
+    anti.hamW[:] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    anti.black ^= ones
+    anti.sweep(n)
+    assert np.array_equal(anti.black ^ ones, plain.black) and np.array_equal(anti.white, plain.white)
