@@ -148,6 +148,12 @@ int ising_init_couplings_black(ising_ctx *ctx);
 int ising_init_couplings_white(ising_ctx *ctx);
 /* Copies rows of a coupling array (which = ISING_BLACK / ISING_WHITE for hamB / hamW) to host memory. Blocking. */
 int ising_read_couplings(ising_ctx *ctx, int which, int64_t row0, int64_t nrows, uint64_t *dst_host);
+/* The other way round (new: the reference only draws its couplings at random): a whole coupling array of a lattice that wraps in
+ * place (nslabs == 1), Y rows of X/32 words in the reference's form -- one nibble per site, bits <up, down, left, right>
+ * (optimized/main.cu:588-612: a set bit flips that neighbour's spin before the energy sum = an antiferromagnetic bond) -- is
+ * copied to the device and brought into the form the context's update kernels read.  The caller keeps hamB and hamW consistent
+ * (hamiltInitW_k, :214-331, derives the white array from the black one).  Blocking. */
+int ising_write_couplings(ising_ctx *ctx, int which, const uint64_t *src_host);
 
 /* Recomputes the exp table / integer thresholds (optimized/main.cu:1684-1703, temperature ramp :1848-1859). */
 int ising_set_temperature(ising_ctx *ctx, float temp);

@@ -1248,4 +1248,25 @@ int ising_read_couplings(ising_ctx *c, int which, int64_t row0, int64_t nrows, u
 	return ISING_OK;
 }
 
+int ising_write_couplings(ising_ctx *c, int which, const uint64_t *src_host) {
+	if (!c || !src_host) return fail(ISING_E_ARG, "null argument");
+	if (which != ISING_BLACK && which != ISING_WHITE) return fail(ISING_E_ARG, "bad coupling array %d", which);
+	if (!c->cfg.use_J) return fail(ISING_E_STATE, "couplings are not enabled (use_J)");
+	if (!c->wrap || c->ham_ghost != 1) return fail(ISING_E_STATE, "ising_write_couplings needs a lattice that wraps in place (nslabs == 1 without ring halo rows)");
+	if (int rc = bind(c)) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream)); // (launches that still read the array)
+	HIP_TRY(hipMemcpy(c->ham(which), src_host, c->ham_words() * sizeof(uint64_t), hipMemcpyHostToDevice));
+	// into the form the update kernels of this layout read (ising_init_couplings_white): the array just written -- and, where the
+	// arrays were still as generated (no white initialisation yet, or nothing at all: zeros are zeros in every form), the other one
+	const int want = c->ham_form ? c->ham_form : (c->ballot ? 2 : (c->dense ? 1 : 0));
+	for (int w = 0; w < 2; w++) {
+		if (w != which && c->ham_form == want) continue;
+		if (want == 2) HIP_TRY(ising::launch_ham_to_ballot(c->ham(w), c->gx, c->cfg.Y, c->stream));
+		if (want == 1) HIP_TRY(ising::launch_ham_planes(c->ham(w), c->ham_words() / 2, c->stream));
+	}
+	c->ham_form = want;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return ISING_OK;
+}
+
 } // extern "C"

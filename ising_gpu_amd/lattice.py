@@ -113,6 +113,12 @@ class IsingSlab:
         check(self._lib.ising_read_couplings(self._h, which, 0, self.Y, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def write_couplings(self, which: int, words: np.ndarray):
+        """A whole coupling array in the reference's form: (Y, X/32) uint64, one nibble per site, bits <up, down, left, right>."""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        assert words.shape == (self.Y, self.lld), words.shape
+        check(self._lib.ising_write_couplings(self._h, which, words.ctypes.data_as(C.c_void_p)))
+
     def current_layout(self) -> int:
         """Device layout right now (a ballot slab turns dense when a temperature has no integer thresholds)."""
         lay = C.c_int()

@@ -83,3 +83,60 @@ def test_cli_J_transcript_vs_unpinned_oracle(gpu, oracle_mod):
             orc.sweep(it - orc.it)
             up, dw = orc.count()
             assert f"up_s: {up:12d}, dw_s: {dw:12d} (iter: {it:8d})" in r.stdout, (ndev, it)
+
+
+ALL_LAYOUTS = pytest.mark.parametrize("layout", [ig.LAYOUT_BALLOT, ig.LAYOUT_DENSE, ig.LAYOUT_NIBBLE], ids=["ballot", "dense", "nibble"])
+
+
+@ALL_LAYOUTS
+def test_written_couplings_read_back_and_drive_the_update(gpu, oracle_mod, layout):
+    """ising_write_couplings: arrays in the reference's nibble form go to the device form of each layout and come back unchanged;
+    the update that follows uses them (against the oracle given the same arrays).  One array written into a fresh context, then
+    the other; then one array replaced."""
+    X, Y, seed = 8192, 64, 606
+    rng = np.random.default_rng(5)
+    hb, hw, hb2 = (rng.integers(0, 2**63, size=(Y, X // 32), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(Y, X // 32), dtype=np.uint64)
+                   for _ in range(3))
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=1.7).init().init_couplings(0.0)
+    with ig.IsingSlab(X, Y, seed=seed, temp=1.7, J_prob=0.5, layout=layout) as s:
+        s.init()
+        s.write_couplings(ig.BLACK, hb)
+        assert np.array_equal(s.read_couplings(ig.BLACK), hb) and not s.read_couplings(ig.WHITE).any()
+        s.write_couplings(ig.WHITE, hw)
+        assert np.array_equal(s.read_couplings(ig.BLACK), hb) and np.array_equal(s.read_couplings(ig.WHITE), hw)
+        orc.hamB[:], orc.hamW[:] = hb, hw
+        s.sweep(3)
+        orc.sweep(3)
+        assert np.array_equal(s.read(ig.BLACK), orc.black) and np.array_equal(s.read(ig.WHITE), orc.white)
+        s.write_couplings(ig.BLACK, hb2)
+        assert np.array_equal(s.read_couplings(ig.BLACK), hb2) and np.array_equal(s.read_couplings(ig.WHITE), hw)
+        orc.hamB[:] = hb2
+        s.sweep(2)
+        orc.sweep(2)
+        assert np.array_equal(s.read(ig.BLACK), orc.black) and np.array_equal(s.read(ig.WHITE), orc.white)
+    with ig.IsingSlab(X, Y, seed=seed, temp=1.7, layout=layout) as s, pytest.raises(ig.IsingError):
+        s.write_couplings(ig.BLACK, hb)  # couplings not enabled
+
+
+@ALL_LAYOUTS
+def test_coupled_update_against_the_plain_one_by_exact_maps(gpu, layout):
+    """No reference vector exists for -J, so the HIP coupling path is tied to the pinned plain path at a size the oracle does not
+    reach, by two exact maps (see tests/test_oracle_kat.py): all coupling bits clear -> the plain trajectory; all bits set (every
+    bond antiferromagnetic) and the black colour complemented -> the plain trajectory with the black colour complemented."""
+    X, Y, seed, temp, n = 16384, 2048, 99, 2.1, 6
+    with ig.IsingSlab(X, Y, seed=seed, temp=temp, layout=layout) as s:
+        s.init().sweep(n)
+        pb, pw = s.read(ig.BLACK), s.read(ig.WHITE)
+    ones = np.uint64(0x1111111111111111)
+    with ig.IsingSlab(X, Y, seed=seed, temp=temp, J_prob=0.0, layout=layout) as s:
+        s.init().init_couplings()
+        s.sweep(n)
+        assert np.array_equal(s.read(ig.BLACK), pb) and np.array_equal(s.read(ig.WHITE), pw)
+    with ig.IsingSlab(X, Y, seed=seed, temp=temp, J_prob=1.0, layout=layout) as s:
+        s.init()
+        full = np.full((Y, X // 32), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+        s.write_couplings(ig.BLACK, full)
+        s.write_couplings(ig.WHITE, full)
+        s.write(ig.BLACK, s.read(ig.BLACK) ^ ones)
+        s.sweep(n)
+        assert np.array_equal(s.read(ig.BLACK) ^ ones, pb) and np.array_equal(s.read(ig.WHITE), pw)
