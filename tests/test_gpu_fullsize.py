@@ -212,3 +212,25 @@ def test_lattices_beyond_2_to_the_32_threads_and_a_million_columns(gpu):
     p0, p2 = gold["points"]
     assert p0["sweeps"] == 0 and p2["sweeps"] == 2
     assert res["dense"] == ((p0["up"], p0["down"]), (p2["up"], p2["down"]), p2["bond_equal"])
+
+
+def test_spin_flip_symmetry_at_the_bench_size(gpu):
+    """A property that needs no oracle, at BASELINE config 3's size: the plain model is symmetric under flipping every spin, and the
+    random numbers do not depend on the state -- so the run that starts from the complemented lattice (written through the
+    1-bit host format, 2 x 256 MiB) is the complement of the run that starts from the lattice itself, bit for bit."""
+    X = Y = 65536
+    with ig.IsingSlab(X, Y, seed=1234, temp=ig.CRIT_TEMP_F32) as s:
+        s.init()
+        start = [s.read_bits(c) for c in (ig.BLACK, ig.WHITE)]
+        s.sweep(8)
+        want = [~s.read_bits(c) for c in (ig.BLACK, ig.WHITE)]
+        s.init()
+        for c in (ig.BLACK, ig.WHITE):
+            s.write_bits(c, ~start[c])
+        del start
+        up, down = s.count()
+        s.sweep(8)
+        for c in (ig.BLACK, ig.WHITE):
+            assert np.array_equal(s.read_bits(c), want[c]), c
+    gold = {p["sweeps"]: p for p in _gold("bench_65536_tc.json")["points"]}[0]
+    assert (up, down) == (gold["down"], gold["up"])  # the complemented start, counted
