@@ -151,8 +151,12 @@ int ising_read_couplings(ising_ctx *ctx, int which, int64_t row0, int64_t nrows,
 /* The other way round (new: the reference only draws its couplings at random): a whole coupling array of a lattice that wraps in
  * place (nslabs == 1), Y rows of X/32 words in the reference's form -- one nibble per site, bits <up, down, left, right>
  * (optimized/main.cu:588-612: a set bit flips that neighbour's spin before the energy sum = an antiferromagnetic bond) -- is
- * copied to the device and brought into the form the context's update kernels read.  The caller keeps hamB and hamW consistent
- * (hamiltInitW_k, :214-331, derives the white array from the black one).  Blocking. */
+ * copied to the device and brought into the form the context's update kernels read.  Which array an update reads is the
+ * reference's choice: the BLACK update takes its sites' nibbles from array ISING_WHITE (hamW) and the WHITE update from array
+ * ISING_BLACK (hamB), each at the destination's own packed index (the launches at :1774 and :1795).  For a model with
+ * symmetric bonds J_ij = J_ji write the black sites' bonds into ISING_WHITE and the white sites' into ISING_BLACK; the arrays
+ * ising_init_couplings draws are the other way round, as in the reference (hamB = the black sites' bonds, hamW = the white
+ * sites' bonds gathered from them, :214-331): with them a site applies the bonds of its horizontal neighbour.  Blocking. */
 int ising_write_couplings(ising_ctx *ctx, int which, const uint64_t *src_host);
 
 /* Recomputes the exp table / integer thresholds (optimized/main.cu:1684-1703, temperature ramp :1848-1859). */

@@ -140,3 +140,26 @@ def test_coupled_update_against_the_plain_one_by_exact_maps(gpu, layout):
         s.write(ig.BLACK, s.read(ig.BLACK) ^ ones)
         s.sweep(n)
         assert np.array_equal(s.read(ig.BLACK) ^ ones, pb) and np.array_equal(s.read(ig.WHITE), pw)
+
+
+@ALL_LAYOUTS
+def test_coupled_update_under_a_random_gauge(gpu, layout):
+    """tests/test_oracle_kat.py::test_coupling_path_under_a_random_gauge on the GPU, 16384 x 2048 on every device layout: Mattis
+    couplings of a random gauge field (each colour's update given its own sites' bond nibbles: black sites' into the array the
+    black update reads, ISING_WHITE) and the gauge-transformed start reproduce the gauge-transformed plain trajectory."""
+    from _gauge import gauge_field, gauge_words, mattis_nibbles
+    X, Y, seed, temp, n = 16384, 2048, 99, 2.1, 6
+    g = gauge_field(X, Y, 7)
+    gw = [gauge_words(g, c) for c in (0, 1)]
+    with ig.IsingSlab(X, Y, seed=seed, temp=temp, layout=layout) as s:
+        s.init().sweep(n)
+        want = [s.read(c) ^ gw[c] for c in (ig.BLACK, ig.WHITE)]
+    with ig.IsingSlab(X, Y, seed=seed, temp=temp, J_prob=0.5, layout=layout) as s:
+        s.init()
+        s.write_couplings(ig.WHITE, mattis_nibbles(g, 0))
+        s.write_couplings(ig.BLACK, mattis_nibbles(g, 1))
+        for c in (ig.BLACK, ig.WHITE):
+            s.write(c, s.read(c) ^ gw[c])
+        s.sweep(n)
+        for c in (ig.BLACK, ig.WHITE):
+            assert np.array_equal(s.read(c), want[c]), c

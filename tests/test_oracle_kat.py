@@ -184,3 +184,28 @@ def test_coupling_path_against_the_plain_path():
     anti.black ^= ones
     anti.sweep(n)
     assert np.array_equal(anti.black ^ ones, plain.black) and np.array_equal(anti.white, plain.white)
+
+
+def test_coupling_path_under_a_random_gauge():
+    """The strongest tie of the -J path to the pinned plain path: a random gauge field g.  With Mattis couplings J_ij = g_i g_j and
+    the start s_i -> g_i s_i, every energy difference -- hence every acceptance with the same random numbers -- is that of the
+    ferromagnet, so the coupled trajectory is the gauge-transformed plain one.  This holds when each colour's update is given the
+    bond nibbles of ITS OWN sites; it pins the direction bits, both colours' neighbour geometry and the periodic wraps.
+    (The reference hands the array it derived for the white sites to the black update and vice versa, optimized/main.cu:1774,
+    :1795 -- with its own pair of arrays the bonds a site sees are its horizontal neighbour's, J_ij != J_ji; the oracle and the
+    library restate that literally, and the derived white array IS the white sites' bonds, as checked here.)"""
+    from _gauge import gauge_field, gauge_words, mattis_nibbles
+    from oracle.pyoracle import lib, _u64
+    X, Y, seed, temp, n = 4096, 64, 2718, 2.0, 4
+    g = gauge_field(X, Y, 1)
+    plain = oracle.OracleLattice(X, Y, seed=seed, temp=temp).init().sweep(n)
+    L = oracle.OracleLattice(X, Y, seed=seed, temp=temp).init().init_couplings(0.0)
+    own = [mattis_nibbles(g, c) for c in (0, 1)]
+    derived = np.zeros_like(own[1])
+    lib().orc_ham_init_white(_u64(own[0]), _u64(derived), X, Y, 0, 0)
+    assert np.array_equal(derived, own[1])  # hamiltInitW_k's gather gives the white sites their bonds as seen from the black ones
+    L.hamW[:], L.hamB[:] = own[0], own[1]   # the black update reads hamW, the white one hamB
+    L.black ^= gauge_words(g, 0)
+    L.white ^= gauge_words(g, 1)
+    L.sweep(n)
+    assert np.array_equal(L.black ^ gauge_words(g, 0), plain.black) and np.array_equal(L.white ^ gauge_words(g, 1), plain.white)
