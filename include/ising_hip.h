@@ -158,6 +158,11 @@ int ising_read_couplings(ising_ctx *ctx, int which, int64_t row0, int64_t nrows,
  * ising_init_couplings draws are the other way round, as in the reference (hamB = the black sites' bonds, hamW = the white
  * sites' bonds gathered from them, :214-331): with them a site applies the bonds of its horizontal neighbour.  Blocking. */
 int ising_write_couplings(ising_ctx *ctx, int which, const uint64_t *src_host);
+/* The two coupling arrays of a slab change places (their halo / ghost rows included): after ising_init_couplings /
+ * ising_ring_init_couplings every colour's update then reads its OWN sites' bonds -- the Edwards-Anderson +-J model with
+ * symmetric bonds -- instead of its horizontal neighbour's, which is what the reference's launches give (above).  Results then
+ * differ from the reference's, by design (cuIsing --J-symmetric).  Call it on every slab of a ring. */
+int ising_swap_couplings(ising_ctx *ctx);
 
 /* Recomputes the exp table / integer thresholds (optimized/main.cu:1684-1703, temperature ramp :1848-1859). */
 int ising_set_temperature(ising_ctx *ctx, float temp);

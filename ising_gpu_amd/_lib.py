@@ -61,6 +61,7 @@ PROTOTYPES = {
     "ising_init_couplings_white": (C.c_int, [C.c_void_p]),
     "ising_read_couplings": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
     "ising_write_couplings": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "ising_swap_couplings": (C.c_int, [C.c_void_p]),
     "ising_ring_init_couplings": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "ising_set_temperature": (C.c_int, [C.c_void_p, C.c_float]),
     "ising_get_tables": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),

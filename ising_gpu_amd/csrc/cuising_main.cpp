@@ -12,6 +12,8 @@
 //            --tsweep-replicas K: K temperature points per batched launch on one GPU, 0 = by lattice size; --tsweep-no-batch: two
 //            points side by side on streams of their own instead, round 2's form; --tsweep-cold: every point starts from the
 //            ordered lattice -- the start that equilibrates below T_c, where a random one coarsens for ages),
+//            --J-symmetric (with -J): the two coupling arrays change places after they are drawn, so that every colour's update reads
+//            its own sites' bonds -- the +-J model with J_ij = J_ji; the reference's launches pair them the other way round,
 //            --checkpoint FILE / --resume FILE (binary checkpoint, ising_ring_checkpoint_*), --transport copy|rccl.
 #include "../../include/ising_hip.h"
 
@@ -120,6 +122,7 @@ struct TsweepSpec {
 	const char *out = nullptr;
 	int replicas = 0; // temperature points simulated side by side (fresh-start mode, one device); 0 = by lattice size
 	int chains = 1;        // --tsweep-chains K: K independent lattices per temperature (seeds seed .. seed + K - 1): means with standard errors
+	bool J_symmetric = false; // --J-symmetric (with -J)
 	bool cold = false;     // --tsweep-cold: every point starts from the ordered lattice (all spins up) instead of the random one
 	bool no_batch = false; // --tsweep-no-batch: the points side by side on streams of their own instead of batched launches (A/B)
 };
@@ -253,7 +256,11 @@ int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_
 				}
 				CHECK(ising_ring_exchange(rp.ctx.data(), rp.n(), ISING_BLACK));
 				CHECK(ising_ring_exchange(rp.ctx.data(), rp.n(), ISING_WHITE));
-				if (useJ && !have_J[j]) { CHECK(ising_ring_init_couplings(rp.ctx.data(), rp.n())); have_J[j] = true; }
+				if (useJ && !have_J[j]) {
+					CHECK(ising_ring_init_couplings(rp.ctx.data(), rp.n()));
+					if (ts.J_symmetric) for (ising_ctx *c : rp.ctx) CHECK(ising_swap_couplings(c));
+					have_J[j] = true;
+				}
 				it = 0;
 			}
 		}
@@ -413,7 +420,7 @@ int main(int argc, char **argv) {
 	    {"devmap", required_argument, 0, 4},   {"layout", required_argument, 0, 5},  {"tsweep", required_argument, 0, 6},
 	    {"tsweep-anneal", no_argument, 0, 7},  {"tsweep-out", required_argument, 0, 8}, {"checkpoint", required_argument, 0, 9},
 	    {"resume", required_argument, 0, 10},  {"transport", required_argument, 0, 11}, {"tsweep-replicas", required_argument, 0, 12},
-	    {"tsweep-no-batch", no_argument, 0, 13}, {"tsweep-cold", no_argument, 0, 14}, {"tsweep-chains", required_argument, 0, 15},
+	    {"tsweep-no-batch", no_argument, 0, 13}, {"tsweep-cold", no_argument, 0, 14}, {"tsweep-chains", required_argument, 0, 15}, {"J-symmetric", no_argument, 0, 16},
 	    {0, 0, 0, 0}};
 	while (1) {
 		int option_index = 0;
@@ -491,6 +498,7 @@ int main(int argc, char **argv) {
 			break;
 		case 13: ts.no_batch = true; break;
 		case 14: ts.cold = true; break;
+		case 16: ts.J_symmetric = true; break;
 		case 15:
 			ts.chains = atoi(optarg);
 			if (ts.chains < 1 || ts.chains > 64) { fprintf(stderr, "error: --tsweep-chains takes 1 .. 64\n"); exit(EXIT_FAILURE); }
@@ -587,6 +595,7 @@ int main(int argc, char **argv) {
 	if (!tempUpdFreq) printf("\ttemp update not set\n");
 	else printf("\ttemp update: %f / %d iterations\n", tempUpdStep, tempUpdFreq);
 	if (useGenHamilt) printf("\tusing Hamiltonian buffer, setting links to -1 with prob %G\n", hamiltPerc1);
+	if (useGenHamilt && ts.J_symmetric) printf("\tsymmetric bonds: each colour's update reads its own sites' links (not the reference's pairing)\n");
 	else printf("\tnot using Hamiltonian buffer\n");
 	printf("\n");
 	if (useSubLatt) { // optimized/main.cu:1583-1588
@@ -644,6 +653,8 @@ int main(int argc, char **argv) {
 	CHECK(ising_ring_exchange(ring.ctx.data(), ndev, ISING_BLACK));
 	CHECK(ising_ring_exchange(ring.ctx.data(), ndev, ISING_WHITE));
 	if (useGenHamilt) CHECK(ising_ring_init_couplings(ring.ctx.data(), ndev)); // optimized/main.cu:1729-1742
+	// --J-symmetric: every colour's update reads its own sites' bonds (J_ij = J_ji) instead of the array the reference hands it
+	if (useGenHamilt && ts.J_symmetric) for (ising_ctx *c : ring.ctx) CHECK(ising_swap_couplings(c));
 	if (ndev > 1) {
 		int tr = 0;
 		CHECK(ising_ring_transport(ring.ctx.data(), ndev, &tr));

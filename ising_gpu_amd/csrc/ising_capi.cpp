@@ -1248,6 +1248,15 @@ int ising_read_couplings(ising_ctx *c, int which, int64_t row0, int64_t nrows, u
 	return ISING_OK;
 }
 
+int ising_swap_couplings(ising_ctx *c) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (!c->cfg.use_J) return fail(ISING_E_STATE, "couplings are not enabled (use_J)");
+	if (int rc = bind(c)) return rc;
+	const size_t per_array = c->ham_alloc_words() / 2; // rows [-ghost, Y + ghost) of one array
+	HIP_TRY(ising::launch_swap_vectors(c->d_ham, c->d_ham + per_array, per_array / 2, c->stream));
+	return ISING_OK;
+}
+
 int ising_write_couplings(ising_ctx *c, int which, const uint64_t *src_host) {
 	if (!c || !src_host) return fail(ISING_E_ARG, "null argument");
 	if (which != ISING_BLACK && which != ISING_WHITE) return fail(ISING_E_ARG, "bad coupling array %d", which);

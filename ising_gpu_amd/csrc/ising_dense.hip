@@ -467,6 +467,22 @@ hipError_t launch_dense_update(const UpdateParams &p, int mode, hipStream_t stre
 	return hipGetLastError();
 }
 
+// ising_swap_couplings: the two coupling arrays change places, 16 bytes per lane and step (whatever form they are in)
+__global__ void __launch_bounds__(THREADS) swap_vectors_k(uint4 *__restrict__ a, uint4 *__restrict__ b, size_t nvec) {
+	for (size_t v = (size_t)blockIdx.x * THREADS + threadIdx.x; v < nvec; v += (size_t)gridDim.x * THREADS) {
+		const uint4 x = a[v], y = b[v];
+		a[v] = y;
+		b[v] = x;
+	}
+}
+
+hipError_t launch_swap_vectors(uint64_t *a, uint64_t *b, size_t nvec, hipStream_t stream) {
+	size_t blocks = (nvec + THREADS - 1) / THREADS;
+	if (blocks > 8192) blocks = 8192;
+	hipLaunchKernelGGL(swap_vectors_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, reinterpret_cast<uint4 *>(a), reinterpret_cast<uint4 *>(b), nvec);
+	return hipGetLastError();
+}
+
 hipError_t launch_ham_planes(uint64_t *ham, size_t nvec, hipStream_t stream) {
 	size_t blocks = (nvec + THREADS - 1) / THREADS;
 	if (blocks > 8192) blocks = 8192;

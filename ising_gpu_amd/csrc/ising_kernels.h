@@ -144,6 +144,7 @@ hipError_t launch_dense_update(const UpdateParams &p, int mode, hipStream_t stre
 hipError_t launch_dense_init(const InitParams &p, hipStream_t stream);
 // in-place nibble -> bit-plane transposition of `nvec` 16-byte coupling vectors (dense layout with -J)
 hipError_t launch_ham_planes(uint64_t *ham, size_t nvec, hipStream_t stream);
+hipError_t launch_swap_vectors(uint64_t *a, uint64_t *b, size_t nvec, hipStream_t stream); // 16-byte vectors of two arrays change places
 hipError_t launch_dense_bond_equal(const BondParams &p, hipStream_t stream);
 hipError_t launch_dense_pack_bits(const uint64_t *black, const uint64_t *white, int wpr, int Y, uint32_t row_base, uint32_t *bits,
                                   hipStream_t stream);

@@ -119,6 +119,11 @@ class IsingSlab:
         assert words.shape == (self.Y, self.lld), words.shape
         check(self._lib.ising_write_couplings(self._h, which, words.ctypes.data_as(C.c_void_p)))
 
+    def swap_couplings(self):
+        """The two coupling arrays change places: every colour's update reads its own sites' bonds (symmetric +-J model)."""
+        check(self._lib.ising_swap_couplings(self._h))
+        return self
+
     def current_layout(self) -> int:
         """Device layout right now (a ballot slab turns dense when a temperature has no integer thresholds)."""
         lay = C.c_int()

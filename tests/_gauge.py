@@ -36,3 +36,22 @@ def mattis_nibbles(g, color):
     me = g[r, c]
     nib = ((me ^ g[(r - 1) % Y, c]) << 3) | ((me ^ g[(r + 1) % Y, c]) << 2) | ((me ^ g[r, (c - 1) % X]) << 1) | (me ^ g[r, (c + 1) % X])
     return _pack(nib, X, Y)
+
+
+def site_nibbles(arr_black_sites, arr_white_sites):
+    """(Y, X) matrix of the nibble each lattice site's update applies, from the packed arrays holding the black / white sites' nibbles."""
+    Y, lld = arr_black_sites.shape
+    X = lld * 32
+    out = np.zeros((Y, X), dtype=np.uint8)
+    sh = (np.arange(16, dtype=np.uint64) * np.uint64(4))[None, None, :]
+    for color, arr in ((0, arr_black_sites), (1, arr_white_sites)):
+        nib = ((arr[:, :, None] >> sh) & np.uint64(0xF)).astype(np.uint8).reshape(Y, X // 2)
+        out[np.arange(Y)[:, None], _cols(X, Y, color)] = nib
+    return out
+
+
+def bonds_symmetric(N):
+    """J_ij == J_ji for every bond of the periodic lattice: a site's <up> bit is its upper neighbour's <down> bit, its <left> bit
+    its left neighbour's <right> bit."""
+    up, down, left, right = (N >> 3) & 1, (N >> 2) & 1, (N >> 1) & 1, N & 1
+    return bool(np.array_equal(up, np.roll(down, 1, axis=0)) and np.array_equal(left, np.roll(right, 1, axis=1)))

@@ -163,3 +163,59 @@ def test_coupled_update_under_a_random_gauge(gpu, layout):
         s.sweep(n)
         for c in (ig.BLACK, ig.WHITE):
             assert np.array_equal(s.read(c), want[c]), c
+
+
+@ALL_LAYOUTS
+def test_swapped_couplings_are_the_symmetric_bond_model(gpu, layout):
+    """What each site applies with the arrays as -J draws them (the black update reads hamW, the white one hamB, optimized/main.cu:1774,
+    :1795) is NOT a symmetric set of bonds; after ising_swap_couplings (cuIsing --J-symmetric) it is: J_ij = J_ji on every bond."""
+    from _gauge import bonds_symmetric, site_nibbles
+    X, Y = 8192, 64
+    with ig.IsingSlab(X, Y, seed=31, temp=1.5, J_prob=0.4, layout=layout) as s:
+        s.init().init_couplings()
+        hb, hw = s.read_couplings(ig.BLACK), s.read_couplings(ig.WHITE)
+        assert bonds_symmetric(site_nibbles(hb, hw))      # hamB = the black sites' bonds, hamW = the white sites': a consistent pair ...
+        assert not bonds_symmetric(site_nibbles(hw, hb))  # ... but not the way the updates read them
+        s.swap_couplings()
+        assert np.array_equal(s.read_couplings(ig.BLACK), hw) and np.array_equal(s.read_couplings(ig.WHITE), hb)
+        # now the black update reads array WHITE = hb = the black sites' bonds, the white update array BLACK = hw
+        assert bonds_symmetric(site_nibbles(s.read_couplings(ig.WHITE), s.read_couplings(ig.BLACK)))
+        s.sweep(3)  # (and the update runs on them: the energy moves towards the ground state of the frustrated model at low T)
+        assert s.count()[0] + s.count()[1] == X * Y
+
+
+def test_cli_symmetric_bonds_flag(gpu):
+    base = ["-x", "4096", "-y", "256", "-n", "8", "-p", "4", "-t", "1.2", "-s", "5", "-J", "0.3"]
+    ref = subprocess.run([CLI] + base, capture_output=True, text=True, timeout=300)
+    sym = subprocess.run([CLI] + base + ["--J-symmetric"], capture_output=True, text=True, timeout=300)
+    assert ref.returncode == 0 and sym.returncode == 0, ref.stderr + sym.stderr
+    assert "symmetric bonds" in sym.stdout and "symmetric bonds" not in ref.stdout
+    pick = lambda out: re.findall(r"magnetization: +[\d.]+, up_s: +(\d+)", out)
+    assert len(pick(ref.stdout)) == len(pick(sym.stdout)) >= 3
+    assert pick(ref.stdout)[0] == pick(sym.stdout)[0] and pick(ref.stdout)[-1] != pick(sym.stdout)[-1]  # same start, another model
+    # ring of two slabs on one device == one slab, also with the arrays swapped
+    two = subprocess.run([CLI, "-x", "4096", "-y", "128", "-d", "2", "--devmap", "0,0"] + base[4:] + ["--J-symmetric"], capture_output=True, text=True, timeout=300)
+    assert two.returncode == 0, two.stderr
+    assert pick(two.stdout) == pick(sym.stdout)
+
+
+def test_swapped_couplings_in_a_ring_with_ghost_rows(gpu):
+    """Ballot ring slabs keep ghost rows of the coupling arrays too (the fused launches update ghost rows): swapped on every slab,
+    three slabs through the C-ABI ring give the single slab's spins."""
+    X, Y, n = 16384, 1536, 3
+    with ig.IsingSlab(X, Y, seed=8, temp=1.3, J_prob=0.3, layout=ig.LAYOUT_BALLOT) as one:
+        one.init().init_couplings().swap_couplings().sweep(40)
+        ref = (one.read(ig.BLACK), one.read(ig.WHITE))
+    slabs = [ig.IsingSlab(X, Y // n, seed=8, temp=1.3, nslabs=n, slab=k, J_prob=0.3, layout=ig.LAYOUT_BALLOT) for k in range(n)]
+    try:
+        ring = ig.SlabSet(slabs).init()
+        assert slabs[0].ghost_ptrs(ig.BLACK)[0] > 1
+        for s in slabs:
+            s.swap_couplings()
+        ring.sweep(33).sweep(7)
+        ring.synchronize()
+        assert np.array_equal(np.concatenate([s.read(ig.BLACK) for s in slabs]), ref[0])
+        assert np.array_equal(np.concatenate([s.read(ig.WHITE) for s in slabs]), ref[1])
+    finally:
+        for s in slabs:
+            s.close()
