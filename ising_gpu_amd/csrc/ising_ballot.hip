@@ -1013,7 +1013,7 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	const bool fused = p.nlevels > 1;
 	const bool usej = fused ? p.jham[0] != nullptr : p.jdst != nullptr;
 	const bool subl = p.slY != 0;
-	const bool streamed = fused && p.nt_stream && NT == BAL_THREADS; // (8-wave workgroups serve lattices that fit the cache)
+	const bool streamed = fused && p.nt_stream;
 	const bool batch = fused && p.nrep > 0;
 	if (batch && (usej || subl || NT != BAL_THREADS)) return hipErrorInvalidValue;
 	if (fused && subl && (usej || NT != BAL_THREADS || p.slY % p.H != 0)) return hipErrorInvalidValue; // (ising_capi.cpp keeps those on one launch per colour)
@@ -1117,10 +1117,6 @@ hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_o
 	if (grid_out) *grid_out = 0;
 	if (p.nunits <= 0) return stop ? hipEventRecord(stop, stream) : hipSuccess;
 	if (p.nlevels < 1) p.nlevels = 1;
-	if (p.nlevels > 1 && p.slY != 0 && p.wide) return hipErrorInvalidValue; // (sub-lattices: 4-wave workgroups only)
-	// 8-wave workgroups for fused launches (ising_create: lattices of ~2^27 spins; ISING_FUSED_WIDE=0/1): half the tickets
-	// per row of work
-	if (p.nlevels > 1 && p.wide) return launch_ballot_update_nt<512>(p, stream, grid_out, stop);
 	return launch_ballot_update_nt<BAL_THREADS>(p, stream, grid_out, stop);
 }
 

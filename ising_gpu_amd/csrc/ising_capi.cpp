@@ -38,7 +38,6 @@ int read_policy(ising_policy *pol) {
 	auto num = [](const char *name, int *out) { if (const char *e = getenv(name)) { *out = atoi(e); return true; } return false; };
 	int v = 0;
 	if (num("ISING_FUSED", &v)) pol->fused = v != 0;
-	if (num("ISING_FUSED_WIDE", &v)) pol->fused_wide = v;
 	if (num("ISING_FUSED_NT", &v)) pol->fused_nt = v != 0;
 	if (num("ISING_FUSED_TICKETS2", &v)) pol->fused_tickets2 = (v == 2 || v == 4) ? v : (v ? 2 : 0);
 	if (num("ISING_FUSED_WGS", &v)) pol->fused_wgs = v > 0 ? v : 0;
@@ -276,7 +275,7 @@ void ballot_planes_to_planes(uint64_t *ham, size_t ngroups) {
 }
 
 // Fused launches: T = tickets (workgroups) per level for strips of H rows; and the launch shape ising_create picks.
-long long fused_tickets(int nwc, int Y, int H, bool wide) { return ((long long)nwc * ((Y + H - 1) / H) + (wide ? 7 : 3)) / (wide ? 8 : 4); }
+long long fused_tickets(int nwc, int Y, int H) { return ((long long)nwc * ((Y + H - 1) / H) + 3) / 4; }
 // Workgroups of 4 waves per CU a level of T tickets carries without its units running into unfinished parents (with the waves'
 // rotating priorities, ising_ballot.hip: a level wants 1.33 x the grid at three per CU, 2 x at four, 3.2 x at five, 5.3 x at
 // six -- 65536^2, T = 8192: 3512 flips/ns with five, 3533 with six; 131072 x 16384, T = 4096 at H = 16: 3504 with five, 3373
@@ -304,7 +303,7 @@ int choose_fused_strip_rows(int nwc, int Y, int rows) {
 	int best = 1, best_score = -1;
 	for (int H = 1; H <= 16; H <<= 1) {
 		if (Y % H) break;
-		const int score = fused_score(H, fused_wgs_for(fused_tickets(nwc, rows, H, false)));
+		const int score = fused_score(H, fused_wgs_for(fused_tickets(nwc, rows, H)));
 		if (score >= best_score) { best = H; best_score = score; }
 	}
 	return best;
@@ -502,7 +501,8 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	//   131072^2             H = 16, 6 per CU (T = 32768)                         3541 vs 3502
 	// (choose_fused_strip_rows / fused_wgs_for above; tools/midsize_probe.py re-measures the neighbours of these choices; before the waves' priorities rotated -- ising_ballot.hip -- the same lattices
 	// wanted two to four times as many tickets a level and ran 3082 at 16384^2, 3479 at 65536^2.)
-	// ISING_FUSED=0/1, ISING_FUSED_WIDE=0/1, cfg.strip_rows and ISING_FUSED_WGS (grid) override.
+	// ISING_FUSED=0/1, cfg.strip_rows and ISING_FUSED_WGS (grid) override.  (8-wave workgroups, an A/B switch of rounds 2-3, lost
+	// at every size once the priorities rotated -- 16384^2 3187 vs 3325, 32768^2 3192 vs 3473 -- and are gone.)
 	const long long spins = (long long)cfg->X * cfg->Y;
 	// (sub-lattices: every XSL x YSL block is a periodic system of its own -- nothing crosses slabs, so ring slabs qualify too --;
 	// their strips must not straddle a block, and the fused kernels carry no couplings next to sub-lattices)
@@ -515,7 +515,6 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// and level, all at about the same time, and three polls per unit of the next)
 	// (from 768 tickets a level: 8192 x 3072 1834 vs the dense layout's 1658; 8192 x 2048, 512 tickets: 1330 vs 1416)
 	c->fused = pol.fused >= 0 ? pol.fused != 0 : (spins >= 3 * (1LL << 23) && c->nwc() < 128);
-	c->fused_wide = cfg->XSL ? 0 : pol.fused_wide; // (8-wave workgroups: an A/B switch since the priorities rotate; 16384 x 8192: 3070 vs 3040 with 4 waves)
 	// AUTO: the ballot kernel's two-phase row pipeline wins from 2^27 spins per slab up -- from 2^25 where fused launches
 	// apply (a slab that wraps in place, a ring slab that can keep ghost rows); below, the dense kernel is ahead.  (A partly dead last wave column wastes its
 	// dead lanes' draws: worth it while they are under a tenth of the row -- the dense kernel is 12 % behind.)
@@ -545,7 +544,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// (its fused launches take the shape a single slab of Y + 2 G rows would)
 	const int launch_rows = deep_ring ? cfg->Y + 2 * c->ghost_rows : cfg->Y;
 	c->H = cfg->strip_rows > 0 ? cfg->strip_rows
-	       : ((fused_shape || deep_ring) ? (c->fused_wide ? ((cfg->Y % 2) == 0 ? 2 : 1) : choose_fused_strip_rows(c->nwc(), cfg->XSL ? cfg->YSL : cfg->Y, launch_rows))
+	       : ((fused_shape || deep_ring) ? choose_fused_strip_rows(c->nwc(), cfg->XSL ? cfg->YSL : cfg->Y, launch_rows)
 	                                     : choose_strip_rows(c->gx, cfg->Y, c->dense, c->ballot));
 	if (cfg->Y % c->H) { const int h = c->H; delete c; return fail(ISING_E_ARG, "strip_rows %d does not divide Y %d", h, cfg->Y); }
 	c->nstrips = cfg->Y / c->H;
@@ -553,15 +552,15 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// lattices larger than the memory-side cache (256 MB = 2^31 spins at 1 bit per spin) stream through it: their words
 	// carry the non-temporal hint, which keeps the accept-mask slots in the L2s (ISING_FUSED_NT=0/1 overrides)
 	c->fused_nt = pol.fused_nt >= 0 ? pol.fused_nt : (spins > (1LL << 31));
-	if (fused_shape || deep_ring) { // workgroups per CU of a fused launch (the chip holds 6 of 4 waves, 3 of 8)
-		const long long T = fused_tickets(c->nwc(), launch_rows, c->H, c->fused_wide != 0);
-		c->fused_wg_per_cu = c->fused_wide ? (T >= 2048 ? 3 : 2) : fused_wgs_for(T);
-		if (deep_ring && !c->fused_wide && T < 16384) c->fused_wg_per_cu = std::min(c->fused_wg_per_cu, 5);
+	if (fused_shape || deep_ring) { // workgroups per CU of a fused launch (the chip holds 6 of 4 waves)
+		const long long T = fused_tickets(c->nwc(), launch_rows, c->H);
+		c->fused_wg_per_cu = fused_wgs_for(T);
+		if (deep_ring && T < 16384) c->fused_wg_per_cu = std::min(c->fused_wg_per_cu, 5);
 		// Several ticket counters where 4-wave workgroups draw one- or two-row units (2^26 spins): one counter hands out
 		// ~80 tickets per us; 8192^2 with one-row units at 2600 flips/ns needs 159 (four counters), with two-row units
 		// 79 (two).  ISING_FUSED_TICKETS2=0/2/4 overrides.
-		const long long T0 = fused_tickets(c->nwc(), cfg->Y, c->H, c->fused_wide != 0); // (without a ring slab's ghost rows)
-		c->fused_tickets2 = (!c->fused_wide && T0 <= 2048 && c->H == 1) ? 4 : ((!c->fused_wide && T0 <= 1024 && c->H == 2) ? 2 : 0);
+		const long long T0 = fused_tickets(c->nwc(), cfg->Y, c->H); // (without a ring slab's ghost rows)
+		c->fused_tickets2 = (T0 <= 2048 && c->H == 1) ? 4 : ((T0 <= 1024 && c->H == 2) ? 2 : 0);
 		if (pol.fused_tickets2 >= 0) c->fused_tickets2 = pol.fused_tickets2;
 	}
 
@@ -817,7 +816,6 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			p.jham[0] = c->cfg.use_J ? c->ham(1) : nullptr;
 			p.jham[1] = c->cfg.use_J ? c->ham(0) : nullptr;
 			p.done = c->d_slotctl + SLOTCTL_TICKET_BYTES / 4;
-			p.wide = c->fused_wide;
 			p.wg_per_cu = c->fused_wg_per_cu;
 			p.nt_stream = c->fused_nt;
 			p.done_base = c->done_base;
@@ -907,7 +905,7 @@ int ising_host::update_deep(ising_ctx *c, int it, int nlevels, bool overlapped) 
 // fused launches carry this slab's sweeps (ballot layout, integer thresholds; with sub-lattices: strips inside the blocks, no couplings)
 static bool sweeps_fused(const ising_ctx *c) {
 	if (!c->ballot || !c->fused || ising_host::needs_generic(c)) return false;
-	if (c->cfg.XSL) return !c->cfg.use_J && !c->fused_wide && (c->cfg.YSL % c->H) == 0;
+	if (c->cfg.XSL) return !c->cfg.use_J && (c->cfg.YSL % c->H) == 0;
 	return c->wrap;
 }
 

@@ -15,7 +15,6 @@
 // in the library calls getenv afterwards (ISING_RCCL_LIB, the path of the RCCL to open, is process-wide and read once).
 struct ising_policy {
 	int fused = -1;          // ISING_FUSED=0/1: one launch per colour / fused launches (-1: by lattice size)
-	int fused_wide = 0;      // ISING_FUSED_WIDE=1: 8-wave workgroups
 	int fused_nt = -1;       // ISING_FUSED_NT=0/1: non-temporal lattice words (-1: lattices above 2^31 spins)
 	int fused_tickets2 = -1; // ISING_FUSED_TICKETS2=0/2/4: ticket counters (-1: by strip height)
 	int fused_wgs = 0;       // ISING_FUSED_WGS=n: persistent grid of n workgroups (0: by tickets per level)
@@ -53,7 +52,6 @@ struct ising_ctx {
 	size_t slotctl_bytes = 0;
 	uint32_t done_base = 0;        // value of every completion counter once everything launched so far has run
 	bool fused = false;            // ising_sweep batches colour half-sweeps into fused launches
-	int fused_wide = 0;            // ... with 512-thread workgroups
 	int fused_wg_per_cu = 0;       // ... and this many workgroups per CU (0: as many as the chip holds)
 	int fused_nt = 0;              // ... whose lattice words carry the non-temporal hint (lattice larger than the 256 MB memory-side cache)
 	unsigned long long ticket_base2[4] = {0, 0, 0, 0}; // fused launches: where the launches so far left the ticket counter(s)

@@ -39,7 +39,6 @@ struct UpdateParams {
 	// ballot layout, persistent launches
 	unsigned long long *ticket; // fused: ticket words (chunk counter + 8 queue words, 64 bytes apart), zero when the launch starts
 	int32_t nwg;              // workgroup units per level (set by the launcher)
-	int32_t wide;             // fused: 512-thread workgroups (8 waves per ticket)
 	int32_t wg_per_cu;        // fused: cap of the persistent grid, workgroups per CU (0: what the chip holds; host side only)
 	int32_t nt_stream;        // fused: lattice words with the non-temporal hint (lattices larger than the memory-side cache; host side only)
 	unsigned long long ticket_base2[4]; // fused: value of the ticket counter(s) when this launch starts (counter k: 64 k bytes on)

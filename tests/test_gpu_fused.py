@@ -93,15 +93,6 @@ def test_fused_with_couplings_and_temperature_changes(gpu, oracle_mod, fused):
         assert s.current_layout() == ig.LAYOUT_DENSE and _same(s, orc2)
 
 
-def test_fused_wide_workgroups(gpu, oracle_mod, fused, monkeypatch):
-    monkeypatch.setenv("ISING_FUSED_WIDE", "1")
-    for X, Y, strip in ((8192, 80, 1), (16384, 96, 2), (8192, 1024, 4)):
-        orc = oracle_mod.OracleLattice(X, Y, seed=3, temp=ig.CRIT_TEMP_F32).init().sweep(9)
-        with ig.IsingSlab(X, Y, seed=3, temp=ig.CRIT_TEMP_F32, layout=ig.LAYOUT_BALLOT, strip_rows=strip) as s:
-            s.init().sweep(4).sweep(5)
-            assert _same(s, orc), (X, Y)
-
-
 def test_fused_equals_plain_at_16384_full_size(gpu, monkeypatch):
     """BASELINE config 2's lattice on both launch forms: identical packed state after 40 sweeps."""
     got = {}

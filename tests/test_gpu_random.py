@@ -71,23 +71,22 @@ def _fused_cases(n):
         strip = int(rng.choice([0, 1, 2, 4, 8]))
         if Y % max(strip, 1):
             strip = 0
-        wide = int(rng.random() < 0.4)
+        rng.random()  # (8-wave workgroups, gone; the draw stays so that the other choices keep their values)
         nt = int(rng.random() < 0.4)
         wgs = rng.choice(["", "1", "2", "3", "5", "17", "64"])
         jp = float(rng.choice([0.2, 0.7])) if (rng.random() < 0.3 and X % 8192 == 0) else None
         temp = float(np.float32(rng.choice([1.0, 2.0, float(ig.CRIT_TEMP_F32), 3.0])))
         seed = int(rng.integers(1, 2**40))
-        out.append(pytest.param(X, Y, strip, wide, nt, str(wgs), jp, temp, seed, id=f"{k}-{X}x{Y}-s{strip}-w{wide}-nt{nt}-g{wgs or 'auto'}-J{jp}-T{temp:.2f}"))
+        out.append(pytest.param(X, Y, strip, nt, str(wgs), jp, temp, seed, id=f"{k}-{X}x{Y}-s{strip}-nt{nt}-g{wgs or 'auto'}-J{jp}-T{temp:.2f}"))
     return out
 
 
-@pytest.mark.parametrize("X,Y,strip,wide,nt,wgs,jp,temp,seed", _fused_cases(28 * _SCALE))
-def test_random_fused_configuration(gpu, oracle_mod, monkeypatch, X, Y, strip, wide, nt, wgs, jp, temp, seed):
-    """The fused launch form under random shapes and switches: 4- and 8-wave workgroups, streaming instantiation, strip
+@pytest.mark.parametrize("X,Y,strip,nt,wgs,jp,temp,seed", _fused_cases(28 * _SCALE))
+def test_random_fused_configuration(gpu, oracle_mod, monkeypatch, X, Y, strip, nt, wgs, jp, temp, seed):
+    """The fused launch form under random shapes and switches: streaming instantiation, strip
     heights, grids from one workgroup (every unit waits for its parents, one after the other) to what the chip holds,
     launches of 1 .. 9 sweeps."""
     monkeypatch.setenv("ISING_FUSED", "1")
-    monkeypatch.setenv("ISING_FUSED_WIDE", str(wide))
     monkeypatch.setenv("ISING_FUSED_NT", str(nt))
     if wgs:
         monkeypatch.setenv("ISING_FUSED_WGS", wgs)
@@ -119,7 +118,7 @@ def _ring_cases(n):
         Yk = int(rng.choice([16, 32, 48, 64, 96, 160]))
         ghost = str(rng.choice(["", "4", "8", "16", "64"]))
         rng.choice(["single", "plain"])  # (a switch of an earlier launch policy; the draw stays so that the other choices keep their values)
-        wide = int(rng.random() < 0.4)
+        rng.random()  # (8-wave workgroups, gone: as above)
         t2 = str(rng.choice(["", "0", "2", "4"]))
         wgs = str(rng.choice(["", "1", "3", "17"]))
         strip = int(rng.choice([0, 1, 2, 4, 8]))
@@ -130,20 +129,19 @@ def _ring_cases(n):
         seed = int(rng.integers(1, 2**40))
         sweeps = (int(rng.integers(1, 20)), int(rng.integers(1, 40)))
         jp = float(rng.choice([0.2, 0.7])) if (rng.random() < 0.35 and X % 8192 == 0) else None
-        out.append(pytest.param(nslabs, X, Yk, ghost, wide, t2, wgs, strip, inline, temp, seed, sweeps, jp,
-                                id=f"{k}-{nslabs}x{X}x{Yk}-G{ghost or 'auto'}-w{wide}-t{t2 or 'auto'}-g{wgs or 'auto'}-s{strip}-i{inline}-n{sweeps[0]}+{sweeps[1]}-J{jp}"))
+        out.append(pytest.param(nslabs, X, Yk, ghost, t2, wgs, strip, inline, temp, seed, sweeps, jp,
+                                id=f"{k}-{nslabs}x{X}x{Yk}-G{ghost or 'auto'}-t{t2 or 'auto'}-g{wgs or 'auto'}-s{strip}-i{inline}-n{sweeps[0]}+{sweeps[1]}-J{jp}"))
     return out
 
 
-@pytest.mark.parametrize("nslabs,X,Yk,ghost,wide,t2,wgs,strip,inline,temp,seed,sweeps,jp", _ring_cases(32 * _SCALE))
-def test_random_ring_with_ghost_rows(gpu, oracle_mod, monkeypatch, nslabs, X, Yk, ghost, wide, t2, wgs, strip, inline, temp, seed, sweeps, jp):
+@pytest.mark.parametrize("nslabs,X,Yk,ghost,t2,wgs,strip,inline,temp,seed,sweeps,jp", _ring_cases(32 * _SCALE))
+def test_random_ring_with_ghost_rows(gpu, oracle_mod, monkeypatch, nslabs, X, Yk, ghost, t2, wgs, strip, inline, temp, seed, sweeps, jp):
     """Ring slabs with ghost rows under random shapes and switches: 1 .. 4 slabs of one device (copy transport on the comm
     streams or inline; a ring of one sends to itself), ghost rows 4 .. 64 deep, one- to eight-row units, several ticket
-    counters, 4- and 8-wave workgroups, grids from one workgroup
+    counters, grids from one workgroup
     up, -J couplings, two sweep calls whose lengths do not line up with the exchange period -- against the oracle's single lattice."""
     monkeypatch.setenv("ISING_RING_STORE", "0")  # (slabs of one device would otherwise store straight into each other's halo rows)
     monkeypatch.setenv("ISING_RING_INLINE", inline)
-    monkeypatch.setenv("ISING_FUSED_WIDE", str(wide))
     for name, val in (("ISING_RING_GHOST", ghost), ("ISING_FUSED_TICKETS2", t2), ("ISING_FUSED_WGS", wgs)):
         if val:
             monkeypatch.setenv(name, val)

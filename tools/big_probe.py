@@ -9,8 +9,8 @@ for X, Y in shapes:
     row = []
     for name, env, H in (("plain H=8 auto tail", {"ISING_FUSED": "0"}, 8), ("plain H=16 auto tail", {"ISING_FUSED": "0"}, 16),
                          ("plain H=16 tail 2048,2", {"ISING_FUSED": "0", "ISING_TAIL": "2048,2"}, 16), ("plain H=16 tail 4096,2", {"ISING_FUSED": "0", "ISING_TAIL": "4096,2"}, 16),
-                         ("fused H=8", {"ISING_FUSED": "1", "ISING_FUSED_WIDE": "0"}, 8), ("fused H=16", {"ISING_FUSED": "1", "ISING_FUSED_WIDE": "0"}, 16), ("fused H=4", {"ISING_FUSED": "1", "ISING_FUSED_WIDE": "0"}, 4)):
-        for k in ("ISING_FUSED", "ISING_TAIL", "ISING_FUSED_WIDE"):
+                         ("fused H=8", {"ISING_FUSED": "1"}, 8), ("fused H=16", {"ISING_FUSED": "1"}, 16), ("fused H=4", {"ISING_FUSED": "1"}, 4)):
+        for k in ("ISING_FUSED", "ISING_TAIL"):
             os.environ.pop(k, None)
         os.environ.update(env)
         with ig.IsingSlab(X, Y, seed=1234, temp=ig.CRIT_TEMP_F32, layout=ig.LAYOUT_BALLOT, strip_rows=H) as s:

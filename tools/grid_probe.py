@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""Fused launches: throughput against workgroup width, strip height and size of the persistent grid (ISING_FUSED_WGS).
+"""Fused launches: throughput against strip height and size of the persistent grid (ISING_FUSED_WGS).  (Rounds 2-3 also varied the
+workgroup width; 8-wave workgroups are gone, the "wide" column is kept at 0.)
 usage: grid_probe.py [X Y]...   (one process per lattice; the grid cap is read once per process, so one subprocess per cap)"""
 import os, sys, subprocess
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 if len(sys.argv) > 1 and sys.argv[1] == "case":
     import ising_gpu_amd as ig
     X, Y, wide = map(int, sys.argv[2:5])
-    os.environ["ISING_FUSED"] = "1"; os.environ["ISING_FUSED_WIDE"] = str(wide)
+    os.environ["ISING_FUSED"] = "1"
     sweeps = max(64, min(4096, (1 << 33) // (X * Y) * 8))
     out = []
     for H in map(int, sys.argv[5:]):
@@ -17,7 +18,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "case":
 else:
     sizes = [tuple(map(int, sys.argv[i:i + 2])) for i in range(1, len(sys.argv), 2)] or [(8192, 8192), (16384, 16384)]
     for X, Y in sizes:
-        for wide, grids in ((0, (768, 1024, 1280, 1536)), (1, (384, 512, 640, 768))):
+        for wide, grids in ((0, (768, 1024, 1280, 1536)),):
             for g in grids:
                 subprocess.run([sys.executable, __file__, "case", str(X), str(Y), str(wide), "1", "2", "4", "8"], env=dict(os.environ, ISING_FUSED_WGS=str(g)),
                                stderr=subprocess.DEVNULL)

@@ -5,7 +5,7 @@ sys.path.insert(0, __file__.rsplit("/", 2)[0])
 if len(sys.argv) > 1 and sys.argv[1] == "case":
     import ising_gpu_amd as ig
     X, Y, fused = map(int, sys.argv[2:5])
-    os.environ["ISING_FUSED"] = str(fused); os.environ["ISING_FUSED_WIDE"] = "0"
+    os.environ["ISING_FUSED"] = str(fused)
     sweeps = max(32, min(4096, (1 << 35) // (X * Y) * 8)) // 32 * 32  # ~0.2 s per measurement
     out = []
     with ig.IsingSlab(X, Y, seed=1234, temp=ig.CRIT_TEMP_F32, layout=ig.LAYOUT_BALLOT) as s:  # preheat: the clock ramp takes ~40 ms under load
