@@ -294,3 +294,30 @@ def test_fused_launches_longer_than_32_sweeps(gpu, oracle_mod, fused, monkeypatc
         assert s.fused and s.max_sweeps_per_launch == (int(cap) if cap else 4096)
         s.init().sweep(150)
         assert _same(s, orc) and s.count() == orc.count()
+
+
+@pytest.mark.parametrize("layout", [ig.LAYOUT_BALLOT, ig.LAYOUT_DENSE], ids=["ballot", "dense"])
+def test_sublattices_do_not_see_each_other(gpu, layout):
+    """A property that needs no oracle, at 2^26 spins: with --xsl/--ysl every block is a periodic system of its own (optimized/main.cu:
+    1423-1462).  Complementing ONE block of the start leaves every other block's trajectory untouched, and that block's trajectory is
+    the complement of what it was (the plain model's spin-flip symmetry; the random numbers do not depend on the state)."""
+    X, Y, XSL, YSL, n = 16384, 4096, 4096, 1024, 12
+    by, bx = 2, 1                                   # the block that starts complemented
+    rows = slice(by * YSL, (by + 1) * YSL)
+    words = slice(bx * XSL // 32, (bx + 1) * XSL // 32)  # 16 sites of a colour per 64-bit word, XSL/2 sites of each colour per block row
+    ones = np.uint64(0x1111111111111111)
+    with ig.IsingSlab(X, Y, seed=77, temp=2.2, layout=layout, XSL=XSL, YSL=YSL) as s:
+        s.init()
+        start = [s.read(c) for c in (ig.BLACK, ig.WHITE)]
+        s.sweep(n)
+        ref = [s.read(c) for c in (ig.BLACK, ig.WHITE)]
+        s.init()
+        for c in (ig.BLACK, ig.WHITE):
+            a = start[c].copy()
+            a[rows, words] ^= ones
+            s.write(c, a)
+        s.sweep(n)
+        for c in (ig.BLACK, ig.WHITE):
+            want = ref[c].copy()
+            want[rows, words] ^= ones
+            assert np.array_equal(s.read(c), want), c
