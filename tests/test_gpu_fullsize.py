@@ -234,3 +234,32 @@ def test_spin_flip_symmetry_at_the_bench_size(gpu):
             assert np.array_equal(s.read_bits(c), want[c]), c
     gold = {p["sweeps"]: p for p in _gold("bench_65536_tc.json")["points"]}[0]
     assert (up, down) == (gold["down"], gold["up"])  # the complemented start, counted
+
+
+def test_checkpoint_round_trip_at_the_bench_size(gpu, tmp_path):
+    """Save -> go on -> load -> go on again at 65536^2 (a 512 MiB file at 1 bit per spin, offsets past 2^31): the continuation repeats
+    itself and both meet the oracle's golden counts; the file loads into two slabs as well (it is decomposition independent)."""
+    pts = {p["sweeps"]: p for p in _gold("bench_65536_tc.json")["points"]}
+    path = str(tmp_path / "bench.ckpt")
+    with ig.IsingSlab(65536, 65536, seed=1234, temp=ig.CRIT_TEMP_F32) as s:
+        one = ig.SlabSet([s]).init()
+        one.sweep(2)
+        assert one.count() == (pts[2]["up"], pts[2]["down"])
+        one.checkpoint_save(path)
+        assert os.path.getsize(path) >= 65536 * 65536 // 8
+        one.sweep(3)
+        assert one.count() == (pts[5]["up"], pts[5]["down"]) and one.bond_equal() == pts[5]["bond_equal"]
+        one.checkpoint_load(path)
+        assert one.it == 2 and one.count() == (pts[2]["up"], pts[2]["down"])
+        one.sweep(3)
+        assert one.count() == (pts[5]["up"], pts[5]["down"]) and one.bond_equal() == pts[5]["bond_equal"]
+    slabs = [ig.IsingSlab(65536, 32768, seed=1234, temp=ig.CRIT_TEMP_F32, nslabs=2, slab=k) for k in range(2)]
+    try:
+        two = ig.SlabSet(slabs).init()
+        two.checkpoint_load(path)
+        assert two.it == 2
+        two.sweep(3)
+        assert two.count() == (pts[5]["up"], pts[5]["down"]) and two.bond_equal() == pts[5]["bond_equal"]
+    finally:
+        for s in slabs:
+            s.close()
