@@ -263,3 +263,15 @@ def test_checkpoint_round_trip_at_the_bench_size(gpu, tmp_path):
     finally:
         for s in slabs:
             s.close()
+
+
+def test_correlation_distance_one_is_the_bond_sum_at_the_bench_size(gpu):
+    """-c at 65536^2: the distance-1 entry of the correlation sums is (parallel - antiparallel bonds) = 2 A - 2 N, with A the bond sum
+    the oracle's golden holds after 5 sweeps -- the correlation kernel against the oracle at full size through an exact identity."""
+    pts = {p["sweeps"]: p for p in _gold("bench_65536_tc.json")["points"]}
+    n = 65536 * 65536
+    with ig.IsingSlab(65536, 65536, seed=1234, temp=ig.CRIT_TEMP_F32) as s:
+        s.init().sweep(5)
+        sums = s.correlations(2)
+        assert sums[0] == 2 * pts[5]["bond_equal"] - 2 * n
+        assert abs(sums[1]) < abs(sums[0])  # (distance 2 is less correlated than distance 1 at T_c after 5 sweeps from a hot start)
