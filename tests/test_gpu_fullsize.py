@@ -275,3 +275,32 @@ def test_correlation_distance_one_is_the_bond_sum_at_the_bench_size(gpu):
         sums = s.correlations(2)
         assert sums[0] == 2 * pts[5]["bond_equal"] - 2 * n
         assert abs(sums[1]) < abs(sums[0])  # (distance 2 is less correlated than distance 1 at T_c after 5 sweeps from a hot start)
+
+
+def test_coupled_update_at_the_bench_size_by_the_antiferromagnetic_map(gpu):
+    """-J at 65536^2 (two coupling arrays of 1 GiB): every bond antiferromagnetic and the black colour complemented is the plain run with
+    the black colour complemented (tests/test_gpu_couplings.py at 2^25 spins) -- here against the oracle's golden counts after 5 sweeps:
+    complementing black turns its up spins into down spins."""
+    pts = {p["sweeps"]: p for p in _gold("bench_65536_tc.json")["points"]}
+    X = Y = 65536
+    with ig.IsingSlab(X, Y, seed=1234, temp=ig.CRIT_TEMP_F32) as s:
+        s.init().sweep(5)
+        assert s.count() == (pts[5]["up"], pts[5]["down"])
+    with ig.IsingSlab(X, Y, seed=1234, temp=ig.CRIT_TEMP_F32, J_prob=1.0) as s:
+        s.init()
+        full = np.full((Y, X // 32), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+        s.write_couplings(ig.BLACK, full)
+        s.write_couplings(ig.WHITE, full)
+        del full
+        b = s.read_bits(ig.BLACK)
+        s.write_bits(ig.BLACK, ~b)
+        del b
+        s.sweep(5)
+        # white as in the plain run, black complemented: up_total = up_white + (N/2 - up_black)
+        bits = s.read_bits(ig.BLACK)
+        up_black_c = sum(int(np.unpackbits(bits[r0:r0 + 4096].view(np.uint8)).sum()) for r0 in range(0, Y, 4096))
+        del bits
+        up, down = s.count()
+        half = X * Y // 2
+        up_white = up - up_black_c
+        assert (up_white + (half - up_black_c), half - up_white + up_black_c) == (pts[5]["up"], pts[5]["down"])
