@@ -37,3 +37,18 @@ def test_ring_of_processes_on_one_gpu(gpu):
                 os.path.join("examples", "ring_of_processes.py")])
     m = re.search(r"2 slabs of 8192 x 32768: after 128 sweeps up (\d+), down (\d+)", out)
     assert m and int(m.group(1)) + int(m.group(2)) == 2 * 8192 * 32768, out
+
+
+def test_c_caller(gpu, tmp_path):
+    """examples/c_caller.c: pedantic C99 against include/ising_hip.h, linked with libising_hip.so, run on the GPU: BASELINE config 2's
+    lattice after 0 and 16 sweeps = the oracle's golden counts and bond sum."""
+    import json
+    exe = str(tmp_path / "c_caller")
+    lib = os.path.join(ROOT, "ising_gpu_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_caller.c"), "-o", exe, "-L", lib, "-lising_hip", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    pts = {p["sweeps"]: p for p in json.load(open(os.path.join(ROOT, "tests", "golden", "config2_16384.json")))["points"]}
+    assert f"sweeps 0: up {pts[0]['up']} down {pts[0]['down']}\n" in r.stdout
+    assert f"sweeps 16: up {pts[16]['up']} down {pts[16]['down']} bond_equal {pts[16]['bond_equal']} (" in r.stdout
