@@ -594,9 +594,12 @@ int main(int argc, char **argv) {
 	printf("\ttemp: %f (%f*T_crit)\n", temp, temp / ISING_CRIT_TEMP);
 	if (!tempUpdFreq) printf("\ttemp update not set\n");
 	else printf("\ttemp update: %f / %d iterations\n", tempUpdStep, tempUpdFreq);
-	if (useGenHamilt) printf("\tusing Hamiltonian buffer, setting links to -1 with prob %G\n", hamiltPerc1);
-	if (useGenHamilt && ts.J_symmetric) printf("\tsymmetric bonds: each colour's update reads its own sites' links (not the reference's pairing)\n");
-	else printf("\tnot using Hamiltonian buffer\n");
+	if (useGenHamilt) { // exactly one of the two lines, optimized/main.cu:1577-1581
+		printf("\tusing Hamiltonian buffer, setting links to -1 with prob %G\n", hamiltPerc1);
+		if (ts.J_symmetric) printf("\tsymmetric bonds: each colour's update reads its own sites' links (not the reference's pairing)\n");
+	} else {
+		printf("\tnot using Hamiltonian buffer\n");
+	}
 	printf("\n");
 	if (useSubLatt) { // optimized/main.cu:1583-1588
 		printf("\tusing sub-lattices:\n");

@@ -78,6 +78,7 @@ def test_cli_J_transcript_vs_unpinned_oracle(gpu, oracle_mod):
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         assert "\tusing Hamiltonian buffer, setting links to -1 with prob 0.25\n" in r.stdout
+        assert "not using Hamiltonian buffer" not in r.stdout  # exactly one of the two lines, optimized/main.cu:1577-1581
         orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=1.0).init().init_couplings(0.25)
         for it in (3, 6):
             orc.sweep(it - orc.it)
