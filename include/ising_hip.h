@@ -51,9 +51,7 @@ enum {
 enum {
 	ISING_KERNEL_AUTO = 0,    /* integer-threshold kernel (v_cmpx form) when the temperature admits it, else generic */
 	ISING_KERNEL_GENERIC = 1, /* per-site FP32 compare against the exp table, exactly as the reference writes it */
-	ISING_KERNEL_FAST = 2,    /* integer thresholds compared per site (v_cmpx); error if thresholds do not fit */
-	ISING_KERNEL_LUT = 3      /* integer thresholds through a 64 KiB LDS rank table (A/B variant: fewer VALU cycles, same
-	                             speed in the power-limited regime); error if thresholds do not fit */
+	ISING_KERNEL_FAST = 2     /* integer thresholds compared per site (v_cmpx); error if thresholds do not fit */
 };
 
 /* device layout of the spin arrays.  The C-ABI always speaks the reference's packed layout (read/write/dump convert). */
@@ -248,14 +246,6 @@ int ising_device_ptr(ising_ctx *ctx, int color, void **ptr, size_t *bytes);
 int ising_measure_enqueue(ising_ctx *ctx);
 int ising_measure_fetch(ising_ctx *ctx, uint64_t *up, int64_t *bond_equal, int max_n, int *n);
 
-/* Test aid: what = 1 leaves the host's record of a slab's completion counters out of step with the device, as a faulted
- * launch would; the next fused launch then gives up after `arg` polls (0: the default bound, ~10 s) and the call that
- * synchronises next returns ISING_E_STATE with tickets and counters reset (tests/test_gpu_fused.py).  what = 2 ages the
- * slab's monotone counters (device and host record together) as billions of sweeps would: the completion counters past the
- * point where the next launch starts them over, the overlapped exchange's counters a few counts before 2^32; results must
- * not change. */
-int ising_debug_fault(ising_ctx *ctx, int what, int arg);
-
 /* The layout in use right now (ISING_LAYOUT_NIBBLE, _DENSE or _BALLOT). */
 int ising_layout(ising_ctx *ctx, int *layout);
 
@@ -341,6 +331,28 @@ int ising_rank_wait(ising_ctx *ctx, int timeout_ms);
 /* Whole-lattice totals, ncclAllReduce over the ranks.  Blocking. */
 int ising_rank_count(ising_ctx *ctx, uint64_t *up, uint64_t *down);
 int ising_rank_bond_equal(ising_ctx *ctx, int64_t *A);
+
+/* Where a ring slab's time goes around its exchanges (new; the reference synchronises every device after every colour and has
+ * nothing to report, optimized/main.cu:1779-1805).  ising_exchange_stats_begin arms sampling of the next `max_exchanges` deep
+ * exchanges of this slab (ballot ring slabs with ghost rows, exchange overlapped with the launches: the default schedule of
+ * ising_ring_sweep / ising_rank_sweep); ising_exchange_stats_fetch waits for the slab's streams and reports, over the sampled
+ * exchanges (timestamps of HIP events that ride on the launches' dispatch packets and on the comm stream):
+ *   launch_ms        duration of the fused launch between two exchanges;
+ *   exchange_ms      from "the launch's edge strips have finished their last level" (the exchange may start) to "the neighbours'
+ *                    rows are in place" -- transport plus whatever the NEIGHBOURS were late by;
+ *   go_after_end_ms  the exchange's end relative to the END of the launch whose rows it carries: negative = hidden in the launch's
+ *                    tail, positive = the next launch had to wait that long (a slow link, or a neighbour that is behind);
+ *   gap_ms           end of a launch to the start of the next (includes the positive part of go_after_end_ms).
+ * Other schedules sample nothing (exchanges = 0).  Costs two events per exchange on the comm stream, nothing on the compute stream. */
+typedef struct ising_exchange_stats {
+	int32_t exchanges;
+	float launch_ms_mean, launch_ms_max;
+	float exchange_ms_mean, exchange_ms_max;
+	float go_after_end_ms_mean, go_after_end_ms_max;
+	float gap_ms_mean, gap_ms_max;
+} ising_exchange_stats;
+int ising_exchange_stats_begin(ising_ctx *ctx, int max_exchanges);
+int ising_exchange_stats_fetch(ising_ctx *ctx, ising_exchange_stats *out);
 
 /* ---- a batch of independent lattices advancing together (the temperature-sweep driver; BASELINE config 5).  The
  * reference runs one lattice per process and temperature (optimized/main.cu:1596-1598, :1465-1471).  Contexts of one shape

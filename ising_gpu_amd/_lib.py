@@ -15,7 +15,7 @@ BLACK, WHITE = 0, 1
 HAM_BLACK = 2  # the black coupling array as a third plane for halo exchange
 CRIT_TEMP_F32 = 2.2691853046417236  # float32(2.26918531421f), CRIT_TEMP optimized/main.cu:42
 SEED_DEF = 463463564571  # optimized/main.cu:63
-KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST, KERNEL_LUT = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST = 0, 1, 2
 LAYOUT_AUTO, LAYOUT_NIBBLE, LAYOUT_DENSE, LAYOUT_BALLOT = 0, 1, 2, 3
 TRANSPORT_AUTO, TRANSPORT_COPY, TRANSPORT_RCCL, TRANSPORT_IPC = 0, 1, 2, 3
 E_ARG, E_HIP, E_STATE, E_NOGPU, E_RCCL, E_TIMEOUT, E_IO = 1, 2, 3, 4, 5, 6, 7
@@ -34,6 +34,13 @@ class IsingConfig(C.Structure):
     ]
 
 
+class ExchangeStats(C.Structure):
+    """ising_exchange_stats (include/ising_hip.h): where a ring slab's time goes around its exchanges, in milliseconds."""
+    _fields_ = [("exchanges", C.c_int32)] + [(n, C.c_float) for n in (
+        "launch_ms_mean", "launch_ms_max", "exchange_ms_mean", "exchange_ms_max",
+        "go_after_end_ms_mean", "go_after_end_ms_max", "gap_ms_mean", "gap_ms_max")]
+
+
 class IsingError(RuntimeError):
     def __init__(self, msg, code=0):
         super().__init__(msg)
@@ -42,7 +49,7 @@ class IsingError(RuntimeError):
 
 _lib = None
 
-# name -> (restype, argtypes); every symbol include/ising_hip.h declares
+# name -> (restype, argtypes); every symbol include/ising_hip.h and include/ising_hip_testing.h declare
 PROTOTYPES = {
     "ising_last_error": (C.c_char_p, []),
     "ising_device_count": (C.c_int, [C.POINTER(C.c_int)]),
@@ -89,6 +96,7 @@ PROTOTYPES = {
     "ising_device_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "ising_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "ising_debug_fault": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "ising_batch_debug_fault": (C.c_int, [C.c_void_p, C.c_int]),
     "ising_dump_text": (C.c_int, [C.c_void_p, C.c_char_p]),
     "ising_ring_set_transport": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "ising_ring_transport": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]),
@@ -112,6 +120,8 @@ PROTOTYPES = {
     "ising_rank_wait": (C.c_int, [C.c_void_p, C.c_int]),
     "ising_rank_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ising_rank_bond_equal": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "ising_exchange_stats_begin": (C.c_int, [C.c_void_p, C.c_int]),
+    "ising_exchange_stats_fetch": (C.c_int, [C.c_void_p, C.POINTER(ExchangeStats)]),
     "ising_ring_exchange": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "ising_ring_sweep": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
     "ising_use_private_stream": (C.c_int, [C.c_void_p]),

@@ -474,7 +474,9 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				}
 				__builtin_amdgcn_s_sleep(127);
 			}
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // rows written by another kernel / a copy engine while this launch ran
+			// rows written while this launch ran by another kernel, a copy engine -- or, IPC transport with a device per rank, by a
+			// PEER device's copy into this slab's ghost rows: system scope (the lattice loads behind it bypass the vector L1 anyway)
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 		}
 #if defined(ISING_FUSED_TRACE) && defined(ISING_FUSED_TRACE_COUNTS)
 		t_unit1 = clock64(); // (behind the wait for the parents)
@@ -1008,7 +1010,7 @@ static int ballot_resident_wgs(int v, const void *fn, int threads, int cus) {
 int ballot_max_wgs(int cus) { return (cus > 0 ? cus : 256) * 8; } // 8 workgroups of 4 waves per CU at most
 
 template <int NT>
-static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, int *grid_out, hipEvent_t stop) {
+static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, int *grid_out, hipEvent_t stop, hipEvent_t start) {
 	p.nwg = (p.nunits + NT / GROUP - 1) / (NT / GROUP); // (p.nunits counts column groups incl. the dead ones: 4 per wave)
 	const bool fused = p.nlevels > 1;
 	const bool usej = fused ? p.jham[0] != nullptr : p.jdst != nullptr;
@@ -1068,8 +1070,9 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	const dim3 g((unsigned)grid), block(NT);
 	// `stop`: an event that fires when this launch is done, hung on the dispatch packet itself (hipExtLaunchKernelGGL) --
 	// a hipEventRecord behind the launch is a packet of its own that drains the queue: 7 us between two 650 us launches
+	// (`start`: the same for the moment the launch begins -- the exchange statistics, ising_exchange_stats_begin)
 	switch (v) {
-#define BAL_LAUNCH(code, inst) case code: hipExtLaunchKernelGGL(inst, g, block, 0, stream, nullptr, stop, 0, p); break;
+#define BAL_LAUNCH(code, inst) case code: hipExtLaunchKernelGGL(inst, g, block, 0, stream, start, stop, 0, p); break;
 	BAL_INSTANCES(BAL_LAUNCH)
 #undef BAL_LAUNCH
 	default: return hipErrorInvalidValue;
@@ -1113,11 +1116,14 @@ void ballot_trace_dump() {
 	(void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), h, sizeof(h));
 }
 #endif
-hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_out, hipEvent_t stop) {
+hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_out, hipEvent_t stop, hipEvent_t start) {
 	if (grid_out) *grid_out = 0;
-	if (p.nunits <= 0) return stop ? hipEventRecord(stop, stream) : hipSuccess;
+	if (p.nunits <= 0) {
+		if (start) if (const hipError_t e = hipEventRecord(start, stream); e != hipSuccess) return e;
+		return stop ? hipEventRecord(stop, stream) : hipSuccess;
+	}
 	if (p.nlevels < 1) p.nlevels = 1;
-	return launch_ballot_update_nt<BAL_THREADS>(p, stream, grid_out, stop);
+	return launch_ballot_update_nt<BAL_THREADS>(p, stream, grid_out, stop, start);
 }
 
 // the BALLOT_MEASURE_SLOTS partial sums of lattice 0 into out[0] (up spins), out[1] (bond sum), and the slots back to zero

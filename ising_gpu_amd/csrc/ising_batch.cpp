@@ -24,6 +24,8 @@ struct ising_batch {
 	uint32_t *d_ctl = nullptr;                               // ticket words, then nrep x (nstrips + 2) completion counters
 	uint32_t done_base = 0;
 	unsigned long long ticket_base = 0;
+	uint32_t *h_abort = nullptr;                             // pinned, device-visible: a batched launch that gave up raises it (the batch's OWN
+	                                                         // word: a member's is cleared by any call on that member, which knows nothing of d_ctl)
 	static constexpr int MEAS_CAP = 1024;
 	static constexpr size_t MEAS_WORDS = (size_t)ising::BALLOT_MEASURE_SLOTS * 8; // per measurement and lattice: 16 partial (up, bond sum) pairs, a line each
 	unsigned long long *d_meas = nullptr, *h_meas = nullptr; // [measurement][lattice][slot][8]
@@ -57,6 +59,21 @@ int refresh_records(ising_batch *b) {
 	HIP_TRY(hipEventRecord(b->ev_upload, b->stream()));
 	b->upload_pending = true;
 	return ISING_OK;
+}
+
+// A batched launch gave up (UpdateParams.abort_flag): the batch's tickets and completion counters start over, pending
+// measurements are dropped, ISING_E_STATE.  Looked at by every batch call, so that the launches after a fault do not each wait
+// ~10 s for counters that are out of step.
+int batch_check_abort(ising_batch *b) {
+	if (!b->h_abort || !__atomic_load_n(b->h_abort, __ATOMIC_ACQUIRE)) return ISING_OK;
+	(void)hipStreamSynchronize(b->stream());
+	(void)hipMemset(b->d_ctl, 0, ising_host::SLOTCTL_TICKET_BYTES + (size_t)b->n() * ((size_t)b->nstrips + 2) * sizeof(uint32_t));
+	b->done_base = 0;
+	b->ticket_base = 0;
+	b->meas_pending = 0;
+	__atomic_store_n(b->h_abort, 0u, __ATOMIC_RELEASE);
+	return fail(ISING_E_STATE, "a batched fused launch gave up: its units' parents never completed; the batch's tickets and counters have been reset, "
+	                           "the members' lattices are undefined -- initialise or load them again");
 }
 
 } // namespace
@@ -95,6 +112,8 @@ int ising_batch_create(ising_ctx **ctxs, int n, ising_batch **out) {
 	if (e == hipSuccess) e = hipMalloc((void **)&b->d_meas, meas_bytes);
 	if (e == hipSuccess) e = hipMemset(b->d_meas, 0, meas_bytes);
 	if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_meas, meas_bytes, hipHostMallocDefault);
+	if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_abort, 64, hipHostMallocMapped);
+	if (e == hipSuccess) memset(b->h_abort, 0, 64);
 	if (e != hipSuccess) {
 		const int rc = fail(ISING_E_HIP, "batch allocation failed: %s", hipGetErrorString(e));
 		ising_batch_destroy(b);
@@ -114,6 +133,7 @@ int ising_batch_destroy(ising_batch *b) {
 	if (b->d_ctl) (void)hipFree(b->d_ctl);
 	if (b->d_meas) (void)hipFree(b->d_meas);
 	if (b->h_meas) (void)hipHostFree(b->h_meas);
+	if (b->h_abort) (void)hipHostFree(b->h_abort);
 	delete b;
 	return ISING_OK;
 }
@@ -130,6 +150,7 @@ int ising_batch_sweep(ising_batch *b, int first_it, int nsweeps) {
 	if (!b) return fail(ISING_E_ARG, "null batch");
 	if (first_it < 0 || nsweeps < 0) return fail(ISING_E_ARG, "bad iteration range");
 	HIP_TRY(hipSetDevice(b->device));
+	if (int rc = batch_check_abort(b)) return rc;
 	if (int rc = refresh_records(b)) return rc;
 	ising_ctx *c0 = b->m[0];
 	const int nwc = c0->nwc(), Y = c0->cfg.Y;
@@ -162,7 +183,7 @@ int ising_batch_sweep(ising_batch *b, int first_it, int nsweeps) {
 		p.nrep = b->n();
 		p.cus = c0->cus;
 		p.grid_cap = c0->pol.fused_wgs;
-		p.abort_flag = c0->h_abort; // (member 0 keeps the word a launch that gives up raises)
+		p.abort_flag = b->h_abort;
 		p.abort_polls = c0->pol.abort_polls;
 		if (b->done_base > (1u << 30)) { // keep the monotone completion counters far from wrapping
 			HIP_TRY(hipMemsetAsync(b->d_ctl + ising_host::SLOTCTL_TICKET_BYTES / 4, 0, (size_t)b->n() * p.done_stride * sizeof(uint32_t), b->stream()));
@@ -178,9 +199,18 @@ int ising_batch_sweep(ising_batch *b, int first_it, int nsweeps) {
 	return ISING_OK;
 }
 
+// test aid (include/ising_hip_testing.h): the host's record of the batch's completion counters out of step with the device
+int ising_batch_debug_fault(ising_batch *b, int polls) {
+	if (!b) return fail(ISING_E_ARG, "null batch");
+	b->done_base += 1u << 20;
+	if (polls > 0) b->m[0]->pol.abort_polls = (uint32_t)polls; // (the bound travels with member 0's policy)
+	return ISING_OK;
+}
+
 int ising_batch_measure_enqueue(ising_batch *b) {
 	if (!b) return fail(ISING_E_ARG, "null batch");
 	HIP_TRY(hipSetDevice(b->device));
+	if (int rc = batch_check_abort(b)) return rc;
 	if (b->meas_pending >= ising_batch::MEAS_CAP) return fail(ISING_E_STATE, "%d measurements pending: ising_batch_measure_fetch first", b->meas_pending);
 	if (int rc = refresh_records(b)) return rc;
 	const ising_ctx *c0 = b->m[0];
@@ -199,13 +229,7 @@ int ising_batch_measure_fetch(ising_batch *b, uint64_t *up, int64_t *bond_equal,
 		HIP_TRY(hipMemsetAsync(b->d_meas, 0, words * sizeof(unsigned long long), b->stream())); // the accumulators of the next round
 	}
 	HIP_TRY(hipStreamSynchronize(b->stream()));
-	if (b->m[0]->h_abort && __atomic_load_n(b->m[0]->h_abort, __ATOMIC_ACQUIRE)) { // a batched launch gave up: its own tickets and counters start over too
-		(void)hipMemset(b->d_ctl, 0, ising_host::SLOTCTL_TICKET_BYTES + (size_t)b->n() * ((size_t)b->nstrips + 2) * sizeof(uint32_t));
-		b->done_base = 0;
-		b->ticket_base = 0;
-		b->meas_pending = 0;
-		return ising_host::check_abort(b->m[0]);
-	}
+	if (int rc = batch_check_abort(b)) return rc;
 	for (size_t i = 0; i < pairs; i++) {
 		unsigned long long u = 0, a = 0;
 		for (int s = 0; s < ising::BALLOT_MEASURE_SLOTS; s++) { u += b->h_meas[i * ising_batch::MEAS_WORDS + 8 * s]; a += b->h_meas[i * ising_batch::MEAS_WORDS + 8 * s + 1]; }

@@ -134,8 +134,9 @@ void ising_host::ballot_tmp_release(ising_ctx *c) {
 bool ising_host::ballot_native_observables(const ising_ctx *c) { return c->ballot && !c->cfg.XSL; }
 
 int ising_host::ballot_measure_into_acc(ising_ctx *c) {
-	if (!c->d_self) {
-		HIP_TRY(hipMalloc((void **)&c->d_self, sizeof(ising::ReplicaParams)));
+	// (each on its own: a slab that nearly fills the device may get the first allocation and not the second)
+	if (!c->d_self) HIP_TRY(hipMalloc((void **)&c->d_self, sizeof(ising::ReplicaParams)));
+	if (!c->d_mslots) {
 		HIP_TRY(hipMalloc((void **)&c->d_mslots, (size_t)ising::BALLOT_MEASURE_SLOTS * 8 * sizeof(unsigned long long)));
 		HIP_TRY(hipMemsetAsync(c->d_mslots, 0, (size_t)ising::BALLOT_MEASURE_SLOTS * 8 * sizeof(unsigned long long), c->stream));
 	}
@@ -216,26 +217,6 @@ void compute_tables(ising_ctx *c, float temp) {
 	c->fast_ok = symmetric && c->thr[0] == always && c->thr[1] == always && c->thr[2] == always &&
 	             c->thr[3] < always && c->thr[4] <= c->thr[3];
 	c->cfg.temp = temp;
-	c->lut_dirty = true;
-}
-
-// Accept-rank table for the LDS kernel: entry h (= top 16 bits of a draw x) holds [x < n3] + [x < n4] when h alone
-// decides both compares, and 4 ("undecidable": the kernel redoes those draws with exact compares) otherwise.
-void build_rank_table(const ising_ctx *c, uint8_t *tab) {
-	const uint32_t n3 = (uint32_t)c->thr[3], n4 = (uint32_t)c->thr[4];
-	auto decided = [](uint32_t h, uint32_t n, int *val) { // x in [h<<16, (h<<16)+0xFFFF] against threshold n
-		const uint32_t lo = h << 16, hi = lo | 0xFFFFu;
-		if (hi < n) { *val = 1; return true; }
-		if (lo >= n) { *val = 0; return true; }
-		return false;
-	};
-	for (uint32_t h = 0; h < 65536; h++) {
-		int a = 0, b = 0;
-		const bool ok3 = decided(h, n3, &a), ok4 = decided(h, n4, &b);
-		const bool ok = ok3 && ok4;
-		if (c->dense) tab[h] = ok ? (uint8_t)(a | (b << 1)) : (uint8_t)2; // fields (c3, c4); "c4 without c3" marks undecided
-		else tab[h] = ok ? (uint8_t)(a + b) : (uint8_t)4;
-	}
 }
 
 // Inverse of ham_planes_k (ising_dense.hip), in place: four coupling bit-planes per vector -> 32 nibbles.
@@ -464,6 +445,10 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		delete c;
 		return fail(ISING_E_ARG, "bad layout %d", cfg->layout);
 	}
+	if (cfg->kernel != ISING_KERNEL_AUTO && cfg->kernel != ISING_KERNEL_GENERIC && cfg->kernel != ISING_KERNEL_FAST) {
+		delete c;
+		return fail(ISING_E_ARG, "bad kernel %d", cfg->kernel);
+	}
 	c->dense = cfg->layout != ISING_LAYOUT_NIBBLE;
 	// the ballot layout covers the integer-threshold update without sub-lattices and couplings, 8192-column granularity
 	// (sub-lattice widths: 2048, 4096 or a multiple of 8192 columns)
@@ -577,7 +562,6 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	}
 	if (e == hipSuccess) e = hipMemset(c->d_lat, 0, c->alloc_words() * sizeof(uint64_t)); // optimized/main.cu:1603
 	if (e == hipSuccess) e = hipMalloc((void **)&c->d_acc, 4 * sizeof(unsigned long long));
-	if (e == hipSuccess) e = hipMalloc((void **)&c->d_lut, 65536);
 	if (e == hipSuccess && c->ballot) {
 		// accept-mask slots, 2 KiB per wave: of every wave of the largest plain launch (one workgroup per unit), and of
 		// every workgroup slot of a fused launch (4 waves each)
@@ -639,7 +623,6 @@ int ising_destroy(ising_ctx *c) {
 	ising_host::ring_release(c);
 	if (c->d_lat && !c->cfg.lattice_mem) (void)hipFree(c->d_lat);
 	if (c->d_acc) (void)hipFree(c->d_acc);
-	if (c->d_lut) (void)hipFree(c->d_lut);
 	if (c->d_tmp) (void)hipFree(c->d_tmp);
 	if (c->d_scratch) (void)hipFree(c->d_scratch);
 	if (c->d_ham && !c->cfg.coupling_mem) (void)hipFree(c->d_ham);
@@ -727,11 +710,14 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	// one-shot requests of the ring schedules for THIS launch (taken here, so that an early return cannot leave them set)
 	const bool edge_scratch = c->edge_scratch_next;
 	const bool overlap = c->overlap_next;
+	hipEvent_t start = c->launch_start_next;
+	if (!stop) stop = c->launch_stop_next;
 	c->edge_scratch_next = false;
 	c->overlap_next = false;
+	c->launch_start_next = c->launch_stop_next = nullptr;
 	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
 	if (it < 0) return fail(ISING_E_ARG, "negative iteration %d", it);
-	int mode = c->cfg.kernel == ISING_KERNEL_GENERIC ? 1 : (c->cfg.kernel == ISING_KERNEL_LUT ? 2 : 0); // AUTO, FAST -> 0
+	int mode = c->cfg.kernel == ISING_KERNEL_GENERIC ? 1 : 0; // AUTO, FAST -> 0
 	if (mode != 1 && !c->fast_ok) {
 		if (c->cfg.kernel != ISING_KERNEL_AUTO) return fail(ISING_E_STATE, "temperature %g does not admit the integer-threshold kernels", (double)c->cfg.temp);
 		mode = 1;
@@ -740,13 +726,6 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	if (c->ballot && mode == 1) if (int rc = ising_host::ballot_leave(c)) return rc; // no integer thresholds at this temperature
 	c->ghost_depth[color] = 0; // (the neighbours' copies of this slab's rows are stale from here on -- and theirs here, by symmetry)
 	if (nlevels > 1) c->ghost_depth[1 - color] = 0;
-	if (mode == 2 && c->lut_dirty) {
-		std::vector<uint8_t> tab(65536);
-		build_rank_table(c, tab.data());
-		HIP_TRY(hipMemcpyAsync(c->d_lut, tab.data(), tab.size(), hipMemcpyHostToDevice, c->stream));
-		HIP_TRY(hipStreamSynchronize(c->stream)); // `tab` is pageable host memory about to go out of scope
-		c->lut_dirty = false;
-	}
 	const int other = 1 - color;
 	ising::UpdateParams p{};
 	p.dst = c->lat(color);
@@ -793,7 +772,6 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	p.n3 = (uint32_t)c->thr[3];
 	p.n4 = (uint32_t)c->thr[4];
 	memcpy(p.tab, c->tab, sizeof(p.tab));
-	p.lut = c->d_lut;
 	// the reference hands hamW to the BLACK update and hamB to the WHITE one (optimized/main.cu:1774, :1795)
 	p.jdst = c->cfg.use_J ? c->ham(other) : nullptr;
 	p.scratch = (edge_scratch && c->d_scratch_edge) ? c->d_scratch_edge : c->d_scratch;
@@ -837,7 +815,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			}
 		}
 		int grid = 0;
-		if (const hipError_t le = ising::launch_ballot_update(p, c->stream, &grid, stop); le != hipSuccess) {
+		if (const hipError_t le = ising::launch_ballot_update(p, c->stream, &grid, stop, start); le != hipSuccess) {
 			// nothing ran: tickets and counters are where the launches before left them, but to be safe they start over
 			if (nlevels > 1) { __atomic_store_n(c->h_abort, 1u, __ATOMIC_RELEASE); (void)ising_host::check_abort(c); }
 			return fail(ISING_E_HIP, "kernel launch failed: %s", hipGetErrorString(le));

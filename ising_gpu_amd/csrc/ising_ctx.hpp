@@ -4,6 +4,7 @@
 #pragma once
 #include <algorithm>
 #include "../../include/ising_hip.h"
+#include "../../include/ising_hip_testing.h"
 #include "ising_kernels.h"
 
 #include <hip/hip_runtime_api.h>
@@ -79,8 +80,6 @@ struct ising_ctx {
 	uint32_t *d_bits = nullptr;          // correlations: (Y + d_bits_extra) x lld words, one bit per spin
 	int d_bits_extra = 0;
 	long long *d_corr = nullptr;         // correlations: 128 sums
-	uint8_t *d_lut = nullptr;            // 64 KiB accept-rank table (see build_rank_table)
-	bool lut_dirty = true;
 	float tab[10]{};
 	uint64_t thr[5]{};
 	bool fast_ok = false;
@@ -114,6 +113,13 @@ struct ising_ctx {
 	uint32_t edge_go_epoch = 0;                  // value d_edge[16] is (being) brought to
 	bool go_set = false;                         // ... and it stands for the exchange that delivered the current ghost rows
 	bool overlap_next = false;                   // one-shot request to launch_ranges: the next deep launch takes part in the overlap
+	hipEvent_t launch_start_next = nullptr, launch_stop_next = nullptr; // one-shot: events on the next launch's dispatch packet
+	// Exchange statistics (ising_exchange_stats_begin / _fetch; sweep_deep_overlapped): four events per sampled exchange --
+	// [4e] launch e begins, [4e+1] launch e ends (both on its dispatch packet), [4e+2] comm stream: the launch's edge strips have
+	// finished their last level (the exchange starts), [4e+3] comm stream: the neighbours' rows are in place and edge_go has moved.
+	hipEvent_t *xs_ev = nullptr;
+	int xs_cap = 0, xs_n = 0;
+	bool xs_on = false;
 	bool store_ring = false;                     // ring on ONE device and one stream: every launch writes its edge rows straight into the
 	                                             // neighbouring slabs' halo rows (UpdateParams.mir0/mirL_bytes): no edge launch, no copies
 	bool copy_inline = false;                    // COPY transport, both neighbours on this slab's device: copies on the compute stream

@@ -96,40 +96,18 @@ __device__ __forceinline__ float u01(uint32_t x) {
 // GENERIC = false: integer thresholds (needs table >= 1 for <= 2 aligned neighbours).  GENERIC = true: the reference's
 // literal per-site FP32 compare against exp_h[spin][n] (optimized/main.cu:637-660) for temperatures that do not admit
 // the integer form (T <= 0, saturated tables).
-// Even bits of a word compacted into its low half (the inverse of a Morton spread).
-__device__ __forceinline__ uint32_t compact_even(uint32_t x) {
-	x &= 0x55555555u;
-	x = (x | (x >> 1)) & 0x33333333u;
-	x = (x | (x >> 2)) & 0x0F0F0F0Fu;
-	x = (x | (x >> 4)) & 0x00FF00FFu;
-	x = (x | (x >> 8)) & 0x0000FFFFu;
-	return x;
-}
-
-constexpr int DENSE_LUT_THREADS = 1024;
-constexpr int dense_threads(int mode) { return mode == 2 ? DENSE_LUT_THREADS : THREADS; }
-
-// MODE 0: integer thresholds, v_cmpx accept.  MODE 1 (GENERIC): FP32 table.  MODE 2: integer thresholds through a
-// 64 KiB LDS table indexed by the top 16 bits of a draw: entry = [x<n3] | [x<n4]<<1 (0, 1 or 3), or 2 where the top
-// half does not decide; sixteen sites accumulate as 2-bit fields with one v_lshl_or each, undecided sites are redone
-// with exact compares.
+// MODE 0: integer thresholds, v_cmpx accept.  MODE 1 (GENERIC): FP32 table.  (A third form -- integer thresholds through a
+// 64 KiB LDS table indexed by the top 16 bits of a draw -- measured equal or -2 % in round 1 and was removed in round 4.)
 template <int MODE, bool SUBL = false, bool USEJ = false>
-__global__ void __launch_bounds__(dense_threads(MODE)) dense_update_k(const UpdateParams p) {
+__global__ void __launch_bounds__(THREADS) dense_update_k(const UpdateParams p) {
 	constexpr bool GENERIC = MODE == 1;
 	__shared__ float sh_tab[10];
-	__shared__ __attribute__((aligned(16))) uint8_t lut[MODE == 2 ? 65536 : 16];
 	if (GENERIC) {
 		if (threadIdx.x < 10) sh_tab[threadIdx.x] = p.tab[threadIdx.x];
 		__syncthreads();
 	}
-	if (MODE == 2) {
-		const uint4 *g = reinterpret_cast<const uint4 *>(p.lut);
-		uint4 *l = reinterpret_cast<uint4 *>(lut);
-		for (int i = threadIdx.x; i < 65536 / 16; i += DENSE_LUT_THREADS) l[i] = g[i];
-		__syncthreads();
-	}
 	const int tx = threadIdx.x & (GROUP - 1);
-	const int unit = blockIdx.x * (dense_threads(MODE) / GROUP) + (threadIdx.x >> 4);
+	const int unit = blockIdx.x * (THREADS / GROUP) + (threadIdx.x >> 4);
 	if (unit >= p.nunits) return;
 	const int rng = unit >= p.nunits0;
 	const int u = unit - (rng ? p.nunits0 : 0);
@@ -180,42 +158,7 @@ __global__ void __launch_bounds__(dense_threads(MODE)) dense_update_k(const Upda
 		const uint32_t tid = ((grow >> 4) * (uint32_t)p.gx + (uint32_t)bx) * 256u + (grow & 15u) * 16u + (uint32_t)tx;
 		const PhiloxRow pr = philox_row_setup(tid, seed_lo_cy, k2y);
 
-		if (MODE == 2) {
-			uint32_t A[2][2] = {{0u, 0u}, {0u, 0u}}; // [vector][half]: sixteen 2-bit fields (c3, c4), site 0 in the low bits
-			static_for<16>([&](auto B) {
-				constexpr int j = B.value >> 3, m = 7 - (B.value & 7); // descending, so the last insert is site 0
-				uint32_t o[4];
-				philox_block(pr, cx_base + (uint32_t)(8 * j + m), p.seed_lo, p.seed_hi, o[0], o[1], o[2], o[3]);
-				const uint32_t a0 = lut[o[0] >> 16], a1 = lut[o[1] >> 16], a2 = lut[o[2] >> 16], a3 = lut[o[3] >> 16];
-				A[j][0] = (A[j][0] << 2) | a2; // site 2m+1
-				A[j][1] = (A[j][1] << 2) | a3; // site 17+2m
-				A[j][0] = (A[j][0] << 2) | a0; // site 2m
-				A[j][1] = (A[j][1] << 2) | a1; // site 16+2m
-			});
-			uint32_t c3[2], c4[2];
-#pragma unroll
-			for (int j = 0; j < 2; ++j) {
-				// field value 2 (below n4 but not below n3) cannot happen: it marks an undecided table row
-				const uint32_t amb0 = (A[j][0] >> 1) & ~A[j][0] & 0x55555555u, amb1 = (A[j][1] >> 1) & ~A[j][1] & 0x55555555u;
-				if (__any((amb0 | amb1) != 0u)) {
-#pragma unroll 1
-					for (int m = 0; m < 8; ++m) {
-						const uint32_t fld = 0xFu << (4 * m); // sites 2m, 2m+1 of a half
-						if (!__any(((amb0 | amb1) & fld) != 0u)) continue;
-						uint32_t o0, o1, o2, o3;
-						philox_block(pr, cx_base + (uint32_t)(8 * j + m), p.seed_lo, p.seed_hi, o0, o1, o2, o3);
-						const uint32_t e0 = (uint32_t)(o0 < p.n3) | ((uint32_t)(o0 < p.n4) << 1), e1 = (uint32_t)(o1 < p.n3) | ((uint32_t)(o1 < p.n4) << 1);
-						const uint32_t e2 = (uint32_t)(o2 < p.n3) | ((uint32_t)(o2 < p.n4) << 1), e3 = (uint32_t)(o3 < p.n3) | ((uint32_t)(o3 < p.n4) << 1);
-						A[j][0] = (A[j][0] & ~fld) | ((e0 | (e2 << 2)) << (4 * m));
-						A[j][1] = (A[j][1] & ~fld) | ((e1 | (e3 << 2)) << (4 * m));
-					}
-				}
-				c3[j] = compact_even(A[j][0]) | (compact_even(A[j][1]) << 16);
-				c4[j] = compact_even(A[j][0] >> 1) | (compact_even(A[j][1] >> 1) << 16);
-			}
-			me0 ^= word_flips(me0, up0, ct0, dw0, side0, back, c3[0], c4[0]);
-			me1 ^= word_flips(me1, up1, ct1, dw1, side1, back, c3[1], c4[1]);
-		} else if (!GENERIC) {
+		if (!GENERIC) {
 			uint32_t c3[2] = {0u, 0u}, c4[2] = {0u, 0u};
 			static_for<16>([&](auto B) {
 				constexpr int j = B.value >> 3, m = B.value & 7;
@@ -446,11 +389,9 @@ hipError_t launch_packed_to_dense(const uint64_t *packed, uint32_t *dense, size_
 
 hipError_t launch_dense_update(const UpdateParams &p, int mode, hipStream_t stream) {
 	if (p.nunits <= 0) return hipSuccess;
-	const int per_block = dense_threads(mode) / GROUP;
-	const dim3 grid((p.nunits + per_block - 1) / per_block), block(dense_threads(mode));
 	const dim3 g0((p.nunits + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), b0(THREADS);
 	const bool generic = mode == 1;
-	if (p.jdst) { // -J couplings: the v_cmpx and generic forms read the coupling planes
+	if (p.jdst) { // -J couplings
 		if (p.slY) {
 			if (generic) hipLaunchKernelGGL((dense_update_k<1, true, true>), g0, b0, 0, stream, p);
 			else         hipLaunchKernelGGL((dense_update_k<0, true, true>), g0, b0, 0, stream, p);
@@ -458,12 +399,11 @@ hipError_t launch_dense_update(const UpdateParams &p, int mode, hipStream_t stre
 			if (generic) hipLaunchKernelGGL((dense_update_k<1, false, true>), g0, b0, 0, stream, p);
 			else         hipLaunchKernelGGL((dense_update_k<0, false, true>), g0, b0, 0, stream, p);
 		}
-	} else if (p.slY) { // sub-lattices: the v_cmpx and generic forms carry the seam logic
+	} else if (p.slY) { // sub-lattices
 		if (generic) hipLaunchKernelGGL((dense_update_k<1, true>), g0, b0, 0, stream, p);
 		else         hipLaunchKernelGGL((dense_update_k<0, true>), g0, b0, 0, stream, p);
-	} else if (generic)   hipLaunchKernelGGL((dense_update_k<1, false>), grid, block, 0, stream, p);
-	else if (mode == 2)   hipLaunchKernelGGL((dense_update_k<2, false>), grid, block, 0, stream, p);
-	else                  hipLaunchKernelGGL((dense_update_k<0, false>), grid, block, 0, stream, p);
+	} else if (generic)   hipLaunchKernelGGL((dense_update_k<1, false>), g0, b0, 0, stream, p);
+	else                  hipLaunchKernelGGL((dense_update_k<0, false>), g0, b0, 0, stream, p);
 	return hipGetLastError();
 }
 

@@ -367,15 +367,16 @@ static int rank_header(const ising_ctx *c, int64_t it, CheckpointHeader *h) {
 int ising_rank_checkpoint_save(ising_ctx *c, const char *path, int64_t it) {
 	if (!c || !path) return fail(ISING_E_ARG, "null argument");
 	if (!c->rank_mode) return fail(ISING_E_STATE, "the slab is not attached to a multi-process ring (single-process rings: ising_ring_checkpoint_save)");
-	if (int rc = ising_rank_wait(c, -1)) return rc;
+	// (a rank on which one of these fails still enters every collective below -- its failure is folded into `rc` and agreed
+	// on with the others -- instead of returning early and leaving them waiting in an all-reduce)
+	int rc = ising_rank_wait(c, -1);
 	uint64_t up = 0, down = 0;
-	if (int rc = ising_rank_count(c, &up, &down)) return rc; // the total for the trailer; every rank has stopped sweeping
+	if (const int rc2 = ising_rank_count(c, &up, &down); rc == ISING_OK) rc = rc2; // the total for the trailer; every rank has stopped sweeping
 	CheckpointHeader h;
 	rank_header(c, it, &h);
 	const std::string tmp = std::string(path) + ".part";
 	const size_t row_bytes = (size_t)c->cfg.X / 64 * 4;
-	int rc = ISING_OK;
-	if (c->cfg.slab == 0) { // lay the file out
+	if (c->cfg.slab == 0 && rc == ISING_OK) { // lay the file out
 		FILE *fp = fopen(tmp.c_str(), "wb");
 		if (!fp) rc = fail(ISING_E_IO, "cannot open %s for writing: %s", tmp.c_str(), strerror(errno));
 		if (rc == ISING_OK && fwrite(&h, sizeof(h), 1, fp) != 1) rc = fail(ISING_E_IO, "write to %s failed", tmp.c_str());
@@ -417,10 +418,10 @@ int ising_rank_checkpoint_save(ising_ctx *c, const char *path, int64_t it) {
 int ising_rank_checkpoint_load(ising_ctx *c, const char *path, int64_t *it) {
 	if (!c || !path) return fail(ISING_E_ARG, "null argument");
 	if (!c->rank_mode) return fail(ISING_E_STATE, "the slab is not attached to a multi-process ring (single-process rings: ising_ring_checkpoint_load)");
-	if (int rc = ising_rank_wait(c, -1)) return rc;
 	// (a rank that fails still takes part in the collectives below: the ranks stay in step and all of them report the failure)
+	int rc = ising_rank_wait(c, -1);
 	FILE *fp = fopen(path, "rb");
-	int rc = fp ? ISING_OK : fail(ISING_E_IO, "cannot open %s: %s", path, strerror(errno));
+	if (!fp && rc == ISING_OK) rc = fail(ISING_E_IO, "cannot open %s: %s", path, strerror(errno));
 	CheckpointHeader h;
 	memset(&h, 0, sizeof(h));
 	if (rc == ISING_OK) rc = read_header(fp, path, &h);

@@ -262,7 +262,20 @@ int ising_ipc_export(ising_ctx *c, void *blob_out) {
 	if (int rc = ising_host::ring_resources(c)) return rc;
 	if (!c->ipc) c->ipc = new ising_ipc_state();
 	ising_ipc_state *ipc = c->ipc;
-	if (!ipc->mine) {
+	if (ipc->mine) {
+		// A re-export (the attach behind an earlier export failed or was abandoned): neighbours that did attach may have pushed or
+		// released into the old segment already, so its counters are not the zeros a new attachment starts from -- a waiter
+		// would take epoch 1 for delivered before the rows arrive.  Every export gets a fresh segment under a fresh name.
+		(void)hipStreamSynchronize(c->stream);
+		if (c->comm) (void)hipStreamSynchronize(c->comm);
+		(void)hipHostUnregister(ipc->mine);
+		(void)munmap(ipc->mine, IPC_SEG_BYTES);
+		(void)shm_unlink(ipc->shm_name.c_str());
+		ipc->mine = nullptr;
+		ipc->mine_flags = ipc->mine_abort = nullptr;
+		ipc->shm_name.clear();
+	}
+	{
 		static std::atomic<unsigned> serial{0};
 		char name[40];
 		const unsigned long long stamp = (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();

@@ -33,7 +33,6 @@ struct UpdateParams {
 	int32_t nunits;           // units of both ranges
 	uint32_t n3, n4;          // integer accept thresholds for 3 / 4 aligned neighbours (fast kernel)
 	float tab[10];            // exp table exp_h[2][5] (generic kernel)
-	const uint8_t *lut;       // 64 KiB rank table indexed by the top 16 bits of a draw (mode 2)
 	const uint64_t *jdst;     // coupling words read for the rows being updated (NULL without -J); same shape as dst
 	uint64_t *scratch;        // ballot layout: 2 KiB of accept-mask slots per wave of the GRID (ballot_max_wgs() x 4 waves)
 	// ballot layout, persistent launches
@@ -87,7 +86,7 @@ struct ReplicaParams { // 32 bytes, 32-byte aligned: one s_load_dwordx8
 	uint32_t seed_lo, seed_hi;
 };
 
-// mode: 0 = integer thresholds via v_cmpx, 1 = generic FP32-table kernel, 2 = integer thresholds via the LDS rank table
+// mode: 0 = integer thresholds via v_cmpx, 1 = generic FP32-table kernel
 hipError_t launch_update(const UpdateParams &p, int mode, hipStream_t stream);
 
 struct InitParams {
@@ -154,11 +153,11 @@ hipError_t launch_packed_to_dense(const uint64_t *packed, uint32_t *dense, size_
 
 // ballot layout (1 bit per spin in wave-ballot order, ising_ballot.hip): integer-threshold update, conversions
 // `p` is completed by the launcher (nwg); *grid_out = workgroups launched
-// `stop` (optional): an event that fires when the launch is done
+// `stop` / `start` (optional): events that fire when the launch is done / begins (they ride on the dispatch packet)
 #if defined(ISING_FUSED_TRACE)
 void ballot_trace_dump(); // measurement builds only (ising_ballot.hip)
 #endif
-hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_out, hipEvent_t stop = nullptr);
+hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_out, hipEvent_t stop = nullptr, hipEvent_t start = nullptr);
 int ballot_max_wgs(int cus); // upper bound of the grid of any ballot launch (scratch sizing)
 // up-spin count and black-site bond sum of `nrep` ballot lattices (gx, Y each; reps[r].lat[]), spread over BALLOT_MEASURE_SLOTS
 // accumulator pairs per lattice, 64 bytes apart: acc[(r * SLOTS + s) * 8 + {0, 1}]

@@ -131,49 +131,15 @@ __device__ __forceinline__ uint32_t apply_flips(uint32_t me, uint32_t S, uint32_
 	return __builtin_amdgcn_bitop3_b32(me, f >> 3, 0x11111111u, 0x78); // me ^ ((f >> 3) & 0x1111...)
 }
 
-// Exact accept ranks for the dword pair (rx, ry) fed by draw blocks cx0..cx0+3 of one vector: plain compares, runtime
-// nibble positions, rolled loop (small code).  Only runs when the rank table reports an undecidable entry
-// (about 3 % of wave-pairs).
-__device__ __forceinline__ void exact_rank_pair(const PhiloxRow &pr, uint32_t cx0, uint32_t seed_lo, uint32_t seed_hi,
-                                                uint32_t n3, uint32_t n4, uint32_t &rx, uint32_t &ry) {
-	uint32_t ax = 0, ay = 0;
-#pragma unroll 1
-	for (int mm = 0; mm < 4; ++mm) {
-		uint32_t o0, o1, o2, o3;
-		philox_block(pr, cx0 + (uint32_t)mm, seed_lo, seed_hi, o0, o1, o2, o3);
-		const int sh = 8 * mm;
-		ax += ((uint32_t)(o0 < n3) + (uint32_t)(o0 < n4)) << sh;
-		ay += ((uint32_t)(o1 < n3) + (uint32_t)(o1 < n4)) << sh;
-		ax += ((uint32_t)(o2 < n3) + (uint32_t)(o2 < n4)) << (sh + 4);
-		ay += ((uint32_t)(o3 < n3) + (uint32_t)(o3 < n4)) << (sh + 4);
-	}
-	rx = ax;
-	ry = ay;
-}
-
-constexpr int LUT_BYTES = 65536;
-constexpr int threads_of(int mode) { return mode == 2 ? 1024 : THREADS; }
-
 // ---------------------------------------------------------------------------------------------- update
-// MODE 0: integer thresholds, v_cmpx accept (default).  MODE 1: generic FP32 table.  MODE 2: integer thresholds
-// through the 64 KiB LDS rank table.
-#ifndef ISING_LUT_WAVES_PER_SIMD
-#define ISING_LUT_WAVES_PER_SIMD 4
-#endif
+// MODE 0: integer thresholds, v_cmpx accept (default).  MODE 1: generic FP32 table.  (A third form -- integer thresholds
+// through a 64 KiB LDS rank table -- lost its A/B comparison in round 1 and was removed in round 4; LAB_NOTES.md keeps its numbers.)
 // USEJ (-J couplings) and SUBL (sub-lattices) are template switches so the common case carries none of their code.
 template <int MODE, bool USEJ = false, bool SUBL = false>
-__global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_PER_SIMD : 1) update_k(const UpdateParams p) {
+__global__ void __launch_bounds__(THREADS) update_k(const UpdateParams p) {
 	__shared__ float sh_tab[10];
-	__shared__ __attribute__((aligned(16))) uint8_t lut[MODE == 2 ? LUT_BYTES : 16];
 	if (MODE == 1) {
 		if (threadIdx.x < 10) sh_tab[threadIdx.x] = p.tab[threadIdx.x];
-		__syncthreads();
-	}
-	if (MODE == 2) {
-		// rank table: lut[x >> 16] = [x < n3] + [x < n4] where the top 16 bits decide, 4 where they do not
-		const uint4 *g = reinterpret_cast<const uint4 *>(p.lut);
-		uint4 *l = reinterpret_cast<uint4 *>(lut);
-		for (int i = threadIdx.x; i < LUT_BYTES / 16; i += threads_of(MODE)) l[i] = g[i];
 		__syncthreads();
 	}
 	const int tx = threadIdx.x & (GROUP - 1);
@@ -183,7 +149,7 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 #if defined(ISING_XCD_REMAP) // A/B tested at 65536^2: no measurable effect (within +-1 % noise), so off by default
 	if ((gridDim.x & 7) == 0) lb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
 #endif
-	const int unit = lb * (threads_of(MODE) / GROUP) + (threadIdx.x >> 4);
+	const int unit = lb * (THREADS / GROUP) + (threadIdx.x >> 4);
 	if (unit >= p.nunits) return;
 	const int rng = unit >= p.nunits0;
 	const int u = unit - (rng ? p.nunits0 : 0);
@@ -241,34 +207,7 @@ __global__ void __launch_bounds__(threads_of(MODE), MODE == 2 ? ISING_LUT_WAVES_
 		const uint32_t tid = ((grow >> 4) * (uint32_t)p.gx + (uint32_t)bx) * 256u + (grow & 15u) * 16u + (uint32_t)tx;
 		const PhiloxRow pr = philox_row_setup(tid, seed_lo_cy, k2y);
 
-		if (MODE == 2) {
-			uint32_t R[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-			static_for<16>([&](auto B) {
-				// pairs of accumulators (word x, word y) are filled high nibble first so each new rank is OR-ed into
-				// nibble 0 after a shift: draw blocks 4k+3, 4k+2, 4k+1, 4k of vector j
-				constexpr int j = B.value >> 3, k = (B.value >> 2) & 1, m = 4 * k + 3 - (B.value & 3);
-				uint32_t o[4];
-				philox_block(pr, cx_base + (uint32_t)(8 * j + m), p.seed_lo, p.seed_hi, o[0], o[1], o[2], o[3]);
-				uint32_t &rx = R[j][k], &ry = R[j][2 + k];
-				const uint32_t a0 = lut[o[0] >> 16], a1 = lut[o[1] >> 16], a2 = lut[o[2] >> 16], a3 = lut[o[3] >> 16];
-				rx = (rx << 4) | a2; // nibble 2m+1
-				ry = (ry << 4) | a3;
-				rx = (rx << 4) | a0; // nibble 2m
-				ry = (ry << 4) | a1;
-				if ((B.value & 3) == 3) {
-					// table entries whose top 16 bits do not decide the compare carry bit 2: redo the pair exactly
-					if (__any(((rx | ry) & 0x44444444u) != 0u))
-						exact_rank_pair(pr, cx_base + (uint32_t)(8 * j + 4 * k), p.seed_lo, p.seed_hi, p.n3, p.n4, rx, ry);
-				}
-			});
-			uint32_t S[4];
-			neighbour_sums<USEJ>(up0, ct0, dw0, side0, back, S, j0);
-			me0 = make_uint4(apply_flips(me0.x, S[0], R[0][0] + 0x66666666u), apply_flips(me0.y, S[1], R[0][1] + 0x66666666u),
-			                 apply_flips(me0.z, S[2], R[0][2] + 0x66666666u), apply_flips(me0.w, S[3], R[0][3] + 0x66666666u));
-			neighbour_sums<USEJ>(up1, ct1, dw1, side1, back, S, j1);
-			me1 = make_uint4(apply_flips(me1.x, S[0], R[1][0] + 0x66666666u), apply_flips(me1.y, S[1], R[1][1] + 0x66666666u),
-			                 apply_flips(me1.z, S[2], R[1][2] + 0x66666666u), apply_flips(me1.w, S[3], R[1][3] + 0x66666666u));
-		} else if (MODE == 0) {
+		if (MODE == 0) {
 			// accept ranks, pre-biased by 6 per nibble (see apply_flips)
 			uint32_t R[2][4] = {{0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u}, {0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u}};
 			static_for<16>([&](auto B) {
@@ -615,23 +554,19 @@ hipError_t launch_corr(const uint32_t *bits, int lld, int Y, int ncorr, int slW,
 
 hipError_t launch_update(const UpdateParams &p, int mode, hipStream_t stream) {
 	if (p.nunits <= 0) return hipSuccess;
-	const int per_block = threads_of(mode) / GROUP;
-	const dim3 grid((p.nunits + per_block - 1) / per_block), block(threads_of(mode));
 	const dim3 g0((p.nunits + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK), b0(THREADS);
 	const bool J = p.jdst != nullptr, S = p.slY != 0;
-	if (J || S) { // -J / sub-lattices: only the v_cmpx and generic kernels carry those paths
-		if (mode == 1) {
-			if (J && S)  hipLaunchKernelGGL((update_k<1, true, true>), g0, b0, 0, stream, p);
-			else if (J)  hipLaunchKernelGGL((update_k<1, true, false>), g0, b0, 0, stream, p);
-			else         hipLaunchKernelGGL((update_k<1, false, true>), g0, b0, 0, stream, p);
-		} else {
-			if (J && S)  hipLaunchKernelGGL((update_k<0, true, true>), g0, b0, 0, stream, p);
-			else if (J)  hipLaunchKernelGGL((update_k<0, true, false>), g0, b0, 0, stream, p);
-			else         hipLaunchKernelGGL((update_k<0, false, true>), g0, b0, 0, stream, p);
-		}
-	} else if (mode == 0) hipLaunchKernelGGL((update_k<0, false, false>), grid, block, 0, stream, p);
-	else if (mode == 1)   hipLaunchKernelGGL((update_k<1, false, false>), grid, block, 0, stream, p);
-	else                  hipLaunchKernelGGL((update_k<2, false, false>), grid, block, 0, stream, p);
+	if (mode == 1) {
+		if (J && S)  hipLaunchKernelGGL((update_k<1, true, true>), g0, b0, 0, stream, p);
+		else if (J)  hipLaunchKernelGGL((update_k<1, true, false>), g0, b0, 0, stream, p);
+		else if (S)  hipLaunchKernelGGL((update_k<1, false, true>), g0, b0, 0, stream, p);
+		else         hipLaunchKernelGGL((update_k<1, false, false>), g0, b0, 0, stream, p);
+	} else {
+		if (J && S)  hipLaunchKernelGGL((update_k<0, true, true>), g0, b0, 0, stream, p);
+		else if (J)  hipLaunchKernelGGL((update_k<0, true, false>), g0, b0, 0, stream, p);
+		else if (S)  hipLaunchKernelGGL((update_k<0, false, true>), g0, b0, 0, stream, p);
+		else         hipLaunchKernelGGL((update_k<0, false, false>), g0, b0, 0, stream, p);
+	}
 	return hipGetLastError();
 }
 

@@ -485,7 +485,7 @@ int sweep_deep(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 // The comm stream of slab c, behind the transfers of the exchange that delivered the current ghost rows: wait until the
 // neighbours' rows are in place as well (RCCL: the receives are this stream's own; IPC: the neighbours' counters; copies:
 // their events), then move the slab's edge_go counter -- the edge strips of the next launch poll it (UpdateParams.edge_go).
-int post_go(ising_ctx *c) {
+int post_go(ising_ctx *c, int xs_slot = -1) { // xs_slot: the exchange-statistics slot this exchange is sampled into
 	if (int rc = bind(c)) return rc;
 	if (c->transport == ISING_TRANSPORT_IPC) {
 		for (int color = 0; color < 2; color++) if (int rc = ising_ipc::wait_plane(c, color, c->comm)) return rc;
@@ -499,6 +499,7 @@ int post_go(ising_ctx *c) {
 	c->edge_go_epoch++;
 	if (int rc = ising_ipc::counter_set_on(c->comm, c->d_edge + 16, c->edge_go_epoch)) return rc;
 	HIP_TRY(hipEventRecord(c->ev_go, c->comm));
+	if (xs_slot >= 0) HIP_TRY(hipEventRecord(c->xs_ev[4 * xs_slot + 3], c->comm));
 	c->go_set = true;
 	return ISING_OK;
 }
@@ -531,6 +532,7 @@ int sweep_deep_overlapped(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 		for (int color = 0; color < 2; color++) if (int rc = exchange_rows(ctxs, n, color, G)) return rc;
 	for (int k = 0; k < n; k++) if (!ctxs[k]->go_set) if (int rc = post_go(ctxs[k])) return rc;
 	const bool copies = ctxs[0]->transport == ISING_TRANSPORT_COPY, ipc = ctxs[0]->transport == ISING_TRANSPORT_IPC;
+	std::vector<int> xs(n, -1);
 	for (int it = first_it, left = nsweeps; left > 0;) {
 		const int ns = std::min(left, G / 2);
 		for (int k = 0; k < n; k++) {
@@ -539,6 +541,9 @@ int sweep_deep_overlapped(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 				if (int rc = bind(c)) return rc;
 				HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_go, 0));
 			}
+			// exchange statistics: this launch and the exchange it feeds go into slot xs[k] (events on the dispatch packet, no extra packets)
+			xs[k] = (c->xs_on && c->xs_n < c->xs_cap) ? c->xs_n++ : -1;
+			if (xs[k] >= 0) { c->launch_start_next = c->xs_ev[4 * xs[k]]; c->launch_stop_next = c->xs_ev[4 * xs[k] + 1]; }
 			if (int rc = ising_host::update_deep(c, it, 2 * ns, true)) return rc;
 		}
 		for (int k = 0; k < n; k++) {
@@ -546,6 +551,7 @@ int sweep_deep_overlapped(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 			if (int rc = bind(c)) return rc;
 			// (a launch that gave up never brings the counter there: the kernel looks at the slab's abort word)
 			if (int rc = ising_ipc::counter_wait_on(c->comm, c->d_edge, c->edge_done_target, c->h_abort)) return rc;
+			if (xs[k] >= 0) HIP_TRY(hipEventRecord(c->xs_ev[4 * xs[k] + 2], c->comm));
 			// this slab's launches are done with its ghost rows: the neighbours may overwrite them
 			if (ipc) for (int color = 0; color < 2; color++) if (int rc = ising_ipc::release_ghosts(c, color, c->comm)) return rc;
 			if (copies) HIP_TRY(hipEventRecord(c->ev_int[0], c->comm));
@@ -559,7 +565,7 @@ int sweep_deep_overlapped(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 			}
 		}
 		for (int color = 0; color < 2; color++) if (int rc = transfer(ctxs, n, color, false, G)) return rc;
-		for (int k = 0; k < n; k++) if (int rc = post_go(ctxs[k])) return rc;
+		for (int k = 0; k < n; k++) if (int rc = post_go(ctxs[k], xs[k])) return rc;
 		it += ns;
 		left -= ns;
 	}
@@ -663,6 +669,14 @@ void ising_host::ring_abort_drain(ising_ctx *c) {
 	ising_ipc::set_abort(c, false);
 }
 
+static void xs_release(ising_ctx *c) {
+	for (int i = 0; c->xs_ev && i < 4 * c->xs_cap; i++) if (c->xs_ev[i]) (void)hipEventDestroy(c->xs_ev[i]);
+	delete[] c->xs_ev;
+	c->xs_ev = nullptr;
+	c->xs_cap = c->xs_n = 0;
+	c->xs_on = false;
+}
+
 void ising_host::ring_release(ising_ctx *c) {
 	// neighbours of a single-process ring must not keep pointing at a slab that is going away
 	if (c->ring_prev && c->ring_prev->ring_next == c) { c->ring_prev->ring_next = nullptr; c->ring_prev->store_ring = false; }
@@ -680,9 +694,66 @@ void ising_host::ring_release(ising_ctx *c) {
 	if (c->ev_go) (void)hipEventDestroy(c->ev_go);
 	c->ev_go = nullptr;
 	c->comm = nullptr;
+	xs_release(c);
 }
 
 extern "C" {
+
+// ------------------------------------------------------------------------------------------------ exchange statistics
+int ising_exchange_stats_begin(ising_ctx *c, int max_exchanges) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (max_exchanges < 1 || max_exchanges > 4096) return fail(ISING_E_ARG, "max_exchanges %d (1 .. 4096)", max_exchanges);
+	if (int rc = bind(c)) return rc;
+	if (c->xs_ev) { // (events of an earlier sampling may still be in flight)
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		if (c->comm) HIP_TRY(hipStreamSynchronize(c->comm));
+	}
+	xs_release(c);
+	c->xs_ev = new hipEvent_t[4 * (size_t)max_exchanges]();
+	c->xs_cap = max_exchanges;
+	for (int i = 0; i < 4 * max_exchanges; i++) HIP_TRY(hipEventCreate(&c->xs_ev[i])); // (with timing)
+	c->xs_on = true;
+	return ISING_OK;
+}
+
+int ising_exchange_stats_fetch(ising_ctx *c, ising_exchange_stats *out) {
+	if (!c || !out) return fail(ISING_E_ARG, "null argument");
+	memset(out, 0, sizeof(*out));
+	if (!c->xs_ev) return fail(ISING_E_STATE, "ising_exchange_stats_begin first");
+	if (int rc = bind(c)) return rc;
+	c->xs_on = false;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (c->comm) HIP_TRY(hipStreamSynchronize(c->comm));
+	if (int rc = ising_host::check_abort(c)) return rc;
+	// b - a in milliseconds, either sign (hipEventElapsedTime wants them in order on some runtimes)
+	auto span = [](hipEvent_t a, hipEvent_t b, float *ms) -> hipError_t {
+		hipError_t e = hipEventElapsedTime(ms, a, b);
+		if (e != hipSuccess) {
+			(void)hipGetLastError();
+			e = hipEventElapsedTime(ms, b, a);
+			*ms = -*ms;
+		}
+		return e;
+	};
+	struct Acc { double sum = 0; float max = 0; int n = 0; void add(float v) { sum += v; max = n ? std::max(max, v) : v; n++; } };
+	Acc launch, xchg, late, gap;
+	for (int e = 0; e < c->xs_n; e++) {
+		hipEvent_t *ev = c->xs_ev + 4 * e;
+		float ms = 0;
+		HIP_TRY(span(ev[0], ev[1], &ms)); launch.add(ms);
+		HIP_TRY(span(ev[2], ev[3], &ms)); xchg.add(ms);
+		HIP_TRY(span(ev[1], ev[3], &ms)); late.add(ms);
+		if (e + 1 < c->xs_n) { HIP_TRY(span(ev[1], ev[4], &ms)); gap.add(ms); }
+	}
+	out->exchanges = c->xs_n;
+	auto put = [](const Acc &a, float *mean, float *max) { *mean = a.n ? (float)(a.sum / a.n) : 0.f; *max = a.max; };
+	put(launch, &out->launch_ms_mean, &out->launch_ms_max);
+	put(xchg, &out->exchange_ms_mean, &out->exchange_ms_max);
+	put(late, &out->go_after_end_ms_mean, &out->go_after_end_ms_max);
+	put(gap, &out->gap_ms_mean, &out->gap_ms_max);
+	c->xs_n = 0;
+	return ISING_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ single-process ring
 int ising_ring_set_transport(ising_ctx **ctxs, int n, int transport) {

@@ -288,6 +288,16 @@ class IsingSlab:
         check(self._lib.ising_rank_count(self._h, C.byref(up), C.byref(dw)))
         return int(up.value), int(dw.value)
 
+    def exchange_stats_begin(self, max_exchanges: int = 64):
+        """Sample the next deep exchanges of this ring slab (ising_exchange_stats_begin)."""
+        check(self._lib.ising_exchange_stats_begin(self._h, max_exchanges))
+
+    def exchange_stats_fetch(self) -> dict:
+        """Wait for the slab's streams; {exchanges, launch_ms_mean, ..., gap_ms_max} over the sampled exchanges."""
+        st = _lib.ExchangeStats()
+        check(self._lib.ising_exchange_stats_fetch(self._h, C.byref(st)))
+        return {n: (int(getattr(st, n)) if n == "exchanges" else round(float(getattr(st, n)), 4)) for n, _ in st._fields_}
+
     def rank_checkpoint_save(self, path: str):
         check(self._lib.ising_rank_checkpoint_save(self._h, str(path).encode(), self.it))
 
@@ -351,6 +361,10 @@ class IsingBatch:
     def measure_enqueue(self):
         check(self._lib.ising_batch_measure_enqueue(self._h))
         return self
+
+    def debug_fault(self, polls: int = 0):
+        """Test aid (ising_batch_debug_fault): the batch's completion counters out of step with the device."""
+        check(self._lib.ising_batch_debug_fault(self._h, polls))
 
     def measure_fetch(self):
         """[[(up, down, bond_equal) per member] per measurement], in enqueue order."""

@@ -437,12 +437,23 @@ class NativeRing:
     def _attach(self):
         from .lattice import rccl_unique_id
         if self.transport == "ipc":
-            mine = self.slab.ipc_export()
+            # a rank whose export fails (shm_open, hipHostRegister, hipIpcGetMemHandle) still takes part in the gather, with
+            # None, so that every rank leaves this function the same way -- an early raise would leave the others in the
+            # collective and the caller's agreement protocol (open_native_ring) a collective out of step
+            try:
+                mine, err = self.slab.ipc_export(), None
+            except IsingError as e:
+                mine, err = None, e
             if self.world == 1:
                 blobs = [mine]
             else:
                 blobs = [None] * self.world
                 dist.all_gather_object(blobs, mine, group=self.group)
+            if err is not None:
+                raise err
+            failed = [r for r, b in enumerate(blobs) if b is None]
+            if failed:
+                raise IsingError(f"IPC export failed on rank(s) {failed}")
             self.slab.ipc_attach(blobs)
             return
         if self.world == 1:

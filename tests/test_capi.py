@@ -11,10 +11,17 @@ import pytest
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def header_symbols():
-    txt = open(os.path.join(ROOT, "include", "ising_hip.h")).read()
+def header_symbols(which=("ising_hip.h", "ising_hip_testing.h")):
+    """Functions the headers under include/ declare (ising_hip_testing.h: the test-only entry points)."""
+    txt = "".join(open(os.path.join(ROOT, "include", h)).read() for h in which)
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(ising_[a-z_]+)\s*\(", txt)))
+
+
+def test_headers_under_include_are_all_known():
+    assert sorted(f for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h")) == ["ising_hip.h", "ising_hip_testing.h"]
+    assert header_symbols(("ising_hip_testing.h",)) == ["ising_batch_debug_fault", "ising_debug_fault"]      # test aids stay out of the boundary header
+    assert "ising_debug_fault" not in header_symbols(("ising_hip.h",))
 
 
 def test_library_exports_every_declared_symbol():
@@ -24,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     syms = header_symbols()
     assert len(syms) >= 20
     for s in syms:
-        assert hasattr(lib, s), f"{s} declared in include/ising_hip.h but not exported"
+        assert hasattr(lib, s), f"{s} declared under include/ but not exported"
 
 
 def test_ctypes_prototypes_cover_header():

@@ -186,6 +186,38 @@ def test_fused_launch_gives_up_instead_of_hanging(gpu, oracle_mod, monkeypatch):
         s.close()
 
 
+def test_batched_launch_that_gives_up_is_reported_once_and_by_any_batch_call(gpu, oracle_mod):
+    """a batched launch raises the BATCH's own abort word.  A call on a member in between (which checks and clears the
+    member's word and knows nothing of the batch's tickets) must not swallow it, the next batch call -- a sweep, not only a fetch --
+    reports ISING_E_STATE within a second, and the batch then runs correctly again without waiting for stale counters."""
+    import time
+    from ising_gpu_amd import _lib
+    X, Y = 8192, 256
+    slabs = [ig.IsingSlab(X, Y, seed=k, temp=2.0, layout=ig.LAYOUT_BALLOT) for k in (5, 6, 7)]
+    with ig.IsingBatch(slabs) as b:
+        b.init().sweep(2)
+        slabs[0].synchronize()
+        b.debug_fault(1 << 13)
+        t0 = time.perf_counter()
+        b.sweep(2)                      # gives up after 8192 polls
+        slabs[0].synchronize()          # a member call: waits for the launch, finds nothing wrong with the MEMBER
+        assert slabs[1].count()[0] > 0  # (a blocking member observable as well)
+        with pytest.raises(ig.IsingError) as e:
+            b.sweep(1)                  # the next batch call of any kind reports it
+        assert e.value.code == _lib.E_STATE and "gave up" in str(e.value)
+        assert time.perf_counter() - t0 < 2.0
+        t0 = time.perf_counter()
+        b.init().sweep(3).measure_enqueue()
+        meas = b.measure_fetch()
+        assert time.perf_counter() - t0 < 2.0  # (no launch waits ~10 s for counters that are out of step)
+        for r, k in enumerate((5, 6, 7)):
+            o = oracle_mod.OracleLattice(X, Y, seed=k, temp=2.0).init().sweep(3)
+            assert meas[0][r] == (*o.count(), o.bond_equal())
+            assert np.array_equal(slabs[r].read(ig.BLACK), o.black)
+    for s in slabs:
+        s.close()
+
+
 def test_contexts_driven_from_threads_of_their_own(gpu, oracle_mod, fused):
     """One context per thread, each on a private stream (ctypes drops the GIL, so the C-ABI calls really overlap): the fused
     launches of four lattices share the chip -- a workgroup only draws a ticket once it runs, so the launches cannot starve each

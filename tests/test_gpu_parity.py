@@ -22,8 +22,8 @@ def _compare(slab, orc, what):
                                  f"hip {int(got[r, q]):016x} oracle {int(ref[r, q]):016x}")
 
 
-VARIANTS = [(ig.LAYOUT_DENSE, ig.KERNEL_AUTO), (ig.LAYOUT_DENSE, ig.KERNEL_LUT), (ig.LAYOUT_DENSE, ig.KERNEL_GENERIC), (ig.LAYOUT_NIBBLE, ig.KERNEL_FAST),
-            (ig.LAYOUT_NIBBLE, ig.KERNEL_LUT), (ig.LAYOUT_NIBBLE, ig.KERNEL_GENERIC)]
+VARIANTS = [(ig.LAYOUT_DENSE, ig.KERNEL_AUTO), (ig.LAYOUT_DENSE, ig.KERNEL_GENERIC), (ig.LAYOUT_NIBBLE, ig.KERNEL_FAST),
+            (ig.LAYOUT_NIBBLE, ig.KERNEL_GENERIC)]
 
 
 @pytest.mark.parametrize("layout,kernel", VARIANTS)
