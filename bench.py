@@ -1,14 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py -- spin-flips/ns of the checkerboard-Metropolis hot loop on N MI355X (weak scaling).
+"""bench.py -- spin-flips/ns of the checkerboard-Metropolis hot loop on N MI355X.
 
 A "step" is one full lattice sweep (black half-sweep + white half-sweep, the reference's hot loop
-optimized/main.cu:1763-1805) over this rank's slab.  Per-GPU workload (fixed as N grows => weak scaling):
-X = 65536 columns x Y = 65536 rows at T = T_c (CRIT_TEMP, optimized/main.cu:42), the 65536^2 lattice BASELINE.json's
-target is quoted on (configs[2]); with N ranks the lattice is (N*65536) x 65536, slabs along Y, 64 rows of each
-colour to each ring neighbour every 32 sweeps (ghost rows; one row per colour half-sweep on the fallback ring).  The lattice is generated on the device from the seed: "synthetic".
+optimized/main.cu:1763-1805) over this rank's slab.  The lattice is generated on the device from the seed ("synthetic"),
+T = T_c (CRIT_TEMP, optimized/main.cu:42), slabs along Y (optimized/main.cu:1590-1591: the lattice is ndev*Y x X).  Workloads:
+
+  config3 (default; weak scaling)   65536 columns x 65536 rows per GPU: the 65536^2 lattice BASELINE.json's target is quoted on
+                                    (configs[2]); with N ranks the lattice is (N*65536) x 65536
+  config4 (weak scaling)            131072 columns x 16384 rows per GPU: BASELINE config 4's slab (131072^2 over 8 GPUs) at every N
+  strong  (strong scaling)          the 65536^2 lattice as a whole, 65536/N rows per GPU (north_star: "spin-flips/ns on a 65536^2
+                                    lattice ... reported at 1, 2, 4 and 8 GPUs")
+
+Every point of a scaling run checks itself: the counts after warm-up + steps are compared with the CPU oracle's committed
+goldens for the TOTAL lattice (tests/golden/bench_65536_tc.json, ring_65536_tc.json, config4_131072.json, scaling.json: 0 / 5 / 25 /
+144 sweeps = the driver's --warmup 5 --steps 20 and the default 16 + 128, for all three workloads at N = 1, 2, 4, 8) --
+`config.parity_checked`; a mismatch is a non-zero exit.
 
   N = 1   the slab sweeps itself (ising_sweep), `batch` sweeps per call (batch = the largest divisor <= 32 of
-          gcd(steps, warmup)).  ising_sweep issues fused launches from 2^26 spins up (ISING_FUSED=0: one launch per
+          gcd(steps, warmup)).  ising_sweep issues fused launches from 1.5 * 2^24 spins up (ISING_FUSED=0: one launch per
           colour): every call is ONE launch of 2 * batch colour half-sweeps, so that every launch of the run -- warm-up
           included -- is the same piece of work and the rocprofv3 per-kernel average agrees with the HIP-event average
           reported here (the default 128 + 16: pieces of 16).  Where that common piece would be under 16 sweeps (--steps 20
@@ -16,17 +25,23 @@ colour to each ring neighbour every 32 sweeps (ghost rows; one row per colour ha
           and `roofline.half_sweeps_per_launch` describe the timed launches.
   N > 1   one process per GPU; the ring lives inside libising_hip.so (ising_rank_*: second HIP stream + RCCL send/recv);
           ballot ring slabs keep ghost rows 64 deep, exchange 64 rows of both colours every 32 sweeps and run one fused launch
-          in between (sweep_deep).  Transports, in this order, every rank agreeing on each outcome: the library's RCCL ring,
+          in between (sweep_deep_overlapped).  Transports, in this order, every rank agreeing on each outcome: the library's RCCL ring,
           the library's RCCL-free peer ring (hipIpcMemHandle-mapped ghost rows, ISING_TRANSPORT_IPC), the torch.distributed
           ring (p2p on ghost rows, p2p / all-gather with one row per colour half-sweep on a torch-owned slab); the JSON line
-          says which one ran.  With more ranks than GPUs (a 1-GPU box running --gpus 2) the ranks share devices: gloo carries
-          the control plane and the peer ring the rows (RCCL refuses two ranks per device).  `python bench.py --gpus N`
-          without a launcher starts itself under torch.distributed.run.  The counts after warm-up + steps are compared with the oracle's committed goldens
-          (tests/golden/bench_65536_tc.json, ring_65536_tc.json) when the run hits one of their points.
+          says which one ran, and `exchange_stats` where each rank's time went around its exchanges (launch, exchange, how far
+          past the launch's end the exchange ran, gap to the next launch: max / mean over ranks and exchanges).  With more
+          ranks than GPUs (a 1-GPU box running --gpus 2) the ranks share devices: gloo carries the control plane and the peer
+          ring the rows (RCCL refuses two ranks per device).  `python bench.py --gpus N` without a launcher starts itself
+          under torch.distributed.run.
+
+The JSON line: `value` = bare sweeps (the contract's timed region); `with_counts_every_16` = a second leg over the same sweeps with
+the magnetisation read back every 16 sweeps inside the timed region, as every number the reference publishes includes it
+(optimized/main.cu:1806-1810); `roofline.bound` = "valu" -- the roof that binds, with the draw-only ceiling measured in the same
+job -- next to SURVEY 8(d)'s HBM accounting (1.5 B/flip) and the device's real HBM traffic.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-                bench.py --gpus N --steps K --warmup W
+                bench.py --gpus N --steps K --warmup W [--workload config3|config4|strong]
 Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -99,23 +114,50 @@ def cpu_baseline(args):
     return out
 
 
-def golden_counts(x, y_per_gpu, seed, world, sweeps):
-    """(up, down) the oracle found for this workload after `sweeps` sweeps, or None (tests/golden/make_golden_big.py)."""
+def golden_records():
+    """Every committed full-size oracle record, keyed on the TOTAL lattice: {(X, Ytot, seed): {sweeps: (up, down)}}.  Results do
+    not depend on the decomposition (optimized/main.cu:514: the Philox stream id uses the global block row; :1590-1591: the
+    lattice is ndev*Y x X), so one record serves every split of its lattice into slabs."""
     gold = os.path.join(ROOT, "tests", "golden")
+    recs = {}
+
+    def add(fx, seed=None):
+        key = (fx["X"], fx["Ytot"], fx.get("seed", seed))
+        pts = recs.setdefault(key, {})
+        for pt in fx["points"]:
+            pts[pt["sweeps"]] = (pt["up"], pt["down"])
+
+    def load(name):
+        try:
+            return json.load(open(os.path.join(gold, name)))
+        except (OSError, ValueError):
+            return None
+    for name in ("bench_65536_tc.json", "config4_131072.json"):  # make_golden_big.py
+        fx = load(name)
+        if fx:
+            add(fx)
+    fx = load("ring_65536_tc.json")                              # make_golden_big.py: (N * 65536) x 65536
+    for r in (fx or {}).get("rings", []):
+        add(r)
+    fx = load("scaling.json")                                    # make_golden_scaling.py: every point of a scaling run
+    for r in (fx or {}).get("lattices", []):
+        add(r, seed=fx.get("seed"))
+    return recs
+
+
+def golden_counts(x, y_total, seed, sweeps):
+    """(up, down) the oracle found for the x-column, y_total-row lattice after `sweeps` sweeps at T_c, or None."""
     try:
-        if world == 1:
-            recs = [json.load(open(os.path.join(gold, "bench_65536_tc.json")))]
-        else:
-            recs = [r for r in json.load(open(os.path.join(gold, "ring_65536_tc.json")))["rings"] if r["nslabs"] == world]
-        recs.append(json.load(open(os.path.join(gold, "config4_131072.json"))))  # 131072^2 (8 slabs of 16384 rows): 0, 1, 2 sweeps
-        for fx in recs:
-            if fx["X"] == x and fx["Ytot"] == y_per_gpu * world and fx["seed"] == seed:
-                for pt in fx["points"]:
-                    if pt["sweeps"] == sweeps:
-                        return pt["up"], pt["down"]
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+        return golden_records().get((x, y_total, seed), {}).get(sweeps)
+    except (KeyError, TypeError):
+        return None
+
+
+WORKLOADS = {  # name -> (columns, rows per rank at N ranks, "weak" | "strong")
+    "config3": (65536, lambda n: 65536, "weak"),
+    "config4": (131072, lambda n: 16384, "weak"),
+    "strong": (65536, lambda n: 65536 // n, "strong"),
+}
 
 
 def main():
@@ -126,9 +168,11 @@ def main():
     ap.add_argument("--x", type=int, default=0, help="columns (per-GPU slab and total)")
     ap.add_argument("--y", type=int, default=0, help="rows per GPU")
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--workload", choices=["config3", "config4"], default="config3",
-                    help="per-GPU slab: config3 = 65536 x 65536 (the size BASELINE's metric is quoted on; default), config4 = 131072 columns x "
-                         "16384 rows (BASELINE config 4: 131072^2 over 8 GPUs, the same slab at every N); --x / --y override")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="config3",
+                    help="config3 (default, weak scaling): 65536 x 65536 per GPU, the size BASELINE's metric is quoted on; config4 (weak): "
+                         "131072 columns x 16384 rows per GPU (BASELINE config 4: 131072^2 over 8 GPUs, the same slab at every N); strong: the "
+                         "65536^2 lattice as a whole, 65536 / N rows per GPU (north_star: 'a 65536^2 lattice ... at 1, 2, 4 and 8 GPUs'); "
+                         "--x / --y override the slab")
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--layout", choices=["auto", "nibble", "dense", "ballot"], default="auto", help="device layout of the spin arrays")
     ap.add_argument("--ring", choices=["native", "torch"], default="native",
@@ -144,12 +188,17 @@ def main():
     ap.add_argument("--force-ring", action="store_true",
                     help="N = 1: run the N > 1 code path anyway -- torch.distributed + the library's RCCL ring with a ring of "
                          "ONE slab (its edge rows travel through ncclSend/ncclRecv to itself); what a 1-GPU box can test of it")
+    ap.add_argument("--no-counts-leg", action="store_true",
+                    help="skip the second timed leg (the same sweeps with the magnetisation read back every 16, as every published "
+                         "number of the reference includes them: optimized/main.cu:1806-1810)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alu-probe", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
-    wx, wy = {"config3": (65536, 65536), "config4": (131072, 16384)}[args.workload]
-    args.x, args.y = args.x or wx, args.y or wy
+    wx, wy_of, scaling = WORKLOADS[args.workload]
+    if args.x or args.y:
+        scaling = "weak"  # a slab given by hand is the same slab at every N
+    args.x, args.y = args.x or wx, args.y or wy_of(max(1, args.gpus))
 
     # must be in the environment before the HIP/HSA runtime initialises (RCCL P2P needs dmabuf IPC on this host driver)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -292,8 +341,13 @@ def main():
     elif ring is not None:
         restart()  # (opening a ring runs one sweep through the transport before it is trusted: start over)
 
+    # the library's ring reports where a slab's time goes around its exchanges (ising_exchange_stats_*: HIP events on the launches'
+    # dispatch packets and on the comm stream); sampled over the timed leg on every rank
+    stats_slab = ring.slab if isinstance(ring, ig.NativeRing) else None
     advance(args.warmup, batch_warm)
     barrier()
+    if stats_slab is not None:
+        stats_slab.exchange_stats_begin(256)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()  # HIP events on the stream the kernels are launched on (torch's current stream = the slab's stream)
@@ -306,6 +360,21 @@ def main():
         t = torch.tensor([dt, ev_ms], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, ev_ms = float(t[0]), float(t[1])
+    xstats = None
+    if stats_slab is not None:
+        mine = stats_slab.exchange_stats_fetch()
+        per_rank = [mine]
+        if world > 1:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+        xstats = {"exchanges_per_rank": per_rank[0]["exchanges"],
+                  "what": "per exchange of 64 ghost rows of both colours (one per fused launch): launch = the fused launch; exchange = edge strips of "
+                          "the launch done -> neighbours' rows in place; go_after_end = the exchange's end relative to the END of the launch whose rows "
+                          "it carries (negative: hidden in the launch's tail; positive: the next launch waited that long -- a slow link or a "
+                          "neighbour that is behind); gap = end of a launch -> start of the next.  ms; mean over ranks of the per-rank means, max over everything"}
+        for k in ("launch_ms", "exchange_ms", "go_after_end_ms", "gap_ms"):
+            xstats[k] = {"mean": round(sum(r[k + "_mean"] for r in per_rank) / len(per_rank), 4), "max": round(max(r[k + "_max"] for r in per_rank), 4),
+                         "by_rank_mean": [r[k + "_mean"] for r in per_rank]}
 
     up, down = ring.count() if ring is not None else slab.count()
     rank_up = [slab.count()[0]]
@@ -316,8 +385,35 @@ def main():
     spins_per_gpu = args.x * args.y
     total_flips = float(spins_per_gpu) * world * args.steps
     value = total_flips / (dt * 1e9)
-    gold = golden_counts(args.x, args.y, args.seed, world, args.warmup + args.steps)
+    gold = golden_counts(args.x, args.y * world, args.seed, args.warmup + args.steps)
     parity = None if gold is None else (gold == (up, down))
+
+    # Second timed leg, the reference's methodology: every number it publishes was measured with the magnetisation read back
+    # inside the timed loop (-p 16: countSpins every 16 sweeps and after the last one, optimized/main.cu:1806-1810, :1862-1874;
+    # BASELINE.md).  Same lattice, same sweeps, from the start; the final counts must be the first leg's.
+    counts_leg = None
+    if not args.no_counts_leg:
+        restart()
+        advance(args.warmup, batch_warm)
+        barrier()
+        t0 = time.perf_counter()
+        ncounts, done, last = 0, 0, None
+        while done < args.steps:
+            n = min(16, args.steps - done)
+            advance(n, min(batch, n))
+            last = ring.count() if ring is not None else slab.count()  # (blocking: two 64-bit counters come back, as :860-866)
+            ncounts += 1
+            done += n
+        barrier()
+        dt2 = time.perf_counter() - t0
+        if ringed:
+            t = torch.tensor([dt2], dtype=torch.float64, device=ctl)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt2 = float(t[0])
+        counts_leg = {"value": round(total_flips / (dt2 * 1e9), 2), "unit": "flips/ns", "ms_per_step": round(dt2 * 1e3 / args.steps, 5),
+                      "counts_in_timed_region": ncounts, "final_counts_equal_first_leg": last == (up, down),
+                      "what": "the same steps with up/down counts read back every 16 sweeps and after the last one inside the timed region "
+                              "(the reference's -p 16 methodology, optimized/main.cu:1806-1810)"}
 
     layout_name, layout_text = {
         ig.LAYOUT_NIBBLE: ("nibble", "reference 4 bit/spin"),
@@ -336,52 +432,73 @@ def main():
             half_sweeps_per_launch = 2 * batch if fused else 1
             launches = args.steps // batch + (1 if args.steps % batch else 0) if fused else 2 * args.steps
         avg_launch_ms = ev_ms / launches
-        alg_bytes_per_launch = BYTES_PER_FLIP * spins_per_gpu / 2.0 * half_sweeps_per_launch  # per colour: src read + dst read + dst write
-        achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": {"ballot": "ballot_update_k", "dense": "dense_update_k", "nibble": "update_k"}[layout_name] + ("<fused>" if fused else ""),
-                "avg_launch_ms": round(avg_launch_ms, 5), "launches": launches, "half_sweeps_per_launch": half_sweeps_per_launch,
-                "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                "note": "achieved = the reference's 1.5 B/flip (4 bit/spin) accounting / launch time; the kernel is bound by the "
-                        "vector ALU (one Philox4x32-10 output per site), see alu_ceiling; its own HBM traffic is `traffic`"}
-        # HBM bytes per launch from the PMC passes of tools/profile.sh (separate runs; FETCH_SIZE / WRITE_SIZE per the guide)
-        prof = os.path.join(ROOT, "profiles", "traffic.json")
+        kernel = {"ballot": "ballot_update_k", "dense": "dense_update_k", "nibble": "update_k"}[layout_name] + ("<fused>" if fused else "")
+        # (a) the reference's accounting, SURVEY 8(d): 1.5 B per flip = source read + destination read + write at 4 bit/spin
+        alg_bytes_per_launch = BYTES_PER_FLIP * spins_per_gpu / 2.0 * half_sweeps_per_launch
+        hbm_ref = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+        hbm_reference = {"achieved": round(hbm_ref, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_ref / HBM_PEAK_GBS, 4),
+                         "bytes_per_flip": BYTES_PER_FLIP, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                         "what": "the reference's own accounting (optimized/main.cu:1887-1889): 1.5 B per flip at its 4 bit/spin, whatever the device stores"}
+        # (b) what the device really moves: HBM bytes per launch from the PMC passes of tools/profile.sh (separate runs; FETCH_SIZE /
+        # WRITE_SIZE per the guide), at this launch shape
+        hbm_real, traffic = None, None
         try:
-            tj = json.load(open(prof))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             if tj.get("x") == args.x and tj.get("y") == args.y and tj.get("device_layout") == layout_name and tj.get("fused", False) == fused:
-                per_half = tj["hbm_bytes_per_half_sweep"]
-                roof["traffic"] = per_half * half_sweeps_per_launch
+                traffic = tj["hbm_bytes_per_half_sweep"] * half_sweeps_per_launch
                 same = tj.get("half_sweeps_per_launch") == half_sweeps_per_launch
-                roof["traffic_source"] = tj.get("tag", "profiles/traffic.json") + (
-                    " (PMC passes of an earlier run of this launch shape, not this run)" if same else
-                    f" (PMC passes of an earlier run with {tj.get('half_sweeps_per_launch')} colour half-sweeps per launch, scaled per half-sweep)")
-                roof["hbm_real_GBs"] = round(roof["traffic"] / (avg_launch_ms * 1e-3) / 1e9, 1)
-                roof["device_algorithmic_bytes_per_launch"] = tj.get("device_bytes_algorithmic_per_half_sweep", 0) * half_sweeps_per_launch
+                real = traffic / (avg_launch_ms * 1e-3) / 1e9
+                hbm_real = {"achieved": round(real, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(real / HBM_PEAK_GBS, 4),
+                            "traffic_bytes_per_launch": traffic,
+                            "device_algorithmic_bytes_per_launch": tj.get("device_bytes_algorithmic_per_half_sweep", 0) * half_sweeps_per_launch,
+                            "source": tj.get("tag", "profiles/traffic.json") + (
+                                " (PMC passes of an earlier run of this launch shape, not this run)" if same else
+                                f" (PMC passes of an earlier run with {tj.get('half_sweeps_per_launch')} colour half-sweeps per launch, scaled per half-sweep)")}
         except (OSError, ValueError, KeyError):
             pass
+        # (c) the roof that binds: the vector ALU.  One 32-bit Philox4x32-10 output per site is forced by bit-exact parity; a kernel that
+        # only draws (same job, same chip, same clocks) is the ceiling.
+        sites_per_launch = spins_per_gpu / 2.0 * half_sweeps_per_launch
+        kern_rate = sites_per_launch / (avg_launch_ms * 1e6)  # sites/ns per GPU inside the kernel
+        ceil, ceil_err = None, None
         if not args.no_alu_probe:
             try:
                 ceil = ig.philox_ceiling(local_rank)
-                roof["alu_ceiling"] = {"value": round(ceil, 1), "unit": "sites/ns per GPU",
-                                       "what": "draw-only kernel (Philox4x32-10, one output per site), same job",
-                                       "frac": round(value / world / ceil, 4)}
             except ig.IsingError as e:
-                roof["alu_ceiling"] = {"error": str(e)}
+                ceil_err = str(e)
+        if ceil:
+            roof = {"bound": "valu", "achieved": round(kern_rate, 1), "peak": round(ceil, 1), "unit": "sites/ns", "frac": round(kern_rate / ceil, 4),
+                    "frac_of_value": round(value / world / ceil, 4),
+                    "peak_what": "draw-only kernel measured in this job (ising_philox_ceiling: Philox4x32-10, one 32-bit output per site exactly as the "
+                                 "update kernels draw them, no accept test, no lattice, no memory traffic)",
+                    "note": "the kernel is bound by the vector ALU, not by HBM (SQ_ACTIVE_INST_VALU x waves per SIMD ~ 1, real HBM use under a fifth "
+                            "of peak): `frac` is the fraction of the roof that binds; the HBM figures -- SURVEY 8(d)'s 1.5 B/flip accounting and the "
+                            "device's real traffic -- are the siblings hbm_reference_accounting and hbm_real"}
+        else:  # (no ALU probe: the contract's HBM form)
+            roof = {"bound": "hbm", "achieved": hbm_reference["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_reference["frac"]}
+            if ceil_err:
+                roof["alu_probe_error"] = ceil_err
+        roof.update({"traffic": traffic, "kernel": kernel, "avg_launch_ms": round(avg_launch_ms, 5), "launches": launches,
+                     "half_sweeps_per_launch": half_sweeps_per_launch, "sites_per_launch": sites_per_launch,
+                     "hbm_reference_accounting": hbm_reference, "hbm_real": hbm_real})
         line = {
             "metric": "spin-flips/ns (whole node) at T=Tc", "value": round(value, 2), "unit": "flips/ns",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt * 1e3 / args.steps, 5), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt * 1e3 / args.steps, 5), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"{args.y * world}x{args.x} lattice ({args.y}x{args.x} per GPU), T=Tc, seed {args.seed}, "
+            "config": {"workload": f"{args.workload}: {args.y * world}x{args.x} lattice ({args.y}x{args.x} per GPU), T=Tc, seed {args.seed}, "
                                    "Philox4x32-10 per site; device layout " + layout_text
-                                   + ", results identical to the reference's packed state", "x": args.x, "y_per_gpu": args.y,
+                                   + ", results identical to the reference's packed state", "x": args.x, "y_per_gpu": args.y, "y_total": args.y * world,
                        "parallelism": f"slab{world}", "nranks": world, "physical_gpus": min(world, ndev), "exchange": ring_name, "strip_rows": slab.strip_rows,
                        "device_layout": layout_name, "sweeps_per_call": batch, "warmup_sweeps_per_call": batch_warm, "preheat_ms": args.preheat_ms, "preheat_sweeps": preheat_sweeps,
                        "up": up, "down": down, "rank_up": rank_up, "parity_checked": parity,
-                       "parity_source": None if gold is None else "tests/golden (CPU oracle, same seed, same number of sweeps)"},
+                       "parity_source": None if gold is None else "tests/golden (CPU oracle on the whole lattice, same seed, same number of sweeps; any decomposition)"},
             "roofline": roof,
         }
+        if counts_leg is not None:
+            line["with_counts_every_16"] = counts_leg
+        if xstats is not None:
+            line["exchange_stats"] = xstats
         if shared:  # more ranks than devices: `value` is what the physical GPUs delivered together, not a scaling point
             line["config"]["note"] = (f"{world} ranks share {ndev} physical GPU(s): the N > 1 path (processes, peer transport, ring schedule) executed and "
                                       "checked, not a scaling measurement")
@@ -396,6 +513,8 @@ def main():
         dist.destroy_process_group()
     if parity is False:
         raise SystemExit(f"bench: counts {(up, down)} differ from the oracle's {gold}")
+    if counts_leg is not None and not counts_leg["final_counts_equal_first_leg"]:
+        raise SystemExit("bench: the leg with counts every 16 sweeps ended on other counts than the first leg")
 
 
 if __name__ == "__main__":

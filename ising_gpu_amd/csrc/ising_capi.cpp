@@ -1,6 +1,8 @@
-// ising_capi.cpp -- the C-ABI of libising_hip.so (see include/ising_hip.h for the reference file:line each
-// entry point replaces).  Host side only: owns device memory, tables and launch order; all arithmetic on the
-// lattice happens in ising_kernels.hip.
+// ising_capi.cpp -- the C-ABI of libising_hip.so (see include/ising_hip.h for the reference file:line each entry point
+// replaces): the context -- creation, the launch-shape policy, tables, streams, initialisation.  The update calls are in
+// ising_update.cpp, the observables in ising_observe.cpp, the -J coupling arrays in ising_couplings.cpp, boundary formats and
+// checkpoints in ising_io.cpp, the slab ring in ising_ring.cpp / ising_ipc.cpp, batches in ising_batch.cpp.  Host side only:
+// owns device memory, tables and launch order; all arithmetic on the lattice happens in the .hip files.
 #include "ising_ctx.hpp"
 
 #include <algorithm>
@@ -99,10 +101,12 @@ using ising_host::SLOTCTL_TICKET_BYTES;
 // cuRAND's curand_uniform on the host: x*2^-32 + 2^-33 in FP32 (product exact, one rounding).
 inline float u01(uint32_t x) { return (float)x * 0x1p-32f + 0x1p-33f; }
 
+} // namespace
+
 // Number of 32-bit draws x for which curand_uniform(x) <= p (le) or < p (!le).  curand_uniform is monotone
 // non-decreasing in x, so the accepted draws form a prefix [0, N) and N is found by bisection over the exact
 // FP32 formula.  NaN p accepts nothing, exactly like the FP32 comparison it replaces.
-uint64_t draw_prefix(float p, bool le) {
+uint64_t ising_host::draw_prefix(float p, bool le) {
 	auto ok = [&](uint32_t x) { const float u = u01(x); return le ? (u <= p) : (u < p); };
 	if (!ok(0u)) return 0;
 	if (ok(0xFFFFFFFFu)) return 1ull << 32;
@@ -114,79 +118,6 @@ uint64_t draw_prefix(float p, bool le) {
 	return hi;
 }
 
-} // namespace
-
-// ballot layout: the dense-order image is allocated by the first call that needs one
-int ising_host::ballot_tmp(ising_ctx *c) {
-	if (!c->d_tmp) HIP_TRY(hipMalloc((void **)&c->d_tmp, c->tmp_words() * sizeof(uint64_t)));
-	return ISING_OK;
-}
-
-void ising_host::ballot_tmp_release(ising_ctx *c) {
-	if (!c->d_tmp) return;
-	(void)hipStreamSynchronize(c->stream);
-	(void)hipFree(c->d_tmp);
-	c->d_tmp = nullptr;
-}
-
-// The observables read the ballot words as they are where the geometry is the plain one (no sub-lattices): no dense-order
-// image, no second copy of the slab -- a slab that fills the device can still be measured.
-bool ising_host::ballot_native_observables(const ising_ctx *c) { return c->ballot && !c->cfg.XSL; }
-
-int ising_host::ballot_measure_into_acc(ising_ctx *c) {
-	// (each on its own: a slab that nearly fills the device may get the first allocation and not the second)
-	if (!c->d_self) HIP_TRY(hipMalloc((void **)&c->d_self, sizeof(ising::ReplicaParams)));
-	if (!c->d_mslots) {
-		HIP_TRY(hipMalloc((void **)&c->d_mslots, (size_t)ising::BALLOT_MEASURE_SLOTS * 8 * sizeof(unsigned long long)));
-		HIP_TRY(hipMemsetAsync(c->d_mslots, 0, (size_t)ising::BALLOT_MEASURE_SLOTS * 8 * sizeof(unsigned long long), c->stream));
-	}
-	if (c->self_lat[0] != c->lat(ISING_BLACK) || c->self_lat[1] != c->lat(ISING_WHITE)) {
-		ising::ReplicaParams r{};
-		r.lat[0] = c->lat(ISING_BLACK);
-		r.lat[1] = c->lat(ISING_WHITE);
-		HIP_TRY(hipMemcpyAsync(c->d_self, &r, sizeof(r), hipMemcpyHostToDevice, c->stream));
-		HIP_TRY(hipStreamSynchronize(c->stream)); // (`r` is on the stack; once per slab)
-		c->self_lat[0] = r.lat[0];
-		c->self_lat[1] = r.lat[1];
-	}
-	HIP_TRY(ising::launch_ballot_measure(c->d_self, 1, c->gx, c->cfg.Y, c->d_mslots, c->stream));
-	HIP_TRY(ising::launch_measure_fold(c->d_mslots, c->d_acc, c->stream));
-	return ISING_OK;
-}
-
-// ballot layout: convert rows [row_lo, row_hi) of `color` (rows -1 and Y are the halo rows) between d_lat and d_tmp
-int ising_host::ballot_rows(ising_ctx *c, int color, long long row_lo, long long row_hi, bool to_dense) {
-	if (int rc = ballot_tmp(c)) return rc;
-	uint64_t *lat = c->lat(color) + row_lo * c->lld, *tmp = c->tmp(color) + row_lo * c->lld_dense;
-	if (to_dense) HIP_TRY(ising::launch_ballot_to_dense(lat, reinterpret_cast<uint32_t *>(tmp), c->gx, row_hi - row_lo, c->stream));
-	else HIP_TRY(ising::launch_dense_to_ballot(reinterpret_cast<const uint32_t *>(tmp), lat, c->gx, row_hi - row_lo, c->stream));
-	return ISING_OK;
-}
-
-// ballot layout: refresh the dense-order image (both colours, halo rows included)
-int ising_host::ballot_image(ising_ctx *c) {
-	for (int color = 0; color < 2; color++)
-		if (int rc = ballot_rows(c, color, -1, (long long)c->cfg.Y + 1, true)) return rc;
-	return ISING_OK;
-}
-
-// ballot -> dense for good (a temperature without integer thresholds was requested): the slab keeps its buffer
-int ising_host::ballot_leave(ising_ctx *c) {
-	if (!c->ballot) return ISING_OK;
-	if (int rc = ising_host::ballot_image(c)) return rc;
-	// the dense-order image becomes the slab (same buffer; when X is not a multiple of 8192 the rows get shorter and the
-	// colour arrays move up: pointers handed out by ising_halo_ptrs / ising_device_ptr before are void)
-	HIP_TRY(hipMemcpyAsync(c->d_lat, c->d_tmp, c->tmp_words() * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
-	c->lld = c->lld_dense;
-	c->color_words = (size_t)c->cfg.Y * c->lld;
-	if (c->ham_form == 2) {
-		for (int w = 0; w < 2; w++) HIP_TRY(ising::launch_ham_ballot_to_planes(c->ham(w), c->gx, c->cfg.Y, c->stream));
-		c->ham_form = 1;
-	}
-	c->ballot = false;
-	ising_host::ballot_tmp_release(c);
-	return ISING_OK;
-}
 
 bool ising_host::needs_generic(const ising_ctx *c) {
 	return c->cfg.kernel == ISING_KERNEL_GENERIC || (c->cfg.kernel == ISING_KERNEL_AUTO && !c->fast_ok);
@@ -208,8 +139,8 @@ void compute_tables(ising_ctx *c, float temp) {
 	}
 	bool symmetric = true;
 	for (int a = 0; a < 5; a++) {
-		const uint64_t up = draw_prefix(c->tab[5 + a], true);       // spin up, n = a neighbours up
-		const uint64_t dn = draw_prefix(c->tab[0 + (4 - a)], true); // spin down, 4-a neighbours up
+		const uint64_t up = ising_host::draw_prefix(c->tab[5 + a], true);       // spin up, n = a neighbours up
+		const uint64_t dn = ising_host::draw_prefix(c->tab[0 + (4 - a)], true); // spin down, 4-a neighbours up
 		c->thr[a] = up;
 		if (up != dn) symmetric = false;
 	}
@@ -217,42 +148,6 @@ void compute_tables(ising_ctx *c, float temp) {
 	c->fast_ok = symmetric && c->thr[0] == always && c->thr[1] == always && c->thr[2] == always &&
 	             c->thr[3] < always && c->thr[4] <= c->thr[3];
 	c->cfg.temp = temp;
-}
-
-// Inverse of ham_planes_k (ising_dense.hip), in place: four coupling bit-planes per vector -> 32 nibbles.
-void planes_to_nibbles(uint64_t *vecs, size_t nvec) {
-	for (size_t v = 0; v < nvec; v++) {
-		uint32_t pl[4];
-		memcpy(pl, vecs + 2 * v, sizeof(pl));
-		uint64_t w[2] = {0, 0};
-		for (int s = 0; s < 32; s++) {
-			const uint64_t nib = ((pl[0] >> s) & 1u) | (((pl[1] >> s) & 1u) << 1) | (((pl[2] >> s) & 1u) << 2) | (((pl[3] >> s) & 1u) << 3);
-			w[s >> 4] |= nib << (4 * (s & 15));
-		}
-		vecs[2 * v] = w[0];
-		vecs[2 * v + 1] = w[1];
-	}
-}
-
-// Host mirror of ham_ballot_to_planes_k (ising_ballot.hip), in place: groups of 4 planes x 64 ballot-order words ->
-// 128 vectors of four 32-bit planes.
-void ballot_planes_to_planes(uint64_t *ham, size_t ngroups) {
-	std::vector<uint64_t> in(256);
-	for (size_t g = 0; g < ngroups; g++) {
-		uint64_t *grp = ham + g * 256;
-		memcpy(in.data(), grp, 256 * sizeof(uint64_t));
-		uint32_t *out = reinterpret_cast<uint32_t *>(grp);
-		for (int v = 0; v < 128; v++) {
-			const int l = ((v >> 5) << 4) | (v & 15), j = (v >> 4) & 1;
-			uint32_t pw[4] = {0, 0, 0, 0};
-			for (int s = 0; s < 32; s++) {
-				const int m = (s & 15) >> 1, q = ((s & 1) << 1) | (s >> 4);
-				const int p = 32 * j + 4 * m + q;
-				for (int pl = 0; pl < 4; pl++) pw[pl] |= (uint32_t)((in[64 * pl + p] >> l) & 1ull) << s;
-			}
-			memcpy(out + 4 * v, pw, sizeof(pw));
-		}
-	}
 }
 
 // Fused launches: T = tickets (workgroups) per level for strips of H rows; and the launch shape ising_create picks.
@@ -665,7 +560,7 @@ int ising_init_lattice(ising_ctx *c) {
 	if (!c) return fail(ISING_E_ARG, "null context");
 	if (int rc = bind(c)) return rc;
 	c->ghost_depth[0] = c->ghost_depth[1] = 0;
-	const uint64_t half = draw_prefix(0.5f, false); // curand_uniform(x) < 0.5f, optimized/main.cu:133
+	const uint64_t half = ising_host::draw_prefix(0.5f, false); // curand_uniform(x) < 0.5f, optimized/main.cu:133
 	for (int color = 0; color < 2; color++) {
 		ising::InitParams p{};
 		p.dst = c->lat(color);
@@ -699,558 +594,6 @@ int ising_strip_info(ising_ctx *c, int *strip_rows, int *nstrips) {
 	if (!c) return fail(ISING_E_ARG, "null context");
 	if (strip_rows) *strip_rows = c->H;
 	if (nstrips) *nstrips = c->nstrips;
-	return ISING_OK;
-}
-
-// launches update_k over up to two row ranges
-// `nlevels` > 1 (ballot layout only): one fused launch of that many colour half-sweeps over the whole slab, starting with
-// `color` at iteration `it`
-// `stop` (optional): an event that fires when the launch is done
-static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int lo1, int hi1, int nlevels = 1, hipEvent_t stop = nullptr) {
-	// one-shot requests of the ring schedules for THIS launch (taken here, so that an early return cannot leave them set)
-	const bool edge_scratch = c->edge_scratch_next;
-	const bool overlap = c->overlap_next;
-	hipEvent_t start = c->launch_start_next;
-	if (!stop) stop = c->launch_stop_next;
-	c->edge_scratch_next = false;
-	c->overlap_next = false;
-	c->launch_start_next = c->launch_stop_next = nullptr;
-	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
-	if (it < 0) return fail(ISING_E_ARG, "negative iteration %d", it);
-	int mode = c->cfg.kernel == ISING_KERNEL_GENERIC ? 1 : 0; // AUTO, FAST -> 0
-	if (mode != 1 && !c->fast_ok) {
-		if (c->cfg.kernel != ISING_KERNEL_AUTO) return fail(ISING_E_STATE, "temperature %g does not admit the integer-threshold kernels", (double)c->cfg.temp);
-		mode = 1;
-	}
-	if (int rc = bind(c)) return rc;
-	if (c->ballot && mode == 1) if (int rc = ising_host::ballot_leave(c)) return rc; // no integer thresholds at this temperature
-	c->ghost_depth[color] = 0; // (the neighbours' copies of this slab's rows are stale from here on -- and theirs here, by symmetry)
-	if (nlevels > 1) c->ghost_depth[1 - color] = 0;
-	const int other = 1 - color;
-	ising::UpdateParams p{};
-	p.dst = c->lat(color);
-	p.src = c->lat(other);
-	// periodic wrap of loadTile (optimized/main.cu:414,:422) through mirrored halo rows: the launch that writes an edge row
-	// also writes its mirror -- this slab's own halo rows, or (ring on one device, ising_ring.cpp) the neighbours'
-	const size_t rowb = (size_t)c->lld * sizeof(uint64_t);
-	if (c->wrap) {
-		p.wrap = 1;
-		p.mir0_bytes = (long long)c->cfg.Y * (long long)rowb;
-		p.mirL_bytes = -(long long)c->cfg.Y * (long long)rowb;
-	} else if (c->store_ring && c->ring_prev && c->ring_next && !c->cfg.XSL) {
-		const char *row0 = reinterpret_cast<const char *>(c->lat(color)), *rowL = row0 + (size_t)(c->cfg.Y - 1) * rowb;
-		p.wrap = 1;
-		p.mir0_bytes = reinterpret_cast<const char *>(c->ring_prev->lat(color) + c->ring_prev->color_words) - row0;
-		p.mirL_bytes = reinterpret_cast<const char *>(c->ring_next->lat(color)) - (long long)rowb - rowL;
-	}
-	p.seed_lo = (uint32_t)c->cfg.seed;
-	p.seed_hi = (uint32_t)(c->cfg.seed >> 32);
-	p.it = (uint32_t)it;
-	p.color = (uint32_t)color;
-	p.gx = c->gx;
-	p.Y = c->cfg.Y;
-	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
-	p.slV = c->cfg.XSL ? c->cfg.XSL / 64 : c->gx * 32; // (XSL/2)/SPIN_X_WORD/2, optimized/main.cu:1771
-	p.slY = c->cfg.XSL ? c->cfg.YSL : 0;
-	p.H = c->H;
-	p.row_lo[0] = lo0; p.row_hi[0] = hi0;
-	p.row_lo[1] = lo1; p.row_hi[1] = hi1;
-	const int ugx = c->ballot ? 4 * c->nwc() : c->gx; // column groups per strip as the kernel counts them (ballot: 4 per wave column)
-	// tail strips (ballot layout, plain full-slab launch): the last rows of the slab in strips of H2 rows
-	int H2 = 0;
-	if (c->ballot && nlevels == 1 && c->tail_rows > 0 && hi1 == lo1 && hi0 - lo0 >= 4 * c->tail_rows) {
-		H2 = c->tail_h;
-		lo1 = hi0 - c->tail_rows;
-		hi1 = hi0;
-		hi0 = lo1;
-		p.row_hi[0] = hi0; p.row_lo[1] = lo1; p.row_hi[1] = hi1;
-	}
-	p.H2 = H2;
-	p.nreal0 = ugx * ((hi0 - lo0 + c->H - 1) / c->H);
-	p.nunits0 = (c->ballot && H2) ? (p.nreal0 + 15) / 16 * 16 : p.nreal0;
-	p.nunits = p.nunits0 + ugx * ((hi1 - lo1 + (H2 ? H2 : c->H) - 1) / (H2 ? H2 : c->H));
-	p.n3 = (uint32_t)c->thr[3];
-	p.n4 = (uint32_t)c->thr[4];
-	memcpy(p.tab, c->tab, sizeof(p.tab));
-	// the reference hands hamW to the BLACK update and hamB to the WHITE one (optimized/main.cu:1774, :1795)
-	p.jdst = c->cfg.use_J ? c->ham(other) : nullptr;
-	p.scratch = (edge_scratch && c->d_scratch_edge) ? c->d_scratch_edge : c->d_scratch;
-	if (c->ballot) {
-		p.ticket = reinterpret_cast<unsigned long long *>(c->d_slotctl);
-		p.nlevels = nlevels;
-		p.cus = c->cus;
-		if (nlevels > 1) {
-			p.grid_cap = c->pol.fused_wgs;
-			p.abort_flag = c->h_abort;
-			p.abort_polls = c->pol.abort_polls;
-			for (int k = 0; k < 4; k++) p.ticket_base2[k] = c->ticket_base2[k]; // (the counters are never reset, ising_ballot.hip)
-			p.tickets2 = c->fused_tickets2;
-			if (c->done_base > (1u << 30)) { // keep the monotone completion counters far from wrapping
-				HIP_TRY(hipMemsetAsync(c->d_slotctl + SLOTCTL_TICKET_BYTES / 4, 0, ((size_t)c->nstrips + 2 * (size_t)c->ghost_rows + 2) * sizeof(uint32_t), c->stream));
-				c->done_base = 0;
-			}
-			p.lat[0] = c->lat(ISING_BLACK);
-			p.lat[1] = c->lat(ISING_WHITE);
-			p.jham[0] = c->cfg.use_J ? c->ham(1) : nullptr;
-			p.jham[1] = c->cfg.use_J ? c->ham(0) : nullptr;
-			p.done = c->d_slotctl + SLOTCTL_TICKET_BYTES / 4;
-			p.wg_per_cu = c->fused_wg_per_cu;
-			p.nt_stream = c->fused_nt;
-			p.done_base = c->done_base;
-			if (lo0 < 0 || hi0 > c->cfg.Y) { // ghost rows are rows of the neighbouring slabs
-				p.total_rows = c->cfg.nslabs * c->cfg.Y;
-				p.trapezoid = c->pol.trapezoid ? 1 : 0;
-				if (overlap && c->d_edge) {
-					// the exchange touches the first / last G rows (read by the sends) and the ghost rows (written by the receives)
-					const int G = c->ghost();
-					p.edge_lo = G;
-					p.edge_hi = c->cfg.Y - G;
-					p.edge_go = c->d_edge + 16;
-					p.edge_go_need = c->edge_go_epoch;
-					p.edge_done = c->d_edge;
-					unsigned strips = 0; // strips of this launch that touch such a row
-					for (int r0 = lo0; r0 < hi0; r0 += c->H) if (r0 < p.edge_lo || std::min(r0 + c->H, hi0) > p.edge_hi) strips++;
-					c->edge_done_target += strips * (uint32_t)c->nwc();
-				}
-			}
-		}
-		int grid = 0;
-		if (const hipError_t le = ising::launch_ballot_update(p, c->stream, &grid, stop, start); le != hipSuccess) {
-			// nothing ran: tickets and counters are where the launches before left them, but to be safe they start over
-			if (nlevels > 1) { __atomic_store_n(c->h_abort, 1u, __ATOMIC_RELEASE); (void)ising_host::check_abort(c); }
-			return fail(ISING_E_HIP, "kernel launch failed: %s", hipGetErrorString(le));
-		}
-		if (nlevels > 1) {
-			c->done_base += (uint32_t)nlevels * (uint32_t)c->nwc();
-			// where the launch leaves the counter(s): its units, and every workgroup drew one ticket too many
-			const unsigned long long total = (unsigned long long)p.nwg * (unsigned long long)nlevels;
-			if (p.tickets2 > 1) { // units and workgroups of class k = those numbered k mod K
-				const unsigned long long K = (unsigned long long)p.tickets2;
-				for (unsigned long long k = 0; k < K; k++) c->ticket_base2[k] += (total + K - 1 - k) / K + ((unsigned long long)grid + K - 1 - k) / K;
-			} else {
-				c->ticket_base2[0] += total + (unsigned long long)grid;
-			}
-		}
-		return ISING_OK;
-	}
-	if (c->dense) HIP_TRY(ising::launch_dense_update(p, mode, c->stream));
-	else HIP_TRY(ising::launch_update(p, mode, c->stream));
-	if (stop) HIP_TRY(hipEventRecord(stop, c->stream)); // (the other layouts' launchers take no event: a packet of its own)
-	return ISING_OK;
-}
-
-int ising_update_color(ising_ctx *c, int it, int color, int row_lo, int row_hi) {
-	if (!c) return fail(ISING_E_ARG, "null context");
-	if (row_lo < 0 || row_hi > c->cfg.Y || row_lo > row_hi) return fail(ISING_E_ARG, "bad row range [%d,%d) of %d", row_lo, row_hi, c->cfg.Y);
-	return launch_ranges(c, it, color, row_lo, row_hi, 0, 0);
-}
-
-int ising_update_edges(ising_ctx *c, int it, int color) {
-	if (!c) return fail(ISING_E_ARG, "null context");
-	return launch_ranges(c, it, color, 0, 1, c->cfg.Y - 1, c->cfg.Y);
-}
-
-} // extern "C"
-
-int ising_host::update_edges_on(ising_ctx *c, int it, int color, hipStream_t s, hipEvent_t stop) {
-	hipStream_t keep = c->stream; // (a context is driven by one host thread)
-	c->stream = s;
-	c->edge_scratch_next = s != keep; // on another stream than the slab's own: it may run next to an interior launch
-	const int rc = launch_ranges(c, it, color, 0, 1, c->cfg.Y - 1, c->cfg.Y, 1, stop);
-	c->stream = keep;
-	return rc;
-}
-
-int ising_host::update_interior(ising_ctx *c, int it, int color, hipEvent_t stop) {
-	return launch_ranges(c, it, color, 1, c->cfg.Y - 1, 0, 0, 1, stop);
-}
-
-// true when the ring sweeps this slab through its ghost rows right now (ising_ring.cpp: sweep_local takes the same decision)
-static bool ghost_sweeps(const ising_ctx *c) {
-	return !c->wrap && c->ballot && c->ghost() > 1 && !c->store_ring && !c->cfg.XSL && !ising_host::needs_generic(c);
-}
-
-// Ring slab with G > 1 ghost rows: `nlevels` colour half-sweeps (black first) in one fused launch over rows
-// [-(G-1), Y+G-1).  The ghost rows are updated like the slab's own -- their draws are the ones the neighbours make --, and
-// what is not valid in them any more (one row per level and side) never reaches a row that is.
-int ising_host::update_deep(ising_ctx *c, int it, int nlevels, bool overlapped) {
-	const int G = c->ghost();
-	if (G < 2 || nlevels > G || nlevels < 2 || c->store_ring) return fail(ISING_E_STATE, "deep launch of %d levels on a slab with %d ghost rows", nlevels, G);
-	c->overlap_next = overlapped;
-	return launch_ranges(c, it, ISING_BLACK, -(G - 1), c->cfg.Y + G - 1, 0, 0, nlevels);
-}
-
-// fused launches carry this slab's sweeps (ballot layout, integer thresholds; with sub-lattices: strips inside the blocks, no couplings)
-static bool sweeps_fused(const ising_ctx *c) {
-	if (!c->ballot || !c->fused || ising_host::needs_generic(c)) return false;
-	if (c->cfg.XSL) return !c->cfg.use_J && (c->cfg.YSL % c->H) == 0;
-	return c->wrap;
-}
-
-extern "C" int ising_sweep(ising_ctx *c, int first_it, int nsweeps) {
-	if (!c) return fail(ISING_E_ARG, "null context");
-	if (!c->wrap) return fail(ISING_E_STATE, "ising_sweep needs a single slab without ring halo rows; drive slabs with ising_ring_sweep / ising_rank_sweep or ising_update_color + halo exchange");
-	return ising_host::sweep_alone(c, first_it, nsweeps);
-}
-
-// `nsweeps` sweeps of a slab that needs nothing from its neighbours: a single slab that wraps in place, or a slab of
-// sub-lattices (also one of several: nothing crosses slabs, optimized/main.cu:1423-1462)
-int ising_host::sweep_alone(ising_ctx *c, int first_it, int nsweeps) {
-	// ballot layout: many sweeps per fused launch (32 at 65536^2, more on smaller lattices) -- the chip does not drain between colours
-	if (sweeps_fused(c)) {
-		const int per_launch = ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y);
-		for (int it = first_it, left = nsweeps; left > 0;) {
-			const int ns = std::min(left, per_launch);
-			if (int rc = launch_ranges(c, it, ISING_BLACK, 0, c->cfg.Y, 0, 0, 2 * ns)) return rc;
-			it += ns;
-			left -= ns;
-		}
-		return ISING_OK;
-	}
-	for (int it = first_it; it < first_it + nsweeps; it++) {
-		if (int rc = ising_update_color(c, it, ISING_BLACK, 0, c->cfg.Y)) return rc;
-		if (int rc = ising_update_color(c, it, ISING_WHITE, 0, c->cfg.Y)) return rc;
-	}
-	return ISING_OK;
-}
-
-extern "C" {
-
-int ising_sweep_info(ising_ctx *c, int *fused, int *max_sweeps_per_launch) {
-	if (!c) return fail(ISING_E_ARG, "null context");
-	const bool f = (c->wrap || c->cfg.XSL) && sweeps_fused(c);
-	// (a ring slab with ghost rows G deep: the ring's sweeps are fused launches of G/2 sweeps between two exchanges)
-	const bool deep = ghost_sweeps(c);
-	if (fused) *fused = (f || deep) ? 1 : 0;
-	if (max_sweeps_per_launch) *max_sweeps_per_launch = f ? ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y) : (deep ? c->ghost() / 2 : 0);
-	return ISING_OK;
-}
-
-int ising_sweep_timed(ising_ctx *c, int first_it, int nsweeps, float *elapsed_ms) {
-	if (!c || !elapsed_ms) return fail(ISING_E_ARG, "null argument");
-	if (int rc = bind(c)) return rc;
-	hipEvent_t e0 = nullptr, e1 = nullptr;
-	hipError_t e = hipEventCreate(&e0);
-	if (e == hipSuccess) e = hipEventCreate(&e1);
-	if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
-	int rc = e == hipSuccess ? ising_sweep(c, first_it, nsweeps) : fail(ISING_E_HIP, "event timing failed: %s", hipGetErrorString(e));
-	if (rc == ISING_OK) {
-		e = hipEventRecord(e1, c->stream);
-		if (e == hipSuccess) e = hipEventSynchronize(e1);
-		if (e == hipSuccess) e = hipEventElapsedTime(elapsed_ms, e0, e1);
-		if (e != hipSuccess) rc = fail(ISING_E_HIP, "event timing failed: %s", hipGetErrorString(e));
-		else rc = ising_host::check_abort(c);
-	}
-	if (e0) (void)hipEventDestroy(e0);
-	if (e1) (void)hipEventDestroy(e1);
-	return rc;
-}
-
-int ising_halo_ptrs(ising_ctx *c, int color, void **send_top, void **send_bot, void **recv_top, void **recv_bot, size_t *row_bytes) {
-	if (!c) return fail(ISING_E_ARG, "null context");
-	if (color != ISING_BLACK && color != ISING_WHITE && color != ISING_HAM_BLACK) return fail(ISING_E_ARG, "bad colour %d", color);
-	if (color == ISING_HAM_BLACK && !c->cfg.use_J) return fail(ISING_E_STATE, "couplings are not enabled (use_J)");
-	if (c->wrap) return fail(ISING_E_STATE, "no halo buffers with nslabs == 1 (rows wrap inside the slab)");
-	uint64_t *base = c->plane(color);
-	const size_t ld = (size_t)c->plane_ld(color);
-	if (send_top) *send_top = base;
-	if (send_bot) *send_bot = base + (size_t)(c->cfg.Y - 1) * ld;
-	if (recv_top) *recv_top = base - ld;
-	if (recv_bot) *recv_bot = base + (size_t)c->cfg.Y * ld;
-	if (row_bytes) *row_bytes = ld * sizeof(uint64_t);
-	return ISING_OK;
-}
-
-int ising_ghost_ptrs(ising_ctx *c, int color, int *depth, void **send_top, void **send_bot, void **recv_top, void **recv_bot, size_t *block_bytes) {
-	if (!c) return fail(ISING_E_ARG, "null context");
-	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
-	if (c->wrap) return fail(ISING_E_STATE, "no halo buffers with nslabs == 1 (rows wrap inside the slab)");
-	const size_t ld = (size_t)c->lld, G = ghost_sweeps(c) ? (size_t)c->ghost() : 1;
-	uint64_t *base = c->lat(color);
-	if (depth) *depth = (int)G;
-	if (send_top) *send_top = base;
-	if (send_bot) *send_bot = base + ((size_t)c->cfg.Y - G) * ld;
-	if (recv_top) *recv_top = base - G * ld;
-	if (recv_bot) *recv_bot = base + (size_t)c->cfg.Y * ld;
-	if (block_bytes) *block_bytes = G * ld * sizeof(uint64_t);
-	return ISING_OK;
-}
-
-int ising_ghost_delivered(ising_ctx *c, int color) {
-	if (!c) return fail(ISING_E_ARG, "null context");
-	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
-	if (c->wrap) return fail(ISING_E_STATE, "no halo buffers with nslabs == 1 (rows wrap inside the slab)");
-	c->ghost_depth[color] = ghost_sweeps(c) ? c->ghost() : 1;
-	return ISING_OK;
-}
-
-int ising_sweep_ghost(ising_ctx *c, int first_it, int nsweeps) {
-	if (!c) return fail(ISING_E_ARG, "null context");
-	if (!ghost_sweeps(c)) return fail(ISING_E_STATE, "the slab does not sweep through ghost rows (ising_ghost_ptrs: depth 1); use ising_update_edges / ising_update_color");
-	const int G = c->ghost();
-	if (nsweeps < 1 || 2 * nsweeps > G) return fail(ISING_E_ARG, "%d sweeps on ghost rows %d deep (at most %d per exchange)", nsweeps, G, G / 2);
-	if (c->ghost_depth[0] < G || c->ghost_depth[1] < G)
-		return fail(ISING_E_STATE, "the ghost rows are not current: deliver both colours (ising_ghost_ptrs, ising_ghost_delivered) after whatever changed the spins");
-	for (int color = 0; color < 2; color++) if (int rc = ising_host::halo_ready(c, color)) return rc; // (a no-op unless the library's own transport is attached too)
-	return ising_host::update_deep(c, first_it, 2 * nsweeps);
-}
-
-int ising_count(ising_ctx *c, uint64_t *up, uint64_t *down) {
-	if (!c || !up || !down) return fail(ISING_E_ARG, "null argument");
-	if (int rc = bind(c)) return rc;
-	HIP_TRY(hipMemsetAsync(c->d_acc, 0, 2 * sizeof(unsigned long long), c->stream));
-	HIP_TRY(ising::launch_popcount(c->lat(ISING_BLACK), c->color_words, c->d_acc, c->stream));
-	HIP_TRY(ising::launch_popcount(c->lat(ISING_WHITE), c->color_words, c->d_acc, c->stream));
-	unsigned long long h = 0;
-	HIP_TRY(hipMemcpyAsync(&h, c->d_acc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-	if (int rc = ising_host::sync_checked(c)) return rc;
-	*up = h;
-	*down = (uint64_t)c->cfg.X * (uint64_t)c->cfg.Y - h; // SPIN_X_WORD - popc per word, optimized/main.cu:722-723
-	return ISING_OK;
-}
-
-int ising_bond_equal(ising_ctx *c, int64_t *A) {
-	if (!c || !A) return fail(ISING_E_ARG, "null argument");
-	if (int rc = bind(c)) return rc;
-	if (int rc = ising_host::halo_ready(c, ISING_WHITE)) return rc; // black sites of rows 0 / Y-1 read the white halo rows
-	if (ising_host::ballot_native_observables(c)) {
-		if (int rc = ising_host::ballot_measure_into_acc(c)) return rc;
-		unsigned long long h2 = 0;
-		HIP_TRY(hipMemcpyAsync(&h2, c->d_acc + 1, sizeof(h2), hipMemcpyDeviceToHost, c->stream));
-		if (int rc = ising_host::sync_checked(c)) return rc;
-		*A = (int64_t)h2;
-		return ISING_OK;
-	}
-	if (c->ballot) if (int rc = ising_host::ballot_image(c)) return rc;
-	ising::BondParams p{};
-	p.black = c->ballot ? c->tmp(ISING_BLACK) : c->lat(ISING_BLACK);
-	p.white = c->ballot ? c->tmp(ISING_WHITE) : c->lat(ISING_WHITE);
-	p.gx = c->gx;
-	p.Y = c->cfg.Y;
-	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
-	p.slV = c->cfg.XSL ? c->cfg.XSL / 64 : c->gx * 32;
-	p.slY = c->cfg.XSL ? c->cfg.YSL : 0;
-	p.acc = c->d_acc + 1;
-	HIP_TRY(hipMemsetAsync(c->d_acc + 1, 0, sizeof(unsigned long long), c->stream));
-	HIP_TRY(c->dense ? ising::launch_dense_bond_equal(p, c->stream) : ising::launch_bond_equal(p, c->stream));
-	unsigned long long h = 0;
-	HIP_TRY(hipMemcpyAsync(&h, c->d_acc + 1, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-	if (int rc = ising_host::sync_checked(c)) return rc;
-	*A = (int64_t)h;
-	ising_host::ballot_tmp_release(c);
-	return ISING_OK;
-}
-
-// Asynchronous measurements: count + bond sum of the state the stream holds at this point, into a pinned host array the
-// context owns; nothing waits until ising_measure_fetch.  A series of (sweeps, measurement) pairs then runs without a
-// single host round trip in between (cuIsing --tsweep: 100 measurements per temperature point).
-int ising_measure_enqueue(ising_ctx *c) {
-	if (!c) return fail(ISING_E_ARG, "null context");
-	if (int rc = bind(c)) return rc;
-	if (!c->h_meas) HIP_TRY(hipHostMalloc((void **)&c->h_meas, (size_t)ising_ctx::MEAS_CAP * 2 * sizeof(unsigned long long), hipHostMallocDefault));
-	if (c->meas_pending >= ising_ctx::MEAS_CAP) return fail(ISING_E_STATE, "%d measurements pending: ising_measure_fetch first", c->meas_pending);
-	if (int rc = ising_host::halo_ready(c, ISING_WHITE)) return rc;
-	if (ising_host::ballot_native_observables(c)) { // two launches on the slab's own words
-		if (int rc = ising_host::ballot_measure_into_acc(c)) return rc;
-		HIP_TRY(hipMemcpyAsync(c->h_meas + 2 * (size_t)c->meas_pending, c->d_acc, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-		c->meas_pending++;
-		return ISING_OK;
-	}
-	HIP_TRY(hipMemsetAsync(c->d_acc, 0, 2 * sizeof(unsigned long long), c->stream));
-	HIP_TRY(ising::launch_popcount(c->lat(ISING_BLACK), c->color_words, c->d_acc, c->stream));
-	HIP_TRY(ising::launch_popcount(c->lat(ISING_WHITE), c->color_words, c->d_acc, c->stream));
-	if (c->ballot) if (int rc = ising_host::ballot_image(c)) return rc;
-	ising::BondParams p{};
-	p.black = c->ballot ? c->tmp(ISING_BLACK) : c->lat(ISING_BLACK);
-	p.white = c->ballot ? c->tmp(ISING_WHITE) : c->lat(ISING_WHITE);
-	p.gx = c->gx;
-	p.Y = c->cfg.Y;
-	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
-	p.slV = c->cfg.XSL ? c->cfg.XSL / 64 : c->gx * 32;
-	p.slY = c->cfg.XSL ? c->cfg.YSL : 0;
-	p.acc = c->d_acc + 1;
-	HIP_TRY(c->dense ? ising::launch_dense_bond_equal(p, c->stream) : ising::launch_bond_equal(p, c->stream));
-	HIP_TRY(hipMemcpyAsync(c->h_meas + 2 * (size_t)c->meas_pending, c->d_acc, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-	c->meas_pending++;
-	return ISING_OK;
-}
-
-int ising_measure_fetch(ising_ctx *c, uint64_t *up, int64_t *bond_equal, int max_n, int *n) {
-	if (!c || !up || !bond_equal || !n || max_n < 0) return fail(ISING_E_ARG, "bad argument");
-	if (int rc = bind(c)) return rc;
-	if (c->meas_pending > max_n) return fail(ISING_E_ARG, "%d measurements pending, room for %d", c->meas_pending, max_n);
-	if (int rc = ising_host::sync_checked(c)) { c->meas_pending = 0; return rc; }
-	for (int i = 0; i < c->meas_pending; i++) {
-		up[i] = c->h_meas[2 * i];
-		bond_equal[i] = (int64_t)c->h_meas[2 * i + 1];
-	}
-	*n = c->meas_pending;
-	c->meas_pending = 0;
-	return ISING_OK;
-}
-
-// Test aids (tests/test_gpu_fused.py).  what = 1 puts the host's idea of the completion counters out of step with the device,
-// as a faulted launch would leave it -- the next fused launch's units wait for counts that never come -- and lowers the
-// bound after which they give up to `arg` polls (0: keep).  what = 2 ages every monotone counter of the slab, device and
-// host record together, as billions of sweeps would: the completion counters stand past the point where the next launch
-// starts them over, the exchange's counters (units that have left the edge rows, epochs) a few counts before 2^32.
-int ising_debug_fault(ising_ctx *c, int what, int arg) {
-	if (!c) return fail(ISING_E_ARG, "null context");
-	if (what == 2) {
-		if (int rc = ising_synchronize(c)) return rc;
-		if (c->comm) HIP_TRY(hipStreamSynchronize(c->comm));
-		if (c->d_slotctl && c->slotctl_bytes > SLOTCTL_TICKET_BYTES) {
-			const uint32_t add = (1u << 30) + 12345u - c->done_base; // (counters of strips that lag a level keep their distance)
-			std::vector<uint32_t> h((c->slotctl_bytes - SLOTCTL_TICKET_BYTES) / 4);
-			HIP_TRY(hipMemcpy(h.data(), c->d_slotctl + SLOTCTL_TICKET_BYTES / 4, h.size() * 4, hipMemcpyDeviceToHost));
-			for (auto &v : h) v += add;
-			HIP_TRY(hipMemcpy(c->d_slotctl + SLOTCTL_TICKET_BYTES / 4, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-			c->done_base += add;
-		}
-		if (c->d_edge) {
-			uint32_t h[32];
-			HIP_TRY(hipMemcpy(h, c->d_edge, sizeof(h), hipMemcpyDeviceToHost));
-			const uint32_t add_done = 0xFFFFFFF0u - c->edge_done_target, add_go = 0xFFFFFFFDu - c->edge_go_epoch;
-			h[0] += add_done;
-			h[16] += add_go;
-			HIP_TRY(hipMemcpy(c->d_edge, h, sizeof(h), hipMemcpyHostToDevice));
-			c->edge_done_target += add_done;
-			c->edge_go_epoch += add_go;
-		}
-		return ISING_OK;
-	}
-	if (what != 1) return fail(ISING_E_ARG, "unknown fault %d", what);
-	c->done_base += 1u << 20;
-	if (arg > 0) c->pol.abort_polls = (uint32_t)arg;
-	return ISING_OK;
-}
-
-int ising_layout(ising_ctx *c, int *layout) {
-	if (!c || !layout) return fail(ISING_E_ARG, "null argument");
-	*layout = c->ballot ? ISING_LAYOUT_BALLOT : (c->dense ? ISING_LAYOUT_DENSE : ISING_LAYOUT_NIBBLE);
-	return ISING_OK;
-}
-
-int ising_device_ptr(ising_ctx *c, int color, void **ptr, size_t *bytes) {
-	if (!c || !ptr) return fail(ISING_E_ARG, "null argument");
-	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
-	*ptr = c->lat(color);
-	if (bytes) *bytes = c->color_words * sizeof(uint64_t);
-	return ISING_OK;
-}
-
-// ------------------------------------------------------------------------------------------------ couplings (-J)
-int ising_init_couplings_black(ising_ctx *c) {
-	if (!c) return fail(ISING_E_ARG, "null context");
-	if (!c->cfg.use_J) return fail(ISING_E_STATE, "couplings are not enabled (use_J)");
-	if (int rc = bind(c)) return rc;
-	const float prob = fminf(fmaxf(0.0f, c->cfg.J_prob), 1.0f);  // optimized/main.cu:1370
-	const uint64_t seed = c->cfg.seed + 1;                        // "just use a different seed", :1734
-	ising::HamInitParams p{};
-	p.hamB = c->ham(0);
-	p.seed_lo = (uint32_t)seed;
-	p.seed_hi = (uint32_t)(seed >> 32);
-	p.gx = c->gx;
-	p.Y = c->cfg.Y;
-	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
-	p.wrap = c->wrap;
-	if (c->ham_ghost > 1) { // ring slab with ghost rows: rows [-hg, Y + hg), each with the draws of its global row
-		const uint32_t total = (uint32_t)c->cfg.nslabs * (uint32_t)c->cfg.Y, hg = (uint32_t)c->ham_ghost;
-		p.hamB = c->ham(0) - (size_t)hg * c->lld_packed;
-		p.Y = c->cfg.Y + 2 * (int)hg;
-		p.row_base = (p.row_base + total - hg % total) % total;
-		p.total_rows = total;
-	}
-	const uint64_t thr = draw_prefix(prob, false); // curand_uniform(x) < tgtProb, :193
-	if (thr >= (1ull << 32)) return fail(ISING_E_ARG, "J probability %g sets every bit", (double)prob); // unreachable: u <= 1 and prob <= 1 gives at most 2^32 - 1... see below
-	p.thr = (uint32_t)thr;
-	HIP_TRY(ising::launch_ham_init_black(p, c->stream));
-	c->ham_form = 0; // nibble form until the white couplings have been assembled from it
-	return ISING_OK;
-}
-
-int ising_init_couplings_white(ising_ctx *c) {
-	if (!c) return fail(ISING_E_ARG, "null context");
-	if (!c->cfg.use_J) return fail(ISING_E_STATE, "couplings are not enabled (use_J)");
-	if (int rc = bind(c)) return rc;
-	ising::HamWhiteParams p{};
-	p.hamB = c->ham(0);
-	p.hamW = c->ham(1);
-	if (c->ham_form) return fail(ISING_E_STATE, "ising_init_couplings_white needs a fresh ising_init_couplings_black");
-	p.lld = c->lld_packed;
-	p.Y = c->cfg.Y;
-	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
-	p.slW = c->cfg.XSL ? c->cfg.XSL / 32 : c->lld_packed;
-	p.slY = c->cfg.XSL ? c->cfg.YSL : 0;
-	p.wrap = c->wrap;
-	const int g = c->ham_ghost - 1; // coupling rows beyond the slab's own that the update reads (ghost rows of a ring slab)
-	if (g > 0) {                    // white rows [-g, Y + g) from black rows [-g - 1, Y + g + 1); only the row parity counts here
-		p.hamB -= (size_t)g * c->lld_packed;
-		p.hamW -= (size_t)g * c->lld_packed;
-		p.Y += 2 * g;
-		p.row_base += (uint32_t)(g & 1);
-	}
-	HIP_TRY(ising::launch_ham_init_white(p, c->stream));
-	if (c->ballot) {
-		// the ballot update reads four planes of ballot-order coupling words per row and wave column
-		for (int w = 0; w < 2; w++) HIP_TRY(ising::launch_ham_to_ballot(c->ham(w) - (size_t)g * c->lld_packed, c->gx, c->cfg.Y + 2 * g, c->stream));
-		c->ham_form = 2;
-	} else if (c->dense) {
-		// the dense update reads four coupling bit-planes per 32-site word: transpose both arrays in place
-		for (int w = 0; w < 2; w++) HIP_TRY(ising::launch_ham_planes(c->ham(w), c->ham_words() / 2, c->stream));
-		c->ham_form = 1;
-	}
-	return ISING_OK;
-}
-
-int ising_init_couplings(ising_ctx *c) {
-	if (!c) return fail(ISING_E_ARG, "null context");
-	if (!c->wrap && !c->cfg.XSL) return fail(ISING_E_STATE, "ising_init_couplings needs nslabs == 1; use the _black/_white pair around a halo exchange");
-	if (int rc = ising_init_couplings_black(c)) return rc;
-	return ising_init_couplings_white(c);
-}
-
-int ising_read_couplings(ising_ctx *c, int which, int64_t row0, int64_t nrows, uint64_t *dst_host) {
-	if (!c || !dst_host) return fail(ISING_E_ARG, "null argument");
-	if (which != ISING_BLACK && which != ISING_WHITE) return fail(ISING_E_ARG, "bad coupling array %d", which);
-	if (row0 < 0 || nrows < 0 || row0 + nrows > c->cfg.Y) return fail(ISING_E_ARG, "rows [%lld,%lld) outside slab of %d rows", (long long)row0, (long long)(row0 + nrows), c->cfg.Y);
-	if (!c->cfg.use_J) return fail(ISING_E_STATE, "couplings are not enabled (use_J)");
-	if (int rc = bind(c)) return rc;
-	const size_t nw = (size_t)nrows * c->lld_packed;
-	HIP_TRY(hipMemcpyAsync(dst_host, c->ham(which) + (size_t)row0 * c->lld_packed, nw * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(hipStreamSynchronize(c->stream));
-	if (c->ham_form == 2) ballot_planes_to_planes(dst_host, nw / 256);
-	if (c->ham_form) planes_to_nibbles(dst_host, nw / 2);
-	return ISING_OK;
-}
-
-int ising_swap_couplings(ising_ctx *c) {
-	if (!c) return fail(ISING_E_ARG, "null context");
-	if (!c->cfg.use_J) return fail(ISING_E_STATE, "couplings are not enabled (use_J)");
-	if (int rc = bind(c)) return rc;
-	const size_t per_array = c->ham_alloc_words() / 2; // rows [-ghost, Y + ghost) of one array
-	HIP_TRY(ising::launch_swap_vectors(c->d_ham, c->d_ham + per_array, per_array / 2, c->stream));
-	return ISING_OK;
-}
-
-int ising_write_couplings(ising_ctx *c, int which, const uint64_t *src_host) {
-	if (!c || !src_host) return fail(ISING_E_ARG, "null argument");
-	if (which != ISING_BLACK && which != ISING_WHITE) return fail(ISING_E_ARG, "bad coupling array %d", which);
-	if (!c->cfg.use_J) return fail(ISING_E_STATE, "couplings are not enabled (use_J)");
-	if (!c->wrap || c->ham_ghost != 1) return fail(ISING_E_STATE, "ising_write_couplings needs a lattice that wraps in place (nslabs == 1 without ring halo rows)");
-	if (int rc = bind(c)) return rc;
-	HIP_TRY(hipStreamSynchronize(c->stream)); // (launches that still read the array)
-	HIP_TRY(hipMemcpy(c->ham(which), src_host, c->ham_words() * sizeof(uint64_t), hipMemcpyHostToDevice));
-	// into the form the update kernels of this layout read (ising_init_couplings_white): the array just written -- and, where the
-	// arrays were still as generated (no white initialisation yet, or nothing at all: zeros are zeros in every form), the other one
-	const int want = c->ham_form ? c->ham_form : (c->ballot ? 2 : (c->dense ? 1 : 0));
-	for (int w = 0; w < 2; w++) {
-		if (w != which && c->ham_form == want) continue;
-		if (want == 2) HIP_TRY(ising::launch_ham_to_ballot(c->ham(w), c->gx, c->cfg.Y, c->stream));
-		if (want == 1) HIP_TRY(ising::launch_ham_planes(c->ham(w), c->ham_words() / 2, c->stream));
-	}
-	c->ham_form = want;
-	HIP_TRY(hipStreamSynchronize(c->stream));
 	return ISING_OK;
 }
 

@@ -1,6 +1,7 @@
 // ising_ctx.hpp -- the context object behind the C-ABI handle and the helpers the host-side translation units of
-// libising_hip.so share (ising_capi.cpp: slab life cycle, updates, observables, boundary formats; ising_ring.cpp: the
-// slab ring and its transports).  Internal to the library.
+// libising_hip.so share (ising_capi.cpp: slab life cycle and launch-shape policy; ising_update.cpp: updates and sweeps;
+// ising_observe.cpp: observables; ising_couplings.cpp: -J; ising_io.cpp: boundary formats; ising_ring.cpp / ising_ipc.cpp: the
+// slab ring and its transports; ising_batch.cpp).  Internal to the library.
 #pragma once
 #include <algorithm>
 #include "../../include/ising_hip.h"
@@ -166,6 +167,8 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 	} while (0)
 
 int bind(const ising_ctx *c); // hipSetDevice(c->cfg.device)
+// Number of 32-bit draws x for which curand_uniform(x) <= p (le) or < p (!le): the accepted draws form a prefix [0, N)
+uint64_t draw_prefix(float p, bool le);
 
 // true when the next update of this slab cannot use the integer-threshold kernels (and a ballot slab turns dense)
 bool needs_generic(const ising_ctx *c);

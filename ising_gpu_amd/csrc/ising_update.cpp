@@ -1,0 +1,350 @@
+// ising_update.cpp -- the update side of the C-ABI (include/ising_hip.h): one colour half-sweep over row ranges, the fused
+// launches that carry many of them, the sweeps of a slab on its own, and the halo / ghost-row surface for a caller's own
+// transport.  Replaces the launch sites of the reference's hot loop, optimized/main.cu:1763-1805.  Host side only: the
+// arithmetic on the lattice is in ising_ballot.hip / ising_dense.hip / ising_kernels.hip.
+#include "ising_ctx.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using ising_host::bind;
+using ising_host::fail;
+using ising_host::SLOTCTL_TICKET_BYTES;
+
+extern "C" {
+
+// launches update_k over up to two row ranges
+// `nlevels` > 1 (ballot layout only): one fused launch of that many colour half-sweeps over the whole slab, starting with
+// `color` at iteration `it`
+// `stop` (optional): an event that fires when the launch is done
+static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int lo1, int hi1, int nlevels = 1, hipEvent_t stop = nullptr) {
+	// one-shot requests of the ring schedules for THIS launch (taken here, so that an early return cannot leave them set)
+	const bool edge_scratch = c->edge_scratch_next;
+	const bool overlap = c->overlap_next;
+	hipEvent_t start = c->launch_start_next;
+	if (!stop) stop = c->launch_stop_next;
+	c->edge_scratch_next = false;
+	c->overlap_next = false;
+	c->launch_start_next = c->launch_stop_next = nullptr;
+	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
+	if (it < 0) return fail(ISING_E_ARG, "negative iteration %d", it);
+	int mode = c->cfg.kernel == ISING_KERNEL_GENERIC ? 1 : 0; // AUTO, FAST -> 0
+	if (mode != 1 && !c->fast_ok) {
+		if (c->cfg.kernel != ISING_KERNEL_AUTO) return fail(ISING_E_STATE, "temperature %g does not admit the integer-threshold kernels", (double)c->cfg.temp);
+		mode = 1;
+	}
+	if (int rc = bind(c)) return rc;
+	if (c->ballot && mode == 1) if (int rc = ising_host::ballot_leave(c)) return rc; // no integer thresholds at this temperature
+	c->ghost_depth[color] = 0; // (the neighbours' copies of this slab's rows are stale from here on -- and theirs here, by symmetry)
+	if (nlevels > 1) c->ghost_depth[1 - color] = 0;
+	const int other = 1 - color;
+	ising::UpdateParams p{};
+	p.dst = c->lat(color);
+	p.src = c->lat(other);
+	// periodic wrap of loadTile (optimized/main.cu:414,:422) through mirrored halo rows: the launch that writes an edge row
+	// also writes its mirror -- this slab's own halo rows, or (ring on one device, ising_ring.cpp) the neighbours'
+	const size_t rowb = (size_t)c->lld * sizeof(uint64_t);
+	if (c->wrap) {
+		p.wrap = 1;
+		p.mir0_bytes = (long long)c->cfg.Y * (long long)rowb;
+		p.mirL_bytes = -(long long)c->cfg.Y * (long long)rowb;
+	} else if (c->store_ring && c->ring_prev && c->ring_next && !c->cfg.XSL) {
+		const char *row0 = reinterpret_cast<const char *>(c->lat(color)), *rowL = row0 + (size_t)(c->cfg.Y - 1) * rowb;
+		p.wrap = 1;
+		p.mir0_bytes = reinterpret_cast<const char *>(c->ring_prev->lat(color) + c->ring_prev->color_words) - row0;
+		p.mirL_bytes = reinterpret_cast<const char *>(c->ring_next->lat(color)) - (long long)rowb - rowL;
+	}
+	p.seed_lo = (uint32_t)c->cfg.seed;
+	p.seed_hi = (uint32_t)(c->cfg.seed >> 32);
+	p.it = (uint32_t)it;
+	p.color = (uint32_t)color;
+	p.gx = c->gx;
+	p.Y = c->cfg.Y;
+	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
+	p.slV = c->cfg.XSL ? c->cfg.XSL / 64 : c->gx * 32; // (XSL/2)/SPIN_X_WORD/2, optimized/main.cu:1771
+	p.slY = c->cfg.XSL ? c->cfg.YSL : 0;
+	p.H = c->H;
+	p.row_lo[0] = lo0; p.row_hi[0] = hi0;
+	p.row_lo[1] = lo1; p.row_hi[1] = hi1;
+	const int ugx = c->ballot ? 4 * c->nwc() : c->gx; // column groups per strip as the kernel counts them (ballot: 4 per wave column)
+	// tail strips (ballot layout, plain full-slab launch): the last rows of the slab in strips of H2 rows
+	int H2 = 0;
+	if (c->ballot && nlevels == 1 && c->tail_rows > 0 && hi1 == lo1 && hi0 - lo0 >= 4 * c->tail_rows) {
+		H2 = c->tail_h;
+		lo1 = hi0 - c->tail_rows;
+		hi1 = hi0;
+		hi0 = lo1;
+		p.row_hi[0] = hi0; p.row_lo[1] = lo1; p.row_hi[1] = hi1;
+	}
+	p.H2 = H2;
+	p.nreal0 = ugx * ((hi0 - lo0 + c->H - 1) / c->H);
+	p.nunits0 = (c->ballot && H2) ? (p.nreal0 + 15) / 16 * 16 : p.nreal0;
+	p.nunits = p.nunits0 + ugx * ((hi1 - lo1 + (H2 ? H2 : c->H) - 1) / (H2 ? H2 : c->H));
+	p.n3 = (uint32_t)c->thr[3];
+	p.n4 = (uint32_t)c->thr[4];
+	memcpy(p.tab, c->tab, sizeof(p.tab));
+	// the reference hands hamW to the BLACK update and hamB to the WHITE one (optimized/main.cu:1774, :1795)
+	p.jdst = c->cfg.use_J ? c->ham(other) : nullptr;
+	p.scratch = (edge_scratch && c->d_scratch_edge) ? c->d_scratch_edge : c->d_scratch;
+	if (c->ballot) {
+		p.ticket = reinterpret_cast<unsigned long long *>(c->d_slotctl);
+		p.nlevels = nlevels;
+		p.cus = c->cus;
+		if (nlevels > 1) {
+			p.grid_cap = c->pol.fused_wgs;
+			p.abort_flag = c->h_abort;
+			p.abort_polls = c->pol.abort_polls;
+			for (int k = 0; k < 4; k++) p.ticket_base2[k] = c->ticket_base2[k]; // (the counters are never reset, ising_ballot.hip)
+			p.tickets2 = c->fused_tickets2;
+			if (c->done_base > (1u << 30)) { // keep the monotone completion counters far from wrapping
+				HIP_TRY(hipMemsetAsync(c->d_slotctl + SLOTCTL_TICKET_BYTES / 4, 0, ((size_t)c->nstrips + 2 * (size_t)c->ghost_rows + 2) * sizeof(uint32_t), c->stream));
+				c->done_base = 0;
+			}
+			p.lat[0] = c->lat(ISING_BLACK);
+			p.lat[1] = c->lat(ISING_WHITE);
+			p.jham[0] = c->cfg.use_J ? c->ham(1) : nullptr;
+			p.jham[1] = c->cfg.use_J ? c->ham(0) : nullptr;
+			p.done = c->d_slotctl + SLOTCTL_TICKET_BYTES / 4;
+			p.wg_per_cu = c->fused_wg_per_cu;
+			p.nt_stream = c->fused_nt;
+			p.done_base = c->done_base;
+			if (lo0 < 0 || hi0 > c->cfg.Y) { // ghost rows are rows of the neighbouring slabs
+				p.total_rows = c->cfg.nslabs * c->cfg.Y;
+				p.trapezoid = c->pol.trapezoid ? 1 : 0;
+				if (overlap && c->d_edge) {
+					// the exchange touches the first / last G rows (read by the sends) and the ghost rows (written by the receives)
+					const int G = c->ghost();
+					p.edge_lo = G;
+					p.edge_hi = c->cfg.Y - G;
+					p.edge_go = c->d_edge + 16;
+					p.edge_go_need = c->edge_go_epoch;
+					p.edge_done = c->d_edge;
+					unsigned strips = 0; // strips of this launch that touch such a row
+					for (int r0 = lo0; r0 < hi0; r0 += c->H) if (r0 < p.edge_lo || std::min(r0 + c->H, hi0) > p.edge_hi) strips++;
+					c->edge_done_target += strips * (uint32_t)c->nwc();
+				}
+			}
+		}
+		int grid = 0;
+		if (const hipError_t le = ising::launch_ballot_update(p, c->stream, &grid, stop, start); le != hipSuccess) {
+			// nothing ran: tickets and counters are where the launches before left them, but to be safe they start over
+			if (nlevels > 1) { __atomic_store_n(c->h_abort, 1u, __ATOMIC_RELEASE); (void)ising_host::check_abort(c); }
+			return fail(ISING_E_HIP, "kernel launch failed: %s", hipGetErrorString(le));
+		}
+		if (nlevels > 1) {
+			c->done_base += (uint32_t)nlevels * (uint32_t)c->nwc();
+			// where the launch leaves the counter(s): its units, and every workgroup drew one ticket too many
+			const unsigned long long total = (unsigned long long)p.nwg * (unsigned long long)nlevels;
+			if (p.tickets2 > 1) { // units and workgroups of class k = those numbered k mod K
+				const unsigned long long K = (unsigned long long)p.tickets2;
+				for (unsigned long long k = 0; k < K; k++) c->ticket_base2[k] += (total + K - 1 - k) / K + ((unsigned long long)grid + K - 1 - k) / K;
+			} else {
+				c->ticket_base2[0] += total + (unsigned long long)grid;
+			}
+		}
+		return ISING_OK;
+	}
+	if (c->dense) HIP_TRY(ising::launch_dense_update(p, mode, c->stream));
+	else HIP_TRY(ising::launch_update(p, mode, c->stream));
+	if (stop) HIP_TRY(hipEventRecord(stop, c->stream)); // (the other layouts' launchers take no event: a packet of its own)
+	return ISING_OK;
+}
+
+int ising_update_color(ising_ctx *c, int it, int color, int row_lo, int row_hi) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (row_lo < 0 || row_hi > c->cfg.Y || row_lo > row_hi) return fail(ISING_E_ARG, "bad row range [%d,%d) of %d", row_lo, row_hi, c->cfg.Y);
+	return launch_ranges(c, it, color, row_lo, row_hi, 0, 0);
+}
+
+int ising_update_edges(ising_ctx *c, int it, int color) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	return launch_ranges(c, it, color, 0, 1, c->cfg.Y - 1, c->cfg.Y);
+}
+
+} // extern "C"
+
+int ising_host::update_edges_on(ising_ctx *c, int it, int color, hipStream_t s, hipEvent_t stop) {
+	hipStream_t keep = c->stream; // (a context is driven by one host thread)
+	c->stream = s;
+	c->edge_scratch_next = s != keep; // on another stream than the slab's own: it may run next to an interior launch
+	const int rc = launch_ranges(c, it, color, 0, 1, c->cfg.Y - 1, c->cfg.Y, 1, stop);
+	c->stream = keep;
+	return rc;
+}
+
+int ising_host::update_interior(ising_ctx *c, int it, int color, hipEvent_t stop) {
+	return launch_ranges(c, it, color, 1, c->cfg.Y - 1, 0, 0, 1, stop);
+}
+
+// true when the ring sweeps this slab through its ghost rows right now (ising_ring.cpp: sweep_local takes the same decision)
+static bool ghost_sweeps(const ising_ctx *c) {
+	return !c->wrap && c->ballot && c->ghost() > 1 && !c->store_ring && !c->cfg.XSL && !ising_host::needs_generic(c);
+}
+
+// Ring slab with G > 1 ghost rows: `nlevels` colour half-sweeps (black first) in one fused launch over rows
+// [-(G-1), Y+G-1).  The ghost rows are updated like the slab's own -- their draws are the ones the neighbours make --, and
+// what is not valid in them any more (one row per level and side) never reaches a row that is.
+int ising_host::update_deep(ising_ctx *c, int it, int nlevels, bool overlapped) {
+	const int G = c->ghost();
+	if (G < 2 || nlevels > G || nlevels < 2 || c->store_ring) return fail(ISING_E_STATE, "deep launch of %d levels on a slab with %d ghost rows", nlevels, G);
+	c->overlap_next = overlapped;
+	return launch_ranges(c, it, ISING_BLACK, -(G - 1), c->cfg.Y + G - 1, 0, 0, nlevels);
+}
+
+// fused launches carry this slab's sweeps (ballot layout, integer thresholds; with sub-lattices: strips inside the blocks, no couplings)
+static bool sweeps_fused(const ising_ctx *c) {
+	if (!c->ballot || !c->fused || ising_host::needs_generic(c)) return false;
+	if (c->cfg.XSL) return !c->cfg.use_J && (c->cfg.YSL % c->H) == 0;
+	return c->wrap;
+}
+
+extern "C" int ising_sweep(ising_ctx *c, int first_it, int nsweeps) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (!c->wrap) return fail(ISING_E_STATE, "ising_sweep needs a single slab without ring halo rows; drive slabs with ising_ring_sweep / ising_rank_sweep or ising_update_color + halo exchange");
+	return ising_host::sweep_alone(c, first_it, nsweeps);
+}
+
+// `nsweeps` sweeps of a slab that needs nothing from its neighbours: a single slab that wraps in place, or a slab of
+// sub-lattices (also one of several: nothing crosses slabs, optimized/main.cu:1423-1462)
+int ising_host::sweep_alone(ising_ctx *c, int first_it, int nsweeps) {
+	// ballot layout: many sweeps per fused launch (32 at 65536^2, more on smaller lattices) -- the chip does not drain between colours
+	if (sweeps_fused(c)) {
+		const int per_launch = ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y);
+		for (int it = first_it, left = nsweeps; left > 0;) {
+			const int ns = std::min(left, per_launch);
+			if (int rc = launch_ranges(c, it, ISING_BLACK, 0, c->cfg.Y, 0, 0, 2 * ns)) return rc;
+			it += ns;
+			left -= ns;
+		}
+		return ISING_OK;
+	}
+	for (int it = first_it; it < first_it + nsweeps; it++) {
+		if (int rc = ising_update_color(c, it, ISING_BLACK, 0, c->cfg.Y)) return rc;
+		if (int rc = ising_update_color(c, it, ISING_WHITE, 0, c->cfg.Y)) return rc;
+	}
+	return ISING_OK;
+}
+
+extern "C" {
+
+int ising_sweep_info(ising_ctx *c, int *fused, int *max_sweeps_per_launch) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	const bool f = (c->wrap || c->cfg.XSL) && sweeps_fused(c);
+	// (a ring slab with ghost rows G deep: the ring's sweeps are fused launches of G/2 sweeps between two exchanges)
+	const bool deep = ghost_sweeps(c);
+	if (fused) *fused = (f || deep) ? 1 : 0;
+	if (max_sweeps_per_launch) *max_sweeps_per_launch = f ? ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y) : (deep ? c->ghost() / 2 : 0);
+	return ISING_OK;
+}
+
+int ising_sweep_timed(ising_ctx *c, int first_it, int nsweeps, float *elapsed_ms) {
+	if (!c || !elapsed_ms) return fail(ISING_E_ARG, "null argument");
+	if (int rc = bind(c)) return rc;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	hipError_t e = hipEventCreate(&e0);
+	if (e == hipSuccess) e = hipEventCreate(&e1);
+	if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
+	int rc = e == hipSuccess ? ising_sweep(c, first_it, nsweeps) : fail(ISING_E_HIP, "event timing failed: %s", hipGetErrorString(e));
+	if (rc == ISING_OK) {
+		e = hipEventRecord(e1, c->stream);
+		if (e == hipSuccess) e = hipEventSynchronize(e1);
+		if (e == hipSuccess) e = hipEventElapsedTime(elapsed_ms, e0, e1);
+		if (e != hipSuccess) rc = fail(ISING_E_HIP, "event timing failed: %s", hipGetErrorString(e));
+		else rc = ising_host::check_abort(c);
+	}
+	if (e0) (void)hipEventDestroy(e0);
+	if (e1) (void)hipEventDestroy(e1);
+	return rc;
+}
+
+int ising_halo_ptrs(ising_ctx *c, int color, void **send_top, void **send_bot, void **recv_top, void **recv_bot, size_t *row_bytes) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (color != ISING_BLACK && color != ISING_WHITE && color != ISING_HAM_BLACK) return fail(ISING_E_ARG, "bad colour %d", color);
+	if (color == ISING_HAM_BLACK && !c->cfg.use_J) return fail(ISING_E_STATE, "couplings are not enabled (use_J)");
+	if (c->wrap) return fail(ISING_E_STATE, "no halo buffers with nslabs == 1 (rows wrap inside the slab)");
+	uint64_t *base = c->plane(color);
+	const size_t ld = (size_t)c->plane_ld(color);
+	if (send_top) *send_top = base;
+	if (send_bot) *send_bot = base + (size_t)(c->cfg.Y - 1) * ld;
+	if (recv_top) *recv_top = base - ld;
+	if (recv_bot) *recv_bot = base + (size_t)c->cfg.Y * ld;
+	if (row_bytes) *row_bytes = ld * sizeof(uint64_t);
+	return ISING_OK;
+}
+
+int ising_ghost_ptrs(ising_ctx *c, int color, int *depth, void **send_top, void **send_bot, void **recv_top, void **recv_bot, size_t *block_bytes) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
+	if (c->wrap) return fail(ISING_E_STATE, "no halo buffers with nslabs == 1 (rows wrap inside the slab)");
+	const size_t ld = (size_t)c->lld, G = ghost_sweeps(c) ? (size_t)c->ghost() : 1;
+	uint64_t *base = c->lat(color);
+	if (depth) *depth = (int)G;
+	if (send_top) *send_top = base;
+	if (send_bot) *send_bot = base + ((size_t)c->cfg.Y - G) * ld;
+	if (recv_top) *recv_top = base - G * ld;
+	if (recv_bot) *recv_bot = base + (size_t)c->cfg.Y * ld;
+	if (block_bytes) *block_bytes = G * ld * sizeof(uint64_t);
+	return ISING_OK;
+}
+
+int ising_ghost_delivered(ising_ctx *c, int color) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (color != ISING_BLACK && color != ISING_WHITE) return fail(ISING_E_ARG, "bad colour %d", color);
+	if (c->wrap) return fail(ISING_E_STATE, "no halo buffers with nslabs == 1 (rows wrap inside the slab)");
+	c->ghost_depth[color] = ghost_sweeps(c) ? c->ghost() : 1;
+	return ISING_OK;
+}
+
+int ising_sweep_ghost(ising_ctx *c, int first_it, int nsweeps) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (!ghost_sweeps(c)) return fail(ISING_E_STATE, "the slab does not sweep through ghost rows (ising_ghost_ptrs: depth 1); use ising_update_edges / ising_update_color");
+	const int G = c->ghost();
+	if (nsweeps < 1 || 2 * nsweeps > G) return fail(ISING_E_ARG, "%d sweeps on ghost rows %d deep (at most %d per exchange)", nsweeps, G, G / 2);
+	if (c->ghost_depth[0] < G || c->ghost_depth[1] < G)
+		return fail(ISING_E_STATE, "the ghost rows are not current: deliver both colours (ising_ghost_ptrs, ising_ghost_delivered) after whatever changed the spins");
+	for (int color = 0; color < 2; color++) if (int rc = ising_host::halo_ready(c, color)) return rc; // (a no-op unless the library's own transport is attached too)
+	return ising_host::update_deep(c, first_it, 2 * nsweeps);
+}
+
+
+// Test aids (tests/test_gpu_fused.py).  what = 1 puts the host's idea of the completion counters out of step with the device,
+// as a faulted launch would leave it -- the next fused launch's units wait for counts that never come -- and lowers the
+// bound after which they give up to `arg` polls (0: keep).  what = 2 ages every monotone counter of the slab, device and
+// host record together, as billions of sweeps would: the completion counters stand past the point where the next launch
+// starts them over, the exchange's counters (units that have left the edge rows, epochs) a few counts before 2^32.
+int ising_debug_fault(ising_ctx *c, int what, int arg) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (what == 2) {
+		if (int rc = ising_synchronize(c)) return rc;
+		if (c->comm) HIP_TRY(hipStreamSynchronize(c->comm));
+		if (c->d_slotctl && c->slotctl_bytes > SLOTCTL_TICKET_BYTES) {
+			const uint32_t add = (1u << 30) + 12345u - c->done_base; // (counters of strips that lag a level keep their distance)
+			std::vector<uint32_t> h((c->slotctl_bytes - SLOTCTL_TICKET_BYTES) / 4);
+			HIP_TRY(hipMemcpy(h.data(), c->d_slotctl + SLOTCTL_TICKET_BYTES / 4, h.size() * 4, hipMemcpyDeviceToHost));
+			for (auto &v : h) v += add;
+			HIP_TRY(hipMemcpy(c->d_slotctl + SLOTCTL_TICKET_BYTES / 4, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+			c->done_base += add;
+		}
+		if (c->d_edge) {
+			uint32_t h[32];
+			HIP_TRY(hipMemcpy(h, c->d_edge, sizeof(h), hipMemcpyDeviceToHost));
+			const uint32_t add_done = 0xFFFFFFF0u - c->edge_done_target, add_go = 0xFFFFFFFDu - c->edge_go_epoch;
+			h[0] += add_done;
+			h[16] += add_go;
+			HIP_TRY(hipMemcpy(c->d_edge, h, sizeof(h), hipMemcpyHostToDevice));
+			c->edge_done_target += add_done;
+			c->edge_go_epoch += add_go;
+		}
+		return ISING_OK;
+	}
+	if (what != 1) return fail(ISING_E_ARG, "unknown fault %d", what);
+	c->done_base += 1u << 20;
+	if (arg > 0) c->pol.abort_polls = (uint32_t)arg;
+	return ISING_OK;
+}
+
+} // extern "C"

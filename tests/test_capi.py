@@ -125,11 +125,11 @@ def test_bench_helpers_and_full_size_goldens():
     import bench
     gold = os.path.join(ROOT, "tests", "golden")
     # the point the round-1 driver run hit: 65536^2, T_c, seed 1234, 5 + 20 sweeps
-    assert bench.golden_counts(65536, 65536, 1234, 1, 25) == (2146725784, 2148241512)
-    assert bench.golden_counts(65536, 65536, 1234, 1, 0) == (2147471050, 2147496246)
-    assert bench.golden_counts(65536, 65536, 1234, 1, 26) is None and bench.golden_counts(65536, 65536, 99, 1, 25) is None
+    assert bench.golden_counts(65536, 65536, 1234, 25) == (2146725784, 2148241512)
+    assert bench.golden_counts(65536, 65536, 1234, 0) == (2147471050, 2147496246)
+    assert bench.golden_counts(65536, 65536, 1234, 26) is None and bench.golden_counts(65536, 65536, 99, 25) is None
     for n in (2, 4, 8):
-        up, down = bench.golden_counts(65536, 65536, 1234, n, 25)
+        up, down = bench.golden_counts(65536, 65536 * n, 1234, 25)
         assert up + down == n * 65536 * 65536
     c4 = json.load(open(os.path.join(gold, "config4_131072.json")))
     for pt in c4["points"]:
@@ -137,6 +137,29 @@ def test_bench_helpers_and_full_size_goldens():
     # the 8-slab ring's initial state is the single lattice's: same counts as config 4's?  (other geometry: 524288 x 65536)
     r8 = [r for r in json.load(open(os.path.join(gold, "ring_65536_tc.json")))["rings"] if r["nslabs"] == 8][0]
     assert r8["Ytot"] == 524288 and r8["points"][0]["sweeps"] == 0
+
+
+def test_every_point_of_a_scaling_run_has_a_golden():
+    """for each workload of bench.py at N = 1, 2, 4, 8 and both sweep counts a scaling run uses (the driver's
+    --warmup 5 --steps 20 = 25, the default 16 + 128 = 144) the oracle's counts of the TOTAL lattice are committed -- so that
+    `parity_checked` is true or false, never null, at every point.  The lookup keys on the total lattice, not on the number of
+    slabs: the strong-scaling splits of 65536^2 all hit bench_65536_tc.json (optimized/main.cu:514, :1590-1591)."""
+    import bench
+    for name, (x, rows_of, kind) in bench.WORKLOADS.items():
+        for n in (1, 2, 4, 8):
+            ytot = rows_of(n) * n
+            for sweeps in (0, 25, 144):
+                got = bench.golden_counts(x, ytot, 1234, sweeps)
+                assert got is not None, (name, n, sweeps)
+                assert got[0] + got[1] == x * ytot, (name, n, sweeps)
+            if kind == "strong":
+                assert ytot == 65536 and bench.golden_counts(x, ytot, 1234, 25) == (2146725784, 2148241512)
+    # one physical fact that ties the files together: lattices with the same number of Philox streams start with the same number of up
+    # spins (latticeInit_k draws per (block row, column group) stream, optimized/main.cu:107-149) -- 131072 x 32768 and 65536^2
+    assert bench.golden_counts(131072, 32768, 1234, 0) == bench.golden_counts(65536, 65536, 1234, 0)
+    # and config 4 at N = 8 is the lattice config4_131072.json pinned in round 2 (points 0 there and in scaling.json agree)
+    rec = bench.golden_records()[(131072, 131072, 1234)]
+    assert {0, 1, 2, 5, 25, 144} <= set(rec)
 
 
 def test_hand_waited_loads_of_the_fused_kernels_pass_the_isa_check():

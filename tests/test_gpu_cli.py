@@ -132,6 +132,18 @@ def test_readme_two_gpu_transcript_every_line_at_its_own_decomposition(gpu):
         assert line in out, line
 
 
+@pytest.mark.parametrize("ndev,lines", [(2, "README_2GPU"), (8, "README_8GPU")])
+def test_readme_multi_gpu_transcripts_on_that_many_devices(gpu, ndev, lines):
+    """`cuIsing -d N` as the reference's README types it -- no --devmap: N devices, one slab each, one host thread driving all of them
+    (optimized/main.cu:1764-1805), RCCL on the comm streams.  Needs N GPUs; the 1-GPU box runs the same lattices through --devmap above."""
+    import ising_gpu_amd as ig
+    if ig.device_count() < ndev:
+        pytest.skip(f"needs >= {ndev} GPUs")
+    out = run(["-y", "65536", "-x", "65536", "-n", "128", "-p", "16", "-d", str(ndev), "-t", "1.5"])
+    for line in globals()[lines] + [f"\tGPU {ndev - 1:2d} done\n"]:
+        assert line in out, line
+
+
 def test_readme_two_gpu_transcript_as_one_slab(gpu):
     """The same lattice as ONE slab of 131072 rows (fused launches, no ring): the counts do not depend on the decomposition."""
     out = run(["-y", "131072", "-x", "65536", "-n", "128", "-p", "16", "-t", "1.5"])

@@ -117,9 +117,18 @@ def test_bench_line_on_a_small_lattice(gpu, oracle_mod):
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in b, key
     assert b["n_gpus"] == 1 and b["steps"] == 4 and b["warmup"] == 2 and b["unit"] == "flips/ns" and b["value"] > 100
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "alu_ceiling"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_reference_accounting", "hbm_real"):
         assert key in b["roofline"], key
+    # the roof that binds is the vector ALU: sites/ns against the draw-only ceiling of the same job; SURVEY 8(d)'s HBM
+    # accounting (1.5 B per flip against 8 TB/s) rides along
+    assert b["roofline"]["bound"] == "valu" and b["roofline"]["unit"] == "sites/ns"
     assert abs(b["roofline"]["frac"] - b["roofline"]["achieved"] / b["roofline"]["peak"]) < 1e-3
+    ref = b["roofline"]["hbm_reference_accounting"]
+    assert ref["peak"] == 8000.0 and abs(ref["frac"] - ref["achieved"] / ref["peak"]) < 1e-3
+    assert abs(ref["achieved"] / 1.5 - b["roofline"]["achieved"]) < 0.01 * b["roofline"]["achieved"]  # the same launch time in both
+    # the reference's methodology: the same sweeps with the counts read back every 16 inside the timed region
+    leg = b["with_counts_every_16"]
+    assert leg["final_counts_equal_first_leg"] is True and leg["counts_in_timed_region"] == 1 and 0 < leg["value"] <= 1.2 * b["value"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in b["cpu_baseline"], key
     orc = oracle_mod.OracleLattice(8192, 8192, seed=1234, temp=oracle_mod.CRIT_TEMP).init().sweep(6)
@@ -139,6 +148,12 @@ def test_bench_ring_code_path_with_one_rank(gpu, oracle_mod, ring, port, exchang
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     b = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert b["config"]["exchange"] == exchange and b["config"]["nranks"] == 1
+    if ring == "native":  # the library's ring says where the time around its exchanges went (one launch + exchange per 32 sweeps)
+        xs = b["exchange_stats"]
+        assert xs["exchanges_per_rank"] == 1 and xs["launch_ms"]["mean"] > 0 and xs["exchange_ms"]["max"] >= xs["exchange_ms"]["mean"] > 0
+        assert len(xs["go_after_end_ms"]["by_rank_mean"]) == 1
+    else:
+        assert "exchange_stats" not in b
     orc = oracle_mod.OracleLattice(8192, 8192, seed=1234, temp=oracle_mod.CRIT_TEMP).init().sweep(6)
     assert (b["config"]["up"], b["config"]["down"]) == orc.count() and b["config"]["rank_up"] == [orc.count()[0]]
 

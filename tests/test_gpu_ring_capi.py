@@ -155,6 +155,52 @@ def test_multi_process_ring_over_nccl(gpu, mode):
     assert r.stdout.count("slab == oracle rows") == 2 * n and "!=" not in r.stdout, r.stdout[-3000:]
 
 
+# ---- the path a scaling run of bench.py takes: ballot ring slabs, 64 ghost rows, fused launches, the exchange overlapped -----------
+def _scale(transport, world, port, *mode, timeout=1800):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("ISING_RING_GHOST", "ISING_RING_OVERLAP", "ISING_FUSED"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), os.path.join(ROOT, "tools", "ring_ranks_scale.py"), transport, *mode],
+                          capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+@pytest.mark.parametrize("world,workload,port", [(2, "config3", 29561), (4, "config3", 29562), (8, "config3", 29563), (8, "strong", 29564),
+                                                 (4, "strong", 29565), (2, "config4", 29566)])
+def test_scaling_path_ipc_ranks_reproduce_the_goldens(gpu, world, workload, port):
+    """bench.py's own slabs at N ranks over the library's peer ring (ISING_TRANSPORT_IPC): every rank a device of its own where the
+    node has them, sharing devices where it has fewer (a 1-GPU box runs all of it) -- 64 ghost rows, fused launches of up to 32
+    sweeps, the exchange overlapped with the launches; counts after 5 / 21 / 25 sweeps = the oracle's goldens of the total lattice."""
+    r = _scale("ipc", world, port, "golden", workload)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    npts = 2 if workload == "config4" else 3
+    assert r.stdout.count("== oracle golden") == npts * world and "!=" not in r.stdout, r.stdout[-3000:]
+    assert r.stdout.count("exchange stats:") == world
+
+
+@pytest.mark.parametrize("world,workload,port", [(2, "config3", 29571), (4, "config3", 29572), (8, "config3", 29573), (8, "strong", 29574), (8, "config4", 29575)])
+def test_scaling_path_rccl_ranks_reproduce_the_goldens(gpu, world, workload, port):
+    """The same over the library's RCCL ring (ncclSend / ncclRecv on the comm stream, one GPU per rank): what the driver's scaling run
+    executes first.  Needs `world` GPUs."""
+    if _ngpu() < world:
+        pytest.skip(f"needs >= {world} GPUs")
+    r = _scale("rccl", world, port, "golden", workload)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    npts = 2 if workload == "config4" else 3
+    assert r.stdout.count("== oracle golden") == npts * world and "!=" not in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("transport,world,port", [("ipc", 2, 29581), ("ipc", 4, 29582), ("rccl", 2, 29583), ("rccl", 4, 29584), ("rccl", 8, 29585)])
+def test_scaling_path_full_state_against_the_oracle(gpu, transport, world, port):
+    """The same schedule on slabs small enough for the CPU oracle to follow (16384 x 2048 per rank, three exchanges deep): every
+    rank's FULL state, the counts and the bond sum."""
+    if transport == "rccl" and _ngpu() < world:
+        pytest.skip(f"needs >= {world} GPUs")
+    r = _scale(transport, world, port, "state")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("== oracle rows") == 3 * world and "!=" not in r.stdout, r.stdout[-3000:]
+
+
 def test_ring_slabs_keep_ghost_rows_where_they_can(gpu, monkeypatch):
     """Ballot ring slabs that own their buffer keep ghost rows (min(64, Y/2) deep; ising_sweep_info: the ring sweeps them in
     fused launches of half as many sweeps), with -J too (the ghost rows' couplings are generated in place); the dense layout, a
