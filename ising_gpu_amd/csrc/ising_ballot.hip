@@ -172,9 +172,18 @@ __device__ unsigned long long g_hist[32];
 #define BAL_SGPR_ATTR
 #endif
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-template <bool SUBL, bool USEJ, bool FUSED, int NT = BAL_THREADS, bool STREAM = false, bool BATCH = false>
+// STATIC (fused launches of lattices whose level fits the chip: round 4): no tickets.  The grid has exactly one workgroup per unit
+// of a level and workgroup b works on unit b at EVERY level -- the unit decode, the completion counters and the hand-over between
+// levels are the ticket form's, but nothing is drawn: a level of 1024 .. 2048 tickets (8192^2, 16384^2) spends 9 .. 6 % of its
+// workgroups' time picking tickets up and drawing the next, and the ticket form must run FEWER workgroups than a level has units
+// or its units find their parents unfinished.  The price is the ticket form's guarantee: every workgroup of the grid must be
+// resident at once (the host launches this form only where the grid fits the chip with room to spare; a launch that shares the
+// chip with another persistent grid may wait for ever -- the bounded polls turn that into ISING_E_STATE, and the context falls
+// back to tickets).
+template <bool SUBL, bool USEJ, bool FUSED, int NT = BAL_THREADS, bool STREAM = false, bool BATCH = false, bool STATIC = false>
 __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const UpdateParams p) {
 	static_assert(!BATCH || (FUSED && !SUBL && !USEJ), "batched launches: fused, no sub-lattices, no couplings");
+	static_assert(!STATIC || (FUSED && !BATCH), "static units: fused launches of one lattice");
 	static_assert(!(FUSED && SUBL && USEJ), "fused launches with sub-lattices: no couplings");
 	const int lane = threadIdx.x & 63;
 	const int tx = threadIdx.x & (GROUP - 1), g = (threadIdx.x >> 4) & 3;
@@ -269,7 +278,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	const unsigned dround = uni((int)(blockIdx.x / (unsigned)p.cus)); // dispatch round = this workgroup's rank on its CU (a grid of k x CUs lands k per CU)
 	if (FUSED && NT == 256 && ISING_FUSED_STAGGER > 0)
 		for (unsigned i = 0; i < dround % 6u; ++i) __builtin_amdgcn_s_sleep(ISING_FUSED_STAGGER);
-	if (FUSED) {
+	if (FUSED && !STATIC) {
 		if (threadIdx.x == 0) ticket_sh[0] = draw_ticket();
 		__syncthreads();
 		tkv = ticket_sh[0];
@@ -280,7 +289,9 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	const int nwc_sh = (nwc & (nwc - 1)) == 0 ? __builtin_ctz((unsigned)nwc) + 2 : -1; // gxp = 4 nwc as a shift where it is one
 	for (int round = 0;; ++round) {
 		unsigned long long tk;
-		if (FUSED) {
+		if (STATIC) { // unit blockIdx of level `round`
+			tk = (round < p.nlevels && (int)blockIdx.x < p.nwg) ? (unsigned long long)(unsigned)round * (unsigned)p.nwg + blockIdx.x : total;
+		} else if (FUSED) {
 			const uint32_t tk_lo = __builtin_amdgcn_readfirstlane((uint32_t)tkv), tk_hi = __builtin_amdgcn_readfirstlane((uint32_t)(tkv >> 32));
 			tk = ((unsigned long long)tk_hi << 32) | tk_lo;
 		} else {
@@ -580,7 +591,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				});
 			}
 			TRC(4); // draw phase
-			if (FUSED && r == rmax && wi == 0) { // wave-uniform branch; read by the workgroup after this unit's last barrier
+			if (FUSED && !STATIC && r == rmax && wi == 0) { // wave-uniform branch; read by the workgroup after this unit's last barrier
 				if (lane == 0) ticket_sh[(round + 1) & 1] = draw_ticket();
 			}
 			TRC(5); // next ticket
@@ -683,7 +694,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			TRC(11); // flips, stores
 			if (wb_wave && r < rmax) asm volatile("s_dcache_wb" ::: "memory");
 		}
-		if (FUSED) tkv = ticket_sh[(round + 1) & 1]; // (on its way while the stores drain)
+		if (FUSED && !STATIC) tkv = ticket_sh[(round + 1) & 1]; // (on its way while the stores drain)
 		if (FUSED && !absent) {
 			// publish: this wave's stores were written through (sc1); once they have left the wave the strip's counter
 			// may move (every storing wave drains its own stores and signals its own unit)
@@ -995,7 +1006,7 @@ __global__ void __launch_bounds__(THREADS) ham_ballot_to_planes_k(uint64_t *__re
 // (contexts may be driven from several host threads, one each: the cache is filled under a lock)
 static int ballot_resident_wgs(int v, const void *fn, int threads, int cus) {
 	static std::mutex mu;
-	static int cache[16][64];
+	static int cache[16][128];
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
 	std::lock_guard<std::mutex> lock(mu);
@@ -1017,6 +1028,7 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	const bool subl = p.slY != 0;
 	const bool streamed = fused && p.nt_stream;
 	const bool batch = fused && p.nrep > 0;
+	if (p.static_units && (!fused || batch || usej || subl)) p.static_units = 0;
 	if (batch && (usej || subl || NT != BAL_THREADS)) return hipErrorInvalidValue;
 	if (fused && subl && (usej || NT != BAL_THREADS || p.slY % p.H != 0)) return hipErrorInvalidValue; // (ising_capi.cpp keeps those on one launch per colour)
 	if (batch) { // a level = the units of all lattices
@@ -1024,8 +1036,17 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 		p.nwg = p.nwg_rep * p.nrep;
 		p.rep_magic = (uint32_t)((0x100000000ull + (unsigned long long)p.nwg_rep - 1) / (unsigned long long)p.nwg_rep);
 	}
-	// kernel instance: bit 0 couplings, 1 sub-lattices, 2 fused, 3 non-temporal lattice words, 4 batched
-	const int v = (usej ? 1 : 0) | (subl ? 2 : 0) | (fused ? 4 : 0) | (streamed ? 8 : 0) | (batch ? 16 : 0);
+	// kernel instance: bit 0 couplings, 1 sub-lattices, 2 fused, 3 non-temporal lattice words, 4 batched, 5 static units
+	int v = (usej ? 1 : 0) | (subl ? 2 : 0) | (fused ? 4 : 0) | (streamed ? 8 : 0) | (batch ? 16 : 0);
+	if (p.static_units) {
+		// every workgroup of the grid must be resident at once: what the occupancy query admits, at most six per CU (the scalar-
+		// register rule of the guide: the query may say seven where the hardware admits six), else tickets
+		if (p.cus <= 0) { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256; p.cus = n; }
+		const void *sfn = streamed ? (const void *)ballot_update_k<false, false, true, BAL_THREADS, true, false, true> : (const void *)ballot_update_k<false, false, true, BAL_THREADS, false, false, true>;
+		const long long room = std::min<long long>(ballot_resident_wgs((v | 32) + (NT == 256 ? 0 : 64), sfn, NT, p.cus), 6LL * p.cus);
+		if ((long long)p.nwg <= room) v |= 32;
+		else p.static_units = 0;
+	}
 	// (the launch is `LAUNCH(instance)`: hipExtLaunchKernelGGL needs the template arguments as written)
 #define BAL_INSTANCES(X)                                                                                              \
 	X(0, (ballot_update_k<false, false, false, NT>))                                                                   \
@@ -1039,7 +1060,9 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	X(13, (ballot_update_k<false, true, true, BAL_THREADS, true>))                                                     \
 	X(14, (ballot_update_k<true, false, true, BAL_THREADS, true>))                                                     \
 	X(20, (ballot_update_k<false, false, true, BAL_THREADS, false, true>))                                             \
-	X(28, (ballot_update_k<false, false, true, BAL_THREADS, true, true>))
+	X(28, (ballot_update_k<false, false, true, BAL_THREADS, true, true>))                                              \
+	X(36, (ballot_update_k<false, false, true, BAL_THREADS, false, false, true>))                                      \
+	X(44, (ballot_update_k<false, false, true, BAL_THREADS, true, false, true>))
 	const void *fn = nullptr;
 	switch (v) {
 #define BAL_FN(code, inst) case code: fn = (const void *)inst; break;
@@ -1058,8 +1081,10 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 		p.cus = n;
 	}
 	const int cus = p.cus;
-	long long grid = fused ? std::min<long long>(std::min(ballot_resident_wgs(v + (NT == 256 ? 0 : 32), fn, NT, cus), ballot_max_wgs(cus) * 256 / NT), total) : total;
-	if (fused) {
+	long long grid = fused ? std::min<long long>(std::min(ballot_resident_wgs(v + (NT == 256 ? 0 : 64), fn, NT, cus), ballot_max_wgs(cus) * 256 / NT), total) : total;
+	if (p.static_units) {
+		grid = p.nwg; // one workgroup per unit of a level, all of them resident (checked above)
+	} else if (fused) {
 		// Fewer workgroups than the chip holds when a level has few tickets: a unit's parents are one level = p.nwg tickets
 		// back, and a workgroup that finds them unfinished holds its slot asleep (ising_create picks wg_per_cu)
 		if (p.grid_cap > 0) grid = std::min<long long>(grid, p.grid_cap); // (ISING_FUSED_WGS, read when the context was created)
