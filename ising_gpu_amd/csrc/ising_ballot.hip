@@ -172,8 +172,8 @@ __device__ unsigned long long g_hist[32];
 #define BAL_SGPR_ATTR
 #endif
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-// STATIC (fused launches of lattices whose level fits the chip: round 4): no tickets.  The grid has exactly one workgroup per unit
-// of a level and workgroup b works on unit b at EVERY level -- the unit decode, the completion counters and the hand-over between
+// STATIC (fused launches of lattices whose level fits the chip a few times: round 4): no tickets.  Workgroup b of a grid of G works on
+// units b, b + G, ... of EVERY level -- the unit decode, the completion counters and the hand-over between
 // levels are the ticket form's, but nothing is drawn: a level of 1024 .. 2048 tickets (8192^2, 16384^2) spends 9 .. 6 % of its
 // workgroups' time picking tickets up and drawing the next, and the ticket form must run FEWER workgroups than a level has units
 // or its units find their parents unfinished.  The price is the ticket form's guarantee: every workgroup of the grid must be
@@ -286,11 +286,15 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	// a workgroup's tickets grow, so its level is a running count (no 64-bit division per unit)
 	int level = 0;
 	unsigned long long level_base = 0;
+	[[maybe_unused]] int st_level = 0, st_j = 0; // STATIC: the level and which of this workgroup's units of it comes next
 	const int nwc_sh = (nwc & (nwc - 1)) == 0 ? __builtin_ctz((unsigned)nwc) + 2 : -1; // gxp = 4 nwc as a shift where it is one
 	for (int round = 0;; ++round) {
 		unsigned long long tk;
-		if (STATIC) { // unit blockIdx of level `round`
-			tk = (round < p.nlevels && (int)blockIdx.x < p.nwg) ? (unsigned long long)(unsigned)round * (unsigned)p.nwg + blockIdx.x : total;
+		if (STATIC) { // this workgroup's units of a level -- blockIdx, blockIdx + grid, ... -- level after level
+			const int unit = (int)blockIdx.x + st_j * (int)gridDim.x;
+			tk = st_level < p.nlevels ? (unsigned long long)(unsigned)st_level * (unsigned)p.nwg + (unsigned)unit : total;
+			st_j = unit + (int)gridDim.x < p.nwg ? st_j + 1 : 0;
+			if (st_j == 0) ++st_level;
 		} else if (FUSED) {
 			const uint32_t tk_lo = __builtin_amdgcn_readfirstlane((uint32_t)tkv), tk_hi = __builtin_amdgcn_readfirstlane((uint32_t)(tkv >> 32));
 			tk = ((unsigned long long)tk_hi << 32) | tk_lo;
@@ -1043,9 +1047,15 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 		// register rule of the guide: the query may say seven where the hardware admits six), else tickets
 		if (p.cus <= 0) { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256; p.cus = n; }
 		const void *sfn = streamed ? (const void *)ballot_update_k<false, false, true, BAL_THREADS, true, false, true> : (const void *)ballot_update_k<false, false, true, BAL_THREADS, false, false, true>;
-		const long long room = std::min<long long>(ballot_resident_wgs((v | 32) + (NT == 256 ? 0 : 64), sfn, NT, p.cus), 6LL * p.cus);
-		if ((long long)p.nwg <= room) v |= 32;
-		else p.static_units = 0;
+		long long room = std::min<long long>(ballot_resident_wgs((v | 32) + (NT == 256 ? 0 : 64), sfn, NT, p.cus), 6LL * p.cus);
+		if (p.grid_cap > 0) room = std::min<long long>(room, p.grid_cap);
+		else if (p.wg_per_cu > 0) room = std::min<long long>(room, (long long)p.wg_per_cu * p.cus);
+		if (room < 1) room = 1;
+		// k = ceil(units / room) units of a level per workgroup, the grid as small as that allows (the same number for every workgroup
+		// where the level divides: a workgroup with one unit more than the others is what every level waits for)
+		const long long k = ((long long)p.nwg + room - 1) / room;
+		p.static_units = (int32_t)(((long long)p.nwg + k - 1) / k);
+		v |= 32;
 	}
 	// (the launch is `LAUNCH(instance)`: hipExtLaunchKernelGGL needs the template arguments as written)
 #define BAL_INSTANCES(X)                                                                                              \
@@ -1083,7 +1093,7 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	const int cus = p.cus;
 	long long grid = fused ? std::min<long long>(std::min(ballot_resident_wgs(v + (NT == 256 ? 0 : 64), fn, NT, cus), ballot_max_wgs(cus) * 256 / NT), total) : total;
 	if (p.static_units) {
-		grid = p.nwg; // one workgroup per unit of a level, all of them resident (checked above)
+		grid = p.static_units; // every workgroup resident, units blockIdx, blockIdx + grid, ... of each level
 	} else if (fused) {
 		// Fewer workgroups than the chip holds when a level has few tickets: a unit's parents are one level = p.nwg tickets
 		// back, and a workgroup that finds them unfinished holds its slot asleep (ising_create picks wg_per_cu)

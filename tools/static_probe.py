@@ -49,14 +49,19 @@ def case(X, Y, H, **env):
 for X, Y in sizes:
     v0, d0 = case(X, Y, 0)
     print(f"{Y} x {X}: default {v0:7.1f} flips/ns (H = {d0[0]}, layout {d0[1]}, fused {d0[2]})", flush=True)
-    for H in (1, 2, 4, 8, 16, 32):
+    for H in (1, 2, 4, 8, 16):
         if Y % H:
             continue
         nwc = (X // 2048 + 3) // 4
         nwg = (4 * nwc * (Y // H) + 15) // 16
-        if nwg > 6 * 256 or nwg < 64:
+        if nwg > 24 * 256 or nwg < 256:
             continue
         vt, dt = case(X, Y, H, ISING_FUSED="1")
-        vs, ds = case(X, Y, H, ISING_FUSED="1", ISING_FUSED_STATIC="1")
-        same = "same counts" if (ds[3:] == d0[3:] if vs else False) else f"COUNTS DIFFER {ds} vs {d0}"
-        print(f"    H = {H:2d} ({nwg:4d} workgroups a level = {nwg / 256:.2f} per CU): tickets {vt if vt else float('nan'):7.1f}   static {vs if vs else float('nan'):7.1f}   {same}", flush=True)
+        row = [f"tickets {vt if vt else float('nan'):7.1f}"]
+        for per_cu in (2, 3, 4, 5, 6):
+            if per_cu * 256 > nwg and (per_cu - 1) * 256 >= nwg:
+                continue
+            vs, ds = case(X, Y, H, ISING_FUSED="1", ISING_FUSED_STATIC="1", ISING_FUSED_WGS=str(per_cu * 256))
+            ok = vs is not None and ds[3:] == d0[3:]
+            row.append(f"static@{per_cu}: {vs if vs else float('nan'):7.1f}" + ("" if ok else " COUNTS DIFFER"))
+        print(f"    H = {H:2d} ({nwg:5d} units a level): " + "   ".join(row), flush=True)
