@@ -172,18 +172,14 @@ __device__ unsigned long long g_hist[32];
 #define BAL_SGPR_ATTR
 #endif
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-// STATIC (fused launches of lattices whose level fits the chip a few times: round 4): no tickets.  Workgroup b of a grid of G works on
-// units b, b + G, ... of EVERY level -- the unit decode, the completion counters and the hand-over between
-// levels are the ticket form's, but nothing is drawn: a level of 1024 .. 2048 tickets (8192^2, 16384^2) spends 9 .. 6 % of its
-// workgroups' time picking tickets up and drawing the next, and the ticket form must run FEWER workgroups than a level has units
-// or its units find their parents unfinished.  The price is the ticket form's guarantee: every workgroup of the grid must be
-// resident at once (the host launches this form only where the grid fits the chip with room to spare; a launch that shares the
-// chip with another persistent grid may wait for ever -- the bounded polls turn that into ISING_E_STATE, and the context falls
-// back to tickets).
-template <bool SUBL, bool USEJ, bool FUSED, int NT = BAL_THREADS, bool STREAM = false, bool BATCH = false, bool STATIC = false>
+// (Round 4 tried fused launches WITHOUT tickets -- every workgroup of a wholly resident grid owning units b, b + G, ... of every level,
+// no atomics, the verdict's "static strip ownership" -- and measured them 6-10 % behind the ticket form at every size and shape
+// (16384^2: 3119 vs 3321 flips/ns at two units per workgroup and level, 2967 vs 3211 at one; 8192^2 2510 vs 2793; 32768^2 3179 vs 3475;
+// profiles/static_probe_r04a.txt, _r04b.txt; the code is in the history at 851dc8e): the 6 % of a workgroup's time that tickets cost
+// buy a load balance between workgroups of unequal speed that is worth more -- with fixed owners every level waits for its slowest.)
+template <bool SUBL, bool USEJ, bool FUSED, int NT = BAL_THREADS, bool STREAM = false, bool BATCH = false>
 __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const UpdateParams p) {
 	static_assert(!BATCH || (FUSED && !SUBL && !USEJ), "batched launches: fused, no sub-lattices, no couplings");
-	static_assert(!STATIC || (FUSED && !BATCH), "static units: fused launches of one lattice");
 	static_assert(!(FUSED && SUBL && USEJ), "fused launches with sub-lattices: no couplings");
 	const int lane = threadIdx.x & 63;
 	const int tx = threadIdx.x & (GROUP - 1), g = (threadIdx.x >> 4) & 3;
@@ -278,7 +274,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	const unsigned dround = uni((int)(blockIdx.x / (unsigned)p.cus)); // dispatch round = this workgroup's rank on its CU (a grid of k x CUs lands k per CU)
 	if (FUSED && NT == 256 && ISING_FUSED_STAGGER > 0)
 		for (unsigned i = 0; i < dround % 6u; ++i) __builtin_amdgcn_s_sleep(ISING_FUSED_STAGGER);
-	if (FUSED && !STATIC) {
+	if (FUSED) {
 		if (threadIdx.x == 0) ticket_sh[0] = draw_ticket();
 		__syncthreads();
 		tkv = ticket_sh[0];
@@ -286,16 +282,10 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	// a workgroup's tickets grow, so its level is a running count (no 64-bit division per unit)
 	int level = 0;
 	unsigned long long level_base = 0;
-	[[maybe_unused]] int st_level = 0, st_j = 0; // STATIC: the level and which of this workgroup's units of it comes next
 	const int nwc_sh = (nwc & (nwc - 1)) == 0 ? __builtin_ctz((unsigned)nwc) + 2 : -1; // gxp = 4 nwc as a shift where it is one
 	for (int round = 0;; ++round) {
 		unsigned long long tk;
-		if (STATIC) { // this workgroup's units of a level -- blockIdx, blockIdx + grid, ... -- level after level
-			const int unit = (int)blockIdx.x + st_j * (int)gridDim.x;
-			tk = st_level < p.nlevels ? (unsigned long long)(unsigned)st_level * (unsigned)p.nwg + (unsigned)unit : total;
-			st_j = unit + (int)gridDim.x < p.nwg ? st_j + 1 : 0;
-			if (st_j == 0) ++st_level;
-		} else if (FUSED) {
+		if (FUSED) {
 			const uint32_t tk_lo = __builtin_amdgcn_readfirstlane((uint32_t)tkv), tk_hi = __builtin_amdgcn_readfirstlane((uint32_t)(tkv >> 32));
 			tk = ((unsigned long long)tk_hi << 32) | tk_lo;
 		} else {
@@ -595,7 +585,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				});
 			}
 			TRC(4); // draw phase
-			if (FUSED && !STATIC && r == rmax && wi == 0) { // wave-uniform branch; read by the workgroup after this unit's last barrier
+			if (FUSED && r == rmax && wi == 0) { // wave-uniform branch; read by the workgroup after this unit's last barrier
 				if (lane == 0) ticket_sh[(round + 1) & 1] = draw_ticket();
 			}
 			TRC(5); // next ticket
@@ -698,7 +688,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			TRC(11); // flips, stores
 			if (wb_wave && r < rmax) asm volatile("s_dcache_wb" ::: "memory");
 		}
-		if (FUSED && !STATIC) tkv = ticket_sh[(round + 1) & 1]; // (on its way while the stores drain)
+		if (FUSED) tkv = ticket_sh[(round + 1) & 1]; // (on its way while the stores drain)
 		if (FUSED && !absent) {
 			// publish: this wave's stores were written through (sc1); once they have left the wave the strip's counter
 			// may move (every storing wave drains its own stores and signals its own unit)
@@ -1010,7 +1000,7 @@ __global__ void __launch_bounds__(THREADS) ham_ballot_to_planes_k(uint64_t *__re
 // (contexts may be driven from several host threads, one each: the cache is filled under a lock)
 static int ballot_resident_wgs(int v, const void *fn, int threads, int cus) {
 	static std::mutex mu;
-	static int cache[16][128];
+	static int cache[16][64];
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
 	std::lock_guard<std::mutex> lock(mu);
@@ -1032,7 +1022,6 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	const bool subl = p.slY != 0;
 	const bool streamed = fused && p.nt_stream;
 	const bool batch = fused && p.nrep > 0;
-	if (p.static_units && (!fused || batch || usej || subl)) p.static_units = 0;
 	if (batch && (usej || subl || NT != BAL_THREADS)) return hipErrorInvalidValue;
 	if (fused && subl && (usej || NT != BAL_THREADS || p.slY % p.H != 0)) return hipErrorInvalidValue; // (ising_capi.cpp keeps those on one launch per colour)
 	if (batch) { // a level = the units of all lattices
@@ -1040,23 +1029,8 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 		p.nwg = p.nwg_rep * p.nrep;
 		p.rep_magic = (uint32_t)((0x100000000ull + (unsigned long long)p.nwg_rep - 1) / (unsigned long long)p.nwg_rep);
 	}
-	// kernel instance: bit 0 couplings, 1 sub-lattices, 2 fused, 3 non-temporal lattice words, 4 batched, 5 static units
-	int v = (usej ? 1 : 0) | (subl ? 2 : 0) | (fused ? 4 : 0) | (streamed ? 8 : 0) | (batch ? 16 : 0);
-	if (p.static_units) {
-		// every workgroup of the grid must be resident at once: what the occupancy query admits, at most six per CU (the scalar-
-		// register rule of the guide: the query may say seven where the hardware admits six), else tickets
-		if (p.cus <= 0) { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256; p.cus = n; }
-		const void *sfn = streamed ? (const void *)ballot_update_k<false, false, true, BAL_THREADS, true, false, true> : (const void *)ballot_update_k<false, false, true, BAL_THREADS, false, false, true>;
-		long long room = std::min<long long>(ballot_resident_wgs((v | 32) + (NT == 256 ? 0 : 64), sfn, NT, p.cus), 6LL * p.cus);
-		if (p.grid_cap > 0) room = std::min<long long>(room, p.grid_cap);
-		else if (p.wg_per_cu > 0) room = std::min<long long>(room, (long long)p.wg_per_cu * p.cus);
-		if (room < 1) room = 1;
-		// k = ceil(units / room) units of a level per workgroup, the grid as small as that allows (the same number for every workgroup
-		// where the level divides: a workgroup with one unit more than the others is what every level waits for)
-		const long long k = ((long long)p.nwg + room - 1) / room;
-		p.static_units = (int32_t)(((long long)p.nwg + k - 1) / k);
-		v |= 32;
-	}
+	// kernel instance: bit 0 couplings, 1 sub-lattices, 2 fused, 3 non-temporal lattice words, 4 batched
+	const int v = (usej ? 1 : 0) | (subl ? 2 : 0) | (fused ? 4 : 0) | (streamed ? 8 : 0) | (batch ? 16 : 0);
 	// (the launch is `LAUNCH(instance)`: hipExtLaunchKernelGGL needs the template arguments as written)
 #define BAL_INSTANCES(X)                                                                                              \
 	X(0, (ballot_update_k<false, false, false, NT>))                                                                   \
@@ -1070,9 +1044,7 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	X(13, (ballot_update_k<false, true, true, BAL_THREADS, true>))                                                     \
 	X(14, (ballot_update_k<true, false, true, BAL_THREADS, true>))                                                     \
 	X(20, (ballot_update_k<false, false, true, BAL_THREADS, false, true>))                                             \
-	X(28, (ballot_update_k<false, false, true, BAL_THREADS, true, true>))                                              \
-	X(36, (ballot_update_k<false, false, true, BAL_THREADS, false, false, true>))                                      \
-	X(44, (ballot_update_k<false, false, true, BAL_THREADS, true, false, true>))
+	X(28, (ballot_update_k<false, false, true, BAL_THREADS, true, true>))
 	const void *fn = nullptr;
 	switch (v) {
 #define BAL_FN(code, inst) case code: fn = (const void *)inst; break;
@@ -1091,10 +1063,8 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 		p.cus = n;
 	}
 	const int cus = p.cus;
-	long long grid = fused ? std::min<long long>(std::min(ballot_resident_wgs(v + (NT == 256 ? 0 : 64), fn, NT, cus), ballot_max_wgs(cus) * 256 / NT), total) : total;
-	if (p.static_units) {
-		grid = p.static_units; // every workgroup resident, units blockIdx, blockIdx + grid, ... of each level
-	} else if (fused) {
+	long long grid = fused ? std::min<long long>(std::min(ballot_resident_wgs(v + (NT == 256 ? 0 : 32), fn, NT, cus), ballot_max_wgs(cus) * 256 / NT), total) : total;
+	if (fused) {
 		// Fewer workgroups than the chip holds when a level has few tickets: a unit's parents are one level = p.nwg tickets
 		// back, and a workgroup that finds them unfinished holds its slot asleep (ising_create picks wg_per_cu)
 		if (p.grid_cap > 0) grid = std::min<long long>(grid, p.grid_cap); // (ISING_FUSED_WGS, read when the context was created)

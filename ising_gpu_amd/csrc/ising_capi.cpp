@@ -44,7 +44,6 @@ int read_policy(ising_policy *pol) {
 	if (num("ISING_FUSED_TICKETS2", &v)) pol->fused_tickets2 = (v == 2 || v == 4) ? v : (v ? 2 : 0);
 	if (num("ISING_FUSED_WGS", &v)) pol->fused_wgs = v > 0 ? v : 0;
 	if (num("ISING_FUSED_MAX_SWEEPS", &v)) pol->fused_max_sweeps = v > 0 ? v : 0;
-	if (num("ISING_FUSED_STATIC", &v)) pol->fused_static = v != 0;
 	if (num("ISING_RING_GHOST", &v)) pol->ring_ghost = v;
 	pol->no_ballot = getenv("ISING_NO_BALLOT") != nullptr;
 	if (const char *e = getenv("ISING_TAIL")) {
@@ -443,7 +442,6 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		const long long T0 = fused_tickets(c->nwc(), cfg->Y, c->H); // (without a ring slab's ghost rows)
 		c->fused_tickets2 = (T0 <= 2048 && c->H == 1) ? 4 : ((T0 <= 1024 && c->H == 2) ? 2 : 0);
 		if (pol.fused_tickets2 >= 0) c->fused_tickets2 = pol.fused_tickets2;
-		c->fused_static = pol.fused_static > 0 && fused_shape && !cfg->XSL && !cfg->use_J; // (experimental in this commit: by request only)
 	}
 
 	hipError_t e = hipSetDevice(cfg->device);

@@ -74,8 +74,6 @@ struct UpdateParams {
 	uint32_t abort_polls;
 	int32_t cus;              // compute units of the device: workgroup b of a persistent grid is in dispatch round b / cus (host: 0 = ask)
 	int32_t grid_cap;         // fused: explicit size of the persistent grid (tests, A/B; 0: by wg_per_cu; host side only)
-	int32_t static_units;     // fused: no tickets -- every workgroup of the (wholly resident) grid works on units blockIdx, blockIdx + grid, ...
-	                          // of every level (ising_ballot.hip: STATIC); in: requested; out (set by the launcher): the grid, 0 = tickets after all
 	const struct ReplicaParams *rep;
 	int32_t nrep, nwg_rep;
 	uint32_t rep_magic;       // ceil(2^32 / nwg_rep)

@@ -112,7 +112,6 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			p.wg_per_cu = c->fused_wg_per_cu;
 			p.nt_stream = c->fused_nt;
 			p.done_base = c->done_base;
-			p.static_units = (c->fused_static && c->wrap && lo0 == 0 && hi0 == c->cfg.Y) ? 1 : 0; // (the launcher clears it when the grid would not be resident at once)
 			if (lo0 < 0 || hi0 > c->cfg.Y) { // ghost rows are rows of the neighbouring slabs
 				p.total_rows = c->cfg.nslabs * c->cfg.Y;
 				p.trapezoid = c->pol.trapezoid ? 1 : 0;
@@ -140,9 +139,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			c->done_base += (uint32_t)nlevels * (uint32_t)c->nwc();
 			// where the launch leaves the counter(s): its units, and every workgroup drew one ticket too many
 			const unsigned long long total = (unsigned long long)p.nwg * (unsigned long long)nlevels;
-			if (p.static_units) {
-				// (no ticket was drawn)
-			} else if (p.tickets2 > 1) { // units and workgroups of class k = those numbered k mod K
+			if (p.tickets2 > 1) { // units and workgroups of class k = those numbered k mod K
 				const unsigned long long K = (unsigned long long)p.tickets2;
 				for (unsigned long long k = 0; k < K; k++) c->ticket_base2[k] += (total + K - 1 - k) / K + ((unsigned long long)grid + K - 1 - k) / K;
 			} else {

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Fused launches without tickets (ISING_FUSED_STATIC=1: one resident workgroup per unit of a level, ising_ballot.hip STATIC) against the
+"""(Round 4; needs the library at commit 851dc8e: the STATIC form was measured, lost and was removed -- profiles/static_probe_r04a/b.txt.)
+Fused launches without tickets (ISING_FUSED_STATIC=1: one resident workgroup per unit of a level, ising_ballot.hip STATIC) against the
 library's default, by strip height, on lattices whose level fits the chip.  Every case also checks counts and bond sum against the
 default path after the same sweeps.  Usage: static_probe.py [X Y ...]  -> flips/ns"""
 import os
