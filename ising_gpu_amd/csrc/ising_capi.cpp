@@ -44,7 +44,6 @@ int read_policy(ising_policy *pol) {
 	if (num("ISING_FUSED_TICKETS2", &v)) pol->fused_tickets2 = (v == 2 || v == 4) ? v : (v ? 2 : 0);
 	if (num("ISING_FUSED_WGS", &v)) pol->fused_wgs = v > 0 ? v : 0;
 	if (num("ISING_FUSED_MAX_SWEEPS", &v)) pol->fused_max_sweeps = v > 0 ? v : 0;
-	if (num("ISING_SWEEP_GRAPH", &v)) pol->sweep_graph = v != 0;
 	if (num("ISING_RING_GHOST", &v)) pol->ring_ghost = v;
 	pol->no_ballot = getenv("ISING_NO_BALLOT") != nullptr;
 	if (const char *e = getenv("ISING_TAIL")) {
@@ -513,8 +512,6 @@ int ising_destroy(ising_ctx *c) {
 #endif
 	if (!c) return ISING_OK;
 	(void)hipSetDevice(c->cfg.device);
-	(void)hipStreamSynchronize(c->stream);
-	ising_host::sweep_graph_release(c);
 	if (c->own_stream) { (void)hipStreamSynchronize(c->own_stream); (void)hipStreamDestroy(c->own_stream); }
 	if (c->h_meas) (void)hipHostFree(c->h_meas);
 	if (c->h_abort) (void)hipHostFree(c->h_abort);

@@ -20,7 +20,6 @@ struct ising_policy {
 	int fused_nt = -1;       // ISING_FUSED_NT=0/1: non-temporal lattice words (-1: lattices above 2^31 spins)
 	int fused_tickets2 = -1; // ISING_FUSED_TICKETS2=0/2/4: ticket counters (-1: by strip height)
 	int fused_wgs = 0;       // ISING_FUSED_WGS=n: persistent grid of n workgroups (0: by tickets per level)
-	int sweep_graph = -1;    // ISING_SWEEP_GRAPH=0/1: one launch per colour replayed from a hipGraph (-1: lattices up to 2^26 spins on the dense / nibble layouts)
 	int fused_max_sweeps = 0; // ISING_FUSED_MAX_SWEEPS=n: sweeps one fused launch of a single slab carries at most (0: ~50 ms worth, 32 .. 4096)
 	int ring_ghost = -1;     // ISING_RING_GHOST=n: ghost rows of ballot ring slabs (-1: 64)
 	bool no_ballot = false;  // ISING_NO_BALLOT: layout AUTO never picks the ballot layout
@@ -116,21 +115,6 @@ struct ising_ctx {
 	bool go_set = false;                         // ... and it stands for the exchange that delivered the current ghost rows
 	bool overlap_next = false;                   // one-shot request to launch_ranges: the next deep launch takes part in the overlap
 	hipEvent_t launch_start_next = nullptr, launch_stop_next = nullptr; // one-shot: events on the next launch's dispatch packet
-	// Sweep graphs (ising_update.cpp): small lattices sweep one launch per colour and are bound by the launches themselves (two per
-	// sweep, ~6 us each from the host: 4096^2 12 us per sweep for ~6 us of kernels), so K sweeps = 2 K launches are captured ONCE into
-	// a hipGraph and replayed; the nodes take the iteration from *d_it (their own arguments are fixed), a last node adds K to it.
-	struct sweep_graph_t {
-		hipGraph_t graph = nullptr;
-		hipGraphExec_t exec = nullptr;
-		hipStream_t cap = nullptr;        // the stream the launches are captured on (never runs anything)
-		uint32_t *d_it = nullptr;         // iteration of the next replay's first sweep
-		int K = 0;
-		uint32_t n3 = 0, n4 = 0;          // what the captured launches carry: a temperature change rebuilds the graph
-		float tab[10] = {};
-		int mode = -1;
-		bool failed = false;              // capture / instantiate / launch did not work here: one launch per colour from now on
-	} sg;
-	const uint32_t *it_dev_next = nullptr; // while a graph is captured: UpdateParams.it_dev of the launches
 	// Exchange statistics (ising_exchange_stats_begin / _fetch; sweep_deep_overlapped): four events per sampled exchange --
 	// [4e] launch e begins, [4e+1] launch e ends (both on its dispatch packet), [4e+2] comm stream: the launch's edge strips have
 	// finished their last level (the exchange starts), [4e+3] comm stream: the neighbours' rows are in place and edge_go has moved.
@@ -225,7 +209,6 @@ int check_abort(ising_ctx *c);
 int read_policy(ising_policy *pol);
 // sweeps of a slab that needs nothing from its neighbours (a single slab that wraps in place, a slab of sub-lattices)
 int sweep_alone(ising_ctx *c, int first_it, int nsweeps);
-void sweep_graph_release(ising_ctx *c); // the captured sweep graph, if any (ising_destroy)
 // sweeps one fused launch of `spins` spins (all lattices of a batch) carries at most: a launch costs ~60 us whatever it
 // carries, so small lattices get long launches (ising_capi.cpp)
 int fused_sweeps_per_launch(const ising_policy &pol, long long spins);

@@ -19,7 +19,6 @@ struct UpdateParams {
 	long long mirL_bytes;     //   previous slab's row Y), row Y-1's copy mirL_bytes behind row Y-1 (own row -1 / next slab's row -1)
 	uint32_t seed_lo, seed_hi;
 	uint32_t it;              // reference's 1-based iteration index (0 for init)
-	const uint32_t *it_dev;   // dense / nibble kernels: when set, *it_dev is added to `it` (launches replayed from a graph)
 	uint32_t color;           // 0 black, 1 white
 	int32_t gx;               // X/2048: 32-vector column groups per row (= reference gridDim.x)
 	int32_t Y;                // rows in this slab

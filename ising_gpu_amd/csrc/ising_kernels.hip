@@ -179,13 +179,10 @@ __global__ void __launch_bounds__(THREADS) update_k(const UpdateParams p) {
 	const ptrdiff_t mir0 = (ptrdiff_t)(p.mir0_bytes / 16), mirL = (ptrdiff_t)(p.mirL_bytes / 16); // see ballot_update_k
 
 	const uint32_t k2y = p.seed_hi + 2u * PHILOX_W1;
-	// (a launch that is a node of a replayed graph takes the iteration of the replay's first sweep from device memory: its own
-	// arguments are fixed when the graph is built -- ising_update.cpp, sweep graphs)
-	const uint32_t it = p.it_dev ? p.it + __builtin_amdgcn_readfirstlane(*p.it_dev) : p.it;
-	const uint32_t cx_base = 16u * (2u * it + p.color);
+	const uint32_t cx_base = 16u * (2u * p.it + p.color);
 	// The draw-block counter 16(2 it + colour) + b is 64 bits wide in cuRAND; its high word (non-zero from iteration
 	// 2^27 on) enters round 1 next to key word 0, so it folds into the seed operand of the per-row setup.
-	const uint32_t seed_lo_cy = p.seed_lo ^ (uint32_t)((2ull * it + p.color) >> 28);
+	const uint32_t seed_lo_cy = p.seed_lo ^ (uint32_t)((2ull * p.it + p.color) >> 28);
 
 	const ptrdiff_t uo = (slY && r0_in_sl == 0) ? (ptrdiff_t)(slY - 1) * vecs : -(ptrdiff_t)vecs;
 	uint4 up0 = pc[uo], up1 = pc[uo + GROUP];

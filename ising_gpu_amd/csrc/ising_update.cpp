@@ -4,8 +4,6 @@
 // arithmetic on the lattice is in ising_ballot.hip / ising_dense.hip / ising_kernels.hip.
 #include "ising_ctx.hpp"
 
-#include <hip/hip_runtime.h>
-
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -63,7 +61,6 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	p.seed_lo = (uint32_t)c->cfg.seed;
 	p.seed_hi = (uint32_t)(c->cfg.seed >> 32);
 	p.it = (uint32_t)it;
-	p.it_dev = c->it_dev_next;
 	p.color = (uint32_t)color;
 	p.gx = c->gx;
 	p.Y = c->cfg.Y;
@@ -211,82 +208,10 @@ extern "C" int ising_sweep(ising_ctx *c, int first_it, int nsweeps) {
 	return ising_host::sweep_alone(c, first_it, nsweeps);
 }
 
-// ---- sweep graphs.  Lattices too small for fused launches (under 1.5 * 2^24 spins: the dense layout, one launch per colour) are
-// bound by the launches, not by the kernels: 4096^2 takes 12.3 us per sweep for two kernels of ~3 us each, 2048^2 9.5 us -- the host
-// needs ~6 us to prepare and submit a launch.  The hardware's own kernel boundary is the cheapest device-wide barrier there is (~1.5 us
-// back to back, MI355X_MICROARCH.md: cheaper than any grid barrier in software), so the remedy is to keep the queue full: 2 K launches
-// = K sweeps are captured once into a hipGraph and replayed.  A graph's kernel arguments are fixed when it is built; the one
-// that changes -- the iteration -- comes from device memory (UpdateParams.it_dev), and the graph's last node advances it by K.
-// (Round 4 also measured the alternatives the verdict named: fused launches with one-row units on the ballot layout at these sizes
-// -- tickets and ticket-free -- lose to this form except at 8192 x 2048, +5 %: profiles/static_probe_r04a.txt.)
-namespace {
-
-constexpr int SWEEP_GRAPH_K = 16;
-
-__global__ void __launch_bounds__(64) it_set_k(uint32_t *p, uint32_t v) { if (threadIdx.x == 0) *p = v; }
-__global__ void __launch_bounds__(64) it_add_k(uint32_t *p, uint32_t k) { if (threadIdx.x == 0) *p += k; }
-
-bool sweep_graph_applies(const ising_ctx *c) {
-	if (c->sg.failed || c->ballot) return false; // (ballot slabs of this size sweep in fused launches)
-	if (c->pol.sweep_graph >= 0) return c->pol.sweep_graph != 0;
-	return (long long)c->cfg.X * c->cfg.Y <= (1LL << 26);
-}
-
-// the graph of SWEEP_GRAPH_K sweeps at the context's current temperature, built on first use and after a temperature change
-int sweep_graph_ready(ising_ctx *c) {
-	ising_ctx::sweep_graph_t &g = c->sg;
-	const int mode = ising_host::needs_generic(c) ? 1 : 0;
-	if (g.exec && g.n3 == (uint32_t)c->thr[3] && g.n4 == (uint32_t)c->thr[4] && g.mode == mode && !memcmp(g.tab, c->tab, sizeof(g.tab))) return ISING_OK;
-	if (int rc = bind(c)) return rc;
-	auto give_up = [&](const char *what, hipError_t e) {
-		(void)hipGetLastError();
-		g.failed = true; // (quietly: the caller sweeps one launch per colour)
-		return fail(ISING_E_HIP, "%s: %s", what, hipGetErrorString(e));
-	};
-	if (g.exec) { (void)hipStreamSynchronize(c->stream); (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
-	if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; }
-	hipError_t e = hipSuccess;
-	if (!g.cap) e = hipStreamCreateWithFlags(&g.cap, hipStreamNonBlocking);
-	if (e == hipSuccess && !g.d_it) e = hipMalloc((void **)&g.d_it, 64);
-	if (e != hipSuccess) return give_up("sweep graph resources", e);
-	if ((e = hipStreamBeginCapture(g.cap, hipStreamCaptureModeThreadLocal)) != hipSuccess) return give_up("hipStreamBeginCapture", e);
-	hipStream_t keep = c->stream;
-	c->stream = g.cap;
-	c->it_dev_next = g.d_it;
-	int rc = ISING_OK;
-	for (int k = 0; k < SWEEP_GRAPH_K && rc == ISING_OK; k++)
-		for (int color = 0; color < 2 && rc == ISING_OK; color++) rc = ising_update_color(c, k, color, 0, c->cfg.Y);
-	if (rc == ISING_OK) {
-		hipLaunchKernelGGL(it_add_k, dim3(1), dim3(64), 0, g.cap, g.d_it, (uint32_t)SWEEP_GRAPH_K);
-		if (hipGetLastError() != hipSuccess) rc = ISING_E_HIP;
-	}
-	c->stream = keep;
-	c->it_dev_next = nullptr;
-	e = hipStreamEndCapture(g.cap, &g.graph);
-	if (rc != ISING_OK || e != hipSuccess) {
-		if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; }
-		return give_up("capturing the sweep graph", e);
-	}
-	if ((e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0)) != hipSuccess) { g.exec = nullptr; return give_up("hipGraphInstantiate", e); }
-	g.n3 = (uint32_t)c->thr[3];
-	g.n4 = (uint32_t)c->thr[4];
-	g.mode = mode;
-	memcpy(g.tab, c->tab, sizeof(g.tab));
-	g.K = SWEEP_GRAPH_K;
-	return ISING_OK;
-}
-
-} // namespace
-
-void ising_host::sweep_graph_release(ising_ctx *c) {
-	ising_ctx::sweep_graph_t &g = c->sg;
-	if (g.exec) (void)hipGraphExecDestroy(g.exec);
-	if (g.graph) (void)hipGraphDestroy(g.graph);
-	if (g.cap) (void)hipStreamDestroy(g.cap);
-	if (g.d_it) (void)hipFree(g.d_it);
-	g = ising_ctx::sweep_graph_t();
-}
-
+// (Lattices too small for fused launches -- under 1.5 * 2^24 spins: the dense layout, one launch per colour -- take ~6 us per launch:
+// 4096^2 12.0 us per sweep, 2048^2 9.6 us.  Round 4 replayed the launches from a captured hipGraph, the iteration coming from device
+// memory: bit-exact and NOT faster, 0.96 .. 1.02 x (profiles/sweep_graph_probe_r04.txt; the code is in the history at 9f35ffa) -- the
+// host keeps up; what a launch costs is the kernel itself at two waves per SIMD plus the device-side boundary between two kernels.)
 // `nsweeps` sweeps of a slab that needs nothing from its neighbours: a single slab that wraps in place, or a slab of
 // sub-lattices (also one of several: nothing crosses slabs, optimized/main.cu:1423-1462)
 int ising_host::sweep_alone(ising_ctx *c, int first_it, int nsweeps) {
@@ -300,23 +225,6 @@ int ising_host::sweep_alone(ising_ctx *c, int first_it, int nsweeps) {
 			left -= ns;
 		}
 		return ISING_OK;
-	}
-	// small lattices on the dense / nibble layouts: whole groups of SWEEP_GRAPH_K sweeps replayed from a captured graph
-	if (sweep_graph_applies(c) && nsweeps >= 2 * SWEEP_GRAPH_K) {
-		if (sweep_graph_ready(c) == ISING_OK) {
-			const int groups = nsweeps / SWEEP_GRAPH_K;
-			hipLaunchKernelGGL(it_set_k, dim3(1), dim3(64), 0, c->stream, c->sg.d_it, (uint32_t)first_it);
-			hipError_t e = hipGetLastError();
-			for (int g = 0; g < groups && e == hipSuccess; g++) e = hipGraphLaunch(c->sg.exec, c->stream);
-			if (e != hipSuccess) {
-				(void)hipGetLastError();
-				c->sg.failed = true;
-				return fail(ISING_E_HIP, "replaying the sweep graph failed: %s", hipGetErrorString(e));
-			}
-			c->ghost_depth[0] = c->ghost_depth[1] = 0;
-			first_it += groups * SWEEP_GRAPH_K;
-			nsweeps -= groups * SWEEP_GRAPH_K;
-		}
 	}
 	for (int it = first_it; it < first_it + nsweeps; it++) {
 		if (int rc = ising_update_color(c, it, ISING_BLACK, 0, c->cfg.Y)) return rc;

@@ -192,26 +192,19 @@ def test_wide_lattice_and_empty_ranges(gpu, oracle_mod):
 
 @pytest.mark.parametrize("layout", [ig.LAYOUT_DENSE, ig.LAYOUT_NIBBLE], ids=["dense", "nibble"])
 @pytest.mark.parametrize("X,Y", [(2048, 256), (4096, 128), (6144, 64)])
-def test_sweep_graphs_replay_the_same_trajectory(gpu, oracle_mod, monkeypatch, X, Y, layout):
-    """Small lattices sweep one launch per colour, replayed from a captured hipGraph in groups of 16 sweeps (csrc/ising_update.cpp:
-    the nodes take their iteration from device memory).  Calls long enough to replay (>= 32 sweeps) and the remainders around them,
-    a temperature change in between (the graph is rebuilt), a generic-kernel temperature, a private stream: the full state equals the
-    oracle's after every call -- and equals what the library does with the graphs switched off."""
+def test_long_calls_with_temperature_changes_on_small_lattices(gpu, oracle_mod, X, Y, layout):
+    """Small lattices (one launch per colour): calls of many sweeps, a temperature change between them, a temperature that needs the
+    generic kernel, a private stream -- the full state equals the oracle's after every call."""
     seed, calls = 97, ((37, 2.0), (5, 2.0), (64, 1.7), (33, 0.0), (48, 2.4))
     orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=2.0).init()
-    got = {}
-    for graphs in ("1", "0"):
-        monkeypatch.setenv("ISING_SWEEP_GRAPH", graphs)
-        with ig.IsingSlab(X, Y, seed=seed, temp=2.0, layout=layout) as s:
-            s.init()
-            for k, (n, t) in enumerate(calls):
-                if k == 3:
-                    s.use_private_stream()
-                s.set_temperature(t)
-                s.sweep(n)
-                if graphs == "1":
-                    orc.temp = float(np.float32(t))
-                    orc.sweep(n)
-                    _compare(s, orc, f"after call {k} ({n} sweeps at T = {t})")
-            got[graphs] = (s.count(), s.bond_equal())
-    assert got["1"] == got["0"] == (orc.count(), orc.bond_equal())
+    with ig.IsingSlab(X, Y, seed=seed, temp=2.0, layout=layout) as s:
+        s.init()
+        for k, (n, t) in enumerate(calls):
+            if k == 3:
+                s.use_private_stream()
+            s.set_temperature(t)
+            s.sweep(n)
+            orc.temp = float(np.float32(t))
+            orc.sweep(n)
+            _compare(s, orc, f"after call {k} ({n} sweeps at T = {t})")
+        assert (s.count(), s.bond_equal()) == (orc.count(), orc.bond_equal())

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Lattices under 1.5 * 2^24 spins (the dense layout, one launch per colour): sweeps replayed from a captured hipGraph (default) against
+"""(Round 4; needs the library at commit 9f35ffa: the sweep graphs were measured -- no gain -- and removed; profiles/sweep_graph_probe_r04.txt.)
+Lattices under 1.5 * 2^24 spins (the dense layout, one launch per colour): sweeps replayed from a captured hipGraph (default) against
 one launch per colour from the host (ISING_SWEEP_GRAPH=0).  Usage: small_probe.py [X Y ...] -> flips/ns, us per sweep"""
 import os
 import subprocess
