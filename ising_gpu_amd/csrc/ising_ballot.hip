@@ -147,6 +147,9 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 // one-launch-per-colour launches, 3458 -> 3389: their workgroups are not a persistent grid; the fifth and sixth wave of a SIMD
 // stepping the other way round.  What remains uneven: the fifth and sixth wave still own all the units that take three times
 // the median, 7 % of the units at 65536^2.)
+#ifndef ISING_FUSED_WAIT_LATE // 1: units of two rows and more draw their first row before they wait for their parents (A/B: make variant DEFS=-DISING_FUSED_WAIT_LATE=0)
+#define ISING_FUSED_WAIT_LATE 1
+#endif
 #ifndef ISING_FUSED_STAGGER // s_sleep units (64 cycles each) between the start of successive dispatch rounds of a fused launch
 #define ISING_FUSED_STAGGER 100
 #endif
@@ -406,17 +409,29 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			dp = p.done + (BATCH ? rep * p.done_stride : 0) + sd;
 			// (inline assembly like the row loop's loads: a tracked load here makes the compiler guard `seen`'s register with
 			// vmcnt(0) waits all through the row loop)
-			if (lane < 3) asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(seen) : "v"(dp) : "memory");
+			// (a unit that waits late looks when it waits: a look requested here would sit in a register the compiler knows nothing
+			// about through a whole draw phase)
+			if (lane < 3 && !(ISING_FUSED_WAIT_LATE && p.wait_late != 0)) asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(seen) : "v"(dp) : "memory");
 		}
 		if (lane < 16) {
 			const PhiloxBlockConst kc = philox_block_const(cx_base + (uint32_t)lane, seed_lo, seed_hi);
 			blk_const[lane] = make_uint4(kc.s0, kc.s1, kc.s2, 0u);
 		}
-		if (must_wait) {
+		auto wait_parents = [&]() {
+			if (!must_wait) return;
 			[[maybe_unused]] int nsleep = 0;
 			uint32_t npoll = 0;
-			for (;;) { // few, patient polls: every poll is a trip to memory that competes with the lattice traffic
+			// The first look (requested above, or -- a unit that waits late -- here) is consumed ONCE, behind its wait and outside the loop;
+			// every later look loads and waits in one statement.  The compiler knows nothing of inline-assembly loads: a loop-carried copy of a
+			// register whose load is still in flight captures the OLD value -- rounds 2-3 polled with `load ... loop { wait; test }` and the
+			// generated code copied the register in front of the loop (`v_mov v0, v63` ... `v_mov v63, v0`, `s_waitcnt`): harmless while
+			// the load landed outside those few cycles, wrong whenever it landed between the two copies.
+			if (ISING_FUSED_WAIT_LATE && p.wait_late != 0) {
+				if (lane < 3) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(seen) : "v"(dp) : "memory");
+			} else {
 				asm volatile("s_waitcnt vmcnt(0)" : "+v"(seen) :: "memory");
+			}
+			for (;;) { // few, patient polls: every poll is a trip to memory that competes with the lattice traffic
 				if (__all((int32_t)(seen - need) >= 0)) break;
 				// Counters that never come (bases out of step with the device after a faulted launch): stop waiting.  The unit
 				// that has polled abort_polls times raises a flag in pinned host memory, every waiting unit looks at it every 64th
@@ -450,10 +465,16 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				TRN(7, (nsleep == 256));
 #endif
 				__builtin_amdgcn_s_sleep(32);
-				if (lane < 3) asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(seen) : "v"(dp) : "memory");
+				if (lane < 3) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(seen) : "v"(dp) : "memory");
 			}
 			TRC(2); // completion counters (+ block constants)
-		}
+		};
+		// Where the unit waits for its parents.  Its first draw phase needs nothing from the lattice -- counters, seed, thresholds --,
+		// so a launch may ask its units to draw their first row BEFORE they wait (UpdateParams.wait_late, round 4): a parent that is a
+		// row's time late then costs nothing, and a level can feed more workgroups before its units run into each other.  The host asks
+		// for it where a level has few tickets per workgroup (ising_capi.cpp); where parents are never late it costs ~0.5 %.
+		const bool wait_late = FUSED && ISING_FUSED_WAIT_LATE && p.wait_late != 0;
+		if (!wait_late) wait_parents();
 		if (edge_unit && level == 0) {
 			// the exchange that follows the previous launch has read this slab's first / last rows and filled its ghost rows
 			// once the comm stream has moved the counter (usually long ago: the exchange starts when the previous launch's
@@ -497,8 +518,10 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			if (FUSED) {
 				// (sub-lattices, fused: strips never straddle a period -- slY is a multiple of H --, so the row above a strip's
 				// first row is the only one that may lie a period away, :414)
-				ld64_coh_issue<STREAM>(up0, rs + ((SUBL && r0_in_sl == 0) ? (ptrdiff_t)(slY - 1) * wpr : -(ptrdiff_t)wpr), lane * 8);
-				ld64_coh_issue<STREAM>(ct0, rs, lane * 8);
+				if (!wait_late) {
+					ld64_coh_issue<STREAM>(up0, rs + ((SUBL && r0_in_sl == 0) ? (ptrdiff_t)(slY - 1) * wpr : -(ptrdiff_t)wpr), lane * 8);
+					ld64_coh_issue<STREAM>(ct0, rs, lane * 8);
+				}
 			} else {
 				up = ld_word<false>(rs + lane + ((SUBL && r0_in_sl == 0) ? (ptrdiff_t)(slY - 1) * wpr : -(ptrdiff_t)wpr));
 				ct = ld_word<false>(rs + lane);
@@ -532,6 +555,13 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			unsigned long long sA0 = 0, sA1 = 0, sC = 0;
 			uint64_t vC = 0;
 			const uint32_t grow_p = grow_w; // global row of row r0 + r - 1, this iteration's word phase (the draw phase below moves grow_w on)
+			if (wait_late && r == 1) { // the first row is drawn: now the parents, then the unit's first two rows (on their way during draw phase 1)
+				wait_parents();
+				if (!idle) {
+					ld64_coh_issue<STREAM>(up0, rs + ((SUBL && r0_in_sl == 0) ? (ptrdiff_t)(slY - 1) * wpr : -(ptrdiff_t)wpr), lane * 8);
+					ld64_coh_issue<STREAM>(ct0, rs, lane * 8);
+				}
+			}
 			if (r > 0 && r <= nrows) {
 				const uint32_t grow = grow_p;
 				const bool back = (color == 0) ? !(grow & 1u) : (grow & 1u);

@@ -18,6 +18,7 @@ struct ising_batch {
 	std::vector<ising_ctx *> m;
 	int device = 0;
 	int H = 1, wg_per_cu = 0, nt = 0, nstrips = 0;
+	bool wait_late = true;                                   // units draw their first row before they wait for their parents (UpdateParams.wait_late)
 	ising::ReplicaParams *d_rep = nullptr, *h_rep = nullptr; // the lattices' records: device copy and pinned staging
 	hipEvent_t ev_upload = nullptr;                          // the last upload has left the staging buffer
 	bool upload_pending = false;
@@ -97,7 +98,8 @@ int ising_batch_create(ising_ctx **ctxs, int n, ising_batch **out) {
 	const ising_ctx *c0 = ctxs[0];
 	b->device = c0->cfg.device;
 	// strips as tall as a level of ALL lattices allows (8192^2 x 31: 8 rows, five workgroups per CU; alone: 2 rows, three)
-	ising_host::fused_shape(c0->nwc(), c0->cfg.Y, (long long)c0->cfg.Y * n, &b->H, &b->wg_per_cu);
+	b->wait_late = c0->pol.fused_wait_late != 0;
+	ising_host::fused_shape(c0->nwc(), c0->cfg.Y, (long long)c0->cfg.Y * n, &b->H, &b->wg_per_cu, b->wait_late);
 	b->nstrips = c0->cfg.Y / b->H;
 	// lattices that together exceed the 256 MB memory-side cache stream through it (ising_capi.cpp: fused_nt)
 	b->nt = (long long)c0->cfg.X * c0->cfg.Y * n > (1LL << 31);
@@ -178,6 +180,7 @@ int ising_batch_sweep(ising_batch *b, int first_it, int nsweeps) {
 		p.done_stride = b->nstrips + 2;
 		p.done_base = b->done_base;
 		p.wg_per_cu = b->wg_per_cu;
+		p.wait_late = b->wait_late ? 1 : 0;
 		p.nt_stream = b->nt;
 		p.rep = b->d_rep;
 		p.nrep = b->n();

@@ -44,6 +44,7 @@ int read_policy(ising_policy *pol) {
 	if (num("ISING_FUSED_TICKETS2", &v)) pol->fused_tickets2 = (v == 2 || v == 4) ? v : (v ? 2 : 0);
 	if (num("ISING_FUSED_WGS", &v)) pol->fused_wgs = v > 0 ? v : 0;
 	if (num("ISING_FUSED_MAX_SWEEPS", &v)) pol->fused_max_sweeps = v > 0 ? v : 0;
+	if (num("ISING_FUSED_WAIT_LATE", &v)) pol->fused_wait_late = v != 0;
 	if (num("ISING_RING_GHOST", &v)) pol->ring_ghost = v;
 	pol->no_ballot = getenv("ISING_NO_BALLOT") != nullptr;
 	if (const char *e = getenv("ISING_TAIL")) {
@@ -161,7 +162,18 @@ long long fused_tickets(int nwc, int Y, int H) { return ((long long)nwc * ((Y + 
 // (round 3: the sixth from 8192 tickets -- the throughput is what counts, and the accept-mask slots' extra traffic is far from any
 // limit: 65536^2 3500 -> 3525 flips/ns, --steps 20 --warmup 5 3490 -> 3510, three alternating runs each on one box.  Ring slabs keep
 // five below 16384 tickets: their transport's kernels want room next to the launch, RCCL's 132 vector registers per lane.)
-int fused_wgs_for(long long T) { return T >= 8192 ? 6 : (T >= 4096 ? 5 : (T >= 2048 ? 4 : (T >= 1024 ? 3 : (T >= 684 ? 2 : 1)))); }
+// Round 4: units draw their first row before they wait for their parents (UpdateParams.wait_late), so a parent that is a row's time
+// late costs nothing and a level of few tickets feeds more workgroups -- the more the shorter its units are (tools/wait_late_probe.py,
+// profiles/wait_late_probe_r04.txt: 8192 x 4096, H = 1, T = 1024: 2305 with three per CU, 2587 with six; 8192^2, H = 2, T = 1024: 2767
+// -> 2915 with five; 16384 x 8192, H = 4, T = 1024: 3051 -> 3110 with four; 16384^2, H = 4, T = 2048: 3298 -> 3315 with five; from
+// T = 4096 up nothing moves).  `late` = 0 gives the rule of rounds 2-3 (ISING_FUSED_WAIT_LATE=0).
+int fused_wgs_for(long long T, int H = 16, bool late = false) {
+	if (late && T >= 1024 && T < 4096) {
+		if (T >= 2048) return H <= 1 ? 6 : 5;
+		return H <= 1 ? 6 : (H == 2 ? 5 : 4);
+	}
+	return T >= 8192 ? 6 : (T >= 4096 ? 5 : (T >= 2048 ? 4 : (T >= 1024 ? 3 : (T >= 684 ? 2 : 1))));
+}
 // flips/ns of strips of H rows at wg workgroups per CU where T is ample (tools/grid_probe2.py on 65536^2 .. 131072^2, 24576^2,
 // 32768 x 16384, 16384^2, 8192^2 at the end of round 2).  One- and two-row units draw tickets from several counters.
 int fused_score(int H, int wg) {
@@ -202,7 +214,7 @@ int ising_host::fused_sweeps_per_launch(const ising_policy &pol, long long spins
 
 // strip height and workgroups per CU of fused launches over `rows` rows of wave columns in all (ising_batch.cpp: the rows of
 // every lattice of a batch), strips dividing Y
-void ising_host::fused_shape(int nwc, int Y, long long rows, int *H, int *wg_per_cu) {
+void ising_host::fused_shape(int nwc, int Y, long long rows, int *H, int *wg_per_cu, bool late) {
 	int best = 1, best_score = -1;
 	for (int h = 1; h <= 16; h <<= 1) {
 		if (Y % h) break;
@@ -211,7 +223,7 @@ void ising_host::fused_shape(int nwc, int Y, long long rows, int *H, int *wg_per
 		if (score >= best_score) { best = h; best_score = score; }
 	}
 	*H = best;
-	*wg_per_cu = fused_wgs_for(((long long)nwc * ((rows + best - 1) / best) + 3) / 4);
+	*wg_per_cu = fused_wgs_for(((long long)nwc * ((rows + best - 1) / best) + 3) / 4, best, late);
 }
 
 namespace {
@@ -434,7 +446,8 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	c->fused_nt = pol.fused_nt >= 0 ? pol.fused_nt : (spins > (1LL << 31));
 	if (fused_shape || deep_ring) { // workgroups per CU of a fused launch (the chip holds 6 of 4 waves)
 		const long long T = fused_tickets(c->nwc(), launch_rows, c->H);
-		c->fused_wg_per_cu = fused_wgs_for(T);
+		c->fused_wait_late = pol.fused_wait_late != 0; // (default on: free where parents are never late, 65536^2 3528.6 vs 3527.4)
+		c->fused_wg_per_cu = fused_wgs_for(T, c->H, c->fused_wait_late);
 		if (deep_ring && T < 16384) c->fused_wg_per_cu = std::min(c->fused_wg_per_cu, 5);
 		// Several ticket counters where 4-wave workgroups draw one- or two-row units (2^26 spins): one counter hands out
 		// ~80 tickets per us; 8192^2 with one-row units at 2600 flips/ns needs 159 (four counters), with two-row units

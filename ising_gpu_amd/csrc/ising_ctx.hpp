@@ -20,6 +20,7 @@ struct ising_policy {
 	int fused_nt = -1;       // ISING_FUSED_NT=0/1: non-temporal lattice words (-1: lattices above 2^31 spins)
 	int fused_tickets2 = -1; // ISING_FUSED_TICKETS2=0/2/4: ticket counters (-1: by strip height)
 	int fused_wgs = 0;       // ISING_FUSED_WGS=n: persistent grid of n workgroups (0: by tickets per level)
+	int fused_wait_late = -1; // ISING_FUSED_WAIT_LATE=0/1: units of fused launches draw their first row before they wait for their parents (-1: by tickets per level)
 	int fused_max_sweeps = 0; // ISING_FUSED_MAX_SWEEPS=n: sweeps one fused launch of a single slab carries at most (0: ~50 ms worth, 32 .. 4096)
 	int ring_ghost = -1;     // ISING_RING_GHOST=n: ghost rows of ballot ring slabs (-1: 64)
 	bool no_ballot = false;  // ISING_NO_BALLOT: layout AUTO never picks the ballot layout
@@ -58,6 +59,7 @@ struct ising_ctx {
 	int fused_nt = 0;              // ... whose lattice words carry the non-temporal hint (lattice larger than the 256 MB memory-side cache)
 	unsigned long long ticket_base2[4] = {0, 0, 0, 0}; // fused launches: where the launches so far left the ticket counter(s)
 	int fused_tickets2 = 0;                      // ... two counters (small lattices: one cannot hand tickets out fast enough)
+	bool fused_wait_late = false;  // ... whose units draw their first row before they wait for their parents (UpdateParams.wait_late)
 	int tail_rows = 0, tail_h = 0; // plain full-slab launches: the last tail_rows rows go in strips of tail_h rows
 	uint64_t *d_pack = nullptr;    // staging for device-side conversion to / from the packed boundary format
 	size_t pack_words = 0;
@@ -213,7 +215,7 @@ int sweep_alone(ising_ctx *c, int first_it, int nsweeps);
 // carries, so small lattices get long launches (ising_capi.cpp)
 int fused_sweeps_per_launch(const ising_policy &pol, long long spins);
 // launch shape of fused launches by tickets per level (ising_capi.cpp)
-void fused_shape(int nwc, int Y, long long rows, int *H, int *wg_per_cu);
+void fused_shape(int nwc, int Y, long long rows, int *H, int *wg_per_cu, bool late = false);
 constexpr size_t SLOTCTL_TICKET_BYTES = 9 * 64; // ticket words in front of the completion counters (d_slotctl)
 
 } // namespace ising_host

@@ -2,8 +2,10 @@
 """Build-time check of the fused ballot kernels' hand-waited loads (ising_ballot.hip issues them as inline assembly, so the
 compiler does not know they are in flight): in the generated ISA no instruction may touch a register an inline-assembly
 global_load_dwordx2 / x4 (lattice words, accept masks) wrote before the inline-assembly s_waitcnt vmcnt that covers it.
-The scan is linear in text order, which is program order for the row loop these loads live in (the completion-counter
-poll, a dword load in a spin loop of its own, is waited for right behind its issue and is not part of the scan).
+The scan is linear in text order, which is program order for the row loop these loads live in.  The looks at the completion
+counters (dword loads) are part of the scan since round 4: a look either carries its wait in the same statement or is waited for
+once, outside any loop, by the code that follows it in the text -- rounds 2-3 polled in a loop whose header held the wait, and
+the compiler's loop-carried copy of the register sat between the load and the wait.
 usage: check_asm_loads.py ising_ballot.s   (hipcc -S --cuda-device-only output)"""
 import re, sys
 
@@ -36,7 +38,10 @@ while i < len(lines):
         in_asm = i > 0 and "#ASMSTART" in lines[i - 1] or (i > 1 and "#ASMSTART" in lines[i - 2] and "#ASMEND" not in lines[i - 1])
         body = ln.split(";")[0].strip()
         if body and not body.endswith(":"):
-            if in_asm and (body.startswith("global_load_dwordx2") or body.startswith("global_load_dwordx4")):
+            fused_wait = i + 1 < len(lines) and lines[i + 1].split(";")[0].strip().startswith("s_waitcnt vmcnt(0)")  # load and wait in ONE statement
+            if in_asm and body.startswith("global_load_dword ") and fused_wait:
+                used = operands(body.split(",", 1)[1])
+            elif in_asm and (body.startswith("global_load_dwordx2") or body.startswith("global_load_dwordx4") or body.startswith("global_load_dword ")):
                 dst = regs(body.split()[1].rstrip(","))
                 for r in dst:
                     pending[r] = i + 1
