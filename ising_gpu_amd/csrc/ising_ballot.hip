@@ -407,11 +407,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				sd = sd < 0 ? sd + nstr : (sd >= nstr ? sd - nstr : sd);
 			}
 			dp = p.done + (BATCH ? rep * p.done_stride : 0) + sd;
-			// (inline assembly like the row loop's loads: a tracked load here makes the compiler guard `seen`'s register with
-			// vmcnt(0) waits all through the row loop)
-			// (a unit that waits late looks when it waits: a look requested here would sit in a register the compiler knows nothing
-			// about through a whole draw phase)
-			if (lane < 3 && !(ISING_FUSED_WAIT_LATE && p.wait_late != 0)) asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(seen) : "v"(dp) : "memory");
+			// (the look itself is taken where the unit waits, load and wait in one statement: wait_parents below)
 		}
 		if (lane < 16) {
 			const PhiloxBlockConst kc = philox_block_const(cx_base + (uint32_t)lane, seed_lo, seed_hi);
@@ -421,16 +417,13 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			if (!must_wait) return;
 			[[maybe_unused]] int nsleep = 0;
 			uint32_t npoll = 0;
-			// The first look (requested above, or -- a unit that waits late -- here) is consumed ONCE, behind its wait and outside the loop;
-			// every later look loads and waits in one statement.  The compiler knows nothing of inline-assembly loads: a loop-carried copy of a
+			// Every look at the counters loads and waits in ONE statement.  The compiler knows nothing of inline-assembly loads: a loop-carried copy of a
 			// register whose load is still in flight captures the OLD value -- rounds 2-3 polled with `load ... loop { wait; test }` and the
 			// generated code copied the register in front of the loop (`v_mov v0, v63` ... `v_mov v63, v0`, `s_waitcnt`): harmless while
 			// the load landed outside those few cycles, wrong whenever it landed between the two copies.
-			if (ISING_FUSED_WAIT_LATE && p.wait_late != 0) {
-				if (lane < 3) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(seen) : "v"(dp) : "memory");
-			} else {
-				asm volatile("s_waitcnt vmcnt(0)" : "+v"(seen) :: "memory");
-			}
+			// (inline assembly like the row loop's loads: a tracked load makes the compiler guard `seen`'s register with vmcnt(0) waits all
+			// through the row loop)
+			if (lane < 3) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(seen) : "v"(dp) : "memory");
 			for (;;) { // few, patient polls: every poll is a trip to memory that competes with the lattice traffic
 				if (__all((int32_t)(seen - need) >= 0)) break;
 				// Counters that never come (bases out of step with the device after a faulted launch): stop waiting.  The unit
@@ -473,7 +466,10 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		// so a launch may ask its units to draw their first row BEFORE they wait (UpdateParams.wait_late, round 4): a parent that is a
 		// row's time late then costs nothing, and a level can feed more workgroups before its units run into each other.  The host asks
 		// for it where a level has few tickets per workgroup (ising_capi.cpp); where parents are never late it costs ~0.5 %.
-		const bool wait_late = FUSED && ISING_FUSED_WAIT_LATE && p.wait_late != 0;
+		// (wait_late = 2: behind the SECOND row's draw phase as well -- units of two rows have then drawn all they will before they wait;
+		// the first word phase's loads are no longer hidden by a draw phase, which costs where parents are never late)
+		const int late_mode = (FUSED && ISING_FUSED_WAIT_LATE) ? uni(p.wait_late) : 0;
+		const bool wait_late = late_mode != 0;
 		if (!wait_late) wait_parents();
 		if (edge_unit && level == 0) {
 			// the exchange that follows the previous launch has read this slab's first / last rows and filled its ghost rows
@@ -537,6 +533,9 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		// one scalar-cache write-back per workgroup and row: every wave runs the same number of iterations and meets at a barrier
 		const int rmax = Hr;
 		const bool wb_wave = threadIdx.x < 64;
+		// (Round 4 also requested the next ticket a row early -- an inline-assembly atomic at the top of the last-but-one iteration, picked up
+		// behind that iteration's word-phase wait, its ~2 us under a draw phase: no gain, -1 % at 8192^2 (profiles/ticket_early_probe_r04.txt):
+		// a ticket that is reserved while its workgroup still works delays the unit it names, as in round 2.)
 		for (int r = 0; r <= rmax; ++r) {
 			// rotating priorities: the waves that share a SIMD (one per dispatch round) take turns at the front
 			if (FUSED) {
@@ -555,14 +554,15 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			unsigned long long sA0 = 0, sA1 = 0, sC = 0;
 			uint64_t vC = 0;
 			const uint32_t grow_p = grow_w; // global row of row r0 + r - 1, this iteration's word phase (the draw phase below moves grow_w on)
-			if (wait_late && r == 1) { // the first row is drawn: now the parents, then the unit's first two rows (on their way during draw phase 1)
+			const bool late_here = wait_late && r == 1; // the first row is drawn: now the parents, then the unit's first two rows
+			if (late_here && late_mode == 1) {          // (on their way during draw phase 1)
 				wait_parents();
 				if (!idle) {
 					ld64_coh_issue<STREAM>(up0, rs + ((SUBL && r0_in_sl == 0) ? (ptrdiff_t)(slY - 1) * wpr : -(ptrdiff_t)wpr), lane * 8);
 					ld64_coh_issue<STREAM>(ct0, rs, lane * 8);
 				}
 			}
-			if (r > 0 && r <= nrows) {
+			if (r > 0 && r <= nrows && !(late_here && late_mode == 2)) {
 				const uint32_t grow = grow_p;
 				const bool back = (color == 0) ? !(grow & 1u) : (grow & 1u);
 				const uint64_t *qc = rs + (back ? u_cb : u_cf);
@@ -613,6 +613,15 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 					             :: "s"(t3), "s"(t4), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(dstp)
 					             : "memory", BAL_CLOB16);
 				});
+			}
+			if (late_here && late_mode == 2) { // ... behind draw phase 1 too: the parents, the first two rows and the row-end word of row 0
+				wait_parents();
+				if (!idle) {
+					ld64_coh_issue<STREAM>(up0, rs + ((SUBL && r0_in_sl == 0) ? (ptrdiff_t)(slY - 1) * wpr : -(ptrdiff_t)wpr), lane * 8);
+					ld64_coh_issue<STREAM>(ct0, rs, lane * 8);
+					const bool back1 = (color == 0) ? !(grow_p & 1u) : (grow_p & 1u);
+					ld64_coh_issue<STREAM>(vC, rs + (back1 ? u_cb : u_cf), 0);
+				}
 			}
 			TRC(4); // draw phase
 			if (FUSED && r == rmax && wi == 0) { // wave-uniform branch; read by the workgroup after this unit's last barrier

@@ -180,7 +180,7 @@ int ising_batch_sweep(ising_batch *b, int first_it, int nsweeps) {
 		p.done_stride = b->nstrips + 2;
 		p.done_base = b->done_base;
 		p.wg_per_cu = b->wg_per_cu;
-		p.wait_late = b->wait_late ? 1 : 0;
+		p.wait_late = b->wait_late ? (c0->pol.fused_wait_late == 1 ? 1 : 2) : 0;
 		p.nt_stream = b->nt;
 		p.rep = b->d_rep;
 		p.nrep = b->n();

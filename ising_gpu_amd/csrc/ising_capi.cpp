@@ -44,7 +44,7 @@ int read_policy(ising_policy *pol) {
 	if (num("ISING_FUSED_TICKETS2", &v)) pol->fused_tickets2 = (v == 2 || v == 4) ? v : (v ? 2 : 0);
 	if (num("ISING_FUSED_WGS", &v)) pol->fused_wgs = v > 0 ? v : 0;
 	if (num("ISING_FUSED_MAX_SWEEPS", &v)) pol->fused_max_sweeps = v > 0 ? v : 0;
-	if (num("ISING_FUSED_WAIT_LATE", &v)) pol->fused_wait_late = v != 0;
+	if (num("ISING_FUSED_WAIT_LATE", &v)) pol->fused_wait_late = v < 0 ? 0 : (v > 2 ? 2 : v);
 	if (num("ISING_RING_GHOST", &v)) pol->ring_ghost = v;
 	pol->no_ballot = getenv("ISING_NO_BALLOT") != nullptr;
 	if (const char *e = getenv("ISING_TAIL")) {
@@ -162,17 +162,17 @@ long long fused_tickets(int nwc, int Y, int H) { return ((long long)nwc * ((Y + 
 // (round 3: the sixth from 8192 tickets -- the throughput is what counts, and the accept-mask slots' extra traffic is far from any
 // limit: 65536^2 3500 -> 3525 flips/ns, --steps 20 --warmup 5 3490 -> 3510, three alternating runs each on one box.  Ring slabs keep
 // five below 16384 tickets: their transport's kernels want room next to the launch, RCCL's 132 vector registers per lane.)
-// Round 4: units draw their first row before they wait for their parents (UpdateParams.wait_late), so a parent that is a row's time
-// late costs nothing and a level of few tickets feeds more workgroups -- the more the shorter its units are (tools/wait_late_probe.py,
-// profiles/wait_late_probe_r04.txt: 8192 x 4096, H = 1, T = 1024: 2305 with three per CU, 2587 with six; 8192^2, H = 2, T = 1024: 2767
-// -> 2915 with five; 16384 x 8192, H = 4, T = 1024: 3051 -> 3110 with four; 16384^2, H = 4, T = 2048: 3298 -> 3315 with five; from
-// T = 4096 up nothing moves).  `late` = 0 gives the rule of rounds 2-3 (ISING_FUSED_WAIT_LATE=0).
+// Round 4: units draw their first TWO rows before they wait for their parents (UpdateParams.wait_late = 2), so a parent that is up to two
+// rows' time late costs nothing and a level of few tickets feeds more workgroups -- the more the shorter its units are: units of one
+// or two rows have drawn everything they will before they wait (tools/wait_late_probe.py, profiles/wait_late_probe_r04.txt and
+// wait_late2_probe_r04.txt; flips/ns at the rule below against rounds 2-3's: 8192 x 4096 2820 (H = 2, T = 512) vs 2305 (H = 1), 8192^2
+// 3087 vs 2767, 16384 x 8192 3246 vs 3051, 16384^2 3330 vs 3298; from T = 4096 up nothing moves, 65536^2 3532.8 vs 3531.8).
+// `late` = false gives the rule of rounds 2-3 (ISING_FUSED_WAIT_LATE=0).
 int fused_wgs_for(long long T, int H = 16, bool late = false) {
-	if (late && T >= 1024 && T < 4096) {
-		if (T >= 2048) return H <= 1 ? 6 : 5;
-		return H <= 1 ? 6 : (H == 2 ? 5 : 4);
-	}
-	return T >= 8192 ? 6 : (T >= 4096 ? 5 : (T >= 2048 ? 4 : (T >= 1024 ? 3 : (T >= 684 ? 2 : 1))));
+	const int base = T >= 8192 ? 6 : (T >= 4096 ? 5 : (T >= 2048 ? 4 : (T >= 1024 ? 3 : (T >= 684 ? 2 : 1))));
+	if (!late || T >= 4096) return base;
+	if (H <= 2) return T >= 2048 ? 6 : (T >= 1024 ? 5 : (T >= 512 ? 4 : base));
+	return T >= 1024 ? base + 1 : base;
 }
 // flips/ns of strips of H rows at wg workgroups per CU where T is ample (tools/grid_probe2.py on 65536^2 .. 131072^2, 24576^2,
 // 32768 x 16384, 16384^2, 8192^2 at the end of round 2).  One- and two-row units draw tickets from several counters.
@@ -438,6 +438,9 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	c->H = cfg->strip_rows > 0 ? cfg->strip_rows
 	       : ((fused_shape || deep_ring) ? choose_fused_strip_rows(c->nwc(), cfg->XSL ? cfg->YSL : cfg->Y, launch_rows)
 	                                     : choose_strip_rows(c->gx, cfg->Y, c->dense, c->ballot));
+	// (units that draw before they wait: two-row units with 512 tickets a level beat one-row units with 1024 -- 8192 x 4096 2820 vs 2660)
+	if (cfg->strip_rows <= 0 && (fused_shape || deep_ring) && c->H == 1 && pol.fused_wait_late != 0 && (cfg->XSL ? cfg->YSL : cfg->Y) % 2 == 0 &&
+	    fused_tickets(c->nwc(), launch_rows, 2) >= 512) c->H = 2;
 	if (cfg->Y % c->H) { const int h = c->H; delete c; return fail(ISING_E_ARG, "strip_rows %d does not divide Y %d", h, cfg->Y); }
 	c->nstrips = cfg->Y / c->H;
 	c->color_words = (size_t)cfg->Y * c->lld;

@@ -74,7 +74,7 @@ struct UpdateParams {
 	uint32_t abort_polls;
 	int32_t cus;              // compute units of the device: workgroup b of a persistent grid is in dispatch round b / cus (host: 0 = ask)
 	int32_t grid_cap;         // fused: explicit size of the persistent grid (tests, A/B; 0: by wg_per_cu; host side only)
-	int32_t wait_late;        // fused: units draw their first row before they wait for their parents (levels with few tickets per workgroup)
+	int32_t wait_late;        // fused: units draw their first row (2: their first two rows) before they wait for their parents
 	const struct ReplicaParams *rep;
 	int32_t nrep, nwg_rep;
 	uint32_t rep_magic;       // ceil(2^32 / nwg_rep)

@@ -110,7 +110,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			p.jham[1] = c->cfg.use_J ? c->ham(0) : nullptr;
 			p.done = c->d_slotctl + SLOTCTL_TICKET_BYTES / 4;
 			p.wg_per_cu = c->fused_wg_per_cu;
-			p.wait_late = c->fused_wait_late ? 1 : 0;
+			p.wait_late = c->fused_wait_late ? (c->pol.fused_wait_late == 1 ? 1 : 2) : 0; // (default 2: behind the second draw phase)
 			p.nt_stream = c->fused_nt;
 			p.done_base = c->done_base;
 			if (lo0 < 0 || hi0 > c->cfg.Y) { // ghost rows are rows of the neighbouring slabs

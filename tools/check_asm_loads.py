@@ -41,7 +41,8 @@ while i < len(lines):
             fused_wait = i + 1 < len(lines) and lines[i + 1].split(";")[0].strip().startswith("s_waitcnt vmcnt(0)")  # load and wait in ONE statement
             if in_asm and body.startswith("global_load_dword ") and fused_wait:
                 used = operands(body.split(",", 1)[1])
-            elif in_asm and (body.startswith("global_load_dwordx2") or body.startswith("global_load_dwordx4") or body.startswith("global_load_dword ")):
+            elif in_asm and (body.startswith("global_load_dwordx2") or body.startswith("global_load_dwordx4") or body.startswith("global_load_dword ")
+                             or (body.startswith("global_atomic_add_x2") and " sc0" in body)):  # (a returning atomic: the next ticket)
                 dst = regs(body.split()[1].rstrip(","))
                 for r in dst:
                     pending[r] = i + 1

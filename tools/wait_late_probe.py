@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""A/B: fused launches whose units draw their first row before they wait for their parents (ISING_FUSED_WAIT_LATE=1) against units that
-wait first (=0), by strip height and workgroups per CU.
+"""A/B: fused launches whose units draw their first two rows (ISING_FUSED_WAIT_LATE=2, the default) or their first row (=1) before they wait for
+their parents against units that wait first (=0), by strip height and workgroups per CU.  (profiles/ticket_early_probe_r04.txt was made with this
+script too, at a commit that could request the next ticket a row early: ISING_FUSED_TICKET_EARLY.)
 Usage: wait_late_probe.py [X Y ...] -> flips/ns"""
 import os
 import subprocess
@@ -31,9 +32,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "case":
     sys.exit(0)
 
 sizes = [tuple(map(int, sys.argv[i:i + 2])) for i in range(1, len(sys.argv), 2)] or [(8192, 4096), (8192, 8192), (16384, 8192), (16384, 16384), (24576, 24576), (32768, 32768), (65536, 65536)]
-libs = {"late": "1", "early": "0"}  # ISING_FUSED_WAIT_LATE
+libs = {"late2": "2", "late1": "1", "early": "0"}  # ISING_FUSED_WAIT_LATE: 0 wait first; 1 behind the first draw phase; 2 (default) behind the second too
 for X, Y in sizes:
-    print(f"{Y} x {X}: rows = strip height (0 = the library's choice), columns = workgroups per CU (0 = the library's choice); late / early", flush=True)
+    print(f"{Y} x {X}: rows = strip height (0 = the library's choice), columns = workgroups per CU (0 = the library's choice); late2 / late1 / early", flush=True)
     ref = None
     for H in (0, 1, 2, 4, 8, 16):
         if H and (Y % H or (X * Y >= (1 << 30) and H < 8) or (X * Y <= (1 << 28) and H > 8) or (X * Y <= (1 << 26) and H > 4) or (X * Y > (1 << 26) and H < 2)):
