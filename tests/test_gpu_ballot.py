@@ -120,7 +120,7 @@ def test_auto_layout_picks_ballot_where_it_applies(gpu):
     with ig.IsingSlab(8192, 8192, temp=1.5, nslabs=2, J_prob=0.2) as s:   # (with -J too)
         assert s.layout == BAL and s.fused
     with ig.IsingSlab(8192, 4096, temp=1.5) as s:       # ... down to 2^25 spins
-        assert s.layout == BAL and s.fused and s.strip_rows == 1
+        assert s.layout == BAL and s.fused and s.strip_rows == 2  # (round 4: units draw before they wait -- two-row units with 512 tickets a level)
     with ig.IsingSlab(8192, 2048, temp=1.5) as s:       # small slabs: the dense kernel is ahead
         assert s.layout == ig.LAYOUT_DENSE
     with ig.IsingSlab(20480, 8192, temp=1.5) as s:      # 10 column groups = 2.5 wave columns: too many dead lanes
