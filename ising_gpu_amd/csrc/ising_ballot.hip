@@ -535,7 +535,10 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		const bool wb_wave = threadIdx.x < 64;
 		// (Round 4 also requested the next ticket a row early -- an inline-assembly atomic at the top of the last-but-one iteration, picked up
 		// behind that iteration's word-phase wait, its ~2 us under a draw phase: no gain, -1 % at 8192^2 (profiles/ticket_early_probe_r04.txt):
-		// a ticket that is reserved while its workgroup still works delays the unit it names, as in round 2.)
+		// a ticket that is reserved while its workgroup still works delays the unit it names, as in round 2.  And, requested in the last iteration
+		// as ever but picked up behind the last word phase instead of in front of the barrier -- the atomic under that phase's loads, the
+		// ticket handed to the other waves through LDS: -0.1 .. -0.3 % everywhere (profiles/ticket_async_probe_r04.txt).  The 4 % of a
+		// workgroup's time that the trace books on "next ticket" is time in which the SIMD's other waves have the vector ALU.)
 		for (int r = 0; r <= rmax; ++r) {
 			// rotating priorities: the waves that share a SIMD (one per dispatch round) take turns at the front
 			if (FUSED) {
