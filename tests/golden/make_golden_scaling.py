@@ -23,7 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
 import oracle  # noqa: E402
 
-OUT = os.path.join(HERE, "scaling.json")
+OUT = os.environ.get("ISING_GOLDEN_OUT", os.path.join(HERE, "scaling.json"))  # (ISING_GOLDEN_OUT: a run on another host, e.g. a GPU box's 16 cores under gpurun)
 POINTS = (0, 5, 25, 144)
 LATTICES = {  # name -> (X, Ytot), cheapest first
     "c4n1": (131072, 16384), "c4n2": (131072, 32768), "c3n2": (65536, 131072), "c4n4": (131072, 65536),
@@ -53,6 +53,8 @@ def main():
             rec = {"name": name, "X": X, "Ytot": Y, "points": []}
             doc["lattices"].append(rec)
         rec["points"] = []  # (the oracle's state is not kept between runs: a partial record starts over)
+        if os.environ.get("ISING_GOLDEN_THREADS"):
+            oracle.set_threads(int(os.environ["ISING_GOLDEN_THREADS"]))
         L = oracle.OracleLattice(X, Y, seed=1234, temp=oracle.CRIT_TEMP).init()
         t0 = time.time()
         for s in POINTS:
