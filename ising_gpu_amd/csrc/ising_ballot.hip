@@ -147,7 +147,7 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 // one-launch-per-colour launches, 3458 -> 3389: their workgroups are not a persistent grid; the fifth and sixth wave of a SIMD
 // stepping the other way round.  What remains uneven: the fifth and sixth wave still own all the units that take three times
 // the median, 7 % of the units at 65536^2.)
-#ifndef ISING_FUSED_WAIT_LATE // 1: units of two rows and more draw their first row before they wait for their parents (A/B: make variant DEFS=-DISING_FUSED_WAIT_LATE=0)
+#ifndef ISING_FUSED_WAIT_LATE // 1: fused launches may ask their units to draw before they wait for their parents (UpdateParams.wait_late); 0 compiles the request out
 #define ISING_FUSED_WAIT_LATE 1
 #endif
 #ifndef ISING_FUSED_STAGGER // s_sleep units (64 cycles each) between the start of successive dispatch rounds of a fused launch
@@ -462,12 +462,12 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			}
 			TRC(2); // completion counters (+ block constants)
 		};
-		// Where the unit waits for its parents.  Its first draw phase needs nothing from the lattice -- counters, seed, thresholds --,
-		// so a launch may ask its units to draw their first row BEFORE they wait (UpdateParams.wait_late, round 4): a parent that is a
-		// row's time late then costs nothing, and a level can feed more workgroups before its units run into each other.  The host asks
-		// for it where a level has few tickets per workgroup (ising_capi.cpp); where parents are never late it costs ~0.5 %.
-		// (wait_late = 2: behind the SECOND row's draw phase as well -- units of two rows have then drawn all they will before they wait;
-		// the first word phase's loads are no longer hidden by a draw phase, which costs where parents are never late)
+		// Where the unit waits for its parents.  A draw phase needs nothing from the lattice -- counter words, seed, thresholds --, so a
+		// launch may ask its units to draw BEFORE they wait (UpdateParams.wait_late, round 4): 1 = behind the first row's draw phase,
+		// 2 (what the host asks for) = behind the second row's as well; the unit's first two rows and its first row-end word are
+		// requested behind the wait.  A parent that is up to two rows' time late then costs nothing -- units of one or two rows have
+		// drawn everything they will --, and a level of few tickets feeds more workgroups before its units run into each other
+		// (ising_capi.cpp: fused_wgs_for; 8192^2 2767 -> 3087 flips/ns); where parents are never late it is free (65536^2 3532.8 vs 3531.8).
 		const int late_mode = (FUSED && ISING_FUSED_WAIT_LATE) ? uni(p.wait_late) : 0;
 		const bool wait_late = late_mode != 0;
 		if (!wait_late) wait_parents();
