@@ -398,12 +398,18 @@ def main():
         barrier()
         t0 = time.perf_counter()
         ncounts, done, last = 0, 0, None
-        while done < args.steps:
-            n = min(16, args.steps - done)
-            advance(n, min(batch, n))
-            last = ring.count() if ring is not None else slab.count()  # (blocking: two 64-bit counters come back, as :860-866)
-            ncounts += 1
-            done += n
+        if ring is None:
+            # a lone slab: the print points ride INSIDE the fused launches (ising_sweep_counted: the units that store the words count
+            # them) -- every iteration that is a multiple of 16, as the reference's loop prints -- and the final count as ever
+            ncounts = len(slab.sweep_counted(args.steps, 16)) + 1
+            last = slab.count()
+        else:
+            while done < args.steps:
+                n = min(16, args.steps - done)
+                advance(n, min(batch, n))
+                last = ring.count()  # (blocking: the ranks' counters come back and are summed, as :860-866)
+                ncounts += 1
+                done += n
         barrier()
         dt2 = time.perf_counter() - t0
         if ringed:
@@ -412,8 +418,10 @@ def main():
             dt2 = float(t[0])
         counts_leg = {"value": round(total_flips / (dt2 * 1e9), 2), "unit": "flips/ns", "ms_per_step": round(dt2 * 1e3 / args.steps, 5),
                       "counts_in_timed_region": ncounts, "final_counts_equal_first_leg": last == (up, down),
-                      "what": "the same steps with up/down counts read back every 16 sweeps and after the last one inside the timed region "
-                              "(the reference's -p 16 methodology, optimized/main.cu:1806-1810)"}
+                      "what": "the same steps with the up/down counts of every iteration that is a multiple of 16, and of the last one, inside the timed "
+                              "region (the reference's -p 16 methodology, optimized/main.cu:1806-1810)"
+                              + ("; N = 1: counted inside the fused launches (ising_sweep_counted), read back with the last" if ring is None else
+                                 "; rings: a blocking count of all ranks every 16 sweeps")}
 
     layout_name, layout_text = {
         ig.LAYOUT_NIBBLE: ("nibble", "reference 4 bit/spin"),

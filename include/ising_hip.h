@@ -184,6 +184,14 @@ int ising_strip_info(ising_ctx *ctx, int *strip_rows, int *nstrips);
 /* nslabs == 1 only: `nsweeps` full sweeps, black then white, iterations first_it .. first_it+nsweeps-1
  * (the hot loop, optimized/main.cu:1763-1805). */
 int ising_sweep(ising_ctx *ctx, int first_it, int nsweeps);
+/* The hot loop WITH its print points (optimized/main.cu:1763-1810: the sweeps, and countSpins whenever the iteration is a multiple of
+ * printFreq -- every number the reference publishes was measured with `-p 16` inside the timed loop).  nslabs == 1 only: `nsweeps` full
+ * sweeps, iterations first_it .. first_it+nsweeps-1; ups[k] = the number of up spins after the k-th iteration `it` of them with
+ * it % every == 0 (at most max_counts; *ncounts = how many).  Where ising_sweep issues fused launches the counts are taken INSIDE the
+ * launches, by the units that store the words -- no launch boundary, no count kernel and no read-back between two print points (16384^2
+ * with a count every 16 sweeps: 3057 -> 3290 flips/ns) --; on the other layouts and with sub-lattices or couplings the call sweeps and
+ * counts in turn.  Blocking: the counts are read back when the last launch is done. */
+int ising_sweep_counted(ising_ctx *ctx, int first_it, int nsweeps, int every, uint64_t *ups, int max_counts, int *ncounts);
 /* How ising_sweep launches right now: *fused = 1 when it issues fused launches (ballot layout from 1.5 * 2^24 spins up, or
  * ISING_FUSED=1: one launch carries up to *max_sweeps_per_launch sweeps = twice as many colour half-sweeps, handed out to
  * a chip-filling grid through in-order tickets; ising_ballot.hip), 0 when it issues one launch per colour.  For a ring slab

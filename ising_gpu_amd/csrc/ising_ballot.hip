@@ -180,8 +180,15 @@ typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 // (16384^2: 3119 vs 3321 flips/ns at two units per workgroup and level, 2967 vs 3211 at one; 8192^2 2510 vs 2793; 32768^2 3179 vs 3475;
 // profiles/static_probe_r04a.txt, _r04b.txt; the code is in the history at 851dc8e): the 6 % of a workgroup's time that tickets cost
 // buy a load balance between workgroups of unequal speed that is worth more -- with fixed owners every level waits for its slowest.)
-template <bool SUBL, bool USEJ, bool FUSED, int NT = BAL_THREADS, bool STREAM = false, bool BATCH = false>
+// COUNT (round 4; fused launches of a lone lattice): the up-spin count of the reference's print points (countSpins every `-p` sweeps,
+// optimized/main.cu:1806-1810) is taken INSIDE the launch.  A print point every 16 sweeps otherwise cuts the launches into pieces of 16
+// with two count launches and a read-back in between (16384^2: 3057 against 3289 flips/ns, 8192^2 2539 against 3023).  Here every unit
+// of a measured sweep's two levels takes the popcount of the words it stores -- two v_bcnt per row -- and leaves its sum in a slot of
+// its own (measurement, colour, wave); a small kernel behind the launches adds the slots up.  (Plain stores: the first form added to 64
+// accumulators per measurement with atomics -- 32768 waves a level at 65536^2 queued at the L2 for ~0.4 ms a level, -4 %.)
+template <bool SUBL, bool USEJ, bool FUSED, int NT = BAL_THREADS, bool STREAM = false, bool BATCH = false, bool COUNT = false>
 __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const UpdateParams p) {
+	static_assert(!COUNT || (FUSED && !SUBL && !USEJ && !BATCH), "in-launch counts: fused launches of one lattice, no sub-lattices, no couplings");
 	static_assert(!BATCH || (FUSED && !SUBL && !USEJ), "batched launches: fused, no sub-lattices, no couplings");
 	static_assert(!(FUSED && SUBL && USEJ), "fused launches with sub-lattices: no couplings");
 	const int lane = threadIdx.x & 63;
@@ -533,6 +540,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		// one scalar-cache write-back per workgroup and row: every wave runs the same number of iterations and meets at a barrier
 		const int rmax = Hr;
 		const bool wb_wave = threadIdx.x < 64;
+		[[maybe_unused]] uint32_t cnt_up = 0; // COUNT: up spins among the words this lane stores in this unit
 		// (Round 4 also requested the next ticket a row early -- an inline-assembly atomic at the top of the last-but-one iteration, picked up
 		// behind that iteration's word-phase wait, its ~2 us under a draw phase: no gain, -1 % at 8192^2 (profiles/ticket_early_probe_r04.txt):
 		// a ticket that is reserved while its workgroup still works delays the unit it names, as in round 2.  And, requested in the last iteration
@@ -703,6 +711,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 					rj += 4 * wpr;
 				}
 				const uint64_t nw = me ^ (flips64(me, nu, nc, nd, sd, c3, c4) & live);
+				if (COUNT) cnt_up += (uint32_t)__popcll(nw); // (dead lanes are zero in memory)
 				if (FUSED) {
 					st64_coh_issue<STREAM>(rd, lane * 8, nw);
 					if (p.wrap) { // the halo rows that mirror this colour's edge rows
@@ -744,6 +753,14 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				if ((te - t_unit1) / (16384ll * p.H / 8) >= 12) tr[10 + min(3u, dround)] += 1; // long units by dispatch round (3: fourth and later)
 			}
 #endif
+			if (COUNT) { // level 2j and 2j + 1 are the black and the white half of the launch's sweep j: both add to its measurement
+				const int swp = level >> 1;
+				if ((p.cnt_mask >> swp) & 1ull) {
+					const unsigned long long tot = wave_sum((unsigned long long)cnt_up);
+					const int meas = p.cnt_slot0 + (int)__popcll(p.cnt_mask & ((1ull << swp) - 1ull));
+					if (lane == 0) p.cnt_acc[((size_t)meas * 2 + (size_t)(level & 1)) * ((size_t)p.nwg * (NT / 64)) + (size_t)wave] = (uint32_t)tot;
+				}
+			}
 			if (lane == 0) __hip_atomic_fetch_add(p.done + (BATCH ? rep * p.done_stride : 0) + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			// last level: the rows the next exchange sends are final and the ghost rows no longer read
 			if (edge_unit && level == p.nlevels - 1 && lane == 0) __hip_atomic_fetch_add(p.edge_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1042,7 +1059,7 @@ __global__ void __launch_bounds__(THREADS) ham_ballot_to_planes_k(uint64_t *__re
 // (contexts may be driven from several host threads, one each: the cache is filled under a lock)
 static int ballot_resident_wgs(int v, const void *fn, int threads, int cus) {
 	static std::mutex mu;
-	static int cache[16][64];
+	static int cache[16][128];
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
 	std::lock_guard<std::mutex> lock(mu);
@@ -1064,6 +1081,8 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	const bool subl = p.slY != 0;
 	const bool streamed = fused && p.nt_stream;
 	const bool batch = fused && p.nrep > 0;
+	const bool count = p.cnt_acc != nullptr;
+	if (count && (!fused || batch || usej || subl || p.color != 0 || p.nlevels > 128)) return hipErrorInvalidValue; // (ising_update.cpp asks only where it applies)
 	if (batch && (usej || subl || NT != BAL_THREADS)) return hipErrorInvalidValue;
 	if (fused && subl && (usej || NT != BAL_THREADS || p.slY % p.H != 0)) return hipErrorInvalidValue; // (ising_capi.cpp keeps those on one launch per colour)
 	if (batch) { // a level = the units of all lattices
@@ -1071,8 +1090,8 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 		p.nwg = p.nwg_rep * p.nrep;
 		p.rep_magic = (uint32_t)((0x100000000ull + (unsigned long long)p.nwg_rep - 1) / (unsigned long long)p.nwg_rep);
 	}
-	// kernel instance: bit 0 couplings, 1 sub-lattices, 2 fused, 3 non-temporal lattice words, 4 batched
-	const int v = (usej ? 1 : 0) | (subl ? 2 : 0) | (fused ? 4 : 0) | (streamed ? 8 : 0) | (batch ? 16 : 0);
+	// kernel instance: bit 0 couplings, 1 sub-lattices, 2 fused, 3 non-temporal lattice words, 4 batched, 5 in-launch counts
+	const int v = (usej ? 1 : 0) | (subl ? 2 : 0) | (fused ? 4 : 0) | (streamed ? 8 : 0) | (batch ? 16 : 0) | (count ? 32 : 0);
 	// (the launch is `LAUNCH(instance)`: hipExtLaunchKernelGGL needs the template arguments as written)
 #define BAL_INSTANCES(X)                                                                                              \
 	X(0, (ballot_update_k<false, false, false, NT>))                                                                   \
@@ -1086,7 +1105,9 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	X(13, (ballot_update_k<false, true, true, BAL_THREADS, true>))                                                     \
 	X(14, (ballot_update_k<true, false, true, BAL_THREADS, true>))                                                     \
 	X(20, (ballot_update_k<false, false, true, BAL_THREADS, false, true>))                                             \
-	X(28, (ballot_update_k<false, false, true, BAL_THREADS, true, true>))
+	X(28, (ballot_update_k<false, false, true, BAL_THREADS, true, true>))                                              \
+	X(36, (ballot_update_k<false, false, true, BAL_THREADS, false, false, true>))                                      \
+	X(44, (ballot_update_k<false, false, true, BAL_THREADS, true, false, true>))
 	const void *fn = nullptr;
 	switch (v) {
 #define BAL_FN(code, inst) case code: fn = (const void *)inst; break;
@@ -1105,7 +1126,7 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 		p.cus = n;
 	}
 	const int cus = p.cus;
-	long long grid = fused ? std::min<long long>(std::min(ballot_resident_wgs(v + (NT == 256 ? 0 : 32), fn, NT, cus), ballot_max_wgs(cus) * 256 / NT), total) : total;
+	long long grid = fused ? std::min<long long>(std::min(ballot_resident_wgs(v + (NT == 256 ? 0 : 64), fn, NT, cus), ballot_max_wgs(cus) * 256 / NT), total) : total;
 	if (fused) {
 		// Fewer workgroups than the chip holds when a level has few tickets: a unit's parents are one level = p.nwg tickets
 		// back, and a workgroup that finds them unfinished holds its slot asleep (ising_create picks wg_per_cu)
@@ -1189,6 +1210,24 @@ __global__ void __launch_bounds__(64) measure_fold_k(unsigned long long *__restr
 		out[0] = u;
 		out[1] = a;
 	}
+}
+
+// in-launch counts: measurement m = the sum of its 2 * waves_per_level slots
+__global__ void __launch_bounds__(THREADS) count_fold_k(const uint32_t *__restrict__ slots, size_t per_meas, unsigned long long *__restrict__ out) {
+	const uint32_t *s = slots + (size_t)blockIdx.x * per_meas;
+	unsigned long long v = 0;
+	for (size_t i = threadIdx.x; i < per_meas; i += THREADS) v += s[i];
+	v = wave_sum(v);
+	__shared__ unsigned long long part[THREADS / 64];
+	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+	__syncthreads();
+	if (threadIdx.x == 0) { unsigned long long t = 0; for (int k = 0; k < THREADS / 64; k++) t += part[k]; out[blockIdx.x] = t; }
+}
+
+hipError_t launch_count_fold(const uint32_t *slots, size_t per_meas, int nmeas, unsigned long long *out, hipStream_t stream) {
+	if (nmeas <= 0) return hipSuccess;
+	hipLaunchKernelGGL(count_fold_k, dim3((unsigned)nmeas), dim3(THREADS), 0, stream, slots, per_meas, out);
+	return hipGetLastError();
 }
 
 hipError_t launch_measure_fold(unsigned long long *acc, unsigned long long *out, hipStream_t stream) {

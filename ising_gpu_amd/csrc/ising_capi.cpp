@@ -546,6 +546,7 @@ int ising_destroy(ising_ctx *c) {
 	if (c->d_conv) (void)hipFree(c->d_conv);
 	if (c->d_self) (void)hipFree(c->d_self);
 	if (c->d_mslots) (void)hipFree(c->d_mslots);
+	if (c->d_cnt) (void)hipFree(c->d_cnt);
 	delete c;
 	return ISING_OK;
 }

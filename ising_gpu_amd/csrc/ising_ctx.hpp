@@ -117,6 +117,12 @@ struct ising_ctx {
 	bool go_set = false;                         // ... and it stands for the exchange that delivered the current ghost rows
 	bool overlap_next = false;                   // one-shot request to launch_ranges: the next deep launch takes part in the overlap
 	hipEvent_t launch_start_next = nullptr, launch_stop_next = nullptr; // one-shot: events on the next launch's dispatch packet
+	// In-launch counts (ising_sweep_counted): accumulators of the measurements of one call (64 lines of 64 bytes each), and the one-shot
+	// request to launch_ranges: which sweeps of the next fused launch are measured, and the number of its first measurement
+	uint32_t *d_cnt = nullptr;     // per measurement 2 x (waves of a level) slots, then (64-bit) one sum per measurement
+	size_t cnt_cap = 0;            // measurements d_cnt holds
+	unsigned long long cnt_mask_next = 0;
+	int cnt_slot0_next = 0;
 	// Exchange statistics (ising_exchange_stats_begin / _fetch; sweep_deep_overlapped): four events per sampled exchange --
 	// [4e] launch e begins, [4e+1] launch e ends (both on its dispatch packet), [4e+2] comm stream: the launch's edge strips have
 	// finished their last level (the exchange starts), [4e+3] comm stream: the neighbours' rows are in place and edge_go has moved.

@@ -75,6 +75,13 @@ struct UpdateParams {
 	int32_t cus;              // compute units of the device: workgroup b of a persistent grid is in dispatch round b / cus (host: 0 = ask)
 	int32_t grid_cap;         // fused: explicit size of the persistent grid (tests, A/B; 0: by wg_per_cu; host side only)
 	int32_t wait_late;        // fused: units draw their first row (2: their first two rows) before they wait for their parents
+	// In-launch counts (fused launches of a lone lattice that start with the black colour, at most 64 sweeps): bit j of cnt_mask = the
+	// up spins are counted after the launch's sweep j; the measurements of a launch are numbered cnt_slot0, cnt_slot0 + 1, ... in sweep
+	// order; the wave that works on unit wave w of a level leaves its sum in cnt_acc[(2 m + colour) * (4 nwg) + w] (zero before the
+	// launch: waves without rows store nothing); launch_count_fold adds a measurement's slots up.  NULL: off.
+	uint32_t *cnt_acc;
+	unsigned long long cnt_mask;
+	int32_t cnt_slot0;
 	const struct ReplicaParams *rep;
 	int32_t nrep, nwg_rep;
 	uint32_t rep_magic;       // ceil(2^32 / nwg_rep)
@@ -166,6 +173,8 @@ constexpr int BALLOT_MEASURE_SLOTS = 16;
 hipError_t launch_ballot_measure(const ReplicaParams *reps, int nrep, int gx, int Y, unsigned long long *acc, hipStream_t stream);
 // one lattice: its slots' sums into out[0] (up spins) and out[1] (bond sum); the slots are zero again afterwards
 hipError_t launch_measure_fold(unsigned long long *acc, unsigned long long *out, hipStream_t stream);
+// in-launch counts: out[m] = the sum of measurement m's per_meas slots, m = 0 .. nmeas - 1
+hipError_t launch_count_fold(const uint32_t *slots, size_t per_meas, int nmeas, unsigned long long *out, hipStream_t stream);
 hipError_t launch_ballot_init(const InitParams &p, hipStream_t stream);
 hipError_t launch_ballot_to_dense(const uint64_t *bal, uint32_t *dense, int gx, long long rows, hipStream_t stream);
 hipError_t launch_dense_to_ballot(const uint32_t *dense, uint64_t *bal, int gx, long long rows, hipStream_t stream);

@@ -26,6 +26,9 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	const bool edge_scratch = c->edge_scratch_next;
 	const bool overlap = c->overlap_next;
 	hipEvent_t start = c->launch_start_next;
+	const unsigned long long cnt_mask = c->cnt_mask_next;
+	const int cnt_slot0 = c->cnt_slot0_next;
+	c->cnt_mask_next = 0;
 	if (!stop) stop = c->launch_stop_next;
 	c->edge_scratch_next = false;
 	c->overlap_next = false;
@@ -111,6 +114,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			p.done = c->d_slotctl + SLOTCTL_TICKET_BYTES / 4;
 			p.wg_per_cu = c->fused_wg_per_cu;
 			p.wait_late = c->fused_wait_late ? (c->pol.fused_wait_late == 1 ? 1 : 2) : 0; // (default 2: behind the second draw phase)
+			if (cnt_mask) { p.cnt_acc = c->d_cnt; p.cnt_mask = cnt_mask; p.cnt_slot0 = cnt_slot0; }
 			p.nt_stream = c->fused_nt;
 			p.done_base = c->done_base;
 			if (lo0 < 0 || hi0 > c->cfg.Y) { // ghost rows are rows of the neighbouring slabs
@@ -231,6 +235,80 @@ int ising_host::sweep_alone(ising_ctx *c, int first_it, int nsweeps) {
 		if (int rc = ising_update_color(c, it, ISING_BLACK, 0, c->cfg.Y)) return rc;
 		if (int rc = ising_update_color(c, it, ISING_WHITE, 0, c->cfg.Y)) return rc;
 	}
+	return ISING_OK;
+}
+
+// The reference's loop with its print points (optimized/main.cu:1763-1810: sweep, and countSpins whenever the iteration is a multiple of
+// printFreq): `nsweeps` sweeps, the up-spin count after every iteration `it` with it % every == 0.  Where ising_sweep issues fused
+// launches (a lone slab on the ballot layout, no sub-lattices, no couplings) the counts are taken INSIDE the launches -- no launch
+// boundary and no read-back between two print points (ising_ballot.hip: COUNT); elsewhere: sweeps and ising_count in turn.
+extern "C" int ising_sweep_counted(ising_ctx *c, int first_it, int nsweeps, int every, uint64_t *ups, int max_counts, int *ncounts) {
+	if (!c || !ups || !ncounts) return fail(ISING_E_ARG, "null argument");
+	if (first_it < 0 || nsweeps < 0 || every < 1) return fail(ISING_E_ARG, "bad iteration range or count interval");
+	if (!c->wrap) return fail(ISING_E_STATE, "ising_sweep_counted needs a single slab without ring halo rows (rings: ising_ring_sweep and ising_ring_count in turn)");
+	const long long last = (long long)first_it + nsweeps - 1;
+	const long long n = nsweeps > 0 ? last / every - ((long long)first_it - 1) / every : 0; // iterations in [first_it, last] that are multiples of `every`
+	*ncounts = 0;
+	if (n > max_counts) return fail(ISING_E_ARG, "%lld counts, room for %d", n, max_counts);
+	if (int rc = bind(c)) return rc;
+	const bool inside = sweeps_fused(c) && !c->cfg.XSL && !c->cfg.use_J;
+	if (!inside) { // one launch per colour, sub-lattices, couplings: the reference's own order of events
+		int it = first_it, k = 0;
+		while (it <= last) {
+			const long long next = std::min<long long>(last, ((long long)it + every - 1) / every * every); // the next multiple of `every` from `it` on
+			if (int rc = ising_host::sweep_alone(c, it, (int)(next - it + 1))) return rc;
+			it = (int)next + 1;
+			if (next % every == 0) {
+				uint64_t up = 0, dw = 0;
+				if (int rc = ising_count(c, &up, &dw)) return rc;
+				ups[k++] = up;
+			}
+		}
+		*ncounts = k;
+		return ISING_OK;
+	}
+	// slots: per measurement one per wave of a level and colour; a call is worked off in chunks of measurements whose slots fit 64 MiB
+	const size_t waves = ((size_t)4 * c->nwc() * (size_t)c->nstrips + 15) / 16 * 4; // 4 waves per workgroup unit, as launch_ballot_update counts them
+	const size_t slots = 2 * waves;
+	const size_t chunk = std::max<size_t>(1, std::min<size_t>(64, ((size_t)64 << 20) / (slots * sizeof(uint32_t))));
+	if (c->cnt_cap < chunk) {
+		if (c->d_cnt) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_cnt)); c->d_cnt = nullptr; c->cnt_cap = 0; }
+		HIP_TRY(hipMalloc((void **)&c->d_cnt, chunk * slots * sizeof(uint32_t) + chunk * sizeof(unsigned long long) + 64));
+		c->cnt_cap = chunk;
+	}
+	unsigned long long *d_sum = reinterpret_cast<unsigned long long *>(c->d_cnt + (chunk * slots + 15) / 16 * 16);
+	const int per_launch = std::min(64, ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y)); // (a launch's measured sweeps are a 64-bit mask)
+	std::vector<unsigned long long> h(chunk);
+	long long got = 0;
+	int it = first_it, left = nsweeps;
+	while (left > 0) {
+		// launches until `chunk` measurements are in flight or the sweeps are done
+		HIP_TRY(hipMemsetAsync(c->d_cnt, 0, chunk * slots * sizeof(uint32_t), c->stream));
+		int inflight = 0;
+		while (left > 0) {
+			int ns = std::min(left, per_launch);
+			unsigned long long mask = 0;
+			int m = 0;
+			for (int j = 0; j < ns; j++) {
+				if ((it + j) % every) continue;
+				if (inflight + m == (int)chunk) { ns = j; break; } // (the launch ends in front of the measurement that no longer fits)
+				mask |= 1ull << j;
+				m++;
+			}
+			if (ns == 0) break;
+			c->cnt_mask_next = mask;
+			c->cnt_slot0_next = inflight;
+			if (int rc = launch_ranges(c, it, ISING_BLACK, 0, c->cfg.Y, 0, 0, 2 * ns)) return rc;
+			inflight += m;
+			it += ns;
+			left -= ns;
+		}
+		HIP_TRY(ising::launch_count_fold(c->d_cnt, slots, inflight, d_sum, c->stream));
+		if (inflight) HIP_TRY(hipMemcpyAsync(h.data(), d_sum, (size_t)inflight * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+		if (int rc = ising_host::sync_checked(c)) return rc;
+		for (int k = 0; k < inflight; k++) ups[got++] = h[k];
+	}
+	*ncounts = (int)got;
 	return ISING_OK;
 }
 

@@ -151,6 +151,16 @@ class IsingSlab:
         self.it += n
         return self
 
+    def sweep_counted(self, n: int, every: int):
+        """n sweeps with the up-spin count after every iteration that is a multiple of `every` (ising_sweep_counted: inside the fused
+        launches where there are any); returns [(up, down), ...]."""
+        cap = n // every + 2
+        ups, k = (C.c_uint64 * cap)(), C.c_int()
+        check(self._lib.ising_sweep_counted(self._h, self.it + 1, n, every, ups, cap, C.byref(k)))
+        self.it += n
+        tot = self.X * self.Y
+        return [(int(ups[i]), tot - int(ups[i])) for i in range(k.value)]
+
     @property
     def fused(self) -> bool:
         """True when sweep() issues fused launches (several colour half-sweeps per launch, ising_sweep_info)."""

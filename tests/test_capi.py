@@ -165,12 +165,12 @@ def test_every_point_of_a_scaling_run_has_a_golden():
 def test_hand_waited_loads_of_the_fused_kernels_pass_the_isa_check():
     """The fused ballot kernels issue their lattice loads as inline assembly and wait for them by hand (ising_ballot.hip);
     the build checks the generated ISA: nothing touches such a register before the covering s_waitcnt.  Here: the check
-    ran on the sources as they are, and it saw all eleven loads in each of the eight fused kernels (with / without couplings and
-    sub-lattices, streamed or not, batched)."""
+    ran on the sources as they are, and it saw all eleven loads in each of the ten fused kernels (with / without couplings and
+    sub-lattices, streamed or not, batched, with in-launch counts)."""
     csrc = os.path.join(ROOT, "ising_gpu_amd", "csrc")
     subprocess.check_call(["make", "-s", "-C", csrc, "check-asm"])   # (no-op when the library was built from these sources)
     report = open(os.path.join(csrc, ".ising_ballot.s.report")).read().splitlines()
     fused = [ln for ln in report if "Lb1ELi" in ln]                  # ballot_update_k<SUBL, USEJ, FUSED = true, NT>
     # (six lattice / mask loads of the row loop; the unit's first two rows at the two places a unit may wait late -- five more loads with the row-end word)
-    assert len(fused) == 8 and all(ln.endswith("11 inline-assembly loads checked") for ln in fused), report
+    assert len(fused) == 10 and all(ln.endswith("11 inline-assembly loads checked") for ln in fused), report
     assert not any("touches" in ln for ln in report)
