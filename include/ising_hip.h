@@ -194,8 +194,10 @@ int ising_sweep(ising_ctx *ctx, int first_it, int nsweeps);
 int ising_sweep_counted(ising_ctx *ctx, int first_it, int nsweeps, int every, uint64_t *ups, int max_counts, int *ncounts);
 /* How ising_sweep launches right now: *fused = 1 when it issues fused launches (ballot layout from 1.5 * 2^24 spins up, or
  * ISING_FUSED=1: one launch carries up to *max_sweeps_per_launch sweeps = twice as many colour half-sweeps, handed out to
- * a chip-filling grid through in-order tickets; ising_ballot.hip), 0 when it issues one launch per colour.  For a ring slab
- * with ghost rows G deep (ballot layout): how the ring sweeps it -- fused launches of up to G/2 sweeps between exchanges. */
+ * a chip-filling grid through in-order tickets; ising_ballot.hip), 0 when it issues one launch per colour, 2 when it issues tile
+ * launches (a lone slab on the dense layout up to 2^24 spins, or ISING_TILES=1: every workgroup sweeps a tile + halo of its own
+ * *max_sweeps_per_launch times without a word from the others; ising_dense.hip: dense_tile_k).  For a ring slab with ghost rows G
+ * deep (ballot layout): how the ring sweeps it -- fused launches of up to G/2 sweeps between exchanges. */
 int ising_sweep_info(ising_ctx *ctx, int *fused, int *max_sweeps_per_launch);
 /* Same, bracketed by HIP events on the context's stream; returns elapsed milliseconds (blocking). */
 int ising_sweep_timed(ising_ctx *ctx, int first_it, int nsweeps, float *elapsed_ms);

@@ -46,6 +46,12 @@ int read_policy(ising_policy *pol) {
 	if (num("ISING_FUSED_MAX_SWEEPS", &v)) pol->fused_max_sweeps = v > 0 ? v : 0;
 	if (num("ISING_FUSED_WAIT_LATE", &v)) pol->fused_wait_late = v < 0 ? 0 : (v > 2 ? 2 : v);
 	if (num("ISING_RING_GHOST", &v)) pol->ring_ghost = v;
+	if (num("ISING_TILES", &v)) pol->tiles = v != 0;
+	if (num("ISING_TILE_ROWS", &v) && v > 0) pol->tile_rows = v;
+	if (num("ISING_TILE_WORDS", &v) && v > 0) pol->tile_words = v;
+	if (num("ISING_TILE_SWEEPS", &v) && v > 0) pol->tile_sweeps = v;
+	if (num("ISING_TILE_THREADS", &v) && v > 0) pol->tile_threads = v;
+	if (num("ISING_TILE_XCD", &v)) pol->tile_xcd = v != 0;
 	pol->no_ballot = getenv("ISING_NO_BALLOT") != nullptr;
 	if (const char *e = getenv("ISING_TAIL")) {
 		int rows = 0, h = 1;
@@ -444,6 +450,46 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (cfg->Y % c->H) { const int h = c->H; delete c; return fail(ISING_E_ARG, "strip_rows %d does not divide Y %d", h, cfg->Y); }
 	c->nstrips = cfg->Y / c->H;
 	c->color_words = (size_t)cfg->Y * c->lld;
+	// Lattices that stay on the dense layout (a lone slab, no couplings, no sub-lattices), up to 2^24 spins: tile launches of several sweeps
+	// (ising_dense.hip: dense_tile_k) instead of one launch per colour, which is bound by the launches themselves below ~2^24 spins (9.7 us
+	// per sweep whatever the lattice).  tools/tile_probe.py, flips/ns tiles / per colour (profiles/tile_probe_r04.txt): 2048 x 1024 479 / 217,
+	// 2048^2 828 / 429, 4096 x 2048 1207 / 867, 4096^2 1595 / 1413.  Shape by measurement: one tile per CU (tile rows 8 .. 64 by 16 words
+	// + halo at 2^21 .. 2^24 spins), 3 / 4 / 6 sweeps a launch for 8 / 16-32 / 48+ rows, 512 threads while the first half-sweep's words fit two rounds of them.
+	if (c->dense && !c->ballot && c->wrap && !cfg->use_J && !cfg->XSL && pol.tiles != 0 && (pol.tiles == 1 || spins <= (1LL << 24))) {
+		const int wpr = c->gx * 32;
+		auto sweeps_for = [&](int tr) { const int s0 = pol.tile_sweeps ? pol.tile_sweeps : (tr <= 8 ? 3 : (tr >= 48 ? 6 : 4)); return std::max(1, std::min({s0, 16, cfg->Y / 2})); };
+		// the shape whose busiest CU has the fewest words to update per sweep: rounds of tiles x (rows + the halo rows' average) x (words + 2)
+		int TR = pol.tile_rows, TWI = pol.tile_words;
+		long long best = -1;
+		for (int tr : {8, 16, 24, 32, 48, 64, 96, 128}) {
+			if (pol.tile_rows ? tr != 8 : (cfg->Y % tr) != 0) continue;
+			for (int tw : {8, 12, 16, 24, 32, 48, 64}) {
+				if (pol.tile_words ? tw != 8 : (wpr % tw) != 0) continue;
+				const int r = pol.tile_rows ? pol.tile_rows : tr, w = pol.tile_words ? pol.tile_words : tw;
+				if (r > cfg->Y || (cfg->Y % r) != 0 || (wpr % w) != 0) continue;
+				const int S = sweeps_for(r);
+				const long long tiles = (long long)(wpr / w) * (cfg->Y / r);
+				const long long rounds = (tiles + c->cus - 1) / c->cus;
+				// (+ a launch's fixed cost, ~7 us, in words' time; + 15 % where a CU takes several tiles in turn: 10240 x 1024 849 vs 1004 flips/ns)
+				const long long cost = rounds * (r + 2 * S - 1) * (w + 2) * (rounds > 1 ? 115 : 100) / 100 + 900 / S;
+				if ((long long)(r + 4 * S - 2) * (w + 2) > 4096) continue; // (four rounds of 1024 threads at most)
+				if (best < 0 || cost < best) { best = cost; TR = r; TWI = w; }
+			}
+		}
+		const int S = sweeps_for(TR > 0 ? TR : 8);
+		int NT = pol.tile_threads;
+		if (!NT) NT = (TR + 4 * S - 2) * (TWI + 2) <= 600 ? 512 : 1024;
+		const bool ok = best >= 0 && (NT == 256 || NT == 512 || NT == 1024);
+		ising::TileParams tp{};
+		tp.TR = TR; tp.TWI = TWI; tp.ns = S;
+		if (ok && ising::dense_tiles_lds_bytes(tp) <= 64 * 1024) {
+			c->tile_rows = TR; c->tile_words = TWI; c->tile_sweeps = S; c->tile_threads = NT;
+			c->tile_xcd = pol.tile_xcd != 0 && ((cfg->Y / TR) % 8) == 0; // (tile rows in bands per XCD: +0 .. 2 %)
+		} else if (pol.tile_rows || pol.tile_words || pol.tile_threads) {
+			delete c;
+			return fail(ISING_E_ARG, "ISING_TILE_*: tiles of %d rows x %d words, %d sweeps, %d threads do not fit a %d x %d lattice", TR, TWI, S, NT, cfg->Y, cfg->X);
+		}
+	}
 	// lattices larger than the memory-side cache (256 MB = 2^31 spins at 1 bit per spin) stream through it: their words
 	// carry the non-temporal hint, which keeps the accept-mask slots in the L2s (ISING_FUSED_NT=0/1 overrides)
 	c->fused_nt = pol.fused_nt >= 0 ? pol.fused_nt : (spins > (1LL << 31));
@@ -535,6 +581,8 @@ int ising_destroy(ising_ctx *c) {
 	if (c->d_lat && !c->cfg.lattice_mem) (void)hipFree(c->d_lat);
 	if (c->d_acc) (void)hipFree(c->d_acc);
 	if (c->d_tmp) (void)hipFree(c->d_tmp);
+	if (c->d_lat2) (void)hipFree(c->d_lat2);
+	if (c->d_tile_cnt) (void)hipFree(c->d_tile_cnt);
 	if (c->d_scratch) (void)hipFree(c->d_scratch);
 	if (c->d_ham && !c->cfg.coupling_mem) (void)hipFree(c->d_ham);
 	if (c->d_bits) (void)hipFree(c->d_bits);

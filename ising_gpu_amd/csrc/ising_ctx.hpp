@@ -22,6 +22,8 @@ struct ising_policy {
 	int fused_wgs = 0;       // ISING_FUSED_WGS=n: persistent grid of n workgroups (0: by tickets per level)
 	int fused_wait_late = -1; // ISING_FUSED_WAIT_LATE=0/1: units of fused launches draw their first row before they wait for their parents (-1: by tickets per level)
 	int fused_max_sweeps = 0; // ISING_FUSED_MAX_SWEEPS=n: sweeps one fused launch of a single slab carries at most (0: ~50 ms worth, 32 .. 4096)
+	int tiles = -1;          // ISING_TILES=0/1: small lattices on the dense layout sweep in tile launches of several sweeps (-1: by lattice size)
+	int tile_rows = 0, tile_words = 0, tile_sweeps = 0, tile_threads = 0, tile_xcd = -1; // ISING_TILE_ROWS / _WORDS / _SWEEPS / _THREADS / _XCD (0 / -1: by lattice size)
 	int ring_ghost = -1;     // ISING_RING_GHOST=n: ghost rows of ballot ring slabs (-1: 64)
 	bool no_ballot = false;  // ISING_NO_BALLOT: layout AUTO never picks the ballot layout
 	int tail_rows = -1, tail_h = 1; // ISING_TAIL=rows[,h]: one-row tail strips of one-launch-per-colour launches (-1: automatic, 0: off)
@@ -46,6 +48,10 @@ struct ising_ctx {
 	                               // checked after every synchronise (ising_host::sync_checked)
 	bool dense = false; // 1 bit per spin on the device (ising_dense.hip); false = the reference's nibble layout
 	bool ballot = false; // dense, with the bits of a row in wave-ballot order (ising_ballot.hip)
+	uint64_t *d_lat2 = nullptr;    // dense layout, tile launches (ising_dense.hip: dense_tile_k): the buffer every other launch writes (shape of d_lat)
+	int tile_rows = 0, tile_words = 0, tile_sweeps = 0, tile_threads = 0, tile_xcd = 0; // ... their shape (tile_rows == 0: no tile launches)
+	unsigned long long *d_tile_cnt = nullptr; // ... the up-spin sums of a call's print points (ising_sweep_counted)
+	size_t tile_cnt_cap = 0;
 	uint64_t *d_tmp = nullptr;     // ballot layout: dense-order image of d_lat (same shape) for conversions and observables;
 	                               // allocated by the first call that needs it (sweeping and counting never do)
 	uint64_t *d_scratch = nullptr; // ballot layout: accept-mask slots of the update kernel (see ising_ballot.hip)

@@ -217,6 +217,121 @@ __global__ void __launch_bounds__(THREADS) dense_update_k(const UpdateParams p) 
 	}
 }
 
+// ---------------------------------------------------------------------------------------------- tiles: many sweeps per launch
+// Lattices of a few million spins finish a colour half-sweep in about a microsecond of arithmetic, and a launch per colour costs
+// several (kernel boundary, ramp, first loads): 2048^2 ran at 9.5 us per sweep, 4096^2 at 12.  No grid barrier is cheaper than that
+// boundary, so this form removes the exchanges instead: a draw depends on (seed, site, iteration) only, hence a workgroup that holds
+// its tile plus a halo can repeat its neighbours' updates of the halo bit for bit -- after h colour half-sweeps everything further
+// than h rows / h sites from the edge of what was loaded is still exact.  2 ns halo rows and one halo word (32 sites >= 2 ns for
+// ns <= 16) per side buy ns whole sweeps without a word from anybody else; the region shrinks by a row per half-sweep and ends on
+// the tile.  The launch reads one buffer and writes the other (the neighbours' halo loads race with nothing).
+// An item = one 32-site word of one row = 8 Philox blocks of one reference thread (tid from the row and the word's column,
+// counter word 16 (2 it + colour) + 8 j + m: SURVEY 8a-R2), dealt to the threads of the workgroup in turn.
+template <int NT>
+__global__ void __launch_bounds__(NT) dense_tile_k(const TileParams p) {
+	extern __shared__ uint32_t lds[];
+	const int wpr = p.gx * 32;
+	const int TW = p.TWI + 2;        // words of a tile row: halo word, TWI words, halo word
+	const int HR = 2 * p.ns;         // halo rows on either side
+	const int TRR = p.TR + 2 * HR;   // rows held
+	const int plane = TRR * TW;
+	uint32_t *tile[2] = {lds, lds + plane};
+	PhiloxBlockConst *ktab = reinterpret_cast<PhiloxBlockConst *>(lds + 2 * plane); // [2 ns half-sweeps][16 blocks]
+	const uint32_t inv_tw = 0xFFFFFFFFu / (uint32_t)TW + 1u; // i / TW = hi(i * inv_tw) for the i that occur (< 2^20)
+	const int ntx = wpr / p.TWI;
+	int tcy = (int)blockIdx.x / ntx;
+	const int tcx = (int)blockIdx.x - tcy * ntx;
+	if (p.xcd_rows > 0) { // workgroup b runs on XCD b % 8: give every XCD a band of tile rows
+		const int q = tcy >> 3, x = tcy & 7;
+		tcy = x * p.xcd_rows + q;
+	}
+	const int row0 = tcy * p.TR - HR; // global row of tile row 0 (negative / beyond Y: periodic)
+	const int col0 = tcx * p.TWI - 1; // global word column of tile column 0
+
+	for (int i = threadIdx.x; i < 2 * p.ns * 16; i += NT) {
+		const uint32_t hs = (uint32_t)i >> 4, b = (uint32_t)i & 15u;
+		ktab[i] = philox_block_const(16u * (2u * p.it + hs) + b, p.seed_lo, p.seed_hi); // 2 (it + hs / 2) + (hs & 1) = 2 it + hs
+	}
+	for (int i0 = threadIdx.x; i0 < 2 * plane; i0 += 4 * NT) { // four loads in flight per thread (the words come from other XCDs' launches: memory latency)
+		uint32_t v[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int i = i0 + k * NT;
+			if (i < 2 * plane) {
+				const int c = i >= plane, rem = i - (c ? plane : 0);
+				const int r = (int)__umulhi((uint32_t)rem, inv_tw), w = rem - r * TW;
+				int g = row0 + r, gc = col0 + w;
+				g += g < 0 ? p.Y : 0; g -= g >= p.Y ? p.Y : 0;
+				gc += gc < 0 ? wpr : 0; gc -= gc >= wpr ? wpr : 0;
+				v[k] = p.src[c][(size_t)g * wpr + gc];
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int i = i0 + k * NT;
+			if (i < 2 * plane) lds[i] = v[k]; // (tile[1] follows tile[0])
+		}
+	}
+	const uint32_t k2y = p.seed_hi + 2u * PHILOX_W1;
+	for (int h = 0; h < 2 * p.ns; ++h) {
+		__syncthreads();
+		const int color = h & 1;
+		const unsigned long long ctr = 2ull * p.it + (unsigned)h; // counter word / 16 (its high part: see dense_update_k)
+		const uint32_t seed_lo_cy = p.seed_lo ^ (uint32_t)(ctr >> 28);
+		const uint32_t *src = tile[1 - color];
+		uint32_t *dst = tile[color];
+		const PhiloxBlockConst *kt = ktab + 16 * h;
+		const int nitems = (TRR - 2 - 2 * h) * TW; // rows [h + 1, TRR - 1 - h)
+		for (int i = threadIdx.x; i < nitems; i += NT) {
+			const int rr = (int)__umulhi((uint32_t)i, inv_tw), w = i - rr * TW, r = rr + h + 1;
+			int g = row0 + r, gc = col0 + w;
+			g += g < 0 ? p.Y : 0; g -= g >= p.Y ? p.Y : 0;
+			gc += gc < 0 ? wpr : 0; gc -= gc >= wpr ? wpr : 0;
+			const uint32_t grow = (uint32_t)g;
+			const uint32_t tid = ((grow >> 4) * (uint32_t)p.gx + ((uint32_t)gc >> 5)) * 256u + (grow & 15u) * 16u + ((uint32_t)gc & 15u);
+			const int j = (gc >> 4) & 1;
+			const bool back = (color == 0) ? !(grow & 1u) : (grow & 1u); // readBack, optimized/main.cu:542
+			const PhiloxRow pr = philox_row_setup(tid, seed_lo_cy, k2y);
+			const int o = r * TW + w;
+			const uint32_t up = src[o - TW], ct = src[o], dw = src[o + TW];
+			const int ws = back ? w - 1 : w + 1; // beyond the halo word: whatever (it cannot reach the tile in 2 ns half-sweeps)
+			const uint32_t side = (ws >= 0 && ws < TW) ? src[o + (ws - w)] : 0u;
+			uint32_t me = dst[o];
+			uint32_t c3 = 0u, c4 = 0u;
+			// (four blocks at a time: their ten-round chains are independent, and a workgroup has few waves per SIMD to hide them behind)
+			static_for<2>([&](auto Q) {
+				uint32_t d[4][4];
+				static_for<4>([&](auto M) { philox_block_pre(pr, kt[8 * j + 4 * Q.value + M.value], p.seed_lo, p.seed_hi, d[M.value][0], d[M.value][1], d[M.value][2], d[M.value][3]); });
+				static_for<4>([&](auto M) { accept_bits<4 * Q.value + M.value>(c3, c4, d[M.value][0], d[M.value][1], d[M.value][2], d[M.value][3], p.n3, p.n4); });
+			});
+			me ^= word_flips(me, up, ct, dw, side, back, c3, c4);
+			dst[o] = me;
+		}
+	}
+	__syncthreads();
+	unsigned ups = 0;
+	for (int i = threadIdx.x; i < 2 * p.TR * p.TWI; i += NT) {
+		const int c = i >= p.TR * p.TWI, rem = i - (c ? p.TR * p.TWI : 0);
+		const int r = rem / p.TWI, w = rem - r * p.TWI;
+		const int g = tcy * p.TR + r, gc = tcx * p.TWI + w;
+		const uint32_t v = tile[c][(HR + r) * TW + 1 + w];
+		uint32_t *q = p.dst[c] + (size_t)g * wpr + gc;
+		*q = v;
+		ups += (unsigned)__popc(v);
+		if (g == 0) q[(size_t)p.Y * wpr] = v;                 // the mirror rows of a lone slab (launch_ranges: wrap)
+		if (g == p.Y - 1) *(q - (ptrdiff_t)p.Y * wpr) = v;
+	}
+	if (p.cnt) { // a print point: getMagn_k's sum (optimized/main.cu:701-734) over the words this workgroup has just stored, one atomic per workgroup
+		__shared__ unsigned wg_ups;
+		if (threadIdx.x == 0) wg_ups = 0;
+		__syncthreads();
+		const unsigned s = (unsigned)wave_sum((unsigned long long)ups);
+		if ((threadIdx.x & 63) == 0 && s) atomicAdd(&wg_ups, s);
+		__syncthreads();
+		if (threadIdx.x == 0) atomicAdd(p.cnt, (unsigned long long)wg_ups);
+	}
+}
+
 // ---------------------------------------------------------------------------------------------- init
 __global__ void __launch_bounds__(THREADS) dense_init_k(const InitParams p) {
 	const int tx = threadIdx.x & (GROUP - 1);
@@ -404,6 +519,22 @@ hipError_t launch_dense_update(const UpdateParams &p, int mode, hipStream_t stre
 		else         hipLaunchKernelGGL((dense_update_k<0, true>), g0, b0, 0, stream, p);
 	} else if (generic)   hipLaunchKernelGGL((dense_update_k<1, false>), g0, b0, 0, stream, p);
 	else                  hipLaunchKernelGGL((dense_update_k<0, false>), g0, b0, 0, stream, p);
+	return hipGetLastError();
+}
+
+size_t dense_tiles_lds_bytes(const TileParams &p) {
+	return ((size_t)2 * (p.TR + 4 * p.ns) * (p.TWI + 2) + (size_t)2 * p.ns * 16 * 3) * sizeof(uint32_t);
+}
+
+hipError_t launch_dense_tiles(const TileParams &p, int threads, hipStream_t stream) {
+	const dim3 g((unsigned)((p.gx * 32 / p.TWI) * (p.Y / p.TR)));
+	const size_t lds = dense_tiles_lds_bytes(p);
+	switch (threads) {
+	case 256:  hipLaunchKernelGGL(dense_tile_k<256>, g, dim3(256), lds, stream, p); break;
+	case 512:  hipLaunchKernelGGL(dense_tile_k<512>, g, dim3(512), lds, stream, p); break;
+	case 1024: hipLaunchKernelGGL(dense_tile_k<1024>, g, dim3(1024), lds, stream, p); break;
+	default: return hipErrorInvalidValue;
+	}
 	return hipGetLastError();
 }
 

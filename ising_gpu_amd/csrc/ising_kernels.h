@@ -147,6 +147,24 @@ hipError_t launch_ham_init_white(const HamWhiteParams &p, hipStream_t stream);
 
 // dense layout (1 bit per spin, ising_dense.hip): same parameter blocks, rows of gx*32 32-bit words
 hipError_t launch_dense_update(const UpdateParams &p, int mode, hipStream_t stream); // mode as launch_update
+
+// Small lattices on the dense layout: `ns` whole sweeps in ONE launch without any exchange between workgroups (ising_dense.hip:
+// dense_tile_k).  A workgroup keeps a tile of both colours in LDS together with 2 ns halo rows above and below and one halo word
+// (32 sites) left and right, updates it 2 ns times over a region that shrinks by one row per colour half-sweep, and stores its own
+// TR x TWI words to the OTHER buffer (the neighbours read their halos from the source buffer while it does).
+struct TileParams {
+	const uint32_t *src[2]; // row 0 of the black / white array the launch reads
+	uint32_t *dst[2];       // ... and of the one it writes (row -1 and row Y of each are the mirror rows of a lone slab)
+	uint32_t seed_lo, seed_hi, it; // `it`: iteration of the launch's first sweep
+	uint32_t n3, n4;
+	int ns;                 // sweeps in this launch (black first)
+	int gx, Y;              // 2048-column blocks per row; rows
+	int TR, TWI;            // tile: rows x 32-site words (TR divides Y, TWI divides 32 gx)
+	int xcd_rows;           // > 0: tile rows are dealt to the 8 XCDs in bands (neighbouring tiles share an L2)
+	unsigned long long *cnt; // not null: the up spins of the state the launch stores are added here (a print point, ising_sweep_counted)
+};
+hipError_t launch_dense_tiles(const TileParams &p, int threads, hipStream_t stream);
+size_t dense_tiles_lds_bytes(const TileParams &p);
 hipError_t launch_dense_init(const InitParams &p, hipStream_t stream);
 // in-place nibble -> bit-plane transposition of `nvec` 16-byte coupling vectors (dense layout with -J)
 hipError_t launch_ham_planes(uint64_t *ham, size_t nvec, hipStream_t stream);

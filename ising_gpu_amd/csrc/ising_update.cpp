@@ -217,6 +217,87 @@ extern "C" int ising_sweep(ising_ctx *c, int first_it, int nsweeps) {
 // 4096^2 12.0 us per sweep, 2048^2 9.6 us.  Round 4 replayed the launches from a captured hipGraph, the iteration coming from device
 // memory: bit-exact and NOT faster, 0.96 .. 1.02 x (profiles/sweep_graph_probe_r04.txt; the code is in the history at 9f35ffa) -- the
 // host keeps up; what a launch costs is the kernel itself at two waves per SIMD plus the device-side boundary between two kernels.)
+// Small lattices on the dense layout (ising_dense.hip: dense_tile_k): launches of several sweeps each, every workgroup on its own tile
+// + halo, no exchange inside a launch.  A launch reads one buffer and writes the other, so a call issues an EVEN number of them and
+// the spins are back in d_lat when it returns (a single sweep takes the two per-colour launches).
+static bool sweeps_tiled(const ising_ctx *c, int nsweeps) {
+	return c->tile_rows > 0 && nsweeps >= 2 && c->wrap && c->dense && !c->ballot && !c->cfg.use_J && !c->cfg.XSL && !ising_host::needs_generic(c);
+}
+
+// one tile launch of `ns` sweeps from buffer `from_second ? d_lat2 : d_lat` into the other one; `cnt`: see TileParams
+static int launch_tiles(ising_ctx *c, int it, int ns, bool from_second, unsigned long long *cnt) {
+	auto plane = [&](uint64_t *base, int color) { return reinterpret_cast<uint32_t *>(base + (c->lat(color) - c->d_lat)); };
+	uint64_t *from = from_second ? c->d_lat2 : c->d_lat, *to = from_second ? c->d_lat : c->d_lat2;
+	ising::TileParams p{};
+	for (int color = 0; color < 2; color++) { p.src[color] = plane(from, color); p.dst[color] = plane(to, color); }
+	p.seed_lo = (uint32_t)c->cfg.seed;
+	p.seed_hi = (uint32_t)(c->cfg.seed >> 32);
+	p.it = (uint32_t)it;
+	p.n3 = (uint32_t)c->thr[3];
+	p.n4 = (uint32_t)c->thr[4];
+	p.ns = ns;
+	p.gx = c->gx;
+	p.Y = c->cfg.Y;
+	p.TR = c->tile_rows;
+	p.TWI = c->tile_words;
+	p.xcd_rows = c->tile_xcd ? (c->cfg.Y / c->tile_rows) / 8 : 0;
+	p.cnt = cnt;
+	HIP_TRY(ising::launch_dense_tiles(p, c->tile_threads, c->stream));
+	return ISING_OK;
+}
+
+static int sweep_tiles(ising_ctx *c, int first_it, int nsweeps) {
+	if (int rc = bind(c)) return rc;
+	if (!c->d_lat2) HIP_TRY(hipMalloc((void **)&c->d_lat2, c->alloc_words() * sizeof(uint64_t)));
+	const int S = c->tile_sweeps;
+	const int L = 2 * ((nsweeps + 2 * S - 1) / (2 * S)); // launches: even, none longer than S sweeps
+	const int base = nsweeps / L, rem = nsweeps % L;
+	int it = first_it;
+	for (int l = 0; l < L; l++) {
+		const int ns = base + (l < rem ? 1 : 0);
+		if (int rc = launch_tiles(c, it, ns, (l & 1) != 0, nullptr)) return rc;
+		it += ns;
+	}
+	return ISING_OK;
+}
+
+// ising_sweep_counted in tile launches: every print point is the end of a launch, whose workgroups count what they store.  The launches
+// alternate between the two buffers; a call that ends in the second one copies it back (the lattices of this path are a few MB).
+static int sweep_tiles_counted(ising_ctx *c, int first_it, int nsweeps, int every, uint64_t *ups, long long n, int *ncounts) {
+	if (int rc = bind(c)) return rc;
+	if (!c->d_lat2) HIP_TRY(hipMalloc((void **)&c->d_lat2, c->alloc_words() * sizeof(uint64_t)));
+	if (c->tile_cnt_cap < (size_t)n) {
+		if (c->d_tile_cnt) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_tile_cnt)); c->d_tile_cnt = nullptr; c->tile_cnt_cap = 0; }
+		const size_t cap = std::max<size_t>(64, (size_t)n);
+		HIP_TRY(hipMalloc((void **)&c->d_tile_cnt, cap * sizeof(unsigned long long)));
+		c->tile_cnt_cap = cap;
+	}
+	if (n) HIP_TRY(hipMemsetAsync(c->d_tile_cnt, 0, (size_t)n * sizeof(unsigned long long), c->stream));
+	const long long last = (long long)first_it + nsweeps - 1;
+	const int S = c->tile_sweeps;
+	bool second = false;
+	int it = first_it, k = 0;
+	while (it <= last) {
+		const long long next = std::min<long long>(last, ((long long)it + every - 1) / every * every); // the next multiple of `every` from `it` on
+		const int seg = (int)(next - it + 1), L = (seg + S - 1) / S;
+		for (int l = 0; l < L; l++) {
+			const int ns = seg / L + (l < seg % L ? 1 : 0);
+			const bool measured = l == L - 1 && next % every == 0;
+			if (int rc = launch_tiles(c, it, ns, second, measured ? c->d_tile_cnt + k : nullptr)) return rc;
+			if (measured) k++;
+			second = !second;
+			it += ns;
+		}
+	}
+	if (second) HIP_TRY(hipMemcpyAsync(c->d_lat, c->d_lat2, c->alloc_words() * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+	std::vector<unsigned long long> h((size_t)std::max(k, 1));
+	if (k) HIP_TRY(hipMemcpyAsync(h.data(), c->d_tile_cnt, (size_t)k * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+	if (int rc = ising_host::sync_checked(c)) return rc;
+	for (int q = 0; q < k; q++) ups[q] = h[q];
+	*ncounts = k;
+	return ISING_OK;
+}
+
 // `nsweeps` sweeps of a slab that needs nothing from its neighbours: a single slab that wraps in place, or a slab of
 // sub-lattices (also one of several: nothing crosses slabs, optimized/main.cu:1423-1462)
 int ising_host::sweep_alone(ising_ctx *c, int first_it, int nsweeps) {
@@ -231,6 +312,7 @@ int ising_host::sweep_alone(ising_ctx *c, int first_it, int nsweeps) {
 		}
 		return ISING_OK;
 	}
+	if (sweeps_tiled(c, nsweeps)) return sweep_tiles(c, first_it, nsweeps);
 	for (int it = first_it; it < first_it + nsweeps; it++) {
 		if (int rc = ising_update_color(c, it, ISING_BLACK, 0, c->cfg.Y)) return rc;
 		if (int rc = ising_update_color(c, it, ISING_WHITE, 0, c->cfg.Y)) return rc;
@@ -251,6 +333,7 @@ extern "C" int ising_sweep_counted(ising_ctx *c, int first_it, int nsweeps, int 
 	*ncounts = 0;
 	if (n > max_counts) return fail(ISING_E_ARG, "%lld counts, room for %d", n, max_counts);
 	if (int rc = bind(c)) return rc;
+	if (sweeps_tiled(c, 2)) return sweep_tiles_counted(c, first_it, nsweeps, every, ups, n, ncounts);
 	const bool inside = sweeps_fused(c) && !c->cfg.XSL && !c->cfg.use_J;
 	if (!inside) { // one launch per colour, sub-lattices, couplings: the reference's own order of events
 		int it = first_it, k = 0;
@@ -319,8 +402,9 @@ int ising_sweep_info(ising_ctx *c, int *fused, int *max_sweeps_per_launch) {
 	const bool f = (c->wrap || c->cfg.XSL) && sweeps_fused(c);
 	// (a ring slab with ghost rows G deep: the ring's sweeps are fused launches of G/2 sweeps between two exchanges)
 	const bool deep = ghost_sweeps(c);
-	if (fused) *fused = (f || deep) ? 1 : 0;
-	if (max_sweeps_per_launch) *max_sweeps_per_launch = f ? ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y) : (deep ? c->ghost() / 2 : 0);
+	const bool tiled = !f && !deep && sweeps_tiled(c, 2);
+	if (fused) *fused = (f || deep) ? 1 : (tiled ? 2 : 0);
+	if (max_sweeps_per_launch) *max_sweeps_per_launch = f ? ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y) : (deep ? c->ghost() / 2 : (tiled ? c->tile_sweeps : 0));
 	return ISING_OK;
 }
 

@@ -166,7 +166,15 @@ class IsingSlab:
         """True when sweep() issues fused launches (several colour half-sweeps per launch, ising_sweep_info)."""
         f, m = C.c_int(), C.c_int()
         check(self._lib.ising_sweep_info(self._h, C.byref(f), C.byref(m)))
-        return bool(f.value)
+        return f.value == 1
+
+    @property
+    def tiled(self) -> bool:
+        """True when sweep() issues tile launches (small lattices on the dense layout: several sweeps per launch, every workgroup on a
+        tile + halo of its own, ising_sweep_info)."""
+        f, m = C.c_int(), C.c_int()
+        check(self._lib.ising_sweep_info(self._h, C.byref(f), C.byref(m)))
+        return f.value == 2
 
     @property
     def max_sweeps_per_launch(self) -> int:
