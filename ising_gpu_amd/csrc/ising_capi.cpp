@@ -472,7 +472,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 				const long long rounds = (tiles + c->cus - 1) / c->cus;
 				// (+ a launch's fixed cost, ~7 us, in words' time; + 15 % where a CU takes several tiles in turn: 10240 x 1024 849 vs 1004 flips/ns)
 				const long long cost = rounds * (r + 2 * S - 1) * (w + 2) * (rounds > 1 ? 115 : 100) / 100 + 900 / S;
-				if ((long long)(r + 4 * S - 2) * (w + 2) > 4096) continue; // (four rounds of 1024 threads at most)
+				if (!pol.tile_rows && !pol.tile_words && (long long)(r + 4 * S - 2) * (w + 2) > 4096) continue; // (the rule: four rounds of 1024 threads at most)
 				if (best < 0 || cost < best) { best = cost; TR = r; TWI = w; }
 			}
 		}

@@ -116,3 +116,42 @@ def test_tiles_counted_sweeps(gpu, oracle_mod, monkeypatch, X, Y, first, n, ever
         s.sweep(3)
         orc.sweep(3)
         _compare(s, orc, "three sweeps later")
+
+
+def test_tiles_randomised(gpu, oracle_mod, monkeypatch):
+    """Random lattices, tile shapes, halo depths, workgroup sizes and call lengths against the oracle (seeded: the same 48 cases every run)."""
+    rng = np.random.default_rng(20260929)
+    for case in range(48):
+        gx = int(rng.integers(1, 4))
+        X = 2048 * gx
+        Y = 16 * int(rng.integers(1, 13))
+        TR = int(rng.choice([t for t in (8, 16, 24, 32, 48, 64, 96, 128) if Y % t == 0]))
+        TWI = int(rng.choice([w for w in (8, 12, 16, 24, 32, 48, 64, 96) if (32 * gx) % w == 0]))
+        S = int(rng.integers(1, min(16, Y // 2) + 1))
+        lds = lambda S: (2 * (TR + 4 * S) * (TWI + 2) + 2 * S * 16 * 3) * 4  # noqa: E731  (both colours of tile + halo, the block constants)
+        while S > 1 and lds(S) > 65536:
+            S -= 1
+        if lds(S) > 65536:
+            continue
+        NT = int(rng.choice([256, 512, 1024]))
+        temp = float(rng.choice([1.5, 2.0, TC, 3.0]))
+        seed = int(rng.integers(1, 2**62))
+        _env(monkeypatch, TILES=1, TILE_ROWS=TR, TILE_WORDS=TWI, TILE_SWEEPS=S, TILE_THREADS=NT, TILE_XCD=int(rng.integers(0, 2)))
+        orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=temp).init()
+        with ig.IsingSlab(X, Y, seed=seed, temp=temp, layout=ig.LAYOUT_DENSE) as s:
+            assert s.tiled and s.max_sweeps_per_launch == S
+            s.init()
+            for n in rng.integers(1, 3 * S + 4, size=3):
+                if rng.integers(0, 3) == 0:
+                    every = int(rng.integers(1, 9))
+                    got = s.sweep_counted(int(n), every)
+                    want = []
+                    for _ in range(int(n)):
+                        orc.sweep(1)
+                        if orc.it % every == 0:
+                            want.append(orc.count())
+                    assert got == want, (case, X, Y, TR, TWI, S, NT)
+                else:
+                    s.sweep(int(n))
+                    orc.sweep(int(n))
+                _compare(s, orc, f"case {case}: {Y} x {X}, tiles {TR} x {TWI}, {S} sweeps a launch, {NT} threads, after {orc.it} sweeps")
