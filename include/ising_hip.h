@@ -182,7 +182,11 @@ int ising_update_edges(ising_ctx *ctx, int it, int color);
 int ising_strip_info(ising_ctx *ctx, int *strip_rows, int *nstrips);
 
 /* nslabs == 1 only: `nsweeps` full sweeps, black then white, iterations first_it .. first_it+nsweeps-1
- * (the hot loop, optimized/main.cu:1763-1805). */
+ * (the hot loop, optimized/main.cu:1763-1805).  How the sweeps are launched depends on the lattice (ising_sweep_info): fused
+ * launches of many sweeps on the ballot layout (from 1.5 * 2^24 spins), tile launches of 3 - 6 sweeps on the dense layout up to
+ * 2^24 spins (the first call allocates a second lattice buffer of the size of the first: every launch reads one and writes the
+ * other, and an even number of launches per call leaves the spins where every other entry point expects them), one launch per
+ * colour otherwise -- the spins after the call are the same in every form. */
 int ising_sweep(ising_ctx *ctx, int first_it, int nsweeps);
 /* The hot loop WITH its print points (optimized/main.cu:1763-1810: the sweeps, and countSpins whenever the iteration is a multiple of
  * printFreq -- every number the reference publishes was measured with `-p 16` inside the timed loop).  nslabs == 1 only: `nsweeps` full
