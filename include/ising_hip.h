@@ -57,7 +57,8 @@ enum {
 /* device layout of the spin arrays.  The C-ABI always speaks the reference's packed layout (read/write/dump convert). */
 enum {
 	ISING_LAYOUT_AUTO = 0,   /* ballot where it applies and pays (from 1.5 * 2^24 spins per slab where fused launches apply: a slab that wraps
-	                            in place, a ring slab that can keep ghost rows; from 2^27 otherwise), else dense */
+	                            in place -- that one also below, while a level of one-row units still feeds two workgroups per CU, e.g.
+	                            8192 x 1280, 16384 x 768 --, a ring slab that can keep ghost rows; from 2^27 otherwise), else dense */
 	ISING_LAYOUT_NIBBLE = 1, /* the reference's: 4 bits per spin, 16 spins per 64-bit word (optimized/main.cu:40, :1243) */
 	ISING_LAYOUT_DENSE = 2,  /* 1 bit per spin, 32 spins per 32-bit word = one reference 128-bit vector per word */
 	ISING_LAYOUT_BALLOT = 3  /* 1 bit per spin, 64-bit words in the update kernel's wave-ballot order (ising_ballot.hip),
@@ -183,8 +184,8 @@ int ising_strip_info(ising_ctx *ctx, int *strip_rows, int *nstrips);
 
 /* nslabs == 1 only: `nsweeps` full sweeps, black then white, iterations first_it .. first_it+nsweeps-1
  * (the hot loop, optimized/main.cu:1763-1805).  How the sweeps are launched depends on the lattice (ising_sweep_info): fused
- * launches of many sweeps on the ballot layout (from 1.5 * 2^24 spins), tile launches of 3 - 6 sweeps on the dense layout up to
- * 2^24 spins (the first call allocates a second lattice buffer of the size of the first: every launch reads one and writes the
+ * launches of many sweeps on the ballot layout (from 1.5 * 2^24 spins, and below for lattices of enough rows), tile launches of 3 - 6
+ * sweeps on the dense layout up to 2^24 spins (the first call allocates a second lattice buffer of the size of the first: every launch reads one and writes the
  * other, and an even number of launches per call leaves the spins where every other entry point expects them), one launch per
  * colour otherwise -- the spins after the call are the same in every form. */
 int ising_sweep(ising_ctx *ctx, int first_it, int nsweeps);
@@ -196,7 +197,7 @@ int ising_sweep(ising_ctx *ctx, int first_it, int nsweeps);
  * with a count every 16 sweeps: 3057 -> 3290 flips/ns) --; on the other layouts and with sub-lattices or couplings the call sweeps and
  * counts in turn.  Blocking: the counts are read back when the last launch is done. */
 int ising_sweep_counted(ising_ctx *ctx, int first_it, int nsweeps, int every, uint64_t *ups, int max_counts, int *ncounts);
-/* How ising_sweep launches right now: *fused = 1 when it issues fused launches (ballot layout from 1.5 * 2^24 spins up, or
+/* How ising_sweep launches right now: *fused = 1 when it issues fused launches (ballot layout: from 1.5 * 2^24 spins up and where ISING_LAYOUT_AUTO picks it below, or
  * ISING_FUSED=1: one launch carries up to *max_sweeps_per_launch sweeps = twice as many colour half-sweeps, handed out to
  * a chip-filling grid through in-order tickets; ising_ballot.hip), 0 when it issues one launch per colour, 2 when it issues tile
  * launches (a lone slab on the dense layout up to 2^24 spins, or ISING_TILES=1: every workgroup sweeps a tile + halo of its own

@@ -174,9 +174,19 @@ long long fused_tickets(int nwc, int Y, int H) { return ((long long)nwc * ((Y + 
 // wait_late2_probe_r04.txt; flips/ns at the rule below against rounds 2-3's: 8192 x 4096 2820 (H = 2, T = 512) vs 2305 (H = 1), 8192^2
 // 3087 vs 2767, 16384 x 8192 3246 vs 3051, 16384^2 3330 vs 3298; from T = 4096 up nothing moves, 65536^2 3532.8 vs 3531.8).
 // `late` = false gives the rule of rounds 2-3 (ISING_FUSED_WAIT_LATE=0).
-int fused_wgs_for(long long T, int H = 16, bool late = false) {
+// One-row units (the end of round 4, tools/small_fused_probe.py, profiles/small_fused_probe_r04.txt): a grid of G workgroups per CU runs at its own
+// plateau (2: 1720 flips/ns, 3: 2150, 4: 2500) as long as a level has r x G x 256 tickets, and falls off a cliff below (8192 x 1536, T = 384: 1355 with three,
+// 1699 with two) -- r grows with the wave columns of a row: 0.54 (1), 0.68 (2), 0.86 (3), 0.90 (4), ~1.9 (8: 65536 x 384 ran 554 with the four
+// the rule used to give it, 1451 with two).
+double fused_level_ratio(int nwc) {
+	static const double R[5] = {0.54, 0.54, 0.68, 0.86, 0.90};
+	return nwc <= 4 ? R[nwc < 1 ? 1 : nwc] : 0.90 + 0.25 * (nwc - 4);
+}
+int fused_wgs_cap(long long T, int nwc) { return (int)std::min<long long>(6, (long long)((double)T / (fused_level_ratio(nwc) * 256.0))); }
+int fused_wgs_for(long long T, int H = 16, bool late = false, int nwc = 0) {
 	const int base = T >= 8192 ? 6 : (T >= 4096 ? 5 : (T >= 2048 ? 4 : (T >= 1024 ? 3 : (T >= 684 ? 2 : 1))));
 	if (!late || T >= 4096) return base;
+	if (H == 1 && nwc > 0) return std::min(T >= 2048 ? 6 : (T >= 1024 ? 5 : 4), std::max(2, fused_wgs_cap(T, nwc)));
 	if (H <= 2) return T >= 2048 ? 6 : (T >= 1024 ? 5 : (T >= 512 ? 4 : base));
 	return T >= 1024 ? base + 1 : base;
 }
@@ -229,7 +239,7 @@ void ising_host::fused_shape(int nwc, int Y, long long rows, int *H, int *wg_per
 		if (score >= best_score) { best = h; best_score = score; }
 	}
 	*H = best;
-	*wg_per_cu = fused_wgs_for(((long long)nwc * ((rows + best - 1) / best) + 3) / 4, best, late);
+	*wg_per_cu = fused_wgs_for(((long long)nwc * ((rows + best - 1) / best) + 3) / 4, best, late, nwc);
 }
 
 namespace {
@@ -412,15 +422,20 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// columns, 3512 at 64, 3445 at 128, 3386 at 256, 3186 at 512: a strip's completion counter takes one atomic per wave column
 	// and level, all at about the same time, and three polls per unit of the next)
 	// (from 768 tickets a level: 8192 x 3072 1834 vs the dense layout's 1658; 8192 x 2048, 512 tickets: 1330 vs 1416)
-	c->fused = pol.fused >= 0 ? pol.fused != 0 : (spins >= 3 * (1LL << 23) && c->nwc() < 128);
+	// Below 1.5 * 2^24 spins (the end of round 4): a lone slab whose levels of ONE-row units still feed two workgroups per CU (fused_wgs_cap) runs 1720 flips/ns
+	// and more in fused launches where the dense layout does 1000 .. 1585 (tile launches) -- 8192 x 2048 2172 vs 1582, 8192 x 2560 2537 vs 1401, 16384 x 1152 2093
+	// vs 1217, 32768 x 640 1687 vs 1250; lattices with fewer tickets a level stay dense (8192 x 1024 1065 vs 1179).
+	const bool small_fused = c->wrap && !cfg->XSL && spins < 3 * (1LL << 23) && pol.fused_wait_late != 0 && fused_wgs_cap(fused_tickets(c->nwc(), cfg->Y, 1), c->nwc()) >= 2;
+	c->fused = pol.fused >= 0 ? pol.fused != 0 : ((spins >= 3 * (1LL << 23) || small_fused) && c->nwc() < 128);
 	// AUTO: the ballot kernel's two-phase row pipeline wins from 2^27 spins per slab up -- from 2^25 where fused launches
 	// apply (a slab that wraps in place, a ring slab that can keep ghost rows); below, the dense kernel is ahead.  (A partly dead last wave column wastes its
 	// dead lanes' draws: worth it while they are under a tenth of the row -- the dense kernel is 12 % behind.)
-	const bool ballot_pays = whole || 10 * c->gx > 9 * 4 * c->nwc();
+	// (up to 2^26 spins the dense layout's launches cost more than a quarter of dead lanes: 12288 x 1536 1898 vs 1245, 12288 x 2048 1925 vs 1618)
+	const bool ballot_pays = whole || 10 * c->gx > 9 * 4 * c->nwc() || (spins <= (1LL << 26) && 4 * c->gx >= 3 * 4 * c->nwc());
 	// (a ring slab that can keep ghost rows sweeps in fused launches as well, see below)
 	const bool deep_can = !c->wrap && !cfg->XSL && !(cfg->use_J && cfg->coupling_mem) && !cfg->lattice_mem && cfg->Y >= 4 &&
 	                      !(pol.ring_ghost >= 0 && pol.ring_ghost < 2);
-	const long long ballot_from = ((c->fused && fused_can) || deep_can) ? 3 * (1LL << 23) : (1LL << 27);
+	const long long ballot_from = (c->fused && fused_can && small_fused) ? 0 : (((c->fused && fused_can) || deep_can) ? 3 * (1LL << 23) : (1LL << 27));
 	if (cfg->layout == ISING_LAYOUT_AUTO && ballot_ok && ballot_pays && c->fast_ok && spins >= ballot_from && !pol.no_ballot)
 		c->ballot = true;
 	if (c->ballot) c->lld = c->nwc() * 64;
@@ -442,11 +457,14 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// (its fused launches take the shape a single slab of Y + 2 G rows would)
 	const int launch_rows = deep_ring ? cfg->Y + 2 * c->ghost_rows : cfg->Y;
 	c->H = cfg->strip_rows > 0 ? cfg->strip_rows
+	       : (fused_shape && small_fused) ? 1
 	       : ((fused_shape || deep_ring) ? choose_fused_strip_rows(c->nwc(), cfg->XSL ? cfg->YSL : cfg->Y, launch_rows)
 	                                     : choose_strip_rows(c->gx, cfg->Y, c->dense, c->ballot));
 	// (units that draw before they wait: two-row units with 512 tickets a level beat one-row units with 1024 -- 8192 x 4096 2820 vs 2660)
 	if (cfg->strip_rows <= 0 && (fused_shape || deep_ring) && c->H == 1 && pol.fused_wait_late != 0 && (cfg->XSL ? cfg->YSL : cfg->Y) % 2 == 0 &&
-	    fused_tickets(c->nwc(), launch_rows, 2) >= 512) c->H = 2;
+	    fused_tickets(c->nwc(), launch_rows, 2) >= 512 && (c->nwc() == 1 || fused_wgs_cap(fused_tickets(c->nwc(), launch_rows, 2), c->nwc()) >= 3)) c->H = 2;
+	// (... where a row is one wave column; rows of several want more tickets a level: 32768 x 1024 ran 745 with two-row units, 2446 with one-row units,
+	// 16384 x 2048 2199 / 2575, 65536 x 512 371 / 1523 -- profiles/small_fused_probe_r04.txt)
 	if (cfg->Y % c->H) { const int h = c->H; delete c; return fail(ISING_E_ARG, "strip_rows %d does not divide Y %d", h, cfg->Y); }
 	c->nstrips = cfg->Y / c->H;
 	c->color_words = (size_t)cfg->Y * c->lld;
@@ -496,7 +514,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (fused_shape || deep_ring) { // workgroups per CU of a fused launch (the chip holds 6 of 4 waves)
 		const long long T = fused_tickets(c->nwc(), launch_rows, c->H);
 		c->fused_wait_late = pol.fused_wait_late != 0; // (default on: free where parents are never late, 65536^2 3528.6 vs 3527.4)
-		c->fused_wg_per_cu = fused_wgs_for(T, c->H, c->fused_wait_late);
+		c->fused_wg_per_cu = fused_wgs_for(T, c->H, c->fused_wait_late, c->nwc());
 		if (deep_ring && T < 16384) c->fused_wg_per_cu = std::min(c->fused_wg_per_cu, 5);
 		// Several ticket counters where 4-wave workgroups draw one- or two-row units (2^26 spins): one counter hands out
 		// ~80 tickets per us; 8192^2 with one-row units at 2600 flips/ns needs 159 (four counters), with two-row units

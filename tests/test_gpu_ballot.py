@@ -121,8 +121,14 @@ def test_auto_layout_picks_ballot_where_it_applies(gpu):
         assert s.layout == BAL and s.fused
     with ig.IsingSlab(8192, 4096, temp=1.5) as s:       # ... down to 2^25 spins
         assert s.layout == BAL and s.fused and s.strip_rows == 2  # (round 4: units draw before they wait -- two-row units with 512 tickets a level)
-    with ig.IsingSlab(8192, 2048, temp=1.5) as s:       # small slabs: the dense kernel is ahead
-        assert s.layout == ig.LAYOUT_DENSE
+    with ig.IsingSlab(8192, 2048, temp=1.5) as s:       # ... and below, while a level of one-row units still feeds two workgroups per CU (end of round 4)
+        assert s.layout == BAL and s.fused and s.strip_rows == 1
+    with ig.IsingSlab(16384, 2048, temp=1.5) as s:      # (rows of several wave columns want more tickets a level before two-row units pay)
+        assert s.layout == BAL and s.fused and s.strip_rows == 1
+    with ig.IsingSlab(8192, 1024, temp=1.5) as s:       # small slabs: the dense layout is ahead (tile launches)
+        assert s.layout == ig.LAYOUT_DENSE and s.tiled
+    with ig.IsingSlab(12288, 2048, temp=1.5) as s:      # 1.5 wave columns: up to 2^26 spins a quarter of dead lanes costs less than the dense layout's launches
+        assert s.layout == BAL and s.fused
     with ig.IsingSlab(20480, 8192, temp=1.5) as s:      # 10 column groups = 2.5 wave columns: too many dead lanes
         assert s.layout == ig.LAYOUT_DENSE
     with ig.IsingSlab(16384, 8192, temp=1.5, XSL=2048, YSL=16) as s:

@@ -1,28 +1,51 @@
 #!/usr/bin/env python3
-"""Lattices below 2^26 spins: what AUTO picks (dense layout, one launch per colour) against fused launches on the ballot layout
-(one- and two-row units, ticket counters, grid).  Usage: small_fused_probe.py [X Y ...]"""
-import os, sys, subprocess
-sys.path.insert(0, __file__.rsplit("/", 2)[0])
-if len(sys.argv) > 1 and sys.argv[1] == "case":
-    import ising_gpu_amd as ig
-    X, Y = map(int, sys.argv[2:4])
-    sweeps = 4096
-    with ig.IsingSlab(16384, 16384, seed=1, temp=ig.CRIT_TEMP_F32) as s:
-        s.init(); s.sweep_timed(512)
-    def run(**kw):
-        with ig.IsingSlab(X, Y, seed=1234, temp=ig.CRIT_TEMP_F32, **kw) as s:
-            s.init(); s.sweep_timed(64)
-            return max(X * Y * sweeps / (s.sweep_timed(sweeps) * 1e6) for _ in range(3)), s.current_layout(), s.strip_rows
-    v, lay, H = run()
-    out = [f"auto[layout {lay}, H={H}] {v:7.1f}"]
-    os.environ["ISING_FUSED"] = "1"
-    for H in (1, 2):
-        v, _, _ = run(layout=ig.LAYOUT_BALLOT, strip_rows=H)
-        out.append(f"fused H={H} {v:7.1f}")
-    print(f"{Y:6d} x {X:6d} t2={os.environ.get('ISING_FUSED_TICKETS2', '-')} wgs={os.environ.get('ISING_FUSED_WGS', 'auto'):>5s}  " + "  ".join(out), flush=True)
-else:
-    sizes = [tuple(map(int, sys.argv[i:i + 2])) for i in range(1, len(sys.argv), 2)] or [(8192, 4096), (16384, 2048), (8192, 2048), (8192, 6144)]
-    for X, Y in sizes:
-        for t2 in ("2", "4"):
-            for g in ("512", "768", "1024"):
-                subprocess.run([sys.executable, __file__, "case", str(X), str(Y)], env=dict(os.environ, ISING_FUSED_TICKETS2=t2, ISING_FUSED_WGS=g), stderr=subprocess.DEVNULL)
+"""Lone slabs around 2^24 spins: what the library picks (layout AUTO) against fused launches of one-row units on the ballot layout at 2 .. 5 workgroups per CU and
+against the dense layout (tile launches / one launch per colour).  profiles/small_fused_probe_r04.txt
+Usage: small_fused_probe.py [X Y ...]"""
+import os
+import sys
+import time
+
+ROOT = __file__.rsplit("/", 2)[0]
+sys.path.insert(0, ROOT)
+import ising_gpu_amd as ig  # noqa: E402
+
+os.environ["ISING_ABORT_POLLS"] = "40000"
+
+
+def rate(X, Y, layout, env, H=0):
+    for k in ("ISING_FUSED", "ISING_TILES", "ISING_FUSED_WGS"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    sweeps = max(512, (1 << 35) // (X * Y) // 64 * 64)
+    try:
+        with ig.IsingSlab(X, Y, seed=1234, temp=ig.CRIT_TEMP_F32, layout=layout, strip_rows=H) as s:
+            s.init()
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.3:
+                s.sweep(64)
+                s.synchronize()
+            best = 0
+            for _ in range(3):
+                t0 = time.perf_counter()
+                s.sweep(sweeps)
+                s.synchronize()
+                best = max(best, X * Y * sweeps / (time.perf_counter() - t0) * 1e-9)
+            return best, f"{'ballot' if s.layout == ig.LAYOUT_BALLOT else 'dense'}{' fused H=%d' % s.strip_rows if s.fused else ''}{' tiles' if s.tiled else ''}"
+    except ig.IsingError:
+        return -1.0, "-"
+
+
+sizes = [tuple(map(int, sys.argv[i:i + 2])) for i in range(1, len(sys.argv), 2)] or (
+    [(8192, y) for y in (1024, 1280, 1536, 1792, 2048, 2560, 3072, 4096)] + [(16384, y) for y in (640, 768, 1024, 1152, 1408, 1536, 2048)] +
+    [(24576, y) for y in (512, 640, 768, 896, 1024)] + [(32768, y) for y in (384, 512, 640, 768, 1024, 2048)] + [(65536, y) for y in (256, 320, 384, 512, 1024)] +
+    [(12288, y) for y in (1024, 1536, 2048, 4096)] + [(6144, y) for y in (2048, 3072, 4096, 8192)] + [(20480, y) for y in (1024, 2048)])
+for X, Y in sizes:
+    nwc = (X + 8191) // 8192
+    lib, how = rate(X, Y, ig.LAYOUT_AUTO, {})
+    out = []
+    for wgs in (2, 3, 4, 5):
+        out.append(f"{wgs}: {rate(X, Y, ig.LAYOUT_BALLOT, {'ISING_FUSED': '1', 'ISING_FUSED_WGS': str(256 * wgs)}, 1)[0]:5.0f}")
+    d = rate(X, Y, ig.LAYOUT_DENSE, {})
+    print(f"{Y} x {X} ({X * Y / 2**24:.2f} x 2^24 spins, {nwc * Y // 4} tickets a level of one-row units): library {lib:6.0f} ({how}); ballot, fused, H = 1, per CU "
+          + "  ".join(out) + f"; dense {d[0]:6.0f} ({d[1]})", flush=True)
