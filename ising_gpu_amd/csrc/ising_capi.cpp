@@ -187,8 +187,12 @@ int fused_wgs_for(long long T, int H = 16, bool late = false, int nwc = 0) {
 	const int base = T >= 8192 ? 6 : (T >= 4096 ? 5 : (T >= 2048 ? 4 : (T >= 1024 ? 3 : (T >= 684 ? 2 : 1))));
 	if (!late || T >= 4096) return base;
 	if (H == 1 && nwc > 0) return std::min(T >= 2048 ? 6 : (T >= 1024 ? 5 : 4), std::max(2, fused_wgs_cap(T, nwc)));
-	if (H <= 2) return T >= 2048 ? 6 : (T >= 1024 ? 5 : (T >= 512 ? 4 : base));
-	return T >= 1024 ? base + 1 : base;
+	const int v = H <= 2 ? (T >= 2048 ? 6 : (T >= 1024 ? 5 : (T >= 512 ? 4 : base))) : (T >= 1024 ? base + 1 : base);
+	if (nwc <= 1) return v;
+	// taller units, rows of several wave columns (tools/wide_probe.py, profiles/wide_probe_r04.txt): the same cliff, at r = 0.75 (2 wave columns), 0.95 (3), 1.0 (4 .. 15),
+	// 1.33 (16 and more) -- 131072 x 1024 (H = 4, T = 1024) 2145 with four per CU, 2995 with three; 65536 x 1024 (H = 2) 1934 with five, 2295 with four; 32768 x 2048 2715 / 2848
+	const double r = nwc >= 16 ? 1.33 : (nwc >= 4 ? 1.0 : (nwc == 3 ? 0.95 : 0.75));
+	return std::min(v, std::max(2, (int)((double)T / (r * 256.0))));
 }
 // flips/ns of strips of H rows at wg workgroups per CU where T is ample (tools/grid_probe2.py on 65536^2 .. 131072^2, 24576^2,
 // 32768 x 16384, 16384^2, 8192^2 at the end of round 2).  One- and two-row units draw tickets from several counters.
