@@ -150,6 +150,9 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 #ifndef ISING_FUSED_WAIT_LATE // 1: fused launches may ask their units to draw before they wait for their parents (UpdateParams.wait_late); 0 compiles the request out
 #define ISING_FUSED_WAIT_LATE 1
 #endif
+#ifndef ISING_POLL_SLEEP // s_sleep units (64 cycles) between two looks of a waiting unit at its parents' counters
+#define ISING_POLL_SLEEP 32
+#endif
 #ifndef ISING_FUSED_STAGGER // s_sleep units (64 cycles each) between the start of successive dispatch rounds of a fused launch
 #define ISING_FUSED_STAGGER 100
 #endif
@@ -464,7 +467,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				TRN(6, (nsleep == 64));  // units that slept 64 polls and more
 				TRN(7, (nsleep == 256));
 #endif
-				__builtin_amdgcn_s_sleep(32);
+				__builtin_amdgcn_s_sleep(ISING_POLL_SLEEP);
 				if (lane < 3) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(seen) : "v"(dp) : "memory");
 			}
 			TRC(2); // completion counters (+ block constants)
