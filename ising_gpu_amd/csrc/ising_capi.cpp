@@ -506,7 +506,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		tp.TR = TR; tp.TWI = TWI; tp.ns = S;
 		if (ok && ising::dense_tiles_lds_bytes(tp) <= 64 * 1024) {
 			c->tile_rows = TR; c->tile_words = TWI; c->tile_sweeps = S; c->tile_threads = NT;
-			c->tile_xcd = pol.tile_xcd != 0 && ((cfg->Y / TR) % 8) == 0; // (tile rows in bands per XCD: +0 .. 2 %)
+			c->tile_xcd = pol.tile_xcd != 0 && (((long long)(wpr / TWI) * (cfg->Y / TR)) % 8) == 0; // (tiles in bands per XCD)
 		} else if (pol.tile_rows || pol.tile_words || pol.tile_threads) {
 			delete c;
 			return fail(ISING_E_ARG, "ISING_TILE_*: tiles of %d rows x %d words, %d sweeps, %d threads do not fit a %d x %d lattice", TR, TWI, S, NT, cfg->Y, cfg->X);

@@ -239,12 +239,10 @@ __global__ void __launch_bounds__(NT) dense_tile_k(const TileParams p) {
 	PhiloxBlockConst *ktab = reinterpret_cast<PhiloxBlockConst *>(lds + 2 * plane); // [2 ns half-sweeps][16 blocks]
 	const uint32_t inv_tw = 0xFFFFFFFFu / (uint32_t)TW + 1u; // i / TW = hi(i * inv_tw) for the i that occur (< 2^20)
 	const int ntx = wpr / p.TWI;
-	int tcy = (int)blockIdx.x / ntx;
-	const int tcx = (int)blockIdx.x - tcy * ntx;
-	if (p.xcd_rows > 0) { // workgroup b runs on XCD b % 8: give every XCD a band of tile rows
-		const int q = tcy >> 3, x = tcy & 7;
-		tcy = x * p.xcd_rows + q;
-	}
+	int t = (int)blockIdx.x;
+	if (p.xcd_rows > 0) t = (t & 7) * p.xcd_rows + (t >> 3); // workgroup b runs on XCD b % 8 (observed, for speed only): every XCD a band of tiles, the same every launch
+	const int tcy = t / ntx;
+	const int tcx = t - tcy * ntx;
 	const int row0 = tcy * p.TR - HR; // global row of tile row 0 (negative / beyond Y: periodic)
 	const int col0 = tcx * p.TWI - 1; // global word column of tile column 0
 

@@ -160,7 +160,7 @@ struct TileParams {
 	int ns;                 // sweeps in this launch (black first)
 	int gx, Y;              // 2048-column blocks per row; rows
 	int TR, TWI;            // tile: rows x 32-site words (TR divides Y, TWI divides 32 gx)
-	int xcd_rows;           // > 0: tile rows are dealt to the 8 XCDs in bands (neighbouring tiles share an L2)
+	int xcd_rows;           // > 0: tiles per XCD -- the tiles are dealt to the 8 XCDs in bands (neighbouring tiles share an L2)
 	unsigned long long *cnt; // not null: the up spins of the state the launch stores are added here (a print point, ising_sweep_counted)
 };
 hipError_t launch_dense_tiles(const TileParams &p, int threads, hipStream_t stream);

@@ -240,7 +240,7 @@ static int launch_tiles(ising_ctx *c, int it, int ns, bool from_second, unsigned
 	p.Y = c->cfg.Y;
 	p.TR = c->tile_rows;
 	p.TWI = c->tile_words;
-	p.xcd_rows = c->tile_xcd ? (c->cfg.Y / c->tile_rows) / 8 : 0;
+	p.xcd_rows = c->tile_xcd ? (c->gx * 32 / c->tile_words) * (c->cfg.Y / c->tile_rows) / 8 : 0;
 	p.cnt = cnt;
 	HIP_TRY(ising::launch_dense_tiles(p, c->tile_threads, c->stream));
 	return ISING_OK;

@@ -71,7 +71,6 @@ for X, Y in sizes:
     if rows:
         print(f"  best: {rows[0]}", flush=True)
         f, TR, TWI, S, NT, ok, tiles = rows[0]
-        if (Y // TR) % 8 == 0:
-            env = {"ISING_TILES": "1", "ISING_TILE_ROWS": str(TR), "ISING_TILE_WORDS": str(TWI), "ISING_TILE_SWEEPS": str(S), "ISING_TILE_THREADS": str(NT), "ISING_TILE_XCD": "1"}
-            f2, ok2, _ = run(X, Y, env, ref)
-            print(f"  the same with tile rows in bands per XCD: {f2:7.1f} flips/ns, state {'==' if ok2 else '!='}", flush=True)
+        env = {"ISING_TILES": "1", "ISING_TILE_ROWS": str(TR), "ISING_TILE_WORDS": str(TWI), "ISING_TILE_SWEEPS": str(S), "ISING_TILE_THREADS": str(NT), "ISING_TILE_XCD": "0"}
+        f2, ok2, _ = run(X, Y, env, ref)
+        print(f"  the same without the tiles dealt to the XCDs in bands (ISING_TILE_XCD=0): {f2:7.1f} flips/ns, state {'==' if ok2 else '!='}", flush=True)
