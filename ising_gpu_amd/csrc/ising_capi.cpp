@@ -182,7 +182,11 @@ double fused_level_ratio(int nwc) {
 	static const double R[5] = {0.54, 0.54, 0.68, 0.86, 0.90};
 	return nwc <= 4 ? R[nwc < 1 ? 1 : nwc] : 0.90 + 0.25 * (nwc - 4);
 }
-int fused_wgs_cap(long long T, int nwc) { return (int)std::min<long long>(6, (long long)((double)T / (fused_level_ratio(nwc) * 256.0))); }
+int fused_wgs_cap(long long T, int nwc) {
+	int cap = (int)std::min<long long>(6, (long long)((double)T / (fused_level_ratio(nwc) * 256.0)));
+	if (cap >= 5 && nwc >= 3 && T < 256 * cap) cap = 4; // (five and six per CU want a level of their own size on wide rows: 32768 x 1152 2143 with five, 2428 with four)
+	return cap;
+}
 int fused_wgs_for(long long T, int H = 16, bool late = false, int nwc = 0) {
 	const int base = T >= 8192 ? 6 : (T >= 4096 ? 5 : (T >= 2048 ? 4 : (T >= 1024 ? 3 : (T >= 684 ? 2 : 1))));
 	if (!late || T >= 4096) return base;
@@ -191,8 +195,12 @@ int fused_wgs_for(long long T, int H = 16, bool late = false, int nwc = 0) {
 	if (nwc <= 1) return v;
 	// taller units, rows of several wave columns (tools/wide_probe.py, profiles/wide_probe_r04.txt): the same cliff, at r = 0.75 (2 wave columns), 0.95 (3), 1.0 (4 .. 15),
 	// 1.33 (16 and more) -- 131072 x 1024 (H = 4, T = 1024) 2145 with four per CU, 2995 with three; 65536 x 1024 (H = 2) 1934 with five, 2295 with four; 32768 x 2048 2715 / 2848
-	const double r = nwc >= 16 ? 1.33 : (nwc >= 4 ? 1.0 : (nwc == 3 ? 0.95 : 0.75));
-	return std::min(v, std::max(2, (int)((double)T / (r * 256.0))));
+	// (two-row units get by on less: 16384 x 2176, T = 544: 2689 with three per CU; 24576 x 1536 and 32768 x 1152, T = 576: 2626 / 2583 with three, off the cliff with four)
+	const double r = H <= 2 ? (nwc >= 16 ? 1.33 : (nwc >= 5 ? 1.1 : (nwc == 4 ? 0.80 : (nwc == 3 ? 0.75 : 0.70))))
+	                        : (nwc >= 16 ? 1.33 : (nwc >= 4 ? 1.0 : (nwc == 3 ? 0.95 : 0.75)));
+	int cap = (int)((double)T / (r * 256.0));
+	if (cap >= 5 && nwc >= 3 && T < 256 * cap) cap = 4; // (as for one-row units: 32768 x 2048, T = 1024: 2848 with four per CU, 2646 with five)
+	return std::min(v, std::max(2, cap));
 }
 // flips/ns of strips of H rows at wg workgroups per CU where T is ample (tools/grid_probe2.py on 65536^2 .. 131072^2, 24576^2,
 // 32768 x 16384, 16384^2, 8192^2 at the end of round 2).  One- and two-row units draw tickets from several counters.
@@ -466,7 +474,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	                                     : choose_strip_rows(c->gx, cfg->Y, c->dense, c->ballot));
 	// (units that draw before they wait: two-row units with 512 tickets a level beat one-row units with 1024 -- 8192 x 4096 2820 vs 2660)
 	if (cfg->strip_rows <= 0 && (fused_shape || deep_ring) && c->H == 1 && pol.fused_wait_late != 0 && (cfg->XSL ? cfg->YSL : cfg->Y) % 2 == 0 &&
-	    fused_tickets(c->nwc(), launch_rows, 2) >= 512 && (c->nwc() == 1 || fused_wgs_cap(fused_tickets(c->nwc(), launch_rows, 2), c->nwc()) >= 3)) c->H = 2;
+	    fused_tickets(c->nwc(), launch_rows, 2) >= 512 && (c->nwc() == 1 || fused_wgs_for(fused_tickets(c->nwc(), launch_rows, 2), 2, true, c->nwc()) >= 3)) c->H = 2;
 	// (... where a row is one wave column; rows of several want more tickets a level: 32768 x 1024 ran 745 with two-row units, 2446 with one-row units,
 	// 16384 x 2048 2199 / 2575, 65536 x 512 371 / 1523 -- profiles/small_fused_probe_r04.txt)
 	if (cfg->Y % c->H) { const int h = c->H; delete c; return fail(ISING_E_ARG, "strip_rows %d does not divide Y %d", h, cfg->Y); }
