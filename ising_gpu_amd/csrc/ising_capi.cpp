@@ -441,9 +441,10 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	c->fused = pol.fused >= 0 ? pol.fused != 0 : ((spins >= 3 * (1LL << 23) || small_fused) && c->nwc() < 128);
 	// AUTO: the ballot kernel's two-phase row pipeline wins from 2^27 spins per slab up -- from 2^25 where fused launches
 	// apply (a slab that wraps in place, a ring slab that can keep ghost rows); below, the dense kernel is ahead.  (A partly dead last wave column wastes its
-	// dead lanes' draws: worth it while they are under a tenth of the row -- the dense kernel is 12 % behind.)
-	// (up to 2^26 spins the dense layout's launches cost more than a quarter of dead lanes: 12288 x 1536 1898 vs 1245, 12288 x 2048 1925 vs 1618)
-	const bool ballot_pays = whole || 10 * c->gx > 9 * 4 * c->nwc() || (spins <= (1LL << 26) && 4 * c->gx >= 3 * 4 * c->nwc());
+	// dead lanes' draws: rounds 1-3 accepted a tenth of the row.)
+	// (end of round 4, measured per fill: a sixth of dead lanes pays at every size -- 20480 x 4096 2495 vs 2075, 20480^2 2815 vs 2687, 28672^2 (an eighth) 3038 vs 2708 --,
+	// a quarter up to 2^27 spins -- 12288 x 1536 1898 vs 1245, 12288 x 8192 2436 vs 2242, 12288 x 16384 2500 vs 2592)
+	const bool ballot_pays = whole || 5 * c->gx >= 4 * 4 * c->nwc() || (spins <= (1LL << 27) && 4 * c->gx >= 3 * 4 * c->nwc());
 	// (a ring slab that can keep ghost rows sweeps in fused launches as well, see below)
 	const bool deep_can = !c->wrap && !cfg->XSL && !(cfg->use_J && cfg->coupling_mem) && !cfg->lattice_mem && cfg->Y >= 4 &&
 	                      !(pol.ring_ghost >= 0 && pol.ring_ghost < 2);
@@ -532,7 +533,10 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		// ~80 tickets per us; 8192^2 with one-row units at 2600 flips/ns needs 159 (four counters), with two-row units
 		// 79 (two).  ISING_FUSED_TICKETS2=0/2/4 overrides.
 		const long long T0 = fused_tickets(c->nwc(), cfg->Y, c->H); // (without a ring slab's ghost rows)
-		c->fused_tickets2 = (T0 <= 2048 && c->H == 1) ? 4 : ((T0 <= 1024 && c->H == 2) ? 2 : 0);
+		// (end of round 4: whatever T0 -- one counter caps one-row units at 1350 flips/ns and two-row units at 2690, the rate at which it hands tickets out:
+		// 24576 x 4096, H = 2, T0 = 1536: 2697 with one counter, 2999 with two)
+		(void)T0;
+		c->fused_tickets2 = c->H == 1 ? 4 : (c->H == 2 ? 2 : 0);
 		if (pol.fused_tickets2 >= 0) c->fused_tickets2 = pol.fused_tickets2;
 	}
 

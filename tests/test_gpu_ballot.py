@@ -129,7 +129,9 @@ def test_auto_layout_picks_ballot_where_it_applies(gpu):
         assert s.layout == ig.LAYOUT_DENSE and s.tiled
     with ig.IsingSlab(12288, 2048, temp=1.5) as s:      # 1.5 wave columns: up to 2^26 spins a quarter of dead lanes costs less than the dense layout's launches
         assert s.layout == BAL and s.fused
-    with ig.IsingSlab(20480, 8192, temp=1.5) as s:      # 10 column groups = 2.5 wave columns: too many dead lanes
+    with ig.IsingSlab(20480, 8192, temp=1.5) as s:      # 10 column groups = 2.5 wave columns: a sixth of dead lanes pays at every size (end of round 4)
+        assert s.layout == BAL
+    with ig.IsingSlab(12288, 16384, temp=1.5) as s:     # 1.5 wave columns: a quarter of dead lanes pays up to 2^27 spins only
         assert s.layout == ig.LAYOUT_DENSE
     with ig.IsingSlab(16384, 8192, temp=1.5, XSL=2048, YSL=16) as s:
         assert s.layout == BAL

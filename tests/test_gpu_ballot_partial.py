@@ -66,7 +66,9 @@ def test_partial_wave_column_formats_ring_and_relayout(gpu, oracle_mod):
 def test_auto_layout_and_partial_wave_columns(gpu):
     with ig.IsingSlab(2048 * 27, 4096, temp=2.0) as s:  # 2^27.8 spins, 27 column groups: 6 full wave columns + 3 of 4 groups
         assert s.layout == ig.LAYOUT_BALLOT
-    with ig.IsingSlab(2048 * 13, 8192, temp=2.0) as s:  # 13 groups: a quarter of the fourth wave column alive -> dense pays
+    with ig.IsingSlab(2048 * 13, 8192, temp=2.0) as s:  # 13 groups of 16: 19 % of dead lanes still pay (end of round 4: a sixth pays at every size)
+        assert s.layout == ig.LAYOUT_BALLOT
+    with ig.IsingSlab(2048 * 9, 8192, temp=2.0) as s:   # 9 groups of 12: a quarter of dead lanes above 2^27 spins -> dense pays
         assert s.layout == ig.LAYOUT_DENSE
     with ig.IsingSlab(2048 * 27, 4096, temp=2.0, XSL=2048, YSL=2048) as s:
         assert s.layout == ig.LAYOUT_DENSE  # sub-lattices of other widths stay on the dense kernel
