@@ -366,7 +366,7 @@ extern "C" int ising_sweep_counted(ising_ctx *c, int first_it, int nsweeps, int 
 	int it = first_it, left = nsweeps;
 	while (left > 0) {
 		// launches until `chunk` measurements are in flight or the sweeps are done
-		HIP_TRY(hipMemsetAsync(c->d_cnt, 0, chunk * slots * sizeof(uint32_t), c->stream));
+		if (n > got) HIP_TRY(hipMemsetAsync(c->d_cnt, 0, std::min<size_t>(chunk, (size_t)(n - got)) * slots * sizeof(uint32_t), c->stream)); // (the slots of the measurements still to come, at most a chunk)
 		int inflight = 0;
 		while (left > 0) {
 			int ns = std::min(left, per_launch);
