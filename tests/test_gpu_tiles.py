@@ -81,10 +81,10 @@ def test_tiles_default_rule(gpu, oracle_mod, monkeypatch):
         assert not s.tiled
 
 
-def test_tiles_counter_high_word(gpu, oracle_mod, monkeypatch):
+@pytest.mark.parametrize("it0", [(1 << 27) - 3, (1 << 30) + 12345, (1 << 31) - 12])
+def test_tiles_counter_high_word(gpu, oracle_mod, monkeypatch, it0):
     """Iterations from 2^27 on: the draw-block counter 16 (2 it + colour) needs its high word (optimized/main.cu:621: the offset is 64 bits)."""
     _env(monkeypatch, TILES=1, TILE_SWEEPS=4)
-    it0 = (1 << 27) - 3
     orc = oracle_mod.OracleLattice(2048, 64, seed=5, temp=TC).init()
     with ig.IsingSlab(2048, 64, seed=5, temp=TC, layout=ig.LAYOUT_DENSE) as s:
         s.init()
