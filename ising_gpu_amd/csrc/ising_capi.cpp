@@ -200,6 +200,7 @@ int fused_wgs_for(long long T, int H = 16, bool late = false, int nwc = 0) {
 	                        : (nwc >= 16 ? 1.33 : (nwc >= 4 ? 1.0 : (nwc == 3 ? 0.95 : 0.75)));
 	int cap = (int)((double)T / (r * 256.0));
 	if (cap >= 5 && nwc >= 3 && T < 256 * cap) cap = 4; // (as for one-row units: 32768 x 2048, T = 1024: 2848 with four per CU, 2646 with five)
+	if (cap >= 5 && nwc >= 16 && 4 * T < 7 * 256 * cap) cap = 4; // (rows of 16 wave columns: 131072 x 2048, T = 2048: 3219 with four, 2923 with five)
 	return std::min(v, std::max(2, cap));
 }
 // flips/ns of strips of H rows at wg workgroups per CU where T is ample (tools/grid_probe2.py on 65536^2 .. 131072^2, 24576^2,
