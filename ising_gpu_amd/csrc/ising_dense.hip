@@ -227,6 +227,10 @@ __global__ void __launch_bounds__(THREADS) dense_update_k(const UpdateParams p) 
 // the tile.  The launch reads one buffer and writes the other (the neighbours' halo loads race with nothing).
 // An item = one 32-site word of one row = 8 Philox blocks of one reference thread (tid from the row and the word's column,
 // counter word 16 (2 it + colour) + 8 j + m: SURVEY 8a-R2), dealt to the threads of the workgroup in turn.
+// Measured (tools/tile_probe.py, profiles/tile_probe_r04.txt, rocprof_r04_tiles_*.txt): 2048^2 427 -> 876 flips/ns, 4096^2 1362 -> 1607; the launches run back to
+// back (19.8 us per 4 sweeps at 2048^2, ~7 of them fixed), the vector ALU is busy 59 % / 86 % of a wave's life at 2048^2 / 4096^2.  Tried and dropped: the blocks of
+// an item 2 or 8 at a time instead of 4 (+-2 %), only the (ns + 1) / 2 blocks of a halo word that can reach the tile as items of their own (-2 .. -6 %: a second class
+// of items costs more in uneven waves than it saves).
 template <int NT>
 __global__ void __launch_bounds__(NT) dense_tile_k(const TileParams p) {
 	extern __shared__ uint32_t lds[];
