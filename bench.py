@@ -403,6 +403,10 @@ def main():
             # them) -- every iteration that is a multiple of 16, as the reference's loop prints -- and the final count as ever
             ncounts = len(slab.sweep_counted(args.steps, 16)) + 1
             last = slab.count()
+        elif hasattr(ring, "sweep_counted"):
+            # the library's ring: every rank's deep launches count their own rows (ising_rank_sweep_counted), the sums travel over the rank transport
+            ncounts = len(ring.sweep_counted(args.steps, 16)) + 1
+            last = ring.count()
         else:
             while done < args.steps:
                 n = min(16, args.steps - done)
@@ -421,7 +425,8 @@ def main():
                       "what": "the same steps with the up/down counts of every iteration that is a multiple of 16, and of the last one, inside the timed "
                               "region (the reference's -p 16 methodology, optimized/main.cu:1806-1810)"
                               + ("; N = 1: counted inside the fused launches (ising_sweep_counted), read back with the last" if ring is None else
-                                 "; rings: a blocking count of all ranks every 16 sweeps")}
+                                 ("; the library's ring: counted inside every rank's deep launches (ising_rank_sweep_counted), summed over the rank transport"
+                                  if hasattr(ring, "sweep_counted") else "; rings: a blocking count of all ranks every 16 sweeps"))}
 
     layout_name, layout_text = {
         ig.LAYOUT_NIBBLE: ("nibble", "reference 4 bit/spin"),

@@ -318,6 +318,12 @@ int ising_ring_exchange(ising_ctx **ctxs, int n, int color);
 int ising_ring_init_couplings(ising_ctx **ctxs, int n);
 /* `nsweeps` full sweeps over all slabs, iterations first_it .. first_it+nsweeps-1 (the hot loop).  Asynchronous. */
 int ising_ring_sweep(ising_ctx **ctxs, int n, int first_it, int nsweeps);
+/* The same WITH the reference's print points (optimized/main.cu:1806-1810: countSpins over all devices whenever the iteration is a multiple of
+ * printFreq, inside the timed loop; see ising_sweep_counted): ups[k] = the up spins of the WHOLE lattice after the k-th iteration of the call
+ * that is a multiple of `every`.  Where the ring sweeps its slabs through ghost rows with the exchanges in the launches' tails (ballot layout,
+ * the default), every slab's launches count their own rows as they store them -- no launch boundary, count kernel or read-back between two
+ * print points --; elsewhere the call sweeps and counts in turn.  Blocking. */
+int ising_ring_sweep_counted(ising_ctx **ctxs, int n, int first_it, int nsweeps, int every, uint64_t *ups, int max_counts, int *ncounts);
 /* Blocks until every slab's compute and comm streams are idle. */
 int ising_ring_synchronize(ising_ctx **ctxs, int n);
 /* Totals over the ring: countSpins (:831-868) and the bond sum of ising_bond_equal.  Blocking. */
@@ -337,6 +343,9 @@ int ising_rank_detach(ising_ctx *ctx, int abort_pending);  /* ncclCommDestroy, o
 int ising_rank_exchange(ising_ctx *ctx, int color);
 int ising_rank_init_couplings(ising_ctx *ctx);
 int ising_rank_sweep(ising_ctx *ctx, int first_it, int nsweeps);
+/* ising_ring_sweep_counted, one process per slab: collective (every rank calls it with the same arguments); the ranks' sums travel over the
+ * rank transport (ncclAllReduce / the peer transport's shared-memory reduction). */
+int ising_rank_sweep_counted(ising_ctx *ctx, int first_it, int nsweeps, int every, uint64_t *ups, int max_counts, int *ncounts);
 /* Waits until both streams of the slab are idle; timeout_ms >= 0 polls and returns ISING_E_TIMEOUT when the time is up
  * (a hung exchange can then be abandoned with ising_rank_detach(ctx, 1)); < 0 blocks. */
 int ising_rank_wait(ising_ctx *ctx, int timeout_ms);

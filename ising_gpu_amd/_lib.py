@@ -77,6 +77,8 @@ PROTOTYPES = {
     "ising_strip_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ising_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ising_sweep_counted": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int)]),
+    "ising_ring_sweep_counted": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int)]),
+    "ising_rank_sweep_counted": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int)]),
     "ising_sweep_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ising_sweep_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "ising_halo_ptrs": (C.c_int, [C.c_void_p, C.c_int] + [C.POINTER(C.c_void_p)] * 4 + [C.POINTER(C.c_size_t)]),

@@ -704,13 +704,14 @@ int main(int argc, char **argv) {
 	// pieces of N sweeps with a count and a read-back in between -- 16384^2 at -p 16: 3057 -> 3290 flips/ns.  The lines are the same; they
 	// appear in bursts of up to 64.  Anything else a print point may do (-m early exit, --energy, -c, -o, the exponential series) keeps the
 	// reference's order of events below.
-	const bool counted = printFreq > 0 && !printExp && tgtMagn == -1.0 && !printEnergy && !corrOut && !dumpOut && ndev == 1;
+	// (several devices: ising_ring_sweep_counted -- every slab's deep launches count their own rows)
+	const bool counted = printFreq > 0 && !printExp && tgtMagn == -1.0 && !printEnergy && !corrOut && !dumpOut;
 	while (counted && j < jend) {
 		long long next = std::min<long long>(jend, (long long)(j / printFreq + 64) * printFreq);
 		if (tempUpdFreq) next = std::min<long long>(next, (long long)(j / tempUpdFreq + 1) * tempUpdFreq);
 		uint64_t ups[80];
 		int k = 0;
-		CHECK(ising_sweep_counted(ring.ctx[0], j + 1, (int)(next - j), printFreq, ups, 80, &k));
+		CHECK(ising_ring_sweep_counted(ring.ctx.data(), ndev, j + 1, (int)(next - j), printFreq, ups, 80, &k));
 		for (int i = 0, it = (j / printFreq + 1) * printFreq; i < k; i++, it += printFreq) {
 			cntPos = ups[i];
 			cntNeg = nspins - ups[i];
@@ -720,7 +721,7 @@ int main(int argc, char **argv) {
 		if (tempUpdFreq && (j % tempUpdFreq) == 0) { // optimized/main.cu:1848-1860
 			temp = std::max(MIN_TEMP, temp + tempUpdStep);
 			printf("Changing temperature to %f\n", temp);
-			CHECK(ising_set_temperature(ring.ctx[0], temp));
+			for (int d = 0; d < ndev; d++) CHECK(ising_set_temperature(ring.ctx[d], temp));
 			float tab[10];
 			CHECK(ising_get_tables(ring.ctx[0], tab, nullptr));
 			for (int i = 0; i < 2; i++)

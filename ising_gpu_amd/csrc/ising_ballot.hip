@@ -183,7 +183,7 @@ typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 // (16384^2: 3119 vs 3321 flips/ns at two units per workgroup and level, 2967 vs 3211 at one; 8192^2 2510 vs 2793; 32768^2 3179 vs 3475;
 // profiles/static_probe_r04a.txt, _r04b.txt; the code is in the history at 851dc8e): the 6 % of a workgroup's time that tickets cost
 // buy a load balance between workgroups of unequal speed that is worth more -- with fixed owners every level waits for its slowest.)
-// COUNT (round 4; fused launches of a lone lattice): the up-spin count of the reference's print points (countSpins every `-p` sweeps,
+// COUNT (round 4; fused launches of a lone lattice, and of a ring slab over its own rows): the up-spin count of the reference's print points (countSpins every `-p` sweeps,
 // optimized/main.cu:1806-1810) is taken INSIDE the launch.  A print point every 16 sweeps otherwise cuts the launches into pieces of 16
 // with two count launches and a read-back in between (16384^2: 3057 against 3289 flips/ns, 8192^2 2539 against 3023).  Here every unit
 // of a measured sweep's two levels takes the popcount of the words it stores -- two v_bcnt per row -- and leaves its sum in a slot of
@@ -714,7 +714,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 					rj += 4 * wpr;
 				}
 				const uint64_t nw = me ^ (flips64(me, nu, nc, nd, sd, c3, c4) & live);
-				if (COUNT) cnt_up += (uint32_t)__popcll(nw); // (dead lanes are zero in memory)
+				if (COUNT && (unsigned)lr < (unsigned)p.Y) cnt_up += (uint32_t)__popcll(nw); // (dead lanes are zero in memory; a ring slab's ghost rows are its neighbours' to count)
 				if (FUSED) {
 					st64_coh_issue<STREAM>(rd, lane * 8, nw);
 					if (p.wrap) { // the halo rows that mirror this colour's edge rows

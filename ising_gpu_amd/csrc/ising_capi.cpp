@@ -46,6 +46,7 @@ int read_policy(ising_policy *pol) {
 	if (num("ISING_FUSED_MAX_SWEEPS", &v)) pol->fused_max_sweeps = v > 0 ? v : 0;
 	if (num("ISING_FUSED_WAIT_LATE", &v)) pol->fused_wait_late = v < 0 ? 0 : (v > 2 ? 2 : v);
 	if (num("ISING_RING_GHOST", &v)) pol->ring_ghost = v;
+	if (num("ISING_RING_COUNTED", &v)) pol->ring_counted = v < 0 ? 0 : (v > 2 ? 2 : v);
 	if (num("ISING_TILES", &v)) pol->tiles = v != 0;
 	if (num("ISING_TILE_ROWS", &v) && v > 0) pol->tile_rows = v;
 	if (num("ISING_TILE_WORDS", &v) && v > 0) pol->tile_words = v;

@@ -24,6 +24,7 @@ struct ising_policy {
 	int fused_max_sweeps = 0; // ISING_FUSED_MAX_SWEEPS=n: sweeps one fused launch of a single slab carries at most (0: ~50 ms worth, 32 .. 4096)
 	int tiles = -1;          // ISING_TILES=0/1: small lattices on the dense layout sweep in tile launches of several sweeps (-1: by lattice size)
 	int tile_rows = 0, tile_words = 0, tile_sweeps = 0, tile_threads = 0, tile_xcd = -1; // ISING_TILE_ROWS / _WORDS / _SWEEPS / _THREADS / _XCD (0 / -1: by lattice size)
+	int ring_counted = -1;   // ISING_RING_COUNTED=0/1/2: print points of rings never / where possible (default) / always (an error where not) inside the deep launches
 	int ring_ghost = -1;     // ISING_RING_GHOST=n: ghost rows of ballot ring slabs (-1: 64)
 	bool no_ballot = false;  // ISING_NO_BALLOT: layout AUTO never picks the ballot layout
 	int tail_rows = -1, tail_h = 1; // ISING_TAIL=rows[,h]: one-row tail strips of one-launch-per-colour launches (-1: automatic, 0: off)
@@ -126,7 +127,8 @@ struct ising_ctx {
 	// In-launch counts (ising_sweep_counted): accumulators of the measurements of one call (64 lines of 64 bytes each), and the one-shot
 	// request to launch_ranges: which sweeps of the next fused launch are measured, and the number of its first measurement
 	uint32_t *d_cnt = nullptr;     // per measurement 2 x (waves of a level) slots, then (64-bit) one sum per measurement
-	size_t cnt_cap = 0;            // measurements d_cnt holds
+	size_t cnt_cap = 0;            // bytes d_cnt holds
+	int ring_cnt_every = 0, ring_cnt_inflight = 0; // ring slab: the deep launches of the call under way count the sweeps whose iteration is a multiple of this (0: none); measurements so far
 	unsigned long long cnt_mask_next = 0;
 	int cnt_slot0_next = 0;
 	// Exchange statistics (ising_exchange_stats_begin / _fetch; sweep_deep_overlapped): four events per sampled exchange --
@@ -218,6 +220,7 @@ void ring_abort_drain(ising_ctx *c);
 // hipStreamSynchronize(c->stream), then: did a fused launch give up (completion counters that never came: UpdateParams.abort_flag)?
 // If so its tickets, counters and their host-side bases start from zero again and ISING_E_STATE is returned.
 int sync_checked(ising_ctx *c);
+int cnt_reserve(ising_ctx *c, size_t strips, size_t *slots, size_t *chunk, unsigned long long **d_sum); // ising_update.cpp: the slots of in-launch counts
 int check_abort(ising_ctx *c);
 // the switches of DESIGN 8a from the environment (ISING_E_ARG for a value that means nothing)
 int read_policy(ising_policy *pol);

@@ -544,6 +544,13 @@ int sweep_deep_overlapped(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 			// exchange statistics: this launch and the exchange it feeds go into slot xs[k] (events on the dispatch packet, no extra packets)
 			xs[k] = (c->xs_on && c->xs_n < c->xs_cap) ? c->xs_n++ : -1;
 			if (xs[k] >= 0) { c->launch_start_next = c->xs_ev[4 * xs[k]]; c->launch_stop_next = c->xs_ev[4 * xs[k] + 1]; }
+			if (c->ring_cnt_every > 0) { // print points inside this launch (ring_sweep_counted below): its sweeps whose iteration is a multiple of `every`
+				unsigned long long mask = 0;
+				for (int j = 0; j < ns; j++) if ((it + j) % c->ring_cnt_every == 0) mask |= 1ull << j;
+				c->cnt_mask_next = mask;
+				c->cnt_slot0_next = c->ring_cnt_inflight;
+				c->ring_cnt_inflight += (int)__builtin_popcountll(mask);
+			}
 			if (int rc = ising_host::update_deep(c, it, 2 * ns, true)) return rc;
 		}
 		for (int k = 0; k < n; k++) {
@@ -601,6 +608,67 @@ int sweep_local(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 			if (int rc = transfer(ctxs, n, color, true)) return rc;
 			for (int k = 0; k < n; k++) if (int rc = ising_update_color(ctxs[k], it, color, 1, ctxs[k]->cfg.Y - 1)) return rc;
 		}
+	}
+	return ISING_OK;
+}
+
+// ising_ring_sweep / ising_rank_sweep with the reference's print points taken INSIDE the deep launches (as ising_sweep_counted does for a lone slab): where the ring
+// sweeps its slabs through their ghost rows with the exchange in the launches' tails, the launches of every slab count the up spins of their OWN rows after every
+// iteration that is a multiple of `every`; mine[k] = this process's slabs' sum for the k-th of them.  ISING_E_UNSUPPORTED-like answer (1 in *fallback) anywhere else.
+int ring_sweep_counted(ising_ctx **ctxs, int n, int first_it, int nsweeps, int every, std::vector<unsigned long long> &mine, bool *fallback) {
+	*fallback = true;
+	if (int rc = settle_layout(ctxs, n)) return rc;
+	bool deep = nsweeps > 0 && !ctxs[0]->cfg.XSL && !ctxs[0]->cfg.use_J && ctxs[0]->ghost() > 1 && ctxs[0]->pol.overlap != 0;
+	for (int k = 0; k < n; k++)
+		deep = deep && ctxs[k]->ballot && ctxs[k]->ghost() == ctxs[0]->ghost() && !ising_host::needs_generic(ctxs[k]) && !ctxs[k]->store_ring && !ctxs[k]->copy_inline &&
+		       ctxs[k]->d_edge && ctxs[k]->comm;
+	if (ctxs[0]->pol.ring_counted == 0) return ISING_OK;
+	if (!deep) return ctxs[0]->pol.ring_counted == 2 ? fail(ISING_E_STATE, "ISING_RING_COUNTED=2: this ring does not sweep through ghost rows with overlapped exchanges") : ISING_OK;
+	*fallback = false;
+	const int G = ctxs[0]->ghost();
+	mine.clear();
+	std::vector<size_t> slots(n), chunk(n);
+	std::vector<unsigned long long *> d_sum(n);
+	size_t per_chunk = 64;
+	for (int k = 0; k < n; k++) {
+		ising_ctx *c = ctxs[k];
+		if (int rc = bind(c)) return rc;
+		const size_t strips = ((size_t)c->cfg.Y + 2 * (size_t)G - 2 + (size_t)c->H - 1) / (size_t)c->H; // rows [-(G - 1), Y + G - 1) of a deep launch
+		if (int rc = ising_host::cnt_reserve(c, strips, &slots[k], &chunk[k], &d_sum[k])) return rc;
+		per_chunk = std::min(per_chunk, chunk[k]);
+	}
+	std::vector<unsigned long long> h(per_chunk);
+	int it = first_it, left = nsweeps;
+	while (left > 0) {
+		// as many sweeps as hold `per_chunk` measurements at most
+		int ns = 0, m = 0;
+		while (ns < left) {
+			if ((it + ns) % every == 0) { if (m == (int)per_chunk) break; m++; }
+			ns++;
+		}
+		for (int k = 0; k < n; k++) {
+			ising_ctx *c = ctxs[k];
+			if (int rc = bind(c)) return rc;
+			if (m) HIP_TRY(hipMemsetAsync(c->d_cnt, 0, (size_t)m * slots[k] * sizeof(uint32_t), c->stream));
+			c->ring_cnt_every = every;
+			c->ring_cnt_inflight = 0;
+		}
+		const int rc = sweep_deep_overlapped(ctxs, n, it, ns);
+		for (int k = 0; k < n; k++) ctxs[k]->ring_cnt_every = 0;
+		if (rc) return rc;
+		const size_t base = mine.size();
+		mine.resize(base + (size_t)m, 0ull);
+		for (int k = 0; k < n && m; k++) {
+			ising_ctx *c = ctxs[k];
+			if (int rc2 = bind(c)) return rc2;
+			if (c->ring_cnt_inflight != m) return fail(ISING_E_STATE, "counted ring sweep: %d measurements launched, %d expected", c->ring_cnt_inflight, m);
+			HIP_TRY(ising::launch_count_fold(c->d_cnt, slots[k], m, d_sum[k], c->stream));
+			HIP_TRY(hipMemcpyAsync(h.data(), d_sum[k], (size_t)m * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+			if (int rc2 = ising_host::sync_checked(c)) return rc2;
+			for (int q = 0; q < m; q++) mine[base + (size_t)q] += h[(size_t)q];
+		}
+		it += ns;
+		left -= ns;
 	}
 	return ISING_OK;
 }
@@ -794,6 +862,40 @@ int ising_ring_sweep(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 	return sweep_local(ctxs, n, first_it, nsweeps);
 }
 
+// ising_ring_sweep with the reference's print points (ising_sweep_counted for rings): ups[k] = the up spins of the WHOLE lattice after the k-th iteration of the call
+// that is a multiple of `every`.  Counted inside the deep launches where the ring sweeps through ghost rows with overlapped exchanges; sweeps and counts in turn elsewhere.
+int ising_ring_sweep_counted(ising_ctx **ctxs, int n, int first_it, int nsweeps, int every, uint64_t *ups, int max_counts, int *ncounts) {
+	if (!ups || !ncounts) return fail(ISING_E_ARG, "null argument");
+	if (first_it < 0 || nsweeps < 0 || every < 1) return fail(ISING_E_ARG, "bad iteration range or count interval");
+	if (int rc = ring_bind(ctxs, n)) return rc;
+	if (ctxs[0]->wrap) return ising_sweep_counted(ctxs[0], first_it, nsweeps, every, ups, max_counts, ncounts);
+	const long long last = (long long)first_it + nsweeps - 1;
+	const long long want = nsweeps > 0 ? last / every - ((long long)first_it - 1) / every : 0;
+	*ncounts = 0;
+	if (want > max_counts) return fail(ISING_E_ARG, "%lld counts, room for %d", want, max_counts);
+	std::vector<unsigned long long> mine;
+	bool fallback = true;
+	if (int rc = ring_sweep_counted(ctxs, n, first_it, nsweeps, every, mine, &fallback)) return rc;
+	if (!fallback) {
+		for (size_t k = 0; k < mine.size(); k++) ups[k] = mine[k];
+		*ncounts = (int)mine.size();
+		return ISING_OK;
+	}
+	int it = first_it, k = 0;
+	while (it <= last) { // the reference's own order of events
+		const long long next = std::min<long long>(last, ((long long)it + every - 1) / every * every);
+		if (int rc = sweep_local(ctxs, n, it, (int)(next - it + 1))) return rc;
+		it = (int)next + 1;
+		if (next % every == 0) {
+			uint64_t up = 0, dw = 0;
+			if (int rc = ising_ring_count(ctxs, n, &up, &dw)) return rc;
+			ups[k++] = up;
+		}
+	}
+	*ncounts = k;
+	return ISING_OK;
+}
+
 int ising_ring_init_couplings(ising_ctx **ctxs, int n) {
 	if (int rc = ring_bind(ctxs, n)) return rc;
 	return couplings_local(ctxs, n);
@@ -937,6 +1039,46 @@ static int rank_allreduce_u64(ising_ctx *c, unsigned long long *d_val, unsigned 
 	RCCL_TRY(api->AllReduce(d_val, c->d_acc + 2, 1, ncclUint64, ncclSum, static_cast<ncclComm_t>(c->rccl_comm), c->stream));
 	HIP_TRY(hipMemcpyAsync(host_out, c->d_acc + 2, sizeof(*host_out), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(hipStreamSynchronize(c->stream));
+	return ISING_OK;
+}
+
+// ising_rank_sweep with print points: collective (every rank calls it with the same arguments); the ranks' sums travel over the rank transport.
+int ising_rank_sweep_counted(ising_ctx *c, int first_it, int nsweeps, int every, uint64_t *ups, int max_counts, int *ncounts) {
+	if (int rc = rank_check(c)) return rc;
+	if (!ups || !ncounts) return fail(ISING_E_ARG, "null argument");
+	if (first_it < 0 || nsweeps < 0 || every < 1) return fail(ISING_E_ARG, "bad iteration range or count interval");
+	const long long last = (long long)first_it + nsweeps - 1;
+	const long long want = nsweeps > 0 ? last / every - ((long long)first_it - 1) / every : 0;
+	*ncounts = 0;
+	if (want > max_counts) return fail(ISING_E_ARG, "%lld counts, room for %d", want, max_counts);
+	std::vector<unsigned long long> mine;
+	bool fallback = true;
+	if (int rc = ring_sweep_counted(&c, 1, first_it, nsweeps, every, mine, &fallback)) return rc;
+	// (every rank takes the same branch: the conditions are the configuration's, which the ranks share -- the sum below says so)
+	unsigned long long fb = 0;
+	if (int rc = ising_host::rank_sum_u64(c, fallback ? 1ull : 0ull, &fb)) return rc;
+	if (fb != 0 && fb != (unsigned long long)c->cfg.nslabs) return fail(ISING_E_STATE, "counted rank sweep: the ranks disagree about the launch form");
+	if (!fallback) {
+		for (size_t k = 0; k < mine.size(); k++) {
+			unsigned long long tot = 0;
+			if (int rc = ising_host::rank_sum_u64(c, mine[k], &tot)) return rc;
+			ups[k] = tot;
+		}
+		*ncounts = (int)mine.size();
+		return ISING_OK;
+	}
+	int it = first_it, k = 0;
+	while (it <= last) {
+		const long long next = std::min<long long>(last, ((long long)it + every - 1) / every * every);
+		if (int rc = sweep_local(&c, 1, it, (int)(next - it + 1))) return rc;
+		it = (int)next + 1;
+		if (next % every == 0) {
+			uint64_t up = 0, dw = 0;
+			if (int rc = ising_rank_count(c, &up, &dw)) return rc;
+			ups[k++] = up;
+		}
+	}
+	*ncounts = k;
 	return ISING_OK;
 }
 

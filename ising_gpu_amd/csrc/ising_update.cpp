@@ -320,6 +320,22 @@ int ising_host::sweep_alone(ising_ctx *c, int first_it, int nsweeps) {
 	return ISING_OK;
 }
 
+// In-launch counts (ising_ballot.hip: COUNT): the wave slots of a chunk of measurements of fused launches over `strips` strips, and their sums behind them.
+// slots: per measurement one per wave of a level and colour; a call is worked off in chunks of measurements whose slots fit 64 MiB.
+int ising_host::cnt_reserve(ising_ctx *c, size_t strips, size_t *slots, size_t *chunk, unsigned long long **d_sum) {
+	const size_t waves = ((size_t)4 * c->nwc() * strips + 15) / 16 * 4; // 4 waves per workgroup unit, as launch_ballot_update counts them
+	*slots = 2 * waves;
+	*chunk = std::max<size_t>(1, std::min<size_t>(64, ((size_t)64 << 20) / (*slots * sizeof(uint32_t))));
+	const size_t words = (*chunk * *slots + 15) / 16 * 16, bytes = words * sizeof(uint32_t) + *chunk * sizeof(unsigned long long) + 64;
+	if (c->cnt_cap < bytes) {
+		if (c->d_cnt) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_cnt)); c->d_cnt = nullptr; c->cnt_cap = 0; }
+		HIP_TRY(hipMalloc((void **)&c->d_cnt, bytes));
+		c->cnt_cap = bytes;
+	}
+	*d_sum = reinterpret_cast<unsigned long long *>(c->d_cnt + words);
+	return ISING_OK;
+}
+
 // The reference's loop with its print points (optimized/main.cu:1763-1810: sweep, and countSpins whenever the iteration is a multiple of
 // printFreq): `nsweeps` sweeps, the up-spin count after every iteration `it` with it % every == 0.  Where ising_sweep issues fused
 // launches (a lone slab on the ballot layout, no sub-lattices, no couplings) the counts are taken INSIDE the launches -- no launch
@@ -350,16 +366,9 @@ extern "C" int ising_sweep_counted(ising_ctx *c, int first_it, int nsweeps, int 
 		*ncounts = k;
 		return ISING_OK;
 	}
-	// slots: per measurement one per wave of a level and colour; a call is worked off in chunks of measurements whose slots fit 64 MiB
-	const size_t waves = ((size_t)4 * c->nwc() * (size_t)c->nstrips + 15) / 16 * 4; // 4 waves per workgroup unit, as launch_ballot_update counts them
-	const size_t slots = 2 * waves;
-	const size_t chunk = std::max<size_t>(1, std::min<size_t>(64, ((size_t)64 << 20) / (slots * sizeof(uint32_t))));
-	if (c->cnt_cap < chunk) {
-		if (c->d_cnt) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_cnt)); c->d_cnt = nullptr; c->cnt_cap = 0; }
-		HIP_TRY(hipMalloc((void **)&c->d_cnt, chunk * slots * sizeof(uint32_t) + chunk * sizeof(unsigned long long) + 64));
-		c->cnt_cap = chunk;
-	}
-	unsigned long long *d_sum = reinterpret_cast<unsigned long long *>(c->d_cnt + (chunk * slots + 15) / 16 * 16);
+	size_t slots = 0, chunk = 0;
+	unsigned long long *d_sum = nullptr;
+	if (int rc = ising_host::cnt_reserve(c, (size_t)c->nstrips, &slots, &chunk, &d_sum)) return rc;
 	const int per_launch = std::min(64, ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y)); // (a launch's measured sweeps are a 64-bit mask)
 	std::vector<unsigned long long> h(chunk);
 	long long got = 0;

@@ -298,6 +298,16 @@ class IsingSlab:
         self.it += n
         return self
 
+    def rank_sweep_counted(self, n: int, every: int):
+        """rank_sweep with the whole lattice's up-spin count after every iteration that is a multiple of `every` (ising_rank_sweep_counted: inside
+        the deep launches where the ring sweeps through ghost rows; collective); returns [(up, down), ...]."""
+        cap = n // every + 2
+        ups, k = (C.c_uint64 * cap)(), C.c_int()
+        check(self._lib.ising_rank_sweep_counted(self._h, self.it + 1, n, every, ups, cap, C.byref(k)))
+        self.it += n
+        tot = self.X * self.Y * self.cfg.nslabs
+        return [(int(ups[i]), tot - int(ups[i])) for i in range(k.value)]
+
     def rank_wait(self, timeout_ms: int = -1):
         check(self._lib.ising_rank_wait(self._h, timeout_ms))
 
@@ -457,6 +467,17 @@ class SlabSet:
         for color in (BLACK, WHITE):
             check(self._lib.ising_ring_exchange(self._arr, self.n, color))
         return self
+
+    def sweep_counted(self, n: int, every: int):
+        """sweep with the whole lattice's up-spin count after every iteration that is a multiple of `every` (ising_ring_sweep_counted)."""
+        cap = n // every + 2
+        ups, k = (C.c_uint64 * cap)(), C.c_int()
+        check(self._lib.ising_ring_sweep_counted(self._arr, self.n, self.it + 1, n, every, ups, cap, C.byref(k)))
+        self.it += n
+        for s in self.slabs:
+            s.it = self.it
+        tot = sum(s.X * s.Y for s in self.slabs)
+        return [(int(ups[i]), tot - int(ups[i])) for i in range(k.value)]
 
     def sweep(self, n: int = 1):
         check(self._lib.ising_ring_sweep(self._arr, self.n, self.it + 1, n))

@@ -485,6 +485,13 @@ class NativeRing:
         self.it += nsweeps
         return self
 
+    def sweep_counted(self, nsweeps: int, every: int):
+        """sweep with the whole lattice's (up, down) after every iteration that is a multiple of `every`, counted inside the deep launches."""
+        self.slab.it = self.it
+        out = self.slab.rank_sweep_counted(nsweeps, every)
+        self.it += nsweeps
+        return out
+
     def quiesce(self):
         self.slab.rank_wait(-1)
 

@@ -295,3 +295,42 @@ def test_deep_exchange_surface_is_one_row_deep_without_ghost_rows(gpu):
     with ig.IsingSlab(8192, 32, layout=ig.LAYOUT_BALLOT) as s:  # a lone slab wraps in place
         with pytest.raises(ig.IsingError, match="wrap"):
             s.ghost_ptrs(ig.BLACK)
+
+
+@pytest.mark.parametrize("transport,world,port", [("ipc", 2, 29591), ("ipc", 4, 29592), ("rccl", 2, 29593), ("rccl", 8, 29594)])
+def test_scaling_path_print_points_inside_the_launches(gpu, transport, world, port):
+    """ising_rank_sweep_counted: the reference's -p N counts of the WHOLE lattice, taken by every rank's deep launches over its own rows and summed over the rank
+    transport -- against the CPU oracle, calls of uneven lengths, the state afterwards."""
+    if transport == "rccl" and _ngpu() < world:
+        pytest.skip(f"needs >= {world} GPUs")
+    r = _scale(transport, world, port, "counted")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("counts == oracle") == 3 * world and r.stdout.count("slab == oracle rows") == world and "!=" not in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("layout,nslabs,Y", [(ig.LAYOUT_BALLOT, 2, 256), (ig.LAYOUT_BALLOT, 3, 128), (ig.LAYOUT_BALLOT, 1, 512), (ig.LAYOUT_DENSE, 2, 64)])
+def test_ring_sweep_counted_one_process(gpu, oracle_mod, monkeypatch, layout, nslabs, Y):
+    """ising_ring_sweep_counted, all slabs in one process: inside the deep launches on the ballot layout (ghost rows: the slabs' own rows only are counted), sweeps and
+    counts in turn on the dense layout -- the same counts and state as the CPU oracle either way."""
+    X, seed = 8192, 313
+    # (ballot slabs: REQUIRE the counts inside the launches -- ISING_RING_COUNTED=2 turns a silent fall-back into an error; the copies then travel on the comm streams)
+    monkeypatch.setenv("ISING_RING_COUNTED", "2" if layout == ig.LAYOUT_BALLOT else "1")
+    if layout == ig.LAYOUT_BALLOT:
+        monkeypatch.setenv("ISING_RING_INLINE", "0")
+    orc = oracle_mod.OracleLattice(X, Y * nslabs, seed=seed, temp=ig.CRIT_TEMP_F32).init()
+    ring = ig.SlabSet([ig.IsingSlab(X, Y, seed=seed, temp=ig.CRIT_TEMP_F32, nslabs=nslabs, slab=k, layout=layout, ring_halo=(nslabs == 1)) for k in range(nslabs)])
+    try:
+        ring.init()
+        for n, every in ((40, 16), (70, 16), (9, 1), (23, 100)):
+            got = ring.sweep_counted(n, every)
+            want = []
+            for _ in range(n):
+                orc.sweep(1)
+                if orc.it % every == 0:
+                    want.append(orc.count())
+            assert got == want, (layout, nslabs, n, every)
+        assert np.array_equal(np.concatenate([s.read(ig.BLACK) for s in ring.slabs]), orc.black)
+        assert np.array_equal(np.concatenate([s.read(ig.WHITE) for s in ring.slabs]), orc.white)
+        assert ring.count() == orc.count()
+    finally:
+        ring.close()

@@ -6,6 +6,7 @@ ring (ISING_TRANSPORT_IPC; ranks spread over the devices there are, sharing them
   golden <workload>   bench.py's slab of <workload> (config3: 65536 x 65536 per rank, config4: 131072 columns x 16384 rows, strong:
                       65536 columns x 65536 / N rows) -- counts after 5 / 21 / 25 sweeps (uneven calls: one crosses an exchange) against
                       the CPU oracle's goldens for the TOTAL lattice (tests/golden: bench.golden_records)
+  counted             16384 x 2048 per rank: ising_rank_sweep_counted's print points (inside the deep launches) and the state afterwards against the CPU oracle
   state               16384 columns x 2048 rows per rank, 64 ghost rows, fused + overlapped as above: FULL state of every rank, counts
                       and bond sum against the CPU oracle after 3, 36 and 71 sweeps (three exchanges deep)
 
@@ -15,6 +16,8 @@ import os
 import sys
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+if len(sys.argv) > 2 and sys.argv[2] == "counted":
+    os.environ["ISING_RING_COUNTED"] = "2"  # the print points INSIDE the deep launches, or an error (no silent fall-back to sweep-and-count)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -89,10 +92,39 @@ def check_state():
     slab.close()
 
 
+def check_counted():
+    """Print points inside the deep launches (ising_rank_sweep_counted): 16384 x 2048 per rank, calls of uneven lengths, counts of every iteration that
+    is a multiple of 16 (then 5) against the CPU oracle, the state afterwards."""
+    import oracle
+    oracle.set_threads(min(16, os.cpu_count() or 1))
+    X, Y, seed = 16384, 2048, 131
+    slab, ring = open_ring(X, Y, seed)
+    orc = oracle.OracleLattice(X, Y * world, seed=seed, temp=oracle.CRIT_TEMP).init()
+    for n, every in ((40, 16), (33, 16), (23, 5)):
+        got = ring.sweep_counted(n, every)
+        want = []
+        for _ in range(n):
+            orc.sweep(1)
+            if orc.it % every == 0:
+                want.append(orc.count())
+        ok = got == want
+        print(f"rank {rank} {transport} counted N={world} sweeps {orc.it - n + 1}..{orc.it} every {every}: {len(got)} counts {'==' if ok else '!='} oracle", flush=True)
+        assert ok, (got, want)
+    ring.quiesce()
+    lo, hi = rank * Y, (rank + 1) * Y
+    ok = np.array_equal(slab.read(ig.BLACK), orc.black[lo:hi]) and np.array_equal(slab.read(ig.WHITE), orc.white[lo:hi]) and ring.count() == orc.count()
+    print(f"rank {rank} {transport} counted N={world} state after {ring.it} sweeps: slab {'==' if ok else '!='} oracle rows [{lo},{hi})", flush=True)
+    assert ok
+    ring.close()
+    slab.close()
+
+
 if mode == "golden":
     check_golden(sys.argv[3] if len(sys.argv) > 3 else "config3")
 elif mode == "state":
     check_state()
+elif mode == "counted":
+    check_counted()
 else:
     raise SystemExit(f"unknown mode {mode!r}")
 dist.barrier()
