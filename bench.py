@@ -405,7 +405,20 @@ def main():
             last = slab.count()
         elif hasattr(ring, "sweep_counted"):
             # the library's ring: every rank's deep launches count their own rows (ising_rank_sweep_counted), the sums travel over the rank transport
-            ncounts = len(ring.sweep_counted(args.steps, 16)) + 1
+            try:
+                ncounts = len(ring.sweep_counted(args.steps, 16)) + 1
+            except Exception as e:  # noqa: BLE001  (a library error here must not cost the line its first leg: every rank sees the same error, the call is collective)
+                log(f"bench: counts leg: {e}; sweeping and counting in turn instead")
+                restart()
+                advance(args.warmup, batch_warm)
+                barrier()
+                t0 = time.perf_counter()
+                while done < args.steps:
+                    n = min(16, args.steps - done)
+                    advance(n, min(batch, n))
+                    ring.count()
+                    ncounts += 1
+                    done += n
             last = ring.count()
         else:
             while done < args.steps:
