@@ -39,3 +39,39 @@ def test_auto_regimes_bit_exact(gpu, oracle_mod, X, Y, layout, fused, tiled, H):
                     bad = np.argwhere(got != ref)
                     raise AssertionError(f"{Y} x {X} after {upto} sweeps: colour {color} differs in {len(bad)} words, first at {tuple(bad[0])}")
             assert s.count() == orc.count() and s.bond_equal() == orc.bond_equal()
+
+
+def test_auto_random_shapes_bit_exact(gpu, oracle_mod):
+    """Layout AUTO on 40 random lattice shapes up to 2^27 spins (seeded: the same every run) -- whatever layout, launch form, strip height, grid and ticket counters
+    ising_create picks -- against the CPU oracle after 1, 7 and 33 sweeps; the counted sweeps' print points too."""
+    oracle_mod.set_threads(16)
+    rng = np.random.default_rng(4)
+    seen = set()
+    for case in range(40):
+        while True:
+            X = 2048 * int(rng.integers(1, 41))
+            Y = 16 * int(rng.integers(1, 513))
+            if X * Y <= (1 << 27) and X * Y >= (1 << 19):
+                break
+        seed = int(rng.integers(1, 2**62))
+        orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=TC).init()
+        with ig.IsingSlab(X, Y, seed=seed, temp=TC) as s:
+            seen.add((s.layout, s.fused, s.tiled, s.strip_rows))
+            s.init()
+            done = 0
+            for upto in (1, 7, 33):
+                if upto == 33:
+                    got = s.sweep_counted(upto - done, 16)
+                    want = []
+                    for _ in range(upto - done):
+                        orc.sweep(1)
+                        if orc.it % 16 == 0:
+                            want.append(orc.count())
+                    assert got == want, (case, X, Y)
+                else:
+                    s.sweep(upto - done)
+                    orc.sweep(upto - done)
+                done = upto
+                ok = np.array_equal(s.read(ig.BLACK), orc.black) and np.array_equal(s.read(ig.WHITE), orc.white) and s.count() == orc.count() and s.bond_equal() == orc.bond_equal()
+                assert ok, f"case {case}: {Y} x {X} after {upto} sweeps (layout {s.layout}, fused {s.fused}, tiled {s.tiled}, H = {s.strip_rows})"
+    assert len(seen) >= 4, seen  # (the cases do spread over the launch forms)
