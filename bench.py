@@ -35,8 +35,8 @@ goldens for the TOTAL lattice (tests/golden/bench_65536_tc.json, ring_65536_tc.j
           under torch.distributed.run.
 
 The JSON line: `value` = bare sweeps (the contract's timed region); `with_counts_every_16` = a second leg over the same sweeps with
-the magnetisation read back every 16 sweeps inside the timed region, as every number the reference publishes includes it
-(optimized/main.cu:1806-1810); `roofline.bound` = "valu" -- the roof that binds, with the draw-only ceiling measured in the same
+the magnetisation of every 16th sweep (and of the last) inside the timed region, as every number the reference publishes includes it
+(optimized/main.cu:1806-1810) -- counted inside the launches: ising_sweep_counted at N = 1, ising_rank_sweep_counted on the library's ring --; `roofline.bound` = "valu" -- the roof that binds, with the draw-only ceiling measured in the same
 job -- next to SURVEY 8(d)'s HBM accounting (1.5 B/flip) and the device's real HBM traffic.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
