@@ -395,6 +395,10 @@ def main():
     if not args.no_counts_leg:
         restart()
         advance(args.warmup, batch_warm)
+        if ring is None:
+            slab.sweep_counted(0, 16)  # (a call of no sweeps: the slots of the in-launch counts are allocated outside the timed region, like the lattice)
+        elif hasattr(ring, "sweep_counted"):
+            ring.sweep_counted(0, 16)
         barrier()
         t0 = time.perf_counter()
         ncounts, done, last = 0, 0, None

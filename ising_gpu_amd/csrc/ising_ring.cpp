@@ -618,7 +618,7 @@ int sweep_local(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 int ring_sweep_counted(ising_ctx **ctxs, int n, int first_it, int nsweeps, int every, std::vector<unsigned long long> &mine, bool *fallback) {
 	*fallback = true;
 	if (int rc = settle_layout(ctxs, n)) return rc;
-	bool deep = nsweeps > 0 && !ctxs[0]->cfg.XSL && !ctxs[0]->cfg.use_J && ctxs[0]->ghost() > 1 && ctxs[0]->pol.overlap != 0;
+	bool deep = !ctxs[0]->cfg.XSL && !ctxs[0]->cfg.use_J && ctxs[0]->ghost() > 1 && ctxs[0]->pol.overlap != 0; // (a call of no sweeps reserves the slots: a warm-up)
 	for (int k = 0; k < n; k++)
 		deep = deep && ctxs[k]->ballot && ctxs[k]->ghost() == ctxs[0]->ghost() && !ising_host::needs_generic(ctxs[k]) && !ctxs[k]->store_ring && !ctxs[k]->copy_inline &&
 		       ctxs[k]->d_edge && ctxs[k]->comm;
