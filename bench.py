@@ -36,7 +36,7 @@ goldens for the TOTAL lattice (tests/golden/bench_65536_tc.json, ring_65536_tc.j
 
 The JSON line: `value` = bare sweeps (the contract's timed region); `with_counts_every_16` = a second leg over the same sweeps with
 the magnetisation of every 16th sweep (and of the last) inside the timed region, as every number the reference publishes includes it
-(optimized/main.cu:1806-1810) -- counted inside the launches: ising_sweep_counted at N = 1, ising_rank_sweep_counted on the library's ring --; `roofline.bound` = "valu" -- the roof that binds, with the draw-only ceiling measured in the same
+(optimized/main.cu:1806-1810); `with_counts_and_energy_every_16` = a third leg with the bond sum (north_star's energy series) at the same points -- both taken inside the launches: ising_sweep_counted at N = 1, ising_rank_sweep_counted on the library's ring --; `roofline.bound` = "valu" -- the roof that binds, with the draw-only ceiling measured in the same
 job -- next to SURVEY 8(d)'s HBM accounting (1.5 B/flip) and the device's real HBM traffic.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
@@ -344,6 +344,9 @@ def main():
     # the library's ring reports where a slab's time goes around its exchanges (ising_exchange_stats_*: HIP events on the launches'
     # dispatch packets and on the comm stream); sampled over the timed leg on every rank
     stats_slab = ring.slab if isinstance(ring, ig.NativeRing) else None
+    clock_slab = slab if ring is None else stats_slab  # the library's own launches leave the marks their shader clock is computed from
+    if clock_slab is not None:
+        clock_slab.kernel_clock(True)
     advance(args.warmup, batch_warm)
     barrier()
     if stats_slab is not None:
@@ -360,6 +363,13 @@ def main():
         t = torch.tensor([dt, ev_ms], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, ev_ms = float(t[0]), float(t[1])
+    sclk_kernel = None
+    if clock_slab is not None:
+        try:
+            sclk_kernel = clock_slab.kernel_clock_fetch()  # (mean, min, max) MHz over the XCDs of the timed leg's LAST fused launch
+        except ig.IsingError:
+            sclk_kernel = None                             # (no fused launch: one launch per colour, tile launches)
+        clock_slab.kernel_clock(False)
     xstats = None
     if stats_slab is not None:
         mine = stats_slab.exchange_stats_fetch()
@@ -391,27 +401,29 @@ def main():
     # Second timed leg, the reference's methodology: every number it publishes was measured with the magnetisation read back
     # inside the timed loop (-p 16: countSpins every 16 sweeps and after the last one, optimized/main.cu:1806-1810, :1862-1874;
     # BASELINE.md).  Same lattice, same sweeps, from the start; the final counts must be the first leg's.
-    counts_leg = None
-    if not args.no_counts_leg:
+    def counted_leg(energy):
+        """one more timed leg over the same sweeps with the print points inside the timed region; energy: the bond sum at every point too"""
         restart()
         advance(args.warmup, batch_warm)
         if ring is None:
-            slab.sweep_counted(0, 16)  # (a call of no sweeps: the slots of the in-launch counts are allocated outside the timed region, like the lattice)
+            slab.sweep_counted(0, 16, energy)  # (a call of no sweeps: the slots of the in-launch counts are allocated outside the timed region, like the lattice)
         elif hasattr(ring, "sweep_counted"):
-            ring.sweep_counted(0, 16)
+            ring.sweep_counted(0, 16, energy)
         barrier()
         t0 = time.perf_counter()
-        ncounts, done, last = 0, 0, None
+        ncounts, done, last, series = 0, 0, None, None
         if ring is None:
             # a lone slab: the print points ride INSIDE the fused launches (ising_sweep_counted: the units that store the words count
             # them) -- every iteration that is a multiple of 16, as the reference's loop prints -- and the final count as ever
-            ncounts = len(slab.sweep_counted(args.steps, 16)) + 1
+            series = slab.sweep_counted(args.steps, 16, energy)
+            ncounts = len(series) + 1
             last = slab.count()
         elif hasattr(ring, "sweep_counted"):
             # the library's ring: every rank's deep launches count their own rows (ising_rank_sweep_counted), the sums travel over the rank transport
             try:
-                ncounts = len(ring.sweep_counted(args.steps, 16)) + 1
-            except Exception as e:  # noqa: BLE001  (a library error here must not cost the line its first leg: every rank sees the same error, the call is collective)
+                series = ring.sweep_counted(args.steps, 16, energy)
+                ncounts = len(series) + 1
+            except Exception as e:  # noqa: BLE001  (a library error here must not cost the line its first leg: every rank returns the same outcome, the call agrees on it)
                 log(f"bench: counts leg: {e}; sweeping and counting in turn instead")
                 restart()
                 advance(args.warmup, batch_warm)
@@ -437,13 +449,29 @@ def main():
             t = torch.tensor([dt2], dtype=torch.float64, device=ctl)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt2 = float(t[0])
-        counts_leg = {"value": round(total_flips / (dt2 * 1e9), 2), "unit": "flips/ns", "ms_per_step": round(dt2 * 1e3 / args.steps, 5),
-                      "counts_in_timed_region": ncounts, "final_counts_equal_first_leg": last == (up, down),
-                      "what": "the same steps with the up/down counts of every iteration that is a multiple of 16, and of the last one, inside the timed "
-                              "region (the reference's -p 16 methodology, optimized/main.cu:1806-1810)"
-                              + ("; N = 1: counted inside the fused launches (ising_sweep_counted), read back with the last" if ring is None else
-                                 ("; the library's ring: counted inside every rank's deep launches (ising_rank_sweep_counted), summed over the rank transport"
-                                  if hasattr(ring, "sweep_counted") else "; rings: a blocking count of all ranks every 16 sweeps"))}
+        leg = {"value": round(total_flips / (dt2 * 1e9), 2), "unit": "flips/ns", "ms_per_step": round(dt2 * 1e3 / args.steps, 5),
+               "counts_in_timed_region": ncounts, "final_counts_equal_first_leg": last == (up, down),
+               "what": "the same steps with the up/down counts" + (" and the bond sum (energy)" if energy else "") + " of every iteration that is a multiple of 16, and the counts "
+                       "of the last one, inside the timed region (the reference's -p 16 methodology, optimized/main.cu:1806-1810"
+                       + ("; the energy series is north_star's, the reference computes none" if energy else "") + ")"
+                       + ("; N = 1: taken inside the fused launches (ising_sweep_counted), read back with the last" if ring is None else
+                          ("; the library's ring: taken inside every rank's deep launches (ising_rank_sweep_counted), summed over the rank transport"
+                           if hasattr(ring, "sweep_counted") else "; rings: a blocking count of all ranks every 16 sweeps"))}
+        if energy and series:
+            n_tot = float(spins_per_gpu) * world
+            leg["last_point"] = {"iteration": (args.warmup + args.steps) // 16 * 16, "up": series[-1][0], "bond_equal": series[-1][2],
+                                 "energy_per_spin": round(-(2.0 * series[-1][2] - 2.0 * n_tot) / n_tot, 9)}
+        return leg
+
+    # Further timed legs, the reference's methodology: every number it publishes was measured with the magnetisation read back
+    # inside the timed loop (-p 16: countSpins every 16 sweeps and after the last one, optimized/main.cu:1806-1810, :1862-1874;
+    # BASELINE.md).  Same lattice, same sweeps, from the start; the final counts must be the first leg's.  The third leg adds
+    # north_star's energy series at the same points.
+    counts_leg = energy_leg = None
+    if not args.no_counts_leg:
+        counts_leg = counted_leg(False)
+        if ring is None or hasattr(ring, "sweep_counted"):
+            energy_leg = counted_leg(True)
 
     layout_name, layout_text = {
         ig.LAYOUT_NIBBLE: ("nibble", "reference 4 bit/spin"),
@@ -490,10 +518,10 @@ def main():
         # only draws (same job, same chip, same clocks) is the ceiling.
         sites_per_launch = spins_per_gpu / 2.0 * half_sweeps_per_launch
         kern_rate = sites_per_launch / (avg_launch_ms * 1e6)  # sites/ns per GPU inside the kernel
-        ceil, ceil_err = None, None
+        ceil, ceil_err, sclk_ceiling = None, None, None
         if not args.no_alu_probe:
             try:
-                ceil = ig.philox_ceiling(local_rank)
+                ceil, sclk_ceiling = ig.philox_ceiling_clocked(local_rank, 25.0)  # an average over >= 25 ms of launches, like the kernel it is compared with
             except ig.IsingError as e:
                 ceil_err = str(e)
         if ceil:
@@ -508,6 +536,19 @@ def main():
             roof = {"bound": "hbm", "achieved": hbm_reference["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_reference["frac"]}
             if ceil_err:
                 roof["alu_probe_error"] = ceil_err
+        # SURVEY 8(d)'s figures as SCALAR keys (the harness keeps only those of `roofline`): the reference's 1.5 B/flip accounting against 8 TB/s, the
+        # device's real HBM rate, real traffic over the device's algorithmic bytes; and the shader clocks of the two kernels `frac` compares
+        roof.update({"frac_hbm_1p5B": hbm_reference["frac"], "hbm_achieved_gbs": hbm_reference["achieved"], "hbm_peak_gbs": HBM_PEAK_GBS,
+                     "hbm_real_gbs": hbm_real["achieved"] if hbm_real else None, "hbm_real_frac": hbm_real["frac"] if hbm_real else None,
+                     "traffic_over_algorithmic": (round(hbm_real["traffic_bytes_per_launch"] / hbm_real["device_algorithmic_bytes_per_launch"], 4)
+                                                  if hbm_real and hbm_real["device_algorithmic_bytes_per_launch"] else None),
+                     "sclk_mhz_kernel": round(sclk_kernel[0], 1) if sclk_kernel else None,
+                     "sclk_mhz_kernel_min_xcd": round(sclk_kernel[1], 1) if sclk_kernel else None,
+                     "sclk_mhz_kernel_max_xcd": round(sclk_kernel[2], 1) if sclk_kernel else None,
+                     "sclk_mhz_ceiling": round(sclk_ceiling, 1) if sclk_ceiling else None,
+                     "frac_at_equal_clock": (round((kern_rate / sclk_kernel[0]) / (ceil / sclk_ceiling), 4) if ceil and sclk_kernel and sclk_ceiling else None),
+                     "sclk_what": "shader cycles / time of the 100 MHz counter, both read inside the kernel by one wave per XCD: the timed leg's last fused launch, "
+                                  "and the last of the draw-only kernel's launches (an average over >= 25 ms of them)"})
         roof.update({"traffic": traffic, "kernel": kernel, "avg_launch_ms": round(avg_launch_ms, 5), "launches": launches,
                      "half_sweeps_per_launch": half_sweeps_per_launch, "sites_per_launch": sites_per_launch,
                      "hbm_reference_accounting": hbm_reference, "hbm_real": hbm_real})
@@ -527,6 +568,8 @@ def main():
         }
         if counts_leg is not None:
             line["with_counts_every_16"] = counts_leg
+        if energy_leg is not None:
+            line["with_counts_and_energy_every_16"] = energy_leg
         if xstats is not None:
             line["exchange_stats"] = xstats
         if shared:  # more ranks than devices: `value` is what the physical GPUs delivered together, not a scaling point
@@ -543,8 +586,9 @@ def main():
         dist.destroy_process_group()
     if parity is False:
         raise SystemExit(f"bench: counts {(up, down)} differ from the oracle's {gold}")
-    if counts_leg is not None and not counts_leg["final_counts_equal_first_leg"]:
-        raise SystemExit("bench: the leg with counts every 16 sweeps ended on other counts than the first leg")
+    for leg in (counts_leg, energy_leg):
+        if leg is not None and not leg["final_counts_equal_first_leg"]:
+            raise SystemExit("bench: a leg with print points every 16 sweeps ended on other counts than the first leg")
 
 
 if __name__ == "__main__":

@@ -87,7 +87,9 @@ typedef struct ising_config {
 	                     slX, slY :413-459), so no halo exchange is needed. */
 	void *lattice_mem;   /* optional caller-owned device buffer of ising_required_bytes() bytes for the spin arrays (e.g. a
 	                        torch tensor, so that its edge/halo rows can be handed to RCCL as ordinary tensors); NULL = the
-	                        library allocates */
+	                        library allocates.  (A lone slab of up to 2^24 spins on ISING_LAYOUT_DENSE sweeps in tile launches that
+	                        alternate between this buffer and a library-owned twin of the same size, allocated by ising_create; the
+	                        spins are back in this buffer whenever a call returns) */
 	void *coupling_mem;  /* the same for the -J coupling arrays */
 	int32_t layout;   /* ISING_LAYOUT_* */
 	int32_t use_J;    /* -J given: allocate coupling arrays and apply them in every update (useGenHamilt, :1368-1372) */
@@ -110,6 +112,15 @@ int ising_device_info(int device, char *name, size_t name_len, int *cus, int *ma
  * output per site exactly as the update kernels generate them, no accept test, no lattice, no memory traffic.  The
  * update kernels are bound by the vector ALU, so this is their ceiling at bit-exact parity.  Blocking (~30 ms). */
 int ising_philox_ceiling(int device, double *sites_per_ns);
+/* The same as an AVERAGE over launches that last min_ms together (the update kernel's figure is an average over a long launch too), with the
+ * shader clock the launches ran at: *sclk_mhz = cycles of the shader's counter / time of the constant 100 MHz counter, both read inside the
+ * kernel by one wave per XCD (0 when the counters make no sense).  Blocking. */
+int ising_philox_ceiling_clocked(int device, double min_ms, double *sites_per_ns, double *sclk_mhz);
+/* Measurement aid: enable != 0 makes the first eight workgroups (one per XCD) of every fused launch of this slab leave the same two counters when
+ * they start and when they leave; ising_kernel_clock_fetch (blocking) turns the LAST launch's marks into the clock it ran at -- mean / min / max over
+ * the XCDs (any pointer may be NULL).  ISING_E_STATE when no fused launch has run since it was enabled.  bench.py reports it next to the ceiling's. */
+int ising_kernel_clock(ising_ctx *ctx, int enable);
+int ising_kernel_clock_fetch(ising_ctx *ctx, double *sclk_mhz_mean, double *sclk_mhz_min, double *sclk_mhz_max);
 
 /* Bytes of one caller-supplied device buffer.  ising_required_bytes: 2 colours x (Y + 2) rows x X/4 bytes -- the
  * reference's 4 bit/spin, enough for every layout and the size of the coupling buffer (coupling_mem).
@@ -195,8 +206,12 @@ int ising_sweep(ising_ctx *ctx, int first_it, int nsweeps);
  * it % every == 0 (at most max_counts; *ncounts = how many).  Where ising_sweep issues fused launches the counts are taken INSIDE the
  * launches, by the units that store the words -- no launch boundary, no count kernel and no read-back between two print points (16384^2
  * with a count every 16 sweeps: 3057 -> 3290 flips/ns) --; on the other layouts and with sub-lattices or couplings the call sweeps and
- * counts in turn.  Blocking: the counts are read back when the last launch is done. */
-int ising_sweep_counted(ising_ctx *ctx, int first_it, int nsweeps, int every, uint64_t *ups, int max_counts, int *ncounts);
+ * counts in turn.  Blocking: the counts are read back when the last launch is done.
+ * bond_equal (NULL: no energy): bond_equal[k] = ising_bond_equal's sum A at the same print point -- north_star's energy series next to the
+ * magnetisation's, e = -(2A - 2N)/N; the reference computes no energy.  Inside the fused launches too: the white level of a measured
+ * sweep counts, per stored word, the neighbours that equal it (four XOR + popcount per row on one level in 2 * every: `cuIsing -p 16 --energy`
+ * costs what `-p 16` costs). */
+int ising_sweep_counted(ising_ctx *ctx, int first_it, int nsweeps, int every, uint64_t *ups, int64_t *bond_equal, int max_counts, int *ncounts);
 /* How ising_sweep launches right now: *fused = 1 when it issues fused launches (ballot layout: from 1.5 * 2^24 spins up and where ISING_LAYOUT_AUTO picks it below, or
  * ISING_FUSED=1: one launch carries up to *max_sweeps_per_launch sweeps = twice as many colour half-sweeps, handed out to
  * a chip-filling grid through in-order tickets; ising_ballot.hip), 0 when it issues one launch per colour, 2 when it issues tile
@@ -322,8 +337,9 @@ int ising_ring_sweep(ising_ctx **ctxs, int n, int first_it, int nsweeps);
  * printFreq, inside the timed loop; see ising_sweep_counted): ups[k] = the up spins of the WHOLE lattice after the k-th iteration of the call
  * that is a multiple of `every`.  Where the ring sweeps its slabs through ghost rows with the exchanges in the launches' tails (ballot layout,
  * the default), every slab's launches count their own rows as they store them -- no launch boundary, count kernel or read-back between two
- * print points --; elsewhere the call sweeps and counts in turn.  Blocking. */
-int ising_ring_sweep_counted(ising_ctx **ctxs, int n, int first_it, int nsweeps, int every, uint64_t *ups, int max_counts, int *ncounts);
+ * print points --; elsewhere the call sweeps and counts in turn.  bond_equal (NULL: no energy): the bond sum of the whole lattice at the same
+ * points, as in ising_sweep_counted.  Blocking. */
+int ising_ring_sweep_counted(ising_ctx **ctxs, int n, int first_it, int nsweeps, int every, uint64_t *ups, int64_t *bond_equal, int max_counts, int *ncounts);
 /* Blocks until every slab's compute and comm streams are idle. */
 int ising_ring_synchronize(ising_ctx **ctxs, int n);
 /* Totals over the ring: countSpins (:831-868) and the bond sum of ising_bond_equal.  Blocking. */
@@ -345,7 +361,7 @@ int ising_rank_init_couplings(ising_ctx *ctx);
 int ising_rank_sweep(ising_ctx *ctx, int first_it, int nsweeps);
 /* ising_ring_sweep_counted, one process per slab: collective (every rank calls it with the same arguments); the ranks' sums travel over the
  * rank transport (ncclAllReduce / the peer transport's shared-memory reduction). */
-int ising_rank_sweep_counted(ising_ctx *ctx, int first_it, int nsweeps, int every, uint64_t *ups, int max_counts, int *ncounts);
+int ising_rank_sweep_counted(ising_ctx *ctx, int first_it, int nsweeps, int every, uint64_t *ups, int64_t *bond_equal, int max_counts, int *ncounts);
 /* Waits until both streams of the slab are idle; timeout_ms >= 0 polls and returns ISING_E_TIMEOUT when the time is up
  * (a hung exchange can then be abandoned with ising_rank_detach(ctx, 1)); < 0 blocks. */
 int ising_rank_wait(ising_ctx *ctx, int timeout_ms);

@@ -56,6 +56,9 @@ PROTOTYPES = {
     "ising_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ising_philox_ceiling": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
+    "ising_philox_ceiling_clocked": (C.c_int, [C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "ising_kernel_clock": (C.c_int, [C.c_void_p, C.c_int]),
+    "ising_kernel_clock_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ising_required_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "ising_required_bytes_layout": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "ising_create": (C.c_int, [C.POINTER(IsingConfig), C.POINTER(C.c_void_p)]),
@@ -76,9 +79,9 @@ PROTOTYPES = {
     "ising_update_edges": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ising_strip_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ising_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
-    "ising_sweep_counted": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int)]),
-    "ising_ring_sweep_counted": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int)]),
-    "ising_rank_sweep_counted": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int)]),
+    "ising_sweep_counted": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int)]),
+    "ising_ring_sweep_counted": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int)]),
+    "ising_rank_sweep_counted": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int)]),
     "ising_sweep_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ising_sweep_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "ising_halo_ptrs": (C.c_int, [C.c_void_p, C.c_int] + [C.POINTER(C.c_void_p)] * 4 + [C.POINTER(C.c_size_t)]),

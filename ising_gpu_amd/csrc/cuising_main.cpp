@@ -77,18 +77,18 @@ void usage(const char *pname) {
 	exit(EXIT_SUCCESS);
 }
 
-// optimized/main.cu:1211-1228
-void generate_times(unsigned long long nsteps, unsigned long long *list_times) {
-	int nt = 0;
-	list_times[0] = MIN_EXP_TIME;
-	unsigned long long t = 0;
-	for (unsigned long long j = 0; j < nsteps && t < nsteps; j++) {
-		t = (unsigned long long)rint(pow(2.0, j / 4.0));
-		if (t >= 2 * list_times[nt] && nt < MAX_EXP_TIME - 1) {
-			nt++;
-			list_times[nt] = t;
-		}
+// The -e series (optimized/main.cu:1211-1228, consumed at :1827): sweep indices (0-based; printed as index + 1) after which the magnetisation is
+// reported.  The first one is MIN_EXP_TIME = 152 (iteration 153).  From there the ladder L_k = rint(2^(k/4)), k = 0, 1, 2, ... is climbed, and a rung
+// becomes a print point when it is at least twice the last print point (305, 610, 1219, 2897, ... as iterations).  The climb stops behind the first
+// rung at or past the run's length -- that rung may still have become a point -- or after `nsteps` rungs; MAX_EXP_TIME points at most.
+std::vector<unsigned long long> exp_print_points(unsigned long long nsteps) {
+	std::vector<unsigned long long> pts{(unsigned long long)MIN_EXP_TIME};
+	unsigned long long rung = 0;
+	for (unsigned long long k = 0; k < nsteps && rung < nsteps; ++k) {
+		rung = (unsigned long long)rint(pow(2.0, (double)k / 4.0)); // (the reference's expression: the rounding must agree to the last rung)
+		if (rung >= 2 * pts.back() && pts.size() < (size_t)MAX_EXP_TIME) pts.push_back(rung);
 	}
+	return pts;
 }
 
 struct Ring {
@@ -310,7 +310,22 @@ int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_
 			if ((m + 1) % 1024 == 0) fetch_batch();
 		}
 		if (batched) fetch_batch();
-		for (int m = 0; !batched && m < ts.nmeas; m++) {
+		// One lattice at a time (annealing runs, --tsweep-replicas 1, rings of slabs) whose measurements fall on multiples of the stride: the whole
+		// series of a point rides inside the launches (ising_ring_sweep_counted with the bond sums), 64 measurements per read-back
+		const bool inlaunch = !batched && nb == 1 && (it % ts.stride) == 0;
+		for (int m = 0; inlaunch && m < ts.nmeas;) {
+			const int nm = std::min(64, ts.nmeas - m);
+			uint64_t ups[64];
+			int64_t eqs[64];
+			int k = 0;
+			CHECK(ising_ring_sweep_counted(reps[0].ctx.data(), reps[0].n(), it + 1, nm * ts.stride, ts.stride, ups, eqs, 64, &k));
+			if (k != nm) { fprintf(stderr, "temperature sweep: %d measurements came back, %d expected\n", k, nm); exit(EXIT_FAILURE); }
+			for (int i = 0; i < k; i++) take(0, it + (i + 1) * ts.stride, ups[i], eqs[i]);
+			fetched[0] += k;
+			it += nm * ts.stride;
+			m += nm;
+		}
+		for (int m = 0; !batched && !inlaunch && m < ts.nmeas; m++) {
 			for (int j = 0; j < nb; j++) {
 				CHECK(ising_ring_sweep(reps[j].ctx.data(), reps[j].n(), it + 1, ts.stride));
 				if (async) CHECK(ising_measure_enqueue(reps[j].ctx[0]));
@@ -326,7 +341,7 @@ int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_
 				}
 			}
 		}
-		if (async && !batched)
+		if (async && !batched && !inlaunch)
 			for (int j = 0; j < nb; j++) fetch(j);
 		for (int j = 0; j < nb; j++) {
 			const float temp = temps[j];
@@ -396,8 +411,9 @@ int main(int argc, char **argv) {
 	int X = 0, Y = 0, dumpOut = 0, nsteps = NUMIT_DEF, ndev = 1;
 	unsigned long long seed = ISING_SEED_DEF;
 	float alpha = -1.0f, temp = -1.0f, tempUpdStep = 0;
-	int tempUpdFreq = 0, printFreq = 0, printExp = 0, printExpCur = 0, printEnergy = 0;
-	unsigned long long printExpSteps[MAX_EXP_TIME];
+	int tempUpdFreq = 0, printFreq = 0, printExp = 0, printEnergy = 0;
+	std::vector<unsigned long long> printExpSteps; // -e: sweep indices of the print points still to come are printExpSteps[printExpCur ...]
+	size_t printExpCur = 0;
 	double tgtMagn = -1.0;
 	int useSubLatt = 0, XSL = 0, YSL = 0, NSLX = 1, NSLY = 1;
 	int corrOut = 0;
@@ -554,8 +570,8 @@ int main(int argc, char **argv) {
 	if (printExp && printFreq) printFreq = 0;
 	const int j0 = ckptIn ? (int)ck.it : 0, jend = j0 + nsteps; // --resume: iterations continue where the checkpoint stopped
 	if (printExp) {
-		generate_times(jend, printExpSteps);
-		while (printExpCur < MAX_EXP_TIME - 1 && (long long)printExpSteps[printExpCur] + 1 <= j0) printExpCur++;
+		printExpSteps = exp_print_points((unsigned long long)jend);
+		while (printExpCur < printExpSteps.size() && (long long)printExpSteps[printExpCur] + 1 <= j0) printExpCur++; // (--resume: points already behind us)
 	}
 	if (ndev < 1) { fprintf(stderr, "error: need at least one device\n"); exit(EXIT_FAILURE); }
 
@@ -702,20 +718,22 @@ int main(int argc, char **argv) {
 	// Plain `-p N` runs on one GPU (the reference's usual command line: every number it publishes has the magnetisation every 16 sweeps inside
 	// the timed loop, :1806-1810): the print points ride inside the library's launches (ising_sweep_counted) instead of cutting them into
 	// pieces of N sweeps with a count and a read-back in between -- 16384^2 at -p 16: 3057 -> 3290 flips/ns.  The lines are the same; they
-	// appear in bursts of up to 64.  Anything else a print point may do (-m early exit, --energy, -c, -o, the exponential series) keeps the
-	// reference's order of events below.
+	// appear in bursts of up to 64.  --energy rides along (round 5: the launches' white levels count equal bonds, north_star's energy series).
+	// Anything else a print point may do (-m early exit, -c, -o, the exponential series) keeps the reference's order of events below.
 	// (several devices: ising_ring_sweep_counted -- every slab's deep launches count their own rows)
-	const bool counted = printFreq > 0 && !printExp && tgtMagn == -1.0 && !printEnergy && !corrOut && !dumpOut;
+	const bool counted = printFreq > 0 && !printExp && tgtMagn == -1.0 && !corrOut && !dumpOut;
 	while (counted && j < jend) {
 		long long next = std::min<long long>(jend, (long long)(j / printFreq + 64) * printFreq);
 		if (tempUpdFreq) next = std::min<long long>(next, (long long)(j / tempUpdFreq + 1) * tempUpdFreq);
 		uint64_t ups[80];
+		int64_t eqs[80];
 		int k = 0;
-		CHECK(ising_ring_sweep_counted(ring.ctx.data(), ndev, j + 1, (int)(next - j), printFreq, ups, 80, &k));
+		CHECK(ising_ring_sweep_counted(ring.ctx.data(), ndev, j + 1, (int)(next - j), printFreq, ups, printEnergy ? eqs : nullptr, 80, &k));
 		for (int i = 0, it = (j / printFreq + 1) * printFreq; i < k; i++, it += printFreq) {
 			cntPos = ups[i];
 			cntNeg = nspins - ups[i];
 			printf("        magnetization: %9.6lf, up_s: %12llu, dw_s: %12llu (iter: %8d)\n", fabs((double)cntPos - (double)cntNeg) / (double)nspins, cntPos, cntNeg, it);
+			if (printEnergy) printf("        energy/spin:   %9.6lf (iter: %8d)\n", -(2.0 * (double)eqs[i] - 2.0 * (double)nspins) / (double)nspins, it);
 		}
 		j = (int)next;
 		if (tempUpdFreq && (j % tempUpdFreq) == 0) { // optimized/main.cu:1848-1860
@@ -731,14 +749,14 @@ int main(int argc, char **argv) {
 	while (j < jend) {
 		int next = jend; // first iteration index (1-based count) at which the host must look at the lattice
 		if (printFreq) next = std::min(next, (j / printFreq + 1) * printFreq);
-		if (printExp) next = std::min<long long>(next, (long long)printExpSteps[printExpCur] + 1 > j ? (long long)printExpSteps[printExpCur] + 1 : jend);
+		if (printExp && printExpCur < printExpSteps.size()) next = (int)std::min<long long>(next, (long long)printExpSteps[printExpCur] + 1);
 		if (tempUpdFreq) next = std::min(next, (j / tempUpdFreq + 1) * tempUpdFreq);
 		if (next <= j) next = j + 1;
 		CHECK(ising_ring_sweep(ring.ctx.data(), ndev, j + 1, next - j));
 		j = next;
 		bool stop = false;
 		if (printFreq && (j % printFreq) == 0) stop = report(j, false);
-		if (!stop && printExp && printExpSteps[printExpCur] == (unsigned long long)(j - 1)) {
+		if (!stop && printExp && printExpCur < printExpSteps.size() && printExpSteps[printExpCur] == (unsigned long long)(j - 1)) {
 			printExpCur++;
 			stop = report(j, true);
 		}

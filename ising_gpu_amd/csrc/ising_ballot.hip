@@ -150,6 +150,9 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 #ifndef ISING_FUSED_WAIT_LATE // 1: fused launches may ask their units to draw before they wait for their parents (UpdateParams.wait_late); 0 compiles the request out
 #define ISING_FUSED_WAIT_LATE 1
 #endif
+#ifndef ISING_PRIO_ROT // 4: the waves' priorities rotate modulo 4 (rounds 2-4); 6: modulo the waves per SIMD (A/B build)
+#define ISING_PRIO_ROT 4
+#endif
 #ifndef ISING_POLL_SLEEP // s_sleep units (64 cycles) between two looks of a waiting unit at its parents' counters
 #define ISING_POLL_SLEEP 32
 #endif
@@ -287,6 +290,22 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 	const unsigned dround = uni((int)(blockIdx.x / (unsigned)p.cus)); // dispatch round = this workgroup's rank on its CU (a grid of k x CUs lands k per CU)
 	if (FUSED && NT == 256 && ISING_FUSED_STAGGER > 0)
 		for (unsigned i = 0; i < dround % 6u; ++i) __builtin_amdgcn_s_sleep(ISING_FUSED_STAGGER);
+	// Measurement aid (ising_kernel_clock): the first eight workgroups of a fused launch -- one per XCD -- leave the shader's cycle counter and the
+	// constant 100 MHz counter in UpdateParams.clk_out when they start and when they leave: cycles / time = the clock the launch ran at.
+	// (The pointer is fetched from the kernel arguments on the spot: no register is kept alive for it.)
+	auto clock_mark = [&](int which) {
+		if (!FUSED || blockIdx.x >= 8u || wi != 0) return;
+		uint64_t cp;
+		asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(cp) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(offsetof(UpdateParams, clk_out)) : "memory");
+		if (cp == 0) return;
+		const unsigned long long cyc = __builtin_readcyclecounter(), ref = __builtin_amdgcn_s_memrealtime();
+		if (lane == 0) {
+			unsigned long long *o = reinterpret_cast<unsigned long long *>(cp) + 4 * blockIdx.x + 2 * which;
+			o[0] = cyc;
+			o[1] = ref;
+		}
+	};
+	clock_mark(0);
 	if (FUSED) {
 		if (threadIdx.x == 0) ticket_sh[0] = draw_ticket();
 		__syncthreads();
@@ -544,21 +563,43 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		const int rmax = Hr;
 		const bool wb_wave = threadIdx.x < 64;
 		[[maybe_unused]] uint32_t cnt_up = 0; // COUNT: up spins among the words this lane stores in this unit
+		// ... and, where the call asks for the energy too (UpdateParams.cnt_bonds), the bonds of those sites to equal neighbours: taken at the WHITE level of a
+		// measured sweep, when both colours are the sweep's final ones -- every bond has exactly one white end, so the white sites' sum is ising_bond_equal's A
+		[[maybe_unused]] uint32_t cnt_eq = 0;
+		[[maybe_unused]] const bool eq_unit = COUNT && p.cnt_bonds != 0 && (level & 1) != 0 && ((p.cnt_mask >> (level >> 1)) & 1ull) != 0;
 		// (Round 4 also requested the next ticket a row early -- an inline-assembly atomic at the top of the last-but-one iteration, picked up
 		// behind that iteration's word-phase wait, its ~2 us under a draw phase: no gain, -1 % at 8192^2 (profiles/ticket_early_probe_r04.txt):
 		// a ticket that is reserved while its workgroup still works delays the unit it names, as in round 2.  And, requested in the last iteration
 		// as ever but picked up behind the last word phase instead of in front of the barrier -- the atomic under that phase's loads, the
 		// ticket handed to the other waves through LDS: -0.1 .. -0.3 % everywhere (profiles/ticket_async_probe_r04.txt).  The 4 % of a
 		// workgroup's time that the trace books on "next ticket" is time in which the SIMD's other waves have the vector ALU.)
+#if ISING_PRIO_ROT == 6
+		const int prio_n = uni(max(1, min(6, (int)((gridDim.x + (unsigned)p.cus - 1u) / (unsigned)p.cus)))); // waves of this launch per SIMD
+		int prio_phase = uni((int)(dround % (unsigned)prio_n));
+#endif
 		for (int r = 0; r <= rmax; ++r) {
 			// rotating priorities: the waves that share a SIMD (one per dispatch round) take turns at the front
 			if (FUSED) {
+#if ISING_PRIO_ROT == 6 // A/B (round 5): a rotation as long as the waves of a SIMD are many -- five or six of them step through {3,2,2,1,1,0} / {3,2,2,1,0}
+				// instead of four priorities modulo 4, where the fifth and sixth wave always tie with the first and second and, younger, lose
+				int pr_ = 3 - ((prio_phase + 1) >> 1);
+				if (prio_n == 6 && prio_phase == 5) pr_ = 0;
+				if (prio_n <= 4) pr_ = 3 - prio_phase;
+				switch (pr_) {
+				case 0: __builtin_amdgcn_s_setprio(0); break;
+				case 1: __builtin_amdgcn_s_setprio(1); break;
+				case 2: __builtin_amdgcn_s_setprio(2); break;
+				default: __builtin_amdgcn_s_setprio(3); break;
+				}
+				prio_phase = prio_phase + 1 >= prio_n ? 0 : prio_phase + 1;
+#else
 				switch ((r + (int)dround) & 3) {
 				case 0: __builtin_amdgcn_s_setprio(0); break;
 				case 1: __builtin_amdgcn_s_setprio(1); break;
 				case 2: __builtin_amdgcn_s_setprio(2); break;
 				default: __builtin_amdgcn_s_setprio(3); break;
 				}
+#endif
 			}
 			// The two words per row whose side neighbours sit in another vector (sites 0 / 31) are assembled on the scalar
 			// unit from three source-colour words of row r0 + r - 1: A0, A1 of this wave's own 64 words, C from the
@@ -714,7 +755,10 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 					rj += 4 * wpr;
 				}
 				const uint64_t nw = me ^ (flips64(me, nu, nc, nd, sd, c3, c4) & live);
-				if (COUNT && (unsigned)lr < (unsigned)p.Y) cnt_up += (uint32_t)__popcll(nw); // (dead lanes are zero in memory; a ring slab's ghost rows are its neighbours' to count)
+				if (COUNT && (unsigned)lr < (unsigned)p.Y) { // (dead lanes are zero in memory; a ring slab's ghost rows are its neighbours' to count)
+					cnt_up += (uint32_t)__popcll(nw);
+					if (eq_unit) cnt_eq += (uint32_t)(__popcll(~(nw ^ up) & live) + __popcll(~(nw ^ ct) & live) + __popcll(~(nw ^ dw) & live) + __popcll(~(nw ^ sd) & live));
+				}
 				if (FUSED) {
 					st64_coh_issue<STREAM>(rd, lane * 8, nw);
 					if (p.wrap) { // the halo rows that mirror this colour's edge rows
@@ -761,7 +805,12 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				if ((p.cnt_mask >> swp) & 1ull) {
 					const unsigned long long tot = wave_sum((unsigned long long)cnt_up);
 					const int meas = p.cnt_slot0 + (int)__popcll(p.cnt_mask & ((1ull << swp) - 1ull));
-					if (lane == 0) p.cnt_acc[((size_t)meas * 2 + (size_t)(level & 1)) * ((size_t)p.nwg * (NT / 64)) + (size_t)wave] = (uint32_t)tot;
+					const size_t planes = p.cnt_bonds ? 3 : 2, per_plane = (size_t)p.nwg * (NT / 64);
+					if (lane == 0) p.cnt_acc[((size_t)meas * planes + (size_t)(level & 1)) * per_plane + (size_t)wave] = (uint32_t)tot;
+					if (eq_unit) {
+						const unsigned long long eq = wave_sum((unsigned long long)cnt_eq);
+						if (lane == 0) p.cnt_acc[((size_t)meas * planes + 2) * per_plane + (size_t)wave] = (uint32_t)eq;
+					}
 				}
 			}
 			if (lane == 0) __hip_atomic_fetch_add(p.done + (BATCH ? rep * p.done_stride : 0) + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -769,6 +818,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			if (edge_unit && level == p.nlevels - 1 && lane == 0) __hip_atomic_fetch_add(p.edge_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
+	clock_mark(1);
 #if defined(ISING_FUSED_TRACE)
 	if (FUSED) {
 		__syncthreads();
@@ -1215,21 +1265,23 @@ __global__ void __launch_bounds__(64) measure_fold_k(unsigned long long *__restr
 	}
 }
 
-// in-launch counts: measurement m = the sum of its 2 * waves_per_level slots
-__global__ void __launch_bounds__(THREADS) count_fold_k(const uint32_t *__restrict__ slots, size_t per_meas, unsigned long long *__restrict__ out) {
+// in-launch counts: measurement m = the sum of its slots -- out[2 m] the up spins (the first `n_up` slots: both colours' waves), out[2 m + 1] the
+// equal bonds (the rest: the white level's waves; none when the call did not ask for the energy)
+__global__ void __launch_bounds__(THREADS) count_fold_k(const uint32_t *__restrict__ slots, size_t per_meas, size_t n_up, unsigned long long *__restrict__ out) {
 	const uint32_t *s = slots + (size_t)blockIdx.x * per_meas;
-	unsigned long long v = 0;
-	for (size_t i = threadIdx.x; i < per_meas; i += THREADS) v += s[i];
+	unsigned long long v = 0, b = 0;
+	for (size_t i = threadIdx.x; i < per_meas; i += THREADS) { if (i < n_up) v += s[i]; else b += s[i]; }
 	v = wave_sum(v);
-	__shared__ unsigned long long part[THREADS / 64];
-	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+	b = wave_sum(b);
+	__shared__ unsigned long long part[2][THREADS / 64];
+	if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = v; part[1][threadIdx.x >> 6] = b; }
 	__syncthreads();
-	if (threadIdx.x == 0) { unsigned long long t = 0; for (int k = 0; k < THREADS / 64; k++) t += part[k]; out[blockIdx.x] = t; }
+	if (threadIdx.x < 2) { unsigned long long t = 0; for (int k = 0; k < THREADS / 64; k++) t += part[threadIdx.x][k]; out[2 * blockIdx.x + threadIdx.x] = t; }
 }
 
-hipError_t launch_count_fold(const uint32_t *slots, size_t per_meas, int nmeas, unsigned long long *out, hipStream_t stream) {
+hipError_t launch_count_fold(const uint32_t *slots, size_t per_meas, size_t n_up, int nmeas, unsigned long long *out, hipStream_t stream) {
 	if (nmeas <= 0) return hipSuccess;
-	hipLaunchKernelGGL(count_fold_k, dim3((unsigned)nmeas), dim3(THREADS), 0, stream, slots, per_meas, out);
+	hipLaunchKernelGGL(count_fold_k, dim3((unsigned)nmeas), dim3(THREADS), 0, stream, slots, per_meas, n_up, out);
 	return hipGetLastError();
 }
 

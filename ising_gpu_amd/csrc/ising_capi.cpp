@@ -298,32 +298,87 @@ int ising_device_info(int device, char *name, size_t name_len, int *cus, int *ma
 	return ISING_OK;
 }
 
-int ising_philox_ceiling(int device, double *sites_per_ns) {
+// the clock a kernel ran at from the marks its first workgroups left: {cycles, 100 MHz ticks} x {start, end} per XCD
+static void clock_from_marks(const unsigned long long *m, int n, double *mean, double *lo, double *hi) {
+	double sum = 0, mn = 0, mx = 0;
+	int got = 0;
+	for (int k = 0; k < n; k++) {
+		const unsigned long long c0 = m[4 * k], r0 = m[4 * k + 1], c1 = m[4 * k + 2], r1 = m[4 * k + 3];
+		if (c1 <= c0 || r1 <= r0) continue; // (a workgroup that never ran, or marks of two different launches)
+		const double mhz = (double)(c1 - c0) / (double)(r1 - r0) * 100.0;
+		sum += mhz;
+		mn = got ? std::min(mn, mhz) : mhz;
+		mx = got ? std::max(mx, mhz) : mhz;
+		got++;
+	}
+	if (mean) *mean = got ? sum / got : 0.0;
+	if (lo) *lo = mn;
+	if (hi) *hi = mx;
+}
+
+int ising_philox_ceiling_clocked(int device, double min_ms, double *sites_per_ns, double *sclk_mhz) {
 	if (!sites_per_ns) return fail(ISING_E_ARG, "null argument");
 	HIP_TRY(hipSetDevice(device));
 	int cus = 0;
 	HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-	const int blocks = cus * 32, nrows = 64; // 8 waves per SIMD over four rounds of blocks; ~2e10 sites per launch
+	const int blocks = cus * 32, nrows = 64; // 8 waves per SIMD over four rounds of blocks; ~8.6e9 sites, ~2 ms per launch
 	uint32_t *out = nullptr;
+	unsigned long long *d_clk = nullptr;
 	HIP_TRY(hipMalloc((void **)&out, (size_t)blocks * 256 * sizeof(uint32_t)));
+	hipError_t e = hipMalloc((void **)&d_clk, 32 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMemset(d_clk, 0, 32 * sizeof(unsigned long long));
 	hipEvent_t e0 = nullptr, e1 = nullptr;
-	hipError_t e = hipEventCreate(&e0);
+	if (e == hipSuccess) e = hipEventCreate(&e0);
 	if (e == hipSuccess) e = hipEventCreate(&e1);
-	double best = 0;
-	for (int rep = 0; rep < 4 && e == hipSuccess; rep++) { // the first launch also warms the clocks up
+	double rate = 0, clock = 0;
+	int n = 2; // two warm launches set the scale; then one timed batch of launches back to back that lasts min_ms
+	for (int pass = 0; pass < 2 && e == hipSuccess; pass++) {
 		e = hipEventRecord(e0, nullptr);
-		if (e == hipSuccess) e = ising::launch_philox_ceiling(out, blocks, nrows, nullptr);
+		for (int k = 0; k < n && e == hipSuccess; k++) e = ising::launch_philox_ceiling(out, blocks, nrows, nullptr, (pass == 1 && k == n - 1) ? d_clk : nullptr);
 		if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
 		if (e == hipSuccess) e = hipEventSynchronize(e1);
 		float ms = 0;
 		if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-		if (e == hipSuccess && ms > 0) best = std::max(best, (double)blocks * 256.0 * nrows * 64.0 / (ms * 1e6));
+		if (e != hipSuccess || ms <= 0) break;
+		if (pass == 0) n = std::max(2, std::min(4096, (int)std::ceil(min_ms / (ms / n))));
+		else rate = (double)n * blocks * 256.0 * nrows * 64.0 / (ms * 1e6);
 	}
+	unsigned long long marks[32];
+	if (e == hipSuccess) e = hipMemcpy(marks, d_clk, sizeof(marks), hipMemcpyDeviceToHost);
+	if (e == hipSuccess) clock_from_marks(marks, 8, &clock, nullptr, nullptr);
 	if (e0) (void)hipEventDestroy(e0);
 	if (e1) (void)hipEventDestroy(e1);
 	(void)hipFree(out);
+	if (d_clk) (void)hipFree(d_clk);
 	if (e != hipSuccess) return fail(ISING_E_HIP, "philox ceiling probe failed: %s", hipGetErrorString(e));
-	*sites_per_ns = best;
+	*sites_per_ns = rate;
+	if (sclk_mhz) *sclk_mhz = clock;
+	return ISING_OK;
+}
+
+// (the form of rounds 1-4, kept for its callers: the average over ~20 ms of launches)
+int ising_philox_ceiling(int device, double *sites_per_ns) { return ising_philox_ceiling_clocked(device, 20.0, sites_per_ns, nullptr); }
+
+int ising_kernel_clock(ising_ctx *c, int enable) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (int rc = bind(c)) return rc;
+	if (enable && !c->d_clk) HIP_TRY(hipMalloc((void **)&c->d_clk, 32 * sizeof(unsigned long long)));
+	if (enable) HIP_TRY(hipMemsetAsync(c->d_clk, 0, 32 * sizeof(unsigned long long), c->stream));
+	c->clk_on = enable != 0;
+	return ISING_OK;
+}
+
+int ising_kernel_clock_fetch(ising_ctx *c, double *mean, double *lo, double *hi) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (!c->d_clk) return fail(ISING_E_STATE, "ising_kernel_clock was never enabled on this slab");
+	if (int rc = bind(c)) return rc;
+	if (int rc = ising_host::sync_checked(c)) return rc;
+	unsigned long long marks[32];
+	HIP_TRY(hipMemcpy(marks, c->d_clk, sizeof(marks), hipMemcpyDeviceToHost));
+	double m = 0;
+	clock_from_marks(marks, 8, &m, lo, hi);
+	if (m <= 0) return fail(ISING_E_STATE, "no fused launch has left its clock marks (ising_sweep's launch form: ising_sweep_info)");
+	if (mean) *mean = m;
 	return ISING_OK;
 }
 
@@ -515,7 +570,10 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		const bool ok = best >= 0 && (NT == 256 || NT == 512 || NT == 1024);
 		ising::TileParams tp{};
 		tp.TR = TR; tp.TWI = TWI; tp.ns = S;
-		if (ok && ising::dense_tiles_lds_bytes(tp) <= 64 * 1024) {
+		// (dense_tile_k's dynamic segment + its static words -- the workgroup's up-spin sum -- against what a workgroup of this device may take)
+		int lds_max = 64 * 1024;
+		if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device) != hipSuccess || lds_max <= 0) { (void)hipGetLastError(); lds_max = 64 * 1024; }
+		if (ok && ising::dense_tiles_lds_bytes(tp) + 64 <= (size_t)std::min(lds_max, 64 * 1024)) {
 			c->tile_rows = TR; c->tile_words = TWI; c->tile_sweeps = S; c->tile_threads = NT;
 			c->tile_xcd = pol.tile_xcd != 0 && (((long long)(wpr / TWI) * (cfg->Y / TR)) % 8) == 0; // (tiles in bands per XCD)
 		} else if (pol.tile_rows || pol.tile_words || pol.tile_threads) {
@@ -554,6 +612,9 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		else e = hipMalloc((void **)&c->d_lat, c->alloc_words() * sizeof(uint64_t));
 	}
 	if (e == hipSuccess) e = hipMemset(c->d_lat, 0, c->alloc_words() * sizeof(uint64_t)); // optimized/main.cu:1603
+	// tile launches read one buffer and write the other: the second one is the library's own (also next to a caller's lattice_mem), allocated
+	// here so that a sweep never allocates and an out-of-memory condition is ising_create's to report
+	if (e == hipSuccess && c->tile_rows > 0) e = hipMalloc((void **)&c->d_lat2, c->alloc_words() * sizeof(uint64_t));
 	if (e == hipSuccess) e = hipMalloc((void **)&c->d_acc, 4 * sizeof(unsigned long long));
 	if (e == hipSuccess && c->ballot) {
 		// accept-mask slots, 2 KiB per wave: of every wave of the largest plain launch (one workgroup per unit), and of
@@ -631,6 +692,7 @@ int ising_destroy(ising_ctx *c) {
 	if (c->d_self) (void)hipFree(c->d_self);
 	if (c->d_mslots) (void)hipFree(c->d_mslots);
 	if (c->d_cnt) (void)hipFree(c->d_cnt);
+	if (c->d_clk) (void)hipFree(c->d_clk);
 	delete c;
 	return ISING_OK;
 }

@@ -131,6 +131,11 @@ struct ising_ctx {
 	int ring_cnt_every = 0, ring_cnt_inflight = 0; // ring slab: the deep launches of the call under way count the sweeps whose iteration is a multiple of this (0: none); measurements so far
 	unsigned long long cnt_mask_next = 0;
 	int cnt_slot0_next = 0;
+	bool cnt_bonds_next = false;   // ... and the launch's white levels leave the equal bonds of their rows too (a third plane of slots per measurement)
+	bool ring_cnt_bonds = false;   // ring slab: ... the call under way asked for the energy
+	// Measurement aid (ising_kernel_clock): the marks the first eight workgroups of the last fused launch left (cycle and 100 MHz counters, start and end)
+	unsigned long long *d_clk = nullptr;
+	bool clk_on = false;
 	// Exchange statistics (ising_exchange_stats_begin / _fetch; sweep_deep_overlapped): four events per sampled exchange --
 	// [4e] launch e begins, [4e+1] launch e ends (both on its dispatch packet), [4e+2] comm stream: the launch's edge strips have
 	// finished their last level (the exchange starts), [4e+3] comm stream: the neighbours' rows are in place and edge_go has moved.
@@ -220,7 +225,7 @@ void ring_abort_drain(ising_ctx *c);
 // hipStreamSynchronize(c->stream), then: did a fused launch give up (completion counters that never came: UpdateParams.abort_flag)?
 // If so its tickets, counters and their host-side bases start from zero again and ISING_E_STATE is returned.
 int sync_checked(ising_ctx *c);
-int cnt_reserve(ising_ctx *c, size_t strips, size_t *slots, size_t *chunk, unsigned long long **d_sum); // ising_update.cpp: the slots of in-launch counts
+int cnt_reserve(ising_ctx *c, size_t strips, bool bonds, size_t *slots, size_t *n_up, size_t *chunk, unsigned long long **d_sum); // ising_update.cpp: the slots of in-launch counts (`bonds`: a third plane)
 int check_abort(ising_ctx *c);
 // the switches of DESIGN 8a from the environment (ISING_E_ARG for a value that means nothing)
 int read_policy(ising_policy *pol);

@@ -82,6 +82,12 @@ struct UpdateParams {
 	uint32_t *cnt_acc;
 	unsigned long long cnt_mask;
 	int32_t cnt_slot0;
+	// ... with the energy: cnt_bonds != 0 = a measurement has a third plane of slots, cnt_acc[(3 m + 2) * (4 nwg) + w] (and its up-spin planes are
+	// (3 m + colour)): the white level's waves leave the number of (white site of their rows, black neighbour) pairs with equal spins there --
+	// their sum over the lattice is ising_bond_equal's A (every bond has one white end)
+	int32_t cnt_bonds;
+	// Measurement aid (ising_kernel_clock): 8 x {cycle counter, 100 MHz counter} x {start, end} left by the launch's first eight workgroups; NULL: off
+	unsigned long long *clk_out;
 	const struct ReplicaParams *rep;
 	int32_t nrep, nwg_rep;
 	uint32_t rep_magic;       // ceil(2^32 / nwg_rep)
@@ -109,7 +115,8 @@ struct InitParams {
 hipError_t launch_init(const InitParams &p, hipStream_t stream);
 
 // measurement aid: `blocks` x 256 lanes x nrows x 16 Philox blocks (= 64 sites each); out holds blocks * 256 words
-hipError_t launch_philox_ceiling(uint32_t *out, int blocks, int nrows, hipStream_t stream);
+// `clk` (optional): the first eight blocks leave {cycle counter, 100 MHz counter} at their start and end there (4 words each)
+hipError_t launch_philox_ceiling(uint32_t *out, int blocks, int nrows, hipStream_t stream, unsigned long long *clk = nullptr);
 
 // up-spin count of `nwords` packed words, accumulated into *acc (one 64-bit atomic per block)
 hipError_t launch_popcount(const uint64_t *v, size_t nwords, unsigned long long *acc, hipStream_t stream);
@@ -191,8 +198,8 @@ constexpr int BALLOT_MEASURE_SLOTS = 16;
 hipError_t launch_ballot_measure(const ReplicaParams *reps, int nrep, int gx, int Y, unsigned long long *acc, hipStream_t stream);
 // one lattice: its slots' sums into out[0] (up spins) and out[1] (bond sum); the slots are zero again afterwards
 hipError_t launch_measure_fold(unsigned long long *acc, unsigned long long *out, hipStream_t stream);
-// in-launch counts: out[m] = the sum of measurement m's per_meas slots, m = 0 .. nmeas - 1
-hipError_t launch_count_fold(const uint32_t *slots, size_t per_meas, int nmeas, unsigned long long *out, hipStream_t stream);
+// in-launch counts: out[2 m] = the sum of the first n_up of measurement m's per_meas slots (up spins), out[2 m + 1] = the sum of the rest (equal bonds), m = 0 .. nmeas - 1
+hipError_t launch_count_fold(const uint32_t *slots, size_t per_meas, size_t n_up, int nmeas, unsigned long long *out, hipStream_t stream);
 hipError_t launch_ballot_init(const InitParams &p, hipStream_t stream);
 hipError_t launch_ballot_to_dense(const uint64_t *bal, uint32_t *dense, int gx, long long rows, hipStream_t stream);
 hipError_t launch_dense_to_ballot(const uint32_t *dense, uint64_t *bal, int gx, long long rows, hipStream_t stream);

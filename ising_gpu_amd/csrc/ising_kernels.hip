@@ -384,8 +384,10 @@ __global__ void __launch_bounds__(THREADS) ham_init_white_k(const HamWhiteParams
 // Philox4x32-10 blocks exactly as the update kernels generate them (philox_row_setup + philox_block: rounds 1-2 of
 // the wave-uniform counter word on the scalar unit), outputs XOR-folded into one word per lane.  sites/ns of this
 // kernel is what a half-sweep could reach if accept test, word logic and memory cost nothing.
-__global__ void __launch_bounds__(THREADS) philox_ceiling_k(uint32_t *__restrict__ out, uint32_t seed_lo, uint32_t seed_hi, int nrows) {
+__global__ void __launch_bounds__(THREADS) philox_ceiling_k(uint32_t *__restrict__ out, uint32_t seed_lo, uint32_t seed_hi, int nrows, unsigned long long *__restrict__ clk) {
 	const uint32_t tid0 = blockIdx.x * THREADS + threadIdx.x;
+	const bool marks = clk != nullptr && blockIdx.x < 8u && threadIdx.x == 0; // one wave per XCD: the clock this launch runs at
+	if (marks) { clk[4 * blockIdx.x] = __builtin_readcyclecounter(); clk[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); }
 	uint32_t acc = 0;
 	for (int r = 0; r < nrows; ++r) {
 		const PhiloxRow pr = philox_row_setup(tid0 + (uint32_t)r * 0x10000u, seed_lo, seed_hi + 2u * PHILOX_W1);
@@ -398,6 +400,7 @@ __global__ void __launch_bounds__(THREADS) philox_ceiling_k(uint32_t *__restrict
 		});
 	}
 	out[tid0] = acc;
+	if (marks) { clk[4 * blockIdx.x + 2] = __builtin_readcyclecounter(); clk[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 __global__ void __launch_bounds__(THREADS) popcount_k(const uint4 *__restrict__ v, size_t nvec, unsigned long long *acc) {
@@ -590,8 +593,8 @@ hipError_t launch_init(const InitParams &p, hipStream_t stream) {
 	return hipGetLastError();
 }
 
-hipError_t launch_philox_ceiling(uint32_t *out, int blocks, int nrows, hipStream_t stream) {
-	hipLaunchKernelGGL(philox_ceiling_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, out, 0x1234567u, 0x89abcdeu, nrows);
+hipError_t launch_philox_ceiling(uint32_t *out, int blocks, int nrows, hipStream_t stream, unsigned long long *clk) {
+	hipLaunchKernelGGL(philox_ceiling_k, dim3((unsigned)blocks), dim3(THREADS), 0, stream, out, 0x1234567u, 0x89abcdeu, nrows, clk);
 	return hipGetLastError();
 }
 

@@ -549,6 +549,7 @@ int sweep_deep_overlapped(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 				for (int j = 0; j < ns; j++) if ((it + j) % c->ring_cnt_every == 0) mask |= 1ull << j;
 				c->cnt_mask_next = mask;
 				c->cnt_slot0_next = c->ring_cnt_inflight;
+				c->cnt_bonds_next = c->ring_cnt_bonds;
 				c->ring_cnt_inflight += (int)__builtin_popcountll(mask);
 			}
 			if (int rc = ising_host::update_deep(c, it, 2 * ns, true)) return rc;
@@ -615,7 +616,9 @@ int sweep_local(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 // ising_ring_sweep / ising_rank_sweep with the reference's print points taken INSIDE the deep launches (as ising_sweep_counted does for a lone slab): where the ring
 // sweeps its slabs through their ghost rows with the exchange in the launches' tails, the launches of every slab count the up spins of their OWN rows after every
 // iteration that is a multiple of `every`; mine[k] = this process's slabs' sum for the k-th of them.  ISING_E_UNSUPPORTED-like answer (1 in *fallback) anywhere else.
-int ring_sweep_counted(ising_ctx **ctxs, int n, int first_it, int nsweeps, int every, std::vector<unsigned long long> &mine, bool *fallback) {
+// `bonds`: the launches' white levels also leave the equal bonds of their rows (every bond of the lattice has one white end in exactly one slab); mine[2 k] = up spins,
+// mine[2 k + 1] = equal bonds (0 without `bonds`) of the k-th print point.
+int ring_sweep_counted(ising_ctx **ctxs, int n, int first_it, int nsweeps, int every, bool bonds, std::vector<unsigned long long> &mine, bool *fallback) {
 	*fallback = true;
 	if (int rc = settle_layout(ctxs, n)) return rc;
 	bool deep = !ctxs[0]->cfg.XSL && !ctxs[0]->cfg.use_J && ctxs[0]->ghost() > 1 && ctxs[0]->pol.overlap != 0; // (a call of no sweeps reserves the slots: a warm-up)
@@ -627,17 +630,17 @@ int ring_sweep_counted(ising_ctx **ctxs, int n, int first_it, int nsweeps, int e
 	*fallback = false;
 	const int G = ctxs[0]->ghost();
 	mine.clear();
-	std::vector<size_t> slots(n), chunk(n);
+	std::vector<size_t> slots(n), n_up(n), chunk(n);
 	std::vector<unsigned long long *> d_sum(n);
 	size_t per_chunk = 64;
 	for (int k = 0; k < n; k++) {
 		ising_ctx *c = ctxs[k];
 		if (int rc = bind(c)) return rc;
 		const size_t strips = ((size_t)c->cfg.Y + 2 * (size_t)G - 2 + (size_t)c->H - 1) / (size_t)c->H; // rows [-(G - 1), Y + G - 1) of a deep launch
-		if (int rc = ising_host::cnt_reserve(c, strips, &slots[k], &chunk[k], &d_sum[k])) return rc;
+		if (int rc = ising_host::cnt_reserve(c, strips, bonds, &slots[k], &n_up[k], &chunk[k], &d_sum[k])) return rc;
 		per_chunk = std::min(per_chunk, chunk[k]);
 	}
-	std::vector<unsigned long long> h(per_chunk);
+	std::vector<unsigned long long> h(2 * per_chunk);
 	int it = first_it, left = nsweeps;
 	while (left > 0) {
 		// as many sweeps as hold `per_chunk` measurements at most
@@ -651,21 +654,22 @@ int ring_sweep_counted(ising_ctx **ctxs, int n, int first_it, int nsweeps, int e
 			if (int rc = bind(c)) return rc;
 			if (m) HIP_TRY(hipMemsetAsync(c->d_cnt, 0, (size_t)m * slots[k] * sizeof(uint32_t), c->stream));
 			c->ring_cnt_every = every;
+			c->ring_cnt_bonds = bonds;
 			c->ring_cnt_inflight = 0;
 		}
 		const int rc = sweep_deep_overlapped(ctxs, n, it, ns);
-		for (int k = 0; k < n; k++) ctxs[k]->ring_cnt_every = 0;
+		for (int k = 0; k < n; k++) { ctxs[k]->ring_cnt_every = 0; ctxs[k]->ring_cnt_bonds = false; }
 		if (rc) return rc;
 		const size_t base = mine.size();
-		mine.resize(base + (size_t)m, 0ull);
+		mine.resize(base + 2 * (size_t)m, 0ull);
 		for (int k = 0; k < n && m; k++) {
 			ising_ctx *c = ctxs[k];
 			if (int rc2 = bind(c)) return rc2;
 			if (c->ring_cnt_inflight != m) return fail(ISING_E_STATE, "counted ring sweep: %d measurements launched, %d expected", c->ring_cnt_inflight, m);
-			HIP_TRY(ising::launch_count_fold(c->d_cnt, slots[k], m, d_sum[k], c->stream));
-			HIP_TRY(hipMemcpyAsync(h.data(), d_sum[k], (size_t)m * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+			HIP_TRY(ising::launch_count_fold(c->d_cnt, slots[k], n_up[k], m, d_sum[k], c->stream));
+			HIP_TRY(hipMemcpyAsync(h.data(), d_sum[k], (size_t)m * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
 			if (int rc2 = ising_host::sync_checked(c)) return rc2;
-			for (int q = 0; q < m; q++) mine[base + (size_t)q] += h[(size_t)q];
+			for (int q = 0; q < 2 * m; q++) mine[base + (size_t)q] += h[(size_t)q];
 		}
 		it += ns;
 		left -= ns;
@@ -864,21 +868,24 @@ int ising_ring_sweep(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 
 // ising_ring_sweep with the reference's print points (ising_sweep_counted for rings): ups[k] = the up spins of the WHOLE lattice after the k-th iteration of the call
 // that is a multiple of `every`.  Counted inside the deep launches where the ring sweeps through ghost rows with overlapped exchanges; sweeps and counts in turn elsewhere.
-int ising_ring_sweep_counted(ising_ctx **ctxs, int n, int first_it, int nsweeps, int every, uint64_t *ups, int max_counts, int *ncounts) {
+int ising_ring_sweep_counted(ising_ctx **ctxs, int n, int first_it, int nsweeps, int every, uint64_t *ups, int64_t *bond_equal, int max_counts, int *ncounts) {
 	if (!ups || !ncounts) return fail(ISING_E_ARG, "null argument");
 	if (first_it < 0 || nsweeps < 0 || every < 1) return fail(ISING_E_ARG, "bad iteration range or count interval");
 	if (int rc = ring_bind(ctxs, n)) return rc;
-	if (ctxs[0]->wrap) return ising_sweep_counted(ctxs[0], first_it, nsweeps, every, ups, max_counts, ncounts);
+	if (ctxs[0]->wrap) return ising_sweep_counted(ctxs[0], first_it, nsweeps, every, ups, bond_equal, max_counts, ncounts);
 	const long long last = (long long)first_it + nsweeps - 1;
 	const long long want = nsweeps > 0 ? last / every - ((long long)first_it - 1) / every : 0;
 	*ncounts = 0;
 	if (want > max_counts) return fail(ISING_E_ARG, "%lld counts, room for %d", want, max_counts);
 	std::vector<unsigned long long> mine;
 	bool fallback = true;
-	if (int rc = ring_sweep_counted(ctxs, n, first_it, nsweeps, every, mine, &fallback)) return rc;
+	if (int rc = ring_sweep_counted(ctxs, n, first_it, nsweeps, every, bond_equal != nullptr, mine, &fallback)) return rc;
 	if (!fallback) {
-		for (size_t k = 0; k < mine.size(); k++) ups[k] = mine[k];
-		*ncounts = (int)mine.size();
+		for (size_t k = 0; k < mine.size() / 2; k++) {
+			ups[k] = mine[2 * k];
+			if (bond_equal) bond_equal[k] = (int64_t)mine[2 * k + 1];
+		}
+		*ncounts = (int)(mine.size() / 2);
 		return ISING_OK;
 	}
 	int it = first_it, k = 0;
@@ -889,6 +896,7 @@ int ising_ring_sweep_counted(ising_ctx **ctxs, int n, int first_it, int nsweeps,
 		if (next % every == 0) {
 			uint64_t up = 0, dw = 0;
 			if (int rc = ising_ring_count(ctxs, n, &up, &dw)) return rc;
+			if (bond_equal) if (int rc = ising_ring_bond_equal(ctxs, n, &bond_equal[k])) return rc;
 			ups[k++] = up;
 		}
 	}
@@ -1043,7 +1051,7 @@ static int rank_allreduce_u64(ising_ctx *c, unsigned long long *d_val, unsigned 
 }
 
 // ising_rank_sweep with print points: collective (every rank calls it with the same arguments); the ranks' sums travel over the rank transport.
-int ising_rank_sweep_counted(ising_ctx *c, int first_it, int nsweeps, int every, uint64_t *ups, int max_counts, int *ncounts) {
+int ising_rank_sweep_counted(ising_ctx *c, int first_it, int nsweeps, int every, uint64_t *ups, int64_t *bond_equal, int max_counts, int *ncounts) {
 	if (int rc = rank_check(c)) return rc;
 	if (!ups || !ncounts) return fail(ISING_E_ARG, "null argument");
 	if (first_it < 0 || nsweeps < 0 || every < 1) return fail(ISING_E_ARG, "bad iteration range or count interval");
@@ -1053,18 +1061,26 @@ int ising_rank_sweep_counted(ising_ctx *c, int first_it, int nsweeps, int every,
 	if (want > max_counts) return fail(ISING_E_ARG, "%lld counts, room for %d", want, max_counts);
 	std::vector<unsigned long long> mine;
 	bool fallback = true;
-	if (int rc = ring_sweep_counted(&c, 1, first_it, nsweeps, every, mine, &fallback)) return rc;
-	// (every rank takes the same branch: the conditions are the configuration's, which the ranks share -- the sum below says so)
+	// A local failure (an allocation, a launch, "measurements launched != expected") must not leave the other ranks in the reductions below:
+	// the outcome travels with the launch form -- low 20 bits: ranks that fell back, above: ranks that failed -- and every rank returns together
+	const int local_rc = ring_sweep_counted(&c, 1, first_it, nsweeps, every, bond_equal != nullptr, mine, &fallback);
+	const std::string local_err = local_rc ? ising_last_error() : "";
 	unsigned long long fb = 0;
-	if (int rc = ising_host::rank_sum_u64(c, fallback ? 1ull : 0ull, &fb)) return rc;
+	if (int rc = ising_host::rank_sum_u64(c, (fallback ? 1ull : 0ull) + (local_rc ? (1ull << 20) : 0ull), &fb)) return rc;
+	if (fb >> 20) return local_rc ? fail(local_rc, "%s", local_err.c_str()) : fail(ISING_E_STATE, "counted rank sweep: %llu other rank(s) failed in their launches", fb >> 20);
+	// (every rank takes the same branch: the conditions are the configuration's, which the ranks share -- the sum says so)
 	if (fb != 0 && fb != (unsigned long long)c->cfg.nslabs) return fail(ISING_E_STATE, "counted rank sweep: the ranks disagree about the launch form");
 	if (!fallback) {
-		for (size_t k = 0; k < mine.size(); k++) {
+		for (size_t k = 0; k < mine.size() / 2; k++) {
 			unsigned long long tot = 0;
-			if (int rc = ising_host::rank_sum_u64(c, mine[k], &tot)) return rc;
+			if (int rc = ising_host::rank_sum_u64(c, mine[2 * k], &tot)) return rc;
 			ups[k] = tot;
+			if (bond_equal) {
+				if (int rc = ising_host::rank_sum_u64(c, mine[2 * k + 1], &tot)) return rc;
+				bond_equal[k] = (int64_t)tot;
+			}
 		}
-		*ncounts = (int)mine.size();
+		*ncounts = (int)(mine.size() / 2);
 		return ISING_OK;
 	}
 	int it = first_it, k = 0;
@@ -1075,6 +1091,7 @@ int ising_rank_sweep_counted(ising_ctx *c, int first_it, int nsweeps, int every,
 		if (next % every == 0) {
 			uint64_t up = 0, dw = 0;
 			if (int rc = ising_rank_count(c, &up, &dw)) return rc;
+			if (bond_equal) if (int rc = ising_rank_bond_equal(c, &bond_equal[k])) return rc;
 			ups[k++] = up;
 		}
 	}

@@ -28,7 +28,9 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	hipEvent_t start = c->launch_start_next;
 	const unsigned long long cnt_mask = c->cnt_mask_next;
 	const int cnt_slot0 = c->cnt_slot0_next;
+	const bool cnt_bonds = c->cnt_bonds_next;
 	c->cnt_mask_next = 0;
+	c->cnt_bonds_next = false;
 	if (!stop) stop = c->launch_stop_next;
 	c->edge_scratch_next = false;
 	c->overlap_next = false;
@@ -114,7 +116,8 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			p.done = c->d_slotctl + SLOTCTL_TICKET_BYTES / 4;
 			p.wg_per_cu = c->fused_wg_per_cu;
 			p.wait_late = c->fused_wait_late ? (c->pol.fused_wait_late == 1 ? 1 : 2) : 0; // (default 2: behind the second draw phase)
-			if (cnt_mask) { p.cnt_acc = c->d_cnt; p.cnt_mask = cnt_mask; p.cnt_slot0 = cnt_slot0; }
+			if (cnt_mask) { p.cnt_acc = c->d_cnt; p.cnt_mask = cnt_mask; p.cnt_slot0 = cnt_slot0; p.cnt_bonds = cnt_bonds ? 1 : 0; }
+			if (c->clk_on && c->d_clk) p.clk_out = c->d_clk;
 			p.nt_stream = c->fused_nt;
 			p.done_base = c->done_base;
 			if (lo0 < 0 || hi0 > c->cfg.Y) { // ghost rows are rows of the neighbouring slabs
@@ -220,8 +223,9 @@ extern "C" int ising_sweep(ising_ctx *c, int first_it, int nsweeps) {
 // Small lattices on the dense layout (ising_dense.hip: dense_tile_k): launches of several sweeps each, every workgroup on its own tile
 // + halo, no exchange inside a launch.  A launch reads one buffer and writes the other, so a call issues an EVEN number of them and
 // the spins are back in d_lat when it returns (a single sweep takes the two per-colour launches).
+// (`fast_ok`: the tile kernel knows integer thresholds only -- KERNEL_FAST at a temperature without them falls through to launch_ranges, which returns ISING_E_STATE as the header says)
 static bool sweeps_tiled(const ising_ctx *c, int nsweeps) {
-	return c->tile_rows > 0 && nsweeps >= 2 && c->wrap && c->dense && !c->ballot && !c->cfg.use_J && !c->cfg.XSL && !ising_host::needs_generic(c);
+	return c->tile_rows > 0 && nsweeps >= 2 && c->wrap && c->dense && !c->ballot && !c->cfg.use_J && !c->cfg.XSL && c->fast_ok && !ising_host::needs_generic(c);
 }
 
 // one tile launch of `ns` sweeps from buffer `from_second ? d_lat2 : d_lat` into the other one; `cnt`: see TileParams
@@ -248,7 +252,7 @@ static int launch_tiles(ising_ctx *c, int it, int ns, bool from_second, unsigned
 
 static int sweep_tiles(ising_ctx *c, int first_it, int nsweeps) {
 	if (int rc = bind(c)) return rc;
-	if (!c->d_lat2) HIP_TRY(hipMalloc((void **)&c->d_lat2, c->alloc_words() * sizeof(uint64_t)));
+	if (!c->d_lat2) return fail(ISING_E_STATE, "tile launches without their second buffer (ising_create allocates it)");
 	const int S = c->tile_sweeps;
 	const int L = 2 * ((nsweeps + 2 * S - 1) / (2 * S)); // launches: even, none longer than S sweeps
 	const int base = nsweeps / L, rem = nsweeps % L;
@@ -265,7 +269,7 @@ static int sweep_tiles(ising_ctx *c, int first_it, int nsweeps) {
 // alternate between the two buffers; a call that ends in the second one copies it back (the lattices of this path are a few MB).
 static int sweep_tiles_counted(ising_ctx *c, int first_it, int nsweeps, int every, uint64_t *ups, long long n, int *ncounts) {
 	if (int rc = bind(c)) return rc;
-	if (!c->d_lat2) HIP_TRY(hipMalloc((void **)&c->d_lat2, c->alloc_words() * sizeof(uint64_t)));
+	if (!c->d_lat2) return fail(ISING_E_STATE, "tile launches without their second buffer (ising_create allocates it)");
 	if (c->tile_cnt_cap < (size_t)n) {
 		if (c->d_tile_cnt) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_tile_cnt)); c->d_tile_cnt = nullptr; c->tile_cnt_cap = 0; }
 		const size_t cap = std::max<size_t>(64, (size_t)n);
@@ -322,11 +326,12 @@ int ising_host::sweep_alone(ising_ctx *c, int first_it, int nsweeps) {
 
 // In-launch counts (ising_ballot.hip: COUNT): the wave slots of a chunk of measurements of fused launches over `strips` strips, and their sums behind them.
 // slots: per measurement one per wave of a level and colour; a call is worked off in chunks of measurements whose slots fit 64 MiB.
-int ising_host::cnt_reserve(ising_ctx *c, size_t strips, size_t *slots, size_t *chunk, unsigned long long **d_sum) {
+int ising_host::cnt_reserve(ising_ctx *c, size_t strips, bool bonds, size_t *slots, size_t *n_up, size_t *chunk, unsigned long long **d_sum) {
 	const size_t waves = ((size_t)4 * c->nwc() * strips + 15) / 16 * 4; // 4 waves per workgroup unit, as launch_ballot_update counts them
-	*slots = 2 * waves;
+	*n_up = 2 * waves;
+	*slots = (bonds ? 3 : 2) * waves;
 	*chunk = std::max<size_t>(1, std::min<size_t>(64, ((size_t)64 << 20) / (*slots * sizeof(uint32_t))));
-	const size_t words = (*chunk * *slots + 15) / 16 * 16, bytes = words * sizeof(uint32_t) + *chunk * sizeof(unsigned long long) + 64;
+	const size_t words = (*chunk * *slots + 15) / 16 * 16, bytes = words * sizeof(uint32_t) + 2 * *chunk * sizeof(unsigned long long) + 64;
 	if (c->cnt_cap < bytes) {
 		if (c->d_cnt) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_cnt)); c->d_cnt = nullptr; c->cnt_cap = 0; }
 		HIP_TRY(hipMalloc((void **)&c->d_cnt, bytes));
@@ -337,21 +342,22 @@ int ising_host::cnt_reserve(ising_ctx *c, size_t strips, size_t *slots, size_t *
 }
 
 // The reference's loop with its print points (optimized/main.cu:1763-1810: sweep, and countSpins whenever the iteration is a multiple of
-// printFreq): `nsweeps` sweeps, the up-spin count after every iteration `it` with it % every == 0.  Where ising_sweep issues fused
-// launches (a lone slab on the ballot layout, no sub-lattices, no couplings) the counts are taken INSIDE the launches -- no launch
-// boundary and no read-back between two print points (ising_ballot.hip: COUNT); elsewhere: sweeps and ising_count in turn.
-extern "C" int ising_sweep_counted(ising_ctx *c, int first_it, int nsweeps, int every, uint64_t *ups, int max_counts, int *ncounts) {
+// printFreq): `nsweeps` sweeps, the up-spin count after every iteration `it` with it % every == 0 -- and, `bond_equal` not null, ising_bond_equal's sum
+// at the same points (north_star's energy series; the reference computes none).  Where ising_sweep issues fused launches (a lone slab on the ballot
+// layout, no sub-lattices, no couplings) both are taken INSIDE the launches -- no launch boundary and no read-back between two print points
+// (ising_ballot.hip: COUNT) --; elsewhere: sweeps, ising_count and ising_bond_equal in turn.
+extern "C" int ising_sweep_counted(ising_ctx *c, int first_it, int nsweeps, int every, uint64_t *ups, int64_t *bond_equal, int max_counts, int *ncounts) {
 	if (!c || !ups || !ncounts) return fail(ISING_E_ARG, "null argument");
 	if (first_it < 0 || nsweeps < 0 || every < 1) return fail(ISING_E_ARG, "bad iteration range or count interval");
-	if (!c->wrap) return fail(ISING_E_STATE, "ising_sweep_counted needs a single slab without ring halo rows (rings: ising_ring_sweep and ising_ring_count in turn)");
+	if (!c->wrap) return fail(ISING_E_STATE, "ising_sweep_counted needs a single slab without ring halo rows (rings: ising_ring_sweep_counted / ising_rank_sweep_counted)");
 	const long long last = (long long)first_it + nsweeps - 1;
 	const long long n = nsweeps > 0 ? last / every - ((long long)first_it - 1) / every : 0; // iterations in [first_it, last] that are multiples of `every`
 	*ncounts = 0;
 	if (n > max_counts) return fail(ISING_E_ARG, "%lld counts, room for %d", n, max_counts);
 	if (int rc = bind(c)) return rc;
-	if (sweeps_tiled(c, 2)) return sweep_tiles_counted(c, first_it, nsweeps, every, ups, n, ncounts);
+	if (sweeps_tiled(c, 2) && !bond_equal) return sweep_tiles_counted(c, first_it, nsweeps, every, ups, n, ncounts);
 	const bool inside = sweeps_fused(c) && !c->cfg.XSL && !c->cfg.use_J;
-	if (!inside) { // one launch per colour, sub-lattices, couplings: the reference's own order of events
+	if (!inside) { // one launch per colour, tiles with the energy, sub-lattices, couplings: the reference's own order of events
 		int it = first_it, k = 0;
 		while (it <= last) {
 			const long long next = std::min<long long>(last, ((long long)it + every - 1) / every * every); // the next multiple of `every` from `it` on
@@ -360,17 +366,18 @@ extern "C" int ising_sweep_counted(ising_ctx *c, int first_it, int nsweeps, int 
 			if (next % every == 0) {
 				uint64_t up = 0, dw = 0;
 				if (int rc = ising_count(c, &up, &dw)) return rc;
+				if (bond_equal) if (int rc = ising_bond_equal(c, &bond_equal[k])) return rc;
 				ups[k++] = up;
+				*ncounts = k;
 			}
 		}
-		*ncounts = k;
 		return ISING_OK;
 	}
-	size_t slots = 0, chunk = 0;
+	size_t slots = 0, n_up = 0, chunk = 0;
 	unsigned long long *d_sum = nullptr;
-	if (int rc = ising_host::cnt_reserve(c, (size_t)c->nstrips, &slots, &chunk, &d_sum)) return rc;
+	if (int rc = ising_host::cnt_reserve(c, (size_t)c->nstrips, bond_equal != nullptr, &slots, &n_up, &chunk, &d_sum)) return rc;
 	const int per_launch = std::min(64, ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y)); // (a launch's measured sweeps are a 64-bit mask)
-	std::vector<unsigned long long> h(chunk);
+	std::vector<unsigned long long> h(2 * chunk);
 	long long got = 0;
 	int it = first_it, left = nsweeps;
 	while (left > 0) {
@@ -390,15 +397,19 @@ extern "C" int ising_sweep_counted(ising_ctx *c, int first_it, int nsweeps, int 
 			if (ns == 0) break;
 			c->cnt_mask_next = mask;
 			c->cnt_slot0_next = inflight;
-			if (int rc = launch_ranges(c, it, ISING_BLACK, 0, c->cfg.Y, 0, 0, 2 * ns)) return rc;
+			c->cnt_bonds_next = bond_equal != nullptr;
+			if (int rc = launch_ranges(c, it, ISING_BLACK, 0, c->cfg.Y, 0, 0, 2 * ns)) { *ncounts = (int)got; return rc; } // (the counts of the chunks before are the caller's)
 			inflight += m;
 			it += ns;
 			left -= ns;
 		}
-		HIP_TRY(ising::launch_count_fold(c->d_cnt, slots, inflight, d_sum, c->stream));
-		if (inflight) HIP_TRY(hipMemcpyAsync(h.data(), d_sum, (size_t)inflight * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-		if (int rc = ising_host::sync_checked(c)) return rc;
-		for (int k = 0; k < inflight; k++) ups[got++] = h[k];
+		HIP_TRY(ising::launch_count_fold(c->d_cnt, slots, n_up, inflight, d_sum, c->stream));
+		if (inflight) HIP_TRY(hipMemcpyAsync(h.data(), d_sum, (size_t)inflight * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+		if (int rc = ising_host::sync_checked(c)) { *ncounts = (int)got; return rc; }
+		for (int k = 0; k < inflight; k++, got++) {
+			ups[got] = h[2 * (size_t)k];
+			if (bond_equal) bond_equal[got] = (int64_t)h[2 * (size_t)k + 1];
+		}
 	}
 	*ncounts = (int)got;
 	return ISING_OK;

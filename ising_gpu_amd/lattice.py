@@ -151,15 +151,27 @@ class IsingSlab:
         self.it += n
         return self
 
-    def sweep_counted(self, n: int, every: int):
+    def sweep_counted(self, n: int, every: int, energy: bool = False):
         """n sweeps with the up-spin count after every iteration that is a multiple of `every` (ising_sweep_counted: inside the fused
-        launches where there are any); returns [(up, down), ...]."""
+        launches where there are any); returns [(up, down), ...] -- with `energy` [(up, down, bond_equal), ...]: the bond sum at the same points."""
         cap = n // every + 2
         ups, k = (C.c_uint64 * cap)(), C.c_int()
-        check(self._lib.ising_sweep_counted(self._h, self.it + 1, n, every, ups, cap, C.byref(k)))
+        eqs = (C.c_int64 * cap)() if energy else None
+        check(self._lib.ising_sweep_counted(self._h, self.it + 1, n, every, ups, eqs, cap, C.byref(k)))
         self.it += n
         tot = self.X * self.Y
-        return [(int(ups[i]), tot - int(ups[i])) for i in range(k.value)]
+        return [(int(ups[i]), tot - int(ups[i])) + ((int(eqs[i]),) if energy else ()) for i in range(k.value)]
+
+    def kernel_clock(self, enable: bool = True):
+        """measurement aid (ising_kernel_clock): fused launches leave the marks their clock is computed from"""
+        check(self._lib.ising_kernel_clock(self._h, 1 if enable else 0))
+        return self
+
+    def kernel_clock_fetch(self):
+        """(mean, min, max) MHz over the XCDs of the last fused launch (ising_kernel_clock_fetch; blocking)"""
+        m, lo, hi = C.c_double(), C.c_double(), C.c_double()
+        check(self._lib.ising_kernel_clock_fetch(self._h, C.byref(m), C.byref(lo), C.byref(hi)))
+        return m.value, lo.value, hi.value
 
     @property
     def fused(self) -> bool:
@@ -298,15 +310,16 @@ class IsingSlab:
         self.it += n
         return self
 
-    def rank_sweep_counted(self, n: int, every: int):
+    def rank_sweep_counted(self, n: int, every: int, energy: bool = False):
         """rank_sweep with the whole lattice's up-spin count after every iteration that is a multiple of `every` (ising_rank_sweep_counted: inside
-        the deep launches where the ring sweeps through ghost rows; collective); returns [(up, down), ...]."""
+        the deep launches where the ring sweeps through ghost rows; collective); returns [(up, down), ...], with `energy` [(up, down, bond_equal), ...]."""
         cap = n // every + 2
         ups, k = (C.c_uint64 * cap)(), C.c_int()
-        check(self._lib.ising_rank_sweep_counted(self._h, self.it + 1, n, every, ups, cap, C.byref(k)))
+        eqs = (C.c_int64 * cap)() if energy else None
+        check(self._lib.ising_rank_sweep_counted(self._h, self.it + 1, n, every, ups, eqs, cap, C.byref(k)))
         self.it += n
         tot = self.X * self.Y * self.cfg.nslabs
-        return [(int(ups[i]), tot - int(ups[i])) for i in range(k.value)]
+        return [(int(ups[i]), tot - int(ups[i])) + ((int(eqs[i]),) if energy else ()) for i in range(k.value)]
 
     def rank_wait(self, timeout_ms: int = -1):
         check(self._lib.ising_rank_wait(self._h, timeout_ms))
@@ -410,6 +423,13 @@ def philox_ceiling(device: int = 0) -> float:
     return v.value
 
 
+def philox_ceiling_clocked(device: int = 0, min_ms: float = 25.0):
+    """(sites/ns, shader MHz) of the draw-only kernel averaged over launches that last min_ms (ising_philox_ceiling_clocked)."""
+    v, mhz = C.c_double(), C.c_double()
+    check(_lib.load().ising_philox_ceiling_clocked(device, float(min_ms), C.byref(v), C.byref(mhz)))
+    return v.value, mhz.value
+
+
 def rccl_version() -> int:
     """Version code of the RCCL the library opened at run time; raises IsingError when there is none."""
     v = C.c_int()
@@ -468,16 +488,18 @@ class SlabSet:
             check(self._lib.ising_ring_exchange(self._arr, self.n, color))
         return self
 
-    def sweep_counted(self, n: int, every: int):
-        """sweep with the whole lattice's up-spin count after every iteration that is a multiple of `every` (ising_ring_sweep_counted)."""
+    def sweep_counted(self, n: int, every: int, energy: bool = False):
+        """sweep with the whole lattice's up-spin count after every iteration that is a multiple of `every` (ising_ring_sweep_counted); with
+        `energy` the bond sum too: [(up, down, bond_equal), ...]."""
         cap = n // every + 2
         ups, k = (C.c_uint64 * cap)(), C.c_int()
-        check(self._lib.ising_ring_sweep_counted(self._arr, self.n, self.it + 1, n, every, ups, cap, C.byref(k)))
+        eqs = (C.c_int64 * cap)() if energy else None
+        check(self._lib.ising_ring_sweep_counted(self._arr, self.n, self.it + 1, n, every, ups, eqs, cap, C.byref(k)))
         self.it += n
         for s in self.slabs:
             s.it = self.it
         tot = sum(s.X * s.Y for s in self.slabs)
-        return [(int(ups[i]), tot - int(ups[i])) for i in range(k.value)]
+        return [(int(ups[i]), tot - int(ups[i])) + ((int(eqs[i]),) if energy else ()) for i in range(k.value)]
 
     def sweep(self, n: int = 1):
         check(self._lib.ising_ring_sweep(self._arr, self.n, self.it + 1, n))

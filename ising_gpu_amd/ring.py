@@ -485,10 +485,10 @@ class NativeRing:
         self.it += nsweeps
         return self
 
-    def sweep_counted(self, nsweeps: int, every: int):
-        """sweep with the whole lattice's (up, down) after every iteration that is a multiple of `every`, counted inside the deep launches."""
+    def sweep_counted(self, nsweeps: int, every: int, energy: bool = False):
+        """sweep with the whole lattice's (up, down[, bond_equal]) after every iteration that is a multiple of `every`, counted inside the deep launches."""
         self.slab.it = self.it
-        out = self.slab.rank_sweep_counted(nsweeps, every)
+        out = self.slab.rank_sweep_counted(nsweeps, every, energy)
         self.it += nsweeps
         return out
 

@@ -183,3 +183,123 @@ def test_baseline_config2_command_line_at_full_length(gpu):
     assert f"Final   magnetization: {abs(p['up'] - p['down']) / n:9.6f}, up_s: {p['up']:12d}, dw_s: {p['down']:12d} (iter:   100000)\n" in out
     m = re.search(r"Kernel execution time for 100000 update steps: \S+ ms, (\d+\.\d\d) flips/ns", out)
     assert m and float(m.group(1)) > 2500.0, out[-400:]  # (3300 on an idle MI355X; the floor only catches a fall back to a slow path)
+
+
+# ---- the corners of the print logic (round-4 verdict): -e beyond its first point, -e with -p, -m with -p and with -e, -s 0 ---------------
+def _exp_points(nsteps):
+    """The reference's -e series (optimized/main.cu:1211-1228) as 1-based iterations: 153, then every rung of rint(2^(k/4)) that has at least
+    doubled the last point (+ 1: the loop prints when its 0-based index equals the list entry, :1827-1831)."""
+    pts, rung, k = [152], 0, 0
+    while k < nsteps and rung < nsteps:
+        rung = int(np.rint(2.0 ** (k / 4.0)))
+        if rung >= 2 * pts[-1] and len(pts) < 200:
+            pts.append(rung)
+        k += 1
+    return [p + 1 for p in pts]
+
+
+def test_exp_series_is_the_reference_s():
+    # (worked by hand from the reference's loop: 2^(33/4) = 304.4, 2^(37/4) = 608.9, 2^(41/4) = 1217.7, 2^(45/4) = 2435.5 -> 2435 < 2436, so 2^(46/4) = 2896.3)
+    assert _exp_points(3000)[:5] == [153, 305, 610, 1219, 2897]
+
+
+def _series(oracle_mod, X, Y, seed, temp, iters):
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=temp).init()
+    out = {}
+    for it in iters:
+        orc.sweep(it - orc.it)
+        up, dw = orc.count()
+        out[it] = (abs(up - dw) / (X * Y), up, dw)
+    return out
+
+
+def test_cli_exppr_series_and_print_freq_ignored(gpu, oracle_mod):
+    """-e over four points of the series (153, 305, 610, 1219); with -p next to it printFreq is ignored (optimized/main.cu:1473-1475)."""
+    X, Y, seed, n = 2048, 32, 77, 1300
+    pts = [p for p in _exp_points(n) if p <= n]
+    assert pts == [153, 305, 610, 1219]
+    ser = _series(oracle_mod, X, Y, seed, 2.0, pts + [n])
+    for extra in ([], ["-p", "100"]):
+        out = run(["-x", str(X), "-y", str(Y), "-n", str(n), "-e", "-t", "2.0", "-s", str(seed)] + extra)
+        assert "\tprint magn. following exponential series\n" in out
+        lines = [ln for ln in out.splitlines() if ln.startswith("        magnetization:")]
+        assert len(lines) == len(pts), lines  # (and none at multiples of 100)
+        for it, ln in zip(pts, lines):
+            m, up, dw = ser[it]
+            assert ln == f"        magnetization: {m:9.6f} (^2: {m*m:9.6f}), up_s: {up:12d}, dw_s: {dw:12d} (iter: {it:8d})"
+        m, up, dw = ser[n]
+        assert f"Final   magnetization: {m:9.6f}, up_s: {up:12d}, dw_s: {dw:12d} (iter: {n:8d})\n" in out
+
+
+def _first_hit(ser, iters, k):
+    """a target magnetisation that the k-th print point is the first to come within 1e-3 of (or None)"""
+    tgt = ser[iters[k]][0]
+    return tgt if all(abs(ser[it][0] - tgt) >= 1.0e-3 for it in iters[:k]) else None
+
+
+def test_cli_magn_early_exit_with_print(gpu, oracle_mod):
+    """-m with -p: the run stops at the first print point whose magnetisation is within 1e-3 of the target; the final line and the
+    performance line report that iteration (optimized/main.cu:65, :1819-1824: j is bumped before the break)."""
+    X, Y, seed, p, n = 2048, 64, 99, 4, 200
+    iters = list(range(p, n + 1, p))
+    ser = _series(oracle_mod, X, Y, seed, 1.0, iters)  # T = 1.0: the magnetisation of a 2^17-spin lattice moves by more than 1e-3 between points
+    k = next(k for k in range(3, len(iters)) if _first_hit(ser, iters, k) is not None)
+    tgt, stop = ser[iters[k]][0], iters[k]
+    out = run(["-x", str(X), "-y", str(Y), "-n", str(n), "-p", str(p), "-t", "1.0", "-s", str(seed), "-m", f"{tgt:.9f}"])
+    assert f"\tearly exit if magn. == {tgt:f}+-0.001000\n" in out
+    lines = [ln for ln in out.splitlines() if ln.startswith("        magnetization:")]
+    assert len(lines) == k + 1
+    m, up, dw = ser[stop]
+    assert lines[-1] == f"        magnetization: {m:9.6f}, up_s: {up:12d}, dw_s: {dw:12d} (iter: {stop:8d})"
+    assert f"Final   magnetization: {m:9.6f}, up_s: {up:12d}, dw_s: {dw:12d} (iter: {stop:8d})\n" in out
+    assert re.search(rf"Kernel execution time for {stop} update steps:", out)
+    # a target nothing comes near: the run goes to its end
+    out = run(["-x", str(X), "-y", str(Y), "-n", "40", "-p", str(p), "-t", "1.0", "-s", str(seed), "-m", "2.0"])
+    assert "(iter:       40)\n" in out and re.search(r"Kernel execution time for 40 update steps:", out)
+    # without -p / -e the target is never looked at (and the configuration block does not mention it)
+    out = run(["-x", str(X), "-y", str(Y), "-n", "8", "-t", "1.0", "-s", str(seed), "-m", f"{ser[iters[1]][0]:.9f}"])
+    assert "early exit" not in out and "(iter:        8)\n" in out
+
+
+def test_cli_magn_early_exit_with_exppr(gpu, oracle_mod):
+    """-m with -e: looked at at the series' points only (optimized/main.cu:1840-1845)."""
+    X, Y, seed, n = 2048, 32, 31, 700
+    pts = [153, 305, 610]
+    ser = _series(oracle_mod, X, Y, seed, 1.0, pts)
+    tgt = _first_hit(ser, pts, 1)
+    if tgt is None:
+        pytest.skip("the first two points of this lattice lie within 1e-3 of each other")
+    out = run(["-x", str(X), "-y", str(Y), "-n", str(n), "-e", "-t", "1.0", "-s", str(seed), "-m", f"{tgt:.9f}"])
+    lines = [ln for ln in out.splitlines() if ln.startswith("        magnetization:")]
+    assert len(lines) == 2 and lines[1].endswith("(iter:      305)")
+    m, up, dw = ser[305]
+    assert f"Final   magnetization: {m:9.6f}, up_s: {up:12d}, dw_s: {dw:12d} (iter: {305:8d})\n" in out
+    assert re.search(r"Kernel execution time for 305 update steps:", out)
+
+
+def test_cli_random_seed_is_printed_and_reproducible(gpu):
+    """-s 0 draws a seed (optimized/main.cu:1329-1334); the configuration block prints it and a second run with that seed repeats the run."""
+    args = ["-x", "2048", "-y", "32", "-n", "12", "-p", "4", "-a", "1"]
+    out = run(args + ["-s", "0"])
+    seed = int(re.search(r"\tseed: (\d+)\n", out).group(1))
+    assert 0 < seed <= 0x7FFFFFFFF
+    again = run(args + ["-s", str(seed)])
+    pick = lambda o: [ln for ln in o.splitlines() if "magnetization" in ln]  # noqa: E731
+    assert pick(out) == pick(again) and len(pick(out)) == 5
+
+
+@pytest.mark.parametrize("X,Y,layout", [(8192, 2048, None), (8192, 128, "ballot"), (2048, 64, None)], ids=["fused-auto", "ballot-small", "dense-tiles"])
+def test_cli_print_with_energy_rides_in_the_launches(gpu, oracle_mod, X, Y, layout):
+    """`-p N --energy` (north_star: magnetisation AND energy time-series): the same lines as the reference's order of events gives, whether the print
+    points ride inside the fused launches (ising_sweep_counted with its bond sums) or the run sweeps and measures in turn."""
+    seed, n, p = 606, 40, 8
+    args = ["-x", str(X), "-y", str(Y), "-n", str(n), "-p", str(p), "-a", "1", "-s", str(seed), "--energy"] + (["--layout", layout] if layout else [])
+    out = run(args)
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=oracle_mod.CRIT_TEMP).init()
+    assert f"Initial energy/spin:   {orc.energy_per_spin():9.6f}\n" in out
+    for it in range(p, n + 1, p):
+        orc.sweep(it - orc.it)
+        up, dw = orc.count()
+        m = abs(up - dw) / (X * Y)
+        assert f"        magnetization: {m:9.6f}, up_s: {up:12d}, dw_s: {dw:12d} (iter: {it:8d})\n        energy/spin:   {orc.energy_per_spin():9.6f} (iter: {it:8d})\n" in out, it
+    assert f"Final   energy/spin:   {orc.energy_per_spin():9.6f}\n" in out

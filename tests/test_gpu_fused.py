@@ -372,23 +372,25 @@ def test_sublattices_do_not_see_each_other(gpu, layout):
 
 @pytest.mark.parametrize("X,Y,H,every,calls", [(8192, 64, 0, 1, (3, 5)), (8192, 128, 4, 3, (7, 2, 70)), (16384, 96, 0, 16, (40, 100)), (24576, 48, 16, 5, (11, 64, 66)),
                                                 (10240, 64, 2, 4, (9, 130))])
-def test_counts_taken_inside_the_fused_launches(gpu, oracle_mod, monkeypatch, X, Y, H, every, calls):
+@pytest.mark.parametrize("energy", [False, True], ids=["counts", "counts+energy"])
+def test_counts_taken_inside_the_fused_launches(gpu, oracle_mod, monkeypatch, X, Y, H, every, calls, energy):
     """ising_sweep_counted: the reference's print points (countSpins whenever the iteration is a multiple of -p, optimized/main.cu:1806-1810)
     taken INSIDE the fused launches by the units that store the words.  Every count equals the oracle's at that iteration -- calls that end
     between two print points, launches of 64 sweeps and more than one launch per call, a partly dead wave column --, and the state
-    afterwards is the oracle's: counting changes nothing."""
+    afterwards is the oracle's: counting changes nothing.  `energy` (round 5): the bond sum of ising_bond_equal at the same points, taken by the white
+    level of every measured sweep -- north_star's energy series next to the magnetisation's."""
     monkeypatch.setenv("ISING_FUSED", "1")
     orc = oracle_mod.OracleLattice(X, Y, seed=77, temp=oracle_mod.CRIT_TEMP).init()
     with ig.IsingSlab(X, Y, seed=77, temp=ig.CRIT_TEMP_F32, layout=ig.LAYOUT_BALLOT, strip_rows=H) as s:
         assert s.fused
         s.init()
         for n in calls:
-            got = s.sweep_counted(n, every)
+            got = s.sweep_counted(n, every, energy)
             want = []
             for _ in range(n):
                 orc.sweep(1)
                 if orc.it % every == 0:
-                    want.append(orc.count())
+                    want.append(orc.count() + ((orc.bond_equal(),) if energy else ()))
             assert got == want, (n, s.it)
         assert _same(s, orc) and s.count() == orc.count()
 
@@ -405,11 +407,12 @@ def test_counted_sweeps_where_the_counts_cannot_ride_in_the_launch(gpu, oracle_m
         if "J_prob" in kw:
             s.init_couplings()
             orc.init_couplings(kw["J_prob"])
-        got = s.sweep_counted(10, 4) + s.sweep_counted(7, 4)
+        energy = "J_prob" not in kw  # (ising_bond_equal knows no couplings)
+        got = s.sweep_counted(10, 4, energy) + s.sweep_counted(7, 4, energy)
         want = []
         for _ in range(17):
             orc.sweep(1)
             if orc.it % 4 == 0:
-                want.append(orc.count())
+                want.append(orc.count() + ((orc.bond_equal(),) if energy else ()))
         assert got == want and len(want) == 4
         assert _same(s, orc)

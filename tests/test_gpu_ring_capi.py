@@ -321,13 +321,13 @@ def test_ring_sweep_counted_one_process(gpu, oracle_mod, monkeypatch, layout, ns
     ring = ig.SlabSet([ig.IsingSlab(X, Y, seed=seed, temp=ig.CRIT_TEMP_F32, nslabs=nslabs, slab=k, layout=layout, ring_halo=(nslabs == 1)) for k in range(nslabs)])
     try:
         ring.init()
-        for n, every in ((40, 16), (70, 16), (9, 1), (23, 100)):
-            got = ring.sweep_counted(n, every)
+        for n, every, energy in ((40, 16, False), (70, 16, True), (9, 1, True), (23, 100, False)):
+            got = ring.sweep_counted(n, every, energy)  # (energy: the bond sum of the whole lattice, every slab's white levels over its own rows)
             want = []
             for _ in range(n):
                 orc.sweep(1)
                 if orc.it % every == 0:
-                    want.append(orc.count())
+                    want.append(orc.count() + ((orc.bond_equal(),) if energy else ()))
             assert got == want, (layout, nslabs, n, every)
         assert np.array_equal(np.concatenate([s.read(ig.BLACK) for s in ring.slabs]), orc.black)
         assert np.array_equal(np.concatenate([s.read(ig.WHITE) for s in ring.slabs]), orc.white)

@@ -155,3 +155,21 @@ def test_tiles_randomised(gpu, oracle_mod, monkeypatch):
                     s.sweep(int(n))
                     orc.sweep(int(n))
                 _compare(s, orc, f"case {case}: {Y} x {X}, tiles {TR} x {TWI}, {S} sweeps a launch, {NT} threads, after {orc.it} sweeps")
+
+
+@pytest.mark.parametrize("temp", [0.0, -1.0])
+def test_tiles_fast_kernel_without_thresholds_is_an_error(gpu, monkeypatch, temp):
+    """ISING_KERNEL_FAST at a temperature whose table has no integer thresholds (T <= 0): the header promises an error, and the tile
+    launches -- which know integer thresholds only -- must not run on truncated ones (round-4 ADVICE)."""
+    _env(monkeypatch)
+    with ig.IsingSlab(2048, 2048, seed=7, temp=temp, layout=ig.LAYOUT_DENSE, kernel=ig.KERNEL_FAST) as s:
+        s.init()
+        before = s.read(ig.BLACK).copy()
+        with pytest.raises(ig.IsingError):
+            s.sweep(4)
+        with pytest.raises(ig.IsingError):
+            s.sweep_counted(4, 2)
+        with pytest.raises(ig.IsingError):
+            s.sweep_counted(4, 2, True)
+        s.synchronize()
+        assert np.array_equal(s.read(ig.BLACK), before), "a refused sweep changed the lattice"
