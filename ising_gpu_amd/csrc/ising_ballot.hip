@@ -566,7 +566,15 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		// ... and, where the call asks for the energy too (UpdateParams.cnt_bonds), the bonds of those sites to equal neighbours: taken at the WHITE level of a
 		// measured sweep, when both colours are the sweep's final ones -- every bond has exactly one white end, so the white sites' sum is ising_bond_equal's A
 		[[maybe_unused]] uint32_t cnt_eq = 0;
-		[[maybe_unused]] const bool eq_unit = COUNT && p.cnt_bonds != 0 && (level & 1) != 0 && ((p.cnt_mask >> (level >> 1)) & 1ull) != 0;
+		// which measurement of the launch this unit's sweep is (-1: none): sweeps cnt_first, cnt_first + cnt_every, ...
+		[[maybe_unused]] int meas_idx = -1;
+		if (COUNT && p.cnt_every > 0 && (level >> 1) >= p.cnt_first) {
+			const uint32_t d = (uint32_t)((level >> 1) - p.cnt_first), e = (uint32_t)p.cnt_every;
+			uint32_t qq = e == 1u ? d : __umulhi(d, p.cnt_magic);
+			if (qq * e > d) --qq; // (the reciprocal rounds up: at most one too many)
+			if (qq * e == d) meas_idx = uni((int)qq);
+		}
+		[[maybe_unused]] const bool eq_unit = COUNT && p.cnt_bonds != 0 && (level & 1) != 0 && meas_idx >= 0;
 		// (Round 4 also requested the next ticket a row early -- an inline-assembly atomic at the top of the last-but-one iteration, picked up
 		// behind that iteration's word-phase wait, its ~2 us under a draw phase: no gain, -1 % at 8192^2 (profiles/ticket_early_probe_r04.txt):
 		// a ticket that is reserved while its workgroup still works delays the unit it names, as in round 2.  And, requested in the last iteration
@@ -801,10 +809,9 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			}
 #endif
 			if (COUNT) { // level 2j and 2j + 1 are the black and the white half of the launch's sweep j: both add to its measurement
-				const int swp = level >> 1;
-				if ((p.cnt_mask >> swp) & 1ull) {
+				if (meas_idx >= 0) {
 					const unsigned long long tot = wave_sum((unsigned long long)cnt_up);
-					const int meas = p.cnt_slot0 + (int)__popcll(p.cnt_mask & ((1ull << swp) - 1ull));
+					const int meas = p.cnt_slot0 + meas_idx;
 					const size_t planes = p.cnt_bonds ? 3 : 2, per_plane = (size_t)p.nwg * (NT / 64);
 					if (lane == 0) p.cnt_acc[((size_t)meas * planes + (size_t)(level & 1)) * per_plane + (size_t)wave] = (uint32_t)tot;
 					if (eq_unit) {
@@ -830,6 +837,360 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 #endif
 	}
 #endif
+}
+
+// ---- Split launches (round 5): the fused launch's work in two kinds of units.  What a level of few tickets costs a fused launch is not the wait for late
+// parents (units draw before they wait) but the height of its strips: a unit's fixed cost -- ticket, decode, counters, the extra loop iteration -- is ~9 % more
+// vector instructions per site at H = 4 than at H = 16 (16384^2: 778 against 714 per row of a wave), and taller strips need as many tickets a level as
+// workgroups run, because a unit cannot start its word phases before its parents have finished theirs.  But 85 % of a unit -- the draws -- needs nothing from
+// the lattice.  So here a DRAW unit (wave column x strip of H rows x level) only draws: 16 Philox blocks a row, the compares' lane masks into a ring of mask
+// slots in memory, no wait, no barrier, one scalar-cache write-back per unit; and a WORD unit, handed out in the same level-major order through a second
+// ticket counter, waits for its masks and its parents and runs the H word phases.  Workgroups alternate: one draw unit, one word unit -- after a lead of
+// `sp_lead` draw units each --, so at any time about a fifth of them hold word tickets: a level needs a quarter of the grid in tickets instead of
+// all of it, strips are 16 rows tall from 2^26 spins up and six workgroups per CU run at every size.
+// The accept masks go from one workgroup to another through the XCD's L2 (scalar stores are written back there, not through), so tickets come in eight
+// classes, one per XCD: a workgroup serves the class of the XCD it RUNS on (HW_REG_XCC_ID, not blockIdx: correctness does not rest on the dispatcher's
+// placement), class x owns the units 8 k + x of every level and a ring of sp_ring slots of its own.  Deadlock: word ticket w is only handed out behind draw
+// ticket w (every workgroup draws first), both go out in order within a class, a draw unit waits for nothing but its slot -- freed by word ticket d - sp_ring,
+// which was handed out long ago because the workgroups of a class hold at most (sp_lead + 1) draw tickets more than word tickets each -- and a word unit
+// for lower tickets only: the lowest unfinished ticket of every class is always held by a running workgroup.  (A class whose XCD runs no workgroup of the
+// launch would never be served: the polls' bound turns that into ISING_E_STATE like any other launch that gives up.)
+template <bool STREAM, bool COUNT>
+__global__ void __launch_bounds__(BAL_THREADS) BAL_SGPR_ATTR ballot_split_k(const UpdateParams p) {
+	const int lane = threadIdx.x & 63;
+	const int tx = threadIdx.x & (GROUP - 1), g = (threadIdx.x >> 4) & 3;
+	const int wi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int nwc = (p.gx + 3) >> 2;
+	const int gxp = nwc << 2;
+	const int wpr = nwc * 64;
+	const int j = lane >> 5, m = (lane >> 2) & 7, q = lane & 3;
+	int backA, fwdA; // lane holding the word with site s-1 / s+1 of the same vectors (ballot_update_k)
+	if (q == 2) backA = word_of(j, m, 0);
+	else if (q == 3) backA = word_of(j, m, 1);
+	else if (q == 0) backA = m ? word_of(j, m - 1, 2) : word_of(j, 7, 3);
+	else backA = m ? word_of(j, m - 1, 3) : word_of(j, 7, 2);
+	if (q == 0) fwdA = word_of(j, m, 2);
+	else if (q == 1) fwdA = word_of(j, m, 3);
+	else if (q == 2) fwdA = m < 7 ? word_of(j, m + 1, 0) : word_of(j, 0, 1);
+	else fwdA = m < 7 ? word_of(j, m + 1, 1) : word_of(j, 0, 0);
+	const ptrdiff_t mir0 = (ptrdiff_t)(p.mir0_bytes / 8), mirL = (ptrdiff_t)(p.mirL_bytes / 8);
+
+	__shared__ uint4 blk_const_all[BAL_THREADS / 64][16];
+	__shared__ unsigned long long ticket_sh[2];
+	uint4 *blk_const = blk_const_all[wi];
+
+	uint32_t xcc;
+	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+	xcc &= 7u;
+	const int T8 = p.nwg >> 3; // tickets per level and class (the host launches this form only where a level's tickets divide by 8)
+	const unsigned long long total = (unsigned long long)p.nlevels * (unsigned long long)T8;
+	unsigned long long *const dtp = p.sp_ctr + 16 * xcc, *const wtp = dtp + 8; // this class's draw / word ticket counters (zero when the launch starts)
+	const int ring_sh = p.sp_ring_sh; // slots per class: 2^ring_sh
+	uint32_t *const flags = p.sp_flags + ((size_t)xcc << (ring_sh + 1)); // per slot {waves that have drawn, waves that have used} -- counts, zero when the launch starts
+	const size_t slot_words = (size_t)4 * (size_t)p.H * 128;               // a slot: 4 waves x H rows x (64 x {c3, c4})
+	uint64_t *const masks = p.sp_masks + (((size_t)xcc << ring_sh) * 4 + (size_t)wi) * (size_t)p.H * 128;
+	const unsigned dround = uni((int)(blockIdx.x / (unsigned)p.cus));
+	const int nstr = (p.row_hi[0] - p.row_lo[0] + p.H - 1) / p.H;
+	const uint32_t seed_lo = p.seed_lo, seed_hi = p.seed_hi;
+	const uint32_t k2y = seed_hi + 2u * PHILOX_W1;
+	const int nwc_sh = (nwc & (nwc - 1)) == 0 ? __builtin_ctz((unsigned)nwc) + 2 : -1; // gxp = 4 nwc as a shift where it is one
+	// A class serves sp_cap workgroups at most -- its ring holds (sp_lead + 1) slots for each of them, which is what keeps draw units from ever waiting for a
+	// word ticket nobody holds --: whoever registers beyond that (a dispatcher that put more of the grid on one XCD than an eighth and a margin) leaves.
+	if (threadIdx.x == 0) ticket_sh[0] = atomicAdd(dtp + 4, 1ull);
+	__syncthreads();
+	if (ticket_sh[0] >= (unsigned long long)p.sp_cap) return;
+	__syncthreads();
+	// (ising_kernel_clock: as in ballot_update_k)
+	auto clock_mark = [&](int which) {
+		if (blockIdx.x >= 8u || wi != 0 || p.clk_out == nullptr) return;
+		const unsigned long long cyc = __builtin_readcyclecounter(), ref = __builtin_amdgcn_s_memrealtime();
+		if (lane == 0) {
+			unsigned long long *o = p.clk_out + 4 * blockIdx.x + 2 * which;
+			o[0] = cyc;
+			o[1] = ref;
+		}
+	};
+	clock_mark(0);
+
+	// a ticket of this class -> its unit of the level: (strip, wave column) of this wave, rows
+	struct Unit { int level, sidx, wc, bx0, r0, nrows; bool absent; uint32_t color, it; };
+	auto decode = [&](int k, int level) -> Unit {
+		Unit u;
+		u.level = level;
+		const int wgi = 8 * k + (int)xcc;
+		const int wave = uni(wgi * (BAL_THREADS / 64) + wi);
+		const int unit0 = wave * 4;
+		u.absent = unit0 >= p.nreal0;
+		const int uu = u.absent ? 0 : unit0;
+		const int pos = nwc_sh >= 0 ? (uu >> nwc_sh) : uni(uu / gxp);
+		u.bx0 = uu - pos * gxp;
+		u.wc = u.bx0 >> 2;
+		u.sidx = uni((pos & 1) ? nstr - 1 - (pos >> 1) : (pos >> 1)); // strips from both ends of the slab inwards, as in the fused launches
+		u.r0 = p.row_lo[0] + u.sidx * p.H;
+		u.nrows = u.absent ? 0 : min(p.H, p.row_hi[0] - u.r0);
+		u.color = uni((p.color + (uint32_t)level) & 1u);
+		u.it = uni(p.it + ((p.color + (uint32_t)level) >> 1));
+		return u;
+	};
+	// counters that never come (see ballot_update_k): the unit that has polled `abort_polls` times raises the flag, every waiter looks at it every 64th poll
+	auto give_up = [&](uint32_t npoll) -> bool {
+		uint64_t fp;
+		uint32_t bound;
+		asm volatile("s_load_dwordx2 %0, %2, %3\n\ts_load_dword %1, %2, %4\n\ts_waitcnt lgkmcnt(0)" : "=&s"(fp), "=&s"(bound)
+		             : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(offsetof(UpdateParams, abort_flag)), "n"(offsetof(UpdateParams, abort_polls)) : "memory");
+		uint32_t *flag = reinterpret_cast<uint32_t *>(fp);
+		if (flag == nullptr) return false;
+		if (npoll >= bound && lane == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		return npoll >= bound || uni(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0u;
+	};
+
+#if defined(ISING_FUSED_TRACE) // measurement build: wave 0 of every workgroup clocks its roles (ballot_trace_dump)
+	__shared__ unsigned long long trs[16];
+	if (threadIdx.x < 16) trs[threadIdx.x] = 0;
+	__syncthreads();
+	long long ts_last = clock64();
+	const long long ts_start = ts_last;
+#define STRC(i) do { if (wi == 0) { const long long t_ = clock64(); if (lane == 0) trs[i] += (unsigned long long)(t_ - ts_last); ts_last = t_; } } while (0)
+#define STRN(i, n) do { if (wi == 0 && lane == 0) trs[i] += (unsigned long long)(n); } while (0)
+#else
+#define STRC(i) do {} while (0)
+#define STRN(i, n) do {} while (0)
+#endif
+	int lvl_d = 0, lvl_w = 0;
+	unsigned long long base_d = 0, base_w = 0;
+	int lead = uni(p.sp_lead);
+	if (ISING_FUSED_STAGGER > 0)
+		for (unsigned i = 0; i < dround % 6u; ++i) __builtin_amdgcn_s_sleep(ISING_FUSED_STAGGER);
+	for (;;) {
+		// ================================================================ a draw unit
+		if (threadIdx.x == 0) ticket_sh[0] = atomicAdd(dtp, 1ull);
+		__syncthreads();
+		const unsigned long long tkd_v = ticket_sh[0];
+		const unsigned long long tkd = ((unsigned long long)uni((uint32_t)(tkd_v >> 32)) << 32) | uni((uint32_t)tkd_v);
+		STRC(0); // draw ticket
+		if (tkd < total) {
+			STRN(8, 1);
+			while (tkd >= base_d + (unsigned)T8) { base_d += (unsigned)T8; ++lvl_d; }
+			const Unit u = decode((int)(tkd - base_d), lvl_d);
+			const uint32_t slot = (uint32_t)tkd & ((1u << ring_sh) - 1u), use = (uint32_t)(tkd >> ring_sh);
+			uint32_t *const fl = flags + 2 * slot;
+			const uint32_t cx_base = 16u * (2u * u.it + u.color);
+			const uint32_t seed_lo_cy = seed_lo ^ (uint32_t)((2ull * u.it + u.color) >> 28); // see dense_update_k
+			if (lane < 16) {
+				const PhiloxBlockConst kc = philox_block_const(cx_base + (uint32_t)lane, seed_lo, seed_hi);
+				blk_const[lane] = make_uint4(kc.s0, kc.s1, kc.s2, 0u);
+			}
+			if (use > 0) { // the slot's previous masks must have been used: four waves each time it served
+				const uint32_t need = 4u * use;
+				uint32_t seen = need, npoll = 0;
+				for (;;) {
+					if (lane == 0) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(seen) : "v"(fl + 1) : "memory");
+					if (__all((int32_t)(seen - need) >= 0)) break;
+					if ((++npoll & 63u) == 0u && give_up(npoll)) break;
+					STRN(10, 1);
+					__builtin_amdgcn_s_sleep(ISING_POLL_SLEEP);
+				}
+			}
+			STRC(1); // draw unit: decode, slot
+			__builtin_amdgcn_wave_barrier();
+			__threadfence_block();
+			const int bx = u.bx0 + g;
+			uint32_t grow_d = p.row_base + (uint32_t)u.r0;
+			uint32_t tid_d = ((grow_d >> 4) * (uint32_t)p.gx + (uint32_t)bx) * 256u + (grow_d & 15u) * 16u + (uint32_t)tx;
+			const uint64_t *cur = masks + (size_t)slot * slot_words;
+			const uint32_t thr3 = p.n3, thr4 = p.n4;
+			for (int r = 0; r < u.nrows; ++r) {
+				switch ((r + (int)dround) & 3) { // rotating priorities: the waves of a SIMD take turns at the front (ballot_update_k)
+				case 0: __builtin_amdgcn_s_setprio(0); break;
+				case 1: __builtin_amdgcn_s_setprio(1); break;
+				case 2: __builtin_amdgcn_s_setprio(2); break;
+				default: __builtin_amdgcn_s_setprio(3); break;
+				}
+				const PhiloxRow pr = philox_row_setup(tid_d, seed_lo_cy, k2y);
+				tid_d += (grow_d & 15u) == 15u ? (uint32_t)p.gx * 256u - 240u : 16u;
+				grow_d += 1u;
+				uint4 kc_next = blk_const[0];
+				static_for<16>([&](auto B) {
+					uint32_t o0, o1, o2, o3;
+					const uint4 kc = kc_next;
+					if (B.value < 15) kc_next = blk_const[B.value + 1];
+					philox_block_pre(pr, PhiloxBlockConst{kc.x, kc.y, kc.z}, seed_lo, seed_hi, o0, o1, o2, o3);
+					if (B.value < 15) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kc_next.x), "+v"(kc_next.y), "+v"(kc_next.z) :: "memory");
+					const uint64_t *dstp = cur + 8 * B.value;
+					const uint32_t t3 = thr3, t4 = thr4;
+					asm volatile("v_cmp_gt_u32_e64 " SG(0, 1) ", %0, %2\n\tv_cmp_gt_u32_e64 " SG(2, 3) ", %1, %2\n\t"
+					             "v_cmp_gt_u32_e64 " SG(4, 5) ", %0, %3\n\tv_cmp_gt_u32_e64 " SG(6, 7) ", %1, %3\n\t"
+					             "v_cmp_gt_u32_e64 " SG(8, 9) ", %0, %4\n\tv_cmp_gt_u32_e64 " SG(10, 11) ", %1, %4\n\t"
+					             "v_cmp_gt_u32_e64 " SG(12, 13) ", %0, %5\n\tv_cmp_gt_u32_e64 " SG(14, 15) ", %1, %5\n\t"
+					             "s_store_dwordx4 " SG(0, 3) ", %6, 0x0\n\ts_store_dwordx4 " SG(4, 7) ", %6, 0x10\n\t"
+					             "s_store_dwordx4 " SG(8, 11) ", %6, 0x20\n\ts_store_dwordx4 " SG(12, 15) ", %6, 0x30"
+					             :: "s"(t3), "s"(t4), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(dstp)
+					             : "memory", BAL_CLOB16);
+				});
+				cur += 128;
+			}
+			// the unit's masks into the XCD's L2, then the slot's count: the word unit of this ticket runs on this XCD
+			STRC(2); // draw rows
+			asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+			if (lane == 0) __hip_atomic_fetch_add(fl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			STRC(3); // write-back
+		}
+		if (lead > 0) { // the launch's first units: draws only, so that the word units find their masks long done
+			--lead;
+			__syncthreads(); // (ticket_sh[0] is rewritten at the top)
+			continue;
+		}
+		// ================================================================ a word unit
+		if (threadIdx.x == 0) ticket_sh[1] = atomicAdd(wtp, 1ull);
+		__syncthreads();
+		const unsigned long long tkw_v = ticket_sh[1];
+		const unsigned long long tkw = ((unsigned long long)uni((uint32_t)(tkw_v >> 32)) << 32) | uni((uint32_t)tkw_v);
+		STRC(4); // word ticket
+		if (tkw >= total) break;
+		STRN(9, 1);
+		while (tkw >= base_w + (unsigned)T8) { base_w += (unsigned)T8; ++lvl_w; }
+		const Unit u = decode((int)(tkw - base_w), lvl_w);
+		const int level = u.level, sidx = u.sidx, wc = u.wc, bx0 = u.bx0, r0 = u.r0, nrows = u.nrows;
+		const uint32_t color = u.color;
+		const uint32_t slot = (uint32_t)tkw & ((1u << ring_sh) - 1u), use = (uint32_t)(tkw >> ring_sh);
+		uint32_t *const fl = flags + 2 * slot;
+		__builtin_amdgcn_s_setprio(3); // word units are the dependency chain: short, and first in line
+		{ // wait: lanes 0..2 for strips s-1, s, s+1 at level - 1 (`nwc` wave columns each per level), lane 3 for the four waves that drew this ticket's masks
+			int sd = sidx + (lane == 0 ? -1 : (lane == 1 ? 0 : 1));
+			sd = sd < 0 ? sd + nstr : (sd >= nstr ? sd - nstr : sd);
+			const bool parents = level > 0 && !u.absent && lane < 3;
+			const uint32_t *dp = parents ? p.done + sd : fl;
+			const uint32_t need = parents ? p.done_base + (uint32_t)level * (uint32_t)nwc : 4u * (use + 1u);
+			uint32_t seen = need, npoll = 0;
+			for (;;) {
+				if (lane < 4) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(seen) : "v"(dp) : "memory");
+				if (__all((int32_t)(seen - need) >= 0)) break;
+				if ((++npoll & 63u) == 0u && give_up(npoll)) break;
+				STRN(11, 1);
+				STRN(12, npoll == 0);
+#if defined(ISING_FUSED_TRACE)
+				{ const bool late_masks = __builtin_amdgcn_readlane((int)(seen - need), 3) < 0; STRN(13, late_masks); }
+#endif
+				__builtin_amdgcn_s_sleep(ISING_POLL_SLEEP);
+			}
+		}
+		STRC(5); // word unit: decode, wait
+		[[maybe_unused]] uint32_t cnt_up = 0, cnt_eq = 0;
+		[[maybe_unused]] int meas_idx = -1;
+		if (COUNT && p.cnt_every > 0 && (level >> 1) >= p.cnt_first) {
+			const uint32_t d = (uint32_t)((level >> 1) - p.cnt_first), e = (uint32_t)p.cnt_every;
+			uint32_t qq = e == 1u ? d : __umulhi(d, p.cnt_magic);
+			if (qq * e > d) --qq;
+			if (qq * e == d) meas_idx = uni((int)qq);
+		}
+		[[maybe_unused]] const bool eq_unit = COUNT && p.cnt_bonds != 0 && (level & 1) != 0 && meas_idx >= 0;
+		if (nrows > 0) {
+			uint64_t *const lat0 = p.lat[0], *const lat1 = p.lat[1];
+			const uint64_t *rs = (color ? lat0 : lat1) + ((ptrdiff_t)r0 * wpr + wc * 64);
+			uint64_t *rd = (color ? lat1 : lat0) + ((ptrdiff_t)r0 * wpr + wc * 64);
+			uint64_t first = 0, last = 0; // bit 16g (16g + 15): group g opens (closes) the row
+#pragma unroll
+			for (int gg = 0; gg < 4; ++gg) {
+				if (bx0 + gg == 0) first |= 1ull << (16 * gg);
+				if (bx0 + gg == p.gx - 1) last |= 1ull << (16 * gg + 15);
+			}
+			const uint64_t u_b1 = LANE0 & ~1ull & ~first, u_f1 = LANE15 & ~(1ull << 63) & ~last;
+			const int alive = min(4, p.gx - bx0);
+			const uint64_t live = alive >= 4 ? ~0ull : ((1ull << (16 * alive)) - 1ull);
+			const int end_here = 16 * alive - 1;
+			const int src_b = wc ? wc - 1 : nwc - 1;
+			const int end_src = 16 * min(4, p.gx - 4 * src_b) - 1;
+			const int u_cb = (src_b - wc) * 64 + word_of(1, 7, 3);
+			const int u_cf = ((wc == nwc - 1 ? 0 : wc + 1) - wc) * 64 + word_of(0, 0, 0);
+			const uint64_t *msk = masks + (size_t)slot * slot_words;
+			uint32_t grow = p.row_base + (uint32_t)r0;
+			uint64_t up, ct;
+			ld64_coh_issue<STREAM>(up, rs - (ptrdiff_t)wpr, lane * 8);
+			ld64_coh_issue<STREAM>(ct, rs, lane * 8);
+			// (waited for HERE: values loaded by inline assembly must not be loop-carried before their wait -- the compiler may copy them at the loop's head)
+			asm volatile("s_waitcnt vmcnt(0)" : "+v"(up), "+v"(ct) :: "memory");
+			for (int r = 0; r < nrows; ++r) {
+				const int lr = r0 + r;
+				const bool back = (color == 0) ? !(grow & 1u) : (grow & 1u); // readBack, optimized/main.cu:542
+				uint64_t vC, dw, me;
+				u32x4 mk;
+				ld64_coh_issue<STREAM>(vC, rs + (back ? u_cb : u_cf), 0);
+				asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=&v"(mk) : "v"(lane * 16), "s"(msk) : "memory");
+				ld64_coh_issue<STREAM>(dw, rs + (ptrdiff_t)wpr, lane * 8);
+				ld64_coh_issue<STREAM>(me, rd, lane * 8);
+				asm volatile("s_waitcnt vmcnt(0)" : "+v"(vC), "+v"(mk), "+v"(dw), "+v"(me) :: "memory");
+				const unsigned long long sA0 = readlane64(ct, back ? word_of(0, 7, 3) : word_of(0, 0, 0));
+				const unsigned long long sA1 = readlane64(ct, back ? word_of(1, 7, 3) : word_of(1, 0, 0));
+				const unsigned long long sC = readlane64(vC, 0);
+				uint64_t w0, w1; // side words of lanes (0,0,0), (1,0,0) [back] / (0,7,3), (1,7,3) [forward]
+				if (back) {
+					w0 = ((sA0 << 1) & ~LANE0) | ((sA1 << 1) & u_b1) | ((sC >> end_src) & 1ull);
+					w1 = ((sA1 << 1) & ~LANE0) | ((sA0 >> 15) & LANE0);
+				} else {
+					w0 = ((sA0 >> 1) & ~LANE15) | ((sA1 << 15) & LANE15);
+					w1 = ((sA1 >> 1) & ~LANE15) | ((sA0 >> 1) & u_f1) | ((sC & 1ull) << end_here);
+				}
+				const uint64_t A = bperm64(back ? backA : fwdA, ct);
+				uint32_t sdl = (uint32_t)A, sdh = (uint32_t)(A >> 32);
+				const uint32_t w0l = __builtin_amdgcn_readfirstlane((uint32_t)w0), w0h = __builtin_amdgcn_readfirstlane((uint32_t)(w0 >> 32));
+				const uint32_t w1l = __builtin_amdgcn_readfirstlane((uint32_t)w1), w1h = __builtin_amdgcn_readfirstlane((uint32_t)(w1 >> 32));
+				if (back) {
+					asm("v_writelane_b32 %0, %2, 0\n\tv_writelane_b32 %1, %3, 0" : "+v"(sdl), "+v"(sdh) : "s"(w0l), "s"(w0h));
+					asm("v_writelane_b32 %0, %2, 32\n\tv_writelane_b32 %1, %3, 32" : "+v"(sdl), "+v"(sdh) : "s"(w1l), "s"(w1h));
+				} else {
+					asm("v_writelane_b32 %0, %2, 31\n\tv_writelane_b32 %1, %3, 31" : "+v"(sdl), "+v"(sdh) : "s"(w0l), "s"(w0h));
+					asm("v_writelane_b32 %0, %2, 63\n\tv_writelane_b32 %1, %3, 63" : "+v"(sdl), "+v"(sdh) : "s"(w1l), "s"(w1h));
+				}
+				const uint64_t sd = ((uint64_t)sdh << 32) | sdl;
+				const uint64_t c3 = ((uint64_t)mk.y << 32) | mk.x, c4 = ((uint64_t)mk.w << 32) | mk.z;
+				const uint64_t nw = me ^ (flips64(me, up, ct, dw, sd, c3, c4) & live);
+				if (COUNT && (unsigned)lr < (unsigned)p.Y) {
+					cnt_up += (uint32_t)__popcll(nw);
+					if (eq_unit) cnt_eq += (uint32_t)(__popcll(~(nw ^ up) & live) + __popcll(~(nw ^ ct) & live) + __popcll(~(nw ^ dw) & live) + __popcll(~(nw ^ sd) & live));
+				}
+				st64_coh_issue<STREAM>(rd, lane * 8, nw);
+				if (p.wrap) { // the halo rows that mirror this colour's edge rows
+					if (lr == 0) st64_coh_issue<STREAM>(rd + mir0, lane * 8, nw);
+					if (lr == p.Y - 1) st64_coh_issue<STREAM>(rd + mirL, lane * 8, nw);
+				}
+				rs += wpr;
+				rd += wpr;
+				msk += 128;
+				up = ct;
+				ct = dw;
+				grow += 1u;
+			}
+		}
+		STRC(6); // word rows
+		// publish: the stores were written through (sc1); once they have left the wave the strip's counter may move, and the slot is free again
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		STRC(7); // drain
+		__builtin_amdgcn_s_setprio(0);
+		if (COUNT && meas_idx >= 0 && !u.absent) {
+			const int wave = uni((8 * (int)(tkw - base_w) + (int)xcc) * (BAL_THREADS / 64) + wi);
+			const unsigned long long tot = wave_sum((unsigned long long)cnt_up);
+			const int meas = p.cnt_slot0 + meas_idx;
+			const size_t planes = p.cnt_bonds ? 3 : 2, per_plane = (size_t)p.nwg * (BAL_THREADS / 64);
+			if (lane == 0) p.cnt_acc[((size_t)meas * planes + (size_t)(level & 1)) * per_plane + (size_t)wave] = (uint32_t)tot;
+			if (eq_unit) {
+				const unsigned long long eq = wave_sum((unsigned long long)cnt_eq);
+				if (lane == 0) p.cnt_acc[((size_t)meas * planes + 2) * per_plane + (size_t)wave] = (uint32_t)eq;
+			}
+		}
+		if (lane == 0) {
+			if (!u.absent) __hip_atomic_fetch_add(p.done + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_fetch_add(fl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+	clock_mark(1);
+#if defined(ISING_FUSED_TRACE)
+	__syncthreads();
+	if (threadIdx.x == 0) trs[14] = (unsigned long long)(clock64() - ts_start);
+	__syncthreads();
+	if (threadIdx.x < 16) atomicAdd(&g_trace[threadIdx.x], trs[threadIdx.x]);
+#endif
+#undef STRC
+#undef STRN
 }
 
 // ---- init (latticeInit_k, optimized/main.cu:92-151): one wave per (row, wave column).  A spin starts up where
@@ -1135,7 +1496,7 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 	const bool streamed = fused && p.nt_stream;
 	const bool batch = fused && p.nrep > 0;
 	const bool count = p.cnt_acc != nullptr;
-	if (count && (!fused || batch || usej || subl || p.color != 0 || p.nlevels > 128)) return hipErrorInvalidValue; // (ising_update.cpp asks only where it applies)
+	if (count && (!fused || batch || usej || subl || p.color != 0)) return hipErrorInvalidValue; // (ising_update.cpp asks only where it applies)
 	if (batch && (usej || subl || NT != BAL_THREADS)) return hipErrorInvalidValue;
 	if (fused && subl && (usej || NT != BAL_THREADS || p.slY % p.H != 0)) return hipErrorInvalidValue; // (ising_capi.cpp keeps those on one launch per colour)
 	if (batch) { // a level = the units of all lattices
@@ -1204,7 +1565,50 @@ static hipError_t launch_ballot_update_nt(UpdateParams &p, hipStream_t stream, i
 }
 
 #if defined(ISING_FUSED_TRACE)
+static void ballot_trace_is_split();
+#endif
+// Split launch (ballot_split_k): p as for a fused launch of the whole slab; the caller has zeroed sp_ctr and sp_flags on the stream.
+hipError_t launch_ballot_split(UpdateParams &p, hipStream_t stream, int *grid_out, hipEvent_t stop, hipEvent_t start) {
+	if (grid_out) *grid_out = 0;
+	p.nwg = (p.nunits + BAL_THREADS / GROUP - 1) / (BAL_THREADS / GROUP);
+	if (p.nlevels < 2 || p.nwg < 8 || (p.nwg & 7) || p.slY != 0 || p.jham[0] != nullptr || p.nrep > 0 || p.color != 0 || !p.sp_masks || !p.sp_ctr || !p.sp_flags) return hipErrorInvalidValue;
+	if (p.cus <= 0) p.cus = 256;
+	const bool count = p.cnt_acc != nullptr, streamed = p.nt_stream != 0;
+	const long long grid = std::max<long long>(8, std::min<long long>((long long)p.sp_cap * 8, (long long)(p.wg_per_cu > 0 ? p.wg_per_cu : 6) * p.cus));
+	const dim3 g((unsigned)grid), block(BAL_THREADS);
+	if (count) {
+		if (streamed) hipExtLaunchKernelGGL((ballot_split_k<true, true>), g, block, 0, stream, start, stop, 0, p);
+		else hipExtLaunchKernelGGL((ballot_split_k<false, true>), g, block, 0, stream, start, stop, 0, p);
+	} else {
+		if (streamed) hipExtLaunchKernelGGL((ballot_split_k<true, false>), g, block, 0, stream, start, stop, 0, p);
+		else hipExtLaunchKernelGGL((ballot_split_k<false, false>), g, block, 0, stream, start, stop, 0, p);
+	}
+	if (grid_out) *grid_out = (int)grid;
+#if defined(ISING_FUSED_TRACE)
+	ballot_trace_is_split();
+#endif
+	return hipGetLastError();
+}
+
+#if defined(ISING_FUSED_TRACE)
+static bool g_trace_split = false;
+static void ballot_trace_is_split() { g_trace_split = true; }
 void ballot_trace_dump() {
+	if (g_trace_split) {
+		static const char *sname[16] = {"draw ticket", "draw: decode + slot", "draw rows", "draw: write-back", "word ticket", "word: decode + wait", "word rows", "word: drain",
+		                                "", "", "", "", "", "", "TOTAL", ""};
+		unsigned long long h[16];
+		if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace), sizeof(h)) != hipSuccess) return;
+		fprintf(stderr, "split trace (wave 0 of every workgroup): %llu draw units, %llu word units; polls that slept: %llu for a slot, %llu for parents / masks in %llu units (%llu of them with the masks late)\n",
+		        h[8], h[9], h[10], h[11], h[12], h[13]);
+		for (int i = 0; i < 15; ++i) {
+			if (!sname[i][0]) continue;
+			fprintf(stderr, "  %-22s %6.2f %% of workgroup time, %8.1f cycles per unit\n", sname[i], 100.0 * (double)h[i] / (double)h[14], (double)h[i] / (double)(h[9] ? h[9] : 1));
+		}
+		for (auto &v : h) v = 0;
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), h, sizeof(h));
+		return;
+	}
 	static const char *name[16] = {"ticket pick-up", "decode", "completion counters", "row prologue", "draw", "next ticket", "barrier", "word: issue",
 	                               "", "", "word: wait loads", "word: flips+store", "", "drain", "TOTAL", ""};
 	unsigned long long h[16];

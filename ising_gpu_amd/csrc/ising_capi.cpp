@@ -45,6 +45,8 @@ int read_policy(ising_policy *pol) {
 	if (num("ISING_FUSED_WGS", &v)) pol->fused_wgs = v > 0 ? v : 0;
 	if (num("ISING_FUSED_MAX_SWEEPS", &v)) pol->fused_max_sweeps = v > 0 ? v : 0;
 	if (num("ISING_FUSED_WAIT_LATE", &v)) pol->fused_wait_late = v < 0 ? 0 : (v > 2 ? 2 : v);
+	if (num("ISING_SPLIT", &v)) pol->split = v != 0;
+	if (num("ISING_SPLIT_LEAD", &v)) pol->split_lead = v < 0 ? 0 : (v > 4 ? 4 : v);
 	if (num("ISING_RING_GHOST", &v)) pol->ring_ghost = v;
 	if (num("ISING_RING_COUNTED", &v)) pol->ring_counted = v < 0 ? 0 : (v > 2 ? 2 : v);
 	if (num("ISING_TILES", &v)) pol->tiles = v != 0;
@@ -600,6 +602,22 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		if (pol.fused_tickets2 >= 0) c->fused_tickets2 = pol.fused_tickets2;
 	}
 
+	// Split launches (round 5; ising_ballot.hip: ballot_split_k) carry the sweeps of a lone slab whose levels have too few tickets for tall strips in the fused form:
+	// ISING_SPLIT=1 asks for them wherever they apply (a lone slab that wraps in place, no sub-lattices, no couplings, a level's tickets a multiple of 8).
+	if (fused_shape && !deep_ring && c->wrap && !cfg->XSL && !cfg->use_J && pol.split == 1) {
+		const long long T = fused_tickets(c->nwc(), cfg->Y, c->H);
+		const int wgs = pol.fused_wgs > 0 ? std::max(8, pol.fused_wgs) : 6 * c->cus;
+		if (T >= 8 && (T % 8) == 0 && ((long long)4 * c->nwc() * c->nstrips) % 16 == 0) {
+			c->split = true;
+			c->split_lead = pol.split_lead >= 0 ? pol.split_lead : 1;
+			c->split_cap = (wgs / 8) * 5 / 4 + 1; // an eighth of the grid and a margin: what a class serves (the rest of an uneven placement leaves)
+			int sh = 3;
+			while ((1 << sh) < (c->split_lead + 1) * c->split_cap) sh++;
+			c->split_ring_sh = sh;
+			c->fused_wg_per_cu = std::max(1, wgs / c->cus);
+		}
+	}
+
 	hipError_t e = hipSetDevice(cfg->device);
 	if (e == hipSuccess && cfg->lattice_mem) {
 		if (int rc = check_caller_buffer(cfg->lattice_mem, cfg->lattice_mem_bytes, c->alloc_words() * sizeof(uint64_t), cfg->device, "lattice_mem")) { delete c; return rc; }
@@ -646,6 +664,12 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		if (e == hipSuccess) e = hipMalloc((void **)&c->d_slotctl, ctl_bytes);
 		if (e == hipSuccess) e = hipMemset(c->d_slotctl, 0, ctl_bytes);
 		c->slotctl_bytes = ctl_bytes;
+		if (e == hipSuccess && c->split) {
+			const size_t mask_bytes = ((size_t)8 << c->split_ring_sh) * 4 * (size_t)c->H * 1024;
+			c->split_ctl_bytes = 8 * 16 * sizeof(unsigned long long) + ((size_t)8 << c->split_ring_sh) * 2 * sizeof(uint32_t);
+			e = hipMalloc((void **)&c->d_split_masks, mask_bytes);
+			if (e == hipSuccess) e = hipMalloc((void **)&c->d_split_ctl, c->split_ctl_bytes);
+		}
 		// the word a fused launch that gives up raises (pinned: the host reads it without a copy, the kernel only when it waits)
 		if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_abort, 64, hipHostMallocMapped);
 		if (e == hipSuccess) memset(c->h_abort, 0, 64);
@@ -693,6 +717,8 @@ int ising_destroy(ising_ctx *c) {
 	if (c->d_mslots) (void)hipFree(c->d_mslots);
 	if (c->d_cnt) (void)hipFree(c->d_cnt);
 	if (c->d_clk) (void)hipFree(c->d_clk);
+	if (c->d_split_masks) (void)hipFree(c->d_split_masks);
+	if (c->d_split_ctl) (void)hipFree(c->d_split_ctl);
 	delete c;
 	return ISING_OK;
 }

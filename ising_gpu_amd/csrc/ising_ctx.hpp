@@ -24,6 +24,8 @@ struct ising_policy {
 	int fused_max_sweeps = 0; // ISING_FUSED_MAX_SWEEPS=n: sweeps one fused launch of a single slab carries at most (0: ~50 ms worth, 32 .. 4096)
 	int tiles = -1;          // ISING_TILES=0/1: small lattices on the dense layout sweep in tile launches of several sweeps (-1: by lattice size)
 	int tile_rows = 0, tile_words = 0, tile_sweeps = 0, tile_threads = 0, tile_xcd = -1; // ISING_TILE_ROWS / _WORDS / _SWEEPS / _THREADS / _XCD (0 / -1: by lattice size)
+	int split = -1;          // ISING_SPLIT=0/1: fused launches of a lone slab in the split form (draw units / word units, ising_ballot.hip: ballot_split_k; -1: by tickets per level)
+	int split_lead = -1;     // ISING_SPLIT_LEAD=n: draw units a workgroup does before its first word unit (-1: 1)
 	int ring_counted = -1;   // ISING_RING_COUNTED=0/1/2: print points of rings never / where possible (default) / always (an error where not) inside the deep launches
 	int ring_ghost = -1;     // ISING_RING_GHOST=n: ghost rows of ballot ring slabs (-1: 64)
 	bool no_ballot = false;  // ISING_NO_BALLOT: layout AUTO never picks the ballot layout
@@ -66,6 +68,11 @@ struct ising_ctx {
 	int fused_nt = 0;              // ... whose lattice words carry the non-temporal hint (lattice larger than the 256 MB memory-side cache)
 	unsigned long long ticket_base2[4] = {0, 0, 0, 0}; // fused launches: where the launches so far left the ticket counter(s)
 	int fused_tickets2 = 0;                      // ... two counters (small lattices: one cannot hand tickets out fast enough)
+	bool split = false;            // ... in the split form (ballot_split_k): draw units and word units with tickets of their own, masks through a ring per XCD
+	int split_ring_sh = 0, split_lead = 1, split_cap = 0; // ring slots per class (log2), lead, workgroups a class serves
+	uint64_t *d_split_masks = nullptr;            // 8 x 2^split_ring_sh slots x 4 waves x H rows x 1 KiB
+	unsigned long long *d_split_ctl = nullptr;    // 8 x 16 ticket words, then 8 x 2^split_ring_sh x 2 slot counts (32-bit); zeroed in front of every launch
+	size_t split_ctl_bytes = 0;
 	bool fused_wait_late = false;  // ... whose units draw their first row before they wait for their parents (UpdateParams.wait_late)
 	int tail_rows = 0, tail_h = 0; // plain full-slab launches: the last tail_rows rows go in strips of tail_h rows
 	uint64_t *d_pack = nullptr;    // staging for device-side conversion to / from the packed boundary format
@@ -129,7 +136,7 @@ struct ising_ctx {
 	uint32_t *d_cnt = nullptr;     // per measurement 2 x (waves of a level) slots, then (64-bit) one sum per measurement
 	size_t cnt_cap = 0;            // bytes d_cnt holds
 	int ring_cnt_every = 0, ring_cnt_inflight = 0; // ring slab: the deep launches of the call under way count the sweeps whose iteration is a multiple of this (0: none); measurements so far
-	unsigned long long cnt_mask_next = 0;
+	int cnt_first_next = 0, cnt_every_next = 0; // (cnt_every_next = 0: the next launch measures nothing)
 	int cnt_slot0_next = 0;
 	bool cnt_bonds_next = false;   // ... and the launch's white levels leave the equal bonds of their rows too (a third plane of slots per measurement)
 	bool ring_cnt_bonds = false;   // ring slab: ... the call under way asked for the energy

@@ -75,12 +75,14 @@ struct UpdateParams {
 	int32_t cus;              // compute units of the device: workgroup b of a persistent grid is in dispatch round b / cus (host: 0 = ask)
 	int32_t grid_cap;         // fused: explicit size of the persistent grid (tests, A/B; 0: by wg_per_cu; host side only)
 	int32_t wait_late;        // fused: units draw their first row (2: their first two rows) before they wait for their parents
-	// In-launch counts (fused launches of a lone lattice that start with the black colour, at most 64 sweeps): bit j of cnt_mask = the
-	// up spins are counted after the launch's sweep j; the measurements of a launch are numbered cnt_slot0, cnt_slot0 + 1, ... in sweep
-	// order; the wave that works on unit wave w of a level leaves its sum in cnt_acc[(2 m + colour) * (4 nwg) + w] (zero before the
-	// launch: waves without rows store nothing); launch_count_fold adds a measurement's slots up.  NULL: off.
+	// In-launch counts (fused launches of a lone lattice, or of a ring slab over its own rows, that start with the black colour): the up spins are counted
+	// after the launch's sweeps cnt_first, cnt_first + cnt_every, ... (cnt_every = 0: none; cnt_magic = ceil(2^32 / cnt_every), unused for 1); the
+	// measurements of a launch are numbered cnt_slot0, cnt_slot0 + 1, ... in sweep order; the wave that works on unit wave w of a level leaves its sum in
+	// cnt_acc[(2 m + colour) * (4 nwg) + w] (zero before the launch: waves without rows store nothing); launch_count_fold adds a measurement's slots up.
+	// NULL: off.  (Rounds 4's 64-bit mask of measured sweeps capped a counted launch at 64 sweeps.)
 	uint32_t *cnt_acc;
-	unsigned long long cnt_mask;
+	int32_t cnt_first, cnt_every;
+	uint32_t cnt_magic;
 	int32_t cnt_slot0;
 	// ... with the energy: cnt_bonds != 0 = a measurement has a third plane of slots, cnt_acc[(3 m + 2) * (4 nwg) + w] (and its up-spin planes are
 	// (3 m + colour)): the white level's waves leave the number of (white site of their rows, black neighbour) pairs with equal spins there --
@@ -88,6 +90,11 @@ struct UpdateParams {
 	int32_t cnt_bonds;
 	// Measurement aid (ising_kernel_clock): 8 x {cycle counter, 100 MHz counter} x {start, end} left by the launch's first eight workgroups; NULL: off
 	unsigned long long *clk_out;
+	// Split launch (ising_ballot.hip: ballot_split_k): draw units and word units with tickets of their own, eight classes (one per XCD).
+	unsigned long long *sp_ctr; // per class 16 words: [0] draw tickets, [4] workgroups registered, [8] word tickets (zero when the launch starts)
+	uint32_t *sp_flags;         // per class and ring slot {waves that have drawn, waves that have used} (counts, zero when the launch starts)
+	uint64_t *sp_masks;         // per class 2^sp_ring_sh slots of 4 waves x H rows x 1 KiB of accept masks
+	int32_t sp_ring_sh, sp_lead, sp_cap; // ring slots per class (log2); draw units a workgroup does before its first word unit; workgroups a class serves
 	const struct ReplicaParams *rep;
 	int32_t nrep, nwg_rep;
 	uint32_t rep_magic;       // ceil(2^32 / nwg_rep)
@@ -191,6 +198,7 @@ hipError_t launch_packed_to_dense(const uint64_t *packed, uint32_t *dense, size_
 void ballot_trace_dump(); // measurement builds only (ising_ballot.hip)
 #endif
 hipError_t launch_ballot_update(UpdateParams &p, hipStream_t stream, int *grid_out, hipEvent_t stop = nullptr, hipEvent_t start = nullptr);
+hipError_t launch_ballot_split(UpdateParams &p, hipStream_t stream, int *grid_out, hipEvent_t stop = nullptr, hipEvent_t start = nullptr);
 int ballot_max_wgs(int cus); // upper bound of the grid of any ballot launch (scratch sizing)
 // up-spin count and black-site bond sum of `nrep` ballot lattices (gx, Y each; reps[r].lat[]), spread over BALLOT_MEASURE_SLOTS
 // accumulator pairs per lattice, 64 bytes apart: acc[(r * SLOTS + s) * 8 + {0, 1}]

@@ -545,12 +545,13 @@ int sweep_deep_overlapped(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 			xs[k] = (c->xs_on && c->xs_n < c->xs_cap) ? c->xs_n++ : -1;
 			if (xs[k] >= 0) { c->launch_start_next = c->xs_ev[4 * xs[k]]; c->launch_stop_next = c->xs_ev[4 * xs[k] + 1]; }
 			if (c->ring_cnt_every > 0) { // print points inside this launch (ring_sweep_counted below): its sweeps whose iteration is a multiple of `every`
-				unsigned long long mask = 0;
-				for (int j = 0; j < ns; j++) if ((it + j) % c->ring_cnt_every == 0) mask |= 1ull << j;
-				c->cnt_mask_next = mask;
+				const int every = c->ring_cnt_every, first = (every - it % every) % every;
+				const int m = first < ns ? (ns - 1 - first) / every + 1 : 0;
+				c->cnt_first_next = first;
+				c->cnt_every_next = m > 0 ? every : 0;
 				c->cnt_slot0_next = c->ring_cnt_inflight;
 				c->cnt_bonds_next = c->ring_cnt_bonds;
-				c->ring_cnt_inflight += (int)__builtin_popcountll(mask);
+				c->ring_cnt_inflight += m;
 			}
 			if (int rc = ising_host::update_deep(c, it, 2 * ns, true)) return rc;
 		}

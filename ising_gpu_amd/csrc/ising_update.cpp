@@ -26,10 +26,10 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	const bool edge_scratch = c->edge_scratch_next;
 	const bool overlap = c->overlap_next;
 	hipEvent_t start = c->launch_start_next;
-	const unsigned long long cnt_mask = c->cnt_mask_next;
+	const int cnt_first = c->cnt_first_next, cnt_every = c->cnt_every_next;
 	const int cnt_slot0 = c->cnt_slot0_next;
 	const bool cnt_bonds = c->cnt_bonds_next;
-	c->cnt_mask_next = 0;
+	c->cnt_every_next = 0;
 	c->cnt_bonds_next = false;
 	if (!stop) stop = c->launch_stop_next;
 	c->edge_scratch_next = false;
@@ -116,7 +116,10 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			p.done = c->d_slotctl + SLOTCTL_TICKET_BYTES / 4;
 			p.wg_per_cu = c->fused_wg_per_cu;
 			p.wait_late = c->fused_wait_late ? (c->pol.fused_wait_late == 1 ? 1 : 2) : 0; // (default 2: behind the second draw phase)
-			if (cnt_mask) { p.cnt_acc = c->d_cnt; p.cnt_mask = cnt_mask; p.cnt_slot0 = cnt_slot0; p.cnt_bonds = cnt_bonds ? 1 : 0; }
+			if (cnt_every > 0 && 2 * cnt_first < nlevels) {
+				p.cnt_acc = c->d_cnt; p.cnt_first = cnt_first; p.cnt_every = cnt_every; p.cnt_slot0 = cnt_slot0; p.cnt_bonds = cnt_bonds ? 1 : 0;
+				p.cnt_magic = (uint32_t)((0x100000000ull + (unsigned long long)cnt_every - 1) / (unsigned long long)cnt_every);
+			}
 			if (c->clk_on && c->d_clk) p.clk_out = c->d_clk;
 			p.nt_stream = c->fused_nt;
 			p.done_base = c->done_base;
@@ -138,7 +141,18 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			}
 		}
 		int grid = 0;
-		if (const hipError_t le = ising::launch_ballot_update(p, c->stream, &grid, stop, start); le != hipSuccess) {
+		// the split form of a fused launch over the whole slab (ising_ballot.hip: ballot_split_k): its ticket words and slot counts start from zero
+		const bool split = c->split && nlevels > 1 && lo0 == 0 && hi0 == c->cfg.Y && hi1 == lo1 && color == ISING_BLACK && c->d_split_masks && c->d_split_ctl;
+		if (split) {
+			HIP_TRY(hipMemsetAsync(c->d_split_ctl, 0, c->split_ctl_bytes, c->stream));
+			p.sp_ctr = c->d_split_ctl;
+			p.sp_flags = reinterpret_cast<uint32_t *>(c->d_split_ctl + 8 * 16);
+			p.sp_masks = c->d_split_masks;
+			p.sp_ring_sh = c->split_ring_sh;
+			p.sp_lead = c->split_lead;
+			p.sp_cap = c->split_cap;
+		}
+		if (const hipError_t le = split ? ising::launch_ballot_split(p, c->stream, &grid, stop, start) : ising::launch_ballot_update(p, c->stream, &grid, stop, start); le != hipSuccess) {
 			// nothing ran: tickets and counters are where the launches before left them, but to be safe they start over
 			if (nlevels > 1) { __atomic_store_n(c->h_abort, 1u, __ATOMIC_RELEASE); (void)ising_host::check_abort(c); }
 			return fail(ISING_E_HIP, "kernel launch failed: %s", hipGetErrorString(le));
@@ -147,7 +161,9 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			c->done_base += (uint32_t)nlevels * (uint32_t)c->nwc();
 			// where the launch leaves the counter(s): its units, and every workgroup drew one ticket too many
 			const unsigned long long total = (unsigned long long)p.nwg * (unsigned long long)nlevels;
-			if (p.tickets2 > 1) { // units and workgroups of class k = those numbered k mod K
+			if (split) {
+				// (its tickets are the split form's own words)
+			} else if (p.tickets2 > 1) { // units and workgroups of class k = those numbered k mod K
 				const unsigned long long K = (unsigned long long)p.tickets2;
 				for (unsigned long long k = 0; k < K; k++) c->ticket_base2[k] += (total + K - 1 - k) / K + ((unsigned long long)grid + K - 1 - k) / K;
 			} else {
@@ -376,7 +392,7 @@ extern "C" int ising_sweep_counted(ising_ctx *c, int first_it, int nsweeps, int 
 	size_t slots = 0, n_up = 0, chunk = 0;
 	unsigned long long *d_sum = nullptr;
 	if (int rc = ising_host::cnt_reserve(c, (size_t)c->nstrips, bond_equal != nullptr, &slots, &n_up, &chunk, &d_sum)) return rc;
-	const int per_launch = std::min(64, ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y)); // (a launch's measured sweeps are a 64-bit mask)
+	const int per_launch = ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y); // (a counted launch is as long as any other)
 	std::vector<unsigned long long> h(2 * chunk);
 	long long got = 0;
 	int it = first_it, left = nsweeps;
@@ -386,16 +402,15 @@ extern "C" int ising_sweep_counted(ising_ctx *c, int first_it, int nsweeps, int 
 		int inflight = 0;
 		while (left > 0) {
 			int ns = std::min(left, per_launch);
-			unsigned long long mask = 0;
-			int m = 0;
-			for (int j = 0; j < ns; j++) {
-				if ((it + j) % every) continue;
-				if (inflight + m == (int)chunk) { ns = j; break; } // (the launch ends in front of the measurement that no longer fits)
-				mask |= 1ull << j;
-				m++;
+			const int first = (every - it % every) % every; // the launch's first measured sweep: iteration it + first is a multiple of `every`
+			int m = first < ns ? (ns - 1 - first) / every + 1 : 0;
+			if (inflight + m > (int)chunk) { // (the launch ends in front of the measurement that no longer fits)
+				m = (int)chunk - inflight;
+				ns = first + m * every;
 			}
 			if (ns == 0) break;
-			c->cnt_mask_next = mask;
+			c->cnt_first_next = first;
+			c->cnt_every_next = m > 0 ? every : 0;
 			c->cnt_slot0_next = inflight;
 			c->cnt_bonds_next = bond_equal != nullptr;
 			if (int rc = launch_ranges(c, it, ISING_BLACK, 0, c->cfg.Y, 0, 0, 2 * ns)) { *ncounts = (int)got; return rc; } // (the counts of the chunks before are the caller's)
@@ -423,7 +438,7 @@ int ising_sweep_info(ising_ctx *c, int *fused, int *max_sweeps_per_launch) {
 	// (a ring slab with ghost rows G deep: the ring's sweeps are fused launches of G/2 sweeps between two exchanges)
 	const bool deep = ghost_sweeps(c);
 	const bool tiled = !f && !deep && sweeps_tiled(c, 2);
-	if (fused) *fused = (f || deep) ? 1 : (tiled ? 2 : 0);
+	if (fused) *fused = (f && c->split && !c->cfg.XSL) ? 3 : ((f || deep) ? 1 : (tiled ? 2 : 0));
 	if (max_sweeps_per_launch) *max_sweeps_per_launch = f ? ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y) : (deep ? c->ghost() / 2 : (tiled ? c->tile_sweeps : 0));
 	return ISING_OK;
 }

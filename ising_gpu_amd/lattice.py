@@ -178,7 +178,14 @@ class IsingSlab:
         """True when sweep() issues fused launches (several colour half-sweeps per launch, ising_sweep_info)."""
         f, m = C.c_int(), C.c_int()
         check(self._lib.ising_sweep_info(self._h, C.byref(f), C.byref(m)))
-        return f.value == 1
+        return f.value in (1, 3)
+
+    @property
+    def split(self) -> bool:
+        """True when sweep()'s fused launches take the split form (draw units and word units with tickets of their own, ising_sweep_info)."""
+        f, m = C.c_int(), C.c_int()
+        check(self._lib.ising_sweep_info(self._h, C.byref(f), C.byref(m)))
+        return f.value == 3
 
     @property
     def tiled(self) -> bool:

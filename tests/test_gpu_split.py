@@ -1,0 +1,72 @@
+"""GPU parity of the split launches (ising_ballot.hip: ballot_split_k -- draw units and word units with tickets of their own, the accept masks through
+a ring per XCD) against the CPU oracle, bit for bit: every word of both colours, counts, bond sum, the print points inside the launches -- over strip
+heights, grids (more workgroups than tickets, fewer than classes want), leads, partly dead wave columns, launches of many levels."""
+import numpy as np
+import pytest
+
+import ising_gpu_amd as ig
+
+pytestmark = pytest.mark.gpu
+TC = ig.CRIT_TEMP_F32
+
+
+def _same(slab, orc):
+    return np.array_equal(slab.read(ig.BLACK), orc.black) and np.array_equal(slab.read(ig.WHITE), orc.white)
+
+
+def _env(monkeypatch, lead=None, wgs=None):
+    monkeypatch.setenv("ISING_SPLIT", "1")
+    monkeypatch.setenv("ISING_FUSED", "1")
+    for k, v in (("ISING_SPLIT_LEAD", lead), ("ISING_FUSED_WGS", wgs)):
+        if v is None:
+            monkeypatch.delenv(k, raising=False)
+        else:
+            monkeypatch.setenv(k, str(v))
+
+
+@pytest.mark.parametrize("X,Y,H,lead,wgs,sweeps", [
+    (8192, 64, 1, 1, None, (1, 2, 5)), (8192, 128, 4, 0, None, (3, 7)), (8192, 256, 8, 1, 64, (2, 9)), (16384, 256, 16, 1, None, (4, 4)),
+    (16384, 512, 16, 2, 512, (11,)), (24576, 128, 4, 1, None, (3, 3)), (10240, 128, 2, 1, None, (5, 2)), (65536, 64, 4, 1, 256, (6,)),
+    (8192, 2048, 16, 1, None, (33,)), (8192, 1024, 2, 0, 1536, (40,)),
+])
+def test_split_launches_bit_exact(gpu, oracle_mod, monkeypatch, X, Y, H, lead, wgs, sweeps):
+    _env(monkeypatch, lead, wgs)
+    orc = oracle_mod.OracleLattice(X, Y, seed=4711, temp=oracle_mod.CRIT_TEMP).init()
+    with ig.IsingSlab(X, Y, seed=4711, temp=TC, layout=ig.LAYOUT_BALLOT, strip_rows=H) as s:
+        assert s.fused and s.split and s.strip_rows == H
+        s.init()
+        for n in sweeps:
+            s.sweep(n)
+            orc.sweep(n)
+            assert _same(s, orc), (X, Y, H, n)
+        assert s.count() == orc.count() and s.bond_equal() == orc.bond_equal()
+
+
+@pytest.mark.parametrize("X,Y,H,every,calls", [(8192, 128, 4, 3, (7, 2, 70)), (16384, 256, 16, 16, (40, 100)), (10240, 64, 2, 4, (9, 130)), (8192, 512, 8, 1, (5, 3))])
+@pytest.mark.parametrize("energy", [False, True], ids=["counts", "counts+energy"])
+def test_split_launches_print_points(gpu, oracle_mod, monkeypatch, X, Y, H, every, calls, energy):
+    """ising_sweep_counted on split launches: the word units count what they store (and the white levels' equal bonds)"""
+    _env(monkeypatch)
+    orc = oracle_mod.OracleLattice(X, Y, seed=77, temp=oracle_mod.CRIT_TEMP).init()
+    with ig.IsingSlab(X, Y, seed=77, temp=TC, layout=ig.LAYOUT_BALLOT, strip_rows=H) as s:
+        assert s.split
+        s.init()
+        for n in calls:
+            got = s.sweep_counted(n, every, energy)
+            want = []
+            for _ in range(n):
+                orc.sweep(1)
+                if orc.it % every == 0:
+                    want.append(orc.count() + ((orc.bond_equal(),) if energy else ()))
+            assert got == want, (n, s.it)
+        assert _same(s, orc)
+
+
+def test_split_launches_low_temperature_and_long_launch(gpu, oracle_mod, monkeypatch):
+    """T = 1.5 (other thresholds), one launch of 600 sweeps = 1200 levels: the rings wrap many times"""
+    _env(monkeypatch)
+    X, Y = 8192, 128
+    orc = oracle_mod.OracleLattice(X, Y, seed=ig.SEED_DEF, temp=1.5).init().sweep(600)
+    with ig.IsingSlab(X, Y, seed=ig.SEED_DEF, temp=1.5, layout=ig.LAYOUT_BALLOT, strip_rows=2) as s:
+        s.init().sweep(600)
+        assert _same(s, orc)

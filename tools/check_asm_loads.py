@@ -28,7 +28,7 @@ lines = open(sys.argv[1]).read().split("\n")
 i = 0
 while i < len(lines):
     ln = lines[i]
-    m = re.match(r"^(_Z\w*ballot_update_k\w*):", ln)
+    m = re.match(r"^(_Z\w*ballot_(?:update|split)_k\w*):", ln)
     if m:
         kern, pending, nloads = m.group(1), {}, 0
     if kern and "s_endpgm" in ln:
