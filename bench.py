@@ -69,6 +69,75 @@ def cgroup_cpus():
         return None
 
 
+def first_contact_block(args, ig, torch, dist, world, rank, device, ndev, shared, attempts, layout, ctl, value, xstats):
+    """Keys that make the first run on a multi-GPU node explain itself (collective: every rank calls it; rank 0 uses the result).
+    transport_attempts: per rank, every transport tried with "ok" or its error string; ranks: device ordinal, PCI bus id, the row of the peer-access matrix,
+    name; versions: HIP runtime and RCCL as the library loaded them; expected: the rate of THIS slab shape as a lone slab (periodic in itself) measured on
+    this rank's device right here (~0.3 s), the envelope of an exchange (one-GPU probes, profiles/strong_slab_probe_r04.txt: 2 x 2 x 256 KiB per exchange
+    at X = 65536; <= 0.45 ms, ending before the launch whose tail hides it); efficiency_vs_lone_slab = value / sum of the ranks' lone-slab rates."""
+    props = torch.cuda.get_device_properties(device)
+    bus = getattr(props, "pci_bus_id", None)
+    pci = None if bus is None else f"{getattr(props, 'pci_domain_id', 0):04x}:{bus:02x}:{getattr(props, 'pci_device_id', 0):02x}.0"
+    peers = []
+    for d in range(ndev):
+        try:
+            peers.append(1 if d == device else int(torch.cuda.can_device_access_peer(device, d)))
+        except Exception:  # noqa: BLE001
+            peers.append(-1)
+    # the lone slab: same shape, same device, wraps in itself; a preheat, then the best of three timed pieces
+    lone = None
+    try:
+        with ig.IsingSlab(args.x, args.y, device=device, seed=args.seed, temp=ig.CRIT_TEMP_F32, strip_rows=args.strip_rows, layout=layout) as s:
+            s.init()
+            piece = max(1, min(32, s.max_sweeps_per_launch or 32))
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.15:
+                s.sweep(piece)
+                s.synchronize()
+            for _ in range(3):
+                t0 = time.perf_counter()
+                s.sweep(piece)
+                s.synchronize()
+                r = args.x * args.y * piece / (time.perf_counter() - t0) * 1e-9
+                lone = r if lone is None else max(lone, r)
+    except ig.IsingError as e:
+        lone = None
+        attempts = attempts + [{"transport": "lone-slab-probe", "ok": False, "error": str(e)}]
+    mine = {"rank": rank, "device": device, "pci_bus_id": pci, "name": props.name, "peer_access_row": peers, "lone_slab_flips_per_ns": None if lone is None else round(lone, 1),
+            "transport_attempts": attempts}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    if rank != 0:
+        return None
+    devices = [r["pci_bus_id"] or f"ordinal{r['device']}" for r in per_rank]
+    lone_sum = sum(r["lone_slab_flips_per_ns"] or 0.0 for r in per_rank)
+    try:
+        rccl = ig.rccl_version()
+    except Exception:  # noqa: BLE001
+        rccl = None
+    out = {
+        "ranks": [{k: r[k] for k in ("rank", "device", "pci_bus_id", "name", "peer_access_row", "lone_slab_flips_per_ns")} for r in per_rank],
+        "distinct_devices": len(set(devices)),
+        "ranks_own_their_device": len(set(devices)) == world and not shared,
+        "transport_attempts": {f"rank{r['rank']}": [(a["transport"] + ": " + ("ok" if a["ok"] else str(a["error"]))
+                                                    + ("" if a.get("all_ranks_ok", a["ok"]) == a["ok"] else " (another rank failed)")) for a in r["transport_attempts"]] for r in per_rank},
+        "versions": {"hip": getattr(torch.version, "hip", None), "rccl": rccl, "torch": torch.__version__},
+        "expected": {"lone_slab_flips_per_ns_sum": round(lone_sum, 1),
+                     "what": "each rank's slab shape as a lone slab (periodic in itself) on its own device, measured in this job; a ring slab does 128 of Y + 128 rows again "
+                             "(the ghost rows) and exchanges once per 32 sweeps",
+                     "ghost_row_overhead": round(128.0 / (args.y + 128.0), 4),
+                     "exchange_ms_max": 0.45, "go_after_end_ms_max": 0.0,
+                     "exchange_what": "one-GPU probes (profiles/strong_slab_probe_r04.txt): an exchange moves 2 colours x 2 neighbours x 64 rows (256 KiB each at X = 65536) and starts when the "
+                                      "launch's edge strips finish their last level, ~0.4 ms before the launch ends -- on real links it should end before the launch does"},
+        "efficiency_vs_lone_slab": None if lone_sum <= 0 else round(value / lone_sum, 4),
+    }
+    if xstats is not None:
+        out["expected"]["exchange_within_envelope"] = bool(xstats["exchange_ms"]["max"] <= 0.45 and xstats["go_after_end_ms"]["max"] <= 0.0)
+    return out
+
+
 def cpu_baseline(args):
     """Reported CPU baseline on the host cores of this box (rank 0, N=1 only): the byte-per-spin algorithm of
     basic_python/ising_basic.py restated in oracle/basic_cpu.c, BASELINE.json configs[0] (1024x1024, alpha 1,
@@ -251,6 +320,7 @@ def main():
 
     layout = {"auto": ig.LAYOUT_AUTO, "nibble": ig.LAYOUT_NIBBLE, "dense": ig.LAYOUT_DENSE, "ballot": ig.LAYOUT_BALLOT}[args.layout]
     log = (lambda m: print(f"[bench rank {rank}] {m}", file=sys.stderr, flush=True))
+    attempts = []  # every ring transport tried on this rank, with its error string (first contact with a multi-GPU node must explain itself)
     if not ringed:
         slab = ig.IsingSlab(args.x, args.y, device=local_rank, seed=args.seed, temp=ig.CRIT_TEMP_F32, strip_rows=args.strip_rows, layout=layout)
         ring, ring_name = None, "none"
@@ -263,7 +333,7 @@ def main():
             slab = ig.IsingSlab(args.x, args.y, device=local_rank, seed=args.seed, temp=ig.CRIT_TEMP_F32, nslabs=world, slab=rank,
                                 strip_rows=args.strip_rows, layout=layout, ring_halo=world == 1)
             transports = {"auto": ("ipc",) if shared else ("rccl", "ipc"), "rccl": ("rccl",), "ipc": ("ipc",)}[args.transport]
-            ring = ig.open_native_ring(slab, log=log, transports=transports)
+            ring = ig.open_native_ring(slab, log=log, transports=transports, attempts=attempts)
             if ring is None:
                 slab.close()
             else:
@@ -276,7 +346,7 @@ def main():
             slab = ig.IsingSlab(args.x, args.y, device=local_rank, seed=args.seed, temp=ig.CRIT_TEMP_F32, nslabs=world, slab=rank,
                                 strip_rows=args.strip_rows, layout=layout, ring_halo=world == 1)
             try:
-                ring, ring_name = ig.open_ring(ig.HipSlabBackend(slab), prefer="torch", exchange="p2p", log=log)
+                ring, ring_name = ig.open_ring(ig.HipSlabBackend(slab), prefer="torch", exchange="p2p", log=log, attempts_out=attempts)
                 if ring.ghost_rows > 1:
                     ring_name += f"-ghost{ring.ghost_rows}"
             except ig.IsingError as e:  # (every rank gets here together: open_ring agrees on each attempt's outcome)
@@ -287,7 +357,7 @@ def main():
             backend = ig.HipSlabBackend.create(args.x, args.y, device=local_rank, seed=args.seed, temp=ig.CRIT_TEMP_F32,
                                                nslabs=world, slab=rank, strip_rows=args.strip_rows, layout=layout, ring_halo=world == 1)
             slab = backend.slab
-            ring, ring_name = ig.open_ring(backend, prefer="torch", exchange=args.exchange, log=log)
+            ring, ring_name = ig.open_ring(backend, prefer="torch", exchange=args.exchange, log=log, attempts_out=attempts)
 
     # sweeps per ising_sweep call: the largest common divisor of steps and warm-up that one fused launch can carry (32), so
     # that every launch of the run is the same piece of work -- unless that leaves pieces under 16 sweeps (the driver's
@@ -473,6 +543,12 @@ def main():
         if ring is None or hasattr(ring, "sweep_counted"):
             energy_leg = counted_leg(True)
 
+    # First contact with a multi-GPU node: who owns which device, what each transport attempt said, and what this slab shape does
+    # as a LONE slab on this rank's device in this job -- so that the line reads as good or bad without a second run.
+    first_contact = None
+    if ringed:
+        first_contact = first_contact_block(args, ig, torch, dist, world, rank, device, ndev, shared, attempts, layout, ctl, value, xstats)
+
     layout_name, layout_text = {
         ig.LAYOUT_NIBBLE: ("nibble", "reference 4 bit/spin"),
         ig.LAYOUT_DENSE: ("dense", "dense 1 bit/spin"),
@@ -572,6 +648,8 @@ def main():
             line["with_counts_and_energy_every_16"] = energy_leg
         if xstats is not None:
             line["exchange_stats"] = xstats
+        if first_contact is not None:
+            line.update(first_contact)
         if shared:  # more ranks than devices: `value` is what the physical GPUs delivered together, not a scaling point
             line["config"]["note"] = (f"{world} ranks share {ndev} physical GPU(s): the N > 1 path (processes, peer transport, ring schedule) executed and "
                                       "checked, not a scaling measurement")

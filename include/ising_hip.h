@@ -219,7 +219,7 @@ int ising_sweep_counted(ising_ctx *ctx, int first_it, int nsweeps, int every, ui
  * *max_sweeps_per_launch times without a word from the others; ising_dense.hip: dense_tile_k).  For a ring slab with ghost rows G
  * deep (ballot layout): how the ring sweeps it -- fused launches of up to G/2 sweeps between exchanges.  3: fused launches in the split form
  * (round 5; ising_ballot.hip: ballot_split_k): draw units -- no wait, no barrier, tall strips -- and word units with tickets of their own, for lone
- * lattices whose levels have too few tickets for tall strips in the plain fused form. */
+ * lattices and ring slabs whose levels have too few tickets for tall strips in the plain fused form. */
 int ising_sweep_info(ising_ctx *ctx, int *fused, int *max_sweeps_per_launch);
 /* Same, bracketed by HIP events on the context's stream; returns elapsed milliseconds (blocking). */
 int ising_sweep_timed(ising_ctx *ctx, int first_it, int nsweeps, float *elapsed_ms);

@@ -1,5 +1,5 @@
 /*
- * ising_hip_testing.h -- entry points of libising_hip.so that exist for its TESTS only (fault injection).  Not part of the
+ * ising_hip_testing.h -- entry points of libising_hip.so that exist for its TESTS only (fault injection, the launch shape).  Not part of the
  * drop-in boundary: a caller that replaces the reference's launch sites needs include/ising_hip.h and nothing from here.
  */
 #ifndef ISING_HIP_TESTING_H
@@ -20,6 +20,9 @@ int ising_debug_fault(ising_ctx *ctx, int what, int arg);
 /* The same for a batch (ising_batch_*): its completion counters out of step; the next batched launch gives up after `polls`
  * polls and every later batch call reports ISING_E_STATE once, with the batch's tickets and counters reset. */
 int ising_batch_debug_fault(ising_batch *b, int polls);
+/* The launch shape ising_create picked for this slab's fused launches (tests/test_gpu_policy.py measures it against its neighbours): strip height,
+ * workgroups per CU of the persistent grid, and for the split form (ising_sweep_info: 3) the lead (0 otherwise).  Any pointer may be NULL. */
+int ising_debug_launch_shape(ising_ctx *ctx, int *strip_rows, int *wg_per_cu, int *split_lead);
 
 #ifdef __cplusplus
 }

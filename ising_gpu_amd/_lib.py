@@ -103,6 +103,7 @@ PROTOTYPES = {
     "ising_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "ising_debug_fault": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ising_batch_debug_fault": (C.c_int, [C.c_void_p, C.c_int]),
+    "ising_debug_launch_shape": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ising_dump_text": (C.c_int, [C.c_void_p, C.c_char_p]),
     "ising_ring_set_transport": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "ising_ring_transport": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]),

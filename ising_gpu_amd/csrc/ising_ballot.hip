@@ -855,7 +855,9 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 // which was handed out long ago because the workgroups of a class hold at most (sp_lead + 1) draw tickets more than word tickets each -- and a word unit
 // for lower tickets only: the lowest unfinished ticket of every class is always held by a running workgroup.  (A class whose XCD runs no workgroup of the
 // launch would never be served: the polls' bound turns that into ISING_E_STATE like any other launch that gives up.)
-template <bool STREAM, bool COUNT>
+// Ring slabs (ghost rows, trapezoid, the exchange's edge units) and levels whose tickets are not a multiple of eight run here as well: a class's last ticket
+// of a level may name a unit that does not exist (absent: it keeps the order of the slots and counts for nothing).
+template <bool COUNT>
 __global__ void __launch_bounds__(BAL_THREADS) BAL_SGPR_ATTR ballot_split_k(const UpdateParams p) {
 	const int lane = threadIdx.x & 63;
 	const int tx = threadIdx.x & (GROUP - 1), g = (threadIdx.x >> 4) & 3;
@@ -882,7 +884,7 @@ __global__ void __launch_bounds__(BAL_THREADS) BAL_SGPR_ATTR ballot_split_k(cons
 	uint32_t xcc;
 	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
 	xcc &= 7u;
-	const int T8 = p.nwg >> 3; // tickets per level and class (the host launches this form only where a level's tickets divide by 8)
+	const int T8 = (p.nwg + 7) >> 3; // tickets per level and class (the last one of a level may name a unit beyond the level's last: absent)
 	const unsigned long long total = (unsigned long long)p.nlevels * (unsigned long long)T8;
 	unsigned long long *const dtp = p.sp_ctr + 16 * xcc, *const wtp = dtp + 8; // this class's draw / word ticket counters (zero when the launch starts)
 	const int ring_sh = p.sp_ring_sh; // slots per class: 2^ring_sh
@@ -912,8 +914,14 @@ __global__ void __launch_bounds__(BAL_THREADS) BAL_SGPR_ATTR ballot_split_k(cons
 	};
 	clock_mark(0);
 
+	// row of the whole lattice behind slab row r: ghost rows of a ring slab are rows of its neighbours, around the ring (ballot_update_k)
+	auto global_row = [&](int r) -> uint32_t {
+		int gr = (int)p.row_base + r;
+		if (p.total_rows) gr = gr < 0 ? gr + p.total_rows : (gr >= p.total_rows ? gr - p.total_rows : gr);
+		return (uint32_t)gr;
+	};
 	// a ticket of this class -> its unit of the level: (strip, wave column) of this wave, rows
-	struct Unit { int level, sidx, wc, bx0, r0, nrows; bool absent; uint32_t color, it; };
+	struct Unit { int level, sidx, wc, bx0, r0, nrows; bool absent, edge; uint32_t color, it; };
 	auto decode = [&](int k, int level) -> Unit {
 		Unit u;
 		u.level = level;
@@ -927,7 +935,13 @@ __global__ void __launch_bounds__(BAL_THREADS) BAL_SGPR_ATTR ballot_split_k(cons
 		u.wc = u.bx0 >> 2;
 		u.sidx = uni((pos & 1) ? nstr - 1 - (pos >> 1) : (pos >> 1)); // strips from both ends of the slab inwards, as in the fused launches
 		u.r0 = p.row_lo[0] + u.sidx * p.H;
-		u.nrows = u.absent ? 0 : min(p.H, p.row_hi[0] - u.r0);
+		const int nrows0 = u.absent ? 0 : min(p.H, p.row_hi[0] - u.r0);
+		// ring slab with ghost rows: at this level only rows within `keep` of the slab's own can still reach one of them (trapezoid, ballot_update_k)
+		const int keep = uni(p.nlevels - 1 - level);
+		const bool skip = p.trapezoid != 0 && !u.absent && (u.r0 + nrows0 <= -keep || u.r0 >= p.Y + keep);
+		u.nrows = skip ? 0 : nrows0;
+		// ... and, exchange overlapped with the launches: a unit that touches rows the exchange reads or writes
+		u.edge = p.edge_go != nullptr && !u.absent && (u.r0 < p.edge_lo || u.r0 + nrows0 > p.edge_hi);
 		u.color = uni((p.color + (uint32_t)level) & 1u);
 		u.it = uni(p.it + ((p.color + (uint32_t)level) >> 1));
 		return u;
@@ -995,7 +1009,7 @@ __global__ void __launch_bounds__(BAL_THREADS) BAL_SGPR_ATTR ballot_split_k(cons
 			__builtin_amdgcn_wave_barrier();
 			__threadfence_block();
 			const int bx = u.bx0 + g;
-			uint32_t grow_d = p.row_base + (uint32_t)u.r0;
+			uint32_t grow_d = global_row(u.r0);
 			uint32_t tid_d = ((grow_d >> 4) * (uint32_t)p.gx + (uint32_t)bx) * 256u + (grow_d & 15u) * 16u + (uint32_t)tx;
 			const uint64_t *cur = masks + (size_t)slot * slot_words;
 			const uint32_t thr3 = p.n3, thr4 = p.n4;
@@ -1007,8 +1021,15 @@ __global__ void __launch_bounds__(BAL_THREADS) BAL_SGPR_ATTR ballot_split_k(cons
 				default: __builtin_amdgcn_s_setprio(3); break;
 				}
 				const PhiloxRow pr = philox_row_setup(tid_d, seed_lo_cy, k2y);
-				tid_d += (grow_d & 15u) == 15u ? (uint32_t)p.gx * 256u - 240u : 16u;
-				grow_d += 1u;
+				{ // the next row's stream id: 16 on, a new block row of 16 every 16 rows, around the ring behind the lattice's last row (ballot_update_k)
+					uint32_t inc = (grow_d & 15u) == 15u ? (uint32_t)p.gx * 256u - 240u : 16u, g1 = grow_d + 1u;
+					if (p.total_rows && g1 == (uint32_t)p.total_rows) {
+						g1 = 0u;
+						inc -= ((uint32_t)p.total_rows >> 4) * (uint32_t)p.gx * 256u;
+					}
+					grow_d = g1;
+					tid_d += inc;
+				}
 				uint4 kc_next = blk_const[0];
 				static_for<16>([&](auto B) {
 					uint32_t o0, o1, o2, o3;
@@ -1074,6 +1095,19 @@ __global__ void __launch_bounds__(BAL_THREADS) BAL_SGPR_ATTR ballot_split_k(cons
 				__builtin_amdgcn_s_sleep(ISING_POLL_SLEEP);
 			}
 		}
+		if (u.edge && level == 0) {
+			// the exchange that follows the previous launch has read this slab's first / last rows and filled its ghost rows once the comm stream has moved
+			// the counter (ballot_update_k: usually long ago; the bound is 16 times a unit's for its parents)
+			uint32_t got = p.edge_go_need, ngo = 0;
+			for (;;) {
+				if (lane == 0) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(got) : "v"(p.edge_go) : "memory");
+				if (__all((int32_t)(got - p.edge_go_need) >= 0)) break;
+				if ((++ngo & 63u) == 0u && give_up(ngo >> 4)) break;
+				__builtin_amdgcn_s_sleep(127);
+			}
+			// rows written while this launch ran by another kernel, a copy engine or a peer device: system scope (the lattice loads behind it bypass the vector L1 anyway)
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+		}
 		STRC(5); // word unit: decode, wait
 		[[maybe_unused]] uint32_t cnt_up = 0, cnt_eq = 0;
 		[[maybe_unused]] int meas_idx = -1;
@@ -1086,8 +1120,8 @@ __global__ void __launch_bounds__(BAL_THREADS) BAL_SGPR_ATTR ballot_split_k(cons
 		[[maybe_unused]] const bool eq_unit = COUNT && p.cnt_bonds != 0 && (level & 1) != 0 && meas_idx >= 0;
 		if (nrows > 0) {
 			uint64_t *const lat0 = p.lat[0], *const lat1 = p.lat[1];
-			const uint64_t *rs = (color ? lat0 : lat1) + ((ptrdiff_t)r0 * wpr + wc * 64);
-			uint64_t *rd = (color ? lat1 : lat0) + ((ptrdiff_t)r0 * wpr + wc * 64);
+			const uint64_t *const rs0 = (color ? lat0 : lat1) + ((ptrdiff_t)r0 * wpr + wc * 64);
+			uint64_t *const rd0 = (color ? lat1 : lat0) + ((ptrdiff_t)r0 * wpr + wc * 64);
 			uint64_t first = 0, last = 0; // bit 16g (16g + 15): group g opens (closes) the row
 #pragma unroll
 			for (int gg = 0; gg < 4; ++gg) {
@@ -1102,22 +1136,30 @@ __global__ void __launch_bounds__(BAL_THREADS) BAL_SGPR_ATTR ballot_split_k(cons
 			const int end_src = 16 * min(4, p.gx - 4 * src_b) - 1;
 			const int u_cb = (src_b - wc) * 64 + word_of(1, 7, 3);
 			const int u_cf = ((wc == nwc - 1 ? 0 : wc + 1) - wc) * 64 + word_of(0, 0, 0);
-			const uint64_t *msk = masks + (size_t)slot * slot_words;
-			uint32_t grow = p.row_base + (uint32_t)r0;
+			const uint64_t *const msk0 = masks + (size_t)slot * slot_words;
+			const uint32_t grow0 = global_row(r0);
+			// A row's flips need the word of the neighbouring wave column, the lane's two masks, the word below and the word itself: four loads, one wait, the flips,
+			// one store -- a memory round trip per row, next to workgroups that draw.  (Round 5 also kept 1 / 2 / 4 rows of loads in flight across the stores of
+			// the rows before -- straight-line code, hand-counted vmcnt(n) per row --: the word rows' share of a workgroup's time halved, 15.7 -> 8.0 %, and the
+			// launches ran 1-2 % SLOWER at every shape on one box (16384^2, H = 16: 3391 -> 3343 / 3334 at one / four rows in flight; 65536 x 8192: 3392 -> 3345 / 3312;
+			// profiles/split_depth_probe_r05.txt): the vector ALU is what binds, the chain of word units is not, and the pipeline's instructions are not free.)
+			uint32_t grow = grow0;
+			const uint64_t *rs = rs0, *msk = msk0;
+			uint64_t *rd = rd0;
 			uint64_t up, ct;
-			ld64_coh_issue<STREAM>(up, rs - (ptrdiff_t)wpr, lane * 8);
-			ld64_coh_issue<STREAM>(ct, rs, lane * 8);
+			ld64_coh_issue<false>(up, rs - (ptrdiff_t)wpr, lane * 8);
+			ld64_coh_issue<false>(ct, rs, lane * 8);
 			// (waited for HERE: values loaded by inline assembly must not be loop-carried before their wait -- the compiler may copy them at the loop's head)
 			asm volatile("s_waitcnt vmcnt(0)" : "+v"(up), "+v"(ct) :: "memory");
 			for (int r = 0; r < nrows; ++r) {
 				const int lr = r0 + r;
-				const bool back = (color == 0) ? !(grow & 1u) : (grow & 1u); // readBack, optimized/main.cu:542
+				const bool back = (color == 0) ? !(grow & 1u) : (grow & 1u) != 0u; // readBack, optimized/main.cu:542
 				uint64_t vC, dw, me;
 				u32x4 mk;
-				ld64_coh_issue<STREAM>(vC, rs + (back ? u_cb : u_cf), 0);
+				ld64_coh_issue<false>(vC, rs + (back ? u_cb : u_cf), 0);
 				asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=&v"(mk) : "v"(lane * 16), "s"(msk) : "memory");
-				ld64_coh_issue<STREAM>(dw, rs + (ptrdiff_t)wpr, lane * 8);
-				ld64_coh_issue<STREAM>(me, rd, lane * 8);
+				ld64_coh_issue<false>(dw, rs + (ptrdiff_t)wpr, lane * 8);
+				ld64_coh_issue<false>(me, rd, lane * 8);
 				asm volatile("s_waitcnt vmcnt(0)" : "+v"(vC), "+v"(mk), "+v"(dw), "+v"(me) :: "memory");
 				const unsigned long long sA0 = readlane64(ct, back ? word_of(0, 7, 3) : word_of(0, 0, 0));
 				const unsigned long long sA1 = readlane64(ct, back ? word_of(1, 7, 3) : word_of(1, 0, 0));
@@ -1144,14 +1186,14 @@ __global__ void __launch_bounds__(BAL_THREADS) BAL_SGPR_ATTR ballot_split_k(cons
 				const uint64_t sd = ((uint64_t)sdh << 32) | sdl;
 				const uint64_t c3 = ((uint64_t)mk.y << 32) | mk.x, c4 = ((uint64_t)mk.w << 32) | mk.z;
 				const uint64_t nw = me ^ (flips64(me, up, ct, dw, sd, c3, c4) & live);
-				if (COUNT && (unsigned)lr < (unsigned)p.Y) {
+				if (COUNT && (unsigned)lr < (unsigned)p.Y) { // (a ring slab's ghost rows are its neighbours' to count)
 					cnt_up += (uint32_t)__popcll(nw);
 					if (eq_unit) cnt_eq += (uint32_t)(__popcll(~(nw ^ up) & live) + __popcll(~(nw ^ ct) & live) + __popcll(~(nw ^ dw) & live) + __popcll(~(nw ^ sd) & live));
 				}
-				st64_coh_issue<STREAM>(rd, lane * 8, nw);
+				st64_coh_issue<false>(rd, lane * 8, nw);
 				if (p.wrap) { // the halo rows that mirror this colour's edge rows
-					if (lr == 0) st64_coh_issue<STREAM>(rd + mir0, lane * 8, nw);
-					if (lr == p.Y - 1) st64_coh_issue<STREAM>(rd + mirL, lane * 8, nw);
+					if (lr == 0) st64_coh_issue<false>(rd + mir0, lane * 8, nw);
+					if (lr == p.Y - 1) st64_coh_issue<false>(rd + mirL, lane * 8, nw);
 				}
 				rs += wpr;
 				rd += wpr;
@@ -1159,6 +1201,7 @@ __global__ void __launch_bounds__(BAL_THREADS) BAL_SGPR_ATTR ballot_split_k(cons
 				up = ct;
 				ct = dw;
 				grow += 1u;
+				if (p.total_rows && grow == (uint32_t)p.total_rows) grow = 0u; // around the ring: row 0 follows the lattice's last row
 			}
 		}
 		STRC(6); // word rows
@@ -1180,6 +1223,8 @@ __global__ void __launch_bounds__(BAL_THREADS) BAL_SGPR_ATTR ballot_split_k(cons
 		if (lane == 0) {
 			if (!u.absent) __hip_atomic_fetch_add(p.done + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			__hip_atomic_fetch_add(fl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			// last level: the rows the next exchange sends are final and the ghost rows no longer read
+			if (u.edge && level == p.nlevels - 1) __hip_atomic_fetch_add(p.edge_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
 	clock_mark(1);
@@ -1571,18 +1616,13 @@ static void ballot_trace_is_split();
 hipError_t launch_ballot_split(UpdateParams &p, hipStream_t stream, int *grid_out, hipEvent_t stop, hipEvent_t start) {
 	if (grid_out) *grid_out = 0;
 	p.nwg = (p.nunits + BAL_THREADS / GROUP - 1) / (BAL_THREADS / GROUP);
-	if (p.nlevels < 2 || p.nwg < 8 || (p.nwg & 7) || p.slY != 0 || p.jham[0] != nullptr || p.nrep > 0 || p.color != 0 || !p.sp_masks || !p.sp_ctr || !p.sp_flags) return hipErrorInvalidValue;
+	if (p.nlevels < 2 || p.nwg < 8 || p.slY != 0 || p.jham[0] != nullptr || p.nrep > 0 || p.color != 0 || p.nt_stream || !p.sp_masks || !p.sp_ctr || !p.sp_flags) return hipErrorInvalidValue;
 	if (p.cus <= 0) p.cus = 256;
-	const bool count = p.cnt_acc != nullptr, streamed = p.nt_stream != 0;
+	const bool count = p.cnt_acc != nullptr;
 	const long long grid = std::max<long long>(8, std::min<long long>((long long)p.sp_cap * 8, (long long)(p.wg_per_cu > 0 ? p.wg_per_cu : 6) * p.cus));
 	const dim3 g((unsigned)grid), block(BAL_THREADS);
-	if (count) {
-		if (streamed) hipExtLaunchKernelGGL((ballot_split_k<true, true>), g, block, 0, stream, start, stop, 0, p);
-		else hipExtLaunchKernelGGL((ballot_split_k<false, true>), g, block, 0, stream, start, stop, 0, p);
-	} else {
-		if (streamed) hipExtLaunchKernelGGL((ballot_split_k<true, false>), g, block, 0, stream, start, stop, 0, p);
-		else hipExtLaunchKernelGGL((ballot_split_k<false, false>), g, block, 0, stream, start, stop, 0, p);
-	}
+	if (count) hipExtLaunchKernelGGL((ballot_split_k<true>), g, block, 0, stream, start, stop, 0, p);
+	else hipExtLaunchKernelGGL((ballot_split_k<false>), g, block, 0, stream, start, stop, 0, p);
 	if (grid_out) *grid_out = (int)grid;
 #if defined(ISING_FUSED_TRACE)
 	ballot_trace_is_split();

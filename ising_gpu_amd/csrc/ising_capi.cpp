@@ -537,6 +537,30 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	    fused_tickets(c->nwc(), launch_rows, 2) >= 512 && (c->nwc() == 1 || fused_wgs_for(fused_tickets(c->nwc(), launch_rows, 2), 2, true, c->nwc()) >= 3)) c->H = 2;
 	// (... where a row is one wave column; rows of several want more tickets a level: 32768 x 1024 ran 745 with two-row units, 2446 with one-row units,
 	// 16384 x 2048 2199 / 2575, 65536 x 512 371 / 1523 -- profiles/small_fused_probe_r04.txt)
+	// Split launches (round 5; ising_ballot.hip: ballot_split_k) carry the sweeps of a slab whose levels have too few tickets for tall strips in the fused form:
+	// a lone slab that wraps in place or a ring slab with ghost rows, no sub-lattices, no couplings, a lattice the memory-side cache holds (the masks travel through
+	// memory: 4 bits a site next to the lattice's 3).  ISING_SPLIT=1 asks for them wherever they apply, 0 never; otherwise by measurement (tools/ab_probe.py on two
+	// boxes, profiles/split_probe_r05e.txt, split_depth_probe_r05.txt; flips/ns split / fused at the fused form's best shape of that box):
+	//   8192^2 3256 / 3067 (H = 4)   8192 x 16384 3419 / 3338 (H = 8)   16384^2 3407 / 3392 (the fused form's 3392 needs eight-row strips at six per CU: 835 on the
+	//   next box, where the split form does 3391 -- it has no such cliffs)   65536 x 8192 3403 / 3380   24576^2 3412 / 3395   32768^2 and 65536 x 16384: equal   65536^2: 3481 / 3513
+	// -- the split form wins while sixteen-row strips make fewer than 2048 tickets a level; its strips are the tallest that still make 512 (8192 x 4096 at H = 4,
+	// 256 tickets: 513 flips/ns), four rows at least, five workgroups per CU (six: +0..1 % on one box, -3..4 % on another).
+	{
+		const bool nt = pol.fused_nt >= 0 ? pol.fused_nt != 0 : spins > (1LL << 31);
+		const bool can = ((fused_shape && c->wrap) || deep_ring) && !cfg->XSL && !cfg->use_J && !nt && pol.split != 0 && c->nwc() < 128;
+		const int Yd = cfg->Y; // strips divide the slab's own rows
+		if (can && pol.split == 1) {
+			c->split = fused_tickets(c->nwc(), launch_rows, c->H) >= 8;
+		} else if (can && !small_fused) {
+			const bool few = fused_tickets(c->nwc(), launch_rows, 16) < 2048;
+			if (cfg->strip_rows > 0) {
+				c->split = few && c->H >= 4 && c->H <= 16 && fused_tickets(c->nwc(), launch_rows, c->H) >= 512;
+			} else if (few) {
+				for (int h = 16; h >= 4 && !c->split; h >>= 1)
+					if (Yd % h == 0 && fused_tickets(c->nwc(), launch_rows, h) >= 512) { c->split = true; c->H = h; }
+			}
+		}
+	}
 	if (cfg->Y % c->H) { const int h = c->H; delete c; return fail(ISING_E_ARG, "strip_rows %d does not divide Y %d", h, cfg->Y); }
 	c->nstrips = cfg->Y / c->H;
 	c->color_words = (size_t)cfg->Y * c->lld;
@@ -602,20 +626,14 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		if (pol.fused_tickets2 >= 0) c->fused_tickets2 = pol.fused_tickets2;
 	}
 
-	// Split launches (round 5; ising_ballot.hip: ballot_split_k) carry the sweeps of a lone slab whose levels have too few tickets for tall strips in the fused form:
-	// ISING_SPLIT=1 asks for them wherever they apply (a lone slab that wraps in place, no sub-lattices, no couplings, a level's tickets a multiple of 8).
-	if (fused_shape && !deep_ring && c->wrap && !cfg->XSL && !cfg->use_J && pol.split == 1) {
-		const long long T = fused_tickets(c->nwc(), cfg->Y, c->H);
-		const int wgs = pol.fused_wgs > 0 ? std::max(8, pol.fused_wgs) : 6 * c->cus;
-		if (T >= 8 && (T % 8) == 0 && ((long long)4 * c->nwc() * c->nstrips) % 16 == 0) {
-			c->split = true;
-			c->split_lead = pol.split_lead >= 0 ? pol.split_lead : 1;
-			c->split_cap = (wgs / 8) * 5 / 4 + 1; // an eighth of the grid and a margin: what a class serves (the rest of an uneven placement leaves)
-			int sh = 3;
-			while ((1 << sh) < (c->split_lead + 1) * c->split_cap) sh++;
-			c->split_ring_sh = sh;
-			c->fused_wg_per_cu = std::max(1, wgs / c->cus);
-		}
+	if (c->split) { // (decided above, with the strip height)
+		int wgs = pol.fused_wgs > 0 ? std::max(8, pol.fused_wgs) : 5 * c->cus;
+		c->split_lead = pol.split_lead >= 0 ? pol.split_lead : 1;
+		c->split_cap = (wgs / 8) * 5 / 4 + 1; // an eighth of the grid and a margin: what a class serves (the rest of an uneven placement leaves)
+		int sh = 3;
+		while ((1 << sh) < (c->split_lead + 1) * c->split_cap) sh++;
+		c->split_ring_sh = sh;
+		c->fused_wg_per_cu = std::max(1, wgs / c->cus);
 	}
 
 	hipError_t e = hipSetDevice(cfg->device);

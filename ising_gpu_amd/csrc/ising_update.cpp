@@ -142,7 +142,8 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 		}
 		int grid = 0;
 		// the split form of a fused launch over the whole slab (ising_ballot.hip: ballot_split_k): its ticket words and slot counts start from zero
-		const bool split = c->split && nlevels > 1 && lo0 == 0 && hi0 == c->cfg.Y && hi1 == lo1 && color == ISING_BLACK && c->d_split_masks && c->d_split_ctl;
+		// (a launch of several levels covers the whole slab, or a ring slab with its ghost rows)
+		const bool split = c->split && nlevels > 1 && hi1 == lo1 && color == ISING_BLACK && c->d_split_masks && c->d_split_ctl;
 		if (split) {
 			HIP_TRY(hipMemsetAsync(c->d_split_ctl, 0, c->split_ctl_bytes, c->stream));
 			p.sp_ctr = c->d_split_ctl;
@@ -438,7 +439,7 @@ int ising_sweep_info(ising_ctx *c, int *fused, int *max_sweeps_per_launch) {
 	// (a ring slab with ghost rows G deep: the ring's sweeps are fused launches of G/2 sweeps between two exchanges)
 	const bool deep = ghost_sweeps(c);
 	const bool tiled = !f && !deep && sweeps_tiled(c, 2);
-	if (fused) *fused = (f && c->split && !c->cfg.XSL) ? 3 : ((f || deep) ? 1 : (tiled ? 2 : 0));
+	if (fused) *fused = ((f || deep) && c->split && !c->cfg.XSL) ? 3 : ((f || deep) ? 1 : (tiled ? 2 : 0));
 	if (max_sweeps_per_launch) *max_sweeps_per_launch = f ? ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y) : (deep ? c->ghost() / 2 : (tiled ? c->tile_sweeps : 0));
 	return ISING_OK;
 }
@@ -518,6 +519,14 @@ int ising_sweep_ghost(ising_ctx *c, int first_it, int nsweeps) {
 // bound after which they give up to `arg` polls (0: keep).  what = 2 ages every monotone counter of the slab, device and
 // host record together, as billions of sweeps would: the completion counters stand past the point where the next launch
 // starts them over, the exchange's counters (units that have left the edge rows, epochs) a few counts before 2^32.
+int ising_debug_launch_shape(ising_ctx *c, int *strip_rows, int *wg_per_cu, int *split_lead) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	if (strip_rows) *strip_rows = c->H;
+	if (wg_per_cu) *wg_per_cu = c->fused_wg_per_cu;
+	if (split_lead) *split_lead = c->split ? c->split_lead : 0;
+	return ISING_OK;
+}
+
 int ising_debug_fault(ising_ctx *c, int what, int arg) {
 	if (!c) return fail(ISING_E_ARG, "null context");
 	if (what == 2) {

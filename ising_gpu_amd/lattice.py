@@ -248,6 +248,12 @@ class IsingSlab:
         self.it += n
         return self
 
+    def launch_shape(self):
+        """Test aid (ising_debug_launch_shape): (strip rows, workgroups per CU, split lead) of this slab's fused launches."""
+        v = [C.c_int() for _ in range(3)]
+        check(self._lib.ising_debug_launch_shape(self._h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
     def debug_fault(self, what: int = 1, arg: int = 0):
         """Test aid (ising_debug_fault): leave the host's record of the completion counters out of step with the device."""
         check(self._lib.ising_debug_fault(self._h, what, arg))

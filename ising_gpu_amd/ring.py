@@ -532,15 +532,17 @@ def _agree(ok: bool) -> bool:
     return bool(int(t[0]))
 
 
-def open_native_ring(slab, log=None, transports=("rccl", "ipc")):
+def open_native_ring(slab, log=None, transports=("rccl", "ipc"), attempts=None):
     """The library's own ring on a slab that owns its buffer (ring slabs on the ballot layout then keep ghost rows 64 deep
     and exchange every 32 sweeps, csrc/ising_ring.cpp: sweep_deep): RCCL send/recv first, then the RCCL-free peer transport
     over hipIpcMemHandle (`transports`; ranks sharing a device go straight to the second -- RCCL refuses them).  Every
     rank takes the same decision: the outcome of each attempt is agreed on before anyone moves on.  None when no transport
-    comes up on every rank (the caller then builds a torch-owned slab and calls open_ring for the torch.distributed rings)."""
+    comes up on every rank (the caller then builds a torch-owned slab and calls open_ring for the torch.distributed rings).
+    `attempts` (a list, optional) receives one record per transport tried on THIS rank: {"transport", "ok", "error", "all_ranks_ok", "seconds"}."""
+    import time
     log = log or (lambda *a: None)
     for tr in transports:
-        ring = None
+        ring, err, t0 = None, None, time.perf_counter()
         try:
             ring = NativeRing(slab, transport=tr)
             ring.init()
@@ -550,8 +552,11 @@ def open_native_ring(slab, log=None, transports=("rccl", "ipc")):
             ok = True
         except Exception as e:  # noqa: BLE001 -- any transport failure means: the caller tries the next one
             log(f"ring transport {tr}-native failed on this rank: {e}")
-            ok = False
-        if _agree(ok):
+            ok, err = False, f"{type(e).__name__}: {e}"
+        agreed = _agree(ok)
+        if attempts is not None:
+            attempts.append({"transport": f"{tr}-native", "ok": ok, "error": err, "all_ranks_ok": agreed, "seconds": round(time.perf_counter() - t0, 3)})
+        if agreed:
             return ring
         if ring is not None:
             try:
@@ -566,7 +571,7 @@ def open_native_ring(slab, log=None, transports=("rccl", "ipc")):
     return None
 
 
-def open_ring(backend: "HipSlabBackend", prefer: str = "native", exchange: Optional[str] = None, log=None):
+def open_ring(backend: "HipSlabBackend", prefer: str = "native", exchange: Optional[str] = None, log=None, attempts_out=None):
     """The ring a multi-process driver (bench.py) should use: the library's own RCCL ring when it comes up, otherwise
     the torch.distributed one (p2p, then all-gather).  Every rank takes the same decision: the outcome of each attempt is
     agreed on with an all-reduce before anyone moves on.  Returns (ring, name)."""
@@ -606,7 +611,10 @@ def open_ring(backend: "HipSlabBackend", prefer: str = "native", exchange: Optio
             last = e
             ok = False
             log(f"ring transport {name} failed on this rank: {e}")
-        if agreed(ok):
+        all_ok = agreed(ok)
+        if attempts_out is not None:
+            attempts_out.append({"transport": name if name == "rccl-native" else f"torch-{name}", "ok": ok, "error": None if ok else f"{type(last).__name__}: {last}", "all_ranks_ok": all_ok})
+        if all_ok:
             return ring, name
         if ring is not None and name == "rccl-native":
             try:

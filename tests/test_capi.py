@@ -20,7 +20,7 @@ def header_symbols(which=("ising_hip.h", "ising_hip_testing.h")):
 
 def test_headers_under_include_are_all_known():
     assert sorted(f for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h")) == ["ising_hip.h", "ising_hip_testing.h"]
-    assert header_symbols(("ising_hip_testing.h",)) == ["ising_batch_debug_fault", "ising_debug_fault"]      # test aids stay out of the boundary header
+    assert header_symbols(("ising_hip_testing.h",)) == ["ising_batch_debug_fault", "ising_debug_fault", "ising_debug_launch_shape"]      # test aids stay out of the boundary header
     assert "ising_debug_fault" not in header_symbols(("ising_hip.h",))
 
 
@@ -170,7 +170,10 @@ def test_hand_waited_loads_of_the_fused_kernels_pass_the_isa_check():
     csrc = os.path.join(ROOT, "ising_gpu_amd", "csrc")
     subprocess.check_call(["make", "-s", "-C", csrc, "check-asm"])   # (no-op when the library was built from these sources)
     report = open(os.path.join(csrc, ".ising_ballot.s.report")).read().splitlines()
-    fused = [ln for ln in report if "Lb1ELi" in ln]                  # ballot_update_k<SUBL, USEJ, FUSED = true, NT>
+    fused = [ln for ln in report if "ballot_update_k" in ln and "Lb1ELi" in ln]   # ballot_update_k<SUBL, USEJ, FUSED = true, NT>
     # (six lattice / mask loads of the row loop; the unit's first two rows at the two places a unit may wait late -- five more loads with the row-end word)
     assert len(fused) == 10 and all(ln.endswith("11 inline-assembly loads checked") for ln in fused), report
+    # the split launches' word units (round 5): two loads for a unit's first rows, four per row; the looks of its waits carry their own
+    split = [ln for ln in report if "ballot_split_k" in ln]
+    assert len(split) == 2 and all(ln.endswith("6 inline-assembly loads checked") for ln in split), report
     assert not any("touches" in ln for ln in report)

@@ -1,0 +1,79 @@
+"""The launch-shape policy of ising_create (csrc/ising_capi.cpp: fused_shape, fused_wgs_for, the split form's rule) defended by measurement: on the shapes
+where round 4's probes found cliffs (8192 x 1536, 16384 x 2176, 65536 x 1024, 131072 x 2048), BASELINE config 2 and the slabs a strong-scaling split of
+65536^2 produces, the library's choice must not be more than 3 % behind the best of its four neighbours -- half and twice the strip height, one workgroup
+per CU fewer and more -- measured right here, on this box, same form of launch.  A driver, clock or firmware change that moves a cliff under the table's
+feet fails this test instead of silently costing a third of the rate (8192 x 1536 ran 1355 against 1699 flips/ns one grid step apart).
+
+Not a parity test: results are compared across shapes only as a sanity check (every cell's counts after the same sweeps are equal)."""
+import os
+
+import pytest
+
+import ising_gpu_amd as ig
+
+pytestmark = pytest.mark.gpu
+TC = ig.CRIT_TEMP_F32
+TOL = 0.03
+
+SHAPES = [  # (X, Y): lattice columns, rows
+    (8192, 1536), (16384, 2176), (65536, 1024), (131072, 2048),      # the cliffs of round 4's wide / small probes
+    (8192, 8192), (16384, 16384),                                     # 2^26 spins; BASELINE config 2
+    (65536, 32768), (65536, 16384), (65536, 8192),                    # north_star's 65536^2 over 2 / 4 / 8 GPUs: a rank's rows as a lone slab
+    (24576, 24576), (8192, 4096), (32768, 4096),
+]
+
+
+def _rate(X, Y, H=0, wgs=0, monkeypatch=None, check=None):
+    """flips/ns of ising_sweep on a lone X x Y lattice at strip height H and wgs workgroups per CU (0: the library's choice); best of 3 pieces of ~25 ms"""
+    if wgs:
+        monkeypatch.setenv("ISING_FUSED_WGS", str(256 * wgs))
+    else:
+        monkeypatch.delenv("ISING_FUSED_WGS", raising=False)
+    sweeps = max(32, min(2048, int(25e-3 * 3.2e9 / (X * Y)) // 32 * 32))
+    with ig.IsingSlab(X, Y, seed=1234, temp=TC, strip_rows=H) as s:
+        shape = s.launch_shape()[:2] + (0, s.split, s.fused, s.layout)
+        s.init().sweep(32)
+        got = s.count()
+        if check is not None:
+            assert got == check, (X, Y, H, wgs, shape)
+        s.sweep_timed(sweeps)
+        best = max(X * Y * sweeps / (s.sweep_timed(sweeps) * 1e6) for _ in range(3))
+    return best, shape, got
+
+
+@pytest.fixture(scope="module")
+def warm_clock(gpu):
+    """the shader clock ramps over the first ~50 ms of load: nobody's first measurement should pay for it"""
+    with ig.IsingSlab(16384, 16384, seed=1, temp=TC) as s:
+        s.init()
+        for _ in range(4):
+            s.sweep_timed(64)
+    return True
+
+
+@pytest.mark.parametrize("X,Y", SHAPES)
+def test_library_choice_within_3_percent_of_its_neighbours(gpu, warm_clock, monkeypatch, X, Y):
+    monkeypatch.setenv("ISING_ABORT_POLLS", "40000")  # (a neighbour that lands beyond a cliff must cost milliseconds, not the watchdog's seconds)
+    mine, shape, counts = _rate(X, Y, monkeypatch=monkeypatch)
+    H, wg = shape[0], shape[1]
+    if not shape[4]:
+        pytest.skip(f"{Y} x {X}: no fused launches here (layout {shape[5]}): nothing of the launch-shape tables applies")
+    cells = {}
+    for h, w in ((H // 2, wg), (2 * H, wg), (H, wg - 1), (H, wg + 1)):
+        if h < 1 or h > 16 or Y % h or w < 1 or w > 6:
+            continue
+        try:
+            r, shp, _ = _rate(X, Y, h, w, monkeypatch, check=counts)
+        except ig.IsingError:
+            continue  # (a shape the library refuses, or one that gave up beyond a cliff)
+        if shp[3] != shape[3]:
+            continue  # (the other form of launch: not a neighbour)
+        cells[(h, w)] = r
+    best = max(cells.values(), default=0.0)
+    if mine < (1.0 - TOL) * best:  # once more, both sides: a single slow piece must not fail the suite
+        mine = max(mine, _rate(X, Y, monkeypatch=monkeypatch)[0])
+        hb, wb = max(cells, key=cells.get)
+        cells[(hb, wb)] = best = _rate(X, Y, hb, wb, monkeypatch)[0]
+    print(f"{Y} x {X}: library H={H} wgs={wg} split={int(shape[3])} {mine:.0f} flips/ns; neighbours " + ", ".join(f"H={h} wgs={w}: {r:.0f}" for (h, w), r in cells.items()))
+    assert mine >= (1.0 - TOL) * best, (f"{Y} x {X}: the library's H={H}, {wg} per CU ({'split' if shape[3] else 'fused'}) runs {mine:.0f} flips/ns, "
+                                        f"a neighbour {best:.0f}: {cells}")

@@ -70,3 +70,65 @@ def test_split_launches_low_temperature_and_long_launch(gpu, oracle_mod, monkeyp
     with ig.IsingSlab(X, Y, seed=ig.SEED_DEF, temp=1.5, layout=ig.LAYOUT_BALLOT, strip_rows=2) as s:
         s.init().sweep(600)
         assert _same(s, orc)
+
+
+@pytest.mark.parametrize("X,Y,H,lead,wgs,sweeps", [
+    (8192, 176, 4, 1, None, (3, 4)), (8192, 720, 16, 1, None, (5,)), (12288, 80, 4, 1, 96, (2, 7)), (20480, 80, 2, 0, None, (6,)),
+    (8192, 2032, 8, 1, None, (9,)), (16384, 1008, 8, 2, None, (4, 4)),
+])
+def test_split_launches_any_ticket_count(gpu, oracle_mod, monkeypatch, X, Y, H, lead, wgs, sweeps):
+    """levels whose tickets are not a multiple of eight (11, 12, 10, 30, 64 with a workgroup whose last waves have no unit, 63)"""
+    _env(monkeypatch, lead, wgs)
+    orc = oracle_mod.OracleLattice(X, Y, seed=15, temp=oracle_mod.CRIT_TEMP).init()
+    with ig.IsingSlab(X, Y, seed=15, temp=TC, layout=ig.LAYOUT_BALLOT, strip_rows=H) as s:
+        assert s.fused and s.split
+        s.init()
+        for n in sweeps:
+            s.sweep(n)
+            orc.sweep(n)
+            assert _same(s, orc), (X, Y, H, n)
+
+
+@pytest.mark.parametrize("nslabs,Yk,H", [(2, 256, 8), (3, 128, 4), (2, 192, 16), (4, 128, 8)])
+def test_split_ring_slabs_one_device(gpu, oracle_mod, monkeypatch, nslabs, Yk, H):
+    """ring slabs with ghost rows in the split form (global rows around the ring, the trapezoid, launches that take turns with copies of the ghost rows):
+    the whole lattice against the oracle, more sweeps than one exchange period"""
+    _env(monkeypatch)
+    X, seed, sweeps = 8192, 77, (3, 40, 33)
+    orc = oracle_mod.OracleLattice(X, Yk * nslabs, seed=seed, temp=oracle_mod.CRIT_TEMP).init()
+    ring = ig.SlabSet([ig.IsingSlab(X, Yk, seed=seed, temp=TC, nslabs=nslabs, slab=k, layout=ig.LAYOUT_BALLOT, strip_rows=H) for k in range(nslabs)])
+    try:
+        ring.init()
+        assert all(s.split for s in ring.slabs)
+        for n in sweeps:
+            ring.sweep(n)
+            orc.sweep(n)
+            assert np.array_equal(np.concatenate([s.read(ig.BLACK) for s in ring.slabs]), orc.black), n
+            assert np.array_equal(np.concatenate([s.read(ig.WHITE) for s in ring.slabs]), orc.white), n
+        assert ring.count() == orc.count() and ring.bond_equal() == orc.bond_equal()
+    finally:
+        ring.close()
+
+
+@pytest.mark.parametrize("every,energy", [(16, False), (5, True)])
+def test_split_ring_of_one_overlapped_and_counted(gpu, oracle_mod, monkeypatch, every, energy):
+    """the library's rank ring with one rank (RCCL to itself, the exchange next to the launches: edge units, edge_go / edge_done) in the split form, print
+    points inside the launches"""
+    import torch  # noqa: F401
+    _env(monkeypatch)
+    X, Y, seed = 8192, 512, 9
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=oracle_mod.CRIT_TEMP).init()
+    with ig.IsingSlab(X, Y, seed=seed, temp=TC, layout=ig.LAYOUT_BALLOT, strip_rows=8, ring_halo=True) as s:
+        ring = ig.NativeRing(s).init()
+        assert s.split
+        for n in (70, 45):
+            got = ring.sweep_counted(n, every, energy)
+            want = []
+            for _ in range(n):
+                orc.sweep(1)
+                if orc.it % every == 0:
+                    want.append(orc.count() + ((orc.bond_equal(),) if energy else ()))
+            assert [tuple(g) for g in got] == want
+        ring.quiesce()
+        assert _same(s, orc)
+        ring.close()

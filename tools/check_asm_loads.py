@@ -6,6 +6,10 @@ The scan is linear in text order, which is program order for the row loop these 
 counters (dword loads) are part of the scan since round 4: a look either carries its wait in the same statement or is waited for
 once, outside any loop, by the code that follows it in the text -- rounds 2-3 polled in a loop whose header held the wait, and
 the compiler's loop-carried copy of the register sat between the load and the wait.
+vmcnt counts loads AND stores, in issue order: the scan numbers every inline-assembly vector-memory operation (round 5: the split launches' word units keep several
+rows of loads in flight across the stores of the rows before), and `s_waitcnt vmcnt(n)` leaves the n youngest of them out.  Operations the compiler issues itself
+are not numbered -- they can only make a wait stricter than the scan assumes; inline-assembly operations must therefore not sit in branches of their own between a
+load and its wait (the mirror stores of the split form are ordinary stores for that reason).
 usage: check_asm_loads.py ising_ballot.s   (hipcc -S --cuda-device-only output)"""
 import re, sys
 
@@ -30,7 +34,7 @@ while i < len(lines):
     ln = lines[i]
     m = re.match(r"^(_Z\w*ballot_(?:update|split)_k\w*):", ln)
     if m:
-        kern, pending, nloads = m.group(1), {}, 0
+        kern, pending, nloads, nops = m.group(1), {}, 0, 0
     if kern and "s_endpgm" in ln:
         print(f"{kern}: {nloads} inline-assembly loads checked")
         kern = None
@@ -44,23 +48,23 @@ while i < len(lines):
             elif in_asm and (body.startswith("global_load_dwordx2") or body.startswith("global_load_dwordx4") or body.startswith("global_load_dword ")
                              or (body.startswith("global_atomic_add_x2") and " sc0" in body)):  # (a returning atomic: the next ticket)
                 dst = regs(body.split()[1].rstrip(","))
+                nops += 1
                 for r in dst:
-                    pending[r] = i + 1
+                    pending[r] = (nops, i + 1)
                 nloads += 1
                 used = operands(body.split(",", 1)[1])  # address operands of the load itself
+            elif in_asm and body.startswith("global_store_dword"):
+                nops += 1  # (a store issued as inline assembly takes a place in the queue)
+                used = operands(body)
             elif in_asm and body.startswith("s_waitcnt") and "vmcnt" in body:
                 n = int(re.search(r"vmcnt\((\d+)\)", body).group(1))
-                if n == 0:
-                    pending.clear()
-                else:  # the n youngest loads may stay out: drop all but the registers of the n most recent loads
-                    order = sorted(set(pending.values()))
-                    keep = set(order[-n:]) if n <= len(order) else set(order)
-                    pending = {r: l for r, l in pending.items() if l in keep}
+                # the n youngest operations may stay out: everything older has landed
+                pending = {r: v for r, v in pending.items() if v[0] > nops - n}
                 used = set()
             else:
                 used = operands(body)
             for r in used & set(pending):
-                print(f"{kern}: line {i + 1} touches v{r}, loaded by inline assembly at line {pending[r]} and not yet waited for: {body}")
+                print(f"{kern}: line {i + 1} touches v{r}, loaded by inline assembly at line {pending[r][1]} and not yet waited for: {body}")
                 bad += 1
     i += 1
 sys.exit(1 if bad else 0)
