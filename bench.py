@@ -69,6 +69,18 @@ def cgroup_cpus():
         return None
 
 
+def exchange_overlap(ring_name):
+    """What "the exchange next to the launches" means per transport: measured on a ring of one, profiles/strong_slab_probe_r04.txt."""
+    if ring_name.startswith("rccl"):
+        return ("tail-serialised: RCCL's send/recv kernel (132 vector registers a lane) finds no room next to the persistent grid and runs when the launch's workgroups "
+                "retire; the next launch waits for it (ev_go).  Ring of one: +0.01..0.04 ms past the launch's end, a gap of 11-44 us per 32 sweeps (<= 0.9 %)")
+    if ring_name.startswith("ipc"):
+        return "inside the launch: one-lane kernels and peer stores on the comm stream move the rows while the launch works on the slab's interior"
+    if ring_name == "none":
+        return None
+    return "between launches (torch.distributed ring: the rows travel when the launch has ended)"
+
+
 def first_contact_block(args, ig, torch, dist, world, rank, device, ndev, shared, attempts, layout, ctl, value, xstats):
     """Keys that make the first run on a multi-GPU node explain itself (collective: every rank calls it; rank 0 uses the result).
     transport_attempts: per rank, every transport tried with "ok" or its error string; ranks: device ordinal, PCI bus id, the row of the peer-access matrix,
@@ -636,7 +648,7 @@ def main():
             "config": {"workload": f"{args.workload}: {args.y * world}x{args.x} lattice ({args.y}x{args.x} per GPU), T=Tc, seed {args.seed}, "
                                    "Philox4x32-10 per site; device layout " + layout_text
                                    + ", results identical to the reference's packed state", "x": args.x, "y_per_gpu": args.y, "y_total": args.y * world,
-                       "parallelism": f"slab{world}", "nranks": world, "physical_gpus": min(world, ndev), "exchange": ring_name, "strip_rows": slab.strip_rows,
+                       "parallelism": f"slab{world}", "nranks": world, "physical_gpus": min(world, ndev), "exchange": ring_name, "exchange_overlap": exchange_overlap(ring_name), "strip_rows": slab.strip_rows,
                        "device_layout": layout_name, "sweeps_per_call": batch, "warmup_sweeps_per_call": batch_warm, "preheat_ms": args.preheat_ms, "preheat_sweeps": preheat_sweeps,
                        "up": up, "down": down, "rank_up": rank_up, "parity_checked": parity,
                        "parity_source": None if gold is None else "tests/golden (CPU oracle on the whole lattice, same seed, same number of sweeps; any decomposition)"},

@@ -543,21 +543,28 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// boxes, profiles/split_probe_r05e.txt, split_depth_probe_r05.txt; flips/ns split / fused at the fused form's best shape of that box):
 	//   8192^2 3256 / 3067 (H = 4)   8192 x 16384 3419 / 3338 (H = 8)   16384^2 3407 / 3392 (the fused form's 3392 needs eight-row strips at six per CU: 835 on the
 	//   next box, where the split form does 3391 -- it has no such cliffs)   65536 x 8192 3403 / 3380   24576^2 3412 / 3395   32768^2 and 65536 x 16384: equal   65536^2: 3481 / 3513
-	// -- the split form wins while sixteen-row strips make fewer than 2048 tickets a level; its strips are the tallest that still make 512 (8192 x 4096 at H = 4,
-	// 256 tickets: 513 flips/ns), four rows at least, five workgroups per CU (six: +0..1 % on one box, -3..4 % on another).
+	// -- the split form wins while sixteen-row strips make fewer than 2048 tickets a level; its strips are the tallest that still make 512 tickets (8192 x 4096 at
+	// H = 4, 256 tickets: 513 flips/ns) AND 512 strips (65536 x 1024 at H = 4, 256 strips of eight wave columns: 544 against the fused form's 2615; 131072 x 2048 at
+	// H = 16, 128 strips: 2473 against 3197 -- a strip's counter waits for ALL its wave columns), four rows at least, rows of eight wave columns at most (what was
+	// measured), five workgroups per CU (six: +0..1 % on one box, -3..4 % on another).  tests/test_gpu_policy.py holds the choice against its neighbours and the other form.
 	{
 		const bool nt = pol.fused_nt >= 0 ? pol.fused_nt != 0 : spins > (1LL << 31);
 		const bool can = ((fused_shape && c->wrap) || deep_ring) && !cfg->XSL && !cfg->use_J && !nt && pol.split != 0 && c->nwc() < 128;
 		const int Yd = cfg->Y; // strips divide the slab's own rows
 		if (can && pol.split == 1) {
 			c->split = fused_tickets(c->nwc(), launch_rows, c->H) >= 8;
-		} else if (can && !small_fused) {
-			const bool few = fused_tickets(c->nwc(), launch_rows, 16) < 2048;
+		} else if (can && !small_fused && !deep_ring) {
+			// (lone slabs only: their launches carry ~50 ms of sweeps.  A launch in the split form ends on word units alone -- the last (lead + 1) x grid of them, five
+			// levels deep at 16384^2, memory round trips with an idle vector ALU: ~0.1 ms more per launch than the fused form (rocprofv3, 16 sweeps of 16384^2 per launch:
+			// 1450 against 1346 us, profiles/rocprof_r05_config2_split.txt / _fused.txt) --, which a ring slab's launches of 32 sweeps do not earn back; ISING_SPLIT=1 still
+			// puts ring slabs on it)
+			const bool few = fused_tickets(c->nwc(), launch_rows, 16) < 2048 && c->nwc() <= 8;
+			auto feeds = [&](int h) { return launch_rows / h >= 512 && fused_tickets(c->nwc(), launch_rows, h) >= 512; };
 			if (cfg->strip_rows > 0) {
-				c->split = few && c->H >= 4 && c->H <= 16 && fused_tickets(c->nwc(), launch_rows, c->H) >= 512;
+				c->split = few && c->H >= 4 && c->H <= 16 && feeds(c->H);
 			} else if (few) {
 				for (int h = 16; h >= 4 && !c->split; h >>= 1)
-					if (Yd % h == 0 && fused_tickets(c->nwc(), launch_rows, h) >= 512) { c->split = true; c->H = h; }
+					if (Yd % h == 0 && feeds(h)) { c->split = true; c->H = h; }
 			}
 		}
 	}

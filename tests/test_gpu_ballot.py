@@ -112,11 +112,15 @@ def test_auto_layout_picks_ballot_where_it_applies(gpu):
     with ig.IsingSlab(16384, 8192, temp=1.5) as s:      # from 2^27 spins per slab up
         assert s.layout == BAL
     with ig.IsingSlab(8192, 8192, temp=1.5) as s:       # from 2^26 spins where ising_sweep's fused launches apply ...
-        assert s.layout == BAL and s.fused and s.strip_rows == 2
+        assert s.layout == BAL and s.fused and s.split and s.strip_rows == 4   # (round 5: the split form where sixteen-row strips make under 2048 tickets a level)
     with ig.IsingSlab(16384, 16384, temp=1.5) as s:     # fused launches all the way up, strip height by tickets per level
-        assert s.layout == BAL and s.fused and s.strip_rows == 4
+        assert s.layout == BAL and s.fused and s.split and s.strip_rows == 16
+    with ig.IsingSlab(32768, 32768, temp=1.5) as s:
+        assert s.layout == BAL and s.fused and not s.split and s.strip_rows == 8
+    with ig.IsingSlab(65536, 1024, temp=1.5) as s:      # (wide and short: too few strips for the split form)
+        assert s.layout == BAL and s.fused and not s.split
     with ig.IsingSlab(8192, 8192, temp=1.5, ring_halo=True) as s:   # ... also for a ring slab: ghost rows, fused launches between exchanges
-        assert s.layout == BAL and s.fused and s.strip_rows == 2 and s.ghost_ptrs(ig.BLACK)[0] == 64
+        assert s.layout == BAL and s.fused and not s.split and s.strip_rows == 2 and s.ghost_ptrs(ig.BLACK)[0] == 64
     with ig.IsingSlab(8192, 8192, temp=1.5, nslabs=2, J_prob=0.2) as s:   # (with -J too)
         assert s.layout == BAL and s.fused
     with ig.IsingSlab(8192, 4096, temp=1.5) as s:       # ... down to 2^25 spins

@@ -1,7 +1,7 @@
 """The launch-shape policy of ising_create (csrc/ising_capi.cpp: fused_shape, fused_wgs_for, the split form's rule) defended by measurement: on the shapes
 where round 4's probes found cliffs (8192 x 1536, 16384 x 2176, 65536 x 1024, 131072 x 2048), BASELINE config 2 and the slabs a strong-scaling split of
 65536^2 produces, the library's choice must not be more than 3 % behind the best of its four neighbours -- half and twice the strip height, one workgroup
-per CU fewer and more -- measured right here, on this box, same form of launch.  A driver, clock or firmware change that moves a cliff under the table's
+per CU fewer and more -- and the other form of launch (fused / split), measured right here, on this box.  A driver, clock or firmware change that moves a cliff under the table's
 feet fails this test instead of silently costing a third of the rate (8192 x 1536 ran 1355 against 1699 flips/ns one grid step apart).
 
 Not a parity test: results are compared across shapes only as a sanity check (every cell's counts after the same sweeps are equal)."""
@@ -19,17 +19,19 @@ SHAPES = [  # (X, Y): lattice columns, rows
     (8192, 1536), (16384, 2176), (65536, 1024), (131072, 2048),      # the cliffs of round 4's wide / small probes
     (8192, 8192), (16384, 16384),                                     # 2^26 spins; BASELINE config 2
     (65536, 32768), (65536, 16384), (65536, 8192),                    # north_star's 65536^2 over 2 / 4 / 8 GPUs: a rank's rows as a lone slab
-    (24576, 24576), (8192, 4096), (32768, 4096),
+    (24576, 24576), (8192, 4096), (32768, 4096), (24576, 4096),
 ]
 
 
-def _rate(X, Y, H=0, wgs=0, monkeypatch=None, check=None):
-    """flips/ns of ising_sweep on a lone X x Y lattice at strip height H and wgs workgroups per CU (0: the library's choice); best of 3 pieces of ~25 ms"""
-    if wgs:
-        monkeypatch.setenv("ISING_FUSED_WGS", str(256 * wgs))
-    else:
-        monkeypatch.delenv("ISING_FUSED_WGS", raising=False)
-    sweeps = max(32, min(2048, int(25e-3 * 3.2e9 / (X * Y)) // 32 * 32))
+def _rate(X, Y, H=0, wgs=0, monkeypatch=None, check=None, split=None):
+    """flips/ns of ising_sweep on a lone X x Y lattice at strip height H and wgs workgroups per CU (0: the library's choice), in the form of launch the library
+    picks (split = None) or the one asked for (0: fused, 1: split); best of 3 pieces of ~25 ms"""
+    for k, v in (("ISING_FUSED_WGS", 256 * wgs if wgs else None), ("ISING_SPLIT", split)):
+        if v is None:
+            monkeypatch.delenv(k, raising=False)
+        else:
+            monkeypatch.setenv(k, str(v))
+    sweeps = max(32, min(2048, int(25e-3 * 3.2e12 / (X * Y)) // 32 * 32))  # (3.2 flips/ns = 3.2e12 flips/s)
     with ig.IsingSlab(X, Y, seed=1234, temp=TC, strip_rows=H) as s:
         shape = s.launch_shape()[:2] + (0, s.split, s.fused, s.layout)
         s.init().sweep(32)
@@ -68,12 +70,21 @@ def test_library_choice_within_3_percent_of_its_neighbours(gpu, warm_clock, monk
             continue  # (a shape the library refuses, or one that gave up beyond a cliff)
         if shp[3] != shape[3]:
             continue  # (the other form of launch: not a neighbour)
-        cells[(h, w)] = r
+        cells[(h, w, None)] = r
+    # ... and the other form of launch, at the shape the library gives it (split launches apply to lattices the memory-side cache holds)
+    other = 0 if shape[3] else 1
+    try:
+        r, shp, _ = _rate(X, Y, 0, 0, monkeypatch, check=counts, split=other)
+        if bool(shp[3]) == bool(other):
+            cells[(shp[0], shp[1], other)] = r
+    except ig.IsingError:
+        pass
     best = max(cells.values(), default=0.0)
     if mine < (1.0 - TOL) * best:  # once more, both sides: a single slow piece must not fail the suite
         mine = max(mine, _rate(X, Y, monkeypatch=monkeypatch)[0])
-        hb, wb = max(cells, key=cells.get)
-        cells[(hb, wb)] = best = _rate(X, Y, hb, wb, monkeypatch)[0]
-    print(f"{Y} x {X}: library H={H} wgs={wg} split={int(shape[3])} {mine:.0f} flips/ns; neighbours " + ", ".join(f"H={h} wgs={w}: {r:.0f}" for (h, w), r in cells.items()))
+        hb, wb, sb = max(cells, key=cells.get)
+        cells[(hb, wb, sb)] = best = _rate(X, Y, 0 if sb is not None else hb, 0 if sb is not None else wb, monkeypatch, split=sb)[0]
+    print(f"{Y} x {X}: library H={H} wgs={wg} split={int(shape[3])} {mine:.0f} flips/ns; neighbours "
+          + ", ".join(f"H={h} wgs={w}{'' if sp is None else (' split' if sp else ' fused')}: {r:.0f}" for (h, w, sp), r in cells.items()))
     assert mine >= (1.0 - TOL) * best, (f"{Y} x {X}: the library's H={H}, {wg} per CU ({'split' if shape[3] else 'fused'}) runs {mine:.0f} flips/ns, "
                                         f"a neighbour {best:.0f}: {cells}")

@@ -14,7 +14,7 @@ B, D = ig.LAYOUT_BALLOT, ig.LAYOUT_DENSE
 CASES = [  # X, Y, layout AUTO picks, fused, tiled, strip rows (0: whatever)
     (8192, 1280, B, True, False, 1), (8192, 2048, B, True, False, 1), (16384, 768, B, True, False, 1), (16384, 2048, B, True, False, 1),
     (24576, 896, B, True, False, 1), (32768, 640, B, True, False, 1), (32768, 1024, B, True, False, 1), (65536, 512, B, True, False, 1),
-    (16384, 2176, B, True, False, 2), (24576, 1536, B, True, False, 2), (131072, 1024, B, True, False, 4), (24576, 4096, B, True, False, 2),
+    (16384, 2176, B, True, False, 2), (24576, 1536, B, True, False, 2), (131072, 1024, B, True, False, 4), (24576, 4096, B, True, False, 4),
     (12288, 1536, B, True, False, 1), (6144, 3072, B, True, False, 1), (20480, 4096, B, True, False, 0), (28672, 4096, B, True, False, 0),
     (8192, 1024, D, False, True, 0), (4096, 4096, D, False, True, 0), (6144, 1024, D, False, True, 0), (2048, 8192, D, False, True, 0), (65536, 256, D, False, True, 0),
 ]

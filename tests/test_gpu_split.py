@@ -89,7 +89,7 @@ def test_split_launches_any_ticket_count(gpu, oracle_mod, monkeypatch, X, Y, H, 
             assert _same(s, orc), (X, Y, H, n)
 
 
-@pytest.mark.parametrize("nslabs,Yk,H", [(2, 256, 8), (3, 128, 4), (2, 192, 16), (4, 128, 8)])
+@pytest.mark.parametrize("nslabs,Yk,H", [(2, 256, 8), (3, 128, 4), (2, 384, 16), (4, 128, 8)])
 def test_split_ring_slabs_one_device(gpu, oracle_mod, monkeypatch, nslabs, Yk, H):
     """ring slabs with ghost rows in the split form (global rows around the ring, the trapezoid, launches that take turns with copies of the ghost rows):
     the whole lattice against the oracle, more sweeps than one exchange period"""

@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r05h_pytest.txt 2>&1; echo "pytest rc $?" >> gpurun_out/r05h_pytest.txt
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/r05h_pytest.txt 2>&1; echo "pytest rc $?" >> gpurun_out/r05h_pytest.txt
 timeout 600 python -m pytest tests/test_gpu_policy.py -q -s > gpurun_out/r05h_policy.txt 2>&1
 timeout 300 python bench.py > gpurun_out/r05h_bench.txt 2>&1
 timeout 300 python bench.py --steps 20 --warmup 5 > gpurun_out/r05h_bench_20_5.txt 2>&1

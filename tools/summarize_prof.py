@@ -43,10 +43,10 @@ def main():
         tot = sum(r[2] for r in rows)
         for n, c, s, a, mn, mx in rows:
             lines.append(f"{n[:28]:28s} {c:6d} {s/1e6:10.3f} {a/1e3:10.2f} {mn/1e3:10.2f} {mx/1e3:10.2f} {100*s/tot:6.2f}")
-            if "update_k" in n:
+            if "update_k" in n or "ballot_split_k" in n:
                 out["update_k_avg_us"] = a / 1e3
                 out["update_k_calls"] = c
-        vg = q(tr[0], "select distinct name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x from kernels where name like '%update_k%'")
+        vg = q(tr[0], "select distinct name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x from kernels where name like '%update_k%' or name like '%ballot_split_k%'")
         for r in vg:
             lines.append(f"   {r[0]}: vgpr {r[1]} agpr {r[2]} sgpr {r[3]} lds {r[4]} scratch {r[5]} grid {r[6]} wg {r[7]}")
     lines.append("")
@@ -55,8 +55,8 @@ def main():
     for db in sorted(glob.glob(os.path.join(src, "pmc_*", "*.db"))):
         try:
             # the timed launch only: the longest update_k dispatches (the warm-up launch carries a quarter of its levels)
-            rows = q(db, "select counter_name, avg(counter_value), count(*), avg(duration) from pmc_events where name like '%update_k%' "
-                         "and duration > 0.6 * (select max(duration) from pmc_events where name like '%update_k%') group by counter_name")
+            rows = q(db, "select counter_name, avg(counter_value), count(*), avg(duration) from pmc_events where (name like '%update_k%' or name like '%ballot_split_k%') "
+                         "and duration > 0.6 * (select max(duration) from pmc_events where name like '%update_k%' or name like '%ballot_split_k%') group by counter_name")
         except Exception as e:
             lines.append(f"{db}: {e}")
             continue

@@ -52,7 +52,7 @@ for X, Y in sizes:
     dflt, ok, _ = run(X, Y, {}, ref)
     print(f"  the library's choice: {dflt:7.1f} flips/ns  x {dflt / base:4.2f}  state {'==' if ok else '!='} per-colour launches", flush=True)
     rows = []
-    for TWI, TR, S, NT in ([(b, a, c, d) for a, b, c, d in SHAPES] if SHAPES else itertools.product((16, 32), (8, 16, 32, 64), (2, 3, 4, 6, 8), (256, 512, 1024))):
+    for TWI, TR, S, NT in ([(b, a, c, d) for a, b, c, d in SHAPES] if SHAPES else itertools.product((8, 16, 32), (8, 16, 32, 64), (2, 3, 4, 6, 8), (256, 512, 1024))):
         if Y % TR or (gx * 32) % TWI:
             continue
         tiles = (gx * 32 // TWI) * (Y // TR)
