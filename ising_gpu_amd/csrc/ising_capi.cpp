@@ -85,7 +85,7 @@ int check_abort(ising_ctx *c) {
 	if (c->d_slotctl) (void)hipMemset(c->d_slotctl, 0, c->slotctl_bytes);
 	if (c->d_edge) (void)hipMemset(c->d_edge, 0, 32 * sizeof(uint32_t));
 	for (auto &t : c->ticket_base2) t = 0;
-	c->done_base = 0;
+	c->done_base = c->split_done_base = 0;
 	c->edge_done_target = c->edge_go_epoch = 0;
 	c->go_set = false;
 	c->ghost_depth[0] = c->ghost_depth[1] = 0;
@@ -552,7 +552,8 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		const bool can = ((fused_shape && c->wrap) || deep_ring) && !cfg->XSL && !cfg->use_J && !nt && pol.split != 0 && c->nwc() < 128;
 		const int Yd = cfg->Y; // strips divide the slab's own rows
 		if (can && pol.split == 1) {
-			c->split = fused_tickets(c->nwc(), launch_rows, c->H) >= 8;
+			c->split = c->split_always = fused_tickets(c->nwc(), launch_rows, c->H) >= 8;
+			c->H_split = c->H;
 		} else if (can && !small_fused && !deep_ring) {
 			// (lone slabs only: their launches carry ~50 ms of sweeps.  A launch in the split form ends on word units alone -- the last (lead + 1) x grid of them, five
 			// levels deep at 16384^2, memory round trips with an idle vector ALU: ~0.1 ms more per launch than the fused form (rocprofv3, 16 sweeps of 16384^2 per launch:
@@ -562,9 +563,11 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 			auto feeds = [&](int h) { return launch_rows / h >= 512 && fused_tickets(c->nwc(), launch_rows, h) >= 512; };
 			if (cfg->strip_rows > 0) {
 				c->split = few && c->H >= 4 && c->H <= 16 && feeds(c->H);
+				c->H_split = c->H;
 			} else if (few) {
+				// (its strips are taller than the fused form's, which keeps its own shape: a call of few sweeps runs that -- ising_update.cpp: split_pays)
 				for (int h = 16; h >= 4 && !c->split; h >>= 1)
-					if (Yd % h == 0 && feeds(h)) { c->split = true; c->H = h; }
+					if (Yd % h == 0 && h >= c->H && feeds(h)) { c->split = true; c->H_split = h; }
 			}
 		}
 	}
@@ -640,7 +643,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		int sh = 3;
 		while ((1 << sh) < (c->split_lead + 1) * c->split_cap) sh++;
 		c->split_ring_sh = sh;
-		c->fused_wg_per_cu = std::max(1, wgs / c->cus);
+		c->split_wg_per_cu = std::max(1, wgs / c->cus);
 	}
 
 	hipError_t e = hipSetDevice(cfg->device);
@@ -685,12 +688,13 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		// two-stream schedule gave wrong spins at 65536^2 (tools/ring_parity_probe.py), unnoticed at test sizes.
 		if (e == hipSuccess) e = hipMalloc((void **)&c->d_scratch_edge, ((size_t)2 * c->nwc() + 8) * 2048);
 		// ticket words (chunk counter + 8 queue words, 64 bytes apart) + one completion counter per strip (fused launches)
-		const size_t ctl_bytes = SLOTCTL_TICKET_BYTES + ((size_t)c->nstrips + 2 * (size_t)c->ghost_rows + 2) * sizeof(uint32_t); // (+ strips of the ghost rows)
+		// (the split form keeps completion counters of its own behind those: its strips are other strips, and both sets are counts that start a launch from a common base)
+		const size_t ctl_bytes = SLOTCTL_TICKET_BYTES + 2 * ((size_t)c->nstrips + 2 * (size_t)c->ghost_rows + 2) * sizeof(uint32_t); // (+ strips of the ghost rows)
 		if (e == hipSuccess) e = hipMalloc((void **)&c->d_slotctl, ctl_bytes);
 		if (e == hipSuccess) e = hipMemset(c->d_slotctl, 0, ctl_bytes);
 		c->slotctl_bytes = ctl_bytes;
 		if (e == hipSuccess && c->split) {
-			const size_t mask_bytes = ((size_t)8 << c->split_ring_sh) * 4 * (size_t)c->H * 1024;
+			const size_t mask_bytes = ((size_t)8 << c->split_ring_sh) * 4 * (size_t)c->H_split * 1024;
 			c->split_ctl_bytes = 8 * 16 * sizeof(unsigned long long) + ((size_t)8 << c->split_ring_sh) * 2 * sizeof(uint32_t);
 			e = hipMalloc((void **)&c->d_split_masks, mask_bytes);
 			if (e == hipSuccess) e = hipMalloc((void **)&c->d_split_ctl, c->split_ctl_bytes);
@@ -806,8 +810,9 @@ int ising_get_tables(ising_ctx *c, float exp_table[10], uint64_t thr[5]) {
 
 int ising_strip_info(ising_ctx *c, int *strip_rows, int *nstrips) {
 	if (!c) return fail(ISING_E_ARG, "null context");
-	if (strip_rows) *strip_rows = c->H;
-	if (nstrips) *nstrips = c->nstrips;
+	// (a slab whose long calls run split launches: their strips)
+	if (strip_rows) *strip_rows = c->split ? c->H_split : c->H;
+	if (nstrips) *nstrips = c->split ? c->cfg.Y / c->H_split : c->nstrips;
 	return ISING_OK;
 }
 

@@ -69,6 +69,11 @@ struct ising_ctx {
 	unsigned long long ticket_base2[4] = {0, 0, 0, 0}; // fused launches: where the launches so far left the ticket counter(s)
 	int fused_tickets2 = 0;                      // ... two counters (small lattices: one cannot hand tickets out fast enough)
 	bool split = false;            // ... in the split form (ballot_split_k): draw units and word units with tickets of their own, masks through a ring per XCD
+	bool split_always = false;     // ISING_SPLIT=1: every launch of several levels; otherwise (ising_create's own choice) the calls that carry split_min_flips and more
+	int H_split = 0;               // strip height of the split launches (>= H, the fused launches' -- a call too short for the split form runs those)
+	int split_wg_per_cu = 0;       // their persistent grid
+	uint32_t split_done_base = 0;  // their completion counters (behind the fused form's in d_slotctl) start every launch from here
+	bool split_next = false;       // one-shot: the caller of launch_ranges decided for the split form (sweep_alone, ising_sweep_counted: by the sweeps of the call)
 	int split_ring_sh = 0, split_lead = 1, split_cap = 0; // ring slots per class (log2), lead, workgroups a class serves
 	uint64_t *d_split_masks = nullptr;            // 8 x 2^split_ring_sh slots x 4 waves x H rows x 1 KiB
 	unsigned long long *d_split_ctl = nullptr;    // 8 x 16 ticket words, then 8 x 2^split_ring_sh x 2 slot counts (32-bit); zeroed in front of every launch

@@ -29,6 +29,8 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	const int cnt_first = c->cnt_first_next, cnt_every = c->cnt_every_next;
 	const int cnt_slot0 = c->cnt_slot0_next;
 	const bool cnt_bonds = c->cnt_bonds_next;
+	const bool split_asked = c->split_next;
+	c->split_next = false;
 	c->cnt_every_next = 0;
 	c->cnt_bonds_next = false;
 	if (!stop) stop = c->launch_stop_next;
@@ -72,7 +74,10 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	p.row_base = (uint32_t)c->cfg.slab * (uint32_t)c->cfg.Y;
 	p.slV = c->cfg.XSL ? c->cfg.XSL / 64 : c->gx * 32; // (XSL/2)/SPIN_X_WORD/2, optimized/main.cu:1771
 	p.slY = c->cfg.XSL ? c->cfg.YSL : 0;
-	p.H = c->H;
+	// the split form of a fused launch (ising_ballot.hip: ballot_split_k; a launch of several levels covers the whole slab, or a ring slab with its ghost rows): strips of its own
+	const bool split = c->ballot && c->split && nlevels > 1 && hi1 == lo1 && color == ISING_BLACK && c->d_split_masks && c->d_split_ctl && (c->split_always || split_asked);
+	const int HL = split ? c->H_split : c->H;
+	p.H = HL;
 	p.row_lo[0] = lo0; p.row_hi[0] = hi0;
 	p.row_lo[1] = lo1; p.row_hi[1] = hi1;
 	const int ugx = c->ballot ? 4 * c->nwc() : c->gx; // column groups per strip as the kernel counts them (ballot: 4 per wave column)
@@ -86,9 +91,9 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 		p.row_hi[0] = hi0; p.row_lo[1] = lo1; p.row_hi[1] = hi1;
 	}
 	p.H2 = H2;
-	p.nreal0 = ugx * ((hi0 - lo0 + c->H - 1) / c->H);
+	p.nreal0 = ugx * ((hi0 - lo0 + HL - 1) / HL);
 	p.nunits0 = (c->ballot && H2) ? (p.nreal0 + 15) / 16 * 16 : p.nreal0;
-	p.nunits = p.nunits0 + ugx * ((hi1 - lo1 + (H2 ? H2 : c->H) - 1) / (H2 ? H2 : c->H));
+	p.nunits = p.nunits0 + ugx * ((hi1 - lo1 + (H2 ? H2 : HL) - 1) / (H2 ? H2 : HL));
 	p.n3 = (uint32_t)c->thr[3];
 	p.n4 = (uint32_t)c->thr[4];
 	memcpy(p.tab, c->tab, sizeof(p.tab));
@@ -105,16 +110,19 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			p.abort_polls = c->pol.abort_polls;
 			for (int k = 0; k < 4; k++) p.ticket_base2[k] = c->ticket_base2[k]; // (the counters are never reset, ising_ballot.hip)
 			p.tickets2 = c->fused_tickets2;
-			if (c->done_base > (1u << 30)) { // keep the monotone completion counters far from wrapping
-				HIP_TRY(hipMemsetAsync(c->d_slotctl + SLOTCTL_TICKET_BYTES / 4, 0, ((size_t)c->nstrips + 2 * (size_t)c->ghost_rows + 2) * sizeof(uint32_t), c->stream));
-				c->done_base = 0;
+			const size_t done_words = (size_t)c->nstrips + 2 * (size_t)c->ghost_rows + 2; // (per form)
+			uint32_t *const done = c->d_slotctl + SLOTCTL_TICKET_BYTES / 4 + (split ? done_words : 0);
+			uint32_t &done_base = split ? c->split_done_base : c->done_base;
+			if (done_base > (1u << 30)) { // keep the monotone completion counters far from wrapping
+				HIP_TRY(hipMemsetAsync(done, 0, done_words * sizeof(uint32_t), c->stream));
+				done_base = 0;
 			}
 			p.lat[0] = c->lat(ISING_BLACK);
 			p.lat[1] = c->lat(ISING_WHITE);
 			p.jham[0] = c->cfg.use_J ? c->ham(1) : nullptr;
 			p.jham[1] = c->cfg.use_J ? c->ham(0) : nullptr;
-			p.done = c->d_slotctl + SLOTCTL_TICKET_BYTES / 4;
-			p.wg_per_cu = c->fused_wg_per_cu;
+			p.done = done;
+			p.wg_per_cu = split ? c->split_wg_per_cu : c->fused_wg_per_cu;
 			p.wait_late = c->fused_wait_late ? (c->pol.fused_wait_late == 1 ? 1 : 2) : 0; // (default 2: behind the second draw phase)
 			if (cnt_every > 0 && 2 * cnt_first < nlevels) {
 				p.cnt_acc = c->d_cnt; p.cnt_first = cnt_first; p.cnt_every = cnt_every; p.cnt_slot0 = cnt_slot0; p.cnt_bonds = cnt_bonds ? 1 : 0;
@@ -122,7 +130,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			}
 			if (c->clk_on && c->d_clk) p.clk_out = c->d_clk;
 			p.nt_stream = c->fused_nt;
-			p.done_base = c->done_base;
+			p.done_base = done_base;
 			if (lo0 < 0 || hi0 > c->cfg.Y) { // ghost rows are rows of the neighbouring slabs
 				p.total_rows = c->cfg.nslabs * c->cfg.Y;
 				p.trapezoid = c->pol.trapezoid ? 1 : 0;
@@ -135,16 +143,13 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 					p.edge_go_need = c->edge_go_epoch;
 					p.edge_done = c->d_edge;
 					unsigned strips = 0; // strips of this launch that touch such a row
-					for (int r0 = lo0; r0 < hi0; r0 += c->H) if (r0 < p.edge_lo || std::min(r0 + c->H, hi0) > p.edge_hi) strips++;
+					for (int r0 = lo0; r0 < hi0; r0 += HL) if (r0 < p.edge_lo || std::min(r0 + HL, hi0) > p.edge_hi) strips++;
 					c->edge_done_target += strips * (uint32_t)c->nwc();
 				}
 			}
 		}
 		int grid = 0;
-		// the split form of a fused launch over the whole slab (ising_ballot.hip: ballot_split_k): its ticket words and slot counts start from zero
-		// (a launch of several levels covers the whole slab, or a ring slab with its ghost rows)
-		const bool split = c->split && nlevels > 1 && hi1 == lo1 && color == ISING_BLACK && c->d_split_masks && c->d_split_ctl;
-		if (split) {
+		if (split) { // (its ticket words and slot counts start from zero)
 			HIP_TRY(hipMemsetAsync(c->d_split_ctl, 0, c->split_ctl_bytes, c->stream));
 			p.sp_ctr = c->d_split_ctl;
 			p.sp_flags = reinterpret_cast<uint32_t *>(c->d_split_ctl + 8 * 16);
@@ -159,7 +164,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			return fail(ISING_E_HIP, "kernel launch failed: %s", hipGetErrorString(le));
 		}
 		if (nlevels > 1) {
-			c->done_base += (uint32_t)nlevels * (uint32_t)c->nwc();
+			(split ? c->split_done_base : c->done_base) += (uint32_t)nlevels * (uint32_t)c->nwc();
 			// where the launch leaves the counter(s): its units, and every workgroup drew one ticket too many
 			const unsigned long long total = (unsigned long long)p.nwg * (unsigned long long)nlevels;
 			if (split) {
@@ -225,6 +230,13 @@ static bool sweeps_fused(const ising_ctx *c) {
 	if (!c->ballot || !c->fused || ising_host::needs_generic(c)) return false;
 	if (c->cfg.XSL) return !c->cfg.use_J && (c->cfg.YSL % c->H) == 0;
 	return c->wrap;
+}
+
+// The split form costs a launch ~0.14 ms more than the fused form (it ends on word units alone) and runs 1-6 % faster in between: it carries the calls that are
+// long enough to earn that back twice over -- ~10 ms of sweeps, 2^35 flips (16384^2: 128 sweeps; break-even measured at 63, profiles/rocprof_r05_config2_split.txt).
+// Shorter calls run the fused form at its own shape, as before round 5.  (ISING_SPLIT=1: every call.)
+static bool split_pays(const ising_ctx *c, int nsweeps) {
+	return c->split && (c->split_always || (long long)nsweeps * c->cfg.X * c->cfg.Y >= (1LL << 35));
 }
 
 extern "C" int ising_sweep(ising_ctx *c, int first_it, int nsweeps) {
@@ -325,8 +337,10 @@ int ising_host::sweep_alone(ising_ctx *c, int first_it, int nsweeps) {
 	// ballot layout: many sweeps per fused launch (32 at 65536^2, more on smaller lattices) -- the chip does not drain between colours
 	if (sweeps_fused(c)) {
 		const int per_launch = ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y);
+		const bool split = split_pays(c, nsweeps);
 		for (int it = first_it, left = nsweeps; left > 0;) {
 			const int ns = std::min(left, per_launch);
+			c->split_next = split;
 			if (int rc = launch_ranges(c, it, ISING_BLACK, 0, c->cfg.Y, 0, 0, 2 * ns)) return rc;
 			it += ns;
 			left -= ns;
@@ -392,7 +406,8 @@ extern "C" int ising_sweep_counted(ising_ctx *c, int first_it, int nsweeps, int 
 	}
 	size_t slots = 0, n_up = 0, chunk = 0;
 	unsigned long long *d_sum = nullptr;
-	if (int rc = ising_host::cnt_reserve(c, (size_t)c->nstrips, bond_equal != nullptr, &slots, &n_up, &chunk, &d_sum)) return rc;
+	const bool split = split_pays(c, nsweeps); // (one form of launch per call: the slots of a measurement are laid out by its strips)
+	if (int rc = ising_host::cnt_reserve(c, (size_t)(split ? c->cfg.Y / c->H_split : c->nstrips), bond_equal != nullptr, &slots, &n_up, &chunk, &d_sum)) return rc;
 	const int per_launch = ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y); // (a counted launch is as long as any other)
 	std::vector<unsigned long long> h(2 * chunk);
 	long long got = 0;
@@ -414,6 +429,7 @@ extern "C" int ising_sweep_counted(ising_ctx *c, int first_it, int nsweeps, int 
 			c->cnt_every_next = m > 0 ? every : 0;
 			c->cnt_slot0_next = inflight;
 			c->cnt_bonds_next = bond_equal != nullptr;
+			c->split_next = split;
 			if (int rc = launch_ranges(c, it, ISING_BLACK, 0, c->cfg.Y, 0, 0, 2 * ns)) { *ncounts = (int)got; return rc; } // (the counts of the chunks before are the caller's)
 			inflight += m;
 			it += ns;
@@ -521,8 +537,8 @@ int ising_sweep_ghost(ising_ctx *c, int first_it, int nsweeps) {
 // starts them over, the exchange's counters (units that have left the edge rows, epochs) a few counts before 2^32.
 int ising_debug_launch_shape(ising_ctx *c, int *strip_rows, int *wg_per_cu, int *split_lead) {
 	if (!c) return fail(ISING_E_ARG, "null context");
-	if (strip_rows) *strip_rows = c->H;
-	if (wg_per_cu) *wg_per_cu = c->fused_wg_per_cu;
+	if (strip_rows) *strip_rows = c->split ? c->H_split : c->H;
+	if (wg_per_cu) *wg_per_cu = c->split ? c->split_wg_per_cu : c->fused_wg_per_cu;
 	if (split_lead) *split_lead = c->split ? c->split_lead : 0;
 	return ISING_OK;
 }
@@ -539,6 +555,7 @@ int ising_debug_fault(ising_ctx *c, int what, int arg) {
 			for (auto &v : h) v += add;
 			HIP_TRY(hipMemcpy(c->d_slotctl + SLOTCTL_TICKET_BYTES / 4, h.data(), h.size() * 4, hipMemcpyHostToDevice));
 			c->done_base += add;
+			c->split_done_base += add; // (the split form's counters are the second half of the same words)
 		}
 		if (c->d_edge) {
 			uint32_t h[32];
@@ -554,6 +571,7 @@ int ising_debug_fault(ising_ctx *c, int what, int arg) {
 	}
 	if (what != 1) return fail(ISING_E_ARG, "unknown fault %d", what);
 	c->done_base += 1u << 20;
+	c->split_done_base += 1u << 20;
 	if (arg > 0) c->pol.abort_polls = (uint32_t)arg;
 	return ISING_OK;
 }

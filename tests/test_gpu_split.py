@@ -132,3 +132,34 @@ def test_split_ring_of_one_overlapped_and_counted(gpu, oracle_mod, monkeypatch, 
         ring.quiesce()
         assert _same(s, orc)
         ring.close()
+
+
+def test_auto_short_calls_fused_long_calls_split(gpu, monkeypatch):
+    """ising_create's own choice (no ISING_SPLIT): a lattice whose long calls run split launches keeps the fused form's shape for the short ones (a split launch
+    costs ~0.14 ms more than a fused one).  Calls of both kinds in turn -- each form with completion counters of its own -- against the same calls with
+    ISING_SPLIT=0: every word, the series of the print points (both forms are held against the oracle on their own, above and in test_gpu_fused.py)."""
+    X, Y = 32768, 2048
+    calls = [("sweep", 40), ("sweep", 600), ("sweep", 7), ("counted", 520, 16, True), ("counted", 30, 4, False), ("sweep", 512), ("sweep", 1)]
+
+    def run(split_env):
+        if split_env is None:
+            monkeypatch.delenv("ISING_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("ISING_SPLIT", split_env)
+        out = []
+        with ig.IsingSlab(X, Y, seed=31, temp=TC) as s:
+            shape = (s.split, s.strip_rows)
+            s.init()
+            for c in calls:
+                if c[0] == "sweep":
+                    s.sweep(c[1])
+                else:
+                    out.append(s.sweep_counted(c[1], c[2], c[3]))
+            out += [s.read(ig.BLACK), s.read(ig.WHITE), s.count(), s.bond_equal()]
+        return shape, out
+
+    shape_auto, got = run(None)
+    shape_off, want = run("0")
+    assert shape_auto[0] and not shape_off[0] and shape_auto[1] > shape_off[1], (shape_auto, shape_off)
+    assert got[0] == want[0] and got[1] == want[1]
+    assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3]) and got[4:] == want[4:]

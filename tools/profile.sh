@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --no-cpu-baseline --no-alu-probe --no-counts-leg $*"   # the default bench command: 128 steps, 16 warm-up
 # counter passes: the driver's own launch shape -- bench.py --steps 20 --warmup 5 = a warm-up launch of 10 colour half-sweeps and the
 # timed launch of 40; tools/summarize_prof.py keeps the timed launch's dispatch (the longest) only
-SHORT="python $R/bench.py --steps 20 --warmup 5 --preheat-ms 0 --no-cpu-baseline --no-alu-probe --no-counts-leg $*"   # (one timed launch of 40 colour half-sweeps: the counts leg would add launches of other lengths)
+SHORT="python $R/bench.py ${SHORT_STEPS:---steps 20 --warmup 5} --preheat-ms 0 --no-cpu-baseline --no-alu-probe --no-counts-leg $*"   # (one timed launch of 40 colour half-sweeps: the counts leg would add launches of other lengths)
 rocprofv3 --kernel-trace --stats -S -T -d $OUT/trace -o bench -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/trace_stderr.txt
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" "GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
