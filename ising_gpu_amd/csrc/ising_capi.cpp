@@ -554,7 +554,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		if (can && pol.split == 1) {
 			c->split = c->split_always = fused_tickets(c->nwc(), launch_rows, c->H) >= 8;
 			c->H_split = c->H;
-		} else if (can && !small_fused && !deep_ring) {
+		} else if (can && !small_fused && !deep_ring && c->cus >= 200) { // (a whole MI355X: eight XCDs that each run their share of the grid -- the classes are theirs)
 			// (lone slabs only: their launches carry ~50 ms of sweeps.  A launch in the split form ends on word units alone -- the last (lead + 1) x grid of them, five
 			// levels deep at 16384^2, memory round trips with an idle vector ALU: ~0.1 ms more per launch than the fused form (rocprofv3, 16 sweeps of 16384^2 per launch:
 			// 1450 against 1346 us, profiles/rocprof_r05_config2_split.txt / _fused.txt) --, which a ring slab's launches of 32 sweeps do not earn back; ISING_SPLIT=1 still
