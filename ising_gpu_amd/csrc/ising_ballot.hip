@@ -150,9 +150,6 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 #ifndef ISING_FUSED_WAIT_LATE // 1: fused launches may ask their units to draw before they wait for their parents (UpdateParams.wait_late); 0 compiles the request out
 #define ISING_FUSED_WAIT_LATE 1
 #endif
-#ifndef ISING_PRIO_ROT // 4: the waves' priorities rotate modulo 4 (rounds 2-4); 6: modulo the waves per SIMD (A/B build)
-#define ISING_PRIO_ROT 4
-#endif
 #ifndef ISING_POLL_SLEEP // s_sleep units (64 cycles) between two looks of a waiting unit at its parents' counters
 #define ISING_POLL_SLEEP 32
 #endif
@@ -581,33 +578,17 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		// as ever but picked up behind the last word phase instead of in front of the barrier -- the atomic under that phase's loads, the
 		// ticket handed to the other waves through LDS: -0.1 .. -0.3 % everywhere (profiles/ticket_async_probe_r04.txt).  The 4 % of a
 		// workgroup's time that the trace books on "next ticket" is time in which the SIMD's other waves have the vector ALU.)
-#if ISING_PRIO_ROT == 6
-		const int prio_n = uni(max(1, min(6, (int)((gridDim.x + (unsigned)p.cus - 1u) / (unsigned)p.cus)))); // waves of this launch per SIMD
-		int prio_phase = uni((int)(dround % (unsigned)prio_n));
-#endif
 		for (int r = 0; r <= rmax; ++r) {
 			// rotating priorities: the waves that share a SIMD (one per dispatch round) take turns at the front
 			if (FUSED) {
-#if ISING_PRIO_ROT == 6 // A/B (round 5): a rotation as long as the waves of a SIMD are many -- five or six of them step through {3,2,2,1,1,0} / {3,2,2,1,0}
-				// instead of four priorities modulo 4, where the fifth and sixth wave always tie with the first and second and, younger, lose
-				int pr_ = 3 - ((prio_phase + 1) >> 1);
-				if (prio_n == 6 && prio_phase == 5) pr_ = 0;
-				if (prio_n <= 4) pr_ = 3 - prio_phase;
-				switch (pr_) {
-				case 0: __builtin_amdgcn_s_setprio(0); break;
-				case 1: __builtin_amdgcn_s_setprio(1); break;
-				case 2: __builtin_amdgcn_s_setprio(2); break;
-				default: __builtin_amdgcn_s_setprio(3); break;
-				}
-				prio_phase = prio_phase + 1 >= prio_n ? 0 : prio_phase + 1;
-#else
+				// (round 5 A/B: a rotation as long as the waves of a SIMD are many -- {3,2,2,1,1,0} for six -- instead of modulo 4: 1-3 % slower at every size,
+				// profiles/prio_rotation_probe_r05.txt; the code is in the history at 7193df8)
 				switch ((r + (int)dround) & 3) {
 				case 0: __builtin_amdgcn_s_setprio(0); break;
 				case 1: __builtin_amdgcn_s_setprio(1); break;
 				case 2: __builtin_amdgcn_s_setprio(2); break;
 				default: __builtin_amdgcn_s_setprio(3); break;
 				}
-#endif
 			}
 			// The two words per row whose side neighbours sit in another vector (sites 0 / 31) are assembled on the scalar
 			// unit from three source-colour words of row r0 + r - 1: A0, A1 of this wave's own 64 words, C from the
