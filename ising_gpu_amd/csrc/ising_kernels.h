@@ -180,6 +180,38 @@ struct TileParams {
 hipError_t launch_dense_tiles(const TileParams &p, int threads, hipStream_t stream);
 size_t dense_tiles_lds_bytes(const TileParams &p);
 hipError_t launch_dense_init(const InitParams &p, hipStream_t stream);
+// Small lattices, round 5 (ising_quad.hip): the "quad" layout -- per colour [Y/4 row groups][gx blocks][64 words], bit 16 r4 + tx of word p = the site
+// reference thread 64 (R & 3) + 16 r4 + tx of block (bx, R / 4) draws with Philox block p / 4, output p % 4 -- and its two kernels: the draws of many levels
+// ahead of the lattice (one KiB of accept masks per level, row group and block), the word phases of 2 T levels per tile without an exchange.
+struct QuadDrawParams {
+	uint64_t *masks;         // [nlev][NRG * gx][128]: (c3, c4) of word p at 16 p bytes
+	uint32_t seed_lo, seed_hi;
+	uint32_t it;             // iteration of level 0 (black); level L = colour L & 1 of iteration it + L / 2
+	uint32_t n3, n4;
+	int gx, NRG;
+	int nlev;
+	int chunk;               // items a wave draws (one level's block constants serve them all)
+	int few_waves;           // the form that runs four waves per SIMD at most (room for the word passes' workgroups on every CU)
+};
+hipError_t launch_quad_draw(const QuadDrawParams &p, hipStream_t stream);
+#if defined(ISING_QUAD_TRACE)
+void quad_trace_dump(); // measurement builds only (ising_quad.hip)
+#endif
+struct QuadWordParams {
+	const uint64_t *src[2];  // black / white lattice the pass reads
+	uint64_t *dst[2];        // ... and writes (another buffer: the neighbours read their halos from src meanwhile)
+	const uint64_t *masks;   // level 0 of this pass
+	int gx, NRG;
+	int C, HG;               // row groups per tile, halo row groups per side (4 HG >= nlev - 1)
+	int nlev;                // levels of the pass (even: whole sweeps, black first)
+	unsigned long long *cnt; // not null: the up spins of the state the pass stores are added here
+};
+hipError_t launch_quad_word(const QuadWordParams &p, int waves, hipStream_t stream);
+size_t quad_word_lds_bytes(const QuadWordParams &p, int waves, int maxi);
+int quad_word_maxi(const QuadWordParams &p, int waves); // items a wave works on per level at most (0: too many for any instantiation)
+hipError_t launch_dense_to_quad(const uint32_t *dense, uint64_t *quad, int gx, int NRG, hipStream_t stream);
+hipError_t launch_quad_to_dense(const uint64_t *quad, uint32_t *dense, int gx, int NRG, hipStream_t stream); // (dense: row 0; rows -1 and Y are refreshed too)
+
 // in-place nibble -> bit-plane transposition of `nvec` 16-byte coupling vectors (dense layout with -J)
 hipError_t launch_ham_planes(uint64_t *ham, size_t nvec, hipStream_t stream);
 hipError_t launch_swap_vectors(uint64_t *a, uint64_t *b, size_t nvec, hipStream_t stream); // 16-byte vectors of two arrays change places

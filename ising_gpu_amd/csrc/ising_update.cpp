@@ -331,6 +331,116 @@ static int sweep_tiles_counted(ising_ctx *c, int first_it, int nsweeps, int ever
 	return ISING_OK;
 }
 
+// Small lattices on the quad layout (ising_quad.hip): the draws of a batch of sweeps run on the context's second stream, a batch AHEAD of the word passes that
+// consume them on the slab's own stream (two mask buffers; ev_qdraw / ev_qword carry the two dependencies); a word pass of <= T sweeps reads one lattice buffer
+// and writes the other.  The spins live in d_lat (dense layout) between calls: a call converts on its way in and out, so everything else the library does with
+// a dense slab -- counts, energy, dumps, a temperature change -- finds what it always found.
+static bool sweeps_quad(const ising_ctx *c, int nsweeps) {
+	return c->quad_C > 0 && nsweeps >= 2 && c->wrap && c->dense && !c->ballot && !c->cfg.use_J && !c->cfg.XSL && c->fast_ok && !ising_host::needs_generic(c);
+}
+
+// `every` > 0: the up spins after every iteration that is a multiple of it are added to d_cnt[0], d_cnt[1], ... (zero on entry); *nmeas = how many
+static int sweep_quad(ising_ctx *c, int first_it, int nsweeps, int every, unsigned long long *d_cnt, int *nmeas) {
+	if (int rc = bind(c)) return rc;
+	if (!c->d_quad || !c->d_qmasks) return fail(ISING_E_STATE, "quad sweeps without their buffers (ising_create allocates them)");
+	struct Pass { int it, ns, meas; };
+	std::vector<Pass> passes;
+	const int T = c->quad_T;
+	const long long last = (long long)first_it + nsweeps - 1;
+	int k = 0;
+	for (int it = first_it; it <= last;) {
+		const long long next = every > 0 ? std::min<long long>(last, ((long long)it + every - 1) / every * every) : last; // the segment's last iteration
+		const int seg = (int)(next - it + 1), L = (seg + T - 1) / T;
+		for (int l = 0; l < L; l++) {
+			const int ns = seg / L + (l < seg % L ? 1 : 0);
+			const bool measured = every > 0 && l == L - 1 && next % every == 0;
+			passes.push_back({it, ns, measured ? k++ : -1});
+			it += ns;
+		}
+	}
+	if (nmeas) *nmeas = k;
+	// batches: consecutive passes whose sweeps fit a mask buffer
+	std::vector<std::pair<size_t, size_t>> batches; // [first pass, one past the last)
+	for (size_t a = 0; a < passes.size();) {
+		size_t b = a;
+		int sum = 0;
+		while (b < passes.size() && sum + passes[b].ns <= c->quad_batch) sum += passes[b++].ns;
+		batches.push_back({a, b});
+		a = b;
+	}
+	const int NRG = c->cfg.Y / 4, gx = c->gx;
+	const size_t qw = c->quad_words(), NI = qw / 64;
+	const size_t mask_words = (size_t)(2 * c->quad_batch) * NI * 128; // per buffer
+	auto draw = [&](size_t bi, unsigned buf) -> int {
+		int sum = 0;
+		for (size_t q = batches[bi].first; q < batches[bi].second; q++) sum += passes[q].ns;
+		ising::QuadDrawParams dp{};
+		dp.masks = c->d_qmasks + (size_t)buf * mask_words;
+		dp.seed_lo = (uint32_t)c->cfg.seed;
+		dp.seed_hi = (uint32_t)(c->cfg.seed >> 32);
+		dp.it = (uint32_t)passes[batches[bi].first].it;
+		dp.n3 = (uint32_t)c->thr[3];
+		dp.n4 = (uint32_t)c->thr[4];
+		dp.gx = gx; dp.NRG = NRG; dp.nlev = 2 * sum; dp.chunk = c->quad_chunk;
+		dp.few_waves = (long long)c->cfg.X * c->cfg.Y <= (1LL << 24);
+		HIP_TRY(hipStreamWaitEvent(c->qstream, c->ev_qword[buf], 0)); // the passes that read this buffer two batches ago
+		HIP_TRY(ising::launch_quad_draw(dp, c->qstream));
+		HIP_TRY(hipEventRecord(c->ev_qdraw[buf], c->qstream));
+		return ISING_OK;
+	};
+	auto dense_plane = [&](int color) { return reinterpret_cast<uint32_t *>(c->lat(color)); };
+	const unsigned buf0 = c->qbatch_no, NB = (unsigned)c->quad_nbuf;
+	// (the draws need nothing from the lattice: the first NB - 1 batches are under way while the spins are converted; batch b + NB - 1 goes out in front of the
+	// passes of batch b -- its buffer was read by batch b - 1, whose event is already recorded)
+	size_t drawn = 0;
+	for (; drawn < batches.size() && drawn + 1 < NB; drawn++) if (int rc = draw(drawn, (buf0 + (unsigned)drawn) % NB)) return rc;
+	int cur = 0;
+	for (int color = 0; color < 2; color++) HIP_TRY(ising::launch_dense_to_quad(dense_plane(color), c->d_quad + (size_t)color * qw, gx, NRG, c->stream));
+	for (size_t bi = 0; bi < batches.size(); bi++) {
+		const unsigned buf = (buf0 + (unsigned)bi) % NB;
+		if (drawn < batches.size()) { if (int rc = draw(drawn, (buf0 + (unsigned)drawn) % NB)) return rc; drawn++; }
+		HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_qdraw[buf], 0));
+		int lev = 0;
+		for (size_t q = batches[bi].first; q < batches[bi].second; q++) {
+			ising::QuadWordParams wp{};
+			for (int color = 0; color < 2; color++) {
+				wp.src[color] = c->d_quad + ((size_t)cur * 2 + color) * qw;
+				wp.dst[color] = c->d_quad + ((size_t)(cur ^ 1) * 2 + color) * qw;
+			}
+			wp.masks = c->d_qmasks + (size_t)buf * mask_words + (size_t)lev * NI * 128;
+			wp.gx = gx; wp.NRG = NRG; wp.C = c->quad_C; wp.HG = c->quad_HG;
+			wp.nlev = 2 * passes[q].ns;
+			wp.cnt = passes[q].meas >= 0 ? d_cnt + passes[q].meas : nullptr;
+			HIP_TRY(ising::launch_quad_word(wp, c->quad_waves, c->stream));
+			lev += wp.nlev;
+			cur ^= 1;
+		}
+		HIP_TRY(hipEventRecord(c->ev_qword[buf], c->stream));
+	}
+	c->qbatch_no = buf0 + (unsigned)batches.size();
+	for (int color = 0; color < 2; color++) HIP_TRY(ising::launch_quad_to_dense(c->d_quad + ((size_t)cur * 2 + color) * qw, dense_plane(color), gx, NRG, c->stream));
+	return ISING_OK;
+}
+
+static int sweep_quad_counted(ising_ctx *c, int first_it, int nsweeps, int every, uint64_t *ups, long long n, int *ncounts) {
+	if (int rc = bind(c)) return rc;
+	if (c->tile_cnt_cap < (size_t)n) {
+		if (c->d_tile_cnt) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_tile_cnt)); c->d_tile_cnt = nullptr; c->tile_cnt_cap = 0; }
+		const size_t cap = std::max<size_t>(64, (size_t)n);
+		HIP_TRY(hipMalloc((void **)&c->d_tile_cnt, cap * sizeof(unsigned long long)));
+		c->tile_cnt_cap = cap;
+	}
+	if (n) HIP_TRY(hipMemsetAsync(c->d_tile_cnt, 0, (size_t)n * sizeof(unsigned long long), c->stream));
+	int k = 0;
+	if (nsweeps > 0) if (int rc = sweep_quad(c, first_it, nsweeps, every, c->d_tile_cnt, &k)) return rc;
+	std::vector<unsigned long long> h((size_t)std::max(k, 1));
+	if (k) HIP_TRY(hipMemcpyAsync(h.data(), c->d_tile_cnt, (size_t)k * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+	if (int rc = ising_host::sync_checked(c)) return rc;
+	for (int q = 0; q < k; q++) ups[q] = h[q];
+	*ncounts = k;
+	return ISING_OK;
+}
+
 // `nsweeps` sweeps of a slab that needs nothing from its neighbours: a single slab that wraps in place, or a slab of
 // sub-lattices (also one of several: nothing crosses slabs, optimized/main.cu:1423-1462)
 int ising_host::sweep_alone(ising_ctx *c, int first_it, int nsweeps) {
@@ -347,6 +457,7 @@ int ising_host::sweep_alone(ising_ctx *c, int first_it, int nsweeps) {
 		}
 		return ISING_OK;
 	}
+	if (sweeps_quad(c, nsweeps)) return sweep_quad(c, first_it, nsweeps, 0, nullptr, nullptr);
 	if (sweeps_tiled(c, nsweeps)) return sweep_tiles(c, first_it, nsweeps);
 	for (int it = first_it; it < first_it + nsweeps; it++) {
 		if (int rc = ising_update_color(c, it, ISING_BLACK, 0, c->cfg.Y)) return rc;
@@ -386,6 +497,7 @@ extern "C" int ising_sweep_counted(ising_ctx *c, int first_it, int nsweeps, int 
 	*ncounts = 0;
 	if (n > max_counts) return fail(ISING_E_ARG, "%lld counts, room for %d", n, max_counts);
 	if (int rc = bind(c)) return rc;
+	if (sweeps_quad(c, 2) && !bond_equal) return sweep_quad_counted(c, first_it, nsweeps, every, ups, n, ncounts);
 	if (sweeps_tiled(c, 2) && !bond_equal) return sweep_tiles_counted(c, first_it, nsweeps, every, ups, n, ncounts);
 	const bool inside = sweeps_fused(c) && !c->cfg.XSL && !c->cfg.use_J;
 	if (!inside) { // one launch per colour, tiles with the energy, sub-lattices, couplings: the reference's own order of events
@@ -454,9 +566,10 @@ int ising_sweep_info(ising_ctx *c, int *fused, int *max_sweeps_per_launch) {
 	const bool f = (c->wrap || c->cfg.XSL) && sweeps_fused(c);
 	// (a ring slab with ghost rows G deep: the ring's sweeps are fused launches of G/2 sweeps between two exchanges)
 	const bool deep = ghost_sweeps(c);
-	const bool tiled = !f && !deep && sweeps_tiled(c, 2);
-	if (fused) *fused = ((f || deep) && c->split && !c->cfg.XSL) ? 3 : ((f || deep) ? 1 : (tiled ? 2 : 0));
-	if (max_sweeps_per_launch) *max_sweeps_per_launch = f ? ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y) : (deep ? c->ghost() / 2 : (tiled ? c->tile_sweeps : 0));
+	const bool quad = !f && !deep && sweeps_quad(c, 2);
+	const bool tiled = !f && !deep && !quad && sweeps_tiled(c, 2);
+	if (fused) *fused = ((f || deep) && c->split && !c->cfg.XSL) ? 3 : ((f || deep) ? 1 : (quad ? 4 : (tiled ? 2 : 0)));
+	if (max_sweeps_per_launch) *max_sweeps_per_launch = f ? ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y) : (deep ? c->ghost() / 2 : (quad ? c->quad_T : (tiled ? c->tile_sweeps : 0)));
 	return ISING_OK;
 }
 

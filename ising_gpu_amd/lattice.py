@@ -196,6 +196,14 @@ class IsingSlab:
         return f.value == 2
 
     @property
+    def quad(self) -> bool:
+        """True when sweep() runs on the quad layout (small lattices: the draws of a batch of sweeps ahead of the lattice on a second stream,
+        word passes of several sweeps on tiles + halo; ising_quad.hip, ising_sweep_info)."""
+        f, m = C.c_int(), C.c_int()
+        check(self._lib.ising_sweep_info(self._h, C.byref(f), C.byref(m)))
+        return f.value == 4
+
+    @property
     def max_sweeps_per_launch(self) -> int:
         """Sweeps one fused launch carries at most (0: one launch per colour); for a ring slab with ghost rows: between
         two exchanges of the ring."""

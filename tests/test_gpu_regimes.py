@@ -11,12 +11,13 @@ pytestmark = pytest.mark.gpu
 TC = ig.CRIT_TEMP_F32
 B, D = ig.LAYOUT_BALLOT, ig.LAYOUT_DENSE
 
-CASES = [  # X, Y, layout AUTO picks, fused, tiled, strip rows (0: whatever)
-    (8192, 1280, B, True, False, 1), (8192, 2048, B, True, False, 1), (16384, 768, B, True, False, 1), (16384, 2048, B, True, False, 1),
+CASES = [  # X, Y, layout AUTO picks, fused, tiled, strip rows (0: whatever); quad (round 5: up to four blocks of 2048 columns, ising_quad.hip) = dense, neither fused nor tiled
+    (8192, 1280, D, False, False, 0), (8192, 2048, D, False, False, 0), (16384, 768, B, True, False, 1), (16384, 2048, B, True, False, 1),
     (24576, 896, B, True, False, 1), (32768, 640, B, True, False, 1), (32768, 1024, B, True, False, 1), (65536, 512, B, True, False, 1),
     (16384, 2176, B, True, False, 2), (24576, 1536, B, True, False, 2), (131072, 1024, B, True, False, 4), (24576, 4096, B, True, False, 4),
-    (12288, 1536, B, True, False, 1), (6144, 3072, B, True, False, 1), (20480, 4096, B, True, False, 0), (28672, 4096, B, True, False, 0),
-    (8192, 1024, D, False, True, 0), (4096, 4096, D, False, True, 0), (6144, 1024, D, False, True, 0), (2048, 8192, D, False, True, 0), (65536, 256, D, False, True, 0),
+    (12288, 1536, B, True, False, 1), (6144, 3072, D, False, False, 0), (20480, 4096, B, True, False, 0), (28672, 4096, B, True, False, 0),
+    (8192, 1024, D, False, False, 0), (4096, 4096, D, False, False, 0), (6144, 1024, D, False, False, 0), (2048, 8192, D, False, False, 0), (65536, 256, D, False, True, 0),
+    (8192, 4096, B, True, False, 2), (10240, 1024, D, False, True, 0),
 ]
 
 
@@ -26,6 +27,7 @@ def test_auto_regimes_bit_exact(gpu, oracle_mod, X, Y, layout, fused, tiled, H):
     orc = oracle_mod.OracleLattice(X, Y, seed=4242, temp=TC).init()
     with ig.IsingSlab(X, Y, seed=4242, temp=TC) as s:
         assert (s.layout, s.fused, s.tiled) == (layout, fused, tiled), (s.layout, s.fused, s.tiled, s.strip_rows)
+        assert s.quad == (layout == D and not tiled and X <= 8192), s.quad
         assert not H or s.strip_rows == H, s.strip_rows
         s.init()
         done = 0
@@ -56,7 +58,7 @@ def test_auto_random_shapes_bit_exact(gpu, oracle_mod):
         seed = int(rng.integers(1, 2**62))
         orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=TC).init()
         with ig.IsingSlab(X, Y, seed=seed, temp=TC) as s:
-            seen.add((s.layout, s.fused, s.tiled, s.strip_rows))
+            seen.add((s.layout, s.fused, s.tiled, s.quad, s.strip_rows))
             s.init()
             done = 0
             for upto in (1, 7, 33):

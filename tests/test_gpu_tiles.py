@@ -15,6 +15,7 @@ KEYS = ("ISING_TILES", "ISING_TILE_ROWS", "ISING_TILE_WORDS", "ISING_TILE_SWEEPS
 def _env(monkeypatch, **kw):
     for k in KEYS:
         monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("ISING_QUAD", "0")  # (round 5: lattices up to four blocks of 2048 columns take the quad path by default -- tests/test_gpu_quad.py; these are the tile launches')
     for k, v in kw.items():
         monkeypatch.setenv("ISING_" + k, str(v))
 
