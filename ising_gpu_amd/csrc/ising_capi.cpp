@@ -59,9 +59,7 @@ int read_policy(ising_policy *pol) {
 	if (num("ISING_QUAD_C", &v) && v > 0) pol->quad_C = v;
 	if (num("ISING_QUAD_T", &v) && v > 0) pol->quad_T = v;
 	if (num("ISING_QUAD_WAVES", &v) && v > 0) pol->quad_waves = v;
-	if (num("ISING_QUAD_BATCH", &v) && v > 0) pol->quad_batch = v;
-	if (num("ISING_QUAD_CHUNK", &v) && v > 0) pol->quad_chunk = v;
-	if (num("ISING_QUAD_NBUF", &v) && v > 0) pol->quad_nbuf = v;
+	if (num("ISING_QUAD_PARTS", &v) && (v == 1 || v == 2 || v == 4)) pol->quad_parts = v;
 	pol->no_ballot = getenv("ISING_NO_BALLOT") != nullptr;
 	if (const char *e = getenv("ISING_TAIL")) {
 		int rows = 0, h = 1;
@@ -490,16 +488,16 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// ISING_FUSED=0/1, cfg.strip_rows and ISING_FUSED_WGS (grid) override.  (8-wave workgroups, an A/B switch of rounds 2-3, lost
 	// at every size once the priorities rotated -- 16384^2 3187 vs 3325, 32768^2 3192 vs 3473 -- and are gone.)
 	const long long spins = (long long)cfg->X * cfg->Y;
-	// Small and narrow lattices (round 5, ising_quad.hip): the draws of a batch of sweeps made ahead of the lattice by the whole chip, word passes of T sweeps on
-	// tiles + halo -- on a dense slab (the spins live in the dense layout between calls).  A lone slab that wraps in place, integer thresholds, no sub-lattices,
-	// no couplings, up to four blocks of 2048 columns (a tile is as wide as the lattice and lives in a workgroup's LDS with three levels of its masks).
-	// By measurement on a whole MI355X (tools/quad_probe.py, profiles/quad_probe_r05.txt; flips/ns quad / the library before): 2048 x 512 627 / 272, 2048 x 1024 1235 / 509,
-	// 2048^2 2030 / 876, 2048 x 4096 2600 / 1218, 2048 x 16384 2708 / 1831, 4096 x 1024 1591 / 875, 4096^2 2756 / 1609, 4096 x 16384 2767 / 2188, 6144 x 2048 2378 / 1626,
-	// 6144^2 2763 / 2205, 8192 x 1024 1859 / 1217, 8192 x 2048 2515 / 2165 -- and 8192 x 4096 2707 / 2774, 8192^2 2735 / 3117: the fused launches' from there on.
-	// ISING_QUAD=1 asks for it wherever it applies, 0 never.
+	// Small and narrow lattices (round 5, ising_quad.hip): one launch per pass of T sweeps = the word pass on tiles + halo next to the draws of the pass to come,
+	// made ONCE by the rest of the chip -- on a dense slab (the spins live in the dense layout between calls).  A lone slab that wraps in place, integer
+	// thresholds, no sub-lattices, no couplings, up to four blocks of 2048 columns (a tile is as wide as the lattice).
+	// By measurement on a whole MI355X (tools/quad_probe.py, profiles/quad_probe_r05.txt; flips/ns quad / the library before): 2048 x 512 739 / 273, 2048^2 1707 / 877,
+	// 2048 x 8192 2226 / 1616, 4096 x 1024 1624 / 875, 4096^2 2306 / 1614, 4096 x 16384 2602 / 2194, 6144 x 2048 1996 / 1630, 6144^2 2341 / 2208, 8192 x 1024 1747 / 1219
+	// -- and 8192 x 2048 2037 / 2183: the fused launches' from there on.  ISING_QUAD=1 asks for it wherever it applies, 0 never; tests/test_gpu_policy.py holds the rule
+	// against the other path.
 	const bool quad_can = c->wrap && !cfg->XSL && !cfg->use_J && c->fast_ok && (cfg->Y % 4) == 0 && c->gx <= 4 && pol.quad != 0 &&
 	                      (cfg->layout == ISING_LAYOUT_AUTO || cfg->layout == ISING_LAYOUT_DENSE) && cfg->kernel != ISING_KERNEL_GENERIC;
-	const bool quad_pick = quad_can && (pol.quad == 1 || (c->cus >= 200 && (c->gx <= 3 ? spins <= (1LL << 26) : cfg->Y <= 2048)));
+	const bool quad_pick = quad_can && (pol.quad == 1 || (c->cus >= 200 && (c->gx <= 2 ? spins <= (1LL << 26) : (c->gx == 3 ? cfg->Y <= 6144 : cfg->Y <= 1024))));
 	// (sub-lattices: every XSL x YSL block is a periodic system of its own -- nothing crosses slabs, so ring slabs qualify too --;
 	// their strips must not straddle a block, and the fused kernels carry no couplings next to sub-lattices)
 	const bool fused_can = cfg->XSL ? !cfg->use_J : c->wrap;
@@ -592,36 +590,29 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	c->nstrips = cfg->Y / c->H;
 	c->color_words = (size_t)cfg->Y * c->lld;
 	// The quad path's shape (quad_pick above).  Tiles of C row groups (4 rows each) x the whole width + HG halo row groups per side, T sweeps a pass, waves per
-	// tile, sweeps per batch of draws, mask buffers -- by measurement (profiles/quad_probe_r05.txt): four row groups, eight sweeps and twelve waves up to two
-	// blocks of 2048 columns; four sweeps and eight waves from three (the masks of three levels of a tile share the LDS with it); batches of 64 sweeps while
-	// four buffers of them stay under a GiB.
+	// workgroup (tiles and drawing workgroups alike: one launch) -- by measurement (profiles/quad_probe_r05.txt).
 	if (quad_pick && c->dense && !c->ballot) {
 		const int NRG = cfg->Y / 4;
-		int T = pol.quad_T ? pol.quad_T : (c->gx <= 2 ? 8 : 4);
+		// (2048 columns: eight sweeps a pass on four row groups, twelve waves -- eight once the tiles are 128 and more: 2048^2 1707 against 1525; 4096: twelve waves,
+		// two items each; 6144: four sweeps a pass; 8192: six on two row groups, sixteen waves.  A wave keeps at most two items: 80 registers, six waves per SIMD.)
+		int T = pol.quad_T ? pol.quad_T : (c->gx <= 2 ? 8 : (c->gx == 3 ? 4 : 6));
 		T = std::max(1, std::min(T, 32));
 		const int HG = (2 * T - 1 + 3) / 4;
-		int C = pol.quad_C ? pol.quad_C : 4;
+		int C = pol.quad_C ? pol.quad_C : (c->gx <= 3 ? 4 : 2);
 		C = std::max(1, std::min(C, NRG));
-		int waves = pol.quad_waves ? pol.quad_waves : (c->gx <= 2 ? 12 : 8);
+		int waves = pol.quad_waves ? pol.quad_waves : (c->gx == 1 ? (NRG / C >= 128 ? 8 : 12) : (c->gx <= 3 ? 12 : 16));
 		waves = std::max(1, std::min(waves, 16));
 		ising::QuadWordParams qp{};
 		qp.gx = c->gx; qp.NRG = NRG; qp.C = C; qp.HG = HG;
 		const int mi = ising::quad_word_maxi(qp, waves);
 		int lds_max = 64 * 1024;
 		if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeSharedMemPerBlockOptin, cfg->device) != hipSuccess || lds_max <= 0) { (void)hipGetLastError(); lds_max = 64 * 1024; }
-		if (mi > 0 && ising::quad_word_lds_bytes(qp, waves, mi) <= (size_t)lds_max) {
+		if (mi > 0 && ising::quad_pass_lds_bytes(qp, waves) <= (size_t)lds_max) {
 			c->quad_C = C; c->quad_T = T; c->quad_HG = HG; c->quad_waves = waves;
-			const long long per_sweep = 2LL * NRG * c->gx * 1024; // bytes of masks
-			c->quad_nbuf = std::max(2, std::min(pol.quad_nbuf ? pol.quad_nbuf : 4, (int)ising_ctx::QUAD_MAX_BUFS));
-			const long long fit = std::max<long long>(T, ((1LL << 30) / c->quad_nbuf / per_sweep) / T * T);
-			c->quad_batch = pol.quad_batch ? std::max(T, pol.quad_batch) : (int)std::min<long long>(c->gx <= 2 ? 64 : 32, fit);
-			// (a drawing wave takes `chunk` items of one level: as many waves as fill the chip six per SIMD, eight items at most -- 2048^2 in batches of 16 sweeps at
-			// eight items a wave ran two waves per SIMD, 1900 sites/ns)
-			const long long per_batch = 2LL * c->quad_batch * NRG * c->gx;
-			c->quad_chunk = pol.quad_chunk ? pol.quad_chunk : (int)std::max<long long>(1, std::min<long long>(8, per_batch / (24LL * c->cus)));
+			c->quad_parts = pol.quad_parts ? pol.quad_parts : 4;
 		} else if (pol.quad == 1 && (pol.quad_C || pol.quad_T || pol.quad_waves)) {
 			delete c;
-			return fail(ISING_E_ARG, "ISING_QUAD_*: tiles of %d row groups + 2 x %d, %d waves do not fit the workgroup's LDS (%d bytes) at X = %d", C, HG, waves, lds_max, cfg->X);
+			return fail(ISING_E_ARG, "ISING_QUAD_*: tiles of %d row groups + 2 x %d at %d waves: too many items a wave, or more LDS than a workgroup's (%d bytes) at X = %d", C, HG, waves, lds_max, cfg->X);
 		}
 	}
 	// Lattices that stay on the dense layout (a lone slab, no couplings, no sub-lattices), up to 2^24 spins: tile launches of several sweeps
@@ -713,14 +704,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (e == hipSuccess && c->tile_rows > 0) e = hipMalloc((void **)&c->d_lat2, c->alloc_words() * sizeof(uint64_t));
 	if (e == hipSuccess && c->quad_C > 0) {
 		e = hipMalloc((void **)&c->d_quad, 4 * c->quad_words() * sizeof(uint64_t));
-		if (e == hipSuccess) e = hipMalloc((void **)&c->d_qmasks, (size_t)c->quad_nbuf * (size_t)(2 * c->quad_batch) * (c->quad_words() / 64) * 1024);
-		int lo = 0, hi = 0;
-		if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&lo, &hi);
-		if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->qstream, hipStreamNonBlocking, getenv("ISING_QUAD_PRIO") ? (atoi(getenv("ISING_QUAD_PRIO")) ? hi : (lo + hi) / 2) : lo); // (the draws give way to the word passes)
-		for (int b = 0; b < c->quad_nbuf && e == hipSuccess; b++) {
-			e = hipEventCreateWithFlags(&c->ev_qdraw[b], hipEventDisableTiming);
-			if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_qword[b], hipEventDisableTiming);
-		}
+		if (e == hipSuccess) e = hipMalloc((void **)&c->d_qmasks, 2 * (size_t)(2 * c->quad_T) * (c->quad_words() / 64) * 1024);
 	}
 	if (e == hipSuccess) e = hipMalloc((void **)&c->d_acc, 4 * sizeof(unsigned long long));
 	if (e == hipSuccess && c->ballot) {
@@ -796,8 +780,6 @@ int ising_destroy(ising_ctx *c) {
 	if (c->d_acc) (void)hipFree(c->d_acc);
 	if (c->d_tmp) (void)hipFree(c->d_tmp);
 	if (c->d_lat2) (void)hipFree(c->d_lat2);
-	if (c->qstream) { (void)hipStreamSynchronize(c->qstream); (void)hipStreamDestroy(c->qstream); }
-	for (int b = 0; b < ising_ctx::QUAD_MAX_BUFS; b++) { if (c->ev_qdraw[b]) (void)hipEventDestroy(c->ev_qdraw[b]); if (c->ev_qword[b]) (void)hipEventDestroy(c->ev_qword[b]); }
 	if (c->d_quad) (void)hipFree(c->d_quad);
 	if (c->d_qmasks) (void)hipFree(c->d_qmasks);
 	if (c->d_tile_cnt) (void)hipFree(c->d_tile_cnt);

@@ -189,25 +189,29 @@ struct QuadDrawParams {
 	uint32_t it;             // iteration of level 0 (black); level L = colour L & 1 of iteration it + L / 2
 	uint32_t n3, n4;
 	int gx, NRG;
-	int nlev;
-	int chunk;               // items a wave draws (one level's block constants serve them all)
-	int few_waves;           // the form that runs four waves per SIMD at most (room for the word passes' workgroups on every CU)
+	int nlev;                // 0: no draws in this launch
+	int parts;               // quarters of an item (4 Philox blocks each) a wave draws: 1, 2 or 4
 };
-hipError_t launch_quad_draw(const QuadDrawParams &p, hipStream_t stream);
-#if defined(ISING_QUAD_TRACE)
-void quad_trace_dump(); // measurement builds only (ising_quad.hip)
-#endif
 struct QuadWordParams {
 	const uint64_t *src[2];  // black / white lattice the pass reads
 	uint64_t *dst[2];        // ... and writes (another buffer: the neighbours read their halos from src meanwhile)
 	const uint64_t *masks;   // level 0 of this pass
 	int gx, NRG;
 	int C, HG;               // row groups per tile, halo row groups per side (4 HG >= nlev - 1)
-	int nlev;                // levels of the pass (even: whole sweeps, black first)
+	int nlev;                // levels of the pass (even: whole sweeps, black first; at most 64); 0: no word pass in this launch
 	unsigned long long *cnt; // not null: the up spins of the state the pass stores are added here
 };
-hipError_t launch_quad_word(const QuadWordParams &p, int waves, hipStream_t stream);
-size_t quad_word_lds_bytes(const QuadWordParams &p, int waves, int maxi);
+struct QuadPassParams {
+	QuadWordParams w;
+	QuadDrawParams d;
+	int cus;                 // compute units of the device
+	int ntiles, stride;      // (set by the launcher) workgroups 0, stride, 2 stride, ... (ntiles of them) are tiles, the rest draw
+};
+hipError_t launch_quad_pass(QuadPassParams &p, int waves, hipStream_t stream);
+#if defined(ISING_QUAD_TRACE)
+void quad_trace_dump(); // measurement builds only (ising_quad.hip)
+#endif
+size_t quad_pass_lds_bytes(const QuadWordParams &w, int waves);
 int quad_word_maxi(const QuadWordParams &p, int waves); // items a wave works on per level at most (0: too many for any instantiation)
 hipError_t launch_dense_to_quad(const uint32_t *dense, uint64_t *quad, int gx, int NRG, hipStream_t stream);
 hipError_t launch_quad_to_dense(const uint64_t *quad, uint32_t *dense, int gx, int NRG, hipStream_t stream); // (dense: row 0; rows -1 and Y are refreshed too)

@@ -24,6 +24,7 @@
 //                reads one lattice buffer, writes its tile to the other.
 // ising_update.cpp (sweep_quad) runs the draws of batch k + 1 on a second stream next to the word passes of batch k.
 #include "ising_device.hpp"
+#include <algorithm>
 #include <cstdio>
 
 namespace ising {
@@ -44,24 +45,32 @@ __device__ __forceinline__ int qword_of_site(int j, int s) {
 #define QSG(a, b) "s[84+" #a ":84+" #b "]"
 #define Q_CLOB16 "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
 
-// ---- draws: unit = (level, chunk of `chunk` consecutive (row group, block) items), one wave each
-// Two forms of the same kernel: at most four waves per SIMD (lattices up to 2^24 spins: a word pass's workgroups -- twelve waves and half the LDS -- find
-// room on every CU the moment they are dispatched; 2048^2 1870 -> 2030 flips/ns, 4096 x 2048 2421 -> 2600) and as many as fit (larger lattices: the draws'
-// own throughput counts; 4096 x 16384 2876 against 2767).
-__device__ __forceinline__ void quad_draw_body(const QuadDrawParams &p);
-__global__ void __launch_bounds__(256) quad_draw_k(const QuadDrawParams p) { quad_draw_body(p); }
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4))) quad_draw4_k(const QuadDrawParams p) { quad_draw_body(p); }
-__device__ __forceinline__ void quad_draw_body(const QuadDrawParams &p) {
-	const int lane = threadIdx.x & 63;
-	const int wi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	__shared__ uint4 blk_const_all[4][16];
-	uint4 *blk_const = blk_const_all[wi];
+// Measurement build (make variant NAME=qtrace DEFS=-DISING_QUAD_TRACE): wave 0 of every word workgroup clocks where its time goes; quad_trace_dump()
+// prints the sums when the slab is destroyed.  Never in the product library.
+#if defined(ISING_QUAD_TRACE)
+__device__ unsigned long long g_qtrace[16];
+#define QTRC(i) do { if (wi == 0) { const long long t_ = wall_clock64(); if (lane == 0) qtr[i] += (unsigned long long)(t_ - qt_last); qt_last = t_; } } while (0)
+#else
+#define QTRC(i) do {} while (0)
+#endif
+
+__device__ __forceinline__ uint32_t lds_addr(const void *q) {
+	return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)q;
+}
+
+// ---- draws.  A drawing workgroup = NW waves on NW consecutive units of one level; a unit = `parts` quarters (4 Philox blocks = 256 B of masks each) of one
+// (row group, block) item -- half an item by default: the draws of a pass are a few units per wave of the chip, and the launch ends when the last wave does.
+__device__ __forceinline__ void quad_draw_part(const QuadDrawParams &p, long long wg, int wi, int lane, int NW, uint64_t *lds) {
+	uint4 *blk_const = reinterpret_cast<uint4 *>(lds) + wi * 16; // (private to the wave: 256 B)
 	const int NI = p.NRG * p.gx;
-	const int upl = (NI + p.chunk - 1) / p.chunk;
-	const long long unit = (long long)blockIdx.x * 4 + wi;
-	if (unit >= (long long)upl * p.nlev) return;
-	const int level = __builtin_amdgcn_readfirstlane((int)(unit / upl));
-	const int ch = __builtin_amdgcn_readfirstlane((int)(unit - (long long)level * upl));
+	const int upi = 4 / p.parts;               // units per item
+	const long long upl = (long long)NI * upi; // units per level
+	const long long wpl = (upl + NW - 1) / NW; // workgroups per level
+	const int level = __builtin_amdgcn_readfirstlane((int)(wg / wpl));
+	const long long u = (wg - (long long)level * wpl) * NW + wi;
+	if (u >= upl) return;
+	const int n = __builtin_amdgcn_readfirstlane((int)(u / upi));
+	const int q0 = __builtin_amdgcn_readfirstlane((int)(u - (long long)n * upi) * p.parts);
 	const uint32_t color = (uint32_t)level & 1u, it = p.it + ((uint32_t)level >> 1);
 	uint32_t seed_lo = p.seed_lo, seed_hi = p.seed_hi;
 	const uint32_t cx_base = 16u * (2u * it + color);
@@ -73,27 +82,23 @@ __device__ __forceinline__ void quad_draw_body(const QuadDrawParams &p) {
 	}
 	__builtin_amdgcn_wave_barrier();
 	__threadfence_block();
-	const int n0 = ch * p.chunk, n1 = min(NI, n0 + p.chunk);
 	uint32_t thr3 = p.n3, thr4 = p.n4;
-	for (int n = n0; n < n1; ++n) {
-		const int R = n / p.gx, bx = n - R * p.gx;
-		const uint32_t tid = (((uint32_t)R >> 2) * (uint32_t)p.gx + (uint32_t)bx) * 256u + ((uint32_t)R & 3u) * 64u + (uint32_t)lane;
-		const PhiloxRow pr = philox_row_setup(tid, seed_lo_cy, k2y);
-#if defined(ISING_QUAD_DRAW_TEST) // measurement builds (wrong masks by design): 1 = every wave stores into one slot of its own, over and over
-		const uint64_t *dst0 = p.masks + ((size_t)(blockIdx.x % 2048u) * 4 + wi) * 128;
-#else
-		const uint64_t *dst0 = p.masks + ((size_t)level * (size_t)NI + (size_t)n) * 128;
-#endif
-		const uint32_t d_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dst0), d_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)dst0 >> 32));
-		const uint64_t *dst = reinterpret_cast<const uint64_t *>(((uintptr_t)d_hi << 32) | d_lo);
-		uint4 kc_next = blk_const[0];
-		static_for<16>([&](auto B) {
+	const int R = n / p.gx, bx = n - R * p.gx;
+	const uint32_t tid = (((uint32_t)R >> 2) * (uint32_t)p.gx + (uint32_t)bx) * 256u + ((uint32_t)R & 3u) * 64u + (uint32_t)lane;
+	const PhiloxRow pr = philox_row_setup(tid, seed_lo_cy, k2y);
+	const uint64_t *dst0 = p.masks + ((size_t)level * (size_t)NI + (size_t)n) * 128;
+	const uint32_t d_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dst0), d_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)dst0 >> 32));
+	const uint64_t *dst = reinterpret_cast<const uint64_t *>(((uintptr_t)d_hi << 32) | d_lo);
+	for (int qq = q0; qq < q0 + p.parts; ++qq) {
+		const uint4 *kcs = blk_const + 4 * qq;
+		uint4 kc_next = kcs[0];
+		static_for<4>([&](auto B) {
 			uint32_t o0, o1, o2, o3;
 			const uint4 kc = kc_next;
-			if (B.value < 15) kc_next = blk_const[B.value + 1];
+			if (B.value < 3) kc_next = kcs[B.value + 1];
 			philox_block_pre(pr, PhiloxBlockConst{kc.x, kc.y, kc.z}, seed_lo, seed_hi, o0, o1, o2, o3);
-			if (B.value < 15) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kc_next.x), "+v"(kc_next.y), "+v"(kc_next.z) :: "memory");
-			const uint64_t *dstp = dst + 8 * B.value;
+			if (B.value < 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kc_next.x), "+v"(kc_next.y), "+v"(kc_next.z) :: "memory");
+			const uint64_t *dstp = dst + 32 * qq + 8 * B.value; // (c3, c4) of output q of block 4 qq + B = word p = 16 qq + 4 B + q: 16 bytes at 16 p
 			const uint32_t t3 = thr3, t4 = thr4;
 			asm volatile("v_cmp_gt_u32_e64 " QSG(0, 1) ", %0, %2\n\tv_cmp_gt_u32_e64 " QSG(2, 3) ", %1, %2\n\t"
 			             "v_cmp_gt_u32_e64 " QSG(4, 5) ", %0, %3\n\tv_cmp_gt_u32_e64 " QSG(6, 7) ", %1, %3\n\t"
@@ -108,42 +113,38 @@ __device__ __forceinline__ void quad_draw_body(const QuadDrawParams &p) {
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// one LDS-direct load of 1 KiB: lane l's 16 bytes at `base` + 16 l land at LDS byte address `lds` + 16 l (tracked by vmcnt, unknown to the compiler)
-__device__ __forceinline__ void mask_fetch(const uint64_t *base, uint32_t lds, int lane16) {
-	uint32_t keep; // (m0 is the compiler's: handed back as found)
-	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "s"(lds), "v"(lane16), "s"(base) : "memory");
+// The accept masks of a word wave's items wait in ACCUMULATION registers: a[4 n .. 4 n + 3], n = set * MAXI + item (three sets = three levels in flight), and
+// one more quad that takes the loads of items a level does not have (every level issues exactly MAXI loads: vmcnt counts them).  Loaded and read by inline
+// assembly alone -- the compiler has no use for these registers in a kernel without MFMA and without spills, knows nothing of loads in flight, and so cannot
+// copy one early (tracked loads into vector registers were fenced with vmcnt(0) on either side: no prefetch left).  The build checks the ISA: no accumulation
+// register outside these statements (tools/check_asm_loads.py --quad).
+#define QM_CASES(X) X(0, 0, 1, 2, 3) X(1, 4, 5, 6, 7) X(2, 8, 9, 10, 11) X(3, 12, 13, 14, 15) X(4, 16, 17, 18, 19) X(5, 20, 21, 22, 23) X(6, 24, 25, 26, 27) \
+	X(7, 28, 29, 30, 31) X(8, 32, 33, 34, 35) X(9, 36, 37, 38, 39) X(10, 40, 41, 42, 43) X(11, 44, 45, 46, 47) X(12, 48, 49, 50, 51)
+template <int N>
+__device__ __forceinline__ void qm_load(int off, const void *base) {
+#define QM_L(I, A, B, C, D) if constexpr (N == I) asm volatile("global_load_dwordx4 a[" #A ":" #D "], %0, %1" :: "v"(off), "s"(base) : "memory", "a" #A, "a" #B, "a" #C, "a" #D);
+	QM_CASES(QM_L)
+#undef QM_L
+}
+template <int N>
+__device__ __forceinline__ void qm_read(uint32_t &x0, uint32_t &x1, uint32_t &x2, uint32_t &x3) {
+#define QM_R(I, A, B, C, D) if constexpr (N == I) asm volatile("v_accvgpr_read_b32 %0, a" #A "\n\tv_accvgpr_read_b32 %1, a" #B "\n\tv_accvgpr_read_b32 %2, a" #C "\n\tv_accvgpr_read_b32 %3, a" #D : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3) :: "memory");
+	QM_CASES(QM_R)
+#undef QM_R
 }
 
-__device__ __forceinline__ uint32_t lds_addr(const void *q) {
-	return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)q;
-}
-
-// Measurement build (make variant NAME=qtrace DEFS=-DISING_QUAD_TRACE): wave 0 of every word workgroup clocks where its time goes; quad_trace_dump()
-// prints the sums when the slab is destroyed.  Never in the product library.
-#if defined(ISING_QUAD_TRACE)
-__device__ unsigned long long g_qtrace[16];
-#define QTRC(i) do { if (wi == 0) { const long long t_ = wall_clock64(); if (lane == 0) qtr[i] += (unsigned long long)(t_ - qt_last); qt_last = t_; } } while (0)
-#else
-#define QTRC(i) do {} while (0)
-#endif
-
-// ---- words: `nlev` levels (black first) of tile blockIdx.x.  Everything that indexes is wave-uniform and lives on the scalar unit; a wave works on
-// its items two at a time (all LDS reads of both first, one exposed round trip per pair).
+// ---- words: `nlev` levels (black first) of tile `tile`.  Everything that indexes is wave-uniform and lives on the scalar unit (a lone wave issues an
+// instruction every four or five cycles whatever its kind); a wave works on its items two at a time (all LDS reads of both first, one exposed round trip per
+// pair); the masks of the level after next are on their way into registers (three sets, the level loop unrolled by six = colours x sets).
 template <int MAXI>
-__global__ void __launch_bounds__(1024) quad_word_k(const QuadWordParams p) {
-	extern __shared__ __attribute__((aligned(16))) uint64_t q_lds[];
-	const int lane = threadIdx.x & 63;
-	const int wi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int NW = __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6));
+__device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile, int wi, int lane, int NW, uint64_t *q_lds) {
 	const int gx = p.gx, NRG = p.NRG, HG = p.HG;
 	const int NG = p.C + 2 * HG;
-	const int A = (int)blockIdx.x * p.C;
+	const int A = tile * p.C;
 	const int Cc = min(p.C, NRG - A);
 	const int gw = gx * 64;                 // words per row group
 	const int plane = NG * gw;              // words per colour in LDS
-	uint64_t *lat = q_lds;                                 // [2][NG][gx][64]
-	uint64_t *ring = q_lds + 2 * plane;                    // [NW][Q_DEPTH][MAXI][128]
-	uint64_t *dummy = ring + (size_t)NW * Q_DEPTH * MAXI * 128; // [NW][128]
+	uint64_t *lat = q_lds;                  // [2][NG][gx][64]
 #if defined(ISING_QUAD_TRACE)
 	__shared__ unsigned long long qtr[16];
 	if (threadIdx.x < 16) qtr[threadIdx.x] = 0;
@@ -151,7 +152,7 @@ __global__ void __launch_bounds__(1024) quad_word_k(const QuadWordParams p) {
 	long long qt_last = wall_clock64();
 	const long long qt_start = qt_last;
 #endif
-	__builtin_amdgcn_s_setprio(3); // (the draws of the batches to come share the chip: a word pass is a chain of short levels, theirs is throughput)
+	__builtin_amdgcn_s_setprio(3); // (the draws of the pass to come share the chip: a word pass is a chain of short levels, theirs is throughput)
 	auto wrapR = [&](int g) { // row group of the lattice behind local group g (no division: a halo wraps around a short lattice a few times at most)
 		int R = A - HG + g;
 		while (R < 0) R += NRG;
@@ -166,12 +167,10 @@ __global__ void __launch_bounds__(1024) quad_word_k(const QuadWordParams p) {
 		it_g[k] = __builtin_amdgcn_readfirstlane(n / gx);
 		it_b[k] = __builtin_amdgcn_readfirstlane(n - (n / gx) * gx);
 	}
-	const uint32_t ring_w = lds_addr(ring) + (uint32_t)wi * (Q_DEPTH * MAXI * 1024), dummy_w = lds_addr(dummy) + (uint32_t)wi * 1024;
 	const int lane16 = lane * 16;
 	const uint32_t gw_b = (uint32_t)gw * 8, plane_b = (uint32_t)plane * 8;
-	// A lone wave issues an instruction every four or five cycles whatever its kind, and a level is a few hundred of them: what indexes a level is computed
-	// ONCE, by the lanes in parallel -- lane L of rb_tab[k] / mk_tab[k] = where item k of level L sits in a colour plane (bytes) / in the pass's masks (KiB),
-	// ~0 where the level's active range does not reach it -- and the level loop picks its scalars up with v_readlane.
+	// What indexes a level is computed ONCE, by the lanes in parallel -- lane L of rb_tab[k] / mk_tab[k] = where item k of level L sits in a colour plane (bytes) /
+	// in the pass's masks (KiB), ~0 where the level's active range does not reach it -- and the level loop picks its scalars up with v_readlane.
 	constexpr uint32_t ABSENT = 0xFFFFFFFFu;
 	uint32_t rb_tab[MAXI], mk_tab[MAXI];
 	{
@@ -186,17 +185,16 @@ __global__ void __launch_bounds__(1024) quad_word_k(const QuadWordParams p) {
 			mk_tab[k] = on ? ((uint32_t)L * (uint32_t)NRG + (uint32_t)wrapR(g)) * (uint32_t)gx + (uint32_t)it_b[k] : ABSENT;
 		}
 	}
-	// masks of level Lp, this wave's items: exactly MAXI loads (absent items land in the wave's dummy slot)
-	auto prefetch = [&](int Lp, uint32_t slot) {
-#pragma unroll
-		for (int k = 0; k < MAXI; ++k) {
-			const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)mk_tab[k], Lp & 63);
-			if (idx != ABSENT && Lp < p.nlev) mask_fetch(p.masks + (size_t)idx * 128, slot + (uint32_t)k * 1024, lane16);
-			else mask_fetch(p.masks, dummy_w, lane16);
-		}
+	// the masks of level Lp into set SLOT: exactly MAXI loads (an item the level does not have, or a level past the pass's last: the spare quad)
+	auto fetch = [&](int Lp, auto SLOT) {
+		static_for<MAXI>([&](auto K) {
+			const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)mk_tab[K.value], Lp & 63);
+			if (idx != ABSENT && Lp < p.nlev) qm_load<SLOT.value * MAXI + K.value>(lane16, reinterpret_cast<const char *>(p.masks) + (size_t)idx * 1024);
+			else qm_load<Q_DEPTH * MAXI>(lane16, p.masks);
+		});
 	};
-	constexpr uint32_t SLOT_B = MAXI * 1024;
-	for (int Lp = 0; Lp < Q_DEPTH - 1; ++Lp) prefetch(Lp, ring_w + (uint32_t)Lp * SLOT_B);
+	fetch(0, std::integral_constant<int, 0>{});
+	fetch(1, std::integral_constant<int, 1>{});
 	// the tile and its halo row groups, both colours
 	for (int cg = wi; cg < 2 * NG; cg += NW) { // (row group, colour) by wave, its gx x 64 words by lane
 		const int c = cg >= NG, g = cg - c * NG;
@@ -219,11 +217,6 @@ __global__ void __launch_bounds__(1024) quad_word_k(const QuadWordParams p) {
 	else fwdA = m < 7 ? qword(j, m + 1, 1) : qword(j, 0, 0);
 	const bool specB = m == 0 && q == 0, specF = m == 7 && q == 3;
 	const int shB = specB ? 1 : 0, shF = specF ? 1 : 0;
-	const uint64_t mAB = specB ? ~Q_LANE0 : ~0ull, mBB = specB ? Q_LANE0 : 0ull;
-	const uint64_t mAF = specF ? ~Q_LANE15 : ~0ull, mBF = specF ? Q_LANE15 : 0ull;
-	// rows whose side neighbour is site s - 1 (readBack, optimized/main.cu:542): the even rows of a black level, the odd rows of a white one
-	const uint64_t m1c[2] = {mAB & Q_EVEN, mAB & ~Q_EVEN}, m2c[2] = {mBB & Q_EVEN, mBB & ~Q_EVEN};
-	const uint64_t m3c[2] = {mAF & ~Q_EVEN, mAF & Q_EVEN}, m4c[2] = {mBF & ~Q_EVEN, mBF & Q_EVEN};
 	// byte offsets inside a row group that do not depend on the level: own word, the two side words, and per item the words across the vector seam
 	const uint32_t o_me = (uint32_t)lane * 8, o_b1 = (uint32_t)backA * 8, o_f1 = (uint32_t)fwdA * 8;
 	uint32_t o_b2[MAXI], o_f2[MAXI]; // (relative to the item's own block)
@@ -238,19 +231,25 @@ __global__ void __launch_bounds__(1024) quad_word_k(const QuadWordParams p) {
 	typedef __attribute__((address_space(3))) uint64_t *lds_p;
 	auto ld = [](uint32_t a) { return *(lds_cp)(uintptr_t)a; };
 
-	// one level; COL = the colour it updates (levels alternate from black: the loop below is unrolled by two)
-	auto level = [&](auto COL, int L, uint32_t slot, uint32_t slot_ahead) {
+	// one level; COL = the colour it updates, SLOT = the set its masks are in (level L: colour L & 1, set L mod 3)
+	auto level = [&](auto COL, auto SLOT, int L) {
 		constexpr int c = COL.value;
-		prefetch(L + Q_DEPTH - 1, slot_ahead);
+		fetch(L + Q_DEPTH - 1, std::integral_constant<int, (SLOT.value + Q_DEPTH - 1) % Q_DEPTH>{});
 		QTRC(1); // prefetch issue
-		asm volatile("s_waitcnt vmcnt(%0)" :: "n"((Q_DEPTH - 1) * MAXI) : "memory");
-		QTRC(2); // wait for this level's masks
+		asm volatile("s_waitcnt vmcnt(%0)" :: "n"((Q_DEPTH - 1) * MAXI) : "memory"); // this level's masks have landed (the two levels behind them may still be out)
 		const uint32_t S_w = lat_w + (c ? 0u : plane_b), D_w = lat_w + (c ? plane_b : 0u);
-		const uint64_t m1 = m1c[c], m2 = m2c[c], m3 = m3c[c], m4 = m4c[c];
-		static_for<(MAXI + 1) / 2>([&](auto KP) {
-			constexpr int k0 = 2 * KP.value, k1 = k0 + 1 < MAXI ? k0 + 1 : k0; // (an odd MAXI's last item stands alone)
+		// rows whose side neighbour is site s - 1 (readBack, optimized/main.cu:542): the even rows of a black level, the odd rows of a white one; the lanes
+		// whose side word crosses the vector seam take one bit per row from the word across it (made here from two flags: eight registers less to keep)
+		constexpr uint64_t BK = c ? ~Q_EVEN : Q_EVEN, FW = ~BK;
+		const uint64_t m1 = specB ? (~Q_LANE0 & BK) : BK, m2 = specB ? (Q_LANE0 & BK) : 0ull;
+		const uint64_t m3 = specF ? (~Q_LANE15 & FW) : FW, m4 = specF ? (Q_LANE15 & FW) : 0ull;
+#ifndef ISING_QUAD_PAIR // items a wave works on at a time: 2 = all LDS reads of a pair first (one exposed round trip per pair, ~25 more registers), 1 = one by one
+#define ISING_QUAD_PAIR 1
+#endif
+		constexpr int STEP = ISING_QUAD_PAIR;
+		static_for<(MAXI + STEP - 1) / STEP>([&](auto KP) {
+			constexpr int k0 = STEP * KP.value, k1 = (STEP > 1 && k0 + 1 < MAXI) ? k0 + 1 : k0; // (an odd MAXI's last item stands alone)
 			constexpr int NK = k1 > k0 ? 2 : 1;
-			constexpr int ks[2] = {k0, k1};
 			const uint32_t rb0 = (uint32_t)__builtin_amdgcn_readlane((int)rb_tab[k0], L);
 			if (rb0 == ABSENT) return; // (items are dealt row group major: the pair's first is its lowest)
 			uint64_t ct[2], upc[2], dnc[2], me[2], x1B[2], x1F[2], x2B[2], x2F[2], c3[2], c4[2];
@@ -274,11 +273,12 @@ __global__ void __launch_bounds__(1024) quad_word_k(const QuadWordParams p) {
 				dnc[t] = ld(S_w + db + o_me);
 				dst[t] = D_w + rb + o_me;
 				me[t] = ld(dst[t]);
-				const uint32_t mk = slot + (uint32_t)k * 1024 + (uint32_t)lane16;
-				c3[t] = ld(mk);
-				c4[t] = ld(mk + 8);
+				uint32_t a0, a1, a2, a3; // (an absent item's set holds whatever it held: its result is not stored)
+				if (t == 0) qm_read<SLOT.value * MAXI + k0>(a0, a1, a2, a3);
+				else qm_read<SLOT.value * MAXI + k1>(a0, a1, a2, a3);
+				c3[t] = ((uint64_t)a1 << 32) | a0;
+				c4[t] = ((uint64_t)a3 << 32) | a2;
 			}
-			(void)ks;
 #pragma unroll
 			for (int t = 0; t < NK; ++t) {
 				const uint64_t sd = ((x1B[t] << shB) & m1) | ((x2B[t] >> 15) & m2) | ((x1F[t] >> shF) & m3) | ((x2F[t] << 15) & m4);
@@ -293,19 +293,12 @@ __global__ void __launch_bounds__(1024) quad_word_k(const QuadWordParams p) {
 		__syncthreads();
 		QTRC(4); // barrier
 	};
-	// (ring slot of level L = L mod Q_DEPTH, kept as two running offsets)
-	uint32_t s_now = 0, s_ahead = (Q_DEPTH - 1) * SLOT_B;
-	auto advance = [&]() {
-		s_now = s_now + SLOT_B == Q_DEPTH * SLOT_B ? 0u : s_now + SLOT_B;
-		s_ahead = s_ahead + SLOT_B == Q_DEPTH * SLOT_B ? 0u : s_ahead + SLOT_B;
-	};
-	for (int L = 0; L < p.nlev; L += 2) { // (whole sweeps: nlev is even)
-		level(std::integral_constant<int, 0>{}, L, ring_w + s_now, ring_w + s_ahead);
-		advance();
-		level(std::integral_constant<int, 1>{}, L + 1, ring_w + s_now, ring_w + s_ahead);
-		advance();
+	for (int L0 = 0; L0 < p.nlev; L0 += 6) { // (six levels a turn: the colour and the mask set of each are compile-time)
+		static_for<6>([&](auto I) {
+			if (L0 + I.value < p.nlev) level(std::integral_constant<int, I.value & 1>{}, std::integral_constant<int, I.value % Q_DEPTH>{}, L0 + I.value);
+		});
 	}
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the dummy loads behind the last level)
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the spare quad's loads behind the last level)
 	// the tile itself into the other buffer; a print point: the up spins of what is stored
 	unsigned long long ups = 0;
 	for (int cg = wi; cg < 2 * Cc; cg += NW) {
@@ -328,6 +321,24 @@ __global__ void __launch_bounds__(1024) quad_word_k(const QuadWordParams p) {
 	__syncthreads();
 	if (threadIdx.x < 16) atomicAdd(&g_qtrace[threadIdx.x], qtr[threadIdx.x]);
 #endif
+}
+
+// One launch = the word pass of T sweeps on the masks the launch before made + the draws of the pass to come: workgroups [0, ntiles) take a tile each (they
+// are dispatched first), the rest draw.  One stream, no events: nothing rests on two hardware queues running side by side (the first form of this path --
+// draws on a second stream -- ran 1950 flips/ns at 2048^2 in a fresh process and 660 in one whose earlier contexts had created high-priority streams).
+// (one and two items a wave: six waves per SIMD -- two workgroups of twelve waves per CU, a tile next to a drawing workgroup -- are worth 80 registers a lane)
+template <int MAXI>
+__global__ void __launch_bounds__(MAXI <= 2 ? 1024 : 512) __attribute__((amdgpu_waves_per_eu(MAXI <= 2 ? 6 : 2))) quad_pass_k(const QuadPassParams p) {
+	extern __shared__ __attribute__((aligned(16))) uint64_t q_lds[];
+	const int lane = threadIdx.x & 63;
+	const int wi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int NW = __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6));
+	// tiles sit at every `stride`-th workgroup index (1: all of them first -- a small lattice's word pass is the launch's critical path; lattices of more tiles
+	// than the chip has CUs spread them among the drawing workgroups, so that the latency-bound and the throughput-bound kind run side by side all along)
+	const unsigned b = blockIdx.x, st = (unsigned)p.stride;
+	const unsigned tiles_before = min((unsigned)p.ntiles, (b + st - 1) / st);
+	if (b % st == 0 && b / st < (unsigned)p.ntiles) quad_word_part<MAXI>(p.w, (int)(b / st), wi, lane, NW, q_lds);
+	else quad_draw_part(p.d, (long long)b - tiles_before, wi, lane, NW, q_lds);
 }
 
 // ---- dense <-> quad, one wave per (row group, block); dense rows are gx * 32 words of 32 sites
@@ -382,7 +393,7 @@ __global__ void __launch_bounds__(256) quad_to_dense_k(const uint64_t *__restric
 void quad_trace_dump() {
 	unsigned long long h[16] = {};
 	if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_qtrace), sizeof(h)) != hipSuccess || !h[7]) return;
-	static const char *names[6] = {"tile load", "prefetch issue", "mask wait", "items", "barrier", "store"};
+	static const char *names[6] = {"tile load", "prefetch issue", "(unused)", "items", "barrier", "store"};
 	fprintf(stderr, "quad word passes: %llu workgroups, %.1f levels each, %.2f us each (100 MHz clock)\n", h[7], (double)h[8] / h[7], (double)h[6] / h[7] / 100.0);
 	for (int i = 0; i < 6; i++) fprintf(stderr, "  %-15s %6.2f us per workgroup  %5.1f %%\n", names[i], (double)h[i] / h[7] / 100.0, 100.0 * h[i] / h[6]);
 	unsigned long long z[16] = {};
@@ -390,49 +401,48 @@ void quad_trace_dump() {
 }
 #endif
 
-hipError_t launch_quad_draw(const QuadDrawParams &p, hipStream_t stream) {
-	const long long NI = (long long)p.NRG * p.gx, units = (NI + p.chunk - 1) / p.chunk * p.nlev;
-	if (p.few_waves) hipLaunchKernelGGL(quad_draw4_k, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, stream, p);
-	else hipLaunchKernelGGL(quad_draw_k, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, stream, p);
-	return hipGetLastError();
-}
-
-size_t quad_word_lds_bytes(const QuadWordParams &p, int waves, int maxi) {
-	const size_t NG = (size_t)p.C + 2 * (size_t)p.HG;
-	return (2 * NG * (size_t)p.gx * 64 + (size_t)waves * Q_DEPTH * (size_t)maxi * 128 + (size_t)waves * 128) * sizeof(uint64_t);
+size_t quad_pass_lds_bytes(const QuadWordParams &w, int waves) {
+	const size_t NG = (size_t)w.C + 2 * (size_t)w.HG;
+	return std::max<size_t>(2 * NG * (size_t)w.gx * 64 * sizeof(uint64_t), (size_t)waves * 256); // the tile + halo, both colours; a drawing workgroup's block constants
 }
 
 int quad_word_maxi(const QuadWordParams &p, int waves) {
 	const int items = (p.C + 2 * p.HG) * p.gx, need = (items + waves - 1) / waves;
-	for (int mi : {1, 2, 3, 4, 6, 8, 12, 16}) if (mi >= need) return mi;
+	for (int mi : {1, 2, 3, 4}) if (mi >= need) return (mi > 2 && waves > 8) ? 0 : mi; // (three and four items a wave: the registers of eight waves at most)
 	return 0;
 }
 
 template <int MAXI>
-static hipError_t launch_word_t(const QuadWordParams &p, int waves, size_t lds, hipStream_t stream) {
+static hipError_t launch_pass_t(const QuadPassParams &p, int waves, long long grid, size_t lds, hipStream_t stream) {
 	static size_t allowed = 0; // (per instantiation; contexts of one process share a device class)
 	if (lds > 64 * 1024 && lds > allowed) {
-		const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&quad_word_k<MAXI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&quad_pass_k<MAXI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if (e != hipSuccess) return e;
 		allowed = lds;
 	}
-	const int tiles = (p.NRG + p.C - 1) / p.C;
-	hipLaunchKernelGGL(quad_word_k<MAXI>, dim3((unsigned)tiles), dim3((unsigned)waves * 64), lds, stream, p);
+	hipLaunchKernelGGL(quad_pass_k<MAXI>, dim3((unsigned)grid), dim3((unsigned)waves * 64), lds, stream, p);
 	return hipGetLastError();
 }
 
-hipError_t launch_quad_word(const QuadWordParams &p, int waves, hipStream_t stream) {
-	const int mi = quad_word_maxi(p, waves);
-	const size_t lds = quad_word_lds_bytes(p, waves, mi);
+// `p.w.nlev` = 0: draws only (the first launch of a call); `p.d.nlev` = 0: words only (its last)
+hipError_t launch_quad_pass(QuadPassParams &p, int waves, hipStream_t stream) {
+	p.ntiles = p.w.nlev > 0 ? (p.w.NRG + p.w.C - 1) / p.w.C : 0;
+	long long draw_wgs = 0;
+	if (p.d.nlev > 0) {
+		const long long upl = (long long)p.d.NRG * p.d.gx * (4 / p.d.parts);
+		draw_wgs = (upl + waves - 1) / waves * p.d.nlev;
+	}
+	const long long grid = p.ntiles + draw_wgs;
+	if (grid <= 0) return hipSuccess;
+	p.stride = (p.ntiles > p.cus && draw_wgs > 0) ? (int)std::max<long long>(1, grid / p.ntiles) : 1;
+	if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+	const int mi = quad_word_maxi(p.w, waves);
+	const size_t lds = quad_pass_lds_bytes(p.w, waves);
 	switch (mi) {
-	case 1: return launch_word_t<1>(p, waves, lds, stream);
-	case 2: return launch_word_t<2>(p, waves, lds, stream);
-	case 3: return launch_word_t<3>(p, waves, lds, stream);
-	case 4: return launch_word_t<4>(p, waves, lds, stream);
-	case 6: return launch_word_t<6>(p, waves, lds, stream);
-	case 8: return launch_word_t<8>(p, waves, lds, stream);
-	case 12: return launch_word_t<12>(p, waves, lds, stream);
-	case 16: return launch_word_t<16>(p, waves, lds, stream);
+	case 1: return launch_pass_t<1>(p, waves, grid, lds, stream);
+	case 2: return launch_pass_t<2>(p, waves, grid, lds, stream);
+	case 3: return launch_pass_t<3>(p, waves, grid, lds, stream);
+	case 4: return launch_pass_t<4>(p, waves, grid, lds, stream);
 	default: return hipErrorInvalidValue;
 	}
 }

@@ -331,10 +331,10 @@ static int sweep_tiles_counted(ising_ctx *c, int first_it, int nsweeps, int ever
 	return ISING_OK;
 }
 
-// Small lattices on the quad layout (ising_quad.hip): the draws of a batch of sweeps run on the context's second stream, a batch AHEAD of the word passes that
-// consume them on the slab's own stream (two mask buffers; ev_qdraw / ev_qword carry the two dependencies); a word pass of <= T sweeps reads one lattice buffer
-// and writes the other.  The spins live in d_lat (dense layout) between calls: a call converts on its way in and out, so everything else the library does with
-// a dense slab -- counts, energy, dumps, a temperature change -- finds what it always found.
+// Small lattices on the quad layout (ising_quad.hip).  A pass = up to T sweeps; launch k = the word pass k on the masks launch k - 1 drew + the draws of pass
+// k + 1 (two mask buffers, one stream, no events: the launches of a call are k = -1 .. passes - 1, the first draws only, the last works on words only).
+// The spins live in d_lat (dense layout) between calls: a call converts on its way in and out, so everything else the library does with a dense slab --
+// counts, energy, dumps, a temperature change -- finds what it always found.
 static bool sweeps_quad(const ising_ctx *c, int nsweeps) {
 	return c->quad_C > 0 && nsweeps >= 2 && c->wrap && c->dense && !c->ballot && !c->cfg.use_J && !c->cfg.XSL && c->fast_ok && !ising_host::needs_generic(c);
 }
@@ -359,65 +359,42 @@ static int sweep_quad(ising_ctx *c, int first_it, int nsweeps, int every, unsign
 		}
 	}
 	if (nmeas) *nmeas = k;
-	// batches: consecutive passes whose sweeps fit a mask buffer
-	std::vector<std::pair<size_t, size_t>> batches; // [first pass, one past the last)
-	for (size_t a = 0; a < passes.size();) {
-		size_t b = a;
-		int sum = 0;
-		while (b < passes.size() && sum + passes[b].ns <= c->quad_batch) sum += passes[b++].ns;
-		batches.push_back({a, b});
-		a = b;
-	}
 	const int NRG = c->cfg.Y / 4, gx = c->gx;
 	const size_t qw = c->quad_words(), NI = qw / 64;
-	const size_t mask_words = (size_t)(2 * c->quad_batch) * NI * 128; // per buffer
-	auto draw = [&](size_t bi, unsigned buf) -> int {
-		int sum = 0;
-		for (size_t q = batches[bi].first; q < batches[bi].second; q++) sum += passes[q].ns;
-		ising::QuadDrawParams dp{};
-		dp.masks = c->d_qmasks + (size_t)buf * mask_words;
-		dp.seed_lo = (uint32_t)c->cfg.seed;
-		dp.seed_hi = (uint32_t)(c->cfg.seed >> 32);
-		dp.it = (uint32_t)passes[batches[bi].first].it;
-		dp.n3 = (uint32_t)c->thr[3];
-		dp.n4 = (uint32_t)c->thr[4];
-		dp.gx = gx; dp.NRG = NRG; dp.nlev = 2 * sum; dp.chunk = c->quad_chunk;
-		dp.few_waves = (long long)c->cfg.X * c->cfg.Y <= (1LL << 24);
-		HIP_TRY(hipStreamWaitEvent(c->qstream, c->ev_qword[buf], 0)); // the passes that read this buffer two batches ago
-		HIP_TRY(ising::launch_quad_draw(dp, c->qstream));
-		HIP_TRY(hipEventRecord(c->ev_qdraw[buf], c->qstream));
-		return ISING_OK;
-	};
+	const size_t mask_words = (size_t)(2 * T) * NI * 128; // per buffer: the levels of one pass
 	auto dense_plane = [&](int color) { return reinterpret_cast<uint32_t *>(c->lat(color)); };
-	const unsigned buf0 = c->qbatch_no, NB = (unsigned)c->quad_nbuf;
-	// (the draws need nothing from the lattice: the first NB - 1 batches are under way while the spins are converted; batch b + NB - 1 goes out in front of the
-	// passes of batch b -- its buffer was read by batch b - 1, whose event is already recorded)
-	size_t drawn = 0;
-	for (; drawn < batches.size() && drawn + 1 < NB; drawn++) if (int rc = draw(drawn, (buf0 + (unsigned)drawn) % NB)) return rc;
 	int cur = 0;
 	for (int color = 0; color < 2; color++) HIP_TRY(ising::launch_dense_to_quad(dense_plane(color), c->d_quad + (size_t)color * qw, gx, NRG, c->stream));
-	for (size_t bi = 0; bi < batches.size(); bi++) {
-		const unsigned buf = (buf0 + (unsigned)bi) % NB;
-		if (drawn < batches.size()) { if (int rc = draw(drawn, (buf0 + (unsigned)drawn) % NB)) return rc; drawn++; }
-		HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_qdraw[buf], 0));
-		int lev = 0;
-		for (size_t q = batches[bi].first; q < batches[bi].second; q++) {
-			ising::QuadWordParams wp{};
+	const int np = (int)passes.size();
+	for (int q = -1; q < np; q++) {
+		ising::QuadPassParams pp{};
+		pp.w.gx = pp.d.gx = gx;
+		pp.w.NRG = pp.d.NRG = NRG;
+		pp.w.C = c->quad_C;
+		pp.w.HG = c->quad_HG;
+		pp.cus = c->cus;
+		if (q >= 0) { // the word pass q: reads lattice buffer `cur` and mask buffer q & 1
 			for (int color = 0; color < 2; color++) {
-				wp.src[color] = c->d_quad + ((size_t)cur * 2 + color) * qw;
-				wp.dst[color] = c->d_quad + ((size_t)(cur ^ 1) * 2 + color) * qw;
+				pp.w.src[color] = c->d_quad + ((size_t)cur * 2 + color) * qw;
+				pp.w.dst[color] = c->d_quad + ((size_t)(cur ^ 1) * 2 + color) * qw;
 			}
-			wp.masks = c->d_qmasks + (size_t)buf * mask_words + (size_t)lev * NI * 128;
-			wp.gx = gx; wp.NRG = NRG; wp.C = c->quad_C; wp.HG = c->quad_HG;
-			wp.nlev = 2 * passes[q].ns;
-			wp.cnt = passes[q].meas >= 0 ? d_cnt + passes[q].meas : nullptr;
-			HIP_TRY(ising::launch_quad_word(wp, c->quad_waves, c->stream));
-			lev += wp.nlev;
+			pp.w.masks = c->d_qmasks + (size_t)(q & 1) * mask_words;
+			pp.w.nlev = 2 * passes[q].ns;
+			pp.w.cnt = passes[q].meas >= 0 ? d_cnt + passes[q].meas : nullptr;
 			cur ^= 1;
 		}
-		HIP_TRY(hipEventRecord(c->ev_qword[buf], c->stream));
+		if (q + 1 < np) { // the draws of pass q + 1 into the other mask buffer
+			pp.d.masks = c->d_qmasks + (size_t)((q + 1) & 1) * mask_words;
+			pp.d.seed_lo = (uint32_t)c->cfg.seed;
+			pp.d.seed_hi = (uint32_t)(c->cfg.seed >> 32);
+			pp.d.it = (uint32_t)passes[q + 1].it;
+			pp.d.n3 = (uint32_t)c->thr[3];
+			pp.d.n4 = (uint32_t)c->thr[4];
+			pp.d.nlev = 2 * passes[q + 1].ns;
+			pp.d.parts = c->quad_parts;
+		}
+		HIP_TRY(ising::launch_quad_pass(pp, c->quad_waves, c->stream));
 	}
-	c->qbatch_no = buf0 + (unsigned)batches.size();
 	for (int color = 0; color < 2; color++) HIP_TRY(ising::launch_quad_to_dense(c->d_quad + ((size_t)cur * 2 + color) * qw, dense_plane(color), gx, NRG, c->stream));
 	return ISING_OK;
 }

@@ -12,7 +12,7 @@ TC = ig.CRIT_TEMP_F32
 B, D = ig.LAYOUT_BALLOT, ig.LAYOUT_DENSE
 
 CASES = [  # X, Y, layout AUTO picks, fused, tiled, strip rows (0: whatever); quad (round 5: up to four blocks of 2048 columns, ising_quad.hip) = dense, neither fused nor tiled
-    (8192, 1280, D, False, False, 0), (8192, 2048, D, False, False, 0), (16384, 768, B, True, False, 1), (16384, 2048, B, True, False, 1),
+    (8192, 1280, B, True, False, 1), (8192, 2048, B, True, False, 1), (16384, 768, B, True, False, 1), (16384, 2048, B, True, False, 1),
     (24576, 896, B, True, False, 1), (32768, 640, B, True, False, 1), (32768, 1024, B, True, False, 1), (65536, 512, B, True, False, 1),
     (16384, 2176, B, True, False, 2), (24576, 1536, B, True, False, 2), (131072, 1024, B, True, False, 4), (24576, 4096, B, True, False, 4),
     (12288, 1536, B, True, False, 1), (6144, 3072, D, False, False, 0), (20480, 4096, B, True, False, 0), (28672, 4096, B, True, False, 0),

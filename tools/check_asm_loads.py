@@ -26,6 +26,44 @@ def operands(line):
         out |= regs(tok)
     return out
 
+def check_quad(path):
+    """ising_quad.hip: the word passes keep their accept masks in accumulation registers that inline assembly alone loads (global_load_dwordx4 a[..]) and
+    reads (v_accvgpr_read_b32) -- the compiler must have no use of its own for any of them in those kernels (no copy of a register whose load is in flight
+    can exist then), and nothing may spill."""
+    bad, kern, in_asm, nasm, mine = 0, None, False, 0, 0
+    for i, ln in enumerate(open(path).read().split("\n")):
+        m = re.match(r"^(_Z\w*quad_pass_kILi(\d+)E\w*):", ln)
+        if m:
+            kern, nasm, mine = m.group(1), 0, 12 * int(m.group(2)) + 4  # a[0 .. 12 MAXI + 3]: three sets of MAXI quads and the spare one
+        if "#ASMSTART" in ln:
+            in_asm = True
+        if "#ASMEND" in ln:
+            in_asm = False
+        if not kern:
+            continue
+        body = ln.split(";")[0].strip()
+        used = [int(x) for x in re.findall(r"\ba(\d+)\b", body)] + [int(y) for x in re.findall(r"\ba\[(\d+):(\d+)\]", body) for y in x]
+        touches = any(r < mine for r in used)
+        if touches and in_asm:
+            nasm += 1
+        if touches and not in_asm:  # (accumulation registers above the masks' are the compiler's to spill into)
+            print(f"{path}:{i + 1}: {kern}: the compiler uses an accumulation register of the masks: {body}")
+            bad += 1
+        if re.match(r"\s*(scratch_|buffer_(load|store).*offen)", body):
+            print(f"{path}:{i + 1}: {kern}: scratch access (a spill?): {body}")
+            bad += 1
+        if "s_endpgm" in ln:
+            print(f"{kern}: {nasm} inline-assembly statements on accumulation registers, none by the compiler")
+            if nasm == 0:
+                print(f"{path}: {kern}: no accumulation-register statement found: the check looks at the wrong thing")
+                bad += 1
+            kern = None
+    return bad
+
+
+if len(sys.argv) > 2 and sys.argv[1] == "--quad":
+    sys.exit(1 if check_quad(sys.argv[2]) else 0)
+
 bad = 0
 kern = None
 lines = open(sys.argv[1]).read().split("\n")
