@@ -59,7 +59,6 @@ int read_policy(ising_policy *pol) {
 	if (num("ISING_QUAD_C", &v) && v > 0) pol->quad_C = v;
 	if (num("ISING_QUAD_T", &v) && v > 0) pol->quad_T = v;
 	if (num("ISING_QUAD_WAVES", &v) && v > 0) pol->quad_waves = v;
-	if (num("ISING_QUAD_PARTS", &v) && (v == 1 || v == 2 || v == 4)) pol->quad_parts = v;
 	pol->no_ballot = getenv("ISING_NO_BALLOT") != nullptr;
 	if (const char *e = getenv("ISING_TAIL")) {
 		int rows = 0, h = 1;
@@ -594,11 +593,11 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	if (quad_pick && c->dense && !c->ballot) {
 		const int NRG = cfg->Y / 4;
 		// (2048 columns: eight sweeps a pass on four row groups, twelve waves -- eight once the tiles are 128 and more: 2048^2 1707 against 1525; 4096: twelve waves,
-		// two items each; 6144: four sweeps a pass; 8192: six on two row groups, sixteen waves.  A wave keeps at most two items: 80 registers, six waves per SIMD.)
-		int T = pol.quad_T ? pol.quad_T : (c->gx <= 2 ? 8 : (c->gx == 3 ? 4 : 6));
+		// two items each; 6144: four sweeps a pass; 8192: the same on sixteen waves.  A wave keeps at most two items: 80 registers, six waves per SIMD.)
+		int T = pol.quad_T ? pol.quad_T : (c->gx <= 2 ? 8 : 4);
 		T = std::max(1, std::min(T, 32));
 		const int HG = (2 * T - 1 + 3) / 4;
-		int C = pol.quad_C ? pol.quad_C : (c->gx <= 3 ? 4 : 2);
+		int C = pol.quad_C ? pol.quad_C : 4;
 		C = std::max(1, std::min(C, NRG));
 		int waves = pol.quad_waves ? pol.quad_waves : (c->gx == 1 ? (NRG / C >= 128 ? 8 : 12) : (c->gx <= 3 ? 12 : 16));
 		waves = std::max(1, std::min(waves, 16));
@@ -609,7 +608,6 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeSharedMemPerBlockOptin, cfg->device) != hipSuccess || lds_max <= 0) { (void)hipGetLastError(); lds_max = 64 * 1024; }
 		if (mi > 0 && ising::quad_pass_lds_bytes(qp, waves) <= (size_t)lds_max) {
 			c->quad_C = C; c->quad_T = T; c->quad_HG = HG; c->quad_waves = waves;
-			c->quad_parts = pol.quad_parts ? pol.quad_parts : 4;
 		} else if (pol.quad == 1 && (pol.quad_C || pol.quad_T || pol.quad_waves)) {
 			delete c;
 			return fail(ISING_E_ARG, "ISING_QUAD_*: tiles of %d row groups + 2 x %d at %d waves: too many items a wave, or more LDS than a workgroup's (%d bytes) at X = %d", C, HG, waves, lds_max, cfg->X);

@@ -25,7 +25,7 @@ struct ising_policy {
 	int tiles = -1;          // ISING_TILES=0/1: small lattices on the dense layout sweep in tile launches of several sweeps (-1: by lattice size)
 	int tile_rows = 0, tile_words = 0, tile_sweeps = 0, tile_threads = 0, tile_xcd = -1; // ISING_TILE_ROWS / _WORDS / _SWEEPS / _THREADS / _XCD (0 / -1: by lattice size)
 	int quad = -1;           // ISING_QUAD=0/1: small lattices on the dense layout sweep on the quad layout -- draws ahead of the lattice, word passes on tiles (ising_quad.hip; -1: by lattice size)
-	int quad_C = 0, quad_T = 0, quad_waves = 0, quad_parts = 0; // ISING_QUAD_C / _T / _WAVES / _PARTS: row groups per tile, sweeps per pass, waves per workgroup, quarters of an item per drawing wave (0: by lattice size)
+	int quad_C = 0, quad_T = 0, quad_waves = 0; // ISING_QUAD_C / _T / _WAVES: row groups per tile, sweeps per pass, waves per workgroup (0: by lattice size)
 	int split = -1;          // ISING_SPLIT=0/1: fused launches of a lone slab in the split form (draw units / word units, ising_ballot.hip: ballot_split_k; -1: by tickets per level)
 	int split_lead = -1;     // ISING_SPLIT_LEAD=n: draw units a workgroup does before its first word unit (-1: 1)
 	int ring_counted = -1;   // ISING_RING_COUNTED=0/1/2: print points of rings never / where possible (default) / always (an error where not) inside the deep launches
@@ -60,7 +60,6 @@ struct ising_ctx {
 	// Small lattices on the quad layout (ising_quad.hip; ising_update.cpp: sweep_quad): the spins live in d_lat (dense layout) between calls; a call converts,
 	// launches once per pass of T sweeps -- the word pass on its tiles + the draws of the pass to come -- and converts back
 	int quad_C = 0, quad_T = 0, quad_HG = 0, quad_waves = 0; // tile: row groups, sweeps per pass, halo row groups per side, waves per workgroup (quad_C == 0: off)
-	int quad_parts = 2;            // quarters of an item a drawing wave takes
 	uint64_t *d_quad = nullptr;    // two lattice buffers of 2 colours x Y/4 row groups x gx blocks x 64 words
 	uint64_t *d_qmasks = nullptr;  // two mask buffers of 2 quad_T levels x Y/4 x gx KiB
 	size_t quad_words() const { return (size_t)cfg.X / 2048 * ((size_t)cfg.Y / 4) * 64; } // per colour

@@ -190,7 +190,7 @@ struct QuadDrawParams {
 	uint32_t n3, n4;
 	int gx, NRG;
 	int nlev;                // 0: no draws in this launch
-	int parts;               // quarters of an item (4 Philox blocks each) a wave draws: 1, 2 or 4
+	int nwaves;              // (set by the launcher) the drawing waves of the launch: each takes an equal run of the pass's quarter items
 };
 struct QuadWordParams {
 	const uint64_t *src[2];  // black / white lattice the pass reads
@@ -205,7 +205,7 @@ struct QuadPassParams {
 	QuadWordParams w;
 	QuadDrawParams d;
 	int cus;                 // compute units of the device
-	int ntiles, stride;      // (set by the launcher) workgroups 0, stride, 2 stride, ... (ntiles of them) are tiles, the rest draw
+	int ntiles;              // (set by the launcher) workgroups [0, ntiles) are tiles, the rest draw
 };
 hipError_t launch_quad_pass(QuadPassParams &p, int waves, hipStream_t stream);
 #if defined(ISING_QUAD_TRACE)

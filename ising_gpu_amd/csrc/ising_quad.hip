@@ -58,57 +58,79 @@ __device__ __forceinline__ uint32_t lds_addr(const void *q) {
 	return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)q;
 }
 
-// ---- draws.  A drawing workgroup = NW waves on NW consecutive units of one level; a unit = `parts` quarters (4 Philox blocks = 256 B of masks each) of one
-// (row group, block) item -- half an item by default: the draws of a pass are a few units per wave of the chip, and the launch ends when the last wave does.
+// ---- draws.  The drawing workgroups of a launch are as many as find room next to its tiles, each wave of them takes an EQUAL share of the pass's draws --
+// a run of consecutive quarter items (4 Philox blocks = 256 B of masks each; level major, item, quarter) -- so the launch's draws end together: workgroups
+// of one item a wave, dealt by the dispatcher, ended a launch of 2048^2 on a second, half-empty round (21.6 us a launch where the draws are 10.4 us of the chip).
 __device__ __forceinline__ void quad_draw_part(const QuadDrawParams &p, long long wg, int wi, int lane, int NW, uint64_t *lds) {
 	uint4 *blk_const = reinterpret_cast<uint4 *>(lds) + wi * 16; // (private to the wave: 256 B)
 	const int NI = p.NRG * p.gx;
-	const int upi = 4 / p.parts;               // units per item
-	const long long upl = (long long)NI * upi; // units per level
-	const long long wpl = (upl + NW - 1) / NW; // workgroups per level
-	const int level = __builtin_amdgcn_readfirstlane((int)(wg / wpl));
-	const long long u = (wg - (long long)level * wpl) * NW + wi;
-	if (u >= upl) return;
-	const int n = __builtin_amdgcn_readfirstlane((int)(u / upi));
-	const int q0 = __builtin_amdgcn_readfirstlane((int)(u - (long long)n * upi) * p.parts);
-	const uint32_t color = (uint32_t)level & 1u, it = p.it + ((uint32_t)level >> 1);
-	uint32_t seed_lo = p.seed_lo, seed_hi = p.seed_hi;
-	const uint32_t cx_base = 16u * (2u * it + color);
-	const uint32_t seed_lo_cy = seed_lo ^ (uint32_t)((2ull * it + color) >> 28); // counter word 1 enters round 1 next to the key (dense_update_k)
-	const uint32_t k2y = seed_hi + 2u * PHILOX_W1;
-	if (lane < 16) {
-		const PhiloxBlockConst kc = philox_block_const(cx_base + (uint32_t)lane, seed_lo, seed_hi);
-		blk_const[lane] = make_uint4(kc.s0, kc.s1, kc.s2, 0u);
+	const unsigned long long Q = (unsigned long long)p.nlev * (unsigned long long)NI * 4ull, W = (unsigned long long)p.nwaves;
+	const unsigned long long w = (unsigned long long)wg * (unsigned)NW + (unsigned)wi;
+	if (w >= W) return;
+	unsigned long long q_lo = Q * w / W, q_hi = Q * (w + 1) / W;
+	{ // (wave-uniform: the scalar unit's)
+		const uint32_t a = __builtin_amdgcn_readfirstlane((uint32_t)q_lo), b = __builtin_amdgcn_readfirstlane((uint32_t)(q_lo >> 32));
+		const uint32_t c = __builtin_amdgcn_readfirstlane((uint32_t)q_hi), d = __builtin_amdgcn_readfirstlane((uint32_t)(q_hi >> 32));
+		q_lo = ((unsigned long long)b << 32) | a;
+		q_hi = ((unsigned long long)d << 32) | c;
 	}
-	__builtin_amdgcn_wave_barrier();
-	__threadfence_block();
+	if (q_lo >= q_hi) return;
+	const unsigned per_level = (unsigned)NI * 4u;
+	int level = (int)(q_lo / per_level);
+	unsigned rem = (unsigned)(q_lo - (unsigned long long)level * per_level);
+	int n = (int)(rem >> 2), qq = (int)(rem & 3u);
+	int R = n / p.gx, bx = n - R * p.gx;
+	uint32_t seed_lo = p.seed_lo, seed_hi = p.seed_hi;
+	const uint32_t k2y = seed_hi + 2u * PHILOX_W1;
 	uint32_t thr3 = p.n3, thr4 = p.n4;
-	const int R = n / p.gx, bx = n - R * p.gx;
-	const uint32_t tid = (((uint32_t)R >> 2) * (uint32_t)p.gx + (uint32_t)bx) * 256u + ((uint32_t)R & 3u) * 64u + (uint32_t)lane;
-	const PhiloxRow pr = philox_row_setup(tid, seed_lo_cy, k2y);
-	const uint64_t *dst0 = p.masks + ((size_t)level * (size_t)NI + (size_t)n) * 128;
-	const uint32_t d_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dst0), d_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)dst0 >> 32));
-	const uint64_t *dst = reinterpret_cast<const uint64_t *>(((uintptr_t)d_hi << 32) | d_lo);
-	for (int qq = q0; qq < q0 + p.parts; ++qq) {
-		const uint4 *kcs = blk_const + 4 * qq;
-		uint4 kc_next = kcs[0];
-		static_for<4>([&](auto B) {
-			uint32_t o0, o1, o2, o3;
-			const uint4 kc = kc_next;
-			if (B.value < 3) kc_next = kcs[B.value + 1];
-			philox_block_pre(pr, PhiloxBlockConst{kc.x, kc.y, kc.z}, seed_lo, seed_hi, o0, o1, o2, o3);
-			if (B.value < 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kc_next.x), "+v"(kc_next.y), "+v"(kc_next.z) :: "memory");
-			const uint64_t *dstp = dst + 32 * qq + 8 * B.value; // (c3, c4) of output q of block 4 qq + B = word p = 16 qq + 4 B + q: 16 bytes at 16 p
-			const uint32_t t3 = thr3, t4 = thr4;
-			asm volatile("v_cmp_gt_u32_e64 " QSG(0, 1) ", %0, %2\n\tv_cmp_gt_u32_e64 " QSG(2, 3) ", %1, %2\n\t"
-			             "v_cmp_gt_u32_e64 " QSG(4, 5) ", %0, %3\n\tv_cmp_gt_u32_e64 " QSG(6, 7) ", %1, %3\n\t"
-			             "v_cmp_gt_u32_e64 " QSG(8, 9) ", %0, %4\n\tv_cmp_gt_u32_e64 " QSG(10, 11) ", %1, %4\n\t"
-			             "v_cmp_gt_u32_e64 " QSG(12, 13) ", %0, %5\n\tv_cmp_gt_u32_e64 " QSG(14, 15) ", %1, %5\n\t"
-			             "s_store_dwordx4 " QSG(0, 3) ", %6, 0x0\n\ts_store_dwordx4 " QSG(4, 7) ", %6, 0x10\n\t"
-			             "s_store_dwordx4 " QSG(8, 11) ", %6, 0x20\n\ts_store_dwordx4 " QSG(12, 15) ", %6, 0x30"
-			             :: "s"(t3), "s"(t4), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(dstp)
-			             : "memory", Q_CLOB16);
-		});
+	bool new_level = true;
+	uint32_t seed_lo_cy = 0;
+	for (unsigned long long q = q_lo; q < q_hi;) { // item by item: the quarters [qq, qe) of item n of `level` (a wave's first and last item may be partial)
+		const int qe = (int)min((unsigned long long)4, (unsigned long long)qq + (q_hi - q));
+		if (new_level) {
+			const uint32_t color = (uint32_t)level & 1u, it = p.it + ((uint32_t)level >> 1);
+			const uint32_t cx_base = 16u * (2u * it + color);
+			seed_lo_cy = seed_lo ^ (uint32_t)((2ull * it + color) >> 28); // counter word 1 enters round 1 next to the key (dense_update_k)
+			__builtin_amdgcn_wave_barrier();
+			if (lane < 16) {
+				const PhiloxBlockConst kc = philox_block_const(cx_base + (uint32_t)lane, seed_lo, seed_hi);
+				blk_const[lane] = make_uint4(kc.s0, kc.s1, kc.s2, 0u);
+			}
+			__builtin_amdgcn_wave_barrier();
+			__threadfence_block();
+			new_level = false;
+		}
+		const uint32_t tid = (((uint32_t)R >> 2) * (uint32_t)p.gx + (uint32_t)bx) * 256u + ((uint32_t)R & 3u) * 64u + (uint32_t)lane;
+		const PhiloxRow pr = philox_row_setup(tid, seed_lo_cy, k2y);
+		const uint64_t *dst0 = p.masks + ((size_t)level * (size_t)NI + (size_t)n) * 128;
+		const uint32_t d_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dst0), d_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)dst0 >> 32));
+		const uint64_t *dst = reinterpret_cast<const uint64_t *>(((uintptr_t)d_hi << 32) | d_lo);
+		for (int qi = qq; qi < qe; ++qi) {
+			const uint4 *kcs = blk_const + 4 * qi;
+			uint4 kc_next = kcs[0];
+			static_for<4>([&](auto B) {
+				uint32_t o0, o1, o2, o3;
+				const uint4 kc = kc_next;
+				if (B.value < 3) kc_next = kcs[B.value + 1];
+				philox_block_pre(pr, PhiloxBlockConst{kc.x, kc.y, kc.z}, seed_lo, seed_hi, o0, o1, o2, o3);
+				if (B.value < 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kc_next.x), "+v"(kc_next.y), "+v"(kc_next.z) :: "memory");
+				const uint64_t *dstp = dst + 32 * qi + 8 * B.value; // (c3, c4) of output o of block 4 qi + B = word p = 16 qi + 4 B + o: 16 bytes at 16 p
+				const uint32_t t3 = thr3, t4 = thr4;
+				asm volatile("v_cmp_gt_u32_e64 " QSG(0, 1) ", %0, %2\n\tv_cmp_gt_u32_e64 " QSG(2, 3) ", %1, %2\n\t"
+				             "v_cmp_gt_u32_e64 " QSG(4, 5) ", %0, %3\n\tv_cmp_gt_u32_e64 " QSG(6, 7) ", %1, %3\n\t"
+				             "v_cmp_gt_u32_e64 " QSG(8, 9) ", %0, %4\n\tv_cmp_gt_u32_e64 " QSG(10, 11) ", %1, %4\n\t"
+				             "v_cmp_gt_u32_e64 " QSG(12, 13) ", %0, %5\n\tv_cmp_gt_u32_e64 " QSG(14, 15) ", %1, %5\n\t"
+				             "s_store_dwordx4 " QSG(0, 3) ", %6, 0x0\n\ts_store_dwordx4 " QSG(4, 7) ", %6, 0x10\n\t"
+				             "s_store_dwordx4 " QSG(8, 11) ", %6, 0x20\n\ts_store_dwordx4 " QSG(12, 15) ", %6, 0x30"
+				             :: "s"(t3), "s"(t4), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(dstp)
+				             : "memory", Q_CLOB16);
+			});
+		}
+		q += (unsigned)(qe - qq);
+		qq = 0; // (whatever follows starts an item: a wave's share is one run)
+		++n;
+		if (++bx == p.gx) { bx = 0; ++R; }
+		if (n == NI) { n = 0; R = 0; bx = 0; ++level; new_level = true; }
 	}
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 }
@@ -333,12 +355,13 @@ __global__ void __launch_bounds__(MAXI <= 2 ? 1024 : 512) __attribute__((amdgpu_
 	const int lane = threadIdx.x & 63;
 	const int wi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int NW = __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6));
-	// tiles sit at every `stride`-th workgroup index (1: all of them first -- a small lattice's word pass is the launch's critical path; lattices of more tiles
-	// than the chip has CUs spread them among the drawing workgroups, so that the latency-bound and the throughput-bound kind run side by side all along)
-	const unsigned b = blockIdx.x, st = (unsigned)p.stride;
-	const unsigned tiles_before = min((unsigned)p.ntiles, (b + st - 1) / st);
-	if (b % st == 0 && b / st < (unsigned)p.ntiles) quad_word_part<MAXI>(p.w, (int)(b / st), wi, lane, NW, q_lds);
-	else quad_draw_part(p.d, (long long)b - tiles_before, wi, lane, NW, q_lds);
+	// Who does what: the tiles first (the dispatcher starts workgroups in index order; a word pass is a chain of short levels, the draws are throughput),
+	// the drawing workgroups behind them.  (Measured and dropped: a tile at every n-th index among the drawing workgroups -- 4096^2 2157 against 2326 flips/ns.)
+	const unsigned b = blockIdx.x;
+	const int tile = b < (unsigned)p.ntiles ? (int)b : -1;
+	const long long draw = (long long)b - p.ntiles;
+	if (tile >= 0) quad_word_part<MAXI>(p.w, tile, wi, lane, NW, q_lds);
+	else quad_draw_part(p.d, draw, wi, lane, NW, q_lds);
 }
 
 // ---- dense <-> quad, one wave per (row group, block); dense rows are gx * 32 words of 32 sites
@@ -426,15 +449,27 @@ static hipError_t launch_pass_t(const QuadPassParams &p, int waves, long long gr
 
 // `p.w.nlev` = 0: draws only (the first launch of a call); `p.d.nlev` = 0: words only (its last)
 hipError_t launch_quad_pass(QuadPassParams &p, int waves, hipStream_t stream) {
+	const int mi0 = quad_word_maxi(p.w, waves);
 	p.ntiles = p.w.nlev > 0 ? (p.w.NRG + p.w.C - 1) / p.w.C : 0;
+	// workgroup slots of the chip: six waves per SIMD with up to two items a wave (80 registers), three beyond
+	const int per_cu = std::max(1, ((mi0 <= 2 ? 6 : 3) * 4) / waves);
+	const int cap = std::max(4, p.cus * per_cu) & ~3;
 	long long draw_wgs = 0;
 	if (p.d.nlev > 0) {
-		const long long upl = (long long)p.d.NRG * p.d.gx * (4 / p.d.parts);
-		draw_wgs = (upl + waves - 1) / waves * p.d.nlev;
+		const long long items = (long long)p.d.NRG * p.d.gx * p.d.nlev;
+		// Few tiles (up to a quarter of the slots: a small lattice, its word pass the launch's critical path): as many drawing workgroups as find room next to
+		// them, every wave an equal share of the draws -- they end together (2048^2 1705 -> 1792 flips/ns).  More tiles: drawing workgroups of one item a wave
+		// that come and go, the dispatcher balancing (drawing workgroups that stay for the whole launch keep the slots the later tiles need: 6144^2 1508 against 2343).
+		if (p.ntiles > cap / 4) {
+			draw_wgs = (items + waves - 1) / waves;
+			p.d.nwaves = (int)std::min<long long>(items, 0x7fffffff);
+		} else { // (a quarter of an item a wave at least)
+			draw_wgs = std::max<long long>(1, std::min<long long>(std::max(cap - p.ntiles, cap / 2), (4 * items + waves - 1) / waves));
+			p.d.nwaves = (int)(draw_wgs * waves);
+		}
 	}
 	const long long grid = p.ntiles + draw_wgs;
 	if (grid <= 0) return hipSuccess;
-	p.stride = (p.ntiles > p.cus && draw_wgs > 0) ? (int)std::max<long long>(1, grid / p.ntiles) : 1;
 	if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
 	const int mi = quad_word_maxi(p.w, waves);
 	const size_t lds = quad_pass_lds_bytes(p.w, waves);

@@ -391,7 +391,6 @@ static int sweep_quad(ising_ctx *c, int first_it, int nsweeps, int every, unsign
 			pp.d.n3 = (uint32_t)c->thr[3];
 			pp.d.n4 = (uint32_t)c->thr[4];
 			pp.d.nlev = 2 * passes[q + 1].ns;
-			pp.d.parts = c->quad_parts;
 		}
 		HIP_TRY(ising::launch_quad_pass(pp, c->quad_waves, c->stream));
 	}

@@ -1,6 +1,6 @@
 """GPU parity of the quad path (small lattices: one launch per pass of several sweeps = the word pass on tiles + halo, next to the draws of the pass to
 come; ising_quad.hip, ising_update.cpp: sweep_quad) against the CPU oracle, bit for bit: every word of both colours, counts and bond sum -- over lattice
-widths (1 .. 4 blocks of 2048 columns), tile heights, sweeps per pass (halo depth), waves per workgroup, quarters of an item per drawing wave, calls that
+widths (1 .. 4 blocks of 2048 columns), tile heights, sweeps per pass (halo depth), waves per workgroup, calls that
 split unevenly into passes, lattices a tile's halo wraps around (several times), and the counter's high word."""
 import numpy as np
 import pytest
@@ -10,7 +10,7 @@ import ising_gpu_amd as ig
 pytestmark = pytest.mark.gpu
 
 TC = ig.CRIT_TEMP_F32
-KEYS = ("ISING_QUAD", "ISING_QUAD_C", "ISING_QUAD_T", "ISING_QUAD_WAVES", "ISING_QUAD_PARTS", "ISING_TILES")
+KEYS = ("ISING_QUAD", "ISING_QUAD_C", "ISING_QUAD_T", "ISING_QUAD_WAVES", "ISING_TILES")
 
 
 def _env(monkeypatch, **kw):
@@ -31,16 +31,16 @@ def _compare(slab, orc, what):
     assert slab.bond_equal() == orc.bond_equal(), what
 
 
-SHAPES = [  # X, Y, row groups per tile, sweeps per pass, waves, quarters of an item per drawing wave
-    (2048, 64, 8, 8, 4, 2), (2048, 64, 4, 4, 8, 1), (2048, 16, 4, 2, 2, 4), (2048, 32, 2, 16, 16, 2), (2048, 128, 16, 3, 8, 1),
-    (4096, 128, 8, 8, 8, 2), (4096, 64, 8, 5, 8, 4), (6144, 48, 3, 6, 16, 2), (8192, 64, 4, 4, 8, 1), (4096, 256, 7, 7, 16, 2),
+SHAPES = [  # X, Y, row groups per tile, sweeps per pass, waves
+    (2048, 64, 8, 8, 4), (2048, 64, 4, 4, 8), (2048, 16, 4, 2, 2), (2048, 32, 2, 16, 16), (2048, 128, 16, 3, 8),
+    (4096, 128, 8, 8, 8), (4096, 64, 8, 5, 8), (6144, 48, 3, 6, 16), (8192, 64, 4, 4, 8), (4096, 256, 7, 7, 16), (4096, 4096, 4, 8, 12), (2048, 8192, 4, 8, 8),
 ]
 
 
-@pytest.mark.parametrize("X,Y,C,T,NW,PARTS", SHAPES)
+@pytest.mark.parametrize("X,Y,C,T,NW", SHAPES)
 @pytest.mark.parametrize("temp,seed", [(1.5, ig.SEED_DEF), (TC, 1234)])
-def test_quad_bit_exact(gpu, oracle_mod, monkeypatch, X, Y, C, T, NW, PARTS, temp, seed):
-    _env(monkeypatch, QUAD=1, QUAD_C=C, QUAD_T=T, QUAD_WAVES=NW, QUAD_PARTS=PARTS)
+def test_quad_bit_exact(gpu, oracle_mod, monkeypatch, X, Y, C, T, NW, temp, seed):
+    _env(monkeypatch, QUAD=1, QUAD_C=C, QUAD_T=T, QUAD_WAVES=NW)
     orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=temp).init()
     with ig.IsingSlab(X, Y, seed=seed, temp=temp, layout=ig.LAYOUT_DENSE) as s:
         assert s.quad and s.max_sweeps_per_launch == T
@@ -50,7 +50,7 @@ def test_quad_bit_exact(gpu, oracle_mod, monkeypatch, X, Y, C, T, NW, PARTS, tem
             s.sweep(upto - done)
             orc.sweep(upto - done)
             done = upto
-            _compare(s, orc, f"after {upto} sweeps (tiles of {C} row groups, {T} sweeps a pass, {NW} waves, {PARTS} quarters a drawing wave)")
+            _compare(s, orc, f"after {upto} sweeps (tiles of {C} row groups, {T} sweeps a pass, {NW} waves)")
 
 
 @pytest.mark.parametrize("it0", [(1 << 27) - 3, (1 << 30) + 12345, (1 << 31) - 12])
@@ -122,7 +122,7 @@ def test_quad_randomised(gpu, oracle_mod, monkeypatch):
             continue
         temp = float(rng.choice([1.5, 2.0, TC, 3.0]))
         seed = int(rng.integers(1, 2**62))
-        _env(monkeypatch, QUAD=1, QUAD_C=C, QUAD_T=T, QUAD_WAVES=NW, QUAD_PARTS=int(rng.choice([1, 2, 4])))
+        _env(monkeypatch, QUAD=1, QUAD_C=C, QUAD_T=T, QUAD_WAVES=NW)
         orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=temp).init()
         with ig.IsingSlab(X, Y, seed=seed, temp=temp, layout=ig.LAYOUT_DENSE) as s:
             assert s.quad and s.max_sweeps_per_launch == T
@@ -162,7 +162,7 @@ def test_quad_default_rule(gpu, oracle_mod, monkeypatch):
     for X, Y, quad in ((4096, 16384, True), (6144, 6144, True), (6144, 8192, False), (8192, 1024, True), (8192, 2048, False), (10240, 1024, False), (4096, 32768, False), (2048, 16, True)):
         with ig.IsingSlab(X, Y, temp=TC) as s:
             assert s.quad == quad, (X, Y)
-            assert not quad or (s.layout == ig.LAYOUT_DENSE and s.max_sweeps_per_launch == {2048: 8, 4096: 8, 6144: 4, 8192: 6}[X])
+            assert not quad or (s.layout == ig.LAYOUT_DENSE and s.max_sweeps_per_launch == {2048: 8, 4096: 8, 6144: 4, 8192: 4}[X])
     with ig.IsingSlab(2048, 512, temp=TC, layout=ig.LAYOUT_DENSE) as s:
         assert s.quad
     for kw in (dict(nslabs=2, slab=0), dict(J_prob=0.1), dict(kernel=ig.KERNEL_GENERIC), dict(layout=ig.LAYOUT_NIBBLE), dict(layout=ig.LAYOUT_BALLOT)):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Small lattices on the quad path (ising_quad.hip: draws ahead of the lattice, word passes on tiles; ISING_QUAD=1 + ISING_QUAD_*) against the library's
 choice without it -- full state compared after an uneven number of sweeps, then flips/ns over a timed run.
-Usage: quad_probe.py [--shapes C,T,NW[,PARTS]:...] [X Y ...]"""
+Usage: quad_probe.py [--shapes C,T,NW:...] [X Y ...]"""
 import os
 import sys
 import time
@@ -12,7 +12,7 @@ ROOT = __file__.rsplit("/", 2)[0]
 sys.path.insert(0, ROOT)
 import ising_gpu_amd as ig  # noqa: E402
 
-KEYS = ("ISING_QUAD", "ISING_QUAD_C", "ISING_QUAD_T", "ISING_QUAD_WAVES", "ISING_QUAD_PARTS")
+KEYS = ("ISING_QUAD", "ISING_QUAD_C", "ISING_QUAD_T", "ISING_QUAD_WAVES")
 
 
 def run(X, Y, env, check=None, layout=ig.LAYOUT_DENSE):
@@ -40,7 +40,7 @@ def run(X, Y, env, check=None, layout=ig.LAYOUT_DENSE):
     return best, ok, state, what
 
 
-SHAPES = [(4, 8, 12), (4, 8, 8), (4, 8, 16), (8, 8, 16), (2, 8, 12), (4, 4, 8), (4, 4, 12), (4, 4, 16), (4, 12, 16), (4, 8, 12, 1), (4, 8, 12, 4)]
+SHAPES = [(4, 8, 12), (4, 8, 8), (4, 8, 16), (8, 8, 16), (2, 8, 12), (4, 4, 8), (4, 4, 12), (4, 4, 16), (4, 12, 16), (4, 6, 12), (8, 4, 12)]
 if len(sys.argv) > 2 and sys.argv[1] == "--shapes":
     SHAPES = [tuple(map(int, t.split(","))) for t in sys.argv[2].split(":")]
     del sys.argv[1:3]
@@ -52,8 +52,6 @@ for X, Y in sizes:
     for sh in SHAPES:
         C, T, NW = sh[:3]
         env = {"ISING_QUAD": "1", "ISING_QUAD_C": str(C), "ISING_QUAD_T": str(T), "ISING_QUAD_WAVES": str(NW)}
-        if len(sh) > 3:
-            env["ISING_QUAD_PARTS"] = str(sh[3])
         try:
             f, ok, _, what = run(X, Y, env, ref)
         except Exception as e:  # noqa: BLE001
