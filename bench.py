@@ -150,6 +150,40 @@ def first_contact_block(args, ig, torch, dist, world, rank, device, ndev, shared
     return out
 
 
+def default_lattice_leg(args, device):
+    """The reference's DEFAULT lattice (2048 x 2048, optimized/main.cu:1395-1410) next to the headline's: what `cuIsing` without -x/-y runs.  Round 5: the quad
+    path (ising_quad.hip: one launch per pass of 8 sweeps = the word pass on tiles + halo next to the draws of the pass to come) against the tile launches of
+    round 4 (ISING_QUAD=0), same seed and sweeps, final counts compared (both paths are held against the oracle bit for bit by the GPU tests)."""
+    import ising_gpu_amd as ig
+    X = Y = 2048
+    n = 4096
+    out = {}
+    for name, env in (("value", None), ("without_quad_path", "0")):
+        old = os.environ.get("ISING_QUAD")
+        if env is None:
+            os.environ.pop("ISING_QUAD", None)
+        else:
+            os.environ["ISING_QUAD"] = env
+        try:
+            with ig.IsingSlab(X, Y, device=device, seed=args.seed, temp=ig.CRIT_TEMP_F32) as s:
+                s.init().sweep(256)
+                s.sweep_timed(n)
+                ms = min(s.sweep_timed(n) for _ in range(3))
+                out[name] = round(X * Y * n / (ms * 1e6), 1)
+                out[name + "_form"] = "quad" if s.quad else ("tiles" if s.tiled else ("fused" if s.fused else "one launch per colour"))
+                out[name + "_counts"] = list(s.count())
+        finally:
+            if old is None:
+                os.environ.pop("ISING_QUAD", None)
+            else:
+                os.environ["ISING_QUAD"] = old
+    return {"value": out["value"], "unit": "flips/ns", "lattice": f"{Y}x{X}", "sweeps_per_call": n, "form": out["value_form"],
+            "without_quad_path": out["without_quad_path"], "without_quad_path_form": out["without_quad_path_form"],
+            "counts_equal": out["value_counts"] == out["without_quad_path_counts"], "up_down": out["value_counts"],
+            "what": "the reference's default lattice (cuIsing without -x/-y, optimized/main.cu:1395-1410) at T = Tc: best of three calls of 4096 sweeps; "
+                    "`without_quad_path` = the same with ISING_QUAD=0 (round 4's tile launches)"}
+
+
 def cpu_baseline(args):
     """Reported CPU baseline on the host cores of this box (rank 0, N=1 only): the byte-per-spin algorithm of
     basic_python/ising_basic.py restated in oracle/basic_cpu.c, BASELINE.json configs[0] (1024x1024, alpha 1,
@@ -273,6 +307,7 @@ def main():
                     help="skip the second timed leg (the same sweeps with the magnetisation read back every 16, as every published "
                          "number of the reference includes them: optimized/main.cu:1806-1810)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-small-leg", action="store_true", help="skip the side leg on the reference's default 2048 x 2048 lattice")
     ap.add_argument("--no-alu-probe", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -667,6 +702,11 @@ def main():
                                       "checked, not a scaling measurement")
         if parity is False:
             line["config"]["parity_expected"] = list(gold)
+        if not ringed and not args.no_small_leg:
+            try:
+                line["default_lattice_2048"] = default_lattice_leg(args, local_rank)
+            except Exception as e:  # noqa: BLE001  (a side leg must not cost the line)
+                line["default_lattice_2048"] = {"error": str(e)}
         if not ringed and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), flush=True)

@@ -30,16 +30,16 @@ def main():
         L.append(f"{'kernel':34s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
         for n, c, s, a, mn, mx in rows:
             L.append(f"{n[:34]:34s} {c:7d} {s/1e6:10.3f} {a/1e3:10.2f} {mn/1e3:10.2f} {mx/1e3:10.2f} {100*s/tot:6.2f}")
-            if ("update_k" in n or "tile_k" in n) and upd_ns is None:
+            if ("update_k" in n or "tile_k" in n or "quad_pass_k" in n) and upd_ns is None:
                 upd_ns = s
-        for r in q(tr[0], "select distinct name, vgpr_count, sgpr_count, lds_size, grid_x, workgroup_x from kernels where name like '%update_k%' or name like '%tile_k%'"):
+        for r in q(tr[0], "select distinct name, vgpr_count, sgpr_count, lds_size, grid_x, workgroup_x from kernels where name like '%update_k%' or name like '%tile_k%' or name like '%quad_pass_k%'"):
             L.append(f"   {r[0]}: vgpr {r[1]} sgpr {r[2]} lds {r[3]} grid {r[4]} wg {r[5]}")
         L.append("")
     pm = {}
     for db in sorted(glob.glob(os.path.join(src, "pmc_*", "*.db"))):
-        for name, tot, cnt, dur in q(db, "select counter_name, sum(counter_value), count(*), sum(duration) from pmc_events where name like '%update_k%' or name like '%tile_k%' group by counter_name"):
+        for name, tot, cnt, dur in q(db, "select counter_name, sum(counter_value), count(*), sum(duration) from pmc_events where name like '%update_k%' or name like '%tile_k%' or name like '%quad_pass_k%' group by counter_name"):
             pm[name] = (tot, cnt, dur)
-            L.append(f"{name:22s} sum {tot:20.1f} over {cnt} update_k / tile_k dispatches ({dur/1e6:.2f} ms under the profiler)")
+            L.append(f"{name:22s} sum {tot:20.1f} over {cnt} update_k / tile_k / quad_pass_k dispatches ({dur/1e6:.2f} ms under the profiler)")
     if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
         rd, wr = pm["FETCH_SIZE"][0] * 1024.0, pm["WRITE_SIZE"][0] * 1024.0
         hbm = 2 * rd + wr
