@@ -199,7 +199,8 @@ struct QuadWordParams {
 	int gx, NRG;
 	int C, HG;               // row groups per tile, halo row groups per side (4 HG >= nlev - 1)
 	int nlev;                // levels of the pass (even: whole sweeps, black first; at most 64); 0: no word pass in this launch
-	unsigned long long *cnt; // not null: the up spins of the state the pass stores are added here
+	unsigned long long *cnt; // not null: the up spins of the state the pass stores are added to these EIGHT words (tile t to word t mod 8)
+	unsigned long long *cnt_eq; // not null (with cnt): ... and the bonds between equal spins (ising_bond_equal's sum: the white sites' equal neighbours) to these eight
 };
 struct QuadPassParams {
 	QuadWordParams w;

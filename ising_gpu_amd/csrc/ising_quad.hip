@@ -254,11 +254,16 @@ __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile
 	auto ld = [](uint32_t a) { return *(lds_cp)(uintptr_t)a; };
 
 	// one level; COL = the colour it updates, SLOT = the set its masks are in (level L: colour L & 1, set L mod 3)
-	auto level = [&](auto COL, auto SLOT, int L) {
+	// (MEAS: no update -- the level's sites as they stand, each with its four neighbours of the other colour: the equal bonds of a print point with the energy)
+	unsigned long long eq_acc = 0;
+	auto level = [&](auto COL, auto SLOT, auto MEAS, int L) {
 		constexpr int c = COL.value;
-		fetch(L + Q_DEPTH - 1, std::integral_constant<int, (SLOT.value + Q_DEPTH - 1) % Q_DEPTH>{});
-		QTRC(1); // prefetch issue
-		asm volatile("s_waitcnt vmcnt(%0)" :: "n"((Q_DEPTH - 1) * MAXI) : "memory"); // this level's masks have landed (the two levels behind them may still be out)
+		constexpr bool meas = MEAS.value;
+		if (!meas) {
+			fetch(L + Q_DEPTH - 1, std::integral_constant<int, (SLOT.value + Q_DEPTH - 1) % Q_DEPTH>{});
+			QTRC(1); // prefetch issue
+			asm volatile("s_waitcnt vmcnt(%0)" :: "n"((Q_DEPTH - 1) * MAXI) : "memory"); // this level's masks have landed (the two levels behind them may still be out)
+		}
 		const uint32_t S_w = lat_w + (c ? 0u : plane_b), D_w = lat_w + (c ? plane_b : 0u);
 		// rows whose side neighbour is site s - 1 (readBack, optimized/main.cu:542): the even rows of a black level, the odd rows of a white one; the lanes
 		// whose side word crosses the vector seam take one bit per row from the word across it (made here from two flags: eight registers less to keep)
@@ -295,9 +300,11 @@ __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile
 				dnc[t] = ld(S_w + db + o_me);
 				dst[t] = D_w + rb + o_me;
 				me[t] = ld(dst[t]);
-				uint32_t a0, a1, a2, a3; // (an absent item's set holds whatever it held: its result is not stored)
-				if (t == 0) qm_read<SLOT.value * MAXI + k0>(a0, a1, a2, a3);
-				else qm_read<SLOT.value * MAXI + k1>(a0, a1, a2, a3);
+				uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0; // (an absent item's set holds whatever it held: its result is not stored)
+				if (!meas) {
+					if (t == 0) qm_read<SLOT.value * MAXI + k0>(a0, a1, a2, a3);
+					else qm_read<SLOT.value * MAXI + k1>(a0, a1, a2, a3);
+				}
 				c3[t] = ((uint64_t)a1 << 32) | a0;
 				c4[t] = ((uint64_t)a3 << 32) | a2;
 			}
@@ -305,6 +312,10 @@ __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile
 			for (int t = 0; t < NK; ++t) {
 				const uint64_t sd = ((x1B[t] << shB) & m1) | ((x2B[t] >> 15) & m2) | ((x1F[t] >> shF) & m3) | ((x2F[t] << 15) & m4);
 				const uint64_t up = (ct[t] << 16) | (upc[t] >> 48), dw = (ct[t] >> 16) | (dnc[t] << 48);
+				if (meas) {
+					if (on[t]) eq_acc += (unsigned long long)(__popcll(~(me[t] ^ up)) + __popcll(~(me[t] ^ ct[t])) + __popcll(~(me[t] ^ dw)) + __popcll(~(me[t] ^ sd)));
+					continue;
+				}
 				const uint32_t flo = flips32((uint32_t)me[t], (uint32_t)up, (uint32_t)ct[t], (uint32_t)dw, (uint32_t)sd, (uint32_t)c3[t], (uint32_t)c4[t]);
 				const uint32_t fhi = flips32((uint32_t)(me[t] >> 32), (uint32_t)(up >> 32), (uint32_t)(ct[t] >> 32), (uint32_t)(dw >> 32), (uint32_t)(sd >> 32),
 				                             (uint32_t)(c3[t] >> 32), (uint32_t)(c4[t] >> 32));
@@ -312,15 +323,22 @@ __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile
 			}
 		});
 		QTRC(3); // items
-		__syncthreads();
+		if (!meas) __syncthreads();
 		QTRC(4); // barrier
 	};
 	for (int L0 = 0; L0 < p.nlev; L0 += 6) { // (six levels a turn: the colour and the mask set of each are compile-time)
 		static_for<6>([&](auto I) {
-			if (L0 + I.value < p.nlev) level(std::integral_constant<int, I.value & 1>{}, std::integral_constant<int, I.value % Q_DEPTH>{}, L0 + I.value);
+			if (L0 + I.value < p.nlev) level(std::integral_constant<int, I.value & 1>{}, std::integral_constant<int, I.value % Q_DEPTH>{}, std::false_type{}, L0 + I.value);
 		});
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the spare quad's loads behind the last level)
+	// A print point with the energy: every bond has one white end, so the white sites' equal neighbours are ising_bond_equal's sum.  The pass's last level was
+	// white on exactly the tile's own rows; the black rows one beyond either edge were final a level earlier: the same items once more, looking instead of flipping.
+	// (the sums of a print point: per wave, then per workgroup through two LDS words, then ONE add per tile into one of eight slots -- a thousand waves adding to
+	// one word cost a measured pass of 2048^2 7.5 us, with the energy 20, of a 19 us launch)
+	__shared__ unsigned long long q_sums[2];
+	if (p.cnt && threadIdx.x < 2) q_sums[threadIdx.x] = 0;
+	if (p.cnt_eq) level(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, std::true_type{}, p.nlev - 1);
 	// the tile itself into the other buffer; a print point: the up spins of what is stored
 	unsigned long long ups = 0;
 	for (int cg = wi; cg < 2 * Cc; cg += NW) {
@@ -333,8 +351,18 @@ __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile
 		}
 	}
 	if (p.cnt) {
+		__syncthreads(); // (q_sums is zero)
 		ups = wave_sum(ups);
-		if (lane == 0) atomicAdd(p.cnt, ups);
+		const unsigned long long eq = wave_sum(eq_acc);
+		if (lane == 0) {
+			atomicAdd(&q_sums[0], ups);
+			if (p.cnt_eq) atomicAdd(&q_sums[1], eq);
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			atomicAdd(p.cnt + (tile & 7), q_sums[0]);
+			if (p.cnt_eq) atomicAdd(p.cnt_eq + (tile & 7), q_sums[1]);
+		}
 	}
 #if defined(ISING_QUAD_TRACE)
 	QTRC(5); // store

@@ -339,8 +339,9 @@ static bool sweeps_quad(const ising_ctx *c, int nsweeps) {
 	return c->quad_C > 0 && nsweeps >= 2 && c->wrap && c->dense && !c->ballot && !c->cfg.use_J && !c->cfg.XSL && c->fast_ok && !ising_host::needs_generic(c);
 }
 
-// `every` > 0: the up spins after every iteration that is a multiple of it are added to d_cnt[0], d_cnt[1], ... (zero on entry); *nmeas = how many
-static int sweep_quad(ising_ctx *c, int first_it, int nsweeps, int every, unsigned long long *d_cnt, int *nmeas) {
+// `every` > 0: the up spins after every iteration that is a multiple of it are added to the eight words d_cnt[8 m ..] (zero on entry) -- `bonds`: to
+// d_cnt[16 m ..], the bonds between equal spins at the same point to d_cnt[16 m + 8 ..] --; *nmeas = how many
+static int sweep_quad(ising_ctx *c, int first_it, int nsweeps, int every, unsigned long long *d_cnt, int *nmeas, bool bonds = false) {
 	if (int rc = bind(c)) return rc;
 	if (!c->d_quad || !c->d_qmasks) return fail(ISING_E_STATE, "quad sweeps without their buffers (ising_create allocates them)");
 	struct Pass { int it, ns, meas; };
@@ -380,7 +381,8 @@ static int sweep_quad(ising_ctx *c, int first_it, int nsweeps, int every, unsign
 			}
 			pp.w.masks = c->d_qmasks + (size_t)(q & 1) * mask_words;
 			pp.w.nlev = 2 * passes[q].ns;
-			pp.w.cnt = passes[q].meas >= 0 ? d_cnt + passes[q].meas : nullptr;
+			pp.w.cnt = passes[q].meas >= 0 ? d_cnt + (size_t)(bonds ? 16 : 8) * passes[q].meas : nullptr;
+			pp.w.cnt_eq = (passes[q].meas >= 0 && bonds) ? d_cnt + (size_t)16 * passes[q].meas + 8 : nullptr;
 			cur ^= 1;
 		}
 		if (q + 1 < np) { // the draws of pass q + 1 into the other mask buffer
@@ -398,21 +400,27 @@ static int sweep_quad(ising_ctx *c, int first_it, int nsweeps, int every, unsign
 	return ISING_OK;
 }
 
-static int sweep_quad_counted(ising_ctx *c, int first_it, int nsweeps, int every, uint64_t *ups, long long n, int *ncounts) {
+static int sweep_quad_counted(ising_ctx *c, int first_it, int nsweeps, int every, uint64_t *ups, int64_t *bond_equal, long long n, int *ncounts) {
 	if (int rc = bind(c)) return rc;
-	if (c->tile_cnt_cap < (size_t)n) {
+	const size_t per = bond_equal ? 16 : 8, need = (size_t)n * per;
+	if (c->tile_cnt_cap < need) {
 		if (c->d_tile_cnt) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_tile_cnt)); c->d_tile_cnt = nullptr; c->tile_cnt_cap = 0; }
-		const size_t cap = std::max<size_t>(64, (size_t)n);
+		const size_t cap = std::max<size_t>(64, need);
 		HIP_TRY(hipMalloc((void **)&c->d_tile_cnt, cap * sizeof(unsigned long long)));
 		c->tile_cnt_cap = cap;
 	}
-	if (n) HIP_TRY(hipMemsetAsync(c->d_tile_cnt, 0, (size_t)n * sizeof(unsigned long long), c->stream));
+	if (need) HIP_TRY(hipMemsetAsync(c->d_tile_cnt, 0, need * sizeof(unsigned long long), c->stream));
 	int k = 0;
-	if (nsweeps > 0) if (int rc = sweep_quad(c, first_it, nsweeps, every, c->d_tile_cnt, &k)) return rc;
-	std::vector<unsigned long long> h((size_t)std::max(k, 1));
-	if (k) HIP_TRY(hipMemcpyAsync(h.data(), c->d_tile_cnt, (size_t)k * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+	if (nsweeps > 0) if (int rc = sweep_quad(c, first_it, nsweeps, every, c->d_tile_cnt, &k, bond_equal != nullptr)) return rc;
+	std::vector<unsigned long long> h((size_t)std::max(k, 1) * per);
+	if (k) HIP_TRY(hipMemcpyAsync(h.data(), c->d_tile_cnt, (size_t)k * per * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
 	if (int rc = ising_host::sync_checked(c)) return rc;
-	for (int q = 0; q < k; q++) ups[q] = h[q];
+	for (int q = 0; q < k; q++) {
+		unsigned long long u = 0, e = 0;
+		for (int w = 0; w < 8; w++) { u += h[(size_t)q * per + w]; if (bond_equal) e += h[(size_t)q * per + 8 + w]; }
+		ups[q] = u;
+		if (bond_equal) bond_equal[q] = (int64_t)e;
+	}
 	*ncounts = k;
 	return ISING_OK;
 }
@@ -473,7 +481,7 @@ extern "C" int ising_sweep_counted(ising_ctx *c, int first_it, int nsweeps, int 
 	*ncounts = 0;
 	if (n > max_counts) return fail(ISING_E_ARG, "%lld counts, room for %d", n, max_counts);
 	if (int rc = bind(c)) return rc;
-	if (sweeps_quad(c, 2) && !bond_equal) return sweep_quad_counted(c, first_it, nsweeps, every, ups, n, ncounts);
+	if (sweeps_quad(c, 2)) return sweep_quad_counted(c, first_it, nsweeps, every, ups, bond_equal, n, ncounts);
 	if (sweeps_tiled(c, 2) && !bond_equal) return sweep_tiles_counted(c, first_it, nsweeps, every, ups, n, ncounts);
 	const bool inside = sweeps_fused(c) && !c->cfg.XSL && !c->cfg.use_J;
 	if (!inside) { // one launch per colour, tiles with the energy, sub-lattices, couplings: the reference's own order of events

@@ -90,6 +90,27 @@ def test_quad_counted_sweeps(gpu, oracle_mod, monkeypatch, X, Y, first, n, every
         _compare(s, orc, "three sweeps later")
 
 
+@pytest.mark.parametrize("X,Y,first,n,every", [(2048, 64, 0, 40, 16), (4096, 128, 5, 37, 7), (6144, 48, 0, 9, 1), (8192, 32, 3, 50, 25), (2048, 2048, 0, 33, 16)])
+def test_quad_counted_sweeps_with_the_energy(gpu, oracle_mod, monkeypatch, X, Y, first, n, every):
+    """... with the bond sum (north_star's energy series) at the same print points: the tiles of a measured pass count, behind its last level, the equal
+    neighbours of their white sites (every bond has one white end) -- no fall-back to sweeping and measuring in turn."""
+    _env(monkeypatch, QUAD=1)
+    orc = oracle_mod.OracleLattice(X, Y, seed=78, temp=TC).init()
+    with ig.IsingSlab(X, Y, seed=78, temp=TC, layout=ig.LAYOUT_DENSE) as s:
+        assert s.quad
+        s.init()
+        s.sweep(first)
+        orc.sweep(first)
+        got = s.sweep_counted(n, every, True)
+        want = []
+        for _ in range(n):
+            orc.sweep(1)
+            if orc.it % every == 0:
+                want.append(orc.count() + (orc.bond_equal(),))
+        assert got == want
+        _compare(s, orc, "after the counted sweeps")
+
+
 def test_quad_temperature_change_between_calls(gpu, oracle_mod, monkeypatch):
     """The draws of a call carry the thresholds of the temperature the call was made at (the `-u` ramp, optimized/main.cu:1848-1860)."""
     _env(monkeypatch, QUAD=1)
@@ -130,12 +151,13 @@ def test_quad_randomised(gpu, oracle_mod, monkeypatch):
             for n in rng.integers(2, 5 * T + 4, size=3):
                 if rng.integers(0, 3) == 0:
                     every = int(rng.integers(1, 9))
-                    got = s.sweep_counted(int(n), every)
+                    energy = bool(rng.integers(0, 2))
+                    got = s.sweep_counted(int(n), every, energy)
                     want = []
                     for _ in range(int(n)):
                         orc.sweep(1)
                         if orc.it % every == 0:
-                            want.append(orc.count())
+                            want.append(orc.count() + ((orc.bond_equal(),) if energy else ()))
                     assert got == want, (case, X, Y, C, T, NW)
                 else:
                     s.sweep(int(n))
