@@ -594,10 +594,13 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		const int NRG = cfg->Y / 4;
 		// (2048 columns: eight sweeps a pass on four row groups, twelve waves -- eight once the tiles are 128 and more: 2048^2 1707 against 1525; 4096: twelve waves,
 		// two items each; 6144: four sweeps a pass; 8192: the same on sixteen waves.  A wave keeps at most two items: 80 registers, six waves per SIMD.)
-		int T = pol.quad_T ? pol.quad_T : (c->gx <= 2 ? 8 : 4);
+		// (... and where the tiles are a thousand and more -- 16384 rows of 2048 columns, 8192 of 4096: throughput, not a tile's chain of levels -- eight row
+		// groups and four sweeps a pass: less of the word phase is halo, 2048 x 32768 2374 -> 2481, 4096 x 16384 2342 -> 2431)
+		const bool many = !pol.quad_T && !pol.quad_C && c->gx <= 2 && (long long)cfg->Y * c->gx >= 16384;
+		int T = pol.quad_T ? pol.quad_T : ((c->gx <= 2 && !many) ? 8 : 4);
 		T = std::max(1, std::min(T, 32));
 		const int HG = (2 * T - 1 + 3) / 4;
-		int C = pol.quad_C ? pol.quad_C : 4;
+		int C = pol.quad_C ? pol.quad_C : (many ? 8 : 4);
 		C = std::max(1, std::min(C, NRG));
 		int waves = pol.quad_waves ? pol.quad_waves : (c->gx == 1 ? (NRG / C >= 128 ? 8 : 12) : (c->gx <= 3 ? 12 : 16));
 		waves = std::max(1, std::min(waves, 16));
