@@ -592,17 +592,32 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// workgroup (tiles and drawing workgroups alike: one launch) -- by measurement (profiles/quad_probe_r05.txt).
 	if (quad_pick && c->dense && !c->ballot) {
 		const int NRG = cfg->Y / 4;
-		// (2048 columns: eight sweeps a pass on four row groups, twelve waves -- eight once the tiles are 128 and more: 2048^2 1707 against 1525; 4096: twelve waves,
-		// two items each; 6144: four sweeps a pass; 8192: the same on sixteen waves.  A wave keeps at most two items: 80 registers, six waves per SIMD.)
-		// (... and where the tiles are a thousand and more -- 16384 rows of 2048 columns, 8192 of 4096: throughput, not a tile's chain of levels -- eight row
-		// groups and four sweeps a pass: less of the word phase is halo, 2048 x 32768 2374 -> 2481, 4096 x 16384 2342 -> 2431)
-		const bool many = !pol.quad_T && !pol.quad_C && c->gx <= 2 && (long long)cfg->Y * c->gx >= 16384;
-		int T = pol.quad_T ? pol.quad_T : ((c->gx <= 2 && !many) ? 8 : 4);
+		// Shape by measurement (tools/quad_probe.py, profiles/quad_shapes_probe_r05.txt; row groups per tile, sweeps per pass, waves).  A launch has a fixed part -- ramp,
+		// the tiles' first loads, the tail -- that long passes spread over more sweeps while a pass's halo (two rows per sweep and side) makes the word phase
+		// dearer: lattices of few tiles want long passes (2048^2: (4, 8, 8) 1799, (4, 12, 8) 2119, (8, 16, 12) 2210 flips/ns), a thousand tiles and more short
+		// ones on tall tiles (throughput: less of the word phase is halo -- 2048 x 32768 (8, 4, 8) 2481 against 2374, 4096 x 16384 (8, 4, 12) 2431 against 2342).
+		// A wave keeps at most two items: 80 registers, six waves per SIMD.
+		int C0 = 4, T0 = 8, W0 = 12;
+		if (c->gx == 1) {
+			if (cfg->Y < 1024) { C0 = 4; T0 = 8; W0 = 12; } // (2048 x 512: 745 against 670 at sixteen sweeps a pass)
+			else if (cfg->Y < 2048) { C0 = 4; T0 = 16; W0 = 12; }
+			else if (cfg->Y < 4096) { C0 = 8; T0 = 16; W0 = 12; }
+			else if (cfg->Y < 8192) { C0 = 4; T0 = 12; W0 = 8; }
+			else if (cfg->Y < 16384) { C0 = 4; T0 = 8; W0 = 8; }
+			else { C0 = 8; T0 = 4; W0 = 8; }
+		} else if (c->gx == 2) {
+			if (cfg->Y < 2048) { C0 = 4; T0 = 12; W0 = 16; }
+			else if (cfg->Y < 8192) { C0 = 4; T0 = 8; W0 = 12; }
+			else { C0 = 8; T0 = 4; W0 = 12; }
+		} else {
+			C0 = 4; T0 = 4; W0 = c->gx == 3 ? 12 : 16;
+		}
+		int T = pol.quad_T ? pol.quad_T : T0;
 		T = std::max(1, std::min(T, 32));
 		const int HG = (2 * T - 1 + 3) / 4;
-		int C = pol.quad_C ? pol.quad_C : (many ? 8 : 4);
+		int C = pol.quad_C ? pol.quad_C : C0;
 		C = std::max(1, std::min(C, NRG));
-		int waves = pol.quad_waves ? pol.quad_waves : (c->gx == 1 ? (NRG / C >= 128 ? 8 : 12) : (c->gx <= 3 ? 12 : 16));
+		int waves = pol.quad_waves ? pol.quad_waves : W0;
 		waves = std::max(1, std::min(waves, 16));
 		ising::QuadWordParams qp{};
 		qp.gx = c->gx; qp.NRG = NRG; qp.C = C; qp.HG = HG;

@@ -184,7 +184,8 @@ def test_quad_default_rule(gpu, oracle_mod, monkeypatch):
     for X, Y, quad in ((4096, 16384, True), (6144, 6144, True), (6144, 8192, False), (8192, 1024, True), (8192, 2048, False), (10240, 1024, False), (4096, 32768, False), (2048, 16, True)):
         with ig.IsingSlab(X, Y, temp=TC) as s:
             assert s.quad == quad, (X, Y)
-            assert not quad or (s.layout == ig.LAYOUT_DENSE and s.max_sweeps_per_launch == (4 if X * Y >= (1 << 25) else {2048: 8, 4096: 8, 6144: 4, 8192: 4}[X]))
+            sweeps_a_pass = {2048: 8 if Y < 1024 else (16 if Y < 4096 else (12 if Y < 8192 else (8 if Y < 16384 else 4))), 4096: 12 if Y < 2048 else (8 if Y < 8192 else 4), 6144: 4, 8192: 4}.get(X)
+            assert not quad or (s.layout == ig.LAYOUT_DENSE and s.max_sweeps_per_launch == sweeps_a_pass)
     with ig.IsingSlab(2048, 512, temp=TC, layout=ig.LAYOUT_DENSE) as s:
         assert s.quad
     for kw in (dict(nslabs=2, slab=0), dict(J_prob=0.1), dict(kernel=ig.KERNEL_GENERIC), dict(layout=ig.LAYOUT_NIBBLE), dict(layout=ig.LAYOUT_BALLOT)):
