@@ -1,12 +1,12 @@
-// ising_quad.hip -- small lattices (round 5): every draw made ONCE, by the whole chip; the cheap part repeated instead.
+// ising_quad.hip -- small and narrow lattices (round 5): every draw made ONCE, ahead of the lattice; the cheap part repeated instead.
 //
 // Below ~2^25 spins a colour half-sweep is a microsecond of arithmetic, and whatever exchanges rows between workgroups once
 // per half-sweep (a launch boundary, a counter in memory) costs several.  The tile launches of round 4 (ising_dense.hip:
 // dense_tile_k) buy S sweeps without an exchange by repeating the neighbours' updates of a halo -- draws included, x 1.5 of the
-// part that is 94 % of the instructions.  But a draw depends on (seed, site, iteration) alone: the accept decisions of any
-// number of sweeps can be made ahead by a kernel that knows nothing of the lattice, at the rate of the large lattices' draw
-// phase, with every SIMD of the chip busy and no redundancy; what has to run in order -- the word phase, 45 of 720 vector
-// instructions per 4096 sites -- can then afford the halo.
+// part that is 94 % of the instructions.  But a draw depends on (seed, site, iteration) alone: the accept masks of a pass of T
+// sweeps can be made ahead by code that knows nothing of the lattice, at the rate of the large lattices' draw phase and
+// without redundancy; what has to run in order -- the word phase, ~75 of ~780 vector instructions per 4096 sites -- can then
+// afford the halo.
 //
 // Layout ("quad": the wave of the reference's thread block as it is, 4 rows x 16 lanes).  Per colour [Y/4 row groups][X/2048
 // blocks][64 words]:
@@ -17,12 +17,14 @@
 // 2048), where the ballot layout's wave columns want 8192.  Vertical neighbours are the word itself shifted by 16 bits (+ 16
 // bits of the row group above / below), horizontal ones the same bit of another word (sites 0 / 31: the neighbouring lane bit).
 //
-//   quad_draw_k  (level, row group, block) -> 1 KiB of accept masks (c3, c4 per word), scalar stores straight into the mask
-//                buffer; no lattice, no barrier, no order.
-//   quad_word_k  one workgroup per tile of C row groups x the whole width, both colours + HG halo row groups in LDS; 2 T
-//                levels over a region that shrinks a row per level; masks prefetched three levels ahead by LDS-direct loads;
-//                reads one lattice buffer, writes its tile to the other.
-// ising_update.cpp (sweep_quad) runs the draws of batch k + 1 on a second stream next to the word passes of batch k.
+// quad_pass_k = ONE launch per pass of T sweeps:
+//   tiles     workgroup t < ntiles: C row groups x the whole width of both colours + HG halo row groups per side in LDS; 2 T
+//             levels over a region that shrinks a row per level; the masks of the level after next on their way into
+//             accumulation registers; reads one lattice buffer, writes its tile to the other (quad_word_part)
+//   drawing   the workgroups behind them: the masks of the NEXT pass -- (level, row group, block) -> 1 KiB (c3, c4 per word),
+//             scalar stores straight into the mask buffer; no lattice, no barrier, no order (quad_draw_part)
+// ising_update.cpp (sweep_quad): launch k = word pass k on the masks launch k - 1 drew + the draws of pass k + 1; one stream,
+// two mask buffers.  DESIGN 4.3; what was measured and dropped on the way: LAB_NOTES 12.
 #include "ising_device.hpp"
 #include <algorithm>
 #include <cstdio>
@@ -33,7 +35,7 @@ namespace {
 constexpr uint64_t Q_LANE0 = 0x0001000100010001ull;  // tx = 0 of each row
 constexpr uint64_t Q_LANE15 = 0x8000800080008000ull; // tx = 15
 constexpr uint64_t Q_EVEN = 0x0000FFFF0000FFFFull;   // rows 4 R, 4 R + 2
-constexpr int Q_DEPTH = 3;                           // levels of masks in flight per wave (ring slots)
+constexpr int Q_DEPTH = 3;                           // levels of masks in flight per wave (sets of accumulation registers)
 
 __device__ __forceinline__ constexpr int qword(int j, int m, int q) { return 32 * j + 4 * m + q; }
 __device__ __forceinline__ int qword_of_site(int j, int s) {
