@@ -180,9 +180,10 @@ struct TileParams {
 hipError_t launch_dense_tiles(const TileParams &p, int threads, hipStream_t stream);
 size_t dense_tiles_lds_bytes(const TileParams &p);
 hipError_t launch_dense_init(const InitParams &p, hipStream_t stream);
-// Small lattices, round 5 (ising_quad.hip): the "quad" layout -- per colour [Y/4 row groups][gx blocks][64 words], bit 16 r4 + tx of word p = the site
-// reference thread 64 (R & 3) + 16 r4 + tx of block (bx, R / 4) draws with Philox block p / 4, output p % 4 -- and its two kernels: the draws of many levels
-// ahead of the lattice (one KiB of accept masks per level, row group and block), the word phases of 2 T levels per tile without an exchange.
+// Small and narrow lattices, round 5 (ising_quad.hip): the "quad" layout -- per colour [Y/4 row groups][gx blocks][64 words], bit 16 r4 + tx of word p = the site
+// reference thread 64 (R & 3) + 16 r4 + tx of block (bx, R / 4) draws with Philox block p / 4, output p % 4 -- and its kernel, one launch per pass of T sweeps:
+// tiles (the word phases of 2 T levels on C row groups + halo, no exchange) next to the draws of the pass to come (one KiB of accept masks per level, row group
+// and block, made once).
 struct QuadDrawParams {
 	uint64_t *masks;         // [nlev][NRG * gx][128]: (c3, c4) of word p at 16 p bytes
 	uint32_t seed_lo, seed_hi;
