@@ -108,14 +108,15 @@ __device__ __forceinline__ void quad_draw_part(const QuadDrawParams &p, long lon
 		const uint32_t d_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dst0), d_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)dst0 >> 32));
 		const uint64_t *dst = reinterpret_cast<const uint64_t *>(((uintptr_t)d_hi << 32) | d_lo);
 		for (int qi = qq; qi < qe; ++qi) {
+			// (the quarter's four block constants at once: LDS and scalar memory share one counter, so every wait for a constant is also a wait for the scalar
+			// stores before it -- one wait a quarter instead of one a block)
 			const uint4 *kcs = blk_const + 4 * qi;
-			uint4 kc_next = kcs[0];
+			uint4 kq[4] = {kcs[0], kcs[1], kcs[2], kcs[3]};
+			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kq[0].x), "+v"(kq[0].y), "+v"(kq[0].z), "+v"(kq[1].x), "+v"(kq[1].y), "+v"(kq[1].z), "+v"(kq[2].x), "+v"(kq[2].y), "+v"(kq[2].z), "+v"(kq[3].x), "+v"(kq[3].y), "+v"(kq[3].z) :: "memory");
 			static_for<4>([&](auto B) {
 				uint32_t o0, o1, o2, o3;
-				const uint4 kc = kc_next;
-				if (B.value < 3) kc_next = kcs[B.value + 1];
+				const uint4 kc = kq[B.value];
 				philox_block_pre(pr, PhiloxBlockConst{kc.x, kc.y, kc.z}, seed_lo, seed_hi, o0, o1, o2, o3);
-				if (B.value < 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kc_next.x), "+v"(kc_next.y), "+v"(kc_next.z) :: "memory");
 				const uint64_t *dstp = dst + 32 * qi + 8 * B.value; // (c3, c4) of output o of block 4 qi + B = word p = 16 qi + 4 B + o: 16 bytes at 16 p
 				const uint32_t t3 = thr3, t4 = thr4;
 				asm volatile("v_cmp_gt_u32_e64 " QSG(0, 1) ", %0, %2\n\tv_cmp_gt_u32_e64 " QSG(2, 3) ", %1, %2\n\t"
@@ -481,8 +482,8 @@ static hipError_t launch_pass_t(const QuadPassParams &p, int waves, long long gr
 hipError_t launch_quad_pass(QuadPassParams &p, int waves, hipStream_t stream) {
 	const int mi0 = quad_word_maxi(p.w, waves);
 	p.ntiles = p.w.nlev > 0 ? (p.w.NRG + p.w.C - 1) / p.w.C : 0;
-	// workgroup slots of the chip: six waves per SIMD with up to two items a wave (80 registers), three beyond
-	const int per_cu = std::max(1, ((mi0 <= 2 ? 6 : 3) * 4) / waves);
+	// workgroup slots of the chip: eight waves per SIMD at one item a wave, six at two (80 registers), three beyond
+	const int per_cu = std::max(1, ((mi0 <= 1 ? 8 : (mi0 <= 2 ? 6 : 3)) * 4) / waves); // (one item a wave: under 64 registers)
 	const int cap = std::max(4, p.cus * per_cu) & ~3;
 	long long draw_wgs = 0;
 	if (p.d.nlev > 0) {
