@@ -80,10 +80,13 @@ def test_library_choice_within_3_percent_of_its_neighbours(gpu, warm_clock, monk
     except ig.IsingError:
         pass
     best = max(cells.values(), default=0.0)
-    if mine < (1.0 - TOL) * best:  # once more, both sides: a single slow piece must not fail the suite
+    for _ in range(3):  # again, both sides (up to three times): a single slow -- or lucky -- piece must not fail the suite
+        if mine >= (1.0 - TOL) * best:
+            break
         mine = max(mine, _rate(X, Y, monkeypatch=monkeypatch)[0])
         hb, wb, sb = max(cells, key=cells.get)
-        cells[(hb, wb, sb)] = best = _rate(X, Y, 0 if sb is not None else hb, 0 if sb is not None else wb, monkeypatch, split=sb)[0]
+        cells[(hb, wb, sb)] = _rate(X, Y, 0 if sb is not None else hb, 0 if sb is not None else wb, monkeypatch, split=sb)[0]
+        best = max(cells.values())
     print(f"{Y} x {X}: library H={H} wgs={wg} split={int(shape[3])} {mine:.0f} flips/ns; neighbours "
           + ", ".join(f"H={h} wgs={w}{'' if sp is None else (' split' if sp else ' fused')}: {r:.0f}" for (h, w, sp), r in cells.items()))
     assert mine >= (1.0 - TOL) * best, (f"{Y} x {X}: the library's H={H}, {wg} per CU ({'split' if shape[3] else 'fused'}) runs {mine:.0f} flips/ns, "
@@ -112,7 +115,10 @@ def test_quad_rule_within_3_percent_of_the_other_path(gpu, warm_clock, monkeypat
     mine, picked, counts = rate(None)
     other, other_quad, counts2 = rate(0 if picked else 1)
     assert counts == counts2 and other_quad != picked
-    if mine < (1.0 - TOL) * other:
+    for _ in range(3):  # (again, both sides, as above)
+        if mine >= (1.0 - TOL) * other:
+            break
         mine = max(mine, rate(None)[0])
+        other = rate(0 if picked else 1)[0]
     print(f"{Y} x {X}: the library ({'quad' if picked else 'no quad'}) {mine:.0f} flips/ns, the other way {other:.0f}")
     assert mine >= (1.0 - TOL) * other, f"{Y} x {X}: the library's choice ({'quad' if picked else 'no quad'}) runs {mine:.0f} flips/ns, the other path {other:.0f}"
