@@ -624,7 +624,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		const int mi = ising::quad_word_maxi(qp, waves);
 		int lds_max = 64 * 1024;
 		if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeSharedMemPerBlockOptin, cfg->device) != hipSuccess || lds_max <= 0) { (void)hipGetLastError(); lds_max = 64 * 1024; }
-		if (mi > 0 && ising::quad_pass_lds_bytes(qp, waves) <= (size_t)lds_max) {
+		if (mi > 0 && ising::quad_pass_lds_bytes(qp, waves) + 64 <= (size_t)lds_max) { // (+ the kernel's static words: a print point's two sums)
 			c->quad_C = C; c->quad_T = T; c->quad_HG = HG; c->quad_waves = waves;
 		} else if (pol.quad == 1 && (pol.quad_C || pol.quad_T || pol.quad_waves)) {
 			delete c;
