@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of the quad path (ising_quad.hip) against the tile launches / one launch per colour of the same library (ISING_QUAD=0): the same lattice, seed and
 number of sweeps through both, final states compared word for word (plus counts and bond sum); calls of uneven lengths so that passes of every length occur,
-every third call with print points (ising_sweep_counted, every 16).
+every third call with print points (ising_sweep_counted, every 16; every other one of those with the energy).
 Usage: soak_quad.py [X Y sweeps ...]   (profiles/soak_quad_r05.txt)"""
 import hashlib
 import os
@@ -27,7 +27,7 @@ def run(X, Y, sweeps, quad):
         while left:
             n = min(left, int(rng.integers(1, 4096)))
             if k % 3 == 2:
-                counts += s.sweep_counted(n, 16)
+                counts += s.sweep_counted(n, 16, k % 2 == 0)  # (every other one with the bond sum at the print points)
             else:
                 s.sweep(n)
             left -= n
