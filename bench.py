@@ -178,6 +178,7 @@ def default_lattice_leg(args, device):
             else:
                 os.environ["ISING_QUAD"] = old
     return {"value": out["value"], "unit": "flips/ns", "lattice": f"{Y}x{X}", "sweeps_per_call": n, "form": out["value_form"],
+            "frac_hbm_1p5B": round(out["value"] * 1.5 / 8000.0, 4), "without_quad_path_frac_hbm_1p5B": round(out["without_quad_path"] * 1.5 / 8000.0, 4),
             "without_quad_path": out["without_quad_path"], "without_quad_path_form": out["without_quad_path_form"],
             "counts_equal": out["value_counts"] == out["without_quad_path_counts"], "up_down": out["value_counts"],
             "what": "the reference's default lattice (cuIsing without -x/-y, optimized/main.cu:1395-1410) at T = Tc: best of three calls of 4096 sweeps; "
