@@ -489,14 +489,16 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	const long long spins = (long long)cfg->X * cfg->Y;
 	// Small and narrow lattices (round 5, ising_quad.hip): one launch per pass of T sweeps = the word pass on tiles + halo next to the draws of the pass to come,
 	// made ONCE by the rest of the chip -- on a dense slab (the spins live in the dense layout between calls).  A lone slab that wraps in place, integer
-	// thresholds, no sub-lattices, no couplings, up to four blocks of 2048 columns (a tile is as wide as the lattice).
+	// thresholds, no sub-lattices, no couplings, up to eight blocks of 2048 columns (a tile is as wide as the lattice and keeps two items a wave).
 	// By measurement on a whole MI355X (tools/quad_probe.py, profiles/quad_probe_r05.txt; flips/ns quad / the library before): 2048 x 512 739 / 273, 2048^2 1707 / 877,
 	// 2048 x 8192 2226 / 1616, 4096 x 1024 1624 / 875, 4096^2 2306 / 1614, 4096 x 16384 2602 / 2194, 6144 x 2048 1996 / 1630, 6144^2 2341 / 2208, 8192 x 1024 1747 / 1219
-	// -- and 8192 x 2048 2037 / 2183: the fused launches' from there on.  ISING_QUAD=1 asks for it wherever it applies, 0 never; tests/test_gpu_policy.py holds the rule
+	// -- and 8192 x 2048 2037 / 2183: the fused launches' from there on.  Five and six blocks up to 1024 rows (passes of two sweeps on tiles of two row groups: a row
+	// of 10240 columns and more is draws enough per launch): 10240 x 512 1161 / 762, 10240 x 1024 1421 / 1011, 12288 x 768 1444 / 1257, 12288 x 1024 1484 / 1293; seven and
+	// eight blocks only when asked (16384 x 1024 1569 / 1718).  ISING_QUAD=1 asks for it wherever it applies, 0 never; tests/test_gpu_policy.py holds the rule
 	// against the other path.
-	const bool quad_can = c->wrap && !cfg->XSL && !cfg->use_J && c->fast_ok && (cfg->Y % 4) == 0 && c->gx <= 4 && pol.quad != 0 &&
+	const bool quad_can = c->wrap && !cfg->XSL && !cfg->use_J && c->fast_ok && (cfg->Y % 4) == 0 && c->gx <= 8 && pol.quad != 0 &&
 	                      (cfg->layout == ISING_LAYOUT_AUTO || cfg->layout == ISING_LAYOUT_DENSE) && cfg->kernel != ISING_KERNEL_GENERIC;
-	const bool quad_pick = quad_can && (pol.quad == 1 || (c->cus >= 200 && (c->gx <= 2 ? spins <= (1LL << 26) : (c->gx == 3 ? cfg->Y <= 6144 : cfg->Y <= 1024))));
+	const bool quad_pick = quad_can && (pol.quad == 1 || (c->cus >= 200 && c->gx <= 6 && (c->gx <= 2 ? spins <= (1LL << 26) : (c->gx == 3 ? cfg->Y <= 6144 : cfg->Y <= 1024))));
 	// (sub-lattices: every XSL x YSL block is a periodic system of its own -- nothing crosses slabs, so ring slabs qualify too --;
 	// their strips must not straddle a block, and the fused kernels carry no couplings next to sub-lattices)
 	const bool fused_can = cfg->XSL ? !cfg->use_J : c->wrap;
@@ -609,8 +611,10 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 			if (cfg->Y < 2048) { C0 = 4; T0 = 12; W0 = 16; }
 			else if (cfg->Y < 8192) { C0 = 4; T0 = 8; W0 = 12; }
 			else { C0 = 8; T0 = 4; W0 = 12; }
-		} else {
+		} else if (c->gx <= 4) {
 			C0 = 4; T0 = 4; W0 = c->gx == 3 ? 12 : 16;
+		} else { // (five to eight blocks: two items a wave of sixteen hold a tile of 32 / gx row groups)
+			C0 = 2; T0 = 2; W0 = c->gx <= 6 ? 12 : 16;
 		}
 		int T = pol.quad_T ? pol.quad_T : T0;
 		T = std::max(1, std::min(T, 32));

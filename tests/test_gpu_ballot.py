@@ -129,7 +129,7 @@ def test_auto_layout_picks_ballot_where_it_applies(gpu):
         assert s.layout == BAL and s.fused and s.strip_rows == 1
     with ig.IsingSlab(16384, 2048, temp=1.5) as s:      # (rows of several wave columns want more tickets a level before two-row units pay)
         assert s.layout == BAL and s.fused and s.strip_rows == 1
-    with ig.IsingSlab(10240, 1024, temp=1.5) as s:      # small slabs: the dense layout is ahead (tile launches; up to four blocks of 2048 columns: the quad path)
+    with ig.IsingSlab(65536, 256, temp=1.5) as s:       # small slabs: the dense layout is ahead (tile launches; up to six blocks of 2048 columns: the quad path)
         assert s.layout == ig.LAYOUT_DENSE and s.tiled
     with ig.IsingSlab(8192, 1024, temp=1.5) as s:
         assert s.layout == ig.LAYOUT_DENSE and s.quad

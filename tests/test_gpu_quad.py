@@ -34,6 +34,7 @@ def _compare(slab, orc, what):
 SHAPES = [  # X, Y, row groups per tile, sweeps per pass, waves
     (2048, 64, 8, 8, 4), (2048, 64, 4, 4, 8), (2048, 16, 4, 2, 2), (2048, 32, 2, 16, 16), (2048, 128, 16, 3, 8),
     (4096, 128, 8, 8, 8), (4096, 64, 8, 5, 8), (6144, 48, 3, 6, 16), (8192, 64, 4, 4, 8), (4096, 256, 7, 7, 16), (4096, 4096, 4, 8, 12), (2048, 8192, 4, 8, 8),
+    (10240, 64, 2, 2, 12), (12288, 128, 2, 2, 12), (14336, 64, 2, 2, 16), (16384, 48, 2, 2, 16),
 ]
 
 
@@ -169,7 +170,7 @@ def test_quad_randomised(gpu, oracle_mod, monkeypatch):
 
 def test_quad_default_rule(gpu, oracle_mod, monkeypatch):
     """Lone slabs of up to four blocks of 2048 columns sweep on the quad path by default (ising_sweep_info: 4) -- up to 2^26 spins for one and two blocks,
-    6144 rows for three, 1024 rows for four; ISING_QUAD=0, wider or larger lattices, ring slabs, couplings, sub-lattices, the generic kernel, temperatures without integer
+    6144 rows for three, 1024 rows for four to six; ISING_QUAD=0, wider or larger lattices, ring slabs, couplings, sub-lattices, the generic kernel, temperatures without integer
     thresholds and the other layouts asked for by name keep what they had."""
     _env(monkeypatch)
     orc = oracle_mod.OracleLattice(2048, 512, seed=99, temp=TC).init()
@@ -181,10 +182,10 @@ def test_quad_default_rule(gpu, oracle_mod, monkeypatch):
             s.init().sweep(23)
             _compare(s, orc, str(env))
     _env(monkeypatch)
-    for X, Y, quad in ((4096, 16384, True), (6144, 6144, True), (6144, 8192, False), (8192, 1024, True), (8192, 2048, False), (10240, 1024, False), (4096, 32768, False), (2048, 16, True)):
+    for X, Y, quad in ((4096, 16384, True), (6144, 6144, True), (6144, 8192, False), (8192, 1024, True), (8192, 2048, False), (10240, 1024, True), (12288, 512, True), (12288, 2048, False), (14336, 1024, False), (4096, 32768, False), (2048, 16, True)):
         with ig.IsingSlab(X, Y, temp=TC) as s:
             assert s.quad == quad, (X, Y)
-            sweeps_a_pass = {2048: 8 if Y < 1024 else (16 if Y < 4096 else (12 if Y < 8192 else (8 if Y < 16384 else 4))), 4096: 12 if Y < 2048 else (8 if Y < 8192 else 4), 6144: 4, 8192: 4}.get(X)
+            sweeps_a_pass = {2048: 8 if Y < 1024 else (16 if Y < 4096 else (12 if Y < 8192 else (8 if Y < 16384 else 4))), 4096: 12 if Y < 2048 else (8 if Y < 8192 else 4), 6144: 4, 8192: 4, 10240: 2, 12288: 2}.get(X)
             assert not quad or (s.layout == ig.LAYOUT_DENSE and s.max_sweeps_per_launch == sweeps_a_pass)
     with ig.IsingSlab(2048, 512, temp=TC, layout=ig.LAYOUT_DENSE) as s:
         assert s.quad
