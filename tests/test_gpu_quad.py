@@ -169,7 +169,7 @@ def test_quad_randomised(gpu, oracle_mod, monkeypatch):
 
 
 def test_quad_default_rule(gpu, oracle_mod, monkeypatch):
-    """Lone slabs of up to four blocks of 2048 columns sweep on the quad path by default (ising_sweep_info: 4) -- up to 2^26 spins for one and two blocks,
+    """Lone slabs of up to six blocks of 2048 columns sweep on the quad path by default (ising_sweep_info: 4) -- up to 2^26 spins for one and two blocks,
     6144 rows for three, 1024 rows for four to six; ISING_QUAD=0, wider or larger lattices, ring slabs, couplings, sub-lattices, the generic kernel, temperatures without integer
     thresholds and the other layouts asked for by name keep what they had."""
     _env(monkeypatch)
