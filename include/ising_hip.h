@@ -196,7 +196,7 @@ int ising_strip_info(ising_ctx *ctx, int *strip_rows, int *nstrips);
 /* nslabs == 1 only: `nsweeps` full sweeps, black then white, iterations first_it .. first_it+nsweeps-1
  * (the hot loop, optimized/main.cu:1763-1805).  How the sweeps are launched depends on the lattice (ising_sweep_info): fused
  * launches of many sweeps on the ballot layout (from 1.5 * 2^24 spins, and below for lattices of enough rows), one launch per pass of 4 - 8 sweeps on the quad
- * layout for lone lattices of one to six blocks of 2048 columns (round 5: a word pass on tiles + halo next to the draws of the pass to come; the spins are
+ * layout for lone lattices of one to eight blocks of 2048 columns (round 5: a word pass on tiles + halo next to the draws of the pass to come; the spins are
  * converted from and to the dense layout at either end of the call), tile launches of 3 - 6
  * sweeps on the dense layout up to 2^24 spins (the first call allocates a second lattice buffer of the size of the first: every launch reads one and writes the
  * other, and an even number of launches per call leaves the spins where every other entry point expects them), one launch per
@@ -223,7 +223,7 @@ int ising_sweep_counted(ising_ctx *ctx, int first_it, int nsweeps, int every, ui
  * (round 5; ising_ballot.hip: ballot_split_k): draw units -- no wait, no barrier, tall strips -- and word units with tickets of their own, for lone
  * lattices and ring slabs whose levels have too few tickets for tall strips in the plain fused form.  4: the quad path (round 5; ising_quad.hip: quad_pass_k) --
  * one launch per pass of *max_sweeps_per_launch sweeps: tiles of a few row groups x the whole width + halo in LDS run the pass's word phases while the rest of
- * the chip draws the accept masks of the pass to come, once (lone lattices of one to six blocks of 2048 columns, or ISING_QUAD=1: up to eight). */
+ * the chip draws the accept masks of the pass to come, once (lone lattices of one to eight blocks of 2048 columns and few enough rows, or ISING_QUAD=1). */
 int ising_sweep_info(ising_ctx *ctx, int *fused, int *max_sweeps_per_launch);
 /* Same, bracketed by HIP events on the context's stream; returns elapsed milliseconds (blocking). */
 int ising_sweep_timed(ising_ctx *ctx, int first_it, int nsweeps, float *elapsed_ms);

@@ -492,13 +492,13 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// thresholds, no sub-lattices, no couplings, up to eight blocks of 2048 columns (a tile is as wide as the lattice and keeps two items a wave).
 	// By measurement on a whole MI355X (tools/quad_probe.py, profiles/quad_probe_r05.txt; flips/ns quad / the library before): 2048 x 512 739 / 273, 2048^2 1707 / 877,
 	// 2048 x 8192 2226 / 1616, 4096 x 1024 1624 / 875, 4096^2 2306 / 1614, 4096 x 16384 2602 / 2194, 6144 x 2048 1996 / 1630, 6144^2 2341 / 2208, 8192 x 1024 1747 / 1219
-	// -- and 8192 x 2048 2037 / 2183: the fused launches' from there on.  Five and six blocks up to 1024 rows (passes of two sweeps on tiles of two row groups: a row
-	// of 10240 columns and more is draws enough per launch): 10240 x 512 1161 / 762, 10240 x 1024 1421 / 1011, 12288 x 768 1444 / 1257, 12288 x 1024 1484 / 1293; seven and
-	// eight blocks only when asked (16384 x 1024 1569 / 1718).  ISING_QUAD=1 asks for it wherever it applies, 0 never; tests/test_gpu_policy.py holds the rule
+	// -- and 8192 x 2048 2037 / 2183: the fused launches' from there on.  Five and six blocks up to 1024 rows (three items a wave of sixteen hold tiles of 48 / gx row groups + halo: passes of four to six sweeps;
+	// a row of 10240 columns and more is draws enough per launch): 10240 x 512 1582 / 762, 10240 x 1024 1748 / 1011, 12288 x 512 1807 / 1054, 12288 x 1024 1904 / 1293; seven and
+	// eight blocks up to 512 rows (14336 x 512 1592 / 1064, 16384 x 512 1747 / 1214; 16384 x 1024: the fused launches' 1728 against 1647).  ISING_QUAD=1 asks for it wherever it applies, 0 never; tests/test_gpu_policy.py holds the rule
 	// against the other path.
 	const bool quad_can = c->wrap && !cfg->XSL && !cfg->use_J && c->fast_ok && (cfg->Y % 4) == 0 && c->gx <= 8 && pol.quad != 0 &&
 	                      (cfg->layout == ISING_LAYOUT_AUTO || cfg->layout == ISING_LAYOUT_DENSE) && cfg->kernel != ISING_KERNEL_GENERIC;
-	const bool quad_pick = quad_can && (pol.quad == 1 || (c->cus >= 200 && c->gx <= 6 && (c->gx <= 2 ? spins <= (1LL << 26) : (c->gx == 3 ? cfg->Y <= 6144 : cfg->Y <= 1024))));
+	const bool quad_pick = quad_can && (pol.quad == 1 || (c->cus >= 200 && (c->gx <= 2 ? spins <= (1LL << 26) : (c->gx == 3 ? cfg->Y <= 6144 : (c->gx <= 6 ? cfg->Y <= 1024 : cfg->Y <= 512)))));
 	// (sub-lattices: every XSL x YSL block is a periodic system of its own -- nothing crosses slabs, so ring slabs qualify too --;
 	// their strips must not straddle a block, and the fused kernels carry no couplings next to sub-lattices)
 	const bool fused_can = cfg->XSL ? !cfg->use_J : c->wrap;
@@ -611,10 +611,20 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 			if (cfg->Y < 2048) { C0 = 4; T0 = 12; W0 = 16; }
 			else if (cfg->Y < 8192) { C0 = 4; T0 = 8; W0 = 12; }
 			else { C0 = 8; T0 = 4; W0 = 12; }
-		} else if (c->gx <= 4) {
-			C0 = 4; T0 = 4; W0 = c->gx == 3 ? 12 : 16;
-		} else { // (five to eight blocks: two items a wave of sixteen hold a tile of 32 / gx row groups)
-			C0 = 2; T0 = 2; W0 = c->gx <= 6 ? 12 : 16;
+		} else if (c->gx == 3) { // (from three blocks on: up to three items a wave of sixteen -- 100 registers, four waves per SIMD: a tile has its CU to itself)
+			if (cfg->Y < 1024) { C0 = 2; T0 = 8; W0 = 16; }       // 6144 x 512: 1361 against (4, 4, 16) 1076
+			else if (cfg->Y < 2048) { C0 = 4; T0 = 8; W0 = 16; }  // 6144 x 1024: 1984 against (4, 4, 12) 1670
+			else if (cfg->Y < 4096) { C0 = 8; T0 = 6; W0 = 16; }  // 6144 x 2048: 2057 against 1951
+			else { C0 = 4; T0 = 4; W0 = 12; }
+		} else if (c->gx == 4) {
+			if (cfg->Y < 1024) { C0 = 2; T0 = 8; W0 = 16; }       // 8192 x 512: 1496 against 1231
+			else if (cfg->Y < 2048) { C0 = 4; T0 = 8; W0 = 16; }  // 8192 x 1024: 2043 against 1642
+			else { C0 = 4; T0 = 4; W0 = 16; }
+		} else if (c->gx <= 6) {
+			if (cfg->Y < 1024) { C0 = 2; T0 = 6; W0 = 16; }       // 10240 x 512: 1582, 12288 x 512: 1807 against (2, 2, 12) 1161 / 1229
+			else { C0 = 4; T0 = 4; W0 = 16; }                     // 10240 x 1024: 1748, 12288 x 1024: 1904 against 1427 / 1466
+		} else {
+			C0 = 2; T0 = 4; W0 = 16;                               // 14336 x 512: 1592, 16384 x 512: 1747 against (2, 2, 16) 1293 / 1313
 		}
 		int T = pol.quad_T ? pol.quad_T : T0;
 		T = std::max(1, std::min(T, 32));

@@ -381,7 +381,7 @@ __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile
 // draws on a second stream -- ran 1950 flips/ns at 2048^2 in a fresh process and 660 in one whose earlier contexts had created high-priority streams).
 // (one and two items a wave: six waves per SIMD -- two workgroups of twelve waves per CU, a tile next to a drawing workgroup -- are worth 80 registers a lane)
 template <int MAXI>
-__global__ void __launch_bounds__(MAXI <= 2 ? 1024 : 512) __attribute__((amdgpu_waves_per_eu(MAXI <= 2 ? 6 : 2))) quad_pass_k(const QuadPassParams p) {
+__global__ void __launch_bounds__(MAXI <= 3 ? 1024 : 512) __attribute__((amdgpu_waves_per_eu(MAXI <= 2 ? 6 : (MAXI == 3 ? 4 : 2)))) quad_pass_k(const QuadPassParams p) {
 	extern __shared__ __attribute__((aligned(16))) uint64_t q_lds[];
 	const int lane = threadIdx.x & 63;
 	const int wi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -462,7 +462,7 @@ size_t quad_pass_lds_bytes(const QuadWordParams &w, int waves) {
 
 int quad_word_maxi(const QuadWordParams &p, int waves) {
 	const int items = (p.C + 2 * p.HG) * p.gx, need = (items + waves - 1) / waves;
-	for (int mi : {1, 2, 3, 4}) if (mi >= need) return (mi > 2 && waves > 8) ? 0 : mi; // (three and four items a wave: the registers of eight waves at most)
+	for (int mi : {1, 2, 3, 4}) if (mi >= need) return (mi > 3 && waves > 8) ? 0 : mi; // (four items a wave: the registers of eight waves at most)
 	return 0;
 }
 
@@ -483,7 +483,7 @@ hipError_t launch_quad_pass(QuadPassParams &p, int waves, hipStream_t stream) {
 	const int mi0 = quad_word_maxi(p.w, waves);
 	p.ntiles = p.w.nlev > 0 ? (p.w.NRG + p.w.C - 1) / p.w.C : 0;
 	// workgroup slots of the chip: eight waves per SIMD at one item a wave, six at two (80 registers), three beyond
-	const int per_cu = std::max(1, ((mi0 <= 1 ? 8 : (mi0 <= 2 ? 6 : 3)) * 4) / waves); // (one item a wave: under 64 registers)
+	const int per_cu = std::max(1, ((mi0 <= 1 ? 8 : (mi0 <= 2 ? 6 : (mi0 == 3 ? 4 : 3))) * 4) / waves); // (one item a wave: under 64 registers; three: 128)
 	const int cap = std::max(4, p.cus * per_cu) & ~3;
 	long long draw_wgs = 0;
 	if (p.d.nlev > 0) {

@@ -93,7 +93,7 @@ def test_library_choice_within_3_percent_of_its_neighbours(gpu, warm_clock, monk
                                         f"a neighbour {best:.0f}: {cells}")
 
 
-QUAD_SHAPES = [(2048, 2048), (4096, 4096), (2048, 16384), (6144, 6144), (8192, 1024), (8192, 2048), (4096, 16384), (10240, 1024), (12288, 768)]
+QUAD_SHAPES = [(2048, 2048), (4096, 4096), (2048, 16384), (6144, 6144), (8192, 1024), (8192, 2048), (4096, 16384), (10240, 1024), (12288, 768), (6144, 1024), (16384, 512)]
 
 
 @pytest.mark.parametrize("X,Y", QUAD_SHAPES)

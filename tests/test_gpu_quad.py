@@ -35,6 +35,7 @@ SHAPES = [  # X, Y, row groups per tile, sweeps per pass, waves
     (2048, 64, 8, 8, 4), (2048, 64, 4, 4, 8), (2048, 16, 4, 2, 2), (2048, 32, 2, 16, 16), (2048, 128, 16, 3, 8),
     (4096, 128, 8, 8, 8), (4096, 64, 8, 5, 8), (6144, 48, 3, 6, 16), (8192, 64, 4, 4, 8), (4096, 256, 7, 7, 16), (4096, 4096, 4, 8, 12), (2048, 8192, 4, 8, 8),
     (10240, 64, 2, 2, 12), (12288, 128, 2, 2, 12), (14336, 64, 2, 2, 16), (16384, 48, 2, 2, 16),
+    (6144, 128, 4, 8, 16), (8192, 256, 2, 8, 16), (12288, 64, 2, 6, 16), (10240, 128, 4, 4, 16), (16384, 64, 2, 4, 16), (6144, 256, 8, 6, 16),
 ]
 
 
@@ -140,7 +141,7 @@ def test_quad_randomised(gpu, oracle_mod, monkeypatch):
         HG = (2 * T + 2) // 4
         items = (min(C, Y // 4) + 2 * HG) * gx
         per_wave = (items + NW - 1) // NW
-        if per_wave > 4 or (per_wave > 2 and NW > 8) or items * 1024 > 150 * 1024:
+        if per_wave > 4 or (per_wave > 3 and NW > 8) or items * 1024 > 150 * 1024:
             continue
         temp = float(rng.choice([1.5, 2.0, TC, 3.0]))
         seed = int(rng.integers(1, 2**62))
@@ -170,7 +171,7 @@ def test_quad_randomised(gpu, oracle_mod, monkeypatch):
 
 def test_quad_default_rule(gpu, oracle_mod, monkeypatch):
     """Lone slabs of up to six blocks of 2048 columns sweep on the quad path by default (ising_sweep_info: 4) -- up to 2^26 spins for one and two blocks,
-    6144 rows for three, 1024 rows for four to six; ISING_QUAD=0, wider or larger lattices, ring slabs, couplings, sub-lattices, the generic kernel, temperatures without integer
+    6144 rows for three, 1024 rows for four to six, 512 for seven and eight; ISING_QUAD=0, wider or larger lattices, ring slabs, couplings, sub-lattices, the generic kernel, temperatures without integer
     thresholds and the other layouts asked for by name keep what they had."""
     _env(monkeypatch)
     orc = oracle_mod.OracleLattice(2048, 512, seed=99, temp=TC).init()
@@ -182,10 +183,11 @@ def test_quad_default_rule(gpu, oracle_mod, monkeypatch):
             s.init().sweep(23)
             _compare(s, orc, str(env))
     _env(monkeypatch)
-    for X, Y, quad in ((4096, 16384, True), (6144, 6144, True), (6144, 8192, False), (8192, 1024, True), (8192, 2048, False), (10240, 1024, True), (12288, 512, True), (12288, 2048, False), (14336, 1024, False), (4096, 32768, False), (2048, 16, True)):
+    for X, Y, quad in ((4096, 16384, True), (6144, 6144, True), (6144, 8192, False), (8192, 1024, True), (8192, 2048, False), (10240, 1024, True), (12288, 512, True), (12288, 2048, False), (14336, 1024, False), (14336, 512, True), (16384, 512, True), (16384, 768, False), (6144, 1024, True), (6144, 2048, True), (8192, 512, True), (4096, 32768, False), (2048, 16, True)):
         with ig.IsingSlab(X, Y, temp=TC) as s:
             assert s.quad == quad, (X, Y)
-            sweeps_a_pass = {2048: 8 if Y < 1024 else (16 if Y < 4096 else (12 if Y < 8192 else (8 if Y < 16384 else 4))), 4096: 12 if Y < 2048 else (8 if Y < 8192 else 4), 6144: 4, 8192: 4, 10240: 2, 12288: 2}.get(X)
+            sweeps_a_pass = {2048: 8 if Y < 1024 else (16 if Y < 4096 else (12 if Y < 8192 else (8 if Y < 16384 else 4))), 4096: 12 if Y < 2048 else (8 if Y < 8192 else 4),
+                             6144: 8 if Y < 2048 else (6 if Y < 4096 else 4), 8192: 8, 10240: 6 if Y < 1024 else 4, 12288: 6 if Y < 1024 else 4, 14336: 4, 16384: 4}.get(X)
             assert not quad or (s.layout == ig.LAYOUT_DENSE and s.max_sweeps_per_launch == sweeps_a_pass)
     with ig.IsingSlab(2048, 512, temp=TC, layout=ig.LAYOUT_DENSE) as s:
         assert s.quad

@@ -27,7 +27,7 @@ def test_auto_regimes_bit_exact(gpu, oracle_mod, X, Y, layout, fused, tiled, H):
     orc = oracle_mod.OracleLattice(X, Y, seed=4242, temp=TC).init()
     with ig.IsingSlab(X, Y, seed=4242, temp=TC) as s:
         assert (s.layout, s.fused, s.tiled) == (layout, fused, tiled), (s.layout, s.fused, s.tiled, s.strip_rows)
-        assert s.quad == (layout == D and not tiled and X <= 12288), s.quad
+        assert s.quad == (layout == D and not tiled and X <= 16384), s.quad
         assert not H or s.strip_rows == H, s.strip_rows
         s.init()
         done = 0
