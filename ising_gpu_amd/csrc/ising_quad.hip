@@ -159,8 +159,9 @@ __device__ __forceinline__ void qm_read(uint32_t &x0, uint32_t &x1, uint32_t &x2
 }
 
 // ---- words: `nlev` levels (black first) of tile `tile`.  Everything that indexes is wave-uniform and lives on the scalar unit (a lone wave issues an
-// instruction every four or five cycles whatever its kind); a wave works on its items two at a time (all LDS reads of both first, one exposed round trip per
-// pair); the masks of the level after next are on their way into registers (three sets, the level loop unrolled by six = colours x sets).
+// instruction every four or five cycles whatever its kind); a wave works on its one to three items in turn (pairs with all LDS reads first cost the registers
+// of a sixth wave per SIMD: ISING_QUAD_PAIR); the masks of the level after next are on their way into accumulation registers (three sets, the level loop
+// unrolled by six = colours x sets).
 template <int MAXI>
 __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile, int wi, int lane, int NW, uint64_t *q_lds) {
 	const int gx = p.gx, NRG = p.NRG, HG = p.HG;
@@ -379,7 +380,8 @@ __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile
 // One launch = the word pass of T sweeps on the masks the launch before made + the draws of the pass to come: workgroups [0, ntiles) take a tile each (they
 // are dispatched first), the rest draw.  One stream, no events: nothing rests on two hardware queues running side by side (the first form of this path --
 // draws on a second stream -- ran 1950 flips/ns at 2048^2 in a fresh process and 660 in one whose earlier contexts had created high-priority streams).
-// (one and two items a wave: six waves per SIMD -- two workgroups of twelve waves per CU, a tile next to a drawing workgroup -- are worth 80 registers a lane)
+// (one and two items a wave: six waves per SIMD -- two workgroups of twelve waves per CU, a tile next to a drawing workgroup -- are worth 80 registers a lane;
+// three items: 128, four waves per SIMD -- a tile of sixteen waves has its CU to itself; four: eight waves a workgroup at most)
 template <int MAXI>
 __global__ void __launch_bounds__(MAXI <= 3 ? 1024 : 512) __attribute__((amdgpu_waves_per_eu(MAXI <= 2 ? 6 : (MAXI == 3 ? 4 : 2)))) quad_pass_k(const QuadPassParams p) {
 	extern __shared__ __attribute__((aligned(16))) uint64_t q_lds[];
