@@ -36,8 +36,8 @@ goldens for the TOTAL lattice (tests/golden/bench_65536_tc.json, ring_65536_tc.j
 
 The JSON line: `value` = bare sweeps (the contract's timed region); `with_counts_every_16` = a second leg over the same sweeps with
 the magnetisation of every 16th sweep (and of the last) inside the timed region, as every number the reference publishes includes it
-(optimized/main.cu:1806-1810); `with_counts_and_energy_every_16` = a third leg with the bond sum (north_star's energy series) at the same points -- both taken inside the launches: ising_sweep_counted at N = 1, ising_rank_sweep_counted on the library's ring --; `roofline.bound` = "valu" -- the roof that binds, with the draw-only ceiling measured in the same
-job -- next to SURVEY 8(d)'s HBM accounting (1.5 B/flip) and the device's real HBM traffic.
+(optimized/main.cu:1806-1810); `with_counts_and_energy_every_16` = a third leg with the bond sum (north_star's energy series) at the same points -- both taken inside the launches: ising_sweep_counted at N = 1, ising_rank_sweep_counted on the library's ring --; `roofline.frac` = SURVEY 8(d)'s number (1.5 B per flip x flips per launch / average launch duration / 8 TB/s: reproducible from the rocprofv3 summary under profiles/),
+`roofline.bound` = "valu" -- the roof that binds in fact, with the ratio to a draw-only kernel measured in the same job as `frac_valu_ceiling` -- and the device's real HBM traffic next to them.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -648,18 +648,20 @@ def main():
                 ceil, sclk_ceiling = ig.philox_ceiling_clocked(local_rank, 25.0)  # an average over >= 25 ms of launches, like the kernel it is compared with
             except ig.IsingError as e:
                 ceil_err = str(e)
+        # `frac` is the CONTRACT's number: algorithmic bytes per launch (1.5 B per flip x the flips of one launch) / the kernel's average launch
+        # duration (HIP events on the launches' stream) / 8 TB/s.  `bound` says which roof binds in fact -- the vector ALU: one 32-bit Philox4x32-10 output per
+        # site is forced by bit-exact parity --, and the ratio to a kernel that only draws (same job, same chip, same clocks) rides along as frac_valu_ceiling.
+        roof = {"bound": "valu" if ceil else "hbm", "achieved": hbm_reference["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_reference["frac"],
+                "frac_what": "SURVEY 8(d): 1.5 B per flip (the reference's accounting, optimized/main.cu:1887-1889) x flips per launch / average launch duration / 8 TB/s"}
         if ceil:
-            roof = {"bound": "valu", "achieved": round(kern_rate, 1), "peak": round(ceil, 1), "unit": "sites/ns", "frac": round(kern_rate / ceil, 4),
-                    "frac_of_value": round(value / world / ceil, 4),
-                    "peak_what": "draw-only kernel measured in this job (ising_philox_ceiling: Philox4x32-10, one 32-bit output per site exactly as the "
-                                 "update kernels draw them, no accept test, no lattice, no memory traffic)",
-                    "note": "the kernel is bound by the vector ALU, not by HBM (SQ_ACTIVE_INST_VALU x waves per SIMD ~ 1, real HBM use under a fifth "
-                            "of peak): `frac` is the fraction of the roof that binds; the HBM figures -- SURVEY 8(d)'s 1.5 B/flip accounting and the "
-                            "device's real traffic -- are the siblings hbm_reference_accounting and hbm_real"}
-        else:  # (no ALU probe: the contract's HBM form)
-            roof = {"bound": "hbm", "achieved": hbm_reference["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_reference["frac"]}
-            if ceil_err:
-                roof["alu_probe_error"] = ceil_err
+            roof.update({"frac_valu_ceiling": round(kern_rate / ceil, 4), "valu_ceiling_sites_ns": round(ceil, 1), "kernel_sites_ns": round(kern_rate, 1),
+                         "frac_valu_ceiling_of_value": round(value / world / ceil, 4),
+                         "valu_ceiling_what": "draw-only kernel measured in this job (ising_philox_ceiling: Philox4x32-10, one 32-bit output per site exactly as the "
+                                              "update kernels draw them, no accept test, no lattice, no memory traffic)",
+                         "note": "the kernel is bound by the vector ALU, not by HBM (SQ_ACTIVE_INST_VALU x waves per SIMD ~ 1, real HBM use under a fifth of peak): "
+                                 "`frac` is the contract's HBM accounting, `frac_valu_ceiling` the fraction of the roof that binds, hbm_real the device's real traffic"})
+        elif ceil_err:
+            roof["alu_probe_error"] = ceil_err
         # SURVEY 8(d)'s figures as SCALAR keys (the harness keeps only those of `roofline`): the reference's 1.5 B/flip accounting against 8 TB/s, the
         # device's real HBM rate, real traffic over the device's algorithmic bytes; and the shader clocks of the two kernels `frac` compares
         roof.update({"frac_hbm_1p5B": hbm_reference["frac"], "hbm_achieved_gbs": hbm_reference["achieved"], "hbm_peak_gbs": HBM_PEAK_GBS,
@@ -705,7 +707,10 @@ def main():
             line["config"]["parity_expected"] = list(gold)
         if not ringed and not args.no_small_leg:
             try:
-                line["default_lattice_2048"] = default_lattice_leg(args, local_rank)
+                leg2048 = default_lattice_leg(args, local_rank)
+                leg2048["frac"] = leg2048["frac_hbm_1p5B"]  # (SURVEY 8(d)'s number for this lattice, as roofline.frac is for the headline's)
+                leg2048["frac_of_plateau"] = round(leg2048["value"] / (value / world), 4)  # against the large-lattice rate of the same job
+                line["default_lattice_2048"] = leg2048
             except Exception as e:  # noqa: BLE001  (a side leg must not cost the line)
                 line["default_lattice_2048"] = {"error": str(e)}
         if not ringed and not args.no_cpu_baseline:

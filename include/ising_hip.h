@@ -89,7 +89,9 @@ typedef struct ising_config {
 	                        torch tensor, so that its edge/halo rows can be handed to RCCL as ordinary tensors); NULL = the
 	                        library allocates.  (A lone slab of up to 2^24 spins on ISING_LAYOUT_DENSE sweeps in tile launches that
 	                        alternate between this buffer and a library-owned twin of the same size, allocated by ising_create; the
-	                        spins are back in this buffer whenever a call returns) */
+	                        spins are back in this buffer whenever a call returns.  The quad path -- lone lattices of one to eight
+	                        blocks of 2048 columns -- keeps four colour arrays of its own, 4 x X*Y/16 bytes, plus the accept masks of two
+	                        passes, 2 x 2T levels x X*Y/16 bytes at T sweeps a pass (T <= 16: up to 4.5 x X*Y bytes in all), next to it) */
 	void *coupling_mem;  /* the same for the -J coupling arrays */
 	int32_t layout;   /* ISING_LAYOUT_* */
 	int32_t use_J;    /* -J given: allocate coupling arrays and apply them in every update (useGenHamilt, :1368-1372) */
@@ -102,11 +104,18 @@ typedef struct ising_config {
 } ising_config;
 
 const char *ising_last_error(void);
+/* Every ISING_* environment switch the library (and its Python mirror) reads, as a markdown table: name, values, meaning and default.  Switches are A/B and test
+ * aids, read once per context in ising_create; docs/SWITCHES.md is this table, tests/test_switches.py holds both against the sources.  buf may be NULL: *needed
+ * = bytes including the terminator; ISING_E_ARG when len is too small (the text is truncated, *needed says how much it takes).  Needs no GPU. */
+int ising_switch_table(char *buf, size_t len, size_t *needed);
 
 /* Number of visible HIP devices (cudaGetDeviceCount at optimized/main.cu:1481-1491). */
 int ising_device_count(int *count);
 /* Device description for the "Using GPUs" block (optimized/main.cu:1482-1490). */
 int ising_device_info(int device, char *name, size_t name_len, int *cus, int *max_threads_per_cu, int *major, int *minor);
+/* One cell of the "GPUs direct access matrix" (cudaDeviceCanAccessPeer, optimized/main.cu:1508-1537): *can_access = 1 when `device` can load and store
+ * `peer`'s memory directly (a device reaches itself: 1).  Asks only; the ring enables peer access where it uses it. */
+int ising_device_peer_access(int device, int peer, int *can_access);
 
 /* Measurement aid for the bench's roofline object: sites per nanosecond of a kernel that only DRAWS -- one Philox4x32-10
  * output per site exactly as the update kernels generate them, no accept test, no lattice, no memory traffic.  The
@@ -198,8 +207,9 @@ int ising_strip_info(ising_ctx *ctx, int *strip_rows, int *nstrips);
  * launches of many sweeps on the ballot layout (from 1.5 * 2^24 spins, and below for lattices of enough rows), one launch per pass of 4 - 8 sweeps on the quad
  * layout for lone lattices of one to eight blocks of 2048 columns (round 5: a word pass on tiles + halo next to the draws of the pass to come; the spins are
  * converted from and to the dense layout at either end of the call), tile launches of 3 - 6
- * sweeps on the dense layout up to 2^24 spins (the first call allocates a second lattice buffer of the size of the first: every launch reads one and writes the
- * other, and an even number of launches per call leaves the spins where every other entry point expects them), one launch per
+ * sweeps on the dense layout up to 2^24 spins (ising_create allocates a second lattice buffer of the size of the first -- a sweep never allocates; without it
+ * the call returns ISING_E_STATE --: every launch reads one and writes the other, and an even number of launches per call leaves the spins where every other entry
+ * point expects them), one launch per
  * colour otherwise -- the spins after the call are the same in every form. */
 int ising_sweep(ising_ctx *ctx, int first_it, int nsweeps);
 /* The hot loop WITH its print points (optimized/main.cu:1763-1810: the sweeps, and countSpins whenever the iteration is a multiple of
@@ -219,12 +229,18 @@ int ising_sweep_counted(ising_ctx *ctx, int first_it, int nsweeps, int every, ui
  * a chip-filling grid through in-order tickets; ising_ballot.hip), 0 when it issues one launch per colour, 2 when it issues tile
  * launches (a lone slab on the dense layout up to 2^24 spins, or ISING_TILES=1: every workgroup sweeps a tile + halo of its own
  * *max_sweeps_per_launch times without a word from the others; ising_dense.hip: dense_tile_k).  For a ring slab with ghost rows G
- * deep (ballot layout): how the ring sweeps it -- fused launches of up to G/2 sweeps between exchanges.  3: fused launches in the split form
+ * deep (ballot layout): how the ring sweeps it -- fused launches of up to G/2 sweeps between exchanges.  3: fused launches, and calls of 2^35 flips and more
+ * (ISING_SPLIT=1: every call) run them in the split form -- a call shorter than that still issues the plain fused form at its own strip height; ising_sweep_form
+ * answers for a given call --
  * (round 5; ising_ballot.hip: ballot_split_k): draw units -- no wait, no barrier, tall strips -- and word units with tickets of their own, for lone
  * lattices and ring slabs whose levels have too few tickets for tall strips in the plain fused form.  4: the quad path (round 5; ising_quad.hip: quad_pass_k) --
  * one launch per pass of *max_sweeps_per_launch sweeps: tiles of a few row groups x the whole width + halo in LDS run the pass's word phases while the rest of
  * the chip draws the accept masks of the pass to come, once (lone lattices of one to eight blocks of 2048 columns and few enough rows, or ISING_QUAD=1). */
 int ising_sweep_info(ising_ctx *ctx, int *fused, int *max_sweeps_per_launch);
+/* The launch form and shape ising_sweep(ctx, ., nsweeps) issues for a call of that many sweeps: *form as ising_sweep_info's *fused, except that 3 is answered only
+ * when THIS call runs split launches (1 otherwise); *strip_rows, *wg_per_cu: strip height and workgroups per CU of the launches of that call (0 where the form has
+ * none: one launch per colour, tiles, quad).  Any pointer may be NULL. */
+int ising_sweep_form(ising_ctx *ctx, int nsweeps, int *form, int *strip_rows, int *wg_per_cu);
 /* Same, bracketed by HIP events on the context's stream; returns elapsed milliseconds (blocking). */
 int ising_sweep_timed(ising_ctx *ctx, int first_it, int nsweeps, float *elapsed_ms);
 

@@ -52,9 +52,11 @@ _lib = None
 # name -> (restype, argtypes); every symbol include/ising_hip.h and include/ising_hip_testing.h declare
 PROTOTYPES = {
     "ising_last_error": (C.c_char_p, []),
+    "ising_switch_table": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ising_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "ising_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ising_device_peer_access": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "ising_philox_ceiling": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "ising_philox_ceiling_clocked": (C.c_int, [C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ising_kernel_clock": (C.c_int, [C.c_void_p, C.c_int]),
@@ -83,6 +85,7 @@ PROTOTYPES = {
     "ising_ring_sweep_counted": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int)]),
     "ising_rank_sweep_counted": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int)]),
     "ising_sweep_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ising_sweep_form": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ising_sweep_timed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "ising_halo_ptrs": (C.c_int, [C.c_void_p, C.c_int] + [C.POINTER(C.c_void_p)] * 4 + [C.POINTER(C.c_size_t)]),
     "ising_ghost_ptrs": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)] + [C.POINTER(C.c_void_p)] * 4 + [C.POINTER(C.c_size_t)]),

@@ -408,18 +408,18 @@ int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_
 } // namespace
 
 int main(int argc, char **argv) {
-	int X = 0, Y = 0, dumpOut = 0, nsteps = NUMIT_DEF, ndev = 1;
+	int X = 0, Y = 0, dump_out = 0, nsteps = NUMIT_DEF, ndev = 1;
 	unsigned long long seed = ISING_SEED_DEF;
-	float alpha = -1.0f, temp = -1.0f, tempUpdStep = 0;
-	int tempUpdFreq = 0, printFreq = 0, printExp = 0, printEnergy = 0;
-	std::vector<unsigned long long> printExpSteps; // -e: sweep indices of the print points still to come are printExpSteps[printExpCur ...]
-	size_t printExpCur = 0;
-	double tgtMagn = -1.0;
-	int useSubLatt = 0, XSL = 0, YSL = 0, NSLX = 1, NSLY = 1;
-	int corrOut = 0;
+	float alpha = -1.0f, temp = -1.0f, ramp_step = 0;
+	int ramp_every = 0, print_every = 0, print_exp = 0, print_energy = 0;
+	std::vector<unsigned long long> exp_points; // -e: sweep indices of the print points still to come are exp_points[exp_next ...]
+	size_t exp_next = 0;
+	double target_magn = -1.0;
+	int with_sublattices = 0, XSL = 0, YSL = 0, NSLX = 1, NSLY = 1;
+	int corr_out = 0;
 	char cname[256];
-	int useGenHamilt = 0;
-	float hamiltPerc1 = 0.0f;
+	int with_couplings = 0;
+	float antiferro_prob = 0.0f;
 	std::vector<int> devmap;
 	int layout = ISING_LAYOUT_AUTO, transport = ISING_TRANSPORT_AUTO;
 	TsweepSpec ts;
@@ -447,7 +447,7 @@ int main(int argc, char **argv) {
 		case 'x': X = atoi(optarg); break;
 		case 'y': Y = atoi(optarg); break;
 		case 'n': nsteps = atoi(optarg); break;
-		case 'o': dumpOut = 1; break;
+		case 'o': dump_out = 1; break;
 		case 'h': usage(argv[0]); break;
 		case 's':
 			seed = atoll(optarg);
@@ -457,27 +457,27 @@ int main(int argc, char **argv) {
 		case 'd': ndev = atoi(optarg); break;
 		case 'a': alpha = atof(optarg); break;
 		case 't': temp = atof(optarg); break;
-		case 'p': printFreq = atoi(optarg); break;
-		case 'e': printExp = 1; break;
+		case 'p': print_every = atoi(optarg); break;
+		case 'e': print_exp = 1; break;
 		case 'u': {
 			char *t0 = strtok(optarg, ",");
 			if (!t0) { fprintf(stderr, "cannot find temperature step in parameter...\n"); exit(EXIT_FAILURE); }
 			char *t1 = strtok(NULL, ",");
 			if (!t1) { fprintf(stderr, "cannot find iteration count in parameter...\n"); exit(EXIT_FAILURE); }
-			tempUpdStep = atof(t0);
-			tempUpdFreq = atoi(t1);
-			printf("tempUpdStep: %f, tempUpdFreq: %d\n", tempUpdStep, tempUpdFreq);
+			ramp_step = atof(t0);
+			ramp_every = atoi(t1);
+			printf("tempUpdStep: %f, tempUpdFreq: %d\n", ramp_step, ramp_every);
 		} break;
-		case 'm': tgtMagn = atof(optarg); break;
-		case 'c': corrOut = 1; break;
+		case 'm': target_magn = atof(optarg); break;
+		case 'c': corr_out = 1; break;
 		case 'J':
-			useGenHamilt = 1;
-			hamiltPerc1 = atof(optarg);
-			hamiltPerc1 = std::min(std::max(0.0f, hamiltPerc1), 1.0f); // optimized/main.cu:1370
+			with_couplings = 1;
+			antiferro_prob = atof(optarg);
+			antiferro_prob = std::min(std::max(0.0f, antiferro_prob), 1.0f); // optimized/main.cu:1370
 			break;
-		case 1: useSubLatt = 1; XSL = atoi(optarg); break;
-		case 2: useSubLatt = 1; YSL = atoi(optarg); break;
-		case 3: printEnergy = 1; break;
+		case 1: with_sublattices = 1; XSL = atoi(optarg); break;
+		case 2: with_sublattices = 1; YSL = atoi(optarg); break;
+		case 3: print_energy = 1; break;
 		case 4:
 			for (char *tok = strtok(optarg, ","); tok; tok = strtok(NULL, ",")) devmap.push_back(atoi(tok));
 			break;
@@ -534,8 +534,8 @@ int main(int argc, char **argv) {
 		if (!Y) Y = ck.Y_total / ndev;
 		if (!seedGiven) seed = ck.seed;
 		if (temp == -1.0f && alpha == -1.0f) temp = ck.temp;
-		if (!useSubLatt && ck.XSL) { useSubLatt = 1; XSL = ck.XSL; YSL = ck.YSL; }
-		if (!useGenHamilt && ck.use_J) { useGenHamilt = 1; hamiltPerc1 = ck.J_prob; }
+		if (!with_sublattices && ck.XSL) { with_sublattices = 1; XSL = ck.XSL; YSL = ck.YSL; }
+		if (!with_couplings && ck.use_J) { with_couplings = 1; antiferro_prob = ck.J_prob; }
 	}
 	// defaults and divisibility rules, optimized/main.cu:1395-1421
 	if (!X || !Y) {
@@ -550,7 +550,7 @@ int main(int argc, char **argv) {
 		fprintf(stderr, "\nPlease specify a Y dim multiple of %d\n\n", Y_MULT);
 		usage(argv[0]);
 	}
-	if (useSubLatt) { // optimized/main.cu:1423-1457
+	if (with_sublattices) { // optimized/main.cu:1423-1457
 		if (!XSL || !YSL) {
 			if (!XSL) XSL = (YSL && !(YSL % X_MULT)) ? YSL : X_MULT;
 			if (!YSL) YSL = !(XSL % Y_MULT) ? XSL : Y_MULT;
@@ -567,11 +567,11 @@ int main(int argc, char **argv) {
 		NSLY = Y / YSL;
 	}
 	if (temp == -1.0f) temp = (alpha == -1.0f) ? ALPHA_DEF * ISING_CRIT_TEMP : alpha * ISING_CRIT_TEMP; // :1465-1471
-	if (printExp && printFreq) printFreq = 0;
+	if (print_exp && print_every) print_every = 0;
 	const int j0 = ckptIn ? (int)ck.it : 0, jend = j0 + nsteps; // --resume: iterations continue where the checkpoint stopped
-	if (printExp) {
-		printExpSteps = exp_print_points((unsigned long long)jend);
-		while (printExpCur < printExpSteps.size() && (long long)printExpSteps[printExpCur] + 1 <= j0) printExpCur++; // (--resume: points already behind us)
+	if (print_exp) {
+		exp_points = exp_print_points((unsigned long long)jend);
+		while (exp_next < exp_points.size() && (long long)exp_points[exp_next] + 1 <= j0) exp_next++; // (--resume: points already behind us)
 	}
 	if (ndev < 1) { fprintf(stderr, "error: need at least one device\n"); exit(EXIT_FAILURE); }
 
@@ -590,34 +590,60 @@ int main(int argc, char **argv) {
 	}
 	printf("\n");
 
-	const size_t lld = (X / 2) / SPIN_X_WORD;
-	const size_t llenLoc = (size_t)Y * lld;
-	const size_t llen = 2ull * ndev * llenLoc;
-	const int gridX = (int)((lld / 2 + 31) / 32), gridY = (Y + 15) / 16; // the reference's launch grid = RNG stream geometry
+	// optimized/main.cu:1508-1537: who reaches whose memory directly.  Slabs that --devmap puts on one device reach each other by definition; a missing link is the
+	// reference's error and exit -- its remote loads need every pair -- unless the rows travel by RCCL, which routes around it.
+	if (ndev > 1) {
+		printf("GPUs direct access matrix:\n       ");
+		for (int i = 0; i < ndev; i++) printf("%4d", i);
+		int missing_links = 0;
+		printf("\n");
+		for (int i = 0; i < ndev; i++) {
+			printf("GPU %2d:", i);
+			for (int k = 0; k < ndev; k++) {
+				int access = 1;
+				if (devmap[i] != devmap[k]) {
+					CHECK(ising_device_peer_access(devmap[i], devmap[k], &access));
+					if (!access) missing_links++;
+				}
+				printf("%4c", access ? 'V' : 'X');
+			}
+			printf("\n");
+		}
+		printf("\n");
+		if (missing_links && transport != ISING_TRANSPORT_RCCL) {
+			fprintf(stderr, "error: %d direct memory links among devices missing\n", missing_links);
+			exit(EXIT_FAILURE);
+		}
+	}
+
+	const size_t row_words = (X / 2) / SPIN_X_WORD;
+	const size_t slab_words = (size_t)Y * row_words;
+	const size_t total_words = 2ull * ndev * slab_words;
+	const int gridX = (int)((row_words / 2 + 31) / 32), gridY = (Y + 15) / 16; // the reference's launch grid = RNG stream geometry
 
 	printf("Run configuration:\n");
 	printf("\tspin/word: %d\n", SPIN_X_WORD);
-	printf("\tspins: %zu\n", llen * SPIN_X_WORD);
+	printf("\tspins: %zu\n", total_words * SPIN_X_WORD);
 	printf("\tseed: %llu\n", seed);
 	printf("\titerations: %d\n", nsteps);
 	printf("\tblock (X, Y): %d, %d\n", 16, 16);
 	printf("\ttile  (X, Y): %d, %d\n", 32, 16);
 	printf("\tgrid  (X, Y): %d, %d\n", gridX, gridY);
-	if (printFreq) printf("\tprint magn. every %d steps\n", printFreq);
-	else if (printExp) printf("\tprint magn. following exponential series\n");
+	if (print_every) printf("\tprint magn. every %d steps\n", print_every);
+	else if (print_exp) printf("\tprint magn. following exponential series\n");
 	else printf("\tprint magn. at 1st and last step\n");
-	if ((printFreq || printExp) && tgtMagn != -1.0) printf("\tearly exit if magn. == %lf+-%lf\n", tgtMagn, TGT_MAGN_MAX_DIFF);
+	if ((print_every || print_exp) && target_magn != -1.0) printf("\tearly exit if magn. == %lf+-%lf\n", target_magn, TGT_MAGN_MAX_DIFF);
 	printf("\ttemp: %f (%f*T_crit)\n", temp, temp / ISING_CRIT_TEMP);
-	if (!tempUpdFreq) printf("\ttemp update not set\n");
-	else printf("\ttemp update: %f / %d iterations\n", tempUpdStep, tempUpdFreq);
-	if (useGenHamilt) { // exactly one of the two lines, optimized/main.cu:1577-1581
-		printf("\tusing Hamiltonian buffer, setting links to -1 with prob %G\n", hamiltPerc1);
+	if (!ramp_every) printf("\ttemp update not set\n");
+	else printf("\ttemp update: %f / %d iterations\n", ramp_step, ramp_every);
+	if (with_couplings) { // exactly one of the two lines, optimized/main.cu:1577-1581
+		printf("\tusing Hamiltonian buffer, setting links to -1 with prob %G\n", antiferro_prob);
 		if (ts.J_symmetric) printf("\tsymmetric bonds: each colour's update reads its own sites' links (not the reference's pairing)\n");
 	} else {
 		printf("\tnot using Hamiltonian buffer\n");
 	}
 	printf("\n");
-	if (useSubLatt) { // optimized/main.cu:1583-1588
+	if (with_sublattices) { // optimized/main.cu:1583-1588
 		printf("\tusing sub-lattices:\n");
 		printf("\t\tno. of sub-lattices per GPU: %8d\n", NSLX * NSLY);
 		printf("\t\tno. of sub-lattices (total): %8d\n", ndev * NSLX * NSLY);
@@ -625,9 +651,9 @@ int main(int argc, char **argv) {
 	}
 	printf("\tlocal lattice size:      %8d x %8d\n", Y, X);
 	printf("\ttotal lattice size:      %8d x %8d\n", ndev * Y, X);
-	printf("\tlocal lattice shape: 2 x %8d x %8zu (%12zu %s)\n", Y, lld, llenLoc * 2, "ulls");
-	printf("\ttotal lattice shape: 2 x %8d x %8zu (%12zu %s)\n", ndev * Y, lld, llen, "ulls");
-	printf("\tmemory: %.2lf MB (%.2lf MB per GPU)\n", (llen * 8) / (1024.0 * 1024.0), llenLoc * 2 * 8 / (1024.0 * 1024.0));
+	printf("\tlocal lattice shape: 2 x %8d x %8zu (%12zu %s)\n", Y, row_words, slab_words * 2, "ulls");
+	printf("\ttotal lattice shape: 2 x %8d x %8zu (%12zu %s)\n", ndev * Y, row_words, total_words, "ulls");
+	printf("\tmemory: %.2lf MB (%.2lf MB per GPU)\n", (total_words * 8) / (1024.0 * 1024.0), slab_words * 2 * 8 / (1024.0 * 1024.0));
 
 	Ring ring;
 	ising_config cfg0; // (slab 0's configuration: --tsweep creates its replicas from it)
@@ -641,8 +667,8 @@ int main(int argc, char **argv) {
 		// --tsweep with two lattices of ~2^26 spins side by side: two-row strips (3 workgroups per CU each: both fit the
 		// chip) instead of the one-row strips a lone lattice of that size gets (4 per CU) -- 1.60 s against 1.65 s for config 5
 		if (doTsweep && ndev == 1 && !ts.anneal && ts.replicas != 1 && (long long)X * Y >= (1LL << 26) && (long long)X * Y < 3 * (1LL << 25) && (Y % 2) == 0) cfg.strip_rows = 2;
-		cfg.XSL = useSubLatt ? XSL : 0; cfg.YSL = useSubLatt ? YSL : 0;
-		cfg.use_J = useGenHamilt; cfg.J_prob = hamiltPerc1;
+		cfg.XSL = with_sublattices ? XSL : 0; cfg.YSL = with_sublattices ? YSL : 0;
+		cfg.use_J = with_couplings; cfg.J_prob = antiferro_prob;
 		ising_ctx *c = nullptr;
 		CHECK(ising_create(&cfg, &c));
 		ring.ctx.push_back(c);
@@ -650,15 +676,15 @@ int main(int argc, char **argv) {
 		if (ndev > 1) { printf("\tGPU %2d done\n", i); fflush(stdout); }
 	}
 
-	if (corrOut) { // optimized/main.cu:1660-1663
-		if (useSubLatt && YSL < MAX_CORR_LEN) { fprintf(stderr, "-c needs sub-lattices of at least %d rows\n", MAX_CORR_LEN); exit(EXIT_FAILURE); }
+	if (corr_out) { // optimized/main.cu:1660-1663
+		if (with_sublattices && YSL < MAX_CORR_LEN) { fprintf(stderr, "-c needs sub-lattices of at least %d rows\n", MAX_CORR_LEN); exit(EXIT_FAILURE); }
 		snprintf(cname, sizeof(cname), "corr_%dx%d_T_%f_%llu", Y, X, temp, seed);
 		remove(cname);
 	}
 	if (transport != ISING_TRANSPORT_AUTO) CHECK(ising_ring_set_transport(ring.ctx.data(), ndev, transport));
-	const size_t nspins = llen * SPIN_X_WORD;
+	const size_t nspins = total_words * SPIN_X_WORD;
 	if (doTsweep) {
-		run_tsweep(ring, cfg0, ts, nspins, useGenHamilt);
+		run_tsweep(ring, cfg0, ts, nspins, with_couplings);
 		for (ising_ctx *c : ring.ctx) ising_destroy(c);
 		return 0;
 	}
@@ -671,29 +697,29 @@ int main(int argc, char **argv) {
 	}
 	CHECK(ising_ring_exchange(ring.ctx.data(), ndev, ISING_BLACK));
 	CHECK(ising_ring_exchange(ring.ctx.data(), ndev, ISING_WHITE));
-	if (useGenHamilt) CHECK(ising_ring_init_couplings(ring.ctx.data(), ndev)); // optimized/main.cu:1729-1742
+	if (with_couplings) CHECK(ising_ring_init_couplings(ring.ctx.data(), ndev)); // optimized/main.cu:1729-1742
 	// --J-symmetric: every colour's update reads its own sites' bonds (J_ij = J_ji) instead of the array the reference hands it
-	if (useGenHamilt && ts.J_symmetric) for (ising_ctx *c : ring.ctx) CHECK(ising_swap_couplings(c));
+	if (with_couplings && ts.J_symmetric) for (ising_ctx *c : ring.ctx) CHECK(ising_swap_couplings(c));
 	if (ndev > 1) {
 		int tr = 0;
 		CHECK(ising_ring_transport(ring.ctx.data(), ndev, &tr));
 		fprintf(stderr, "halo rows travel by %s on a second stream per GPU\n", tr == ISING_TRANSPORT_RCCL ? "RCCL send/recv" : "peer-to-peer copies");
 	}
 
-	unsigned long long cntPos = 0, cntNeg = 0;
-	ring.count(&cntPos, &cntNeg);
+	unsigned long long n_up = 0, n_down = 0;
+	ring.count(&n_up, &n_down);
 	printf("\nInitial magnetization: %9.6lf, up_s: %12llu, dw_s: %12llu\n",
-	       fabs((double)cntPos - (double)cntNeg) / (double)nspins, cntPos, cntNeg);
-	if (printEnergy) printf("Initial energy/spin:   %9.6lf\n", ring.energy(nspins));
+	       fabs((double)n_up - (double)n_down) / (double)nspins, n_up, n_down);
+	if (print_energy) printf("Initial energy/spin:   %9.6lf\n", ring.energy(nspins));
 	CHECK(ising_ring_synchronize(ring.ctx.data(), ndev));
 
 	auto report = [&](int iter, bool exp_style) -> bool {
-		ring.count(&cntPos, &cntNeg);
-		const double magn = fabs((double)cntPos - (double)cntNeg) / (double)nspins;
-		if (exp_style) printf("        magnetization: %9.6lf (^2: %9.6lf), up_s: %12llu, dw_s: %12llu (iter: %8d)\n", magn, magn * magn, cntPos, cntNeg, iter);
-		else printf("        magnetization: %9.6lf, up_s: %12llu, dw_s: %12llu (iter: %8d)\n", magn, cntPos, cntNeg, iter);
-		if (printEnergy) printf("        energy/spin:   %9.6lf (iter: %8d)\n", ring.energy(nspins), iter);
-		if (corrOut) { // computeCorr, optimized/main.cu:1072-1138
+		ring.count(&n_up, &n_down);
+		const double magn = fabs((double)n_up - (double)n_down) / (double)nspins;
+		if (exp_style) printf("        magnetization: %9.6lf (^2: %9.6lf), up_s: %12llu, dw_s: %12llu (iter: %8d)\n", magn, magn * magn, n_up, n_down, iter);
+		else printf("        magnetization: %9.6lf, up_s: %12llu, dw_s: %12llu (iter: %8d)\n", magn, n_up, n_down, iter);
+		if (print_energy) printf("        energy/spin:   %9.6lf (iter: %8d)\n", ring.energy(nspins), iter);
+		if (corr_out) { // computeCorr, optimized/main.cu:1072-1138
 			int64_t sums[MAX_CORR_LEN];
 			CHECK(ising_ring_correlations(ring.ctx.data(), ndev, MAX_CORR_LEN, sums));
 			FILE *fp = fopen(cname, "a");
@@ -703,12 +729,12 @@ int main(int argc, char **argv) {
 			fprintf(fp, "\n");
 			fclose(fp);
 		}
-		if (dumpOut) {
+		if (dump_out) {
 			char fname[256];
 			snprintf(fname, sizeof(fname), "lattice_%dx%d_T_%f_IT_%08d_", Y, X, temp, iter);
 			ring.dump(fname);
 		}
-		return tgtMagn != -1.0 && fabs(magn - tgtMagn) < TGT_MAGN_MAX_DIFF;
+		return target_magn != -1.0 && fabs(magn - target_magn) < TGT_MAGN_MAX_DIFF;
 	};
 
 	// hot loop, optimized/main.cu:1756-1871.  Sweeps between two host-side events (print, ramp) are enqueued as
@@ -721,28 +747,28 @@ int main(int argc, char **argv) {
 	// appear in bursts of up to 64.  --energy rides along (round 5: the launches' white levels count equal bonds, north_star's energy series).
 	// Anything else a print point may do (-m early exit, -c, -o, the exponential series) keeps the reference's order of events below.
 	// (several devices: ising_ring_sweep_counted -- every slab's deep launches count their own rows)
-	const bool counted = printFreq > 0 && !printExp && tgtMagn == -1.0 && !corrOut && !dumpOut;
+	const bool counted = print_every > 0 && !print_exp && target_magn == -1.0 && !corr_out && !dump_out;
 	// (a burst is 64 print points on lattices of 2^26 spins and more, up to 4096 on smaller ones: a call costs a read-back and, on the small lattices' paths, a
 	// conversion of the spins at either end -- 2048^2 at -p 16: 1473 flips/ns in bursts of 64, against 1788 without print points)
 	const long long burst = 64 * std::max<long long>(1, std::min<long long>(64, (1LL << 26) / std::max<long long>(1, (long long)nspins)));
 	std::vector<uint64_t> ups_v((size_t)burst + 16);
 	std::vector<int64_t> eqs_v((size_t)burst + 16);
 	while (counted && j < jend) {
-		long long next = std::min<long long>(jend, (long long)(j / printFreq + burst) * printFreq);
-		if (tempUpdFreq) next = std::min<long long>(next, (long long)(j / tempUpdFreq + 1) * tempUpdFreq);
+		long long next = std::min<long long>(jend, (long long)(j / print_every + burst) * print_every);
+		if (ramp_every) next = std::min<long long>(next, (long long)(j / ramp_every + 1) * ramp_every);
 		uint64_t *ups = ups_v.data();
 		int64_t *eqs = eqs_v.data();
 		int k = 0;
-		CHECK(ising_ring_sweep_counted(ring.ctx.data(), ndev, j + 1, (int)(next - j), printFreq, ups, printEnergy ? eqs : nullptr, (int)burst + 16, &k));
-		for (int i = 0, it = (j / printFreq + 1) * printFreq; i < k; i++, it += printFreq) {
-			cntPos = ups[i];
-			cntNeg = nspins - ups[i];
-			printf("        magnetization: %9.6lf, up_s: %12llu, dw_s: %12llu (iter: %8d)\n", fabs((double)cntPos - (double)cntNeg) / (double)nspins, cntPos, cntNeg, it);
-			if (printEnergy) printf("        energy/spin:   %9.6lf (iter: %8d)\n", -(2.0 * (double)eqs[i] - 2.0 * (double)nspins) / (double)nspins, it);
+		CHECK(ising_ring_sweep_counted(ring.ctx.data(), ndev, j + 1, (int)(next - j), print_every, ups, print_energy ? eqs : nullptr, (int)burst + 16, &k));
+		for (int i = 0, it = (j / print_every + 1) * print_every; i < k; i++, it += print_every) {
+			n_up = ups[i];
+			n_down = nspins - ups[i];
+			printf("        magnetization: %9.6lf, up_s: %12llu, dw_s: %12llu (iter: %8d)\n", fabs((double)n_up - (double)n_down) / (double)nspins, n_up, n_down, it);
+			if (print_energy) printf("        energy/spin:   %9.6lf (iter: %8d)\n", -(2.0 * (double)eqs[i] - 2.0 * (double)nspins) / (double)nspins, it);
 		}
 		j = (int)next;
-		if (tempUpdFreq && (j % tempUpdFreq) == 0) { // optimized/main.cu:1848-1860
-			temp = std::max(MIN_TEMP, temp + tempUpdStep);
+		if (ramp_every && (j % ramp_every) == 0) { // optimized/main.cu:1848-1860
+			temp = std::max(MIN_TEMP, temp + ramp_step);
 			printf("Changing temperature to %f\n", temp);
 			for (int d = 0; d < ndev; d++) CHECK(ising_set_temperature(ring.ctx[d], temp));
 			float tab[10];
@@ -753,21 +779,21 @@ int main(int argc, char **argv) {
 	}
 	while (j < jend) {
 		int next = jend; // first iteration index (1-based count) at which the host must look at the lattice
-		if (printFreq) next = std::min(next, (j / printFreq + 1) * printFreq);
-		if (printExp && printExpCur < printExpSteps.size()) next = (int)std::min<long long>(next, (long long)printExpSteps[printExpCur] + 1);
-		if (tempUpdFreq) next = std::min(next, (j / tempUpdFreq + 1) * tempUpdFreq);
+		if (print_every) next = std::min(next, (j / print_every + 1) * print_every);
+		if (print_exp && exp_next < exp_points.size()) next = (int)std::min<long long>(next, (long long)exp_points[exp_next] + 1);
+		if (ramp_every) next = std::min(next, (j / ramp_every + 1) * ramp_every);
 		if (next <= j) next = j + 1;
 		CHECK(ising_ring_sweep(ring.ctx.data(), ndev, j + 1, next - j));
 		j = next;
 		bool stop = false;
-		if (printFreq && (j % printFreq) == 0) stop = report(j, false);
-		if (!stop && printExp && printExpCur < printExpSteps.size() && printExpSteps[printExpCur] == (unsigned long long)(j - 1)) {
-			printExpCur++;
+		if (print_every && (j % print_every) == 0) stop = report(j, false);
+		if (!stop && print_exp && exp_next < exp_points.size() && exp_points[exp_next] == (unsigned long long)(j - 1)) {
+			exp_next++;
 			stop = report(j, true);
 		}
 		if (stop) break;
-		if (tempUpdFreq && (j % tempUpdFreq) == 0) { // optimized/main.cu:1848-1860
-			temp = std::max(MIN_TEMP, temp + tempUpdStep);
+		if (ramp_every && (j % ramp_every) == 0) { // optimized/main.cu:1848-1860
+			temp = std::max(MIN_TEMP, temp + ramp_step);
 			printf("Changing temperature to %f\n", temp);
 			for (ising_ctx *c : ring.ctx) CHECK(ising_set_temperature(c, temp));
 			float tab[10];
@@ -779,18 +805,18 @@ int main(int argc, char **argv) {
 	CHECK(ising_ring_synchronize(ring.ctx.data(), ndev));
 	const double et = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
-	ring.count(&cntPos, &cntNeg);
+	ring.count(&n_up, &n_down);
 	printf("Final   magnetization: %9.6lf, up_s: %12llu, dw_s: %12llu (iter: %8d)\n\n",
-	       fabs((double)cntPos - (double)cntNeg) / (double)nspins, cntPos, cntNeg, j);
-	if (printEnergy) printf("Final   energy/spin:   %9.6lf\n\n", ring.energy(nspins));
+	       fabs((double)n_up - (double)n_down) / (double)nspins, n_up, n_down, j);
+	if (print_energy) printf("Final   energy/spin:   %9.6lf\n\n", ring.energy(nspins));
 
 	// optimized/main.cu:1884-1890 (1.5 bytes per flip + the 20-byte table per reference block)
 	const int jrun = j - j0;
 	printf("Kernel execution time for %d update steps: %E ms, %.2lf flips/ns (BW: %.2lf GB/s)\n", jrun, et,
 	       (double)nspins * jrun / (et * 1.0E+6),
-	       (2ull * jrun * (8.0 * ((llen / 2) + (llen / 2) + (llen / 2)) + 4.0 * 5 * gridX * gridY) / 1.0E+9) / (et / 1.0E+3));
+	       (2ull * jrun * (8.0 * ((total_words / 2) + (total_words / 2) + (total_words / 2)) + 4.0 * 5 * gridX * gridY) / 1.0E+9) / (et / 1.0E+3));
 
-	if (dumpOut) {
+	if (dump_out) {
 		char fname[256];
 		snprintf(fname, sizeof(fname), "lattice_%dx%d_T_%f_IT_%08d_", Y, X, temp, j);
 		ring.dump(fname);

@@ -93,6 +93,9 @@ int check_abort(ising_ctx *c) {
 	c->edge_done_target = c->edge_go_epoch = 0;
 	c->go_set = false;
 	c->ghost_depth[0] = c->ghost_depth[1] = 0;
+	// A split launch whose word units never got their masks: a ticket class that no resident workgroup serves (a device or partition that does not run
+	// workgroups on all eight XCC ids, a CU mask) -- the plain fused form carries this slab's sweeps from here on.
+	if (c->last_launch_split) { c->split = c->split_always = false; c->last_launch_split = false; }
 	__atomic_store_n(c->h_abort, 0u, __ATOMIC_RELEASE);
 	return fail(ISING_E_STATE, "a fused launch gave up: its units' parents never completed (completion counters out of step with the device after a faulted "
 	                           "launch?); tickets and counters have been reset, the lattice is undefined -- initialise or load it again");
@@ -104,6 +107,56 @@ int sync_checked(ising_ctx *c) {
 }
 
 } // namespace ising_host
+
+
+// every switch the library and its Python mirror take from the environment -- one table, printed by ising_switch_table, kept as docs/SWITCHES.md, and held
+// against the sources by tests/test_switches.py (a getenv the table does not know fails the suite).
+namespace {
+struct SwitchDoc { const char *name, *values, *meaning; };
+const SwitchDoc kSwitches[] = {
+	{"ISING_FUSED", "0/1", "`ising_sweep` on the ballot layout: one launch per colour / fused launches (default: fused from 1.5*2^24 spins, and below where a level of one-row units feeds two workgroups per CU)"},
+	{"ISING_FUSED_WGS", "n", "size of a fused launch's persistent grid, in workgroups (default: by tickets per level, strip height and wave columns: `fused_wgs_for`)"},
+	{"ISING_FUSED_TICKETS2", "0/2/4", "fused launches draw from that many ticket counters (default: four for one-row units, two for two-row units, one above)"},
+	{"ISING_FUSED_NT", "0/1", "lattice words of fused launches with the non-temporal hint (default: lattices above 2^31 spins)"},
+	{"ISING_FUSED_WAIT_LATE", "0/1/2", "units of fused launches draw that many rows before they wait for their parents (default 2)"},
+	{"ISING_FUSED_MAX_SWEEPS", "n", "sweeps one fused launch of a single slab or a batch carries at most (default: ~50 ms worth, 32 .. 4096)"},
+	{"ISING_SPLIT", "0/1", "fused launches in the split form (draw units / word units, `ballot_split_k`): never / every launch of several levels wherever the form applies (default: lone slabs whose sixteen-row strips make under 2048 tickets a level, on calls of 2^35 flips and more; eight XCC ids required either way)"},
+	{"ISING_SPLIT_LEAD", "0..4", "draw units a workgroup of a split launch does before its first word unit (default 1)"},
+	{"ISING_QUAD", "0/1", "lone lattices of one to eight blocks of 2048 columns on the quad path (`quad_pass_k`): never / wherever it applies (default: the rule by width and rows in `ising_create`, on a whole MI355X)"},
+	{"ISING_QUAD_C", "n", "quad path: row groups (4 rows each) per tile (default: the shape table in `ising_create`)"},
+	{"ISING_QUAD_T", "n", "quad path: sweeps per pass, 1 .. 32 (default: the shape table)"},
+	{"ISING_QUAD_WAVES", "n", "quad path: waves per workgroup, 1 .. 16 (default: the shape table)"},
+	{"ISING_TILES", "0/1", "lone slabs on the dense layout sweep in tile launches (`dense_tile_k`): never / always (default: up to 2^24 spins where the quad path does not apply)"},
+	{"ISING_TILE_ROWS", "n", "tile launches: rows per tile (default: the shape rule of `ising_create`)"},
+	{"ISING_TILE_WORDS", "n", "tile launches: 32-bit words per tile row"},
+	{"ISING_TILE_SWEEPS", "n", "tile launches: sweeps per launch (default 3 / 4 / 6 by tile rows)"},
+	{"ISING_TILE_THREADS", "256/512/1024", "tile launches: workgroup size"},
+	{"ISING_TILE_XCD", "0/1", "tile launches: tiles in bands per XCD (default on where the tiles divide by eight)"},
+	{"ISING_TAIL", "rows[,h]", "one-row tail strips of the one-launch-per-colour form (`0`: off; default: two thirds of a strip per workgroup slot)"},
+	{"ISING_NO_BALLOT", "(set)", "layout AUTO never picks the ballot layout"},
+	{"ISING_RING_GHOST", "n", "ghost rows of ballot ring slabs (default 64; `1`: one halo row and the per-colour schedules)"},
+	{"ISING_RING_COUNTED", "0/1/2", "print points of rings never / where possible (default) / always (an error where not) inside the deep launches"},
+	{"ISING_RING_OVERLAP", "0/1/2", "the deep exchange between two launches / in the tail of the running launch, the next one waits for it on the stream (default) / free-running, only the next launch's edge units wait (copies and IPC only)"},
+	{"ISING_RING_TRAPEZOID", "0/1", "0: every ghost row at every level (default 1: a level touches only the ghost rows that can still reach the slab)"},
+	{"ISING_RING_TRANSPORT", "auto/copy/rccl", "a single-process ring's transport"},
+	{"ISING_RCCL_LIB", "path", "the librccl to open (process-wide, read when RCCL is first needed)"},
+	{"ISING_RING_STORE", "0/1", "slabs sharing one device: never / always store edge rows straight into the neighbours' halo rows (default: only slabs without ghost rows do)"},
+	{"ISING_RING_INLINE", "0/1", "peer copies on the comm streams / on the compute stream (default: by device placement)"},
+	{"ISING_RING_COMM_PRIORITY", "0/1", "0: comm streams at default priority (default 1: high priority)"},
+	{"ISING_ABORT_POLLS", "n", "polls after which a unit of a fused launch gives its parents up (default 2^22, ~10 s)"},
+	{"ISING_LIB", "path", "(Python mirror) another build of libising_hip.so, for measurement builds"},
+	{"ISING_HIP_RUNTIME", "auto/system", "(Python mirror) `system`: do not preload torch's HIP runtime before the library"},
+	{"ISING_RING_EXCHANGE", "p2p/allgather", "(Python mirror, torch.distributed ring) how the edge rows travel"},
+};
+} // namespace
+
+extern "C" int ising_switch_table(char *buf, size_t len, size_t *needed) {
+	std::string out = "| Variable | Values | Meaning |\n|---|---|---|\n";
+	for (const SwitchDoc &d : kSwitches) out += std::string("| `") + d.name + "` | " + d.values + " | " + d.meaning + " |\n";
+	if (needed) *needed = out.size() + 1;
+	if (buf && len) { const size_t n = std::min(len - 1, out.size()); memcpy(buf, out.data(), n); buf[n] = 0; }
+	return (buf && len > out.size()) || !buf ? ISING_OK : ising_host::fail(ISING_E_ARG, "ising_switch_table: %zu bytes needed", out.size() + 1);
+}
 
 using ising_host::bind;
 using ising_host::fail;
@@ -304,6 +357,17 @@ int ising_device_info(int device, char *name, size_t name_len, int *cus, int *ma
 	return ISING_OK;
 }
 
+int ising_device_peer_access(int device, int peer, int *can_access) {
+	if (!can_access) return fail(ISING_E_ARG, "can_access is null");
+	*can_access = 0;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(ISING_E_NOGPU, "no HIP device visible");
+	if (device < 0 || device >= ndev || peer < 0 || peer >= ndev) return fail(ISING_E_ARG, "devices %d, %d out of range (%d visible)", device, peer, ndev);
+	if (device == peer) { *can_access = 1; return ISING_OK; }
+	HIP_TRY(hipDeviceCanAccessPeer(can_access, device, peer));
+	return ISING_OK;
+}
+
 // the clock a kernel ran at from the marks its first workgroups left: {cycles, 100 MHz ticks} x {start, end} per XCD
 static void clock_from_marks(const unsigned long long *m, int n, double *mean, double *lo, double *hi) {
 	double sum = 0, mn = 0, mx = 0;
@@ -438,6 +502,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	c->cfg = *cfg;
 	if (int rc = ising_host::read_policy(&c->pol)) { delete c; return rc; }
 	if (hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || c->cus < 1) { (void)hipGetLastError(); c->cus = 256; }
+	if (hipDeviceGetAttribute(&c->xccs, hipDeviceAttributeNumberOfXccs, cfg->device) != hipSuccess || c->xccs < 1) { (void)hipGetLastError(); c->xccs = c->cus >= 200 ? 8 : 1; }
 	const ising_policy &pol = c->pol;
 	if (cfg->layout != ISING_LAYOUT_AUTO && cfg->layout != ISING_LAYOUT_NIBBLE && cfg->layout != ISING_LAYOUT_DENSE && cfg->layout != ISING_LAYOUT_BALLOT) {
 		delete c;
@@ -565,7 +630,8 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 	// measured), five workgroups per CU (six: +0..1 % on one box, -3..4 % on another).  tests/test_gpu_policy.py holds the choice against its neighbours and the other form.
 	{
 		const bool nt = pol.fused_nt >= 0 ? pol.fused_nt != 0 : spins > (1LL << 31);
-		const bool can = ((fused_shape && c->wrap) || deep_ring) && !cfg->XSL && !cfg->use_J && !nt && pol.split != 0 && c->nwc() < 128;
+		// (eight ticket classes, one per XCC id: a device or partition that reports another number of dies runs the plain fused form, ISING_SPLIT=1 or not)
+		const bool can = ((fused_shape && c->wrap) || deep_ring) && !cfg->XSL && !cfg->use_J && !nt && pol.split != 0 && c->nwc() < 128 && c->xccs == 8;
 		const int Yd = cfg->Y; // strips divide the slab's own rows
 		if (can && pol.split == 1) {
 			c->split = c->split_always = fused_tickets(c->nwc(), launch_rows, c->H) >= 8;

@@ -49,6 +49,8 @@ struct ising_ctx {
 	ising_config cfg{};
 	ising_policy pol{};
 	int cus = 256;                 // compute units of the slab's device
+	int xccs = 8;                  // ... and its accelerator dies (XCDs): the split form's ticket classes are theirs
+	bool last_launch_split = false; // the form of the last fused launch (a split launch that gives up takes the form out of service: check_abort)
 	uint32_t *h_abort = nullptr;   // pinned, device-visible: [0] != 0 = a fused launch gave up (or the host wants the polling kernels to);
 	                               // checked after every synchronise (ising_host::sync_checked)
 	bool dense = false; // 1 bit per spin on the device (ising_dense.hip); false = the reference's nibble layout

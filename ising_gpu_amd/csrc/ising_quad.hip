@@ -27,6 +27,7 @@
 // two mask buffers.  DESIGN 4.3; what was measured and dropped on the way: LAB_NOTES 12.
 #include "ising_device.hpp"
 #include <algorithm>
+#include <mutex>
 #include <cstdio>
 
 namespace ising {
@@ -470,11 +471,19 @@ int quad_word_maxi(const QuadWordParams &p, int waves) {
 
 template <int MAXI>
 static hipError_t launch_pass_t(const QuadPassParams &p, int waves, long long grid, size_t lds, hipStream_t stream) {
-	static size_t allowed = 0; // (per instantiation; contexts of one process share a device class)
-	if (lds > 64 * 1024 && lds > allowed) {
-		const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&quad_pass_k<MAXI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		if (e != hipSuccess) return e;
-		allowed = lds;
+	// tiles past 64 KiB: the limit is raised per device (hipFuncSetAttribute applies to the current one) and remembered per device, under a lock -- contexts on
+	// several GPUs, driven by several host threads, share this function
+	if (lds > 64 * 1024) {
+		static std::mutex mu;
+		static size_t allowed[64] = {};
+		int dev = 0;
+		if (const hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+		std::lock_guard<std::mutex> lock(mu);
+		if (dev < 0 || dev >= 64 || lds > allowed[dev]) {
+			const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&quad_pass_k<MAXI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			if (e != hipSuccess) return e;
+			if (dev >= 0 && dev < 64) allowed[dev] = lds;
+		}
 	}
 	hipLaunchKernelGGL(quad_pass_k<MAXI>, dim3((unsigned)grid), dim3((unsigned)waves * 64), lds, stream, p);
 	return hipGetLastError();
@@ -485,7 +494,9 @@ hipError_t launch_quad_pass(QuadPassParams &p, int waves, hipStream_t stream) {
 	const int mi0 = quad_word_maxi(p.w, waves);
 	p.ntiles = p.w.nlev > 0 ? (p.w.NRG + p.w.C - 1) / p.w.C : 0;
 	// workgroup slots of the chip: eight waves per SIMD at one item a wave, six at two (80 registers), three beyond
-	const int per_cu = std::max(1, ((mi0 <= 1 ? 8 : (mi0 <= 2 ? 6 : (mi0 == 3 ? 4 : 3))) * 4) / waves); // (one item a wave: under 64 registers; three: 128)
+	// (the drawing workgroups of the grid reserve the tiles' LDS segment as well -- one launch, one size --: what a CU's 160 KiB hold bounds them too)
+	const int per_cu_regs = std::max(1, ((mi0 <= 1 ? 8 : (mi0 <= 2 ? 6 : (mi0 == 3 ? 4 : 3))) * 4) / waves); // (one item a wave: under 64 registers; three: 128)
+	const int per_cu = std::max(1, std::min<int>(per_cu_regs, (int)((160 * 1024) / std::max<size_t>(quad_pass_lds_bytes(p.w, waves), 1))));
 	const int cap = std::max(4, p.cus * per_cu) & ~3;
 	long long draw_wgs = 0;
 	if (p.d.nlev > 0) {

@@ -164,6 +164,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 			return fail(ISING_E_HIP, "kernel launch failed: %s", hipGetErrorString(le));
 		}
 		if (nlevels > 1) {
+			c->last_launch_split = split;
 			(split ? c->split_done_base : c->done_base) += (uint32_t)nlevels * (uint32_t)c->nwc();
 			// where the launch leaves the counter(s): its units, and every workgroup drew one ticket too many
 			const unsigned long long total = (unsigned long long)p.nwg * (unsigned long long)nlevels;
@@ -554,6 +555,18 @@ int ising_sweep_info(ising_ctx *c, int *fused, int *max_sweeps_per_launch) {
 	const bool tiled = !f && !deep && !quad && sweeps_tiled(c, 2);
 	if (fused) *fused = ((f || deep) && c->split && !c->cfg.XSL) ? 3 : ((f || deep) ? 1 : (quad ? 4 : (tiled ? 2 : 0)));
 	if (max_sweeps_per_launch) *max_sweeps_per_launch = f ? ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y) : (deep ? c->ghost() / 2 : (quad ? c->quad_T : (tiled ? c->tile_sweeps : 0)));
+	return ISING_OK;
+}
+
+int ising_sweep_form(ising_ctx *c, int nsweeps, int *form, int *strip_rows, int *wg_per_cu) {
+	if (!c) return fail(ISING_E_ARG, "null context");
+	int f = 0;
+	if (int rc = ising_sweep_info(c, &f, nullptr)) return rc;
+	const bool fused_any = f == 1 || f == 3;
+	const bool split = f == 3 && (ghost_sweeps(c) ? c->split_always : split_pays(c, nsweeps));
+	if (form) *form = f == 3 ? (split ? 3 : 1) : f;
+	if (strip_rows) *strip_rows = fused_any ? (split ? c->H_split : c->H) : 0;
+	if (wg_per_cu) *wg_per_cu = fused_any ? (split ? c->split_wg_per_cu : c->fused_wg_per_cu) : 0;
 	return ISING_OK;
 }
 

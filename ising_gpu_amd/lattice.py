@@ -182,10 +182,17 @@ class IsingSlab:
 
     @property
     def split(self) -> bool:
-        """True when sweep()'s fused launches take the split form (draw units and word units with tickets of their own, ising_sweep_info)."""
+        """True when sweep()'s LONG calls (2^35 flips and more; ISING_SPLIT=1: all) take the split form (draw units and word units with tickets of their own,
+        ising_sweep_info); sweep_form(n) answers for a call of n sweeps."""
         f, m = C.c_int(), C.c_int()
         check(self._lib.ising_sweep_info(self._h, C.byref(f), C.byref(m)))
         return f.value == 3
+
+    def sweep_form(self, nsweeps: int):
+        """(form, strip rows, workgroups per CU) of the launches sweep(nsweeps) issues (ising_sweep_form; form as ising_sweep_info, 3 only when THIS call runs split launches)."""
+        v = [C.c_int() for _ in range(3)]
+        check(self._lib.ising_sweep_form(self._h, nsweeps, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
 
     @property
     def tiled(self) -> bool:
@@ -197,8 +204,8 @@ class IsingSlab:
 
     @property
     def quad(self) -> bool:
-        """True when sweep() runs on the quad layout (small lattices: the draws of a batch of sweeps ahead of the lattice on a second stream,
-        word passes of several sweeps on tiles + halo; ising_quad.hip, ising_sweep_info)."""
+        """True when sweep() runs on the quad layout (small lattices: one launch per pass of several sweeps = the word pass on tiles + halo next to the
+        drawing workgroups that make the accept masks of the pass to come, one stream; ising_quad.hip, ising_sweep_info)."""
         f, m = C.c_int(), C.c_int()
         check(self._lib.ising_sweep_info(self._h, C.byref(f), C.byref(m)))
         return f.value == 4

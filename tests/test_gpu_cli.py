@@ -121,6 +121,12 @@ README_8GPU = [  # ./cuIsing -y 65536 -x 65536 -n 128 -p 16 -d 8 -t 1.5   (8 x A
 ]
 
 
+def peer_matrix_block(n):
+    """The "GPUs direct access matrix" block of an n-device run in which every pair is linked, as optimized/main.cu:1508-1531 prints it."""
+    return ("GPUs direct access matrix:\n       " + "".join(f"{i:4d}" for i in range(n)) + "\n"
+            + "".join(f"GPU {i:2d}:" + "   V" * n + "\n" for i in range(n)) + "\n")
+
+
 def test_readme_two_gpu_transcript_every_line_at_its_own_decomposition(gpu):
     """README.md:205-252 at the reference's own decomposition: 2 slabs of 65536 x 65536 (both on device 0; one MI355X holds
     the whole 131072 x 65536 lattice).  All nine magnetisation lines and the final one, character for character."""
@@ -130,6 +136,8 @@ def test_readme_two_gpu_transcript_every_line_at_its_own_decomposition(gpu):
                                "\ttotal lattice shape: 2 x   131072 x     2048 (   536870912 ulls)\n", "\tmemory: 4096.00 MB (2048.00 MB per GPU)\n",
                                "Setting up multi-gpu configuration:\n", "\tGPU  0 done\n", "\tGPU  1 done\n"]:
         assert line in out, line
+    # the block between "Using GPUs" and "Run configuration" (optimized/main.cu:1508-1537; README.md:213-216): slabs of one device reach each other
+    assert "ECC on)\n\n" + peer_matrix_block(2) + "Run configuration:\n" in out
 
 
 @pytest.mark.parametrize("ndev,lines", [(2, "README_2GPU"), (8, "README_8GPU")])
@@ -142,6 +150,7 @@ def test_readme_multi_gpu_transcripts_on_that_many_devices(gpu, ndev, lines):
     out = run(["-y", "65536", "-x", "65536", "-n", "128", "-p", "16", "-d", str(ndev), "-t", "1.5"])
     for line in globals()[lines] + [f"\tGPU {ndev - 1:2d} done\n"]:
         assert line in out, line
+    assert peer_matrix_block(ndev) + "Run configuration:\n" in out  # (a node whose devices all see each other, as the README's)
 
 
 def test_readme_two_gpu_transcript_as_one_slab(gpu):
@@ -159,6 +168,7 @@ def test_readme_eight_gpu_transcript_every_line_at_its_own_decomposition(gpu):
                                "\ttotal lattice shape: 2 x   524288 x     2048 (  2147483648 ulls)\n", "\tmemory: 16384.00 MB (2048.00 MB per GPU)\n",
                                "\tGPU  7 done\n"]:
         assert line in out, line
+    assert "ECC on)\n\n" + peer_matrix_block(8) + "Run configuration:\n" in out  # README.md:270-280
 
 
 def test_readme_eight_gpu_transcript_as_one_slab(gpu):
@@ -303,3 +313,9 @@ def test_cli_print_with_energy_rides_in_the_launches(gpu, oracle_mod, X, Y, layo
         m = abs(up - dw) / (X * Y)
         assert f"        magnetization: {m:9.6f}, up_s: {up:12d}, dw_s: {dw:12d} (iter: {it:8d})\n        energy/spin:   {orc.energy_per_spin():9.6f} (iter: {it:8d})\n" in out, it
     assert f"Final   energy/spin:   {orc.energy_per_spin():9.6f}\n" in out
+
+
+def test_single_device_run_prints_no_peer_matrix(gpu):
+    """optimized/main.cu:1496: the direct-access block belongs to runs on several devices only."""
+    out = run(["-x", "2048", "-y", "2048", "-n", "4"])
+    assert "GPUs direct access matrix" not in out and "ECC on)\n\nRun configuration:\n" in out
