@@ -75,7 +75,8 @@ def exchange_overlap(ring_name):
         return ("tail-serialised: RCCL's send/recv kernel (132 vector registers a lane) finds no room next to the persistent grid and runs when the launch's workgroups "
                 "retire; the next launch waits for it (ev_go).  Ring of one: +0.01..0.04 ms past the launch's end, a gap of 11-44 us per 32 sweeps (<= 0.9 %)")
     if ring_name.startswith("ipc"):
-        return "inside the launch: one-lane kernels and peer stores on the comm stream move the rows while the launch works on the slab's interior"
+        return ("inside the launch: one-lane kernels and peer stores on the comm stream move the rows while the launch works on the slab's interior; a device per rank: ONE "
+                "persistent launch carries several exchange epochs (ISING_RING_EPOCHS), its edge units wait for each exchange in place -- no launch boundary per exchange")
     if ring_name == "none":
         return None
     return "between launches (torch.distributed ring: the rows travel when the launch has ended)"
@@ -495,8 +496,10 @@ def main():
         if world > 1:
             per_rank = [None] * world
             dist.all_gather_object(per_rank, mine)
-        xstats = {"exchanges_per_rank": per_rank[0]["exchanges"],
-                  "what": "per exchange of 64 ghost rows of both colours (one per fused launch): launch = the fused launch; exchange = edge strips of "
+        xstats = {"exchanges_per_rank": per_rank[0]["exchanges"], "launches_per_rank": per_rank[0]["launches"],
+                  "what": "per exchange of 64 ghost rows of both colours (RCCL: one per fused launch; the peer (IPC) transport with a device per rank: several exchange "
+                          "epochs inside ONE persistent launch -- launches_per_rank < exchanges_per_rank --, the figures below then describe each launch's LAST exchange): "
+                          "launch = the fused launch; exchange = edge strips of "
                           "the launch done -> neighbours' rows in place; go_after_end = the exchange's end relative to the END of the launch whose rows "
                           "it carries (negative: hidden in the launch's tail; positive: the next launch waited that long -- a slow link or a "
                           "neighbour that is behind); gap = end of a launch -> start of the next.  ms; mean over ranks of the per-rank means, max over everything"}
@@ -609,6 +612,8 @@ def main():
         if fused and ringed:  # the library's ring on ghost rows: fused launches of up to max_sweeps_per_launch sweeps between exchanges
             per = max(1, slab.max_sweeps_per_launch)
             launches = (args.steps + per - 1) // per
+            if xstats is not None and 0 < xstats["launches_per_rank"] < launches:  # (several exchange epochs per persistent launch: the launches the library really issued)
+                launches = xstats["launches_per_rank"]
             half_sweeps_per_launch = 2.0 * args.steps / launches
         else:
             half_sweeps_per_launch = 2 * batch if fused else 1

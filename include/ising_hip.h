@@ -405,13 +405,17 @@ int ising_rank_bond_equal(ising_ctx *ctx, int64_t *A);
  *   go_after_end_ms  the exchange's end relative to the END of the launch whose rows it carries: negative = hidden in the launch's
  *                    tail, positive = the next launch had to wait that long (a slow link, or a neighbour that is behind);
  *   gap_ms           end of a launch to the start of the next (includes the positive part of go_after_end_ms).
- * Other schedules sample nothing (exchanges = 0).  Costs two events per exchange on the comm stream, nothing on the compute stream. */
+ * Other schedules sample nothing (exchanges = 0).  Costs two events per exchange on the comm stream, nothing on the compute stream.
+ * Round 6: over the peer (IPC) transport with a device per rank ONE persistent launch carries several exchange epochs (ISING_RING_EPOCHS; docs/SWITCHES.md), the
+ * exchanges running next to it: `launches` = sampled launches (max_exchanges bounds these), `exchanges` = the exchange epochs inside them; launch_ms is a whole
+ * launch, exchange_ms / go_after_end_ms / gap_ms describe each launch's LAST exchange -- the one the next launch waits for. */
 typedef struct ising_exchange_stats {
 	int32_t exchanges;
 	float launch_ms_mean, launch_ms_max;
 	float exchange_ms_mean, exchange_ms_max;
 	float go_after_end_ms_mean, go_after_end_ms_max;
 	float gap_ms_mean, gap_ms_max;
+	int32_t launches;
 } ising_exchange_stats;
 int ising_exchange_stats_begin(ising_ctx *ctx, int max_exchanges);
 int ising_exchange_stats_fetch(ising_ctx *ctx, ising_exchange_stats *out);

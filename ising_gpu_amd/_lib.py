@@ -38,7 +38,7 @@ class ExchangeStats(C.Structure):
     """ising_exchange_stats (include/ising_hip.h): where a ring slab's time goes around its exchanges, in milliseconds."""
     _fields_ = [("exchanges", C.c_int32)] + [(n, C.c_float) for n in (
         "launch_ms_mean", "launch_ms_max", "exchange_ms_mean", "exchange_ms_max",
-        "go_after_end_ms_mean", "go_after_end_ms_max", "gap_ms_mean", "gap_ms_max")]
+        "go_after_end_ms_mean", "go_after_end_ms_max", "gap_ms_mean", "gap_ms_max")] + [("launches", C.c_int32)]
 
 
 class IsingError(RuntimeError):

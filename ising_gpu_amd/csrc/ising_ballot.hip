@@ -373,7 +373,10 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		const int nrows0 = absent ? 0 : min(Hr, p.row_hi[rng] - r0);
 		// ring slab with ghost rows: at this level only rows within `keep` of the slab's own can still reach one of them; a strip
 		// wholly further out has nothing to do (it still waits for its parents and counts as complete: its counter is a count)
-		const int keep = uni(p.nlevels - 1 - level); // (pinned: the compiler takes the running level count for lane-dependent)
+		// (several exchange epochs per launch, UpdateParams.epoch_sh: the trapezoid starts over with every epoch)
+		const int elev = uni(FUSED && p.epoch_sh ? level & ((1 << p.epoch_sh) - 1) : level);   // the level within its epoch
+		const int elast = uni(FUSED && p.epoch_sh ? (1 << p.epoch_sh) - 1 : p.nlevels - 1);     // an epoch's last level
+		const int keep = uni(elast - elev); // (pinned: the compiler takes the running level count for lane-dependent)
 		const bool skip = FUSED && p.trapezoid != 0 && !absent && (r0 + nrows0 <= -keep || r0 >= p.Y + keep);
 		const bool idle = absent || skip;
 		const int nrows = skip ? 0 : nrows0;
@@ -487,6 +490,11 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 				if (lane < 3) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(seen) : "v"(dp) : "memory");
 			}
 			TRC(2); // completion counters (+ block constants)
+			// Several epochs in one launch: an epoch's second level is the last that reads words the exchange wrote (the white rows' own words; from there on
+			// every word a unit touches was stored by this launch).  Its units may run on an XCD none of the epoch's first edge units ran on, and with no launch
+			// boundary in between nothing has dropped what that XCD's L2 holds of those rows from the epoch before: the first level's acquire here as well --
+			// behind the wait for the parents, which waited for the exchange; the unit's rows are requested behind this point.
+			if (FUSED && p.epoch_sh && edge_unit && elev == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 		};
 		// Where the unit waits for its parents.  A draw phase needs nothing from the lattice -- counter words, seed, thresholds --, so a
 		// launch may ask its units to draw BEFORE they wait (UpdateParams.wait_late, round 4): 1 = behind the first row's draw phase,
@@ -497,14 +505,15 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 		const int late_mode = (FUSED && ISING_FUSED_WAIT_LATE) ? uni(p.wait_late) : 0;
 		const bool wait_late = late_mode != 0;
 		if (!wait_late) wait_parents();
-		if (edge_unit && level == 0) {
-			// the exchange that follows the previous launch has read this slab's first / last rows and filled its ghost rows
-			// once the comm stream has moved the counter (usually long ago: the exchange starts when the previous launch's
-			// edge strips finish their last level, a level before the launch ends)
-			uint32_t got = p.edge_go_need, ngo = 0;
+		if (edge_unit && elev == 0) {
+			// the exchange that follows the previous launch (the previous epoch of this one) has read this slab's first / last rows and filled
+			// its ghost rows once the comm stream has moved the counter (usually long ago: the exchange starts when the edge strips finish
+			// the last level of their epoch, a level before the launch ends or the next epoch begins)
+			const uint32_t go_need = uni(p.edge_go_need + (p.epoch_sh ? (uint32_t)level >> p.epoch_sh : 0u));
+			uint32_t got = go_need, ngo = 0;
 			for (;;) {
 				if (lane == 0) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(got) : "v"(p.edge_go) : "memory");
-				if (__all((int32_t)(got - p.edge_go_need) >= 0)) break;
+				if (__all((int32_t)(got - go_need) >= 0)) break;
 				// (no bound of its own -- a neighbour may be seconds behind --, but the host can call the launch off)
 				// (a neighbour may be seconds behind, so the bound is 16 times the one for a unit's parents -- but there is one:
 				// an exchange that never completes ends the launch with an error, not at the watchdog)
@@ -803,7 +812,7 @@ __global__ void __launch_bounds__(NT) BAL_SGPR_ATTR ballot_update_k(const Update
 			}
 			if (lane == 0) __hip_atomic_fetch_add(p.done + (BATCH ? rep * p.done_stride : 0) + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			// last level: the rows the next exchange sends are final and the ghost rows no longer read
-			if (edge_unit && level == p.nlevels - 1 && lane == 0) __hip_atomic_fetch_add(p.edge_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (edge_unit && (elev == elast || level == p.nlevels - 1) && lane == 0) __hip_atomic_fetch_add(p.edge_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
 	clock_mark(1);

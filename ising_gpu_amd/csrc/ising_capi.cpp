@@ -48,6 +48,7 @@ int read_policy(ising_policy *pol) {
 	if (num("ISING_SPLIT", &v)) pol->split = v != 0;
 	if (num("ISING_SPLIT_LEAD", &v)) pol->split_lead = v < 0 ? 0 : (v > 4 ? 4 : v);
 	if (num("ISING_RING_GHOST", &v)) pol->ring_ghost = v;
+	if (num("ISING_RING_EPOCHS", &v)) pol->ring_epochs = v < 0 ? 0 : (v > 1024 ? 1024 : v);
 	if (num("ISING_RING_COUNTED", &v)) pol->ring_counted = v < 0 ? 0 : (v > 2 ? 2 : v);
 	if (num("ISING_TILES", &v)) pol->tiles = v != 0;
 	if (num("ISING_TILE_ROWS", &v) && v > 0) pol->tile_rows = v;
@@ -135,6 +136,7 @@ const SwitchDoc kSwitches[] = {
 	{"ISING_TAIL", "rows[,h]", "one-row tail strips of the one-launch-per-colour form (`0`: off; default: two thirds of a strip per workgroup slot)"},
 	{"ISING_NO_BALLOT", "(set)", "layout AUTO never picks the ballot layout"},
 	{"ISING_RING_GHOST", "n", "ghost rows of ballot ring slabs (default 64; `1`: one halo row and the per-colour schedules)"},
+	{"ISING_RING_EPOCHS", "n", "exchange epochs (of `ISING_RING_GHOST`/2 sweeps each) that ONE persistent launch of a ring slab carries, the exchanges running next to it on the comm stream (IPC transport, a device per rank, fused form; default: ~50 ms worth, at most 64; `1`: a launch per exchange, as before round 6 and as RCCL and peer copies still do)"},
 	{"ISING_RING_COUNTED", "0/1/2", "print points of rings never / where possible (default) / always (an error where not) inside the deep launches"},
 	{"ISING_RING_OVERLAP", "0/1/2", "the deep exchange between two launches / in the tail of the running launch, the next one waits for it on the stream (default) / free-running, only the next launch's edge units wait (copies and IPC only)"},
 	{"ISING_RING_TRAPEZOID", "0/1", "0: every ghost row at every level (default 1: a level touches only the ghost rows that can still reach the slab)"},

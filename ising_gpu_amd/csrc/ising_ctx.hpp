@@ -30,6 +30,7 @@ struct ising_policy {
 	int split_lead = -1;     // ISING_SPLIT_LEAD=n: draw units a workgroup does before its first word unit (-1: 1)
 	int ring_counted = -1;   // ISING_RING_COUNTED=0/1/2: print points of rings never / where possible (default) / always (an error where not) inside the deep launches
 	int ring_ghost = -1;     // ISING_RING_GHOST=n: ghost rows of ballot ring slabs (-1: 64)
+	int ring_epochs = 0;     // ISING_RING_EPOCHS=n: exchange epochs one persistent launch of a ring slab carries at most (0: ~50 ms worth, up to 64; 1: a launch per exchange)
 	bool no_ballot = false;  // ISING_NO_BALLOT: layout AUTO never picks the ballot layout
 	int tail_rows = -1, tail_h = 1; // ISING_TAIL=rows[,h]: one-row tail strips of one-launch-per-colour launches (-1: automatic, 0: off)
 	bool trapezoid = true;   // ISING_RING_TRAPEZOID=0: every ghost row at every level
@@ -141,7 +142,9 @@ struct ising_ctx {
 	// deep exchange overlapped with the launches (ising_ring.cpp: sweep_deep_overlapped; UpdateParams.edge_go / edge_done)
 	uint32_t *d_edge = nullptr;                  // [0]: units of the launches' last levels that have left the exchange's rows (a count),
 	                                             // [16]: epoch of the last exchange that is complete for this slab (set by the comm stream)
-	uint32_t edge_done_target = 0;               // value of d_edge[0] once every launch issued so far has run
+	uint32_t edge_done_target = 0;               // value of d_edge[0] once every exchange epoch whose wait is on the comm stream has run
+	uint32_t edge_units_per_epoch = 0;           // what the last overlapped deep launch adds to d_edge[0] per exchange epoch (launch_ranges)
+	int epoch_sh_next = 0;                       // one-shot: the next deep launch carries several epochs of 2^epoch_sh_next levels (update_deep)
 	uint32_t edge_go_epoch = 0;                  // value d_edge[16] is (being) brought to
 	bool go_set = false;                         // ... and it stands for the exchange that delivered the current ghost rows
 	bool overlap_next = false;                   // one-shot request to launch_ranges: the next deep launch takes part in the overlap
@@ -162,7 +165,7 @@ struct ising_ctx {
 	// [4e] launch e begins, [4e+1] launch e ends (both on its dispatch packet), [4e+2] comm stream: the launch's edge strips have
 	// finished their last level (the exchange starts), [4e+3] comm stream: the neighbours' rows are in place and edge_go has moved.
 	hipEvent_t *xs_ev = nullptr;
-	int xs_cap = 0, xs_n = 0;
+	int xs_cap = 0, xs_n = 0, xs_epochs = 0; // slots, sampled launches, the exchange epochs inside them
 	bool xs_on = false;
 	bool store_ring = false;                     // ring on ONE device and one stream: every launch writes its edge rows straight into the
 	                                             // neighbouring slabs' halo rows (UpdateParams.mir0/mirL_bytes): no edge launch, no copies
@@ -236,7 +239,7 @@ int update_edges_on(ising_ctx *c, int it, int color, hipStream_t s, hipEvent_t s
 int update_interior(ising_ctx *c, int it, int color, hipEvent_t stop);
 // ring slab with ghost rows: one fused launch of `nlevels` (even, <= ghost rows) colour half-sweeps, ghost rows included;
 // `overlapped`: its edge strips wait for / announce the exchange themselves (ising_ring.cpp: sweep_deep_overlapped)
-int update_deep(ising_ctx *c, int it, int nlevels, bool overlapped = false);
+int update_deep(ising_ctx *c, int it, int nlevels, bool overlapped = false, int epochs = 1);
 // called by ising_destroy
 void ring_release(ising_ctx *c);
 // a ring slab's second stream, events and counters (created once per slab)

@@ -216,6 +216,7 @@ int ipc_allreduce_u64(ising_ctx *c, unsigned long long mine_val, unsigned long l
 
 // ------------------------------------------------------------------------------------------------ what the ring uses
 bool ising_ipc::attached(const ising_ctx *c) { return c->ipc && c->ipc->attached; }
+int ising_ipc::sharing(const ising_ctx *c) { return (c->ipc && c->ipc->attached) ? c->ipc->sharing : 1; }
 const uint32_t *ising_ipc::abort_word(const ising_ctx *c) { return c->ipc ? c->ipc->mine_abort : nullptr; }
 void ising_ipc::set_abort(ising_ctx *c, bool on) { if (c->ipc && c->ipc->mine) __atomic_store_n(&c->ipc->mine->abort, on ? 1u : 0u, __ATOMIC_RELEASE); }
 int ising_ipc::wait_plane(ising_ctx *c, int plane, hipStream_t s) { return ipc_wait_plane(c, plane, s); }

@@ -6,6 +6,8 @@
 namespace ising_ipc {
 
 bool attached(const ising_ctx *c);
+// ranks of the attached ring (this one included) whose slabs live on this rank's device (1: the rank has its device to itself)
+int sharing(const ising_ctx *c);
 // pinned, device-visible word this rank's polling kernels look at: set by the host, they give up (NULL: not exported)
 const uint32_t *abort_word(const ising_ctx *c);
 void set_abort(ising_ctx *c, bool on);

@@ -62,6 +62,11 @@ struct UpdateParams {
 	uint32_t edge_go_need;
 	uint32_t *edge_done;
 	int32_t edge_lo, edge_hi;
+	// Several exchange EPOCHS in one launch (round 6; ballot_update_k, fused form): with epoch_sh = s > 0 the launch's levels fall into epochs of 2^s
+	// levels (= the ghost rows' depth) -- the trapezoid starts over with every epoch, edge units wait at each epoch's first level until *edge_go has reached
+	// edge_go_need + epoch, and add to *edge_done at each epoch's last level (and at the launch's last): the comm stream runs one exchange per epoch next
+	// to ONE persistent launch, which neither drains nor restarts in between.  0: the whole launch is one epoch.
+	int32_t epoch_sh;
 	// Batched fused launch (ising_batch_*): `nrep` independent lattices of one shape share the launch's tickets -- a level has
 	// nrep x nwg_rep of them, workgroup unit u of a level belongs to lattice u / nwg_rep -- so that small lattices (8192^2: a
 	// level of 128 .. 1024 tickets) fill the chip with tall strips.  Per lattice: a 32-byte record in device memory (both

@@ -524,6 +524,21 @@ int post_go(ising_ctx *c, int xs_slot = -1) { // xs_slot: the exchange-statistic
 // is what happened with a ring of one over RCCL at 65536 x 8192 after ~3000 sweeps (tools/soak_overlap.py).  With the wait the
 // exchange still runs in the tail of the launch whose rows it carries, and the gap between two launches is an event, not an
 // exchange.  ISING_RING_OVERLAP=2 drops the wait (copies and the IPC transport: their kernels are one wave each).
+// Exchange epochs one launch of this slab may carry (round 6).  A launch boundary per exchange costs a ring slab its ramp, its tail and the gap to the next launch
+// every G/2 sweeps (65536 x 8192: ~1 % of a 5 ms launch) although nothing forces the launch to end: the exchange only concerns the edge units, which can wait for
+// it INSIDE a running launch (UpdateParams.epoch_sh) as they already do at a launch's first level.  That needs a transport whose kernels find room next to a
+// chip-filling persistent grid -- the peer (IPC) transport's one-lane kernels and copies do, RCCL's send/recv kernel does not -- and a device that no
+// other rank's persistent grid shares (two of them waiting for each other's exchange inside launches that never end would stop both: the next launch's turn is
+// what lets a co-resident rank in).  Ghost rows a power of two deep, the fused form (the split form's word-only tail is per launch as well, but it has no epochs).
+int epochs_per_launch(const ising_ctx *c, int n) {
+	const int G = c->ghost();
+	if (n != 1 || c->transport != ISING_TRANSPORT_IPC || ising_ipc::sharing(c) != 1 || c->pol.ring_epochs == 1 || (G & (G - 1)) != 0 || G < 4 || c->split_always ||
+	    c->pol.overlap == 0) return 1;
+	if (c->pol.ring_epochs > 1) return c->pol.ring_epochs;
+	const double epoch_ms = (double)c->cfg.X * ((double)c->cfg.Y + G) * (G / 2) / 3.4e9; // (3.4 flips/ns)
+	return (int)std::max(1.0, std::min(64.0, 50.0 / std::max(epoch_ms, 1e-3)));
+}
+
 int sweep_deep_overlapped(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 	const int G = ctxs[0]->ghost();
 	bool current = true;
@@ -532,18 +547,20 @@ int sweep_deep_overlapped(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 		for (int color = 0; color < 2; color++) if (int rc = exchange_rows(ctxs, n, color, G)) return rc;
 	for (int k = 0; k < n; k++) if (!ctxs[k]->go_set) if (int rc = post_go(ctxs[k])) return rc;
 	const bool copies = ctxs[0]->transport == ISING_TRANSPORT_COPY, ipc = ctxs[0]->transport == ISING_TRANSPORT_IPC;
+	const int E = epochs_per_launch(ctxs[0], n);
 	std::vector<int> xs(n, -1);
 	for (int it = first_it, left = nsweeps; left > 0;) {
-		const int ns = std::min(left, G / 2);
+		const int ns = std::min(left, E * (G / 2));        // sweeps of this launch ...
+		const int nep = (2 * ns + G - 1) / G;               // ... in that many exchange epochs (the last may be shorter)
 		for (int k = 0; k < n; k++) {
 			ising_ctx *c = ctxs[k];
 			if (c->pol.overlap != 2 || c->transport == ISING_TRANSPORT_RCCL) {
 				if (int rc = bind(c)) return rc;
 				HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_go, 0));
 			}
-			// exchange statistics: this launch and the exchange it feeds go into slot xs[k] (events on the dispatch packet, no extra packets)
+			// exchange statistics: this launch and the exchange that follows it (several epochs: its last) go into slot xs[k] (events on the dispatch packet, no extra packets)
 			xs[k] = (c->xs_on && c->xs_n < c->xs_cap) ? c->xs_n++ : -1;
-			if (xs[k] >= 0) { c->launch_start_next = c->xs_ev[4 * xs[k]]; c->launch_stop_next = c->xs_ev[4 * xs[k] + 1]; }
+			if (xs[k] >= 0) { c->launch_start_next = c->xs_ev[4 * xs[k]]; c->launch_stop_next = c->xs_ev[4 * xs[k] + 1]; c->xs_epochs += nep; }
 			if (c->ring_cnt_every > 0) { // print points inside this launch (ring_sweep_counted below): its sweeps whose iteration is a multiple of `every`
 				const int every = c->ring_cnt_every, first = (every - it % every) % every;
 				const int m = first < ns ? (ns - 1 - first) / every + 1 : 0;
@@ -553,28 +570,32 @@ int sweep_deep_overlapped(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 				c->cnt_bonds_next = c->ring_cnt_bonds;
 				c->ring_cnt_inflight += m;
 			}
-			if (int rc = ising_host::update_deep(c, it, 2 * ns, true)) return rc;
+			if (int rc = ising_host::update_deep(c, it, 2 * ns, true, nep)) return rc;
 		}
-		for (int k = 0; k < n; k++) {
-			ising_ctx *c = ctxs[k];
-			if (int rc = bind(c)) return rc;
-			// (a launch that gave up never brings the counter there: the kernel looks at the slab's abort word)
-			if (int rc = ising_ipc::counter_wait_on(c->comm, c->d_edge, c->edge_done_target, c->h_abort)) return rc;
-			if (xs[k] >= 0) HIP_TRY(hipEventRecord(c->xs_ev[4 * xs[k] + 2], c->comm));
-			// this slab's launches are done with its ghost rows: the neighbours may overwrite them
-			if (ipc) for (int color = 0; color < 2; color++) if (int rc = ising_ipc::release_ghosts(c, color, c->comm)) return rc;
-			if (copies) HIP_TRY(hipEventRecord(c->ev_int[0], c->comm));
-		}
-		if (copies) {
+		for (int e = 0; e < nep; e++) { // one exchange per epoch, behind the epoch's edge units, next to the launch
+			const bool last = e == nep - 1;
 			for (int k = 0; k < n; k++) {
-				ising_ctx *c = ctxs[k], *prev = c->ring_prev, *next = c->ring_next;
+				ising_ctx *c = ctxs[k];
 				if (int rc = bind(c)) return rc;
-				if (prev && prev != c) HIP_TRY(hipStreamWaitEvent(c->comm, prev->ev_int[0], 0));
-				if (next && next != c && next != prev) HIP_TRY(hipStreamWaitEvent(c->comm, next->ev_int[0], 0));
+				// (a launch that gave up never brings the counter there: the kernel looks at the slab's abort word)
+				c->edge_done_target += c->edge_units_per_epoch;
+				if (int rc = ising_ipc::counter_wait_on(c->comm, c->d_edge, c->edge_done_target, c->h_abort)) return rc;
+				if (last && xs[k] >= 0) HIP_TRY(hipEventRecord(c->xs_ev[4 * xs[k] + 2], c->comm));
+				// this slab's launches are done with its ghost rows: the neighbours may overwrite them
+				if (ipc) for (int color = 0; color < 2; color++) if (int rc = ising_ipc::release_ghosts(c, color, c->comm)) return rc;
+				if (copies) HIP_TRY(hipEventRecord(c->ev_int[0], c->comm));
 			}
+			if (copies) {
+				for (int k = 0; k < n; k++) {
+					ising_ctx *c = ctxs[k], *prev = c->ring_prev, *next = c->ring_next;
+					if (int rc = bind(c)) return rc;
+					if (prev && prev != c) HIP_TRY(hipStreamWaitEvent(c->comm, prev->ev_int[0], 0));
+					if (next && next != c && next != prev) HIP_TRY(hipStreamWaitEvent(c->comm, next->ev_int[0], 0));
+				}
+			}
+			for (int color = 0; color < 2; color++) if (int rc = transfer(ctxs, n, color, false, G)) return rc;
+			for (int k = 0; k < n; k++) if (int rc = post_go(ctxs[k], last ? xs[k] : -1)) return rc;
 		}
-		for (int color = 0; color < 2; color++) if (int rc = transfer(ctxs, n, color, false, G)) return rc;
-		for (int k = 0; k < n; k++) if (int rc = post_go(ctxs[k], xs[k])) return rc;
 		it += ns;
 		left -= ns;
 	}
@@ -746,7 +767,7 @@ static void xs_release(ising_ctx *c) {
 	for (int i = 0; c->xs_ev && i < 4 * c->xs_cap; i++) if (c->xs_ev[i]) (void)hipEventDestroy(c->xs_ev[i]);
 	delete[] c->xs_ev;
 	c->xs_ev = nullptr;
-	c->xs_cap = c->xs_n = 0;
+	c->xs_cap = c->xs_n = c->xs_epochs = 0;
 	c->xs_on = false;
 }
 
@@ -818,13 +839,14 @@ int ising_exchange_stats_fetch(ising_ctx *c, ising_exchange_stats *out) {
 		HIP_TRY(span(ev[1], ev[3], &ms)); late.add(ms);
 		if (e + 1 < c->xs_n) { HIP_TRY(span(ev[1], ev[4], &ms)); gap.add(ms); }
 	}
-	out->exchanges = c->xs_n;
+	out->exchanges = c->xs_epochs;
+	out->launches = c->xs_n;
 	auto put = [](const Acc &a, float *mean, float *max) { *mean = a.n ? (float)(a.sum / a.n) : 0.f; *max = a.max; };
 	put(launch, &out->launch_ms_mean, &out->launch_ms_max);
 	put(xchg, &out->exchange_ms_mean, &out->exchange_ms_max);
 	put(late, &out->go_after_end_ms_mean, &out->go_after_end_ms_max);
 	put(gap, &out->gap_ms_mean, &out->gap_ms_max);
-	c->xs_n = 0;
+	c->xs_n = c->xs_epochs = 0;
 	return ISING_OK;
 }
 

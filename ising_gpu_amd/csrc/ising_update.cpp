@@ -30,7 +30,9 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 	const int cnt_slot0 = c->cnt_slot0_next;
 	const bool cnt_bonds = c->cnt_bonds_next;
 	const bool split_asked = c->split_next;
+	const int epoch_sh = c->epoch_sh_next;
 	c->split_next = false;
+	c->epoch_sh_next = 0;
 	c->cnt_every_next = 0;
 	c->cnt_bonds_next = false;
 	if (!stop) stop = c->launch_stop_next;
@@ -144,7 +146,10 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 					p.edge_done = c->d_edge;
 					unsigned strips = 0; // strips of this launch that touch such a row
 					for (int r0 = lo0; r0 < hi0; r0 += HL) if (r0 < p.edge_lo || std::min(r0 + HL, hi0) > p.edge_hi) strips++;
-					c->edge_done_target += strips * (uint32_t)c->nwc();
+					// what the launch adds to *edge_done per exchange epoch (the caller keeps edge_done_target: one wait per epoch on the comm stream)
+					c->edge_units_per_epoch = strips * (uint32_t)c->nwc();
+					// several epochs in this launch (ising_ring.cpp: sweep_deep_overlapped): epochs of 2^epoch_sh levels = the ghost rows' depth
+					if (epoch_sh > 0 && !split && nlevels > (1 << epoch_sh)) p.epoch_sh = epoch_sh;
 				}
 			}
 		}
@@ -219,10 +224,16 @@ static bool ghost_sweeps(const ising_ctx *c) {
 // Ring slab with G > 1 ghost rows: `nlevels` colour half-sweeps (black first) in one fused launch over rows
 // [-(G-1), Y+G-1).  The ghost rows are updated like the slab's own -- their draws are the ones the neighbours make --, and
 // what is not valid in them any more (one row per level and side) never reaches a row that is.
-int ising_host::update_deep(ising_ctx *c, int it, int nlevels, bool overlapped) {
+// `epochs` > 1 (overlapped exchanges only, G a power of two): the launch carries that many exchange epochs of G levels each (the last may be shorter) -- the
+// caller runs one exchange per epoch on the comm stream next to it (UpdateParams.epoch_sh).
+int ising_host::update_deep(ising_ctx *c, int it, int nlevels, bool overlapped, int epochs) {
 	const int G = c->ghost();
-	if (G < 2 || nlevels > G || nlevels < 2 || c->store_ring) return fail(ISING_E_STATE, "deep launch of %d levels on a slab with %d ghost rows", nlevels, G);
+	if (epochs < 1 || (epochs > 1 && (!overlapped || (G & (G - 1)) != 0 || c->split_always)))
+		return fail(ISING_E_STATE, "deep launch of %d epochs: needs overlapped exchanges, ghost rows a power of two deep (%d) and the fused form", epochs, G);
+	if (G < 2 || nlevels > epochs * G || nlevels <= (epochs - 1) * G || nlevels < 2 || c->store_ring)
+		return fail(ISING_E_STATE, "deep launch of %d levels in %d epoch(s) on a slab with %d ghost rows", nlevels, epochs, G);
 	c->overlap_next = overlapped;
+	c->epoch_sh_next = epochs > 1 ? __builtin_ctz((unsigned)G) : 0;
 	return launch_ranges(c, it, ISING_BLACK, -(G - 1), c->cfg.Y + G - 1, 0, 0, nlevels);
 }
 

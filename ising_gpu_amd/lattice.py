@@ -365,7 +365,7 @@ class IsingSlab:
         """Wait for the slab's streams; {exchanges, launch_ms_mean, ..., gap_ms_max} over the sampled exchanges."""
         st = _lib.ExchangeStats()
         check(self._lib.ising_exchange_stats_fetch(self._h, C.byref(st)))
-        return {n: (int(getattr(st, n)) if n == "exchanges" else round(float(getattr(st, n)), 4)) for n, _ in st._fields_}
+        return {n: (int(getattr(st, n)) if n in ("exchanges", "launches") else round(float(getattr(st, n)), 4)) for n, _ in st._fields_}
 
     def rank_checkpoint_save(self, path: str):
         check(self._lib.ising_rank_checkpoint_save(self._h, str(path).encode(), self.it))

@@ -122,3 +122,74 @@ def test_quad_rule_within_3_percent_of_the_other_path(gpu, warm_clock, monkeypat
         other = rate(0 if picked else 1)[0]
     print(f"{Y} x {X}: the library ({'quad' if picked else 'no quad'}) {mine:.0f} flips/ns, the other way {other:.0f}")
     assert mine >= (1.0 - TOL) * other, f"{Y} x {X}: the library's choice ({'quad' if picked else 'no quad'}) runs {mine:.0f} flips/ns, the other path {other:.0f}"
+
+
+RING_SHAPES = [(65536, 32768), (65536, 16384), (65536, 8192), (131072, 16384)]  # a rank's slab of 65536^2 over 2 / 4 / 8 GPUs; BASELINE config 4's slab
+
+
+@pytest.mark.parametrize("X,Y", RING_SHAPES)
+def test_ring_slab_choice_within_3_percent_of_its_neighbours(gpu, warm_clock, monkeypatch, X, Y):
+    """the shapes of RING slabs (launch rows = Y + 2 G ghost rows, five workgroups per CU at most, the exchange next to a persistent launch of several
+    epochs) under the same defence as the lone slabs': a ring of ONE over the peer (IPC) transport -- what a rank of an N-rank ring executes except a link -- at the
+    library's choice against half / twice the strip height, one workgroup per CU fewer / more, the split form, and one launch per exchange (ISING_RING_EPOCHS=1,
+    the form of rounds 3-5).  Counts after the same sweeps are equal in every cell."""
+    monkeypatch.setenv("ISING_ABORT_POLLS", "40000")
+    sweeps = max(64, min(2048, int(40e-3 * 3.2e12 / (X * Y)) // 64 * 64))
+
+    def rate(H=0, wgs=0, split=None, epochs=None, check=None):
+        for k, v in (("ISING_FUSED_WGS", 256 * wgs if wgs else None), ("ISING_SPLIT", split), ("ISING_RING_EPOCHS", epochs)):
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, str(v))
+        slab = ig.IsingSlab(X, Y, seed=1234, temp=TC, ring_halo=True, strip_rows=H)
+        try:
+            ring = ig.NativeRing(slab, transport="ipc").init()
+            shape = slab.launch_shape()[:2] + (slab.sweep_form(sweeps)[0] == 3,)
+            ring.sweep(64)
+            ring.quiesce()
+            got = ring.count()
+            if check is not None:
+                assert got == check, (X, Y, H, wgs, split, epochs)
+            best = 0.0
+            import time
+            for _ in range(3):
+                t0 = time.perf_counter()
+                ring.sweep(sweeps)
+                ring.quiesce()
+                best = max(best, X * Y * sweeps / (time.perf_counter() - t0) * 1e-9)
+            ring.close()
+            return best, shape, got
+        finally:
+            slab.close()
+
+    mine, shape, counts = rate()
+    H, wg, is_split = shape
+    cells = {}
+    for h, w in ((H // 2, wg), (2 * H, wg), (H, wg - 1), (H, wg + 1)):
+        if h < 1 or h > 16 or Y % h or w < 1 or w > 6:
+            continue
+        try:
+            r, shp, _ = rate(h, w, check=counts)
+        except ig.IsingError:
+            continue
+        if shp[2] == is_split:
+            cells[(h, w, "")] = r
+    for name, kw in (("split" if not is_split else "fused", {"split": 0 if is_split else 1}), ("a launch per exchange", {"epochs": 1})):
+        try:
+            r, shp, _ = rate(check=counts, **kw)
+            cells[(shp[0], shp[1], name)] = r
+        except ig.IsingError:
+            pass
+    best = max(cells.values(), default=0.0)
+    for _ in range(3):
+        if mine >= (1.0 - TOL) * best:
+            break
+        mine = max(mine, rate()[0])
+        hb, wb, nb = max(cells, key=cells.get)
+        kw = {"": {"H": hb, "wgs": wb}, "split": {"split": 1}, "fused": {"split": 0}, "a launch per exchange": {"epochs": 1}}[nb]
+        cells[(hb, wb, nb)] = rate(**kw)[0]
+        best = max(cells.values())
+    print(f"ring of one {Y} x {X}: library H={H} wgs={wg} split={int(is_split)} {mine:.0f} flips/ns; neighbours "
+          + ", ".join(f"H={h} wgs={w} {nm}: {r:.0f}" for (h, w, nm), r in cells.items()))
+    assert mine >= (1.0 - TOL) * best, f"ring slab {Y} x {X}: the library's H={H}, {wg} per CU runs {mine:.0f} flips/ns, a neighbour {best:.0f}: {cells}"

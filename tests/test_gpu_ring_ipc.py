@@ -147,3 +147,48 @@ def test_ipc_attach_rejects_foreign_blobs(gpu):
         a.ipc_attach([bytes(256), bytes(256)])
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("ghost", ["8", "64"])
+@pytest.mark.parametrize("epochs", ["1", "2", "3", None])
+def test_several_exchange_epochs_in_one_launch(gpu, oracle_mod, monkeypatch, ghost, epochs):
+    """Round 6 (ising_ring.cpp: epochs_per_launch; UpdateParams.epoch_sh): over the peer transport with a device to itself a ring slab's persistent launch carries
+    several exchange epochs -- the trapezoid starts over, the edge units wait for each exchange inside the running launch -- instead of ending with every exchange.
+    Same spins as the oracle's whatever the number of epochs a launch carries (1 = the form of rounds 3-5), ghost rows 8 and 64 deep, calls that end inside an epoch;
+    the print points inside the launches (counts and bond sums) as well; and the launches really are fewer than the exchanges."""
+    import ising_gpu_amd as ig
+    monkeypatch.setenv("ISING_RING_GHOST", ghost)
+    if epochs is None:
+        monkeypatch.delenv("ISING_RING_EPOCHS", raising=False)
+    else:
+        monkeypatch.setenv("ISING_RING_EPOCHS", epochs)
+    X, Y, seed = 16384, 512, 12
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=oracle_mod.CRIT_TEMP).init()
+    slab = ig.IsingSlab(X, Y, seed=seed, temp=ig.CRIT_TEMP_F32, layout=ig.LAYOUT_BALLOT, ring_halo=True)
+    ring = ig.NativeRing(slab, transport="ipc").init()
+    slab.exchange_stats_begin(256)
+    total = 0
+    for n in (33, 1, 64, 7, 130):
+        ring.sweep(n)
+        orc.sweep(n)
+        total += n
+        assert ring.count() == orc.count() and ring.bond_equal() == orc.bond_equal(), (n, total)
+    st = slab.exchange_stats_fetch()
+    G = int(ghost)
+    per_call = [-(-2 * n // G) for n in (33, 1, 64, 7, 130)]  # exchange epochs of every call
+    assert st["exchanges"] == sum(per_call)
+    E = {None: 64, "1": 1, "2": 2, "3": 3}[epochs]
+    assert st["launches"] == sum(-(-e // E) for e in per_call), st
+    ring.quiesce()
+    assert np.array_equal(slab.read(ig.BLACK), orc.black) and np.array_equal(slab.read(ig.WHITE), orc.white)
+    # the reference's print points, taken inside the launches of several epochs
+    series = ring.sweep_counted(40, 8, True)
+    want = []
+    for k in range(40):
+        orc.sweep(1)
+        total += 1
+        if total % 8 == 0:
+            want.append((*orc.count(), orc.bond_equal()))
+    assert [tuple(p) for p in series] == want
+    ring.close()
+    slab.close()

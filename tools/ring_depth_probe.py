@@ -2,7 +2,8 @@
 """Ring slabs against the lone slab's rate: a ring of ONE slab over the peer (IPC) transport -- everything a rank of an N-rank ring executes
 except a real link -- by ghost depth G (= 2 x the sweeps a launch carries), launch form (fused / split) and strip height, next to the same rows as a lone slab.
 Counts after the timed sweeps are compared with the lone slab's (a shape or a depth never changes results).
-Usage: ring_depth_probe.py [--sweeps N] [--cases "G:form:H,..."] X Y [X Y ...]      form: f = fused, s = split; H = 0: the library's choice"""
+Usage: ring_depth_probe.py [--sweeps N] [--cases "G:form:H[:E],..."] X Y [X Y ...]      form: f = fused, s = split, a = the library's choice; H = 0: the library's
+choice; E = exchange epochs per launch (ISING_RING_EPOCHS; absent or 0: the library's choice, 1: a launch per exchange)"""
 import argparse
 import os
 import sys
@@ -14,7 +15,7 @@ import ising_gpu_amd as ig  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--sweeps", type=int, default=0)
-ap.add_argument("--cases", default="64:f:0,128:f:0,256:f:0,64:s:16,128:s:16,256:s:16,128:s:8")
+ap.add_argument("--cases", default="64:f:0:1,64:f:0:0,32:f:0:0,128:f:0:0,64:f:16:0,64:f:0:4")
 ap.add_argument("--transport", default="ipc")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("sizes", nargs="*", type=int)
@@ -62,8 +63,8 @@ for X, Y in sizes:
         assert s.count() == ref
         print(f"{Y} x {X} lone, library's choice: {r:7.1f} flips/ns  shape {s.launch_shape()} split {s.split}", flush=True)
     for case in args.cases.split(","):
-        G, form, H = case.split(":")
-        setenv(ISING_RING_GHOST=G if int(G) > 0 else None, ISING_SPLIT={"f": "0", "s": "1", "a": None}[form])
+        G, form, H, E = (case.split(":") + ["0"])[:4]
+        setenv(ISING_RING_GHOST=G if int(G) > 0 else None, ISING_SPLIT={"f": "0", "s": "1", "a": None}[form], ISING_RING_EPOCHS=E if int(E) > 0 else None)
         try:
             slab = ig.IsingSlab(X, Y, seed=1234, temp=ig.CRIT_TEMP_F32, ring_halo=True, strip_rows=int(H))
         except ig.IsingError as e:
@@ -73,9 +74,9 @@ for X, Y in sizes:
             ring = ig.NativeRing(slab, transport=args.transport).init()
             r = rate(ring.sweep, ring.quiesce, X, Y, n)
             cnt = ring.count()
-            print(f"{Y} x {X} ring of one ({args.transport}) G={G:>4} {form} H={H:>2}: {r:7.1f} flips/ns  shape {slab.launch_shape()} split {slab.split}  "
+            print(f"{Y} x {X} ring of one ({args.transport}) G={G:>4} {form} H={H:>2} E={E:>2}: {r:7.1f} flips/ns  shape {slab.launch_shape()} split {slab.split}  "
                   f"{slab.max_sweeps_per_launch} sweeps a launch  counts {'==' if cnt == ref else '!='} lone", flush=True)
             ring.close()
         finally:
             slab.close()
-    setenv(ISING_RING_GHOST=None, ISING_SPLIT=None)
+    setenv(ISING_RING_GHOST=None, ISING_SPLIT=None, ISING_RING_EPOCHS=None)
