@@ -429,7 +429,12 @@ int ising_exchange_stats_fetch(ising_ctx *ctx, ising_exchange_stats *out);
  * (8192^2: 2766 flips/ns alone) run at the large-lattice rate; ising_batch_measure_enqueue adds ONE launch that takes the
  * up count and the bond sum (ising_count, ising_bond_equal) of every member.  Each member's spins are bit for bit what
  * ising_sweep on that context gives, and the members stay ordinary contexts (init, read, sweep them alone in between: same
- * stream).  Asynchronous like ising_sweep; the fetch blocks. */
+ * stream).  Asynchronous like ising_sweep; the fetch blocks.
+ * Round 6 -- lattices of the quad path (what ISING_LAYOUT_AUTO picks up to ~2^26 spins and eight blocks of 2048 columns; ising_sweep_info: 4) form batches
+ * too, all members of one kind: ONE launch per pass carries the tiles of every member and the draws of every member for the pass to come, tile and pass length
+ * chosen for the many tiles of the batch (ising_batch_quad_info), so that 31 x 2048^2 -- the finite-size end of a temperature series; the reference's own
+ * many-small-systems mode, --xsl/--ysl, optimized/main.cu:1423-1457, knows one temperature -- run at the rate of one tall lattice.
+ * ising_batch_sweep_counted is ising_sweep_counted for a batch: the print points ride inside the passes of a quad batch (a ballot batch: one measuring launch each). */
 typedef struct ising_batch ising_batch;
 int ising_batch_create(ising_ctx **ctxs, int n, ising_batch **out);
 int ising_batch_destroy(ising_batch *b);                              /* before its members are destroyed */
@@ -438,6 +443,10 @@ int ising_batch_sweep(ising_batch *b, int first_it, int nsweeps);
 int ising_batch_measure_enqueue(ising_batch *b);
 /* up[k * lattices + r], bond_equal[...]: measurement k (enqueue order) of member r; at most 1024 measurements may be pending */
 int ising_batch_measure_fetch(ising_batch *b, uint64_t *up, int64_t *bond_equal, int max_n, int *n);
+/* `nsweeps` sweeps of every member (iterations first_it ..), the up spins -- and, bond_equal not NULL, ising_bond_equal's sums -- after every iteration that is a
+ * multiple of `every`: up[k * lattices + r] = point k, member r (the reference's print points, optimized/main.cu:1785-1798, for every lattice of the batch).  Blocks. */
+int ising_batch_sweep_counted(ising_batch *b, int first_it, int nsweeps, int every, uint64_t *up, int64_t *bond_equal, int max_counts, int *ncounts);
+int ising_batch_quad_info(ising_batch *b, int *tile_row_groups, int *sweeps_per_pass, int *waves); /* a quad batch's shape (zeros: a ballot batch) */
 
 /* -- one process per slab WITHOUT RCCL: direct peer access, the reference's own multi-GPU mechanism
  * (cudaDeviceCanAccessPeer / cudaDeviceEnablePeerAccess, optimized/main.cu:1496-1537; remote loads of the two rows outside

@@ -164,8 +164,8 @@ int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_
 	// Fresh-start mode on one device runs the temperature points as a BATCH: lattices of one shape share the tickets of every
 	// fused launch (ising_batch_sweep) and one launch measures all of them -- 8192^2 alone fills 70 % of an MI355X, 31 of them
 	// in one launch run at the large-lattice rate.  As many points at a time as fit 2^35 spins (4 GiB at 1 bit per spin), 64
-	// at most; --tsweep-replicas K forces K.  Lattices the batch cannot carry (dense layout: under 1.5 * 2^24 spins; -J)
-	// run two at a time on streams of their own, as in round 2.
+	// at most; --tsweep-replicas K forces K.  Small lattices (the quad path: up to ~2^26 spins) batch as well from round 6 on -- one launch
+	// per pass of all of them, the measurements inside the passes.  Lattices no batch can carry (-J) run two at a time on streams of their own, as in round 2.
 	bool batched = false;
 	if (ndev == 1 && !ts.anneal) {
 		const int fit = (int)std::max<unsigned long long>(1, std::min<unsigned long long>(64, (1ull << 35) / nspins));
@@ -224,10 +224,14 @@ int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_
 		nrep = keep;
 		reps.resize(nrep);
 	}
+	bool quad_batch = false; // small lattices: one quad_pass_k launch per pass for all of them, the measurements inside the passes (ising_batch_sweep_counted)
 	if (batched) {
-		int h = 0, w = 0;
+		int h = 0, w = 0, qc = 0, qt = 0, qw = 0;
 		CHECK(ising_batch_info(batch, &h, &w, nullptr));
-		fprintf(stderr, "temperature sweep: %d %s per batched launch (strips of %d rows, %d workgroups per CU)\n", nrep, K > 1 ? "lattices" : "points", h, w);
+		CHECK(ising_batch_quad_info(batch, &qc, &qt, &qw));
+		quad_batch = qc > 0;
+		if (quad_batch) fprintf(stderr, "temperature sweep: %d %s per batched launch (tiles of %d rows, passes of %d sweeps, %d waves per workgroup)\n", nrep, K > 1 ? "lattices" : "points", 4 * qc, qt, qw);
+		else fprintf(stderr, "temperature sweep: %d %s per batched launch (strips of %d rows, %d workgroups per CU)\n", nrep, K > 1 ? "lattices" : "points", h, w);
 	} else if (nrep > 1) {
 		fprintf(stderr, "temperature sweep: %d points side by side, one stream each\n", nrep);
 		for (Ring &rp : reps) CHECK(ising_use_private_stream(rp.ctx[0]));
@@ -303,13 +307,28 @@ int run_tsweep(Ring &ring, const ising_config &base, const TsweepSpec &ts, size_
 				for (int j = 0; j < nb; j++) take(j, it_meas0 + (fetched[j] + i + 1) * ts.stride, ups[(size_t)i * nb + j], As[(size_t)i * nb + j]);
 			for (int j = 0; j < nb; j++) fetched[j] += n;
 		};
-		for (int m = 0; batched && m < ts.nmeas; m++) {
+		// a batch of small lattices whose measurements fall on multiples of the stride: the series rides inside the passes, 1024 measurements per read-back
+		const bool inpass = batched && quad_batch && (it % ts.stride) == 0;
+		for (int m = 0; inpass && m < ts.nmeas;) {
+			const int nm = std::min(1024, ts.nmeas - m);
+			std::vector<uint64_t> ups((size_t)nm * nb);
+			std::vector<int64_t> As((size_t)nm * nb);
+			int k = 0;
+			CHECK(ising_batch_sweep_counted(batch, it + 1, nm * ts.stride, ts.stride, ups.data(), As.data(), nm, &k));
+			if (k != nm) { fprintf(stderr, "temperature sweep: %d measurements came back, %d expected\n", k, nm); exit(EXIT_FAILURE); }
+			for (int i = 0; i < k; i++)
+				for (int j = 0; j < nb; j++) take(j, it + (i + 1) * ts.stride, ups[(size_t)i * nb + j], As[(size_t)i * nb + j]);
+			for (int j = 0; j < nb; j++) fetched[j] += k;
+			it += nm * ts.stride;
+			m += nm;
+		}
+		for (int m = 0; batched && !inpass && m < ts.nmeas; m++) {
 			CHECK(ising_batch_sweep(batch, it + 1, ts.stride));
 			CHECK(ising_batch_measure_enqueue(batch));
 			it += ts.stride;
 			if ((m + 1) % 1024 == 0) fetch_batch();
 		}
-		if (batched) fetch_batch();
+		if (batched && !inpass) fetch_batch();
 		// One lattice at a time (annealing runs, --tsweep-replicas 1, rings of slabs) whose measurements fall on multiples of the stride: the whole
 		// series of a point rides inside the launches (ising_ring_sweep_counted with the bond sums), 64 measurements per read-back
 		const bool inlaunch = !batched && nb == 1 && (it % ts.stride) == 0;

@@ -334,6 +334,39 @@ int choose_strip_rows(int gx, int Y, bool dense, bool ballot = false) {
 
 } // namespace
 
+// The quad path's shape by width and rows (row groups per tile, sweeps per pass, waves per workgroup), by measurement: ising_create's comment at its call.
+// `rows`: of the lattice -- of ALL lattices of a batch (ising_batch.cpp): many tiles are many tiles whoever owns them.
+void ising_host::quad_shape(int gx, long long rows, int *C, int *T, int *W) {
+	int C0 = 4, T0 = 8, W0 = 12;
+	if (gx == 1) {
+		if (rows < 1024) { C0 = 4; T0 = 8; W0 = 12; } // (2048 x 512: 745 against 670 at sixteen sweeps a pass)
+		else if (rows < 2048) { C0 = 4; T0 = 16; W0 = 12; }
+		else if (rows < 4096) { C0 = 8; T0 = 16; W0 = 12; }
+		else if (rows < 8192) { C0 = 4; T0 = 12; W0 = 8; }
+		else if (rows < 16384) { C0 = 4; T0 = 8; W0 = 8; }
+		else { C0 = 8; T0 = 4; W0 = 8; }
+	} else if (gx == 2) {
+		if (rows < 2048) { C0 = 4; T0 = 12; W0 = 16; }
+		else if (rows < 8192) { C0 = 4; T0 = 8; W0 = 12; }
+		else { C0 = 8; T0 = 4; W0 = 12; }
+	} else if (gx == 3) { // (from three blocks on: up to three items a wave of sixteen -- 100 registers, four waves per SIMD: a tile has its CU to itself)
+		if (rows < 1024) { C0 = 2; T0 = 8; W0 = 16; }       // 6144 x 512: 1361 against (4, 4, 16) 1076
+		else if (rows < 2048) { C0 = 4; T0 = 8; W0 = 16; }  // 6144 x 1024: 1984 against (4, 4, 12) 1670
+		else if (rows < 4096) { C0 = 8; T0 = 6; W0 = 16; }  // 6144 x 2048: 2057 against 1951
+		else { C0 = 4; T0 = 4; W0 = 12; }
+	} else if (gx == 4) {
+		if (rows < 1024) { C0 = 2; T0 = 8; W0 = 16; }       // 8192 x 512: 1496 against 1231
+		else if (rows < 2048) { C0 = 4; T0 = 8; W0 = 16; }  // 8192 x 1024: 2043 against 1642
+		else { C0 = 4; T0 = 4; W0 = 16; }
+	} else if (gx <= 6) {
+		if (rows < 1024) { C0 = 2; T0 = 6; W0 = 16; }       // 10240 x 512: 1582, 12288 x 512: 1807 against (2, 2, 12) 1161 / 1229
+		else { C0 = 4; T0 = 4; W0 = 16; }                     // 10240 x 1024: 1748, 12288 x 1024: 1904 against 1427 / 1466
+	} else {
+		C0 = 2; T0 = 4; W0 = 16;                               // 14336 x 512: 1592, 16384 x 512: 1747 against (2, 2, 16) 1293 / 1313
+	}
+	*C = C0; *T = T0; *W = W0;
+}
+
 extern "C" {
 
 const char *ising_last_error(void) { return g_err.c_str(); }
@@ -668,32 +701,7 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		// ones on tall tiles (throughput: less of the word phase is halo -- 2048 x 32768 (8, 4, 8) 2481 against 2374, 4096 x 16384 (8, 4, 12) 2431 against 2342).
 		// A wave keeps at most two items: 80 registers, six waves per SIMD.
 		int C0 = 4, T0 = 8, W0 = 12;
-		if (c->gx == 1) {
-			if (cfg->Y < 1024) { C0 = 4; T0 = 8; W0 = 12; } // (2048 x 512: 745 against 670 at sixteen sweeps a pass)
-			else if (cfg->Y < 2048) { C0 = 4; T0 = 16; W0 = 12; }
-			else if (cfg->Y < 4096) { C0 = 8; T0 = 16; W0 = 12; }
-			else if (cfg->Y < 8192) { C0 = 4; T0 = 12; W0 = 8; }
-			else if (cfg->Y < 16384) { C0 = 4; T0 = 8; W0 = 8; }
-			else { C0 = 8; T0 = 4; W0 = 8; }
-		} else if (c->gx == 2) {
-			if (cfg->Y < 2048) { C0 = 4; T0 = 12; W0 = 16; }
-			else if (cfg->Y < 8192) { C0 = 4; T0 = 8; W0 = 12; }
-			else { C0 = 8; T0 = 4; W0 = 12; }
-		} else if (c->gx == 3) { // (from three blocks on: up to three items a wave of sixteen -- 100 registers, four waves per SIMD: a tile has its CU to itself)
-			if (cfg->Y < 1024) { C0 = 2; T0 = 8; W0 = 16; }       // 6144 x 512: 1361 against (4, 4, 16) 1076
-			else if (cfg->Y < 2048) { C0 = 4; T0 = 8; W0 = 16; }  // 6144 x 1024: 1984 against (4, 4, 12) 1670
-			else if (cfg->Y < 4096) { C0 = 8; T0 = 6; W0 = 16; }  // 6144 x 2048: 2057 against 1951
-			else { C0 = 4; T0 = 4; W0 = 12; }
-		} else if (c->gx == 4) {
-			if (cfg->Y < 1024) { C0 = 2; T0 = 8; W0 = 16; }       // 8192 x 512: 1496 against 1231
-			else if (cfg->Y < 2048) { C0 = 4; T0 = 8; W0 = 16; }  // 8192 x 1024: 2043 against 1642
-			else { C0 = 4; T0 = 4; W0 = 16; }
-		} else if (c->gx <= 6) {
-			if (cfg->Y < 1024) { C0 = 2; T0 = 6; W0 = 16; }       // 10240 x 512: 1582, 12288 x 512: 1807 against (2, 2, 12) 1161 / 1229
-			else { C0 = 4; T0 = 4; W0 = 16; }                     // 10240 x 1024: 1748, 12288 x 1024: 1904 against 1427 / 1466
-		} else {
-			C0 = 2; T0 = 4; W0 = 16;                               // 14336 x 512: 1592, 16384 x 512: 1747 against (2, 2, 16) 1293 / 1313
-		}
+		ising_host::quad_shape(c->gx, cfg->Y, &C0, &T0, &W0);
 		int T = pol.quad_T ? pol.quad_T : T0;
 		T = std::max(1, std::min(T, 32));
 		const int HG = (2 * T - 1 + 3) / 4;

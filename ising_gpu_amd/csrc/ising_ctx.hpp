@@ -12,6 +12,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 
 // A/B and test switches.  The environment is read ONCE per context, in ising_create, into this record; nothing
 // in the library calls getenv afterwards (ISING_RCCL_LIB, the path of the RCCL to open, is process-wide and read once).
@@ -261,6 +262,13 @@ int sweep_alone(ising_ctx *c, int first_it, int nsweeps);
 int fused_sweeps_per_launch(const ising_policy &pol, long long spins);
 // launch shape of fused launches by tickets per level (ising_capi.cpp)
 void fused_shape(int nwc, int Y, long long rows, int *H, int *wg_per_cu, bool late = false);
+// the quad path's tile and pass by width and rows (ising_capi.cpp)
+void quad_shape(int gx, long long rows, int *C, int *T, int *W);
+// the slab sweeps on the quad path as things stand (its temperature has integer thresholds, its buffers exist)
+bool quad_ready(const ising_ctx *c);
+// the passes of a call on the quad path: iteration of the first sweep, sweeps, index of the print point the pass ends on (-1: none)
+struct QuadPass { int it, ns, meas; };
+std::vector<QuadPass> quad_passes(int first_it, int nsweeps, int every, int T, int *nmeas);
 constexpr size_t SLOTCTL_TICKET_BYTES = 9 * 64; // ticket words in front of the completion counters (d_slotctl)
 
 } // namespace ising_host

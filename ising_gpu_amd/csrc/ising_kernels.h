@@ -189,6 +189,16 @@ hipError_t launch_dense_init(const InitParams &p, hipStream_t stream);
 // reference thread 64 (R & 3) + 16 r4 + tx of block (bx, R / 4) draws with Philox block p / 4, output p % 4 -- and its kernel, one launch per pass of T sweeps:
 // tiles (the word phases of 2 T levels on C row groups + halo, no exchange) next to the draws of the pass to come (one KiB of accept masks per level, row group
 // and block, made once).
+// Many small lattices of one shape in ONE launch (round 6, ising_batch.cpp): the tiles of all of them side by side, the drawing workgroups draw for all of
+// them.  What differs from lattice to lattice travels in a record the kernel fetches with scalar loads (as ballot_update_k<BATCH> does with ReplicaParams).
+struct alignas(64) QuadRec {
+	uint64_t *quad;          // the lattice's four planes [buffer][colour][quad words] (ising_ctx::d_quad)
+	uint64_t *masks;         // its two mask buffers (ising_ctx::d_qmasks)
+	uint32_t *dense[2];      // row 0 of its dense planes (the conversion launches on a call's way in and out)
+	uint32_t seed_lo, seed_hi;
+	uint32_t n3, n4;
+	uint32_t pad_[4];
+};
 struct QuadDrawParams {
 	uint64_t *masks;         // [nlev][NRG * gx][128]: (c3, c4) of word p at 16 p bytes
 	uint32_t seed_lo, seed_hi;
@@ -197,6 +207,9 @@ struct QuadDrawParams {
 	int gx, NRG;
 	int nlev;                // 0: no draws in this launch
 	int nwaves;              // (set by the launcher) the drawing waves of the launch: each takes an equal run of the pass's quarter items
+	const QuadRec *rep;      // not null: `nrep` lattices, lattice major -- seed and thresholds from the records, masks = rep[r].masks + mask_off
+	int nrep;
+	size_t mask_off;         // (words)
 };
 struct QuadWordParams {
 	const uint64_t *src[2];  // black / white lattice the pass reads
@@ -207,6 +220,10 @@ struct QuadWordParams {
 	int nlev;                // levels of the pass (even: whole sweeps, black first; at most 64); 0: no word pass in this launch
 	unsigned long long *cnt; // not null: the up spins of the state the pass stores are added to these EIGHT words (tile t to word t mod 8)
 	unsigned long long *cnt_eq; // not null (with cnt): ... and the bonds between equal spins (ising_bond_equal's sum: the white sites' equal neighbours) to these eight
+	const QuadRec *rep;      // not null: tile t belongs to lattice t / tiles_per_lat; planes = rep[r].quad + src_off / dst_off, masks = rep[r].masks + mask_off,
+	int nrep;                // print points: cnt / cnt_eq + r * cnt_stride
+	int tiles_per_lat;       // (set by the launcher)
+	size_t src_off[2], dst_off[2], mask_off, cnt_stride; // (words)
 };
 struct QuadPassParams {
 	QuadWordParams w;
@@ -222,6 +239,8 @@ size_t quad_pass_lds_bytes(const QuadWordParams &w, int waves);
 int quad_word_maxi(const QuadWordParams &p, int waves); // items a wave works on per level at most (0: too many for any instantiation)
 hipError_t launch_dense_to_quad(const uint32_t *dense, uint64_t *quad, int gx, int NRG, hipStream_t stream);
 hipError_t launch_quad_to_dense(const uint64_t *quad, uint32_t *dense, int gx, int NRG, hipStream_t stream); // (dense: row 0; rows -1 and Y are refreshed too)
+// ... of every lattice of a batch, both colours, in one launch: rep[r].dense[colour] <-> rep[r].quad + (2 buffer + colour) * gx * NRG * 64
+hipError_t launch_quad_convert_batch(const QuadRec *rep, int nrep, int buffer, bool to_quad, int gx, int NRG, hipStream_t stream);
 
 // in-place nibble -> bit-plane transposition of `nvec` 16-byte coupling vectors (dense layout with -J)
 hipError_t launch_ham_planes(uint64_t *ham, size_t nvec, hipStream_t stream);

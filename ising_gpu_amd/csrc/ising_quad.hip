@@ -67,7 +67,11 @@ __device__ __forceinline__ uint32_t lds_addr(const void *q) {
 __device__ __forceinline__ void quad_draw_part(const QuadDrawParams &p, long long wg, int wi, int lane, int NW, uint64_t *lds) {
 	uint4 *blk_const = reinterpret_cast<uint4 *>(lds) + wi * 16; // (private to the wave: 256 B)
 	const int NI = p.NRG * p.gx;
-	const unsigned long long Q = (unsigned long long)p.nlev * (unsigned long long)NI * 4ull, W = (unsigned long long)p.nwaves;
+	// a batch (p.rep): the lattices one after another, each level major -- a wave's run crosses a lattice now and then and picks up its record there
+	const int nrep = p.rep ? p.nrep : 1;
+	const unsigned per_level = (unsigned)NI * 4u;
+	const unsigned long long per_lat = (unsigned long long)p.nlev * per_level;
+	const unsigned long long Q = per_lat * (unsigned)nrep, W = (unsigned long long)p.nwaves;
 	const unsigned long long w = (unsigned long long)wg * (unsigned)NW + (unsigned)wi;
 	if (w >= W) return;
 	unsigned long long q_lo = Q * w / W, q_hi = Q * (w + 1) / W;
@@ -78,14 +82,27 @@ __device__ __forceinline__ void quad_draw_part(const QuadDrawParams &p, long lon
 		q_hi = ((unsigned long long)d << 32) | c;
 	}
 	if (q_lo >= q_hi) return;
-	const unsigned per_level = (unsigned)NI * 4u;
-	int level = (int)(q_lo / per_level);
-	unsigned rem = (unsigned)(q_lo - (unsigned long long)level * per_level);
+	int r = p.rep ? (int)(q_lo / per_lat) : 0;
+	const unsigned rem_lat = (unsigned)(q_lo - (unsigned long long)r * per_lat);
+	int level = (int)(rem_lat / per_level);
+	unsigned rem = rem_lat - (unsigned)level * per_level;
 	int n = (int)(rem >> 2), qq = (int)(rem & 3u);
 	int R = n / p.gx, bx = n - R * p.gx;
 	uint32_t seed_lo = p.seed_lo, seed_hi = p.seed_hi;
-	const uint32_t k2y = seed_hi + 2u * PHILOX_W1;
 	uint32_t thr3 = p.n3, thr4 = p.n4;
+	uint64_t *masks = p.masks;
+	auto pick_up = [&](int rr) { // lattice rr's record (scalar loads: rr is wave-uniform)
+		const QuadRec *rc = p.rep + rr;
+		seed_lo = __builtin_amdgcn_readfirstlane(rc->seed_lo);
+		seed_hi = __builtin_amdgcn_readfirstlane(rc->seed_hi);
+		thr3 = __builtin_amdgcn_readfirstlane(rc->n3);
+		thr4 = __builtin_amdgcn_readfirstlane(rc->n4);
+		const uintptr_t m = (uintptr_t)(rc->masks + p.mask_off);
+		const uint32_t m_lo = __builtin_amdgcn_readfirstlane((uint32_t)m), m_hi = __builtin_amdgcn_readfirstlane((uint32_t)(m >> 32));
+		masks = reinterpret_cast<uint64_t *>(((uintptr_t)m_hi << 32) | m_lo);
+	};
+	if (p.rep) pick_up(r);
+	uint32_t k2y = seed_hi + 2u * PHILOX_W1;
 	bool new_level = true;
 	uint32_t seed_lo_cy = 0;
 	for (unsigned long long q = q_lo; q < q_hi;) { // item by item: the quarters [qq, qe) of item n of `level` (a wave's first and last item may be partial)
@@ -105,7 +122,7 @@ __device__ __forceinline__ void quad_draw_part(const QuadDrawParams &p, long lon
 		}
 		const uint32_t tid = (((uint32_t)R >> 2) * (uint32_t)p.gx + (uint32_t)bx) * 256u + ((uint32_t)R & 3u) * 64u + (uint32_t)lane;
 		const PhiloxRow pr = philox_row_setup(tid, seed_lo_cy, k2y);
-		const uint64_t *dst0 = p.masks + ((size_t)level * (size_t)NI + (size_t)n) * 128;
+		const uint64_t *dst0 = masks + ((size_t)level * (size_t)NI + (size_t)n) * 128;
 		const uint32_t d_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dst0), d_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)dst0 >> 32));
 		const uint64_t *dst = reinterpret_cast<const uint64_t *>(((uintptr_t)d_hi << 32) | d_lo);
 		for (int qi = qq; qi < qe; ++qi) {
@@ -134,7 +151,13 @@ __device__ __forceinline__ void quad_draw_part(const QuadDrawParams &p, long lon
 		qq = 0; // (whatever follows starts an item: a wave's share is one run)
 		++n;
 		if (++bx == p.gx) { bx = 0; ++R; }
-		if (n == NI) { n = 0; R = 0; bx = 0; ++level; new_level = true; }
+		if (n == NI) {
+			n = 0; R = 0; bx = 0; ++level; new_level = true;
+			if (level == p.nlev && p.rep) { // the next lattice of the batch
+				level = 0;
+				if (++r < nrep) { pick_up(r); k2y = seed_hi + 2u * PHILOX_W1; }
+			}
+		}
 	}
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 }
@@ -167,6 +190,22 @@ template <int MAXI>
 __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile, int wi, int lane, int NW, uint64_t *q_lds) {
 	const int gx = p.gx, NRG = p.NRG, HG = p.HG;
 	const int NG = p.C + 2 * HG;
+	// whose tile: a batch's tiles are dealt lattice by lattice; the lattice's planes, masks and print-point words by its record (scalar loads)
+	const uint64_t *srcp[2] = {p.src[0], p.src[1]};
+	uint64_t *dstp[2] = {p.dst[0], p.dst[1]};
+	const uint64_t *masks = p.masks;
+	unsigned long long *cnt = p.cnt, *cnt_eq = p.cnt_eq;
+	if (p.rep) {
+		const int r = __builtin_amdgcn_readfirstlane(tile / p.tiles_per_lat);
+		tile -= r * p.tiles_per_lat;
+		const QuadRec *rc = p.rep + r;
+		uint64_t *const planes = rc->quad;
+		srcp[0] = planes + p.src_off[0]; srcp[1] = planes + p.src_off[1];
+		dstp[0] = planes + p.dst_off[0]; dstp[1] = planes + p.dst_off[1];
+		masks = rc->masks + p.mask_off;
+		if (cnt) cnt += (size_t)r * p.cnt_stride;
+		if (cnt_eq) cnt_eq += (size_t)r * p.cnt_stride;
+	}
 	const int A = tile * p.C;
 	const int Cc = min(p.C, NRG - A);
 	const int gw = gx * 64;                 // words per row group
@@ -216,8 +255,8 @@ __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile
 	auto fetch = [&](int Lp, auto SLOT) {
 		static_for<MAXI>([&](auto K) {
 			const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)mk_tab[K.value], Lp & 63);
-			if (idx != ABSENT && Lp < p.nlev) qm_load<SLOT.value * MAXI + K.value>(lane16, reinterpret_cast<const char *>(p.masks) + (size_t)idx * 1024);
-			else qm_load<Q_DEPTH * MAXI>(lane16, p.masks);
+			if (idx != ABSENT && Lp < p.nlev) qm_load<SLOT.value * MAXI + K.value>(lane16, reinterpret_cast<const char *>(masks) + (size_t)idx * 1024);
+			else qm_load<Q_DEPTH * MAXI>(lane16, masks);
 		});
 	};
 	fetch(0, std::integral_constant<int, 0>{});
@@ -225,7 +264,7 @@ __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile
 	// the tile and its halo row groups, both colours
 	for (int cg = wi; cg < 2 * NG; cg += NW) { // (row group, colour) by wave, its gx x 64 words by lane
 		const int c = cg >= NG, g = cg - c * NG;
-		const uint64_t *from = p.src[c] + (size_t)wrapR(g) * gw;
+		const uint64_t *from = (c ? srcp[1] : srcp[0]) + (size_t)wrapR(g) * gw;
 		for (int w = lane; w < gw; w += 64) lat[c * plane + g * gw + w] = from[w];
 	}
 	__syncthreads();
@@ -342,31 +381,31 @@ __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile
 	// (the sums of a print point: per wave, then per workgroup through two LDS words, then ONE add per tile into one of eight slots -- a thousand waves adding to
 	// one word cost a measured pass of 2048^2 7.5 us, with the energy 20, of a 19 us launch)
 	__shared__ unsigned long long q_sums[2];
-	if (p.cnt && threadIdx.x < 2) q_sums[threadIdx.x] = 0;
-	if (p.cnt_eq) level(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, std::true_type{}, p.nlev - 1);
+	if (cnt && threadIdx.x < 2) q_sums[threadIdx.x] = 0;
+	if (cnt_eq) level(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, std::true_type{}, p.nlev - 1);
 	// the tile itself into the other buffer; a print point: the up spins of what is stored
 	unsigned long long ups = 0;
 	for (int cg = wi; cg < 2 * Cc; cg += NW) {
 		const int c = cg >= Cc, g = cg - c * Cc;
-		uint64_t *to = p.dst[c] + (size_t)(A + g) * gw;
+		uint64_t *to = (c ? dstp[1] : dstp[0]) + (size_t)(A + g) * gw;
 		for (int w = lane; w < gw; w += 64) {
 			const uint64_t v = lat[c * plane + (HG + g) * gw + w];
 			to[w] = v;
 			ups += (unsigned long long)__popcll(v);
 		}
 	}
-	if (p.cnt) {
+	if (cnt) {
 		__syncthreads(); // (q_sums is zero)
 		ups = wave_sum(ups);
 		const unsigned long long eq = wave_sum(eq_acc);
 		if (lane == 0) {
 			atomicAdd(&q_sums[0], ups);
-			if (p.cnt_eq) atomicAdd(&q_sums[1], eq);
+			if (cnt_eq) atomicAdd(&q_sums[1], eq);
 		}
 		__syncthreads();
 		if (threadIdx.x == 0) {
-			atomicAdd(p.cnt + (tile & 7), q_sums[0]);
-			if (p.cnt_eq) atomicAdd(p.cnt_eq + (tile & 7), q_sums[1]);
+			atomicAdd(cnt + (tile & 7), q_sums[0]);
+			if (cnt_eq) atomicAdd(cnt_eq + (tile & 7), q_sums[1]);
 		}
 	}
 #if defined(ISING_QUAD_TRACE)
@@ -399,7 +438,7 @@ __global__ void __launch_bounds__(MAXI <= 3 ? 1024 : 512) __attribute__((amdgpu_
 }
 
 // ---- dense <-> quad, one wave per (row group, block); dense rows are gx * 32 words of 32 sites
-__global__ void __launch_bounds__(256) dense_to_quad_k(const uint32_t *__restrict__ dense, uint64_t *__restrict__ quad, int gx, int NRG) {
+__device__ __forceinline__ void dense_to_quad_body(const uint32_t *__restrict__ dense, uint64_t *__restrict__ quad, int gx, int NRG) {
 	__shared__ uint32_t sh[4][128];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const int j = lane >> 5, m = (lane >> 2) & 7, q = lane & 3;
@@ -419,8 +458,12 @@ __global__ void __launch_bounds__(256) dense_to_quad_k(const uint32_t *__restric
 	quad[n * 64 + lane] = w;
 }
 
+__global__ void __launch_bounds__(256) dense_to_quad_k(const uint32_t *__restrict__ dense, uint64_t *__restrict__ quad, int gx, int NRG) {
+	dense_to_quad_body(dense, quad, gx, NRG);
+}
+
 // (also refreshes the dense layout's mirror rows -1 and Y: dense points at row 0 of an array with a row above and Y + 1 rows below)
-__global__ void __launch_bounds__(256) quad_to_dense_k(const uint64_t *__restrict__ quad, uint32_t *__restrict__ dense, int gx, int NRG) {
+__device__ __forceinline__ void quad_to_dense_body(const uint64_t *__restrict__ quad, uint32_t *__restrict__ dense, int gx, int NRG) {
 	__shared__ uint64_t sh[4][64];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const long long n = (long long)blockIdx.x * 4 + wv;
@@ -442,6 +485,19 @@ __global__ void __launch_bounds__(256) quad_to_dense_k(const uint64_t *__restric
 		if (row == 0) dense[(ptrdiff_t)Y * ld + 32 * bx + vv] = d;
 		if (row == Y - 1) dense[-ld + 32 * bx + vv] = d;
 	}
+}
+__global__ void __launch_bounds__(256) quad_to_dense_k(const uint64_t *__restrict__ quad, uint32_t *__restrict__ dense, int gx, int NRG) {
+	quad_to_dense_body(quad, dense, gx, NRG);
+}
+
+// ... of a batch: blockIdx.y = 2 r + colour
+template <bool TO_QUAD>
+__global__ void __launch_bounds__(256) quad_convert_batch_k(const QuadRec *__restrict__ rep, int buffer, int gx, int NRG) {
+	const QuadRec *rc = rep + (blockIdx.y >> 1);
+	const int color = blockIdx.y & 1;
+	uint64_t *quad = rc->quad + (size_t)(2 * buffer + color) * (size_t)gx * (size_t)NRG * 64;
+	if (TO_QUAD) dense_to_quad_body(rc->dense[color], quad, gx, NRG);
+	else quad_to_dense_body(quad, rc->dense[color], gx, NRG);
 }
 
 } // namespace
@@ -492,7 +548,11 @@ static hipError_t launch_pass_t(const QuadPassParams &p, int waves, long long gr
 // `p.w.nlev` = 0: draws only (the first launch of a call); `p.d.nlev` = 0: words only (its last)
 hipError_t launch_quad_pass(QuadPassParams &p, int waves, hipStream_t stream) {
 	const int mi0 = quad_word_maxi(p.w, waves);
-	p.ntiles = p.w.nlev > 0 ? (p.w.NRG + p.w.C - 1) / p.w.C : 0;
+	const int nrep = p.w.rep ? p.w.nrep : (p.d.rep ? p.d.nrep : 1);
+	p.w.tiles_per_lat = (p.w.NRG + p.w.C - 1) / p.w.C;
+	const long long all_tiles = (long long)p.w.tiles_per_lat * nrep;
+	if (all_tiles > 0x3fffffffLL) return hipErrorInvalidValue;
+	p.ntiles = p.w.nlev > 0 ? (int)all_tiles : 0;
 	// workgroup slots of the chip: eight waves per SIMD at one item a wave, six at two (80 registers), three beyond
 	// (the drawing workgroups of the grid reserve the tiles' LDS segment as well -- one launch, one size --: what a CU's 160 KiB hold bounds them too)
 	const int per_cu_regs = std::max(1, ((mi0 <= 1 ? 8 : (mi0 <= 2 ? 6 : (mi0 == 3 ? 4 : 3))) * 4) / waves); // (one item a wave: under 64 registers; three: 128)
@@ -500,7 +560,7 @@ hipError_t launch_quad_pass(QuadPassParams &p, int waves, hipStream_t stream) {
 	const int cap = std::max(4, p.cus * per_cu) & ~3;
 	long long draw_wgs = 0;
 	if (p.d.nlev > 0) {
-		const long long items = (long long)p.d.NRG * p.d.gx * p.d.nlev;
+		const long long items = (long long)p.d.NRG * p.d.gx * p.d.nlev * nrep;
 		// Few tiles (up to a quarter of the slots: a small lattice, its word pass the launch's critical path): as many drawing workgroups as find room next to
 		// them, every wave an equal share of the draws -- they end together (2048^2 1705 -> 1792 flips/ns).  More tiles: drawing workgroups of one item a wave
 		// that come and go, the dispatcher balancing (drawing workgroups that stay for the whole launch keep the slots the later tiles need: 6144^2 1508 against 2343).
@@ -529,6 +589,15 @@ hipError_t launch_quad_pass(QuadPassParams &p, int waves, hipStream_t stream) {
 hipError_t launch_dense_to_quad(const uint32_t *dense, uint64_t *quad, int gx, int NRG, hipStream_t stream) {
 	const long long n = (long long)NRG * gx;
 	hipLaunchKernelGGL(dense_to_quad_k, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, dense, quad, gx, NRG);
+	return hipGetLastError();
+}
+
+hipError_t launch_quad_convert_batch(const QuadRec *rep, int nrep, int buffer, bool to_quad, int gx, int NRG, hipStream_t stream) {
+	const long long n = (long long)NRG * gx;
+	if (nrep < 1 || 2 * nrep > 65535) return hipErrorInvalidValue;
+	const dim3 grid((unsigned)((n + 3) / 4), (unsigned)(2 * nrep));
+	if (to_quad) hipLaunchKernelGGL(quad_convert_batch_k<true>, grid, dim3(256), 0, stream, rep, buffer, gx, NRG);
+	else hipLaunchKernelGGL(quad_convert_batch_k<false>, grid, dim3(256), 0, stream, rep, buffer, gx, NRG);
 	return hipGetLastError();
 }
 

@@ -343,22 +343,10 @@ static int sweep_tiles_counted(ising_ctx *c, int first_it, int nsweeps, int ever
 	return ISING_OK;
 }
 
-// Small lattices on the quad layout (ising_quad.hip).  A pass = up to T sweeps; launch k = the word pass k on the masks launch k - 1 drew + the draws of pass
-// k + 1 (two mask buffers, one stream, no events: the launches of a call are k = -1 .. passes - 1, the first draws only, the last works on words only).
-// The spins live in d_lat (dense layout) between calls: a call converts on its way in and out, so everything else the library does with a dense slab --
-// counts, energy, dumps, a temperature change -- finds what it always found.
-static bool sweeps_quad(const ising_ctx *c, int nsweeps) {
-	return c->quad_C > 0 && nsweeps >= 2 && c->wrap && c->dense && !c->ballot && !c->cfg.use_J && !c->cfg.XSL && c->fast_ok && !ising_host::needs_generic(c);
-}
-
-// `every` > 0: the up spins after every iteration that is a multiple of it are added to the eight words d_cnt[8 m ..] (zero on entry) -- `bonds`: to
-// d_cnt[16 m ..], the bonds between equal spins at the same point to d_cnt[16 m + 8 ..] --; *nmeas = how many
-static int sweep_quad(ising_ctx *c, int first_it, int nsweeps, int every, unsigned long long *d_cnt, int *nmeas, bool bonds = false) {
-	if (int rc = bind(c)) return rc;
-	if (!c->d_quad || !c->d_qmasks) return fail(ISING_E_STATE, "quad sweeps without their buffers (ising_create allocates them)");
-	struct Pass { int it, ns, meas; };
-	std::vector<Pass> passes;
-	const int T = c->quad_T;
+// The passes of `nsweeps` sweeps from iteration first_it on, T sweeps a pass at most: a segment between two print points (`every` > 0: the iterations that are
+// multiples of it) is cut into passes of equal length, the one that ends on a print point carries its index.
+std::vector<ising_host::QuadPass> ising_host::quad_passes(int first_it, int nsweeps, int every, int T, int *nmeas) {
+	std::vector<QuadPass> passes;
 	const long long last = (long long)first_it + nsweeps - 1;
 	int k = 0;
 	for (int it = first_it; it <= last;) {
@@ -371,6 +359,28 @@ static int sweep_quad(ising_ctx *c, int first_it, int nsweeps, int every, unsign
 			it += ns;
 		}
 	}
+	if (nmeas) *nmeas = k;
+	return passes;
+}
+
+// Small lattices on the quad layout (ising_quad.hip).  A pass = up to T sweeps; launch k = the word pass k on the masks launch k - 1 drew + the draws of pass
+// k + 1 (two mask buffers, one stream, no events: the launches of a call are k = -1 .. passes - 1, the first draws only, the last works on words only).
+// The spins live in d_lat (dense layout) between calls: a call converts on its way in and out, so everything else the library does with a dense slab --
+// counts, energy, dumps, a temperature change -- finds what it always found.
+static bool sweeps_quad(const ising_ctx *c, int nsweeps) {
+	return c->quad_C > 0 && nsweeps >= 2 && c->wrap && c->dense && !c->ballot && !c->cfg.use_J && !c->cfg.XSL && c->fast_ok && !ising_host::needs_generic(c);
+}
+
+bool ising_host::quad_ready(const ising_ctx *c) { return sweeps_quad(c, 2) && c->d_quad && c->d_qmasks; }
+
+// `every` > 0: the up spins after every iteration that is a multiple of it are added to the eight words d_cnt[8 m ..] (zero on entry) -- `bonds`: to
+// d_cnt[16 m ..], the bonds between equal spins at the same point to d_cnt[16 m + 8 ..] --; *nmeas = how many
+static int sweep_quad(ising_ctx *c, int first_it, int nsweeps, int every, unsigned long long *d_cnt, int *nmeas, bool bonds = false) {
+	if (int rc = bind(c)) return rc;
+	if (!c->d_quad || !c->d_qmasks) return fail(ISING_E_STATE, "quad sweeps without their buffers (ising_create allocates them)");
+	const int T = c->quad_T;
+	int k = 0;
+	const std::vector<ising_host::QuadPass> passes = ising_host::quad_passes(first_it, nsweeps, every, T, &k);
 	if (nmeas) *nmeas = k;
 	const int NRG = c->cfg.Y / 4, gx = c->gx;
 	const size_t qw = c->quad_words(), NI = qw / 64;

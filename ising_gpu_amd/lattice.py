@@ -396,6 +396,10 @@ class IsingBatch:
         h, w, n = C.c_int(), C.c_int(), C.c_int()
         check(self._lib.ising_batch_info(self._h, C.byref(h), C.byref(w), C.byref(n)))
         self.strip_rows, self.wg_per_cu, self.n = h.value, w.value, n.value
+        c, t, wv = C.c_int(), C.c_int(), C.c_int()
+        check(self._lib.ising_batch_quad_info(self._h, C.byref(c), C.byref(t), C.byref(wv)))
+        #: a batch of quad-path lattices: (row groups per tile, sweeps per pass, waves per workgroup); None: a ballot batch
+        self.quad_shape = (c.value, t.value, wv.value) if c.value else None
 
     def close(self):
         if self._h:
@@ -426,6 +430,19 @@ class IsingBatch:
         for s in self.slabs:
             s.it = self.it
         return self
+
+    def sweep_counted(self, n: int, every: int, energy: bool = False):
+        """`n` sweeps of every member with the reference's print points (iterations that are multiples of `every`):
+        [[(up, down, bond_equal or None) per member] per point] (ising_batch_sweep_counted)."""
+        cap = max(1, n // every + 1)
+        up, bond, k = (C.c_uint64 * (cap * self.n))(), (C.c_int64 * (cap * self.n))(), C.c_int()
+        check(self._lib.ising_batch_sweep_counted(self._h, self.it + 1, n, every, up, bond if energy else None, cap, C.byref(k)))
+        self.it += n
+        for s in self.slabs:
+            s.it = self.it
+        tot = self.slabs[0].X * self.slabs[0].Y
+        return [[(int(up[i * self.n + r]), tot - int(up[i * self.n + r]), int(bond[i * self.n + r]) if energy else None) for r in range(self.n)]
+                for i in range(k.value)]
 
     def measure_enqueue(self):
         check(self._lib.ising_batch_measure_enqueue(self._h))

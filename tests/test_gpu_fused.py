@@ -422,3 +422,25 @@ def test_counted_sweeps_where_the_counts_cannot_ride_in_the_launch(gpu, oracle_m
                 want.append(orc.count() + ((orc.bond_equal(),) if energy else ()))
         assert got == want and len(want) == 4
         assert _same(s, orc)
+
+
+@pytest.mark.parametrize("n,port", [(2, 29561), (8, 29562)])
+def test_the_drivers_multi_gpu_command_verbatim(gpu, n, port):
+    """the command the driver runs for SCALE_rNN.json -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps 20 --warmup 5`, nothing added -- on this box, where the N ranks share the one GPU: processes, rendezvous, the peer
+    transport, the ring schedule and the parity check against the committed goldens all execute; what the line reports about the ranks and their links is there
+    to be read on the first real node (optimized/main.cu:1496-1537, :1763-1805 is what it replaces)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "20", "--warmup", "5"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == n and b["steps"] == 20 and b["warmup"] == 5 and b["unit"] == "flips/ns" and b["value"] > 100
+    cfg = b["config"]
+    assert cfg["nranks"] == n and cfg["parity_checked"] is True and ("inside the launch" in cfg["exchange_overlap"] or "tail" in cfg["exchange_overlap"])
+    assert len(b["ranks"]) == n and all(rk["pci_bus_id"] and rk["lone_slab_flips_per_ns"] > 0 for rk in b["ranks"])
+    assert sorted(b["transport_attempts"]) == sorted(f"rank{k}" for k in range(n)) and all(any(a.endswith(": ok") for a in v) for v in b["transport_attempts"].values())
+    assert b["expected"]["lone_slab_flips_per_ns_sum"] > 0 and 0 < b["efficiency_vs_lone_slab"] < 1.5
+    assert b["distinct_devices"] >= 1 and len(cfg["rank_up"]) == n and sum(cfg["rank_up"]) == cfg["up"]

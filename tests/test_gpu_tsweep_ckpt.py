@@ -235,3 +235,36 @@ def test_bits_and_packed_boundary_formats_round_trip(gpu, oracle_mod, layout):
             s.it = 2
             s.sweep(3)
             assert np.array_equal(s.read(ig.BLACK), orc.black) and np.array_equal(s.read(ig.WHITE), orc.white)
+
+
+def test_tsweep_small_lattices_ride_in_batched_passes(gpu, tmp_path):
+    """Round 6: a temperature series on lattices of the quad path (2048^2: 64 tiles for 256 CUs each) runs as ONE batch -- the tiles of all 31 x 2 lattices in one
+    launch per pass, the measurements inside the passes (ising_batch_sweep_counted) --, and every (up, down, bond) triple is the oracle's for that temperature
+    and seed (tests/golden/tsweep_2048.json: seeds 1234 / 1235 = --tsweep-chains 2, after 8, 16, 24, 32 sweeps)."""
+    fx = json.load(open(os.path.join(GOLD, "tsweep_2048.json")))
+    r = subprocess.run([CLI, "-x", str(fx["X"]), "-y", str(fx["Y"]), "-s", str(fx["seeds"][0]), "--tsweep", "1.5,3.0,0.05,0,4,8", "--tsweep-chains", "2", "--tsweep-out", "ts"],
+                       capture_output=True, text=True, cwd=tmp_path, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    if "per batched launch (tiles of" not in r.stderr:
+        pytest.skip("the quad path is the default on a whole MI355X only: " + r.stderr[-300:])
+    series = list(csv.DictReader(open(tmp_path / "ts.series.csv")))
+    assert len(series) == 31 * 2 * 4
+    gold = {(s["seed"], s["temp_bits"], p["sweeps"]): p for s in fx["series"] for p in s["points"]}
+    for row in series:
+        g = gold[(fx["seeds"][0] + int(row["chain"]), int(row["temp_bits"]), int(row["iter"]))]
+        assert (int(row["up"]), int(row["down"]), int(row["bond_equal"])) == (g["up"], g["down"], g["bond_equal"]), row
+    assert {int(row["iter"]) for row in series} == {8, 16, 24, 32}
+
+
+@pytest.mark.parametrize("extra", [[], ["--tsweep-replicas", "7"], ["--tsweep-no-batch"]])
+def test_tsweep_4096_against_oracle_series(gpu, tmp_path, extra):
+    """... 4096^2 (two blocks of 2048 columns), eight sweeps of equilibration and one measurement eight sweeps later = the golden's point at sixteen sweeps; groups of
+    seven points (a last group of three) and the unbatched form give the same integers."""
+    fx = json.load(open(os.path.join(GOLD, "tsweep_4096.json")))
+    run(["-x", fx["X"], "-y", fx["Y"], "-s", fx["seeds"][0], "--tsweep", "1.5,3.0,0.05,8,1,8", "--tsweep-out", "ts"] + extra, cwd=tmp_path)
+    series = list(csv.DictReader(open(tmp_path / "ts.series.csv")))
+    assert len(series) == 31
+    for row, s in zip(series, fx["series"]):
+        g = [p for p in s["points"] if p["sweeps"] == 16][0]
+        assert int(row["temp_bits"]) == s["temp_bits"]
+        assert (int(row["iter"]), int(row["up"]), int(row["down"]), int(row["bond_equal"])) == (16, g["up"], g["down"], g["bond_equal"])
