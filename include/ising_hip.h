@@ -241,6 +241,21 @@ int ising_sweep_info(ising_ctx *ctx, int *fused, int *max_sweeps_per_launch);
  * when THIS call runs split launches (1 otherwise); *strip_rows, *wg_per_cu: strip height and workgroups per CU of the launches of that call (0 where the form has
  * none: one launch per colour, tiles, quad).  Any pointer may be NULL. */
 int ising_sweep_form(ising_ctx *ctx, int nsweeps, int *form, int *strip_rows, int *wg_per_cu);
+/* The run-time guard under the fused launches' shape table (round 6).  Strip height and workgroups per CU of a lone slab's fused launches come from tables fitted
+ * on the boxes this library was measured on, and some mid-size entries sit next to cliffs (the same shape: 3392 flips/ns on one box, 835 on the next).  The first
+ * launches of ising_sweep on such a slab are therefore timed on their dispatch packets -- the host waits for them, once per context.  On the plateau (4096 tickets
+ * a level and more: 32768^2 and up) a rate of 0.8 x what a lattice of that size runs at settles it after one launch; below, or under that rate, the neighbouring
+ * shapes (a workgroup per CU fewer, one more -- on down the slope while it pays --, half the strip height) get one launch each and the fastest stays if it is
+ * worth 3 %.  Results never depend on the shape.  ISING_GUARD=0 turns it off (default: on, on a whole MI355X); ising_sweep_form reports the shape in
+ * force.  state: 0 off (not a lone slab in the fused form), 1 timing the table's shape, 2 trying neighbours, 3 settled.  Blocks while a timed launch is in flight. */
+typedef struct ising_guard_info {
+	int32_t state, switched, launches_timed;
+	int32_t table_strip_rows, table_wg_per_cu;  /* the shape ising_create (or ISING_FUSED_WGS / strip_rows) gave */
+	int32_t strip_rows, wg_per_cu;              /* the shape in force */
+	float expected_flips_per_ns;                /* what the first launches were held against (x 0.8) */
+	float table_flips_per_ns, kept_flips_per_ns; /* measured: the table's shape, the shape that stayed */
+} ising_guard_info;
+int ising_shape_guard_info(ising_ctx *ctx, ising_guard_info *out);
 /* Same, bracketed by HIP events on the context's stream; returns elapsed milliseconds (blocking). */
 int ising_sweep_timed(ising_ctx *ctx, int first_it, int nsweeps, float *elapsed_ms);
 
@@ -436,6 +451,7 @@ int ising_exchange_stats_fetch(ising_ctx *ctx, ising_exchange_stats *out);
  * many-small-systems mode, --xsl/--ysl, optimized/main.cu:1423-1457, knows one temperature -- run at the rate of one tall lattice.
  * ising_batch_sweep_counted is ising_sweep_counted for a batch: the print points ride inside the passes of a quad batch (a ballot batch: one measuring launch each). */
 typedef struct ising_batch ising_batch;
+
 int ising_batch_create(ising_ctx **ctxs, int n, ising_batch **out);
 int ising_batch_destroy(ising_batch *b);                              /* before its members are destroyed */
 int ising_batch_info(ising_batch *b, int *strip_rows, int *wg_per_cu, int *lattices); /* launch shape chosen for the batch */

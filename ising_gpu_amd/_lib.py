@@ -121,6 +121,7 @@ PROTOTYPES = {
     "ising_batch_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ising_batch_measure_enqueue": (C.c_int, [C.c_void_p]),
     "ising_batch_sweep_counted": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int)]),
+    "ising_shape_guard_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ising_batch_quad_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ising_batch_measure_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int)]),
     "ising_ipc_export": (C.c_int, [C.c_void_p, C.c_void_p]),

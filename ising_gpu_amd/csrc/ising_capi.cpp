@@ -44,6 +44,8 @@ int read_policy(ising_policy *pol) {
 	if (num("ISING_FUSED_TICKETS2", &v)) pol->fused_tickets2 = (v == 2 || v == 4) ? v : (v ? 2 : 0);
 	if (num("ISING_FUSED_WGS", &v)) pol->fused_wgs = v > 0 ? v : 0;
 	if (num("ISING_FUSED_MAX_SWEEPS", &v)) pol->fused_max_sweeps = v > 0 ? v : 0;
+	if (num("ISING_GUARD", &v)) pol->guard = v != 0;
+	if (const char *e = getenv("ISING_GUARD_EXPECT")) { const double x = atof(e); if (x > 0) pol->guard_expect = (float)x; }
 	if (num("ISING_FUSED_WAIT_LATE", &v)) pol->fused_wait_late = v < 0 ? 0 : (v > 2 ? 2 : v);
 	if (num("ISING_SPLIT", &v)) pol->split = v != 0;
 	if (num("ISING_SPLIT_LEAD", &v)) pol->split_lead = v < 0 ? 0 : (v > 4 ? 4 : v);
@@ -117,6 +119,8 @@ struct SwitchDoc { const char *name, *values, *meaning; };
 const SwitchDoc kSwitches[] = {
 	{"ISING_FUSED", "0/1", "`ising_sweep` on the ballot layout: one launch per colour / fused launches (default: fused from 1.5*2^24 spins, and below where a level of one-row units feeds two workgroups per CU)"},
 	{"ISING_FUSED_WGS", "n", "size of a fused launch's persistent grid, in workgroups (default: by tickets per level, strip height and wave columns: `fused_wgs_for`)"},
+	{"ISING_GUARD", "0/1", "run-time guard under the fused launches' shape table: the first launches of a lone slab are timed; below the plateau (under 4096 tickets a level), or under 0.8 x the expected rate, the neighbouring shapes (one workgroup per CU fewer / more, half the strip height) get a launch each and the fastest stays if it is worth 3 % (default: on a whole MI355X)"},
+	{"ISING_GUARD_EXPECT", "flips/ns", "what the guard expects of the lattice (default: by its size, `guard_expected`)"},
 	{"ISING_FUSED_TICKETS2", "0/2/4", "fused launches draw from that many ticket counters (default: four for one-row units, two for two-row units, one above)"},
 	{"ISING_FUSED_NT", "0/1", "lattice words of fused launches with the non-temporal hint (default: lattices above 2^31 spins)"},
 	{"ISING_FUSED_WAIT_LATE", "0/1/2", "units of fused launches draw that many rows before they wait for their parents (default 2)"},
@@ -832,7 +836,12 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		else if (pol.tail_rows > 0 && pol.tail_rows % c->H == 0 && pol.tail_rows % pol.tail_h == 0 && pol.tail_h < c->H && 2 * pol.tail_rows < cfg->Y) { c->tail_rows = pol.tail_rows; c->tail_h = pol.tail_h; }
 		const size_t strips = c->tail_rows ? (size_t)(cfg->Y - c->tail_rows) / c->H + (size_t)c->tail_rows / c->tail_h : (size_t)c->nstrips;
 		// (+ H: the flag-synchronised ring schedule may turn one more H-row strip into one-row strips, launch_ranges)
-		const size_t plain = (size_t)c->nwc() * (strips + 2 + (size_t)c->H) * 2048 + 16 * 2048, fused = (size_t)ising::ballot_max_wgs(c->cus) * 4 * 2048;
+		const bool guard_can = c->fused && fused_shape && c->wrap && !cfg->XSL && !cfg->use_J && (pol.guard >= 0 ? pol.guard != 0 : c->cus >= 200);
+		if (guard_can) {
+			c->guard.state = 1;
+			if (hipEventCreate(&c->guard.e0) != hipSuccess || hipEventCreate(&c->guard.e1) != hipSuccess) { (void)hipGetLastError(); c->guard.state = 0; }
+		}
+		const size_t plain = (size_t)c->nwc() * (strips * (guard_can ? 2 : 1) + 2 + (size_t)c->H) * 2048 + 16 * 2048, fused = (size_t)ising::ballot_max_wgs(c->cus) * 4 * 2048;
 		e = hipMalloc((void **)&c->d_scratch, std::max(plain, fused));
 		// The ring's edge-row launches (two rows, comm stream) run next to the interior launch of the same colour (compute
 		// stream): slots of their own, or the two launches overwrite each other's accept masks -- which they did: the
@@ -840,7 +849,9 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		if (e == hipSuccess) e = hipMalloc((void **)&c->d_scratch_edge, ((size_t)2 * c->nwc() + 8) * 2048);
 		// ticket words (chunk counter + 8 queue words, 64 bytes apart) + one completion counter per strip (fused launches)
 		// (the split form keeps completion counters of its own behind those: its strips are other strips, and both sets are counts that start a launch from a common base)
-		const size_t ctl_bytes = SLOTCTL_TICKET_BYTES + 2 * ((size_t)c->nstrips + 2 * (size_t)c->ghost_rows + 2) * sizeof(uint32_t); // (+ strips of the ghost rows)
+		// (the guard may halve a lone slab's strip height once: room for twice the strips, here and in the plain launches' accept-mask slots above)
+		c->ctl_strips = (size_t)c->nstrips * (guard_can ? 2 : 1);
+		const size_t ctl_bytes = SLOTCTL_TICKET_BYTES + 2 * (c->ctl_strips + 2 * (size_t)c->ghost_rows + 2) * sizeof(uint32_t); // (+ strips of the ghost rows)
 		if (e == hipSuccess) e = hipMalloc((void **)&c->d_slotctl, ctl_bytes);
 		if (e == hipSuccess) e = hipMemset(c->d_slotctl, 0, ctl_bytes);
 		c->slotctl_bytes = ctl_bytes;
@@ -893,6 +904,8 @@ int ising_destroy(ising_ctx *c) {
 	if (c->d_ham && !c->cfg.coupling_mem) (void)hipFree(c->d_ham);
 	if (c->d_bits) (void)hipFree(c->d_bits);
 	if (c->d_corr) (void)hipFree(c->d_corr);
+	if (c->guard.e0) (void)hipEventDestroy(c->guard.e0);
+	if (c->guard.e1) (void)hipEventDestroy(c->guard.e1);
 	if (c->d_slotctl) (void)hipFree(c->d_slotctl);
 	if (c->d_edge) (void)hipFree(c->d_edge);
 	if (c->d_scratch_edge) (void)hipFree(c->d_scratch_edge);

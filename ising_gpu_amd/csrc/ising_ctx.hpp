@@ -21,6 +21,8 @@ struct ising_policy {
 	int fused_nt = -1;       // ISING_FUSED_NT=0/1: non-temporal lattice words (-1: lattices above 2^31 spins)
 	int fused_tickets2 = -1; // ISING_FUSED_TICKETS2=0/2/4: ticket counters (-1: by strip height)
 	int fused_wgs = 0;       // ISING_FUSED_WGS=n: persistent grid of n workgroups (0: by tickets per level)
+	int guard = -1;          // ISING_GUARD=0/1: the run-time guard under the fused launches' shape table (ising_update.cpp: guard_*; -1: on a whole MI355X)
+	float guard_expect = 0;  // ISING_GUARD_EXPECT=flips/ns: what the guard holds the first launches against (0: by lattice size)
 	int fused_wait_late = -1; // ISING_FUSED_WAIT_LATE=0/1: units of fused launches draw their first row before they wait for their parents (-1: by tickets per level)
 	int fused_max_sweeps = 0; // ISING_FUSED_MAX_SWEEPS=n: sweeps one fused launch of a single slab carries at most (0: ~50 ms worth, 32 .. 4096)
 	int tiles = -1;          // ISING_TILES=0/1: small lattices on the dense layout sweep in tile launches of several sweeps (-1: by lattice size)
@@ -75,6 +77,23 @@ struct ising_ctx {
 	uint32_t *d_slotctl = nullptr; // ballot layout, fused launches: ticket words (576 bytes) + per-strip completion counters
 	size_t slotctl_bytes = 0;
 	uint32_t done_base = 0;        // value of every completion counter once everything launched so far has run
+	size_t ctl_strips = 0;         // strips the completion counters of ONE form have room for (the guard may halve the strip height: twice ising_create's strips)
+	// The run-time guard under the shape table (round 6, ising_update.cpp: guard_before / guard_settle): the first launches of a lone slab's fused form are timed on
+	// their dispatch packets; under 0.8 x what the table expects of that lattice the neighbouring shapes get one launch each and the fastest stays.
+	struct ShapeGuard {
+		int state = 0;             // 0: off, 1: timing the table's shape, 2: trying neighbours, 3: settled
+		hipEvent_t e0 = nullptr, e1 = nullptr;
+		bool pending = false;      // a timed launch is in flight
+		double pending_flips = 0;
+		int timed = 0;             // launches timed at the table's shape
+		int ncand = 0, cand = 0;
+		static constexpr int MAXC = 8;
+		int cand_H[MAXC] = {}, cand_wg[MAXC] = {};
+		int base_H = 0, base_wg = 0, best_H = 0, best_wg = 0;
+		float base_rate = 0, best_rate = 0, expected = 0;
+		bool switched = false, grid_override = false; // grid_override: the guard's workgroups per CU replace ISING_FUSED_WGS
+		int launches = 0;          // launches it looked at
+	} guard;
 	bool fused = false;            // ising_sweep batches colour half-sweeps into fused launches
 	int fused_wg_per_cu = 0;       // ... and this many workgroups per CU (0: as many as the chip holds)
 	int fused_nt = 0;              // ... whose lattice words carry the non-temporal hint (lattice larger than the 256 MB memory-side cache)

@@ -107,12 +107,12 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 		p.nlevels = nlevels;
 		p.cus = c->cus;
 		if (nlevels > 1) {
-			p.grid_cap = c->pol.fused_wgs;
+			p.grid_cap = c->guard.grid_override ? 0 : c->pol.fused_wgs; // (a shape the guard chose replaces ISING_FUSED_WGS)
 			p.abort_flag = c->h_abort;
 			p.abort_polls = c->pol.abort_polls;
 			for (int k = 0; k < 4; k++) p.ticket_base2[k] = c->ticket_base2[k]; // (the counters are never reset, ising_ballot.hip)
 			p.tickets2 = c->fused_tickets2;
-			const size_t done_words = (size_t)c->nstrips + 2 * (size_t)c->ghost_rows + 2; // (per form)
+			const size_t done_words = c->ctl_strips + 2 * (size_t)c->ghost_rows + 2; // (per form)
 			uint32_t *const done = c->d_slotctl + SLOTCTL_TICKET_BYTES / 4 + (split ? done_words : 0);
 			uint32_t &done_base = split ? c->split_done_base : c->done_base;
 			if (done_base > (1u << 30)) { // keep the monotone completion counters far from wrapping
@@ -447,6 +447,132 @@ static int sweep_quad_counted(ising_ctx *c, int first_it, int nsweeps, int every
 	return ISING_OK;
 }
 
+// ---- The run-time guard under the shape table.  The fused launches' strip height and workgroups per CU come from tables fitted on the boxes
+// this library was measured on (ising_capi.cpp: choose_fused_strip_rows, fused_wgs_for), and their mid-size entries sit next to cliffs -- 16384^2 at eight-row strips
+// and six per CU: 3392 flips/ns on one box, 835 on the next --; tests/test_gpu_policy.py finds a moved cliff only when somebody runs it.  So the first
+// launches of a lone slab's fused form are timed on their dispatch packets (the host waits for them: once per context).  On the plateau (4096 tickets a level and
+// more) a rate of 0.8 x what a lattice of that size runs at settles it after ONE launch.  Below, or under that rate, the neighbouring shapes get one launch each -- a
+// workgroup per CU fewer, one more (and on down the slope while it pays), half the strip height -- and the fastest stays if it is worth 3 %.  A shape never changes
+// results (every unit's draws depend on its sites and the iteration alone), only who computes what when.
+namespace {
+
+// flips/ns a lone slab of this size runs at in the fused form on a whole MI355X (the plateau of DESIGN 4.1 and the mid-size table of 4.2, rounded down; dead lanes of
+// a partly filled last wave column draw for nothing).  ISING_GUARD_EXPECT overrides.
+double guard_expected(const ising_ctx *c, bool model_only = false) {
+	if (c->pol.guard_expect > 0 && !model_only) return c->pol.guard_expect;
+	const long long spins = (long long)c->cfg.X * c->cfg.Y;
+	const double full = spins >= (1LL << 28) ? 3300.0 : (spins >= (1LL << 27) ? 3150.0 : (spins >= (1LL << 26) ? 2950.0 : (spins >= (1LL << 25) ? 2400.0 : (spins >= 3 * (1LL << 23) ? 1700.0 : 1400.0))));
+	return full * (double)c->gx / (4.0 * c->nwc()) * std::min(1.0, c->cus / 256.0);
+}
+
+int guard_wg_now(const ising_ctx *c) {
+	if (!c->guard.grid_override && c->pol.fused_wgs > 0) return std::max(1, c->pol.fused_wgs / std::max(1, c->cus));
+	return c->fused_wg_per_cu > 0 ? c->fused_wg_per_cu : 6;
+}
+
+// the slab's fused launches take shape (H, wg) from the next one on
+int guard_apply(ising_ctx *c, int H, int wg) {
+	if (H != c->H) { // other strips: their completion counters start over (stream order: behind every launch so far)
+		const size_t done_words = c->ctl_strips + 2 * (size_t)c->ghost_rows + 2;
+		HIP_TRY(hipMemsetAsync(c->d_slotctl + ising_host::SLOTCTL_TICKET_BYTES / 4, 0, done_words * sizeof(uint32_t), c->stream));
+		c->done_base = 0;
+		c->H = H;
+		c->nstrips = c->cfg.Y / H;
+		if (c->pol.fused_tickets2 < 0) c->fused_tickets2 = H == 1 ? 4 : (H == 2 ? 2 : 0);
+	}
+	c->fused_wg_per_cu = wg;
+	c->guard.grid_override = true;
+	return ISING_OK;
+}
+
+// A timed launch is in flight: wait for it, judge it, move on.
+int guard_settle(ising_ctx *c) {
+	ising_ctx::ShapeGuard &g = c->guard;
+	if (!g.pending) return ISING_OK;
+	g.pending = false;
+	float ms = 0;
+	if (hipEventSynchronize(g.e1) != hipSuccess || hipEventElapsedTime(&ms, g.e0, g.e1) != hipSuccess || ms <= 0) { (void)hipGetLastError(); g.state = 3; return ISING_OK; }
+	const float rate = (float)(g.pending_flips / ((double)ms * 1.0e6));
+	g.launches++;
+	auto add = [&](int H, int wg) {
+		if (g.ncand >= ising_ctx::ShapeGuard::MAXC || wg < 1 || wg > 6) return;
+		if (H == g.base_H && wg == g.base_wg) return;
+		for (int k = 0; k < g.ncand; k++) if (g.cand_H[k] == H && g.cand_wg[k] == wg) return;
+		g.cand_H[g.ncand] = H; g.cand_wg[g.ncand++] = wg;
+	};
+	if (g.state == 1) {
+		g.timed++;
+		g.base_rate = std::max(g.base_rate, rate);
+		// Where a level has tickets for every workgroup the chip holds several times over (the plateau: 32768^2 and up) no shape of the table sits near a cliff: a rate
+		// near the expectation settles it.  Below, the neighbours get a launch each whatever the rate -- a shape one step from a cliff loses a fifth, not three
+		// quarters (8192 x 1536: 1662 / 1521 / 1240 flips/ns at two / three / four workgroups per CU), and no table of expectations is that sharp.
+		const long long tickets = ((long long)c->nwc() * (c->cfg.Y / std::max(1, g.base_H)) + 3) / 4;
+		const bool plateau = tickets >= 4096;
+		if (plateau && rate >= 0.8f * g.expected) { g.state = 3; g.best_rate = g.base_rate; return ISING_OK; }
+		if (g.timed < 2) return ISING_OK; // (a context's first launch also pays for the code's way into the chip: one more before anything changes)
+		g.best_H = g.base_H; g.best_wg = g.base_wg; g.best_rate = g.base_rate;
+		g.ncand = 0;
+		add(g.base_H, g.base_wg - 1);
+		add(g.base_H, g.base_wg + 1);
+		if (g.base_H >= 2 && (size_t)(c->cfg.Y / (g.base_H / 2)) <= c->ctl_strips) add(g.base_H / 2, g.base_wg); // (twice the tickets a level, the same grid)
+		if (!g.ncand) { g.state = 3; return ISING_OK; }
+		g.state = 2;
+		g.cand = 0;
+		return guard_apply(c, g.cand_H[0], g.cand_wg[0]);
+	}
+	// state 2: candidate g.cand ran
+	const int cH = g.cand_H[g.cand], cw = g.cand_wg[g.cand];
+	if (rate > g.best_rate) {
+		// (downhill from here? one more step the same way, a launch each, while it pays)
+		if (rate > 1.01f * g.best_rate && cH == g.best_H && cw != g.best_wg) add(cH, cw + (cw > g.best_wg ? 1 : -1));
+		g.best_rate = rate; g.best_H = cH; g.best_wg = cw;
+	}
+	if (++g.cand >= g.ncand) {
+		g.state = 3;
+		// (a neighbour stays when it is worth it: 3 % -- two launches' noise is one --, or anything where the table's shape fell short of the expectation)
+		const bool worth = g.best_rate > 1.03f * g.base_rate || (g.base_rate < 0.8f * g.expected && g.best_rate > g.base_rate);
+		g.switched = worth && (g.best_H != g.base_H || g.best_wg != g.base_wg);
+		if (!g.switched) { // back to the table's shape, ISING_FUSED_WGS included
+			g.best_H = g.base_H; g.best_wg = g.base_wg; g.best_rate = g.base_rate;
+			const int rc = guard_apply(c, g.base_H, g.base_wg);
+			g.grid_override = false;
+			return rc;
+		}
+		return guard_apply(c, g.best_H, g.best_wg);
+	}
+	return guard_apply(c, g.cand_H[g.cand], g.cand_wg[g.cand]);
+}
+
+// a call whose launches the guard does not time (print points inside the launches: their slots are laid out by the strips): what is known so far decides
+int guard_finish(ising_ctx *c) {
+	ising_ctx::ShapeGuard &g = c->guard;
+	if (g.state != 1 && g.state != 2) return ISING_OK;
+	if (int rc = guard_settle(c)) return rc;
+	if (g.state != 2) return ISING_OK;
+	g.state = 3;
+	g.switched = g.best_rate > 1.03f * g.base_rate && (g.best_H != g.base_H || g.best_wg != g.base_wg);
+	if (!g.switched) { g.best_H = g.base_H; g.best_wg = g.base_wg; g.best_rate = g.base_rate; }
+	if (int rc = guard_apply(c, g.best_H, g.best_wg)) return rc;
+	if (!g.switched) g.grid_override = false;
+	return ISING_OK;
+}
+
+// in front of a plain fused launch of `ns` sweeps: the events it is to be timed with, or nothing
+void guard_before(ising_ctx *c, int ns, hipEvent_t *stop) {
+	ising_ctx::ShapeGuard &g = c->guard;
+	*stop = nullptr;
+	if (g.state != 1 && g.state != 2) return;
+	if (g.state == 1 && g.timed == 0) { g.expected = (float)guard_expected(c); g.base_H = c->H; g.base_wg = guard_wg_now(c); }
+	const double flips = (double)c->cfg.X * c->cfg.Y * ns;
+	if (flips < 2.0e6 * guard_expected(c, true)) return; // (under ~2 ms the launch's fixed part shows: not a launch to judge a shape by)
+	c->launch_start_next = g.e0;
+	*stop = g.e1;
+	g.pending = true;
+	g.pending_flips = flips;
+}
+
+} // namespace
+
 // `nsweeps` sweeps of a slab that needs nothing from its neighbours: a single slab that wraps in place, or a slab of
 // sub-lattices (also one of several: nothing crosses slabs, optimized/main.cu:1423-1462)
 int ising_host::sweep_alone(ising_ctx *c, int first_it, int nsweeps) {
@@ -457,6 +583,15 @@ int ising_host::sweep_alone(ising_ctx *c, int first_it, int nsweeps) {
 		for (int it = first_it, left = nsweeps; left > 0;) {
 			const int ns = std::min(left, per_launch);
 			c->split_next = split;
+			if (c->guard.state == 1 || c->guard.state == 2) {
+				if (int rc = guard_settle(c)) return rc;
+				hipEvent_t stop = nullptr;
+				if (!split && c->wrap) guard_before(c, ns, &stop);
+				if (int rc = launch_ranges(c, it, ISING_BLACK, 0, c->cfg.Y, 0, 0, 2 * ns, stop)) { c->guard.pending = false; return rc; }
+				it += ns;
+				left -= ns;
+				continue;
+			}
 			if (int rc = launch_ranges(c, it, ISING_BLACK, 0, c->cfg.Y, 0, 0, 2 * ns)) return rc;
 			it += ns;
 			left -= ns;
@@ -522,6 +657,7 @@ extern "C" int ising_sweep_counted(ising_ctx *c, int first_it, int nsweeps, int 
 		}
 		return ISING_OK;
 	}
+	if (int rc = guard_finish(c)) return rc;
 	size_t slots = 0, n_up = 0, chunk = 0;
 	unsigned long long *d_sum = nullptr;
 	const bool split = split_pays(c, nsweeps); // (one form of launch per call: the slots of a measurement are laid out by its strips)
@@ -576,6 +712,20 @@ int ising_sweep_info(ising_ctx *c, int *fused, int *max_sweeps_per_launch) {
 	const bool tiled = !f && !deep && !quad && sweeps_tiled(c, 2);
 	if (fused) *fused = ((f || deep) && c->split && !c->cfg.XSL) ? 3 : ((f || deep) ? 1 : (quad ? 4 : (tiled ? 2 : 0)));
 	if (max_sweeps_per_launch) *max_sweeps_per_launch = f ? ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y) : (deep ? c->ghost() / 2 : (quad ? c->quad_T : (tiled ? c->tile_sweeps : 0)));
+	return ISING_OK;
+}
+
+int ising_shape_guard_info(ising_ctx *c, ising_guard_info *out) {
+	if (!c || !out) return fail(ISING_E_ARG, "null argument");
+	if (c->guard.state == 1 || c->guard.state == 2) if (int rc = guard_settle(c)) return rc; // (a timed launch in flight: its verdict first -- blocks)
+	const ising_ctx::ShapeGuard &g = c->guard;
+	memset(out, 0, sizeof(*out));
+	out->state = g.state;
+	out->switched = g.switched ? 1 : 0;
+	out->launches_timed = g.launches;
+	out->table_strip_rows = g.base_H; out->table_wg_per_cu = g.base_wg;
+	out->strip_rows = c->H; out->wg_per_cu = guard_wg_now(c);
+	out->expected_flips_per_ns = g.expected; out->table_flips_per_ns = g.base_rate; out->kept_flips_per_ns = g.best_rate;
 	return ISING_OK;
 }
 

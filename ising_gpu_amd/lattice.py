@@ -194,6 +194,16 @@ class IsingSlab:
         check(self._lib.ising_sweep_form(self._h, nsweeps, *[C.byref(x) for x in v]))
         return tuple(x.value for x in v)
 
+    def guard_info(self) -> dict:
+        """The run-time guard under the fused launches' shape table (ising_shape_guard_info): state (0 off, 1 timing the table's shape, 2 trying neighbours,
+        3 settled), whether it switched, the table's shape and rate, the shape and rate that stayed.  Blocks while a timed launch is in flight."""
+        class _G(C.Structure):
+            _fields_ = [(k, C.c_int32) for k in ("state", "switched", "launches_timed", "table_strip_rows", "table_wg_per_cu", "strip_rows", "wg_per_cu")] + \
+                       [(k, C.c_float) for k in ("expected_flips_per_ns", "table_flips_per_ns", "kept_flips_per_ns")]
+        g = _G()
+        check(self._lib.ising_shape_guard_info(self._h, C.byref(g)))
+        return {k: getattr(g, k) for k, _ in _G._fields_}
+
     @property
     def tiled(self) -> bool:
         """True when sweep() issues tile launches (small lattices on the dense layout: several sweeps per launch, every workgroup on a

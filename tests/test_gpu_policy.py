@@ -26,6 +26,7 @@ SHAPES = [  # (X, Y): lattice columns, rows
 def _rate(X, Y, H=0, wgs=0, monkeypatch=None, check=None, split=None):
     """flips/ns of ising_sweep on a lone X x Y lattice at strip height H and wgs workgroups per CU (0: the library's choice), in the form of launch the library
     picks (split = None) or the one asked for (0: fused, 1: split); best of 3 pieces of ~25 ms"""
+    monkeypatch.setenv("ISING_GUARD", "0")  # (the table's choice against its neighbours AS ASKED FOR: the run-time guard would move a neighbour off its cliff)
     for k, v in (("ISING_FUSED_WGS", 256 * wgs if wgs else None), ("ISING_SPLIT", split)):
         if v is None:
             monkeypatch.delenv(k, raising=False)
@@ -193,3 +194,71 @@ def test_ring_slab_choice_within_3_percent_of_its_neighbours(gpu, warm_clock, mo
     print(f"ring of one {Y} x {X}: library H={H} wgs={wg} split={int(is_split)} {mine:.0f} flips/ns; neighbours "
           + ", ".join(f"H={h} wgs={w} {nm}: {r:.0f}" for (h, w, nm), r in cells.items()))
     assert mine >= (1.0 - TOL) * best, f"ring slab {Y} x {X}: the library's H={H}, {wg} per CU runs {mine:.0f} flips/ns, a neighbour {best:.0f}: {cells}"
+
+
+# ---- the run-time guard under the tables (ising_update.cpp: guard_*) -------------------------------------------------------------------------
+def _guarded_run(X, Y, monkeypatch, env, launches=6):
+    """a fresh slab under `env`: `launches` full-length fused launches through ising_sweep (the guard acts between them), then the rate of three more calls; returns
+    (flips/ns, guard record, counts, sweeps done)"""
+    for k in ("ISING_FUSED_WGS", "ISING_SPLIT", "ISING_GUARD", "ISING_GUARD_EXPECT", "ISING_FUSED_MAX_SWEEPS"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, str(v))
+    monkeypatch.setenv("ISING_ABORT_POLLS", "400000")
+    with ig.IsingSlab(X, Y, seed=1234, temp=TC, layout=ig.LAYOUT_BALLOT) as s:
+        assert s.fused
+        per = s.max_sweeps_per_launch
+        s.init()
+        for _ in range(launches):
+            s.sweep(per)
+        info = s.guard_info()
+        rate = max(X * Y * per / (s.sweep_timed(per) * 1e6) for _ in range(3))
+        return rate, info, s.count(), s.launch_shape()[:2]
+
+
+def test_guard_tries_the_neighbours_and_keeps_the_fastest(gpu, warm_clock, monkeypatch):
+    """The mechanism, made deterministic: with an expectation nothing can meet (ISING_GUARD_EXPECT) the table's shape is timed twice, every neighbour once, and the
+    fastest of them stays -- within noise of the best of the same shapes asked for one by one; the spins do not depend on any of it."""
+    X, Y = 8192, 8192
+    r_off, g_off, counts_off, shape_off = _guarded_run(X, Y, monkeypatch, {"ISING_GUARD": 0, "ISING_SPLIT": 0})
+    assert g_off["state"] == 0 and g_off["switched"] == 0
+    r_on, g, counts_on, shape_on = _guarded_run(X, Y, monkeypatch, {"ISING_GUARD": 1, "ISING_SPLIT": 0, "ISING_GUARD_EXPECT": 1e6})
+    assert counts_on == counts_off  # (same seed, same number of sweeps: a shape never changes results)
+    assert g["state"] == 3 and (g["table_strip_rows"], g["table_wg_per_cu"]) == shape_off
+    assert 4 <= g["launches_timed"] <= 10  # the table's shape twice, two or three neighbours, a step or two further where it kept paying
+    assert (g["strip_rows"], g["wg_per_cu"]) == shape_on and g["kept_flips_per_ns"] >= g["table_flips_per_ns"] > 0
+    print(f"{Y} x {X}: table {shape_off} {g['table_flips_per_ns']:.0f} flips/ns in the guard's launch, kept {shape_on} {g['kept_flips_per_ns']:.0f}; afterwards {r_on:.0f} against {r_off:.0f} without the guard")
+    assert r_on >= 0.95 * r_off
+    # a healthy box meets the expectation at once: one timed launch, nothing tried
+    _, g2, counts2, shape2 = _guarded_run(X, Y, monkeypatch, {"ISING_GUARD": 1, "ISING_SPLIT": 0})
+    assert counts2 == counts_off
+    assert g2["state"] == 3 and (g2["switched"] == 1) == (shape2 != shape_off) and g2["kept_flips_per_ns"] >= g2["table_flips_per_ns"]
+    # ... and on the plateau a healthy box settles after one timed launch
+    _, g3, _, shape3 = _guarded_run(32768, 32768, monkeypatch, {"ISING_GUARD": 1}, launches=3)
+    if g3["table_flips_per_ns"] >= 0.8 * g3["expected_flips_per_ns"]:
+        assert g3["state"] == 3 and g3["switched"] == 0 and g3["launches_timed"] == 1
+
+
+@pytest.mark.parametrize("X,Y", [(8192, 1536), (16384, 2176), (16384, 16384), (65536, 1024)])
+def test_guard_recovers_from_an_injected_cliff(gpu, warm_clock, monkeypatch, X, Y):
+    """An injected bad shape -- ISING_FUSED_WGS one step past a cliff of THIS box, found here by measuring the grids of one to six workgroups per CU with the guard off --
+    recovers to within 5 % of its best neighbour inside the guard's handful of launches (the table's shape twice, each neighbour once, on down the slope while it
+    pays); results bit-identical."""
+    rates = {}
+    for wg in range(1, 7):
+        try:
+            rates[wg], _, _, _ = _guarded_run(X, Y, monkeypatch, {"ISING_GUARD": 0, "ISING_SPLIT": 0, "ISING_FUSED_WGS": 256 * wg}, launches=1)
+        except ig.IsingError:
+            rates[wg] = 0.0
+            continue
+    cliff = [wg for wg in range(2, 7) if rates[wg] < 0.85 * rates[wg - 1]]
+    print(f"{Y} x {X}: flips/ns by workgroups per CU {', '.join(f'{w}: {r:.0f}' for w, r in rates.items())}")
+    if not cliff:
+        pytest.skip(f"{Y} x {X}: no cliff between one and six workgroups per CU on this box")
+    wg = cliff[0]
+    best_nb = max(rates[wg - 1], rates.get(wg + 1, 0.0))
+    r, g, c3, shape = _guarded_run(X, Y, monkeypatch, {"ISING_GUARD": 1, "ISING_SPLIT": 0, "ISING_FUSED_WGS": 256 * wg}, launches=10)
+    print(f"{Y} x {X}: injected {wg} per CU ({rates[wg]:.0f} flips/ns): the guard kept {shape} after {g['launches_timed']} timed launches, {r:.0f} flips/ns (best neighbour {best_nb:.0f})")
+    assert g["state"] == 3 and g["switched"] == 1 and g["launches_timed"] <= 10
+    assert r >= 0.95 * best_nb
+    assert c3 == _guarded_run(X, Y, monkeypatch, {"ISING_GUARD": 0, "ISING_SPLIT": 0, "ISING_FUSED_WGS": 256 * wg}, launches=10)[2]  # (same seed, same sweeps)

@@ -8,6 +8,7 @@ import argparse
 import os
 import sys
 import time
+os.environ.setdefault("ISING_GUARD", "0")  # (a probe measures the shapes it asks for: the run-time guard would move them)
 
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 import torch  # noqa: E402,F401

@@ -5,6 +5,7 @@ Usage: small_fused_probe.py [X Y ...]"""
 import os
 import sys
 import time
+os.environ.setdefault("ISING_GUARD", "0")  # (a probe measures the shapes it asks for: the run-time guard would move them)
 
 ROOT = __file__.rsplit("/", 2)[0]
 sys.path.insert(0, ROOT)

@@ -4,6 +4,7 @@ workgroups per CU.  profiles/wide_probe_r04.txt      Usage: wide_probe.py [X Y .
 import os
 import sys
 import time
+os.environ.setdefault("ISING_GUARD", "0")  # (a probe measures the shapes it asks for: the run-time guard would move them)
 
 ROOT = __file__.rsplit("/", 2)[0]
 sys.path.insert(0, ROOT)
