@@ -295,8 +295,8 @@ def main():
     ap.add_argument("--ring", choices=["native", "torch"], default="native",
                     help="N > 1: the ring inside libising_hip.so (RCCL on a second stream) or the torch.distributed one")
     ap.add_argument("--transport", choices=["auto", "rccl", "ipc"], default="auto",
-                    help="N > 1, native ring: RCCL send/recv, the RCCL-free peer transport over hipIpcMemHandle, or (auto) the first "
-                         "of the two that comes up on every rank")
+                    help="N > 1, native ring: the peer transport over hipIpcMemHandle (primary: its exchange runs inside the launch), RCCL send/recv "
+                         "(fallback), or (auto) the first of the two, in that order, that comes up on every rank")
     ap.add_argument("--exchange", choices=["p2p", "allgather"], default=None,
                     help="N > 1, torch ring: how the edge rows travel (forces --ring torch)")
     ap.add_argument("--preheat-ms", type=float, default=150.0,
@@ -381,7 +381,8 @@ def main():
             # every 32 sweeps and run fused launches in between (csrc/ising_ring.cpp: sweep_deep)
             slab = ig.IsingSlab(args.x, args.y, device=local_rank, seed=args.seed, temp=ig.CRIT_TEMP_F32, nslabs=world, slab=rank,
                                 strip_rows=args.strip_rows, layout=layout, ring_halo=world == 1)
-            transports = {"auto": ("ipc",) if shared else ("rccl", "ipc"), "rccl": ("rccl",), "ipc": ("ipc",)}[args.transport]
+            # (auto: the peer transport first -- its exchange runs inside the launch, DESIGN 5 --, RCCL behind it; ranks that share a device have only the first)
+            transports = {"auto": ("ipc",) if shared else ("ipc", "rccl"), "rccl": ("rccl",), "ipc": ("ipc",)}[args.transport]
             ring = ig.open_native_ring(slab, log=log, transports=transports, attempts=attempts)
             if ring is None:
                 slab.close()

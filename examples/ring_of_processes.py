@@ -21,7 +21,7 @@ shared = world > ndev                                                   # more r
 dist.init_process_group("gloo" if shared else "nccl")
 X, Y = 32768, 8192                                                      # per rank
 slab = ig.IsingSlab(X, Y, device=device, seed=1234, temp=ig.CRIT_TEMP_F32, nslabs=world, slab=rank)
-ring = ig.open_native_ring(slab, transports=("ipc",) if shared else ("rccl", "ipc"))
+ring = ig.open_native_ring(slab, transports=("ipc",) if shared else ("ipc", "rccl"))
 assert ring is not None, "no ring transport came up"
 ring.init()                                                             # (open_native_ring swept once to try the transport: start over)
 ring.sweep(128)

@@ -19,7 +19,7 @@
 //
 // quad_pass_k = ONE launch per pass of T sweeps:
 //   tiles     workgroup t < ntiles: C row groups x the whole width of both colours + HG halo row groups per side in LDS; 2 T
-//             levels over a region that shrinks a row per level; the masks of the level after next on their way into
+//             levels over a region that shrinks a row per level; the masks of the next level on their way into
 //             accumulation registers; reads one lattice buffer, writes its tile to the other (quad_word_part)
 //   drawing   the workgroups behind them: the masks of the NEXT pass -- (level, row group, block) -> 1 KiB (c3, c4 per word),
 //             scalar stores straight into the mask buffer; no lattice, no barrier, no order (quad_draw_part)
@@ -36,7 +36,16 @@ namespace {
 constexpr uint64_t Q_LANE0 = 0x0001000100010001ull;  // tx = 0 of each row
 constexpr uint64_t Q_LANE15 = 0x8000800080008000ull; // tx = 15
 constexpr uint64_t Q_EVEN = 0x0000FFFF0000FFFFull;   // rows 4 R, 4 R + 2
-constexpr int Q_DEPTH = 3;                           // levels of masks in flight per wave (sets of accumulation registers)
+// Levels of masks in flight per wave.  Round 5 kept three (this level's, the next two on their way); round 6 measured two against it (A/B builds, 2 .. 5): the
+// latency of a level's 1 KiB per item is covered by ONE level of word work, and what the third set cost -- eight to twelve accumulation registers, a level loop
+// unrolled six times instead of twice -- was worth 3-6 % wherever the tiles are many (31 x 2048^2 2420 -> 2572 flips/ns, 4096 x 16384 2359 -> 2480, 6144^2 2278 ->
+// 2364, 12288 x 768 at three items a wave 1496 -> 1664: 88 registers instead of 100) and nothing where they are few (2048^2 2227 / 2243); four and five: slower
+// everywhere (profiles/quad_depth_probe_r06.txt).
+#ifndef ISING_QUAD_DEPTH
+#define ISING_QUAD_DEPTH 2
+#endif
+constexpr int Q_DEPTH = ISING_QUAD_DEPTH;            // levels of masks in flight per wave (sets of accumulation registers)
+constexpr int Q_UNROLL = (Q_DEPTH % 2) ? 2 * Q_DEPTH : Q_DEPTH; // levels a turn of the level loop: colour and mask set of each are compile-time
 
 __device__ __forceinline__ constexpr int qword(int j, int m, int q) { return 32 * j + 4 * m + q; }
 __device__ __forceinline__ int qword_of_site(int j, int s) {
@@ -162,13 +171,14 @@ __device__ __forceinline__ void quad_draw_part(const QuadDrawParams &p, long lon
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// The accept masks of a word wave's items wait in ACCUMULATION registers: a[4 n .. 4 n + 3], n = set * MAXI + item (three sets = three levels in flight), and
+// The accept masks of a word wave's items wait in ACCUMULATION registers: a[4 n .. 4 n + 3], n = set * MAXI + item (Q_DEPTH sets = levels in flight: two), and
 // one more quad that takes the loads of items a level does not have (every level issues exactly MAXI loads: vmcnt counts them).  Loaded and read by inline
 // assembly alone -- the compiler has no use for these registers in a kernel without MFMA and without spills, knows nothing of loads in flight, and so cannot
 // copy one early (tracked loads into vector registers were fenced with vmcnt(0) on either side: no prefetch left).  The build checks the ISA: no accumulation
 // register outside these statements (tools/check_asm_loads.py --quad).
 #define QM_CASES(X) X(0, 0, 1, 2, 3) X(1, 4, 5, 6, 7) X(2, 8, 9, 10, 11) X(3, 12, 13, 14, 15) X(4, 16, 17, 18, 19) X(5, 20, 21, 22, 23) X(6, 24, 25, 26, 27) \
-	X(7, 28, 29, 30, 31) X(8, 32, 33, 34, 35) X(9, 36, 37, 38, 39) X(10, 40, 41, 42, 43) X(11, 44, 45, 46, 47) X(12, 48, 49, 50, 51)
+	X(7, 28, 29, 30, 31) X(8, 32, 33, 34, 35) X(9, 36, 37, 38, 39) X(10, 40, 41, 42, 43) X(11, 44, 45, 46, 47) X(12, 48, 49, 50, 51) \
+	X(13, 52, 53, 54, 55) X(14, 56, 57, 58, 59) X(15, 60, 61, 62, 63) X(16, 64, 65, 66, 67)
 template <int N>
 __device__ __forceinline__ void qm_load(int off, const void *base) {
 #define QM_L(I, A, B, C, D) if constexpr (N == I) asm volatile("global_load_dwordx4 a[" #A ":" #D "], %0, %1" :: "v"(off), "s"(base) : "memory", "a" #A, "a" #B, "a" #C, "a" #D);
@@ -184,8 +194,8 @@ __device__ __forceinline__ void qm_read(uint32_t &x0, uint32_t &x1, uint32_t &x2
 
 // ---- words: `nlev` levels (black first) of tile `tile`.  Everything that indexes is wave-uniform and lives on the scalar unit (a lone wave issues an
 // instruction every four or five cycles whatever its kind); a wave works on its one to three items in turn (pairs with all LDS reads first cost the registers
-// of a sixth wave per SIMD: ISING_QUAD_PAIR); the masks of the level after next are on their way into accumulation registers (three sets, the level loop
-// unrolled by six = colours x sets).
+// of a sixth wave per SIMD: ISING_QUAD_PAIR); the masks of the next level are on their way into accumulation registers (two sets -- Q_DEPTH --, the level loop
+// unrolled by two = colours x sets).
 template <int MAXI>
 __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile, int wi, int lane, int NW, uint64_t *q_lds) {
 	const int gx = p.gx, NRG = p.NRG, HG = p.HG;
@@ -259,8 +269,7 @@ __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile
 			else qm_load<Q_DEPTH * MAXI>(lane16, masks);
 		});
 	};
-	fetch(0, std::integral_constant<int, 0>{});
-	fetch(1, std::integral_constant<int, 1>{});
+	static_for<Q_DEPTH - 1>([&](auto D) { fetch(D.value, std::integral_constant<int, D.value>{}); });
 	// the tile and its halo row groups, both colours
 	for (int cg = wi; cg < 2 * NG; cg += NW) { // (row group, colour) by wave, its gx x 64 words by lane
 		const int c = cg >= NG, g = cg - c * NG;
@@ -306,7 +315,7 @@ __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile
 		if (!meas) {
 			fetch(L + Q_DEPTH - 1, std::integral_constant<int, (SLOT.value + Q_DEPTH - 1) % Q_DEPTH>{});
 			QTRC(1); // prefetch issue
-			asm volatile("s_waitcnt vmcnt(%0)" :: "n"((Q_DEPTH - 1) * MAXI) : "memory"); // this level's masks have landed (the two levels behind them may still be out)
+			asm volatile("s_waitcnt vmcnt(%0)" :: "n"((Q_DEPTH - 1) * MAXI) : "memory"); // this level's masks have landed (the level(s) behind them may still be out)
 		}
 		const uint32_t S_w = lat_w + (c ? 0u : plane_b), D_w = lat_w + (c ? plane_b : 0u);
 		// rows whose side neighbour is site s - 1 (readBack, optimized/main.cu:542): the even rows of a black level, the odd rows of a white one; the lanes
@@ -370,8 +379,8 @@ __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile
 		if (!meas) __syncthreads();
 		QTRC(4); // barrier
 	};
-	for (int L0 = 0; L0 < p.nlev; L0 += 6) { // (six levels a turn: the colour and the mask set of each are compile-time)
-		static_for<6>([&](auto I) {
+	for (int L0 = 0; L0 < p.nlev; L0 += Q_UNROLL) { // (two levels a turn at two sets: the colour and the mask set of each are compile-time)
+		static_for<Q_UNROLL>([&](auto I) {
 			if (L0 + I.value < p.nlev) level(std::integral_constant<int, I.value & 1>{}, std::integral_constant<int, I.value % Q_DEPTH>{}, std::false_type{}, L0 + I.value);
 		});
 	}
@@ -422,8 +431,11 @@ __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile
 // draws on a second stream -- ran 1950 flips/ns at 2048^2 in a fresh process and 660 in one whose earlier contexts had created high-priority streams).
 // (one and two items a wave: six waves per SIMD -- two workgroups of twelve waves per CU, a tile next to a drawing workgroup -- are worth 80 registers a lane;
 // three items: 128, four waves per SIMD -- a tile of sixteen waves has its CU to itself; four: eight waves a workgroup at most)
+#ifndef ISING_QUAD_WPE // waves per SIMD the one- and two-item instantiations are compiled for (A/B: 5 = 96 registers, workgroups of ten waves)
+#define ISING_QUAD_WPE 6
+#endif
 template <int MAXI>
-__global__ void __launch_bounds__(MAXI <= 3 ? 1024 : 512) __attribute__((amdgpu_waves_per_eu(MAXI <= 2 ? 6 : (MAXI == 3 ? 4 : 2)))) quad_pass_k(const QuadPassParams p) {
+__global__ void __launch_bounds__(MAXI <= 3 ? 1024 : 512) __attribute__((amdgpu_waves_per_eu(MAXI <= 2 ? ISING_QUAD_WPE : (MAXI == 3 ? 4 : 2)))) quad_pass_k(const QuadPassParams p) {
 	extern __shared__ __attribute__((aligned(16))) uint64_t q_lds[];
 	const int lane = threadIdx.x & 63;
 	const int wi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -545,6 +557,31 @@ static hipError_t launch_pass_t(const QuadPassParams &p, int waves, long long gr
 	return hipGetLastError();
 }
 
+// workgroups of `waves` waves a CU holds (hipOccupancyMaxActiveBlocksPerMultiprocessor, remembered per instantiation, size and LDS segment)
+static int quad_pass_occupancy(int mi, int waves, size_t lds) {
+	static std::mutex mu;
+	static struct { int mi, waves; size_t lds; int n; } memo[16];
+	static int nmemo = 0;
+	std::lock_guard<std::mutex> lock(mu);
+	for (int k = 0; k < nmemo; k++) if (memo[k].mi == mi && memo[k].waves == waves && memo[k].lds == lds) return memo[k].n;
+	int n = 0;
+	hipError_t e = hipErrorInvalidValue;
+	switch (mi) {
+	case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, quad_pass_k<1>, waves * 64, lds); break;
+	case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, quad_pass_k<2>, waves * 64, lds); break;
+	case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, quad_pass_k<3>, waves * 64, lds); break;
+	case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, quad_pass_k<4>, waves * 64, lds); break;
+	default: break;
+	}
+	if (e != hipSuccess || n < 1) { // (the rule of thumb of round 5)
+		(void)hipGetLastError();
+		const int regs = std::max(1, ((mi <= 1 ? 8 : (mi <= 2 ? 6 : (mi == 3 ? 4 : 3))) * 4) / waves);
+		n = std::max(1, std::min<int>(regs, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
+	}
+	if (nmemo < 16) memo[nmemo++] = {mi, waves, lds, n};
+	return n;
+}
+
 // `p.w.nlev` = 0: draws only (the first launch of a call); `p.d.nlev` = 0: words only (its last)
 hipError_t launch_quad_pass(QuadPassParams &p, int waves, hipStream_t stream) {
 	const int mi0 = quad_word_maxi(p.w, waves);
@@ -553,10 +590,9 @@ hipError_t launch_quad_pass(QuadPassParams &p, int waves, hipStream_t stream) {
 	const long long all_tiles = (long long)p.w.tiles_per_lat * nrep;
 	if (all_tiles > 0x3fffffffLL) return hipErrorInvalidValue;
 	p.ntiles = p.w.nlev > 0 ? (int)all_tiles : 0;
-	// workgroup slots of the chip: eight waves per SIMD at one item a wave, six at two (80 registers), three beyond
-	// (the drawing workgroups of the grid reserve the tiles' LDS segment as well -- one launch, one size --: what a CU's 160 KiB hold bounds them too)
-	const int per_cu_regs = std::max(1, ((mi0 <= 1 ? 8 : (mi0 <= 2 ? 6 : (mi0 == 3 ? 4 : 3))) * 4) / waves); // (one item a wave: under 64 registers; three: 128)
-	const int per_cu = std::max(1, std::min<int>(per_cu_regs, (int)((160 * 1024) / std::max<size_t>(quad_pass_lds_bytes(p.w, waves), 1))));
+	// workgroup slots of the chip: what the runtime says a CU holds of this instantiation at this workgroup size and LDS segment (registers -- eight waves per SIMD
+	// at one item a wave, six at two, four at three -- and the tiles' LDS segment, which the drawing workgroups of the grid reserve as well: one launch, one size)
+	const int per_cu = std::max(1, quad_pass_occupancy(mi0, waves, quad_pass_lds_bytes(p.w, waves)));
 	const int cap = std::max(4, p.cus * per_cu) & ~3;
 	long long draw_wgs = 0;
 	if (p.d.nlev > 0) {

@@ -532,10 +532,12 @@ def _agree(ok: bool) -> bool:
     return bool(int(t[0]))
 
 
-def open_native_ring(slab, log=None, transports=("rccl", "ipc"), attempts=None):
+def open_native_ring(slab, log=None, transports=("ipc", "rccl"), attempts=None):
     """The library's own ring on a slab that owns its buffer (ring slabs on the ballot layout then keep ghost rows 64 deep
-    and exchange every 32 sweeps, csrc/ising_ring.cpp: sweep_deep): RCCL send/recv first, then the RCCL-free peer transport
-    over hipIpcMemHandle (`transports`; ranks sharing a device go straight to the second -- RCCL refuses them).  Every
+    and exchange every 32 sweeps, csrc/ising_ring.cpp: sweep_deep).  Primary transport (round 6): the peer transport over
+    hipIpcMemHandle -- direct stores into the neighbours' rows, the reference's own mechanism across processes (optimized/main.cu:1496-1537,
+    :1637-1642), the one whose exchange runs INSIDE the launch and whose launches carry several exchange epochs; RCCL send/recv is the
+    fallback (its kernel runs when the launch's workgroups retire).  Ranks sharing a device can only use the first -- RCCL refuses them.  Every
     rank takes the same decision: the outcome of each attempt is agreed on before anyone moves on.  None when no transport
     comes up on every rank (the caller then builds a torch-owned slab and calls open_ring for the torch.distributed rings).
     `attempts` (a list, optional) receives one record per transport tried on THIS rank: {"transport", "ok", "error", "all_ranks_ok", "seconds"}."""
@@ -547,7 +549,7 @@ def open_native_ring(slab, log=None, transports=("rccl", "ipc"), attempts=None):
             ring = NativeRing(slab, transport=tr)
             ring.init()
             ring.sweep(1)  # one real sweep through the transport before it is trusted
-            ring.quiesce()
+            ring.slab.rank_wait(ring.probe_timeout_ms)  # (bounded, like the first exchange: a transport that stalls is an error to fall back from, not a hang)
             torch.cuda.synchronize()
             ok = True
         except Exception as e:  # noqa: BLE001 -- any transport failure means: the caller tries the next one

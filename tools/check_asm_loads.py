@@ -29,35 +29,48 @@ def operands(line):
 def check_quad(path):
     """ising_quad.hip: the word passes keep their accept masks in accumulation registers that inline assembly alone loads (global_load_dwordx4 a[..]) and
     reads (v_accvgpr_read_b32) -- the compiler must have no use of its own for any of them in those kernels (no copy of a register whose load is in flight
-    can exist then), and nothing may spill."""
-    bad, kern, in_asm, nasm, mine = 0, None, False, 0, 0
-    for i, ln in enumerate(open(path).read().split("\n")):
+    can exist then), and nothing may spill.  The masks' registers are a[0 .. n): Q_DEPTH sets of MAXI quads and the spare one -- n is read off the inline
+    assembly itself (its highest register), so the check follows the kernel's depth."""
+    bad = 0
+    lines = open(path).read().split("\n")
+
+    def acc(body):
+        return [int(x) for x in re.findall(r"\ba(\d+)\b", body)] + [int(y) for x in re.findall(r"\ba\[(\d+):(\d+)\]", body) for y in x]
+
+    start = None
+    for i, ln in enumerate(lines + [""]):
         m = re.match(r"^(_Z\w*quad_pass_kILi(\d+)E\w*):", ln)
         if m:
-            kern, nasm, mine = m.group(1), 0, 12 * int(m.group(2)) + 4  # a[0 .. 12 MAXI + 3]: three sets of MAXI quads and the spare one
-        if "#ASMSTART" in ln:
-            in_asm = True
-        if "#ASMEND" in ln:
-            in_asm = False
-        if not kern:
+            start, kern = i, m.group(1)
+        if start is None or "s_endpgm" not in ln:
             continue
-        body = ln.split(";")[0].strip()
-        used = [int(x) for x in re.findall(r"\ba(\d+)\b", body)] + [int(y) for x in re.findall(r"\ba\[(\d+):(\d+)\]", body) for y in x]
-        touches = any(r < mine for r in used)
-        if touches and in_asm:
-            nasm += 1
-        if touches and not in_asm:  # (accumulation registers above the masks' are the compiler's to spill into)
-            print(f"{path}:{i + 1}: {kern}: the compiler uses an accumulation register of the masks: {body}")
-            bad += 1
-        if re.match(r"\s*(scratch_|buffer_(load|store).*offen)", body):
-            print(f"{path}:{i + 1}: {kern}: scratch access (a spill?): {body}")
-            bad += 1
-        if "s_endpgm" in ln:
-            print(f"{kern}: {nasm} inline-assembly statements on accumulation registers, none by the compiler")
-            if nasm == 0:
-                print(f"{path}: {kern}: no accumulation-register statement found: the check looks at the wrong thing")
+        # one kernel: lines[start .. i]
+        in_asm, mine, marks = False, 0, []
+        for j in range(start, i + 1):
+            if "#ASMSTART" in lines[j]:
+                in_asm = True
+            if "#ASMEND" in lines[j]:
+                in_asm = False
+            marks.append(in_asm)
+            if in_asm:
+                mine = max([mine] + [r + 1 for r in acc(lines[j].split(";")[0])])
+        nasm = 0
+        for j in range(start, i + 1):
+            body = lines[j].split(";")[0].strip()
+            touches = any(r < mine for r in acc(body))
+            if touches and marks[j - start]:
+                nasm += 1
+            if touches and not marks[j - start]:  # (accumulation registers above the masks' are the compiler's to spill into)
+                print(f"{path}:{j + 1}: {kern}: the compiler uses an accumulation register of the masks: {body}")
                 bad += 1
-            kern = None
+            if re.match(r"\s*(scratch_|buffer_(load|store).*offen)", body):
+                print(f"{path}:{j + 1}: {kern}: scratch access (a spill?): {body}")
+                bad += 1
+        print(f"{kern}: {nasm} inline-assembly statements on accumulation registers a[0 .. {mine}), none by the compiler")
+        if nasm == 0:
+            print(f"{path}: {kern}: no accumulation-register statement found: the check looks at the wrong thing")
+            bad += 1
+        start = None
     return bad
 
 

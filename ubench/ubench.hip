@@ -94,6 +94,19 @@ __global__ void __launch_bounds__(256) NAME(unsigned* out, unsigned s) { \
 KERNEL64(k_mad64,   "v_mad_u64_u32 %0, vcc, %1, %2, %0")
 KERNEL64(k_mad64z,  "v_mad_u64_u32 %0, vcc, %1, %2, 0")
 KERNEL64(k_lshladd64, "v_lshl_add_u64 %0, %0, 1, %0")
+// round 6: the quad word phase's candidates (64-bit shifts against funnel shifts, packed 16-bit shifts, bit-field insert, and-or)
+KERNEL64(k_lshl64,    "v_lshlrev_b64 %0, 16, %0")
+KERNEL64(k_lshr64,    "v_lshrrev_b64 %0, 15, %0")
+KERNEL64(k_lshl64v,   "v_lshlrev_b64 %0, %1, %0")
+KERNEL32(k_pklshl16,  "v_pk_lshlrev_b16 %0, 1, %0 op_sel_hi:[0,1]")
+KERNEL32(k_pklshl16v, "v_pk_lshlrev_b16 %0, %1, %0")
+KERNEL32(k_bfi,       "v_bfi_b32 %0, %1, %0, %1")
+KERNEL32(k_andor,     "v_and_or_b32 %0, %0, %1, %1")
+KERNEL32(k_or3,       "v_or3_b32 %0, %0, %1, %1")
+KERNEL32(k_alignbitv, "v_alignbit_b32 %0, %0, %1, 16")
+KERNEL32(k_accread,   "v_accvgpr_read_b32 %0, a0")
+KERNEL32(k_readlane,  "v_readlane_b32 s20, %0, 3")
+KERNEL32(k_bperm,     "ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)")
 
 // Full Philox4x32-10 block throughput, generic (all 10 rounds with vector multiplies)
 __device__ __forceinline__ unsigned x3(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
@@ -195,6 +208,7 @@ int main() {
            sc / sr, wc, sc / sr * wc * 1e-6, sc / blocks / (ITERS * 4.0 * 8) / 1.0);
   }
   RUN(k_mul24) RUN(k_mad24) RUN(k_mullo) RUN(k_mulhi) RUN(k_mad64) RUN(k_mad64z) RUN(k_lshladd64)
+  RUN(k_lshl64) RUN(k_lshr64) RUN(k_lshl64v) RUN(k_pklshl16) RUN(k_pklshl16v) RUN(k_bfi) RUN(k_andor) RUN(k_or3) RUN(k_alignbitv) RUN(k_accread) RUN(k_readlane) RUN(k_bperm)
   {
     int nblk = 2048;
     float ms = time_ms([&]{ hipLaunchKernelGGL(k_philox<0>, dim3(blocks), dim3(256), 0, 0, out, 0x1234567u, 0x89abcdeu, nblk); });
