@@ -228,7 +228,10 @@ __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile
 	long long qt_last = wall_clock64();
 	const long long qt_start = qt_last;
 #endif
-	__builtin_amdgcn_s_setprio(3); // (the draws of the pass to come share the chip: a word pass is a chain of short levels, theirs is throughput)
+#if !defined(ISING_QUAD_ABL_NOPRIO)
+	__builtin_amdgcn_s_setprio(3);
+#endif
+	// (the draws of the pass to come share the chip: a word pass is a chain of short levels, theirs is throughput)
 	auto wrapR = [&](int g) { // row group of the lattice behind local group g (no division: a halo wraps around a short lattice a few times at most)
 		int R = A - HG + g;
 		while (R < 0) R += NRG;
@@ -263,6 +266,9 @@ __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile
 	}
 	// the masks of level Lp into set SLOT: exactly MAXI loads (an item the level does not have, or a level past the pass's last: the spare quad)
 	auto fetch = [&](int Lp, auto SLOT) {
+#if defined(ISING_QUAD_ABL_NOFETCH) // (ablation builds: timing only, results wrong by design -- never in the product library)
+		return;
+#endif
 		static_for<MAXI>([&](auto K) {
 			const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)mk_tab[K.value], Lp & 63);
 			if (idx != ABSENT && Lp < p.nlev) qm_load<SLOT.value * MAXI + K.value>(lane16, reinterpret_cast<const char *>(masks) + (size_t)idx * 1024);
@@ -316,6 +322,7 @@ __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile
 			fetch(L + Q_DEPTH - 1, std::integral_constant<int, (SLOT.value + Q_DEPTH - 1) % Q_DEPTH>{});
 			QTRC(1); // prefetch issue
 			asm volatile("s_waitcnt vmcnt(%0)" :: "n"((Q_DEPTH - 1) * MAXI) : "memory"); // this level's masks have landed (the level(s) behind them may still be out)
+			QTRC(2); // wait for the masks
 		}
 		const uint32_t S_w = lat_w + (c ? 0u : plane_b), D_w = lat_w + (c ? plane_b : 0u);
 		// rows whose side neighbour is site s - 1 (readBack, optimized/main.cu:542): the even rows of a black level, the odd rows of a white one; the lanes
@@ -376,7 +383,9 @@ __device__ __forceinline__ void quad_word_part(const QuadWordParams &p, int tile
 			}
 		});
 		QTRC(3); // items
+#if !defined(ISING_QUAD_ABL_NOBARRIER)
 		if (!meas) __syncthreads();
+#endif
 		QTRC(4); // barrier
 	};
 	for (int L0 = 0; L0 < p.nlev; L0 += Q_UNROLL) { // (two levels a turn at two sets: the colour and the mask set of each are compile-time)
@@ -518,7 +527,7 @@ __global__ void __launch_bounds__(256) quad_convert_batch_k(const QuadRec *__res
 void quad_trace_dump() {
 	unsigned long long h[16] = {};
 	if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_qtrace), sizeof(h)) != hipSuccess || !h[7]) return;
-	static const char *names[6] = {"tile load", "prefetch issue", "(unused)", "items", "barrier", "store"};
+	static const char *names[6] = {"tile load", "prefetch issue", "mask wait", "items", "barrier", "store"};
 	fprintf(stderr, "quad word passes: %llu workgroups, %.1f levels each, %.2f us each (100 MHz clock)\n", h[7], (double)h[8] / h[7], (double)h[6] / h[7] / 100.0);
 	for (int i = 0; i < 6; i++) fprintf(stderr, "  %-15s %6.2f us per workgroup  %5.1f %%\n", names[i], (double)h[i] / h[7] / 100.0, 100.0 * h[i] / h[6]);
 	unsigned long long z[16] = {};
