@@ -186,6 +186,36 @@ def default_lattice_leg(args, device):
                     "`without_quad_path` = the same with ISING_QUAD=0 (round 4's tile launches)"}
 
 
+def batched_small_leg(args, device, lone_counts):
+    """31 lattices of 2048 x 2048 -- a temperature series at the reference's default size, T = 1.5 .. 3.0 -- as ONE batch (round 6: the tiles of all of them in one
+    quad_pass_k launch per pass, ising_batch_sweep).  The reference's own many-small-systems mode (--xsl/--ysl, optimized/main.cu:1423-1457; README.md:148-198: at
+    its big-lattice rate) knows one temperature.  Member 0 runs at T = Tc with the bench's seed: its counts after the same sweeps must be the lone lattice's."""
+    import ising_gpu_amd as ig
+    X = Y = 2048
+    n_lat, n = 31, 4096
+    temps = [ig.CRIT_TEMP_F32] + [1.5 + 0.05 * k for k in range(1, n_lat)]
+    slabs = [ig.IsingSlab(X, Y, device=device, seed=args.seed, temp=t) for t in temps]
+    try:
+        with ig.IsingBatch(slabs) as b:
+            b.init().sweep(256)
+            slabs[0].synchronize()
+            best = 0.0
+            for _ in range(4):  # 256 + 4 x 4096 sweeps = the default-lattice leg's
+                t0 = time.perf_counter()
+                b.sweep(n)
+                slabs[0].synchronize()
+                best = max(best, X * Y * n_lat * n / (time.perf_counter() - t0) * 1e-9)
+            counts0 = list(slabs[0].count())
+            shape = b.quad_shape
+    finally:
+        for s in slabs:
+            s.close()
+    return {"value": round(best, 1), "unit": "flips/ns", "lattices": n_lat, "lattice": f"{Y}x{X}", "sweeps_per_call": n, "frac": round(best * 1.5 / 8000.0, 4),
+            "form": "quad batch" if shape else "ballot batch", "tile_row_groups_sweeps_per_pass_waves": list(shape) if shape else None,
+            "member0_counts_equal_lone_lattice": counts0 == list(lone_counts),
+            "what": "31 lattices of the reference's default size at 31 temperatures in one launch per pass (ising_batch_sweep); best of four calls of 4096 sweeps, host clock"}
+
+
 def cpu_baseline(args):
     """Reported CPU baseline on the host cores of this box (rank 0, N=1 only): the byte-per-spin algorithm of
     basic_python/ising_basic.py restated in oracle/basic_cpu.c, BASELINE.json configs[0] (1024x1024, alpha 1,
@@ -717,6 +747,12 @@ def main():
                 leg2048["frac"] = leg2048["frac_hbm_1p5B"]  # (SURVEY 8(d)'s number for this lattice, as roofline.frac is for the headline's)
                 leg2048["frac_of_plateau"] = round(leg2048["value"] / (value / world), 4)  # against the large-lattice rate of the same job
                 line["default_lattice_2048"] = leg2048
+                try:
+                    legb = batched_small_leg(args, local_rank, leg2048["up_down"])
+                    legb["frac_of_plateau"] = round(legb["value"] / (value / world), 4)
+                    line["batched_31x2048"] = legb
+                except Exception as e:  # noqa: BLE001
+                    line["batched_31x2048"] = {"error": str(e)}
             except Exception as e:  # noqa: BLE001  (a side leg must not cost the line)
                 line["default_lattice_2048"] = {"error": str(e)}
         if not ringed and not args.no_cpu_baseline:

@@ -132,6 +132,8 @@ def test_bench_line_on_a_small_lattice(gpu, oracle_mod):
     assert abs(ref["achieved"] / 1.5 - rf["kernel_sites_ns"]) < 0.01 * rf["kernel_sites_ns"]  # the same launch time in both
     small = b["default_lattice_2048"]
     assert small["frac"] == small["frac_hbm_1p5B"] and 0 < small["frac_of_plateau"] < 2
+    many = b["batched_31x2048"]  # (round 6: 31 of them at 31 temperatures in one launch per pass)
+    assert many["member0_counts_equal_lone_lattice"] is True and many["lattices"] == 31 and many["value"] > 100 and many["frac_of_plateau"] > 0
     # the reference's methodology: the same sweeps with the counts read back every 16 inside the timed region
     leg = b["with_counts_every_16"]
     assert leg["final_counts_equal_first_leg"] is True and leg["counts_in_timed_region"] == 1 and leg["value"] > 100
