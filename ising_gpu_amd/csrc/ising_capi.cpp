@@ -347,8 +347,7 @@ void ising_host::quad_shape(int gx, long long rows, int *C, int *T, int *W) {
 		else if (rows < 2048) { C0 = 4; T0 = 16; W0 = 12; }
 		else if (rows < 4096) { C0 = 8; T0 = 16; W0 = 12; }
 		else if (rows < 8192) { C0 = 4; T0 = 12; W0 = 8; }
-		else if (rows < 16384) { C0 = 4; T0 = 8; W0 = 8; }
-		else { C0 = 8; T0 = 4; W0 = 8; }
+		else { C0 = 8; T0 = 8; W0 = 8; } // (round 6, two sets of masks in flight: 2048 x 8192 2553 against (4, 8, 8) 2340, 2048 x 16384 2601 against (8, 4, 8) 2462)
 	} else if (gx == 2) {
 		if (rows < 2048) { C0 = 4; T0 = 12; W0 = 16; }
 		else if (rows < 8192) { C0 = 4; T0 = 8; W0 = 12; }
@@ -356,14 +355,14 @@ void ising_host::quad_shape(int gx, long long rows, int *C, int *T, int *W) {
 	} else if (gx == 3) { // (from three blocks on: up to three items a wave of sixteen -- 100 registers, four waves per SIMD: a tile has its CU to itself)
 		if (rows < 1024) { C0 = 2; T0 = 8; W0 = 16; }       // 6144 x 512: 1361 against (4, 4, 16) 1076
 		else if (rows < 2048) { C0 = 4; T0 = 8; W0 = 16; }  // 6144 x 1024: 1984 against (4, 4, 12) 1670
-		else if (rows < 4096) { C0 = 8; T0 = 6; W0 = 16; }  // 6144 x 2048: 2057 against 1951
+		else if (rows < 4096) { C0 = 8; T0 = 6; W0 = 16; }  // 6144 x 2048: 2057 against 1951 (round 6: (2, 6, 12) 2100, inside the noise of two boxes)
 		else { C0 = 4; T0 = 4; W0 = 12; }
 	} else if (gx == 4) {
 		if (rows < 1024) { C0 = 2; T0 = 8; W0 = 16; }       // 8192 x 512: 1496 against 1231
 		else if (rows < 2048) { C0 = 4; T0 = 8; W0 = 16; }  // 8192 x 1024: 2043 against 1642
 		else { C0 = 4; T0 = 4; W0 = 16; }
 	} else if (gx <= 6) {
-		if (rows < 1024) { C0 = 2; T0 = 6; W0 = 16; }       // 10240 x 512: 1582, 12288 x 512: 1807 against (2, 2, 12) 1161 / 1229
+		if (rows < 768) { C0 = 2; T0 = 6; W0 = 16; }        // 10240 x 512: 1582, 12288 x 512: 1807 against (2, 2, 12) 1161 / 1229 (round 6: 12288 x 768 (4, 4, 16) 1797 against 1668)
 		else { C0 = 4; T0 = 4; W0 = 16; }                     // 10240 x 1024: 1748, 12288 x 1024: 1904 against 1427 / 1466
 	} else {
 		C0 = 2; T0 = 4; W0 = 16;                               // 14336 x 512: 1592, 16384 x 512: 1747 against (2, 2, 16) 1293 / 1313
