@@ -134,7 +134,7 @@ def first_contact_block(args, ig, torch, dist, world, rank, device, ndev, shared
         "ranks": [{k: r[k] for k in ("rank", "device", "pci_bus_id", "name", "peer_access_row", "lone_slab_flips_per_ns")} for r in per_rank],
         "distinct_devices": len(set(devices)),
         "ranks_own_their_device": len(set(devices)) == world and not shared,
-        "transport_attempts": {f"rank{r['rank']}": [(a["transport"] + ": " + ("ok" if a["ok"] else str(a["error"]))
+        "transport_attempts": {f"rank{r['rank']}": [(a["transport"] + ": " + ("ok" if a["ok"] else str(a["error"])) + (f" [{a['cross_check']}]" if a.get("cross_check") else "")
                                                     + ("" if a.get("all_ranks_ok", a["ok"]) == a["ok"] else " (another rank failed)")) for a in r["transport_attempts"]] for r in per_rank},
         "versions": {"hip": getattr(torch.version, "hip", None), "rccl": rccl, "torch": torch.__version__},
         "expected": {"lone_slab_flips_per_ns_sum": round(lone_sum, 1),

@@ -532,7 +532,7 @@ def _agree(ok: bool) -> bool:
     return bool(int(t[0]))
 
 
-def open_native_ring(slab, log=None, transports=("ipc", "rccl"), attempts=None):
+def open_native_ring(slab, log=None, transports=("ipc", "rccl"), attempts=None, cross_check=None, check_sweeps: int = 40):
     """The library's own ring on a slab that owns its buffer (ring slabs on the ballot layout then keep ghost rows 64 deep
     and exchange every 32 sweeps, csrc/ising_ring.cpp: sweep_deep).  Primary transport (round 6): the peer transport over
     hipIpcMemHandle -- direct stores into the neighbours' rows, the reference's own mechanism across processes (optimized/main.cu:1496-1537,
@@ -540,26 +540,37 @@ def open_native_ring(slab, log=None, transports=("ipc", "rccl"), attempts=None):
     fallback (its kernel runs when the launch's workgroups retire).  Ranks sharing a device can only use the first -- RCCL refuses them.  Every
     rank takes the same decision: the outcome of each attempt is agreed on before anyone moves on.  None when no transport
     comes up on every rank (the caller then builds a torch-owned slab and calls open_ring for the torch.distributed rings).
-    `attempts` (a list, optional) receives one record per transport tried on THIS rank: {"transport", "ok", "error", "all_ranks_ok", "seconds"}."""
+    `cross_check` (default: whenever more than one transport is listed): the first transport that comes up is not taken at its word -- the next one
+    runs the same `check_sweeps` sweeps from the same start (they cross an exchange of ghost rows), and the whole lattice's counts must agree; if they
+    do not, the LATER transport of the list is kept (RCCL, the one with the mileage between distinct devices) and the attempt record says so.  A
+    transport that has never run between two devices should not be able to cost a scaling run its parity.
+    `attempts` (a list, optional) receives one record per transport tried on THIS rank: {"transport", "ok", "error", "all_ranks_ok", "seconds"[, "cross_check"]}."""
+    import os
     import time
     log = log or (lambda *a: None)
-    for tr in transports:
-        ring, err, t0 = None, None, time.perf_counter()
+    if cross_check is None:
+        cross_check = len(transports) > 1
+
+    def bring_up(tr, sweeps):
+        """(ring or None, counts or None): the transport attached, the lattice initialised, `sweeps` sweeps through it, the whole lattice counted"""
+        ring, err, counts, t0 = None, None, None, time.perf_counter()
         try:
             ring = NativeRing(slab, transport=tr)
             ring.init()
-            ring.sweep(1)  # one real sweep through the transport before it is trusted
+            ring.sweep(sweeps)  # real sweeps through the transport before it is trusted
             ring.slab.rank_wait(ring.probe_timeout_ms)  # (bounded, like the first exchange: a transport that stalls is an error to fall back from, not a hang)
             torch.cuda.synchronize()
+            counts = ring.count() if sweeps > 1 else None
             ok = True
         except Exception as e:  # noqa: BLE001 -- any transport failure means: the caller tries the next one
             log(f"ring transport {tr}-native failed on this rank: {e}")
             ok, err = False, f"{type(e).__name__}: {e}"
         agreed = _agree(ok)
+        rec = {"transport": f"{tr}-native", "ok": ok, "error": err, "all_ranks_ok": agreed, "seconds": round(time.perf_counter() - t0, 3)}
         if attempts is not None:
-            attempts.append({"transport": f"{tr}-native", "ok": ok, "error": err, "all_ranks_ok": agreed, "seconds": round(time.perf_counter() - t0, 3)})
+            attempts.append(rec)
         if agreed:
-            return ring
+            return ring, counts, rec
         if ring is not None:
             try:
                 ring.close(abort=True)
@@ -570,6 +581,39 @@ def open_native_ring(slab, log=None, transports=("ipc", "rccl"), attempts=None):
                 slab.rank_detach(True)  # (an attachment that half came up)
             except Exception:  # noqa: BLE001
                 pass
+        return None, None, rec
+
+    todo = list(transports)
+    while todo:
+        tr = todo.pop(0)
+        ring, counts, rec = bring_up(tr, check_sweeps if (cross_check and todo) else 1)
+        if ring is None:
+            continue
+        if not (cross_check and todo):
+            return ring
+        if os.environ.get("ISING_TEST_RING_CROSSCHECK_PERTURB"):  # (test aid: the first transport's counts off by one)
+            counts = (counts[0] + 1, counts[1] - 1)
+        # the next transport over the same sweeps
+        ring.close()
+        other = None
+        while todo and other is None:
+            tr2 = todo.pop(0)
+            other, counts2, rec2 = bring_up(tr2, check_sweeps)
+        if other is None:  # nothing to hold it against: the first transport it is
+            rec["cross_check"] = "no second transport came up"
+            again, _, _ = bring_up(tr, 1)
+            return again
+        if counts2 == counts:
+            rec["cross_check"] = rec2["cross_check"] = f"{tr} and {tr2} agree after {check_sweeps} sweeps: {counts}"
+            other.close()
+            again, _, _ = bring_up(tr, 1)
+            if again is not None:
+                return again
+            other, _, _ = bring_up(tr2, 1)  # (the first one did not come up a second time)
+            return other
+        rec["cross_check"] = rec2["cross_check"] = f"{tr} {counts} and {tr2} {counts2} DISAGREE after {check_sweeps} sweeps: {tr2} kept"
+        log(f"ring transports disagree after {check_sweeps} sweeps ({tr}: {counts}, {tr2}: {counts2}): keeping {tr2}")
+        return other
     return None
 
 

@@ -158,6 +158,9 @@ def test_bench_ring_code_path_with_one_rank(gpu, oracle_mod, ring, port, exchang
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     b = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert b["config"]["exchange"] == exchange and b["config"]["nranks"] == 1
+    if ring == "native":  # (auto: both of the library's transports come up on a ring of one -- the peer transport is held against RCCL over 40 sweeps before it is kept)
+        notes = " ".join(b["transport_attempts"]["rank0"])
+        assert "ipc and rccl agree after 40 sweeps" in notes, notes
     if ring.startswith("native"):  # the library's ring says where the time around its exchanges went (one launch + exchange per 32 sweeps)
         xs = b["exchange_stats"]
         assert xs["exchanges_per_rank"] >= 1 and xs["launch_ms"]["mean"] > 0 and xs["exchange_ms"]["max"] >= xs["exchange_ms"]["mean"] > 0
@@ -166,6 +169,20 @@ def test_bench_ring_code_path_with_one_rank(gpu, oracle_mod, ring, port, exchang
         assert "exchange_stats" not in b
     orc = oracle_mod.OracleLattice(8192, 8192, seed=1234, temp=oracle_mod.CRIT_TEMP).init().sweep(6)
     assert (b["config"]["up"], b["config"]["down"]) == orc.count() and b["config"]["rank_up"] == [orc.count()[0]]
+
+
+def test_a_transport_that_disagrees_is_not_kept(gpu, oracle_mod):
+    """open_native_ring's cross-check: with the first transport's counts made to differ (test aid), the ring that comes back is the second transport's."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ISING_TEST_RING_CROSSCHECK_PERTURB="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29554",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-ring", "--steps", "4", "--warmup", "2", "--x", "8192", "--y", "8192", "--preheat-ms", "5",
+                        "--layout", "ballot", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    b = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert b["config"]["exchange"] == "rccl-native"
+    assert "DISAGREE after 40 sweeps: rccl kept" in " ".join(b["transport_attempts"]["rank0"])
+    orc = oracle_mod.OracleLattice(8192, 8192, seed=1234, temp=oracle_mod.CRIT_TEMP).init().sweep(6)
+    assert (b["config"]["up"], b["config"]["down"]) == orc.count()
 
 
 def test_fused_launch_gives_up_instead_of_hanging(gpu, oracle_mod, monkeypatch):
