@@ -166,3 +166,51 @@ def test_quad_batch_at_a_temperature_series_size(gpu, oracle_mod, monkeypatch):
         _same(slabs, orcs, "31 lattices after 24 sweeps")
     for s in slabs:
         s.close()
+
+
+def test_quad_batch_randomised(gpu, oracle_mod, monkeypatch):
+    """Random batches -- lattice widths, rows, lattices per batch, tile heights, halo depths, workgroup sizes, call lengths, print points with and without the energy --
+    against the oracle, every member (seeded: the same cases every run)."""
+    rng = np.random.default_rng(20260931)
+    done = 0
+    for case in range(48):
+        gx = int(rng.integers(1, 5))
+        X = 2048 * gx
+        Y = 16 * int(rng.integers(1, 9))
+        n = int(rng.integers(2, 7))
+        T = int(rng.integers(1, 9 if gx > 1 else 13))
+        C = int(rng.integers(1, 9 if gx > 1 else 17))
+        NW = int(rng.choice([4, 8, 12, 16] if gx > 1 else [1, 2, 4, 8, 12, 16]))
+        HG = (2 * T + 2) // 4
+        items = (min(C, Y // 4) + 2 * HG) * gx
+        per_wave = (items + NW - 1) // NW
+        if per_wave > 4 or (per_wave > 3 and NW > 8) or items * 1024 > 150 * 1024:
+            continue
+        temps = [float(rng.choice([1.5, 2.0, TC, 2.5, 3.0])) for _ in range(n)]
+        seeds = [int(rng.integers(1, 2**62)) for _ in range(n)]
+        _env(monkeypatch, QUAD=1, QUAD_C=C, QUAD_T=T, QUAD_WAVES=NW)
+        slabs = _members(X, Y, temps, seeds)
+        orcs = [oracle_mod.OracleLattice(X, Y, seed=s, temp=t).init() for t, s in zip(temps, seeds)]
+        with ig.IsingBatch(slabs) as b:
+            b.init()
+            for k in rng.integers(1, 4 * T + 4, size=3):
+                k = int(k)
+                if rng.integers(0, 2) == 0:
+                    every, energy = int(rng.integers(1, 9)), bool(rng.integers(0, 2))
+                    got = b.sweep_counted(k, every, energy)
+                    want = []
+                    for _ in range(k):
+                        for o in orcs:
+                            o.sweep(1)
+                        if orcs[0].it % every == 0:
+                            want.append([o.count() + ((o.bond_equal(),) if energy else (None,)) for o in orcs])
+                    assert got == want, (case, X, Y, n, C, T, NW)
+                else:
+                    b.sweep(k)
+                    for o in orcs:
+                        o.sweep(k)
+                _same(slabs, orcs, f"case {case}: {n} x {Y} x {X}, tiles of {C} row groups, {T} sweeps a pass, {NW} waves, after {orcs[0].it} sweeps")
+        for s in slabs:
+            s.close()
+        done += 1
+    assert done >= 16, done
