@@ -246,7 +246,8 @@ int ising_sweep_form(ising_ctx *ctx, int nsweeps, int *form, int *strip_rows, in
  * launches of ising_sweep on such a slab are therefore timed on their dispatch packets -- the host waits for them, once per context.  On the plateau (4096 tickets
  * a level and more: 32768^2 and up) a rate of 0.8 x what a lattice of that size runs at settles it after one launch; below, or under that rate, the neighbouring
  * shapes (a workgroup per CU fewer, one more -- on down the slope while it pays --, half the strip height) get one launch each and the fastest stays if it is
- * worth 3 %.  Results never depend on the shape.  ISING_GUARD=0 turns it off (default: on, on a whole MI355X); ising_sweep_form reports the shape in
+ * worth 3 %.  Where the table gives long calls the split form, one split and one fused launch are timed the same way and the faster form stays (round 5's boxes:
+ * split 1-6 % ahead; one of round 6's: 3-5 % behind at 65536 x 8192 and 24576^2).  Results never depend on the shape or the form.  ISING_GUARD=0 turns it off (default: on, on a whole MI355X); ising_sweep_form reports the shape in
  * force.  state: 0 off (not a lone slab in the fused form), 1 timing the table's shape, 2 trying neighbours, 3 settled.  Blocks while a timed launch is in flight. */
 typedef struct ising_guard_info {
 	int32_t state, switched, launches_timed;
@@ -254,6 +255,10 @@ typedef struct ising_guard_info {
 	int32_t strip_rows, wg_per_cu;              /* the shape in force */
 	float expected_flips_per_ns;                /* what the first launches were held against (x 0.8) */
 	float table_flips_per_ns, kept_flips_per_ns; /* measured: the table's shape, the shape that stayed */
+	/* the FORM of a long call's launches where the table says "split" (ising_sweep_info: 3): one launch of each form is timed, the faster stays (2 %) */
+	int32_t form_state;                         /* -1: no split form here (or ISING_SPLIT=1: always), 0: nothing timed yet, 1: a split launch timed, 2: a fused one in flight, 3: decided */
+	int32_t split_kept;                         /* long calls run split launches */
+	float split_flips_per_ns, fused_flips_per_ns;
 } ising_guard_info;
 int ising_shape_guard_info(ising_ctx *ctx, ising_guard_info *out);
 /* Same, bracketed by HIP events on the context's stream; returns elapsed milliseconds (blocking). */

@@ -93,6 +93,12 @@ struct ising_ctx {
 		float base_rate = 0, best_rate = 0, expected = 0;
 		bool switched = false, grid_override = false; // grid_override: the guard's workgroups per CU replace ISING_FUSED_WGS
 		int launches = 0;          // launches it looked at
+		// ... and the FORM of a long call's launches where the table says "split" (ballot_split_k): one launch of each is timed, the faster stays
+		int form = 0;              // 0: nothing timed yet, 1: a split launch timed, 2: a fused one too, 3: decided
+		int form_pending = 0;      // the timed launch in flight is 1: a split, 2: a fused one (0: the shape guard's, or none)
+		bool form_warm = false;    // a split launch has run untimed (a context's first launch of a form is 2-3 % slow)
+		float split_rate = 0, fused_rate = 0;
+		bool no_split = false;     // the fused form won: split_pays answers no from now on
 	} guard;
 	bool fused = false;            // ising_sweep batches colour half-sweeps into fused launches
 	int fused_wg_per_cu = 0;       // ... and this many workgroups per CU (0: as many as the chip holds)

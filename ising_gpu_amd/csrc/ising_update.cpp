@@ -248,7 +248,7 @@ static bool sweeps_fused(const ising_ctx *c) {
 // long enough to earn that back twice over -- ~10 ms of sweeps, 2^35 flips (16384^2: 128 sweeps; break-even measured at 63, profiles/rocprof_r05_config2_split.txt).
 // Shorter calls run the fused form at its own shape, as before round 5.  (ISING_SPLIT=1: every call.)
 static bool split_pays(const ising_ctx *c, int nsweeps) {
-	return c->split && (c->split_always || (long long)nsweeps * c->cfg.X * c->cfg.Y >= (1LL << 35));
+	return c->split && !c->guard.no_split && (c->split_always || (long long)nsweeps * c->cfg.X * c->cfg.Y >= (1LL << 35));
 }
 
 extern "C" int ising_sweep(ising_ctx *c, int first_it, int nsweeps) {
@@ -491,9 +491,19 @@ int guard_settle(ising_ctx *c) {
 	if (!g.pending) return ISING_OK;
 	g.pending = false;
 	float ms = 0;
-	if (hipEventSynchronize(g.e1) != hipSuccess || hipEventElapsedTime(&ms, g.e0, g.e1) != hipSuccess || ms <= 0) { (void)hipGetLastError(); g.state = 3; return ISING_OK; }
+	if (hipEventSynchronize(g.e1) != hipSuccess || hipEventElapsedTime(&ms, g.e0, g.e1) != hipSuccess || ms <= 0) { (void)hipGetLastError(); g.state = 3; g.form = 3; g.form_pending = 0; return ISING_OK; }
 	const float rate = (float)(g.pending_flips / ((double)ms * 1.0e6));
 	g.launches++;
+	if (g.form_pending) { // the form of a long call's launches: a split launch, then a fused one, the faster stays (2 %: a launch's noise)
+		if (g.form_pending == 1) { g.split_rate = rate; g.form = 1; }
+		else {
+			g.fused_rate = rate;
+			g.form = 3;
+			g.no_split = g.fused_rate > 1.02f * g.split_rate;
+		}
+		g.form_pending = 0;
+		return ISING_OK;
+	}
 	auto add = [&](int H, int wg) {
 		if (g.ncand >= ising_ctx::ShapeGuard::MAXC || wg < 1 || wg > 6) return;
 		if (H == g.base_H && wg == g.base_wg) return;
@@ -546,6 +556,7 @@ int guard_settle(ising_ctx *c) {
 // a call whose launches the guard does not time (print points inside the launches: their slots are laid out by the strips): what is known so far decides
 int guard_finish(ising_ctx *c) {
 	ising_ctx::ShapeGuard &g = c->guard;
+	if (g.pending) if (int rc = guard_settle(c)) return rc;
 	if (g.state != 1 && g.state != 2) return ISING_OK;
 	if (int rc = guard_settle(c)) return rc;
 	if (g.state != 2) return ISING_OK;
@@ -579,10 +590,33 @@ int ising_host::sweep_alone(ising_ctx *c, int first_it, int nsweeps) {
 	// ballot layout: many sweeps per fused launch (32 at 65536^2, more on smaller lattices) -- the chip does not drain between colours
 	if (sweeps_fused(c)) {
 		const int per_launch = ising_host::fused_sweeps_per_launch(c->pol, (long long)c->cfg.X * c->cfg.Y);
-		const bool split = split_pays(c, nsweeps);
 		for (int it = first_it, left = nsweeps; left > 0;) {
 			const int ns = std::min(left, per_launch);
+			const bool split = split_pays(c, nsweeps); // (per launch: the guard may decide against the form in the middle of a call)
 			c->split_next = split;
+			if (split && c->guard.e0 && c->guard.form < 3 && !c->split_always && c->wrap) {
+				// where the table says "split": one launch of each form on this box, timed, before the call's other launches follow the faster
+				// (the split form was 1-6 % ahead on round 5's boxes and 3-5 % behind at 65536 x 8192 and 24576^2 on one of round 6's)
+				if (int rc = guard_settle(c)) return rc;
+				ising_ctx::ShapeGuard &g = c->guard;
+				const bool as_split = g.form == 0 || (g.form == 3 && !g.no_split);
+				hipEvent_t stop = nullptr;
+				const bool long_enough = (double)c->cfg.X * c->cfg.Y * ns >= 2.0e6 * guard_expected(c, true);
+				if (g.form == 0 && !g.form_warm && long_enough) g.form_warm = true; // (this one runs untimed: the form's first launch)
+				else if (g.form < 2 && long_enough) {
+					c->launch_start_next = g.e0;
+					stop = g.e1;
+					g.pending = true;
+					g.pending_flips = (double)c->cfg.X * c->cfg.Y * ns;
+					g.form_pending = as_split ? 1 : 2;
+					if (!as_split) g.form = 2;
+				}
+				c->split_next = as_split;
+				if (int rc = launch_ranges(c, it, ISING_BLACK, 0, c->cfg.Y, 0, 0, 2 * ns, stop)) { g.pending = false; g.form_pending = 0; return rc; }
+				it += ns;
+				left -= ns;
+				continue;
+			}
 			if (c->guard.state == 1 || c->guard.state == 2) {
 				if (int rc = guard_settle(c)) return rc;
 				hipEvent_t stop = nullptr;
@@ -717,7 +751,7 @@ int ising_sweep_info(ising_ctx *c, int *fused, int *max_sweeps_per_launch) {
 
 int ising_shape_guard_info(ising_ctx *c, ising_guard_info *out) {
 	if (!c || !out) return fail(ISING_E_ARG, "null argument");
-	if (c->guard.state == 1 || c->guard.state == 2) if (int rc = guard_settle(c)) return rc; // (a timed launch in flight: its verdict first -- blocks)
+	if (c->guard.pending) if (int rc = guard_settle(c)) return rc; // (a timed launch in flight: its verdict first -- blocks)
 	const ising_ctx::ShapeGuard &g = c->guard;
 	memset(out, 0, sizeof(*out));
 	out->state = g.state;
@@ -726,6 +760,9 @@ int ising_shape_guard_info(ising_ctx *c, ising_guard_info *out) {
 	out->table_strip_rows = g.base_H; out->table_wg_per_cu = g.base_wg;
 	out->strip_rows = c->H; out->wg_per_cu = guard_wg_now(c);
 	out->expected_flips_per_ns = g.expected; out->table_flips_per_ns = g.base_rate; out->kept_flips_per_ns = g.best_rate;
+	out->form_state = c->split && !c->split_always ? g.form : -1;
+	out->split_flips_per_ns = g.split_rate; out->fused_flips_per_ns = g.fused_rate;
+	out->split_kept = c->split && !g.no_split ? 1 : 0;
 	return ISING_OK;
 }
 

@@ -199,7 +199,8 @@ class IsingSlab:
         3 settled), whether it switched, the table's shape and rate, the shape and rate that stayed.  Blocks while a timed launch is in flight."""
         class _G(C.Structure):
             _fields_ = [(k, C.c_int32) for k in ("state", "switched", "launches_timed", "table_strip_rows", "table_wg_per_cu", "strip_rows", "wg_per_cu")] + \
-                       [(k, C.c_float) for k in ("expected_flips_per_ns", "table_flips_per_ns", "kept_flips_per_ns")]
+                       [(k, C.c_float) for k in ("expected_flips_per_ns", "table_flips_per_ns", "kept_flips_per_ns")] + \
+                       [("form_state", C.c_int32), ("split_kept", C.c_int32), ("split_flips_per_ns", C.c_float), ("fused_flips_per_ns", C.c_float)]
         g = _G()
         check(self._lib.ising_shape_guard_info(self._h, C.byref(g)))
         return {k: getattr(g, k) for k, _ in _G._fields_}

@@ -266,3 +266,34 @@ def test_guard_recovers_from_an_injected_cliff(gpu, warm_clock, monkeypatch, X, 
     assert g["state"] == 3 and g["switched"] == 1 and g["launches_timed"] <= 10
     assert r >= 0.95 * best_nb
     assert c3 == _guarded_run(X, Y, monkeypatch, {"ISING_GUARD": 0, "ISING_SPLIT": 0, "ISING_FUSED_WGS": 256 * wg}, launches=10)[2]  # (same seed, same sweeps)
+
+
+@pytest.mark.parametrize("X,Y", [(65536, 8192), (24576, 24576), (8192, 8192)])
+def test_guard_picks_the_form_of_long_calls(gpu, warm_clock, monkeypatch, X, Y):
+    """Where the table gives long calls the split form, the guard times one split and one fused launch on this box and keeps the faster: afterwards the slab runs
+    within 3 % of the better of the two forms asked for by name, with the same spins."""
+    def run(env, calls=4):
+        for k in ("ISING_FUSED_WGS", "ISING_SPLIT", "ISING_GUARD", "ISING_GUARD_EXPECT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, str(v))
+        with ig.IsingSlab(X, Y, seed=1234, temp=TC) as s:
+            per = s.max_sweeps_per_launch
+            n = max(2 * per, ((1 << 36) // (X * Y) + per - 1) // per * per)  # a call of 2^36 flips and more: the table's split form applies
+            s.init()
+            for _ in range(calls):
+                s.sweep(n)
+            info = s.guard_info()
+            rate = max(X * Y * n / (s.sweep_timed(n) * 1e6) for _ in range(2))
+            return rate, info, s.count(), s.sweep_form(n)[0]
+    r_split, g0, counts, form_s = run({"ISING_GUARD": 0})
+    if form_s != 3:
+        pytest.skip(f"{Y} x {X}: the table does not give this lattice the split form here")
+    r_fused, _, counts_f, form_f = run({"ISING_GUARD": 0, "ISING_SPLIT": 0})
+    r, g, counts_g, form_g = run({"ISING_GUARD": 1})
+    assert counts == counts_f == counts_g and form_f == 1
+    assert g["form_state"] == 3 and g["split_flips_per_ns"] > 0 and g["fused_flips_per_ns"] > 0
+    assert (g["split_kept"] == 1) == (form_g == 3) == (not g["fused_flips_per_ns"] > 1.02 * g["split_flips_per_ns"])
+    print(f"{Y} x {X}: split {r_split:.0f}, fused {r_fused:.0f} flips/ns by name; the guard timed {g['split_flips_per_ns']:.0f} / {g['fused_flips_per_ns']:.0f} and kept "
+          f"{'split' if g['split_kept'] else 'fused'}: {r:.0f}")
+    assert r >= 0.97 * max(r_split, r_fused)
