@@ -120,6 +120,7 @@ const SwitchDoc kSwitches[] = {
 	{"ISING_FUSED", "0/1", "`ising_sweep` on the ballot layout: one launch per colour / fused launches (default: fused from 1.5*2^24 spins, and below where a level of one-row units feeds two workgroups per CU)"},
 	{"ISING_FUSED_WGS", "n", "size of a fused launch's persistent grid, in workgroups (default: by tickets per level, strip height and wave columns: `fused_wgs_for`)"},
 	{"ISING_GUARD", "0/1", "run-time guard under the fused launches' shape table: the first launches of a lone slab are timed; below the plateau (under 4096 tickets a level), or under 0.8 x the expected rate, the neighbouring shapes (one workgroup per CU fewer / more, half the strip height) get a launch each and the fastest stays if it is worth 3 %; where the table gives long calls the split form, one split and one fused launch are timed and the faster form stays (default: on a whole MI355X)"},
+	{"ISING_TEST_RING_CROSSCHECK_PERTURB", "1", "test aid (Python mirror, `open_native_ring`): the first rank transport's whole-lattice counts are made to differ, so that the cross-check against the second transport has something to catch"},
 	{"ISING_GUARD_EXPECT", "flips/ns", "what the guard expects of the lattice (default: by its size, `guard_expected`)"},
 	{"ISING_FUSED_TICKETS2", "0/2/4", "fused launches draw from that many ticket counters (default: four for one-row units, two for two-row units, one above)"},
 	{"ISING_FUSED_NT", "0/1", "lattice words of fused launches with the non-temporal hint (default: lattices above 2^31 spins)"},
