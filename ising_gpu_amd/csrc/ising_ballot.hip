@@ -911,7 +911,7 @@ __global__ void __launch_bounds__(BAL_THREADS) BAL_SGPR_ATTR ballot_split_k(cons
 		return (uint32_t)gr;
 	};
 	// a ticket of this class -> its unit of the level: (strip, wave column) of this wave, rows
-	struct Unit { int level, sidx, wc, bx0, r0, nrows; bool absent, edge; uint32_t color, it; };
+	struct Unit { int level, elev, sidx, wc, bx0, r0, nrows; bool absent, edge, elast; uint32_t color, it; };
 	auto decode = [&](int k, int level) -> Unit {
 		Unit u;
 		u.level = level;
@@ -927,7 +927,11 @@ __global__ void __launch_bounds__(BAL_THREADS) BAL_SGPR_ATTR ballot_split_k(cons
 		u.r0 = p.row_lo[0] + u.sidx * p.H;
 		const int nrows0 = u.absent ? 0 : min(p.H, p.row_hi[0] - u.r0);
 		// ring slab with ghost rows: at this level only rows within `keep` of the slab's own can still reach one of them (trapezoid, ballot_update_k)
-		const int keep = uni(p.nlevels - 1 - level);
+		// (several exchange epochs per launch, UpdateParams.epoch_sh -- round 6, as in ballot_update_k: the trapezoid starts over with every epoch)
+		u.elev = uni(p.epoch_sh ? level & ((1 << p.epoch_sh) - 1) : level);
+		const int elast = uni(p.epoch_sh ? (1 << p.epoch_sh) - 1 : p.nlevels - 1);
+		u.elast = u.elev == elast || level == p.nlevels - 1;
+		const int keep = uni(elast - u.elev);
 		const bool skip = p.trapezoid != 0 && !u.absent && (u.r0 + nrows0 <= -keep || u.r0 >= p.Y + keep);
 		u.nrows = skip ? 0 : nrows0;
 		// ... and, exchange overlapped with the launches: a unit that touches rows the exchange reads or writes
@@ -1085,13 +1089,16 @@ __global__ void __launch_bounds__(BAL_THREADS) BAL_SGPR_ATTR ballot_split_k(cons
 				__builtin_amdgcn_s_sleep(ISING_POLL_SLEEP);
 			}
 		}
-		if (u.edge && level == 0) {
-			// the exchange that follows the previous launch has read this slab's first / last rows and filled its ghost rows once the comm stream has moved
-			// the counter (ballot_update_k: usually long ago; the bound is 16 times a unit's for its parents)
-			uint32_t got = p.edge_go_need, ngo = 0;
+		// (an epoch's second level is the last that reads words the exchange wrote, possibly on an XCD none of the epoch's first edge units ran on: ballot_update_k)
+		if (p.epoch_sh && u.edge && u.elev == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+		if (u.edge && u.elev == 0) {
+			// the exchange that follows the previous launch (the previous epoch of this one) has read this slab's first / last rows and filled its ghost rows once
+			// the comm stream has moved the counter (ballot_update_k: usually long ago; the bound is 16 times a unit's for its parents)
+			const uint32_t go_need = uni(p.edge_go_need + (p.epoch_sh ? (uint32_t)level >> p.epoch_sh : 0u));
+			uint32_t got = go_need, ngo = 0;
 			for (;;) {
 				if (lane == 0) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(got) : "v"(p.edge_go) : "memory");
-				if (__all((int32_t)(got - p.edge_go_need) >= 0)) break;
+				if (__all((int32_t)(got - go_need) >= 0)) break;
 				if ((++ngo & 63u) == 0u && give_up(ngo >> 4)) break;
 				__builtin_amdgcn_s_sleep(127);
 			}
@@ -1214,7 +1221,7 @@ __global__ void __launch_bounds__(BAL_THREADS) BAL_SGPR_ATTR ballot_split_k(cons
 			if (!u.absent) __hip_atomic_fetch_add(p.done + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			__hip_atomic_fetch_add(fl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			// last level: the rows the next exchange sends are final and the ghost rows no longer read
-			if (u.edge && level == p.nlevels - 1) __hip_atomic_fetch_add(p.edge_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (u.edge && u.elast) __hip_atomic_fetch_add(p.edge_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
 	clock_mark(1);

@@ -675,6 +675,17 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 		if (can && pol.split == 1) {
 			c->split = c->split_always = fused_tickets(c->nwc(), launch_rows, c->H) >= 8;
 			c->H_split = c->H;
+		} else if (can && deep_ring && !small_fused && c->cus >= 200 && cfg->strip_rows <= 0) {
+			// Ring slabs (round 6): their launches are tied to the exchanges -- 32 sweeps each, which do not earn back the split form's word-only tail -- UNLESS one
+			// persistent launch carries several exchange epochs (the peer transport with a device to itself, ising_ring.cpp: epochs_per_launch): then the rule of
+			// the lone slabs applies, and the ring's sweep asks for the form launch by launch (ising_host::update_deep).  Ring of one, 65536 x 8192 (the slab of
+			// 65536^2 on eight GPUs): fused 3339, split at sixteen-row strips with epochs 3368 (ghost rows 32 deep: 3385), without epochs 3260; 65536 x 16384
+			// (2064 tickets a level at sixteen rows: not "few"): fused 3444, split 3340 (profiles/ring_depth_probe_r06.txt).
+			const bool few = fused_tickets(c->nwc(), launch_rows, 16) < 2048 && c->nwc() <= 8;
+			auto feeds = [&](int h) { return launch_rows / h >= 512 && fused_tickets(c->nwc(), launch_rows, h) >= 512; };
+			if (few)
+				for (int h = 16; h >= 4 && !c->split; h >>= 1)
+					if (Yd % h == 0 && h >= c->H && c->ghost_rows % h == 0 && feeds(h)) { c->split = true; c->H_split = h; }
 		} else if (can && !small_fused && !deep_ring && c->cus >= 200) { // (a whole MI355X: eight XCDs that each run their share of the grid -- the classes are theirs)
 			// (lone slabs only: their launches carry ~50 ms of sweeps.  A launch in the split form ends on word units alone -- the last (lead + 1) x grid of them, five
 			// levels deep at 16384^2, memory round trips with an idle vector ALU: ~0.1 ms more per launch than the fused form (rocprofv3, 16 sweeps of 16384^2 per launch:

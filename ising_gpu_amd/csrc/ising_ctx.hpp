@@ -265,7 +265,7 @@ int update_edges_on(ising_ctx *c, int it, int color, hipStream_t s, hipEvent_t s
 int update_interior(ising_ctx *c, int it, int color, hipEvent_t stop);
 // ring slab with ghost rows: one fused launch of `nlevels` (even, <= ghost rows) colour half-sweeps, ghost rows included;
 // `overlapped`: its edge strips wait for / announce the exchange themselves (ising_ring.cpp: sweep_deep_overlapped)
-int update_deep(ising_ctx *c, int it, int nlevels, bool overlapped = false, int epochs = 1);
+int update_deep(ising_ctx *c, int it, int nlevels, bool overlapped = false, int epochs = 1, bool split = false);
 // called by ising_destroy
 void ring_release(ising_ctx *c);
 // a ring slab's second stream, events and counters (created once per slab)

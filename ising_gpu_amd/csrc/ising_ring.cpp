@@ -529,10 +529,10 @@ int post_go(ising_ctx *c, int xs_slot = -1) { // xs_slot: the exchange-statistic
 // it INSIDE a running launch (UpdateParams.epoch_sh) as they already do at a launch's first level.  That needs a transport whose kernels find room next to a
 // chip-filling persistent grid -- the peer (IPC) transport's one-lane kernels and copies do, RCCL's send/recv kernel does not -- and a device that no
 // other rank's persistent grid shares (two of them waiting for each other's exchange inside launches that never end would stop both: the next launch's turn is
-// what lets a co-resident rank in).  Ghost rows a power of two deep, the fused form (the split form's word-only tail is per launch as well, but it has no epochs).
+// what lets a co-resident rank in).  Ghost rows a power of two deep; either form of launch (the split form's word-only tail is per launch: it is the epochs that let ring slabs afford it).
 int epochs_per_launch(const ising_ctx *c, int n) {
 	const int G = c->ghost();
-	if (n != 1 || c->transport != ISING_TRANSPORT_IPC || ising_ipc::sharing(c) != 1 || c->pol.ring_epochs == 1 || (G & (G - 1)) != 0 || G < 4 || c->split_always ||
+	if (n != 1 || c->transport != ISING_TRANSPORT_IPC || ising_ipc::sharing(c) != 1 || c->pol.ring_epochs == 1 || (G & (G - 1)) != 0 || G < 4 ||
 	    c->pol.overlap == 0) return 1;
 	if (c->pol.ring_epochs > 1) return c->pol.ring_epochs;
 	const double epoch_ms = (double)c->cfg.X * ((double)c->cfg.Y + G) * (G / 2) / 3.4e9; // (3.4 flips/ns)
@@ -570,7 +570,8 @@ int sweep_deep_overlapped(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 				c->cnt_bonds_next = c->ring_cnt_bonds;
 				c->ring_cnt_inflight += m;
 			}
-			if (int rc = ising_host::update_deep(c, it, 2 * ns, true, nep)) return rc;
+			// (the split form where ising_create's rule gives the slab one: launches of several epochs, no print points inside -- their slots are laid out by the fused strips)
+			if (int rc = ising_host::update_deep(c, it, 2 * ns, true, nep, c->split && !c->split_always && E > 1 && nep > 1 && c->ring_cnt_every == 0)) return rc;
 		}
 		for (int e = 0; e < nep; e++) { // one exchange per epoch, behind the epoch's edge units, next to the launch
 			const bool last = e == nep - 1;

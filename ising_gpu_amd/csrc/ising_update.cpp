@@ -149,7 +149,7 @@ static int launch_ranges(ising_ctx *c, int it, int color, int lo0, int hi0, int 
 					// what the launch adds to *edge_done per exchange epoch (the caller keeps edge_done_target: one wait per epoch on the comm stream)
 					c->edge_units_per_epoch = strips * (uint32_t)c->nwc();
 					// several epochs in this launch (ising_ring.cpp: sweep_deep_overlapped): epochs of 2^epoch_sh levels = the ghost rows' depth
-					if (epoch_sh > 0 && !split && nlevels > (1 << epoch_sh)) p.epoch_sh = epoch_sh;
+					if (epoch_sh > 0 && nlevels > (1 << epoch_sh)) p.epoch_sh = epoch_sh;
 				}
 			}
 		}
@@ -226,13 +226,14 @@ static bool ghost_sweeps(const ising_ctx *c) {
 // what is not valid in them any more (one row per level and side) never reaches a row that is.
 // `epochs` > 1 (overlapped exchanges only, G a power of two): the launch carries that many exchange epochs of G levels each (the last may be shorter) -- the
 // caller runs one exchange per epoch on the comm stream next to it (UpdateParams.epoch_sh).
-int ising_host::update_deep(ising_ctx *c, int it, int nlevels, bool overlapped, int epochs) {
+int ising_host::update_deep(ising_ctx *c, int it, int nlevels, bool overlapped, int epochs, bool split) {
 	const int G = c->ghost();
-	if (epochs < 1 || (epochs > 1 && (!overlapped || (G & (G - 1)) != 0 || c->split_always)))
-		return fail(ISING_E_STATE, "deep launch of %d epochs: needs overlapped exchanges, ghost rows a power of two deep (%d) and the fused form", epochs, G);
+	if (epochs < 1 || (epochs > 1 && (!overlapped || (G & (G - 1)) != 0)))
+		return fail(ISING_E_STATE, "deep launch of %d epochs: needs overlapped exchanges and ghost rows a power of two deep (%d)", epochs, G);
 	if (G < 2 || nlevels > epochs * G || nlevels <= (epochs - 1) * G || nlevels < 2 || c->store_ring)
 		return fail(ISING_E_STATE, "deep launch of %d levels in %d epoch(s) on a slab with %d ghost rows", nlevels, epochs, G);
 	c->overlap_next = overlapped;
+	c->split_next = split; // (the split form where the caller asks for it: a launch of several epochs on a slab whose table says so; ISING_SPLIT=1: always)
 	c->epoch_sh_next = epochs > 1 ? __builtin_ctz((unsigned)G) : 0;
 	return launch_ranges(c, it, ISING_BLACK, -(G - 1), c->cfg.Y + G - 1, 0, 0, nlevels);
 }

@@ -149,15 +149,20 @@ def test_ipc_attach_rejects_foreign_blobs(gpu):
     b.close()
 
 
+@pytest.mark.parametrize("split", [None, "1"])
 @pytest.mark.parametrize("ghost", ["8", "64"])
 @pytest.mark.parametrize("epochs", ["1", "2", "3", None])
-def test_several_exchange_epochs_in_one_launch(gpu, oracle_mod, monkeypatch, ghost, epochs):
+def test_several_exchange_epochs_in_one_launch(gpu, oracle_mod, monkeypatch, ghost, epochs, split):
     """Round 6 (ising_ring.cpp: epochs_per_launch; UpdateParams.epoch_sh): over the peer transport with a device to itself a ring slab's persistent launch carries
     several exchange epochs -- the trapezoid starts over, the edge units wait for each exchange inside the running launch -- instead of ending with every exchange.
     Same spins as the oracle's whatever the number of epochs a launch carries (1 = the form of rounds 3-5), ghost rows 8 and 64 deep, calls that end inside an epoch;
     the print points inside the launches (counts and bond sums) as well; and the launches really are fewer than the exchanges."""
     import ising_gpu_amd as ig
     monkeypatch.setenv("ISING_RING_GHOST", ghost)
+    if split is None:  # (the fused form; "1": the split form -- draw units and word units --, whose launches carry epochs too from round 6 on)
+        monkeypatch.delenv("ISING_SPLIT", raising=False)
+    else:
+        monkeypatch.setenv("ISING_SPLIT", split)
     if epochs is None:
         monkeypatch.delenv("ISING_RING_EPOCHS", raising=False)
     else:
@@ -166,6 +171,7 @@ def test_several_exchange_epochs_in_one_launch(gpu, oracle_mod, monkeypatch, gho
     orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=oracle_mod.CRIT_TEMP).init()
     slab = ig.IsingSlab(X, Y, seed=seed, temp=ig.CRIT_TEMP_F32, layout=ig.LAYOUT_BALLOT, ring_halo=True)
     ring = ig.NativeRing(slab, transport="ipc").init()
+    assert slab.split == (split == "1")
     slab.exchange_stats_begin(256)
     total = 0
     for n in (33, 1, 64, 7, 130):
@@ -190,5 +196,39 @@ def test_several_exchange_epochs_in_one_launch(gpu, oracle_mod, monkeypatch, gho
         if total % 8 == 0:
             want.append((*orc.count(), orc.bond_equal()))
     assert [tuple(p) for p in series] == want
+    ring.close()
+    slab.close()
+
+
+def test_ring_slab_of_few_tickets_runs_split_launches_of_several_epochs(gpu, oracle_mod, monkeypatch):
+    """Round 6: where ising_create's rule gives a ring slab the split form (few tickets a level at sixteen-row strips -- the slab of a strong-scaling split), the
+    ring's persistent launches of several exchange epochs run it by themselves (no ISING_SPLIT): same spins as the oracle's, print points (which keep the fused
+    form: their slots are laid out by its strips) included."""
+    import ising_gpu_amd as ig
+    for k in ("ISING_SPLIT", "ISING_RING_EPOCHS", "ISING_RING_GHOST"):
+        monkeypatch.delenv(k, raising=False)
+    X, Y, seed = 65536, 2048, 21
+    slab = ig.IsingSlab(X, Y, seed=seed, temp=ig.CRIT_TEMP_F32, layout=ig.LAYOUT_BALLOT, ring_halo=True)
+    if not slab.split:
+        slab.close()
+        pytest.skip("the rule applies on a whole MI355X (eight XCDs)")
+    orc = oracle_mod.OracleLattice(X, Y, seed=seed, temp=oracle_mod.CRIT_TEMP).init()
+    ring = ig.NativeRing(slab, transport="ipc").init()
+    slab.exchange_stats_begin(64)
+    for n in (70, 33):
+        ring.sweep(n)
+        orc.sweep(n)
+        assert ring.count() == orc.count() and ring.bond_equal() == orc.bond_equal(), n
+    st = slab.exchange_stats_fetch()
+    assert st["exchanges"] == 3 + 2 and st["launches"] == 2  # (70 and 33 sweeps at 32 an epoch: one launch each)
+    series = ring.sweep_counted(24, 8, True)
+    want = []
+    for _ in range(24):
+        orc.sweep(1)
+        if orc.it % 8 == 0:
+            want.append((*orc.count(), orc.bond_equal()))
+    assert [tuple(p) for p in series] == want and len(want) == 3
+    ring.quiesce()
+    assert np.array_equal(slab.read(ig.BLACK), orc.black) and np.array_equal(slab.read(ig.WHITE), orc.white)
     ring.close()
     slab.close()
