@@ -681,7 +681,9 @@ int ising_create(const ising_config *cfg, ising_ctx **out) {
 			// the lone slabs applies, and the ring's sweep asks for the form launch by launch (ising_host::update_deep).  Ring of one, 65536 x 8192 (the slab of
 			// 65536^2 on eight GPUs): fused 3339, split at sixteen-row strips with epochs 3368 (ghost rows 32 deep: 3385), without epochs 3260; 65536 x 16384
 			// (2064 tickets a level at sixteen rows: not "few"): fused 3444, split 3340 (profiles/ring_depth_probe_r06.txt).
-			const bool few = fused_tickets(c->nwc(), launch_rows, 16) < 2048 && c->nwc() <= 8;
+			// More ring slabs, same probe (split / fused): 8192^2 3005 / 2980, 16384^2 3317 / 3279, 16384 x 8192 3250 / 3181, 24576^2 3361 / 3381 -- and slabs of 4096 rows,
+			// where the ghost rows are 3 % of a launch's: 32768 x 4096 2994 / 3119, 16384 x 4096 2780 / 2779: from 8192 rows on.
+			const bool few = fused_tickets(c->nwc(), launch_rows, 16) < 2048 && c->nwc() <= 8 && cfg->Y >= 8192;
 			auto feeds = [&](int h) { return launch_rows / h >= 512 && fused_tickets(c->nwc(), launch_rows, h) >= 512; };
 			if (few)
 				for (int h = 16; h >= 4 && !c->split; h >>= 1)
