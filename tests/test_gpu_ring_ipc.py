@@ -207,7 +207,7 @@ def test_ring_slab_of_few_tickets_runs_split_launches_of_several_epochs(gpu, ora
     import ising_gpu_amd as ig
     for k in ("ISING_SPLIT", "ISING_RING_EPOCHS", "ISING_RING_GHOST"):
         monkeypatch.delenv(k, raising=False)
-    X, Y, seed = 65536, 2048, 21
+    X, Y, seed = 8192, 8192, 21  # (the rule: few tickets a level at sixteen-row strips, 8192 rows and more)
     slab = ig.IsingSlab(X, Y, seed=seed, temp=ig.CRIT_TEMP_F32, layout=ig.LAYOUT_BALLOT, ring_halo=True)
     if not slab.split:
         slab.close()
