@@ -570,8 +570,35 @@ int sweep_deep_overlapped(ising_ctx **ctxs, int n, int first_it, int nsweeps) {
 				c->cnt_bonds_next = c->ring_cnt_bonds;
 				c->ring_cnt_inflight += m;
 			}
-			// (the split form where ising_create's rule gives the slab one: launches of several epochs, no print points inside -- their slots are laid out by the fused strips)
-			if (int rc = ising_host::update_deep(c, it, 2 * ns, true, nep, c->split && !c->split_always && E > 1 && nep > 1 && c->ring_cnt_every == 0)) return rc;
+			// (the split form where ising_create's rule gives the slab one: launches of several epochs, no print points inside -- their slots are laid out by the fused strips --;
+			// which of the two forms is ahead depends on the box, +1.4 .. -0.9 % at 65536 x 8192: the slab's first full launches are timed on their dispatch packets, a warm
+			// and a timed one of each form, and the faster stays -- the lone slabs' guard, ising_update.cpp)
+			bool as_split = c->split && !c->split_always && E > 1 && nep > 1 && c->ring_cnt_every == 0 && !c->guard.no_split;
+			if (as_split && c->pol.guard != 0 && c->guard.form < 3 && nep >= std::min(E, 4) && xs[k] < 0) { // (launches of four epochs and more: rates that compare)
+				ising_ctx::ShapeGuard &g = c->guard;
+				if (!g.e0) { HIP_TRY(hipEventCreate(&g.e0)); HIP_TRY(hipEventCreate(&g.e1)); }
+				if (g.pending) { // the timed launch of the step before: wait for it (twice per slab, once in its life)
+					float ms = 0;
+					g.pending = false;
+					if (hipEventSynchronize(g.e1) != hipSuccess || hipEventElapsedTime(&ms, g.e0, g.e1) != hipSuccess || ms <= 0) { (void)hipGetLastError(); g.form = 3; }
+					else if (g.form_pending == 1) { g.split_rate = (float)(g.pending_flips / ((double)ms * 1.0e6)); g.form = 1; g.form_warm = false; }
+					else { g.fused_rate = (float)(g.pending_flips / ((double)ms * 1.0e6)); g.form = 3; g.no_split = g.fused_rate > 1.02f * g.split_rate; }
+					g.form_pending = 0;
+					g.launches++;
+				}
+				if (g.form < 3) {
+					as_split = g.form == 0; // (form 0: the split launches; 1: the fused ones)
+					if (!g.form_warm) g.form_warm = true; // (this one runs untimed: the form's first launch of the series)
+					else {
+						c->launch_start_next = g.e0;
+						c->launch_stop_next = g.e1;
+						g.pending = true;
+						g.pending_flips = (double)c->cfg.X * c->cfg.Y * ns;
+						g.form_pending = as_split ? 1 : 2;
+					}
+				} else as_split = !g.no_split;
+			}
+			if (int rc = ising_host::update_deep(c, it, 2 * ns, true, nep, as_split)) return rc;
 		}
 		for (int e = 0; e < nep; e++) { // one exchange per epoch, behind the epoch's edge units, next to the launch
 			const bool last = e == nep - 1;

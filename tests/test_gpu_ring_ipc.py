@@ -232,3 +232,37 @@ def test_ring_slab_of_few_tickets_runs_split_launches_of_several_epochs(gpu, ora
     assert np.array_equal(slab.read(ig.BLACK), orc.black) and np.array_equal(slab.read(ig.WHITE), orc.white)
     ring.close()
     slab.close()
+
+
+def test_ring_slab_times_both_forms_and_keeps_the_faster(gpu, monkeypatch):
+    """... and which of the two forms a ring slab's long launches take is measured on the box (a warm and a timed launch of each, the lone slabs' guard): afterwards
+    the slab runs the one that was faster, the record says which, and the spins are those of the same slab swept with the guard off."""
+    import ising_gpu_amd as ig
+    for k in ("ISING_SPLIT", "ISING_RING_EPOCHS", "ISING_RING_GHOST", "ISING_GUARD"):
+        monkeypatch.delenv(k, raising=False)
+    X, Y, seed = 16384, 8192, 5
+
+    def run(guard):
+        monkeypatch.setenv("ISING_GUARD", guard)
+        slab = ig.IsingSlab(X, Y, seed=seed, temp=ig.CRIT_TEMP_F32, layout=ig.LAYOUT_BALLOT, ring_halo=True)
+        if not slab.split:
+            slab.close()
+            return None
+        ring = ig.NativeRing(slab, transport="ipc").init()
+        for _ in range(6):
+            ring.sweep(512)  # (launches of several epochs each: a warm and a timed one per form, then the form that stays)
+        ring.quiesce()
+        out = (ring.count(), ring.bond_equal(), slab.guard_info())
+        ring.close()
+        slab.close()
+        return out
+    off = run("0")
+    if off is None:
+        pytest.skip("the rule applies on a whole MI355X (eight XCDs)")
+    on = run("1")
+    assert on[:2] == off[:2]
+    g = on[2]
+    assert off[2]["form_state"] == 0  # (guard off: nothing timed, the table's form)
+    assert g["form_state"] == 3 and g["split_flips_per_ns"] > 0 and g["fused_flips_per_ns"] > 0
+    assert (g["split_kept"] == 1) == (not g["fused_flips_per_ns"] > 1.02 * g["split_flips_per_ns"])
+    print(f"ring of one {Y} x {X}: split {g['split_flips_per_ns']:.0f}, fused {g['fused_flips_per_ns']:.0f} flips/ns in the timed launches: kept {'split' if g['split_kept'] else 'fused'}")
